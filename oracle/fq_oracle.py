@@ -1,0 +1,337 @@
+"""CPU ORACLE — test infrastructure, NOT product code.
+
+A plain-numpy restatement of the reference's fake-quantisation / calibration algorithm, written from the reference's
+Python (file:line cited per function).  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` may import this package; the shipped path (`quantization.mxnet_amd`) never does and fails loudly when
+its HIP library is missing.
+
+Parity status (DESIGN.md "Oracle"):
+  * histogram / collect / KL functions: PINNED — checked in tests/test_oracle_golden.py against outputs of the
+    reference's real `quantize/distribution_calibrate.py` executed in the build container (tests/golden/g1..g3).
+  * everything that needs MXNet in the reference: pinned for COMPOSITION only — the goldens g4..g9 were produced by
+    running the reference's unchanged Python over a CPU stand-in for `mxnet` whose primitive ops encode MXNet's
+    documented semantics (the reference has no golden vectors or asserting tests of its own for this boundary:
+    SURVEY.md F6).  Third-party arithmetic holder: Apache MXNet (unpinned in the reference, ~1.5.x) and numpy
+    (this container: 2.2.x; scalar promotion follows NEP 50).
+
+Primitive semantics restated here: fp32 everywhere unless stated; `roundf` = half AWAY from zero;
+tensor / scalar = IEEE fp32 divide by fp32(scalar); `clip(a, lo, hi) = min(max(a, lo), hi)`; cast-to-int32
+truncates toward zero; batch mean = fp32(sequential fp64 sum) / fp32(N).
+"""
+import numpy as np
+
+F32 = np.float32
+EPS = F32(1e-10)          # ste_func.py:39,41  `scale + 1e-10`  (fp32 add: numpy-2 weak python float / MXNet _plus_scalar)
+
+__all__ = ["roundf", "absmax_per_sample", "batch_mean", "act_scale", "ste_codes", "ste_forward",
+           "conv_input_fake_quant", "dense_input_fake_quant", "act_output_fake_quant", "weight_fake_quant",
+           "winograd_G", "wino_weight_fake_quant", "ema_update", "discrete_histogram", "kl_calibrate",
+           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain"]
+
+
+def roundf(x):
+    """C roundf (MXNet `round`): nearest, ties away from zero.  x - trunc(x) is exact."""
+    x = np.asarray(x, dtype=F32)
+    t = np.trunc(x)
+    frac = x - t
+    return np.where(np.abs(frac) >= F32(0.5), t + np.sign(x).astype(F32), t).astype(F32)
+
+
+# ---- activations --------------------------------------------------------------------------------------
+def absmax_per_sample(x):
+    """`F.max(F.abs(x), axis=(1,2,3))` (convert_conv2d.py:56) / `axis=1` (convert_dense.py:41): one value per sample."""
+    x = np.asarray(x, dtype=F32)
+    return np.abs(x).reshape(x.shape[0], -1).max(axis=1).astype(F32)
+
+
+def batch_mean(per_sample):
+    """`.mean()` of the N per-sample maxima (convert_conv2d.py:56).  Defined here as fp32(sum in fp64, n = 0..N-1)
+    divided in fp32 by N — MXNet's CPU reducer is compensated, its GPU reducer a tree: both agree with this to the
+    last bit for the N <= 1024 non-negative values seen here except at double-rounding ties."""
+    acc = np.float64(0.0)
+    for v in np.asarray(per_sample, dtype=F32):
+        acc += np.float64(v)
+    return F32(F32(acc) / F32(len(per_sample)))
+
+
+def act_scale(max_, signed, width):
+    """convert_conv2d.py:59-64: fp32 `max_ / (2^(w-1)-1)` (signed) or `max_ / (2^w-1)` (unsigned)."""
+    levels = (2 ** (width - 1) - 1) if signed else (2 ** width - 1)
+    return F32(F32(max_) / F32(levels))
+
+
+def ste_codes(x, scale, clip_max=None, clip_min=None, eps=EPS):
+    """Integer stage of LinearQuantizeSTE.forward (ste_func.py:39,41): round(clip(x) / (scale + 1e-10)), as fp32."""
+    x = np.asarray(x, dtype=F32)
+    scale = np.asarray(scale, dtype=F32)
+    denom = (scale + F32(eps)).astype(F32)
+    if clip_max is not None:
+        lo = F32(0.0) if clip_min is None else F32(clip_min)          # ste_func.py:34
+        x = np.minimum(np.maximum(x, lo), F32(clip_max))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return roundf((x / denom).astype(F32))
+
+
+def ste_forward(x, scale, clip_max=None, clip_min=None, eps=EPS):
+    """LinearQuantizeSTE.forward (ste_func.py:37-41): codes * scale (scale WITHOUT epsilon)."""
+    scale = np.asarray(scale, dtype=F32)
+    return (ste_codes(x, scale, clip_max, clip_min, eps) * scale).astype(F32)
+
+
+def conv_input_fake_quant(x, signed=False, width=8, offline_threshold=None):
+    """Activation branch of `_conv2d_forward` (convert_conv2d.py:53-66).
+    Returns (x_q, current_input_max, scale, codes)."""
+    cur = batch_mean(absmax_per_sample(x))
+    max_ = F32(offline_threshold) if offline_threshold is not None else cur
+    scale = act_scale(max_, signed, width)
+    min_ = F32(-max_) if signed else F32(0.0)
+    codes = ste_codes(x, scale, max_, min_)
+    return (codes * scale).astype(F32), cur, scale, codes
+
+
+def dense_input_fake_quant(x, signed=False, width=8, offline_threshold=None):
+    """`_dense_forward` (convert_dense.py:39-49): as conv but STE gets no clip_min => clips to [0, max] even when
+    signed (reference quirk, kept)."""
+    cur = batch_mean(absmax_per_sample(x))
+    max_ = F32(offline_threshold) if offline_threshold is not None else cur
+    scale = act_scale(max_, signed, width)
+    codes = ste_codes(x, scale, max_, None)
+    return (codes * scale).astype(F32), cur, scale, codes
+
+
+def act_output_fake_quant(act, width=8, offline_threshold=None):
+    """`_act_forward` (convert_act.py:49-54): per-sample max WITHOUT abs, no epsilon, unsigned."""
+    a = np.asarray(act, dtype=F32)
+    cur = batch_mean(a.reshape(a.shape[0], -1).max(axis=1))
+    max_ = F32(offline_threshold) if offline_threshold is not None else cur
+    scale = F32(max_ / F32(2 ** width - 1))
+    codes = ste_codes(a, scale, max_, 0.0, eps=F32(0.0))
+    return (codes * scale).astype(F32), cur, scale, codes
+
+
+# ---- weights ------------------------------------------------------------------------------------------
+def weight_fake_quant(w, quant_type="layer", width=8, num_group=1):
+    """Weight branch of `_conv2d_forward` (convert_conv2d.py:68-95) and `_dense_forward` (convert_dense.py:52-63).
+    layer: one scale; channel: one per w.shape[0]; group: one per `num_group` rows of reshape((G,-1)), broadcast as
+    (G,1,1,1) — only shape-valid when G in {1, Cout}, as in the reference.  No clipping; scale array so the epsilon
+    add is an fp32 tensor add.  Returns (w_q, scales)."""
+    w = np.asarray(w, dtype=F32)
+    levels = F32(2 ** (width - 1) - 1)
+    if quant_type == "layer":
+        rows = 1
+    elif quant_type == "channel":
+        rows = w.shape[0]
+    elif quant_type == "group":
+        rows = num_group
+        if rows not in (1, w.shape[0]):
+            raise ValueError("group quantisation broadcasts (G,1,1,1) against (Cout,...): needs G in {1, Cout}")
+    else:
+        raise ValueError(quant_type)
+    max_ = np.abs(w).reshape(rows, -1).max(axis=1).astype(F32)
+    scale = (max_ / levels).astype(F32)
+    sc = scale.reshape((rows,) + (1,) * (w.ndim - 1)) if rows > 1 else scale.reshape((1,) * w.ndim)
+    return ste_forward(w, sc), scale
+
+
+_G = {
+    "F23": [[1, 0, 0], [1 / 2, 1 / 2, 1 / 2], [1 / 2, -1 / 2, 1 / 2], [0, 0, 1]],
+    "F43": [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+            [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+    "F63": [[1, 0, 0], [-2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9], [1 / 90, 1 / 45, 2 / 45],
+            [1 / 90, -1 / 45, 2 / 45], [32 / 45, 16 / 45, 8 / 45], [32 / 45, -16 / 45, 8 / 45], [0, 0, 1]],
+}
+
+
+def winograd_G(variant):
+    """Winograd weight-transform matrices F(2,3) 4x3, F(4,3) 6x3, F(6,3) 8x3 (wino_matrix.py:29-60), fp32."""
+    return np.asarray(_G[variant], dtype=F32)
+
+
+def _seq_dot_last_first(a, b):
+    """MXNet `dot`: contract last axis of a with first axis of b; k-sequential fp32, multiply and add separately
+    rounded (no FMA) — the order the HIP kernel uses."""
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K).astype(F32)
+    b2 = b.reshape(K, -1).astype(F32)
+    acc = (a2[:, 0:1] * b2[0:1, :]).astype(F32)
+    for k in range(1, K):
+        acc = (acc + (a2[:, k:k + 1] * b2[k:k + 1, :]).astype(F32)).astype(F32)
+    return acc.reshape(a.shape[:-1] + b.shape[1:])
+
+
+def wino_weight_fake_quant(w, variant, width=8, GI=None, GTI=None):
+    """Winograd-domain per-channel weight fake-quant (convert_conv2d.py:71-83): U = G g G^T per (co,ci);
+    per-out-channel abs-max over U; STE; back with pinv(G), pinv(G^T) (host numpy SVD, fp32)."""
+    w = np.asarray(w, dtype=F32)
+    G = winograd_G(variant)
+    if GI is None:
+        GI = np.linalg.pinv(G)
+    if GTI is None:
+        GTI = np.linalg.pinv(G.T)
+    t1 = _seq_dot_last_first(G, w.transpose(2, 3, 0, 1)).transpose(2, 3, 0, 1)       # (co, ci, t, 3)
+    U = _seq_dot_last_first(np.ascontiguousarray(t1), np.ascontiguousarray(G.T))      # (co, ci, t, t)
+    cout = w.shape[0]
+    levels = F32(2 ** (width - 1) - 1)
+    max_ = np.abs(U).reshape(cout, -1).max(axis=1).astype(F32)
+    scale = (max_ / levels).astype(F32)
+    Uq = ste_forward(U, scale.reshape(cout, 1, 1, 1))
+    t2 = _seq_dot_last_first(GI.astype(F32), Uq.transpose(2, 3, 0, 1)).transpose(2, 3, 0, 1)
+    wq = _seq_dot_last_first(np.ascontiguousarray(t2), GTI.astype(F32))
+    return wq.astype(F32), scale, U
+
+
+# ---- EMA ----------------------------------------------------------------------------------------------
+def ema_update(state, current, momentum=0.9):
+    """`_update_ema` (convert.py:70): input_max <- (1-m)*current + m*input_max, every product/sum rounded to fp32."""
+    a = (F32(1 - momentum) * np.asarray(current, dtype=F32)).astype(F32)
+    b = (np.asarray(state, dtype=F32) * F32(momentum)).astype(F32)
+    return (a + b).astype(F32)
+
+
+# ---- KL calibration -----------------------------------------------------------------------------------
+def discrete_histogram(fm, bins, max_=None):
+    """`_discrete_histogram` (distribution_calibrate.py:31-47).  Deviation, documented in DESIGN.md: an index equal
+    to `bins` (possible once max_ >= 256, where fp32 `max_ + 1e-5 == max_`) is clamped into the last bin; the
+    reference would return a (bins+1)-long histogram there."""
+    fm = np.asarray(fm, dtype=F32)
+    if max_ is None:
+        max_ = np.max(fm)
+    max_ = F32(max_)
+    assert np.min(fm) >= 0.0, "Activation should >=0"
+    assert max_ > 0, "Bad distribution: all zero-value"
+    v = np.minimum(np.maximum(fm.reshape(-1), F32(0)), max_)
+    v = v[v != 0]
+    scales = F32(F32(bins) / F32(max_ + F32(1e-5)))
+    idx = (v * scales).astype(F32).astype(np.int32)
+    idx = np.minimum(idx, bins - 1)
+    return np.bincount(idx, minlength=bins).astype(F32), max_
+
+
+def _seq_sum(a, dtype):
+    """Python's builtin `sum()` over a numpy array = strictly sequential accumulation in the array's dtype
+    (numpy 2 promotion).  `np.cumsum` is the same left-to-right recurrence, vectorised."""
+    a = np.asarray(a, dtype=dtype)
+    if a.size == 0:
+        return dtype(0)
+    return np.cumsum(a, dtype=dtype)[-1]
+
+
+def kl_calibrate(data, levels, min_bins, bins):
+    """`kl_calibrate` (distribution_calibrate.py:117-171), same arithmetic and summation order:
+    P: fp32, tail mass folded with a sequential fp32 sum, normalised by a sequential fp32 sum;
+    Q: fp64 merge into `levels`, linear-interpolated expansion, masked where P == 0, normalised by a sequential fp64
+    sum; KL = sequential fp64 sum of P*log(P/Q) over Q != 0; strict `<` keeps the first minimum."""
+    assert min_bins >= levels
+    data = np.asarray(data, dtype=F32)
+    best, best_div = min_bins, np.inf
+    for i in range(min_bins, bins):
+        p = data[:i].copy()
+        tail = _seq_sum(data[i:], F32)
+        p[i - 1] = F32(p[i - 1] + tail)
+        s = _seq_sum(p, F32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            p = (p / s).astype(F32)
+        b = np.arange(i) * levels / i
+        fl = b.astype(np.int32)
+        q = np.zeros(levels, np.float64)
+        np.add.at(q, fl, data[:i].astype(np.float64))            # sequential in j, like the reference loop
+        ce = np.clip(np.ceil(b), 0, levels - 1).astype(np.int32)
+        qe = (q[ce] - q[fl]) * (b - fl) + q[fl]
+        qe = qe * (p != 0)
+        qs = _seq_sum(qe, np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            qe = qe / qs
+            m = qe != 0
+            terms = p[m] * np.log(p[m] / qe[m])
+        div = _seq_sum(terms, np.float64)
+        if div < best_div:
+            best_div, best = div, i
+    return best
+
+
+def kl_threshold(best_bins, fm_max, bins):
+    """Caller-side threshold (examples/simulate_quantization.py:310): (best + 0.5) * (fm_max / bins)."""
+    return F32((best_bins + 0.5) * (F32(fm_max) / bins))
+
+
+# ---- int-code path (nn/quantized_conv.py) ---------------------------------------------------------------
+def quantize_codes(x, out_type="int8", fixed_range=None):
+    """`quantize` + `_quantize` (nn/quantized_conv.py:54-72): global range, clip, scale = max/127 if symmetric else
+    (max-min)/255 (no zero-point), round(x/scale) (no epsilon), int32.  Returns (codes int32, scale fp32)."""
+    x = np.asarray(x, dtype=F32)
+    if fixed_range is not None:
+        mn, mx = F32(fixed_range[0]), F32(fixed_range[1])
+    elif out_type == "int8":
+        mx = np.abs(x).max().astype(F32)
+        mn = F32(-mx)
+    elif out_type == "uint8":
+        mx, mn = x.max().astype(F32), x.min().astype(F32)
+    else:
+        raise ValueError("unknown out type: " + str(out_type))
+    xc = np.minimum(np.maximum(x, mn), mx)
+    scale = F32(mx / F32(127)) if mx == -mn else F32(F32(mx - mn) / F32(255))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        codes = roundf((xc / scale).astype(F32)).astype(np.int32)
+    return codes, scale
+
+
+def dequantize(codes, scale):
+    """`dequantize` (nn/quantized_conv.py:74-76)."""
+    return (np.asarray(codes).astype(F32) * F32(scale)).astype(F32)
+
+
+def qconv2d_forward(x, w, b, stride, padding, groups, input_dtype="uint8", weight_dtype="int8", quantized=True):
+    """`Conv2D.hybrid_forward` (nn/quantized_conv.py:106-159) with the im2col + dot done as an exact integer
+    correlation (the reference's fp32 dot is exact while |acc| < 2^24, :140-144)."""
+    x = np.asarray(x, dtype=F32)
+    ph, pw = padding
+    x = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
+    if quantized:
+        xi, in_s = quantize_codes(x, input_dtype)
+        wi, w_s = quantize_codes(w, weight_dtype)
+        bi = None
+        if b is not None:
+            b_scale = F32(in_s * w_s)
+            b_max = F32(F32(in_s * w_s) * F32(2 ** 31))
+            bc = np.minimum(np.maximum(np.asarray(b, dtype=F32), -b_max), b_max)
+            bi = roundf((bc / b_scale).astype(F32)).astype(np.int64)
+        xa, wa = xi.astype(np.int64), wi.astype(np.int64)
+    else:
+        xa, wa, bi = x.astype(np.float64), np.asarray(w, dtype=np.float64), None if b is None else np.asarray(b, np.float64)
+    N, C, H, W = xa.shape
+    Co, Cg, kh, kw = wa.shape
+    sh, sw = stride
+    # NB the reference computes out_h = (H - kh + 1) // sh but collects range(0, H-kh+1, sh) columns (:42-49);
+    # they agree for stride 1, the only stride its tests use.
+    oh, ow = len(range(0, H - kh + 1, sh)), len(range(0, W - kw + 1, sw))
+    y = np.zeros((N, Co, oh, ow), dtype=xa.dtype)
+    cpg_out = Co // groups
+    for g in range(groups):
+        xs = xa[:, g * Cg:(g + 1) * Cg]
+        for i in range(oh):
+            for j in range(ow):
+                win = xs[:, :, i * sh:i * sh + kh, j * sw:j * sw + kw].reshape(N, -1)
+                wg = wa[g * cpg_out:(g + 1) * cpg_out].reshape(cpg_out, -1)
+                y[:, g * cpg_out:(g + 1) * cpg_out, i, j] = win @ wg.T
+    if bi is not None:
+        y = y + bi.reshape(1, -1, 1, 1)
+    if quantized:
+        return dequantize(y.astype(np.int32), F32(in_s * w_s))
+    return y.astype(F32)
+
+
+# ---- the reference's UNFUSED op chain, pass by pass (used as the CPU baseline workload) -------------------
+def unfused_reference_chain(x, signed=False, width=8):
+    """What `_conv2d_forward` + `LinearQuantizeSTE.forward` execute on the reference's CPU path for one activation
+    tensor, one full-tensor pass per NDArray op (convert_conv2d.py:56-66, ste_func.py:41):
+    abs -> per-sample max -> mean -> clip -> divide -> round -> multiply."""
+    a = np.abs(x)
+    m = a.reshape(a.shape[0], -1).max(axis=1)
+    cur = batch_mean(m)
+    scale = act_scale(cur, signed, width)
+    lo = F32(-cur) if signed else F32(0)
+    c = np.clip(x, lo, cur)
+    d = c / F32(scale + EPS)
+    t = np.trunc(d)
+    r = np.where(np.abs(d - t) >= F32(0.5), t + np.sign(d), t).astype(F32)
+    return r * scale, cur

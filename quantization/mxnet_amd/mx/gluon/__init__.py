@@ -1,0 +1,6 @@
+"""Gluon-shaped host facade (see block.py / parameter.py / nn.py)."""
+from .parameter import Parameter, ParameterDict
+from .block import Block, HybridBlock
+from . import nn
+from . import data
+from . import model_zoo

@@ -1,0 +1,248 @@
+"""Gluon-shaped `Parameter` / `ParameterDict` over torch device memory.
+
+The reference keeps every piece of quantisation state as a Gluon Parameter created through
+`m.params.get("input_max", shape=(1,), init="zeros", allow_deferred_init=True, differentiable=False)`
+(quantize/convert/convert_conv2d.py:116-119) and mutates it with `set_data` / reads it with `data()`
+(quantize/convert/convert.py:70; convert_conv2d.py:101-105).  Only that surface is reproduced.
+"""
+import re
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import initializer as _init
+from ..context import Context, cpu
+from ..ndarray import NDArray
+
+__all__ = ["Parameter", "ParameterDict", "DeferredInitializationError"]
+
+
+class DeferredInitializationError(RuntimeError):
+    pass
+
+
+class Parameter(object):
+    def __init__(self, name, grad_req="write", shape=None, dtype="float32", init=None,
+                 allow_deferred_init=False, differentiable=True, **_ignored):
+        self.name = name
+        self.shape = None if shape is None else tuple(int(s) for s in ((shape,) if isinstance(shape, int) else shape))
+        self.dtype = dtype
+        self.init = init
+        self.allow_deferred_init = allow_deferred_init
+        self.differentiable = differentiable
+        self.grad_req = grad_req if differentiable else "null"
+        self._data = None            # NDArray
+        self._deferred = None        # (init, ctx)
+        self._ctx = None
+
+    def __repr__(self):
+        return "Parameter %s (shape=%s, dtype=%s)" % (self.name, self.shape, self.dtype)
+
+    def _shape_known(self):
+        return self.shape is not None and all(s > 0 for s in self.shape)
+
+    def initialize(self, init=None, ctx=None, default_init=None, force_reinit=False):
+        if self._data is not None and not force_reinit:
+            return
+        if isinstance(ctx, (list, tuple)):
+            ctx = ctx[0]
+        ctx = ctx or cpu()
+        # Gluon rule: an explicit `init` argument wins; otherwise the Parameter's own init; otherwise the
+        # dict-wide default (`ParameterDict.initialize(init)` passes its init as `default_init`).
+        if init is None:
+            init = default_init if self.init is None else self.init
+        chosen = _init.create(init, None)
+        if not self._shape_known():
+            if not self.allow_deferred_init:
+                raise ValueError("Cannot initialize Parameter %s: unknown shape %s" % (self.name, self.shape))
+            self._deferred = (chosen, ctx)
+            return
+        self._finish_init(chosen, ctx)
+
+    def _finish_init(self, init, ctx):
+        arr = init(self.shape)
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(ctx.torch_device)
+        self._data = NDArray(t)
+        self._ctx = ctx
+        self._deferred = None
+
+    def _finish_deferred_init(self, shape):
+        self.shape = tuple(shape)
+        if self._deferred is None:
+            raise DeferredInitializationError("Parameter %s was never initialized" % self.name)
+        init, ctx = self._deferred
+        self._finish_init(init, ctx)
+
+    def _check(self):
+        if self._data is None:
+            if self._deferred is not None:
+                raise DeferredInitializationError(
+                    "Parameter %s has deferred initialization pending (shape %s)" % (self.name, self.shape))
+            raise RuntimeError("Parameter %s has not been initialized" % self.name)
+
+    def data(self, ctx=None):
+        self._check()
+        if ctx is not None and isinstance(ctx, Context) and ctx != self._ctx:
+            raise RuntimeError("Parameter %s was not initialized on context %s (it lives on %s)"
+                               % (self.name, ctx, self._ctx))
+        return self._data
+
+    def list_data(self):
+        return [self.data()]
+
+    def list_ctx(self):
+        if self._data is None and self._deferred is not None:
+            return [self._deferred[1]]
+        self._check()
+        return [self._ctx]
+
+    def set_data(self, data):
+        if not isinstance(data, NDArray):
+            data = NDArray(torch.as_tensor(np.asarray(data, dtype=np.float32)))
+        if self._data is None:
+            ctx = self._deferred[1] if self._deferred is not None else data.context
+            self.shape = data.shape
+            self._data = NDArray(data._t.to(ctx.torch_device, copy=True))
+            self._ctx = ctx
+            self._deferred = None
+            return
+        assert tuple(data.shape) == tuple(self._data.shape), \
+            "set_data shape mismatch for %s: %s vs %s" % (self.name, data.shape, self._data.shape)
+        self._data._t.copy_(data._t)
+
+    def reset_ctx(self, ctx):
+        if isinstance(ctx, (list, tuple)):
+            ctx = ctx[0]
+        if self._data is not None:
+            self._data = NDArray(self._data._t.to(ctx.torch_device))
+            self._ctx = ctx
+        elif self._deferred is not None:
+            self._deferred = (self._deferred[0], ctx)
+        else:
+            raise ValueError("Cannot reset context for Parameter %s: not initialized" % self.name)
+
+    def zero_grad(self):
+        pass
+
+    def cast(self, dtype):
+        self.dtype = dtype
+
+
+class ParameterDict(object):
+    def __init__(self, prefix="", shared=None):
+        self._prefix = prefix
+        self._params = OrderedDict()
+        self._shared = shared
+
+    @property
+    def prefix(self):
+        return self._prefix
+
+    def __repr__(self):
+        return "%s(\n%s\n)" % (self._prefix, "\n".join("  " + repr(p) for p in self._params.values()))
+
+    def __getitem__(self, key):
+        return self._params[key]
+
+    def __iter__(self):
+        return iter(self._params)
+
+    def __len__(self):
+        return len(self._params)
+
+    def __contains__(self, key):
+        return key in self._params
+
+    def items(self):
+        return self._params.items()
+
+    def keys(self):
+        return self._params.keys()
+
+    def values(self):
+        return self._params.values()
+
+    def _get_impl(self, name):
+        if name in self._params:
+            return self._params[name]
+        if self._shared is not None and name in self._shared._params:
+            self._params[name] = self._shared._params[name]
+            return self._params[name]
+        return None
+
+    def get(self, name, **kwargs):
+        name = self._prefix + name
+        param = self._get_impl(name)
+        if param is None:
+            param = Parameter(name, **kwargs)
+            self._params[name] = param
+        else:
+            for k, v in kwargs.items():
+                if k == "shape" and v is not None and param.shape is not None:
+                    v = tuple((v,) if isinstance(v, int) else v)
+                    if len(v) == len(param.shape) and all(a == b or a == 0 or b == 0 for a, b in zip(v, param.shape)):
+                        param.shape = tuple(a if a != 0 else b for a, b in zip(v, param.shape))
+                        continue
+                    raise AssertionError("Parameter %s shape mismatch: %s vs %s" % (name, v, param.shape))
+        return param
+
+    def update(self, other):
+        for k, v in other.items():
+            if k in self._params:
+                assert self._params[k] is v, "Cannot update self with other because they have different " \
+                                             "Parameters with the same name %s" % k
+            else:
+                self._params[k] = v
+
+    def initialize(self, init=None, ctx=None, verbose=False, force_reinit=False):
+        for p in self.values():
+            p.initialize(None, ctx, init, force_reinit=force_reinit)
+
+    def reset_ctx(self, ctx):
+        for p in self.values():
+            p.reset_ctx(ctx)
+
+    def zero_grad(self):
+        pass
+
+    def setattr(self, name, value):
+        for p in self.values():
+            setattr(p, name, value)
+
+    # -- flat {name: array} file: carries thresholds/scales across runs (checkpoint row) --
+    def save(self, filename, strip_prefix=""):
+        out = {}
+        for name, p in self.items():
+            key = name[len(strip_prefix):] if strip_prefix and name.startswith(strip_prefix) else name
+            out[key] = p.data().asnumpy()
+        with open(filename, "wb") as f:
+            np.savez(f, **out)
+
+    def load(self, filename, ctx=None, allow_missing=False, ignore_extra=False, restore_prefix=""):
+        with np.load(filename) as z:
+            loaded = {restore_prefix + k: z[k] for k in z.files}
+        if not allow_missing:
+            for name in self.keys():
+                assert name in loaded, "Parameter %s is missing in file %s" % (name, filename)
+        for name, arr in loaded.items():
+            if name not in self._params:
+                assert ignore_extra, "Parameter %s loaded from file %s is not present in ParameterDict" % (name, filename)
+                continue
+            p = self._params[name]
+            if p._data is None:
+                if p._deferred is None:
+                    p._deferred = (_init.Zero(), ctx or cpu())
+                p.shape = tuple(arr.shape)
+                p._finish_init(_init.Constant(arr), p._deferred[1] if ctx is None else ctx)
+            else:
+                p.set_data(NDArray(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))))
+
+    def select(self, pattern):
+        """`collect_params(select)` filter: regex matched against the full name (Gluon uses re.match)."""
+        rx = re.compile(pattern)
+        ret = ParameterDict(self._prefix)
+        for k, v in self.items():
+            if rx.match(k):
+                ret._params[k] = v
+        return ret
