@@ -1,0 +1,132 @@
+/*
+ * fakequant.h — C ABI of libfakequant.so: the MI355X (gfx950) simulated-quantisation hot path of
+ * hey-yahei/Quantization.MXNet, as a drop-in for the bodies of the reference's patched `hybrid_forward`s.
+ *
+ * The reference has no native boundary on this path: every op is a Python call into Apache MXNet NDArray ops
+ * (SURVEY.md F1/F2).  The only FFI it shows is the libmxnet convention at quantize/freeze/freeze.py:67-76,125
+ * (`check_call(_LIB.MXQuantizeSymbol(...))`: int status, out-params, error text fetched separately).  This header
+ * keeps that convention, and each entry point names the reference lines whose op chain it replaces.  The ctypes
+ * binding a reference maintainer would add is shown in INTEGRATION.md and lives in quantization/mxnet_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; `fq_last_error()` returns the thread-local message;
+ *   - all tensor pointers are DEVICE pointers owned by the caller (its tensor library); fp32, C-contiguous (NCHW);
+ *   - the library never allocates, frees or synchronises: scratch comes from the caller (`*_workspace_bytes`),
+ *     every launch is asynchronous on the `hipStream_t` passed as `stream` (void* here so C callers need no HIP
+ *     headers); results the reference pulled to the host with `.asscalar()` stay in device scalars;
+ *   - no CPU fallback exists in this library.
+ */
+#ifndef FAKEQUANT_H_
+#define FAKEQUANT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQ_OK 0
+#define FQ_ERR_INVALID 1
+#define FQ_ERR_HIP 2
+
+typedef void* fqStream_t; /* hipStream_t */
+
+/* flags for the activation entry points */
+#define FQ_ACT_SIGNED 1u       /* levels = 2^(w-1)-1 instead of 2^w-1        (convert_conv2d.py:59-64)            */
+#define FQ_ACT_LO_NEG_MAX 2u   /* clip to [-max, max] instead of [0, max]    (conv signed :60; Dense never :49)   */
+#define FQ_ACT_NO_ABS 4u       /* statistic = max(x) not max|x|              (convert_act.py:50)                  */
+#define FQ_ACT_NO_EPS 8u       /* divide by scale, not scale + 1e-10         (convert_act.py:54)                  */
+
+/* quantize_codes modes (nn/quantized_conv.py:63-72,112-127) */
+#define FQ_CODES_INT8 0   /* range = [-max|x|, max|x|]                      */
+#define FQ_CODES_UINT8 1  /* range = [min x, max x]                         */
+#define FQ_CODES_RANGE 2  /* range given in range_dev[0..1]                 */
+#define FQ_CODES_SCALE 3  /* range in range_dev[0..1], scale in range_dev[2] (the int32 bias, :122-127) */
+
+const char* fq_last_error(void);
+int fq_version(void);
+/* Name (e.g. "gfx950"), compute units and wavefront size of the current HIP device. */
+int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront);
+
+/* ---- activations ---------------------------------------------------------------------------------------------
+ * x is (n, inner) = (N, C*H*W).  `ws` is a caller workspace of fq_act_workspace_bytes(n) bytes.                  */
+size_t fq_act_workspace_bytes(int64_t n);
+
+/* Replaces `F.max(F.abs(x), axis=(1,2,3))` (convert_conv2d.py:56; convert_dense.py:41; convert_act.py:50 with
+ * FQ_ACT_NO_ABS).  out_max[n] <- per-sample statistic.                                                          */
+int fq_absmax_per_sample(const float* x, int64_t n, int64_t inner, unsigned flags, float* out_max,
+                         fqStream_t stream);
+
+/* Replaces `.mean()` of the per-sample maxima (convert_conv2d.py:56): out[0] <- fp32(sum_fp64(v[0..n)))/n.      */
+int fq_batch_mean(const float* v, int64_t n, float* out, fqStream_t stream);
+
+/* Replaces convert_conv2d.py:56-66 + ste_func.py:41 in ONLINE mode (threshold = this batch's statistic):
+ *   cur = mean_n max|x[n]|;  scale = cur/levels;  y = roundf(clip(x, lo, cur) / (scale + eps)) * scale.
+ * out_current_max (device scalar, may be NULL) <- cur.  codes (int32, may be NULL) <- the integer stage.
+ * Two launches (statistic pass, apply pass) + one memset on `stream`; algorithmic traffic 12 B/elem.            */
+int fq_fake_quant_online(const float* x, float* y, int64_t n, int64_t inner, int width, unsigned flags,
+                         float* out_current_max, int32_t* codes, void* ws, fqStream_t stream);
+
+/* Same arithmetic in OFFLINE mode: threshold read from the device scalar `threshold` (`input_max`,
+ * convert_conv2d.py:58).  If out_current_max != NULL the batch statistic is ALSO produced (the reference computes
+ * it in every mode, :56) — fused into the same pass over x, so traffic stays 8 B/elem.                          */
+int fq_fake_quant_offline(const float* x, float* y, int64_t n, int64_t inner, const float* threshold, int width,
+                          unsigned flags, float* out_current_max, int32_t* codes, void* ws, fqStream_t stream);
+
+/* Generic LinearQuantizeSTE.forward (ste_func.py:37-41) for API completeness: x viewed as (rows, row_len) with one
+ * scale per row read from the DEVICE array `scales` (rows = 1: scalar scale; rows = Cout: (Cout,1,1,1) broadcast):
+ *   y = roundf( (has_clip ? clip(x, clip_lo, clip_hi) : x) / (scales[r] + eps) ) * scales[r].                    */
+int fq_ste_forward(const float* x, float* y, int64_t rows, int64_t row_len, const float* scales, int has_clip,
+                   float clip_lo, float clip_hi, float eps, fqStream_t stream);
+
+/* ---- weights ---------------------------------------------------------------------------------------------------
+ * Replaces convert_conv2d.py:70-95 / convert_dense.py:52-63: w viewed as (rows, row_len); per-row
+ *   s = max|w[r,:]| / (2^(width-1)-1);   w_q = roundf(w / (s + 1e-10)) * s     (no clipping).
+ * rows = 1 (layer), = Cout (channel / depthwise group), = G with G in {1, Cout} (group).
+ * scales_out (device, rows floats, may be NULL) <- s.  ws: fq_weight_workspace_bytes(rows) bytes.               */
+size_t fq_weight_workspace_bytes(int64_t rows);
+int fq_weight_fake_quant(const float* w, float* w_q, int64_t rows, int64_t row_len, int width, float* scales_out,
+                         void* ws, fqStream_t stream);
+
+/* Replaces convert_conv2d.py:71-83 (+ wino_matrix.py): per-out-channel fake-quant in the Winograd domain.
+ * w is (cout, cin_g, 3, 3); t = 4/6/8 for F23/F43/F63; G is t x 3, GI = pinv(G) is 3 x t, GTI = pinv(G^T) is
+ * t x 3 — HOST pointers, row-major fp32 (the reference computes the pseudo-inverses on the host with numpy).     */
+int fq_wino_weight_fake_quant(const float* w, float* w_q, int64_t cout, int64_t cin_g, int t, const float* G,
+                              const float* GI, const float* GTI, int width, float* scales_out, void* ws,
+                              fqStream_t stream);
+
+/* ---- calibration -------------------------------------------------------------------------------------------------
+ * Replaces `_update_ema` (convert.py:66-79) for L scalars at once: state <- (1-m)*current + m*state.            */
+int fq_ema_update(float* state, const float* current, int64_t count, double momentum, fqStream_t stream);
+
+/* out[0] <- max(x) over the whole tensor (distribution_calibrate.py:33-34: first batch fixes the range).        */
+int fq_global_max(const float* x, int64_t numel, float* out, fqStream_t stream);
+
+/* Replaces `_discrete_histogram` + the accumulation at distribution_calibrate.py:39-45,103-104:
+ * hist[bins] (uint64, device) += histogram of clip(x, 0, *max_dev) without exact zeros, index
+ * = int(v * (bins / (max + 1e-5))), clamped to bins-1.  neg_count (may be NULL) += #elements < 0 (the reference
+ * asserts there are none, :35).                                                                                  */
+int fq_histogram_accumulate(const float* x, int64_t numel, const float* max_dev, int bins, uint64_t* hist,
+                            uint32_t* neg_count, fqStream_t stream);
+int fq_hist_to_float(const uint64_t* hist, float* out, int64_t count, fqStream_t stream);
+
+/* Replaces `kl_calibrate` (distribution_calibrate.py:117-171) for L histograms at once.
+ * hist: (L, bins) fp32; out_best: (L) int32.  ws: fq_kl_workspace_bytes(L, bins) bytes.                         */
+size_t fq_kl_workspace_bytes(int64_t L, int bins);
+int fq_kl_search(const float* hist, int64_t L, int bins, int levels, int min_bins, int32_t* out_best, void* ws,
+                 fqStream_t stream);
+
+/* ---- int-code path (nn/quantized_conv.py:54-76) --------------------------------------------------------------------
+ * codes <- int32(roundf(clip(x, min, max) / scale)); scale = max/127 if max == -min else (max-min)/255.
+ * range_dev: device float[3] = {min, max, scale}; written by modes INT8/UINT8 (and scale by RANGE), read by SCALE.
+ * ws: fq_act_workspace_bytes(1).                                                                                 */
+int fq_quantize_codes(const float* x, int32_t* codes, int64_t numel, int mode, float* range_dev, void* ws,
+                      fqStream_t stream);
+/* y <- float(codes) * scale_dev[0]  (dequantize, :74-76) */
+int fq_dequantize(const int32_t* codes, float* y, int64_t numel, const float* scale_dev, fqStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAKEQUANT_H_ */

@@ -1,0 +1,90 @@
+"""ctypes binding of libfakequant.so (include/fakequant.h), in the style the reference binds libmxnet
+(quantize/freeze/freeze.py:32-34,67-76: `check_call(_LIB.fn(...))`, int status, error text fetched separately).
+
+There is no CPU fallback: if the library cannot be loaded every entry point raises, loudly.
+"""
+import ctypes
+import os
+
+__all__ = ["LIB", "check_call", "load", "library_path", "FakeQuantError", "EXPORTS"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "csrc", "libfakequant.so")
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp, _i64, _int, _uint, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/fakequant.h one to one (tests/test_abi.py checks both directions)
+EXPORTS = {
+    "fq_last_error": (ctypes.c_char_p, []),
+    "fq_version": (_int, []),
+    "fq_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "fq_act_workspace_bytes": (ctypes.c_size_t, [_i64]),
+    "fq_absmax_per_sample": (_int, [_vp, _i64, _i64, _uint, _vp, _vp]),
+    "fq_batch_mean": (_int, [_vp, _i64, _vp, _vp]),
+    "fq_fake_quant_online": (_int, [_vp, _vp, _i64, _i64, _int, _uint, _vp, _vp, _vp, _vp]),
+    "fq_fake_quant_offline": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp, _vp]),
+    "fq_ste_forward": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _f32, _f32, _f32, _vp]),
+    "fq_weight_workspace_bytes": (ctypes.c_size_t, [_i64]),
+    "fq_weight_fake_quant": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
+    "fq_wino_weight_fake_quant": (_int, [_vp, _vp, _i64, _i64, _int, c_f32p, c_f32p, c_f32p, _int, _vp, _vp, _vp]),
+    "fq_ema_update": (_int, [_vp, _vp, _i64, ctypes.c_double, _vp]),
+    "fq_global_max": (_int, [_vp, _i64, _vp, _vp]),
+    "fq_histogram_accumulate": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _vp]),
+    "fq_hist_to_float": (_int, [_vp, _vp, _i64, _vp]),
+    "fq_kl_workspace_bytes": (ctypes.c_size_t, [_i64, _int]),
+    "fq_kl_search": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, _vp]),
+    "fq_quantize_codes": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp]),
+    "fq_dequantize": (_int, [_vp, _vp, _i64, _vp, _vp]),
+}
+
+FQ_ACT_SIGNED, FQ_ACT_LO_NEG_MAX, FQ_ACT_NO_ABS, FQ_ACT_NO_EPS = 1, 2, 4, 8
+FQ_CODES_INT8, FQ_CODES_UINT8, FQ_CODES_RANGE, FQ_CODES_SCALE = 0, 1, 2, 3
+
+
+class FakeQuantError(RuntimeError):
+    """Error raised by the HIP library (the analogue of MXNetError)."""
+
+
+class _Missing(object):
+    def __init__(self, why):
+        self._why = why
+
+    def __getattr__(self, name):
+        raise FakeQuantError(
+            "libfakequant.so is not available (%s). Build it with `python -m quantization.mxnet_amd.csrc.build` "
+            "(needs hipcc, target gfx950). There is no CPU fallback for the fake-quant path." % self._why)
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load(path=None):
+    """dlopen the library and attach prototypes.  torch is imported first so that the HIP runtime already mapped
+    into the process (torch's bundled libamdhip64.so.7) is the one libfakequant binds to — two HIP runtimes in
+    one process would not share device pointers or streams."""
+    import torch  # noqa: F401  (side effect: loads libamdhip64)
+    path = path or _LIB_PATH
+    if not os.path.exists(path):
+        return _Missing("no file at %s" % path)
+    try:
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:            # pragma: no cover
+        return _Missing(str(e))
+    for name, (restype, argtypes) in EXPORTS.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+LIB = load()
+
+
+def check_call(ret):
+    if ret != 0:
+        raise FakeQuantError(LIB.fq_last_error().decode("utf-8", "replace"))

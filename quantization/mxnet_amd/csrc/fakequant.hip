@@ -1,0 +1,1140 @@
+// libfakequant — hand-written HIP kernels for MI355X (gfx950 / CDNA4) + the C ABI of include/fakequant.h.
+//
+// Everything here is HBM-bound elementwise / reduction work (no contraction -> no MFMA).  Design rules applied:
+//   * 64-wide wavefronts, 256-thread workgroups, 16 B per lane per access (global_load/store_dwordx4), 8
+//     independent loads in flight per lane (32 KiB per workgroup per step) and a grid capped at 8 workgroups per
+//     CU with a grid-stride loop;
+//   * per-sample / per-row statistics: lane-local max -> wavefront shuffle tree -> LDS across the 4 waves -> ONE
+//     integer atomicMax per workgroup step (|x| >= 0, so the fp32 bit pattern orders like an unsigned int);
+//   * the batch statistic never leaves the device: the apply pass re-derives mean -> scale in its prologue from
+//     the N per-sample maxima (scalar loads, fp64 accumulate in sample order) — no `.asscalar()` round trip;
+//   * arithmetic that decides an integer code is IEEE: true fp32 division (never rcp-multiply), C roundf
+//     (half away from zero), clip before divide, multiply by the epsilon-free scale; the file is compiled with
+//     -ffp-contract=off so no multiply-add is fused behind the oracle's back.
+//
+// Reference lines each kernel replaces are cited at its C entry point in include/fakequant.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "fakequant.h"
+
+namespace {
+
+constexpr int kBlock = 256;                       // 4 wavefronts
+constexpr int kVec = 4;                           // floats per lane per access (16 B)
+constexpr int kUnroll = 8;                        // independent 16 B accesses in flight per lane
+constexpr int kChunk = kBlock * kVec * kUnroll;   // 8192 floats = 32 KiB per workgroup step
+constexpr int kMaxBlocksPerCU = 8;
+constexpr float kEps = 1e-10f;                    // ste_func.py:39,41
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define FQ_HIP(expr)                                                                             \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(FQ_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));       \
+  } while (0)
+#define FQ_REQUIRE(cond, ...)                                 \
+  do {                                                        \
+    if (!(cond)) return fail(FQ_ERR_INVALID, __VA_ARGS__);    \
+  } while (0)
+#define FQ_LAUNCH_CHECK() FQ_HIP(hipGetLastError())
+
+int g_num_cu = 0;
+int num_cu() {
+  if (g_num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cu = prop.multiProcessorCount;
+    if (g_num_cu <= 0) g_num_cu = 256;
+  }
+  return g_num_cu;
+}
+
+inline int grid_for(int64_t work_items) {
+  int64_t cap = (int64_t)num_cu() * kMaxBlocksPerCU;
+  int64_t g = work_items < cap ? work_items : cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// max over the workgroup; result valid in thread 0.  `red` = 4 floats of LDS.
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();                       // protect `red` against the previous step's readers
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  return v;
+}
+__device__ __forceinline__ float block_min(float v, float* red) {
+  v = wave_min(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) v = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+  return v;
+}
+
+// Order-preserving atomics on fp32 through integer atomics (no CAS loop).
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.0f)
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+  if (v >= 0.0f)
+    atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+// Deterministic batch mean: fp64 accumulate in sample order, one rounding to fp32, fp32 divide (oracle: batch_mean).
+__device__ __forceinline__ float batch_mean_dev(const float* __restrict__ v, int n) {
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) acc += (double)v[i];
+  return (float)acc / (float)n;
+}
+
+struct QParams {
+  float lo, hi;      // clip bounds
+  float denom;       // scale + eps
+  float scale;       // multiply-back scale (no eps)
+};
+
+__device__ __forceinline__ QParams make_qparams(float max_, float levels, bool lo_neg_max, float eps) {
+  QParams q;
+  q.hi = max_;
+  q.lo = lo_neg_max ? -max_ : 0.0f;
+  q.scale = max_ / levels;
+  q.denom = q.scale + eps;
+  return q;
+}
+
+// The integer stage and the dequantised value (ste_func.py:41): clip -> IEEE divide -> roundf -> multiply.
+__device__ __forceinline__ float fq_code(float x, const QParams& q) {
+  float c = fminf(fmaxf(x, q.lo), q.hi);
+  return roundf(c / q.denom);
+}
+
+template <bool USE_ABS>
+__device__ __forceinline__ float stat_of(float v) {
+  return USE_ABS ? fabsf(v) : v;
+}
+template <bool USE_ABS>
+__device__ __forceinline__ float stat_init() {
+  return USE_ABS ? 0.0f : -INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K0: fill
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming helpers.  f4 is the native 16-byte vector (the nontemporal builtins want a native vector type).
+// Policy bits (host-chosen, see stream_policy()):
+//   kPolNtLoad   : x is dead after this pass -> nontemporal loads (do not displace other lines in L2 / Infinity Cache)
+//   kPolNtStore  : nontemporal stores of y
+//   kPolReverse  : walk each workgroup's chunk range backwards — the second pass of the online path starts with the
+//                  chunks the statistic pass read LAST, which are the ones still resident in the 256 MiB Infinity
+//                  Cache when the tensor is larger than it.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+constexpr int kPolNtLoad = 1, kPolNtStore = 2, kPolReverse = 4;
+
+template <bool NT>
+__device__ __forceinline__ f4 ld4(const f4* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st4(f4* p, f4 v) {
+  if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+template <bool USE_ABS>
+__device__ __forceinline__ float stat4(f4 v) {
+  return fmaxf(fmaxf(stat_of<USE_ABS>(v.x), stat_of<USE_ABS>(v.y)), fmaxf(stat_of<USE_ABS>(v.z), stat_of<USE_ABS>(v.w)));
+}
+
+// Each workgroup owns a CONTIGUOUS range of 32 KiB chunks; a chunk never spans two samples.  The lane-local running
+// maximum is carried across chunks and only reduced (shuffle tree -> LDS -> one atomic) when the sample changes.
+struct ChunkRange {
+  int64_t begin, end;   // [begin, end)
+};
+__device__ __forceinline__ ChunkRange block_range(int64_t total_chunks) {
+  const int64_t per = (total_chunks + gridDim.x - 1) / gridDim.x;
+  ChunkRange r;
+  r.begin = (int64_t)blockIdx.x * per;
+  r.end = r.begin + per < total_chunks ? r.begin + per : total_chunks;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1: per-sample statistic.  x viewed as (n, inner).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool USE_ABS, bool VEC, bool NTL>
+__global__ __launch_bounds__(kBlock) void absmax_per_sample_kernel(const float* __restrict__ x, int64_t inner,
+                                                                   int chunks_per_sample, int64_t total_chunks,
+                                                                   float* __restrict__ out_max) {
+  __shared__ float red[4];
+  const ChunkRange rg = block_range(total_chunks);
+  int64_t cur_s = -1;
+  float m = stat_init<USE_ABS>();
+  for (int64_t c = rg.begin; c < rg.end; ++c) {
+    const int64_t s = c / chunks_per_sample;
+    if (s != cur_s) {
+      if (cur_s >= 0) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) atomic_max_f32(out_max + cur_s, m);
+      }
+      cur_s = s;
+      m = stat_init<USE_ABS>();
+    }
+    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kChunk;
+    const float* base = x + s * inner + off0;
+    const int64_t rem = inner - off0;
+    if (VEC) {
+      const f4* p = reinterpret_cast<const f4*>(base);
+      if (rem >= kChunk) {
+        f4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = ld4<NTL>(p + threadIdx.x + u * kBlock);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) m = fmaxf(m, stat4<USE_ABS>(v[u]));
+      } else {
+        const int nvec = (int)(rem / kVec);
+        for (int i = threadIdx.x; i < nvec; i += kBlock) m = fmaxf(m, stat4<USE_ABS>(ld4<NTL>(p + i)));
+      }
+    } else {
+      const int cnt = (int)(rem < kChunk ? rem : kChunk);
+      for (int i = threadIdx.x; i < cnt; i += kBlock) m = fmaxf(m, stat_of<USE_ABS>(base[i]));
+    }
+  }
+  if (cur_s >= 0) {
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomic_max_f32(out_max + cur_s, m);
+  }
+}
+
+// K1b: mean of n floats (one thread; n is a batch size)
+__global__ void batch_mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = batch_mean_dev(v, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2: apply.  ONLINE: threshold = mean of stat_in[0..n);  else threshold = thr[0].
+//     STATS (offline only): also produce the per-sample statistic of x into stat_out (fused, same pass).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f4 fq_code4(f4 v, const QParams& q) {
+  f4 k;
+  k.x = fq_code(v.x, q);
+  k.y = fq_code(v.y, q);
+  k.z = fq_code(v.z, q);
+  k.w = fq_code(v.w, q);
+  return k;
+}
+
+template <bool ONLINE, bool STATS, bool CODES, bool USE_ABS, bool VEC, bool NTL, bool NTS>
+__global__ __launch_bounds__(kBlock) void act_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int32_t* __restrict__ codes, int64_t inner,
+                                                           int chunks_per_sample, int64_t total_chunks,
+                                                           const float* __restrict__ stat_in, int n,
+                                                           const float* __restrict__ thr, float levels,
+                                                           int lo_neg_max, float eps, int reverse,
+                                                           float* __restrict__ stat_out,
+                                                           float* __restrict__ cur_max_out) {
+  __shared__ float red[4];
+  const float max_ = ONLINE ? batch_mean_dev(stat_in, n) : thr[0];
+  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+
+  const ChunkRange rg = block_range(total_chunks);
+  int64_t cur_s = -1;
+  float m = stat_init<USE_ABS>();
+  for (int64_t cc = rg.begin; cc < rg.end; ++cc) {
+    const int64_t c = reverse ? (rg.end - 1 - (cc - rg.begin)) : cc;
+    const int64_t s = c / chunks_per_sample;
+    if (STATS && s != cur_s) {
+      if (cur_s >= 0) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+      }
+      cur_s = s;
+      m = stat_init<USE_ABS>();
+    }
+    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kChunk;
+    const int64_t gbase = s * inner + off0;
+    const int64_t rem = inner - off0;
+    if (VEC) {
+      const f4* p = reinterpret_cast<const f4*>(x + gbase);
+      f4* o = reinterpret_cast<f4*>(y + gbase);
+      i4* oc = CODES ? reinterpret_cast<i4*>(codes + gbase) : nullptr;
+      if (rem >= kChunk) {
+        f4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = ld4<NTL>(p + threadIdx.x + u * kBlock);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          if (STATS) m = fmaxf(m, stat4<USE_ABS>(v[u]));
+          const f4 k = fq_code4(v[u], q);
+          if (CODES) oc[threadIdx.x + u * kBlock] = __builtin_convertvector(k, i4);
+          st4<NTS>(o + threadIdx.x + u * kBlock, k * q.scale);
+        }
+      } else {
+        const int nvec = (int)(rem / kVec);
+        for (int i = threadIdx.x; i < nvec; i += kBlock) {
+          const f4 v = ld4<NTL>(p + i);
+          if (STATS) m = fmaxf(m, stat4<USE_ABS>(v));
+          const f4 k = fq_code4(v, q);
+          if (CODES) oc[i] = __builtin_convertvector(k, i4);
+          st4<NTS>(o + i, k * q.scale);
+        }
+      }
+    } else {
+      const int cnt = (int)(rem < kChunk ? rem : kChunk);
+      for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        const float v = x[gbase + i];
+        if (STATS) m = fmaxf(m, stat_of<USE_ABS>(v));
+        const float k = fq_code(v, q);
+        if (CODES) codes[gbase + i] = (int)k;
+        y[gbase + i] = k * q.scale;
+      }
+    }
+  }
+  if (STATS && cur_s >= 0) {
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3: weights, (rows, row_len).  Small rows: a workgroup stages several whole rows in LDS (one HBM read), reduces
+// each row with a wavefront, then applies from LDS.  Long rows (layer mode): K1 per row + K3b apply.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWTile = 8192;   // floats of LDS staging per workgroup (32 KiB)
+
+__global__ __launch_bounds__(kBlock) void weight_rows_lds_kernel(const float* __restrict__ w,
+                                                                 float* __restrict__ wq, int64_t rows, int row_len,
+                                                                 int rows_per_block, float levels,
+                                                                 float* __restrict__ scales_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;                       // rows_per_block * row_len
+  float* sc = smem + kWTile;                // rows_per_block scales
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int nrows = (int)((rows - r0) < rows_per_block ? (rows - r0) : rows_per_block);
+  const int cnt = nrows * row_len;
+  const float* src = w + r0 * row_len;
+  float* dst = wq + r0 * row_len;
+  const bool vec = ((row_len & 3) == 0) && ((((uintptr_t)src) & 15u) == 0) && ((((uintptr_t)dst) & 15u) == 0);
+  if (vec) {
+    const float4* p = reinterpret_cast<const float4*>(src);
+    float4* t4 = reinterpret_cast<float4*>(tile);
+    for (int i = threadIdx.x; i < cnt / 4; i += kBlock) t4[i] = p[i];
+  } else {
+    for (int i = threadIdx.x; i < cnt; i += kBlock) tile[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < nrows; r += kBlock / 64) {
+    const float* row = tile + r * row_len;
+    float m = 0.0f;
+    for (int i = lane; i < row_len; i += 64) m = fmaxf(m, fabsf(row[i]));
+    m = wave_max(m);
+    if (lane == 0) {
+      const float s = m / levels;
+      sc[r] = s;
+      if (scales_out != nullptr) scales_out[r0 + r] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cnt; i += kBlock) {
+    const int r = i / row_len;
+    const float s = sc[r];
+    dst[i] = roundf(tile[i] / (s + kEps)) * s;
+  }
+}
+
+// K3b: apply with per-row scale = rowmax[r] / levels (rows long enough that a chunk never spans two rows).
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void weight_apply_kernel(const float* __restrict__ w, float* __restrict__ wq,
+                                                              int64_t row_len, int chunks_per_row,
+                                                              int64_t total_chunks, const float* __restrict__ rowmax,
+                                                              float levels, float* __restrict__ scales_out) {
+  for (int64_t c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+    const int64_t r = c / chunks_per_row;
+    const int64_t off0 = (c - r * chunks_per_row) * (int64_t)kChunk;
+    const int64_t gbase = r * row_len + off0;
+    const int64_t rem = row_len - off0;
+    const float s = rowmax[r] / levels;
+    const float d = s + kEps;
+    if (scales_out != nullptr && off0 == 0 && threadIdx.x == 0) scales_out[r] = s;
+    const int cnt = (int)(rem < kChunk ? rem : kChunk);
+    if (VEC) {
+      const float4* p = reinterpret_cast<const float4*>(w + gbase);
+      float4* o = reinterpret_cast<float4*>(wq + gbase);
+      for (int i = threadIdx.x; i < cnt / 4; i += kBlock) {
+        float4 v = p[i];
+        o[i] = make_float4(roundf(v.x / d) * s, roundf(v.y / d) * s, roundf(v.z / d) * s, roundf(v.w / d) * s);
+      }
+    } else {
+      for (int i = threadIdx.x; i < cnt; i += kBlock) wq[gbase + i] = roundf(w[gbase + i] / d) * s;
+    }
+  }
+}
+
+// K3c: generic STE (per-row device scale, optional clip)
+__global__ __launch_bounds__(kBlock) void ste_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     int64_t numel, int64_t row_len,
+                                                     const float* __restrict__ scales, int has_clip, float lo,
+                                                     float hi, float eps) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
+    const float s = scales[i / row_len];
+    float v = x[i];
+    if (has_clip) v = fminf(fmaxf(v, lo), hi);
+    y[i] = roundf(v / (s + eps)) * s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K4: Winograd-domain per-out-channel weight fake-quant.  One workgroup per output channel; each thread owns
+// (ci) filters: U = G g G^T in registers (k-sequential, multiply and add separately rounded — oracle order).
+// ---------------------------------------------------------------------------------------------------------------
+struct WinoMats {
+  float G[8 * 3];     // t x 3
+  float GI[3 * 8];    // 3 x t
+  float GTI[8 * 3];   // t x 3
+};
+
+template <int T>
+__device__ __forceinline__ void wino_forward(const float* __restrict__ g9, const WinoMats& M, float (&U)[T][T]) {
+  float t1[T][3];
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float acc = M.G[a * 3 + 0] * g9[0 * 3 + j];
+      acc = acc + M.G[a * 3 + 1] * g9[1 * 3 + j];
+      acc = acc + M.G[a * 3 + 2] * g9[2 * 3 + j];
+      t1[a][j] = acc;
+    }
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b) {
+      float acc = t1[a][0] * M.G[b * 3 + 0];     // G^T[k][b] = G[b][k]
+      acc = acc + t1[a][1] * M.G[b * 3 + 1];
+      acc = acc + t1[a][2] * M.G[b * 3 + 2];
+      U[a][b] = acc;
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ wq,
+                                                             int cin_g, WinoMats M, float levels,
+                                                             float* __restrict__ scales_out) {
+  __shared__ float red[4];
+  __shared__ float s_scale;
+  const int co = blockIdx.x;
+  const float* wc = w + (int64_t)co * cin_g * 9;
+  float* oc = wq + (int64_t)co * cin_g * 9;
+  float m = 0.0f;
+  for (int ci = threadIdx.x; ci < cin_g; ci += kBlock) {
+    float g9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g9[k] = wc[ci * 9 + k];
+    float U[T][T];
+    wino_forward<T>(g9, M, U);
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+      for (int b = 0; b < T; ++b) m = fmaxf(m, fabsf(U[a][b]));
+  }
+  m = block_max(m, red);
+  if (threadIdx.x == 0) {
+    s_scale = m / levels;
+    if (scales_out != nullptr) scales_out[co] = s_scale;
+  }
+  __syncthreads();
+  const float s = s_scale;
+  const float d = s + kEps;
+  for (int ci = threadIdx.x; ci < cin_g; ci += kBlock) {
+    float g9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g9[k] = wc[ci * 9 + k];
+    float U[T][T];
+    wino_forward<T>(g9, M, U);
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+      for (int b = 0; b < T; ++b) U[a][b] = roundf(U[a][b] / d) * s;
+    // back: t2 = GI (3 x T) . Uq (T x T);  g = t2 (3 x T) . GTI (T x 3)
+    float t2[3][T];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int b = 0; b < T; ++b) {
+        float acc = M.GI[i * T + 0] * U[0][b];
+#pragma unroll
+        for (int a = 1; a < T; ++a) acc = acc + M.GI[i * T + a] * U[a][b];
+        t2[i][b] = acc;
+      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float acc = t2[i][0] * M.GTI[0 * 3 + j];
+#pragma unroll
+        for (int b = 1; b < T; ++b) acc = acc + t2[i][b] * M.GTI[b * 3 + j];
+        oc[ci * 9 + i * 3 + j] = acc;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5: EMA of L scalars
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void ema_kernel(float* __restrict__ state, const float* __restrict__ cur, int64_t n, float one_minus_m,
+                           float m) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float a = one_minus_m * cur[i];
+    const float b = state[i] * m;
+    state[i] = a + b;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6: global max / min-max (flat)
+// ---------------------------------------------------------------------------------------------------------------
+template <bool WANT_MIN, bool USE_ABS>
+__global__ __launch_bounds__(kBlock) void minmax_kernel(const float* __restrict__ x, int64_t numel, int vec_ok,
+                                                        float* __restrict__ out_min, float* __restrict__ out_max) {
+  __shared__ float red[4];
+  float mx = USE_ABS ? 0.0f : -INFINITY, mn = INFINITY;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  if (vec_ok) {
+    const float4* p = reinterpret_cast<const float4*>(x);
+    const int64_t nvec = numel / 4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+      float4 v = p[i];
+      mx = fmaxf(mx, fmaxf(fmaxf(stat_of<USE_ABS>(v.x), stat_of<USE_ABS>(v.y)),
+                           fmaxf(stat_of<USE_ABS>(v.z), stat_of<USE_ABS>(v.w))));
+      if (WANT_MIN) mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+    }
+    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
+      mx = fmaxf(mx, stat_of<USE_ABS>(x[i]));
+      if (WANT_MIN) mn = fminf(mn, x[i]);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
+      mx = fmaxf(mx, stat_of<USE_ABS>(x[i]));
+      if (WANT_MIN) mn = fminf(mn, x[i]);
+    }
+  }
+  mx = block_max(mx, red);
+  if (threadIdx.x == 0) atomic_max_f32(out_max, mx);
+  if (WANT_MIN) {
+    mn = block_min(mn, red);
+    if (threadIdx.x == 0) atomic_min_f32(out_min, mn);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K7: 2048-bin histogram, LDS-privatised (one copy per wavefront), zeros skipped, exact uint64 accumulation.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void histogram_kernel(const float* __restrict__ x, int64_t numel, int vec_ok,
+                                                           const float* __restrict__ max_dev, int bins,
+                                                           unsigned long long* __restrict__ hist,
+                                                           unsigned int* __restrict__ neg_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int lh[];      // 4 * bins
+  for (int i = threadIdx.x; i < 4 * bins; i += kBlock) lh[i] = 0u;
+  __syncthreads();
+  unsigned int* mine = lh + (threadIdx.x >> 6) * bins;
+  const float mx = max_dev[0];
+  const float scales = (float)bins / (mx + 1e-5f);                       // distribution_calibrate.py:41
+  unsigned int neg = 0;
+  auto put = [&](float v) {
+    neg += (v < 0.0f) ? 1u : 0u;
+    const float c = fminf(fmaxf(v, 0.0f), mx);                           // :39
+    if (c != 0.0f) {                                                     // :40
+      int idx = (int)(c * scales);                                       // :42 (truncation)
+      idx = idx < bins ? idx : bins - 1;
+      atomicAdd(&mine[idx], 1u);
+    }
+  };
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  if (vec_ok) {
+    const float4* p = reinterpret_cast<const float4*>(x);
+    const int64_t nvec = numel / 4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+      float4 v = p[i];
+      put(v.x);
+      put(v.y);
+      put(v.z);
+      put(v.w);
+    }
+    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) put(x[i]);
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) put(x[i]);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += kBlock) {
+    const unsigned int c = lh[b] + lh[bins + b] + lh[2 * bins + b] + lh[3 * bins + b];
+    if (c) atomicAdd(&hist[b], (unsigned long long)c);
+  }
+  if (neg_count != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) neg += __shfl_xor(neg, off, 64);
+    if ((threadIdx.x & 63) == 0 && neg) atomicAdd(neg_count, neg);
+  }
+}
+
+__global__ void hist_to_float_kernel(const unsigned long long* __restrict__ h, float* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)h[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K8: KL threshold search.  One THREAD per candidate bin count i, every sum in the reference's own order and
+// precision (distribution_calibrate.py:136-171); the `levels` merged bins of each candidate live in LDS,
+// laid out [level][lane] so a wavefront's accesses are conflict-free.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kKlBlock = 64;
+
+__global__ __launch_bounds__(kKlBlock) void kl_divergence_kernel(const float* __restrict__ hist, int bins,
+                                                                 int levels, int min_bins,
+                                                                 double* __restrict__ div_out) {
+  extern __shared__ __attribute__((aligned(16))) double q[];             // levels * kKlBlock
+  const int layer = blockIdx.y;
+  const int i = min_bins + blockIdx.x * kKlBlock + threadIdx.x;
+  const float* __restrict__ d = hist + (int64_t)layer * bins;
+  double* out = div_out + (int64_t)layer * bins;
+  if (i >= bins) return;
+  const int tid = threadIdx.x;
+  // P (fp32): tail mass folded into bin i-1, sequential sums (python `sum` over an fp32 array)
+  float tail = 0.0f;
+  for (int j = i; j < bins; ++j) tail = tail + d[j];
+  const float plast = d[i - 1] + tail;
+  float s = 0.0f;
+  for (int j = 0; j < i - 1; ++j) s = s + d[j];
+  s = s + plast;
+  // Q: merge i bins into `levels` (fp64 accumulate in j order)
+  for (int l = 0; l < levels; ++l) q[l * kKlBlock + tid] = 0.0;
+  const double di = (double)i;
+  for (int j = 0; j < i; ++j) {
+    const int fl = (int)((double)((long long)j * levels) / di);
+    q[fl * kKlBlock + tid] += (double)d[j];
+  }
+  // expand with linear interpolation, mask where P == 0, sequential fp64 sum
+  double qs = 0.0;
+  for (int j = 0; j < i; ++j) {
+    const double b = (double)((long long)j * levels) / di;
+    const int fl = (int)b;
+    int ce = (int)ceil(b);
+    ce = ce > levels - 1 ? levels - 1 : ce;
+    const double qf = q[fl * kKlBlock + tid];
+    double qe = (q[ce * kKlBlock + tid] - qf) * (b - (double)fl) + qf;
+    const float pj = ((j == i - 1) ? plast : d[j]) / s;
+    qe = qe * ((pj != 0.0f) ? 1.0 : 0.0);
+    qs = qs + qe;
+  }
+  double div = 0.0;
+  for (int j = 0; j < i; ++j) {
+    const double b = (double)((long long)j * levels) / di;
+    const int fl = (int)b;
+    int ce = (int)ceil(b);
+    ce = ce > levels - 1 ? levels - 1 : ce;
+    const double qf = q[fl * kKlBlock + tid];
+    double qe = (q[ce * kKlBlock + tid] - qf) * (b - (double)fl) + qf;
+    const float pj = ((j == i - 1) ? plast : d[j]) / s;
+    qe = qe * ((pj != 0.0f) ? 1.0 : 0.0);
+    qe = qe / qs;
+    if (qe != 0.0) div = div + (double)pj * log((double)pj / qe);
+  }
+  out[i] = div;
+}
+
+__global__ void kl_argmin_kernel(const double* __restrict__ div, int bins, int min_bins, int32_t* __restrict__ best) {
+  const int layer = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const double* dv = div + (int64_t)layer * bins;
+  double m = INFINITY;
+  int b = min_bins;
+  for (int i = min_bins; i < bins; ++i)
+    if (dv[i] < m) {          // strict: first minimum wins; NaN never selected (:167-169)
+      m = dv[i];
+      b = i;
+    }
+  best[layer] = b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K9: int-code quantise / dequantise
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void codes_range_kernel(float* __restrict__ range, int mode, const float* __restrict__ ws) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float mn, mx;
+  if (mode == FQ_CODES_INT8) {
+    mx = ws[1];
+    mn = -mx;
+  } else if (mode == FQ_CODES_UINT8) {
+    mn = ws[0];
+    mx = ws[1];
+  } else {
+    mn = range[0];
+    mx = range[1];
+  }
+  range[0] = mn;
+  range[1] = mx;
+  if (mode != FQ_CODES_SCALE) range[2] = (mx == -mn) ? (mx / 127.0f) : ((mx - mn) / 255.0f);
+}
+
+__global__ __launch_bounds__(kBlock) void quantize_codes_kernel(const float* __restrict__ x,
+                                                                int32_t* __restrict__ codes, int64_t numel,
+                                                                const float* __restrict__ range) {
+  const float mn = range[0], mx = range[1], sc = range[2];
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
+    const float c = fminf(fmaxf(x[i], mn), mx);
+    codes[i] = (int32_t)roundf(c / sc);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void dequantize_kernel(const int32_t* __restrict__ codes, float* __restrict__ y,
+                                                            int64_t numel, const float* __restrict__ scale) {
+  const float sc = scale[0];
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) y[i] = (float)codes[i] * sc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ---------------------------------------------------------------------------------------------------------------
+struct Chunking {
+  int chunks_per_sample;
+  int64_t total;
+};
+inline Chunking chunking(int64_t n, int64_t inner) {
+  Chunking c;
+  c.chunks_per_sample = (int)((inner + kChunk - 1) / kChunk);
+  c.total = n * c.chunks_per_sample;
+  return c;
+}
+
+// Streaming policy.  Defaults chosen from measurements on MI355X (profiles/); FQ_POLICY_STAT /
+// FQ_POLICY_ONLINE / FQ_POLICY_OFFLINE (integers, OR of the kPol* bits) override them for tuning runs.
+int env_policy(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+int policy_stat() {
+  static int p = env_policy("FQ_POLICY_STAT", 0);
+  return p;
+}
+int policy_online() {
+  static int p = env_policy("FQ_POLICY_ONLINE", kPolReverse | kPolNtLoad | kPolNtStore);
+  return p;
+}
+int policy_offline() {
+  static int p = env_policy("FQ_POLICY_OFFLINE", kPolNtLoad | kPolNtStore);
+  return p;
+}
+
+int launch_absmax(const float* x, int64_t n, int64_t inner, bool use_abs, float* out, hipStream_t st) {
+  // caller has initialised `out` (0 for |x|, -inf otherwise)
+  const Chunking ck = chunking(n, inner);
+  const bool vec = (inner % kVec == 0) && aligned16(x);
+  const int grid = grid_for(ck.total);
+  const bool ntl = (policy_stat() & kPolNtLoad) != 0;
+#define FQ_ABSMAX(A, V, L)                                                                                    \
+  hipLaunchKernelGGL((absmax_per_sample_kernel<A, V, L>), dim3(grid), dim3(kBlock), 0, st, x, inner,          \
+                     ck.chunks_per_sample, ck.total, out)
+  if (use_abs) {
+    if (vec) {
+      if (ntl) FQ_ABSMAX(true, true, true); else FQ_ABSMAX(true, true, false);
+    } else {
+      FQ_ABSMAX(true, false, false);
+    }
+  } else {
+    if (vec) FQ_ABSMAX(false, true, false); else FQ_ABSMAX(false, false, false);
+  }
+#undef FQ_ABSMAX
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int init_stat(float* p, int64_t n, bool use_abs, hipStream_t st) {
+  if (use_abs) {
+    FQ_HIP(hipMemsetAsync(p, 0, n * sizeof(float), st));
+  } else {
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, -INFINITY);
+    FQ_LAUNCH_CHECK();
+  }
+  return FQ_OK;
+}
+
+template <bool ONLINE, bool STATS, bool CODES>
+int launch_apply(const float* x, float* y, int32_t* codes, int64_t n, int64_t inner, const float* stat_in,
+                 const float* thr, float levels, unsigned flags, float* stat_out, float* cur_out, hipStream_t st) {
+  const Chunking ck = chunking(n, inner);
+  const bool vec = (inner % kVec == 0) && aligned16(x) && aligned16(y) && (!CODES || aligned16(codes));
+  const bool use_abs = !(flags & FQ_ACT_NO_ABS);
+  const int grid = grid_for(ck.total);
+  const int lo_neg = (flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+  const float eps = (flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+  int pol = ONLINE ? policy_online() : policy_offline();
+  if (x == y) pol &= ~kPolNtLoad;
+  const int reverse = (pol & kPolReverse) ? 1 : 0;
+#define FQ_APPLY(A, V, L, S)                                                                                     \
+  hipLaunchKernelGGL((act_apply_kernel<ONLINE, STATS, CODES, A, V, L, S>), dim3(grid), dim3(kBlock), 0, st, x,   \
+                     y, codes, inner, ck.chunks_per_sample, ck.total, stat_in, (int)n, thr, levels, lo_neg, eps, \
+                     reverse, stat_out, cur_out)
+  if (use_abs && vec && !CODES) {
+    switch (pol & (kPolNtLoad | kPolNtStore)) {
+      case 0: FQ_APPLY(true, true, false, false); break;
+      case kPolNtLoad: FQ_APPLY(true, true, true, false); break;
+      case kPolNtStore: FQ_APPLY(true, true, false, true); break;
+      default: FQ_APPLY(true, true, true, true); break;
+    }
+  } else if (use_abs) {
+    if (vec) FQ_APPLY(true, true, false, false); else FQ_APPLY(true, false, false, false);
+  } else {
+    if (vec) FQ_APPLY(false, true, false, false); else FQ_APPLY(false, false, false, false);
+  }
+#undef FQ_APPLY
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+inline float act_levels(int width, unsigned flags) {
+  return (flags & FQ_ACT_SIGNED) ? (float)((1 << (width - 1)) - 1) : (float)((1 << width) - 1);
+}
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+const char* fq_last_error(void) { return g_err; }
+int fq_version(void) { return 100; }
+
+int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront) {
+  int dev = 0;
+  FQ_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  FQ_HIP(hipGetDeviceProperties(&prop, dev));
+  if (arch != nullptr && arch_len > 0) {
+    strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (wavefront) *wavefront = prop.warpSize;
+  return FQ_OK;
+}
+
+size_t fq_act_workspace_bytes(int64_t n) { return (size_t)(n < 1 ? 1 : n) * sizeof(float) * 2 + 64; }
+
+int fq_absmax_per_sample(const float* x, int64_t n, int64_t inner, unsigned flags, float* out_max,
+                         fqStream_t stream) {
+  FQ_REQUIRE(x && out_max, "fq_absmax_per_sample: null pointer");
+  FQ_REQUIRE(n > 0 && inner > 0, "fq_absmax_per_sample: empty tensor (n=%lld inner=%lld)", (long long)n,
+             (long long)inner);
+  hipStream_t st = (hipStream_t)stream;
+  const bool use_abs = !(flags & FQ_ACT_NO_ABS);
+  if (int rc = init_stat(out_max, n, use_abs, st)) return rc;
+  return launch_absmax(x, n, inner, use_abs, out_max, st);
+}
+
+int fq_batch_mean(const float* v, int64_t n, float* out, fqStream_t stream) {
+  FQ_REQUIRE(v && out, "fq_batch_mean: null pointer");
+  FQ_REQUIRE(n > 0 && n < (1ll << 31), "fq_batch_mean: bad n=%lld", (long long)n);
+  hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, v, (int)n, out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_fake_quant_online(const float* x, float* y, int64_t n, int64_t inner, int width, unsigned flags,
+                         float* out_current_max, int32_t* codes, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(x && y && ws, "fq_fake_quant_online: null pointer");
+  FQ_REQUIRE(n > 0 && inner > 0 && n < (1ll << 31), "fq_fake_quant_online: bad shape (n=%lld inner=%lld)",
+             (long long)n, (long long)inner);
+  FQ_REQUIRE(width >= 2 && width <= 16, "fq_fake_quant_online: width %d out of range", width);
+  hipStream_t st = (hipStream_t)stream;
+  float* stat = (float*)ws;
+  const bool use_abs = !(flags & FQ_ACT_NO_ABS);
+  if (int rc = init_stat(stat, n, use_abs, st)) return rc;
+  if (int rc = launch_absmax(x, n, inner, use_abs, stat, st)) return rc;
+  const float levels = act_levels(width, flags);
+  if (codes)
+    return launch_apply<true, false, true>(x, y, codes, n, inner, stat, nullptr, levels, flags, nullptr,
+                                           out_current_max, st);
+  return launch_apply<true, false, false>(x, y, nullptr, n, inner, stat, nullptr, levels, flags, nullptr,
+                                          out_current_max, st);
+}
+
+int fq_fake_quant_offline(const float* x, float* y, int64_t n, int64_t inner, const float* threshold, int width,
+                          unsigned flags, float* out_current_max, int32_t* codes, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(x && y && threshold, "fq_fake_quant_offline: null pointer");
+  FQ_REQUIRE(n > 0 && inner > 0 && n < (1ll << 31), "fq_fake_quant_offline: bad shape (n=%lld inner=%lld)",
+             (long long)n, (long long)inner);
+  FQ_REQUIRE(width >= 2 && width <= 16, "fq_fake_quant_offline: width %d out of range", width);
+  hipStream_t st = (hipStream_t)stream;
+  const float levels = act_levels(width, flags);
+  if (out_current_max == nullptr) {
+    if (codes)
+      return launch_apply<false, false, true>(x, y, codes, n, inner, nullptr, threshold, levels, flags, nullptr,
+                                              nullptr, st);
+    return launch_apply<false, false, false>(x, y, nullptr, n, inner, nullptr, threshold, levels, flags, nullptr,
+                                             nullptr, st);
+  }
+  FQ_REQUIRE(ws, "fq_fake_quant_offline: workspace required when out_current_max is requested");
+  float* stat = (float*)ws;
+  const bool use_abs = !(flags & FQ_ACT_NO_ABS);
+  if (int rc = init_stat(stat, n, use_abs, st)) return rc;
+  int rc;
+  if (codes)
+    rc = launch_apply<false, true, true>(x, y, codes, n, inner, nullptr, threshold, levels, flags, stat, nullptr, st);
+  else
+    rc = launch_apply<false, true, false>(x, y, nullptr, n, inner, nullptr, threshold, levels, flags, stat, nullptr,
+                                          st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, st, stat, (int)n, out_current_max);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_ste_forward(const float* x, float* y, int64_t rows, int64_t row_len, const float* scales, int has_clip,
+                   float clip_lo, float clip_hi, float eps, fqStream_t stream) {
+  FQ_REQUIRE(x && y && scales, "fq_ste_forward: null pointer");
+  FQ_REQUIRE(rows > 0 && row_len > 0, "fq_ste_forward: empty tensor");
+  const int64_t numel = rows * row_len;
+  const int grid = grid_for((numel + kBlock * 4 - 1) / (kBlock * 4));
+  hipLaunchKernelGGL(ste_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, x, y, numel, row_len, scales,
+                     has_clip, clip_lo, clip_hi, eps);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+size_t fq_weight_workspace_bytes(int64_t rows) { return (size_t)(rows < 1 ? 1 : rows) * sizeof(float) + 64; }
+
+int fq_weight_fake_quant(const float* w, float* w_q, int64_t rows, int64_t row_len, int width, float* scales_out,
+                         void* ws, fqStream_t stream) {
+  FQ_REQUIRE(w && w_q, "fq_weight_fake_quant: null pointer");
+  FQ_REQUIRE(rows > 0 && row_len > 0, "fq_weight_fake_quant: empty tensor (rows=%lld row_len=%lld)",
+             (long long)rows, (long long)row_len);
+  FQ_REQUIRE(width >= 2 && width <= 16, "fq_weight_fake_quant: width %d out of range", width);
+  hipStream_t st = (hipStream_t)stream;
+  const float levels = (float)((1 << (width - 1)) - 1);
+  if (row_len <= kWTile) {
+    int rpb = (int)(kWTile / row_len);
+    if (rpb > 1024) rpb = 1024;
+    // keep >= ~2 workgroups per CU busy when there are many short rows
+    const int64_t want_blocks = (int64_t)num_cu() * 2;
+    int64_t balanced = (rows + want_blocks - 1) / want_blocks;
+    if (balanced < 1) balanced = 1;
+    if (rpb > balanced) rpb = (int)balanced;
+    const int64_t blocks = (rows + rpb - 1) / rpb;
+    const size_t lds = (size_t)(kWTile + 1024) * sizeof(float);
+    hipLaunchKernelGGL(weight_rows_lds_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, st, w, w_q, rows,
+                       (int)row_len, rpb, levels, scales_out);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+  }
+  FQ_REQUIRE(ws, "fq_weight_fake_quant: workspace required for rows longer than %d", kWTile);
+  float* rowmax = (float*)ws;
+  FQ_HIP(hipMemsetAsync(rowmax, 0, rows * sizeof(float), st));
+  if (int rc = launch_absmax(w, rows, row_len, true, rowmax, st)) return rc;
+  const Chunking ck = chunking(rows, row_len);
+  const bool vec = (row_len % kVec == 0) && aligned16(w) && aligned16(w_q);
+  const int grid = grid_for(ck.total);
+  if (vec)
+    hipLaunchKernelGGL((weight_apply_kernel<true>), dim3(grid), dim3(kBlock), 0, st, w, w_q, row_len,
+                       ck.chunks_per_sample, ck.total, rowmax, levels, scales_out);
+  else
+    hipLaunchKernelGGL((weight_apply_kernel<false>), dim3(grid), dim3(kBlock), 0, st, w, w_q, row_len,
+                       ck.chunks_per_sample, ck.total, rowmax, levels, scales_out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_wino_weight_fake_quant(const float* w, float* w_q, int64_t cout, int64_t cin_g, int t, const float* G,
+                              const float* GI, const float* GTI, int width, float* scales_out, void* ws,
+                              fqStream_t stream) {
+  (void)ws;
+  FQ_REQUIRE(w && w_q && G && GI && GTI, "fq_wino_weight_fake_quant: null pointer");
+  FQ_REQUIRE(t == 4 || t == 6 || t == 8, "fq_wino_weight_fake_quant: t must be 4 (F23), 6 (F43) or 8 (F63), got %d", t);
+  FQ_REQUIRE(cout > 0 && cin_g > 0 && cin_g < (1ll << 28), "fq_wino_weight_fake_quant: bad shape");
+  FQ_REQUIRE(width >= 2 && width <= 16, "fq_wino_weight_fake_quant: width %d out of range", width);
+  WinoMats M;
+  memset(&M, 0, sizeof(M));
+  memcpy(M.G, G, sizeof(float) * t * 3);
+  memcpy(M.GI, GI, sizeof(float) * 3 * t);
+  memcpy(M.GTI, GTI, sizeof(float) * t * 3);
+  const float levels = (float)((1 << (width - 1)) - 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (t == 4)
+    hipLaunchKernelGGL((wino_weight_kernel<4>), dim3((unsigned)cout), dim3(kBlock), 0, st, w, w_q, (int)cin_g, M,
+                       levels, scales_out);
+  else if (t == 6)
+    hipLaunchKernelGGL((wino_weight_kernel<6>), dim3((unsigned)cout), dim3(kBlock), 0, st, w, w_q, (int)cin_g, M,
+                       levels, scales_out);
+  else
+    hipLaunchKernelGGL((wino_weight_kernel<8>), dim3((unsigned)cout), dim3(kBlock), 0, st, w, w_q, (int)cin_g, M,
+                       levels, scales_out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_ema_update(float* state, const float* current, int64_t count, double momentum, fqStream_t stream) {
+  FQ_REQUIRE(state && current, "fq_ema_update: null pointer");
+  FQ_REQUIRE(count > 0, "fq_ema_update: count must be positive");
+  // (1 - momentum) is formed in double like the python expression `(1 - momentum)` (convert.py:70), then cast
+  // (momentum arrives as a double for that reason: 1 - 0.9f != fp32(1 - 0.9))
+  const float omm = (float)(1.0 - momentum);
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, state,
+                     current, count, omm, (float)momentum);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_global_max(const float* x, int64_t numel, float* out, fqStream_t stream) {
+  FQ_REQUIRE(x && out, "fq_global_max: null pointer");
+  FQ_REQUIRE(numel > 0, "fq_global_max: empty tensor");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, out, (int64_t)1, -INFINITY);
+  const int grid = grid_for((numel + kChunk - 1) / kChunk);
+  hipLaunchKernelGGL((minmax_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, x, numel,
+                     aligned16(x) ? 1 : 0, (float*)nullptr, out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_histogram_accumulate(const float* x, int64_t numel, const float* max_dev, int bins, uint64_t* hist,
+                            uint32_t* neg_count, fqStream_t stream) {
+  FQ_REQUIRE(x && max_dev && hist, "fq_histogram_accumulate: null pointer");
+  FQ_REQUIRE(numel > 0, "fq_histogram_accumulate: empty tensor");
+  FQ_REQUIRE(bins > 0 && bins <= 8192, "fq_histogram_accumulate: bins=%d out of range (1..8192)", bins);
+  const int grid = grid_for((numel + kChunk - 1) / kChunk);
+  hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(kBlock), (size_t)4 * bins * sizeof(unsigned int),
+                     (hipStream_t)stream, x, numel, aligned16(x) ? 1 : 0, max_dev, bins,
+                     (unsigned long long*)hist, (unsigned int*)neg_count);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_hist_to_float(const uint64_t* hist, float* out, int64_t count, fqStream_t stream) {
+  FQ_REQUIRE(hist && out && count > 0, "fq_hist_to_float: bad arguments");
+  hipLaunchKernelGGL(hist_to_float_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const unsigned long long*)hist, out, count);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+size_t fq_kl_workspace_bytes(int64_t L, int bins) { return (size_t)L * (size_t)bins * sizeof(double) + 64; }
+
+int fq_kl_search(const float* hist, int64_t L, int bins, int levels, int min_bins, int32_t* out_best, void* ws,
+                 fqStream_t stream) {
+  FQ_REQUIRE(hist && out_best && ws, "fq_kl_search: null pointer");
+  FQ_REQUIRE(L > 0 && L < 65536, "fq_kl_search: L=%lld out of range", (long long)L);
+  FQ_REQUIRE(min_bins >= levels, "min_bins should be greater than levels (%d vs. %d)", min_bins, levels);
+  FQ_REQUIRE(levels >= 2 && (size_t)levels * kKlBlock * sizeof(double) <= 160 * 1024,
+             "fq_kl_search: levels=%d does not fit the LDS staging (max %d)", levels,
+             (int)(160 * 1024 / (kKlBlock * sizeof(double))));
+  FQ_REQUIRE(bins > min_bins, "fq_kl_search: bins (%d) must exceed min_bins (%d)", bins, min_bins);
+  hipStream_t st = (hipStream_t)stream;
+  double* div = (double*)ws;
+  const size_t lds = (size_t)levels * kKlBlock * sizeof(double);
+  if (lds > 64 * 1024)
+    FQ_HIP(hipFuncSetAttribute((const void*)kl_divergence_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  const int cands = bins - min_bins;
+  dim3 grid((unsigned)((cands + kKlBlock - 1) / kKlBlock), (unsigned)L);
+  hipLaunchKernelGGL(kl_divergence_kernel, grid, dim3(kKlBlock), lds, st, hist, bins, levels, min_bins, div);
+  FQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kl_argmin_kernel, dim3((unsigned)L), dim3(64), 0, st, div, bins, min_bins, out_best);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_quantize_codes(const float* x, int32_t* codes, int64_t numel, int mode, float* range_dev, void* ws,
+                      fqStream_t stream) {
+  FQ_REQUIRE(x && codes && range_dev, "fq_quantize_codes: null pointer");
+  FQ_REQUIRE(numel > 0, "fq_quantize_codes: empty tensor");
+  FQ_REQUIRE(mode >= FQ_CODES_INT8 && mode <= FQ_CODES_SCALE, "unknown out type: %d", mode);
+  hipStream_t st = (hipStream_t)stream;
+  float* mm = (float*)ws;   // {min, max}
+  const int grid = grid_for((numel + kChunk - 1) / kChunk);
+  if (mode == FQ_CODES_INT8 || mode == FQ_CODES_UINT8) {
+    FQ_REQUIRE(ws, "fq_quantize_codes: workspace required");
+    hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, mm, (int64_t)1, INFINITY);
+    hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, mm + 1, (int64_t)1,
+                       mode == FQ_CODES_INT8 ? 0.0f : -INFINITY);
+    if (mode == FQ_CODES_INT8)
+      hipLaunchKernelGGL((minmax_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, x, numel,
+                         aligned16(x) ? 1 : 0, mm, mm + 1);
+    else
+      hipLaunchKernelGGL((minmax_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, x, numel,
+                         aligned16(x) ? 1 : 0, mm, mm + 1);
+    FQ_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(codes_range_kernel, dim3(1), dim3(64), 0, st, range_dev, mode, mm);
+  hipLaunchKernelGGL(quantize_codes_kernel, dim3(grid), dim3(kBlock), 0, st, x, codes, numel, range_dev);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_dequantize(const int32_t* codes, float* y, int64_t numel, const float* scale_dev, fqStream_t stream) {
+  FQ_REQUIRE(codes && y && scale_dev, "fq_dequantize: null pointer");
+  FQ_REQUIRE(numel > 0, "fq_dequantize: empty tensor");
+  const int grid = grid_for((numel + kChunk - 1) / kChunk);
+  hipLaunchKernelGGL(dequantize_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, codes, y, numel,
+                     scale_dev);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+}  // extern "C"

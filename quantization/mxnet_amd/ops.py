@@ -1,0 +1,282 @@
+"""Python entry points over the C ABI: raw device pointers of torch-ROCm tensors + torch's current HIP stream.
+
+Each function names the reference op chain it stands in for.  Inputs must be fp32, contiguous and resident on a
+HIP device; anything else raises (there is deliberately no CPU path here — the oracle under oracle/ is test
+infrastructure and is never imported by this package).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check_call, FakeQuantError
+
+__all__ = ["ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+           "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
+           "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
+
+_WS = {}
+
+
+def _lib_():
+    return _lib.LIB
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _check(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch tensor (got %s)" % (name, type(t)))
+    if not t.is_cuda:
+        raise FakeQuantError("%s lives on %s: the fake-quant path runs on a HIP device only (no CPU fallback)"
+                             % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _workspace(dev, nbytes):
+    """Stream-ordered scratch: one growing buffer per (device, stream)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=dev)
+        _WS[key] = buf
+    return buf
+
+
+def device_info():
+    arch = ctypes.create_string_buffer(64)
+    cu, wf = ctypes.c_int(0), ctypes.c_int(0)
+    check_call(_lib_().fq_device_info(arch, 64, ctypes.byref(cu), ctypes.byref(wf)))
+    return {"arch": arch.value.decode(), "compute_units": cu.value, "wavefront": wf.value}
+
+
+def act_flags(signed=False, lo_neg_max=None, no_abs=False, no_eps=False):
+    """`lo_neg_max` defaults to `signed` (conv: convert_conv2d.py:59-63); Dense passes False (convert_dense.py:49)."""
+    if lo_neg_max is None:
+        lo_neg_max = signed
+    f = 0
+    if signed:
+        f |= _lib.FQ_ACT_SIGNED
+    if lo_neg_max:
+        f |= _lib.FQ_ACT_LO_NEG_MAX
+    if no_abs:
+        f |= _lib.FQ_ACT_NO_ABS
+    if no_eps:
+        f |= _lib.FQ_ACT_NO_EPS
+    return f
+
+
+def _n_inner(x):
+    if x.dim() < 1 or x.numel() == 0:
+        raise ValueError("empty activation tensor %s" % (tuple(x.shape),))
+    n = x.shape[0]
+    return n, x.numel() // n
+
+
+def absmax_per_sample(x, no_abs=False):
+    """`F.max(F.abs(x), axis=(1,2,3))` (convert_conv2d.py:56) -> (N,) device tensor."""
+    _check(x, "x")
+    n, inner = _n_inner(x)
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    check_call(_lib_().fq_absmax_per_sample(_ptr(x), n, inner, act_flags(no_abs=no_abs), _ptr(out), _stream(x)))
+    return out
+
+
+def batch_mean(v):
+    """`.mean()` of the per-sample maxima (convert_conv2d.py:56) -> (1,) device tensor."""
+    _check(v, "v")
+    out = torch.empty(1, dtype=torch.float32, device=v.device)
+    check_call(_lib_().fq_batch_mean(_ptr(v), v.numel(), _ptr(out), _stream(v)))
+    return out
+
+
+def fake_quant_online(x, width=8, flags=0, out=None, cur_out=None, want_codes=False):
+    """convert_conv2d.py:56-66 + ste_func.py:41, threshold = this batch's statistic.
+    Returns (y, current_max (1,) device tensor, codes or None)."""
+    _check(x, "x")
+    n, inner = _n_inner(x)
+    y = torch.empty_like(x) if out is None else _check(out, "out")
+    cur = torch.empty(1, dtype=torch.float32, device=x.device) if cur_out is None else _check(cur_out, "cur_out")
+    codes = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_codes else None
+    ws = _workspace(x.device, _lib_().fq_act_workspace_bytes(n))
+    check_call(_lib_().fq_fake_quant_online(_ptr(x), _ptr(y), n, inner, int(width), int(flags), _ptr(cur),
+                                            _ptr(codes), _ptr(ws), _stream(x)))
+    return y, cur, codes
+
+
+def fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, want_stat=True, want_codes=False):
+    """Same arithmetic with the stored threshold `input_max` (convert_conv2d.py:58).  `want_stat` also yields the
+    batch statistic the reference computes in every mode (:56), fused into the same pass."""
+    _check(x, "x")
+    _check(threshold, "threshold")
+    n, inner = _n_inner(x)
+    y = torch.empty_like(x) if out is None else _check(out, "out")
+    cur = None
+    if want_stat:
+        cur = torch.empty(1, dtype=torch.float32, device=x.device) if cur_out is None else _check(cur_out, "cur_out")
+    codes = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_codes else None
+    ws = _workspace(x.device, _lib_().fq_act_workspace_bytes(n))
+    check_call(_lib_().fq_fake_quant_offline(_ptr(x), _ptr(y), n, inner, _ptr(threshold), int(width), int(flags),
+                                             _ptr(cur), _ptr(codes), _ptr(ws), _stream(x)))
+    return y, cur, codes
+
+
+def ste_forward(x, scales, clip_max=None, clip_min=None, eps=1e-10, out=None):
+    """Generic `LinearQuantizeSTE.forward` (ste_func.py:37-41): `scales` is a device tensor with one scale per
+    leading row of x (1 element = scalar scale)."""
+    _check(x, "x")
+    _check(scales, "scales")
+    rows = scales.numel()
+    if rows <= 0 or x.numel() == 0 or x.numel() % rows:
+        raise ValueError("cannot broadcast %d scales over %s" % (rows, tuple(x.shape)))
+    y = torch.empty_like(x) if out is None else _check(out, "out")
+    has_clip = clip_max is not None
+    lo = 0.0 if clip_min is None else float(clip_min)           # ste_func.py:34
+    check_call(_lib_().fq_ste_forward(_ptr(x), _ptr(y), rows, x.numel() // rows, _ptr(scales), int(has_clip), lo,
+                                      float(clip_max) if has_clip else 0.0, float(eps), _stream(x)))
+    return y
+
+
+def weight_fake_quant(w, rows, width=8, out=None, want_scales=False):
+    """convert_conv2d.py:70-95 / convert_dense.py:52-63 with w viewed as (rows, numel/rows)."""
+    _check(w, "w")
+    if w.numel() == 0 or rows <= 0 or w.numel() % rows:
+        raise ValueError("weight of %d elements cannot be viewed as %d rows" % (w.numel(), rows))
+    wq = torch.empty_like(w) if out is None else _check(out, "out")
+    scales = torch.empty(rows, dtype=torch.float32, device=w.device) if want_scales else None
+    ws = _workspace(w.device, _lib_().fq_weight_workspace_bytes(rows))
+    check_call(_lib_().fq_weight_fake_quant(_ptr(w), _ptr(wq), rows, w.numel() // rows, int(width), _ptr(scales),
+                                            _ptr(ws), _stream(w)))
+    return (wq, scales) if want_scales else wq
+
+
+_G = {
+    "F23": [[1, 0, 0], [1 / 2, 1 / 2, 1 / 2], [1 / 2, -1 / 2, 1 / 2], [0, 0, 1]],
+    "F43": [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+            [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+    "F63": [[1, 0, 0], [-2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9], [1 / 90, 1 / 45, 2 / 45],
+            [1 / 90, -1 / 45, 2 / 45], [32 / 45, 16 / 45, 8 / 45], [32 / 45, -16 / 45, 8 / 45], [0, 0, 1]],
+}
+_WINO_CACHE = {}
+
+
+def winograd_matrices(variant):
+    """(G, pinv(G), pinv(G^T)) as fp32 numpy arrays.  G as in wino_matrix.py:29-54; the pseudo-inverses are computed
+    on the host with numpy exactly like convert_conv2d.py:81-82, once per variant instead of on every forward."""
+    if variant not in _WINO_CACHE:
+        G = np.asarray(_G[variant], dtype=np.float32)
+        _WINO_CACHE[variant] = (G, np.ascontiguousarray(np.linalg.pinv(G), dtype=np.float32),
+                                np.ascontiguousarray(np.linalg.pinv(G.T), dtype=np.float32))
+    return _WINO_CACHE[variant]
+
+
+def wino_weight_fake_quant(w, variant, width=8, out=None, want_scales=False, GI=None, GTI=None):
+    """convert_conv2d.py:71-83: per-out-channel fake-quant of 3x3 filters in the Winograd domain."""
+    _check(w, "w")
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("Winograd-domain quantisation needs (Cout, Cin/g, 3, 3) weights, got %s" % (tuple(w.shape),))
+    G, GI0, GTI0 = winograd_matrices(variant)
+    GI = GI0 if GI is None else np.ascontiguousarray(GI, dtype=np.float32)
+    GTI = GTI0 if GTI is None else np.ascontiguousarray(GTI, dtype=np.float32)
+    t = G.shape[0]
+    wq = torch.empty_like(w) if out is None else _check(out, "out")
+    cout, cin_g = w.shape[0], w.shape[1]
+    scales = torch.empty(cout, dtype=torch.float32, device=w.device) if want_scales else None
+    fp = ctypes.POINTER(ctypes.c_float)
+    check_call(_lib_().fq_wino_weight_fake_quant(_ptr(w), _ptr(wq), cout, cin_g, t, G.ctypes.data_as(fp),
+                                                 GI.ctypes.data_as(fp), GTI.ctypes.data_as(fp), int(width),
+                                                 _ptr(scales), ctypes.c_void_p(0), _stream(w)))
+    return (wq, scales) if want_scales else wq
+
+
+def ema_update(state, current, momentum=0.9):
+    """`_update_ema` (convert.py:66-79) over a contiguous vector of per-block scalars, in place on `state`."""
+    _check(state, "state")
+    _check(current, "current")
+    if state.numel() != current.numel():
+        raise ValueError("state/current size mismatch")
+    check_call(_lib_().fq_ema_update(_ptr(state), _ptr(current), state.numel(), float(momentum), _stream(state)))
+    return state
+
+
+def global_max(x):
+    """`np.max(feature_maps)` (distribution_calibrate.py:33-34) -> (1,) device tensor."""
+    _check(x, "x")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check_call(_lib_().fq_global_max(_ptr(x), x.numel(), _ptr(out), _stream(x)))
+    return out
+
+
+def histogram_accumulate(x, max_dev, hist, neg_count=None):
+    """`_discrete_histogram` + `hist_collector[m] += hist` (distribution_calibrate.py:39-45,103-104).
+    `hist`: int64 device tensor of `bins` exact counts, accumulated in place."""
+    _check(x, "x")
+    _check(max_dev, "max_dev")
+    _check(hist, "hist", torch.int64)
+    if neg_count is not None:
+        _check(neg_count, "neg_count", torch.int32)
+    check_call(_lib_().fq_histogram_accumulate(_ptr(x), x.numel(), _ptr(max_dev), hist.numel(), _ptr(hist),
+                                               _ptr(neg_count), _stream(x)))
+    return hist
+
+
+def hist_to_float(hist):
+    _check(hist, "hist", torch.int64)
+    out = torch.empty(hist.shape, dtype=torch.float32, device=hist.device)
+    check_call(_lib_().fq_hist_to_float(_ptr(hist), _ptr(out), hist.numel(), _stream(hist)))
+    return out
+
+
+def kl_search(hist, levels, min_bins):
+    """`kl_calibrate` (distribution_calibrate.py:117-171) for L histograms: hist (L, bins) fp32 -> (L,) int32."""
+    _check(hist, "hist")
+    if hist.dim() == 1:
+        hist = hist.reshape(1, -1)
+    L, bins = hist.shape
+    out = torch.empty(L, dtype=torch.int32, device=hist.device)
+    ws = _workspace(hist.device, _lib_().fq_kl_workspace_bytes(L, bins))
+    check_call(_lib_().fq_kl_search(_ptr(hist), L, bins, int(levels), int(min_bins), _ptr(out), _ptr(ws),
+                                    _stream(hist)))
+    return out
+
+
+_CODE_MODES = {"int8": _lib.FQ_CODES_INT8, "uint8": _lib.FQ_CODES_UINT8, "range": _lib.FQ_CODES_RANGE,
+               "scale": _lib.FQ_CODES_SCALE}
+
+
+def quantize_codes(x, out_type="int8", range_dev=None):
+    """`quantize`/`_quantize` (nn/quantized_conv.py:54-72).  Returns (codes int32, range_dev = [min, max, scale])."""
+    _check(x, "x")
+    if out_type not in _CODE_MODES:
+        raise ValueError("unknown out type: %s" % (out_type,))
+    mode = _CODE_MODES[out_type]
+    if range_dev is None:
+        if mode >= _lib.FQ_CODES_RANGE:
+            raise ValueError("range_dev is required for out_type=%s" % out_type)
+        range_dev = torch.empty(3, dtype=torch.float32, device=x.device)
+    _check(range_dev, "range_dev")
+    codes = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    ws = _workspace(x.device, _lib_().fq_act_workspace_bytes(1))
+    check_call(_lib_().fq_quantize_codes(_ptr(x), _ptr(codes), x.numel(), mode, _ptr(range_dev), _ptr(ws),
+                                         _stream(x)))
+    return codes, range_dev
+
+
+def dequantize(codes, scale_dev):
+    """`dequantize` (nn/quantized_conv.py:74-76)."""
+    _check(codes, "codes", torch.int32)
+    _check(scale_dev, "scale_dev")
+    y = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+    check_call(_lib_().fq_dequantize(_ptr(codes), _ptr(y), codes.numel(), _ptr(scale_dev), _stream(codes)))
+    return y

@@ -1,0 +1,342 @@
+"""GPU parity: the HIP path (through the C ABI, via quantization.mxnet_amd.ops) against
+  (a) the committed golden vectors made by the reference's own Python, and
+  (b) the CPU oracle on seeded inputs, and
+  (c) size-independent properties at BASELINE.json's full tensor sizes.
+Bar: integer stage bit-exact; dequantised fp32 bit-exact (the op order is fully defined), which is tighter than the
+1e-6 relative the north star allows — the looser bound is used only where a different but valid summation order exists
+(none on this path today)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6      # north-star tolerance on the dequantised float
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from quantization.mxnet_amd import ops
+    info = ops.device_info()
+    assert info["wavefront"] == 64, info
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from quantization.mxnet_amd import ops as _ops
+    return _ops
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _eq(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+    assert not bad.any(), "%s: %d/%d mismatches; first at %s: got %r want %r" % (
+        what, int(bad.sum()), a.size, np.argwhere(bad)[0], a[bad][0], b[bad][0])
+
+
+def _flags(ops, tag_signed, dense=False):
+    return ops.act_flags(signed=tag_signed, lo_neg_max=False if dense else None)
+
+
+# ---- activations vs golden (G4) ------------------------------------------------------------------------------
+def test_conv_activation_golden(golden, dev, ops):
+    g = golden("g4_activation")
+    tags = sorted({k.split("/")[0] for k in g if k.startswith("conv_") and not k.startswith("conv_zero")})
+    assert len(tags) == 12
+    for tag in tags:
+        signed = "_s_" in tag
+        width = int(tag.rsplit("w", 1)[1])
+        x = T(g[tag + "/x"], dev)
+        y, cur, codes = ops.fake_quant_online(x, width, _flags(ops, signed), want_codes=True)
+        assert N(cur)[0] == g[tag + "/online_max"], tag
+        _eq(N(codes), g[tag + "/online_codes"].astype(np.int32), tag + " online codes")
+        _eq(N(y), g[tag + "/online_y"], tag + " online y")
+        thr = T(np.float32([g[tag + "/offline_thr"]]), dev)
+        y, cur, codes = ops.fake_quant_offline(x, thr, width, _flags(ops, signed), want_codes=True)
+        assert N(cur)[0] == g[tag + "/offline_curmax"], tag
+        _eq(N(codes), g[tag + "/offline_codes"].astype(np.int32), tag + " offline codes")
+        _eq(N(y), g[tag + "/offline_y"], tag + " offline y")
+        y2, cur2, _ = ops.fake_quant_offline(x, thr, width, _flags(ops, signed), want_stat=False)
+        assert cur2 is None
+        _eq(N(y2), g[tag + "/offline_y"], tag + " offline y (no stat)")
+
+
+def test_conv_activation_all_zero(golden, dev, ops):
+    g = golden("g4_activation")
+    y, cur, _ = ops.fake_quant_online(T(g["conv_zero/x"], dev))
+    assert N(cur)[0] == 0.0
+    _eq(N(y), g["conv_zero/online_y"])
+
+
+def test_dense_activation_golden(golden, dev, ops):
+    g = golden("g4_activation")
+    for tag in sorted({k.split("/")[0] for k in g if k.startswith("dense_")}):
+        signed = "_s_" in tag
+        width = int(tag.rsplit("w", 1)[1])
+        x = T(g[tag + "/x"], dev)
+        y, cur, _ = ops.fake_quant_online(x, width, _flags(ops, signed, dense=True))
+        assert N(cur)[0] == g[tag + "/online_max"]
+        _eq(N(y), g[tag + "/online_y"], tag)
+        y, _, _ = ops.fake_quant_offline(x, T(np.float32([g[tag + "/offline_thr"]]), dev), width,
+                                         _flags(ops, signed, dense=True))
+        _eq(N(y), g[tag + "/offline_y"], tag + " offline")
+
+
+# ---- activations vs oracle on seeded shapes (ragged, unaligned, tiny, multi-chunk) ----------------------------
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (3, 5, 9, 11), (2, 7), (128, 1024), (5, 3, 33, 31),
+                                   (4, 32, 56, 56), (2, 64, 112, 112), (7, 8200), (3, 8192), (2, 8196)])
+@pytest.mark.parametrize("signed,width", [(False, 8), (True, 8), (False, 4), (True, 2)])
+def test_activation_vs_oracle(dev, ops, shape, signed, width):
+    rng = np.random.default_rng(hash((shape, signed, width)) % (2 ** 31))
+    x = rng.standard_normal(shape).astype(np.float32) * np.float32(rng.uniform(0.01, 30))
+    if not signed:
+        x = np.where(rng.random(shape) < 0.5, 0, x).astype(np.float32)
+    want_y, want_cur, _, want_codes = O.conv_input_fake_quant(x, signed, width)
+    y, cur, codes = ops.fake_quant_online(T(x, dev), width, ops.act_flags(signed=signed), want_codes=True)
+    assert N(cur)[0] == want_cur
+    _eq(N(codes), want_codes.astype(np.int32), "codes")
+    _eq(N(y), want_y, "y")
+    np.testing.assert_allclose(N(y), want_y, rtol=REL_TOL, atol=0)
+    _eq(N(ops.absmax_per_sample(T(x, dev))), O.absmax_per_sample(x), "per-sample abs-max")
+    thr = np.float32(want_cur * np.float32(0.7))
+    want_y, want_cur, _, want_codes = O.conv_input_fake_quant(x, signed, width, offline_threshold=thr)
+    y, cur, codes = ops.fake_quant_offline(T(x, dev), T(np.float32([thr]), dev), width, ops.act_flags(signed=signed),
+                                           want_codes=True)
+    assert N(cur)[0] == want_cur
+    _eq(N(codes), want_codes.astype(np.int32), "offline codes")
+    _eq(N(y), want_y, "offline y")
+
+
+def test_unaligned_views_take_the_scalar_path(dev, ops):
+    rng = np.random.default_rng(3)
+    big = rng.standard_normal(4 * 1000 + 1).astype(np.float32)
+    x = T(big, dev)[1:].reshape(4, 1000)              # 4-byte-aligned only; contiguous
+    assert x.data_ptr() % 16 != 0 and x.is_contiguous()
+    want_y, want_cur, _, _ = O.conv_input_fake_quant(big[1:].reshape(4, 1000), True, 8)
+    y, cur, _ = ops.fake_quant_online(x, 8, ops.act_flags(signed=True))
+    assert N(cur)[0] == want_cur
+    _eq(N(y), want_y)
+
+
+def test_act_output_variant_no_abs_no_eps(dev, ops):
+    """convert_act.py:49-54: statistic = max (not abs-max), no epsilon, unsigned."""
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((6, 4, 5, 5)).astype(np.float32) - np.float32(0.3)
+    want_y, want_cur, _, _ = O.act_output_fake_quant(a, 8)
+    y, cur, _ = ops.fake_quant_online(T(a, dev), 8, ops.act_flags(no_abs=True, no_eps=True))
+    assert N(cur)[0] == want_cur
+    _eq(N(y), want_y)
+    allneg = -np.abs(a) - 1
+    y, cur, _ = ops.fake_quant_online(T(allneg, dev), 8, ops.act_flags(no_abs=True, no_eps=True))
+    assert N(cur)[0] == O.act_output_fake_quant(allneg, 8)[1] < 0
+
+
+def test_batch_mean_is_the_defined_order(dev, ops):
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 127, 128, 1000):
+        v = (rng.random(n) * 10).astype(np.float32)
+        assert N(ops.batch_mean(T(v, dev)))[0] == O.batch_mean(v)
+
+
+def test_in_place_apply(dev, ops):
+    rng = np.random.default_rng(6)
+    x = np.abs(rng.standard_normal((8, 16, 28, 28))).astype(np.float32)
+    want, _, _, _ = O.conv_input_fake_quant(x)
+    t = T(x, dev)
+    y, _, _ = ops.fake_quant_online(t, out=t)
+    assert y.data_ptr() == t.data_ptr()
+    _eq(N(t), want)
+
+
+# ---- weights (G5, G6) -------------------------------------------------------------------------------------------
+def test_weight_golden(golden, dev, ops):
+    g = golden("g5_weight")
+    for name in ("dw16", "pw32x16", "c8x4k3"):
+        w = g[name + "/w"]
+        for qt in ("layer", "group", "channel"):
+            for width in (8, 4):
+                key = "%s/%s_w%d" % (name, qt, width)
+                if key not in g:
+                    continue
+                rows = 1 if qt == "layer" else (w.shape[0] if qt == "channel" else (16 if name == "dw16" else 1))
+                wq, sc = ops.weight_fake_quant(T(w, dev), rows, width, want_scales=True)
+                _eq(N(wq), g[key], key)
+                _eq(N(sc), O.weight_fake_quant(w, qt, width, num_group=rows)[1], key + " scales")
+    for qt in ("layer", "channel"):
+        for width in (8, 4):
+            w = g["dense/%s_w%d/w" % (qt, width)]
+            wq = ops.weight_fake_quant(T(w, dev), 1 if qt == "layer" else w.shape[0], width)
+            _eq(N(wq), g["dense/%s_w%d/wq" % (qt, width)], "dense " + qt)
+
+
+@pytest.mark.parametrize("shape,rows", [((1024, 1, 3, 3), 1024), ((1024, 1, 3, 3), 1), ((512, 512, 3, 3), 512),
+                                        ((512, 512, 3, 3), 1), ((1000, 2048), 1000), ((1000, 2048), 1),
+                                        ((64, 3, 7, 7), 64), ((5, 9001), 5), ((3, 8193), 3), ((2, 8192), 2)])
+def test_weight_vs_oracle_real_layer_shapes(dev, ops, shape, rows):
+    rng = np.random.default_rng(sum(shape) + rows)
+    w = (rng.standard_normal(shape) * rng.uniform(0.01, 2.0, (shape[0],) + (1,) * (len(shape) - 1))).astype(np.float32)
+    qt = "layer" if rows == 1 else "channel"
+    for width in (8, 4):
+        want, want_sc = O.weight_fake_quant(w, qt, width)
+        wq, sc = ops.weight_fake_quant(T(w, dev), rows, width, want_scales=True)
+        _eq(N(sc), want_sc, "scales")
+        _eq(N(wq), want, "w_q")
+
+
+@pytest.mark.parametrize("variant", ["F23", "F43", "F63"])
+def test_winograd_golden(golden, dev, ops, variant):
+    g = golden("g6_winograd")
+    G, GI, GTI = ops.winograd_matrices(variant)
+    _eq(G, g[variant + "/G"])
+    _eq(GI, g[variant + "/GI"], "pinv(G) (LAPACK-dependent; same image on the GPU box)")
+    _eq(GTI, g[variant + "/GTI"])
+    for name in ("c8x4k3", "dw16"):
+        for width in (8, 4):
+            w = g["%s/%s_w%d/w" % (variant, name, width)]
+            wq = ops.wino_weight_fake_quant(T(w, dev), variant, width, GI=g[variant + "/GI"], GTI=g[variant + "/GTI"])
+            _eq(N(wq), g["%s/%s_w%d/wq" % (variant, name, width)], "%s %s w%d" % (variant, name, width))
+
+
+def test_winograd_resnet_shape_vs_oracle(dev, ops):
+    rng = np.random.default_rng(9)
+    w = (rng.standard_normal((64, 300, 3, 3)) * 0.05).astype(np.float32)      # cin_g > workgroup size
+    want, want_sc, _ = O.wino_weight_fake_quant(w, "F43", 8)
+    wq, sc = ops.wino_weight_fake_quant(T(w, dev), "F43", 8, want_scales=True)
+    _eq(N(sc), want_sc)
+    _eq(N(wq), want)
+
+
+# ---- EMA (G7) ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["layer_w8", "channel_w4"])
+def test_ema_golden(golden, dev, ops, tag):
+    g = golden("g7_g9_ema_state")
+    cur, ema = g[tag + "/calib_cur"], g[tag + "/calib_ema"]
+    state = torch.zeros(cur.shape[1], dtype=torch.float32, device=dev)
+    for step in range(cur.shape[0]):
+        ops.ema_update(state, T(cur[step], dev), 0.9)
+        _eq(N(state), ema[step], "ema step %d" % step)
+
+
+# ---- histogram / KL (G1-G3: pinned to the real reference module) ---------------------------------------------------
+@pytest.mark.parametrize("name", ["halfnormal", "exponential", "relu_outlier", "tiny_range", "shape4d"])
+def test_histogram_golden(golden, dev, ops, name):
+    g = golden("g1_histogram")
+    fm = T(g[name + "/fm"], dev)
+    mx = ops.global_max(fm)
+    assert N(mx)[0] == g[name + "/max_auto"]
+    hist = torch.zeros(2048, dtype=torch.int64, device=dev)
+    neg = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.histogram_accumulate(fm, mx, hist, neg)
+    _eq(N(ops.hist_to_float(hist)), g[name + "/hist_auto"], "auto")
+    assert int(N(neg)[0]) == 0
+    hist.zero_()
+    ops.histogram_accumulate(fm, T(np.float32([g[name + "/max_fixed"]]), dev), hist)
+    _eq(N(hist).astype(np.float32), g[name + "/hist_fixed"], "fixed range")
+    h128 = torch.zeros(128, dtype=torch.int64, device=dev)
+    ops.histogram_accumulate(fm, mx, h128)
+    _eq(N(h128).astype(np.float32), g[name + "/hist_auto_b128"], "128 bins")
+
+
+def test_histogram_accumulates_across_batches_like_collect_feature_maps(golden, dev, ops):
+    g = golden("g3_collect")
+    for k in range(3):
+        hist = torch.zeros(2048, dtype=torch.int64, device=dev)
+        fm_max = None
+        for b in g["batches"]:
+            fm = np.maximum(b, 0) * np.float32(k + 1)
+            if k == 2:
+                fm = np.ascontiguousarray(fm[:, :, ::2, ::2])
+            t = T(fm, dev)
+            if fm_max is None:
+                fm_max = ops.global_max(t)
+            ops.histogram_accumulate(t, fm_max, hist)
+        _eq(N(hist).astype(np.float32), g["hist%d" % k])
+        assert N(fm_max)[0] == g["fm_max%d" % k]
+
+
+def test_histogram_counts_negatives_and_clamps_last_bin(dev, ops):
+    x = np.float32([-1.0, 0.0, 0.5, 300.0, 300.0, 1e-30])
+    hist = torch.zeros(16, dtype=torch.int64, device=dev)
+    neg = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.histogram_accumulate(T(x, dev), T(np.float32([300.0]), dev), hist, neg)
+    assert int(N(neg)[0]) == 1
+    want, _ = O.discrete_histogram(np.maximum(x, 0), 16, np.float32(300.0))
+    _eq(N(hist).astype(np.float32), want)
+    assert N(hist)[15] == 2         # fp32(300 + 1e-5) == 300 -> index == bins, clamped (DESIGN.md deviation note)
+
+
+def test_kl_search_golden_all_cases_one_launch_per_level(golden, dev, ops):
+    g = golden("g2_kl")
+    names = ["halfnormal", "exponential", "relu_outlier", "accumulated6", "sparse", "spike"]
+    hists = T(np.stack([g[n + "/hist"] for n in names]), dev)
+    for levels in (256, 128, 16, 8):
+        best = N(ops.kl_search(hists, levels, levels))
+        want = np.asarray([int(g["%s/best_L%d" % (n, levels)]) for n in names])
+        _eq(best, want.astype(np.int32), "levels=%d" % levels)
+    for n in ("halfnormal", "sparse"):
+        h = T(g[n + "/hist_b256"], dev)
+        for levels in (16, 32):
+            assert int(N(ops.kl_search(h, levels, levels))[0]) == int(g["%s/best_b256_L%d" % (n, levels)])
+
+
+# ---- int-code path (G8) ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["u01", "normal", "shifted"])
+@pytest.mark.parametrize("t", ["int8", "uint8"])
+def test_quantize_codes_golden(golden, dev, ops, name, t):
+    g = golden("g8_quantized_conv")
+    codes, rng_dev = ops.quantize_codes(T(g[name + "/x"], dev), t)
+    _eq(N(codes), g["%s/%s_codes" % (name, t)])
+    assert N(rng_dev)[2] == g["%s/%s_scale" % (name, t)]
+    _eq(N(ops.dequantize(codes, rng_dev[2:3])), g["%s/%s_deq" % (name, t)])
+
+
+def test_quantize_codes_fixed_range_and_explicit_scale(dev, ops):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(1000).astype(np.float32) * 3
+    want, sc = O.quantize_codes(x, fixed_range=(-2.0, 2.0))
+    codes, r = ops.quantize_codes(T(x, dev), "range", T(np.float32([-2, 2, 0]), dev))
+    _eq(N(codes), want)
+    assert N(r)[2] == sc
+    codes, _ = ops.quantize_codes(T(x, dev), "scale", T(np.float32([-1e9, 1e9, 0.0123]), dev))
+    _eq(N(codes), O.roundf((x / np.float32(0.0123)).astype(np.float32)).astype(np.int32))
+
+
+# ---- full-size properties (BASELINE configs[1]: mobilenet1.0 activations at batch 128) ---------------------------------
+def test_headline_tensor_properties(dev, ops):
+    """(128, 64, 112, 112) fp32 = 411 MB, the largest MobileNet activation.  Size-independent checks:
+    codes in range; y == codes*scale; idempotence (re-quantising with the same threshold is the identity);
+    sampled slices equal the oracle."""
+    torch.manual_seed(7)
+    x = torch.relu(torch.randn(128, 64, 112, 112, device=dev)) * 1.7
+    y, cur, codes = ops.fake_quant_online(x, 8, 0, want_codes=True)
+    cur_h = N(cur)[0]
+    want_cur = O.batch_mean(N(torch.amax(x.abs().reshape(128, -1), dim=1)))
+    assert cur_h == want_cur
+    assert int(codes.min()) == 0 and int(codes.max()) == 255
+    scale = np.float32(cur_h / np.float32(255))
+    assert torch.equal(y, codes.float() * float(scale))
+    y2, _, codes2 = ops.fake_quant_offline(y, cur, 8, 0, want_stat=False, want_codes=True)
+    assert torch.equal(codes2, codes) and torch.equal(y2, y)
+    for n in (0, 63, 127):
+        xs = N(x[n, 5])
+        want = O.ste_forward(xs, scale, cur_h, 0.0)
+        _eq(N(y[n, 5]), want, "slice %d" % n)
+    del y2, codes2, codes
+    hist = torch.zeros(2048, dtype=torch.int64, device=dev)
+    mx = ops.global_max(x)
+    ops.histogram_accumulate(x, mx, hist)
+    assert int(hist.sum()) == int((x != 0).sum())      # every non-zero lands in exactly one bin
