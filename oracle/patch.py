@@ -1,0 +1,199 @@
+"""TEST INFRASTRUCTURE: run the product's HOST logic (converters, state machine, calibration loops, CLI) on CPU by
+temporarily replacing the HIP entry points of `quantization.mxnet_amd.ops` with the numpy oracle.
+
+Used only by tests/ (host-logic and whole-net parity tests) and by bench.py's `cpu_baseline` leg.  The product never
+imports this module, never calls `oracle_ops()` and has no switch that could route it here; without this context
+manager every product entry point raises on CPU tensors.
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+from . import fq_oracle as O
+
+F32 = np.float32
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _t(a, like=None, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t
+
+
+def _flags(flags):
+    return bool(flags & 1), bool(flags & 2), bool(flags & 4), bool(flags & 8)
+
+
+def _stat(x, no_abs):
+    a = _np(x).astype(F32)
+    a = a.reshape(a.shape[0], -1)
+    return (a.max(axis=1) if no_abs else np.abs(a).max(axis=1)).astype(F32)
+
+
+def _apply(x, max_, width, flags):
+    signed, lo_neg, no_abs, no_eps = _flags(flags)
+    scale = O.act_scale(max_, signed, width)
+    lo = F32(-max_) if lo_neg else F32(0)
+    codes = O.ste_codes(_np(x), scale, max_, lo, eps=F32(0) if no_eps else O.EPS)
+    return (codes * scale).astype(F32), codes
+
+
+def absmax_per_sample(x, no_abs=False, out=None):
+    r = _t(_stat(x, no_abs))
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def batch_mean(v, out=None):
+    r = _t(np.asarray([O.batch_mean(_np(v).reshape(-1))], dtype=F32))
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def fake_quant_online(x, width=8, flags=0, out=None, cur_out=None, want_codes=False, stat_ws=None):
+    per = _stat(x, bool(flags & 4))
+    if stat_ws is not None:
+        stat_ws[:len(per)].copy_(_t(per))
+    cur = O.batch_mean(per)
+    y, codes = _apply(x, cur, width, flags)
+    yt = _t(y).reshape(x.shape)
+    if out is not None:
+        out.copy_(yt)
+        yt = out
+    ct = _t(np.asarray([cur], dtype=F32))
+    if cur_out is not None:
+        cur_out.copy_(ct)
+        ct = cur_out
+    return yt, ct, (_t(codes.astype(np.int32)).reshape(x.shape) if want_codes else None)
+
+
+def fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, want_stat=True, want_codes=False,
+                       stat_ws=None):
+    thr = F32(_np(threshold).reshape(-1)[0])
+    y, codes = _apply(x, thr, width, flags)
+    yt = _t(y).reshape(x.shape)
+    if out is not None:
+        out.copy_(yt)
+        yt = out
+    ct = None
+    if want_stat:
+        per = _stat(x, bool(flags & 4))
+        if stat_ws is not None:
+            stat_ws[:len(per)].copy_(_t(per))
+        ct = _t(np.asarray([O.batch_mean(per)], dtype=F32))
+        if cur_out is not None:
+            cur_out.copy_(ct)
+            ct = cur_out
+    return yt, ct, (_t(codes.astype(np.int32)).reshape(x.shape) if want_codes else None)
+
+
+def ste_forward(x, scales, clip_max=None, clip_min=None, eps=1e-10, out=None):
+    a = _np(x)
+    s = _np(scales).reshape(-1).astype(F32)
+    rows = s.size
+    y = O.ste_forward(a.reshape(rows, -1), s.reshape(rows, 1), clip_max, clip_min, eps=F32(eps)).reshape(a.shape)
+    return _t(y)
+
+
+def weight_fake_quant(w, rows, width=8, out=None, want_scales=False):
+    a = _np(w)
+    wq, sc = O.weight_fake_quant(a.reshape(rows, -1), "layer" if rows == 1 else "channel", width)
+    wq = _t(wq.reshape(a.shape))
+    return (wq, _t(sc)) if want_scales else wq
+
+
+def wino_weight_fake_quant(w, variant, width=8, out=None, want_scales=False, GI=None, GTI=None):
+    wq, sc, _ = O.wino_weight_fake_quant(_np(w), variant, width, GI, GTI)
+    return (_t(wq), _t(sc)) if want_scales else _t(wq)
+
+
+def ema_update(state, current, momentum=0.9):
+    state.copy_(_t(O.ema_update(_np(state), _np(current), momentum)))
+    return state
+
+
+def global_max(x):
+    return _t(np.asarray([_np(x).max()], dtype=F32))
+
+
+def histogram_accumulate(x, max_dev, hist, neg_count=None):
+    a = _np(x).reshape(-1)
+    if neg_count is not None:
+        neg_count += int((a < 0).sum())
+    mx = F32(_np(max_dev)[0])
+    if mx > 0:          # (the device kernel has no assert; the caller checks max > 0 once, at the end)
+        h, _ = O.discrete_histogram(np.maximum(a, 0), hist.numel(), mx)
+        hist += _t(h.astype(np.int64))
+    return hist
+
+
+def hist_to_float(hist):
+    return hist.to(torch.float32)
+
+
+def kl_search(hist, levels, min_bins):
+    h = _np(hist)
+    if h.ndim == 1:
+        h = h.reshape(1, -1)
+    return _t(np.asarray([O.kl_calibrate(r, levels, min_bins, h.shape[1]) for r in h], dtype=np.int32))
+
+
+def quantize_codes(x, out_type="int8", range_dev=None):
+    a = _np(x)
+    if out_type in ("int8", "uint8"):
+        codes, scale = O.quantize_codes(a, out_type)
+        mx = np.abs(a).max() if out_type == "int8" else a.max()
+        mn = -mx if out_type == "int8" else a.min()
+        rng = _t(np.asarray([mn, mx, scale], dtype=F32))
+    elif out_type == "range":
+        r = _np(range_dev)
+        codes, scale = O.quantize_codes(a, fixed_range=(r[0], r[1]))
+        rng = _t(np.asarray([r[0], r[1], scale], dtype=F32))
+    else:
+        r = _np(range_dev)
+        c = np.minimum(np.maximum(a, r[0]), r[1])
+        codes = O.roundf((c / F32(r[2])).astype(F32)).astype(np.int32)
+        rng = range_dev
+    return _t(codes), rng
+
+
+def dequantize(codes, scale_dev):
+    return _t(O.dequantize(_np(codes), F32(_np(scale_dev).reshape(-1)[0])))
+
+
+def require_hip(device, what="tensor"):
+    return None
+
+
+def default_device(what="this call"):
+    return torch.device("cpu")
+
+
+_REPLACED = ["require_hip", "default_device", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
+             "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
+
+
+@contextlib.contextmanager
+def oracle_ops():
+    """`with oracle_ops(): ...` — product host code runs against the CPU oracle inside the block only."""
+    from quantization.mxnet_amd import ops
+    saved = {name: getattr(ops, name) for name in _REPLACED}
+    g = globals()
+    for name in _REPLACED:
+        setattr(ops, name, g[name])
+    try:
+        yield
+    finally:
+        for name, fn in saved.items():
+            setattr(ops, name, fn)

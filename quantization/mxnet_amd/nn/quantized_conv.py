@@ -1,0 +1,133 @@
+"""`nn.Conv2D` — the reference's stand-alone "really quantised" convolution (nn/quantized_conv.py:79-175).
+
+Same constructor and semantics: per-tensor quantise input and weight to int32 codes (`quantize` / `_quantize`, :54-72:
+global range, scale = max/127 if symmetric else (max-min)/255, NO zero-point), int32 bias at scale in_s*w_s clipped to
++-scale*2^31 (:122-127), integer correlation, optional activation, `dequantize` by in_s*w_s (:74-76, :158).
+
+What differs is the machinery: the quantise / dequantise stages are HIP kernels (`fq_quantize_codes`, `fq_dequantize`;
+ranges and scales stay in device scalars — no `.asscalar()`), and the reference's Python im2col double loop + fp32 `dot`
+(:34-52, :134-151; 12 544 slices per 112x112 map) is one grouped convolution on the integer codes held in fp32, which
+is exact under the same condition as the reference's own fp32 dot (|accumulator| < 2^24, :140-144).  A true int8 MFMA
+convolution is listed as "next" in DESIGN.md.
+"""
+import torch
+import torch.nn.functional as TF
+
+from ..mx.gluon import nn
+from ..mx.ndarray import NDArray
+from .. import ops
+
+__all__ = ['Conv2D', 'quantize', 'dequantize']
+
+
+def _int2tuple(x):
+    return (x, ) * 2 if isinstance(x, int) else x
+
+
+def quantize(F, x, out_type='int8'):
+    """(:63-72) -> (int32 codes NDArray, scale as a (1,) device NDArray)."""
+    if out_type not in ('int8', 'uint8'):
+        raise ValueError("unknown out type: ", out_type)
+    codes, rng = ops.quantize_codes(x._t.contiguous(), out_type)
+    return NDArray(codes), NDArray(rng[2:3])
+
+
+def _quantize(F, x, min_range, max_range):
+    """(:54-61) with a caller-fixed range."""
+    rng = torch.tensor([float(min_range), float(max_range), 0.0], dtype=torch.float32, device=x._t.device)
+    codes, rng = ops.quantize_codes(x._t.contiguous(), "range", rng)
+    return NDArray(codes), NDArray(rng[2:3])
+
+
+def dequantize(F, x, scale):
+    """(:74-76)"""
+    st = scale._t if isinstance(scale, NDArray) else torch.tensor([float(scale)], dtype=torch.float32,
+                                                                  device=x._t.device)
+    return NDArray(ops.dequantize(x._t.contiguous(), st.reshape(1)))
+
+
+class Conv2D(nn.HybridBlock):
+    def __init__(self, channels, kernel_size, strides, padding, in_channels, groups=1,
+                 activation=None, use_bias=True, quantized=False,
+                 input_dtype='float32', weight_dtype='float32',
+                 weight_initializer=None, bias_initializer='zeros',
+                 prefix=None, params=None):
+        super(Conv2D, self).__init__(prefix, params)
+        with self.name_scope():
+            self._channels = channels
+            self._in_channels = in_channels
+            self._groups = groups
+            assert in_channels % groups == 0 and channels % groups == 0
+            self._kernel_size = _int2tuple(kernel_size)
+            self._strides = _int2tuple(strides)
+            self._padding = _int2tuple(padding)
+            self._quantized = quantized
+            self._input_dtype = input_dtype
+            self._weight_dtype = weight_dtype
+            self._input_range = None
+            self._weight_range = None
+
+            self.weight = self.params.get('weight', shape=(channels, in_channels // groups, *self._kernel_size),
+                                          init=weight_initializer, allow_deferred_init=True)
+            self.bias = self.params.get('bias', shape=(channels, ),
+                                        init=bias_initializer, allow_deferred_init=True) if use_bias else None
+            self.act = nn.Activation(activation, prefix=activation + '_') if activation is not None else None
+
+    def _alias(self):
+        return "conv2d"
+
+    def hybrid_forward(self, F, inputs, weight, bias=None):
+        # Pad (:108-109)
+        ph, pw = self._padding
+        x = TF.pad(inputs._t, (pw, pw, ph, ph), mode="constant", value=0.0).contiguous()
+        w = weight._t.contiguous()
+        b = None if bias is None else bias._t
+        if self._quantized:
+            # Quantize and cast into int32 (:111-127)
+            if self._input_range is None:
+                xi, in_scale = quantize(F, NDArray(x), self._input_dtype)
+            else:
+                xi, in_scale = _quantize(F, NDArray(x), *self._input_range)
+            if self._weight_range is None:
+                wi, w_scale = quantize(F, NDArray(w), self._weight_dtype)
+            else:
+                wi, w_scale = _quantize(F, NDArray(w), *self._weight_range)
+            b_scale = (in_scale._t * w_scale._t)                     # fp32 product, device scalar
+            if b is not None:
+                b_max = b_scale * float(2 ** 31)
+                rng = torch.cat([-b_max, b_max, b_scale]).contiguous()
+                bi, _ = ops.quantize_codes(b.contiguous(), "scale", rng)
+                b = bi.to(torch.float32)
+            x, w = xi._t.to(torch.float32), wi._t.to(torch.float32)
+        # Grouped correlation, stride as the reference's window loop (:42-47)
+        y = TF.conv2d(x, w, None, stride=self._strides, padding=0, groups=self._groups)
+        if self._quantized:
+            y = y.to(torch.int32)                                      # (:144) cast back to int32
+            if b is not None:
+                y = y + b.to(torch.int32).reshape(1, -1, 1, 1)
+        elif b is not None:
+            y = y + b.reshape(1, -1, 1, 1)
+        y = NDArray(y)
+        if self.act is not None:
+            y = self.act(y if not self._quantized else NDArray(y._t))
+        # Dequantize (:157-158)
+        if self._quantized:
+            yt = y._t if y._t.dtype == torch.int32 else y._t.to(torch.int32)
+            y = NDArray(ops.dequantize(yt.contiguous(), b_scale.reshape(1).contiguous()))
+        return y
+
+    def __repr__(self):
+        s = '{name}({mapping}, kernel_size={}, stride={}'.format(self._kernel_size, self._strides)
+        len_kernel_size = len(self._kernel_size)
+        if self._padding != (0,) * len_kernel_size:
+            s += ', padding={}'.format(self._padding)
+        if self._groups != 1:
+            s += ', groups={}'.format(self._groups)
+        if self.bias is None:
+            s += ', bias=False'
+        if self.act:
+            s += ', {}'.format(self.act)
+        s += ')'
+        shape = self.weight.shape
+        return s.format(name=self.__class__.__name__,
+                        mapping='{0} -> {1}'.format(shape[1] if shape[1] else None, shape[0]))

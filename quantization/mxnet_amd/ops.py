@@ -44,6 +44,18 @@ def _check(t, name, dtype=torch.float32):
     return t
 
 
+def require_hip(device, what="tensor"):
+    if torch.device(device).type != "cuda":
+        raise FakeQuantError("%s lives on %s: the fake-quant path runs on a HIP device only (no CPU fallback)"
+                             % (what, device))
+
+
+def default_device(what="this call"):
+    if not torch.cuda.is_available():
+        raise FakeQuantError("%s needs a HIP device (no CPU fallback)" % what)
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 def _workspace(dev, nbytes):
     """Stream-ordered scratch: one growing buffer per (device, stream)."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
@@ -84,24 +96,35 @@ def _n_inner(x):
     return n, x.numel() // n
 
 
-def absmax_per_sample(x, no_abs=False):
+def absmax_per_sample(x, no_abs=False, out=None):
     """`F.max(F.abs(x), axis=(1,2,3))` (convert_conv2d.py:56) -> (N,) device tensor."""
     _check(x, "x")
     n, inner = _n_inner(x)
-    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    out = torch.empty(n, dtype=torch.float32, device=x.device) if out is None else _check(out, "out")
     check_call(_lib_().fq_absmax_per_sample(_ptr(x), n, inner, act_flags(no_abs=no_abs), _ptr(out), _stream(x)))
     return out
 
 
-def batch_mean(v):
+def batch_mean(v, out=None):
     """`.mean()` of the per-sample maxima (convert_conv2d.py:56) -> (1,) device tensor."""
     _check(v, "v")
-    out = torch.empty(1, dtype=torch.float32, device=v.device)
+    out = torch.empty(1, dtype=torch.float32, device=v.device) if out is None else _check(out, "out")
     check_call(_lib_().fq_batch_mean(_ptr(v), v.numel(), _ptr(out), _stream(v)))
     return out
 
 
-def fake_quant_online(x, width=8, flags=0, out=None, cur_out=None, want_codes=False):
+def _stat_ws(x, n, stat_ws):
+    """Scratch for the per-sample statistic.  A caller-owned `stat_ws` (>= n floats) keeps the per-sample maxima
+    readable after the call (the multi-GPU calibration all-gathers them: dist.py)."""
+    if stat_ws is None:
+        return _workspace(x.device, _lib_().fq_act_workspace_bytes(n))
+    _check(stat_ws, "stat_ws")
+    if stat_ws.numel() < n:
+        raise ValueError("stat_ws holds %d floats, need %d" % (stat_ws.numel(), n))
+    return stat_ws
+
+
+def fake_quant_online(x, width=8, flags=0, out=None, cur_out=None, want_codes=False, stat_ws=None):
     """convert_conv2d.py:56-66 + ste_func.py:41, threshold = this batch's statistic.
     Returns (y, current_max (1,) device tensor, codes or None)."""
     _check(x, "x")
@@ -109,13 +132,14 @@ def fake_quant_online(x, width=8, flags=0, out=None, cur_out=None, want_codes=Fa
     y = torch.empty_like(x) if out is None else _check(out, "out")
     cur = torch.empty(1, dtype=torch.float32, device=x.device) if cur_out is None else _check(cur_out, "cur_out")
     codes = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_codes else None
-    ws = _workspace(x.device, _lib_().fq_act_workspace_bytes(n))
+    ws = _stat_ws(x, n, stat_ws)
     check_call(_lib_().fq_fake_quant_online(_ptr(x), _ptr(y), n, inner, int(width), int(flags), _ptr(cur),
                                             _ptr(codes), _ptr(ws), _stream(x)))
     return y, cur, codes
 
 
-def fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, want_stat=True, want_codes=False):
+def fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, want_stat=True, want_codes=False,
+                       stat_ws=None):
     """Same arithmetic with the stored threshold `input_max` (convert_conv2d.py:58).  `want_stat` also yields the
     batch statistic the reference computes in every mode (:56), fused into the same pass."""
     _check(x, "x")
@@ -126,7 +150,7 @@ def fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, w
     if want_stat:
         cur = torch.empty(1, dtype=torch.float32, device=x.device) if cur_out is None else _check(cur_out, "cur_out")
     codes = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_codes else None
-    ws = _workspace(x.device, _lib_().fq_act_workspace_bytes(n))
+    ws = _stat_ws(x, n, stat_ws)
     check_call(_lib_().fq_fake_quant_offline(_ptr(x), _ptr(y), n, inner, _ptr(threshold), int(width), int(flags),
                                              _ptr(cur), _ptr(codes), _ptr(ws), _stream(x)))
     return y, cur, codes

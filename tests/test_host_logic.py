@@ -1,0 +1,257 @@
+"""Host logic of the product (converters, fixed_params state machine, EMA arena, KL collection loop, nn.Conv2D
+plumbing) on CPU, with the HIP entry points replaced by the oracle (oracle/patch.py) — and compared with the goldens
+produced by the reference's own convert.py / convert_conv2d.py / initialize.py running over the same tiny net."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.patch import oracle_ops
+from quantization.mxnet_amd import mx
+from quantization.mxnet_amd.mx.gluon import nn
+from quantization.mxnet_amd.mx.gluon.block import reset_naming
+from quantization.mxnet_amd.quantize import convert
+from quantization.mxnet_amd.quantize.initialize import qparams_init
+
+
+def tiny_net(params):
+    reset_naming()
+    net = nn.HybridSequential(prefix="tiny_")
+    with net.name_scope():
+        net.add(nn.Conv2D(8, 3, padding=1, in_channels=3, use_bias=False), nn.Activation("relu"),
+                nn.Conv2D(8, 3, padding=1, groups=8, in_channels=8, use_bias=True), nn.Activation("relu"),
+                nn.Conv2D(12, 1, in_channels=8, use_bias=False), nn.Activation("relu"),
+                nn.GlobalAvgPool2D(), nn.Flatten(), nn.Dense(5, in_units=12))
+    net.initialize()
+    for name, p in net.collect_params().items():
+        p.set_data(mx.nd.array(params[name]))
+    return net
+
+
+def build(g, tag, quant_type, wt):
+    params = {k.split("/param/")[1]: v for k, v in g.items() if k.startswith(tag + "/param/")}
+    net = tiny_net(params)
+    convert_fn = {nn.Conv2D: convert.gen_conv2d_converter(quant_type=quant_type, weight_width=wt),
+                  nn.Dense: convert.gen_dense_converter(quant_type=quant_type, weight_width=wt),
+                  nn.Activation: None, nn.BatchNorm: None}
+    convert.convert_model(net, exclude=[net[0]], convert_fn=convert_fn)
+    qparams_init(net)
+    return net
+
+
+def close(a, b, what):
+    # conv/FC themselves run in torch on both sides; allow fp32 reassociation noise there, nothing more
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6, err_msg=what)
+
+
+@pytest.mark.parametrize("tag,quant_type,wt", [("layer_w8", "layer", 8), ("channel_w4", "channel", 4)])
+def test_cli_state_machine_matches_reference(golden, tag, quant_type, wt):
+    g = golden("g7_g9_ema_state")
+    with oracle_ops():
+        net = build(g, tag, quant_type, wt)
+        blocks = net.collect_quantized_blocks()
+        assert len(blocks) == int(g[tag + "/n_blocks"]) == 3
+        assert net[0] not in blocks and not hasattr(net[0], "quantize_args")          # excluded by identity
+        assert [getattr(b, "fixed_params", -9) for b in blocks] == [-1, -1, -9]       # Dense has no fixed_params
+        xs = g[tag + "/xs"]
+        # A. naive calibration: online + update_ema
+        net.quantize_input(enable=True, online=True)
+        for i, x in enumerate(xs):
+            y = net(mx.nd.array(x))
+            net.update_ema()
+            cur = np.asarray([float(b.current_input_max) for b in blocks], np.float32)
+            ema = np.asarray([b.input_max.data().asscalar() for b in blocks], np.float32)
+            np.testing.assert_array_equal(cur, g[tag + "/calib_cur"][i], "current_input_max step %d" % i)
+            np.testing.assert_array_equal(ema, g[tag + "/calib_ema"][i], "input_max EMA step %d" % i)
+            close(y.asnumpy(), g[tag + "/calib_logits"][i], "calibration logits %d" % i)
+        # the EMA state is one contiguous vector and the Parameters are views into it
+        arena = net.calibration_arena()
+        assert arena.state.numel() == 3
+        for i, b in enumerate(blocks):
+            assert b.input_max.data()._t.data_ptr() == arena.state.data_ptr() + 4 * i
+        # B. freeze + offline
+        net.fix_params()
+        net.quantize_input(enable=True, online=False)
+        np.testing.assert_array_equal([getattr(b, "fixed_params", -9) for b in blocks], g[tag + "/fixed_before"])
+        close(net(mx.nd.array(xs[0])).asnumpy(), g[tag + "/offline_logits0"], "offline logits 0")
+        np.testing.assert_array_equal([getattr(b, "fixed_params", -9) for b in blocks], g[tag + "/fixed_after"])
+        close(net(mx.nd.array(xs[1])).asnumpy(), g[tag + "/offline_logits1"], "offline logits 1")
+        for name, p in net.collect_params().items():
+            np.testing.assert_array_equal(p.data().asnumpy(), g["%s/frozen/%s" % (tag, name)],
+                                          "frozen parameter " + name)
+        # C. disable_quantize / D. online on frozen net / E. input quantisation off
+        net.disable_quantize()
+        close(net(mx.nd.array(xs[2])).asnumpy(), g[tag + "/disabled_logits"], "disabled")
+        net.enable_quantize()
+        net.quantize_input(enable=True, online=True)
+        close(net(mx.nd.array(xs[3])).asnumpy(), g[tag + "/online_frozen_logits"], "online on frozen")
+        net.quantize_input(enable=False)
+        close(net(mx.nd.array(xs[4])).asnumpy(), g[tag + "/noinput_logits"], "no input quant")
+
+
+def test_converter_api_surface():
+    conv = nn.Conv2D(4, 3, in_channels=2)
+    conv.initialize()
+    convert.gen_conv2d_converter(weight_width=4, quant_type="group", input_signed=True, input_width=6,
+                                 wino_quantize="F43")(conv)
+    qa = conv.quantize_args
+    assert (qa.wt_width, qa.quant_type, qa.in_signed, qa.in_width, qa.wino_quantize, qa.fake_bn,
+            qa.quantize_input) == (4, "group", True, 6, "F43", False, True)
+    assert conv.fixed_params == -1 and conv.enable_quantize and conv.quantize_input
+    assert conv.quantize_input_offline is False and conv.current_input_max == 0.
+    assert conv.input_max.shape == (1,) and "input_max" in conv._reg_params
+    assert callable(conv.origin_forward)
+    with pytest.raises(AssertionError):
+        convert.gen_conv2d_converter(wino_quantize="F99")
+    with pytest.raises(AssertionError):
+        convert.gen_dense_converter()(conv)
+    dense = nn.Dense(3, in_units=4)
+    convert.gen_dense_converter(quant_type="group")(dense)
+    assert dense.quantize_args.quant_type == "channel" and not hasattr(dense, "fixed_params")
+    act = nn.Activation("relu")
+    convert.gen_act_converter(width=4)(act)
+    assert act.quantize_args.width == 4 and act.act_max.shape == (1,)
+    assert set(convert.default_convert_fn) == {nn.Conv2D, nn.Dense, nn.Activation, nn.BatchNorm}
+
+
+def test_dispatch_is_by_exact_type_with_custom_override_and_exclude():
+    class MyConv(nn.Conv2D):
+        pass
+    reset_naming()
+    net = nn.HybridSequential()
+    a, b, c = nn.Conv2D(2, 1, in_channels=2), MyConv(2, 1, in_channels=2), nn.Conv2D(2, 1, in_channels=2)
+    net.add(a, b, c)
+    marker = []
+    convert.convert_model(net, exclude=[c], custom_fn={b: lambda m: marker.append(m)})
+    assert hasattr(a, "quantize_args") and not hasattr(b, "quantize_args") and not hasattr(c, "quantize_args")
+    assert marker == [b]
+    assert net.collect_quantized_blocks() == [a]
+    for meth in ("update_ema", "collect_quantized_blocks", "quantize_input", "enable_quantize", "disable_quantize",
+                 "fix_params"):
+        assert callable(getattr(net, meth))
+
+
+def test_group_quant_on_general_grouped_conv_raises_like_the_reference_broadcast():
+    conv = nn.Conv2D(8, 1, groups=2, in_channels=4, use_bias=False)
+    conv.initialize()
+    convert.gen_conv2d_converter(quant_type="group", quantize_input=False)(conv)
+    with oracle_ops(), pytest.raises(ValueError, match="broadcast"):
+        conv(mx.nd.array(np.ones((1, 4, 2, 2), np.float32)))
+
+
+def test_product_on_cpu_without_oracle_raises():
+    from quantization.mxnet_amd._lib import FakeQuantError
+    conv = nn.Conv2D(4, 1, in_channels=2)
+    conv.initialize()
+    convert.gen_conv2d_converter()(conv)
+    conv.input_max.initialize(mx.initializer.Constant(0))
+    with pytest.raises(FakeQuantError, match="no CPU fallback"):
+        conv(mx.nd.array(np.ones((1, 2, 3, 3), np.float32)))
+
+
+def test_collect_feature_maps_and_kl_loop(golden):
+    """The calibration driver of simulate_quantization.py:294-315 against the reference's collect_feature_maps."""
+    from quantization.mxnet_amd.quantize.distribution_calibrate import collect_feature_maps, kl_calibrate
+    g = golden("g3_collect")
+
+    class Blk(nn.HybridBlock):
+        def __init__(self, k):
+            super().__init__()
+            self.k = k
+            self.quantize_args = True
+
+        def forward(self, x):
+            return x
+
+    class Net(nn.HybridBlock):
+        def __init__(self):
+            super().__init__()
+            self.b = [Blk(0), Blk(1), Blk(2)]
+
+        def collect_quantized_blocks(self):
+            return self.b
+
+        def forward(self, X):
+            for k, b in enumerate(self.b):
+                fm = mx.nd.relu(X) * float(k + 1)
+                if k == 2:
+                    fm = mx.nd.NDArray(fm._t[:, :, ::2, ::2].contiguous())
+                b(fm)
+            return X
+    net = Net()
+    loader = [(mx.nd.array(b), None) for b in g["batches"]]
+    with oracle_ops():
+        hists, maxes = collect_feature_maps(net, 2048, loader, mx.cpu())
+        for k, b in enumerate(net.b):
+            np.testing.assert_array_equal(hists[b], g["hist%d" % k])
+            assert maxes[b] == g["fm_max%d" % k] and hists[b].dtype == np.float32
+        assert all(len(b._forward_hooks) == 0 for b in net.b)            # hooks detached (:111-112)
+        gk = golden("g2_kl")
+        assert kl_calibrate(gk["sparse/hist_b256"], 16, 16, 256) == int(gk["sparse/best_b256_L16"])
+        with pytest.raises(AssertionError, match="min_bins should be greater than levels"):
+            kl_calibrate(gk["sparse/hist_b256"], 32, 16, 256)
+
+        class RawNet(Net):
+            def forward(self, X):
+                self.b[0](X)
+                return X
+        raw = RawNet()
+        raw.b = raw.b[:1]
+        bad = [(mx.nd.array(np.float32([[[[1.0, -0.5], [2.0, 0.0]]]])), None)]
+        with pytest.raises(AssertionError, match="Activation should >=0"):
+            collect_feature_maps(raw, 16, bad, mx.cpu())
+        with pytest.raises(AssertionError, match="all zero-value"):
+            collect_feature_maps(raw, 16, [(mx.nd.array(np.zeros((1, 1, 2, 2), np.float32)), None)], mx.cpu())
+
+
+@pytest.mark.parametrize("use_bias", [0, 1])
+@pytest.mark.parametrize("groups", [1, 2])
+def test_nn_conv2d_three_way(golden, use_bias, groups):
+    """reference tests/test_quantized_conv.py:36-57, asserted: int-code conv == the reference's result."""
+    from quantization.mxnet_amd import nn as qnn
+    g = golden("g8_quantized_conv")
+    tag = "conv_b%d_g%d" % (use_bias, groups)
+    with oracle_ops():
+        for quantized in (False, True):
+            c = qnn.Conv2D(10, 3, 1, 1, in_channels=2, groups=groups, use_bias=bool(use_bias), quantized=quantized,
+                           input_dtype="uint8", weight_dtype="int8")
+            c.initialize()
+            c.weight.set_data(mx.nd.array(g[tag + "/w"]))
+            if use_bias:
+                c.bias.set_data(mx.nd.array(g[tag + "/b"]))
+            y = c(mx.nd.array(g[tag + "/x"])).asnumpy()
+            if quantized:
+                np.testing.assert_array_equal(y, g[tag + "/y_int"])
+            else:
+                np.testing.assert_allclose(y, g[tag + "/y_float"], rtol=1e-5, atol=1e-5)
+
+
+def test_ste_function_api(golden):
+    g = golden("g4_activation")
+    tag = "conv_4x8x7x7_u_w8"
+    with oracle_ops():
+        ste = convert.LinearQuantizeSTE(g[tag + "/online_scale"], g[tag + "/online_max"], 0.0)
+        y = ste(mx.nd.array(g[tag + "/x"]))
+        np.testing.assert_array_equal(y.asnumpy(), g[tag + "/online_y"])
+        dy = mx.nd.array(np.ones(3, np.float32))
+        assert ste.backward(dy) is dy
+        assert convert.LinearQuantizeSTE(1.0).clip_min == 0.0
+
+
+def test_model_zoo_layouts_match_cli_exclusions():
+    from quantization.mxnet_amd.mx.gluon.model_zoo import get_model
+    np.random.seed(7)
+    net = get_model("mobilenet1.0", classes=1000)
+    convert.convert_model(net, exclude=[net.features[0], net.features[1]],
+                          convert_fn={nn.Conv2D: convert.gen_conv2d_converter(), nn.Dense: convert.gen_dense_converter(),
+                                      nn.Activation: None, nn.BatchNorm: None})
+    assert len(net.collect_quantized_blocks()) == 27
+    net = get_model("resnet50_v1", classes=1000)
+    convert.convert_model(net, exclude=[net.features[0], net.features[1]])
+    assert len(net.collect_quantized_blocks()) == 53
+    net = get_model("cifar_resnet20_v1", classes=10)
+    convert.convert_model(net, exclude=[net.features[0], net.features[1], net.features[2][0].body[0],
+                                        net.features[2][0].body[1]])
+    assert len(net.collect_quantized_blocks()) == 20
+    net = get_model("mobilenetv2_1.0", classes=1000)
+    convert.convert_model(net, exclude=[net.features[0], net.features[1], net.output[0]])
+    assert len(net.collect_quantized_blocks()) == 52
