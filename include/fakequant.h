@@ -49,6 +49,24 @@ int fq_version(void);
 /* Name (e.g. "gfx950"), compute units and wavefront size of the current HIP device. */
 int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront);
 
+/* ---- optional per-kernel timing (bench.py's roofline leg) ------------------------------------------------------
+ * When enabled, every launch of the streaming kernels is bracketed by a pair of HIP events recorded on the launch
+ * stream.  fq_profile_read() waits for the recorded events (the ONLY call in this library that synchronises),
+ * adds up durations / launches / algorithmic bytes per kernel id since the last reset, and releases the events.
+ * Do not enable during hipGraph capture.                                                                          */
+#define FQ_KERNEL_STAT 0          /* absmax_per_sample_kernel      : 4 B/elem (read x)                              */
+#define FQ_KERNEL_APPLY_ONLINE 1  /* act_apply_kernel<ONLINE>      : 8 B/elem (read x, write y)                     */
+#define FQ_KERNEL_APPLY_OFFLINE 2 /* act_apply_kernel<!ONLINE>     : 8 B/elem                                       */
+#define FQ_KERNEL_WEIGHT 3        /* weight kernels                : 8 B/elem                                       */
+#define FQ_KERNEL_HISTOGRAM 4     /* histogram_kernel              : 4 B/elem                                       */
+#define FQ_KERNEL_COUNT 5
+int fq_profile_enable(int on);
+int fq_profile_reset(void);
+int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes);
+/* Median elapsed time (ms) of an event pair bracketing a one-element fill kernel on `stream`: the fixed cost the
+ * event pair adds to every bracketed launch (marker packets + dispatch latency).  `scratch`: >= 4 device bytes.   */
+int fq_profile_calibrate(void* scratch, int repeats, double* median_ms, fqStream_t stream);
+
 /* ---- activations ---------------------------------------------------------------------------------------------
  * x is (n, inner) = (N, C*H*W).  `ws` is a caller workspace of fq_act_workspace_bytes(n) bytes.                  */
 size_t fq_act_workspace_bytes(int64_t n);

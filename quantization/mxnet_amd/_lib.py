@@ -22,6 +22,11 @@ EXPORTS = {
     "fq_last_error": (ctypes.c_char_p, []),
     "fq_version": (_int, []),
     "fq_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "fq_profile_enable": (_int, [_int]),
+    "fq_profile_reset": (_int, []),
+    "fq_profile_read": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
+                               ctypes.POINTER(ctypes.c_double)]),
+    "fq_profile_calibrate": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_double), _vp]),
     "fq_act_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "fq_absmax_per_sample": (_int, [_vp, _i64, _i64, _uint, _vp, _vp]),
     "fq_batch_mean": (_int, [_vp, _i64, _vp, _vp]),

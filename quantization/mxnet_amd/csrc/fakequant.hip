@@ -15,12 +15,15 @@
 // Reference lines each kernel replaces are cited at its C entry point in include/fakequant.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "fakequant.h"
 
@@ -53,6 +56,38 @@ int fail(int code, const char* fmt, ...) {
     if (!(cond)) return fail(FQ_ERR_INVALID, __VA_ARGS__);    \
   } while (0)
 #define FQ_LAUNCH_CHECK() FQ_HIP(hipGetLastError())
+
+// ---- optional per-kernel event timing (fq_profile_*) -----------------------------------------------------------
+struct ProfRec {
+  int kid;
+  double bytes;
+  hipEvent_t a, b;
+};
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+  bool on;
+  ProfRec r;
+  hipStream_t st;
+  ProfScope(int kid, double bytes, hipStream_t s) : on(g_prof_on), st(s) {
+    if (!on) return;
+    r.kid = kid;
+    r.bytes = bytes;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(r.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
+  }
+};
 
 int g_num_cu = 0;
 int num_cu() {
@@ -788,6 +823,7 @@ int launch_absmax(const float* x, int64_t n, int64_t inner, bool use_abs, float*
   const bool vec = (inner % kVec == 0) && aligned16(x);
   const int grid = grid_for(ck.total);
   const bool ntl = (policy_stat() & kPolNtLoad) != 0;
+  ProfScope prof(FQ_KERNEL_STAT, 4.0 * (double)n * (double)inner, st);
 #define FQ_ABSMAX(A, V, L)                                                                                    \
   hipLaunchKernelGGL((absmax_per_sample_kernel<A, V, L>), dim3(grid), dim3(kBlock), 0, st, x, inner,          \
                      ck.chunks_per_sample, ck.total, out)
@@ -827,6 +863,7 @@ int launch_apply(const float* x, float* y, int32_t* codes, int64_t n, int64_t in
   int pol = ONLINE ? policy_online() : policy_offline();
   if (x == y) pol &= ~kPolNtLoad;
   const int reverse = (pol & kPolReverse) ? 1 : 0;
+  ProfScope prof(ONLINE ? FQ_KERNEL_APPLY_ONLINE : FQ_KERNEL_APPLY_OFFLINE, 8.0 * (double)n * (double)inner, st);
 #define FQ_APPLY(A, V, L, S)                                                                                     \
   hipLaunchKernelGGL((act_apply_kernel<ONLINE, STATS, CODES, A, V, L, S>), dim3(grid), dim3(kBlock), 0, st, x,   \
                      y, codes, inner, ck.chunks_per_sample, ck.total, stat_in, (int)n, thr, levels, lo_neg, eps, \
@@ -873,6 +910,66 @@ int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront)
   }
   if (compute_units) *compute_units = prop.multiProcessorCount;
   if (wavefront) *wavefront = prop.warpSize;
+  return FQ_OK;
+}
+
+int fq_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return FQ_OK;
+}
+
+int fq_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  return FQ_OK;
+}
+
+int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes) {
+  FQ_REQUIRE(kernel_id >= 0 && kernel_id < FQ_KERNEL_COUNT, "fq_profile_read: bad kernel id %d", kernel_id);
+  FQ_REQUIRE(total_ms && launches && total_bytes, "fq_profile_read: null pointer");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double ms = 0.0, bytes = 0.0;
+  int64_t cnt = 0;
+  for (auto& r : g_prof) {
+    if (r.kid != kernel_id) continue;
+    FQ_HIP(hipEventSynchronize(r.b));
+    float t = 0.f;
+    FQ_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t;
+    bytes += r.bytes;
+    ++cnt;
+  }
+  *total_ms = ms;
+  *launches = cnt;
+  *total_bytes = bytes;
+  return FQ_OK;
+}
+
+int fq_profile_calibrate(void* scratch, int repeats, double* median_ms, fqStream_t stream) {
+  FQ_REQUIRE(scratch && median_ms && repeats > 0 && repeats <= 4096, "fq_profile_calibrate: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  // Enqueue every bracketed launch back to back (a busy queue, like the timed region), synchronise once at the end.
+  std::vector<hipEvent_t> ev((size_t)repeats * 2);
+  for (auto& e : ev) FQ_HIP(hipEventCreate(&e));
+  for (int i = 0; i < repeats; ++i) {
+    FQ_HIP(hipEventRecord(ev[2 * i], st));
+    hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, (float*)scratch, (int64_t)1, 0.0f);
+    FQ_HIP(hipEventRecord(ev[2 * i + 1], st));
+  }
+  FQ_HIP(hipEventSynchronize(ev.back()));
+  std::vector<float> ts;
+  for (int i = 0; i < repeats; ++i) {
+    float t = 0.f;
+    FQ_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+    ts.push_back(t);
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  std::sort(ts.begin(), ts.end());
+  *median_ms = ts[ts.size() / 2];
   return FQ_OK;
 }
 
@@ -979,6 +1076,7 @@ int fq_weight_fake_quant(const float* w, float* w_q, int64_t rows, int64_t row_l
     if (rpb > balanced) rpb = (int)balanced;
     const int64_t blocks = (rows + rpb - 1) / rpb;
     const size_t lds = (size_t)(kWTile + 1024) * sizeof(float);
+    ProfScope prof(FQ_KERNEL_WEIGHT, 8.0 * (double)rows * (double)row_len, st);
     hipLaunchKernelGGL(weight_rows_lds_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, st, w, w_q, rows,
                        (int)row_len, rpb, levels, scales_out);
     FQ_LAUNCH_CHECK();
@@ -1059,6 +1157,7 @@ int fq_histogram_accumulate(const float* x, int64_t numel, const float* max_dev,
   FQ_REQUIRE(numel > 0, "fq_histogram_accumulate: empty tensor");
   FQ_REQUIRE(bins > 0 && bins <= 8192, "fq_histogram_accumulate: bins=%d out of range (1..8192)", bins);
   const int grid = grid_for((numel + kChunk - 1) / kChunk);
+  ProfScope prof(FQ_KERNEL_HISTOGRAM, 4.0 * (double)numel, (hipStream_t)stream);
   hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(kBlock), (size_t)4 * bins * sizeof(unsigned int),
                      (hipStream_t)stream, x, numel, aligned16(x) ? 1 : 0, max_dev, bins,
                      (unsigned long long*)hist, (unsigned int*)neg_count);

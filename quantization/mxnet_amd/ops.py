@@ -73,6 +73,38 @@ def device_info():
     return {"arch": arch.value.decode(), "compute_units": cu.value, "wavefront": wf.value}
 
 
+KERNEL_IDS = {"stat": 0, "apply_online": 1, "apply_offline": 2, "weight": 3, "histogram": 4}
+
+
+def profile_enable(on=True):
+    """Bracket every streaming-kernel launch with HIP events on its launch stream (include/fakequant.h)."""
+    check_call(_lib_().fq_profile_enable(1 if on else 0))
+
+
+def profile_reset():
+    check_call(_lib_().fq_profile_reset())
+
+
+def profile_read():
+    """{kernel: {"ms": total, "launches": n, "bytes": algorithmic bytes}} since the last reset (synchronises)."""
+    out = {}
+    for name, kid in KERNEL_IDS.items():
+        ms, n, b = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+        check_call(_lib_().fq_profile_read(kid, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)))
+        out[name] = {"ms": ms.value, "launches": n.value, "bytes": b.value}
+    return out
+
+
+def profile_event_overhead_ms(device=None, repeats=200):
+    """Fixed cost of one bracketing event pair around a trivial kernel (see fq_profile_calibrate)."""
+    device = default_device() if device is None else device
+    scratch = torch.zeros(4, dtype=torch.float32, device=device)
+    ms = ctypes.c_double(0)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    check_call(_lib_().fq_profile_calibrate(_ptr(scratch), int(repeats), ctypes.byref(ms), st))
+    return ms.value
+
+
 def act_flags(signed=False, lo_neg_max=None, no_abs=False, no_eps=False):
     """`lo_neg_max` defaults to `signed` (conv: convert_conv2d.py:59-63); Dense passes False (convert_dense.py:49)."""
     if lo_neg_max is None:

@@ -1,0 +1,217 @@
+"""GPU whole-net parity for the BASELINE.json configs (reduced spatial size so the oracle finishes in seconds):
+every quantised block of the converted net is spied on while the net runs on the MI355X; each block's RAW input and
+weight are then pushed through the CPU oracle and must reproduce, bit for bit, what the HIP path handed to the
+convolution.  (End-to-end logits cannot be compared bit-exactly across devices: MIOpen and the CPU convolution sum in
+different orders, so activations differ in the last bits BEFORE they reach the next fake-quant.)"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from quantization.mxnet_amd import mx
+    return mx.gpu(0)
+
+
+def _build(model, classes, ctx, quant_type="layer", wt=8, in_w=8, signed=False, wino="none"):
+    from quantization.mxnet_amd.mx.gluon import nn
+    from quantization.mxnet_amd.mx.gluon.model_zoo import get_model
+    from quantization.mxnet_amd.quantize import convert
+    from quantization.mxnet_amd.quantize.initialize import qparams_init
+    np.random.seed(7)
+    net = get_model(model, classes=classes)
+    convert_fn = {nn.Conv2D: convert.gen_conv2d_converter(quantize_input=True, wino_quantize=wino, input_signed=signed,
+                                                          weight_width=wt, input_width=in_w, quant_type=quant_type),
+                  nn.Dense: convert.gen_dense_converter(quantize_input=True, input_signed=signed, weight_width=wt,
+                                                        input_width=in_w, quant_type=quant_type),
+                  nn.Activation: None, nn.BatchNorm: None}
+    exclude = [net.features[0], net.features[1]]
+    if model.startswith("mobilenetv2_"):
+        exclude.append(net.output[0])
+    if model.startswith("cifar_resnet"):
+        exclude.extend([net.features[2][0].body[0], net.features[2][0].body[1]])
+    convert.convert_model(net, exclude=exclude, convert_fn=convert_fn)
+    qparams_init(net)
+    net.collect_params().reset_ctx(ctx)
+    return net
+
+
+class Spy(object):
+    """Capture, per quantised block and per forward: raw input, raw weight, what reached origin_forward."""
+
+    def __init__(self, net):
+        self.records = []
+        self.blocks = net.collect_quantized_blocks()
+        for b in self.blocks:
+            self._wrap(b)
+
+    def _wrap(self, b):
+        orig = b.origin_forward
+        spy = self
+
+        def pre(m, args):
+            m._spy_raw = args[0]._t.detach().clone()
+            m._spy_w = m.weight.data()._t.detach().clone()
+            m._spy_fixed = getattr(m, "fixed_params", None)
+        b.register_forward_pre_hook(pre)
+
+        def wrapped(F, xq, wq, bias=None):
+            spy.records.append(dict(block=b, x=b._spy_raw, w=b._spy_w, xq=xq._t.detach().clone(),
+                                    wq=wq._t.detach().clone(), fixed=b._spy_fixed,
+                                    cur=b._fq_cur.detach().clone() if hasattr(b, "_fq_cur") else None,
+                                    thr=b.input_max.data()._t.detach().clone()))
+            return orig(F, xq, wq, bias)
+        b.origin_forward = wrapped
+
+
+def _check_records(records, signed, in_w, wt, quant_type, wino, offline):
+    from quantization.mxnet_amd.mx.gluon import nn
+    assert records
+    for r in records:
+        b = r["block"]
+        x, xq = r["x"].cpu().numpy(), r["xq"].cpu().numpy()
+        thr = np.float32(r["thr"].cpu().numpy()[0]) if offline else None
+        if isinstance(b, nn.Dense):
+            want, cur, _, _ = O.dense_input_fake_quant(x, signed, in_w, offline_threshold=thr)
+        else:
+            want, cur, _, _ = O.conv_input_fake_quant(x, signed, in_w, offline_threshold=thr)
+        assert np.array_equal(xq, want), "%s: activation fake-quant differs from the oracle" % b.name
+        assert r["cur"].cpu().numpy()[0] == cur, "%s: current_input_max" % b.name
+        w, wq = r["w"].cpu().numpy(), r["wq"].cpu().numpy()
+        if isinstance(b, nn.Conv2D) and r["fixed"] == 1:
+            assert np.array_equal(wq, w)                      # frozen weights pass through (convert_conv2d.py:96-97)
+            continue
+        if isinstance(b, nn.Conv2D) and quant_type == "channel" and wino != "none" and tuple(w.shape[2:]) == (3, 3):
+            want_w, _, _ = O.wino_weight_fake_quant(w, wino, wt)
+        elif isinstance(b, nn.Dense):
+            want_w, _ = O.weight_fake_quant(w, "channel" if quant_type in ("channel", "group") else "layer", wt)
+        else:
+            want_w, _ = O.weight_fake_quant(w, quant_type, wt, num_group=b._kwargs["num_group"])
+        assert np.array_equal(wq, want_w), "%s: weight fake-quant differs from the oracle" % b.name
+
+
+CONFIGS = [
+    # (BASELINE config, model, classes, hw, batch, kwargs)
+    ("cfg1 cifar_resnet20_v1 per-layer W8A8 online", "cifar_resnet20_v1", 10, 32, 8, dict()),
+    ("cfg2 mobilenet1.0 per-layer W8A8 online", "mobilenet1.0", 1000, 64, 4, dict()),
+    ("cfg3 resnet50_v1 per-channel W8A8", "resnet50_v1", 1000, 64, 2, dict(quant_type="channel")),
+    ("cfg4 mobilenetv2_1.0 per-channel W4A8", "mobilenetv2_1.0", 1000, 64, 4, dict(quant_type="channel", wt=4)),
+    ("cfg5 resnet50_v1 Winograd F43 per-channel", "resnet50_v1", 1000, 64, 2, dict(quant_type="channel", wino="F43")),
+    ("signed int8 inputs, group-wise weights", "mobilenet1.0", 1000, 32, 4, dict(signed=True, quant_type="group")),
+]
+
+
+@pytest.mark.parametrize("name,model,classes,hw,batch,kw", CONFIGS, ids=[c[0].split()[0] + "_" + c[1] for c in CONFIGS])
+def test_every_quantised_block_matches_oracle_online_then_frozen(gpu, name, model, classes, hw, batch, kw):
+    from quantization.mxnet_amd import mx
+    net = _build(model, classes, gpu, **kw)
+    spy = Spy(net)
+    rng = np.random.default_rng(7)
+    X = mx.nd.array(rng.standard_normal((batch, 3, hw, hw)).astype(np.float32), ctx=gpu)
+    net.fix_params()
+    net.quantize_input(enable=True, online=True)
+    out = net(X)
+    assert out.shape == (batch, classes) and np.isfinite(out.asnumpy()).all()
+    args = dict(signed=kw.get("signed", False), in_w=kw.get("in_w", 8), wt=kw.get("wt", 8),
+                quant_type=kw.get("quant_type", "layer"), wino=kw.get("wino", "none"))
+    _check_records(spy.records, offline=False, **args)
+    n_first = len(spy.records)
+    assert n_first == len(spy.blocks)
+    from quantization.mxnet_amd.mx.gluon import nn
+    assert all(b.fixed_params == 1 for b in spy.blocks if isinstance(b, nn.Conv2D))
+    spy.records.clear()
+    net(X)                                                    # second forward: weights frozen
+    _check_records(spy.records, offline=False, **args)
+
+
+def test_naive_ema_calibration_then_offline_eval(gpu):
+    """Config 4's flow (simulate_quantization.py:320-323,337-339) on the GPU; EMA checked step by step."""
+    from quantization.mxnet_amd import mx
+    net = _build("mobilenetv2_1.0", 1000, gpu, quant_type="channel", wt=4)
+    spy = Spy(net)
+    blocks = spy.blocks
+    rng = np.random.default_rng(11)
+    state = np.zeros(len(blocks), np.float32)
+    net.quantize_input(enable=True, online=True)
+    for step in range(4):
+        X = mx.nd.array(rng.standard_normal((4, 3, 64, 64)).astype(np.float32) * (1 + 0.3 * step), ctx=gpu)
+        spy.records.clear()
+        net(X)
+        net.update_ema()
+        cur = np.asarray([float(b.current_input_max) for b in blocks], np.float32)
+        state = O.ema_update(state, cur, 0.9)
+        got = np.asarray([b.input_max.data().asscalar() for b in blocks], np.float32)
+        assert np.array_equal(got, state), "EMA step %d" % step
+        _check_records(spy.records, signed=False, in_w=8, wt=4, quant_type="channel", wino="none", offline=False)
+    arena = net.calibration_arena()
+    assert arena.state.is_cuda and arena.state.numel() == len(blocks)
+    net.fix_params()
+    net.quantize_input(enable=True, online=False)
+    spy.records.clear()
+    net(X)
+    _check_records(spy.records, signed=False, in_w=8, wt=4, quant_type="channel", wino="none", offline=True)
+
+
+def test_kl_calibration_flow(gpu):
+    """Config 3's flow (simulate_quantization.py:294-315): disable_quantize -> collect_feature_maps -> kl_calibrate ->
+    thresholds -> offline eval; histograms and best_bins against the oracle on the captured block inputs."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.quantize.distribution_calibrate import collect_feature_maps, kl_calibrate, \
+        kl_calibrate_many
+    net = _build("cifar_resnet20_v1", 10, gpu, quant_type="channel")
+    blocks = net.collect_quantized_blocks()
+    captured = {b: [] for b in blocks}
+    hooks = [b.register_forward_pre_hook(lambda m, a: captured[m].append(a[0].asnumpy())) for b in blocks]
+    rng = np.random.default_rng(5)
+    loader = [(mx.nd.array(rng.standard_normal((8, 3, 32, 32)).astype(np.float32)), None) for _ in range(3)]
+    net.disable_quantize()
+    hists, maxes = collect_feature_maps(net, 2048, loader, gpu)
+    for h in hooks:
+        h.detach()
+    assert set(hists) == set(blocks)
+    for b in blocks:
+        want, fm_max = None, None
+        for fm in captured[b]:
+            h, m = O.discrete_histogram(fm, 2048, fm_max)
+            fm_max = m if fm_max is None else fm_max
+            want = h if want is None else want + h
+        assert maxes[b] == fm_max and np.array_equal(hists[b], want), b.name
+    levels = 2 ** 8
+    best_all = kl_calibrate_many([hists[b] for b in blocks], levels, levels, 2048)
+    for b, best in list(zip(blocks, best_all))[:3] + list(zip(blocks, best_all))[-2:]:
+        assert best == O.kl_calibrate(hists[b], levels, levels, 2048), b.name
+        assert kl_calibrate(hists[b], levels=levels, min_bins=levels, bins=2048) == best
+    for b, best in zip(blocks, best_all):
+        th = (best + 0.5) * (maxes[b] / 2048)
+        b.input_max.set_data(mx.nd.array([th], ctx=gpu))
+    net.enable_quantize()
+    net.fix_params()
+    net.quantize_input(enable=True, online=False)
+    spy = Spy(net)
+    out = net(loader[0][0].as_in_context(gpu))
+    assert np.isfinite(out.asnumpy()).all()
+    _check_records(spy.records, signed=False, in_w=8, wt=8, quant_type="channel", wino="none", offline=True)
+
+
+def test_nn_conv2d_int_code_path_on_gpu(gpu, golden):
+    from quantization.mxnet_amd import mx, nn as qnn
+    g = golden("g8_quantized_conv")
+    for use_bias in (0, 1):
+        for groups in (1, 2):
+            tag = "conv_b%d_g%d" % (use_bias, groups)
+            c = qnn.Conv2D(10, 3, 1, 1, in_channels=2, groups=groups, use_bias=bool(use_bias), quantized=True,
+                           input_dtype="uint8", weight_dtype="int8")
+            c.initialize(ctx=gpu)
+            c.weight.set_data(mx.nd.array(g[tag + "/w"]))
+            if use_bias:
+                c.bias.set_data(mx.nd.array(g[tag + "/b"]))
+            y = c(mx.nd.array(g[tag + "/x"], ctx=gpu)).asnumpy()
+            assert np.array_equal(y, g[tag + "/y_int"]), tag
+            assert np.abs(y - g[tag + "/y_sim"]).max() < 0.1 and np.abs(y - g[tag + "/y_float"]).max() < 0.1
