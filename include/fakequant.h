@@ -78,6 +78,13 @@ int fq_absmax_per_sample(const float* x, int64_t n, int64_t inner, unsigned flag
 
 /* Replaces `.mean()` of the per-sample maxima (convert_conv2d.py:56): out[0] <- fp32(sum_fp64(v[0..n)))/n.      */
 int fq_batch_mean(const float* v, int64_t n, float* out, fqStream_t stream);
+/* Row-wise form for L layers at once (the multi-GPU calibration step): out[r] <- batch mean of v[r*row_stride ..+n). */
+int fq_batch_mean_rows(const float* v, int64_t rows, int64_t n, int64_t row_stride, float* out, fqStream_t stream);
+
+/* Sharded-batch form (dist.py): `packs` holds `world` records of `stride` floats, record w = {n_w, v_w[0..n_w)} as
+ * all-gathered from the ranks; out[0] <- the batch mean over the concatenation v_0 | v_1 | ... (global sample order),
+ * same ordered fp64 accumulation.  No host round trip for the (possibly ragged) counts.                            */
+int fq_batch_mean_gathered(const float* packs, int world, int64_t stride, float* out, fqStream_t stream);
 
 /* Replaces convert_conv2d.py:56-66 + ste_func.py:41 in ONLINE mode (threshold = this batch's statistic):
  *   cur = mean_n max|x[n]|;  scale = cur/levels;  y = roundf(clip(x, lo, cur) / (scale + eps)) * scale.

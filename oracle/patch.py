@@ -60,6 +60,24 @@ def batch_mean(v, out=None):
     return r
 
 
+def batch_mean_gathered(packs, out=None):
+    a = _np(packs)
+    vals = np.concatenate([rec[1:1 + int(rec[0])] for rec in a])
+    r = _t(np.asarray([O.batch_mean(vals)], dtype=F32))
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def batch_mean_rows(v, out=None):
+    r = _t(np.asarray([O.batch_mean(row) for row in _np(v)], dtype=F32))
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 def fake_quant_online(x, width=8, flags=0, out=None, cur_out=None, want_codes=False, stat_ws=None):
     per = _stat(x, bool(flags & 4))
     if stat_ws is not None:
@@ -179,7 +197,7 @@ def default_device(what="this call"):
     return torch.device("cpu")
 
 
-_REPLACED = ["require_hip", "default_device", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+_REPLACED = ["require_hip", "default_device", "batch_mean_rows", "batch_mean_gathered", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

@@ -30,6 +30,8 @@ EXPORTS = {
     "fq_act_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "fq_absmax_per_sample": (_int, [_vp, _i64, _i64, _uint, _vp, _vp]),
     "fq_batch_mean": (_int, [_vp, _i64, _vp, _vp]),
+    "fq_batch_mean_gathered": (_int, [_vp, _int, _i64, _vp, _vp]),
+    "fq_batch_mean_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "fq_fake_quant_online": (_int, [_vp, _vp, _i64, _i64, _int, _uint, _vp, _vp, _vp, _vp]),
     "fq_fake_quant_offline": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp, _vp]),
     "fq_ste_forward": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _f32, _f32, _f32, _vp]),

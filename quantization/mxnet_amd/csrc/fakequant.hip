@@ -297,6 +297,26 @@ __global__ void batch_mean_kernel(const float* __restrict__ v, int n, float* __r
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = batch_mean_dev(v, n);
 }
 
+__global__ void batch_mean_gathered_kernel(const float* __restrict__ packs, int world, int64_t stride,
+                                           float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double acc = 0.0;
+  long long total = 0;
+  for (int w = 0; w < world; ++w) {
+    const float* rec = packs + (int64_t)w * stride;
+    const int c = (int)rec[0];
+    for (int i = 0; i < c; ++i) acc += (double)rec[1 + i];
+    total += c;
+  }
+  out[0] = (float)acc / (float)total;
+}
+
+__global__ void batch_mean_rows_kernel(const float* __restrict__ v, int64_t rows, int n, int64_t stride,
+                                       float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) out[r] = batch_mean_dev(v + r * stride, n);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K2: apply.  ONLINE: threshold = mean of stat_in[0..n);  else threshold = thr[0].
 //     STATS (offline only): also produce the per-sample statistic of x into stat_out (fused, same pass).
@@ -990,6 +1010,23 @@ int fq_batch_mean(const float* v, int64_t n, float* out, fqStream_t stream) {
   FQ_REQUIRE(v && out, "fq_batch_mean: null pointer");
   FQ_REQUIRE(n > 0 && n < (1ll << 31), "fq_batch_mean: bad n=%lld", (long long)n);
   hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, v, (int)n, out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_batch_mean_gathered(const float* packs, int world, int64_t stride, float* out, fqStream_t stream) {
+  FQ_REQUIRE(packs && out, "fq_batch_mean_gathered: null pointer");
+  FQ_REQUIRE(world > 0 && stride > 1, "fq_batch_mean_gathered: bad shape");
+  hipLaunchKernelGGL(batch_mean_gathered_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, packs, world, stride, out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_batch_mean_rows(const float* v, int64_t rows, int64_t n, int64_t row_stride, float* out, fqStream_t stream) {
+  FQ_REQUIRE(v && out, "fq_batch_mean_rows: null pointer");
+  FQ_REQUIRE(rows > 0 && n > 0 && n < (1ll << 31) && row_stride >= n, "fq_batch_mean_rows: bad shape");
+  hipLaunchKernelGGL(batch_mean_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, v,
+                     rows, (int)n, row_stride, out);
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -142,6 +142,26 @@ def batch_mean(v, out=None):
     _check(v, "v")
     out = torch.empty(1, dtype=torch.float32, device=v.device) if out is None else _check(out, "out")
     check_call(_lib_().fq_batch_mean(_ptr(v), v.numel(), _ptr(out), _stream(v)))
+    return out
+
+
+def batch_mean_gathered(packs, out=None):
+    """Batch mean over all-gathered per-rank records {n_w, v_w[0..n_w)} in rank order (dist.py); packs: (W, stride)."""
+    _check(packs, "packs")
+    if packs.dim() != 2:
+        raise ValueError("batch_mean_gathered wants a (world, stride) tensor")
+    out = torch.empty(1, dtype=torch.float32, device=packs.device) if out is None else _check(out, "out")
+    check_call(_lib_().fq_batch_mean_gathered(_ptr(packs), packs.shape[0], packs.shape[1], _ptr(out), _stream(packs)))
+    return out
+
+
+def batch_mean_rows(v, out=None):
+    """Row-wise `batch_mean`: v (rows, n) contiguous -> (rows,)."""
+    _check(v, "v")
+    if v.dim() != 2:
+        raise ValueError("batch_mean_rows wants a 2-D tensor")
+    out = torch.empty(v.shape[0], dtype=torch.float32, device=v.device) if out is None else _check(out, "out")
+    check_call(_lib_().fq_batch_mean_rows(_ptr(v), v.shape[0], v.shape[1], v.stride(0), _ptr(out), _stream(v)))
     return out
 
 

@@ -48,7 +48,17 @@ def _fake_quant_input(m, x, input_max, flags, width):
     stat_ws = getattr(m, "_fq_stat_ws", None)
     if stat_ws is not None and (stat_ws.device != t.device or stat_ws.numel() < t.shape[0]):
         stat_ws = None
-    if m.quantize_input:
+    gstat = getattr(m, "_fq_global_stat", None)
+    if gstat is not None and stat_ws is not None:
+        # batch sharded over ranks (dist.py): statistic pass -> all-gather -> GLOBAL batch mean -> apply pass
+        n = t.shape[0]
+        per_sample = ops.absmax_per_sample(t, out=stat_ws[:n])
+        gstat(per_sample, n, cur)
+        if m.quantize_input:
+            thr = input_max._t if m.quantize_input_offline else cur
+            y, _, _ = ops.fake_quant_offline(t, thr, width, flags, want_stat=False)
+            x = NDArray(y)
+    elif m.quantize_input:
         if m.quantize_input_offline:
             y, _, _ = ops.fake_quant_offline(t, input_max._t, width, flags, cur_out=cur,
                                              want_stat=getattr(m, "track_input_stat", True), stat_ws=stat_ws)

@@ -1,0 +1,123 @@
+"""examples/simulate_quantization.py: flags identical to the reference's CLI (:49-103) and its three flows end to end.
+CPU runs use the oracle stand-in for the HIP entry points (host logic only); GPU runs are marked."""
+import importlib.util
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle.patch import oracle_ops
+
+
+def _cli():
+    spec = importlib.util.spec_from_file_location("fq_cli", os.path.join(ROOT, "examples", "simulate_quantization.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+REFERENCE_FLAGS = ["--model", "--print-model", "--list-models", "--use-gpu", "--dataset", "--use-gn", "--batch-norm",
+                   "--use-se", "--last-gamma", "--merge-bn", "--weight-bits-width", "--input-signed",
+                   "--input-bits-width", "--quant-type", "-j", "--num-data-workers", "--batch-size", "--num-sample",
+                   "--quantize-input-offline", "--calib-mode", "--calib-epoch", "--disable-cudnn-autotune",
+                   "--eval-per-calib", "--exclude-first-conv", "--fixed-random-seed", "--wino_quantize"]
+
+
+def test_cli_keeps_every_reference_flag_and_default():
+    cli = _cli()
+    src = open(os.path.join(ROOT, "examples", "simulate_quantization.py")).read()
+    for flag in REFERENCE_FLAGS:
+        assert re.search(r"['\"]%s['\"]" % re.escape(flag), src), flag
+    opt = cli.parse_args(["--model", "mobilenet1.0"])
+    assert (opt.use_gpu, opt.dataset, opt.weight_bits_width, opt.input_signed, opt.input_bits_width, opt.quant_type,
+            opt.num_workers, opt.batch_size, opt.num_sample, opt.calib_mode, opt.calib_epoch, opt.exclude_first_conv,
+            opt.fixed_random_seed, opt.wino_quantize, opt.quantize_input_offline, opt.merge_bn) == \
+        (-1, "imagenet", 8, "false", 8, "layer", 4, 128, 5, "naive", 3, "true", 7, "none", False, False)
+
+
+def test_cli_refuses_cpu_context():
+    cli = _cli()
+    with pytest.raises(SystemExit, match="no CPU fallback"):
+        cli.main(["--model", "cifar_resnet20_v1", "--dataset", "cifar10"])
+
+
+def test_uniform_sampler_matches_reference_semantics():
+    cli = _cli()
+    labels = np.arange(200) % 10
+    np.random.seed(7)
+    s = cli.UniformSampler(10, 3, labels)
+    idx = list(iter(s))
+    assert len(idx) == len(s) == 30
+    assert all((labels[idx] == c).sum() == 3 for c in range(10))
+    np.random.seed(7)
+    assert idx == list(iter(cli.UniformSampler(10, 3, labels)))         # same seed -> same draw on every rank
+    with pytest.raises(ValueError, match="Number of samples for class"):
+        list(iter(cli.UniformSampler(10, 30, labels)))
+
+
+@pytest.fixture()
+def tiny_data(monkeypatch):
+    monkeypatch.setenv("FQ_SYNTH_VAL_IMAGES", "16")
+    monkeypatch.setenv("FQ_SYNTH_TRAIN_PER_CLASS", "2")
+
+
+BASE = ["--model", "cifar_resnet20_v1", "--dataset", "cifar10", "--batch-size", "8", "--num-sample", "1"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--quantize-input-offline", "--calib-epoch", "1", "--quant-type", "channel",
+                                        "--weight-bits-width", "4"],
+                                   ["--input-signed", "true", "--quant-type", "channel", "--wino_quantize", "F23"]],
+                         ids=["online", "naive_ema_w4", "signed_wino"])
+def test_cli_flows_on_cpu_with_oracle(tiny_data, capsys, extra):
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.mx.gluon import nn
+    cli = _cli()
+    opt = cli.parse_args(BASE + extra)
+    with oracle_ops():
+        acc, avg_acc, net = cli.run(opt, mx.cpu())
+    out = capsys.readouterr().out
+    assert "Exclude blocks" in out and "Result" in out and "acc" in out
+    assert 0.0 <= acc <= 1.0 and 0.0 <= avg_acc <= 1.0
+    blocks = net.collect_quantized_blocks()
+    assert len(blocks) == 20
+    assert all(b.fixed_params == 1 for b in blocks if isinstance(b, nn.Conv2D))
+    if "--quantize-input-offline" in extra:
+        assert out.count("Best threshold for") == 20
+        assert all(b.quantize_input_offline and float(b.input_max.data().asscalar()) > 0 for b in blocks)
+
+
+def test_cli_kl_flow_and_qparams_roundtrip_on_cpu_with_oracle(tiny_data, capsys, tmp_path):
+    from quantization.mxnet_amd import mx
+    cli = _cli()
+    path = str(tmp_path / "q.npz")
+    opt = cli.parse_args(BASE + ["--quantize-input-offline", "--calib-mode", "kl", "--input-bits-width", "4",
+                                 "--save-qparams", path])
+    with oracle_ops():
+        acc, _, net = cli.run(opt, mx.cpu())
+        out = capsys.readouterr().out
+        assert "KL Calibration" in out and out.count("Best threshold for") == 20
+        thr = [b.input_max.data().asscalar() for b in net.collect_quantized_blocks()]
+        assert all(t > 0 for t in thr)
+        opt2 = cli.parse_args(BASE + ["--quantize-input-offline", "--load-qparams", path])
+        acc2, _, net2 = cli.run(opt2, mx.cpu())
+        thr2 = [b.input_max.data().asscalar() for b in net2.collect_quantized_blocks()]
+    assert thr == thr2 and acc == acc2          # thresholds survive the parameter file (checkpoint/resume row)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--quantize-input-offline", "--calib-epoch", "2", "--quant-type", "channel",
+                                        "--weight-bits-width", "4"],
+                                   ["--quantize-input-offline", "--calib-mode", "kl", "--quant-type", "channel"],
+                                   ["--quant-type", "channel", "--wino_quantize", "F43"], ["--merge-bn"]],
+                         ids=["online", "naive_ema_w4", "kl", "wino_f43", "merge_bn"])
+def test_cli_flows_on_gpu(tiny_data, capsys, extra):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    cli = _cli()
+    acc, avg_acc, net = cli.main(BASE + ["--use-gpu", "0"] + extra)
+    out = capsys.readouterr().out
+    assert "Result" in out and "images/sec" in out
+    assert 0.0 <= acc <= 1.0
