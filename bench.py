@@ -177,8 +177,8 @@ def main():
         prof = ops.profile_read()
     ops.profile_reset()
     # A bracketing event pair adds a fixed cost to every launch it times (two marker packets + dispatch latency).
-    # It is measured live around a one-element kernel whose own duration is ~1.5 us in rocprofv3 traces, and removed.
-    null_kernel_us = 1.5
+    # It is measured live around a one-element kernel whose own duration is known from the rocprofv3 trace, and removed.
+    null_kernel_us = 3.4          # fill_kernel average in profiles/r1_bench_kernel_stats.csv (rocprofv3)
     ev_overhead_ms = max(ops.profile_event_overhead_ms(dev) - null_kernel_us * 1e-3, 0.0)
 
     if distributed:

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs) per kernel family and
+write profiles/pmc_traffic.json.  Corrections (MI355X_MICROARCH.md "HBM"; verified here on a device copy of known size,
+see profiles/r1_pmc_headline.txt): both counters are in KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a
+wide coalesced streaming read -> x2; WRITE_SIZE needs no correction for 16 B/lane streaming stores."""
+import collections
+import csv
+import json
+import sys
+
+csv.field_size_limit(10 ** 9)
+
+
+def family(n):
+    if 'act_apply_kernel<true' in n:
+        return 'act_apply_online'
+    if 'act_apply_kernel<false' in n:
+        return 'act_apply_offline'
+    if 'absmax_per_sample' in n:
+        return 'absmax_per_sample'
+    if 'histogram_kernel' in n:
+        return 'histogram'
+    if 'direct_copy' in n or 'copyBuffer' in n:
+        return 'device_copy(calibration)'
+    return None
+
+
+def load(path, cname):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != cname:
+            continue
+        k = family(r['Kernel_Name'])
+        if k:
+            agg[k].append(float(r['Counter_Value']))
+    return agg
+
+
+def main(fetch_csv, write_csv, out_json=None, tag=""):
+    f, w = load(fetch_csv, 'FETCH_SIZE'), load(write_csv, 'WRITE_SIZE')
+    res = {}
+    for k in sorted(set(f) | set(w)):
+        fv, wv = f.get(k, []), w.get(k, [])
+        rd = 2.0 * 1024.0 * sum(fv) / max(len(fv), 1)
+        wr = 1024.0 * sum(wv) / max(len(wv), 1)
+        res[k] = {"launches_fetch_pass": len(fv), "launches_write_pass": len(wv),
+                  "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+        print("%-28s launches %4d/%4d  read %10.1f MB  write %10.1f MB  total %10.1f MB per launch"
+              % (k, len(fv), len(wv), rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
+    if out_json:
+        json.dump({"source": tag, "act_apply_online_bytes_per_launch": res.get("act_apply_online", {}).get("hbm_bytes_per_launch"),
+                   "absmax_bytes_per_launch": res.get("absmax_per_sample", {}).get("hbm_bytes_per_launch"),
+                   "kernels": res}, open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None, sys.argv[4] if len(sys.argv) > 4 else "")
