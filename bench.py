@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def build_net(model, classes, ctx, seed=7):
+def build_net(model, classes, ctx, seed=7, fuse=True):
     from quantization.mxnet_amd.mx.gluon import nn
     from quantization.mxnet_amd.mx.gluon.model_zoo import get_model
     from quantization.mxnet_amd.quantize import convert
@@ -51,6 +51,9 @@ def build_net(model, classes, ctx, seed=7):
     net.collect_params().reset_ctx(ctx)
     net.fix_params()
     net.quantize_input(enable=True, online=True)
+    if fuse and ctx.device_type == "gpu":
+        from quantization.mxnet_amd.quantize import fuse as _fuse
+        _fuse.fuse_inference(net)
     return net
 
 
@@ -87,6 +90,8 @@ def main():
     ap.add_argument("--model", default="mobilenet1.0")
     ap.add_argument("--batch-size", type=int, default=128, help="per GPU (CLI default, simulate_quantization.py:81)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="keep BatchNorm / ReLU as separate torch ops (no quantize.fuse.fuse_inference)")
     ap.add_argument("--autotune", action="store_true",
                     help="MIOpen find/benchmark mode (measured: no gain for these shapes, +60 s of search)")
     ap.add_argument("--cpu-sample", type=int, default=16)
@@ -117,7 +122,7 @@ def main():
     classes = 10 if args.model.startswith("cifar") else 1000
     hw = 32 if args.model.startswith("cifar") else 224
     ctx = mx.gpu(local_rank)
-    net = build_net(args.model, classes, ctx)
+    net = build_net(args.model, classes, ctx, fuse=not args.no_fuse)
     nblocks = len(net.collect_quantized_blocks())
 
     torch.manual_seed(7 + rank)
@@ -213,7 +218,7 @@ def main():
                                    % (args.model, args.batch_size, hw, hw, nblocks),
                        "global_batch": world * args.batch_size, "parallelism": "dp%d (replicated weights, sharded "
                        "batch, no data-path collective; counters all-reduced once)" % world,
-                       "hipgraph": bool(args.graph)},
+                       "hipgraph": bool(args.graph), "fused_bn_relu_stat": not args.no_fuse},
             "roofline": {"bound": "hbm", "kernel": "act_apply_kernel<ONLINE> (fq_fake_quant_online, apply pass)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -59,7 +59,9 @@ int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront)
 #define FQ_KERNEL_APPLY_OFFLINE 2 /* act_apply_kernel<!ONLINE>     : 8 B/elem                                       */
 #define FQ_KERNEL_WEIGHT 3        /* weight kernels                : 8 B/elem                                       */
 #define FQ_KERNEL_HISTOGRAM 4     /* histogram_kernel              : 4 B/elem                                       */
-#define FQ_KERNEL_COUNT 5
+#define FQ_KERNEL_BN_ACT 5        /* bn_act_stat_kernel            : 8 B/elem                                       */
+#define FQ_KERNEL_DWCONV 6        /* dwconv3x3_kernel              : 4 B/in elem + 4 B/out elem                     */
+#define FQ_KERNEL_COUNT 7
 int fq_profile_enable(int on);
 int fq_profile_reset(void);
 int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes);
@@ -98,6 +100,23 @@ int fq_fake_quant_online(const float* x, float* y, int64_t n, int64_t inner, int
  * it in every mode, :56) — fused into the same pass over x, so traffic stays 8 B/elem.                          */
 int fq_fake_quant_offline(const float* x, float* y, int64_t n, int64_t inner, const float* threshold, int width,
                           unsigned flags, float* out_current_max, int32_t* codes, void* ws, fqStream_t stream);
+
+/* ONLINE mode when the per-sample statistic of x is ALREADY known (its producer computed it, see fq_bn_act_stat):
+ * only the apply pass runs (8 B/elem instead of 12).  stat[n] = max|x[n]| exactly as fq_absmax_per_sample gives.   */
+int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t inner, const float* stat, int width,
+                                 unsigned flags, float* out_current_max, int32_t* codes, fqStream_t stream);
+
+/* ---- producer fusion (inference) -----------------------------------------------------------------------------------
+ * What sits between two quantised convolutions in the reference's nets is BatchNorm (inference) + ReLU as separate
+ * Gluon blocks, i.e. two more full passes over the tensor before the next layer's statistic pass.  This entry point
+ * does all three in one pass: x is (n, c, hw);  y = act(x * scale[c] + shift[c])  with separately rounded multiply and
+ * add, act: 0 none, 1 relu, 2 relu6 (clip to [0,6]);  stat_out[n] (may be NULL) <- max|y[n]| for the consumer's
+ * fq_fake_quant_online_prestat.  scale = gamma/sqrt(var+eps), shift = beta - mean*scale are prepared by the caller.  */
+#define FQ_ACT_NONE 0
+#define FQ_ACT_RELU 1
+#define FQ_ACT_RELU6 2
+int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                   const float* shift, int act, float* stat_out, fqStream_t stream);
 
 /* Generic LinearQuantizeSTE.forward (ste_func.py:37-41) for API completeness: x viewed as (rows, row_len) with one
  * scale per row read from the DEVICE array `scales` (rows = 1: scalar scale; rows = Cout: (Cout,1,1,1) broadcast):

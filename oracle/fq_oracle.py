@@ -26,7 +26,7 @@ EPS = F32(1e-10)          # ste_func.py:39,41  `scale + 1e-10`  (fp32 add: numpy
 __all__ = ["roundf", "absmax_per_sample", "batch_mean", "act_scale", "ste_codes", "ste_forward",
            "conv_input_fake_quant", "dense_input_fake_quant", "act_output_fake_quant", "weight_fake_quant",
            "winograd_G", "wino_weight_fake_quant", "ema_update", "discrete_histogram", "kl_calibrate",
-           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain"]
+           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act"]
 
 
 def roundf(x):
@@ -317,6 +317,21 @@ def qconv2d_forward(x, w, b, stride, padding, groups, input_dtype="uint8", weigh
         y = y + bi.reshape(1, -1, 1, 1)
     if quantized:
         return dequantize(y.astype(np.int32), F32(in_s * w_s))
+    return y.astype(F32)
+
+
+# ---- fused producer (project addition; quantize/fuse.py) ---------------------------------------------------------
+def bn_act(x, scale, shift, act="relu"):
+    """Inference BatchNorm folded to per-channel scale/shift, multiply and add separately rounded, then the activation:
+    the arithmetic of `fq_bn_act_stat` (x is (N, C, ...))."""
+    x = np.asarray(x, dtype=F32)
+    bshape = (1, -1) + (1,) * (x.ndim - 2)
+    y = (x * np.asarray(scale, dtype=F32).reshape(bshape)).astype(F32)
+    y = (y + np.asarray(shift, dtype=F32).reshape(bshape)).astype(F32)
+    if act == "relu":
+        y = np.maximum(y, F32(0))
+    elif act == "relu6":
+        y = np.minimum(np.maximum(y, F32(0)), F32(6))
     return y.astype(F32)
 
 

@@ -95,6 +95,28 @@ def fake_quant_online(x, width=8, flags=0, out=None, cur_out=None, want_codes=Fa
     return yt, ct, (_t(codes.astype(np.int32)).reshape(x.shape) if want_codes else None)
 
 
+def fake_quant_online_prestat(x, stat, width=8, flags=0, out=None, cur_out=None, want_codes=False):
+    per = _np(stat).reshape(-1)[:x.shape[0]].astype(F32)
+    cur = O.batch_mean(per)
+    y, codes = _apply(x, cur, width, flags)
+    yt = _t(y).reshape(x.shape)
+    if out is not None:
+        out.copy_(yt)
+        yt = out
+    ct = _t(np.asarray([cur], dtype=F32))
+    if cur_out is not None:
+        cur_out.copy_(ct)
+        ct = cur_out
+    return yt, ct, (_t(codes.astype(np.int32)).reshape(x.shape) if want_codes else None)
+
+
+def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
+    a = _np(x)
+    y = O.bn_act(a, _np(scale), _np(shift), act)
+    stat = _t(np.abs(y).reshape(y.shape[0], -1).max(axis=1).astype(F32)) if want_stat else None
+    return _t(y), stat
+
+
 def fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, want_stat=True, want_codes=False,
                        stat_ws=None):
     thr = F32(_np(threshold).reshape(-1)[0])
@@ -197,7 +219,8 @@ def default_device(what="this call"):
     return torch.device("cpu")
 
 
-_REPLACED = ["require_hip", "default_device", "batch_mean_rows", "batch_mean_gathered", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+_REPLACED = ["require_hip", "default_device", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
+             "bn_act_stat", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

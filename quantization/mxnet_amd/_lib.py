@@ -33,6 +33,8 @@ EXPORTS = {
     "fq_batch_mean_gathered": (_int, [_vp, _int, _i64, _vp, _vp]),
     "fq_batch_mean_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "fq_fake_quant_online": (_int, [_vp, _vp, _i64, _i64, _int, _uint, _vp, _vp, _vp, _vp]),
+    "fq_fake_quant_online_prestat": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp]),
+    "fq_bn_act_stat": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "fq_fake_quant_offline": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp, _vp]),
     "fq_ste_forward": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _f32, _f32, _f32, _vp]),
     "fq_weight_workspace_bytes": (ctypes.c_size_t, [_i64]),

@@ -248,10 +248,11 @@ __device__ __forceinline__ ChunkRange block_range(int64_t total_chunks) {
 // ---------------------------------------------------------------------------------------------------------------
 // K1: per-sample statistic.  x viewed as (n, inner).
 // ---------------------------------------------------------------------------------------------------------------
-template <bool USE_ABS, bool VEC, bool NTL>
+template <bool USE_ABS, bool VEC, bool NTL, int U>
 __global__ __launch_bounds__(kBlock) void absmax_per_sample_kernel(const float* __restrict__ x, int64_t inner,
                                                                    int chunks_per_sample, int64_t total_chunks,
                                                                    float* __restrict__ out_max) {
+  constexpr int kCh = kBlock * kVec * U;
   __shared__ float red[4];
   const ChunkRange rg = block_range(total_chunks);
   int64_t cur_s = -1;
@@ -266,23 +267,23 @@ __global__ __launch_bounds__(kBlock) void absmax_per_sample_kernel(const float* 
       cur_s = s;
       m = stat_init<USE_ABS>();
     }
-    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kChunk;
+    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kCh;
     const float* base = x + s * inner + off0;
     const int64_t rem = inner - off0;
     if (VEC) {
       const f4* p = reinterpret_cast<const f4*>(base);
-      if (rem >= kChunk) {
-        f4 v[kUnroll];
+      if (rem >= kCh) {
+        f4 v[U];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = ld4<NTL>(p + threadIdx.x + u * kBlock);
+        for (int u = 0; u < U; ++u) v[u] = ld4<NTL>(p + threadIdx.x + u * kBlock);
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) m = fmaxf(m, stat4<USE_ABS>(v[u]));
+        for (int u = 0; u < U; ++u) m = fmaxf(m, stat4<USE_ABS>(v[u]));
       } else {
         const int nvec = (int)(rem / kVec);
         for (int i = threadIdx.x; i < nvec; i += kBlock) m = fmaxf(m, stat4<USE_ABS>(ld4<NTL>(p + i)));
       }
     } else {
-      const int cnt = (int)(rem < kChunk ? rem : kChunk);
+      const int cnt = (int)(rem < kCh ? rem : kCh);
       for (int i = threadIdx.x; i < cnt; i += kBlock) m = fmaxf(m, stat_of<USE_ABS>(base[i]));
     }
   }
@@ -330,7 +331,7 @@ __device__ __forceinline__ f4 fq_code4(f4 v, const QParams& q) {
   return k;
 }
 
-template <bool ONLINE, bool STATS, bool CODES, bool USE_ABS, bool VEC, bool NTL, bool NTS>
+template <bool ONLINE, bool STATS, bool CODES, bool USE_ABS, bool VEC, bool NTL, bool NTS, int U>
 __global__ __launch_bounds__(kBlock) void act_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            int32_t* __restrict__ codes, int64_t inner,
                                                            int chunks_per_sample, int64_t total_chunks,
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(kBlock) void act_apply_kernel(const float* __restri
                                                            int lo_neg_max, float eps, int reverse,
                                                            float* __restrict__ stat_out,
                                                            float* __restrict__ cur_max_out) {
+  constexpr int kCh = kBlock * kVec * U;
   __shared__ float red[4];
   const float max_ = ONLINE ? batch_mean_dev(stat_in, n) : thr[0];
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
@@ -358,19 +360,19 @@ __global__ __launch_bounds__(kBlock) void act_apply_kernel(const float* __restri
       cur_s = s;
       m = stat_init<USE_ABS>();
     }
-    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kChunk;
+    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kCh;
     const int64_t gbase = s * inner + off0;
     const int64_t rem = inner - off0;
     if (VEC) {
       const f4* p = reinterpret_cast<const f4*>(x + gbase);
       f4* o = reinterpret_cast<f4*>(y + gbase);
       i4* oc = CODES ? reinterpret_cast<i4*>(codes + gbase) : nullptr;
-      if (rem >= kChunk) {
-        f4 v[kUnroll];
+      if (rem >= kCh) {
+        f4 v[U];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = ld4<NTL>(p + threadIdx.x + u * kBlock);
+        for (int u = 0; u < U; ++u) v[u] = ld4<NTL>(p + threadIdx.x + u * kBlock);
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < U; ++u) {
           if (STATS) m = fmaxf(m, stat4<USE_ABS>(v[u]));
           const f4 k = fq_code4(v[u], q);
           if (CODES) oc[threadIdx.x + u * kBlock] = __builtin_convertvector(k, i4);
@@ -387,13 +389,98 @@ __global__ __launch_bounds__(kBlock) void act_apply_kernel(const float* __restri
         }
       }
     } else {
-      const int cnt = (int)(rem < kChunk ? rem : kChunk);
+      const int cnt = (int)(rem < kCh ? rem : kCh);
       for (int i = threadIdx.x; i < cnt; i += kBlock) {
         const float v = x[gbase + i];
         if (STATS) m = fmaxf(m, stat_of<USE_ABS>(v));
         const float k = fq_code(v, q);
         if (CODES) codes[gbase + i] = (int)k;
         y[gbase + i] = k * q.scale;
+      }
+    }
+  }
+  if (STATS && cur_s >= 0) {
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2b: fused inference BatchNorm (as per-channel scale/shift) + activation + per-sample statistic of the OUTPUT.
+// x is (n, c, hw).  One division per 16-byte access finds the channel; the walk to the next channel inside the access
+// is incremental (hw need not be a multiple of 4: 7x7 planes).
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ float bn_act1(float v, float sc, float sh) {
+  float r = v * sc;
+  r = r + sh;
+  if (ACT == FQ_ACT_RELU) r = fmaxf(r, 0.0f);
+  if (ACT == FQ_ACT_RELU6) r = fminf(fmaxf(r, 0.0f), 6.0f);
+  return r;
+}
+
+template <int ACT, bool STATS, bool VEC, int U>
+__global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int64_t inner, int hw, int chunks_per_sample,
+                                                             int64_t total_chunks, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             float* __restrict__ stat_out) {
+  constexpr int kCh = kBlock * kVec * U;
+  __shared__ float red[4];
+  const ChunkRange rg = block_range(total_chunks);
+  int64_t cur_s = -1;
+  float m = 0.0f;
+  for (int64_t c = rg.begin; c < rg.end; ++c) {
+    const int64_t s = c / chunks_per_sample;
+    if (STATS && s != cur_s) {
+      if (cur_s >= 0) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+      }
+      cur_s = s;
+      m = 0.0f;
+    }
+    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kCh;     // offset inside the sample
+    const int64_t gbase = s * inner + off0;
+    const int64_t rem = inner - off0;
+    if (VEC) {
+      const f4* p = reinterpret_cast<const f4*>(x + gbase);
+      f4* o = reinterpret_cast<f4*>(y + gbase);
+      const int nvec = (int)((rem < kCh ? rem : kCh) / kVec);
+      f4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * kBlock;
+        if (i < nvec) v[u] = p[i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * kBlock;
+        if (i < nvec) {
+          const unsigned e0 = (unsigned)(off0 + (int64_t)i * kVec);       // element index inside the sample (< 2^32)
+          unsigned ch = e0 / (unsigned)hw;
+          unsigned r = e0 - ch * (unsigned)hw;
+          float sc = scale[ch], sh = shift[ch];
+          f4 q;
+          q.x = bn_act1<ACT>(v[u].x, sc, sh);
+          if (++r == (unsigned)hw) { r = 0; ++ch; sc = scale[ch]; sh = shift[ch]; }
+          q.y = bn_act1<ACT>(v[u].y, sc, sh);
+          if (++r == (unsigned)hw) { r = 0; ++ch; sc = scale[ch]; sh = shift[ch]; }
+          q.z = bn_act1<ACT>(v[u].z, sc, sh);
+          if (++r == (unsigned)hw) { r = 0; ++ch; sc = scale[ch]; sh = shift[ch]; }
+          q.w = bn_act1<ACT>(v[u].w, sc, sh);
+          if (STATS) m = fmaxf(m, stat4<true>(q));
+          o[i] = q;
+        }
+      }
+    } else {
+      const int cnt = (int)(rem < kCh ? rem : kCh);
+      for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        const unsigned e = (unsigned)(off0 + i);
+        const unsigned ch = e / (unsigned)hw;
+        const float q = bn_act1<ACT>(x[gbase + i], scale[ch], shift[ch]);
+        if (STATS) m = fmaxf(m, fabsf(q));
+        y[gbase + i] = q;
       }
     }
   }
@@ -811,51 +898,73 @@ struct Chunking {
   int chunks_per_sample;
   int64_t total;
 };
-inline Chunking chunking(int64_t n, int64_t inner) {
+inline Chunking chunking(int64_t n, int64_t inner, int chunk = kChunk) {
   Chunking c;
-  c.chunks_per_sample = (int)((inner + kChunk - 1) / kChunk);
+  c.chunks_per_sample = (int)((inner + chunk - 1) / chunk);
   c.total = n * c.chunks_per_sample;
   return c;
 }
+// Small tensors: 32 KiB steps would leave most CUs with < 1 workgroup; use 8 KiB steps (2 accesses in flight per
+// lane) once the tensor has fewer 32 KiB chunks than 8 workgroups per CU.
+constexpr int kSmallUnroll = 2;
+constexpr int kSmallChunk = kBlock * kVec * kSmallUnroll;
+inline bool use_small_chunks(int64_t n, int64_t inner) {
+  return chunking(n, inner).total < (int64_t)num_cu() * kMaxBlocksPerCU;
+}
 
-// Streaming policy.  Defaults chosen from measurements on MI355X (profiles/); FQ_POLICY_STAT /
-// FQ_POLICY_ONLINE / FQ_POLICY_OFFLINE (integers, OR of the kPol* bits) override them for tuning runs.
-int env_policy(const char* name, int dflt) {
+// Streaming policy, by kernel and tensor size.  Measured on MI355X (profiles/r1_policy_sweep.txt, r1_kbench.txt):
+// tensors that (with their output) fit the 256 MiB Infinity Cache want PLAIN loads/stores — the producer just left x
+// there and the consumer (the convolution) will find y there; larger tensors want nontemporal loads+stores in the apply
+// pass, and the online apply pass walks backwards to start on what the statistic pass read last.
+// FQ_POLICY_STAT / FQ_POLICY_ONLINE / FQ_POLICY_OFFLINE (integer OR of the kPol* bits) override for tuning runs;
+// FQ_POLICY_BIG_BYTES moves the size threshold.
+int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return (e && *e) ? atoi(e) : dflt;
 }
-int policy_stat() {
-  static int p = env_policy("FQ_POLICY_STAT", 0);
-  return p;
-}
-int policy_online() {
-  static int p = env_policy("FQ_POLICY_ONLINE", kPolReverse | kPolNtLoad | kPolNtStore);
-  return p;
-}
-int policy_offline() {
-  static int p = env_policy("FQ_POLICY_OFFLINE", kPolNtLoad | kPolNtStore);
-  return p;
+int stream_policy(int kernel_id, int64_t numel) {
+  static const int ov_stat = env_int("FQ_POLICY_STAT", -1);
+  static const int ov_on = env_int("FQ_POLICY_ONLINE", -1);
+  static const int ov_off = env_int("FQ_POLICY_OFFLINE", -1);
+  static const int64_t big = (int64_t)env_int("FQ_POLICY_BIG_MB", 160) * 1000000;
+  const bool is_big = numel * (int64_t)sizeof(float) >= big;
+  switch (kernel_id) {
+    case FQ_KERNEL_STAT:
+      return ov_stat >= 0 ? ov_stat : 0;
+    case FQ_KERNEL_APPLY_ONLINE:
+      if (ov_on >= 0) return ov_on;
+      return is_big ? (kPolReverse | kPolNtLoad | kPolNtStore) : kPolReverse;
+    default:
+      if (ov_off >= 0) return ov_off;
+      return is_big ? (kPolNtLoad | kPolNtStore) : 0;
+  }
 }
 
 int launch_absmax(const float* x, int64_t n, int64_t inner, bool use_abs, float* out, hipStream_t st) {
   // caller has initialised `out` (0 for |x|, -inf otherwise)
-  const Chunking ck = chunking(n, inner);
+  const bool small = use_small_chunks(n, inner);
+  const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
   const bool vec = (inner % kVec == 0) && aligned16(x);
   const int grid = grid_for(ck.total);
-  const bool ntl = (policy_stat() & kPolNtLoad) != 0;
+  const bool ntl = (stream_policy(FQ_KERNEL_STAT, n * inner) & kPolNtLoad) != 0;
   ProfScope prof(FQ_KERNEL_STAT, 4.0 * (double)n * (double)inner, st);
-#define FQ_ABSMAX(A, V, L)                                                                                    \
-  hipLaunchKernelGGL((absmax_per_sample_kernel<A, V, L>), dim3(grid), dim3(kBlock), 0, st, x, inner,          \
+#define FQ_ABSMAX(A, V, L, UU)                                                                                \
+  hipLaunchKernelGGL((absmax_per_sample_kernel<A, V, L, UU>), dim3(grid), dim3(kBlock), 0, st, x, inner,      \
                      ck.chunks_per_sample, ck.total, out)
+#define FQ_ABSMAX_U(A, V, L)                                            \
+  do {                                                                  \
+    if (small) FQ_ABSMAX(A, V, L, kSmallUnroll); else FQ_ABSMAX(A, V, L, kUnroll); \
+  } while (0)
   if (use_abs) {
     if (vec) {
-      if (ntl) FQ_ABSMAX(true, true, true); else FQ_ABSMAX(true, true, false);
+      if (ntl) FQ_ABSMAX_U(true, true, true); else FQ_ABSMAX_U(true, true, false);
     } else {
-      FQ_ABSMAX(true, false, false);
+      FQ_ABSMAX_U(true, false, false);
     }
   } else {
-    if (vec) FQ_ABSMAX(false, true, false); else FQ_ABSMAX(false, false, false);
+    if (vec) FQ_ABSMAX_U(false, true, false); else FQ_ABSMAX_U(false, false, false);
   }
+#undef FQ_ABSMAX_U
 #undef FQ_ABSMAX
   FQ_LAUNCH_CHECK();
   return FQ_OK;
@@ -874,32 +983,38 @@ int init_stat(float* p, int64_t n, bool use_abs, hipStream_t st) {
 template <bool ONLINE, bool STATS, bool CODES>
 int launch_apply(const float* x, float* y, int32_t* codes, int64_t n, int64_t inner, const float* stat_in,
                  const float* thr, float levels, unsigned flags, float* stat_out, float* cur_out, hipStream_t st) {
-  const Chunking ck = chunking(n, inner);
+  const bool small = use_small_chunks(n, inner);
+  const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
   const bool vec = (inner % kVec == 0) && aligned16(x) && aligned16(y) && (!CODES || aligned16(codes));
   const bool use_abs = !(flags & FQ_ACT_NO_ABS);
   const int grid = grid_for(ck.total);
   const int lo_neg = (flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
   const float eps = (flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
-  int pol = ONLINE ? policy_online() : policy_offline();
+  int pol = stream_policy(ONLINE ? FQ_KERNEL_APPLY_ONLINE : FQ_KERNEL_APPLY_OFFLINE, n * inner);
   if (x == y) pol &= ~kPolNtLoad;
   const int reverse = (pol & kPolReverse) ? 1 : 0;
   ProfScope prof(ONLINE ? FQ_KERNEL_APPLY_ONLINE : FQ_KERNEL_APPLY_OFFLINE, 8.0 * (double)n * (double)inner, st);
-#define FQ_APPLY(A, V, L, S)                                                                                     \
-  hipLaunchKernelGGL((act_apply_kernel<ONLINE, STATS, CODES, A, V, L, S>), dim3(grid), dim3(kBlock), 0, st, x,   \
-                     y, codes, inner, ck.chunks_per_sample, ck.total, stat_in, (int)n, thr, levels, lo_neg, eps, \
-                     reverse, stat_out, cur_out)
+#define FQ_APPLY(A, V, L, S, UU)                                                                                 \
+  hipLaunchKernelGGL((act_apply_kernel<ONLINE, STATS, CODES, A, V, L, S, UU>), dim3(grid), dim3(kBlock), 0, st,  \
+                     x, y, codes, inner, ck.chunks_per_sample, ck.total, stat_in, (int)n, thr, levels, lo_neg,   \
+                     eps, reverse, stat_out, cur_out)
+#define FQ_APPLY_U(A, V, L, S)                                                      \
+  do {                                                                              \
+    if (small) FQ_APPLY(A, V, L, S, kSmallUnroll); else FQ_APPLY(A, V, L, S, kUnroll); \
+  } while (0)
   if (use_abs && vec && !CODES) {
     switch (pol & (kPolNtLoad | kPolNtStore)) {
-      case 0: FQ_APPLY(true, true, false, false); break;
-      case kPolNtLoad: FQ_APPLY(true, true, true, false); break;
-      case kPolNtStore: FQ_APPLY(true, true, false, true); break;
-      default: FQ_APPLY(true, true, true, true); break;
+      case 0: FQ_APPLY_U(true, true, false, false); break;
+      case kPolNtLoad: FQ_APPLY_U(true, true, true, false); break;
+      case kPolNtStore: FQ_APPLY_U(true, true, false, true); break;
+      default: FQ_APPLY_U(true, true, true, true); break;
     }
   } else if (use_abs) {
-    if (vec) FQ_APPLY(true, true, false, false); else FQ_APPLY(true, false, false, false);
+    if (vec) FQ_APPLY_U(true, true, false, false); else FQ_APPLY_U(true, false, false, false);
   } else {
-    if (vec) FQ_APPLY(false, true, false, false); else FQ_APPLY(false, false, false, false);
+    if (vec) FQ_APPLY_U(false, true, false, false); else FQ_APPLY_U(false, false, false, false);
   }
+#undef FQ_APPLY_U
 #undef FQ_APPLY
   FQ_LAUNCH_CHECK();
   return FQ_OK;
@@ -1048,6 +1163,60 @@ int fq_fake_quant_online(const float* x, float* y, int64_t n, int64_t inner, int
                                            out_current_max, st);
   return launch_apply<true, false, false>(x, y, nullptr, n, inner, stat, nullptr, levels, flags, nullptr,
                                           out_current_max, st);
+}
+
+int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t inner, const float* stat, int width,
+                                 unsigned flags, float* out_current_max, int32_t* codes, fqStream_t stream) {
+  FQ_REQUIRE(x && y && stat, "fq_fake_quant_online_prestat: null pointer");
+  FQ_REQUIRE(n > 0 && inner > 0 && n < (1ll << 31), "fq_fake_quant_online_prestat: bad shape (n=%lld inner=%lld)",
+             (long long)n, (long long)inner);
+  FQ_REQUIRE(width >= 2 && width <= 16, "fq_fake_quant_online_prestat: width %d out of range", width);
+  const float levels = act_levels(width, flags);
+  if (codes)
+    return launch_apply<true, false, true>(x, y, codes, n, inner, stat, nullptr, levels, flags, nullptr,
+                                           out_current_max, (hipStream_t)stream);
+  return launch_apply<true, false, false>(x, y, nullptr, n, inner, stat, nullptr, levels, flags, nullptr,
+                                          out_current_max, (hipStream_t)stream);
+}
+
+int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                   const float* shift, int act, float* stat_out, fqStream_t stream) {
+  FQ_REQUIRE(x && y && scale && shift, "fq_bn_act_stat: null pointer");
+  FQ_REQUIRE(n > 0 && c > 0 && hw > 0 && c * hw < (1ll << 32) && hw < (1ll << 31),
+             "fq_bn_act_stat: bad shape (n=%lld c=%lld hw=%lld)", (long long)n, (long long)c, (long long)hw);
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_bn_act_stat: unknown activation %d", act);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t inner = c * hw;
+  if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  const bool small = use_small_chunks(n, inner);
+  const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
+  const bool vec = (inner % kVec == 0) && aligned16(x) && aligned16(y);
+  const int grid = grid_for(ck.total);
+  ProfScope prof(FQ_KERNEL_BN_ACT, 8.0 * (double)n * (double)inner, st);
+#define FQ_BN(A, S, V, UU)                                                                                       \
+  hipLaunchKernelGGL((bn_act_stat_kernel<A, S, V, UU>), dim3(grid), dim3(kBlock), 0, st, x, y, inner, (int)hw,   \
+                     ck.chunks_per_sample, ck.total, scale, shift, stat_out)
+#define FQ_BN_U(A, S, V)                                                 \
+  do {                                                                   \
+    if (small) FQ_BN(A, S, V, kSmallUnroll); else FQ_BN(A, S, V, kUnroll); \
+  } while (0)
+#define FQ_BN_V(A, S)                                   \
+  do {                                                  \
+    if (vec) FQ_BN_U(A, S, true); else FQ_BN_U(A, S, false); \
+  } while (0)
+#define FQ_BN_S(A)                                         \
+  do {                                                     \
+    if (stat_out) FQ_BN_V(A, true); else FQ_BN_V(A, false); \
+  } while (0)
+  if (act == FQ_ACT_RELU) FQ_BN_S(FQ_ACT_RELU);
+  else if (act == FQ_ACT_RELU6) FQ_BN_S(FQ_ACT_RELU6);
+  else FQ_BN_S(FQ_ACT_NONE);
+#undef FQ_BN_S
+#undef FQ_BN_V
+#undef FQ_BN_U
+#undef FQ_BN
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
 }
 
 int fq_fake_quant_offline(const float* x, float* y, int64_t n, int64_t inner, const float* threshold, int width,

@@ -59,12 +59,16 @@ def _roundf(t):
 
 class NDArray(object):
     """Thin wrapper: one torch tensor, MXNet method names."""
-    __slots__ = ("_t",)
+    # _fq_stat: optional side channel — per-sample max|x| left by a fused producer (quantize/fuse.py) so that the
+    # consuming fake-quant can skip its statistic pass.  Never set by the generic ops.
+    __slots__ = ("_t", "_fq_stat")
     __array_priority__ = 1000.0
+    __array_ufunc__ = None
 
     def __init__(self, t):
         assert isinstance(t, torch.Tensor), type(t)
         self._t = t
+        self._fq_stat = None
 
     # -- plumbing ---------------------------------------------------------------------------
     @property
@@ -159,6 +163,7 @@ class NDArray(object):
 
     def __setitem__(self, key, value):
         key = _unwrap_key(key)
+        self._fq_stat = None
         self._t[key] = value._t if isinstance(value, NDArray) else value
 
     # -- shape ops --------------------------------------------------------------------------
@@ -235,10 +240,12 @@ class NDArray(object):
         return NDArray(self._t ** _operand(o, self._t))
 
     def __iadd__(self, o):
+        self._fq_stat = None
         self._t += _operand(o, self._t)
         return self
 
     def __imul__(self, o):
+        self._fq_stat = None
         self._t *= _operand(o, self._t)
         return self
 

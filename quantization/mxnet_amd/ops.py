@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["fake_quant_online_prestat", "bn_act_stat", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -73,7 +73,8 @@ def device_info():
     return {"arch": arch.value.decode(), "compute_units": cu.value, "wavefront": wf.value}
 
 
-KERNEL_IDS = {"stat": 0, "apply_online": 1, "apply_offline": 2, "weight": 3, "histogram": 4}
+KERNEL_IDS = {"stat": 0, "apply_online": 1, "apply_offline": 2, "weight": 3, "histogram": 4, "bn_act": 5,
+              "dwconv": 6}
 
 
 def profile_enable(on=True):
@@ -188,6 +189,45 @@ def fake_quant_online(x, width=8, flags=0, out=None, cur_out=None, want_codes=Fa
     check_call(_lib_().fq_fake_quant_online(_ptr(x), _ptr(y), n, inner, int(width), int(flags), _ptr(cur),
                                             _ptr(codes), _ptr(ws), _stream(x)))
     return y, cur, codes
+
+
+def fake_quant_online_prestat(x, stat, width=8, flags=0, out=None, cur_out=None, want_codes=False):
+    """Online fake-quant when the per-sample statistic of x was already produced (by `bn_act_stat`): apply pass only."""
+    _check(x, "x")
+    _check(stat, "stat")
+    n, inner = _n_inner(x)
+    if stat.numel() < n:
+        raise ValueError("stat holds %d values for %d samples" % (stat.numel(), n))
+    y = torch.empty_like(x) if out is None else _check(out, "out")
+    cur = torch.empty(1, dtype=torch.float32, device=x.device) if cur_out is None else _check(cur_out, "cur_out")
+    codes = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_codes else None
+    check_call(_lib_().fq_fake_quant_online_prestat(_ptr(x), _ptr(y), n, inner, _ptr(stat), int(width), int(flags),
+                                                    _ptr(cur), _ptr(codes), _stream(x)))
+    return y, cur, codes
+
+
+_ACTS = {None: 0, "none": 0, "relu": 1, "relu6": 2}
+
+
+def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
+    """Fused inference BatchNorm (per-channel scale/shift) + activation + per-sample max|y| in one pass.
+    x: (N, C, ...) ; returns (y, stat (N,) or None)."""
+    _check(x, "x")
+    _check(scale, "scale")
+    _check(shift, "shift")
+    if x.dim() < 2 or x.numel() == 0:
+        raise ValueError("bn_act_stat wants (N, C, ...) input")
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    if scale.numel() != c or shift.numel() != c:
+        raise ValueError("scale/shift must have %d elements" % c)
+    if act not in _ACTS:
+        raise ValueError("unknown activation %r" % (act,))
+    y = torch.empty_like(x) if out is None else _check(out, "out")
+    stat = torch.empty(n, dtype=torch.float32, device=x.device) if want_stat else None
+    check_call(_lib_().fq_bn_act_stat(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act], _ptr(stat),
+                                      _stream(x)))
+    return y, stat
 
 
 def fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, want_stat=True, want_codes=False,

@@ -49,15 +49,30 @@ def _fake_quant_input(m, x, input_max, flags, width):
     if stat_ws is not None and (stat_ws.device != t.device or stat_ws.numel() < t.shape[0]):
         stat_ws = None
     gstat = getattr(m, "_fq_global_stat", None)
+    # per-sample max|x| already produced by a fused producer (quantize/fuse.py)?  Exactly what the statistic pass
+    # would compute, so using it changes no result — it only removes a pass over x.
+    hint = x._fq_stat if x._t is t else None
+    if hint is not None and (hint.numel() != t.shape[0] or hint.device != t.device):
+        hint = None
     if gstat is not None and stat_ws is not None:
         # batch sharded over ranks (dist.py): statistic pass -> all-gather -> GLOBAL batch mean -> apply pass
         n = t.shape[0]
-        per_sample = ops.absmax_per_sample(t, out=stat_ws[:n])
+        per_sample = hint if hint is not None else ops.absmax_per_sample(t, out=stat_ws[:n])
         gstat(per_sample, n, cur)
         if m.quantize_input:
             thr = input_max._t if m.quantize_input_offline else cur
             y, _, _ = ops.fake_quant_offline(t, thr, width, flags, want_stat=False)
             x = NDArray(y)
+    elif hint is not None:
+        if m.quantize_input:
+            if m.quantize_input_offline:
+                y, _, _ = ops.fake_quant_offline(t, input_max._t, width, flags, want_stat=False)
+                ops.batch_mean(hint, out=cur)
+            else:
+                y, _, _ = ops.fake_quant_online_prestat(t, hint, width, flags, cur_out=cur)
+            x = NDArray(y)
+        else:
+            ops.batch_mean(hint, out=cur)
     elif m.quantize_input:
         if m.quantize_input_offline:
             y, _, _ = ops.fake_quant_offline(t, input_max._t, width, flags, cur_out=cur,

@@ -1,0 +1,111 @@
+"""Inference-time producer fusion (new; not in the reference — it only re-schedules work).
+
+Between two quantised convolutions the reference's nets run BatchNorm (inference) and ReLU/ReLU6 as separate Gluon
+blocks, then the next layer's fake-quant first makes a statistic pass: BN (r+w) + ReLU (r+w) + statistic (r) = 20 B per
+element of pure elementwise traffic.  `fuse_inference(net)` rewires every `[BatchNorm -> relu | RELU6]` pair (and lone
+BatchNorms) found as consecutive children of a (Hybrid)Sequential so that ONE HIP pass (`fq_bn_act_stat`, 8 B/elem)
+produces the activation AND its per-sample max|y|; the statistic rides along on the NDArray (`_fq_stat`) and the
+consumer's fake-quant then runs its apply pass only.
+
+What does not change: every fake-quantised tensor is still exactly `oracle(fake_quant)(its actual input)` — the
+statistic handed over is bit-identical to the one the statistic pass would compute.  What does change, in the last bit:
+BatchNorm is evaluated as x*scale[c] + shift[c] (scale = gamma/sqrt(var+eps), shift = beta - mean*scale; multiply and
+add separately rounded) instead of MIOpen's formula — the same freedom any BN implementation takes.
+
+Use after parameters are final and on their device (`reset_ctx`, `load_parameters`); `unfuse(net)` restores the blocks.
+"""
+import types
+
+import torch
+
+from ..mx.gluon import nn
+from ..mx.ndarray import NDArray
+from .. import ops
+
+__all__ = ["fuse_inference", "unfuse", "refresh"]
+
+
+def _is_relu6_block(b):
+    return type(b).__name__ == "RELU6"
+
+
+def _act_kind(b):
+    if isinstance(b, nn.Activation) and b._act_type == "relu" and not hasattr(b, "quantize_args") \
+            and b.hybrid_forward.__func__ is nn.Activation.hybrid_forward:
+        return "relu"
+    if _is_relu6_block(b):
+        return "relu6"
+    return None
+
+
+def _bn_constants(bn):
+    g, b = bn.gamma.data()._t, bn.beta.data()._t
+    mean, var = bn.running_mean.data()._t, bn.running_var.data()._t
+    if bn._kwargs.get("fix_gamma", False):
+        g = torch.ones_like(g)
+    scale = g / torch.sqrt(var + bn._kwargs["eps"])
+    shift = b - mean * scale
+    key = (bn.gamma.data()._t.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr())
+    return scale.contiguous(), shift.contiguous(), key
+
+
+def _fused_bn_forward(self, F, x, gamma, beta, running_mean, running_var):
+    st = self._fq_fused
+    key = (gamma._t.data_ptr(), beta._t.data_ptr(), running_mean._t.data_ptr(), running_var._t.data_ptr())
+    if st["key"] != key:                       # parameters moved (reset_ctx / load): recompute the constants
+        st["scale"], st["shift"], st["key"] = _bn_constants(self)
+    t = x._t if x._t.is_contiguous() else x._t.contiguous()
+    y, stat = ops.bn_act_stat(t, st["scale"], st["shift"], st["act"], want_stat=True)
+    out = NDArray(y)
+    out._fq_stat = stat
+    return out
+
+
+def _identity_forward(self, F, x, *args, **kwargs):
+    return x
+
+
+def fuse_inference(net):
+    """Returns the number of BatchNorm blocks fused."""
+    fused = [0]
+
+    def visit(container):
+        kids = list(container._children.values())
+        for i, b in enumerate(kids):
+            if type(b) is not nn.BatchNorm or hasattr(b, "_fq_fused") or b._kwargs.get("axis", 1) != 1:
+                continue
+            if b.hybrid_forward.__func__ is not nn.BatchNorm.hybrid_forward:
+                continue                                   # already patched by someone else (e.g. bypass_bn)
+            nxt = kids[i + 1] if i + 1 < len(kids) and isinstance(container, (nn.Sequential, nn.HybridSequential)) \
+                else None
+            act = _act_kind(nxt) if nxt is not None else None
+            b._fq_fused = {"act": act or "none", "key": None, "scale": None, "shift": None,
+                           "orig": b.hybrid_forward, "act_block": nxt if act else None}
+            b.hybrid_forward = types.MethodType(_fused_bn_forward, b)
+            if act:
+                nxt._fq_bypassed_orig = nxt.hybrid_forward
+                nxt.hybrid_forward = types.MethodType(_identity_forward, nxt)
+            fused[0] += 1
+
+    net.apply(visit)
+    return fused[0]
+
+
+def refresh(net):
+    """Recompute the folded BatchNorm constants (after in-place parameter changes)."""
+    def visit(b):
+        if hasattr(b, "_fq_fused"):
+            b._fq_fused["key"] = None
+    net.apply(visit)
+
+
+def unfuse(net):
+    def visit(b):
+        if hasattr(b, "_fq_fused"):
+            st = b._fq_fused
+            b.hybrid_forward = st["orig"]
+            if st["act_block"] is not None:
+                st["act_block"].hybrid_forward = st["act_block"]._fq_bypassed_orig
+                del st["act_block"]._fq_bypassed_orig
+            del b._fq_fused
+    net.apply(visit)

@@ -215,3 +215,35 @@ def test_nn_conv2d_int_code_path_on_gpu(gpu, golden):
             y = c(mx.nd.array(g[tag + "/x"], ctx=gpu)).asnumpy()
             assert np.array_equal(y, g[tag + "/y_int"]), tag
             assert np.abs(y - g[tag + "/y_sim"]).max() < 0.1 and np.abs(y - g[tag + "/y_float"]).max() < 0.1
+
+
+@pytest.mark.parametrize("model,classes,hw,batch,kw", [("mobilenet1.0", 1000, 64, 4, dict()),
+                                                       ("mobilenetv2_1.0", 1000, 64, 4, dict(quant_type="channel", wt=4)),
+                                                       ("resnet50_v1", 1000, 64, 2, dict(quant_type="channel")),
+                                                       ("cifar_resnet20_v1", 10, 32, 8, dict())],
+                         ids=["mobilenet1.0", "mobilenetv2_1.0", "resnet50_v1", "cifar_resnet20_v1"])
+def test_fused_inference_keeps_every_block_exact(gpu, model, classes, hw, batch, kw):
+    """quantize/fuse.py: BN+ReLU(+statistic) in one pass, consumer skips its statistic pass.  Every quantised block
+    must still be exactly oracle(its actual input); logits stay within BN-formula rounding of the unfused net."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.quantize import fuse
+    net = _build(model, classes, gpu, **kw)
+    rng = np.random.default_rng(7)
+    X = mx.nd.array(rng.standard_normal((batch, 3, hw, hw)).astype(np.float32), ctx=gpu)
+    net.fix_params()
+    net.quantize_input(enable=True, online=True)
+    ref = net(X).asnumpy()
+    n = fuse.fuse_inference(net)
+    assert n > 0
+    spy = Spy(net)
+    out = net(X).asnumpy()
+    args = dict(signed=False, in_w=8, wt=kw.get("wt", 8), quant_type=kw.get("quant_type", "layer"), wino="none")
+    _check_records(spy.records, offline=False, **args)
+    hinted = sum(1 for r in spy.records if r["block"].current_input_max is not None)
+    assert hinted == len(spy.records)
+    scale = np.abs(ref).max()
+    assert np.abs(out - ref).max() <= 2e-2 * scale, (np.abs(out - ref).max(), scale)
+    fuse.unfuse(net)
+    again = net(X).asnumpy()
+    # (not bit-equal across calls: MIOpen may pick a different convolution solver once its find-db is warm)
+    assert np.abs(again - ref).max() <= 2e-2 * scale

@@ -340,3 +340,28 @@ def test_headline_tensor_properties(dev, ops):
     mx = ops.global_max(x)
     ops.histogram_accumulate(x, mx, hist)
     assert int(hist.sum()) == int((x != 0).sum())      # every non-zero lands in exactly one bin
+
+
+# ---- fused producer: BN + activation + statistic (quantize/fuse.py) -------------------------------------------------
+@pytest.mark.parametrize("shape", [(4, 8, 7, 7), (3, 5, 9, 11), (2, 1024, 7, 7), (8, 32, 56, 56), (2, 64, 112, 112),
+                                   (5, 3, 1, 1), (6, 10)])
+@pytest.mark.parametrize("act", ["relu", "relu6", "none"])
+def test_bn_act_stat_vs_oracle(dev, ops, shape, act):
+    rng = np.random.default_rng(sum(shape))
+    x = (rng.standard_normal(shape) * 3).astype(np.float32)
+    c = shape[1]
+    scale = rng.uniform(0.2, 2.0, c).astype(np.float32) * rng.choice([-1, 1], c).astype(np.float32)
+    shift = rng.standard_normal(c).astype(np.float32)
+    y, stat = ops.bn_act_stat(T(x, dev), T(scale, dev), T(shift, dev), act)
+    want = O.bn_act(x, scale, shift, act)
+    _eq(N(y), want, "bn_act")
+    _eq(N(stat), O.absmax_per_sample(want), "per-sample statistic of the output")
+    y2, none = ops.bn_act_stat(T(x, dev), T(scale, dev), T(shift, dev), act, want_stat=False)
+    assert none is None
+    _eq(N(y2), want)
+    # the consumer's apply-only online path == the two-pass online path
+    a, cur_a, codes_a = ops.fake_quant_online(y, 8, 0, want_codes=True)
+    b, cur_b, codes_b = ops.fake_quant_online_prestat(y, stat, 8, 0, want_codes=True)
+    assert N(cur_a)[0] == N(cur_b)[0]
+    _eq(N(codes_a), N(codes_b))
+    _eq(N(a), N(b))

@@ -32,9 +32,31 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only-headline", action="store_true")
+    ap.add_argument("--policy-table", action="store_true", help="all shapes x a few policies, compact table")
     ap.add_argument("--policy-sweep", action="store_true",
                     help="re-run the headline shape in child processes under every FQ_POLICY_* combination")
     args = ap.parse_args()
+    if args.policy_table:
+        import subprocess
+        import re
+        table = {}
+        for pol in ("default", 0, 3, 4, 7):
+            env = dict(os.environ)
+            if pol != "default":
+                env.update(FQ_POLICY_ONLINE=str(pol), FQ_POLICY_OFFLINE=str(pol & 3))
+            out = subprocess.run([sys.executable, __file__, "--iters", str(args.iters)], env=env,
+                                 capture_output=True, text=True).stdout
+            shape = None
+            for l in out.splitlines():
+                if l.startswith("shape"):
+                    shape = l.split("  ")[0]
+                m = re.match(r"\s+(\S+)\s+\(\d+B\)\s+median\s+([\d.]+) ms.*->\s+([\d.]+) GB/s", l)
+                if m and shape:
+                    table.setdefault((shape, m.group(1)), {})[pol] = float(m.group(3))
+        print("%-28s %-10s %s" % ("shape", "case", "  ".join("%8s" % str(p) for p in ("default", 0, 3, 4, 7))))
+        for (shape, case), row in table.items():
+            print("%-28s %-10s %s" % (shape, case, "  ".join("%8.0f" % row.get(p, 0) for p in ("default", 0, 3, 4, 7))))
+        return
     if args.policy_sweep:
         import subprocess
         for stat in (0, 1):
