@@ -118,6 +118,21 @@ int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t in
 int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                    const float* shift, int act, float* stat_out, fqStream_t stream);
 
+/* Depthwise 3x3 convolution (pad 1, dilation 1, stride 1|2, one filter per channel) with the fake-quant of its INPUT
+ * folded into the load and BatchNorm/activation/statistic folded into the store — per depthwise layer x is read once
+ * and y written once (the reference: fake-quant 4 passes, F.Convolution, BatchNorm, ReLU, next layer's statistic).
+ *   xq   = in_thr/in_stat given ? roundf(clip(x, lo, max_)/(max_/levels + eps)) * (max_/levels) : x
+ *          with max_ = in_thr[0] (offline / pre-reduced) or the batch mean of in_stat[0..n) (online) — bit-identical to
+ *          fq_fake_quant_offline / _online_prestat;
+ *   acc  = sum over ky,kx (row-major) of fmaf(w[c][ky][kx], xq[..], acc), zero padding, + bias[c] if given;
+ *   y    = act(acc * bn_scale[c] + bn_shift[c]) if bn_scale given else act(acc);
+ *   stat_out[n] (may be NULL) <- max|y[n]|;  out_current_max (may be NULL; online only) <- max_.
+ * x: (n, c, h, w);  w: (c, 1, 3, 3);  y: (n, c, ho, wo), ho = (h - 1) / stride + 1.                                 */
+int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
+                 int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                 float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                 fqStream_t stream);
+
 /* Generic LinearQuantizeSTE.forward (ste_func.py:37-41) for API completeness: x viewed as (rows, row_len) with one
  * scale per row read from the DEVICE array `scales` (rows = 1: scalar scale; rows = Cout: (Cout,1,1,1) broadcast):
  *   y = roundf( (has_clip ? clip(x, clip_lo, clip_hi) : x) / (scales[r] + eps) ) * scales[r].                    */

@@ -26,7 +26,7 @@ EPS = F32(1e-10)          # ste_func.py:39,41  `scale + 1e-10`  (fp32 add: numpy
 __all__ = ["roundf", "absmax_per_sample", "batch_mean", "act_scale", "ste_codes", "ste_forward",
            "conv_input_fake_quant", "dense_input_fake_quant", "act_output_fake_quant", "weight_fake_quant",
            "winograd_G", "wino_weight_fake_quant", "ema_update", "discrete_histogram", "kl_calibrate",
-           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act"]
+           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act", "dwconv3x3"]
 
 
 def roundf(x):
@@ -333,6 +333,38 @@ def bn_act(x, scale, shift, act="relu"):
     elif act == "relu6":
         y = np.minimum(np.maximum(y, F32(0)), F32(6))
     return y.astype(F32)
+
+
+def dwconv3x3(x, w, bias=None, stride=1, in_max=None, signed=False, width=8, lo_neg_max=None, bn_scale=None,
+              bn_shift=None, act=None):
+    """Arithmetic of `fq_dwconv3x3`: optional fake-quant of x with threshold `in_max` (exactly `ste_forward`), then
+    acc = fmaf(w[ky][kx], xq, acc) over ky, kx row-major with zero padding (fmaf emulated as fp32(fp64 product + fp64
+    acc): the fp64 product of two fp32 is exact), + bias, folded BN (separately rounded mul, add), activation."""
+    x = np.asarray(x, dtype=F32)
+    if in_max is not None:
+        lo_neg = signed if lo_neg_max is None else lo_neg_max
+        scale = act_scale(in_max, signed, width)
+        x = ste_forward(x, scale, in_max, F32(-F32(in_max)) if lo_neg else F32(0))
+    N, C, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    xp = np.zeros((N, C, H + 2, W + 2), F32)
+    xp[:, :, 1:-1, 1:-1] = x
+    w = np.asarray(w, dtype=F32).reshape(C, 3, 3)
+    acc = np.zeros((N, C, Ho, Wo), F32)
+    for ky in range(3):
+        for kx in range(3):
+            tap = xp[:, :, ky:ky + (Ho - 1) * stride + 1:stride, kx:kx + (Wo - 1) * stride + 1:stride]
+            acc = (w[None, :, ky, kx, None, None].astype(np.float64) * tap.astype(np.float64)
+                   + acc.astype(np.float64)).astype(F32)
+    if bias is not None:
+        acc = (acc + np.asarray(bias, dtype=F32).reshape(1, C, 1, 1)).astype(F32)
+    if bn_scale is not None:
+        return bn_act(acc, bn_scale, bn_shift, act or "none")
+    if act == "relu":
+        acc = np.maximum(acc, F32(0))
+    elif act == "relu6":
+        acc = np.minimum(np.maximum(acc, F32(0)), F32(6))
+    return acc.astype(F32)
 
 
 # ---- the reference's UNFUSED op chain, pass by pass (used as the CPU baseline workload) -------------------

@@ -491,6 +491,189 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K2c: depthwise 3x3 (pad 1, stride S) with quantise-on-load and BN / activation / statistic epilogue.
+// A workgroup step ("tile") is P whole planes (small planes) or a strip of output rows of one plane (large planes).
+// The input rows of a tile are contiguous in memory: they are read once, coalesced (16 B per lane), quantised ONCE per
+// element and staged into an LDS tile that carries a zero border, so the 9-tap loop has no bounds checks.  In the
+// compute phase consecutive lanes own consecutive output COLUMNS (conflict-free LDS reads, coalesced stores) and slide
+// down a segment of rows keeping the 3x3 window in registers: 3 new LDS values per output (6 for stride 2).
+// ---------------------------------------------------------------------------------------------------------------
+struct DwGeom {
+  int C, H, W, Ho, Wo;
+  int P;        // planes per tile (whole-plane mode) or 1
+  int TR;       // output rows per tile
+  int strips;   // tiles per plane along rows (1 in whole-plane mode)
+  int IR;       // LDS rows per plane (TR*S + 2)
+  int WS;       // LDS row stride (>= W + 2)
+  int nseg;     // row segments per tile in the compute phase
+  int RS;       // output rows per segment
+  int vec_in;   // 16-byte loads allowed
+};
+
+__device__ __forceinline__ float act_rt(float v, int act) {
+  if (act == FQ_ACT_RELU) v = fmaxf(v, 0.0f);
+  if (act == FQ_ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+  return v;
+}
+
+template <int S, bool QUANT, bool ONLINE>
+__global__ __launch_bounds__(kBlock) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           DwGeom g, int64_t tiles, const float* __restrict__ in_stat,
+                                                           int n, const float* __restrict__ in_thr, float levels,
+                                                           int lo_neg_max, float eps,
+                                                           float* __restrict__ cur_max_out,
+                                                           const float* __restrict__ bn_scale,
+                                                           const float* __restrict__ bn_shift, int act,
+                                                           float* __restrict__ stat_out) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ float red[4];
+  QParams q;
+  q.lo = q.hi = q.denom = q.scale = 0.0f;
+  if (QUANT) {
+    const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  }
+  const int lds_elems = g.P * g.IR * g.WS;
+  const int plane_in = g.H * g.W, plane_out = g.Ho * g.Wo;
+  const bool has_bn = bn_scale != nullptr;
+  const bool has_stat = stat_out != nullptr;
+
+  const ChunkRange rg = block_range(tiles);
+  for (int64_t t = rg.begin; t < rg.end; ++t) {
+    const int64_t pg = t / g.strips;                   // plane group
+    const int strip = (int)(t - pg * g.strips);
+    const int64_t plane0 = pg * g.P;                   // first (n*C + c) plane of the tile
+    const int ch0 = (int)(plane0 % g.C);               // P divides C: the tile's planes are ch0 .. ch0+P-1 of ONE sample
+    const int orow0 = strip * g.TR;                    // first output row
+    const int orows = (g.Ho - orow0) < g.TR ? (g.Ho - orow0) : g.TR;
+    const int irow_first = orow0 * S - 1;              // input row held by LDS row 0 (may be -1)
+    const int r_lo = irow_first < 0 ? 0 : irow_first;
+    int r_hi = irow_first + g.IR - 1;
+    if (r_hi > g.H - 1) r_hi = g.H - 1;
+
+    __syncthreads();                                   // previous tile fully consumed
+    for (int i = threadIdx.x * 4; i < lds_elems; i += kBlock * 4)
+      *reinterpret_cast<f4*>(tile + i) = (f4){0.f, 0.f, 0.f, 0.f};     // (allocation is padded to a multiple of 4)
+    __syncthreads();
+    // ---- load + quantise + stage: rows [r_lo, r_hi] of P consecutive planes -------------------------------------
+    // whole-plane mode: r_lo = 0, r_hi = H-1 and the P planes are one contiguous range; strip mode: P = 1.
+    {
+      const float* src = x + plane0 * (int64_t)plane_in + (int64_t)r_lo * g.W;
+      const int rows_per_plane = r_hi - r_lo + 1;
+      const int cnt = (g.P > 1) ? g.P * plane_in : rows_per_plane * g.W;
+      const unsigned W = (unsigned)g.W, RP = (unsigned)rows_per_plane;
+      if (g.vec_in) {
+        const f4* p4 = reinterpret_cast<const f4*>(src);
+        for (int i = threadIdx.x; i < cnt / 4; i += kBlock) {
+          f4 v = p4[i];
+          if (QUANT) v = fq_code4(v, q) * q.scale;
+          const unsigned e = (unsigned)i * 4u;
+          unsigned row = e / W;                                   // row index over the tile's planes
+          unsigned col = e - row * W;
+          unsigned pl = row / RP;
+          unsigned r = row - pl * RP;
+          float* d = tile + (pl * g.IR + (r + r_lo - irow_first)) * g.WS + col + 1;
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            d[0] = vv[k];
+            ++d;
+            if (++col == W) {                                     // next row (possibly next plane)
+              col = 0;
+              if (++r == RP) { r = 0; ++pl; }
+              d = tile + (pl * g.IR + (r + r_lo - irow_first)) * g.WS + 1;
+            }
+          }
+        }
+      } else {
+        for (int i = threadIdx.x; i < cnt; i += kBlock) {
+          float v = src[i];
+          if (QUANT) v = fq_code(v, q) * q.scale;
+          const unsigned row = (unsigned)i / W;
+          const unsigned col = (unsigned)i - row * W;
+          const unsigned pl = row / RP;
+          const unsigned r = row - pl * RP;
+          tile[(pl * g.IR + (r + r_lo - irow_first)) * g.WS + col + 1] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- sliding 3x3 window down a row segment; lane <-> output column ------------------------------------------
+    float m = 0.0f;
+    const int items = g.P * g.nseg * g.Wo;
+    for (int it = threadIdx.x; it < items; it += kBlock) {
+      const unsigned ps = (unsigned)it / (unsigned)g.Wo;
+      const unsigned col = (unsigned)it - ps * (unsigned)g.Wo;
+      const unsigned pl = ps / (unsigned)g.nseg;
+      const unsigned seg = ps - pl * (unsigned)g.nseg;
+      const int rr0 = (int)seg * g.RS;
+      int rr1 = rr0 + g.RS;
+      if (rr1 > orows) rr1 = orows;
+      if (rr0 >= rr1) continue;
+      const int ch = ch0 + (int)pl;
+      const float* wk = wgt + ch * 9;
+      const float w00 = wk[0], w01 = wk[1], w02 = wk[2], w10 = wk[3], w11 = wk[4], w12 = wk[5], w20 = wk[6],
+                  w21 = wk[7], w22 = wk[8];
+      const float bch = bias != nullptr ? bias[ch] : 0.0f;
+      const float bsc = has_bn ? bn_scale[ch] : 1.0f, bsh = has_bn ? bn_shift[ch] : 0.0f;
+      const float* l = tile + (pl * g.IR + rr0 * S) * g.WS + col * S;       // LDS col 0 == input col -1
+      float a0 = l[0], a1 = l[1], a2 = l[2];
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+      if (S == 1) {
+        b0 = l[g.WS];
+        b1 = l[g.WS + 1];
+        b2 = l[g.WS + 2];
+      }
+      float* dst = y + (plane0 + pl) * (int64_t)plane_out + (int64_t)(orow0 + rr0) * g.Wo + col;
+      for (int r = rr0; r < rr1; ++r) {
+        float c0, c1, c2;
+        if (S == 1) {
+          const float* lc = l + 2 * g.WS;
+          c0 = lc[0]; c1 = lc[1]; c2 = lc[2];
+        } else {
+          const float* lb = l + g.WS;
+          b0 = lb[0]; b1 = lb[1]; b2 = lb[2];
+          const float* lc = lb + g.WS;
+          c0 = lc[0]; c1 = lc[1]; c2 = lc[2];
+        }
+        float acc = 0.0f;
+        acc = fmaf(w00, a0, acc);
+        acc = fmaf(w01, a1, acc);
+        acc = fmaf(w02, a2, acc);
+        acc = fmaf(w10, b0, acc);
+        acc = fmaf(w11, b1, acc);
+        acc = fmaf(w12, b2, acc);
+        acc = fmaf(w20, c0, acc);
+        acc = fmaf(w21, c1, acc);
+        acc = fmaf(w22, c2, acc);
+        if (bias != nullptr) acc = acc + bch;
+        if (has_bn) {
+          acc = acc * bsc;
+          acc = acc + bsh;
+        }
+        acc = act_rt(acc, act);
+        *dst = acc;
+        m = fmaxf(m, fabsf(acc));
+        dst += g.Wo;
+        l += S * g.WS;
+        if (S == 1) {
+          a0 = b0; a1 = b1; a2 = b2;
+          b0 = c0; b1 = c1; b2 = c2;
+        } else {
+          a0 = c0; a1 = c1; a2 = c2;
+        }
+      }
+    }
+    if (has_stat) {
+      m = block_max(m, red);
+      if (threadIdx.x == 0) atomic_max_f32(stat_out + plane0 / g.C, m);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K3: weights, (rows, row_len).  Small rows: a workgroup stages several whole rows in LDS (one HBM read), reduces
 // each row with a wavefront, then applies from LDS.  Long rows (layer mode): K1 per row + K3b apply.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1215,6 +1398,88 @@ int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, c
 #undef FQ_BN_V
 #undef FQ_BN_U
 #undef FQ_BN
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
+                 int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                 float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                 fqStream_t stream) {
+  FQ_REQUIRE(x && w && y, "fq_dwconv3x3: null pointer");
+  FQ_REQUIRE(n > 0 && c > 0 && h > 0 && wdt > 0 && n * c < (1ll << 31) && h * wdt < (1ll << 28),
+             "fq_dwconv3x3: bad shape (n=%lld c=%lld h=%lld w=%lld)", (long long)n, (long long)c, (long long)h,
+             (long long)wdt);
+  FQ_REQUIRE(stride == 1 || stride == 2, "fq_dwconv3x3: stride must be 1 or 2, got %d", stride);
+  FQ_REQUIRE(!(in_stat && in_thr), "fq_dwconv3x3: give in_stat (online) OR in_thr (offline), not both");
+  FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_dwconv3x3: bn_scale and bn_shift go together");
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_dwconv3x3: unknown activation %d", act);
+  const bool quant = in_stat != nullptr || in_thr != nullptr;
+  if (quant) FQ_REQUIRE(in_width >= 2 && in_width <= 16, "fq_dwconv3x3: width %d out of range", in_width);
+  hipStream_t st = (hipStream_t)stream;
+  DwGeom g;
+  g.C = (int)c;
+  g.H = (int)h;
+  g.W = (int)wdt;
+  g.Ho = (int)((h - 1) / stride + 1);
+  g.Wo = (int)((wdt - 1) / stride + 1);
+  g.WS = g.W + 2;
+  if ((g.WS & 1) == 0) g.WS += 1;                       // odd dword stride
+  const int lds_budget = 8192;                          // floats (32 KiB) -> up to 5 workgroups per CU
+  const int plane_in = g.H * g.W;
+  if (plane_in <= 4096 && (g.H + 2) * g.WS <= lds_budget) {
+    g.TR = g.Ho;
+    g.strips = 1;
+    g.IR = g.H + 2;
+    g.P = 1;
+    for (int p = (int)(c < 64 ? c : 64); p >= 1; --p)
+      if (c % p == 0 && p * g.IR * g.WS <= lds_budget) {
+        g.P = p;
+        break;
+      }
+  } else {
+    g.P = 1;
+    int tr = (lds_budget / g.WS - 2) / stride;
+    FQ_REQUIRE(tr >= 1, "fq_dwconv3x3: rows of %d floats do not fit the LDS tile", g.W);
+    g.strips = (g.Ho + tr - 1) / tr;
+    g.TR = (g.Ho + g.strips - 1) / g.strips;
+    g.IR = g.TR * stride + 2;
+  }
+  {
+    const int per_seg = g.P * g.Wo;
+    int nseg = (2 * kBlock + per_seg - 1) / per_seg;    // aim at ~2 work items per lane
+    if (nseg < 1) nseg = 1;
+    if (nseg > g.TR) nseg = g.TR;
+    g.RS = (g.TR + nseg - 1) / nseg;
+    g.nseg = (g.TR + g.RS - 1) / g.RS;
+  }
+  const bool base_ok = aligned16(x);
+  if (g.P > 1 || g.strips == 1)
+    g.vec_in = base_ok && (((int64_t)g.P * plane_in) % 4 == 0) && (plane_in % 4 == 0 || g.P % 4 == 0);
+  else
+    g.vec_in = base_ok && (g.W % 4 == 0) && (plane_in % 4 == 0);
+  const int64_t tiles = (n * c / g.P) * g.strips;
+  size_t lds = (size_t)((g.P * g.IR * g.WS + 3) / 4 * 4 + 16) * sizeof(float);
+  const int grid = grid_for(tiles);
+  const float levels = act_levels(in_width, in_flags);
+  const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+  const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+  if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * g.Ho * g.Wo), st);
+#define FQ_DW(SS, Q, O)                                                                                           \
+  hipLaunchKernelGGL((dwconv3x3_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), lds, st, x, w, bias, y, g, tiles,    \
+                     in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale, bn_shift, act,      \
+                     stat_out)
+  if (stride == 1) {
+    if (!quant) FQ_DW(1, false, false);
+    else if (in_stat) FQ_DW(1, true, true);
+    else FQ_DW(1, true, false);
+  } else {
+    if (!quant) FQ_DW(2, false, false);
+    else if (in_stat) FQ_DW(2, true, true);
+    else FQ_DW(2, true, false);
+  }
+#undef FQ_DW
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["fake_quant_online_prestat", "bn_act_stat", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["fake_quant_online_prestat", "bn_act_stat", "dwconv3x3", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -227,6 +227,28 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     stat = torch.empty(n, dtype=torch.float32, device=x.device) if want_stat else None
     check_call(_lib_().fq_bn_act_stat(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act], _ptr(stat),
                                       _stream(x)))
+    return y, stat
+
+
+def dwconv3x3(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None, bn_scale=None,
+              bn_shift=None, act=None, want_stat=True):
+    """Depthwise 3x3 (pad 1) with optional quantise-on-load of x (in_stat: online, in_thr: offline) and fused
+    BatchNorm/activation/per-sample-statistic epilogue.  Returns (y, stat (N,) or None)."""
+    _check(x, "x")
+    _check(w, "w")
+    if x.dim() != 4 or w.dim() != 4 or tuple(w.shape[1:]) != (1, 3, 3) or w.shape[0] != x.shape[1]:
+        raise ValueError("dwconv3x3 wants x (N,C,H,W) and w (C,1,3,3); got %s and %s" % (tuple(x.shape), tuple(w.shape)))
+    for name, t in (("bias", bias), ("in_stat", in_stat), ("in_thr", in_thr), ("bn_scale", bn_scale),
+                    ("bn_shift", bn_shift), ("cur_out", cur_out)):
+        if t is not None:
+            _check(t, name)
+    n, c, h, wd = x.shape
+    ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    stat = torch.empty(n, dtype=torch.float32, device=x.device) if want_stat else None
+    check_call(_lib_().fq_dwconv3x3(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, c, h, wd, int(stride), _ptr(in_stat),
+                                    _ptr(in_thr), int(width), int(flags), _ptr(cur_out), _ptr(bn_scale),
+                                    _ptr(bn_shift), _ACTS[act], _ptr(stat), _stream(x)))
     return y, stat
 
 

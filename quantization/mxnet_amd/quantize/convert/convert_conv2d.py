@@ -89,9 +89,62 @@ def _fake_quant_input(m, x, input_max, flags, width):
     return x
 
 
+def _fused_input_params(m, x, input_max, flags, width):
+    """Activation branch when the convolution itself quantises on load (quantize/fuse.py, depthwise 3x3): produce the
+    statistic / threshold exactly as `_fake_quant_input` would, but NO apply pass.  Returns kwargs for ops.dwconv3x3."""
+    t = x._t if x._t.is_contiguous() else x._t.contiguous()
+    n = t.shape[0]
+    cur = _cur_slot(m, t)
+    stat_ws = getattr(m, "_fq_stat_ws", None)
+    if stat_ws is not None and (stat_ws.device != t.device or stat_ws.numel() < n):
+        stat_ws = None
+    gstat = getattr(m, "_fq_global_stat", None)
+    hint = x._fq_stat if x._t is t else None
+    if hint is not None and (hint.numel() != n or hint.device != t.device):
+        hint = None
+    online = m.quantize_input and not m.quantize_input_offline
+    need_stat = online or gstat is not None or getattr(m, "track_input_stat", True)
+    per_sample = None
+    if need_stat:
+        per_sample = hint if hint is not None else \
+            ops.absmax_per_sample(t, out=None if stat_ws is None else stat_ws[:n])
+    kw = {}
+    if gstat is not None and stat_ws is not None:
+        gstat(per_sample, n, cur)
+        if m.quantize_input:
+            kw = dict(in_thr=input_max._t if m.quantize_input_offline else cur, width=width, flags=flags)
+    elif online:
+        kw = dict(in_stat=per_sample, width=width, flags=flags, cur_out=cur)      # the kernel writes cur
+    else:
+        if per_sample is not None:
+            ops.batch_mean(per_sample, out=cur)
+        if m.quantize_input:
+            kw = dict(in_thr=input_max._t, width=width, flags=flags)
+    m._fq_last_n = n
+    m.current_input_max = DeviceScalar(cur)
+    return kw
+
+
+def _dw_fused_conv(m, x, weight_q, bias, quant_kw):
+    """Depthwise 3x3 through fq_dwconv3x3: quantise-on-load + the BatchNorm / activation that followed this block +
+    the per-sample statistic of the output for the next fake-quant."""
+    fz = m._fq_dw_fused
+    t = x._t if x._t.is_contiguous() else x._t.contiguous()
+    w = weight_q._t if weight_q._t.is_contiguous() else weight_q._t.contiguous()
+    b = None if bias is None else bias._t
+    scale, shift = fz["constants"]() if fz["bn"] is not None else (None, None)
+    y, stat = ops.dwconv3x3(t, w, b, stride=m._kwargs["stride"][0], bn_scale=scale, bn_shift=shift, act=fz["act"],
+                            **quant_kw)
+    out = NDArray(y)
+    out._fq_stat = stat
+    return out
+
+
 def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
                     gamma=None, beta=None, running_mean=None, running_var=None):
     qa = self.quantize_args
+    fz = getattr(self, "_fq_dw_fused", None)
+    quant_kw = {}
     # Fake bn (:47-51)
     if self.fixed_params != 1 and qa.fake_bn:
         w_shape = weight.shape
@@ -103,7 +156,10 @@ def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
     if self.enable_quantize:
         # Quantize input (:55-66)
         if qa.quantize_input:
-            x = _fake_quant_input(self, x, input_max, ops.act_flags(signed=qa.in_signed), qa.in_width)
+            if fz is None:
+                x = _fake_quant_input(self, x, input_max, ops.act_flags(signed=qa.in_signed), qa.in_width)
+            else:
+                quant_kw = _fused_input_params(self, x, input_max, ops.act_flags(signed=qa.in_signed), qa.in_width)
 
         # Simulate quantization for weight (:68-99)
         if self.fixed_params != 1:
@@ -137,6 +193,8 @@ def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
             self.bias.set_data(bias)
 
     # Normal convolution (:108) — MIOpen through torch; not the path this project replaces
+    if fz is not None:
+        return _dw_fused_conv(self, x, weight_q, bias, quant_kw)
     act = self.origin_forward(F, x, weight_q, bias)
 
     return act

@@ -65,9 +65,72 @@ def _identity_forward(self, F, x, *args, **kwargs):
     return x
 
 
-def fuse_inference(net):
-    """Returns the number of BatchNorm blocks fused."""
+def _is_dw3x3(b):
+    if type(b) is not nn.Conv2D:
+        return False
+    k = b._kwargs
+    cin = b.weight.shape[1] if b.weight.shape else 0
+    return (k["kernel"] == (3, 3) and k["pad"] == (1, 1) and k["dilate"] == (1, 1) and k["stride"] in ((1, 1), (2, 2))
+            and k["num_group"] == k["num_filter"] and cin == 1 and k["layout"] == "NCHW" and b.act is None
+            and not getattr(getattr(b, "quantize_args", None), "fake_bn", False))
+
+
+def _plain_dw_forward(self, F, x, weight, bias=None):
+    from .convert.convert_conv2d import _dw_fused_conv
+    return _dw_fused_conv(self, x, weight, bias, {})
+
+
+def _bn_constants_getter(bn):
+    cache = {"key": None, "val": None}
+
+    def get():
+        key = (bn.gamma.data()._t.data_ptr(), bn.beta.data()._t.data_ptr(), bn.running_mean.data()._t.data_ptr(),
+               bn.running_var.data()._t.data_ptr(), bn.__dict__.get("_fq_refresh", 0))
+        if cache["key"] != key:
+            scale, shift, _ = _bn_constants(bn)
+            cache["key"], cache["val"] = key, (scale, shift)
+        return cache["val"]
+    return get
+
+
+def fuse_inference(net, depthwise=True):
+    """Returns the number of blocks fused (BatchNorms folded + depthwise convolutions taken over)."""
     fused = [0]
+
+    def bypass(blk):
+        blk._fq_bypassed_orig = blk.hybrid_forward
+        blk.hybrid_forward = types.MethodType(_identity_forward, blk)
+
+    def visit_dw(container):
+        if not isinstance(container, (nn.Sequential, nn.HybridSequential)):
+            return
+        kids = list(container._children.values())
+        for i, b in enumerate(kids):
+            if not _is_dw3x3(b) or hasattr(b, "_fq_dw_fused"):
+                continue
+            converted = hasattr(b, "quantize_args")
+            if not converted and b.hybrid_forward.__func__ is not nn.Conv2D.hybrid_forward:
+                continue
+            bn = kids[i + 1] if i + 1 < len(kids) else None
+            if not (type(bn) is nn.BatchNorm and not hasattr(bn, "_fq_fused") and bn._kwargs.get("axis", 1) == 1
+                    and bn.hybrid_forward.__func__ is nn.BatchNorm.hybrid_forward):
+                bn = None
+            nxt = kids[i + 2] if bn is not None and i + 2 < len(kids) else (kids[i + 1] if bn is None and i + 1 < len(kids) else None)
+            act = _act_kind(nxt) if nxt is not None else None
+            b._fq_dw_fused = {"bn": bn, "act": act or "none", "act_block": nxt if act else None,
+                              "constants": _bn_constants_getter(bn) if bn is not None else None,
+                              "orig": None if converted else b.hybrid_forward}
+            if not converted:
+                b.hybrid_forward = types.MethodType(_plain_dw_forward, b)
+            if bn is not None:
+                bn._fq_fused = {"taken_by_conv": True, "orig": bn.hybrid_forward, "act_block": None}
+                bn.hybrid_forward = types.MethodType(_identity_forward, bn)
+            if act:
+                bypass(nxt)
+            fused[0] += 1
+
+    if depthwise:
+        net.apply(visit_dw)
 
     def visit(container):
         kids = list(container._children.values())
@@ -79,12 +142,13 @@ def fuse_inference(net):
             nxt = kids[i + 1] if i + 1 < len(kids) and isinstance(container, (nn.Sequential, nn.HybridSequential)) \
                 else None
             act = _act_kind(nxt) if nxt is not None else None
+            if act and hasattr(nxt, "_fq_bypassed_orig"):
+                act = None
             b._fq_fused = {"act": act or "none", "key": None, "scale": None, "shift": None,
                            "orig": b.hybrid_forward, "act_block": nxt if act else None}
             b.hybrid_forward = types.MethodType(_fused_bn_forward, b)
             if act:
-                nxt._fq_bypassed_orig = nxt.hybrid_forward
-                nxt.hybrid_forward = types.MethodType(_identity_forward, nxt)
+                bypass(nxt)
             fused[0] += 1
 
     net.apply(visit)
@@ -96,16 +160,26 @@ def refresh(net):
     def visit(b):
         if hasattr(b, "_fq_fused"):
             b._fq_fused["key"] = None
+            b._fq_refresh = b.__dict__.get("_fq_refresh", 0) + 1
     net.apply(visit)
 
 
 def unfuse(net):
+    def restore_act(blk):
+        if blk is not None and hasattr(blk, "_fq_bypassed_orig"):
+            blk.hybrid_forward = blk._fq_bypassed_orig
+            del blk._fq_bypassed_orig
+
     def visit(b):
+        if hasattr(b, "_fq_dw_fused"):
+            st = b._fq_dw_fused
+            if st["orig"] is not None:
+                b.hybrid_forward = st["orig"]
+            restore_act(st["act_block"])
+            del b._fq_dw_fused
         if hasattr(b, "_fq_fused"):
             st = b._fq_fused
             b.hybrid_forward = st["orig"]
-            if st["act_block"] is not None:
-                st["act_block"].hybrid_forward = st["act_block"]._fq_bypassed_orig
-                del st["act_block"]._fq_bypassed_orig
+            restore_act(st["act_block"])
             del b._fq_fused
     net.apply(visit)

@@ -236,11 +236,36 @@ def test_fused_inference_keeps_every_block_exact(gpu, model, classes, hw, batch,
     n = fuse.fuse_inference(net)
     assert n > 0
     spy = Spy(net)
-    out = net(X).asnumpy()
+    # depthwise convolutions taken over by fq_dwconv3x3 never reach origin_forward: record the kernel calls instead
+    from quantization.mxnet_amd import ops
+    dw_calls = []
+    real_dw = ops.dwconv3x3
+
+    def spy_dw(x, w, bias=None, **k):
+        y, stat = real_dw(x, w, bias, **k)
+        dw_calls.append(dict(x=x.detach().clone(), w=w.detach().clone(), y=y.detach().clone(), stat=stat.detach().clone(),
+                             k={a: (b.detach().clone() if torch.is_tensor(b) else b) for a, b in k.items()}))
+        return y, stat
+    ops.dwconv3x3 = spy_dw
+    try:
+        out = net(X).asnumpy()
+    finally:
+        ops.dwconv3x3 = real_dw
     args = dict(signed=False, in_w=8, wt=kw.get("wt", 8), quant_type=kw.get("quant_type", "layer"), wino="none")
     _check_records(spy.records, offline=False, **args)
-    hinted = sum(1 for r in spy.records if r["block"].current_input_max is not None)
-    assert hinted == len(spy.records)
+    n_dw = sum(1 for b in spy.blocks if hasattr(b, "_fq_dw_fused"))
+    assert len(dw_calls) == n_dw and len(spy.records) + n_dw == len(spy.blocks)
+    for call in dw_calls:
+        k = call["k"]
+        x_raw = call["x"].cpu().numpy()
+        per_sample = O.absmax_per_sample(x_raw)
+        assert np.array_equal(k["in_stat"].cpu().numpy(), per_sample)           # hint == what the statistic pass gives
+        assert k["cur_out"].cpu().numpy()[0] == O.batch_mean(per_sample)
+        want = O.dwconv3x3(x_raw, call["w"].cpu().numpy(), None, k["stride"], O.batch_mean(per_sample), False, 8, None,
+                           k["bn_scale"].cpu().numpy(), k["bn_shift"].cpu().numpy(), k["act"])
+        got = call["y"].cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+        assert np.array_equal(call["stat"].cpu().numpy(), O.absmax_per_sample(got))
     scale = np.abs(ref).max()
     assert np.abs(out - ref).max() <= 2e-2 * scale, (np.abs(out - ref).max(), scale)
     fuse.unfuse(net)

@@ -365,3 +365,56 @@ def test_bn_act_stat_vs_oracle(dev, ops, shape, act):
     assert N(cur_a)[0] == N(cur_b)[0]
     _eq(N(codes_a), N(codes_b))
     _eq(N(a), N(b))
+
+
+# ---- fused depthwise 3x3: quantise-on-load + BN/act/statistic epilogue ------------------------------------------------
+DW_SHAPES = [(2, 8, 7, 7), (3, 16, 14, 14), (2, 32, 28, 28), (2, 8, 56, 56), (2, 4, 112, 112), (1, 3, 9, 11),
+             (2, 5, 13, 6), (4, 1024, 7, 7), (2, 6, 70, 70), (1, 2, 113, 113)]
+
+
+@pytest.mark.parametrize("shape", DW_SHAPES)
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("mode", ["plain", "online", "offline_signed", "bn_relu_online", "bias_relu6"])
+def test_dwconv3x3_vs_oracle(dev, ops, shape, stride, mode):
+    rng = np.random.default_rng(sum(shape) * 7 + stride)
+    n, c, h, w = shape
+    x = (rng.standard_normal(shape) * 2).astype(np.float32)
+    if "signed" not in mode:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((c, 1, 3, 3)) * 0.5).astype(np.float32)
+    kw, okw = {}, {}
+    if mode in ("online", "bn_relu_online"):
+        stat = O.absmax_per_sample(x)
+        kw.update(in_stat=T(stat, dev), width=8, flags=0)
+        okw.update(in_max=O.batch_mean(stat), signed=False, width=8)
+    if mode == "offline_signed":
+        thr = np.float32(1.7)
+        kw.update(in_thr=T(np.float32([thr]), dev), width=4, flags=ops.act_flags(signed=True))
+        okw.update(in_max=thr, signed=True, width=4)
+    if mode == "bn_relu_online":
+        sc = rng.uniform(0.3, 1.5, c).astype(np.float32)
+        sh = rng.standard_normal(c).astype(np.float32)
+        kw.update(bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu")
+        okw.update(bn_scale=sc, bn_shift=sh, act="relu")
+    if mode == "bias_relu6":
+        b = rng.standard_normal(c).astype(np.float32)
+        kw.update(bias=T(b, dev), act="relu6")
+        okw.update(bias=b, act="relu6")
+    cur = torch.zeros(1, device=dev)
+    y, stat_out = ops.dwconv3x3(T(x, dev), T(wt, dev), stride=stride, cur_out=cur, **kw)
+    want = O.dwconv3x3(x, wt, stride=stride, **okw)
+    got = N(y)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    assert (got != want).mean() < 1e-3                         # fmaf emulation differs only at double-rounding ties
+    _eq(N(stat_out), O.absmax_per_sample(got), "statistic of the produced output")
+    if "online" in mode:
+        assert N(cur)[0] == okw["in_max"]
+    # against an independent implementation (torch conv on the quantised input), loose
+    import torch.nn.functional as TF
+    xq = x if "in_max" not in okw else O.conv_input_fake_quant(x, okw["signed"], okw["width"],
+                                                                offline_threshold=okw["in_max"])[0]
+    ref = TF.conv2d(torch.from_numpy(xq).double(), torch.from_numpy(wt).double(), None, stride=stride, padding=1,
+                    groups=c).numpy()
+    if mode == "plain":
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
