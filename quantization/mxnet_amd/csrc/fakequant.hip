@@ -674,6 +674,436 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K2d: depthwise 3x3, register sliding-window form (no LDS, no barriers).  A wavefront holds `segs` independent
+// SEGMENTS; a segment is `sw` adjacent output columns of one plane plus halo lanes (stride 1: one on each side, stride
+// 2: one on the left).  Every lane streams ITS input column(s) top to bottom — one coalesced 4-byte load per lane per
+// input row, quantised once — and gets its horizontal neighbours from the adjacent lanes with wavefront shuffles; the
+// three live input rows stay in registers, loads run D rows ahead of their use.
+// ---------------------------------------------------------------------------------------------------------------
+struct DwColGeom {
+  int C, H, W, Ho, Wo;
+  int sw;       // output columns per segment
+  int nsegx;    // segments per plane row
+  int SEG;      // lanes per segment (sw + halo lanes)
+  int segs;     // segments per wavefront
+};
+
+template <int S, bool QUANT, bool ONLINE>
+__global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
+    const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
+    float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
+    const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
+  constexpr int D = (S == 1) ? 8 : 4;                   // output rows of input kept in flight (S=2: 4 loads per row)
+  __shared__ float red_m[4];
+  __shared__ int red_s[4];
+  QParams q;
+  q.lo = q.hi = q.denom = q.scale = 0.0f;
+  if (QUANT) {
+    const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg_in_wave = lane / g.SEG;
+  const int pos = lane - seg_in_wave * g.SEG;
+  const bool lane_used = seg_in_wave < g.segs;
+  const int64_t segs_per_block = (int64_t)g.segs * (kBlock / 64);
+  const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
+  const int plane_in = g.H * g.W, plane_out = g.Ho * g.Wo;
+
+  // (Row strips per plane were tried for load balance and measured slower: every strip restarts the prefetch ring.)
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t seg = blk * segs_per_block + (int64_t)wave * g.segs + seg_in_wave;
+    const bool seg_ok = lane_used && seg < total_segs;
+    const int64_t plane = seg_ok ? seg / g.nsegx : 0;
+    const int sx = seg_ok ? (int)(seg - plane * g.nsegx) : 0;
+    const int ch = (int)(plane % g.C);
+    const int sample = (int)(plane / g.C);
+    // column bookkeeping
+    int oc, ic0;                                          // output column; first input column this lane loads
+    bool is_out;
+    if (S == 1) {
+      ic0 = sx * g.sw + pos - 1;                          // pos 0 / sw+1 are the halo lanes
+      oc = ic0;
+      is_out = seg_ok && pos >= 1 && pos <= g.sw && oc < g.Wo;
+    } else {
+      oc = sx * g.sw + pos - 1;                           // pos 0 is the left-halo lane
+      ic0 = 2 * oc;                                       // this lane loads input columns 2*oc and 2*oc + 1
+      is_out = seg_ok && pos >= 1 && oc < g.Wo;
+    }
+    const bool ld0 = seg_ok && (S == 1 ? (ic0 >= 0 && ic0 < g.W) : (pos >= 1 && ic0 < g.W));
+    const bool ld1 = seg_ok && S == 2 && (ic0 + 1 >= 0) && (ic0 + 1 < g.W);     // stride 2: second column (halo lane: col 2*sx*sw - 1)
+    const float* xp = x + plane * (int64_t)plane_in + ic0;
+    float* yp = y + plane * (int64_t)plane_out + oc;
+    const float* wk = wgt + ch * 9;
+    const float w00 = wk[0], w01 = wk[1], w02 = wk[2], w10 = wk[3], w11 = wk[4], w12 = wk[5], w20 = wk[6],
+                w21 = wk[7], w22 = wk[8];
+    const float bch = bias != nullptr ? bias[ch] : 0.0f;
+    const float bsc = has_bn ? bn_scale[ch] : 1.0f, bsh = has_bn ? bn_shift[ch] : 0.0f;
+    float m = 0.0f;
+
+    // Loads are UNCONDITIONAL from clamped (always valid) addresses and masked afterwards with a bitwise AND — a
+    // `cond ? load : 0` select is turned back into a predicated load by hipcc (CodeGenPrepare sinks the load under a
+    // branch), which then waits vmcnt(0) right behind it and the prefetch ring is gone.
+    const int last_row = g.H - 1;
+    auto keep = [](float v, bool ok) -> float { return __uint_as_float(__float_as_uint(v) & (ok ? 0xFFFFFFFFu : 0u)); };
+    if (S == 1) {
+      // rows: a = input row r-1, b = row r, c = row r+1 (each as left / centre / right)
+      const float* xs = ld0 ? xp : x;                      // lanes with nothing to load read element 0
+      auto ldrow = [&](int row) -> float {
+        const int rc = row < last_row ? row : last_row;
+        return keep(xs[(int64_t)rc * g.W], ld0 && row <= last_row);
+      };
+      auto emit = [&](int r, float c1, float& a0, float& a1, float& a2, float& b0, float& b1, float& b2) {
+        if (QUANT) c1 = fq_code(c1, q) * q.scale;
+        const float c0 = __shfl_up(c1, 1, 64), c2 = __shfl_down(c1, 1, 64);
+        float acc = 0.0f;
+        acc = fmaf(w00, a0, acc);
+        acc = fmaf(w01, a1, acc);
+        acc = fmaf(w02, a2, acc);
+        acc = fmaf(w10, b0, acc);
+        acc = fmaf(w11, b1, acc);
+        acc = fmaf(w12, b2, acc);
+        acc = fmaf(w20, c0, acc);
+        acc = fmaf(w21, c1, acc);
+        acc = fmaf(w22, c2, acc);
+        if (bias != nullptr) acc = acc + bch;
+        if (has_bn) {
+          acc = acc * bsc;
+          acc = acc + bsh;
+        }
+        acc = act_rt(acc, act);
+        m = fmaxf(m, keep(fabsf(acc), is_out));
+        if (is_out) yp[(int64_t)r * g.Wo] = acc;
+        a0 = b0; a1 = b1; a2 = b2;
+        b0 = c0; b1 = c1; b2 = c2;
+      };
+      float raw[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) raw[k] = ldrow(1 + k);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      float b1 = ldrow(0);
+      if (QUANT) b1 = fq_code(b1, q) * q.scale;
+      float b0 = __shfl_up(b1, 1, 64), b2 = __shfl_down(b1, 1, 64);
+      const int rend = g.Ho;                              // same trip count for every lane of the grid
+      int r0 = 0;
+      for (; r0 + D <= rend; r0 += D) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float c1 = raw[k];
+          raw[k] = ldrow(r0 + k + 1 + D);
+          emit(r0 + k, c1, a0, a1, a2, b0, b1, b2);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (r0 + k < rend) emit(r0 + k, raw[k], a0, a1, a2, b0, b1, b2);
+    } else {
+      // stride 2: output row r uses input rows 2r-1 (a), 2r (b), 2r+1 (c); per input row: left = neighbour's 2nd
+      // column, centre = own 1st column, right = own 2nd column
+      const float* xs0 = ld0 ? xp : x;
+      const float* xs1 = ld1 ? xp + 1 : x;
+      auto ld_a = [&](int row) -> float {
+        const int rc = row < last_row ? row : last_row;
+        return keep(xs0[(int64_t)rc * g.W], ld0 && row <= last_row);
+      };
+      auto ld_b = [&](int row) -> float {
+        const int rc = row < last_row ? row : last_row;
+        return keep(xs1[(int64_t)rc * g.W], ld1 && row <= last_row);
+      };
+      auto emit2 = [&](int r, float b1, float b2, float c1, float c2, float& a0, float& a1, float& a2) {
+        if (QUANT) {
+          b1 = fq_code(b1, q) * q.scale;
+          b2 = fq_code(b2, q) * q.scale;
+          c1 = fq_code(c1, q) * q.scale;
+          c2 = fq_code(c2, q) * q.scale;
+        }
+        const float b0 = __shfl_up(b2, 1, 64), c0 = __shfl_up(c2, 1, 64);
+        float acc = 0.0f;
+        acc = fmaf(w00, a0, acc);
+        acc = fmaf(w01, a1, acc);
+        acc = fmaf(w02, a2, acc);
+        acc = fmaf(w10, b0, acc);
+        acc = fmaf(w11, b1, acc);
+        acc = fmaf(w12, b2, acc);
+        acc = fmaf(w20, c0, acc);
+        acc = fmaf(w21, c1, acc);
+        acc = fmaf(w22, c2, acc);
+        if (bias != nullptr) acc = acc + bch;
+        if (has_bn) {
+          acc = acc * bsc;
+          acc = acc + bsh;
+        }
+        acc = act_rt(acc, act);
+        m = fmaxf(m, keep(fabsf(acc), is_out));
+        if (is_out) yp[(int64_t)r * g.Wo] = acc;
+        a0 = c0; a1 = c1; a2 = c2;
+      };
+      float rb0[D], rb1[D], rc0[D], rc1[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        rb0[k] = ld_a(2 * k);
+        rb1[k] = ld_b(2 * k);
+        rc0[k] = ld_a(2 * k + 1);
+        rc1[k] = ld_b(2 * k + 1);
+      }
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      const int rend = g.Ho;
+      int r0 = 0;
+      for (; r0 + D <= rend; r0 += D) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float b1 = rb0[k], b2 = rb1[k], c1 = rc0[k], c2 = rc1[k];
+          const int rn = r0 + k + D;
+          rb0[k] = ld_a(2 * rn);
+          rb1[k] = ld_b(2 * rn);
+          rc0[k] = ld_a(2 * rn + 1);
+          rc1[k] = ld_b(2 * rn + 1);
+          emit2(r0 + k, b1, b2, c1, c2, a0, a1, a2);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (r0 + k < rend) emit2(r0 + k, rb0[k], rb1[k], rc0[k], rc1[k], a0, a1, a2);
+    }
+    if (has_stat) {
+      // one atomic per workgroup when all its lanes belong to one sample (the common case), else per wave / lane
+      const int s0 = __shfl(sample, 0, 64);
+      const bool wave_uniform = __all(!is_out || sample == s0);
+      const float wm = wave_max(is_out ? m : 0.0f);
+      __syncthreads();
+      if (lane == 0) {
+        red_m[wave] = wm;
+        red_s[wave] = wave_uniform ? s0 : -1;
+      }
+      __syncthreads();
+      const bool blk_uniform = red_s[0] >= 0 && red_s[0] == red_s[1] && red_s[1] == red_s[2] && red_s[2] == red_s[3];
+      if (blk_uniform) {
+        if (threadIdx.x == 0)
+          atomic_max_f32(stat_out + red_s[0], fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3])));
+      } else if (wave_uniform) {
+        if (lane == 0) atomic_max_f32(stat_out + s0, wm);
+      } else if (is_out) {
+        atomic_max_f32(stat_out + sample, m);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2e: the same sliding window with FOUR input columns per lane (16-byte loads, 16-byte stores for stride 1 / 8-byte
+// for stride 2) — needs W % 4 == 0.  With 4-byte accesses the kernel above cannot keep enough bytes in flight
+// (PMC: 38 % of wave cycles parked on vmcnt at 4.1 TB/s); this form has 4x the bytes per outstanding load.
+// Lane p of a segment: p = 0 left-halo lane, 1..L compute lanes (input columns 4(p-1)..4(p-1)+3), L+1 right-halo lane
+// (stride 1 only).  Halo lanes load and quantise like the others; their neighbours pick up .w / .x by shuffle.
+// ---------------------------------------------------------------------------------------------------------------
+template <int S, bool QUANT, bool ONLINE>
+__global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
+    const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
+    float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
+    const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
+  // Input rows are fetched in BURSTS of D rows (double buffered): the D loads of a burst leave the wave back to back
+  // and hit the same DRAM pages; one load per step (a ring) spreads them ~700 cycles apart, and with thousands of
+  // waves each streaming its own plane every access then opens a new page.
+  constexpr int D = (S == 1) ? 4 : 2;
+  __shared__ float red_m[4];
+  __shared__ int red_s[4];
+  QParams q;
+  q.lo = q.hi = q.denom = q.scale = 0.0f;
+  if (QUANT) {
+    const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg_in_wave = lane / g.SEG;
+  const int pos = lane - seg_in_wave * g.SEG;
+  const bool lane_used = seg_in_wave < g.segs;
+  const int64_t segs_per_block = (int64_t)g.segs * (kBlock / 64);
+  const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
+  const int plane_in = g.H * g.W, plane_out = g.Ho * g.Wo;
+  const int last_row = g.H - 1;
+  auto keep4 = [](f4 v, bool ok) -> f4 {
+    const unsigned mk = ok ? 0xFFFFFFFFu : 0u;
+    f4 r;
+    r.x = __uint_as_float(__float_as_uint(v.x) & mk);
+    r.y = __uint_as_float(__float_as_uint(v.y) & mk);
+    r.z = __uint_as_float(__float_as_uint(v.z) & mk);
+    r.w = __uint_as_float(__float_as_uint(v.w) & mk);
+    return r;
+  };
+  auto keep = [](float v, bool ok) -> float { return __uint_as_float(__float_as_uint(v) & (ok ? 0xFFFFFFFFu : 0u)); };
+
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t seg = blk * segs_per_block + (int64_t)wave * g.segs + seg_in_wave;
+    const bool seg_ok = lane_used && seg < total_segs;
+    const int64_t plane = seg_ok ? seg / g.nsegx : 0;
+    const int sx = seg_ok ? (int)(seg - plane * g.nsegx) : 0;
+    const int ch = (int)(plane % g.C);
+    const int sample = (int)(plane / g.C);
+    const int ic0 = (sx * g.sw + pos - 1) * 4;            // first of the 4 input columns this lane loads
+    const bool ld_ok = seg_ok && ic0 >= 0 && ic0 < g.W;
+    const int oc = S == 1 ? ic0 : ic0 / 2;                // first output column (4 outputs for S=1, 2 for S=2)
+    const bool is_out = seg_ok && pos >= 1 && pos <= g.sw && oc < g.Wo;
+    const f4* xs = reinterpret_cast<const f4*>(ld_ok ? x + plane * (int64_t)plane_in + ic0 : x);
+    float* yp = y + plane * (int64_t)plane_out + oc;
+    const int rowq = g.W / 4;                             // f4 per input row
+    const float* wk = wgt + ch * 9;
+    const float w00 = wk[0], w01 = wk[1], w02 = wk[2], w10 = wk[3], w11 = wk[4], w12 = wk[5], w20 = wk[6],
+                w21 = wk[7], w22 = wk[8];
+    const float bch = bias != nullptr ? bias[ch] : 0.0f;
+    const float bsc = has_bn ? bn_scale[ch] : 1.0f, bsh = has_bn ? bn_shift[ch] : 0.0f;
+    float m = 0.0f;
+    auto ldrow = [&](int row) -> f4 {
+      const int rc = row < last_row ? row : last_row;
+      return keep4(xs[(int64_t)rc * rowq], ld_ok && row <= last_row);
+    };
+    auto quant4 = [&](f4 v) -> f4 { return QUANT ? fq_code4(v, q) * q.scale : v; };
+    auto finish = [&](float acc) -> float {
+      if (bias != nullptr) acc = acc + bch;
+      if (has_bn) {
+        acc = acc * bsc;
+        acc = acc + bsh;
+      }
+      return act_rt(acc, act);
+    };
+
+    if (S == 1) {
+      // a, b, c: rows r-1, r, r+1 as (left, v.x, v.y, v.z, v.w, right)
+      float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b[6];
+      f4 raw[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) raw[k] = ldrow(1 + k);
+      {
+        const f4 v = quant4(ldrow(0));
+        b[0] = __shfl_up(v.w, 1, 64);
+        b[1] = v.x; b[2] = v.y; b[3] = v.z; b[4] = v.w;
+        b[5] = __shfl_down(v.x, 1, 64);
+      }
+      auto emit = [&](int r, f4 craw) {
+        const f4 v = quant4(craw);
+        float c[6];
+        c[0] = __shfl_up(v.w, 1, 64);
+        c[1] = v.x; c[2] = v.y; c[3] = v.z; c[4] = v.w;
+        c[5] = __shfl_down(v.x, 1, 64);
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float acc = 0.0f;
+          acc = fmaf(w00, a[k], acc);
+          acc = fmaf(w01, a[k + 1], acc);
+          acc = fmaf(w02, a[k + 2], acc);
+          acc = fmaf(w10, b[k], acc);
+          acc = fmaf(w11, b[k + 1], acc);
+          acc = fmaf(w12, b[k + 2], acc);
+          acc = fmaf(w20, c[k], acc);
+          acc = fmaf(w21, c[k + 1], acc);
+          acc = fmaf(w22, c[k + 2], acc);
+          o[k] = finish(acc);
+        }
+        const float mm = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        m = fmaxf(m, keep(mm, is_out));
+        if (is_out) *reinterpret_cast<f4*>(yp + (int64_t)r * g.Wo) = (f4){o[0], o[1], o[2], o[3]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          a[k] = b[k];
+          b[k] = c[k];
+        }
+      };
+      int r0 = 0;
+      for (; r0 + D <= g.Ho; r0 += D) {
+        f4 nxt[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) nxt[k] = ldrow(r0 + k + 1 + D);
+#pragma unroll
+        for (int k = 0; k < D; ++k) emit(r0 + k, raw[k]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) raw[k] = nxt[k];
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (r0 + k < g.Ho) emit(r0 + k, raw[k]);
+    } else {
+      // stride 2: lane holds input columns 4j..4j+3 -> outputs 2j (cols 4j-1,4j,4j+1) and 2j+1 (cols 4j+1..4j+3)
+      float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};              // (left, x, y, z, w) of input row 2r-1
+      f4 rb[D], rc[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        rb[k] = ldrow(2 * k);
+        rc[k] = ldrow(2 * k + 1);
+      }
+      auto emit2 = [&](int r, f4 braw, f4 craw) {
+        const f4 vb = quant4(braw), vc = quant4(craw);
+        const float b[5] = {__shfl_up(vb.w, 1, 64), vb.x, vb.y, vb.z, vb.w};
+        const float c[5] = {__shfl_up(vc.w, 1, 64), vc.x, vc.y, vc.z, vc.w};
+        float o[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          float acc = 0.0f;
+          acc = fmaf(w00, a[2 * k], acc);
+          acc = fmaf(w01, a[2 * k + 1], acc);
+          acc = fmaf(w02, a[2 * k + 2], acc);
+          acc = fmaf(w10, b[2 * k], acc);
+          acc = fmaf(w11, b[2 * k + 1], acc);
+          acc = fmaf(w12, b[2 * k + 2], acc);
+          acc = fmaf(w20, c[2 * k], acc);
+          acc = fmaf(w21, c[2 * k + 1], acc);
+          acc = fmaf(w22, c[2 * k + 2], acc);
+          o[k] = finish(acc);
+        }
+        m = fmaxf(m, keep(fmaxf(fabsf(o[0]), fabsf(o[1])), is_out));
+        if (is_out) *reinterpret_cast<float2*>(yp + (int64_t)r * g.Wo) = make_float2(o[0], o[1]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a[k] = c[k];
+      };
+      int r0 = 0;
+      for (; r0 + D <= g.Ho; r0 += D) {
+        f4 nb[D], nc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          nb[k] = ldrow(2 * (r0 + k + D));
+          nc[k] = ldrow(2 * (r0 + k + D) + 1);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) emit2(r0 + k, rb[k], rc[k]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          rb[k] = nb[k];
+          rc[k] = nc[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (r0 + k < g.Ho) emit2(r0 + k, rb[k], rc[k]);
+    }
+    if (has_stat) {
+      const int s0 = __shfl(sample, 0, 64);
+      const bool wave_uniform = __all(!is_out || sample == s0);
+      const float wm = wave_max(is_out ? m : 0.0f);
+      __syncthreads();
+      if (lane == 0) {
+        red_m[wave] = wm;
+        red_s[wave] = wave_uniform ? s0 : -1;
+      }
+      __syncthreads();
+      const bool blk_uniform = red_s[0] >= 0 && red_s[0] == red_s[1] && red_s[1] == red_s[2] && red_s[2] == red_s[3];
+      if (blk_uniform) {
+        if (threadIdx.x == 0)
+          atomic_max_f32(stat_out + red_s[0], fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3])));
+      } else if (wave_uniform) {
+        if (lane == 0) atomic_max_f32(stat_out + s0, wm);
+      } else if (is_out) {
+        atomic_max_f32(stat_out + sample, m);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K3: weights, (rows, row_len).  Small rows: a workgroup stages several whole rows in LDS (one HBM read), reduces
 // each row with a wavefront, then applies from LDS.  Long rows (layer mode): K1 per row + K3b apply.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1417,6 +1847,88 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
   const bool quant = in_stat != nullptr || in_thr != nullptr;
   if (quant) FQ_REQUIRE(in_width >= 2 && in_width <= 16, "fq_dwconv3x3: width %d out of range", in_width);
   hipStream_t st = (hipStream_t)stream;
+  static const int form = env_int("FQ_DW_FORM", 0);     // 0 auto, 1 LDS tiles, 2 sliding window 1 col/lane, 3: 4 cols/lane
+  const bool can4 = (wdt % 4 == 0) && aligned16(x) && aligned16(y) && ((h * wdt) % 4 == 0) &&
+                    (stride == 1 || ((wdt / 2) % 2 == 0));
+  if ((form == 3 || form == 0) && can4) {
+    DwColGeom cg;
+    cg.C = (int)c;
+    cg.H = (int)h;
+    cg.W = (int)wdt;
+    cg.Ho = (int)((h - 1) / stride + 1);
+    cg.Wo = (int)((wdt - 1) / stride + 1);
+    const int halo = stride == 1 ? 2 : 1;
+    const int quads = (int)(wdt / 4);                    // compute lanes per full row
+    const int max_sw = 64 - halo;
+    cg.nsegx = (quads + max_sw - 1) / max_sw;
+    cg.sw = (quads + cg.nsegx - 1) / cg.nsegx;           // compute lanes per segment
+    cg.SEG = cg.sw + halo;
+    cg.segs = 64 / cg.SEG;
+    const int64_t total_segs = n * c * cg.nsegx;
+    const int64_t segs_per_block = (int64_t)cg.segs * (kBlock / 64);
+    const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
+    const int grid = (int)(nblk < (int64_t)num_cu() * 64 ? nblk : (int64_t)num_cu() * 64);
+    const float levels = act_levels(in_width, in_flags);
+    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+    if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+    ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
+#define FQ_DWC4(SS, Q, O)                                                                                         \
+  hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, cg,       \
+                     total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,         \
+                     bn_shift, act, stat_out)
+    if (stride == 1) {
+      if (!quant) FQ_DWC4(1, false, false);
+      else if (in_stat) FQ_DWC4(1, true, true);
+      else FQ_DWC4(1, true, false);
+    } else {
+      if (!quant) FQ_DWC4(2, false, false);
+      else if (in_stat) FQ_DWC4(2, true, true);
+      else FQ_DWC4(2, true, false);
+    }
+#undef FQ_DWC4
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+  }
+  if (form == 2 || ((form == 0 || form == 3) && wdt >= 14)) {   // narrow planes (7x7): LDS staging coalesces better
+    DwColGeom cg;
+    cg.C = (int)c;
+    cg.H = (int)h;
+    cg.W = (int)wdt;
+    cg.Ho = (int)((h - 1) / stride + 1);
+    cg.Wo = (int)((wdt - 1) / stride + 1);
+    const int halo = stride == 1 ? 2 : 1;
+    const int max_sw = 64 - halo;
+    cg.nsegx = (cg.Wo + max_sw - 1) / max_sw;
+    cg.sw = (cg.Wo + cg.nsegx - 1) / cg.nsegx;
+    cg.SEG = cg.sw + halo;
+    cg.segs = 64 / cg.SEG;
+    const int64_t total_segs = n * c * cg.nsegx;
+    const int64_t segs_per_block = (int64_t)cg.segs * (kBlock / 64);
+    const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
+    const int grid = (int)(nblk < (int64_t)num_cu() * 64 ? nblk : (int64_t)num_cu() * 64);
+    const float levels = act_levels(in_width, in_flags);
+    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+    if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+    ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
+#define FQ_DWC(SS, Q, O)                                                                                          \
+  hipLaunchKernelGGL((dwconv3x3_cols_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, cg,        \
+                     total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,         \
+                     bn_shift, act, stat_out)
+    if (stride == 1) {
+      if (!quant) FQ_DWC(1, false, false);
+      else if (in_stat) FQ_DWC(1, true, true);
+      else FQ_DWC(1, true, false);
+    } else {
+      if (!quant) FQ_DWC(2, false, false);
+      else if (in_stat) FQ_DWC(2, true, true);
+      else FQ_DWC(2, true, false);
+    }
+#undef FQ_DWC
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+  }
   DwGeom g;
   g.C = (int)c;
   g.H = (int)h;
