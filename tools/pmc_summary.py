@@ -12,14 +12,19 @@ csv.field_size_limit(10 ** 9)
 
 
 def family(n):
+    """Kernel name -> the key bench.py uses (ops.KERNEL_IDS)."""
     if 'act_apply_kernel<true' in n:
-        return 'act_apply_online'
+        return 'apply_online'
     if 'act_apply_kernel<false' in n:
-        return 'act_apply_offline'
+        return 'apply_offline'
     if 'absmax_per_sample' in n:
-        return 'absmax_per_sample'
+        return 'stat'
     if 'histogram_kernel' in n:
         return 'histogram'
+    if 'dwconv3x3' in n:
+        return 'dwconv'
+    if 'bn_act_stat_kernel' in n:
+        return 'bn_act'
     if 'direct_copy' in n or 'copyBuffer' in n:
         return 'device_copy(calibration)'
     return None
@@ -48,9 +53,7 @@ def main(fetch_csv, write_csv, out_json=None, tag=""):
         print("%-28s launches %4d/%4d  read %10.1f MB  write %10.1f MB  total %10.1f MB per launch"
               % (k, len(fv), len(wv), rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
     if out_json:
-        json.dump({"source": tag, "act_apply_online_bytes_per_launch": res.get("act_apply_online", {}).get("hbm_bytes_per_launch"),
-                   "absmax_bytes_per_launch": res.get("absmax_per_sample", {}).get("hbm_bytes_per_launch"),
-                   "kernels": res}, open(out_json, "w"), indent=1)
+        json.dump({"source": tag, "kernels": res}, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
