@@ -98,6 +98,9 @@ def parse_args(argv=None):
                         help="'true' (look for a local checkpoint, else seeded weights), 'false', or a parameter file")
     parser.add_argument('--save-qparams', type=str, default=None,
                         help='write the calibrated parameters (incl. every input_max) to this file')
+    parser.add_argument('--no-fuse', action='store_true',
+                        help='keep BatchNorm / ReLU / depthwise convolution as separate library ops '
+                             '(default: quantize.fuse.fuse_inference folds them into the fake-quant kernels)')
     parser.add_argument('--load-qparams', type=str, default=None,
                         help='load thresholds written by --save-qparams instead of calibrating')
     opt = parser.parse_args(argv)
@@ -265,6 +268,11 @@ def run(opt, ctx, rank=0, world=1):
     # initialize for quantization parameters and reset context (:253-255)
     qparams_init(net)
     net.collect_params().reset_ctx(ctx)
+    if not opt.no_fuse and ctx.device_type == "gpu":
+        from quantization.mxnet_amd.quantize import fuse
+        n_fused = fuse.fuse_inference(net)
+        if r0:
+            print("[fuse] %d BatchNorm / depthwise blocks folded into fused HIP passes (--no-fuse to disable)" % n_fused)
 
     # construct transformer (:258-269)
     if opt.dataset == 'imagenet':

@@ -272,3 +272,19 @@ def test_fused_inference_keeps_every_block_exact(gpu, model, classes, hw, batch,
     again = net(X).asnumpy()
     # (not bit-equal across calls: MIOpen may pick a different convolution solver once its find-db is warm)
     assert np.abs(again - ref).max() <= 2e-2 * scale
+
+
+def test_fake_bn_flow_on_gpu_matches_reference_goldens(gpu, golden):
+    """--merge-bn (fake-BN fold + bypass_bn) on the device, against G10 made by the reference's own code."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_logic import run_fake_bn_flow
+    g = golden("g10_fake_bn")
+    out = run_fake_bn_flow(g, ctx=gpu)
+    for key, ref in (("calib", "fakebn/calib_logits"), ("frozen0", "fakebn/frozen_logits0"),
+                     ("frozen1", "fakebn/frozen_logits1")):
+        np.testing.assert_allclose(out[key], g[ref], rtol=2e-3, atol=2e-3)       # MIOpen vs CPU convolution order
+    for name, v in out["params"].items():
+        if name.endswith(("weight", "bias")) and "conv0" not in name and "dense" not in name:
+            np.testing.assert_allclose(v, g["fakebn/frozen/" + name], rtol=1e-5, atol=1e-6, err_msg=name)

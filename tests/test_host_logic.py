@@ -255,3 +255,74 @@ def test_model_zoo_layouts_match_cli_exclusions():
     net = get_model("mobilenetv2_1.0", classes=1000)
     convert.convert_model(net, exclude=[net.features[0], net.features[1], net.output[0]])
     assert len(net.collect_quantized_blocks()) == 52
+
+
+# ---- G10: fake-BN (--merge-bn) and one-shot merge_bn against the reference's own code ---------------------------------
+def _bn_net(params):
+    reset_naming()
+    net = nn.HybridSequential(prefix="bnnet_")
+    with net.name_scope():
+        net.add(nn.Conv2D(8, 3, padding=1, in_channels=3, use_bias=False), nn.BatchNorm(in_channels=8), nn.Activation("relu"),
+                nn.Conv2D(8, 3, padding=1, groups=8, in_channels=8, use_bias=False), nn.BatchNorm(in_channels=8),
+                nn.Activation("relu"),
+                nn.Conv2D(12, 1, in_channels=8, use_bias=True), nn.BatchNorm(in_channels=12), nn.Activation("relu"),
+                nn.GlobalAvgPool2D(), nn.Flatten(), nn.Dense(5, in_units=12))
+    net.initialize()
+    for name, p in net.collect_params().items():
+        p.set_data(mx.nd.array(params[name]))
+    return net
+
+
+def _g10_params(g):
+    return {k.split("param/")[1]: v for k, v in g.items() if k.startswith("param/")}
+
+
+def run_fake_bn_flow(g, ctx=None):
+    net = _bn_net(_g10_params(g))
+    convert_fn = {nn.Conv2D: convert.gen_conv2d_converter(fake_bn=True, input_signed=True),
+                  nn.Dense: convert.gen_dense_converter(input_signed=True),
+                  nn.Activation: None, nn.BatchNorm: convert.bypass_bn}
+    convert.convert_model(net, exclude=[net[0], net[1]], convert_fn=convert_fn)
+    qparams_init(net)
+    if ctx is not None:
+        net.collect_params().reset_ctx(ctx)
+    xs = g["xs"]
+    arr = (lambda a: mx.nd.array(a, ctx=ctx)) if ctx is not None else mx.nd.array
+    net.quantize_input(enable=True, online=True)
+    out = {"calib": net(arr(xs[0])).asnumpy()}
+    net.fix_params()
+    out["frozen0"] = net(arr(xs[1])).asnumpy()
+    out["frozen1"] = net(arr(xs[2])).asnumpy()
+    out["params"] = {name: p.data().asnumpy() for name, p in net.collect_params().items()}
+    return out
+
+
+def test_fake_bn_merge_bn_flag_matches_reference(golden):
+    g = golden("g10_fake_bn")
+    with oracle_ops():
+        out = run_fake_bn_flow(g)
+    close(out["calib"], g["fakebn/calib_logits"], "fake-bn calibration logits")
+    close(out["frozen0"], g["fakebn/frozen_logits0"], "fake-bn frozen logits 0")
+    close(out["frozen1"], g["fakebn/frozen_logits1"], "fake-bn frozen logits 1")
+    for name, v in out["params"].items():
+        np.testing.assert_array_equal(v, g["fakebn/frozen/" + name], "frozen " + name)
+    assert "bnnet_conv1_bias" in out["params"]          # bias created by qparams_init (initialize.py:63-70)
+
+
+def test_merge_bn_matches_reference(golden, capsys):
+    from quantization.mxnet_amd.quantize.freeze import merge_bn
+    g = golden("g10_fake_bn")
+    net = _bn_net(_g10_params(g))
+    x = mx.nd.array(g["xs"][0])
+    before = net(x).asnumpy()
+    merge_bn(net)
+    assert "Merge bnnet_batchnorm0 to bnnet_conv0" in capsys.readouterr().out
+    after = net(x).asnumpy()
+    close(before, g["merge/logits_before"], "before")
+    close(after, g["merge/logits_after"], "after")
+    for name, p in net.collect_params().items():
+        np.testing.assert_allclose(p.data().asnumpy(), g["merge/param/" + name], rtol=1e-6, atol=1e-7, err_msg=name)
+    conv = net[0]
+    convert.gen_conv2d_converter(fake_bn=True)(conv)
+    with pytest.raises(AssertionError, match="fake bn"):
+        merge_bn(net)

@@ -52,6 +52,11 @@ def install_mxnet_standin():
     sys.modules["mxnet.gluon.data"] = mx.gluon.data
     sys.modules["mxnet.autograd"] = mx.autograd
     sys.modules["mxnet.initializer"] = mx.initializer
+    from quantization.mxnet_amd.mx.gluon import parameter as _parameter, block as _block
+    from quantization.mxnet_amd.mx import context as _context
+    sys.modules["mxnet.gluon.parameter"] = _parameter
+    sys.modules["mxnet.gluon.block"] = _block
+    sys.modules["mxnet.context"] = _context
     return mx
 
 
@@ -487,6 +492,72 @@ def gen_qconv(mx, qconv, convert, initialize, out):
     np.savez_compressed(os.path.join(out, "g8_quantized_conv.npz"), **cases)
 
 
+def _bn_net(mx, rng):
+    """conv3x3(3->8) bn relu | dw3x3(8) bn relu | pw1x1(8->12) bn relu | pool | dense(12->5), gluon-style names."""
+    nn = mx.gluon.nn
+    from quantization.mxnet_amd.mx.gluon.block import reset_naming
+    reset_naming()
+    net = nn.HybridSequential(prefix="bnnet_")
+    with net.name_scope():
+        net.add(nn.Conv2D(8, 3, padding=1, in_channels=3, use_bias=False), nn.BatchNorm(in_channels=8), nn.Activation("relu"),
+                nn.Conv2D(8, 3, padding=1, groups=8, in_channels=8, use_bias=False), nn.BatchNorm(in_channels=8),
+                nn.Activation("relu"),
+                nn.Conv2D(12, 1, in_channels=8, use_bias=True), nn.BatchNorm(in_channels=12), nn.Activation("relu"),
+                nn.GlobalAvgPool2D(), nn.Flatten(), nn.Dense(5, in_units=12))
+    net.initialize()
+    params = {}
+    for name, p in net.collect_params().items():
+        if name.endswith("running_var"):
+            a = rng.uniform(0.5, 2.0, p.shape).astype(np.float32)
+        elif name.endswith("gamma"):
+            a = rng.uniform(0.5, 1.5, p.shape).astype(np.float32)
+        else:
+            a = (rng.standard_normal(p.shape) * 0.4).astype(np.float32)
+        p.set_data(mx.nd.array(a))
+        params[name] = a
+    return net, params
+
+
+def gen_fake_bn(mx, convert, initialize, ref, out):
+    """G10: fake-BN fold (convert_conv2d.py:47-51,122-141; initialize.py:46-70; convert_bn.py) = the CLI's --merge-bn,
+    and the one-shot `merge_bn` (quantize/freeze/merge_bn.py:34-92, loaded by path)."""
+    spec = importlib.util.spec_from_file_location("refq_merge_bn", os.path.join(ref, "quantize", "freeze", "merge_bn.py"))
+    mb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mb)
+    nn = mx.gluon.nn
+    rng = np.random.default_rng(SEED + 7)
+    cases = {}
+    xs = [(rng.standard_normal((4, 3, 8, 8)) * 1.3).astype(np.float32) for _ in range(3)]
+    cases["xs"] = np.stack(xs)
+    # --- A: CLI --merge-bn flow -------------------------------------------------------------------------------
+    net, params = _bn_net(mx, rng)
+    for k, v in params.items():
+        cases["param/" + k] = v
+    convert_fn = {nn.Conv2D: convert.gen_conv2d_converter(fake_bn=True, input_signed=True),
+                  nn.Dense: convert.gen_dense_converter(input_signed=True),
+                  nn.Activation: None, nn.BatchNorm: convert.bypass_bn}
+    convert.convert_model(net, exclude=[net[0], net[1]], convert_fn=convert_fn)
+    initialize.qparams_init(net)
+    net.quantize_input(enable=True, online=True)
+    cases["fakebn/calib_logits"] = net(mx.nd.array(xs[0])).asnumpy()
+    net.fix_params()
+    cases["fakebn/frozen_logits0"] = net(mx.nd.array(xs[1])).asnumpy()
+    cases["fakebn/frozen_logits1"] = net(mx.nd.array(xs[2])).asnumpy()
+    for name, p in net.collect_params().items():
+        cases["fakebn/frozen/" + name] = p.data().asnumpy()
+    # --- B: merge_bn on a fresh float net ---------------------------------------------------------------------------
+    rng2 = np.random.default_rng(SEED + 7)
+    _ = [(rng2.standard_normal((4, 3, 8, 8)) * 1.3) for _ in range(3)]
+    net2, _p = _bn_net(mx, rng2)
+    before = net2(mx.nd.array(xs[0])).asnumpy()
+    mb.merge_bn(net2)
+    cases["merge/logits_before"] = before
+    cases["merge/logits_after"] = net2(mx.nd.array(xs[0])).asnumpy()
+    for name, p in net2.collect_params().items():
+        cases["merge/param/" + name] = p.data().asnumpy()
+    np.savez_compressed(os.path.join(out, "g10_fake_bn.npz"), **cases)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -522,6 +593,9 @@ def main():
     if want("g8"):
         gen_qconv(mx, qconv, convert, initialize, args.out)
         print("g8 done", flush=True)
+    if want("g10"):
+        gen_fake_bn(mx, convert, initialize, args.ref, args.out)
+        print("g10 done", flush=True)
     with open(os.path.join(args.out, "PROVENANCE.txt"), "w") as f:
         import scipy
         import torch
