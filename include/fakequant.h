@@ -61,7 +61,8 @@ int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront)
 #define FQ_KERNEL_HISTOGRAM 4     /* histogram_kernel              : 4 B/elem                                       */
 #define FQ_KERNEL_BN_ACT 5        /* bn_act_stat_kernel            : 8 B/elem                                       */
 #define FQ_KERNEL_DWCONV 6        /* dwconv3x3_kernel              : 4 B/in elem + 4 B/out elem                     */
-#define FQ_KERNEL_COUNT 7
+#define FQ_KERNEL_PWCONV 7        /* pwconv_i8_kernel              : 4 B/in elem + 4 B/out elem                     */
+#define FQ_KERNEL_COUNT 8
 int fq_profile_enable(int on);
 int fq_profile_reset(void);
 int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes);
@@ -131,6 +132,29 @@ int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, c
 int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
                  int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
                  float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                 fqStream_t stream);
+
+/* ---- pointwise (1x1) convolution on the integer codes -----------------------------------------------------------------
+ * After fake-quantisation both operands of a convolution are integers times a scale: x_q = cx * sx (cx in [0, 2^w-1]
+ * or [-(2^(w-1)-1), 2^(w-1)-1]) and w_q[co,:] = cw * sw[co].  For a 1x1 convolution the reference's fp32
+ * F.Convolution computes  sum_ci w_q * x_q  with fp32 rounding at every step; the SAME sum is  sx*sw[co] * sum_ci cw*cx,
+ * and the integer sum is exact on the int8 matrix cores (v_mfma_i32_16x16x64_i8, int32 accumulate).  This entry point
+ * does that, with the fake-quant of x folded into the load and BatchNorm / activation / per-sample statistic into the
+ * store (same contract as fq_dwconv3x3):
+ *   cx   = roundf(clip(x, lo, max_) / (max_/levels + eps))          bit-identical to the fake-quant kernels
+ *   y    = act( (float(sum_ci cw[co,ci]*cx[ci]) * (sx * wscale[co]) + bias[co]) * bn_scale[co] + bn_shift[co] )
+ * x: (n, cin, hw) fp32;  y: (n, cout, hw) fp32;  wcodes: int8 [cout_pad][cin_pad] (zero padded; cin_pad % 64 == 0,
+ * cout_pad % 64 == 0) from fq_weight_codes;  wscale[cout], wsum[cout] (= sum_ci cw, used for the +128 re-centring of
+ * unsigned activations).  Needs in_width <= 8.                                                                       */
+int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_scale, int width, int64_t row_pad,
+                    int64_t rows_pad, int8_t* codes, float* scales, int32_t* rowsum, void* ws, fqStream_t stream);
+/* Two launches: (A) quantise + transpose x into int8 codes [(n*hw)][cin_pad] in `ws` (fq_pwconv_workspace_bytes),
+ * (B) the integer GEMM with both operands K-contiguous + epilogue.  Online mode requires out_current_max.            */
+size_t fq_pwconv_workspace_bytes(int64_t n, int64_t cin_pad, int64_t hw);
+int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                 float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                 const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                 const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
                  fqStream_t stream);
 
 /* Generic LinearQuantizeSTE.forward (ste_func.py:37-41) for API completeness: x viewed as (rows, row_len) with one

@@ -26,7 +26,7 @@ EPS = F32(1e-10)          # ste_func.py:39,41  `scale + 1e-10`  (fp32 add: numpy
 __all__ = ["roundf", "absmax_per_sample", "batch_mean", "act_scale", "ste_codes", "ste_forward",
            "conv_input_fake_quant", "dense_input_fake_quant", "act_output_fake_quant", "weight_fake_quant",
            "winograd_G", "wino_weight_fake_quant", "ema_update", "discrete_histogram", "kl_calibrate",
-           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act", "dwconv3x3"]
+           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act", "dwconv3x3", "weight_codes", "pwconv_i8"]
 
 
 def roundf(x):
@@ -365,6 +365,45 @@ def dwconv3x3(x, w, bias=None, stride=1, in_max=None, signed=False, width=8, lo_
     elif act == "relu6":
         acc = np.minimum(np.maximum(acc, F32(0)), F32(6))
     return acc.astype(F32)
+
+
+def weight_codes(w, rows_per_scale, width=8):
+    """Integer codes of the weight fake-quant: code = roundf(w / (s + 1e-10)), s = max|w| over the scale group /
+    (2^(w-1)-1) (convert_conv2d.py:70-95).  Returns (codes int32 (rows, row_len), scales (rows,))."""
+    w = np.asarray(w, dtype=F32)
+    rows = w.shape[0]
+    w2 = w.reshape(rows, -1)
+    groups = rows // rows_per_scale
+    gmax = np.abs(w2).reshape(groups, -1).max(axis=1).astype(F32)
+    s = np.repeat((gmax / F32(2 ** (width - 1) - 1)).astype(F32), rows_per_scale)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        codes = roundf((w2 / (s + EPS).astype(F32)[:, None]).astype(F32)).astype(np.int32)
+    return codes, s
+
+
+def pwconv_i8(x, w, rows_per_scale, wt_width, in_max, signed=False, width=8, lo_neg_max=None, bias=None,
+              bn_scale=None, bn_shift=None, act=None):
+    """Arithmetic of `fq_pwconv_i8`: integer codes of x and w, EXACT integer dot products, one fp32 multiply by
+    sx*sw[co], bias, folded BN, activation."""
+    x = np.asarray(x, dtype=F32)
+    lo_neg = signed if lo_neg_max is None else lo_neg_max
+    sx = act_scale(in_max, signed, width)
+    cx = ste_codes(x, sx, in_max, F32(-F32(in_max)) if lo_neg else F32(0)).astype(np.int64)
+    cw, sw = weight_codes(w, rows_per_scale, wt_width)
+    N, C = x.shape[0], x.shape[1]
+    isum = np.einsum("oc,ncp->nop", cw.astype(np.int64), cx.reshape(N, C, -1))
+    sxw = (F32(sx) * sw).astype(F32)
+    y = (isum.astype(F32) * sxw[None, :, None]).astype(F32)
+    if bias is not None:
+        y = (y + np.asarray(bias, dtype=F32)[None, :, None]).astype(F32)
+    y = y.reshape((N, cw.shape[0]) + x.shape[2:])
+    if bn_scale is not None:
+        return bn_act(y, bn_scale, bn_shift, act or "none")
+    if act == "relu":
+        y = np.maximum(y, F32(0))
+    elif act == "relu6":
+        y = np.minimum(np.maximum(y, F32(0)), F32(6))
+    return y.astype(F32)
 
 
 # ---- the reference's UNFUSED op chain, pass by pass (used as the CPU baseline workload) -------------------

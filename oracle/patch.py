@@ -134,6 +134,47 @@ def dwconv3x3(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8, fla
     return _t(y), stat
 
 
+def weight_codes(w, rows_per_scale, width=8):
+    a = _np(w)
+    codes, scales = O.weight_codes(a, rows_per_scale, width)
+    rows, row_len = codes.shape
+    rp, cp = (rows + 63) // 64 * 64, (row_len + 63) // 64 * 64
+    padded = np.zeros((rp, cp), np.int8)
+    padded[:rows, :row_len] = codes.astype(np.int8)
+    return _t(padded), _t(scales), _t(codes.sum(axis=1).astype(np.int32))
+
+
+def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
+              bn_scale=None, bn_shift=None, act=None, want_stat=True):
+    signed, lo_neg, _, _ = _flags(flags)
+    if in_stat is not None:
+        in_max = O.batch_mean(_np(in_stat).reshape(-1)[:x.shape[0]])
+        if cur_out is not None:
+            cur_out.copy_(_t(np.asarray([in_max], dtype=F32)))
+    else:
+        in_max = F32(_np(in_thr).reshape(-1)[0])
+    a = _np(x)
+    sx = O.act_scale(in_max, signed, width)
+    cx = O.ste_codes(a, sx, in_max, F32(-in_max) if lo_neg else F32(0)).astype(np.int64)
+    sw = _np(wscale)
+    cout, cin = sw.size, a.shape[1]
+    cw = _np(wcodes)[:cout, :cin].astype(np.int64)
+    n = a.shape[0]
+    isum = np.einsum("oc,ncp->nop", cw, cx.reshape(n, cin, -1))
+    y = (isum.astype(F32) * (F32(sx) * sw).astype(F32)[None, :, None]).astype(F32)
+    if bias is not None:
+        y = (y + _np(bias)[None, :, None]).astype(F32)
+    y = y.reshape((n, cout) + a.shape[2:])
+    if bn_scale is not None:
+        y = O.bn_act(y, _np(bn_scale), _np(bn_shift), act or "none")
+    elif act == "relu":
+        y = np.maximum(y, F32(0))
+    elif act == "relu6":
+        y = np.minimum(np.maximum(y, F32(0)), F32(6))
+    stat = _t(np.abs(y).reshape(n, -1).max(axis=1).astype(F32)) if want_stat else None
+    return _t(y.astype(F32)), stat
+
+
 def fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, want_stat=True, want_codes=False,
                        stat_ws=None):
     thr = F32(_np(threshold).reshape(-1)[0])
@@ -237,7 +278,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "dwconv3x3", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

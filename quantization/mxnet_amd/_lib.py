@@ -37,6 +37,10 @@ EXPORTS = {
     "fq_bn_act_stat": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "fq_dwconv3x3": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _uint, _vp, _vp, _vp, _int,
                             _vp, _vp]),
+    "fq_weight_codes": (_int, [_vp, _i64, _i64, _int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "fq_pwconv_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
+    "fq_pwconv_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
+                            _vp, _int, _vp, _vp, _vp]),
     "fq_fake_quant_offline": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp, _vp]),
     "fq_ste_forward": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _f32, _f32, _f32, _vp]),
     "fq_weight_workspace_bytes": (ctypes.c_size_t, [_i64]),

@@ -1104,6 +1104,264 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K2f: pointwise (1x1) convolution on integer codes with v_mfma_i32_16x16x64_i8.
+// Operand layout of the instruction (probed on gfx950, tools/mfma_i8_probe.hip): lane l holds, for A, row l&15 and the
+// 16 consecutive k = 16*(l>>4) .. +15 (one 16-byte register quad); the same for B with column l&15; C/D: column l&15,
+// rows 4*(l>>4) + r.  NCHW keeps PIXELS contiguous, the MFMA wants K (= input channels) contiguous for both operands:
+// weights are stored [co][ci] (fine), the activation tile is transposed on its way into LDS — it is read from HBM
+// once, coalesced along pixels, quantised, and written as int8 codes [column][ci] with byte stores.
+// A workgroup owns PT_B columns (column = (sample, pixel) flattened) and ALL output channels, so x is read exactly once;
+// its 4 waves are arranged wm x wn over (64 output channels) x (64 columns) wave tiles and loop over channel passes.
+// ---------------------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct PwGeom {
+  int Cin, CinPad, Cout, HW;
+  int64_t cols;        // n * HW
+  int PT_B;            // columns per workgroup tile (64 * wn)
+  int wm, wn;          // wave grid
+  int passes;          // ceil(Cout / (64 * wm))
+  int stride;          // LDS bytes per column (CinPad + 16)
+  int zoff;            // 128 for unsigned codes (stored re-centred), 0 for signed
+};
+
+// K2f-A: quantise + transpose.  x (n, Cin, HW) fp32 -> codes [(n*HW + p)][CinPad] int8 (column-major for the GEMM:
+// K contiguous).  Workgroup tile = 64 channels x 64 pixels of one sample: every thread loads 4 channel rows x 4 pixels
+// (16-byte loads, 256 B contiguous per row across 16 lanes), quantises, transposes its 4x4 block in registers into 4
+// dwords (4 channels of one pixel each), and the tile goes through a small LDS stage (odd dword stride: conflict-free)
+// so that the stores are 16 bytes per lane, 64 contiguous bytes per pixel.
+template <bool ONLINE>
+__global__ __launch_bounds__(kBlock) void quant_transpose_i8_kernel(
+    const float* __restrict__ x, int8_t* __restrict__ codes, int Cin, int CinPad, int HW, int ptiles, int ctiles,
+    int64_t tiles, const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels,
+    int lo_neg_max, float eps, int zoff, float* __restrict__ cur_max_out) {
+  __shared__ int lds[64 * 17];
+  const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  const int c = threadIdx.x & 15;            // pixel quad
+  const int rq = threadIdx.x >> 4;           // channel quad (0..15)
+  const bool hw_vec = (HW & 3) == 0;
+  const ChunkRange rg = block_range(tiles);
+  for (int64_t t = rg.begin; t < rg.end; ++t) {
+    // tile order: channel tile fastest, then pixel tile, then sample
+    const int ct = (int)(t % ctiles);
+    const int64_t t2 = t / ctiles;
+    const int pt = (int)(t2 % ptiles);
+    const int64_t smp = t2 / ptiles;
+    const int ci0 = ct * 64 + rq * 4, p0 = pt * 64 + c * 4;
+    float v[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ci = ci0 + k;
+      const int cic = ci < Cin ? ci : Cin - 1;
+      const float* src = x + (smp * Cin + cic) * (int64_t)HW;
+      if (hw_vec && p0 + 3 < HW) {
+        const f4 r = *reinterpret_cast<const f4*>(src + p0);
+        v[k][0] = r.x; v[k][1] = r.y; v[k][2] = r.z; v[k][3] = r.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pe = p0 + e < HW ? p0 + e : HW - 1;
+          v[k][e] = src[pe];
+        }
+      }
+    }
+    __syncthreads();                                                   // LDS free (previous tile stored)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                                       // pixel p0 + e: channels ci0 .. ci0+3 in one dword
+      unsigned packed = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int code = (int)fq_code(v[k][e], q) - zoff;
+        if (ci0 + k >= Cin) code = 0;
+        packed |= ((unsigned)code & 0xFFu) << (8 * k);
+      }
+      lds[(c * 4 + e) * 17 + rq] = (int)packed;
+    }
+    __syncthreads();
+    // store: thread (pixel = tid / 4, 16-byte piece = tid % 4)
+    const int sp = threadIdx.x >> 2, piece = threadIdx.x & 3;
+    const int p = pt * 64 + sp;
+    if (p < HW) {
+      const int* l = lds + sp * 17 + piece * 4;
+      const v4i o = (v4i){l[0], l[1], l[2], l[3]};
+      *reinterpret_cast<v4i*>(codes + (smp * HW + p) * (int64_t)CinPad + ct * 64 + piece * 16) = o;
+    }
+  }
+}
+
+// K2f-B: integer GEMM + epilogue.  Both MFMA operands are K-contiguous in global memory (weights [co][CinPad], codes
+// [column][CinPad]) and go straight to registers, double buffered over the K loop; no LDS.  A workgroup computes
+// (64*wm output channels) x (64*wn columns); waves own 64 x 64 sub-tiles = 16 accumulators of 16x16.
+template <int DUMMY>
+__global__ __launch_bounds__(kBlock) void pwconv_i8_kernel(
+    const int8_t* __restrict__ xc, const int8_t* __restrict__ wc, const float* __restrict__ wscale,
+    const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwGeom g, int64_t tiles,
+    const float* __restrict__ sx_src, float levels, const float* __restrict__ bn_scale,
+    const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
+  // per-output-channel constants of this workgroup's channel block, staged in LDS once: loading them from global in
+  // the epilogue (16 dependent round trips per tile) was 90 % of this kernel's time
+  constexpr int kStatSlots = 16;
+  __shared__ float k_sxw[256], k_bias[256], k_bsc[256], k_bsh[256];
+  __shared__ int k_zs[256];
+  __shared__ unsigned k_stat[kStatSlots];
+  const float sx = sx_src[0] / levels;                                  // scale = max_/levels, as make_qparams
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wmi = wave % g.wm, wni = wave / g.wm;
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
+  const unsigned HW = (unsigned)g.HW;
+  const int64_t plane_stride = (int64_t)g.HW;
+  const int cblocks = g.passes;                                         // output-channel blocks of 64*wm
+  // gridDim.x is a multiple of cblocks (host), so a workgroup keeps ONE channel block over all its tiles
+  const int cb = (int)(blockIdx.x % cblocks);
+  {
+    const int co = cb * g.wm * 64 + threadIdx.x;
+    const bool ok = threadIdx.x < g.wm * 64 && co < g.Cout;
+    const int coc = ok ? co : 0;
+    k_sxw[threadIdx.x] = sx * wscale[coc];
+    k_zs[threadIdx.x] = g.zoff * wsum[coc];
+    k_bias[threadIdx.x] = bias != nullptr ? bias[coc] : 0.0f;
+    k_bsc[threadIdx.x] = has_bn ? bn_scale[coc] : 1.0f;
+    k_bsh[threadIdx.x] = has_bn ? bn_shift[coc] : 0.0f;
+  }
+  __syncthreads();
+
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t ctile = t / cblocks;
+    const unsigned j0 = (unsigned)(ctile * g.PT_B) + wni * 64;
+    const int co0 = (cb * g.wm + wmi) * 64;                             // (weights are zero-padded to 64 rows: no early exit,
+    v4i acc[4][4];                                                      //  every wave reaches the barriers below)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (v4i){0, 0, 0, 0};
+    // a wave whose 64 channels lie entirely beyond Cout (Cout not a multiple of 64*wm) reads channel block 0 instead:
+    // its results are masked in the epilogue, but the weight buffer is only padded to the next multiple of 64 rows
+    const int co_ld = co0 < g.Cout ? co0 : 0;
+    const int8_t* wrow = wc + (int64_t)(co_ld + (lane & 15)) * g.CinPad + 16 * (lane >> 4);
+    const int8_t* xrow = xc + (int64_t)(j0 + (lane & 15)) * g.CinPad + 16 * (lane >> 4);
+    const int64_t step16 = (int64_t)16 * g.CinPad;
+    v4i a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = *reinterpret_cast<const v4i*>(wrow + i * step16);
+      b[i] = *reinterpret_cast<const v4i*>(xrow + i * step16);
+    }
+    for (int k0 = 0; k0 < g.CinPad; k0 += 64) {
+      v4i an[4], bn[4];
+      const int kn = k0 + 64 < g.CinPad ? k0 + 64 : k0;                 // last step re-reads its own slab (discarded)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        an[i] = *reinterpret_cast<const v4i*>(wrow + i * step16 + kn);
+        bn[i] = *reinterpret_cast<const v4i*>(xrow + i * step16 + kn);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) acc[tt][uu] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[tt], b[uu], acc[tt][uu], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = an[i];
+        b[i] = bn[i];
+      }
+    }
+    // epilogue: lane holds, per (tt, uu), rows co0 + tt*16 + 4*(lane>>4) + r and column j0 + uu*16 + (lane&15)
+    int64_t ybase[4];
+    bool cok[4];
+    unsigned smps[4];
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) {
+      const unsigned j = j0 + uu * 16 + (lane & 15);
+      cok[uu] = j < (unsigned)g.cols;
+      const unsigned smp = cok[uu] ? j / HW : 0;
+      smps[uu] = smp;
+      ybase[uu] = ((int64_t)smp * g.Cout) * plane_stride + (j - smp * HW);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = wmi * 64 + tt * 16 + 4 * (lane >> 4) + r;       // channel index inside the block
+        const int co = co0 + tt * 16 + 4 * (lane >> 4) + r;
+        const bool co_ok = co < g.Cout;
+        const float sxw = k_sxw[col];
+        const int zs = k_zs[col];
+        const float bch = k_bias[col], bsc = k_bsc[col], bsh = k_bsh[col];
+        const int64_t coff = (int64_t)(co_ok ? co : 0) * plane_stride;
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+          float v = (float)(acc[tt][uu][r] + zs) * sxw;
+          if (bias != nullptr) v = v + bch;
+          if (has_bn) {
+            v = v * bsc;
+            v = v + bsh;
+          }
+          v = act_rt(v, act);
+          if (co_ok && cok[uu]) {
+            y[ybase[uu] + coff] = v;
+            m[uu] = fmaxf(m[uu], fabsf(v));
+          }
+        }
+      }
+    }
+    if (has_stat) {
+      // per-sample maxima of this tile through an LDS table (a tile spans <= kStatSlots samples), then ONE global atomic
+      // per touched sample: per-wave global atomics on the 128 hot addresses serialised in L2 and cost 80 % of the
+      // kernel (100 k same-address atomics per launch)
+      const unsigned s_base = (unsigned)(ctile * g.PT_B) / HW;
+      __syncthreads();
+      if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
+      __syncthreads();
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        if (cok[uu]) {
+          const unsigned slot = smps[uu] - s_base;
+          if (slot < kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(m[uu]));
+          else atomic_max_f32(stat_out + smps[uu], m[uu]);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < (unsigned)(g.cols / HW))
+        atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+    }
+  }
+}
+
+// weight codes: one workgroup per (padded) row: code = roundf(w / (s + eps)), zero padding, row sums
+__global__ __launch_bounds__(kBlock) void weight_codes_kernel(const float* __restrict__ w, int rows, int row_len,
+                                                              int rows_per_scale, float levels, int row_pad,
+                                                              const float* __restrict__ gmax,
+                                                              int8_t* __restrict__ codes, float* __restrict__ scales,
+                                                              int* __restrict__ rowsum) {
+  __shared__ int red[4];
+  const int r = blockIdx.x;
+  int8_t* dst = codes + (int64_t)r * row_pad;
+  if (r >= rows) {                                                     // padded row
+    for (int i = threadIdx.x; i < row_pad; i += kBlock) dst[i] = 0;
+    return;
+  }
+  const float s = gmax[r / rows_per_scale] / levels;
+  const float d = s + kEps;
+  int acc = 0;
+  for (int i = threadIdx.x; i < row_pad; i += kBlock) {
+    int c = 0;
+    if (i < row_len) c = (int)roundf(w[(int64_t)r * row_len + i] / d);
+    dst[i] = (int8_t)c;
+    acc += c;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rowsum[r] = red[0] + red[1] + red[2] + red[3];
+    scales[r] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K3: weights, (rows, row_len).  Small rows: a workgroup stages several whole rows in LDS (one HBM read), reduces
 // each row with a wavefront, then applies from LDS.  Long rows (layer mode): K1 per row + K3b apply.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1992,6 +2250,96 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     else FQ_DW(2, true, false);
   }
 #undef FQ_DW
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_scale, int width, int64_t row_pad,
+                    int64_t rows_pad, int8_t* codes, float* scales, int32_t* rowsum, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(w && codes && scales && rowsum && ws, "fq_weight_codes: null pointer");
+  FQ_REQUIRE(rows > 0 && row_len > 0 && rows_per_scale > 0 && rows % rows_per_scale == 0,
+             "fq_weight_codes: bad shape (rows=%lld row_len=%lld rows_per_scale=%d)", (long long)rows,
+             (long long)row_len, rows_per_scale);
+  FQ_REQUIRE(width >= 2 && width <= 8, "fq_weight_codes: width %d does not fit int8 codes", width);
+  FQ_REQUIRE(row_pad >= row_len && rows_pad >= rows && rows_pad < (1ll << 31), "fq_weight_codes: bad padding");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t groups = rows / rows_per_scale;
+  float* gmax = (float*)ws;
+  FQ_HIP(hipMemsetAsync(gmax, 0, groups * sizeof(float), st));
+  if (int rc = launch_absmax(w, groups, (int64_t)rows_per_scale * row_len, true, gmax, st)) return rc;
+  const float levels = (float)((1 << (width - 1)) - 1);
+  hipLaunchKernelGGL(weight_codes_kernel, dim3((unsigned)rows_pad), dim3(kBlock), 0, st, w, (int)rows, (int)row_len,
+                     rows_per_scale, levels, (int)row_pad, gmax, codes, scales, (int*)rowsum);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+size_t fq_pwconv_workspace_bytes(int64_t n, int64_t cin_pad, int64_t hw) {
+  const int64_t cols_pad = (n * hw + 255) / 256 * 256;
+  return (size_t)cols_pad * (size_t)cin_pad + 64;
+}
+
+int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                 float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                 const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                 const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
+                 fqStream_t stream) {
+  FQ_REQUIRE(x && wcodes && wscale && wsum && y && ws, "fq_pwconv_i8: null pointer");
+  FQ_REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && hw < (1ll << 30) && n * hw < (1ll << 31) - 512,
+             "fq_pwconv_i8: bad shape");
+  FQ_REQUIRE(cin_pad >= cin && cin_pad % 64 == 0 && cin_pad <= 8192, "fq_pwconv_i8: cin_pad=%lld must be a multiple "
+             "of 64 covering cin=%lld", (long long)cin_pad, (long long)cin);
+  FQ_REQUIRE((in_stat != nullptr) != (in_thr != nullptr), "fq_pwconv_i8: give in_stat (online) OR in_thr (offline): the "
+             "integer path needs a quantised input");
+  FQ_REQUIRE(in_stat == nullptr || out_current_max != nullptr, "fq_pwconv_i8: online mode needs out_current_max (the "
+             "GEMM reads the batch statistic from it)");
+  FQ_REQUIRE(in_width >= 2 && in_width <= 8, "fq_pwconv_i8: input width %d does not fit int8 codes", in_width);
+  FQ_REQUIRE(!(in_flags & (FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "fq_pwconv_i8: unsupported activation flags");
+  FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_pwconv_i8: bn_scale and bn_shift go together");
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_pwconv_i8: unknown activation %d", act);
+  FQ_REQUIRE(aligned16(wcodes) && aligned16(ws) && aligned16(x), "fq_pwconv_i8: x, wcodes and ws must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const bool signed_codes = (in_flags & FQ_ACT_SIGNED) != 0;
+  const int zoff = signed_codes ? 0 : 128;      // unsigned codes are stored re-centred so they fit int8
+  const float levels = act_levels(in_width, in_flags);
+  const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+  int8_t* codes = (int8_t*)ws;
+  ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), st);
+  {  // A: quantise + transpose
+    const int ptiles = (int)((hw + 63) / 64), ctiles = (int)(cin_pad / 64);
+    const int64_t tiles = n * ptiles * ctiles;
+    const int grid = grid_for(tiles);
+    if (in_stat)
+      hipLaunchKernelGGL((quant_transpose_i8_kernel<true>), dim3(grid), dim3(kBlock), 0, st, x, codes, (int)cin,
+                         (int)cin_pad, (int)hw, ptiles, ctiles, tiles, in_stat, (int)n, in_thr, levels, lo_neg, kEps,
+                         zoff, out_current_max);
+    else
+      hipLaunchKernelGGL((quant_transpose_i8_kernel<false>), dim3(grid), dim3(kBlock), 0, st, x, codes, (int)cin,
+                         (int)cin_pad, (int)hw, ptiles, ctiles, tiles, in_stat, (int)n, in_thr, levels, lo_neg, kEps,
+                         zoff, out_current_max);
+    FQ_LAUNCH_CHECK();
+  }
+  PwGeom g;
+  g.Cin = (int)cin;
+  g.CinPad = (int)cin_pad;
+  g.Cout = (int)cout;
+  g.HW = (int)hw;
+  g.cols = n * hw;
+  if (cout > 128) { g.wm = 4; g.wn = 1; }
+  else if (cout > 64) { g.wm = 2; g.wn = 2; }
+  else { g.wm = 1; g.wn = 4; }
+  g.PT_B = 64 * g.wn;
+  g.passes = (int)((cout + 64 * g.wm - 1) / (64 * g.wm));
+  g.stride = 0;
+  g.zoff = zoff;
+  const int64_t tiles = ((g.cols + g.PT_B - 1) / g.PT_B) * g.passes;
+  if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  int64_t grid64 = tiles < (int64_t)num_cu() * 32 ? tiles : (int64_t)num_cu() * 32;
+  grid64 = grid64 / g.passes * g.passes;                  // multiple of the channel blocks (tiles is one already)
+  const int grid = (int)(grid64 < g.passes ? g.passes : grid64);
+  const float* sx_src = in_stat ? out_current_max : in_thr;
+  hipLaunchKernelGGL((pwconv_i8_kernel<0>), dim3(grid), dim3(kBlock), 0, st, (const int8_t*)codes, wcodes, wscale,
+                     (const int*)wsum, bias, y, g, tiles, sx_src, levels, bn_scale, bn_shift, act, stat_out);
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

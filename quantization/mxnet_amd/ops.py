@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["fake_quant_online_prestat", "bn_act_stat", "dwconv3x3", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["fake_quant_online_prestat", "bn_act_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -74,7 +74,7 @@ def device_info():
 
 
 KERNEL_IDS = {"stat": 0, "apply_online": 1, "apply_offline": 2, "weight": 3, "histogram": 4, "bn_act": 5,
-              "dwconv": 6}
+              "dwconv": 6, "pwconv": 7}
 
 
 def profile_enable(on=True):
@@ -249,6 +249,52 @@ def dwconv3x3(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8, fla
     check_call(_lib_().fq_dwconv3x3(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, c, h, wd, int(stride), _ptr(in_stat),
                                     _ptr(in_thr), int(width), int(flags), _ptr(cur_out), _ptr(bn_scale),
                                     _ptr(bn_shift), _ACTS[act], _ptr(stat), _stream(x)))
+    return y, stat
+
+
+def weight_codes(w, rows_per_scale, width=8):
+    """Integer codes of the weight fake-quant (convert_conv2d.py:70-95): code = roundf(w / (s + 1e-10)) with one scale
+    per `rows_per_scale` leading rows.  Returns (codes int8 [rows_pad, row_pad] zero padded to multiples of 64,
+    scales (rows,), rowsum int32 (rows,))."""
+    _check(w, "w")
+    rows = w.shape[0]
+    row_len = w.numel() // rows
+    row_pad = (row_len + 63) // 64 * 64
+    rows_pad = (rows + 63) // 64 * 64
+    codes = torch.empty((rows_pad, row_pad), dtype=torch.int8, device=w.device)
+    scales = torch.empty(rows, dtype=torch.float32, device=w.device)
+    rowsum = torch.empty(rows, dtype=torch.int32, device=w.device)
+    ws = _workspace(w.device, _lib_().fq_weight_workspace_bytes(rows))
+    check_call(_lib_().fq_weight_codes(_ptr(w), rows, row_len, int(rows_per_scale), int(width), row_pad, rows_pad,
+                                       _ptr(codes), _ptr(scales), _ptr(rowsum), _ptr(ws), _stream(w)))
+    return codes, scales, rowsum
+
+
+def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
+              bn_scale=None, bn_shift=None, act=None, want_stat=True):
+    """1x1 convolution on the integer codes (int8 MFMA, exact int32 accumulation) with quantise-on-load and fused
+    BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations.  Returns (y, stat or None)."""
+    _check(x, "x")
+    _check(wcodes, "wcodes", torch.int8)
+    _check(wscale, "wscale")
+    _check(wsum, "wsum", torch.int32)
+    for name, t in (("bias", bias), ("in_stat", in_stat), ("in_thr", in_thr), ("bn_scale", bn_scale),
+                    ("bn_shift", bn_shift), ("cur_out", cur_out)):
+        if t is not None:
+            _check(t, name)
+    n, cin = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * cin)
+    cout = wscale.numel()
+    cin_pad = wcodes.shape[1]
+    y = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    stat = torch.empty(n, dtype=torch.float32, device=x.device) if want_stat else None
+    if in_stat is not None and cur_out is None:
+        cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, hw), dtype=torch.uint8, device=x.device)
+    check_call(_lib_().fq_pwconv_i8(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin,
+                                    cin_pad, cout, hw, _ptr(in_stat), _ptr(in_thr), int(width), int(flags),
+                                    _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift), _ACTS[act], _ptr(stat), _ptr(ws),
+                                    _stream(x)))
     return y, stat
 
 

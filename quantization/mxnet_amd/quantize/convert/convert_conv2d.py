@@ -140,10 +140,68 @@ def _dw_fused_conv(m, x, weight_q, bias, quant_kw):
     return out
 
 
+def _rows_per_scale(m, qa):
+    cout = m._kwargs["num_filter"]
+    if qa.quant_type == "channel":
+        return 1
+    if qa.quant_type == "group" and m._kwargs["num_group"] == cout:
+        return 1
+    return cout
+
+
+def _pw_fused_conv(m, F, x, weight_raw, weight_q, bias, quant_kw, weights_quantised):
+    """1x1 convolution taken over by quantize/fuse.py.  When both operands are quantised to <= 8 bits the convolution
+    runs on the integer codes (fq_pwconv_i8: exact int32 sums on the int8 matrix cores, quantise-on-load, BN / activation
+    / statistic on store); otherwise the library convolution runs and only BN + activation + statistic are fused."""
+    fz = m._fq_pw_fused
+    qa = m.quantize_args
+    scale, shift = fz["constants"]() if fz["bn"] is not None else (None, None)
+    int8_ok = bool(quant_kw) and weights_quantised and qa.in_width <= 8 and qa.wt_width <= 8 \
+        and not getattr(m, "_fq_no_int8", False)
+    if int8_ok:
+        t = x._t if x._t.is_contiguous() else x._t.contiguous()
+        cache = getattr(m, "_fq_pw_cache", None)
+        if m.fixed_params == 1 and cache is not None and cache[3] == m.weight.data()._t.data_ptr():
+            codes, scales, rowsum = cache[:3]
+        else:
+            # codes of the weights being used by THIS forward: the raw weights while they are (re-)quantised every
+            # forward or being frozen right now, the frozen (already fake-quantised) ones afterwards
+            src = weight_raw if m.fixed_params != 1 or cache is None else weight_q
+            wsrc = src._t if src._t.is_contiguous() else src._t.contiguous()
+            codes, scales, rowsum = ops.weight_codes(wsrc, _rows_per_scale(m, qa), qa.wt_width)
+            if m.fixed_params == 1:
+                m._fq_pw_cache = (codes, scales, rowsum, m.weight.data()._t.data_ptr())
+        b = None if bias is None else bias._t
+        y, stat = ops.pwconv_i8(t, codes, scales, rowsum, b, bn_scale=scale, bn_shift=shift, act=fz["act"], **quant_kw)
+    else:
+        if quant_kw:          # input is to be quantised but the integer path does not apply: explicit apply pass
+            t = x._t if x._t.is_contiguous() else x._t.contiguous()
+            if "in_stat" in quant_kw:
+                yq, _, _ = ops.fake_quant_online_prestat(t, quant_kw["in_stat"], quant_kw["width"], quant_kw["flags"],
+                                                         cur_out=quant_kw.get("cur_out"))
+            else:
+                yq, _, _ = ops.fake_quant_offline(t, quant_kw["in_thr"], quant_kw["width"], quant_kw["flags"],
+                                                  want_stat=False)
+            x = NDArray(yq)
+        out = m.origin_forward(F, x, weight_q, bias)
+        if fz["bn"] is None and fz["act"] == "none":
+            return out
+        c = out.shape[1]
+        if scale is None:
+            scale = torch.ones(c, dtype=torch.float32, device=out._t.device)
+            shift = torch.zeros(c, dtype=torch.float32, device=out._t.device)
+        y, stat = ops.bn_act_stat(out._t.contiguous(), scale, shift, fz["act"])
+    res = NDArray(y)
+    res._fq_stat = stat
+    return res
+
+
 def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
                     gamma=None, beta=None, running_mean=None, running_var=None):
     qa = self.quantize_args
     fz = getattr(self, "_fq_dw_fused", None)
+    fzp = getattr(self, "_fq_pw_fused", None)
+    weight_raw = weight
     quant_kw = {}
     # Fake bn (:47-51)
     if self.fixed_params != 1 and qa.fake_bn:
@@ -156,7 +214,7 @@ def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
     if self.enable_quantize:
         # Quantize input (:55-66)
         if qa.quantize_input:
-            if fz is None:
+            if fz is None and fzp is None:
                 x = _fake_quant_input(self, x, input_max, ops.act_flags(signed=qa.in_signed), qa.in_width)
             else:
                 quant_kw = _fused_input_params(self, x, input_max, ops.act_flags(signed=qa.in_signed), qa.in_width)
@@ -195,6 +253,8 @@ def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
     # Normal convolution (:108) — MIOpen through torch; not the path this project replaces
     if fz is not None:
         return _dw_fused_conv(self, x, weight_q, bias, quant_kw)
+    if fzp is not None:
+        return _pw_fused_conv(self, F, x, weight_raw, weight_q, bias, quant_kw, bool(self.enable_quantize))
     act = self.origin_forward(F, x, weight_q, bias)
 
     return act

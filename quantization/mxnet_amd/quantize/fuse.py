@@ -75,6 +75,15 @@ def _is_dw3x3(b):
             and not getattr(getattr(b, "quantize_args", None), "fake_bn", False))
 
 
+def _is_pw1x1(b):
+    if type(b) is not nn.Conv2D or not hasattr(b, "quantize_args"):
+        return False
+    k = b._kwargs
+    return (k["kernel"] == (1, 1) and k["pad"] == (0, 0) and k["dilate"] == (1, 1) and k["stride"] == (1, 1)
+            and k["num_group"] == 1 and k["layout"] == "NCHW" and b.act is None
+            and not b.quantize_args.fake_bn)
+
+
 def _plain_dw_forward(self, F, x, weight, bias=None):
     from .convert.convert_conv2d import _dw_fused_conv
     return _dw_fused_conv(self, x, weight, bias, {})
@@ -93,8 +102,8 @@ def _bn_constants_getter(bn):
     return get
 
 
-def fuse_inference(net, depthwise=True):
-    """Returns the number of blocks fused (BatchNorms folded + depthwise convolutions taken over)."""
+def fuse_inference(net, depthwise=True, pointwise_int8=True):
+    """Returns the number of blocks fused (BatchNorms folded + depthwise / pointwise convolutions taken over)."""
     fused = [0]
 
     def bypass(blk):
@@ -129,8 +138,32 @@ def fuse_inference(net, depthwise=True):
                 bypass(nxt)
             fused[0] += 1
 
+    def visit_pw(container):
+        if not isinstance(container, (nn.Sequential, nn.HybridSequential)):
+            return
+        kids = list(container._children.values())
+        for i, b in enumerate(kids):
+            if not _is_pw1x1(b) or hasattr(b, "_fq_pw_fused") or hasattr(b, "_fq_dw_fused"):
+                continue
+            bn = kids[i + 1] if i + 1 < len(kids) else None
+            if not (type(bn) is nn.BatchNorm and not hasattr(bn, "_fq_fused") and bn._kwargs.get("axis", 1) == 1
+                    and bn.hybrid_forward.__func__ is nn.BatchNorm.hybrid_forward):
+                bn = None
+            nxt = kids[i + 2] if bn is not None and i + 2 < len(kids) else (kids[i + 1] if bn is None and i + 1 < len(kids) else None)
+            act = _act_kind(nxt) if nxt is not None else None
+            b._fq_pw_fused = {"bn": bn, "act": act or "none", "act_block": nxt if act else None,
+                              "constants": _bn_constants_getter(bn) if bn is not None else None}
+            if bn is not None:
+                bn._fq_fused = {"taken_by_conv": True, "orig": bn.hybrid_forward, "act_block": None}
+                bn.hybrid_forward = types.MethodType(_identity_forward, bn)
+            if act:
+                bypass(nxt)
+            fused[0] += 1
+
     if depthwise:
         net.apply(visit_dw)
+    if pointwise_int8:
+        net.apply(visit_pw)
 
     def visit(container):
         kids = list(container._children.values())
@@ -177,6 +210,11 @@ def unfuse(net):
                 b.hybrid_forward = st["orig"]
             restore_act(st["act_block"])
             del b._fq_dw_fused
+        if hasattr(b, "_fq_pw_fused"):
+            restore_act(b._fq_pw_fused["act_block"])
+            del b._fq_pw_fused
+            if hasattr(b, "_fq_pw_cache"):
+                del b._fq_pw_cache
         if hasattr(b, "_fq_fused"):
             st = b._fq_fused
             b.hybrid_forward = st["orig"]

@@ -418,3 +418,66 @@ def test_dwconv3x3_vs_oracle(dev, ops, shape, stride, mode):
                     groups=c).numpy()
     if mode == "plain":
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+# ---- pointwise convolution on integer codes (int8 MFMA) ---------------------------------------------------------------
+PW_CASES = [  # (n, cin, cout, h, w)
+    (2, 32, 64, 28, 28), (3, 64, 128, 14, 14), (2, 128, 128, 9, 12), (2, 128, 256, 14, 14), (5, 512, 512, 7, 7),
+    (3, 1024, 1024, 7, 7), (2, 24, 40, 5, 7), (1, 3, 8, 4, 4), (2, 96, 576, 6, 6), (4, 1024, 1000, 1, 1),
+    (2, 960, 320, 7, 7), (2, 144, 24, 14, 14), (2, 16, 96, 9, 9)]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=["%dx%d->%d@%dx%d" % c for c in PW_CASES])
+@pytest.mark.parametrize("mode", ["online_u8_layer", "offline_s8_channel_w4", "online_u8_bn_relu", "dense_quirk_bias"])
+def test_pwconv_i8_vs_oracle(dev, ops, case, mode):
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case))
+    x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+    if "s8" not in mode:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * rng.uniform(0.05, 1.0, (cout, 1, 1, 1))).astype(np.float32)
+    per_channel = "channel" in mode
+    wt_width = 4 if "w4" in mode else 8
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), 1 if per_channel else cout, wt_width)
+    ocodes, oscales = O.weight_codes(wt, 1 if per_channel else cout, wt_width)
+    _eq(N(codes)[:cout, :cin], ocodes.astype(np.int8), "weight codes")
+    assert not N(codes)[cout:].any() and not N(codes)[:, cin:].any()
+    _eq(N(scales), oscales, "weight scales")
+    _eq(N(rowsum), ocodes.sum(axis=1).astype(np.int32), "row sums")
+    kw, okw = {}, {}
+    if mode.startswith("online"):
+        stat = O.absmax_per_sample(x)
+        kw.update(in_stat=T(stat, dev), width=8, flags=0)
+        okw.update(in_max=O.batch_mean(stat), signed=False, width=8)
+    elif mode.startswith("offline"):
+        thr = np.float32(2.3)
+        kw.update(in_thr=T(np.float32([thr]), dev), width=8, flags=ops.act_flags(signed=True))
+        okw.update(in_max=thr, signed=True, width=8)
+    else:   # Dense quirk: signed levels, clip at zero
+        stat = O.absmax_per_sample(x)
+        kw.update(in_stat=T(stat, dev), width=8, flags=ops.act_flags(signed=True, lo_neg_max=False))
+        okw.update(in_max=O.batch_mean(stat), signed=True, width=8, lo_neg_max=False)
+    if "bn_relu" in mode:
+        sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+        sh = rng.standard_normal(cout).astype(np.float32)
+        kw.update(bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu")
+        okw.update(bn_scale=sc, bn_shift=sh, act="relu")
+    if "bias" in mode:
+        b = rng.standard_normal(cout).astype(np.float32)
+        kw.update(bias=T(b, dev))
+        okw.update(bias=b)
+    cur = torch.zeros(1, device=dev)
+    y, stat_out = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, cur_out=cur, **kw)
+    want = O.pwconv_i8(x, wt, 1 if per_channel else cout, wt_width, **okw)
+    got = N(y)
+    _eq(got, want, "pointwise int8 convolution (exact integer sums)")
+    _eq(N(stat_out), O.absmax_per_sample(got), "statistic")
+    # the same layer through the reference's formulation (fp32 conv of the dequantised tensors): equal up to fp32 conv noise
+    wq = O.weight_fake_quant(wt, "channel" if per_channel else "layer", wt_width)[0]
+    xq = O.ste_forward(x, O.act_scale(okw["in_max"], okw["signed"], okw["width"]), okw["in_max"],
+                       -okw["in_max"] if okw.get("lo_neg_max", okw["signed"]) else 0.0)
+    ref = np.einsum("oc,nchw->nohw", wq.reshape(cout, cin).astype(np.float64), xq.astype(np.float64))
+    if "bias" in mode:
+        ref = ref + okw["bias"].reshape(1, -1, 1, 1)
+    if "bn_relu" not in mode:
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
