@@ -201,6 +201,8 @@ def main():
                  "dwconv": "dwconv3x3_*_kernel (depthwise 3x3 with fake-quant on load + BN/ReLU/statistic on store, "
                            "4 B/in-elem + 4 B/out-elem)",
                  "bn_act": "bn_act_stat_kernel (BN + ReLU + statistic, 8 B/elem)",
+                 "pwconv": "quant_transpose_i8_kernel + pwconv_i8_kernel (1x1 conv on int8 codes: fake-quant on load, "
+                           "exact int32 MFMA sums, BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
                  "weight": "weight fake-quant kernels (8 B/elem)", "histogram": "histogram_kernel (4 B/elem)"}
         kernels = {}
         for key, rec in prof.items():

@@ -1257,63 +1257,88 @@ __global__ __launch_bounds__(kBlock) void pwconv_i8_kernel(
         bn[i] = *reinterpret_cast<const v4i*>(xrow + i * step16 + kn);
       }
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+      for (int uu = 0; uu < 4; ++uu)
 #pragma unroll
-        for (int uu = 0; uu < 4; ++uu) acc[tt][uu] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[tt], b[uu], acc[tt][uu], 0, 0, 0);
+        for (int tt = 0; tt < 4; ++tt) acc[uu][tt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b[uu], a[tt], acc[uu][tt], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         a[i] = an[i];
         b[i] = bn[i];
       }
     }
-    // epilogue: lane holds, per (tt, uu), rows co0 + tt*16 + 4*(lane>>4) + r and column j0 + uu*16 + (lane&15)
+    // epilogue.  The MFMAs were issued with the ACTIVATION codes as the A operand, so D = (pixels x channels): lane
+    // holds, per (uu, tt), the 4 consecutive PIXELS j0 + uu*16 + 4*(lane>>4) + r of channel co0 + tt*16 + (lane&15)
+    // -> one 16-byte store per (uu, tt) when the four pixels sit in one sample, and the per-channel constants are
+    // per LANE (read once per tt).
+    // per-sample maxima of this tile go through an LDS table (a tile spans <= kStatSlots samples), then ONE global
+    // atomic per touched sample: per-wave global atomics on the 128 hot addresses serialised in L2 and cost 80 % of the
+    // kernel (100 k same-address atomics per launch)
+    const unsigned s_base = (unsigned)(ctile * g.PT_B) / HW;
+    if (has_stat) {
+      __syncthreads();
+      if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
+      __syncthreads();
+    }
     int64_t ybase[4];
-    bool cok[4];
+    bool cok[4], vec_ok[4];
     unsigned smps[4];
     float m[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int uu = 0; uu < 4; ++uu) {
-      const unsigned j = j0 + uu * 16 + (lane & 15);
+      const unsigned j = j0 + uu * 16 + 4 * (lane >> 4);               // first of this lane's 4 pixels
       cok[uu] = j < (unsigned)g.cols;
       const unsigned smp = cok[uu] ? j / HW : 0;
+      const unsigned p = j - smp * HW;
       smps[uu] = smp;
-      ybase[uu] = ((int64_t)smp * g.Cout) * plane_stride + (j - smp * HW);
+      ybase[uu] = ((int64_t)smp * g.Cout) * plane_stride + p;
+      vec_ok[uu] = cok[uu] && ((HW & 3u) == 0u) && (p + 3 < HW) && (j + 3 < (unsigned)g.cols);
     }
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
+      const int col = wmi * 64 + tt * 16 + (lane & 15);                 // channel index inside the block
+      const int co = co0 + tt * 16 + (lane & 15);
+      const bool co_ok = co < g.Cout;
+      const float sxw = k_sxw[col];
+      const int zs = k_zs[col];
+      const float bch = k_bias[col], bsc = k_bsc[col], bsh = k_bsh[col];
+      const int64_t coff = (int64_t)(co_ok ? co : 0) * plane_stride;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = wmi * 64 + tt * 16 + 4 * (lane >> 4) + r;       // channel index inside the block
-        const int co = co0 + tt * 16 + 4 * (lane >> 4) + r;
-        const bool co_ok = co < g.Cout;
-        const float sxw = k_sxw[col];
-        const int zs = k_zs[col];
-        const float bch = k_bias[col], bsc = k_bsc[col], bsh = k_bsh[col];
-        const int64_t coff = (int64_t)(co_ok ? co : 0) * plane_stride;
+      for (int uu = 0; uu < 4; ++uu) {
+        float o[4];
 #pragma unroll
-        for (int uu = 0; uu < 4; ++uu) {
-          float v = (float)(acc[tt][uu][r] + zs) * sxw;
+        for (int r = 0; r < 4; ++r) {
+          float v = (float)(acc[uu][tt][r] + zs) * sxw;
           if (bias != nullptr) v = v + bch;
           if (has_bn) {
             v = v * bsc;
             v = v + bsh;
           }
-          v = act_rt(v, act);
-          if (co_ok && cok[uu]) {
-            y[ybase[uu] + coff] = v;
-            m[uu] = fmaxf(m[uu], fabsf(v));
+          o[r] = act_rt(v, act);
+        }
+        if (co_ok && vec_ok[uu]) {
+          *reinterpret_cast<f4*>(y + ybase[uu] + coff) = (f4){o[0], o[1], o[2], o[3]};
+          m[uu] = fmaxf(m[uu], fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        } else if (co_ok && cok[uu]) {
+          // ragged: the 4 pixels may straddle a sample boundary or the end of the tensor
+          const unsigned jb = j0 + uu * 16 + 4 * (lane >> 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned j = jb + r;
+            if (j < (unsigned)g.cols) {
+              const unsigned smp = j / HW;
+              y[((int64_t)smp * g.Cout) * plane_stride + (j - smp * HW) + coff] = o[r];
+              if (smp == smps[uu]) m[uu] = fmaxf(m[uu], fabsf(o[r]));
+              else if (has_stat) {
+                const unsigned slot = smp - s_base;
+                if (slot < kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(fabsf(o[r])));
+                else atomic_max_f32(stat_out + smp, fabsf(o[r]));
+              }
+            }
           }
         }
       }
     }
     if (has_stat) {
-      // per-sample maxima of this tile through an LDS table (a tile spans <= kStatSlots samples), then ONE global atomic
-      // per touched sample: per-wave global atomics on the 128 hot addresses serialised in L2 and cost 80 % of the
-      // kernel (100 k same-address atomics per launch)
-      const unsigned s_base = (unsigned)(ctile * g.PT_B) / HW;
-      __syncthreads();
-      if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
-      __syncthreads();
 #pragma unroll
       for (int uu = 0; uu < 4; ++uu) {
         if (cok[uu]) {
