@@ -116,6 +116,8 @@ int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t in
 #define FQ_ACT_NONE 0
 #define FQ_ACT_RELU 1
 #define FQ_ACT_RELU6 2
+/* OR into `act`: stat_out is already zero (the caller zeroes ONE arena per forward instead of one memset per layer) */
+#define FQ_STAT_PREZEROED 0x100
 int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                    const float* shift, int act, float* stat_out, fqStream_t stream);
 

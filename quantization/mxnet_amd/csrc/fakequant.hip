@@ -2080,10 +2080,12 @@ int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, c
   FQ_REQUIRE(x && y && scale && shift, "fq_bn_act_stat: null pointer");
   FQ_REQUIRE(n > 0 && c > 0 && hw > 0 && c * hw < (1ll << 32) && hw < (1ll << 31),
              "fq_bn_act_stat: bad shape (n=%lld c=%lld hw=%lld)", (long long)n, (long long)c, (long long)hw);
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
   FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_bn_act_stat: unknown activation %d", act);
   hipStream_t st = (hipStream_t)stream;
   const int64_t inner = c * hw;
-  if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   const bool small = use_small_chunks(n, inner);
   const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
   const bool vec = (inner % kVec == 0) && aligned16(x) && aligned16(y);
@@ -2126,6 +2128,8 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
   FQ_REQUIRE(stride == 1 || stride == 2, "fq_dwconv3x3: stride must be 1 or 2, got %d", stride);
   FQ_REQUIRE(!(in_stat && in_thr), "fq_dwconv3x3: give in_stat (online) OR in_thr (offline), not both");
   FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_dwconv3x3: bn_scale and bn_shift go together");
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
   FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_dwconv3x3: unknown activation %d", act);
   const bool quant = in_stat != nullptr || in_thr != nullptr;
   if (quant) FQ_REQUIRE(in_width >= 2 && in_width <= 16, "fq_dwconv3x3: width %d out of range", in_width);
@@ -2154,7 +2158,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     const float levels = act_levels(in_width, in_flags);
     const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
-    if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+    if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
 #define FQ_DWC4(SS, Q, O)                                                                                         \
   hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, cg,       \
@@ -2193,7 +2197,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     const float levels = act_levels(in_width, in_flags);
     const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
-    if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+    if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
 #define FQ_DWC(SS, Q, O)                                                                                          \
   hipLaunchKernelGGL((dwconv3x3_cols_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, cg,        \
@@ -2259,7 +2263,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
   const float levels = act_levels(in_width, in_flags);
   const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
   const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
-  if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * g.Ho * g.Wo), st);
 #define FQ_DW(SS, Q, O)                                                                                           \
   hipLaunchKernelGGL((dwconv3x3_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), lds, st, x, w, bias, y, g, tiles,    \
@@ -2321,6 +2325,8 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
   FQ_REQUIRE(in_width >= 2 && in_width <= 8, "fq_pwconv_i8: input width %d does not fit int8 codes", in_width);
   FQ_REQUIRE(!(in_flags & (FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "fq_pwconv_i8: unsupported activation flags");
   FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_pwconv_i8: bn_scale and bn_shift go together");
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
   FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_pwconv_i8: unknown activation %d", act);
   FQ_REQUIRE(aligned16(wcodes) && aligned16(ws) && aligned16(x), "fq_pwconv_i8: x, wcodes and ws must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -2358,7 +2364,7 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
   g.stride = 0;
   g.zoff = zoff;
   const int64_t tiles = ((g.cols + g.PT_B - 1) / g.PT_B) * g.passes;
-  if (stat_out) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   int64_t grid64 = tiles < (int64_t)num_cu() * 32 ? tiles : (int64_t)num_cu() * 32;
   grid64 = grid64 / g.passes * g.passes;                  // multiple of the channel blocks (tiles is one already)
   const int grid = (int)(grid64 < g.passes ? g.passes : grid64);

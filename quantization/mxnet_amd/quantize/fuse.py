@@ -160,11 +160,6 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True):
                 bypass(nxt)
             fused[0] += 1
 
-    if depthwise:
-        net.apply(visit_dw)
-    if pointwise_int8:
-        net.apply(visit_pw)
-
     def visit(container):
         kids = list(container._children.values())
         for i, b in enumerate(kids):
@@ -184,8 +179,34 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True):
                 bypass(nxt)
             fused[0] += 1
 
+    if depthwise:
+        net.apply(visit_dw)
+    if pointwise_int8:
+        net.apply(visit_pw)
     net.apply(visit)
+    _install_stat_arena(net, fused[0])
     return fused[0]
+
+
+def _install_stat_arena(net, producers):
+    """One zeroing launch per forward for all producers' per-sample statistic rows (ops.StatArena)."""
+    if producers <= 0 or hasattr(net, "_fq_arena_hooks"):
+        return
+    state = {"arena": None}
+
+    def pre(block, args):
+        x = args[0]
+        dev = x._t.device
+        if dev.type != "cuda":
+            return
+        if state["arena"] is None or state["arena"].device != dev:
+            state["arena"] = ops.StatArena(producers + 8, dev)
+        state["arena"].begin(x.shape[0])
+
+    def post(block, args, out):
+        if state["arena"] is not None:
+            state["arena"].end()
+    net._fq_arena_hooks = (net.register_forward_pre_hook(pre), net.register_forward_hook(post))
 
 
 def refresh(net):
@@ -198,6 +219,11 @@ def refresh(net):
 
 
 def unfuse(net):
+    if hasattr(net, "_fq_arena_hooks"):
+        for h in net._fq_arena_hooks:
+            h.detach()
+        del net._fq_arena_hooks
+
     def restore_act(blk):
         if blk is not None and hasattr(blk, "_fq_bypassed_orig"):
             blk.hybrid_forward = blk._fq_bypassed_orig
