@@ -2518,7 +2518,11 @@ int fq_histogram_accumulate(const float* x, int64_t numel, const float* max_dev,
   FQ_REQUIRE(x && max_dev && hist, "fq_histogram_accumulate: null pointer");
   FQ_REQUIRE(numel > 0, "fq_histogram_accumulate: empty tensor");
   FQ_REQUIRE(bins > 0 && bins <= 8192, "fq_histogram_accumulate: bins=%d out of range (1..8192)", bins);
-  const int grid = grid_for((numel + kChunk - 1) / kChunk);
+  // every workgroup ends with up to `bins` global 64-bit atomics: keep the grid at ~2 workgroups per CU (enough loads in
+  // flight for a read-only stream) so that the flush stays a small fraction of the work
+  int64_t hg = (numel + kChunk - 1) / kChunk;
+  if (hg > (int64_t)num_cu() * 2) hg = (int64_t)num_cu() * 2;
+  const int grid = (int)(hg < 1 ? 1 : hg);
   ProfScope prof(FQ_KERNEL_HISTOGRAM, 4.0 * (double)numel, (hipStream_t)stream);
   hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(kBlock), (size_t)4 * bins * sizeof(unsigned int),
                      (hipStream_t)stream, x, numel, aligned16(x) ? 1 : 0, max_dev, bins,
