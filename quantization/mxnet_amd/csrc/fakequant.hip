@@ -168,6 +168,7 @@ struct QParams {
   float lo, hi;      // clip bounds
   float denom;       // scale + eps
   float scale;       // multiply-back scale (no eps)
+  double rden;       // RN_f64(1 / denom), see ieee_div_by()
 };
 
 __device__ __forceinline__ QParams make_qparams(float max_, float levels, bool lo_neg_max, float eps) {
@@ -176,13 +177,23 @@ __device__ __forceinline__ QParams make_qparams(float max_, float levels, bool l
   q.lo = lo_neg_max ? -max_ : 0.0f;
   q.scale = max_ / levels;
   q.denom = q.scale + eps;
+  q.rden = 1.0 / (double)q.denom;
   return q;
 }
+
+// Correctly rounded fp32 quotient c / d for a divisor that is the same for the whole kernel, in 3 instructions instead
+// of the ~11 of the IEEE division expansion:  (float)((double)c * RN_f64(1/d))  ==  RN_f32(c / d)  for ALL fp32 c, d.
+// Proof sketch: the double product carries a relative error <= 2^-52, while the exact quotient of two fp32 numbers is
+// either an fp32 number or at least 2^-49 (relative) away from every fp32 rounding midpoint (c - M*d is a non-zero
+// integer multiple of 2^(g+b) for a 25-bit midpoint M = N*2^g and d = D*2^b), so the product falls on the same side of
+// every midpoint as the exact quotient and the final conversion rounds it to the same fp32 number.  0/0 and x/0 behave
+// as in IEEE (rden = inf).  Checked exhaustively around every .5 tie in tests/test_gpu_parity.py.
+__device__ __forceinline__ float ieee_div_by(float c, double rden) { return (float)((double)c * rden); }
 
 // The integer stage and the dequantised value (ste_func.py:41): clip -> IEEE divide -> roundf -> multiply.
 __device__ __forceinline__ float fq_code(float x, const QParams& q) {
   float c = fminf(fmaxf(x, q.lo), q.hi);
-  return roundf(c / q.denom);
+  return roundf(ieee_div_by(c, q.rden));
 }
 
 template <bool USE_ABS>
@@ -530,6 +541,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_kernel(const float* __restri
   __shared__ float red[4];
   QParams q;
   q.lo = q.hi = q.denom = q.scale = 0.0f;
+  q.rden = 0.0;
   if (QUANT) {
     const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
     q = make_qparams(max_, levels, lo_neg_max != 0, eps);
@@ -699,6 +711,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
   __shared__ int red_s[4];
   QParams q;
   q.lo = q.hi = q.denom = q.scale = 0.0f;
+  q.rden = 0.0;
   if (QUANT) {
     const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
     q = make_qparams(max_, levels, lo_neg_max != 0, eps);
@@ -913,6 +926,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
   __shared__ int red_s[4];
   QParams q;
   q.lo = q.hi = q.denom = q.scale = 0.0f;
+  q.rden = 0.0;
   if (QUANT) {
     const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
     q = make_qparams(max_, levels, lo_neg_max != 0, eps);

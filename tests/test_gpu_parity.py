@@ -481,3 +481,29 @@ def test_pwconv_i8_vs_oracle(dev, ops, case, mode):
         ref = ref + okw["bias"].reshape(1, -1, 1, 1)
     if "bn_relu" not in mode:
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
+def test_division_by_double_reciprocal_is_ieee_exact(dev, ops):
+    """fq_code divides with (float)((double)c * RN_f64(1/d)) (csrc: ieee_div_by).  Stress it where it could matter: inputs
+    placed 0, +-1, +-2 ulp around every k + 0.5 rounding tie of the quotient, for many divisors, signed and unsigned."""
+    rng = np.random.default_rng(123)
+    for trial in range(40):
+        width = int(rng.choice([8, 8, 4, 2, 7]))
+        signed = bool(trial % 2)
+        levels = (2 ** (width - 1) - 1) if signed else (2 ** width - 1)
+        thr = np.float32(rng.uniform(1e-4, 300.0) if trial % 5 else rng.uniform(1e-12, 1e-6))
+        scale = np.float32(thr / np.float32(levels))
+        denom = np.float32(scale + np.float32(1e-10))
+        ks = np.arange(-levels - 2 if signed else -2, levels + 3, dtype=np.float64)
+        base = ((ks[:, None] + 0.5) * np.float64(denom)).astype(np.float32)            # quotient ~ k + 0.5
+        xs = base.copy()
+        for _ in range(3):
+            xs = np.concatenate([np.nextafter(xs, np.float32(np.inf)), xs, np.nextafter(xs, np.float32(-np.inf))], axis=1)
+        extra = (rng.standard_normal(4096) * float(thr)).astype(np.float32)
+        x = np.concatenate([xs.reshape(-1), extra, np.float32([0.0, -0.0, thr, -thr, 1e-45, 3e38])]).astype(np.float32)
+        x = np.resize(x, (4, (x.size + 3) // 4))
+        want_y, _, _, want_codes = O.conv_input_fake_quant(x, signed, width, offline_threshold=thr)
+        y, _, codes = ops.fake_quant_offline(T(x, dev), T(np.float32([thr]), dev), width, ops.act_flags(signed=signed),
+                                             want_stat=False, want_codes=True)
+        _eq(N(codes), want_codes.astype(np.int32), "codes (trial %d, thr %g, width %d)" % (trial, thr, width))
+        _eq(N(y), want_y, "y")
