@@ -9,7 +9,8 @@ import os
 __all__ = ["LIB", "check_call", "load", "library_path", "FakeQuantError", "EXPORTS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "csrc", "libfakequant.so")
+# FQ_LIB_PATH: load another build of the same library (debug / trace builds made by tools/)
+_LIB_PATH = os.environ.get("FQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libfakequant.so")
 
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_i32p = ctypes.POINTER(ctypes.c_int32)

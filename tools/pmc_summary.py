@@ -25,33 +25,42 @@ def family(n):
         return 'dwconv'
     if 'bn_act_stat_kernel' in n:
         return 'bn_act'
+    if 'pwconv_i8_kernel' in n or 'quant_transpose_i8_kernel' in n:
+        return 'pwconv'
+    if 'weight_codes_kernel' in n or 'weight_rows_lds_kernel' in n or 'weight_apply_kernel' in n:
+        return 'weight'
     if 'direct_copy' in n or 'copyBuffer' in n:
         return 'device_copy(calibration)'
     return None
 
 
 def load(path, cname):
-    agg = collections.defaultdict(list)
+    """family -> (counter values, number of library calls).  One fq_pwconv_i8 call launches two kernels (quantise +
+    transpose, then the int8 GEMM) that the library's event scope brackets together, so its traffic is summed per CALL."""
+    agg, calls = collections.defaultdict(list), collections.Counter()
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != cname:
             continue
         k = family(r['Kernel_Name'])
         if k:
             agg[k].append(float(r['Counter_Value']))
-    return agg
+            if not (k == 'pwconv' and 'quant_transpose' in r['Kernel_Name']):
+                calls[k] += 1
+    return agg, calls
 
 
 def main(fetch_csv, write_csv, out_json=None, tag=""):
-    f, w = load(fetch_csv, 'FETCH_SIZE'), load(write_csv, 'WRITE_SIZE')
+    (f, fc), (w, wc) = load(fetch_csv, 'FETCH_SIZE'), load(write_csv, 'WRITE_SIZE')
     res = {}
     for k in sorted(set(f) | set(w)):
         fv, wv = f.get(k, []), w.get(k, [])
-        rd = 2.0 * 1024.0 * sum(fv) / max(len(fv), 1)
-        wr = 1024.0 * sum(wv) / max(len(wv), 1)
-        res[k] = {"launches_fetch_pass": len(fv), "launches_write_pass": len(wv),
+        nf, nw = fc.get(k, 0), wc.get(k, 0)
+        rd = 2.0 * 1024.0 * sum(fv) / max(nf, 1)
+        wr = 1024.0 * sum(wv) / max(nw, 1)
+        res[k] = {"launches_fetch_pass": nf, "launches_write_pass": nw,
                   "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-        print("%-28s launches %4d/%4d  read %10.1f MB  write %10.1f MB  total %10.1f MB per launch"
-              % (k, len(fv), len(wv), rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
+        print("%-28s calls %4d/%4d  read %10.1f MB  write %10.1f MB  total %10.1f MB per call"
+              % (k, nf, nw, rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
     if out_json:
         json.dump({"source": tag, "kernels": res}, open(out_json, "w"), indent=1)
 
