@@ -1415,6 +1415,14 @@ __global__ __launch_bounds__(kBlock) void pwconv_i8_kernel(
   }
 }
 
+// Ordering fence for hand-pipelined loops: the asm memory clobber stops IR-level motion of loads, the sched_barrier the
+// machine scheduler's (it sinks prefetches next to their use, or hoists every load of an unrolled loop to the top).
+#define FQ_PIN()                         \
+  do {                                   \
+    asm volatile("" ::: "memory");        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+
 // K2g: the two kernels above in ONE launch, no int8 intermediate in HBM.  A workgroup owns PX = 64*wn columns
 // (column = (sample, pixel) flattened): phase 1 reads their fp32 activations once (coalesced along pixels), fake-quantises
 // them and leaves the int8 codes, transposed to K-contiguous rows, in an LDS panel [PX][K]; phase 2 runs the integer
@@ -1837,18 +1845,24 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     r.p = j - r.smp * HW;
     return r;
   };
+  // addresses: wave-uniform base (SGPR arithmetic) + ONE 32-bit per-lane byte offset per tile (host checks the tensors
+  // are < 4 GB).  With 64-bit per-lane pointers the compiler materialised an address pair per load and spilled.
+  auto lane_off = [&](const Pix& px, int c0) __attribute__((always_inline)) {
+    return (unsigned)((((int64_t)px.smp * g.Cin + c0) * plane + px.p) * 4);
+  };
   auto issue = [&](const Pix& px, int kt, float (&v)[16]) __attribute__((always_inline)) {
     const int cg = kt * 32 + 16 * h;                                   // this half-wave's 16 channels of slab kt
-    const float* base = x + ((int64_t)px.smp * g.Cin + (cg < g.Cin ? cg : 0)) * plane + px.p;
+    const unsigned off = lane_off(px, cg < g.Cin ? 16 * h : 0);        // padded group: read the valid half, discarded
+    const char* ub = reinterpret_cast<const char*>(x) + (int64_t)kt * 32 * plane * 4;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = base[(int64_t)i * plane];
+    for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float*>(ub + (int64_t)i * plane * 4 + off);
   };
 
   float bufa[16], bufb[16];
   int64_t t_first = t_begin < g.tiles ? t_begin : g.tiles - 1;
   Pix nxt = pix_of(t_first);
   issue(nxt, 0, bufa);                                                  // in flight during the whole set-up
-  __builtin_amdgcn_sched_barrier(0);
+  FQ_PIN();
 
   const float max_ = in_stat != nullptr ? batch_mean_dev(in_stat, n) : in_thr[0];
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
@@ -1886,11 +1900,14 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
       }
       f[d] = gvalid ? (int)packed : 0;
     }
+    // pin the quantisation HERE: it is pure arithmetic whose results are only needed by the MFMAs, and the optimiser
+    // otherwise sinks it below every prefetch, keeping all 16 * KT loaded values live (256 VGPRs + spills)
+    asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
     bfrag[kt] = f;
   };
   auto tile_done = [&](const Pix& px, auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
-    float* yb = y + ((int64_t)px.smp * g.Cout) * plane + px.p;
+    const unsigned yoff = (unsigned)((((int64_t)px.smp * g.Cout + 4 * h) * plane + px.p) * 4);
     float m = 0.0f;
 #pragma unroll 1
     for (int ct = 0; ct < g.CT; ++ct) {
@@ -1923,7 +1940,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
           }
           v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
           if (ok) {
-            yb[(int64_t)(c0 + r) * plane] = v;
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff) = v;
             m = fmaxf(m, fabsf(v));
           }
         }
@@ -1957,12 +1974,12 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
       float (&other)[16] = (kt & 1) ? first : second;
       if (kt + 1 < KT) issue(cur, kt + 1, other);
       else issue(nxt, 0, other);
-      __builtin_amdgcn_sched_barrier(0);
+      FQ_PIN();
       quant(kt, mine);
-      __builtin_amdgcn_sched_barrier(0);
+      FQ_PIN();
     }
     tile_done(cur, bias_c, bn_c, act_c);
-    __builtin_amdgcn_sched_barrier(0);
+    FQ_PIN();
   };
   auto run_all = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
     if (KT & 1) {                                                       // the buffers swap roles from tile to tile
@@ -1985,6 +2002,242 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{});
   else
     run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});
+
+  if (has_stat) {
+    __syncthreads();
+    if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < cols / HW)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+  }
+}
+
+// K2i: the streaming form for layers whose weights do NOT fit in LDS (K = 256 / 512, Cout up to 1024).  Activations
+// exactly as K2h (lane = pixel, codes built in registers: K/32 fragments of 4 VGPRs stay resident for the whole tile),
+// the weight matrix streams through LDS in chunks of CTC channel tiles (32 KB), double buffered: while the wavefronts
+// multiply chunk c (A fragments by ds_read_b128, B fragments from registers) and store its outputs, every thread has
+// chunk c+1's 16-byte pieces in flight from L2, and writes them to the other LDS buffer before the (single) barrier of
+// the iteration.  The chunk sequence is cyclic, so the pipeline runs across tile batches.  `wsplit` wavefronts share one
+// 32-pixel tile and divide a chunk's channel tiles among themselves when there are too few pixels to give every
+// wavefront its own tile (7x7 planes); they quantise that tile redundantly.
+struct PwcGeom {
+  int Cin, K, Cout, CT, HW;   // K: row stride of the weight codes; CT = ceil(Cout / 32)
+  int CTC, NC;                // channel tiles per chunk, chunks = ceil(CT / CTC)
+  int wsplit;                 // wavefronts per tile: 1, 2 or 4
+  int rows;                   // rows of the weight code buffer (Cout rounded up to 64)
+  int64_t cols, tiles, batches;   // n * HW, ceil(cols / 32), ceil(tiles / (4 / wsplit))
+  int zoff;
+};
+
+template <int KT, int PIECES>
+__global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
+    const float* __restrict__ x, const int8_t* __restrict__ wc, const float* __restrict__ wscale,
+    const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwcGeom g,
+    const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
+    float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
+    float* __restrict__ stat_out) {
+  constexpr int kSlots = 8;
+  constexpr int kMaxPieces = PIECES;                                    // 16-byte pieces per thread: CTC * KT / 4
+  extern __shared__ __attribute__((aligned(16))) unsigned char pwc_smem[];
+  __shared__ unsigned k_stat[kSlots];
+  const int chunk_frags = g.CTC * KT;                                   // 1 KB fragments per chunk
+  const int nchc = g.CTC * 32;                                          // channels per chunk
+  const size_t buf_bytes = (size_t)chunk_frags * 1024 + (size_t)nchc * 5 * sizeof(float);
+  auto bufA = [&](int b) __attribute__((always_inline)) { return reinterpret_cast<v4i*>(pwc_smem + (size_t)b * buf_bytes); };
+  auto bufC = [&](int b) __attribute__((always_inline)) {
+    return reinterpret_cast<float*>(pwc_smem + (size_t)b * buf_bytes + (size_t)chunk_frags * 1024);
+  };
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, pl = lane & 31;
+  const unsigned HW = (unsigned)g.HW, cols = (unsigned)g.cols;
+  const int64_t plane = (int64_t)g.HW;
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
+  const int tiles_per_wg = 4 / g.wsplit;
+  const int my_tile = wave / g.wsplit, sub = wave - my_tile * g.wsplit;
+  const int64_t b_begin = g.batches * blockIdx.x / gridDim.x, b_end = g.batches * (blockIdx.x + 1) / gridDim.x;
+  unsigned s_base;
+  {
+    const unsigned j0 = (unsigned)(b_begin * tiles_per_wg) * 32u;
+    s_base = (j0 < cols ? j0 : cols - 1) / HW;
+  }
+
+  const float max_ = in_stat != nullptr ? batch_mean_dev(in_stat, n) : in_thr[0];
+  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  if (in_stat != nullptr && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  const float sx = q.scale;
+  if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
+
+  // ---- weight chunk staging (global -> registers -> LDS, fragment order) ---------------------------------------------
+  v4i stage[kMaxPieces];
+  float cst[5];
+  const unsigned w_lane_off = (unsigned)(pl * g.K + h * 16);            // row pl, 16-byte half h of a 32-byte slab
+  auto chunk_issue = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < kMaxPieces; ++i) {
+      const int f = wave + 4 * i;                                       // fragment inside the chunk (wave-uniform)
+      const int ctl = f / KT, kt = f - ctl * KT;
+      int row0 = (c * g.CTC + ctl) * 32;
+      row0 = row0 + 32 <= g.rows ? row0 : g.rows - 32;                  // tiles past the padded buffer: discarded channels
+      stage[i] = *reinterpret_cast<const v4i*>(wc + ((int64_t)row0 * g.K + kt * 32) + w_lane_off);
+    }
+    if ((int)threadIdx.x < nchc) {
+      const int ch = c * nchc + threadIdx.x;
+      const bool ok = ch < g.Cout;
+      const int cc = ok ? ch : 0;
+      cst[0] = sx * wscale[cc];
+      cst[1] = has_bn ? bn_scale[cc] : 1.0f;
+      cst[2] = has_bn ? bn_shift[cc] : 0.0f;
+      cst[3] = bias != nullptr ? bias[cc] : 0.0f;
+      cst[4] = __int_as_float(ok ? g.zoff * wsum[cc] : 0);
+    }
+  };
+  auto chunk_commit = [&](int b) __attribute__((always_inline)) {
+    v4i* A = bufA(b);
+#pragma unroll
+    for (int i = 0; i < kMaxPieces; ++i) A[((wave + 4 * i) << 6) + lane] = stage[i];
+    if ((int)threadIdx.x < nchc) {
+      float* C = bufC(b);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) C[k * nchc + threadIdx.x] = cst[k];
+    }
+  };
+
+  struct Pix { unsigned smp, p; bool valid; };
+  auto pix_of = [&](int64_t t) __attribute__((always_inline)) {
+    Pix r;
+    unsigned j = (unsigned)t * 32u + (unsigned)pl;
+    r.valid = t < g.tiles && j < cols;
+    j = r.valid ? j : cols - 1;
+    r.smp = j / HW;
+    r.p = j - r.smp * HW;
+    return r;
+  };
+  auto issue = [&](const Pix& px, int kt, float (&v)[16]) __attribute__((always_inline)) {
+    const int cg = kt * 32 + 16 * h;
+    const unsigned off = (unsigned)((((int64_t)px.smp * g.Cin + (cg < g.Cin ? 16 * h : 0)) * plane + px.p) * 4);
+    const char* ub = reinterpret_cast<const char*>(x) + (int64_t)kt * 32 * plane * 4;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float*>(ub + (int64_t)i * plane * 4 + off);
+  };
+  v4i bfrag[KT];
+  auto quant = [&](int kt, const float (&v)[16]) __attribute__((always_inline)) {
+    const bool gvalid = kt * 32 + 16 * h < g.Cin;
+    v4i f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      unsigned packed = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int code = fq_code_int(v[4 * d + e], q) - g.zoff;
+        packed |= ((unsigned)code & 0xFFu) << (8 * e);
+      }
+      f[d] = gvalid ? (int)packed : 0;
+    }
+    // pin the quantisation HERE: it is pure arithmetic whose results are only needed by the MFMAs, and the optimiser
+    // otherwise sinks it below every prefetch, keeping all 16 * KT loaded values live (256 VGPRs + spills)
+    asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+    bfrag[kt] = f;
+  };
+
+  chunk_issue(0);
+  chunk_commit(0);
+  __syncthreads();
+
+  auto run = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+    constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
+    float bufa[16], bufb[16];
+    for (int64_t b = b_begin; b < b_end; ++b) {
+      const Pix px = pix_of(b * tiles_per_wg + my_tile);
+      // phase Q: the tile's K/32 slabs -> B fragments (two load buffers)
+      issue(px, 0, bufa);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        float (&mine)[16] = (kt & 1) ? bufb : bufa;
+        float (&other)[16] = (kt & 1) ? bufa : bufb;
+        issue(px, kt + 1 < KT ? kt + 1 : kt, other);
+        FQ_PIN();
+        quant(kt, mine);
+        FQ_PIN();
+      }
+      const unsigned yoff = (unsigned)((((int64_t)px.smp * g.Cout + 4 * h) * plane + px.p) * 4);
+      float m = 0.0f;
+      for (int c = 0; c < g.NC; ++c) {
+        const int cur = c & 1;                                          // NC is even or 1 (host): buffers line up across batches
+        chunk_issue(c + 1 < g.NC ? c + 1 : 0);
+        FQ_PIN();
+        const v4i* A = bufA(g.NC == 1 ? 0 : cur);
+        const float* C = bufC(g.NC == 1 ? 0 : cur);
+#pragma unroll 1
+        for (int ctl = sub; ctl < g.CTC; ctl += g.wsplit) {
+          const int cb = ctl * 32 + 4 * h;                              // channel index inside the chunk
+          v16i acc;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const v4i z = *reinterpret_cast<const v4i*>(C + 4 * nchc + cb + 8 * gq);
+            acc[4 * gq + 0] = z.x; acc[4 * gq + 1] = z.y; acc[4 * gq + 2] = z.z; acc[4 * gq + 3] = z.w;
+          }
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[((ctl * KT + kt) << 6) + lane], bfrag[kt], acc, 0, 0, 0);
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int c0 = cb + 8 * gq;
+            const int ch0 = c * nchc + c0;                              // global channel of register 4gq
+            const f4 sxw = *reinterpret_cast<const f4*>(C + c0);
+            const f4 bsc = *reinterpret_cast<const f4*>(C + nchc + c0);
+            const f4 bsh = *reinterpret_cast<const f4*>(C + 2 * nchc + c0);
+            f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
+            if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(C + 3 * nchc + c0);
+            const bool ok = px.valid && ch0 < g.Cout;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = (float)acc[4 * gq + r] * sxw[r];
+              if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) v = v + bch[r];
+              if (BN_M == 1 || (BN_M < 0 && has_bn)) {
+                v = v * bsc[r];
+                v = v + bsh[r];
+              }
+              v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
+              if (ok) {
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(y) +
+                                          (int64_t)(c * nchc + ctl * 32 + 8 * gq + r) * plane * 4 + yoff) = v;
+                m = fmaxf(m, fabsf(v));
+              }
+            }
+          }
+        }
+        FQ_PIN();
+        if (g.NC > 1) {
+          chunk_commit(cur ^ 1);
+          __syncthreads();
+        }
+      }
+      if (has_stat) {
+        const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)px.smp);
+        const bool uniform = __all(!px.valid || px.smp == s0);
+        if (uniform) {
+          const float wm = wave_max(px.valid ? m : 0.0f);
+          if (lane == 0) {
+            const unsigned slot = s0 - s_base;
+            if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+            else atomic_max_f32(stat_out + s0, wm);
+          }
+        } else if (px.valid) {
+          const unsigned slot = px.smp - s_base;
+          if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+          else atomic_max_f32(stat_out + px.smp, m);
+        }
+      }
+    }
+  };
+  using std::integral_constant;
+  if (bias == nullptr && has_bn && act == FQ_ACT_RELU)
+    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
+  else if (bias == nullptr && has_bn && act == FQ_ACT_RELU6)
+    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{});
+  else if (bias == nullptr && has_bn && act == FQ_ACT_NONE)
+    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{});
+  else
+    run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});
 
   if (has_stat) {
     __syncthreads();
@@ -3027,6 +3280,46 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
       return FQ_OK;
     }
     FQ_REQUIRE(pw_form != 3, "fq_pwconv_i8: FQ_PW_FORM=3 but the shape does not fit the streaming kernel");
+    // chunked streaming form: weights through LDS in double-buffered chunks, K = 256 or 512
+    static const int pwc_ctc = env_int("FQ_PWC_CTC", 0), pwc_wsplit = env_int("FQ_PWC_WSPLIT", 0);
+    if ((pw_form == 0 || pw_form == 4) && cin % 16 == 0 && cout % 4 == 0 && (kt == 8 || kt == 16)) {
+      PwcGeom c;
+      c.Cin = (int)cin; c.K = (int)cin_pad; c.Cout = (int)cout; c.CT = ct; c.HW = (int)hw;
+      c.cols = n * hw; c.tiles = (c.cols + 31) / 32; c.zoff = zoff;
+      c.rows = (int)((cout + 63) / 64 * 64);
+      // few tiles (7x7 planes): all four wavefronts share one tile and split a 4-tile chunk; otherwise one tile each
+      c.wsplit = c.tiles < (int64_t)num_cu() * 2 ? 4 : 1;
+      if (pwc_wsplit > 0) c.wsplit = pwc_wsplit;
+      c.CTC = c.wsplit == 4 ? 4 : (kt == 16 ? 2 : 4);
+      if (pwc_ctc > 0) c.CTC = pwc_ctc;
+      c.NC = (ct + c.CTC - 1) / c.CTC;
+      const int pieces = c.CTC * kt / 4;
+      const bool ok = (c.NC == 1 || c.NC % 2 == 0) && c.wsplit <= c.CTC && (pieces == 8 || pieces == 16) &&
+                      (c.wsplit == 1 || c.wsplit == 2 || c.wsplit == 4);
+      if (ok) {
+        c.batches = (c.tiles + (4 / c.wsplit) - 1) / (4 / c.wsplit);
+        const size_t lds2 = 2 * ((size_t)c.CTC * kt * 1024 + (size_t)c.CTC * 32 * 5 * sizeof(float));
+        int per_cu = (int)((160 * 1024) / (lds2 + 1024));
+        per_cu = per_cu > 2 ? 2 : (per_cu < 1 ? 1 : per_cu);
+        int64_t grid = (int64_t)num_cu() * per_cu;
+        if (grid > c.batches) grid = c.batches;
+        if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+#define FQ_PWC_CASE(KT_, P_)                                                                                           \
+  if (kt == KT_ && pieces == P_) {                                                                                     \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_chunk_kernel<KT_, P_>),      \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess; \
+    FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the chunked kernel");                     \
+    hipLaunchKernelGGL((pwconv_chunk_kernel<KT_, P_>), dim3((unsigned)grid), dim3(kBlock), lds2, st, x, wcodes, wscale, \
+                       (const int*)wsum, bias, y, c, in_stat, (int)n, in_thr, levels, lo_neg, kEps, out_current_max,   \
+                       bn_scale, bn_shift, act, stat_out);                                                             \
+  }
+        FQ_PWC_CASE(8, 8) FQ_PWC_CASE(8, 16) FQ_PWC_CASE(16, 8) FQ_PWC_CASE(16, 16)
+#undef FQ_PWC_CASE
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+      }
+    }
+    FQ_REQUIRE(pw_form != 4, "fq_pwconv_i8: FQ_PW_FORM=4 but the shape does not fit the chunked kernel");
   }
   {
     PwfGeom f;
