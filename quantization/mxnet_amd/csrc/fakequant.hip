@@ -231,14 +231,25 @@ __device__ __forceinline__ float fq_code(float x, const QParams& q) {
   return roundf(ieee_div_by(c, q.rden));
 }
 
-// The integer code itself, for the kernels that keep codes (int8 paths): the same value as (int)fq_code(x, q), with the
-// roundf done in fp64 where Q + copysign(0.5, Q) is exact (Q is an fp32 number, |Q| < 2^24) and the conversion
-// truncates: trunc(Q +- 0.5) is round-half-away-from-zero.  9 VALU instructions instead of ~16: these kernels are
-// VALU-bound, not HBM-bound (tools/pw_trace.py --ablate).
+// The integer code itself, for the kernels that keep codes (int8 paths): the same value as (int)fq_code(x, q) in
+// fewer instructions — these kernels are instruction-bound, not HBM-bound (tools/pw_trace.py --ablate).
+// roundf(Q) == trunc(Q + copysign(pred(0.5), Q)) for every fp32 |Q| < 2^23 (checked exhaustively for |Q| <= 70000:
+// the only fp32 for which Q + 0.5 itself would round across an integer is pred(0.5), and pred(0.5) + pred(0.5) is exact).
 __device__ __forceinline__ int fq_code_int(float x, const QParams& q) {
   const float c = fminf(fmaxf(x, q.lo), q.hi);
-  const double t = (double)ieee_div_by(c, q.rden);
-  return (int)(t + __builtin_copysign(0.5, t));
+  const float Q = ieee_div_by(c, q.rden);
+  return (int)(Q + __builtin_copysignf(0.49999997f, Q));
+}
+
+// Four codes -> one dword of int8.  `ubias` = 128 - zoff makes every code non-negative (unsigned codes are stored
+// re-centred by zoff = 128, signed ones as they are), so the bytes can be merged without masks; the final XOR turns
+// u = code + 128 back into the two's complement byte of code - zoff... i.e. (u ^ 0x80) == (u - 128) mod 256.
+__device__ __forceinline__ int pack4_codes(int k0, int k1, int k2, int k3, int ubias) {
+  unsigned u = (unsigned)(k0 + ubias);
+  u |= (unsigned)(k1 + ubias) << 8;
+  u |= (unsigned)(k2 + ubias) << 16;
+  u |= (unsigned)(k3 + ubias) << 24;
+  return (int)(u ^ 0x80808080u);
 }
 
 template <bool USE_ABS>
@@ -1892,13 +1903,9 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     v4i f;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      unsigned packed = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int code = fq_code_int(v[4 * d + e], q) - g.zoff;
-        packed |= ((unsigned)code & 0xFFu) << (8 * e);
-      }
-      f[d] = gvalid ? (int)packed : 0;
+      const int packed = pack4_codes(fq_code_int(v[4 * d + 0], q), fq_code_int(v[4 * d + 1], q),
+                                     fq_code_int(v[4 * d + 2], q), fq_code_int(v[4 * d + 3], q), 128 - g.zoff);
+      f[d] = gvalid ? packed : 0;
     }
     // pin the quantisation HERE: it is pure arithmetic whose results are only needed by the MFMAs, and the optimiser
     // otherwise sinks it below every prefetch, keeping all 16 * KT loaded values live (256 VGPRs + spills)
@@ -1929,7 +1936,6 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
         f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
         if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
-        const bool ok = px.valid && c0 < g.Cout;                        // Cout % 4 == 0 on this path
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = (float)acc[4 * gq + r] * sxw[r];
@@ -1939,10 +1945,10 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
             v = v + bsh[r];
           }
           v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
-          if (ok) {
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff) = v;
-            m = fmaxf(m, fabsf(v));
-          }
+          // no masks: lanes past the end hold a copy of the last pixel (clamped loads) and re-store its values, and the
+          // host guarantees Cout % 32 == 0
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff) = v;
+          m = fmaxf(m, fabsf(v));
         }
       }
     }
@@ -2033,7 +2039,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwcGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
-    float* __restrict__ stat_out) {
+    float* __restrict__ stat_out, float* __restrict__ sink) {
   constexpr int kSlots = 8;
   constexpr int kMaxPieces = PIECES;                                    // 16-byte pieces per thread: CTC * KT / 4
   extern __shared__ __attribute__((aligned(16))) unsigned char pwc_smem[];
@@ -2060,6 +2066,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
     s_base = (j0 < cols ? j0 : cols - 1) / HW;
   }
 
+  PW_STAMP(0);
   const float max_ = in_stat != nullptr ? batch_mean_dev(in_stat, n) : in_thr[0];
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   if (in_stat != nullptr && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
@@ -2079,15 +2086,16 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
       row0 = row0 + 32 <= g.rows ? row0 : g.rows - 32;                  // tiles past the padded buffer: discarded channels
       stage[i] = *reinterpret_cast<const v4i*>(wc + ((int64_t)row0 * g.K + kt * 32) + w_lane_off);
     }
+    // per-channel constants: RAW loads only here (any arithmetic on them would make the compiler wait for them - and,
+    // the counter being in-order, for everything issued before - right at the top of the iteration)
     if ((int)threadIdx.x < nchc) {
       const int ch = c * nchc + threadIdx.x;
-      const bool ok = ch < g.Cout;
-      const int cc = ok ? ch : 0;
-      cst[0] = sx * wscale[cc];
+      const int cc = ch < g.Cout ? ch : 0;
+      cst[0] = wscale[cc];
       cst[1] = has_bn ? bn_scale[cc] : 1.0f;
       cst[2] = has_bn ? bn_shift[cc] : 0.0f;
       cst[3] = bias != nullptr ? bias[cc] : 0.0f;
-      cst[4] = __int_as_float(ok ? g.zoff * wsum[cc] : 0);
+      cst[4] = __int_as_float(wsum[cc]);
     }
   };
   auto chunk_commit = [&](int b) __attribute__((always_inline)) {
@@ -2096,8 +2104,11 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
     for (int i = 0; i < kMaxPieces; ++i) A[((wave + 4 * i) << 6) + lane] = stage[i];
     if ((int)threadIdx.x < nchc) {
       float* C = bufC(b);
-#pragma unroll
-      for (int k = 0; k < 5; ++k) C[k * nchc + threadIdx.x] = cst[k];
+      C[0 * nchc + threadIdx.x] = sx * cst[0];
+      C[1 * nchc + threadIdx.x] = cst[1];
+      C[2 * nchc + threadIdx.x] = cst[2];
+      C[3 * nchc + threadIdx.x] = cst[3];
+      C[4 * nchc + threadIdx.x] = __int_as_float(g.zoff * __float_as_int(cst[4]));
     }
   };
 
@@ -2124,13 +2135,9 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
     v4i f;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      unsigned packed = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int code = fq_code_int(v[4 * d + e], q) - g.zoff;
-        packed |= ((unsigned)code & 0xFFu) << (8 * e);
-      }
-      f[d] = gvalid ? (int)packed : 0;
+      const int packed = pack4_codes(fq_code_int(v[4 * d + 0], q), fq_code_int(v[4 * d + 1], q),
+                                     fq_code_int(v[4 * d + 2], q), fq_code_int(v[4 * d + 3], q), 128 - g.zoff);
+      f[d] = gvalid ? packed : 0;
     }
     // pin the quantisation HERE: it is pure arithmetic whose results are only needed by the MFMAs, and the optimiser
     // otherwise sinks it below every prefetch, keeping all 16 * KT loaded values live (256 VGPRs + spills)
@@ -2138,56 +2145,62 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
     bfrag[kt] = f;
   };
 
+  PW_STAMP(1);
   chunk_issue(0);
   chunk_commit(0);
   __syncthreads();
+  PW_STAMP(2);
 
   auto run = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
-    float bufa[16], bufb[16];
+    float bufa[16], bufb[16], bufc[16];
     for (int64_t b = b_begin; b < b_end; ++b) {
       const Pix px = pix_of(b * tiles_per_wg + my_tile);
-      // phase Q: the tile's K/32 slabs -> B fragments (two load buffers)
+      // phase Q: the tile's K/32 slabs -> B fragments.  Three load buffers, two slabs (32 dwords per lane) in flight:
+      // with one workgroup per CU a single slab in flight left every quantisation waiting a full HBM latency
       issue(px, 0, bufa);
+      issue(px, 1 < KT ? 1 : 0, bufb);
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
-        float (&mine)[16] = (kt & 1) ? bufb : bufa;
-        float (&other)[16] = (kt & 1) ? bufa : bufb;
-        issue(px, kt + 1 < KT ? kt + 1 : kt, other);
-        FQ_PIN();
-        quant(kt, mine);
+        const int nk = kt + 2 < KT ? kt + 2 : KT - 1;
+        if (kt % 3 == 0) { issue(px, nk, bufc); FQ_PIN(); quant(kt, bufa); }
+        else if (kt % 3 == 1) { issue(px, nk, bufa); FQ_PIN(); quant(kt, bufb); }
+        else { issue(px, nk, bufb); FQ_PIN(); quant(kt, bufc); }
         FQ_PIN();
       }
       const unsigned yoff = (unsigned)((((int64_t)px.smp * g.Cout + 4 * h) * plane + px.p) * 4);
       float m = 0.0f;
+      if (b == b_begin) PW_STAMP(3);
       for (int c = 0; c < g.NC; ++c) {
         const int cur = c & 1;                                          // NC is even or 1 (host): buffers line up across batches
         chunk_issue(c + 1 < g.NC ? c + 1 : 0);
         FQ_PIN();
         const v4i* A = bufA(g.NC == 1 ? 0 : cur);
         const float* C = bufC(g.NC == 1 ? 0 : cur);
-#pragma unroll 1
-        for (int ctl = sub; ctl < g.CTC; ctl += g.wsplit) {
-          const int cb = ctl * 32 + 4 * h;                              // channel index inside the chunk
-          v16i acc;
+        // two channel tiles at a time on independent accumulators: one accumulator chained 16 dependent MFMAs, each
+        // waiting out the previous one's full latency
+        auto load_zs = [&](int ctl, v16i& acc) __attribute__((always_inline)) {
+          const int cb = ctl * 32 + 4 * h;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             const v4i z = *reinterpret_cast<const v4i*>(C + 4 * nchc + cb + 8 * gq);
             acc[4 * gq + 0] = z.x; acc[4 * gq + 1] = z.y; acc[4 * gq + 2] = z.z; acc[4 * gq + 3] = z.w;
           }
-#pragma unroll
-          for (int kt = 0; kt < KT; ++kt)
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[((ctl * KT + kt) << 6) + lane], bfrag[kt], acc, 0, 0, 0);
+        };
+        // No masks in the epilogue: lanes past the end of the tensor hold a copy of the LAST pixel (clamped loads), so
+        // they recompute and re-store that pixel's values (benign duplicates); the host guarantees Cout % 32 == 0 and
+        // CT % CTC == 0.  Masked stores cost 2 selects + 64-bit address arithmetic per output - more than the MFMAs.
+        auto finish = [&](int ctl, const v16i& acc) __attribute__((always_inline)) {
+          const int cb = ctl * 32 + 4 * h;                              // channel index inside the chunk
+          char* ybase = reinterpret_cast<char*>(y) + (int64_t)(c * nchc + ctl * 32) * plane * 4;   // wave-uniform
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             const int c0 = cb + 8 * gq;
-            const int ch0 = c * nchc + c0;                              // global channel of register 4gq
             const f4 sxw = *reinterpret_cast<const f4*>(C + c0);
             const f4 bsc = *reinterpret_cast<const f4*>(C + nchc + c0);
             const f4 bsh = *reinterpret_cast<const f4*>(C + 2 * nchc + c0);
             f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
             if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(C + 3 * nchc + c0);
-            const bool ok = px.valid && ch0 < g.Cout;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float v = (float)acc[4 * gq + r] * sxw[r];
@@ -2197,12 +2210,48 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
                 v = v + bsh[r];
               }
               v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
-              if (ok) {
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(y) +
-                                          (int64_t)(c * nchc + ctl * 32 + 8 * gq + r) * plane * 4 + yoff) = v;
-                m = fmaxf(m, fabsf(v));
-              }
+              *reinterpret_cast<float*>(ybase + (int64_t)(8 * gq + r) * plane * 4 + yoff) = v;
+              m = fmaxf(m, fabsf(v));
             }
+          }
+        };
+        // A fragments are read two K steps ahead of their MFMAs (LDS latency ~ two 32-cycle MFMAs)
+#pragma unroll 1
+        for (int ctl = sub; ctl < g.CTC; ctl += 2 * g.wsplit) {
+          const int ctl2 = ctl + g.wsplit;
+          if (ctl2 < g.CTC) {
+            v16i acc0, acc1;
+            load_zs(ctl, acc0);
+            load_zs(ctl2, acc1);
+            const v4i* A0 = A + ((ctl * KT) << 6) + lane;
+            const v4i* A1 = A + ((ctl2 * KT) << 6) + lane;
+            v4i fa[3], fb[3];
+            fa[0] = A0[0]; fb[0] = A1[0];
+            fa[1] = A0[(KT > 1 ? 1 : 0) << 6]; fb[1] = A1[(KT > 1 ? 1 : 0) << 6];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+              const int kn = kt + 2 < KT ? kt + 2 : KT - 1;
+              fa[(kt + 2) % 3] = A0[kn << 6];
+              fb[(kt + 2) % 3] = A1[kn << 6];
+              acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kt % 3], bfrag[kt], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[kt % 3], bfrag[kt], acc1, 0, 0, 0);
+            }
+            finish(ctl, acc0);
+            finish(ctl2, acc1);
+          } else {
+            v16i acc0;
+            load_zs(ctl, acc0);
+            const v4i* A0 = A + ((ctl * KT) << 6) + lane;
+            v4i fa[3];
+            fa[0] = A0[0];
+            fa[1] = A0[(KT > 1 ? 1 : 0) << 6];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+              const int kn = kt + 2 < KT ? kt + 2 : KT - 1;
+              fa[(kt + 2) % 3] = A0[kn << 6];
+              acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kt % 3], bfrag[kt], acc0, 0, 0, 0);
+            }
+            finish(ctl, acc0);
           }
         }
         FQ_PIN();
@@ -2211,6 +2260,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
           __syncthreads();
         }
       }
+      if (b == b_begin) PW_STAMP(4);
       if (has_stat) {
         const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)px.smp);
         const bool uniform = __all(!px.valid || px.smp == s0);
@@ -2239,6 +2289,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_chunk_kernel(
   else
     run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});
 
+  PW_STAMP(5);
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < cols / HW)
@@ -3246,7 +3297,7 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
     const int ct = (int)((cout + 31) / 32);
     const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 5 * sizeof(float);
     const bool kt_ok = kt == 1 || kt == 2 || kt == 3 || kt == 4 || kt == 6 || kt == 8;
-    const bool shape_ok = cin % 16 == 0 && cout % 4 == 0 && kt_ok && lds <= 72 * 1024;
+    const bool shape_ok = cin % 16 == 0 && cout % 32 == 0 && kt_ok && lds <= 72 * 1024;
     if ((pw_form == 0 || pw_form == 3) && shape_ok) {
       PwsGeom s;
       s.Cin = (int)cin; s.K = (int)cin_pad; s.Cout = (int)cout; s.CT = ct; s.HW = (int)hw;
@@ -3282,7 +3333,7 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
     FQ_REQUIRE(pw_form != 3, "fq_pwconv_i8: FQ_PW_FORM=3 but the shape does not fit the streaming kernel");
     // chunked streaming form: weights through LDS in double-buffered chunks, K = 256 or 512
     static const int pwc_ctc = env_int("FQ_PWC_CTC", 0), pwc_wsplit = env_int("FQ_PWC_WSPLIT", 0);
-    if ((pw_form == 0 || pw_form == 4) && cin % 16 == 0 && cout % 4 == 0 && (kt == 8 || kt == 16)) {
+    if ((pw_form == 0 || pw_form == 4) && cin % 16 == 0 && cout % 32 == 0 && (kt == 8 || kt == 16)) {
       PwcGeom c;
       c.Cin = (int)cin; c.K = (int)cin_pad; c.Cout = (int)cout; c.CT = ct; c.HW = (int)hw;
       c.cols = n * hw; c.tiles = (c.cols + 31) / 32; c.zoff = zoff;
@@ -3294,7 +3345,7 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
       if (pwc_ctc > 0) c.CTC = pwc_ctc;
       c.NC = (ct + c.CTC - 1) / c.CTC;
       const int pieces = c.CTC * kt / 4;
-      const bool ok = (c.NC == 1 || c.NC % 2 == 0) && c.wsplit <= c.CTC && (pieces == 8 || pieces == 16) &&
+      const bool ok = (c.NC == 1 || c.NC % 2 == 0) && ct % c.CTC == 0 && c.wsplit <= c.CTC && (pieces == 8 || pieces == 16) &&
                       (c.wsplit == 1 || c.wsplit == 2 || c.wsplit == 4);
       if (ok) {
         c.batches = (c.tiles + (4 / c.wsplit) - 1) / (4 / c.wsplit);
@@ -3311,7 +3362,7 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the chunked kernel");                     \
     hipLaunchKernelGGL((pwconv_chunk_kernel<KT_, P_>), dim3((unsigned)grid), dim3(kBlock), lds2, st, x, wcodes, wscale, \
                        (const int*)wsum, bias, y, c, in_stat, (int)n, in_thr, levels, lo_neg, kEps, out_current_max,   \
-                       bn_scale, bn_shift, act, stat_out);                                                             \
+                       bn_scale, bn_shift, act, stat_out, (float*)ws);                                                 \
   }
         FQ_PWC_CASE(8, 8) FQ_PWC_CASE(8, 16) FQ_PWC_CASE(16, 8) FQ_PWC_CASE(16, 16)
 #undef FQ_PWC_CASE

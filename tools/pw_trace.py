@@ -77,10 +77,15 @@ def main():
         print("%d->%d %dx%d: %d workgroups on %d distinct CUs; kernel span %.1f us" % (cin, cout, hw, hw, len(t),
               len(set(cuid.tolist())), st[:, 5].max()))
         names = ["start", "setup done", "phase1 issued", "phase1 barrier", "gemm(block0) done", "end"]
+        if "--chunk" in sys.argv:
+            names = ["start", "batch mean done", "chunk0 in LDS", "Q phase done (batch 0)", "chunks done (batch 0)", "end"]
         for i, nm in enumerate(names):
             print("   %-18s min %7.2f  median %7.2f  max %7.2f us" % (nm, st[:, i].min(), np.median(st[:, i]), st[:, i].max()))
         d = np.diff(st, axis=1)
-        for i, nm in enumerate(["setup", "phase1 (load+quant+LDS)", "barrier wait", "gemm block0", "epilogue(+other blocks)"]):
+        dn = ["setup", "phase1 (load+quant+LDS)", "barrier wait", "gemm block0", "epilogue(+other blocks)"]
+        if "--chunk" in sys.argv:
+            dn = ["batch mean", "chunk 0 -> LDS", "Q phase", "chunk loop", "other batches + stat"]
+        for i, nm in enumerate(dn):
             print("   d %-24s median %7.2f  p90 %7.2f us" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
         late = (st[:, 0] > 1.0).sum()
         print("   workgroups starting later than 1 us after the first: %d" % late)
