@@ -121,6 +121,19 @@ int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t in
 int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                    const float* shift, int act, float* stat_out, fqStream_t stream);
 
+/* The first ("stem") convolution of the ImageNet nets, which the reference leaves un-quantised (simulate_quantization.py
+ * excludes the first convolution; it runs as F.Convolution, mxnet gluon/nn/conv_layers.py, followed by separate
+ * BatchNorm / Activation blocks and then the next layer's statistic pass): dense 3x3, stride 2, pad 1, fp32, with
+ * BatchNorm / activation folded into the store and the per-sample statistic of the result.
+ *   acc = sum over ci, ky, kx (in that order) of fmaf(w[co][ci][ky][kx], x[..], acc), zero padding, + bias[co] if given;
+ *   y   = act(acc * bn_scale[co] + bn_shift[co]) if bn_scale given else act(acc);   stat_out[n] (may be NULL) <- max|y[n]|
+ * x: (n, cin, h, w);  y: (n, cout, ho, wo) with ho = (h - 1) / 2 + 1.  The weights are passed TAP-MAJOR,
+ * w_tap_major[ci][ky][kx][co] (the caller permutes the (cout, cin, 3, 3) parameter once): the cout weights of a tap are
+ * then one contiguous, wave-uniform block.  Built for cin = 3, cout = 32 (MobileNet v1 / v2); other shapes: FQ_INVALID. */
+int fq_stem_conv3x3s2(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
+                      int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
+                      float* stat_out, fqStream_t stream);
+
 /* Depthwise 3x3 convolution (pad 1, dilation 1, stride 1|2, one filter per channel) with the fake-quant of its INPUT
  * folded into the load and BatchNorm/activation/statistic folded into the store — per depthwise layer x is read once
  * and y written once (the reference: fake-quant 4 passes, F.Convolution, BatchNorm, ReLU, next layer's statistic).

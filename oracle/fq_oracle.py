@@ -335,6 +335,36 @@ def bn_act(x, scale, shift, act="relu"):
     return y.astype(F32)
 
 
+def stem_conv3x3s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None):
+    """Arithmetic of `fq_stem_conv3x3s2` (the un-quantised first convolution; reference: mxnet F.Convolution called by
+    gluon/nn/conv_layers.py, then the separate BatchNorm / Activation blocks): dense 3x3, stride 2, pad 1,
+    acc = fmaf(w[co][ci][ky][kx], x, acc) over ci, ky, kx in that order (fmaf emulated as in `dwconv3x3`), + bias, folded
+    BN (separately rounded mul, add), activation."""
+    x = np.asarray(x, dtype=F32)
+    w = np.asarray(w, dtype=F32)
+    N, C, H, W = x.shape
+    Co = w.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xp = np.zeros((N, C, H + 2, W + 2), F32)
+    xp[:, :, 1:-1, 1:-1] = x
+    acc = np.zeros((N, Co, Ho, Wo), F32)
+    for ci in range(C):
+        for ky in range(3):
+            for kx in range(3):
+                tap = xp[:, ci, ky:ky + (Ho - 1) * 2 + 1:2, kx:kx + (Wo - 1) * 2 + 1:2]
+                acc = (w[None, :, ci, ky, kx, None, None].astype(np.float64) * tap[:, None].astype(np.float64)
+                       + acc.astype(np.float64)).astype(F32)
+    if bias is not None:
+        acc = (acc + np.asarray(bias, dtype=F32).reshape(1, Co, 1, 1)).astype(F32)
+    if bn_scale is not None:
+        return bn_act(acc, bn_scale, bn_shift, act or "none")
+    if act == "relu":
+        acc = np.maximum(acc, F32(0))
+    elif act == "relu6":
+        acc = np.minimum(np.maximum(acc, F32(0)), F32(6))
+    return acc.astype(F32)
+
+
 def dwconv3x3(x, w, bias=None, stride=1, in_max=None, signed=False, width=8, lo_neg_max=None, bn_scale=None,
               bn_shift=None, act=None):
     """Arithmetic of `fq_dwconv3x3`: optional fake-quant of x with threshold `in_max` (exactly `ste_forward`), then

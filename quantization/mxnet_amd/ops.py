@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["fake_quant_online_prestat", "bn_act_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -275,6 +275,34 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     check_call(_lib_().fq_bn_act_stat(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,
                                       _ptr(stat), _stream(x)))
     return y, stat
+
+
+def stem_conv3x3s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None):
+    """The un-quantised first convolution (3x3, stride 2, pad 1, 3 -> 32 channels) with fused BatchNorm / activation /
+    per-sample statistic.  w: (32, 3, 3, 3) as the Conv2D parameter holds it; pass `w_tap_major` (= w.permute(1,2,3,0)
+    contiguous) to skip the permutation.  Returns (y, stat (N,) or None)."""
+    _check(x, "x")
+    _check(w, "w")
+    if x.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[1] != x.shape[1]:
+        raise ValueError("stem_conv3x3s2 wants x (N,C,H,W) and w (Cout,C,3,3); got %s and %s" % (tuple(x.shape), tuple(w.shape)))
+    for name, t in (("bias", bias), ("bn_scale", bn_scale), ("bn_shift", bn_shift), ("w_tap_major", w_tap_major)):
+        if t is not None:
+            _check(t, name)
+    act = act or "none"
+    if act not in _ACTS:
+        raise ValueError("unknown activation %r" % (act,))
+    n, cin, h, wd = x.shape
+    cout = w.shape[0]
+    wt = w_tap_major if w_tap_major is not None else w.permute(1, 2, 3, 0).contiguous()
+    y = torch.empty((n, cout, (h - 1) // 2 + 1, (wd - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    stat, zflag = _stat_target(n, x.device, want_stat)
+    check_call(_lib_().fq_stem_conv3x3s2(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), n, cin, cout, h, wd, _ptr(bn_scale),
+                                         _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _stream(x)))
+    return y, stat
+
+
+def stem_conv_supported(cin, cout, kernel, stride, pad):
+    return cin == 3 and cout == 32 and tuple(kernel) == (3, 3) and tuple(stride) == (2, 2) and tuple(pad) == (1, 1)
 
 
 def dwconv3x3(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None, bn_scale=None,

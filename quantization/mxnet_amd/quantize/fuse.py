@@ -84,6 +84,35 @@ def _is_pw1x1(b):
             and not b.quantize_args.fake_bn)
 
 
+def _is_stem3x3s2(b):
+    """The un-quantised first convolution of the ImageNet MobileNets: Conv2D(3 -> 32, 3x3, stride 2, pad 1)."""
+    if type(b) is not nn.Conv2D or hasattr(b, "quantize_args"):
+        return False
+    if b.hybrid_forward.__func__ is not nn.Conv2D.hybrid_forward:
+        return False
+    k = b._kwargs
+    shp = b.weight.shape
+    return (len(shp) == 4 and k["num_group"] == 1 and k["dilate"] == (1, 1) and k["layout"] == "NCHW" and b.act is None
+            and ops.stem_conv_supported(shp[1], shp[0], k["kernel"], k["stride"], k["pad"]))
+
+
+def _stem_forward(self, F, x, weight, bias=None):
+    st = self._fq_stem_fused
+    w = weight._t
+    key = (w.data_ptr(), w._version)
+    if st["wkey"] != key:                      # tap-major copy of the weights, refreshed when the parameter changes
+        st["wt"], st["wkey"] = w.permute(1, 2, 3, 0).contiguous(), key
+    scale = shift = None
+    if st["constants"] is not None:
+        scale, shift = st["constants"]()
+    t = x._t if x._t.is_contiguous() else x._t.contiguous()
+    y, stat = ops.stem_conv3x3s2(t, w, None if bias is None else bias._t, bn_scale=scale, bn_shift=shift,
+                                 act=st["act"], want_stat=True, w_tap_major=st["wt"])
+    out = NDArray(y)
+    out._fq_stat = stat
+    return out
+
+
 def _plain_dw_forward(self, F, x, weight, bias=None):
     from .convert.convert_conv2d import _dw_fused_conv
     return _dw_fused_conv(self, x, weight, bias, {})
@@ -102,7 +131,7 @@ def _bn_constants_getter(bn):
     return get
 
 
-def fuse_inference(net, depthwise=True, pointwise_int8=True):
+def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True):
     """Returns the number of blocks fused (BatchNorms folded + depthwise / pointwise convolutions taken over)."""
     fused = [0]
 
@@ -131,6 +160,30 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True):
                               "orig": None if converted else b.hybrid_forward}
             if not converted:
                 b.hybrid_forward = types.MethodType(_plain_dw_forward, b)
+            if bn is not None:
+                bn._fq_fused = {"taken_by_conv": True, "orig": bn.hybrid_forward, "act_block": None}
+                bn.hybrid_forward = types.MethodType(_identity_forward, bn)
+            if act:
+                bypass(nxt)
+            fused[0] += 1
+
+    def visit_stem(container):
+        if not isinstance(container, (nn.Sequential, nn.HybridSequential)):
+            return
+        kids = list(container._children.values())
+        for i, b in enumerate(kids):
+            if not _is_stem3x3s2(b) or hasattr(b, "_fq_stem_fused"):
+                continue
+            bn = kids[i + 1] if i + 1 < len(kids) else None
+            if not (type(bn) is nn.BatchNorm and not hasattr(bn, "_fq_fused") and bn._kwargs.get("axis", 1) == 1
+                    and bn.hybrid_forward.__func__ is nn.BatchNorm.hybrid_forward):
+                bn = None
+            nxt = kids[i + 2] if bn is not None and i + 2 < len(kids) else (kids[i + 1] if bn is None and i + 1 < len(kids) else None)
+            act = _act_kind(nxt) if nxt is not None else None
+            b._fq_stem_fused = {"bn": bn, "act": act or "none", "act_block": nxt if act else None, "wt": None, "wkey": None,
+                                "constants": _bn_constants_getter(bn) if bn is not None else None,
+                                "orig": b.hybrid_forward}
+            b.hybrid_forward = types.MethodType(_stem_forward, b)
             if bn is not None:
                 bn._fq_fused = {"taken_by_conv": True, "orig": bn.hybrid_forward, "act_block": None}
                 bn.hybrid_forward = types.MethodType(_identity_forward, bn)
@@ -179,6 +232,8 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True):
                 bypass(nxt)
             fused[0] += 1
 
+    if stem:
+        net.apply(visit_stem)
     if depthwise:
         net.apply(visit_dw)
     if pointwise_int8:
@@ -230,6 +285,11 @@ def unfuse(net):
             del blk._fq_bypassed_orig
 
     def visit(b):
+        if hasattr(b, "_fq_stem_fused"):
+            st = b._fq_stem_fused
+            b.hybrid_forward = st["orig"]
+            restore_act(st["act_block"])
+            del b._fq_stem_fused
         if hasattr(b, "_fq_dw_fused"):
             st = b._fq_dw_fused
             if st["orig"] is not None:

@@ -507,3 +507,45 @@ def test_division_by_double_reciprocal_is_ieee_exact(dev, ops):
                                              want_stat=False, want_codes=True)
         _eq(N(codes), want_codes.astype(np.int32), "codes (trial %d, thr %g, width %d)" % (trial, thr, width))
         _eq(N(y), want_y, "y")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 32, 32), (3, 3, 33, 47), (1, 3, 224, 224), (5, 3, 18, 130)])
+@pytest.mark.parametrize("mode", ["plain", "bn_relu", "bias_relu6"])
+def test_stem_conv3x3s2_vs_oracle(dev, ops, shape, mode):
+    """fq_stem_conv3x3s2 (the un-quantised first convolution + BatchNorm + activation + statistic) against the oracle's
+    fmaf-ordered restatement and, loosely, against torch's convolution in fp64."""
+    rng = np.random.default_rng(sum(shape) + len(mode))
+    x = rng.standard_normal(shape).astype(np.float32)
+    wt = (rng.standard_normal((32, 3, 3, 3)) * 0.3).astype(np.float32)
+    kw, okw = {}, {}
+    if mode == "bn_relu":
+        sc = rng.uniform(0.3, 1.5, 32).astype(np.float32)
+        sh = rng.standard_normal(32).astype(np.float32)
+        kw.update(bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu")
+        okw.update(bn_scale=sc, bn_shift=sh, act="relu")
+    if mode == "bias_relu6":
+        b = rng.standard_normal(32).astype(np.float32)
+        kw.update(bias=T(b, dev), act="relu6")
+        okw.update(bias=b, act="relu6")
+    y, stat = ops.stem_conv3x3s2(T(x, dev), T(wt, dev), **kw)
+    want = O.stem_conv3x3s2(x, wt, **okw)
+    got = N(y)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    assert (got != want).mean() < 1e-3                         # fmaf emulation differs only at double-rounding ties
+    _eq(N(stat), O.absmax_per_sample(got), "statistic of the produced output")
+    import torch.nn.functional as TF
+    ref = TF.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, stride=2, padding=1).numpy()
+    if mode == "bn_relu":
+        ref = np.maximum(ref * okw["bn_scale"].reshape(1, -1, 1, 1) + okw["bn_shift"].reshape(1, -1, 1, 1), 0)
+    if mode == "bias_relu6":
+        ref = np.clip(ref + okw["bias"].reshape(1, -1, 1, 1), 0, 6)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_stem_conv_rejects_other_shapes(dev, ops):
+    from quantization.mxnet_amd._lib import FakeQuantError
+    x = torch.zeros(1, 4, 8, 8, device=dev)
+    w = torch.zeros(32, 4, 3, 3, device=dev)
+    with pytest.raises(FakeQuantError):
+        ops.stem_conv3x3s2(x, w)

@@ -87,6 +87,10 @@ def main():
             dn = ["batch mean", "chunk 0 -> LDS", "Q phase", "chunk loop", "other batches + stat"]
         for i, nm in enumerate(dn):
             print("   d %-24s median %7.2f  p90 %7.2f us" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
+        if "--chunk" in sys.argv:
+            t67 = (t[:, 6:8].astype(np.float64) - t0) / 100.0
+            print("   chunk 0 of batch 0: mfma+epilogue %.2f us, commit+barrier %.2f us (medians)"
+                  % (np.median(t67[:, 0] - st[:, 3]), np.median(t67[:, 1] - t67[:, 0])))
         late = (st[:, 0] > 1.0).sum()
         print("   workgroups starting later than 1 us after the first: %d" % late)
 
