@@ -213,9 +213,11 @@ def main():
                  "stat": "absmax_per_sample_kernel (statistic pass, 4 B/elem)",
                  "dwconv": "dwconv3x3_*_kernel (depthwise 3x3 with fake-quant on load + BN/ReLU/statistic on store, "
                            "4 B/in-elem + 4 B/out-elem)",
-                 "bn_act": "bn_act_stat_kernel (BN + ReLU + statistic, 8 B/elem)",
-                 "pwconv": "quant_transpose_i8_kernel + pwconv_i8_kernel (1x1 conv on int8 codes: fake-quant on load, "
-                           "exact int32 MFMA sums, BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
+                 "bn_act": "stem_conv3x3s2_kernel / bn_act_stat_kernel (un-quantised first conv + BN + ReLU + statistic, "
+                           "4 B/in-elem + 4 B/out-elem; lone BN + ReLU + statistic passes, 8 B/elem)",
+                 "pwconv": "pwconv_stream_kernel / pwconv_chunk_kernel (+ quant_transpose_i8 + pwconv_i8 for K=1024): 1x1 "
+                           "conv on int8 codes, fake-quant on load, exact int32 MFMA sums, BN/ReLU/statistic on store; "
+                           "4 B/in-elem + 4 B/out-elem",
                  "weight": "weight fake-quant kernels (8 B/elem)", "histogram": "histogram_kernel (4 B/elem)"}
         kernels = {}
         for key, rec in prof.items():

@@ -23,9 +23,9 @@ def family(n):
         return 'histogram'
     if 'dwconv3x3' in n:
         return 'dwconv'
-    if 'bn_act_stat_kernel' in n:
+    if 'bn_act_stat_kernel' in n or 'stem_conv3x3s2_kernel' in n:
         return 'bn_act'
-    if 'pwconv_i8_kernel' in n or 'quant_transpose_i8_kernel' in n:
+    if 'pwconv_' in n or 'quant_transpose_i8_kernel' in n:
         return 'pwconv'
     if 'weight_codes_kernel' in n or 'weight_rows_lds_kernel' in n or 'weight_apply_kernel' in n:
         return 'weight'
