@@ -226,9 +226,14 @@ __device__ __forceinline__ QParams make_qparams(float max_, float levels, bool l
 __device__ __forceinline__ float ieee_div_by(float c, double rden) { return (float)((double)c * rden); }
 
 // The integer stage and the dequantised value (ste_func.py:41): clip -> IEEE divide -> roundf -> multiply.
+// roundf(Q) (half away from zero) == trunc(Q + copysign(pred(0.5), Q)) for every fp32 |Q| < 2^23: the only fp32 whose
+// sum with 0.5 would round across an integer is pred(0.5), and pred(0.5) + pred(0.5) is exact (checked exhaustively for
+// |Q| <= 70000; codes are <= 65535).  3 instructions instead of roundf's 6; NaN and Inf pass through as with roundf.
+__device__ __forceinline__ float round_half_away(float Q) { return truncf(Q + __builtin_copysignf(0.49999997f, Q)); }
+
 __device__ __forceinline__ float fq_code(float x, const QParams& q) {
   float c = fminf(fmaxf(x, q.lo), q.hi);
-  return roundf(ieee_div_by(c, q.rden));
+  return round_half_away(ieee_div_by(c, q.rden));
 }
 
 // The integer code itself, for the kernels that keep codes (int8 paths): the same value as (int)fq_code(x, q) in
@@ -567,6 +572,18 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
 // compute phase consecutive lanes own consecutive output COLUMNS (conflict-free LDS reads, coalesced stores) and slide
 // down a segment of rows keeping the 3x3 window in registers: 3 new LDS values per output (6 for stride 2).
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef FQ_PW_TRACE
+// debug build only (tools/pw_trace.py): per-workgroup wall-clock stamps of the fused pointwise kernel's phases
+__device__ unsigned long long* g_pw_trace = nullptr;
+__device__ int g_pw_dbg = 0;          // experiments: 1 = skip the output stores, 2 = skip the activation loads
+#define PW_STAMP(i)                                                                       \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && g_pw_trace != nullptr) g_pw_trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define PW_STAMP(i) do { } while (0)
+#endif
+
 struct DwGeom {
   int C, H, W, Ho, Wo;
   int P;        // planes per tile (whole-plane mode) or 1
@@ -764,9 +781,13 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
     float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
     const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
-  constexpr int D = (S == 1) ? 8 : 4;                   // output rows of input kept in flight (S=2: 4 loads per row)
-  __shared__ float red_m[4];
-  __shared__ int red_s[4];
+  // output rows of input kept in flight (S=2: 4 loads per row).  (16 / 8 - every row of a 14x14 plane in flight at
+  // once - measured SLOWER on the same box: 38 vs 36 us per 512x14x14 layer.)
+  constexpr int D = (S == 1) ? 8 : 4;
+  constexpr int kStatSlots = 16;
+  __shared__ unsigned k_stat[kStatSlots];
+  if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
+  PW_STAMP(0);
   QParams q;
   q.lo = q.hi = q.denom = q.scale = 0.0f;
   q.rden = 0.0;
@@ -775,6 +796,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
     q = make_qparams(max_, levels, lo_neg_max != 0, eps);
     if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
   }
+  PW_STAMP(1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg_in_wave = lane / g.SEG;
   const int pos = lane - seg_in_wave * g.SEG;
@@ -785,13 +807,27 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
   const int plane_in = g.H * g.W, plane_out = g.Ho * g.Wo;
 
   // (Row strips per plane were tried for load balance and measured slower: every strip restarts the prefetch ring.)
-  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int64_t seg = blk * segs_per_block + (int64_t)wave * g.segs + seg_in_wave;
-    const bool seg_ok = lane_used && seg < total_segs;
-    const int64_t plane = seg_ok ? seg / g.nsegx : 0;
-    const int sx = seg_ok ? (int)(seg - plane * g.nsegx) : 0;
-    const int ch = (int)(plane % g.C);
-    const int sample = (int)(plane / g.C);
+  // A workgroup takes a CONTIGUOUS range of blocks (few samples -> a small LDS statistic table, one flush) and its
+  // wavefronts run through them without barriers.  Index arithmetic is unsigned 32-bit (host: total_segs < 2^31): the
+  // 64-bit divisions it replaces cost each block 2.3 us (tools/dw_trace.py).
+  const unsigned nblk_u = (unsigned)nblk, tsegs = (unsigned)total_segs, nsegx = (unsigned)g.nsegx, C_u = (unsigned)g.C;
+  const unsigned blk_begin = (unsigned)((uint64_t)nblk_u * blockIdx.x / gridDim.x);
+  const unsigned blk_end = (unsigned)((uint64_t)nblk_u * (blockIdx.x + 1) / gridDim.x);
+  const unsigned n_samples = tsegs / nsegx / C_u;
+  unsigned s_base;
+  {
+    const unsigned seg0 = blk_begin * (unsigned)segs_per_block;
+    s_base = (seg0 < tsegs ? seg0 : tsegs - 1) / nsegx / C_u;
+  }
+  __syncthreads();                                       // statistic table zeroed
+  for (unsigned blk = blk_begin; blk < blk_end; ++blk) {
+    const unsigned seg = blk * (unsigned)segs_per_block + (unsigned)wave * (unsigned)g.segs + (unsigned)seg_in_wave;
+    const bool seg_ok = lane_used && seg < tsegs;
+    const unsigned plane = seg_ok ? seg / nsegx : 0u;
+    const int sx = seg_ok ? (int)(seg - plane * nsegx) : 0;
+    const unsigned sample_u = plane / C_u;
+    const int ch = (int)(plane - sample_u * C_u);
+    const int sample = (int)sample_u;
     // column bookkeeping
     int oc, ic0;                                          // output column; first input column this lane loads
     bool is_out;
@@ -814,6 +850,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
     const float bch = bias != nullptr ? bias[ch] : 0.0f;
     const float bsc = has_bn ? bn_scale[ch] : 1.0f, bsh = has_bn ? bn_shift[ch] : 0.0f;
     float m = 0.0f;
+    if (blk == blk_begin) PW_STAMP(2);
 
     // Loads are UNCONDITIONAL from clamped (always valid) addresses and masked afterwards with a bitwise AND — a
     // `cond ? load : 0` select is turned back into a predicated load by hipcc (CodeGenPrepare sinks the load under a
@@ -939,28 +976,31 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
       for (int k = 0; k < D; ++k)
         if (r0 + k < rend) emit2(r0 + k, rb0[k], rb1[k], rc0[k], rc1[k], a0, a1, a2);
     }
+    if (blk == blk_begin) PW_STAMP(3);
     if (has_stat) {
-      // one atomic per workgroup when all its lanes belong to one sample (the common case), else per wave / lane
-      const int s0 = __shfl(sample, 0, 64);
-      const bool wave_uniform = __all(!is_out || sample == s0);
-      const float wm = wave_max(is_out ? m : 0.0f);
-      __syncthreads();
-      if (lane == 0) {
-        red_m[wave] = wm;
-        red_s[wave] = wave_uniform ? s0 : -1;
-      }
-      __syncthreads();
-      const bool blk_uniform = red_s[0] >= 0 && red_s[0] == red_s[1] && red_s[1] == red_s[2] && red_s[2] == red_s[3];
-      if (blk_uniform) {
-        if (threadIdx.x == 0)
-          atomic_max_f32(stat_out + red_s[0], fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3])));
-      } else if (wave_uniform) {
-        if (lane == 0) atomic_max_f32(stat_out + s0, wm);
+      // per-wave update of the workgroup's LDS table (no barrier inside the block loop); flushed once at the end
+      const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane(sample);
+      const bool wave_uniform = __all(!is_out || (unsigned)sample == s0);
+      if (wave_uniform) {
+        const float wm = wave_max(is_out ? m : 0.0f);
+        if (lane == 0 && __float_as_uint(wm) != 0u) {
+          const unsigned slot = s0 - s_base;
+          if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+          else atomic_max_f32(stat_out + s0, wm);
+        }
       } else if (is_out) {
-        atomic_max_f32(stat_out + sample, m);
+        const unsigned slot = (unsigned)sample - s_base;
+        if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+        else atomic_max_f32(stat_out + sample, m);
       }
     }
   }
+  if (has_stat) {
+    __syncthreads();
+    if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < (unsigned)n_samples)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+  }
+  PW_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -980,8 +1020,9 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
   // and hit the same DRAM pages; one load per step (a ring) spreads them ~700 cycles apart, and with thousands of
   // waves each streaming its own plane every access then opens a new page.
   constexpr int D = (S == 1) ? 4 : 2;
-  __shared__ float red_m[4];
-  __shared__ int red_s[4];
+  constexpr int kStatSlots = 16;
+  __shared__ unsigned k_stat[kStatSlots];
+  if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
   QParams q;
   q.lo = q.hi = q.denom = q.scale = 0.0f;
   q.rden = 0.0;
@@ -1010,13 +1051,27 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
   };
   auto keep = [](float v, bool ok) -> float { return __uint_as_float(__float_as_uint(v) & (ok ? 0xFFFFFFFFu : 0u)); };
 
-  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int64_t seg = blk * segs_per_block + (int64_t)wave * g.segs + seg_in_wave;
-    const bool seg_ok = lane_used && seg < total_segs;
-    const int64_t plane = seg_ok ? seg / g.nsegx : 0;
-    const int sx = seg_ok ? (int)(seg - plane * g.nsegx) : 0;
-    const int ch = (int)(plane % g.C);
-    const int sample = (int)(plane / g.C);
+  // A workgroup takes a CONTIGUOUS range of blocks (few samples -> a small LDS statistic table, one flush) and its
+  // wavefronts run through them without barriers.  Index arithmetic is unsigned 32-bit (host: total_segs < 2^31): the
+  // 64-bit divisions it replaces cost each block 2.3 us (tools/dw_trace.py).
+  const unsigned nblk_u = (unsigned)nblk, tsegs = (unsigned)total_segs, nsegx = (unsigned)g.nsegx, C_u = (unsigned)g.C;
+  const unsigned blk_begin = (unsigned)((uint64_t)nblk_u * blockIdx.x / gridDim.x);
+  const unsigned blk_end = (unsigned)((uint64_t)nblk_u * (blockIdx.x + 1) / gridDim.x);
+  const unsigned n_samples = tsegs / nsegx / C_u;
+  unsigned s_base;
+  {
+    const unsigned seg0 = blk_begin * (unsigned)segs_per_block;
+    s_base = (seg0 < tsegs ? seg0 : tsegs - 1) / nsegx / C_u;
+  }
+  __syncthreads();                                       // statistic table zeroed
+  for (unsigned blk = blk_begin; blk < blk_end; ++blk) {
+    const unsigned seg = blk * (unsigned)segs_per_block + (unsigned)wave * (unsigned)g.segs + (unsigned)seg_in_wave;
+    const bool seg_ok = lane_used && seg < tsegs;
+    const unsigned plane = seg_ok ? seg / nsegx : 0u;
+    const int sx = seg_ok ? (int)(seg - plane * nsegx) : 0;
+    const unsigned sample_u = plane / C_u;
+    const int ch = (int)(plane - sample_u * C_u);
+    const int sample = (int)sample_u;
     const int ic0 = (sx * g.sw + pos - 1) * 4;            // first of the 4 input columns this lane loads
     const bool ld_ok = seg_ok && ic0 >= 0 && ic0 < g.W;
     const int oc = S == 1 ? ic0 : ic0 / 2;                // first output column (4 outputs for S=1, 2 for S=2)
@@ -1153,25 +1208,27 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
         if (r0 + k < g.Ho) emit2(r0 + k, rb[k], rc[k]);
     }
     if (has_stat) {
-      const int s0 = __shfl(sample, 0, 64);
-      const bool wave_uniform = __all(!is_out || sample == s0);
-      const float wm = wave_max(is_out ? m : 0.0f);
-      __syncthreads();
-      if (lane == 0) {
-        red_m[wave] = wm;
-        red_s[wave] = wave_uniform ? s0 : -1;
-      }
-      __syncthreads();
-      const bool blk_uniform = red_s[0] >= 0 && red_s[0] == red_s[1] && red_s[1] == red_s[2] && red_s[2] == red_s[3];
-      if (blk_uniform) {
-        if (threadIdx.x == 0)
-          atomic_max_f32(stat_out + red_s[0], fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3])));
-      } else if (wave_uniform) {
-        if (lane == 0) atomic_max_f32(stat_out + s0, wm);
+      // per-wave update of the workgroup's LDS table (no barrier inside the block loop); flushed once at the end
+      const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane(sample);
+      const bool wave_uniform = __all(!is_out || (unsigned)sample == s0);
+      if (wave_uniform) {
+        const float wm = wave_max(is_out ? m : 0.0f);
+        if (lane == 0 && __float_as_uint(wm) != 0u) {
+          const unsigned slot = s0 - s_base;
+          if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+          else atomic_max_f32(stat_out + s0, wm);
+        }
       } else if (is_out) {
-        atomic_max_f32(stat_out + sample, m);
+        const unsigned slot = (unsigned)sample - s_base;
+        if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+        else atomic_max_f32(stat_out + sample, m);
       }
     }
+  }
+  if (has_stat) {
+    __syncthreads();
+    if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < (unsigned)n_samples)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
   }
 }
 
@@ -1538,18 +1595,6 @@ __global__ __launch_bounds__(kBlock) void stem_conv3x3s2_kernel(
 // weight fragments straight from global memory (L2 resident), both ping-pong buffered over an explicitly 2x unrolled K
 // loop; the epilogue is K2f-B's.  Panel rows are XOR-swizzled in 16-byte chunks so that the 4-byte transposing writes
 // and the 16-byte fragment reads are both (nearly) bank-conflict free without padding.
-#ifdef FQ_PW_TRACE
-// debug build only (tools/pw_trace.py): per-workgroup wall-clock stamps of the fused pointwise kernel's phases
-__device__ unsigned long long* g_pw_trace = nullptr;
-__device__ int g_pw_dbg = 0;          // experiments: 1 = skip the output stores, 2 = skip the activation loads
-#define PW_STAMP(i)                                                                       \
-  do {                                                                                    \
-    if (threadIdx.x == 0 && g_pw_trace != nullptr) g_pw_trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
-  } while (0)
-#else
-#define PW_STAMP(i) do { } while (0)
-#endif
-
 struct PwfGeom {
   int Cin, K, Cout, HW;
   int64_t cols;        // n * HW
@@ -3196,7 +3241,10 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     const int64_t total_segs = n * c * cg.nsegx;
     const int64_t segs_per_block = (int64_t)cg.segs * (kBlock / 64);
     const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
-    const int grid = (int)(nblk < (int64_t)num_cu() * 64 ? nblk : (int64_t)num_cu() * 64);
+    FQ_REQUIRE(total_segs < (1ll << 31) - 1024, "fq_dwconv3x3: tensor too large for 32-bit segment indices");
+    // every workgroup resident at once (8 per CU), each walking a contiguous range of blocks
+    static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 8);
+    const int grid = (int)(nblk < (int64_t)num_cu() * dw_wg_per_cu ? nblk : (int64_t)num_cu() * dw_wg_per_cu);
     const float levels = act_levels(in_width, in_flags);
     const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
@@ -3235,7 +3283,10 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     const int64_t total_segs = n * c * cg.nsegx;
     const int64_t segs_per_block = (int64_t)cg.segs * (kBlock / 64);
     const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
-    const int grid = (int)(nblk < (int64_t)num_cu() * 64 ? nblk : (int64_t)num_cu() * 64);
+    FQ_REQUIRE(total_segs < (1ll << 31) - 1024, "fq_dwconv3x3: tensor too large for 32-bit segment indices");
+    // every workgroup resident at once (8 per CU), each walking a contiguous range of blocks
+    static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 8);
+    const int grid = (int)(nblk < (int64_t)num_cu() * dw_wg_per_cu ? nblk : (int64_t)num_cu() * dw_wg_per_cu);
     const float levels = act_levels(in_width, in_flags);
     const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
