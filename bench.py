@@ -132,16 +132,11 @@ def main():
     torch.manual_seed(7 + rank)
     X = mx.nd.NDArray(torch.randn(args.batch_size, 3, hw, hw, device=dev))
     y = torch.randint(0, classes, (args.batch_size,), device=dev)
-    counters = torch.zeros(2 * classes + 1, dtype=torch.float32, device=dev)   # correct[c], label[c], n_correct
-    ones = torch.ones(args.batch_size, dtype=torch.float32, device=dev)
+    counters = torch.zeros(2 + 2 * classes, dtype=torch.float32, device=dev)   # n_correct, total, correct[c], label[c]
 
     def step():
         out = net(X)._t
-        pred = out.argmax(dim=1)
-        hit = (pred == y)
-        counters[2 * classes] += hit.sum()
-        counters[classes:2 * classes].scatter_add_(0, y, ones)              # label_counter[gt] += 1
-        counters[:classes].scatter_add_(0, y, hit.float())                 # correct_counter[gt] += (p == gt)
+        ops.eval_counters(out, y, counters)           # the eval loop's argmax + counters (fq_eval_counters, one launch)
         return out
 
     def barrier():

@@ -23,7 +23,7 @@ from tqdm import tqdm
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch  # noqa: E402
-from quantization.mxnet_amd import mx, dist as fqdist  # noqa: E402
+from quantization.mxnet_amd import mx, ops, dist as fqdist  # noqa: E402
 from quantization.mxnet_amd.mx import cpu, gpu, nd  # noqa: E402
 from quantization.mxnet_amd.mx.gluon import nn  # noqa: E402
 from quantization.mxnet_amd.mx.gluon.data import Sampler, DataLoader, vision  # noqa: E402
@@ -135,12 +135,7 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
             outputs = net(X)
             if update_ema:
                 net.update_ema()
-            pred = outputs._t.argmax(dim=1)
-            hit = (pred == y).float()
-            counters[0] += hit.sum()
-            counters[1] += float(y.numel())
-            counters[2:2 + num_class].scatter_add_(0, y, hit)
-            counters[2 + num_class:].scatter_add_(0, y, torch.ones_like(hit))
+            ops.eval_counters(outputs._t, y, counters)       # argmax + per-class counters, one launch (fq_eval_counters)
             n_images += int(y.numel())
             pbar.update(1)
     torch.cuda.synchronize(dev) if dev.type == "cuda" else None

@@ -121,6 +121,15 @@ int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t in
 int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                    const float* shift, int act, float* stat_out, fqStream_t stream);
 
+/* The evaluation counters of the reference CLI (examples/simulate_quantization.py:122-148: pred = argmax(outputs, axis=1),
+ * test_num_correct += (pred == y), label_counter[gt] += 1, correct_counter[gt] += (pred == gt)) accumulated on the device
+ * in one launch.  logits: (n, classes) fp32;  labels: (n) int64 (labels outside [0, classes) only count in `total`);
+ * counters (2 + 2*classes floats, accumulated into, the caller zeroes them once per evaluation):
+ *   [0] n_correct, [1] total, [2 .. 2+classes) correct_counter, [2+classes .. 2+2*classes) label_counter.
+ * argmax takes the FIRST index among equal maxima and treats NaN as the maximum.  Exact while every count < 2^24.     */
+int fq_eval_counters(const float* logits, const int64_t* labels, int64_t n, int64_t classes, float* counters,
+                     fqStream_t stream);
+
 /* The first ("stem") convolution of the ImageNet nets, which the reference leaves un-quantised (simulate_quantization.py
  * excludes the first convolution; it runs as F.Convolution, mxnet gluon/nn/conv_layers.py, followed by separate
  * BatchNorm / Activation blocks and then the next layer's statistic pass): dense 3x3, stride 2, pad 1, fp32, with

@@ -335,6 +335,24 @@ def bn_act(x, scale, shift, act="relu"):
     return y.astype(F32)
 
 
+def eval_counters(logits, labels, counters=None):
+    """The evaluation loop's bookkeeping (reference examples/simulate_quantization.py:122-148): pred = argmax(axis=1)
+    (first index on ties), n_correct, total, correct_counter[gt], label_counter[gt] -> [n_correct, total, correct[c], label[c]]."""
+    logits = np.asarray(logits, dtype=F32)
+    labels = np.asarray(labels).astype(np.int64)
+    n, classes = logits.shape
+    out = np.zeros(2 + 2 * classes, dtype=F32) if counters is None else np.asarray(counters, dtype=F32).copy()
+    pred = np.argmax(logits, axis=1)
+    for p_, gt in zip(pred, labels):
+        out[1] += 1
+        if 0 <= gt < classes:
+            out[2 + classes + gt] += 1
+            if p_ == gt:
+                out[0] += 1
+                out[2 + gt] += 1
+    return out
+
+
 def stem_conv3x3s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None):
     """Arithmetic of `fq_stem_conv3x3s2` (the un-quantised first convolution; reference: mxnet F.Convolution called by
     gluon/nn/conv_layers.py, then the separate BatchNorm / Activation blocks): dense 3x3, stride 2, pad 1,

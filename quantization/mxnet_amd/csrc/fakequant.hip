@@ -1483,6 +1483,53 @@ __global__ __launch_bounds__(kBlock) void pwconv_i8_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K9: the evaluation counters of simulate_quantization.py:122-148 (pred = argmax(outputs, axis=1), first index on
+// ties as MXNet's argmax; test_num_correct, label_counter[gt], correct_counter[gt]) in ONE launch: a wavefront per
+// sample.  The tensor-library formulation is nine launch-bound kernels (~60 us per batch, 4 % of an evaluation step).
+// counters = [n_correct, total, correct[classes], label[classes]] as floats: the increments are 1.0, exact below 2^24.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void eval_counters_kernel(const float* __restrict__ logits,
+                                                               const long long* __restrict__ labels, int64_t n,
+                                                               int classes, float* __restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  const int64_t smp = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (smp >= n) return;
+  const float* row = logits + smp * classes;
+  float best = 0.0f;
+  int bidx = 0x7FFFFFFF;
+  bool bnan = false;
+  // better(a, b): NaN beats everything (as torch / numpy argmax), then the larger value, then the smaller index
+  auto take = [&](float v, int i) {
+    const bool vnan = v != v;
+    const bool better = bidx == 0x7FFFFFFF || (vnan && !bnan) || (!bnan && !vnan && v > best) ||
+                        (((vnan && bnan) || (!vnan && !bnan && v == best)) && i < bidx);
+    if (better) {
+      best = v;
+      bidx = i;
+      bnan = vnan;
+    }
+  };
+  for (int i = lane; i < classes; i += 64) take(row[i], i);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(bidx, off, 64);
+    if (oi != 0x7FFFFFFF) take(ov, oi);
+  }
+  if (lane == 0) {
+    const long long gt = labels[smp];
+    atomicAdd(counters + 1, 1.0f);
+    if (gt >= 0 && gt < classes) {
+      atomicAdd(counters + 2 + classes + gt, 1.0f);
+      if ((long long)bidx == gt) {
+        atomicAdd(counters, 1.0f);
+        atomicAdd(counters + 2 + gt, 1.0f);
+      }
+    }
+  }
+}
+
 // Ordering fence for hand-pipelined loops: the asm memory clobber stops IR-level motion of loads, the sched_barrier the
 // machine scheduler's (it sinks prefetches next to their use, or hoists every load of an unrolled loop to the top).
 #define FQ_PIN()                         \
@@ -3392,6 +3439,17 @@ int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_
   const float levels = (float)((1 << (width - 1)) - 1);
   hipLaunchKernelGGL(weight_codes_kernel, dim3((unsigned)rows_pad), dim3(kBlock), 0, st, w, (int)rows, (int)row_len,
                      rows_per_scale, levels, (int)row_pad, gmax, codes, scales, (int*)rowsum);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_eval_counters(const float* logits, const int64_t* labels, int64_t n, int64_t classes, float* counters,
+                     fqStream_t stream) {
+  FQ_REQUIRE(logits && labels && counters, "fq_eval_counters: null pointer");
+  FQ_REQUIRE(n > 0 && classes > 0 && classes < (1ll << 30) && n < (1ll << 31), "fq_eval_counters: bad shape");
+  const int64_t grid = (n + (kBlock / 64) - 1) / (kBlock / 64);
+  hipLaunchKernelGGL(eval_counters_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, logits,
+                     (const long long*)labels, n, (int)classes, counters);
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -275,6 +275,23 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     check_call(_lib_().fq_bn_act_stat(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,
                                       _ptr(stat), _stream(x)))
     return y, stat
+
+
+def eval_counters(logits, labels, counters):
+    """counters ([n_correct, total, correct[c], label[c]], float32, 2 + 2*classes) += the batch's evaluation counts
+    (reference CLI :122-148).  logits (N, classes) fp32, labels (N,) int64.  Returns `counters`."""
+    _check(logits, "logits")
+    _check(counters, "counters")
+    require_hip(labels.device, "labels")
+    if logits.dim() != 2 or labels.dim() != 1 or labels.shape[0] != logits.shape[0] or labels.dtype != torch.int64:
+        raise ValueError("eval_counters wants logits (N, classes) float32 and labels (N,) int64")
+    n, classes = logits.shape
+    if counters.numel() != 2 + 2 * classes or not counters.is_contiguous():
+        raise ValueError("counters must hold 2 + 2*classes contiguous floats")
+    lg = logits if logits.is_contiguous() else logits.contiguous()
+    lb = labels if labels.is_contiguous() else labels.contiguous()
+    check_call(_lib_().fq_eval_counters(_ptr(lg), lb.data_ptr(), n, classes, _ptr(counters), _stream(logits)))
+    return counters
 
 
 def stem_conv3x3s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None):

@@ -549,3 +549,30 @@ def test_stem_conv_rejects_other_shapes(dev, ops):
     w = torch.zeros(32, 4, 3, 3, device=dev)
     with pytest.raises(FakeQuantError):
         ops.stem_conv3x3s2(x, w)
+
+
+@pytest.mark.parametrize("n,classes", [(128, 1000), (7, 10), (300, 37), (1, 1)])
+def test_eval_counters_vs_oracle(dev, ops, n, classes):
+    """fq_eval_counters (the CLI's argmax / per-class counters in one launch) against the oracle, with ties, NaN-free
+    logits, out-of-range labels and accumulation over two batches."""
+    rng = np.random.default_rng(n * 31 + classes)
+    counters = torch.zeros(2 + 2 * classes, device=dev)
+    want = None
+    for batch in range(2):
+        logits = rng.standard_normal((n, classes)).astype(np.float32)
+        labels = rng.integers(0, classes, n).astype(np.int64)
+        if classes > 3:
+            logits[0, 1] = logits[0, 3] = np.float32(9.0)            # tie: the first index wins
+            labels[0] = 1
+            if n > 2:
+                logits[1, 2] = logits[1, 0] = np.float32(9.0)
+                labels[1] = 2                                         # tie lost: prediction is index 0
+                labels[2] = classes + 5                               # outside: only `total` moves
+        # make roughly half the predictions correct
+        for i in range(0, n, 2):
+            if 0 <= labels[i] < classes and i > 2:
+                logits[i, labels[i]] = np.float32(20.0)
+        ops.eval_counters(T(logits, dev), torch.from_numpy(labels).to(dev), counters)
+        want = O.eval_counters(logits, labels, want)
+    _eq(N(counters), want, "evaluation counters")
+    assert N(counters)[1] == 2 * n
