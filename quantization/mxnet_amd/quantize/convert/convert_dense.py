@@ -41,11 +41,17 @@ def _dense_forward(self, F, x, weight, bias=None, input_max=None):
                 self.current_input_max = DeviceScalar(cur)
 
         # Simulate quantization for weight (:52-63)
+        # The reference recomputes this on every forward; the result only depends on the weight, so it is kept until the
+        # parameter's storage or in-place version counter changes (an optimiser step / set_data bumps it): identical
+        # values, three launches less per forward.
         wt = weight._t if weight._t.is_contiguous() else weight._t.contiguous()
-        if qa.quant_type == 'channel':
-            weight_q = NDArray(ops.weight_fake_quant(wt, self._units, qa.wt_width))
-        else:
-            weight_q = NDArray(ops.weight_fake_quant(wt, 1, qa.wt_width))
+        key = (weight._t.data_ptr(), weight._t._version, qa.quant_type, qa.wt_width, str(wt.device))
+        cache = self.__dict__.get("_fq_wq_cache")
+        if cache is None or cache[0] != key:
+            groups = self._units if qa.quant_type == 'channel' else 1
+            cache = (key, ops.weight_fake_quant(wt, groups, qa.wt_width))
+            self.__dict__["_fq_wq_cache"] = cache
+        weight_q = NDArray(cache[1])
     else:
         weight_q = weight
 

@@ -317,3 +317,45 @@ def test_fake_bn_flow_on_gpu_matches_reference_goldens(gpu, golden):
     for name, v in out["params"].items():
         if name.endswith(("weight", "bias")) and "conv0" not in name and "dense" not in name:
             np.testing.assert_allclose(v, g["fakebn/frozen/" + name], rtol=1e-5, atol=1e-6, err_msg=name)
+
+
+def test_dense_weight_cache_follows_the_parameter(gpu):
+    """convert_dense keeps the fake-quantised weight between forwards (the reference recomputes it, :52-63) — it must be
+    refreshed as soon as the parameter changes in place or is replaced."""
+    from quantization.mxnet_amd import mx, ops
+    from quantization.mxnet_amd.mx.gluon import nn
+    from quantization.mxnet_amd.quantize import convert
+    net = nn.HybridSequential()
+    net.add(nn.Dense(8, in_units=16))
+    net.initialize(ctx=gpu)
+    convert.convert_model(net, convert_fn={nn.Dense: convert.gen_dense_converter(quantize_input=False)})
+    dense = net[0]
+    rng = np.random.default_rng(5)
+    X = mx.nd.array(rng.standard_normal((4, 16)).astype(np.float32), ctx=gpu)
+
+    def expect():
+        w = dense.weight.data()._t
+        wq = ops.weight_fake_quant(w.contiguous(), 1, 8)
+        return (X._t @ wq.t() + dense.bias.data()._t).cpu().numpy()
+    calls = []
+    real = ops.weight_fake_quant
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    ops.weight_fake_quant = spy
+    try:
+        y0 = net(X).asnumpy()
+        y0b = net(X).asnumpy()
+        assert len(calls) == 1                                       # second forward: cached
+        dense.weight.data()._t.mul_(1.7)                             # in-place update (optimiser step)
+        y1 = net(X).asnumpy()
+        assert len(calls) == 2
+        dense.weight.set_data(mx.nd.array(rng.standard_normal((8, 16)).astype(np.float32), ctx=gpu))
+        y2 = net(X).asnumpy()
+        assert len(calls) == 3
+    finally:
+        ops.weight_fake_quant = real
+    np.testing.assert_array_equal(y0, y0b)
+    np.testing.assert_allclose(y2, expect(), rtol=1e-5, atol=1e-5)
+    assert not np.allclose(y0, y1)
