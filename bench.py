@@ -112,12 +112,20 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the fake-quant path has no CPU fallback)")
+    # test-only knobs for exercising the N > 1 path on a one-GPU box: every rank on device 0, gloo instead of RCCL
+    share_gpu = os.environ.get("FQ_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("FQ_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from quantization.mxnet_amd import mx, ops
     # MXNet autotunes convolutions by default (the reference only offers --disable-cudnn-autotune,
