@@ -1,0 +1,157 @@
+"""CPU restatement of ONE quantisation-aware-training step of the reference (TEST INFRASTRUCTURE ONLY — nothing under
+quantization/ may import this).
+
+Reference: examples/quantize_aware_training_cifar10.ipynb cell 15 (`with autograd.record(): outputs = net(X); loss =
+loss_func(outputs, y)`; `net.update_ema()`; `loss.backward()`; `trainer.step(batch, ignore_stale_grad=True)`), the patched
+forwards quantize/convert/convert_conv2d.py:44-110 / convert_dense.py:37-70, the straight-through estimator
+quantize/convert/ste_func.py:30-44 (backward = identity, the scale is not an input), `_update_ema` convert.py:66-78,
+gluon BatchNorm in train mode (batch statistics, biased variance, moving = moving*momentum + batch*(1-momentum)),
+gluon.loss.SoftmaxCrossEntropyLoss and MXNet's Adam (optimizer.py: lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+w -= lr_t*m/(sqrt(v)+eps); gradients rescaled by 1/batch_size).
+
+It is deliberately independent of the facade: a functional torch-CPU graph (torch is only the differentiator of the
+float convolution / dense / BN / loss), every fake-quant is the numpy oracle (`fq_oracle`) behind an identity-backward
+node.  Parity pinned by: the quantisers' own golden vectors (tests/test_oracle_golden.py); the step as a whole has no
+reference-generated fixture (MXNet cannot run here) — "parity unpinned" for the composition, stated in DESIGN.md.
+
+The net is described by a list of layer dicts (see tests/test_qat.py):
+  {"op": "conv", "w": name, "stride": s, "pad": p, "groups": g, "quant": True/False}
+  {"op": "bn", "gamma": .., "beta": .., "mean": .., "var": .., "momentum": 0.9, "eps": 1e-5}
+  {"op": "relu"} {"op": "gap"} {"op": "flatten"} {"op": "dense", "w": .., "b": .., "quant": True}
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+from . import fq_oracle as O
+
+F32 = np.float32
+
+
+class _STE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fn):
+        return torch.from_numpy(np.ascontiguousarray(fn(x.detach().numpy()), dtype=F32))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def _quant_input(x, state, name, signed, width, offline, dense=False):
+    """convert_conv2d.py:55-66 / convert_dense.py:40-49; records current_input_max for update_ema."""
+    a = x.detach().numpy()
+    cur = O.batch_mean(O.absmax_per_sample(a))
+    state["current_input_max"][name] = F32(cur)
+    thr = state["input_max"][name] if offline else cur
+    if dense:
+        fn = lambda v: O.dense_input_fake_quant(v, signed, width, offline_threshold=thr)[0]
+    else:
+        fn = lambda v: O.conv_input_fake_quant(v, signed, width, offline_threshold=thr)[0]
+    return _STE.apply(x, fn)
+
+
+def _quant_weight(w, quant_type, width, num_group=1):
+    def fn(v):
+        out = O.weight_fake_quant(v, quant_type, width, num_group)
+        return out[0] if isinstance(out, tuple) else out
+    return _STE.apply(w, fn)
+
+
+def forward(layers, params, X, state, train=True, signed=False, in_width=8, wt_width=8, quant_type="layer",
+            offline=False):
+    """params: name -> torch tensor (leaves with requires_grad for the trainable ones).  Returns logits."""
+    x = X
+    qi = 0
+    for L in layers:
+        op = L["op"]
+        if op == "conv":
+            w = params[L["w"]]
+            if L.get("quant", True):
+                name = "q%d" % qi
+                qi += 1
+                x = _quant_input(x, state, name, signed, in_width, offline)
+                w = _quant_weight(w, quant_type, wt_width, L.get("groups", 1))
+            b = params[L["b"]] if L.get("b") else None
+            x = TF.conv2d(x, w, b, stride=L.get("stride", 1), padding=L.get("pad", 0), groups=L.get("groups", 1))
+        elif op == "dense":
+            w = params[L["w"]]
+            if L.get("quant", True):
+                name = "q%d" % qi
+                qi += 1
+                x = _quant_input(x, state, name, signed, in_width, offline, dense=True)
+                w = _quant_weight(w, "channel" if quant_type in ("channel", "group") else "layer", wt_width)
+            x = TF.linear(x, w, params[L["b"]] if L.get("b") else None)
+        elif op == "bn":
+            g, b = params[L["gamma"]], params[L["beta"]]
+            eps, mom = L.get("eps", 1e-5), L.get("momentum", 0.9)
+            if train:
+                mean = x.mean(dim=(0, 2, 3))
+                var = ((x - mean.reshape(1, -1, 1, 1)) ** 2).mean(dim=(0, 2, 3))
+                with torch.no_grad():
+                    params[L["mean"]].mul_(mom).add_(mean.detach() * (1.0 - mom))
+                    params[L["var"]].mul_(mom).add_(var.detach() * (1.0 - mom))
+            else:
+                mean, var = params[L["mean"]], params[L["var"]]
+            x = (x - mean.reshape(1, -1, 1, 1)) / torch.sqrt(var.reshape(1, -1, 1, 1) + eps) * g.reshape(1, -1, 1, 1) \
+                + b.reshape(1, -1, 1, 1)
+        elif op == "relu":
+            x = torch.relu(x)
+        elif op == "gap":
+            x = x.mean(dim=(2, 3), keepdim=True)
+        elif op == "flatten":
+            x = x.reshape(x.shape[0], -1)
+        else:
+            raise ValueError(op)
+    return x
+
+
+def softmax_ce(logits, y):
+    """gluon.loss.SoftmaxCrossEntropyLoss: one value per sample."""
+    return -torch.gather(TF.log_softmax(logits, dim=-1), 1, y.long().reshape(-1, 1)).reshape(-1)
+
+
+def update_ema(state, momentum=0.9):
+    """convert.py:66-71: input_max = (1 - m) * current_input_max + m * input_max (fp32, as `oracle.ema_update`)."""
+    for k, cur in state["current_input_max"].items():
+        state["input_max"][k] = O.ema_update(state["input_max"][k], cur, momentum)
+
+
+class Adam(object):
+    """MXNet Adam with gluon.Trainer's 1/batch_size rescale."""
+
+    def __init__(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.m, self.v, self.t = {}, {}, {}
+
+    def step(self, params, trainable, batch_size):
+        with torch.no_grad():
+            for k in trainable:
+                w = params[k]
+                if w.grad is None:
+                    continue                                   # ignore_stale_grad=True
+                g = w.grad / float(batch_size)
+                if k not in self.m:
+                    self.m[k], self.v[k], self.t[k] = torch.zeros_like(w), torch.zeros_like(w), 0
+                self.t[k] += 1
+                t = self.t[k]
+                self.m[k].mul_(self.b1).add_((1 - self.b1) * g)
+                self.v[k].mul_(self.b2).add_((1 - self.b2) * g * g)
+                lr_t = self.lr * math.sqrt(1 - self.b2 ** t) / (1 - self.b1 ** t)
+                w.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + self.eps))
+                w.grad = None
+
+
+def train_step(layers, params, trainable, X, y, state, opt, **fwd_kw):
+    """One notebook iteration.  Returns (per-sample loss, logits, {name: grad}) and updates params / state in place."""
+    for k in trainable:
+        params[k].requires_grad_(True)
+    logits = forward(layers, params, X, state, train=True, **fwd_kw)
+    loss = softmax_ce(logits, y)
+    update_ema(state)
+    loss.backward(torch.ones_like(loss))
+    grads = {k: (None if params[k].grad is None else params[k].grad.detach().clone()) for k in trainable}
+    opt.step(params, trainable, X.shape[0])
+    return loss.detach().numpy(), logits.detach().numpy(), grads

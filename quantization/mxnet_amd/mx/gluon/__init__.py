@@ -4,3 +4,5 @@ from .block import Block, HybridBlock
 from . import nn
 from . import data
 from . import model_zoo
+from . import loss
+from .trainer import Trainer

@@ -16,6 +16,7 @@ import threading
 from collections import OrderedDict
 
 from .. import ndarray as nd
+from .. import autograd as _autograd
 from ..ndarray import NDArray
 from .parameter import Parameter, ParameterDict, DeferredInitializationError
 
@@ -171,11 +172,13 @@ class Block(object):
         self.collect_params().load(filename, ctx, allow_missing, ignore_extra, restore_prefix=self.prefix)
 
     def __call__(self, *args):
-        for hook in list(self._forward_pre_hooks.values()):
-            hook(self, args)
-        out = self.forward(*args)
-        for hook in list(self._forward_hooks.values()):
-            hook(self, args, out)
+        # torch's grad mode follows mx.autograd's recording flag: outside `autograd.record()` no graph is ever built
+        with _autograd.grad_mode():
+            for hook in list(self._forward_pre_hooks.values()):
+                hook(self, args)
+            out = self.forward(*args)
+            for hook in list(self._forward_hooks.values()):
+                hook(self, args, out)
         return out
 
     def forward(self, *args):
@@ -200,6 +203,9 @@ class HybridBlock(Block):
         except DeferredInitializationError:
             self._infer_param_shapes(x, *args)
             params = {k: p.data() for k, p in self._reg_params.items()}
+        if _autograd.is_recording():
+            for p in self._reg_params.values():
+                p._mark_trainable()
         return self.hybrid_forward(nd, x, *args, **params)
 
     def hybrid_forward(self, F, x, *args, **kwargs):

@@ -109,7 +109,8 @@ class Parameter(object):
             return
         assert tuple(data.shape) == tuple(self._data.shape), \
             "set_data shape mismatch for %s: %s vs %s" % (self.name, data.shape, self._data.shape)
-        self._data._t.copy_(data._t)
+        with torch.no_grad():
+            self._data._t.copy_(data._t)
 
     def reset_ctx(self, ctx):
         if isinstance(ctx, (list, tuple)):
@@ -122,8 +123,28 @@ class Parameter(object):
         else:
             raise ValueError("Cannot reset context for Parameter %s: not initialized" % self.name)
 
+    # ---- gradients (mx.autograd over torch's tape) ---------------------------------------------------------------------
+    def _mark_trainable(self):
+        """Called by Block.__call__ while recording: the leaf gets a .grad on backward."""
+        if self._data is not None and self.grad_req != "null" and not self._data._t.requires_grad:
+            self._data._t.requires_grad_(True)
+
+    def grad(self, ctx=None):
+        self._check()
+        if self.grad_req == "null":
+            raise RuntimeError("Cannot get gradient array for Parameter '%s' because grad_req='null'" % self.name)
+        g = self._data._t.grad
+        if g is None:
+            g = torch.zeros_like(self._data._t)
+            self._data._t.grad = g
+        return NDArray(g)
+
+    def list_grad(self):
+        return [self.grad()]
+
     def zero_grad(self):
-        pass
+        if self._data is not None and self._data._t.grad is not None:
+            self._data._t.grad.zero_()
 
     def cast(self, dtype):
         self.dtype = dtype

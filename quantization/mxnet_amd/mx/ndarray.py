@@ -287,6 +287,19 @@ class NDArray(object):
     def argmax(self, axis=None):
         return argmax(self, axis=axis)
 
+    # ---- autograd (mx.autograd over torch's tape) -------------------------------------------------------------------
+    def attach_grad(self, grad_req="write"):
+        self._t.requires_grad_(grad_req != "null")
+
+    @property
+    def grad(self):
+        g = self._t.grad
+        return None if g is None else NDArray(g)
+
+    def backward(self, out_grad=None, retain_graph=False, train_mode=True):
+        from . import autograd
+        autograd.backward([self], None if out_grad is None else [out_grad], retain_graph=retain_graph)
+
 
 def _unwrap_key(key):
     if isinstance(key, NDArray):
@@ -537,8 +550,24 @@ def Activation(data, act_type="relu", name=None):
 
 
 def BatchNorm(data, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.9, fix_gamma=False,
-              use_global_stats=True, axis=1, name=None, **_ignored):
+              use_global_stats=False, axis=1, name=None, **_ignored):
+    """Inference: running statistics.  Under `autograd.train_mode` (and not use_global_stats): batch statistics,
+    differentiable, and MXNet's update of the moving statistics (src/operator/nn/batch_norm.cc):
+    moving = moving * momentum + batch * (1 - momentum) with the BIASED batch variance."""
+    from . import autograd
     g = torch.ones_like(gamma._t) if fix_gamma else gamma._t
+    if autograd.is_training() and not use_global_stats:
+        x = data._t
+        dims = [d for d in range(x.dim()) if d != axis]
+        shape = [1] * x.dim()
+        shape[axis] = -1
+        mean = x.mean(dim=dims)
+        var = ((x - mean.reshape(shape)) ** 2).mean(dim=dims)
+        y = (x - mean.reshape(shape)) / torch.sqrt(var.reshape(shape) + eps) * g.reshape(shape) + beta._t.reshape(shape)
+        with torch.no_grad():
+            running_mean._t.mul_(momentum).add_(mean.detach() * (1.0 - momentum))
+            running_var._t.mul_(momentum).add_(var.detach() * (1.0 - momentum))
+        return NDArray(y)
     return NDArray(TF.batch_norm(data._t, running_mean._t, running_var._t, g, beta._t, False, 0.0, eps))
 
 

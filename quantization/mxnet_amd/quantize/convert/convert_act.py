@@ -9,6 +9,7 @@ from collections import namedtuple
 import torch
 
 from ...mx.ndarray import NDArray
+from ...mx import autograd
 from ...mx.gluon.nn import Activation
 from ... import ops
 from .._state import DeviceScalar
@@ -44,7 +45,7 @@ def _act_forward(self, F, x, act_max=None):
                 y, _, _ = ops.fake_quant_offline(t, act_max._t, self.quantize_args.width, flags, cur_out=cur)
             else:
                 y, _, _ = ops.fake_quant_online(t, self.quantize_args.width, flags, cur_out=cur)
-            act = NDArray(y)
+            act = NDArray(autograd.ste_link(t, y))                # identity backward; no-op unless recording
         else:
             ops.batch_mean(ops.absmax_per_sample(t, no_abs=True), out=cur)
         self.current_act_max = DeviceScalar(cur)

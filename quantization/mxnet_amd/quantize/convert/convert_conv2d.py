@@ -18,6 +18,7 @@ from collections import namedtuple
 import torch
 
 from ...mx import nd
+from ...mx import autograd
 from ...mx.ndarray import NDArray
 from ...mx.gluon.nn import Conv2D
 from ... import ops
@@ -43,6 +44,7 @@ def _cur_slot(m, like):
 
 def _fake_quant_input(m, x, input_max, flags, width):
     """Activation branch shared by Conv2D and Dense (convert_conv2d.py:55-66, convert_dense.py:40-49)."""
+    x_in = x
     t = x._t if x._t.is_contiguous() else x._t.contiguous()
     cur = _cur_slot(m, t)
     stat_ws = getattr(m, "_fq_stat_ws", None)
@@ -86,6 +88,9 @@ def _fake_quant_input(m, x, input_max, flags, width):
         ops.batch_mean(per_sample, out=cur)
     m._fq_last_n = t.shape[0]
     m.current_input_max = DeviceScalar(cur)
+    if x is not x_in:
+        # under autograd.record(): straight-through link to the un-quantised input (ste_func.py:43-44, identity)
+        x = NDArray(autograd.ste_link(t, x._t))
     return x
 
 
@@ -201,6 +206,9 @@ def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
     qa = self.quantize_args
     fz = getattr(self, "_fq_dw_fused", None)
     fzp = getattr(self, "_fq_pw_fused", None)
+    if (fz is not None or fzp is not None) and autograd.is_recording():
+        raise RuntimeError("this net was rewired by quantize.fuse.fuse_inference (inference only): call "
+                           "quantize.fuse.unfuse(net) before recording gradients")
     weight_raw = weight
     quant_kw = {}
     # Fake bn (:47-51)
@@ -225,6 +233,8 @@ def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
             if qa.quant_type == 'channel':
                 if qa.wino_quantize != 'none' and self._kwargs['kernel'] == (3, 3):
                     wq = ops.wino_weight_fake_quant(wt, qa.wino_quantize, qa.wt_width)
+                    wq = autograd.wino_link(wt, wq, *ops.winograd_matrices(qa.wino_quantize))
+                    wt = None                                          # already linked (with the transform's gradient)
                 else:
                     wq = ops.weight_fake_quant(wt, self._kwargs['num_filter'], qa.wt_width)
             elif qa.quant_type == 'group':
@@ -237,7 +247,8 @@ def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
                 wq = ops.weight_fake_quant(wt, num, qa.wt_width)
             else:
                 wq = ops.weight_fake_quant(wt, 1, qa.wt_width)
-            weight_q = NDArray(wq)
+            # identity backward (ste_func.py:43-44); a no-op unless autograd is recording
+            weight_q = NDArray(wq if wt is None else autograd.ste_link(wt, wq))
         else:
             weight_q = weight
     else:
@@ -292,6 +303,7 @@ def _add_fake_bn_params(m):
 
 
 def _add_fake_bn_ema_hook(m):
+    @torch.no_grad()
     def _ema_hook(m, x):
         x = x[0]
         weight = m.weight.data()

@@ -7,6 +7,7 @@ import types
 from collections import namedtuple
 
 from ...mx.ndarray import NDArray
+from ...mx import autograd
 from ...mx.gluon.nn import Dense
 from ... import ops
 from .._state import DeviceScalar
@@ -37,7 +38,7 @@ def _dense_forward(self, F, x, weight, bias=None, input_max=None):
                 if self.quantize_input:
                     thr = input_max._t if self.quantize_input_offline else cur
                     y, _, _ = ops.fake_quant_offline(t, thr, qa.in_width, flags, want_stat=False)
-                    x = NDArray(y)
+                    x = NDArray(autograd.ste_link(t, y))
                 self.current_input_max = DeviceScalar(cur)
 
         # Simulate quantization for weight (:52-63)
@@ -51,7 +52,7 @@ def _dense_forward(self, F, x, weight, bias=None, input_max=None):
             groups = self._units if qa.quant_type == 'channel' else 1
             cache = (key, ops.weight_fake_quant(wt, groups, qa.wt_width))
             self.__dict__["_fq_wq_cache"] = cache
-        weight_q = NDArray(cache[1])
+        weight_q = NDArray(autograd.ste_link(wt, cache[1]))       # identity backward; no-op unless recording
     else:
         weight_q = weight
 

@@ -25,3 +25,13 @@ def golden():
                 cache[name] = {k: z[k] for k in z.files}
         return cache[name]
     return load
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    """mx.gpu(0) on a real device; GPU-marked tests are skipped without one."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from quantization.mxnet_amd import mx
+    return mx.gpu(0)

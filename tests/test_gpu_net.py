@@ -12,14 +12,6 @@ from oracle import fq_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gpu():
-    if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
-    from quantization.mxnet_amd import mx
-    return mx.gpu(0)
-
-
 def _build(model, classes, ctx, quant_type="layer", wt=8, in_w=8, signed=False, wino="none"):
     from quantization.mxnet_amd.mx.gluon import nn
     from quantization.mxnet_amd.mx.gluon.model_zoo import get_model
