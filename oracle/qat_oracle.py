@@ -40,11 +40,15 @@ class _STE(torch.autograd.Function):
         return g, None
 
 
-def _quant_input(x, state, name, signed, width, offline, dense=False):
-    """convert_conv2d.py:55-66 / convert_dense.py:40-49; records current_input_max for update_ema."""
+def _quant_input(x, state, name, signed, width, offline, dense=False, enabled=True):
+    """convert_conv2d.py:55-66 / convert_dense.py:40-49; records current_input_max for update_ema.  The statistic is
+    taken whenever the converter was built with quantize_input (:55-56); the quantiser itself only runs when
+    `net.quantize_input(enable=True, ...)` (:57)."""
     a = x.detach().numpy()
     cur = O.batch_mean(O.absmax_per_sample(a))
     state["current_input_max"][name] = F32(cur)
+    if not enabled:
+        return x
     thr = state["input_max"][name] if offline else cur
     if dense:
         fn = lambda v: O.dense_input_fake_quant(v, signed, width, offline_threshold=thr)[0]
@@ -61,18 +65,38 @@ def _quant_weight(w, quant_type, width, num_group=1):
 
 
 def forward(layers, params, X, state, train=True, signed=False, in_width=8, wt_width=8, quant_type="layer",
-            offline=False):
+            offline=False, input_quant=True):
     """params: name -> torch tensor (leaves with requires_grad for the trainable ones).  Returns logits."""
     x = X
     qi = 0
     for L in layers:
         op = L["op"]
-        if op == "conv":
+        if op == "fbconv":
+            # fake-BN convolution (convert_conv2d.py:47-51 fold, :144-154 batch-statistic pre-hook)
+            w, b = params[L["w"]], params[L["b"]]
+            g, be, rm, rv = params[L["gamma"]], params[L["beta"]], params[L["mean"]], params[L["var"]]
+            kw = dict(stride=L.get("stride", 1), padding=L.get("pad", 0), groups=L.get("groups", 1))
+            with torch.no_grad():
+                yh = TF.conv2d(x, w, b, **kw)
+                ns = yh.shape[0] * yh.shape[2] * yh.shape[3]
+                cm = yh.sum(dim=(0, 2, 3)) / ns
+                cv = ((yh - cm.reshape(1, -1, 1, 1)) ** 2).sum(dim=(0, 2, 3)) / ns
+                state.setdefault("current_mean", {})[L["mean"]] = cm
+                state.setdefault("current_var", {})[L["var"]] = cv
+            cout = w.shape[0]
+            wf = (w.reshape(cout, -1) * g.reshape(-1, 1) / torch.sqrt(rv + 1e-10).reshape(-1, 1)).reshape(w.shape)
+            bf = g * (b - rm) / torch.sqrt(rv + 1e-10) + be
+            name = "q%d" % qi
+            qi += 1
+            x = _quant_input(x, state, name, signed, in_width, offline, enabled=input_quant)
+            wq = _quant_weight(wf, quant_type, wt_width, L.get("groups", 1))
+            x = TF.conv2d(x, wq, bf, **kw)
+        elif op == "conv":
             w = params[L["w"]]
             if L.get("quant", True):
                 name = "q%d" % qi
                 qi += 1
-                x = _quant_input(x, state, name, signed, in_width, offline)
+                x = _quant_input(x, state, name, signed, in_width, offline, enabled=input_quant)
                 w = _quant_weight(w, quant_type, wt_width, L.get("groups", 1))
             b = params[L["b"]] if L.get("b") else None
             x = TF.conv2d(x, w, b, stride=L.get("stride", 1), padding=L.get("pad", 0), groups=L.get("groups", 1))
@@ -81,7 +105,7 @@ def forward(layers, params, X, state, train=True, signed=False, in_width=8, wt_w
             if L.get("quant", True):
                 name = "q%d" % qi
                 qi += 1
-                x = _quant_input(x, state, name, signed, in_width, offline, dense=True)
+                x = _quant_input(x, state, name, signed, in_width, offline, dense=True, enabled=input_quant)
                 w = _quant_weight(w, "channel" if quant_type in ("channel", "group") else "layer", wt_width)
             x = TF.linear(x, w, params[L["b"]] if L.get("b") else None)
         elif op == "bn":
@@ -113,10 +137,16 @@ def softmax_ce(logits, y):
     return -torch.gather(TF.log_softmax(logits, dim=-1), 1, y.long().reshape(-1, 1)).reshape(-1)
 
 
-def update_ema(state, momentum=0.9):
-    """convert.py:66-71: input_max = (1 - m) * current_input_max + m * input_max (fp32, as `oracle.ema_update`)."""
+def update_ema(state, momentum=0.9, params=None):
+    """convert.py:66-78: input_max = (1 - m) * current_input_max + m * input_max (fp32, as `oracle.ema_update`); for
+    fake-BN convolutions the same for running_mean / running_var from the pre-hook's batch statistics."""
     for k, cur in state["current_input_max"].items():
         state["input_max"][k] = O.ema_update(state["input_max"][k], cur, momentum)
+    if params is not None:
+        with torch.no_grad():
+            for key in ("current_mean", "current_var"):
+                for name, cur in state.get(key, {}).items():
+                    params[name].copy_((1 - momentum) * cur + momentum * params[name])
 
 
 class Adam(object):
@@ -150,7 +180,7 @@ def train_step(layers, params, trainable, X, y, state, opt, **fwd_kw):
         params[k].requires_grad_(True)
     logits = forward(layers, params, X, state, train=True, **fwd_kw)
     loss = softmax_ce(logits, y)
-    update_ema(state)
+    update_ema(state, params=params)
     loss.backward(torch.ones_like(loss))
     grads = {k: (None if params[k].grad is None else params[k].grad.detach().clone()) for k in trainable}
     opt.step(params, trainable, X.shape[0])

@@ -253,3 +253,133 @@ def test_recording_through_a_fused_net_is_refused(gpu):
     with mx.autograd.record():
         out = net(mx.nd.array(Xs[0], ctx=gpu))
     out.backward()
+
+
+# ---- the notebook's own configuration (cells 6-7): per-channel W4A4, fake_bn=True, BatchNorm bypassed, first conv + BN
+# excluded, input quantisation disabled until `offline_at` ------------------------------------------------------------
+NB_LAYERS = [
+    {"op": "conv", "w": "c0_w", "stride": 1, "pad": 1, "groups": 1, "quant": False},
+    {"op": "bn", "gamma": "b0_g", "beta": "b0_b", "mean": "b0_m", "var": "b0_v"},
+    {"op": "relu"},
+    {"op": "fbconv", "w": "c1_w", "b": "c1_b", "gamma": "b1_g", "beta": "b1_b", "mean": "b1_m", "var": "b1_v",
+     "stride": 2, "pad": 1, "groups": 8},
+    {"op": "relu"},
+    {"op": "fbconv", "w": "c2_w", "b": "c2_b", "gamma": "b2_g", "beta": "b2_b", "mean": "b2_m", "var": "b2_v",
+     "stride": 1, "pad": 0, "groups": 1},
+    {"op": "relu"},
+    {"op": "gap"}, {"op": "flatten"},
+    {"op": "dense", "w": "d_w", "b": "d_b", "quant": True},
+]
+NB_TRAINABLE = ["c0_w", "b0_g", "b0_b", "c1_w", "c1_b", "b1_g", "b1_b", "c2_w", "c2_b", "b2_g", "b2_b", "d_w", "d_b"]
+
+
+def _run_notebook_config(ctx, steps, offline_at, lr=1e-3):
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.mx import autograd, gluon
+    from quantization.mxnet_amd.mx.gluon import nn
+    from quantization.mxnet_amd.quantize import convert
+    from quantization.mxnet_amd.quantize.initialize import qparams_init
+    nn_block = nn
+    from quantization.mxnet_amd.mx.gluon.block import reset_naming
+    reset_naming()
+    params = _init_params()
+    params["c1_b"] = np.zeros(8, np.float32)
+    params["c2_b"] = np.zeros(16, np.float32)
+    Xs, ys = _data(steps)
+    # restatement
+    p = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    state = {"input_max": {"q%d" % i: np.float32(0) for i in range(3)}, "current_input_max": {}}
+    opt = QO.Adam(lr)
+    ora = []
+    for s in range(steps):
+        on = offline_at is not None and s >= offline_at
+        loss, logits, grads = QO.train_step(NB_LAYERS, p, NB_TRAINABLE, torch.from_numpy(Xs[s]), torch.from_numpy(ys[s]),
+                                            state, opt, quant_type="channel", in_width=4, wt_width=4, offline=on,
+                                            input_quant=on)
+        ora.append((loss, logits, {k: (None if g is None else g.numpy()) for k, g in grads.items()}))
+    # facade
+    net = nn_block.HybridSequential()
+    net.add(nn.Conv2D(8, 3, 1, 1, use_bias=False, in_channels=3), nn.BatchNorm(in_channels=8), nn.Activation("relu"),
+            nn.Conv2D(8, 3, 2, 1, groups=8, use_bias=False, in_channels=8), nn.BatchNorm(in_channels=8),
+            nn.Activation("relu"),
+            nn.Conv2D(16, 1, 1, 0, use_bias=False, in_channels=8), nn.BatchNorm(in_channels=16), nn.Activation("relu"),
+            nn.GlobalAvgPool2D(), nn.Flatten(), nn.Dense(10, in_units=16))
+    net.initialize(ctx=ctx)
+    kids = list(net._children.values())
+    A = lambda a: mx.nd.array(a, ctx=ctx)
+    for i, ci in enumerate((0, 3, 6)):
+        kids[ci].weight.set_data(A(params["c%d_w" % i]))
+        bn = kids[ci + 1]
+        bn.gamma.set_data(A(params["b%d_g" % i]))
+        bn.beta.set_data(A(params["b%d_b" % i]))
+        bn.running_mean.set_data(A(params["b%d_m" % i]))
+        bn.running_var.set_data(A(params["b%d_v" % i]))
+    kids[11].weight.set_data(A(params["d_w"]))
+    kids[11].bias.set_data(A(params["d_b"]))
+    converter = {nn.Conv2D: convert.gen_conv2d_converter(quant_type="channel", fake_bn=True, input_width=4, weight_width=4),
+                 nn.Dense: convert.gen_dense_converter(quant_type="channel", input_width=4, weight_width=4),
+                 nn.Activation: None, nn.BatchNorm: convert.bypass_bn}
+    convert.convert_model(net, exclude=[kids[0], kids[1]], convert_fn=converter)
+    net.quantize_input(enable=False)
+    qparams_init(net)
+    names = {"c0_w": kids[0].weight, "b0_g": kids[1].gamma, "b0_b": kids[1].beta, "b0_m": kids[1].running_mean,
+             "b0_v": kids[1].running_var, "d_w": kids[11].weight, "d_b": kids[11].bias}
+    for i, ci in ((1, 3), (2, 6)):
+        c = kids[ci]
+        names.update({"c%d_w" % i: c.weight, "c%d_b" % i: c.bias, "b%d_g" % i: c.gamma, "b%d_b" % i: c.beta,
+                      "b%d_m" % i: c.running_mean, "b%d_v" % i: c.running_var})
+    loss_func = gluon.loss.SoftmaxCrossEntropyLoss()
+    trainer = gluon.Trainer(net.collect_params(), "adam", {"learning_rate": lr})
+    fac = []
+    for s in range(steps):
+        if offline_at is not None and s == offline_at:
+            net.quantize_input(enable=True, online=False)
+        X, y = A(Xs[s]), A(ys[s].astype(np.float32))
+        with autograd.record():
+            outputs = net(X)
+            loss = loss_func(outputs, y)
+        net.update_ema()
+        loss.backward()
+        grads = {k: (None if names[k].data()._t.grad is None else names[k].data()._t.grad.detach().cpu().numpy().copy())
+                 for k in NB_TRAINABLE}
+        trainer.step(Xs[s].shape[0], ignore_stale_grad=True)
+        fac.append((loss.asnumpy(), outputs.asnumpy(), grads))
+    final_f = {k: v.data().asnumpy() for k, v in names.items()}
+    final_o = {k: v.detach().numpy() for k, v in p.items()}
+    im_f = [float(b.input_max.data().asnumpy()[0]) for b in net.collect_quantized_blocks()]
+    im_o = [float(state["input_max"]["q%d" % i]) for i in range(3)]
+    return fac, ora, final_f, final_o, im_f, im_o
+
+
+def _check_notebook(res, steps, tl, tg, tp):
+    fac, ora, ff, fo, im_f, im_o = res
+    for s in range(steps):
+        np.testing.assert_allclose(fac[s][0], ora[s][0], rtol=tl, atol=tl, err_msg="loss, step %d" % s)
+        for k in NB_TRAINABLE:
+            gf, go = fac[s][2][k], ora[s][2][k]
+            assert (gf is None) == (go is None), (k, s)
+            if go is not None:
+                scale = max(np.abs(go).max(), 1e-6)
+                assert np.abs(gf - go).max() <= tg * scale, ("grad", k, s, np.abs(gf - go).max(), scale)
+    for k, v in fo.items():
+        scale = max(np.abs(v).max(), 1e-6)
+        assert np.abs(ff[k] - v).max() <= tp * scale, ("param", k, np.abs(ff[k] - v).max(), scale)
+    np.testing.assert_allclose(im_f, im_o, rtol=max(tl, 1e-6))
+
+
+def test_notebook_configuration_on_cpu():
+    """cells 6-7 + 15: fake-BN fold trained through gamma / beta / bias, running statistics EMA'd from the pre-hook's
+    batch statistics, bypassed BatchNorms receive no gradient (hence ignore_stale_grad), input quantisers disabled
+    for two steps and then switched on OFFLINE with the EMA'd thresholds."""
+    from quantization.mxnet_amd import mx
+    with OP.oracle_ops():
+        res = _run_notebook_config(mx.cpu(), steps=4, offline_at=2)
+    _check_notebook(res, 4, 2e-5, 5e-4, 5e-5)
+    fac = res[0]
+    assert np.abs(res[2]["b1_m"] - _init_params()["b1_m"]).max() > 1e-4         # running statistics were EMA'd
+
+
+@pytest.mark.gpu
+def test_notebook_configuration_on_gpu(gpu):
+    res = _run_notebook_config(gpu, steps=4, offline_at=2)
+    _check_notebook(res, 4, 1e-2, 5e-2, 5e-3)
