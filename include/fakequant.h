@@ -121,6 +121,17 @@ int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t in
 int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                    const float* shift, int act, float* stat_out, fqStream_t stream);
 
+/* The integer core of the reference's stand-alone quantised convolution (nn/quantized_conv.py:134-151: every im2col slice
+ * times the reshaped filters, accumulated as integers) on the int8 matrix cores, exact in int32:
+ *   out[n][co][p] = sum_k xcodes[n*l + p][k] * wcodes[co][k] + zoff * wsum[co]
+ * xcodes: (n*l rows rounded up to 32) x k_pad int8, the im2col rows, k contiguous, zero padded to k_pad % 32 == 0;
+ *         unsigned codes are passed re-centred (code - 128) with zoff = 128, signed codes as they are with zoff = 0;
+ * wcodes: (cout rounded up to 32) x k_pad int8, zero padded;  wsum[co] = sum_k wcodes[co][k];
+ * out   : (n, cout, l) int32.  Bias, activation and the dequantisation by in_scale*w_scale stay with the caller
+ *         (fq_dequantize), as in the reference (:146-158).                                                          */
+int fq_gemm_i8_codes(const int8_t* xcodes, const int8_t* wcodes, const int32_t* wsum, int32_t* out, int64_t n,
+                     int64_t l, int64_t k_pad, int64_t cout, int zoff, fqStream_t stream);
+
 /* The evaluation counters of the reference CLI (examples/simulate_quantization.py:122-148: pred = argmax(outputs, axis=1),
  * test_num_correct += (pred == y), label_counter[gt] += 1, correct_counter[gt] += (pred == gt)) accumulated on the device
  * in one launch.  logits: (n, classes) fp32;  labels: (n) int64 (labels outside [0, classes) only count in `total`);

@@ -335,6 +335,15 @@ def bn_act(x, scale, shift, act="relu"):
     return y.astype(F32)
 
 
+def gemm_i8_codes(xcodes, wcodes, n, l, zoff=0):
+    """Arithmetic of `fq_gemm_i8_codes` (the integer accumulation of nn/quantized_conv.py:134-151):
+    out[n][co][p] = sum_k xcodes[n*l + p][k] * wcodes[co][k] + zoff * sum_k wcodes[co][k], exact in int64 -> int32."""
+    x = np.asarray(xcodes).astype(np.int64)
+    w = np.asarray(wcodes).astype(np.int64)
+    acc = x @ w.T + int(zoff) * w.sum(axis=1)[None, :]
+    return acc.reshape(n, l, w.shape[0]).transpose(0, 2, 1).astype(np.int32)
+
+
 def eval_counters(logits, labels, counters=None):
     """The evaluation loop's bookkeeping (reference examples/simulate_quantization.py:122-148): pred = argmax(axis=1)
     (first index on ties), n_correct, total, correct_counter[gt], label_counter[gt] -> [n_correct, total, correct[c], label[c]]."""

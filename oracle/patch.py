@@ -117,6 +117,10 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     return _t(y), stat
 
 
+def gemm_i8_codes(xcodes, wcodes, n, l, zoff):
+    return torch.from_numpy(O.gemm_i8_codes(xcodes.cpu().numpy(), wcodes.cpu().numpy(), n, l, zoff))
+
+
 def eval_counters(logits, labels, counters):
     counters.copy_(_t(O.eval_counters(_np(logits), labels.cpu().numpy(), _np(counters))))
     return counters
@@ -291,7 +295,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "eval_counters", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "eval_counters", "gemm_i8_codes", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

@@ -1243,6 +1243,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
 // its 4 waves are arranged wm x wn over (64 output channels) x (64 columns) wave tiles and loop over channel passes.
 // ---------------------------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
 struct PwGeom {
   int Cin, CinPad, Cout, HW;
@@ -1479,6 +1480,53 @@ __global__ __launch_bounds__(kBlock) void pwconv_i8_kernel(
       __syncthreads();
       if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < (unsigned)(g.cols / HW))
         atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K10: integer GEMM on 8-bit codes with exact int32 results - the arithmetic core of the reference's stand-alone
+// quantised convolution (nn/quantized_conv.py:134-151: im2col slices x reshaped filters, accumulated as integers).
+//   out[n][co][p] = sum_k xc[n*L + p][k] * wc[co][k]  (+ zoff * wsum[co] when the activation codes were stored
+//   re-centred by zoff = 128 to fit int8)
+// xc: [cols_pad][K] int8, K-contiguous im2col rows (K % 32 == 0, zero padded);  wc: [rows_pad][K] int8.
+// v_mfma_i32_32x32x32_i8 with the activation rows as the B operand: lane = pixel, so every store instruction writes two
+// full 128-byte lines of the NCHW result.  Lanes past the last column re-read and re-store the last one (benign).
+// Correctness first (this block is only exercised by the reference's tests): operands come straight from global / L2.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gemm_i8_codes_kernel(const int8_t* __restrict__ xc,
+                                                               const int8_t* __restrict__ wc,
+                                                               const int* __restrict__ wsum, int* __restrict__ out,
+                                                               int64_t cols, int L, int K, int Cout, int zoff) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, pl = lane & 31;
+  const int64_t tiles = (cols + 31) / 32;
+  const int KT = K >> 5, CT = (Cout + 31) / 32;
+  for (int64_t t = (int64_t)blockIdx.x * (kBlock / 64) + wave; t < tiles; t += (int64_t)gridDim.x * (kBlock / 64)) {
+    int64_t col = t * 32 + pl;
+    col = col < cols ? col : cols - 1;
+    const int64_t smp = col / L;
+    const int p = (int)(col - smp * L);
+    const int8_t* xrow = xc + col * K + 16 * h;
+    int* obase = out + (smp * Cout) * (int64_t)L + p;
+    for (int ct = 0; ct < CT; ++ct) {
+      v16i acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        acc[r] = ch < Cout ? zoff * wsum[ch] : 0;
+      }
+      const int8_t* wrow = wc + (int64_t)(ct * 32 + pl) * K + 16 * h;     // A fragment: row pl, 16-byte half h
+      for (int kt = 0; kt < KT; ++kt) {
+        const v4i a = *reinterpret_cast<const v4i*>(wrow + kt * 32);
+        const v4i b = *reinterpret_cast<const v4i*>(xrow + kt * 32);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = ct * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (ch < Cout) obase[(int64_t)ch * L] = acc[r];
+      }
     }
   }
 }
@@ -1994,7 +2042,6 @@ __global__ __launch_bounds__(kBlock, 3) void pwconv_fused_kernel(
 // ds_read_b128 per lane); per-channel constants sit next to them and are read 4 channels at a time (D holds channels
 // 8*(r/4) + 4*(l>>5) + r%4 in register r).  A wavefront walks a contiguous range of 32-pixel tiles; the loads of the
 // next slab / tile are issued before the current one is quantised (two register buffers).
-typedef int v16i __attribute__((ext_vector_type(16)));
 
 struct PwsGeom {
   int Cin, K, Cout, CT, HW;   // K: row stride of the weight codes (cin_pad); CT = ceil(Cout / 32)
@@ -3439,6 +3486,22 @@ int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_
   const float levels = (float)((1 << (width - 1)) - 1);
   hipLaunchKernelGGL(weight_codes_kernel, dim3((unsigned)rows_pad), dim3(kBlock), 0, st, w, (int)rows, (int)row_len,
                      rows_per_scale, levels, (int)row_pad, gmax, codes, scales, (int*)rowsum);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_gemm_i8_codes(const int8_t* xcodes, const int8_t* wcodes, const int32_t* wsum, int32_t* out, int64_t n,
+                     int64_t l, int64_t k_pad, int64_t cout, int zoff, fqStream_t stream) {
+  FQ_REQUIRE(xcodes && wcodes && wsum && out, "fq_gemm_i8_codes: null pointer");
+  FQ_REQUIRE(n > 0 && l > 0 && cout > 0 && k_pad > 0 && k_pad % 32 == 0 && n * l < (1ll << 40) && l < (1ll << 31),
+             "fq_gemm_i8_codes: bad shape (k_pad=%lld must be a positive multiple of 32)", (long long)k_pad);
+  FQ_REQUIRE(zoff == 0 || zoff == 128, "fq_gemm_i8_codes: zoff must be 0 (signed codes) or 128 (re-centred unsigned)");
+  FQ_REQUIRE(aligned16(xcodes) && aligned16(wcodes), "fq_gemm_i8_codes: code buffers must be 16-byte aligned");
+  const int64_t tiles = (n * l + 31) / 32;
+  int64_t grid = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
+  if (grid > (int64_t)num_cu() * 16) grid = (int64_t)num_cu() * 16;
+  hipLaunchKernelGGL(gemm_i8_codes_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, xcodes, wcodes,
+                     (const int*)wsum, (int*)out, n * l, (int)l, (int)k_pad, (int)cout, zoff);
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

@@ -6,9 +6,11 @@ global range, scale = max/127 if symmetric else (max-min)/255, NO zero-point), i
 
 What differs is the machinery: the quantise / dequantise stages are HIP kernels (`fq_quantize_codes`, `fq_dequantize`;
 ranges and scales stay in device scalars — no `.asscalar()`), and the reference's Python im2col double loop + fp32 `dot`
-(:34-52, :134-151; 12 544 slices per 112x112 map) is one grouped convolution on the integer codes held in fp32, which
-is exact under the same condition as the reference's own fp32 dot (|accumulator| < 2^24, :140-144).  A true int8 MFMA
-convolution is listed as "next" in DESIGN.md.
+(:34-52, :134-151; 12 544 slices per 112x112 map) is, for dense convolutions (groups == 1, int8 weights), an im2col of the CODES
+followed by `fq_gemm_i8_codes`: int8 x int8 -> exact int32 on the matrix cores (v_mfma_i32_32x32x32_i8), for any
+accumulator size.  Grouped / depthwise convolutions (K = 9 per group) and uint8 weights keep one grouped convolution on
+the integer codes held in fp32, exact under the same condition as the reference's own fp32 dot (|accumulator| < 2^24,
+:140-144).
 """
 import torch
 import torch.nn.functional as TF
@@ -99,14 +101,32 @@ class Conv2D(nn.HybridBlock):
                 bi, _ = ops.quantize_codes(b.contiguous(), "scale", rng)
                 b = bi.to(torch.float32)
             x, w = xi._t.to(torch.float32), wi._t.to(torch.float32)
-        # Grouped correlation, stride as the reference's window loop (:42-47)
-        y = TF.conv2d(x, w, None, stride=self._strides, padding=0, groups=self._groups)
-        if self._quantized:
-            y = y.to(torch.int32)                                      # (:144) cast back to int32
+        if self._quantized and self._groups == 1 and self._weight_dtype == 'int8' and self._weight_range is None:
+            # Dense convolution on the int8 matrix cores: im2col of the CODES (the reference's slices,
+            # :34-52), then fq_gemm_i8_codes - exact int32 for any accumulator size, where the fp32 formulation below
+            # (and the reference's own fp32 `dot`, :140-144) is only exact below 2^24.
+            n, _, hp, wp = x.shape
+            kh, kw = self._kernel_size
+            ho, wo = (hp - kh) // self._strides[0] + 1, (wp - kw) // self._strides[1] + 1
+            zoff = 128 if self._input_dtype == 'uint8' and self._input_range is None else 0
+            if self._input_range is not None:
+                zoff = 128 if float(self._input_range[0]) >= 0 else 0   # `_quantize`: codes in [0,255] or [-127,127]
+            cols = TF.unfold(x, (kh, kw), stride=self._strides)          # (n, C*kh*kw, L): small exact integers
+            xc = (cols.transpose(1, 2).reshape(n * ho * wo, -1) - float(zoff)).to(torch.int8)
+            wc = w.reshape(w.shape[0], -1).to(torch.int8)
+            y = ops.gemm_i8_codes(xc.contiguous(), wc.contiguous(), n, ho * wo, zoff).reshape(n, -1, ho, wo)
             if b is not None:
                 y = y + b.to(torch.int32).reshape(1, -1, 1, 1)
-        elif b is not None:
-            y = y + b.reshape(1, -1, 1, 1)
+        else:
+            # Grouped / depthwise (K = 9 per group: nothing for a matrix core) and the float path: correlation with
+            # the stride of the reference's window loop (:42-47); integer codes held in fp32, exact below 2^24
+            y = TF.conv2d(x, w, None, stride=self._strides, padding=0, groups=self._groups)
+            if self._quantized:
+                y = y.to(torch.int32)                                  # (:144) cast back to int32
+                if b is not None:
+                    y = y + b.to(torch.int32).reshape(1, -1, 1, 1)
+            elif b is not None:
+                y = y + b.reshape(1, -1, 1, 1)
         y = NDArray(y)
         if self.act is not None:
             y = self.act(y if not self._quantized else NDArray(y._t))

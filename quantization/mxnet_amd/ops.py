@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -275,6 +275,28 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     check_call(_lib_().fq_bn_act_stat(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,
                                       _ptr(stat), _stream(x)))
     return y, stat
+
+
+def gemm_i8_codes(xcodes, wcodes, n, l, zoff):
+    """Exact int32 GEMM of int8 code matrices on the matrix cores (fq_gemm_i8_codes).
+    xcodes: (n*l, K) int8 im2col rows (already re-centred by `zoff` if unsigned); wcodes: (Cout, K) int8.
+    Returns (n, Cout, l) int32 = sum_k x*w + zoff * rowsum(w)."""
+    require_hip(xcodes.device, "xcodes")
+    require_hip(wcodes.device, "wcodes")
+    if xcodes.dtype != torch.int8 or wcodes.dtype != torch.int8 or xcodes.dim() != 2 or wcodes.dim() != 2 \
+            or xcodes.shape[1] != wcodes.shape[1] or xcodes.shape[0] != n * l:
+        raise ValueError("gemm_i8_codes wants xcodes (n*l, K) and wcodes (Cout, K), both int8")
+    k, cout = xcodes.shape[1], wcodes.shape[0]
+    kp, rp, cp = (k + 31) // 32 * 32, (cout + 31) // 32 * 32, (n * l + 31) // 32 * 32
+    xc = torch.zeros((cp, kp), dtype=torch.int8, device=xcodes.device)
+    xc[:n * l, :k] = xcodes
+    wc = torch.zeros((rp, kp), dtype=torch.int8, device=xcodes.device)
+    wc[:cout, :k] = wcodes
+    wsum = wcodes.to(torch.int32).sum(dim=1).to(torch.int32).contiguous()
+    out = torch.empty((n, cout, l), dtype=torch.int32, device=xcodes.device)
+    check_call(_lib_().fq_gemm_i8_codes(xc.data_ptr(), wc.data_ptr(), wsum.data_ptr(), out.data_ptr(), n, l, kp, cout,
+                                        int(zoff), _stream(xcodes)))
+    return out
 
 
 def eval_counters(logits, labels, counters):

@@ -351,3 +351,50 @@ def test_dense_weight_cache_follows_the_parameter(gpu):
     np.testing.assert_array_equal(y0, y0b)
     np.testing.assert_allclose(y2, expect(), rtol=1e-5, atol=1e-5)
     assert not np.allclose(y0, y1)
+
+
+def test_quantized_conv2d_is_exact_beyond_the_fp32_accumulator_limit(gpu):
+    """nn.Conv2D(quantized=True) on the int8 matrix cores: with 128 input channels, 3x3 filters and
+    saturated codes the integer accumulator reaches 1152 * 255 * 127 = 3.7e7 > 2^24, where an fp32 accumulation (the
+    reference's own `dot`, nn/quantized_conv.py:140-144) is no longer exact.  The block must return in_scale * w_scale
+    times the EXACT integer correlation."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.nn import Conv2D
+    rng = np.random.default_rng(9)
+    x = np.full((2, 128, 6, 6), 3.0, np.float32)
+    x[:, :, ::2, ::3] = rng.uniform(2.5, 3.0, x[:, :, ::2, ::3].shape).astype(np.float32)
+    x[0, 0, 0, 0] = 0.0                                              # uint8 range [0, 3]
+    w = np.full((40, 128, 3, 3), 0.5, np.float32)
+    w[::3] = rng.uniform(0.45, 0.5, w[::3].shape).astype(np.float32)
+    w[1, 0, 0, 0] = -0.5                                             # int8 symmetric range 0.5
+    conv = Conv2D(40, 3, 1, 0, in_channels=128, use_bias=False, quantized=True, input_dtype='uint8',
+                  weight_dtype='int8')
+    conv.initialize(ctx=gpu)
+    conv.weight.set_data(mx.nd.array(w, ctx=gpu))
+    from quantization.mxnet_amd import ops
+    seen = []
+    real = ops.gemm_i8_codes
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        seen.append(out.detach().cpu().numpy().astype(np.int64))
+        return out
+    ops.gemm_i8_codes = spy
+    try:
+        y = conv(mx.nd.array(x, ctx=gpu)).asnumpy()
+    finally:
+        ops.gemm_i8_codes = real
+    in_scale = np.float32(np.float32(3.0 - 0.0) / np.float32(255))
+    w_scale = np.float32(np.float32(0.5) / np.float32(127))
+    xc = np.round(x / in_scale).astype(np.int64)
+    wc = np.round(w / w_scale).astype(np.int64)
+    assert xc.max() == 255 and wc.max() == 127
+    want = np.zeros((2, 40, 4, 4), np.int64)
+    for i in range(4):
+        for j in range(4):
+            want[:, :, i, j] = np.einsum("ncij,ocij->no", xc[:, :, i:i + 3, j:j + 3], wc)
+    assert np.abs(want).max() > 2 ** 24
+    assert len(seen) == 1                                            # the block went through the int8 matrix-core GEMM
+    np.testing.assert_array_equal(seen[0].reshape(want.shape), want)  # exact integers
+    # the block's fp32 output cannot carry integers above 2^24 exactly: one rounding of int -> fp32 and one of the product
+    np.testing.assert_allclose(y, want.astype(np.float64) * np.float64(np.float32(in_scale * w_scale)), rtol=2.5e-7)

@@ -576,3 +576,30 @@ def test_eval_counters_vs_oracle(dev, ops, n, classes):
         want = O.eval_counters(logits, labels, want)
     _eq(N(counters), want, "evaluation counters")
     assert N(counters)[1] == 2 * n
+
+
+@pytest.mark.parametrize("n,l,k,cout,zoff", [(2, 49, 27, 32, 128), (3, 100, 288, 70, 0), (1, 7, 9, 5, 128),
+                                              (4, 196, 1152, 96, 128), (1, 33, 64, 33, 0)])
+def test_gemm_i8_codes_is_exact(dev, ops, n, l, k, cout, zoff):
+    """fq_gemm_i8_codes: int8 x int8 -> int32 on the matrix cores, bit-exact against integer matmul, including
+    accumulators far beyond 2^24 (the fp32 formulation's limit), ragged K / Cout / column counts and the 128 re-centring."""
+    rng = np.random.default_rng(n * 1000 + l + k + cout)
+    if zoff:
+        xu = rng.integers(0, 256, (n * l, k))                          # unsigned codes ...
+        xs = (xu - 128).astype(np.int8)                                # ... as stored
+    else:
+        xu = rng.integers(-127, 128, (n * l, k))
+        xs = xu.astype(np.int8)
+    if k >= 1000:
+        xu[:, :] = 255 if zoff else 127                                # drive |acc| past 2^24: 1152 * 255 * 127 = 3.7e7
+        xs = (xu - zoff).astype(np.int8)
+    w = rng.integers(-127, 128, (cout, k)).astype(np.int8)
+    if k >= 1000:
+        w[::2, :] = 127
+    got = ops.gemm_i8_codes(torch.from_numpy(xs).to(dev), torch.from_numpy(w).to(dev), n, l, zoff)
+    want = (xu.astype(np.int64) @ w.astype(np.int64).T).reshape(n, l, cout).transpose(0, 2, 1)
+    assert got.dtype == torch.int32 and tuple(got.shape) == (n, cout, l)
+    _eq(N(got).astype(np.int64), want, "integer GEMM")
+    _eq(N(got), O.gemm_i8_codes(xs, w, n, l, zoff), "oracle")
+    if k >= 1000:
+        assert np.abs(want).max() > 2 ** 24
