@@ -101,6 +101,9 @@ def parse_args(argv=None):
     parser.add_argument('--no-fuse', action='store_true',
                         help='keep BatchNorm / ReLU / depthwise convolution as separate library ops '
                              '(default: quantize.fuse.fuse_inference folds them into the fake-quant kernels)')
+    parser.add_argument('--export-scale-table', type=str, default=None,
+                        help='after calibration write an ncnn-style int8 scale table (per-channel weight scales after '
+                             'BN folding, one input scale per layer; quantize/freeze/scale_table.py) to this file')
     parser.add_argument('--load-qparams', type=str, default=None,
                         help='load thresholds written by --save-qparams instead of calibrating')
     opt = parser.parse_args(argv)
@@ -360,6 +363,10 @@ def run(opt, ctx, rank=0, world=1):
                 print()
         if opt.save_qparams and r0:
             net.save_parameters(opt.save_qparams)
+        if opt.export_scale_table and r0:
+            from quantization.mxnet_amd.quantize.freeze import export_scale_table
+            export_scale_table(net, opt.export_scale_table, weight_width=8, input_width=8,
+                               json_path=opt.export_scale_table + ".json")
         if not opt.eval_per_calib:
             net.fix_params()
             net.quantize_input(enable=True, online=False)

@@ -326,3 +326,52 @@ def test_merge_bn_matches_reference(golden, capsys):
     convert.gen_conv2d_converter(fake_bn=True)(conv)
     with pytest.raises(AssertionError, match="fake bn"):
         merge_bn(net)
+
+
+def test_scale_table_export(tmp_path):
+    """quantize/freeze/scale_table.py: per-channel weight scales of the BN-FOLDED weights and one
+    input scale per layer, ncnn table layout (README.md:267-274 of the reference fixes the content)."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.mx.gluon import nn
+    from quantization.mxnet_amd.mx.gluon.block import reset_naming
+    from quantization.mxnet_amd.quantize import convert
+    from quantization.mxnet_amd.quantize.initialize import qparams_init
+    from quantization.mxnet_amd.quantize.freeze import export_scale_table
+    reset_naming()
+    rng = np.random.default_rng(4)
+    net = nn.HybridSequential()
+    net.add(nn.Conv2D(6, 3, 1, 1, use_bias=False, in_channels=3), nn.BatchNorm(in_channels=6), nn.Activation("relu"),
+            nn.GlobalAvgPool2D(), nn.Flatten(), nn.Dense(4, in_units=6))
+    net.initialize()
+    conv, bn, dense = net[0], net[1], net[5]
+    w = rng.standard_normal((6, 3, 3, 3)).astype(np.float32)
+    g = rng.uniform(0.5, 2.0, 6).astype(np.float32)
+    var = rng.uniform(0.5, 2.0, 6).astype(np.float32)
+    conv.weight.set_data(mx.nd.array(w))
+    bn.gamma.set_data(mx.nd.array(g))
+    bn.running_var.set_data(mx.nd.array(var))
+    wd = rng.standard_normal((4, 6)).astype(np.float32)
+    dense.weight.set_data(mx.nd.array(wd))
+    convert.convert_model(net, convert_fn={nn.Conv2D: convert.gen_conv2d_converter(quant_type="channel", fake_bn=True),
+                                           nn.Dense: convert.gen_dense_converter(quant_type="channel"),
+                                           nn.BatchNorm: convert.bypass_bn})
+    qparams_init(net)
+    conv.input_max.set_data(mx.nd.array(np.float32([2.5])))
+    dense.input_max.set_data(mx.nd.array(np.float32([0.8])))
+    path = str(tmp_path / "table.txt")
+    entries = export_scale_table(net, path, weight_width=8, input_width=8, json_path=path + ".json")
+    folded = w * (g / np.sqrt(var + np.float32(1e-10))).reshape(-1, 1, 1, 1)
+    by = {e["name"]: e for e in entries}
+    np.testing.assert_allclose(by[conv.name + "_param_0"]["scales"], 127.0 / np.abs(folded).reshape(6, -1).max(axis=1),
+                               rtol=1e-6)
+    np.testing.assert_allclose(by[dense.name + "_param_0"]["scales"], 127.0 / np.abs(wd).max(axis=1), rtol=1e-6)
+    np.testing.assert_allclose(by[conv.name]["scales"], [127.0 / 2.5], rtol=1e-6)
+    np.testing.assert_allclose(by[dense.name]["scales"], [127.0 / 0.8], rtol=1e-6)
+    lines = open(path).read().strip().split("\n")
+    assert [l.split()[0] for l in lines] == [conv.name + "_param_0", dense.name + "_param_0", conv.name, dense.name]
+    assert len(lines[0].split()) == 1 + 6 and len(lines[2].split()) == 2
+    import json
+    assert json.load(open(path + ".json"))[0]["kind"] == "weight"
+    # the block's own widths when none are forced: unsigned 8-bit input -> 255 levels
+    own = {e["name"]: e for e in export_scale_table(net)}
+    np.testing.assert_allclose(own[conv.name]["scales"], [255.0 / 2.5], rtol=1e-6)
