@@ -1019,7 +1019,11 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
   // Input rows are fetched in BURSTS of D rows (double buffered): the D loads of a burst leave the wave back to back
   // and hit the same DRAM pages; one load per step (a ring) spreads them ~700 cycles apart, and with thousands of
   // waves each streaming its own plane every access then opens a new page.
-  constexpr int D = (S == 1) ? 4 : 2;
+#ifndef FQ_DW4_D1
+#define FQ_DW4_D1 4
+#define FQ_DW4_D2 2
+#endif
+  constexpr int D = (S == 1) ? FQ_DW4_D1 : FQ_DW4_D2;
   constexpr int kStatSlots = 16;
   __shared__ unsigned k_stat[kStatSlots];
   if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
