@@ -246,7 +246,8 @@ def main():
                 traffic = None
         dk = kernels.get(dominant, {"achieved": 0.0, "frac": 0.0, "kernel": None})
         line = {
-            "metric": "images/sec int8-sim MobileNet1.0 (per-layer W8A8, online input quant)",
+            "metric": "images/sec int8-sim %s (per-layer W8A8, online input quant)"
+                      % ("MobileNet1.0" if args.model == "mobilenet1.0" else args.model),
             "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
