@@ -178,8 +178,10 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
  * store (same contract as fq_dwconv3x3):
  *   cx   = roundf(clip(x, lo, max_) / (max_/levels + eps))          bit-identical to the fake-quant kernels
  *   y    = act( (float(sum_ci cw[co,ci]*cx[ci]) * (sx * wscale[co]) + bias[co]) * bn_scale[co] + bn_shift[co] )
- * x: (n, cin, hw) fp32;  y: (n, cout, hw) fp32;  wcodes: int8 [cout_pad][cin_pad] (zero padded; cin_pad % 64 == 0,
- * cout_pad % 64 == 0) from fq_weight_codes;  wscale[cout], wsum[cout] (= sum_ci cw, used for the +128 re-centring of
+ * x: (n, cin, hw) fp32;  y: (n, cout, hw) fp32;  wcodes: the buffer written by fq_weight_codes: int8 [cout_pad][cin_pad]
+ * row-major (zero padded; cin_pad % 64 == 0, cout_pad % 64 == 0) FOLLOWED by the same codes in MFMA-fragment order
+ * (another cout_pad*cin_pad bytes: fragment (co/32, ci/32) = 64 lanes x 16 bytes, lane = co%32 + 32*((ci%32)/16), byte =
+ * ci%16), i.e. `codes` must hold 2*rows_pad*row_pad bytes;  wscale[cout], wsum[cout] (= sum_ci cw, used for the +128 re-centring of
  * unsigned activations).  Needs in_width <= 8.                                                                       */
 int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_scale, int width, int64_t row_pad,
                     int64_t rows_pad, int8_t* codes, float* scales, int32_t* rowsum, void* ws, fqStream_t stream);

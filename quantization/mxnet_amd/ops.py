@@ -375,7 +375,9 @@ def weight_codes(w, rows_per_scale, width=8):
     row_len = w.numel() // rows
     row_pad = (row_len + 63) // 64 * 64
     rows_pad = (rows + 63) // 64 * 64
-    codes = torch.empty((rows_pad, row_pad), dtype=torch.int8, device=w.device)
+    # row-major codes followed by the fragment-major copy the tiled pointwise kernel streams (include/fakequant.h)
+    buf = torch.empty(2 * rows_pad * row_pad, dtype=torch.int8, device=w.device)
+    codes = buf[:rows_pad * row_pad].view(rows_pad, row_pad)
     scales = torch.empty(rows, dtype=torch.float32, device=w.device)
     rowsum = torch.empty(rows, dtype=torch.int32, device=w.device)
     ws = _workspace(w.device, _lib_().fq_weight_workspace_bytes(rows))

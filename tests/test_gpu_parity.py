@@ -424,12 +424,26 @@ def test_dwconv3x3_vs_oracle(dev, ops, shape, stride, mode):
 PW_CASES = [  # (n, cin, cout, h, w)
     (2, 32, 64, 28, 28), (3, 64, 128, 14, 14), (2, 128, 128, 9, 12), (2, 128, 256, 14, 14), (5, 512, 512, 7, 7),
     (3, 1024, 1024, 7, 7), (2, 24, 40, 5, 7), (1, 3, 8, 4, 4), (2, 96, 576, 6, 6), (4, 1024, 1000, 1, 1),
-    (2, 960, 320, 7, 7), (2, 144, 24, 14, 14), (2, 16, 96, 9, 9)]
+    (2, 960, 320, 7, 7), (2, 144, 24, 14, 14), (2, 16, 96, 9, 9),
+    (3, 256, 512, 5, 6)]     # tile form, K = 256 instantiation, ragged last 32-pixel tile (90 columns)
 
 
 @pytest.mark.parametrize("case", PW_CASES, ids=["%dx%d->%d@%dx%d" % c for c in PW_CASES])
 @pytest.mark.parametrize("mode", ["online_u8_layer", "offline_s8_channel_w4", "online_u8_bn_relu", "dense_quirk_bias"])
 def test_pwconv_i8_vs_oracle(dev, ops, case, mode):
+    _pwconv_case(dev, ops, case, mode)
+
+
+@pytest.mark.parametrize("case,mode", [((84, 512, 512, 14, 14), "online_u8_bn_relu"),
+                                       ((86, 256, 512, 14, 14), "offline_s8_channel_w4")],
+                         ids=["chunk<16,8>", "chunk<8,8>"])
+def test_pwconv_i8_chunked_form_vs_oracle(dev, ops, case, mode):
+    """>= 512 tiles of 32 columns: the shapes fq_pwconv_i8 sends through the chunked-weights kernel (the small cases
+    above take the tile form for these channel counts); 86 * 196 columns also end in a ragged tile."""
+    _pwconv_case(dev, ops, case, mode)
+
+
+def _pwconv_case(dev, ops, case, mode):
     n, cin, cout, h, w = case
     rng = np.random.default_rng(sum(case))
     x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
