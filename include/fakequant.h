@@ -121,6 +121,13 @@ int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t in
 int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                    const float* shift, int act, float* stat_out, fqStream_t stream);
 
+/* Global average pooling (gluon GlobalAvgPool2D -> F.Pooling(global_pool=True, pool_type='avg'), the block in front of
+ * the classifier of every model of the zoo) with the per-sample statistic the following quantised Dense needs
+ * (convert_dense.py:40-41): x (n, c, hw) -> y (n, c) = fp32(sum over hw accumulated in fp64, in order) / fp32(hw);
+ * stat_out[n] (may be NULL) <- max_c |y[n][c]|.  flags: 0 or FQ_STAT_PREZEROED.                                       */
+int fq_global_avg_pool_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, int flags, float* stat_out,
+                            fqStream_t stream);
+
 /* The integer core of the reference's stand-alone quantised convolution (nn/quantized_conv.py:134-151: every im2col slice
  * times the reshaped filters, accumulated as integers) on the int8 matrix cores, exact in int32:
  *   out[n][co][p] = sum_k xcodes[n*l + p][k] * wcodes[co][k] + zoff * wsum[co]

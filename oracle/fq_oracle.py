@@ -335,6 +335,17 @@ def bn_act(x, scale, shift, act="relu"):
     return y.astype(F32)
 
 
+def global_avg_pool(x):
+    """Arithmetic of `fq_global_avg_pool_stat` (gluon GlobalAvgPool2D): fp32(fp64 sum over the plane, in order) / fp32(hw)."""
+    x = np.asarray(x, dtype=F32)
+    n, c = x.shape[:2]
+    flat = x.reshape(n, c, -1).astype(np.float64)
+    acc = np.zeros((n, c), np.float64)
+    for i in range(flat.shape[2]):
+        acc = acc + flat[:, :, i]
+    return (acc.astype(F32) / F32(flat.shape[2])).astype(F32).reshape(n, c, 1, 1)
+
+
 def gemm_i8_codes(xcodes, wcodes, n, l, zoff=0):
     """Arithmetic of `fq_gemm_i8_codes` (the integer accumulation of nn/quantized_conv.py:134-151):
     out[n][co][p] = sum_k xcodes[n*l + p][k] * wcodes[co][k] + zoff * sum_k wcodes[co][k], exact in int64 -> int32."""

@@ -117,6 +117,12 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     return _t(y), stat
 
 
+def global_avg_pool_stat(x, want_stat=True):
+    y = O.global_avg_pool(_np(x))
+    stat = _t(np.abs(y).reshape(y.shape[0], -1).max(axis=1).astype(F32)) if want_stat else None
+    return _t(y), stat
+
+
 def gemm_i8_codes(xcodes, wcodes, n, l, zoff):
     return torch.from_numpy(O.gemm_i8_codes(xcodes.cpu().numpy(), wcodes.cpu().numpy(), n, l, zoff))
 
@@ -295,7 +301,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "eval_counters", "gemm_i8_codes", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

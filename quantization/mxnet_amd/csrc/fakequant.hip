@@ -1536,6 +1536,37 @@ __global__ __launch_bounds__(kBlock) void gemm_i8_codes_kernel(const int8_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K11: global average pooling (gluon GlobalAvgPool2D = F.Pooling(global_pool=True, pool_type='avg')) with the per-sample
+// max|y| the following Dense layer's input quantiser needs (convert_dense.py:40-41) - one launch instead of the library
+// reduction + memset + statistic pass.  y[n][c] = fp32(sum over the plane in fp64, in order) / fp32(hw): deterministic,
+// within an ulp of any fp32 summation order.  A thread owns a plane (hw is 49 here: 25 MB in all, latency-bound).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gap_stat_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int64_t planes, int c, int hw, float* __restrict__ stat_out) {
+  __shared__ float red[4];
+  const int64_t pl = (int64_t)blockIdx.x * kBlock + threadIdx.x;       // host: c % kBlock == 0 or one sample per block
+  float v = 0.0f;
+  if (pl < planes) {
+    const float* p = x + pl * hw;
+    double acc = 0.0;
+    for (int i = 0; i < hw; ++i) acc += (double)p[i];
+    v = (float)acc / (float)hw;
+    y[pl] = v;
+  }
+  if (stat_out != nullptr) {
+    // all planes of a block belong to one sample when c % kBlock == 0 (host checks); otherwise per-thread atomics
+    const int64_t first = (int64_t)blockIdx.x * kBlock;
+    const bool one_sample = (c % kBlock) == 0;
+    if (one_sample) {
+      const float m = block_max(fabsf(v), red);
+      if (threadIdx.x == 0 && first < planes) atomic_max_f32(stat_out + first / c, m);
+    } else if (pl < planes) {
+      atomic_max_f32(stat_out + pl / c, fabsf(v));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K9: the evaluation counters of simulate_quantization.py:122-148 (pred = argmax(outputs, axis=1), first index on
 // ties as MXNet's argmax; test_num_correct, label_counter[gt], correct_counter[gt]) in ONE launch: a wavefront per
 // sample.  The tensor-library formulation is nine launch-bound kernels (~60 us per batch, 4 % of an evaluation step).
@@ -3719,6 +3750,20 @@ int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_
   hipLaunchKernelGGL(weight_codes_kernel, dim3((unsigned)rows_pad), dim3(kBlock), 0, st, w, (int)rows, (int)row_len,
                      rows_per_scale, levels, (int)row_pad, gmax, codes, scales, (int*)rowsum,
                      codes + rows_pad * row_pad);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_global_avg_pool_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, int flags, float* stat_out,
+                            fqStream_t stream) {
+  FQ_REQUIRE(x && y, "fq_global_avg_pool_stat: null pointer");
+  FQ_REQUIRE(n > 0 && c > 0 && hw > 0 && hw < (1ll << 31) && c < (1ll << 31), "fq_global_avg_pool_stat: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const bool prezeroed = (flags & FQ_STAT_PREZEROED) != 0;
+  if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  const int64_t planes = n * c;
+  hipLaunchKernelGGL(gap_stat_kernel, dim3((unsigned)((planes + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, x, y, planes,
+                     (int)c, (int)hw, stat_out);
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -274,6 +274,19 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     stat, zflag = _stat_target(n, x.device, want_stat)
     check_call(_lib_().fq_bn_act_stat(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,
                                       _ptr(stat), _stream(x)))
+    return y, stat
+
+
+def global_avg_pool_stat(x, want_stat=True):
+    """Global average pooling of (N, C, H, W) -> (N, C, 1, 1) plus the per-sample max|y| for the consumer's input
+    quantiser (fq_global_avg_pool_stat).  Returns (y, stat (N,) or None)."""
+    _check(x, "x")
+    if x.dim() != 4:
+        raise ValueError("global_avg_pool_stat wants (N, C, H, W)")
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, 1, 1), dtype=torch.float32, device=x.device)
+    stat, zflag = _stat_target(n, x.device, want_stat)
+    check_call(_lib_().fq_global_avg_pool_stat(_ptr(x), _ptr(y), n, c, h * w, int(zflag), _ptr(stat), _stream(x)))
     return y, stat
 
 

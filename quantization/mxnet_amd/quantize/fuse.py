@@ -113,6 +113,20 @@ def _stem_forward(self, F, x, weight, bias=None):
     return out
 
 
+def _gap_stat_forward(self, F, x):
+    t = x._t if x._t.is_contiguous() else x._t.contiguous()
+    y, stat = ops.global_avg_pool_stat(t, want_stat=True)
+    out = NDArray(y)
+    out._fq_stat = stat
+    return out
+
+
+def _flatten_keep_stat_forward(self, F, x):
+    out = NDArray(x._t.reshape(x._t.shape[0], -1))
+    out._fq_stat = x._fq_stat                       # a per-sample statistic is unchanged by flattening
+    return out
+
+
 def _plain_dw_forward(self, F, x, weight, bias=None):
     from .convert.convert_conv2d import _dw_fused_conv
     return _dw_fused_conv(self, x, weight, bias, {})
@@ -191,6 +205,32 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True):
                 bypass(nxt)
             fused[0] += 1
 
+    def visit_gap(container):
+        """GlobalAvgPool2D [-> Flatten] -> quantised Dense: pool and statistic in one launch, carried through Flatten."""
+        if not isinstance(container, (nn.Sequential, nn.HybridSequential)):
+            return
+        kids = list(container._children.values())
+        for i, b in enumerate(kids):
+            if type(b) is not nn.GlobalAvgPool2D or hasattr(b, "_fq_gap_fused"):
+                continue
+            if b.hybrid_forward.__func__ is not nn.GlobalAvgPool2D.hybrid_forward:
+                continue
+            j = i + 1
+            flat = None
+            if j < len(kids) and type(kids[j]) is nn.Flatten and \
+                    kids[j].hybrid_forward.__func__ is nn.Flatten.hybrid_forward:
+                flat = kids[j]
+                j += 1
+            cons = kids[j] if j < len(kids) else None
+            if not (type(cons) is nn.Dense and hasattr(cons, "quantize_args") and cons.quantize_args.quantize_input):
+                continue
+            b._fq_gap_fused = {"orig": b.hybrid_forward, "flatten": flat,
+                               "flatten_orig": None if flat is None else flat.hybrid_forward}
+            b.hybrid_forward = types.MethodType(_gap_stat_forward, b)
+            if flat is not None:
+                flat.hybrid_forward = types.MethodType(_flatten_keep_stat_forward, flat)
+            fused[0] += 1
+
     def visit_pw(container):
         if not isinstance(container, (nn.Sequential, nn.HybridSequential)):
             return
@@ -238,6 +278,7 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True):
         net.apply(visit_dw)
     if pointwise_int8:
         net.apply(visit_pw)
+    net.apply(visit_gap)
     net.apply(visit)
     _install_stat_arena(net, fused[0])
     return fused[0]
@@ -285,6 +326,12 @@ def unfuse(net):
             del blk._fq_bypassed_orig
 
     def visit(b):
+        if hasattr(b, "_fq_gap_fused"):
+            st = b._fq_gap_fused
+            b.hybrid_forward = st["orig"]
+            if st["flatten"] is not None:
+                st["flatten"].hybrid_forward = st["flatten_orig"]
+            del b._fq_gap_fused
         if hasattr(b, "_fq_stem_fused"):
             st = b._fq_stem_fused
             b.hybrid_forward = st["orig"]

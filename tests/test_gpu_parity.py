@@ -617,3 +617,14 @@ def test_gemm_i8_codes_is_exact(dev, ops, n, l, k, cout, zoff):
     _eq(N(got), O.gemm_i8_codes(xs, w, n, l, zoff), "oracle")
     if k >= 1000:
         assert np.abs(want).max() > 2 ** 24
+
+
+@pytest.mark.parametrize("shape", [(128, 1024, 7, 7), (3, 17, 5, 4), (2, 256, 1, 1), (5, 512, 14, 14)])
+def test_global_avg_pool_stat_vs_oracle(dev, ops, shape):
+    rng = np.random.default_rng(sum(shape))
+    x = np.maximum(rng.standard_normal(shape), 0).astype(np.float32) * 3
+    y, stat = ops.global_avg_pool_stat(T(x, dev))
+    want = O.global_avg_pool(x)
+    _eq(N(y), want, "pooled")
+    _eq(N(stat), O.absmax_per_sample(want), "statistic")
+    np.testing.assert_allclose(N(y), x.mean(axis=(2, 3), keepdims=True), rtol=2e-6, atol=1e-7)
