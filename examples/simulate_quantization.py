@@ -101,6 +101,10 @@ def parse_args(argv=None):
     parser.add_argument('--no-fuse', action='store_true',
                         help='keep BatchNorm / ReLU / depthwise convolution as separate library ops '
                              '(default: quantize.fuse.fuse_inference folds them into the fake-quant kernels)')
+    parser.add_argument('--synthetic-on-device', action='store_true',
+                        help='(synthetic datasets only) generate normalised image batches directly on the GPU instead '
+                             'of image by image on the host, so the reported speed is the network\'s, not the data '
+                             'pipeline\'s; sample values differ from the host pipeline\'s (both are random)')
     parser.add_argument('--export-scale-table', type=str, default=None,
                         help='after calibration write an ncnn-style int8 scale table (per-channel weight scales after '
                              'BN folding, one input scale per layer; quantize/freeze/scale_table.py) to this file')
@@ -124,6 +128,29 @@ def parse_args(argv=None):
         print('*'*(25*2+len(' Setting ')))
         print()
     return opt
+
+
+class DeviceSyntheticLoader(object):
+    """Stand-in for DataLoader over the synthetic datasets: N(0,1) "normalised images" and uniform labels generated on
+    the device, one generator seed per batch index (so every rank count / batch size sees a well-defined sequence);
+    batches are strided across ranks like the real loader's."""
+
+    def __init__(self, n_images, batch_size, shape, classes, ctx, seed, rank=0, world_size=1):
+        self._n, self._b, self._shape, self._classes = int(n_images), int(batch_size), tuple(shape), int(classes)
+        self._dev, self._seed, self._rank, self._world = ctx.torch_device, int(seed), int(rank), int(world_size)
+        self._batches = [i for i in range((self._n + self._b - 1) // self._b) if i % self._world == self._rank]
+
+    def __len__(self):
+        return len(self._batches)
+
+    def __iter__(self):
+        g = torch.Generator(device=self._dev)
+        for i in self._batches:
+            b = min(self._b, self._n - i * self._b)
+            g.manual_seed(self._seed * 1000003 + i)
+            X = torch.randn((b,) + self._shape, device=self._dev, generator=g)
+            y = torch.randint(0, self._classes, (b,), device=self._dev, generator=g).float()
+            yield mx.nd.NDArray(X), mx.nd.NDArray(y)
 
 
 def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"):
@@ -292,7 +319,13 @@ def run(opt, ctx, rank=0, world=1):
     eval_dataset = dataset(train=False).transform_first(eval_transformer)
     eval_loader = DataLoader(dataset=eval_dataset, batch_size=opt.batch_size, num_workers=opt.num_workers,
                              last_batch='keep', **shard)
-    if opt.quantize_input_offline and not opt.load_qparams:
+    if opt.synthetic_on_device:
+        hw_in = 224 if opt.dataset == 'imagenet' else 32
+        eval_loader = DeviceSyntheticLoader(len(eval_dataset), opt.batch_size, (3, hw_in, hw_in), classes, ctx, 7, **shard)
+        if opt.quantize_input_offline and not opt.load_qparams:
+            train_loader = DeviceSyntheticLoader(classes * opt.num_sample, opt.batch_size, (3, hw_in, hw_in), classes, ctx,
+                                                 11, **shard)
+    if opt.quantize_input_offline and not opt.load_qparams and not opt.synthetic_on_device:
         train_dataset = dataset(train=True).transform_first(eval_transformer)
         if opt.dataset == 'imagenet':
             train_labels = [item[1] for item in train_dataset._data.items]
