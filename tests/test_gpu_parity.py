@@ -628,3 +628,77 @@ def test_global_avg_pool_stat_vs_oracle(dev, ops, shape):
     _eq(N(y), want, "pooled")
     _eq(N(stat), O.absmax_per_sample(want), "statistic")
     np.testing.assert_allclose(N(y), x.mean(axis=(2, 3), keepdims=True), rtol=2e-6, atol=1e-7)
+
+
+# ---- fused producers at the benchmark's full batch (BASELINE configs[1]: mobilenet1.0, batch 128) ----------------------
+def _subset_pins_full_batch(run, x_full, picks, oracle_fn, what, exact=True):
+    """`run(x)` -> (y, stat).  In offline mode a sample's output cannot depend on its batch-mates: the full-batch result
+    on `picks` must be BIT-IDENTICAL to a small-batch call (different grid / tile boundaries), and that small call is
+    checked against the oracle - which pins the full-size kernel to the oracle on those samples.  The per-sample
+    statistic must be the abs-max of what was actually written, for every sample."""
+    y_full, stat_full = run(x_full)
+    xs = x_full[picks].contiguous()
+    y_small, stat_small = run(xs)
+    assert torch.equal(y_full[picks], y_small), what + ": full-batch output differs from the small-batch call"
+    assert torch.equal(stat_full[picks], stat_small), what + ": statistic differs"
+    assert torch.equal(stat_full, y_full.abs().reshape(y_full.shape[0], -1).amax(dim=1)), what + ": statistic != max|y|"
+    want = oracle_fn(xs.cpu().numpy())
+    got = y_small.cpu().numpy()
+    if exact:
+        _eq(got, want, what + " vs oracle")
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6, err_msg=what)
+        assert (got != want).mean() < 1e-3
+
+
+def test_fused_producers_full_batch_properties(dev, ops):
+    """stem (128,3,224,224); depthwise 32@112x112 stride 1 and 64@112x112 stride 2; pointwise 32->64@112x112 (stream
+    form), 512->512@14x14 (chunked form), 512->1024@7x7 and 1024->1024@7x7 (tile form) - the largest instance of every
+    producer kernel family in the benchmark step."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    rng = np.random.default_rng(5)
+    picks = torch.tensor([0, 63, 127], device=dev)
+    thr = np.float32(2.1)
+    thr_t = T(np.float32([thr]), dev)
+
+    def bn(c):
+        return rng.uniform(0.4, 1.4, c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+
+    # stem
+    x = torch.randn(128, 3, 224, 224, device=dev, generator=g)
+    w = (rng.standard_normal((32, 3, 3, 3)) * 0.3).astype(np.float32)
+    sc, sh = bn(32)
+    _subset_pins_full_batch(lambda t: ops.stem_conv3x3s2(t, T(w, dev), bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu"),
+                            x, picks, lambda a: O.stem_conv3x3s2(a, w, None, sc, sh, "relu"), "stem", exact=False)
+    del x
+    # depthwise
+    for c, hw, s in [(32, 112, 1), (64, 112, 2), (512, 14, 1)]:
+        x = torch.relu(torch.randn(128, c, hw, hw, device=dev, generator=g)) * 1.5
+        w = (rng.standard_normal((c, 1, 3, 3)) * 0.4).astype(np.float32)
+        sc, sh = bn(c)
+        _subset_pins_full_batch(
+            lambda t: ops.dwconv3x3(t, T(w, dev), None, stride=s, in_thr=thr_t, width=8, flags=0, bn_scale=T(sc, dev),
+                                    bn_shift=T(sh, dev), act="relu"),
+            x, picks, lambda a: O.dwconv3x3(a, w, None, s, thr, False, 8, None, sc, sh, "relu"),
+            "depthwise %d@%d s%d" % (c, hw, s), exact=False)
+        del x
+    # pointwise: stream / chunk / tile forms
+    for cin, cout, hw in [(32, 64, 112), (512, 512, 14), (512, 1024, 7), (1024, 1024, 7)]:
+        x = torch.relu(torch.randn(128, cin, hw, hw, device=dev, generator=g)) * 1.5
+        w = (rng.standard_normal((cout, cin, 1, 1)) * 0.1).astype(np.float32)
+        sc, sh = bn(cout)
+        codes, scales, rowsum = ops.weight_codes(T(w, dev), cout, 8)
+        _subset_pins_full_batch(
+            lambda t: ops.pwconv_i8(t, codes, scales, rowsum, in_thr=thr_t, width=8, flags=0, bn_scale=T(sc, dev),
+                                    bn_shift=T(sh, dev), act="relu"),
+            x, picks, lambda a: O.pwconv_i8(a, w, cout, 8, in_max=thr, signed=False, width=8, bn_scale=sc, bn_shift=sh,
+                                            act="relu"),
+            "pointwise %d->%d@%d" % (cin, cout, hw))
+        # exact linearity in a power-of-two weight scale (codes identical, scales doubled), without BN / activation
+        y1, _ = ops.pwconv_i8(x, codes, scales, rowsum, in_thr=thr_t, width=8, flags=0)
+        c2, s2, r2 = ops.weight_codes(T(w * 2, dev), cout, 8)
+        assert torch.equal(c2, codes)
+        y2, _ = ops.pwconv_i8(x, c2, s2, r2, in_thr=thr_t, width=8, flags=0)
+        assert torch.equal(y2, y1 * 2), "pointwise %d->%d: not linear in the weight scale" % (cin, cout)
+        del x, y1, y2
