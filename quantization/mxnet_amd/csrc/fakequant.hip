@@ -231,8 +231,13 @@ __device__ __forceinline__ float ieee_div_by(float c, double rden) { return (flo
 // |Q| <= 70000; codes are <= 65535).  3 instructions instead of roundf's 6; NaN and Inf pass through as with roundf.
 __device__ __forceinline__ float round_half_away(float Q) { return truncf(Q + __builtin_copysignf(0.49999997f, Q)); }
 
+// clip(x, lo, hi) in one instruction: v_med3_f32 is the median of three, i.e. the clamp when lo <= hi (always: hi = max_ >= 0,
+// lo = 0 or -max_); a NaN input yields lo, exactly as fminf(fmaxf(NaN, lo), hi) does.  (fmaxf/fminf cost three: the
+// compiler first canonicalises x with a v_max.)
+__device__ __forceinline__ float fq_clip(float x, const QParams& q) { return __builtin_amdgcn_fmed3f(x, q.lo, q.hi); }
+
 __device__ __forceinline__ float fq_code(float x, const QParams& q) {
-  float c = fminf(fmaxf(x, q.lo), q.hi);
+  float c = fq_clip(x, q);
   return round_half_away(ieee_div_by(c, q.rden));
 }
 
@@ -241,7 +246,7 @@ __device__ __forceinline__ float fq_code(float x, const QParams& q) {
 // roundf(Q) == trunc(Q + copysign(pred(0.5), Q)) for every fp32 |Q| < 2^23 (checked exhaustively for |Q| <= 70000:
 // the only fp32 for which Q + 0.5 itself would round across an integer is pred(0.5), and pred(0.5) + pred(0.5) is exact).
 __device__ __forceinline__ int fq_code_int(float x, const QParams& q) {
-  const float c = fminf(fmaxf(x, q.lo), q.hi);
+  const float c = fq_clip(x, q);
   const float Q = ieee_div_by(c, q.rden);
   return (int)(Q + __builtin_copysignf(0.49999997f, Q));
 }
