@@ -1,16 +1,32 @@
 // libfakequant — hand-written HIP kernels for MI355X (gfx950 / CDNA4) + the C ABI of include/fakequant.h.
 //
-// Everything here is HBM-bound elementwise / reduction work (no contraction -> no MFMA).  Design rules applied:
-//   * 64-wide wavefronts, 256-thread workgroups, 16 B per lane per access (global_load/store_dwordx4), 8
-//     independent loads in flight per lane (32 KiB per workgroup per step) and a grid capped at 8 workgroups per
-//     CU with a grid-stride loop;
-//   * per-sample / per-row statistics: lane-local max -> wavefront shuffle tree -> LDS across the 4 waves -> ONE
-//     integer atomicMax per workgroup step (|x| >= 0, so the fp32 bit pattern orders like an unsigned int);
-//   * the batch statistic never leaves the device: the apply pass re-derives mean -> scale in its prologue from
-//     the N per-sample maxima (scalar loads, fp64 accumulate in sample order) — no `.asscalar()` round trip;
-//   * arithmetic that decides an integer code is IEEE: true fp32 division (never rcp-multiply), C roundf
-//     (half away from zero), clip before divide, multiply by the epsilon-free scale; the file is compiled with
-//     -ffp-contract=off so no multiply-add is fused behind the oracle's back.
+// Contents (search for the tag):
+//   K0  fill (event-overhead calibration)          K1  per-sample abs-max statistic        K1b batch means
+//   K2  fake-quant apply (online / offline)        K2b BatchNorm + activation + statistic
+//   K2c/K2d/K2e depthwise 3x3 with quantise-on-load: LDS tiles / 1 column per lane / 4 columns per lane
+//   K2f pointwise 1x1 on int8 codes, two kernels (quantise+transpose, 16x16x64 MFMA GEMM)   K2g LDS-panel single launch
+//   K2h streaming form (32x32x32 MFMA, activations as B operand, weights in LDS)
+//   K2i chunked-weights streaming form             K2j tile form (split quantisation, weights streamed from L2)
+//   K2s stem convolution 3x3 s2 (3 -> 32)          K3/K3b/K3c weight fake-quant, generic STE   K4 Winograd-domain weights
+//   K5  EMA    K6 global min/max    K7 histogram   K8 KL threshold search    K9 int-code quantise / dequantise
+//   K10 exact int8 x int8 -> int32 GEMM (nn.Conv2D(quantized=True))          K11 global average pool + statistic
+//   K12 evaluation counters                        then: host-side launch helpers and the extern "C" entry points.
+//
+// Design rules applied:
+//   * 64-wide wavefronts, 256-thread workgroups, 16 B per lane per access where the layout allows; streaming kernels keep
+//     8 independent loads in flight per lane and cap the grid at 8 workgroups per CU with contiguous work ranges;
+//   * per-sample statistics: lane-local max -> wavefront shuffle tree -> LDS -> ONE integer atomicMax per workgroup and
+//     sample (|x| >= 0, so the fp32 bit pattern orders like an unsigned int; same-address global atomics serialise in L2);
+//   * the batch statistic never leaves the device: every consumer re-derives mean -> scale in its prologue from the N
+//     per-sample maxima (wave-parallel fp64 sum, accepted only when the exponent spread proves every order exact);
+//   * arithmetic that decides an integer code is exactly the reference's clip -> IEEE fp32 divide -> roundf -> multiply by
+//     the epsilon-free scale, computed as v_med3 clamp, (float)((double)c * RN_f64(1/d)) (proven equal to the fp32
+//     quotient, see ieee_div_by) and trunc(Q + copysign(pred(0.5), Q)) (checked exhaustively); compiled with
+//     -ffp-contract=off and without fast-math so nothing is fused or re-associated behind the oracle's back;
+//   * the 1x1 convolutions multiply the integer CODES on the int8 matrix cores (exact int32 sums); everything else is
+//     elementwise / reduction / small-stencil work bounded by HBM or by instruction issue (profiles/r1_pmc_sq.txt);
+//   * hipcc's scheduler is kept honest in the hand-pipelined loops with FQ_PIN (asm memory clobber + sched_barrier) and
+//     empty "+v" asm pins (it otherwise sinks arithmetic below prefetches or hoists every load of an unrolled loop).
 //
 // Reference lines each kernel replaces are cited at its C entry point in include/fakequant.h.
 #include <hip/hip_runtime.h>
@@ -1572,7 +1588,7 @@ __global__ __launch_bounds__(kBlock) void gap_stat_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K9: the evaluation counters of simulate_quantization.py:122-148 (pred = argmax(outputs, axis=1), first index on
+// K12: the evaluation counters of simulate_quantization.py:122-148 (pred = argmax(outputs, axis=1), first index on
 // ties as MXNet's argmax; test_num_correct, label_counter[gt], correct_counter[gt]) in ONE launch: a wavefront per
 // sample.  The tensor-library formulation is nine launch-bound kernels (~60 us per batch, 4 % of an evaluation step).
 // counters = [n_correct, total, correct[classes], label[classes]] as floats: the increments are 1.0, exact below 2^24.
