@@ -57,6 +57,36 @@ def build_net(model, classes, ctx, seed=7, fuse=True):
     return net
 
 
+def headline_tensor(dev, ops):
+    """BASELINE.json's second figure: achieved HBM bandwidth of the fused online fake-quant (statistic pass + apply pass,
+    12 algorithmic B/elem: two reads and one write, no credit for Infinity-Cache hits) on the largest
+    MobileNet activation, (128, 64, 112, 112) fp32 = 411 MB, measured with HIP events on the launch stream after the
+    benchmark's timed region (median of 20).  Reported beside `roofline`, which describes the dominant kernel of the step."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    x = torch.relu(torch.randn(128, 64, 112, 112, device=dev, generator=g)) * 2.0
+    out = torch.empty_like(x)
+    cur = torch.zeros(1, device=dev)
+
+    def run():
+        ops.fake_quant_online(x, 8, 0, out=out, cur_out=cur)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in evs:
+        a.record()
+        run()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)[10]
+    nbytes = 12.0 * x.numel()
+    return {"what": "online fake-quant (absmax_per_sample + act_apply kernels) on (128,64,112,112) fp32, 12 B/elem",
+            "bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms": round(ms, 4)}
+
+
 def cpu_baseline(model, classes, hw, sample_images, budget_s=25.0):
     """Oracle leg: identical converted net on the host, fake-quant through oracle/ (numpy restatement of the
     reference's op chain), conv/FC through torch-CPU.  Bounded sample; reports images/sec."""
@@ -94,6 +124,8 @@ def main():
                     help="bracket the library's kernels with HIP events in every n-th timed step (default 10)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (roofline fields become empty)")
+    ap.add_argument("--no-headline", action="store_true",
+                    help="skip the stand-alone fake-quant measurement on the 411 MB headline tensor (extra JSON object)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="keep BatchNorm / ReLU as separate torch ops (no quantize.fuse.fuse_inference)")
     ap.add_argument("--autotune", action="store_true",
@@ -264,6 +296,8 @@ def main():
                                            % (profiled_steps, args.steps),
                          "event_pair_overhead_us_removed": round(ev_overhead_ms * 1e3, 3), "kernels": kernels},
         }
+        if world == 1 and not args.no_headline:
+            line["headline_tensor"] = headline_tensor(dev, ops)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.model, classes, hw, args.cpu_sample)
         elif world == 1:
