@@ -1,21 +1,30 @@
 """Build libfakequant.so in-tree with plain hipcc for gfx950 (no JIT cache: the .so travels with the repo snapshot).
 
-    python -m quantization.mxnet_amd.csrc.build [--force]
+    python -m quantization.mxnet_amd.csrc.build [--force] [--amalgamate] [-DNAME[=V] ...] [-o OUT]
+
+Every `fq_*.hip` translation unit is compiled to an object under `csrc/build/` (in parallel, only when it or a header
+changed) and the objects are linked into one shared library.  `--amalgamate` compiles all units as ONE translation unit
+instead (used by the trace build `-DFQ_PW_TRACE`, whose `__device__` debug symbols must exist once).
 
 Flags that matter for parity: `-ffp-contract=off` (HIP defaults to fast contraction; a fused multiply-add would change
 Winograd/EMA/interpolation results against the oracle) and NO fast-math (IEEE fp32 division and roundf decide the
 integer codes).
 """
+import glob
+import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
-SRC = os.path.join(HERE, "fakequant.hip")
 OUT = os.path.join(HERE, "libfakequant.so")
+OBJ_DIR = os.path.join(HERE, "build")
 INCLUDE = os.path.join(ROOT, "include")
 ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+         "-Wno-unused-function", "-I", INCLUDE, "-I", HERE]
 
 
 def hipcc():
@@ -25,28 +34,64 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def command(out=OUT):
-    return [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-            "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I", INCLUDE, SRC, "-o", out]
+def sources():
+    return sorted(glob.glob(os.path.join(HERE, "fq_*.hip")))
 
 
-def up_to_date():
-    if not os.path.exists(OUT):
-        return False
-    deps = [SRC, os.path.join(INCLUDE, "fakequant.h"), os.path.abspath(__file__)]
-    return all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)
+def headers():
+    return sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(INCLUDE, "fakequant.h"),
+                                                           os.path.abspath(__file__)]
 
 
-def build_library(force=False, verbose=True):
-    if not force and up_to_date():
-        return OUT
-    cmd = command()
+def _newer(target, deps):
+    return os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
+
+
+def up_to_date(out=OUT):
+    return _newer(out, sources() + headers())
+
+
+def _run(cmd, verbose):
     if verbose:
         print("[build] " + " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+
+
+def build_library(force=False, verbose=True, defines=(), out=OUT, amalgamate=False, jobs=None):
+    """Returns the path of the library.  `defines` (e.g. ["-DFQ_PW_TRACE"]) select a separate object directory."""
+    defines = list(defines)
+    if not force and not defines and out == OUT and up_to_date(out):
+        return out
+    tag = hashlib.sha1(" ".join(defines).encode()).hexdigest()[:8] if defines else "default"
+    objdir = os.path.join(OBJ_DIR, tag)
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    hdrs = headers()
+    if amalgamate:
+        unit = os.path.join(objdir, "fq_all.hip")
+        with open(unit, "w") as f:
+            for s in sources():
+                f.write('#include "%s"\n' % os.path.basename(s))
+        _run([cc] + FLAGS + defines + ["-shared", unit, "-o", out], verbose)
+        return out
+    todo, objs = [], []
+    for s in sources():
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not _newer(o, [s] + hdrs):
+            todo.append([cc] + FLAGS + defines + ["-c", s, "-o", o])
+    jobs = jobs or min(len(todo) or 1, os.cpu_count() or 4)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(lambda c: _run(c, verbose), todo))
+    _run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", out], verbose)
+    return out
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
-    print(OUT)
+    argv = sys.argv[1:]
+    out = OUT
+    if "-o" in argv:
+        out = os.path.abspath(argv[argv.index("-o") + 1])
+    build_library(force="--force" in argv, defines=[a for a in argv if a.startswith("-D")], out=out,
+                  amalgamate="--amalgamate" in argv)
+    print(out)

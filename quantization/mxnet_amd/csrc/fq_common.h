@@ -1,0 +1,442 @@
+// libfakequant — internal header shared by every translation unit of the library (not installed; the public boundary
+// is include/fakequant.h).  Host-side state that must exist once (error text, event records, per-device CU counts,
+// streaming policy) lives in namespace fqi and is defined in fq_core.hip; everything device-side is header-only and sits
+// in an anonymous namespace, so each translation unit carries its own copy and no relocatable device code is needed.
+//
+// Translation units (csrc/build.py compiles them in parallel and links libfakequant.so):
+//   fq_core.hip        errors, event timing (fq_profile_*), device info, streaming policy
+//   fq_stream.hip      K1 per-sample statistic, K1b batch means, K2 fake-quant apply, K2b BatchNorm+activation+statistic,
+//                      K11 global average pool + statistic, K12 evaluation counters
+//   fq_dwconv.hip      K2c/K2d/K2e depthwise 3x3 with quantise-on-load (LDS tiles / 1 column per lane / 4 columns per lane)
+//   fq_stem.hip        K2s first convolution 3x3 s2 (3 -> 32)
+//   fq_pw_stream.hip   K2h pointwise on int8 codes, weights resident in LDS
+//   fq_pw_chunk.hip    K2i pointwise, weights streamed through LDS in chunks
+//   fq_pw_tile.hip     K2j pointwise for few-tile layers, and the weight-code kernel (fq_weight_codes)
+//   fq_pw_generic.hip  K2f/K2g pointwise for every other shape (quantise+transpose + GEMM, or one LDS-panel launch)
+//   fq_pwconv.hip      fq_pwconv_i8: shape-based choice between the pointwise forms
+//   fq_weights.hip     K3 weight fake-quant (layer / group / channel), generic STE, K4 Winograd-domain weights
+//   fq_calib.hip       K5 EMA, K6 global max, K7 histogram, K8 KL threshold search
+//   fq_codes.hip       K9 int-code quantise / dequantise, K10 exact int8 GEMM (nn.Conv2D(quantized=True))
+//
+// Design rules applied throughout:
+//   * 64-wide wavefronts, 256-thread workgroups, 16 B per lane per access where the layout allows; streaming kernels keep
+//     8 independent loads in flight per lane and cap the grid at 8 workgroups per CU with contiguous work ranges;
+//   * per-sample statistics: lane-local max -> wavefront shuffle tree -> LDS -> ONE integer atomicMax per workgroup and
+//     sample (|x| >= 0, so the fp32 bit pattern orders like an unsigned int; same-address global atomics serialise in L2);
+//   * the batch statistic never leaves the device: every consumer re-derives mean -> scale in its prologue from the N
+//     per-sample maxima (wave-parallel fp64 sum, accepted only when the exponent spread proves every order exact);
+//   * arithmetic that decides an integer code is exactly the reference's clip -> IEEE fp32 divide -> roundf -> multiply by
+//     the epsilon-free scale, computed as v_med3 clamp, (float)((double)c * RN_f64(1/d)) (proven equal to the fp32
+//     quotient, see ieee_div_by) and trunc(Q + copysign(pred(0.5), Q)) (checked exhaustively); compiled with
+//     -ffp-contract=off and without fast-math so nothing is fused or re-associated behind the oracle's back;
+//   * the 1x1 convolutions multiply the integer CODES on the int8 matrix cores (exact int32 sums); everything else is
+//     elementwise / reduction / small-stencil work bounded by HBM or by instruction issue;
+//   * hipcc's scheduler is kept honest in the hand-pipelined loops with FQ_PIN (asm memory clobber + sched_barrier) and
+//     empty "+v" asm pins (it otherwise sinks arithmetic below prefetches or hoists every load of an unrolled loop).
+#ifndef FQ_COMMON_H_
+#define FQ_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "fakequant.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side state shared by all translation units (defined in fq_core.hip)
+// ---------------------------------------------------------------------------------------------------------------
+namespace fqi {
+
+int fail(int code, const char* fmt, ...);           // records the thread-local error text, returns `code`
+int num_cu();                                       // compute units of the CURRENT device (cached per device)
+int env_int(const char* name, int dflt);
+int stream_policy(int kernel_id, int64_t numel);    // kPol* bits by kernel and tensor size
+
+struct ProfRec {
+  int kid;
+  double bytes;
+  hipEvent_t a, b;
+};
+extern bool g_prof_on;
+void prof_push(const ProfRec& r);
+
+// Brackets the launches of one entry point with two events on the launch stream while fq_profile_enable(1) is set.
+struct ProfScope {
+  bool on;
+  ProfRec r;
+  hipStream_t st;
+  ProfScope(int kid, double bytes, hipStream_t s) : on(g_prof_on), st(s) {
+    if (!on) return;
+    r.kid = kid;
+    r.bytes = bytes;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(r.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, st);
+    prof_push(r);
+  }
+};
+
+// defined in fq_stream.hip; used by the weight paths too
+int launch_absmax(const float* x, int64_t n, int64_t inner, bool use_abs, float* out, hipStream_t st);
+int init_stat(float* p, int64_t n, bool use_abs, hipStream_t st);
+
+}  // namespace fqi
+
+#define FQ_HIP(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) return fqi::fail(FQ_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));       \
+  } while (0)
+#define FQ_REQUIRE(cond, ...)                                      \
+  do {                                                             \
+    if (!(cond)) return fqi::fail(FQ_ERR_INVALID, __VA_ARGS__);    \
+  } while (0)
+#define FQ_LAUNCH_CHECK() FQ_HIP(hipGetLastError())
+
+// Ordering fence for hand-pipelined loops: the asm memory clobber stops IR-level motion of loads, the sched_barrier the
+// machine scheduler's (it sinks prefetches next to their use, or hoists every load of an unrolled loop to the top).
+#define FQ_PIN()                         \
+  do {                                   \
+    asm volatile("" ::: "memory");        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+
+namespace {
+
+using namespace fqi;
+
+constexpr int kBlock = 256;                       // 4 wavefronts
+constexpr int kVec = 4;                           // floats per lane per access (16 B)
+constexpr int kUnroll = 8;                        // independent 16 B accesses in flight per lane
+constexpr int kChunk = kBlock * kVec * kUnroll;   // 8192 floats = 32 KiB per workgroup step
+constexpr int kMaxBlocksPerCU = 8;
+constexpr float kEps = 1e-10f;                    // ste_func.py:39,41
+
+inline int grid_for(int64_t work_items) {
+  int64_t cap = (int64_t)num_cu() * kMaxBlocksPerCU;
+  int64_t g = work_items < cap ? work_items : cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline float act_levels(int width, unsigned flags) {
+  return (flags & FQ_ACT_SIGNED) ? (float)((1 << (width - 1)) - 1) : (float)((1 << width) - 1);
+}
+
+struct Chunking {
+  int chunks_per_sample;
+  int64_t total;
+};
+inline Chunking chunking(int64_t n, int64_t inner, int chunk = kChunk) {
+  Chunking c;
+  c.chunks_per_sample = (int)((inner + chunk - 1) / chunk);
+  c.total = n * c.chunks_per_sample;
+  return c;
+}
+// Small tensors: 32 KiB steps would leave most CUs with < 1 workgroup; use 8 KiB steps (2 accesses in flight per
+// lane) once the tensor has fewer 32 KiB chunks than 8 workgroups per CU.
+constexpr int kSmallUnroll = 2;
+constexpr int kSmallChunk = kBlock * kVec * kSmallUnroll;
+inline bool use_small_chunks(int64_t n, int64_t inner) {
+  return chunking(n, inner).total < (int64_t)num_cu() * kMaxBlocksPerCU;
+}
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// max over the workgroup; result valid in thread 0.  `red` = 4 floats of LDS.
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();                       // protect `red` against the previous step's readers
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  return v;
+}
+__device__ __forceinline__ float block_min(float v, float* red) {
+  v = wave_min(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) v = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+  return v;
+}
+
+// Order-preserving atomics on fp32 through integer atomics (no CAS loop).
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.0f)
+    atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+  if (v >= 0.0f)
+    atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else
+    atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+// Deterministic batch mean: fp64 accumulate in sample order, one rounding to fp32, fp32 divide (oracle: batch_mean).
+__device__ __forceinline__ float batch_mean_seq(const float* __restrict__ v, int n) {
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) acc += (double)v[i];
+  return (float)acc / (float)n;
+}
+
+// The same value computed by a whole (converged) wavefront: every kernel that takes the online statistic starts with
+// this, and the serial loop above cost each workgroup ~6 us before its first useful load (tools/pw_trace.py).
+// Lanes take strided partial sums and the wave tree-reduces them in fp64.  That changes the ORDER of the additions, so
+// the result is only accepted when order provably cannot matter: all finite non-zero inputs are integer multiples of
+// q = 2^(emin-23), so every partial sum of any subset is a multiple of q bounded by n * 2^(emax+1); when
+// (emax - emin) + 24 + ceil(log2 n) <= 53 all of them are exactly representable in fp64, i.e. every addition in every
+// order is exact.  Otherwise (statistics spread over > 2^20, Inf/NaN) the wave falls back to the serial loop.
+__device__ __forceinline__ float batch_mean_dev(const float* __restrict__ v, int n) {
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  unsigned emin = 255u, emax = 0u;
+  for (int i = lane; i < n; i += 64) {
+    const float f = v[i];
+    acc += (double)f;
+    unsigned e = (__float_as_uint(f) >> 23) & 0xFFu;
+    if ((__float_as_uint(f) & 0x7FFFFFFFu) != 0u) {
+      e = e < 1u ? 1u : e;                       // denormals share the lsb of exponent field 1
+      emin = e < emin ? e : emin;
+      emax = e > emax ? e : emax;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    acc += __shfl_xor(acc, off, 64);
+    const unsigned a = (unsigned)__shfl_xor((int)emin, off, 64), b = (unsigned)__shfl_xor((int)emax, off, 64);
+    emin = a < emin ? a : emin;
+    emax = b > emax ? b : emax;
+  }
+  const int logn = 32 - __clz(n > 1 ? n - 1 : 1);
+  const bool exact = emax == 0u || (emax < 255u && (int)(emax - emin) + 24 + logn <= 53);
+  if (!exact) return batch_mean_seq(v, n);
+  return (float)acc / (float)n;
+}
+
+struct QParams {
+  float lo, hi;      // clip bounds
+  float denom;       // scale + eps
+  float scale;       // multiply-back scale (no eps)
+  double rden;       // RN_f64(1 / denom), see ieee_div_by()
+};
+
+__device__ __forceinline__ QParams make_qparams(float max_, float levels, bool lo_neg_max, float eps) {
+  QParams q;
+  q.hi = max_;
+  q.lo = lo_neg_max ? -max_ : 0.0f;
+  q.scale = max_ / levels;
+  q.denom = q.scale + eps;
+  q.rden = 1.0 / (double)q.denom;
+  return q;
+}
+
+// Correctly rounded fp32 quotient c / d for a divisor that is the same for the whole kernel, in 3 instructions instead
+// of the ~11 of the IEEE division expansion:  (float)((double)c * RN_f64(1/d))  ==  RN_f32(c / d)  for ALL fp32 c, d.
+// Proof sketch: the double product carries a relative error <= 2^-52, while the exact quotient of two fp32 numbers is
+// either an fp32 number or at least 2^-49 (relative) away from every fp32 rounding midpoint (c - M*d is a non-zero
+// integer multiple of 2^(g+b) for a 25-bit midpoint M = N*2^g and d = D*2^b), so the product falls on the same side of
+// every midpoint as the exact quotient and the final conversion rounds it to the same fp32 number.  0/0 and x/0 behave
+// as in IEEE (rden = inf).  Checked exhaustively around every .5 tie in tests/test_gpu_parity.py.
+__device__ __forceinline__ float ieee_div_by(float c, double rden) { return (float)((double)c * rden); }
+
+// The integer stage and the dequantised value (ste_func.py:41): clip -> IEEE divide -> roundf -> multiply.
+// roundf(Q) (half away from zero) == trunc(Q + copysign(pred(0.5), Q)) for every fp32 |Q| < 2^23: the only fp32 whose
+// sum with 0.5 would round across an integer is pred(0.5), and pred(0.5) + pred(0.5) is exact (checked exhaustively for
+// |Q| <= 70000; codes are <= 65535).  3 instructions instead of roundf's 6; NaN and Inf pass through as with roundf.
+__device__ __forceinline__ float round_half_away(float Q) { return truncf(Q + __builtin_copysignf(0.49999997f, Q)); }
+
+// clip(x, lo, hi) in one instruction: v_med3_f32 is the median of three, i.e. the clamp when lo <= hi (always: hi = max_ >= 0,
+// lo = 0 or -max_); a NaN input yields lo, exactly as fminf(fmaxf(NaN, lo), hi) does.  (fmaxf/fminf cost three: the
+// compiler first canonicalises x with a v_max.)
+__device__ __forceinline__ float fq_clip(float x, const QParams& q) { return __builtin_amdgcn_fmed3f(x, q.lo, q.hi); }
+
+__device__ __forceinline__ float fq_code(float x, const QParams& q) {
+  float c = fq_clip(x, q);
+  return round_half_away(ieee_div_by(c, q.rden));
+}
+
+// The integer code itself, for the kernels that keep codes (int8 paths): the same value as (int)fq_code(x, q) in
+// fewer instructions — these kernels are instruction-bound, not HBM-bound (tools/pw_trace.py --ablate).
+// roundf(Q) == trunc(Q + copysign(pred(0.5), Q)) for every fp32 |Q| < 2^23 (checked exhaustively for |Q| <= 70000:
+// the only fp32 for which Q + 0.5 itself would round across an integer is pred(0.5), and pred(0.5) + pred(0.5) is exact).
+__device__ __forceinline__ int fq_code_int(float x, const QParams& q) {
+  const float c = fq_clip(x, q);
+  const float Q = ieee_div_by(c, q.rden);
+  return (int)(Q + __builtin_copysignf(0.49999997f, Q));
+}
+
+// Four codes -> one dword of int8.  `ubias` = 128 - zoff makes every code non-negative (unsigned codes are stored
+// re-centred by zoff = 128, signed ones as they are), so the bytes can be merged without masks; the final XOR turns
+// u = code + 128 back into the two's complement byte of code - zoff... i.e. (u ^ 0x80) == (u - 128) mod 256.
+__device__ __forceinline__ int pack4_codes(int k0, int k1, int k2, int k3, int ubias) {
+  unsigned u = (unsigned)(k0 + ubias);
+  u |= (unsigned)(k1 + ubias) << 8;
+  u |= (unsigned)(k2 + ubias) << 16;
+  u |= (unsigned)(k3 + ubias) << 24;
+  return (int)(u ^ 0x80808080u);
+}
+
+template <bool USE_ABS>
+__device__ __forceinline__ float stat_of(float v) {
+  return USE_ABS ? fabsf(v) : v;
+}
+template <bool USE_ABS>
+__device__ __forceinline__ float stat_init() {
+  return USE_ABS ? 0.0f : -INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K0: fill
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming helpers.  f4 is the native 16-byte vector (the nontemporal builtins want a native vector type).
+// Policy bits (host-chosen, see stream_policy()):
+//   kPolNtLoad   : x is dead after this pass -> nontemporal loads (do not displace other lines in L2 / Infinity Cache)
+//   kPolNtStore  : nontemporal stores of y
+//   kPolReverse  : walk each workgroup's chunk range backwards — the second pass of the online path starts with the
+//                  chunks the statistic pass read LAST, which are the ones still resident in the 256 MiB Infinity
+//                  Cache when the tensor is larger than it.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+constexpr int kPolNtLoad = 1, kPolNtStore = 2, kPolReverse = 4;
+
+template <bool NT>
+__device__ __forceinline__ f4 ld4(const f4* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st4(f4* p, f4 v) {
+  if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+__device__ __forceinline__ f4 fq_code4(f4 v, const QParams& q) {
+  f4 k;
+  k.x = fq_code(v.x, q);
+  k.y = fq_code(v.y, q);
+  k.z = fq_code(v.z, q);
+  k.w = fq_code(v.w, q);
+  return k;
+}
+
+template <bool USE_ABS>
+__device__ __forceinline__ float stat4(f4 v) {
+  return fmaxf(fmaxf(stat_of<USE_ABS>(v.x), stat_of<USE_ABS>(v.y)), fmaxf(stat_of<USE_ABS>(v.z), stat_of<USE_ABS>(v.w)));
+}
+
+// Each workgroup owns a CONTIGUOUS range of 32 KiB chunks; a chunk never spans two samples.  The lane-local running
+// maximum is carried across chunks and only reduced (shuffle tree -> LDS -> one atomic) when the sample changes.
+struct ChunkRange {
+  int64_t begin, end;   // [begin, end)
+};
+__device__ __forceinline__ ChunkRange block_range(int64_t total_chunks) {
+  const int64_t per = (total_chunks + gridDim.x - 1) / gridDim.x;
+  ChunkRange r;
+  r.begin = (int64_t)blockIdx.x * per;
+  r.end = r.begin + per < total_chunks ? r.begin + per : total_chunks;
+  return r;
+}
+
+__device__ __forceinline__ float act_rt(float v, int act) {
+  if (act == FQ_ACT_RELU) v = fmaxf(v, 0.0f);
+  if (act == FQ_ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+  return v;
+}
+
+#ifdef FQ_PW_TRACE
+// debug build only (tools/pw_trace.py; built as ONE translation unit, csrc/build.py --amalgamate -DFQ_PW_TRACE, so that
+// these symbols exist once): per-workgroup wall-clock stamps of the fused pointwise kernel's phases
+__device__ unsigned long long* g_pw_trace = nullptr;
+__device__ int g_pw_dbg = 0;          // experiments: 1 = skip the output stores, 2 = skip the activation loads
+#define PW_STAMP(i)                                                                       \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && g_pw_trace != nullptr) g_pw_trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define PW_STAMP(i) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6: global max / min-max (flat)
+// ---------------------------------------------------------------------------------------------------------------
+template <bool WANT_MIN, bool USE_ABS>
+__global__ __launch_bounds__(kBlock) void minmax_kernel(const float* __restrict__ x, int64_t numel, int vec_ok,
+                                                        float* __restrict__ out_min, float* __restrict__ out_max) {
+  __shared__ float red[4];
+  float mx = USE_ABS ? 0.0f : -INFINITY, mn = INFINITY;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  if (vec_ok) {
+    const float4* p = reinterpret_cast<const float4*>(x);
+    const int64_t nvec = numel / 4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+      float4 v = p[i];
+      mx = fmaxf(mx, fmaxf(fmaxf(stat_of<USE_ABS>(v.x), stat_of<USE_ABS>(v.y)),
+                           fmaxf(stat_of<USE_ABS>(v.z), stat_of<USE_ABS>(v.w))));
+      if (WANT_MIN) mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+    }
+    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
+      mx = fmaxf(mx, stat_of<USE_ABS>(x[i]));
+      if (WANT_MIN) mn = fminf(mn, x[i]);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
+      mx = fmaxf(mx, stat_of<USE_ABS>(x[i]));
+      if (WANT_MIN) mn = fminf(mn, x[i]);
+    }
+  }
+  mx = block_max(mx, red);
+  if (threadIdx.x == 0) atomic_max_f32(out_max, mx);
+  if (WANT_MIN) {
+    mn = block_min(mn, red);
+    if (threadIdx.x == 0) atomic_min_f32(out_min, mn);
+  }
+}
+
+
+}  // namespace
+
+#endif  // FQ_COMMON_H_

@@ -1,0 +1,156 @@
+// libfakequant — errors, event timing, device info, streaming policy
+// (see fq_common.h for the list of translation units and the design rules)
+#include "fq_common.h"
+
+namespace fqi {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---- optional per-kernel event timing (fq_profile_*) -----------------------------------------------------------
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+
+void prof_push(const ProfRec& r) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back(r);
+}
+
+// Compute units of the device the calling thread has current (the caller selects the device of its tensors before it
+// calls in; the grid caps follow that device).
+int num_cu() {
+  constexpr int kMaxDev = 64;
+  static int cache[kMaxDev] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+  if (cache[dev] == 0) {
+    hipDeviceProp_t prop;
+    int cu = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cu = prop.multiProcessorCount;
+    cache[dev] = cu > 0 ? cu : 256;
+  }
+  return cache[dev];
+}
+
+// Streaming policy, by kernel and tensor size.  Measured on MI355X (profiles/r1_policy_sweep.txt, r1_kbench.txt):
+// tensors that (with their output) fit the 256 MiB Infinity Cache want PLAIN loads/stores — the producer just left x
+// there and the consumer (the convolution) will find y there; larger tensors want nontemporal loads+stores in the apply
+// pass, and the online apply pass walks backwards to start on what the statistic pass read last.
+// FQ_POLICY_STAT / FQ_POLICY_ONLINE / FQ_POLICY_OFFLINE (integer OR of the kPol* bits) override for tuning runs;
+// FQ_POLICY_BIG_BYTES moves the size threshold.
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+constexpr int kPolNtLoad_ = 1, kPolNtStore_ = 2, kPolReverse_ = 4;   // = kPol* of fq_common.h
+int stream_policy(int kernel_id, int64_t numel) {
+  static const int ov_stat = env_int("FQ_POLICY_STAT", -1);
+  static const int ov_on = env_int("FQ_POLICY_ONLINE", -1);
+  static const int ov_off = env_int("FQ_POLICY_OFFLINE", -1);
+  static const int64_t big = (int64_t)env_int("FQ_POLICY_BIG_MB", 160) * 1000000;
+  const bool is_big = numel * (int64_t)sizeof(float) >= big;
+  switch (kernel_id) {
+    case FQ_KERNEL_STAT:
+      return ov_stat >= 0 ? ov_stat : 0;
+    case FQ_KERNEL_APPLY_ONLINE:
+      if (ov_on >= 0) return ov_on;
+      return is_big ? (kPolReverse_ | kPolNtLoad_ | kPolNtStore_) : kPolReverse_;
+    default:
+      if (ov_off >= 0) return ov_off;
+      return is_big ? (kPolNtLoad_ | kPolNtStore_) : 0;
+  }
+}
+
+}  // namespace fqi
+
+using namespace fqi;
+
+extern "C" {
+
+const char* fq_last_error(void) { return g_err; }
+int fq_version(void) { return 100; }
+
+int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront) {
+  int dev = 0;
+  FQ_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  FQ_HIP(hipGetDeviceProperties(&prop, dev));
+  if (arch != nullptr && arch_len > 0) {
+    strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (wavefront) *wavefront = prop.warpSize;
+  return FQ_OK;
+}
+
+int fq_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return FQ_OK;
+}
+
+int fq_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  return FQ_OK;
+}
+
+int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes) {
+  FQ_REQUIRE(kernel_id >= 0 && kernel_id < FQ_KERNEL_COUNT, "fq_profile_read: bad kernel id %d", kernel_id);
+  FQ_REQUIRE(total_ms && launches && total_bytes, "fq_profile_read: null pointer");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double ms = 0.0, bytes = 0.0;
+  int64_t cnt = 0;
+  for (auto& r : g_prof) {
+    if (r.kid != kernel_id) continue;
+    FQ_HIP(hipEventSynchronize(r.b));
+    float t = 0.f;
+    FQ_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t;
+    bytes += r.bytes;
+    ++cnt;
+  }
+  *total_ms = ms;
+  *launches = cnt;
+  *total_bytes = bytes;
+  return FQ_OK;
+}
+
+int fq_profile_calibrate(void* scratch, int repeats, double* median_ms, fqStream_t stream) {
+  FQ_REQUIRE(scratch && median_ms && repeats > 0 && repeats <= 4096, "fq_profile_calibrate: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  // Enqueue every bracketed launch back to back (a busy queue, like the timed region), synchronise once at the end.
+  std::vector<hipEvent_t> ev((size_t)repeats * 2);
+  for (auto& e : ev) FQ_HIP(hipEventCreate(&e));
+  for (int i = 0; i < repeats; ++i) {
+    FQ_HIP(hipEventRecord(ev[2 * i], st));
+    hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, (float*)scratch, (int64_t)1, 0.0f);
+    FQ_HIP(hipEventRecord(ev[2 * i + 1], st));
+  }
+  FQ_HIP(hipEventSynchronize(ev.back()));
+  std::vector<float> ts;
+  for (int i = 0; i < repeats; ++i) {
+    float t = 0.f;
+    FQ_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+    ts.push_back(t);
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  std::sort(ts.begin(), ts.end());
+  *median_ms = ts[ts.size() / 2];
+  return FQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,838 @@
+// libfakequant — K2c/K2d/K2e depthwise 3x3 with quantise-on-load
+// (see fq_common.h for the list of translation units and the design rules)
+#include "fq_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2c: depthwise 3x3 (pad 1, stride S) with quantise-on-load and BN / activation / statistic epilogue.
+// A workgroup step ("tile") is P whole planes (small planes) or a strip of output rows of one plane (large planes).
+// The input rows of a tile are contiguous in memory: they are read once, coalesced (16 B per lane), quantised ONCE per
+// element and staged into an LDS tile that carries a zero border, so the 9-tap loop has no bounds checks.  In the
+// compute phase consecutive lanes own consecutive output COLUMNS (conflict-free LDS reads, coalesced stores) and slide
+// down a segment of rows keeping the 3x3 window in registers: 3 new LDS values per output (6 for stride 2).
+// ---------------------------------------------------------------------------------------------------------------
+struct DwGeom {
+  int C, H, W, Ho, Wo;
+  int P;        // planes per tile (whole-plane mode) or 1
+  int TR;       // output rows per tile
+  int strips;   // tiles per plane along rows (1 in whole-plane mode)
+  int IR;       // LDS rows per plane (TR*S + 2)
+  int WS;       // LDS row stride (>= W + 2)
+  int nseg;     // row segments per tile in the compute phase
+  int RS;       // output rows per segment
+  int vec_in;   // 16-byte loads allowed
+};
+
+template <int S, bool QUANT, bool ONLINE>
+__global__ __launch_bounds__(kBlock) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           DwGeom g, int64_t tiles, const float* __restrict__ in_stat,
+                                                           int n, const float* __restrict__ in_thr, float levels,
+                                                           int lo_neg_max, float eps,
+                                                           float* __restrict__ cur_max_out,
+                                                           const float* __restrict__ bn_scale,
+                                                           const float* __restrict__ bn_shift, int act,
+                                                           float* __restrict__ stat_out) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ float red[4];
+  QParams q;
+  q.lo = q.hi = q.denom = q.scale = 0.0f;
+  q.rden = 0.0;
+  if (QUANT) {
+    const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  }
+  const int lds_elems = g.P * g.IR * g.WS;
+  const int plane_in = g.H * g.W, plane_out = g.Ho * g.Wo;
+  const bool has_bn = bn_scale != nullptr;
+  const bool has_stat = stat_out != nullptr;
+
+  const ChunkRange rg = block_range(tiles);
+  for (int64_t t = rg.begin; t < rg.end; ++t) {
+    const int64_t pg = t / g.strips;                   // plane group
+    const int strip = (int)(t - pg * g.strips);
+    const int64_t plane0 = pg * g.P;                   // first (n*C + c) plane of the tile
+    const int ch0 = (int)(plane0 % g.C);               // P divides C: the tile's planes are ch0 .. ch0+P-1 of ONE sample
+    const int orow0 = strip * g.TR;                    // first output row
+    const int orows = (g.Ho - orow0) < g.TR ? (g.Ho - orow0) : g.TR;
+    const int irow_first = orow0 * S - 1;              // input row held by LDS row 0 (may be -1)
+    const int r_lo = irow_first < 0 ? 0 : irow_first;
+    int r_hi = irow_first + g.IR - 1;
+    if (r_hi > g.H - 1) r_hi = g.H - 1;
+
+    __syncthreads();                                   // previous tile fully consumed
+    for (int i = threadIdx.x * 4; i < lds_elems; i += kBlock * 4)
+      *reinterpret_cast<f4*>(tile + i) = (f4){0.f, 0.f, 0.f, 0.f};     // (allocation is padded to a multiple of 4)
+    __syncthreads();
+    // ---- load + quantise + stage: rows [r_lo, r_hi] of P consecutive planes -------------------------------------
+    // whole-plane mode: r_lo = 0, r_hi = H-1 and the P planes are one contiguous range; strip mode: P = 1.
+    {
+      const float* src = x + plane0 * (int64_t)plane_in + (int64_t)r_lo * g.W;
+      const int rows_per_plane = r_hi - r_lo + 1;
+      const int cnt = (g.P > 1) ? g.P * plane_in : rows_per_plane * g.W;
+      const unsigned W = (unsigned)g.W, RP = (unsigned)rows_per_plane;
+      if (g.vec_in) {
+        const f4* p4 = reinterpret_cast<const f4*>(src);
+        for (int i = threadIdx.x; i < cnt / 4; i += kBlock) {
+          f4 v = p4[i];
+          if (QUANT) v = fq_code4(v, q) * q.scale;
+          const unsigned e = (unsigned)i * 4u;
+          unsigned row = e / W;                                   // row index over the tile's planes
+          unsigned col = e - row * W;
+          unsigned pl = row / RP;
+          unsigned r = row - pl * RP;
+          float* d = tile + (pl * g.IR + (r + r_lo - irow_first)) * g.WS + col + 1;
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            d[0] = vv[k];
+            ++d;
+            if (++col == W) {                                     // next row (possibly next plane)
+              col = 0;
+              if (++r == RP) { r = 0; ++pl; }
+              d = tile + (pl * g.IR + (r + r_lo - irow_first)) * g.WS + 1;
+            }
+          }
+        }
+      } else {
+        for (int i = threadIdx.x; i < cnt; i += kBlock) {
+          float v = src[i];
+          if (QUANT) v = fq_code(v, q) * q.scale;
+          const unsigned row = (unsigned)i / W;
+          const unsigned col = (unsigned)i - row * W;
+          const unsigned pl = row / RP;
+          const unsigned r = row - pl * RP;
+          tile[(pl * g.IR + (r + r_lo - irow_first)) * g.WS + col + 1] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- sliding 3x3 window down a row segment; lane <-> output column ------------------------------------------
+    float m = 0.0f;
+    const int items = g.P * g.nseg * g.Wo;
+    for (int it = threadIdx.x; it < items; it += kBlock) {
+      const unsigned ps = (unsigned)it / (unsigned)g.Wo;
+      const unsigned col = (unsigned)it - ps * (unsigned)g.Wo;
+      const unsigned pl = ps / (unsigned)g.nseg;
+      const unsigned seg = ps - pl * (unsigned)g.nseg;
+      const int rr0 = (int)seg * g.RS;
+      int rr1 = rr0 + g.RS;
+      if (rr1 > orows) rr1 = orows;
+      if (rr0 >= rr1) continue;
+      const int ch = ch0 + (int)pl;
+      const float* wk = wgt + ch * 9;
+      const float w00 = wk[0], w01 = wk[1], w02 = wk[2], w10 = wk[3], w11 = wk[4], w12 = wk[5], w20 = wk[6],
+                  w21 = wk[7], w22 = wk[8];
+      const float bch = bias != nullptr ? bias[ch] : 0.0f;
+      const float bsc = has_bn ? bn_scale[ch] : 1.0f, bsh = has_bn ? bn_shift[ch] : 0.0f;
+      const float* l = tile + (pl * g.IR + rr0 * S) * g.WS + col * S;       // LDS col 0 == input col -1
+      float a0 = l[0], a1 = l[1], a2 = l[2];
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+      if (S == 1) {
+        b0 = l[g.WS];
+        b1 = l[g.WS + 1];
+        b2 = l[g.WS + 2];
+      }
+      float* dst = y + (plane0 + pl) * (int64_t)plane_out + (int64_t)(orow0 + rr0) * g.Wo + col;
+      for (int r = rr0; r < rr1; ++r) {
+        float c0, c1, c2;
+        if (S == 1) {
+          const float* lc = l + 2 * g.WS;
+          c0 = lc[0]; c1 = lc[1]; c2 = lc[2];
+        } else {
+          const float* lb = l + g.WS;
+          b0 = lb[0]; b1 = lb[1]; b2 = lb[2];
+          const float* lc = lb + g.WS;
+          c0 = lc[0]; c1 = lc[1]; c2 = lc[2];
+        }
+        float acc = 0.0f;
+        acc = fmaf(w00, a0, acc);
+        acc = fmaf(w01, a1, acc);
+        acc = fmaf(w02, a2, acc);
+        acc = fmaf(w10, b0, acc);
+        acc = fmaf(w11, b1, acc);
+        acc = fmaf(w12, b2, acc);
+        acc = fmaf(w20, c0, acc);
+        acc = fmaf(w21, c1, acc);
+        acc = fmaf(w22, c2, acc);
+        if (bias != nullptr) acc = acc + bch;
+        if (has_bn) {
+          acc = acc * bsc;
+          acc = acc + bsh;
+        }
+        acc = act_rt(acc, act);
+        *dst = acc;
+        m = fmaxf(m, fabsf(acc));
+        dst += g.Wo;
+        l += S * g.WS;
+        if (S == 1) {
+          a0 = b0; a1 = b1; a2 = b2;
+          b0 = c0; b1 = c1; b2 = c2;
+        } else {
+          a0 = c0; a1 = c1; a2 = c2;
+        }
+      }
+    }
+    if (has_stat) {
+      m = block_max(m, red);
+      if (threadIdx.x == 0) atomic_max_f32(stat_out + plane0 / g.C, m);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2d: depthwise 3x3, register sliding-window form (no LDS, no barriers).  A wavefront holds `segs` independent
+// SEGMENTS; a segment is `sw` adjacent output columns of one plane plus halo lanes (stride 1: one on each side, stride
+// 2: one on the left).  Every lane streams ITS input column(s) top to bottom — one coalesced 4-byte load per lane per
+// input row, quantised once — and gets its horizontal neighbours from the adjacent lanes with wavefront shuffles; the
+// three live input rows stay in registers, loads run D rows ahead of their use.
+// ---------------------------------------------------------------------------------------------------------------
+struct DwColGeom {
+  int C, H, W, Ho, Wo;
+  int sw;       // output columns per segment
+  int nsegx;    // segments per plane row
+  int SEG;      // lanes per segment (sw + halo lanes)
+  int segs;     // segments per wavefront
+};
+
+template <int S, bool QUANT, bool ONLINE>
+__global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
+    const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
+    float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
+    const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
+  // output rows of input kept in flight (S=2: 4 loads per row).  (16 / 8 - every row of a 14x14 plane in flight at
+  // once - measured SLOWER on the same box: 38 vs 36 us per 512x14x14 layer.)
+  constexpr int D = (S == 1) ? 8 : 4;
+  constexpr int kStatSlots = 16;
+  __shared__ unsigned k_stat[kStatSlots];
+  if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
+  PW_STAMP(0);
+  QParams q;
+  q.lo = q.hi = q.denom = q.scale = 0.0f;
+  q.rden = 0.0;
+  if (QUANT) {
+    const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  }
+  PW_STAMP(1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg_in_wave = lane / g.SEG;
+  const int pos = lane - seg_in_wave * g.SEG;
+  const bool lane_used = seg_in_wave < g.segs;
+  const int64_t segs_per_block = (int64_t)g.segs * (kBlock / 64);
+  const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
+  const int plane_in = g.H * g.W, plane_out = g.Ho * g.Wo;
+
+  // (Row strips per plane were tried for load balance and measured slower: every strip restarts the prefetch ring.)
+  // A workgroup takes a CONTIGUOUS range of blocks (few samples -> a small LDS statistic table, one flush) and its
+  // wavefronts run through them without barriers.  Index arithmetic is unsigned 32-bit (host: total_segs < 2^31): the
+  // 64-bit divisions it replaces cost each block 2.3 us (tools/dw_trace.py).
+  const unsigned nblk_u = (unsigned)nblk, tsegs = (unsigned)total_segs, nsegx = (unsigned)g.nsegx, C_u = (unsigned)g.C;
+  const unsigned blk_begin = (unsigned)((uint64_t)nblk_u * blockIdx.x / gridDim.x);
+  const unsigned blk_end = (unsigned)((uint64_t)nblk_u * (blockIdx.x + 1) / gridDim.x);
+  const unsigned n_samples = tsegs / nsegx / C_u;
+  unsigned s_base;
+  {
+    const unsigned seg0 = blk_begin * (unsigned)segs_per_block;
+    s_base = (seg0 < tsegs ? seg0 : tsegs - 1) / nsegx / C_u;
+  }
+  __syncthreads();                                       // statistic table zeroed
+  for (unsigned blk = blk_begin; blk < blk_end; ++blk) {
+    const unsigned seg = blk * (unsigned)segs_per_block + (unsigned)wave * (unsigned)g.segs + (unsigned)seg_in_wave;
+    const bool seg_ok = lane_used && seg < tsegs;
+    const unsigned plane = seg_ok ? seg / nsegx : 0u;
+    const int sx = seg_ok ? (int)(seg - plane * nsegx) : 0;
+    const unsigned sample_u = plane / C_u;
+    const int ch = (int)(plane - sample_u * C_u);
+    const int sample = (int)sample_u;
+    // column bookkeeping
+    int oc, ic0;                                          // output column; first input column this lane loads
+    bool is_out;
+    if (S == 1) {
+      ic0 = sx * g.sw + pos - 1;                          // pos 0 / sw+1 are the halo lanes
+      oc = ic0;
+      is_out = seg_ok && pos >= 1 && pos <= g.sw && oc < g.Wo;
+    } else {
+      oc = sx * g.sw + pos - 1;                           // pos 0 is the left-halo lane
+      ic0 = 2 * oc;                                       // this lane loads input columns 2*oc and 2*oc + 1
+      is_out = seg_ok && pos >= 1 && oc < g.Wo;
+    }
+    const bool ld0 = seg_ok && (S == 1 ? (ic0 >= 0 && ic0 < g.W) : (pos >= 1 && ic0 < g.W));
+    const bool ld1 = seg_ok && S == 2 && (ic0 + 1 >= 0) && (ic0 + 1 < g.W);     // stride 2: second column (halo lane: col 2*sx*sw - 1)
+    const float* xp = x + plane * (int64_t)plane_in + ic0;
+    float* yp = y + plane * (int64_t)plane_out + oc;
+    const float* wk = wgt + ch * 9;
+    const float w00 = wk[0], w01 = wk[1], w02 = wk[2], w10 = wk[3], w11 = wk[4], w12 = wk[5], w20 = wk[6],
+                w21 = wk[7], w22 = wk[8];
+    const float bch = bias != nullptr ? bias[ch] : 0.0f;
+    const float bsc = has_bn ? bn_scale[ch] : 1.0f, bsh = has_bn ? bn_shift[ch] : 0.0f;
+    float m = 0.0f;
+    if (blk == blk_begin) PW_STAMP(2);
+
+    // Loads are UNCONDITIONAL from clamped (always valid) addresses and masked afterwards with a bitwise AND — a
+    // `cond ? load : 0` select is turned back into a predicated load by hipcc (CodeGenPrepare sinks the load under a
+    // branch), which then waits vmcnt(0) right behind it and the prefetch ring is gone.
+    const int last_row = g.H - 1;
+    auto keep = [](float v, bool ok) -> float { return __uint_as_float(__float_as_uint(v) & (ok ? 0xFFFFFFFFu : 0u)); };
+    if (S == 1) {
+      // rows: a = input row r-1, b = row r, c = row r+1 (each as left / centre / right)
+      const float* xs = ld0 ? xp : x;                      // lanes with nothing to load read element 0
+      auto ldrow = [&](int row) -> float {
+        const int rc = row < last_row ? row : last_row;
+        return keep(xs[(int64_t)rc * g.W], ld0 && row <= last_row);
+      };
+      auto emit = [&](int r, float c1, float& a0, float& a1, float& a2, float& b0, float& b1, float& b2) {
+        if (QUANT) c1 = fq_code(c1, q) * q.scale;
+        const float c0 = __shfl_up(c1, 1, 64), c2 = __shfl_down(c1, 1, 64);
+        float acc = 0.0f;
+        acc = fmaf(w00, a0, acc);
+        acc = fmaf(w01, a1, acc);
+        acc = fmaf(w02, a2, acc);
+        acc = fmaf(w10, b0, acc);
+        acc = fmaf(w11, b1, acc);
+        acc = fmaf(w12, b2, acc);
+        acc = fmaf(w20, c0, acc);
+        acc = fmaf(w21, c1, acc);
+        acc = fmaf(w22, c2, acc);
+        if (bias != nullptr) acc = acc + bch;
+        if (has_bn) {
+          acc = acc * bsc;
+          acc = acc + bsh;
+        }
+        acc = act_rt(acc, act);
+        m = fmaxf(m, keep(fabsf(acc), is_out));
+        if (is_out) yp[(int64_t)r * g.Wo] = acc;
+        a0 = b0; a1 = b1; a2 = b2;
+        b0 = c0; b1 = c1; b2 = c2;
+      };
+      float raw[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) raw[k] = ldrow(1 + k);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      float b1 = ldrow(0);
+      if (QUANT) b1 = fq_code(b1, q) * q.scale;
+      float b0 = __shfl_up(b1, 1, 64), b2 = __shfl_down(b1, 1, 64);
+      const int rend = g.Ho;                              // same trip count for every lane of the grid
+      int r0 = 0;
+      for (; r0 + D <= rend; r0 += D) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float c1 = raw[k];
+          raw[k] = ldrow(r0 + k + 1 + D);
+          emit(r0 + k, c1, a0, a1, a2, b0, b1, b2);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (r0 + k < rend) emit(r0 + k, raw[k], a0, a1, a2, b0, b1, b2);
+    } else {
+      // stride 2: output row r uses input rows 2r-1 (a), 2r (b), 2r+1 (c); per input row: left = neighbour's 2nd
+      // column, centre = own 1st column, right = own 2nd column
+      const float* xs0 = ld0 ? xp : x;
+      const float* xs1 = ld1 ? xp + 1 : x;
+      auto ld_a = [&](int row) -> float {
+        const int rc = row < last_row ? row : last_row;
+        return keep(xs0[(int64_t)rc * g.W], ld0 && row <= last_row);
+      };
+      auto ld_b = [&](int row) -> float {
+        const int rc = row < last_row ? row : last_row;
+        return keep(xs1[(int64_t)rc * g.W], ld1 && row <= last_row);
+      };
+      auto emit2 = [&](int r, float b1, float b2, float c1, float c2, float& a0, float& a1, float& a2) {
+        if (QUANT) {
+          b1 = fq_code(b1, q) * q.scale;
+          b2 = fq_code(b2, q) * q.scale;
+          c1 = fq_code(c1, q) * q.scale;
+          c2 = fq_code(c2, q) * q.scale;
+        }
+        const float b0 = __shfl_up(b2, 1, 64), c0 = __shfl_up(c2, 1, 64);
+        float acc = 0.0f;
+        acc = fmaf(w00, a0, acc);
+        acc = fmaf(w01, a1, acc);
+        acc = fmaf(w02, a2, acc);
+        acc = fmaf(w10, b0, acc);
+        acc = fmaf(w11, b1, acc);
+        acc = fmaf(w12, b2, acc);
+        acc = fmaf(w20, c0, acc);
+        acc = fmaf(w21, c1, acc);
+        acc = fmaf(w22, c2, acc);
+        if (bias != nullptr) acc = acc + bch;
+        if (has_bn) {
+          acc = acc * bsc;
+          acc = acc + bsh;
+        }
+        acc = act_rt(acc, act);
+        m = fmaxf(m, keep(fabsf(acc), is_out));
+        if (is_out) yp[(int64_t)r * g.Wo] = acc;
+        a0 = c0; a1 = c1; a2 = c2;
+      };
+      float rb0[D], rb1[D], rc0[D], rc1[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        rb0[k] = ld_a(2 * k);
+        rb1[k] = ld_b(2 * k);
+        rc0[k] = ld_a(2 * k + 1);
+        rc1[k] = ld_b(2 * k + 1);
+      }
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      const int rend = g.Ho;
+      int r0 = 0;
+      for (; r0 + D <= rend; r0 += D) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float b1 = rb0[k], b2 = rb1[k], c1 = rc0[k], c2 = rc1[k];
+          const int rn = r0 + k + D;
+          rb0[k] = ld_a(2 * rn);
+          rb1[k] = ld_b(2 * rn);
+          rc0[k] = ld_a(2 * rn + 1);
+          rc1[k] = ld_b(2 * rn + 1);
+          emit2(r0 + k, b1, b2, c1, c2, a0, a1, a2);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (r0 + k < rend) emit2(r0 + k, rb0[k], rb1[k], rc0[k], rc1[k], a0, a1, a2);
+    }
+    if (blk == blk_begin) PW_STAMP(3);
+    if (has_stat) {
+      // per-wave update of the workgroup's LDS table (no barrier inside the block loop); flushed once at the end
+      const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane(sample);
+      const bool wave_uniform = __all(!is_out || (unsigned)sample == s0);
+      if (wave_uniform) {
+        const float wm = wave_max(is_out ? m : 0.0f);
+        if (lane == 0 && __float_as_uint(wm) != 0u) {
+          const unsigned slot = s0 - s_base;
+          if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+          else atomic_max_f32(stat_out + s0, wm);
+        }
+      } else if (is_out) {
+        const unsigned slot = (unsigned)sample - s_base;
+        if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+        else atomic_max_f32(stat_out + sample, m);
+      }
+    }
+  }
+  if (has_stat) {
+    __syncthreads();
+    if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < (unsigned)n_samples)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+  }
+  PW_STAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2e: the same sliding window with FOUR input columns per lane (16-byte loads, 16-byte stores for stride 1 / 8-byte
+// for stride 2) — needs W % 4 == 0.  With 4-byte accesses the kernel above cannot keep enough bytes in flight
+// (PMC: 38 % of wave cycles parked on vmcnt at 4.1 TB/s); this form has 4x the bytes per outstanding load.
+// Lane p of a segment: p = 0 left-halo lane, 1..L compute lanes (input columns 4(p-1)..4(p-1)+3), L+1 right-halo lane
+// (stride 1 only).  Halo lanes load and quantise like the others; their neighbours pick up .w / .x by shuffle.
+// ---------------------------------------------------------------------------------------------------------------
+template <int S, bool QUANT, bool ONLINE>
+__global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
+    const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
+    float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
+    const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
+  // Input rows are fetched in BURSTS of D rows (double buffered): the D loads of a burst leave the wave back to back
+  // and hit the same DRAM pages; one load per step (a ring) spreads them ~700 cycles apart, and with thousands of
+  // waves each streaming its own plane every access then opens a new page.
+#ifndef FQ_DW4_D1
+#define FQ_DW4_D1 4
+#define FQ_DW4_D2 2
+#endif
+  constexpr int D = (S == 1) ? FQ_DW4_D1 : FQ_DW4_D2;
+  constexpr int kStatSlots = 16;
+  __shared__ unsigned k_stat[kStatSlots];
+  if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
+  QParams q;
+  q.lo = q.hi = q.denom = q.scale = 0.0f;
+  q.rden = 0.0;
+  if (QUANT) {
+    const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg_in_wave = lane / g.SEG;
+  const int pos = lane - seg_in_wave * g.SEG;
+  const bool lane_used = seg_in_wave < g.segs;
+  const int64_t segs_per_block = (int64_t)g.segs * (kBlock / 64);
+  const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
+  const int plane_in = g.H * g.W, plane_out = g.Ho * g.Wo;
+  const int last_row = g.H - 1;
+  auto keep4 = [](f4 v, bool ok) -> f4 {
+    const unsigned mk = ok ? 0xFFFFFFFFu : 0u;
+    f4 r;
+    r.x = __uint_as_float(__float_as_uint(v.x) & mk);
+    r.y = __uint_as_float(__float_as_uint(v.y) & mk);
+    r.z = __uint_as_float(__float_as_uint(v.z) & mk);
+    r.w = __uint_as_float(__float_as_uint(v.w) & mk);
+    return r;
+  };
+  auto keep = [](float v, bool ok) -> float { return __uint_as_float(__float_as_uint(v) & (ok ? 0xFFFFFFFFu : 0u)); };
+
+  // A workgroup takes a CONTIGUOUS range of blocks (few samples -> a small LDS statistic table, one flush) and its
+  // wavefronts run through them without barriers.  Index arithmetic is unsigned 32-bit (host: total_segs < 2^31): the
+  // 64-bit divisions it replaces cost each block 2.3 us (tools/dw_trace.py).
+  const unsigned nblk_u = (unsigned)nblk, tsegs = (unsigned)total_segs, nsegx = (unsigned)g.nsegx, C_u = (unsigned)g.C;
+  const unsigned blk_begin = (unsigned)((uint64_t)nblk_u * blockIdx.x / gridDim.x);
+  const unsigned blk_end = (unsigned)((uint64_t)nblk_u * (blockIdx.x + 1) / gridDim.x);
+  const unsigned n_samples = tsegs / nsegx / C_u;
+  unsigned s_base;
+  {
+    const unsigned seg0 = blk_begin * (unsigned)segs_per_block;
+    s_base = (seg0 < tsegs ? seg0 : tsegs - 1) / nsegx / C_u;
+  }
+  __syncthreads();                                       // statistic table zeroed
+  for (unsigned blk = blk_begin; blk < blk_end; ++blk) {
+    const unsigned seg = blk * (unsigned)segs_per_block + (unsigned)wave * (unsigned)g.segs + (unsigned)seg_in_wave;
+    const bool seg_ok = lane_used && seg < tsegs;
+    const unsigned plane = seg_ok ? seg / nsegx : 0u;
+    const int sx = seg_ok ? (int)(seg - plane * nsegx) : 0;
+    const unsigned sample_u = plane / C_u;
+    const int ch = (int)(plane - sample_u * C_u);
+    const int sample = (int)sample_u;
+    const int ic0 = (sx * g.sw + pos - 1) * 4;            // first of the 4 input columns this lane loads
+    const bool ld_ok = seg_ok && ic0 >= 0 && ic0 < g.W;
+    const int oc = S == 1 ? ic0 : ic0 / 2;                // first output column (4 outputs for S=1, 2 for S=2)
+    const bool is_out = seg_ok && pos >= 1 && pos <= g.sw && oc < g.Wo;
+    const f4* xs = reinterpret_cast<const f4*>(ld_ok ? x + plane * (int64_t)plane_in + ic0 : x);
+    float* yp = y + plane * (int64_t)plane_out + oc;
+    const int rowq = g.W / 4;                             // f4 per input row
+    const float* wk = wgt + ch * 9;
+    const float w00 = wk[0], w01 = wk[1], w02 = wk[2], w10 = wk[3], w11 = wk[4], w12 = wk[5], w20 = wk[6],
+                w21 = wk[7], w22 = wk[8];
+    const float bch = bias != nullptr ? bias[ch] : 0.0f;
+    const float bsc = has_bn ? bn_scale[ch] : 1.0f, bsh = has_bn ? bn_shift[ch] : 0.0f;
+    float m = 0.0f;
+    auto ldrow = [&](int row) -> f4 {
+      const int rc = row < last_row ? row : last_row;
+      return keep4(xs[(int64_t)rc * rowq], ld_ok && row <= last_row);
+    };
+    auto quant4 = [&](f4 v) -> f4 { return QUANT ? fq_code4(v, q) * q.scale : v; };
+    auto finish = [&](float acc) -> float {
+      if (bias != nullptr) acc = acc + bch;
+      if (has_bn) {
+        acc = acc * bsc;
+        acc = acc + bsh;
+      }
+      return act_rt(acc, act);
+    };
+
+    if (S == 1) {
+      // a, b, c: rows r-1, r, r+1 as (left, v.x, v.y, v.z, v.w, right)
+      float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b[6];
+      f4 raw[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) raw[k] = ldrow(1 + k);
+      {
+        const f4 v = quant4(ldrow(0));
+        b[0] = __shfl_up(v.w, 1, 64);
+        b[1] = v.x; b[2] = v.y; b[3] = v.z; b[4] = v.w;
+        b[5] = __shfl_down(v.x, 1, 64);
+      }
+      auto emit = [&](int r, f4 craw) {
+        const f4 v = quant4(craw);
+        float c[6];
+        c[0] = __shfl_up(v.w, 1, 64);
+        c[1] = v.x; c[2] = v.y; c[3] = v.z; c[4] = v.w;
+        c[5] = __shfl_down(v.x, 1, 64);
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float acc = 0.0f;
+          acc = fmaf(w00, a[k], acc);
+          acc = fmaf(w01, a[k + 1], acc);
+          acc = fmaf(w02, a[k + 2], acc);
+          acc = fmaf(w10, b[k], acc);
+          acc = fmaf(w11, b[k + 1], acc);
+          acc = fmaf(w12, b[k + 2], acc);
+          acc = fmaf(w20, c[k], acc);
+          acc = fmaf(w21, c[k + 1], acc);
+          acc = fmaf(w22, c[k + 2], acc);
+          o[k] = finish(acc);
+        }
+        const float mm = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        m = fmaxf(m, keep(mm, is_out));
+        if (is_out) *reinterpret_cast<f4*>(yp + (int64_t)r * g.Wo) = (f4){o[0], o[1], o[2], o[3]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          a[k] = b[k];
+          b[k] = c[k];
+        }
+      };
+      int r0 = 0;
+      for (; r0 + D <= g.Ho; r0 += D) {
+        f4 nxt[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) nxt[k] = ldrow(r0 + k + 1 + D);
+#pragma unroll
+        for (int k = 0; k < D; ++k) emit(r0 + k, raw[k]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) raw[k] = nxt[k];
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (r0 + k < g.Ho) emit(r0 + k, raw[k]);
+    } else {
+      // stride 2: lane holds input columns 4j..4j+3 -> outputs 2j (cols 4j-1,4j,4j+1) and 2j+1 (cols 4j+1..4j+3)
+      float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};              // (left, x, y, z, w) of input row 2r-1
+      f4 rb[D], rc[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        rb[k] = ldrow(2 * k);
+        rc[k] = ldrow(2 * k + 1);
+      }
+      auto emit2 = [&](int r, f4 braw, f4 craw) {
+        const f4 vb = quant4(braw), vc = quant4(craw);
+        const float b[5] = {__shfl_up(vb.w, 1, 64), vb.x, vb.y, vb.z, vb.w};
+        const float c[5] = {__shfl_up(vc.w, 1, 64), vc.x, vc.y, vc.z, vc.w};
+        float o[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          float acc = 0.0f;
+          acc = fmaf(w00, a[2 * k], acc);
+          acc = fmaf(w01, a[2 * k + 1], acc);
+          acc = fmaf(w02, a[2 * k + 2], acc);
+          acc = fmaf(w10, b[2 * k], acc);
+          acc = fmaf(w11, b[2 * k + 1], acc);
+          acc = fmaf(w12, b[2 * k + 2], acc);
+          acc = fmaf(w20, c[2 * k], acc);
+          acc = fmaf(w21, c[2 * k + 1], acc);
+          acc = fmaf(w22, c[2 * k + 2], acc);
+          o[k] = finish(acc);
+        }
+        m = fmaxf(m, keep(fmaxf(fabsf(o[0]), fabsf(o[1])), is_out));
+        if (is_out) *reinterpret_cast<float2*>(yp + (int64_t)r * g.Wo) = make_float2(o[0], o[1]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a[k] = c[k];
+      };
+      int r0 = 0;
+      for (; r0 + D <= g.Ho; r0 += D) {
+        f4 nb[D], nc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          nb[k] = ldrow(2 * (r0 + k + D));
+          nc[k] = ldrow(2 * (r0 + k + D) + 1);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) emit2(r0 + k, rb[k], rc[k]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          rb[k] = nb[k];
+          rc[k] = nc[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (r0 + k < g.Ho) emit2(r0 + k, rb[k], rc[k]);
+    }
+    if (has_stat) {
+      // per-wave update of the workgroup's LDS table (no barrier inside the block loop); flushed once at the end
+      const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane(sample);
+      const bool wave_uniform = __all(!is_out || (unsigned)sample == s0);
+      if (wave_uniform) {
+        const float wm = wave_max(is_out ? m : 0.0f);
+        if (lane == 0 && __float_as_uint(wm) != 0u) {
+          const unsigned slot = s0 - s_base;
+          if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+          else atomic_max_f32(stat_out + s0, wm);
+        }
+      } else if (is_out) {
+        const unsigned slot = (unsigned)sample - s_base;
+        if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+        else atomic_max_f32(stat_out + sample, m);
+      }
+    }
+  }
+  if (has_stat) {
+    __syncthreads();
+    if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < (unsigned)n_samples)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+  }
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
+                 int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                 float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                 fqStream_t stream) {
+  FQ_REQUIRE(x && w && y, "fq_dwconv3x3: null pointer");
+  FQ_REQUIRE(n > 0 && c > 0 && h > 0 && wdt > 0 && n * c < (1ll << 31) && h * wdt < (1ll << 28),
+             "fq_dwconv3x3: bad shape (n=%lld c=%lld h=%lld w=%lld)", (long long)n, (long long)c, (long long)h,
+             (long long)wdt);
+  FQ_REQUIRE(stride == 1 || stride == 2, "fq_dwconv3x3: stride must be 1 or 2, got %d", stride);
+  FQ_REQUIRE(!(in_stat && in_thr), "fq_dwconv3x3: give in_stat (online) OR in_thr (offline), not both");
+  FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_dwconv3x3: bn_scale and bn_shift go together");
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_dwconv3x3: unknown activation %d", act);
+  const bool quant = in_stat != nullptr || in_thr != nullptr;
+  if (quant) FQ_REQUIRE(in_width >= 2 && in_width <= 16, "fq_dwconv3x3: width %d out of range", in_width);
+  hipStream_t st = (hipStream_t)stream;
+  static const int form = env_int("FQ_DW_FORM", 0);     // 0 auto, 1 LDS tiles, 2 sliding window 1 col/lane, 3: 4 cols/lane
+  const bool can4 = (wdt % 4 == 0) && aligned16(x) && aligned16(y) && ((h * wdt) % 4 == 0) &&
+                    (stride == 1 || ((wdt / 2) % 2 == 0));
+  if ((form == 3 || form == 0) && can4) {
+    DwColGeom cg;
+    cg.C = (int)c;
+    cg.H = (int)h;
+    cg.W = (int)wdt;
+    cg.Ho = (int)((h - 1) / stride + 1);
+    cg.Wo = (int)((wdt - 1) / stride + 1);
+    const int halo = stride == 1 ? 2 : 1;
+    const int quads = (int)(wdt / 4);                    // compute lanes per full row
+    const int max_sw = 64 - halo;
+    cg.nsegx = (quads + max_sw - 1) / max_sw;
+    cg.sw = (quads + cg.nsegx - 1) / cg.nsegx;           // compute lanes per segment
+    cg.SEG = cg.sw + halo;
+    cg.segs = 64 / cg.SEG;
+    const int64_t total_segs = n * c * cg.nsegx;
+    const int64_t segs_per_block = (int64_t)cg.segs * (kBlock / 64);
+    const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
+    FQ_REQUIRE(total_segs < (1ll << 31) - 1024, "fq_dwconv3x3: tensor too large for 32-bit segment indices");
+    // every workgroup resident at once (8 per CU), each walking a contiguous range of blocks
+    static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 8);
+    const int grid = (int)(nblk < (int64_t)num_cu() * dw_wg_per_cu ? nblk : (int64_t)num_cu() * dw_wg_per_cu);
+    const float levels = act_levels(in_width, in_flags);
+    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+    if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+    ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
+#define FQ_DWC4(SS, Q, O)                                                                                         \
+  hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, cg,       \
+                     total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,         \
+                     bn_shift, act, stat_out)
+    if (stride == 1) {
+      if (!quant) FQ_DWC4(1, false, false);
+      else if (in_stat) FQ_DWC4(1, true, true);
+      else FQ_DWC4(1, true, false);
+    } else {
+      if (!quant) FQ_DWC4(2, false, false);
+      else if (in_stat) FQ_DWC4(2, true, true);
+      else FQ_DWC4(2, true, false);
+    }
+#undef FQ_DWC4
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+  }
+  if (form == 2 || ((form == 0 || form == 3) && wdt >= 14)) {   // narrow planes (7x7): LDS staging coalesces better
+    DwColGeom cg;
+    cg.C = (int)c;
+    cg.H = (int)h;
+    cg.W = (int)wdt;
+    cg.Ho = (int)((h - 1) / stride + 1);
+    cg.Wo = (int)((wdt - 1) / stride + 1);
+    const int halo = stride == 1 ? 2 : 1;
+    const int max_sw = 64 - halo;
+    cg.nsegx = (cg.Wo + max_sw - 1) / max_sw;
+    cg.sw = (cg.Wo + cg.nsegx - 1) / cg.nsegx;
+    cg.SEG = cg.sw + halo;
+    cg.segs = 64 / cg.SEG;
+    const int64_t total_segs = n * c * cg.nsegx;
+    const int64_t segs_per_block = (int64_t)cg.segs * (kBlock / 64);
+    const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
+    FQ_REQUIRE(total_segs < (1ll << 31) - 1024, "fq_dwconv3x3: tensor too large for 32-bit segment indices");
+    // every workgroup resident at once (8 per CU), each walking a contiguous range of blocks
+    static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 8);
+    const int grid = (int)(nblk < (int64_t)num_cu() * dw_wg_per_cu ? nblk : (int64_t)num_cu() * dw_wg_per_cu);
+    const float levels = act_levels(in_width, in_flags);
+    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+    if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+    ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
+#define FQ_DWC(SS, Q, O)                                                                                          \
+  hipLaunchKernelGGL((dwconv3x3_cols_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, cg,        \
+                     total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,         \
+                     bn_shift, act, stat_out)
+    if (stride == 1) {
+      if (!quant) FQ_DWC(1, false, false);
+      else if (in_stat) FQ_DWC(1, true, true);
+      else FQ_DWC(1, true, false);
+    } else {
+      if (!quant) FQ_DWC(2, false, false);
+      else if (in_stat) FQ_DWC(2, true, true);
+      else FQ_DWC(2, true, false);
+    }
+#undef FQ_DWC
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+  }
+  DwGeom g;
+  g.C = (int)c;
+  g.H = (int)h;
+  g.W = (int)wdt;
+  g.Ho = (int)((h - 1) / stride + 1);
+  g.Wo = (int)((wdt - 1) / stride + 1);
+  g.WS = g.W + 2;
+  if ((g.WS & 1) == 0) g.WS += 1;                       // odd dword stride
+  const int lds_budget = 8192;                          // floats (32 KiB) -> up to 5 workgroups per CU
+  const int plane_in = g.H * g.W;
+  if (plane_in <= 4096 && (g.H + 2) * g.WS <= lds_budget) {
+    g.TR = g.Ho;
+    g.strips = 1;
+    g.IR = g.H + 2;
+    g.P = 1;
+    for (int p = (int)(c < 64 ? c : 64); p >= 1; --p)
+      if (c % p == 0 && p * g.IR * g.WS <= lds_budget) {
+        g.P = p;
+        break;
+      }
+  } else {
+    g.P = 1;
+    int tr = (lds_budget / g.WS - 2) / stride;
+    FQ_REQUIRE(tr >= 1, "fq_dwconv3x3: rows of %d floats do not fit the LDS tile", g.W);
+    g.strips = (g.Ho + tr - 1) / tr;
+    g.TR = (g.Ho + g.strips - 1) / g.strips;
+    g.IR = g.TR * stride + 2;
+  }
+  {
+    const int per_seg = g.P * g.Wo;
+    int nseg = (2 * kBlock + per_seg - 1) / per_seg;    // aim at ~2 work items per lane
+    if (nseg < 1) nseg = 1;
+    if (nseg > g.TR) nseg = g.TR;
+    g.RS = (g.TR + nseg - 1) / nseg;
+    g.nseg = (g.TR + g.RS - 1) / g.RS;
+  }
+  const bool base_ok = aligned16(x);
+  if (g.P > 1 || g.strips == 1)
+    g.vec_in = base_ok && (((int64_t)g.P * plane_in) % 4 == 0) && (plane_in % 4 == 0 || g.P % 4 == 0);
+  else
+    g.vec_in = base_ok && (g.W % 4 == 0) && (plane_in % 4 == 0);
+  const int64_t tiles = (n * c / g.P) * g.strips;
+  size_t lds = (size_t)((g.P * g.IR * g.WS + 3) / 4 * 4 + 16) * sizeof(float);
+  const int grid = grid_for(tiles);
+  const float levels = act_levels(in_width, in_flags);
+  const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+  const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+  if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * g.Ho * g.Wo), st);
+#define FQ_DW(SS, Q, O)                                                                                           \
+  hipLaunchKernelGGL((dwconv3x3_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), lds, st, x, w, bias, y, g, tiles,    \
+                     in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale, bn_shift, act,      \
+                     stat_out)
+  if (stride == 1) {
+    if (!quant) FQ_DW(1, false, false);
+    else if (in_stat) FQ_DW(1, true, true);
+    else FQ_DW(1, true, false);
+  } else {
+    if (!quant) FQ_DW(2, false, false);
+    else if (in_stat) FQ_DW(2, true, true);
+    else FQ_DW(2, true, false);
+  }
+#undef FQ_DW
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// libfakequant — internal interface between fq_pwconv_i8 (fq_pwconv.hip) and the pointwise forms, one translation unit
+// each.  A form inspects the call, launches when the shape is one it takes and reports that through *taken.
+#ifndef FQ_PW_H_
+#define FQ_PW_H_
+
+#include "fq_common.h"
+
+namespace fqi {
+
+struct PwCall {
+  const float* x;
+  const int8_t* wcodes;          // [rows_pad][cin_pad] int8 (+ the fragment-major copy behind it, fq_weight_codes)
+  const float* wscale;
+  const int32_t* wsum;
+  const float* bias;
+  float* y;
+  int64_t n, cin, cin_pad, cout, hw;
+  const float* in_stat;          // online: per-sample statistic of x
+  const float* in_thr;           // offline: threshold
+  float levels;
+  int lo_neg, zoff;
+  float* out_current_max;
+  const float* bn_scale;
+  const float* bn_shift;
+  int act;
+  float* stat_out;
+  bool prezeroed;
+  void* ws;
+  hipStream_t st;
+  int form;                      // FQ_PW_FORM: 0 auto, 1 two kernels, 2 panel, 3 stream, 4 chunk, 5 tile
+};
+
+int pw_try_stream(const PwCall& c, bool* taken);    // K2h  fq_pw_stream.hip
+int pw_try_tile(const PwCall& c, bool* taken);      // K2j  fq_pw_tile.hip
+int pw_try_chunk(const PwCall& c, bool* taken);     // K2i  fq_pw_chunk.hip
+int pw_try_panel(const PwCall& c, bool* taken);     // K2g  fq_pw_generic.hip
+int pw_two_kernels(const PwCall& c);                // K2f  fq_pw_generic.hip (takes every shape)
+
+inline int pw_zero_stat(const PwCall& c) {
+  if (c.stat_out && !c.prezeroed) {
+    hipError_t e = hipMemsetAsync(c.stat_out, 0, c.n * sizeof(float), c.st);
+    if (e != hipSuccess) return fail(FQ_ERR_HIP, "hipMemsetAsync(stat_out): %s", hipGetErrorString(e));
+  }
+  return FQ_OK;
+}
+
+}  // namespace fqi
+
+#endif  // FQ_PW_H_

@@ -1,0 +1,279 @@
+// libfakequant — K2h pointwise (1x1) convolution on int8 codes, whole weight matrix resident in LDS
+// (see fq_common.h for the list of translation units and the design rules)
+#include "fq_pw.h"
+
+namespace {
+
+// K2h: streaming form of the pointwise convolution for layers whose whole weight matrix fits in LDS (Cout*K <= 64 KB:
+// the large-plane layers, where the bytes are).  v_mfma_i32_32x32x32_i8 with the ACTIVATIONS as the B operand: lane l
+// owns pixel l&31 and needs the 16 consecutive channels 16*(l>>5).. of a 32-channel slab in its registers — which is
+// exactly what 16 plain dword loads of NCHW give it (for a fixed channel, 32 lanes read 128 contiguous bytes).  So
+// there is no transposition at all: load, fake-quantise, pack four codes per dword, multiply.  D comes out with
+// lane = pixel, register = channel: every store instruction writes two full 128-byte lines.  No LDS traffic for the
+// activations, no barrier inside the loop, ~110 VGPRs: waves are independent and hide each other's latencies, unlike
+// the panel kernel above whose workgroups move through load / quantise / multiply / store phases in lock step.
+// Weights sit in LDS in fragment order (1 KB per (32 channels x 32 k) fragment, read with one conflict-free
+// ds_read_b128 per lane); per-channel constants sit next to them and are read 4 channels at a time (D holds channels
+// 8*(r/4) + 4*(l>>5) + r%4 in register r).  A wavefront walks a contiguous range of 32-pixel tiles; the loads of the
+// next slab / tile are issued before the current one is quantised (two register buffers).
+
+struct PwsGeom {
+  int Cin, K, Cout, CT, HW;   // K: row stride of the weight codes (cin_pad); CT = ceil(Cout / 32)
+  int64_t cols, tiles;        // n * HW, ceil(cols / 32)
+  int zoff;
+};
+
+template <int KT>
+__global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
+    const float* __restrict__ x, const int8_t* __restrict__ wc, const float* __restrict__ wscale,
+    const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwsGeom g,
+    const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
+    float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
+    float* __restrict__ stat_out) {
+  constexpr int kSlots = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char pws_smem[];
+  __shared__ unsigned k_stat[kSlots];
+  v4i* ldsA = reinterpret_cast<v4i*>(pws_smem);                        // [CT][KT][64] fragments
+  const int nch = g.CT * 32;
+  float* c_sxw = reinterpret_cast<float*>(pws_smem + (size_t)g.CT * KT * 1024);
+  float* c_bsc = c_sxw + nch;
+  float* c_bsh = c_bsc + nch;
+  float* c_bias = c_bsh + nch;
+  int* c_zs = reinterpret_cast<int*>(c_bias + nch);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, pl = lane & 31;
+  const unsigned HW = (unsigned)g.HW, cols = (unsigned)g.cols;
+  const int64_t plane = (int64_t)g.HW;
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
+  const int64_t nwaves = (int64_t)gridDim.x * 4, wid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t t_begin = g.tiles * wid / nwaves, t_end = g.tiles * (wid + 1) / nwaves;
+  unsigned s_base;
+  {
+    const int64_t t0 = g.tiles * ((int64_t)blockIdx.x * 4) / nwaves;
+    const unsigned j0 = (unsigned)t0 * 32u;
+    s_base = (j0 < cols ? j0 : cols - 1) / HW;
+  }
+
+  // per-tile pixel record of this lane
+  struct Pix { unsigned smp, p; bool valid; };
+  auto pix_of = [&](int64_t t) __attribute__((always_inline)) {
+    Pix r;
+    unsigned j = (unsigned)t * 32u + (unsigned)pl;
+    r.valid = j < cols;
+    j = r.valid ? j : cols - 1;
+    r.smp = j / HW;
+    r.p = j - r.smp * HW;
+    return r;
+  };
+  // addresses: wave-uniform base (SGPR arithmetic) + ONE 32-bit per-lane byte offset per tile (host checks the tensors
+  // are < 4 GB).  With 64-bit per-lane pointers the compiler materialised an address pair per load and spilled.
+  auto lane_off = [&](const Pix& px, int c0) __attribute__((always_inline)) {
+    return (unsigned)((((int64_t)px.smp * g.Cin + c0) * plane + px.p) * 4);
+  };
+  auto issue = [&](const Pix& px, int kt, float (&v)[16]) __attribute__((always_inline)) {
+    const int cg = kt * 32 + 16 * h;                                   // this half-wave's 16 channels of slab kt
+    const unsigned off = lane_off(px, cg < g.Cin ? 16 * h : 0);        // padded group: read the valid half, discarded
+    const char* ub = reinterpret_cast<const char*>(x) + (int64_t)kt * 32 * plane * 4;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float*>(ub + (int64_t)i * plane * 4 + off);
+  };
+
+  float bufa[16], bufb[16];
+  int64_t t_first = t_begin < g.tiles ? t_begin : g.tiles - 1;
+  Pix nxt = pix_of(t_first);
+  issue(nxt, 0, bufa);                                                  // in flight during the whole set-up
+  FQ_PIN();
+
+  const float max_ = in_stat != nullptr ? batch_mean_dev(in_stat, n) : in_thr[0];
+  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  if (in_stat != nullptr && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  const float sx = q.scale;
+  if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
+  // weights -> fragment order: fragment (ct, kt), lane (row % 32) + 32 * (16-byte chunk % 2)
+  for (int idx = threadIdx.x; idx < nch * KT * 2; idx += kBlock) {
+    const int row = idx / (KT * 2), kc = idx - row * (KT * 2);
+    const v4i wv = *reinterpret_cast<const v4i*>(wc + (int64_t)row * g.K + kc * 16);
+    ldsA[(((row >> 5) * KT + (kc >> 1)) << 6) + (row & 31) + 32 * (kc & 1)] = wv;
+  }
+  for (int i = threadIdx.x; i < nch; i += kBlock) {
+    const bool ok = i < g.Cout;
+    const int ic = ok ? i : 0;
+    c_sxw[i] = sx * wscale[ic];
+    c_zs[i] = ok ? g.zoff * wsum[ic] : 0;
+    c_bias[i] = bias != nullptr ? bias[ic] : 0.0f;
+    c_bsc[i] = has_bn ? bn_scale[ic] : 1.0f;
+    c_bsh[i] = has_bn ? bn_shift[ic] : 0.0f;
+  }
+  __syncthreads();
+
+  v4i bfrag[KT];
+  auto quant = [&](int kt, const float (&v)[16]) __attribute__((always_inline)) {
+    const bool gvalid = kt * 32 + 16 * h < g.Cin;
+    v4i f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int packed = pack4_codes(fq_code_int(v[4 * d + 0], q), fq_code_int(v[4 * d + 1], q),
+                                     fq_code_int(v[4 * d + 2], q), fq_code_int(v[4 * d + 3], q), 128 - g.zoff);
+      f[d] = gvalid ? packed : 0;
+    }
+    // pin the quantisation HERE: it is pure arithmetic whose results are only needed by the MFMAs, and the optimiser
+    // otherwise sinks it below every prefetch, keeping all 16 * KT loaded values live (256 VGPRs + spills)
+    asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+    bfrag[kt] = f;
+  };
+  auto tile_done = [&](const Pix& px, auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+    constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
+    const unsigned yoff = (unsigned)((((int64_t)px.smp * g.Cout + 4 * h) * plane + px.p) * 4);
+    float m = 0.0f;
+#pragma unroll 1
+    for (int ct = 0; ct < g.CT; ++ct) {
+      v16i acc;
+      const int cb = ct * 32 + 4 * h;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const v4i z = *reinterpret_cast<const v4i*>(c_zs + cb + 8 * gq);
+        acc[4 * gq + 0] = z.x; acc[4 * gq + 1] = z.y; acc[4 * gq + 2] = z.z; acc[4 * gq + 3] = z.w;
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ldsA[((ct * KT + kt) << 6) + lane], bfrag[kt], acc, 0, 0, 0);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int c0 = cb + 8 * gq;                                     // channels c0 .. c0+3 in registers 4gq .. 4gq+3
+        const f4 sxw = *reinterpret_cast<const f4*>(c_sxw + c0);
+        const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
+        const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
+        f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
+        if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = (float)acc[4 * gq + r] * sxw[r];
+          if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) v = v + bch[r];
+          if (BN_M == 1 || (BN_M < 0 && has_bn)) {
+            v = v * bsc[r];
+            v = v + bsh[r];
+          }
+          v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
+          // no masks: lanes past the end hold a copy of the last pixel (clamped loads) and re-store its values, and the
+          // host guarantees Cout % 32 == 0
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff) = v;
+          m = fmaxf(m, fabsf(v));
+        }
+      }
+    }
+    if (has_stat) {
+      const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)px.smp);
+      const bool uniform = __all(!px.valid || px.smp == s0);
+      if (uniform) {
+        const float wm = wave_max(px.valid ? m : 0.0f);
+        if (lane == 0) {
+          const unsigned slot = s0 - s_base;
+          if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+          else atomic_max_f32(stat_out + s0, wm);
+        }
+      } else if (px.valid) {
+        const unsigned slot = px.smp - s_base;
+        if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+        else atomic_max_f32(stat_out + px.smp, m);
+      }
+    }
+  };
+  // one tile: its first slab is already in `first`; the prefetch of the following slab / tile alternates buffers
+  auto run_tile = [&](int64_t t, float (&first)[16], float (&second)[16], auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+    const Pix cur = nxt;
+    const int64_t tn = t + 1 < g.tiles ? t + 1 : g.tiles - 1;
+    nxt = pix_of(tn);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      float (&mine)[16] = (kt & 1) ? second : first;
+      float (&other)[16] = (kt & 1) ? first : second;
+      if (kt + 1 < KT) issue(cur, kt + 1, other);
+      else issue(nxt, 0, other);
+      FQ_PIN();
+      quant(kt, mine);
+      FQ_PIN();
+    }
+    tile_done(cur, bias_c, bn_c, act_c);
+    FQ_PIN();
+  };
+  auto run_all = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+    if (KT & 1) {                                                       // the buffers swap roles from tile to tile
+      int64_t t = t_begin;
+      for (; t + 1 < t_end; t += 2) {
+        run_tile(t, bufa, bufb, bias_c, bn_c, act_c);
+        run_tile(t + 1, bufb, bufa, bias_c, bn_c, act_c);
+      }
+      if (t < t_end) run_tile(t, bufa, bufb, bias_c, bn_c, act_c);
+    } else {
+      for (int64_t t = t_begin; t < t_end; ++t) run_tile(t, bufa, bufb, bias_c, bn_c, act_c);
+    }
+  };
+  using std::integral_constant;
+  if (bias == nullptr && has_bn && act == FQ_ACT_RELU)
+    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
+  else if (bias == nullptr && has_bn && act == FQ_ACT_RELU6)
+    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{});
+  else if (bias == nullptr && has_bn && act == FQ_ACT_NONE)
+    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{});
+  else
+    run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});
+
+  if (has_stat) {
+    __syncthreads();
+    if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < cols / HW)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+  }
+}
+
+
+}  // namespace
+
+namespace fqi {
+
+// streaming form: the whole weight matrix in LDS, activations straight from NCHW into MFMA registers
+int pw_try_stream(const PwCall& c, bool* taken) {
+  *taken = false;
+  const int kt = (int)((c.cin + 31) / 32);
+  const int ct = (int)((c.cout + 31) / 32);
+  const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 5 * sizeof(float);
+  const bool kt_ok = kt == 1 || kt == 2 || kt == 3 || kt == 4 || kt == 6 || kt == 8;
+  const bool shape_ok = c.cin % 16 == 0 && c.cout % 32 == 0 && kt_ok && lds <= 72 * 1024;
+  if (!((c.form == 0 || c.form == 3) && shape_ok)) {
+    FQ_REQUIRE(c.form != 3, "fq_pwconv_i8: FQ_PW_FORM=3 but the shape does not fit the streaming kernel");
+    return FQ_OK;
+  }
+  PwsGeom s;
+  s.Cin = (int)c.cin; s.K = (int)c.cin_pad; s.Cout = (int)c.cout; s.CT = ct; s.HW = (int)c.hw;
+  s.cols = c.n * c.hw; s.tiles = (s.cols + 31) / 32; s.zoff = c.zoff;
+  // persistent workgroups: as many as stay resident (LDS / 2 per SIMD by registers), each wave a contiguous range
+  // (measured, tools/pwbench.py: 3 per CU for the 126-VGPR instantiations KT <= 2, 2 above)
+  int per_cu = (int)((160 * 1024) / (lds + 1024));
+  const int by_regs = kt <= 2 ? 3 : 2;
+  per_cu = per_cu > by_regs ? by_regs : per_cu;
+  static const int pws_wg = env_int("FQ_PWS_WG_PER_CU", 0);
+  if (pws_wg > 0) per_cu = pws_wg;
+  int64_t grid = (int64_t)num_cu() * per_cu;
+  const int64_t need = (s.tiles + 3) / 4;
+  if (grid > need) grid = need;
+  if (int rc = pw_zero_stat(c)) return rc;
+#define FQ_PWS_CASE(KT_)                                                                                               \
+  case KT_: {                                                                                                          \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_>),         \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess; \
+    FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the streaming kernel");                   \
+    hipLaunchKernelGGL((pwconv_stream_kernel<KT_>), dim3((unsigned)grid), dim3(kBlock), lds, c.st, c.x, c.wcodes,      \
+                       c.wscale, (const int*)c.wsum, c.bias, c.y, s, c.in_stat, (int)c.n, c.in_thr, c.levels, c.lo_neg, \
+                       kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out);                            \
+  } break;
+  switch (kt) {
+    FQ_PWS_CASE(1) FQ_PWS_CASE(2) FQ_PWS_CASE(3) FQ_PWS_CASE(4) FQ_PWS_CASE(6) FQ_PWS_CASE(8)
+    default: break;
+  }
+#undef FQ_PWS_CASE
+  FQ_LAUNCH_CHECK();
+  *taken = true;
+  return FQ_OK;
+}
+
+}  // namespace fqi

@@ -1,0 +1,584 @@
+// libfakequant — streaming kernels: per-sample statistic, fake-quant apply, BatchNorm+activation+statistic, pooling, counters
+// (see fq_common.h for the list of translation units and the design rules)
+#include "fq_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1: per-sample statistic.  x viewed as (n, inner).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool USE_ABS, bool VEC, bool NTL, int U>
+__global__ __launch_bounds__(kBlock) void absmax_per_sample_kernel(const float* __restrict__ x, int64_t inner,
+                                                                   int chunks_per_sample, int64_t total_chunks,
+                                                                   float* __restrict__ out_max) {
+  constexpr int kCh = kBlock * kVec * U;
+  __shared__ float red[4];
+  const ChunkRange rg = block_range(total_chunks);
+  int64_t cur_s = -1;
+  float m = stat_init<USE_ABS>();
+  for (int64_t c = rg.begin; c < rg.end; ++c) {
+    const int64_t s = c / chunks_per_sample;
+    if (s != cur_s) {
+      if (cur_s >= 0) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) atomic_max_f32(out_max + cur_s, m);
+      }
+      cur_s = s;
+      m = stat_init<USE_ABS>();
+    }
+    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kCh;
+    const float* base = x + s * inner + off0;
+    const int64_t rem = inner - off0;
+    if (VEC) {
+      const f4* p = reinterpret_cast<const f4*>(base);
+      if (rem >= kCh) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld4<NTL>(p + threadIdx.x + u * kBlock);
+#pragma unroll
+        for (int u = 0; u < U; ++u) m = fmaxf(m, stat4<USE_ABS>(v[u]));
+      } else {
+        const int nvec = (int)(rem / kVec);
+        for (int i = threadIdx.x; i < nvec; i += kBlock) m = fmaxf(m, stat4<USE_ABS>(ld4<NTL>(p + i)));
+      }
+    } else {
+      const int cnt = (int)(rem < kCh ? rem : kCh);
+      for (int i = threadIdx.x; i < cnt; i += kBlock) m = fmaxf(m, stat_of<USE_ABS>(base[i]));
+    }
+  }
+  if (cur_s >= 0) {
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomic_max_f32(out_max + cur_s, m);
+  }
+}
+
+// K1b: mean of n floats (one thread; n is a batch size)
+__global__ void batch_mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;                    // one whole wavefront
+  const float m = batch_mean_dev(v, n);
+  if (threadIdx.x == 0) out[0] = m;
+}
+
+__global__ void batch_mean_gathered_kernel(const float* __restrict__ packs, int world, int64_t stride,
+                                           float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double acc = 0.0;
+  long long total = 0;
+  for (int w = 0; w < world; ++w) {
+    const float* rec = packs + (int64_t)w * stride;
+    const int c = (int)rec[0];
+    for (int i = 0; i < c; ++i) acc += (double)rec[1 + i];
+    total += c;
+  }
+  out[0] = (float)acc / (float)total;
+}
+
+__global__ void batch_mean_rows_kernel(const float* __restrict__ v, int64_t rows, int n, int64_t stride,
+                                       float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) out[r] = batch_mean_seq(v + r * stride, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2: apply.  ONLINE: threshold = mean of stat_in[0..n);  else threshold = thr[0].
+//     STATS (offline only): also produce the per-sample statistic of x into stat_out (fused, same pass).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool ONLINE, bool STATS, bool CODES, bool USE_ABS, bool VEC, bool NTL, bool NTS, int U>
+__global__ __launch_bounds__(kBlock) void act_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int32_t* __restrict__ codes, int64_t inner,
+                                                           int chunks_per_sample, int64_t total_chunks,
+                                                           const float* __restrict__ stat_in, int n,
+                                                           const float* __restrict__ thr, float levels,
+                                                           int lo_neg_max, float eps, int reverse,
+                                                           float* __restrict__ stat_out,
+                                                           float* __restrict__ cur_max_out) {
+  constexpr int kCh = kBlock * kVec * U;
+  __shared__ float red[4];
+  const float max_ = ONLINE ? batch_mean_dev(stat_in, n) : thr[0];
+  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+
+  const ChunkRange rg = block_range(total_chunks);
+  int64_t cur_s = -1;
+  float m = stat_init<USE_ABS>();
+  for (int64_t cc = rg.begin; cc < rg.end; ++cc) {
+    const int64_t c = reverse ? (rg.end - 1 - (cc - rg.begin)) : cc;
+    const int64_t s = c / chunks_per_sample;
+    if (STATS && s != cur_s) {
+      if (cur_s >= 0) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+      }
+      cur_s = s;
+      m = stat_init<USE_ABS>();
+    }
+    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kCh;
+    const int64_t gbase = s * inner + off0;
+    const int64_t rem = inner - off0;
+    if (VEC) {
+      const f4* p = reinterpret_cast<const f4*>(x + gbase);
+      f4* o = reinterpret_cast<f4*>(y + gbase);
+      i4* oc = CODES ? reinterpret_cast<i4*>(codes + gbase) : nullptr;
+      if (rem >= kCh) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld4<NTL>(p + threadIdx.x + u * kBlock);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (STATS) m = fmaxf(m, stat4<USE_ABS>(v[u]));
+          const f4 k = fq_code4(v[u], q);
+          if (CODES) oc[threadIdx.x + u * kBlock] = __builtin_convertvector(k, i4);
+          st4<NTS>(o + threadIdx.x + u * kBlock, k * q.scale);
+        }
+      } else {
+        const int nvec = (int)(rem / kVec);
+        for (int i = threadIdx.x; i < nvec; i += kBlock) {
+          const f4 v = ld4<NTL>(p + i);
+          if (STATS) m = fmaxf(m, stat4<USE_ABS>(v));
+          const f4 k = fq_code4(v, q);
+          if (CODES) oc[i] = __builtin_convertvector(k, i4);
+          st4<NTS>(o + i, k * q.scale);
+        }
+      }
+    } else {
+      const int cnt = (int)(rem < kCh ? rem : kCh);
+      for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        const float v = x[gbase + i];
+        if (STATS) m = fmaxf(m, stat_of<USE_ABS>(v));
+        const float k = fq_code(v, q);
+        if (CODES) codes[gbase + i] = (int)k;
+        y[gbase + i] = k * q.scale;
+      }
+    }
+  }
+  if (STATS && cur_s >= 0) {
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2b: fused inference BatchNorm (as per-channel scale/shift) + activation + per-sample statistic of the OUTPUT.
+// x is (n, c, hw).  One division per 16-byte access finds the channel; the walk to the next channel inside the access
+// is incremental (hw need not be a multiple of 4: 7x7 planes).
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ float bn_act1(float v, float sc, float sh) {
+  float r = v * sc;
+  r = r + sh;
+  if (ACT == FQ_ACT_RELU) r = fmaxf(r, 0.0f);
+  if (ACT == FQ_ACT_RELU6) r = fminf(fmaxf(r, 0.0f), 6.0f);
+  return r;
+}
+
+template <int ACT, bool STATS, bool VEC, int U>
+__global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int64_t inner, int hw, int chunks_per_sample,
+                                                             int64_t total_chunks, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             float* __restrict__ stat_out) {
+  constexpr int kCh = kBlock * kVec * U;
+  __shared__ float red[4];
+  const ChunkRange rg = block_range(total_chunks);
+  int64_t cur_s = -1;
+  float m = 0.0f;
+  for (int64_t c = rg.begin; c < rg.end; ++c) {
+    const int64_t s = c / chunks_per_sample;
+    if (STATS && s != cur_s) {
+      if (cur_s >= 0) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+      }
+      cur_s = s;
+      m = 0.0f;
+    }
+    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kCh;     // offset inside the sample
+    const int64_t gbase = s * inner + off0;
+    const int64_t rem = inner - off0;
+    if (VEC) {
+      const f4* p = reinterpret_cast<const f4*>(x + gbase);
+      f4* o = reinterpret_cast<f4*>(y + gbase);
+      const int nvec = (int)((rem < kCh ? rem : kCh) / kVec);
+      f4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * kBlock;
+        if (i < nvec) v[u] = p[i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * kBlock;
+        if (i < nvec) {
+          const unsigned e0 = (unsigned)(off0 + (int64_t)i * kVec);       // element index inside the sample (< 2^32)
+          unsigned ch = e0 / (unsigned)hw;
+          unsigned r = e0 - ch * (unsigned)hw;
+          float sc = scale[ch], sh = shift[ch];
+          f4 q;
+          q.x = bn_act1<ACT>(v[u].x, sc, sh);
+          if (++r == (unsigned)hw) { r = 0; ++ch; sc = scale[ch]; sh = shift[ch]; }
+          q.y = bn_act1<ACT>(v[u].y, sc, sh);
+          if (++r == (unsigned)hw) { r = 0; ++ch; sc = scale[ch]; sh = shift[ch]; }
+          q.z = bn_act1<ACT>(v[u].z, sc, sh);
+          if (++r == (unsigned)hw) { r = 0; ++ch; sc = scale[ch]; sh = shift[ch]; }
+          q.w = bn_act1<ACT>(v[u].w, sc, sh);
+          if (STATS) m = fmaxf(m, stat4<true>(q));
+          o[i] = q;
+        }
+      }
+    } else {
+      const int cnt = (int)(rem < kCh ? rem : kCh);
+      for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        const unsigned e = (unsigned)(off0 + i);
+        const unsigned ch = e / (unsigned)hw;
+        const float q = bn_act1<ACT>(x[gbase + i], scale[ch], shift[ch]);
+        if (STATS) m = fmaxf(m, fabsf(q));
+        y[gbase + i] = q;
+      }
+    }
+  }
+  if (STATS && cur_s >= 0) {
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K11: global average pooling (gluon GlobalAvgPool2D = F.Pooling(global_pool=True, pool_type='avg')) with the per-sample
+// max|y| the following Dense layer's input quantiser needs (convert_dense.py:40-41) - one launch instead of the library
+// reduction + memset + statistic pass.  y[n][c] = fp32(sum over the plane in fp64, in order) / fp32(hw): deterministic,
+// within an ulp of any fp32 summation order.  A thread owns a plane (hw is 49 here: 25 MB in all, latency-bound).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gap_stat_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int64_t planes, int c, int hw, float* __restrict__ stat_out) {
+  __shared__ float red[4];
+  const int64_t pl = (int64_t)blockIdx.x * kBlock + threadIdx.x;       // host: c % kBlock == 0 or one sample per block
+  float v = 0.0f;
+  if (pl < planes) {
+    const float* p = x + pl * hw;
+    double acc = 0.0;
+    for (int i = 0; i < hw; ++i) acc += (double)p[i];
+    v = (float)acc / (float)hw;
+    y[pl] = v;
+  }
+  if (stat_out != nullptr) {
+    // all planes of a block belong to one sample when c % kBlock == 0 (host checks); otherwise per-thread atomics
+    const int64_t first = (int64_t)blockIdx.x * kBlock;
+    const bool one_sample = (c % kBlock) == 0;
+    if (one_sample) {
+      const float m = block_max(fabsf(v), red);
+      if (threadIdx.x == 0 && first < planes) atomic_max_f32(stat_out + first / c, m);
+    } else if (pl < planes) {
+      atomic_max_f32(stat_out + pl / c, fabsf(v));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K12: the evaluation counters of simulate_quantization.py:122-148 (pred = argmax(outputs, axis=1), first index on
+// ties as MXNet's argmax; test_num_correct, label_counter[gt], correct_counter[gt]) in ONE launch: a wavefront per
+// sample.  The tensor-library formulation is nine launch-bound kernels (~60 us per batch, 4 % of an evaluation step).
+// counters = [n_correct, total, correct[classes], label[classes]] as floats: the increments are 1.0, exact below 2^24.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void eval_counters_kernel(const float* __restrict__ logits,
+                                                               const long long* __restrict__ labels, int64_t n,
+                                                               int classes, float* __restrict__ counters) {
+  const int lane = threadIdx.x & 63;
+  const int64_t smp = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (smp >= n) return;
+  const float* row = logits + smp * classes;
+  float best = 0.0f;
+  int bidx = 0x7FFFFFFF;
+  bool bnan = false;
+  // better(a, b): NaN beats everything (as torch / numpy argmax), then the larger value, then the smaller index
+  auto take = [&](float v, int i) {
+    const bool vnan = v != v;
+    const bool better = bidx == 0x7FFFFFFF || (vnan && !bnan) || (!bnan && !vnan && v > best) ||
+                        (((vnan && bnan) || (!vnan && !bnan && v == best)) && i < bidx);
+    if (better) {
+      best = v;
+      bidx = i;
+      bnan = vnan;
+    }
+  };
+  for (int i = lane; i < classes; i += 64) take(row[i], i);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(bidx, off, 64);
+    if (oi != 0x7FFFFFFF) take(ov, oi);
+  }
+  if (lane == 0) {
+    const long long gt = labels[smp];
+    atomicAdd(counters + 1, 1.0f);
+    if (gt >= 0 && gt < classes) {
+      atomicAdd(counters + 2 + classes + gt, 1.0f);
+      if ((long long)bidx == gt) {
+        atomicAdd(counters, 1.0f);
+        atomicAdd(counters + 2 + gt, 1.0f);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+namespace fqi {
+
+int launch_absmax(const float* x, int64_t n, int64_t inner, bool use_abs, float* out, hipStream_t st) {
+  // caller has initialised `out` (0 for |x|, -inf otherwise)
+  const bool small = use_small_chunks(n, inner);
+  const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
+  const bool vec = (inner % kVec == 0) && aligned16(x);
+  const int grid = grid_for(ck.total);
+  const bool ntl = (stream_policy(FQ_KERNEL_STAT, n * inner) & kPolNtLoad) != 0;
+  ProfScope prof(FQ_KERNEL_STAT, 4.0 * (double)n * (double)inner, st);
+#define FQ_ABSMAX(A, V, L, UU)                                                                                \
+  hipLaunchKernelGGL((absmax_per_sample_kernel<A, V, L, UU>), dim3(grid), dim3(kBlock), 0, st, x, inner,      \
+                     ck.chunks_per_sample, ck.total, out)
+#define FQ_ABSMAX_U(A, V, L)                                            \
+  do {                                                                  \
+    if (small) FQ_ABSMAX(A, V, L, kSmallUnroll); else FQ_ABSMAX(A, V, L, kUnroll); \
+  } while (0)
+  if (use_abs) {
+    if (vec) {
+      if (ntl) FQ_ABSMAX_U(true, true, true); else FQ_ABSMAX_U(true, true, false);
+    } else {
+      FQ_ABSMAX_U(true, false, false);
+    }
+  } else {
+    if (vec) FQ_ABSMAX_U(false, true, false); else FQ_ABSMAX_U(false, false, false);
+  }
+#undef FQ_ABSMAX_U
+#undef FQ_ABSMAX
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int init_stat(float* p, int64_t n, bool use_abs, hipStream_t st) {
+  if (use_abs) {
+    FQ_HIP(hipMemsetAsync(p, 0, n * sizeof(float), st));
+  } else {
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, -INFINITY);
+    FQ_LAUNCH_CHECK();
+  }
+  return FQ_OK;
+}
+
+}  // namespace fqi
+
+namespace {
+
+template <bool ONLINE, bool STATS, bool CODES>
+int launch_apply(const float* x, float* y, int32_t* codes, int64_t n, int64_t inner, const float* stat_in,
+                 const float* thr, float levels, unsigned flags, float* stat_out, float* cur_out, hipStream_t st) {
+  const bool small = use_small_chunks(n, inner);
+  const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
+  const bool vec = (inner % kVec == 0) && aligned16(x) && aligned16(y) && (!CODES || aligned16(codes));
+  const bool use_abs = !(flags & FQ_ACT_NO_ABS);
+  const int grid = grid_for(ck.total);
+  const int lo_neg = (flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+  const float eps = (flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+  int pol = stream_policy(ONLINE ? FQ_KERNEL_APPLY_ONLINE : FQ_KERNEL_APPLY_OFFLINE, n * inner);
+  if (x == y) pol &= ~kPolNtLoad;
+  const int reverse = (pol & kPolReverse) ? 1 : 0;
+  ProfScope prof(ONLINE ? FQ_KERNEL_APPLY_ONLINE : FQ_KERNEL_APPLY_OFFLINE, 8.0 * (double)n * (double)inner, st);
+#define FQ_APPLY(A, V, L, S, UU)                                                                                 \
+  hipLaunchKernelGGL((act_apply_kernel<ONLINE, STATS, CODES, A, V, L, S, UU>), dim3(grid), dim3(kBlock), 0, st,  \
+                     x, y, codes, inner, ck.chunks_per_sample, ck.total, stat_in, (int)n, thr, levels, lo_neg,   \
+                     eps, reverse, stat_out, cur_out)
+#define FQ_APPLY_U(A, V, L, S)                                                      \
+  do {                                                                              \
+    if (small) FQ_APPLY(A, V, L, S, kSmallUnroll); else FQ_APPLY(A, V, L, S, kUnroll); \
+  } while (0)
+  if (use_abs && vec && !CODES) {
+    switch (pol & (kPolNtLoad | kPolNtStore)) {
+      case 0: FQ_APPLY_U(true, true, false, false); break;
+      case kPolNtLoad: FQ_APPLY_U(true, true, true, false); break;
+      case kPolNtStore: FQ_APPLY_U(true, true, false, true); break;
+      default: FQ_APPLY_U(true, true, true, true); break;
+    }
+  } else if (use_abs) {
+    if (vec) FQ_APPLY_U(true, true, false, false); else FQ_APPLY_U(true, false, false, false);
+  } else {
+    if (vec) FQ_APPLY_U(false, true, false, false); else FQ_APPLY_U(false, false, false, false);
+  }
+#undef FQ_APPLY_U
+#undef FQ_APPLY
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fq_act_workspace_bytes(int64_t n) { return (size_t)(n < 1 ? 1 : n) * sizeof(float) * 2 + 64; }
+
+int fq_absmax_per_sample(const float* x, int64_t n, int64_t inner, unsigned flags, float* out_max,
+                         fqStream_t stream) {
+  FQ_REQUIRE(x && out_max, "fq_absmax_per_sample: null pointer");
+  FQ_REQUIRE(n > 0 && inner > 0, "fq_absmax_per_sample: empty tensor (n=%lld inner=%lld)", (long long)n,
+             (long long)inner);
+  hipStream_t st = (hipStream_t)stream;
+  const bool use_abs = !(flags & FQ_ACT_NO_ABS);
+  if (int rc = init_stat(out_max, n, use_abs, st)) return rc;
+  return launch_absmax(x, n, inner, use_abs, out_max, st);
+}
+
+int fq_batch_mean(const float* v, int64_t n, float* out, fqStream_t stream) {
+  FQ_REQUIRE(v && out, "fq_batch_mean: null pointer");
+  FQ_REQUIRE(n > 0 && n < (1ll << 31), "fq_batch_mean: bad n=%lld", (long long)n);
+  hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, v, (int)n, out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_batch_mean_gathered(const float* packs, int world, int64_t stride, float* out, fqStream_t stream) {
+  FQ_REQUIRE(packs && out, "fq_batch_mean_gathered: null pointer");
+  FQ_REQUIRE(world > 0 && stride > 1, "fq_batch_mean_gathered: bad shape");
+  hipLaunchKernelGGL(batch_mean_gathered_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, packs, world, stride, out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_batch_mean_rows(const float* v, int64_t rows, int64_t n, int64_t row_stride, float* out, fqStream_t stream) {
+  FQ_REQUIRE(v && out, "fq_batch_mean_rows: null pointer");
+  FQ_REQUIRE(rows > 0 && n > 0 && n < (1ll << 31) && row_stride >= n, "fq_batch_mean_rows: bad shape");
+  hipLaunchKernelGGL(batch_mean_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, v,
+                     rows, (int)n, row_stride, out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_fake_quant_online(const float* x, float* y, int64_t n, int64_t inner, int width, unsigned flags,
+                         float* out_current_max, int32_t* codes, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(x && y && ws, "fq_fake_quant_online: null pointer");
+  FQ_REQUIRE(n > 0 && inner > 0 && n < (1ll << 31), "fq_fake_quant_online: bad shape (n=%lld inner=%lld)",
+             (long long)n, (long long)inner);
+  FQ_REQUIRE(width >= 2 && width <= 16, "fq_fake_quant_online: width %d out of range", width);
+  hipStream_t st = (hipStream_t)stream;
+  float* stat = (float*)ws;
+  const bool use_abs = !(flags & FQ_ACT_NO_ABS);
+  if (int rc = init_stat(stat, n, use_abs, st)) return rc;
+  if (int rc = launch_absmax(x, n, inner, use_abs, stat, st)) return rc;
+  const float levels = act_levels(width, flags);
+  if (codes)
+    return launch_apply<true, false, true>(x, y, codes, n, inner, stat, nullptr, levels, flags, nullptr,
+                                           out_current_max, st);
+  return launch_apply<true, false, false>(x, y, nullptr, n, inner, stat, nullptr, levels, flags, nullptr,
+                                          out_current_max, st);
+}
+
+int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t inner, const float* stat, int width,
+                                 unsigned flags, float* out_current_max, int32_t* codes, fqStream_t stream) {
+  FQ_REQUIRE(x && y && stat, "fq_fake_quant_online_prestat: null pointer");
+  FQ_REQUIRE(n > 0 && inner > 0 && n < (1ll << 31), "fq_fake_quant_online_prestat: bad shape (n=%lld inner=%lld)",
+             (long long)n, (long long)inner);
+  FQ_REQUIRE(width >= 2 && width <= 16, "fq_fake_quant_online_prestat: width %d out of range", width);
+  const float levels = act_levels(width, flags);
+  if (codes)
+    return launch_apply<true, false, true>(x, y, codes, n, inner, stat, nullptr, levels, flags, nullptr,
+                                           out_current_max, (hipStream_t)stream);
+  return launch_apply<true, false, false>(x, y, nullptr, n, inner, stat, nullptr, levels, flags, nullptr,
+                                          out_current_max, (hipStream_t)stream);
+}
+
+int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                   const float* shift, int act, float* stat_out, fqStream_t stream) {
+  FQ_REQUIRE(x && y && scale && shift, "fq_bn_act_stat: null pointer");
+  FQ_REQUIRE(n > 0 && c > 0 && hw > 0 && c * hw < (1ll << 32) && hw < (1ll << 31),
+             "fq_bn_act_stat: bad shape (n=%lld c=%lld hw=%lld)", (long long)n, (long long)c, (long long)hw);
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_bn_act_stat: unknown activation %d", act);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t inner = c * hw;
+  if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  const bool small = use_small_chunks(n, inner);
+  const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
+  const bool vec = (inner % kVec == 0) && aligned16(x) && aligned16(y);
+  const int grid = grid_for(ck.total);
+  ProfScope prof(FQ_KERNEL_BN_ACT, 8.0 * (double)n * (double)inner, st);
+#define FQ_BN(A, S, V, UU)                                                                                       \
+  hipLaunchKernelGGL((bn_act_stat_kernel<A, S, V, UU>), dim3(grid), dim3(kBlock), 0, st, x, y, inner, (int)hw,   \
+                     ck.chunks_per_sample, ck.total, scale, shift, stat_out)
+#define FQ_BN_U(A, S, V)                                                 \
+  do {                                                                   \
+    if (small) FQ_BN(A, S, V, kSmallUnroll); else FQ_BN(A, S, V, kUnroll); \
+  } while (0)
+#define FQ_BN_V(A, S)                                   \
+  do {                                                  \
+    if (vec) FQ_BN_U(A, S, true); else FQ_BN_U(A, S, false); \
+  } while (0)
+#define FQ_BN_S(A)                                         \
+  do {                                                     \
+    if (stat_out) FQ_BN_V(A, true); else FQ_BN_V(A, false); \
+  } while (0)
+  if (act == FQ_ACT_RELU) FQ_BN_S(FQ_ACT_RELU);
+  else if (act == FQ_ACT_RELU6) FQ_BN_S(FQ_ACT_RELU6);
+  else FQ_BN_S(FQ_ACT_NONE);
+#undef FQ_BN_S
+#undef FQ_BN_V
+#undef FQ_BN_U
+#undef FQ_BN
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_fake_quant_offline(const float* x, float* y, int64_t n, int64_t inner, const float* threshold, int width,
+                          unsigned flags, float* out_current_max, int32_t* codes, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(x && y && threshold, "fq_fake_quant_offline: null pointer");
+  FQ_REQUIRE(n > 0 && inner > 0 && n < (1ll << 31), "fq_fake_quant_offline: bad shape (n=%lld inner=%lld)",
+             (long long)n, (long long)inner);
+  FQ_REQUIRE(width >= 2 && width <= 16, "fq_fake_quant_offline: width %d out of range", width);
+  hipStream_t st = (hipStream_t)stream;
+  const float levels = act_levels(width, flags);
+  if (out_current_max == nullptr) {
+    if (codes)
+      return launch_apply<false, false, true>(x, y, codes, n, inner, nullptr, threshold, levels, flags, nullptr,
+                                              nullptr, st);
+    return launch_apply<false, false, false>(x, y, nullptr, n, inner, nullptr, threshold, levels, flags, nullptr,
+                                             nullptr, st);
+  }
+  FQ_REQUIRE(ws, "fq_fake_quant_offline: workspace required when out_current_max is requested");
+  float* stat = (float*)ws;
+  const bool use_abs = !(flags & FQ_ACT_NO_ABS);
+  if (int rc = init_stat(stat, n, use_abs, st)) return rc;
+  int rc;
+  if (codes)
+    rc = launch_apply<false, true, true>(x, y, codes, n, inner, nullptr, threshold, levels, flags, stat, nullptr, st);
+  else
+    rc = launch_apply<false, true, false>(x, y, nullptr, n, inner, nullptr, threshold, levels, flags, stat, nullptr,
+                                          st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(batch_mean_kernel, dim3(1), dim3(64), 0, st, stat, (int)n, out_current_max);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_global_avg_pool_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, int flags, float* stat_out,
+                            fqStream_t stream) {
+  FQ_REQUIRE(x && y, "fq_global_avg_pool_stat: null pointer");
+  FQ_REQUIRE(n > 0 && c > 0 && hw > 0 && hw < (1ll << 31) && c < (1ll << 31), "fq_global_avg_pool_stat: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const bool prezeroed = (flags & FQ_STAT_PREZEROED) != 0;
+  if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  const int64_t planes = n * c;
+  hipLaunchKernelGGL(gap_stat_kernel, dim3((unsigned)((planes + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, x, y, planes,
+                     (int)c, (int)hw, stat_out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_eval_counters(const float* logits, const int64_t* labels, int64_t n, int64_t classes, float* counters,
+                     fqStream_t stream) {
+  FQ_REQUIRE(logits && labels && counters, "fq_eval_counters: null pointer");
+  FQ_REQUIRE(n > 0 && classes > 0 && classes < (1ll << 30) && n < (1ll << 31), "fq_eval_counters: bad shape");
+  const int64_t grid = (n + (kBlock / 64) - 1) / (kBlock / 64);
+  hipLaunchKernelGGL(eval_counters_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, logits,
+                     (const long long*)labels, n, (int)classes, counters);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+}  // extern "C"
