@@ -20,8 +20,14 @@ __global__ void ema_kernel(float* __restrict__ state, const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------------------------
 // K7: 2048-bin histogram, LDS-privatised (one copy per wavefront), zeros skipped, exact uint64 accumulation.
+// Bound by the 4 B/elem read: a workgroup walks a contiguous range of 32 KiB chunks with all 8 x 16 B loads of a
+// chunk in flight per lane BEFORE the first LDS atomic (the atomics are order-free, the compiler otherwise keeps one
+// load outstanding per iteration: 3.6 TB/s), then bins the 32 values.  Bin = (int)(clip(v, 0, max) * bins/(max+1e-5))
+// exactly as distribution_calibrate.py:39-42; an index equal to `bins` (max >= 256: fp32 max + 1e-5 == max) is clamped
+// into the last bin (documented deviation).  Flush: one 64-bit global atomic per non-empty bin and workgroup.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void histogram_kernel(const float* __restrict__ x, int64_t numel, int vec_ok,
+template <bool VEC, bool NT, bool PIPE>
+__global__ __launch_bounds__(kBlock) void histogram_kernel(const float* __restrict__ x, int64_t numel,
                                                            const float* __restrict__ max_dev, int bins,
                                                            unsigned long long* __restrict__ hist,
                                                            unsigned int* __restrict__ neg_count) {
@@ -31,30 +37,63 @@ __global__ __launch_bounds__(kBlock) void histogram_kernel(const float* __restri
   unsigned int* mine = lh + (threadIdx.x >> 6) * bins;
   const float mx = max_dev[0];
   const float scales = (float)bins / (mx + 1e-5f);                       // distribution_calibrate.py:41
+  const int last = bins - 1;
   unsigned int neg = 0;
   auto put = [&](float v) {
     neg += (v < 0.0f) ? 1u : 0u;
-    const float c = fminf(fmaxf(v, 0.0f), mx);                           // :39
+    const float c = __builtin_amdgcn_fmed3f(v, 0.0f, mx);                // :39 (NaN -> 0, like fmin(fmax()))
     if (c != 0.0f) {                                                     // :40
       int idx = (int)(c * scales);                                       // :42 (truncation)
-      idx = idx < bins ? idx : bins - 1;
+      idx = idx < last ? idx : last;
       atomicAdd(&mine[idx], 1u);
     }
   };
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  if (vec_ok) {
-    const float4* p = reinterpret_cast<const float4*>(x);
-    const int64_t nvec = numel / 4;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-      float4 v = p[i];
-      put(v.x);
-      put(v.y);
-      put(v.z);
-      put(v.w);
+  auto put8 = [&](const f4 (&v)[kUnroll]) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      put(v[u].x);
+      put(v[u].y);
+      put(v[u].z);
+      put(v[u].w);
     }
-    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) put(x[i]);
-  } else {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) put(x[i]);
+  };
+  const int64_t chunks = (numel + kChunk - 1) / kChunk;
+  const int64_t full = numel / kChunk;                                   // chunks [0, full) are whole
+  const ChunkRange rg = block_range(chunks);
+  const int64_t vend = VEC ? (rg.end < full ? rg.end : full) : rg.begin; // whole chunks of this workgroup: [begin, vend)
+  if (VEC && rg.begin < vend) {
+    const f4* p = reinterpret_cast<const f4*>(x) + rg.begin * (kChunk / kVec) + threadIdx.x;
+    f4 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) v[u] = ld4<NT>(p + u * kBlock);
+    for (int64_t c = rg.begin; c < vend; ++c) {
+      if (PIPE) {
+        // next chunk's loads go out before this chunk's atomics (the last iteration re-reads its own chunk)
+        const f4* pn = p + (c + 1 < vend ? (kChunk / kVec) : 0);
+        f4 w[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) w[u] = ld4<NT>(pn + u * kBlock);
+        FQ_PIN();
+        put8(v);
+        FQ_PIN();
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = w[u];
+        p = pn;
+      } else {
+        put8(v);
+        if (c + 1 < vend) {
+          p += kChunk / kVec;
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) v[u] = ld4<NT>(p + u * kBlock);
+        }
+      }
+    }
+  }
+  for (int64_t c = (VEC ? vend : rg.begin); c < rg.end; ++c) {           // ragged last chunk / unaligned tensors
+    const int64_t base = c * (int64_t)kChunk;
+    const int64_t rem = numel - base;
+    const int cnt = (int)(rem < kChunk ? rem : kChunk);
+    for (int i = threadIdx.x; i < cnt; i += kBlock) put(x[base + i]);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < bins; b += kBlock) {
@@ -181,15 +220,24 @@ int fq_histogram_accumulate(const float* x, int64_t numel, const float* max_dev,
   FQ_REQUIRE(x && max_dev && hist, "fq_histogram_accumulate: null pointer");
   FQ_REQUIRE(numel > 0, "fq_histogram_accumulate: empty tensor");
   FQ_REQUIRE(bins > 0 && bins <= 8192, "fq_histogram_accumulate: bins=%d out of range (1..8192)", bins);
-  // every workgroup ends with up to `bins` global 64-bit atomics: keep the grid at ~2 workgroups per CU (enough loads in
-  // flight for a read-only stream) so that the flush stays a small fraction of the work
+  // every workgroup ends with up to `bins` global 64-bit atomics: a few workgroups per CU (each with 32 KiB of loads in
+  // flight) keep the stream busy while the flush stays a small fraction of the work
+  static const int wg_per_cu = env_int("FQ_HIST_WG_PER_CU", 2);
   int64_t hg = (numel + kChunk - 1) / kChunk;
-  if (hg > (int64_t)num_cu() * 2) hg = (int64_t)num_cu() * 2;
+  if (hg > (int64_t)num_cu() * wg_per_cu) hg = (int64_t)num_cu() * wg_per_cu;
   const int grid = (int)(hg < 1 ? 1 : hg);
   ProfScope prof(FQ_KERNEL_HISTOGRAM, 4.0 * (double)numel, (hipStream_t)stream);
-  hipLaunchKernelGGL(histogram_kernel, dim3(grid), dim3(kBlock), (size_t)4 * bins * sizeof(unsigned int),
-                     (hipStream_t)stream, x, numel, aligned16(x) ? 1 : 0, max_dev, bins,
-                     (unsigned long long*)hist, (unsigned int*)neg_count);
+  const size_t lds = (size_t)4 * bins * sizeof(unsigned int);
+  static const int hist_form = env_int("FQ_HIST_FORM", 3);          // bit 0: nontemporal loads, bit 1: pipelined loads
+#define FQ_HIST(V, N, P)                                                                                              \
+  hipLaunchKernelGGL((histogram_kernel<V, N, P>), dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, x, numel,       \
+                     max_dev, bins, (unsigned long long*)hist, (unsigned int*)neg_count)
+  if (!aligned16(x)) FQ_HIST(false, false, false);
+  else if (hist_form == 0) FQ_HIST(true, false, false);
+  else if (hist_form == 1) FQ_HIST(true, true, false);
+  else if (hist_form == 2) FQ_HIST(true, false, true);
+  else FQ_HIST(true, true, true);
+#undef FQ_HIST
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

@@ -408,24 +408,31 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(const float* __restrict_
                                                         float* __restrict__ out_min, float* __restrict__ out_max) {
   __shared__ float red[4];
   float mx = USE_ABS ? 0.0f : -INFINITY, mn = INFINITY;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  if (vec_ok) {
-    const float4* p = reinterpret_cast<const float4*>(x);
-    const int64_t nvec = numel / 4;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-      float4 v = p[i];
-      mx = fmaxf(mx, fmaxf(fmaxf(stat_of<USE_ABS>(v.x), stat_of<USE_ABS>(v.y)),
-                           fmaxf(stat_of<USE_ABS>(v.z), stat_of<USE_ABS>(v.w))));
-      if (WANT_MIN) mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
-    }
-    for (int64_t i = nvec * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
-      mx = fmaxf(mx, stat_of<USE_ABS>(x[i]));
-      if (WANT_MIN) mn = fminf(mn, x[i]);
-    }
-  } else {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
-      mx = fmaxf(mx, stat_of<USE_ABS>(x[i]));
-      if (WANT_MIN) mn = fminf(mn, x[i]);
+  auto take = [&](float v) {
+    mx = fmaxf(mx, stat_of<USE_ABS>(v));
+    if (WANT_MIN) mn = fminf(mn, v);
+  };
+  // contiguous ranges of 32 KiB chunks, all 8 loads of a chunk in flight per lane (as K1)
+  const int64_t chunks = (numel + kChunk - 1) / kChunk;
+  const ChunkRange rg = block_range(chunks);
+  for (int64_t c = rg.begin; c < rg.end; ++c) {
+    const int64_t base = c * (int64_t)kChunk;
+    const int64_t rem = numel - base;
+    if (vec_ok && rem >= kChunk) {
+      const f4* p = reinterpret_cast<const f4*>(x + base);
+      f4 v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) v[u] = p[threadIdx.x + u * kBlock];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        take(v[u].x);
+        take(v[u].y);
+        take(v[u].z);
+        take(v[u].w);
+      }
+    } else {
+      const int cnt = (int)(rem < kChunk ? rem : kChunk);
+      for (int i = threadIdx.x; i < cnt; i += kBlock) take(x[base + i]);
     }
   }
   mx = block_max(mx, red);
@@ -435,7 +442,6 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(const float* __restrict_
     if (threadIdx.x == 0) atomic_min_f32(out_min, mn);
   }
 }
-
 
 }  // namespace
 

@@ -1,0 +1,244 @@
+"""The C++/OpenMP restatement (oracle/fq_host.cpp -> oracle/libfq_host.so, include/fakequant_host.h) pinned bit-for-bit
+against the golden vectors made from the reference's own Python and against the numpy oracle on seeded inputs.  CPU only.
+Once pinned here it serves as the fast oracle for the full-size GPU parity tests and as bench.py's CPU baseline."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import fq_oracle as O
+from oracle import host as H
+
+
+def _eq(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.array_equal(a, b, equal_nan=True), "%s: %d mismatches, max |d|=%g" % (
+        what, int((a != b).sum()), float(np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)))))
+
+
+def test_host_library_exports_every_declared_symbol():
+    import ctypes
+    text = open(os.path.join(ROOT, "include", "fakequant_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(fq_[a-z0-9_]+_host)\s*\(", text)))
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(H.build())
+    for name in declared:
+        assert hasattr(lib, name), name
+    # every device entry point that computes has a host twin
+    dev = open(os.path.join(ROOT, "include", "fakequant.h")).read()
+    dev = re.sub(r"/\*.*?\*/", "", dev, flags=re.S)
+    skip = {"fq_device_info", "fq_profile_enable", "fq_profile_reset", "fq_profile_read", "fq_profile_calibrate",
+            "fq_act_workspace_bytes", "fq_pwconv_workspace_bytes", "fq_weight_workspace_bytes",
+            "fq_kl_workspace_bytes"}
+    for name in sorted(set(re.findall(r"\b(fq_[a-z0-9_]+)\s*\(", dev)) - skip):
+        assert name + "_host" in declared, "no host twin for " + name
+
+
+# ---- against the golden vectors (the reference's own code) ---------------------------------------------------------
+@pytest.mark.parametrize("name", ["halfnormal", "exponential", "relu_outlier", "tiny_range", "shape4d"])
+def test_histogram_golden(golden, name):
+    g = golden("g1_histogram")
+    fm = g[name + "/fm"]
+    h, m = H.discrete_histogram(fm, 2048, None)
+    _eq(h, g[name + "/hist_auto"])
+    assert m == g[name + "/max_auto"]
+    _eq(H.discrete_histogram(fm, 2048, g[name + "/max_fixed"])[0], g[name + "/hist_fixed"])
+    _eq(H.discrete_histogram(fm, 128, None)[0], g[name + "/hist_auto_b128"])
+
+
+def test_kl_golden(golden):
+    g = golden("g2_kl")
+    for name, levels in [("halfnormal", 256), ("exponential", 128), ("relu_outlier", 16), ("accumulated6", 256),
+                         ("sparse", 8), ("spike", 128)]:
+        assert int(H.kl_search(g[name + "/hist"], levels, levels)[0]) == int(g["%s/best_L%d" % (name, levels)])
+    for name in ("halfnormal", "sparse"):
+        for levels in (16, 32):
+            assert int(H.kl_search(g[name + "/hist_b256"], levels, levels)[0]) == \
+                int(g["%s/best_b256_L%d" % (name, levels)])
+    # several layers in one call
+    hs = np.stack([g[n + "/hist"] for n in ("halfnormal", "accumulated6")])
+    _eq(H.kl_search(hs, 256, 256), np.int32([g["halfnormal/best_L256"], g["accumulated6/best_L256"]]))
+
+
+def test_activation_golden(golden):
+    g = golden("g4_activation")
+    tags = sorted({k.split("/")[0] for k in g if k.startswith("conv_")})
+    for tag in tags:
+        x = g[tag + "/x"]
+        if tag == "conv_zero":
+            _eq(H.fake_quant_online(x)[0], g["conv_zero/online_y"])
+            continue
+        signed = "_s_" in tag
+        width = int(tag.rsplit("w", 1)[1])
+        fl = H.act_flags(signed)
+        y, cur, codes = H.fake_quant_online(x, width, fl, want_codes=True)
+        assert cur == g[tag + "/online_max"]
+        _eq(codes, g[tag + "/online_codes"].astype(np.int32), tag)
+        _eq(y, g[tag + "/online_y"], tag)
+        y, cur, codes = H.fake_quant_offline(x, g[tag + "/offline_thr"], width, fl, want_codes=True)
+        assert cur == g[tag + "/offline_curmax"]
+        _eq(codes, g[tag + "/offline_codes"].astype(np.int32), tag)
+        _eq(y, g[tag + "/offline_y"], tag)
+        _eq(H.unfused_chain(x, width, fl)[0], g[tag + "/online_y"], tag + " unfused chain")
+    for tag in sorted({k.split("/")[0] for k in g if k.startswith("dense_")}):
+        signed = "_s_" in tag
+        width = int(tag.rsplit("w", 1)[1])
+        fl = H.act_flags(signed, lo_neg_max=False)
+        _eq(H.fake_quant_online(g[tag + "/x"], width, fl)[0], g[tag + "/online_y"], tag)
+        _eq(H.fake_quant_offline(g[tag + "/x"], g[tag + "/offline_thr"], width, fl)[0], g[tag + "/offline_y"], tag)
+
+
+def test_weight_golden(golden):
+    g = golden("g5_weight")
+    for name, grp in {"dw16": 16, "pw32x16": 1, "c8x4k3": 1}.items():
+        w = g[name + "/w"]
+        for qt in ("layer", "group", "channel"):
+            for width in (8, 4):
+                key = "%s/%s_w%d" % (name, qt, width)
+                if key in g:
+                    rows = {"layer": 1, "group": grp, "channel": w.shape[0]}[qt]
+                    _eq(H.weight_fake_quant(w, rows, width)[0], g[key], key)
+    for qt in ("layer", "channel"):
+        for width in (8, 4):
+            w = g["dense/%s_w%d/w" % (qt, width)]
+            _eq(H.weight_fake_quant(w, 1 if qt == "layer" else w.shape[0], width)[0], g["dense/%s_w%d/wq" % (qt, width)])
+
+
+@pytest.mark.parametrize("variant", ["F23", "F43", "F63"])
+def test_winograd_golden(golden, variant):
+    g = golden("g6_winograd")
+    for name in ("c8x4k3", "dw16"):
+        for width in (8, 4):
+            w = g["%s/%s_w%d/w" % (variant, name, width)]
+            wq, _ = H.wino_weight_fake_quant(w, g[variant + "/G"], g[variant + "/GI"], g[variant + "/GTI"], width)
+            _eq(wq, g["%s/%s_w%d/wq" % (variant, name, width)])
+
+
+def test_ema_and_codes_golden(golden):
+    g = golden("g7_g9_ema_state")
+    for tag in ("layer_w8", "channel_w4"):
+        cur, ema = g[tag + "/calib_cur"], g[tag + "/calib_ema"]
+        state = np.zeros(cur.shape[1], np.float32)
+        for step in range(cur.shape[0]):
+            state = H.ema_update(state, cur[step], 0.9)
+            _eq(state, ema[step])
+    g = golden("g8_quantized_conv")
+    for name in ("u01", "normal", "shifted"):
+        for t in ("int8", "uint8"):
+            codes, rng = H.quantize_codes(g[name + "/x"], t)
+            _eq(codes, g["%s/%s_codes" % (name, t)])
+            assert rng[2] == g["%s/%s_scale" % (name, t)]
+            _eq(H.dequantize(codes, rng[2]), g["%s/%s_deq" % (name, t)])
+
+
+# ---- against the numpy oracle on seeded inputs (ragged shapes, ties, negatives, every mode) ---------------------------
+SHAPES = [(4, 8, 7, 7), (3, 5, 9, 11), (2, 32, 14, 14), (5, 1000), (1, 3, 17, 5)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("signed,width", [(False, 8), (True, 8), (False, 4), (True, 4), (False, 2)])
+def test_activation_vs_numpy_oracle(shape, signed, width):
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(shape) * 2.5).astype(np.float32)
+    x.reshape(-1)[::7] = 0
+    want_y, want_cur, scale, want_codes = O.conv_input_fake_quant(x, signed, width)
+    # exact ties of the quotient: multiples of half the scale
+    x.reshape(-1)[1::11] = (np.arange(x.reshape(-1)[1::11].size, dtype=np.float32) + np.float32(0.5)) * scale
+    want_y, want_cur, scale, want_codes = O.conv_input_fake_quant(x, signed, width)
+    y, cur, codes = H.fake_quant_online(x, width, H.act_flags(signed), want_codes=True)
+    assert cur == want_cur
+    _eq(codes, want_codes.astype(np.int32))
+    _eq(y, want_y)
+    _eq(H.absmax_per_sample(x), O.absmax_per_sample(x))
+    y2, _, _ = H.fake_quant_online_prestat(x, O.absmax_per_sample(x), width, H.act_flags(signed))
+    _eq(y2, want_y)
+    thr = np.float32(1.7)
+    _eq(H.fake_quant_offline(x, thr, width, H.act_flags(signed))[0], O.conv_input_fake_quant(x, signed, width, thr)[0])
+    _eq(H.fake_quant_online(x, width, H.act_flags(signed, lo_neg_max=False))[0],
+        O.dense_input_fake_quant(x, signed, width)[0])
+    a = np.abs(x) + np.float32(0.1)
+    ya, cura, _ = H.fake_quant_online(a, width, H.act_flags(no_abs=True, no_eps=True))
+    wa, wcur, _, _ = O.act_output_fake_quant(a, width)
+    assert cura == wcur
+    _eq(ya, wa)
+
+
+def test_fused_producers_vs_numpy_oracle():
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((3, 8, 9, 10)) * 2).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 8).astype(np.float32)
+    sh = rng.standard_normal(8).astype(np.float32)
+    for act in ("relu", "relu6", "none"):
+        y, stat = H.bn_act(x, sc, sh, act, want_stat=True)
+        _eq(y, O.bn_act(x, sc, sh, act))
+        _eq(stat, O.absmax_per_sample(y))
+    _eq(H.global_avg_pool(x), O.global_avg_pool(x))
+    w = (rng.standard_normal((8, 1, 3, 3)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(8).astype(np.float32)
+    for stride in (1, 2):
+        for in_max in (None, np.float32(2.2)):
+            for signed in (False, True):
+                want = O.dwconv3x3(x, w, b, stride, in_max, signed, 8, None, sc, sh, "relu6")
+                _eq(H.dwconv3x3(x, w, b, stride, in_max, signed=signed, bn_scale=sc, bn_shift=sh, act="relu6"), want)
+    stat = O.absmax_per_sample(x)
+    _eq(H.dwconv3x3(x, w, None, 1, in_stat=stat, act="relu"), O.dwconv3x3(x, w, None, 1, O.batch_mean(stat), act="relu"))
+    xs = rng.standard_normal((2, 3, 12, 14)).astype(np.float32)
+    ws = (rng.standard_normal((32, 3, 3, 3)) * 0.2).astype(np.float32)
+    sc32, sh32 = rng.uniform(0.5, 1.5, 32).astype(np.float32), rng.standard_normal(32).astype(np.float32)
+    _eq(H.stem_conv3x3s2(xs, ws, None, sc32, sh32, "relu"), O.stem_conv3x3s2(xs, ws, None, sc32, sh32, "relu"))
+    # pointwise on integer codes: per-layer and per-channel weights, 8 and 4 bit, signed and unsigned inputs
+    wp = (rng.standard_normal((24, 8, 1, 1)) * 0.2).astype(np.float32)
+    for rps, ww in ((24, 8), (1, 8), (1, 4)):
+        for signed in (False, True):
+            want = O.pwconv_i8(x, wp, rps, ww, np.float32(2.0), signed, 8, None, None, sc[:1].repeat(24), sh[:1].repeat(24),
+                               "relu")
+            got = H.pwconv_i8(x, wp, rps, ww, np.float32(2.0), signed=signed, bn_scale=sc[:1].repeat(24),
+                              bn_shift=sh[:1].repeat(24), act="relu")
+            _eq(got, want)
+    codes, scales, rowsum = H.weight_codes(wp, 1, 4)
+    wc, ws_ = O.weight_codes(wp, 1, 4)
+    _eq(codes[:24, :8].astype(np.int32), wc)
+    _eq(scales, ws_)
+    _eq(rowsum, wc.sum(axis=1).astype(np.int32))
+
+
+def test_calibration_vs_numpy_oracle():
+    rng = np.random.default_rng(5)
+    fm = np.maximum(rng.standard_normal((4, 16, 14, 14)), 0).astype(np.float32) * np.float32(3)
+    h, m = H.discrete_histogram(fm, 2048)
+    wh, wm = O.discrete_histogram(fm, 2048)
+    assert m == wm
+    _eq(h, wh)
+    h300, _ = H.discrete_histogram(fm * np.float32(100), 2048)      # max >= 256: index == bins clamps into the last bin
+    _eq(h300, O.discrete_histogram(fm * np.float32(100), 2048)[0])
+    for levels in (256, 128, 16):
+        assert int(H.kl_search(h, levels, levels)[0]) == O.kl_calibrate(h, levels, levels, 2048)
+    with pytest.raises(RuntimeError, match="min_bins should be greater than levels"):
+        H.kl_search(h, 256, 128)
+    lg = rng.standard_normal((7, 10)).astype(np.float32)
+    lg[2, 3] = lg[2, 7] = lg[2].max() + 1                            # tie: first index wins
+    lb = np.array([1, 2, 3, 4, 5, 6, 11], np.int64)
+    _eq(H.eval_counters(lg, lb), O.eval_counters(lg, lb))
+    xc = rng.integers(-128, 128, (64, 64)).astype(np.int8)
+    wc = rng.integers(-127, 128, (32, 64)).astype(np.int8)
+    _eq(H.gemm_i8_codes(xc, wc, 2, 32, 128), O.gemm_i8_codes(xc, wc, 2, 32, 128))
+    _eq(H.ste_forward(lg, np.float32([0.1]), 1.0, -1.0), O.ste_forward(lg, np.float32(0.1), 1.0, -1.0))
+
+
+def test_thread_count_does_not_change_results():
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((6, 16, 28, 28)) * 2).astype(np.float32)
+    H.set_threads(1)
+    y1, c1, _ = H.fake_quant_online(x)
+    h1, _ = H.discrete_histogram(np.abs(x), 2048)
+    H.set_threads(0)
+    assert H.threads() >= 1
+    y2, c2, _ = H.fake_quant_online(x)
+    h2, _ = H.discrete_histogram(np.abs(x), 2048)
+    assert c1 == c2
+    _eq(y1, y2)
+    _eq(h1, h2)
