@@ -84,6 +84,15 @@ int fq_batch_mean(const float* v, int64_t n, float* out, fqStream_t stream);
 /* Row-wise form for L layers at once (the multi-GPU calibration step): out[r] <- batch mean of v[r*row_stride ..+n). */
 int fq_batch_mean_rows(const float* v, int64_t rows, int64_t n, int64_t row_stride, float* out, fqStream_t stream);
 
+/* The calibration-step collective of a sharded batch (dist.py; reference arithmetic: the `.mean()` of convert_conv2d.py:56
+ * feeding `_update_ema`, convert.py:66-70, taken over the GLOBAL batch):
+ *   fq_stat_rows_sum : out[r] <- sum_fp64(v[r*row_stride .. +n)) in sample order for r < rows, out[rows] <- n (as a double):
+ *                      one record of rows+1 doubles per rank; the ranks' records are then summed by ONE all-reduce;
+ *   fq_mean_from_sums: out[r] <- fp32(sums[r]) / fp32(sums[rows]) — the batch mean of the global batch for every layer.
+ * n may be 0 (a rank without a batch in this step contributes an empty record).                                        */
+int fq_stat_rows_sum(const float* v, int64_t rows, int64_t n, int64_t row_stride, double* out, fqStream_t stream);
+int fq_mean_from_sums(const double* sums, int64_t rows, float* out, fqStream_t stream);
+
 /* Sharded-batch form (dist.py): `packs` holds `world` records of `stride` floats, record w = {n_w, v_w[0..n_w)} as
  * all-gathered from the ranks; out[0] <- the batch mean over the concatenation v_0 | v_1 | ... (global sample order),
  * same ordered fp64 accumulation.  No host round trip for the (possibly ragged) counts.                            */

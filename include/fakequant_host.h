@@ -35,6 +35,8 @@ int fq_absmax_per_sample_host(const float* x, int64_t n, int64_t inner, unsigned
 int fq_batch_mean_host(const float* v, int64_t n, float* out, fqStream_t stream);
 int fq_batch_mean_rows_host(const float* v, int64_t rows, int64_t n, int64_t row_stride, float* out,
                             fqStream_t stream);
+int fq_stat_rows_sum_host(const float* v, int64_t rows, int64_t n, int64_t row_stride, double* out, fqStream_t stream);
+int fq_mean_from_sums_host(const double* sums, int64_t rows, float* out, fqStream_t stream);
 int fq_batch_mean_gathered_host(const float* packs, int world, int64_t stride, float* out, fqStream_t stream);
 int fq_fake_quant_online_host(const float* x, float* y, int64_t n, int64_t inner, int width, unsigned flags,
                               float* out_current_max, int32_t* codes, void* ws, fqStream_t stream);

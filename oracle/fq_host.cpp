@@ -159,6 +159,23 @@ int fq_batch_mean_rows_host(const float* v, int64_t rows, int64_t n, int64_t row
   return FQ_OK;
 }
 
+int fq_stat_rows_sum_host(const float* v, int64_t rows, int64_t n, int64_t row_stride, double* out, fqStream_t) {
+  REQUIRE(v && out && rows > 0 && n >= 0 && row_stride >= n, "fq_stat_rows_sum_host: bad arguments");
+  for (int64_t r = 0; r < rows; ++r) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) acc += (double)v[r * row_stride + i];
+    out[r] = acc;
+  }
+  out[rows] = (double)n;
+  return FQ_OK;
+}
+
+int fq_mean_from_sums_host(const double* sums, int64_t rows, float* out, fqStream_t) {
+  REQUIRE(sums && out && rows > 0, "fq_mean_from_sums_host: bad arguments");
+  for (int64_t r = 0; r < rows; ++r) out[r] = (float)sums[r] / (float)sums[rows];
+  return FQ_OK;
+}
+
 int fq_batch_mean_gathered_host(const float* packs, int world, int64_t stride, float* out, fqStream_t) {
   REQUIRE(packs && out && world > 0 && stride > 1, "fq_batch_mean_gathered_host: bad arguments");
   double acc = 0.0;

@@ -70,6 +70,31 @@ def batch_mean_gathered(packs, out=None):
     return r
 
 
+def stat_rows_sum(stats, n, out=None):
+    a = _np(stats).astype(np.float64)
+    rec = np.zeros(a.shape[0] + 1, np.float64)
+    for r in range(a.shape[0]):
+        acc = np.float64(0.0)
+        for v in a[r, :int(n)]:
+            acc += v
+        rec[r] = acc
+    rec[-1] = float(n)
+    r_ = torch.from_numpy(rec)
+    if out is not None:
+        out.copy_(r_)
+        return out
+    return r_
+
+
+def mean_from_sums(sums, out=None):
+    a = _np(sums)
+    r_ = _t((a[:-1].astype(F32) / F32(a[-1])).astype(F32))
+    if out is not None:
+        out.copy_(r_)
+        return out
+    return r_
+
+
 def batch_mean_rows(v, out=None):
     r = _t(np.asarray([O.batch_mean(row) for row in _np(v)], dtype=F32))
     if out is not None:
@@ -300,7 +325,7 @@ def default_device(what="this call"):
     return torch.device("cpu")
 
 
-_REPLACED = ["require_hip", "default_device", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
+_REPLACED = ["require_hip", "default_device", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
              "bn_act_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]

@@ -32,6 +32,8 @@ EXPORTS = {
     "fq_absmax_per_sample": (_int, [_vp, _i64, _i64, _uint, _vp, _vp]),
     "fq_batch_mean": (_int, [_vp, _i64, _vp, _vp]),
     "fq_batch_mean_gathered": (_int, [_vp, _int, _i64, _vp, _vp]),
+    "fq_stat_rows_sum": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "fq_mean_from_sums": (_int, [_vp, _i64, _vp, _vp]),
     "fq_batch_mean_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "fq_fake_quant_online": (_int, [_vp, _vp, _i64, _i64, _int, _uint, _vp, _vp, _vp, _vp]),
     "fq_fake_quant_online_prestat": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp]),

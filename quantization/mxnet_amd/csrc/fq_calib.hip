@@ -228,7 +228,9 @@ int fq_histogram_accumulate(const float* x, int64_t numel, const float* max_dev,
   const int grid = (int)(hg < 1 ? 1 : hg);
   ProfScope prof(FQ_KERNEL_HISTOGRAM, 4.0 * (double)numel, (hipStream_t)stream);
   const size_t lds = (size_t)4 * bins * sizeof(unsigned int);
-  static const int hist_form = env_int("FQ_HIST_FORM", 3);          // bit 0: nontemporal loads, bit 1: pipelined loads
+  static const int hist_form = env_int("FQ_HIST_FORM", 1);          // bit 0: nontemporal loads, bit 1: pipelined loads
+  // measured on (128,64,112,112), 2 workgroups per CU (profiles/r2_hist_variants.txt): plain 5.28, nontemporal 5.88,
+  // pipelined 5.31, both 5.80 TB/s; 3-4 workgroups per CU are slower in every form
 #define FQ_HIST(V, N, P)                                                                                              \
   hipLaunchKernelGGL((histogram_kernel<V, N, P>), dim3(grid), dim3(kBlock), lds, (hipStream_t)stream, x, numel,       \
                      max_dev, bins, (unsigned long long*)hist, (unsigned int*)neg_count)

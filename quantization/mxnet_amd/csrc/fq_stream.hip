@@ -79,6 +79,26 @@ __global__ void batch_mean_rows_kernel(const float* __restrict__ v, int64_t rows
   if (r < rows) out[r] = batch_mean_seq(v + r * stride, n);
 }
 
+// K1c: the two ends of the calibration-step collective (dist.py): per layer the fp64 sum of its per-sample maxima (sample
+// order) followed by the local sample count, and — after the ranks' records were summed — mean = fp32(sum) / fp32(count),
+// i.e. the batch mean of K1b over the GLOBAL batch (fp64 partial sums of a few thousand fp32 values are exact unless their
+// exponents spread over more than 2^20, the same condition batch_mean_dev accepts).
+__global__ void stat_rows_sum_kernel(const float* __restrict__ v, int64_t rows, int n, int64_t stride,
+                                     double* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) {
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += (double)v[r * stride + i];
+    out[r] = acc;
+  }
+  if (r == rows) out[rows] = (double)n;
+}
+
+__global__ void mean_from_sums_kernel(const double* __restrict__ sums, int64_t rows, float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) out[r] = (float)sums[r] / (float)sums[rows];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K2: apply.  ONLINE: threshold = mean of stat_in[0..n);  else threshold = thr[0].
 //     STATS (offline only): also produce the per-sample statistic of x into stat_out (fused, same pass).
@@ -446,6 +466,23 @@ int fq_batch_mean_rows(const float* v, int64_t rows, int64_t n, int64_t row_stri
   FQ_REQUIRE(rows > 0 && n > 0 && n < (1ll << 31) && row_stride >= n, "fq_batch_mean_rows: bad shape");
   hipLaunchKernelGGL(batch_mean_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, v,
                      rows, (int)n, row_stride, out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_stat_rows_sum(const float* v, int64_t rows, int64_t n, int64_t row_stride, double* out, fqStream_t stream) {
+  FQ_REQUIRE(v && out, "fq_stat_rows_sum: null pointer");
+  FQ_REQUIRE(rows > 0 && n >= 0 && n < (1ll << 31) && row_stride >= n, "fq_stat_rows_sum: bad shape");
+  hipLaunchKernelGGL(stat_rows_sum_kernel, dim3((unsigned)((rows + 1 + 63) / 64)), dim3(64), 0, (hipStream_t)stream, v,
+                     rows, (int)n, row_stride, out);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_mean_from_sums(const double* sums, int64_t rows, float* out, fqStream_t stream) {
+  FQ_REQUIRE(sums && out && rows > 0, "fq_mean_from_sums: bad arguments");
+  hipLaunchKernelGGL(mean_from_sums_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sums,
+                     rows, out);
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

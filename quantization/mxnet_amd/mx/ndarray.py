@@ -115,6 +115,7 @@ class NDArray(object):
         if isinstance(other, Context):
             return NDArray(self._t.to(other.torch_device, copy=True))
         other._t.copy_(self._t)
+        other._fq_stat = None                   # a fused producer's statistic described the OLD contents
         return other
 
     def copy(self):

@@ -5,6 +5,7 @@ HIP device; anything else raises (there is deliberately no CPU path here — the
 infrastructure and is never imported by this package).
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -12,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -24,7 +25,14 @@ def _lib_():
 
 
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    """HIP stream handle for a launch on `t`'s device.  The library launches on whatever device is CURRENT for the
+    calling thread (kernels, memsets and the cached compute-unit count follow it), so the tensor's device is made current
+    here — every entry point evaluates `_stream(x)` as an argument of its C call, i.e. before the call happens.  A process
+    that only ever uses one GPU (the normal case: one process per GPU) never takes the branch."""
+    dev = t.device
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _ptr(t):
@@ -156,6 +164,29 @@ def batch_mean_gathered(packs, out=None):
     return out
 
 
+def stat_rows_sum(stats, n, out=None):
+    """One rank's record for the calibration-step collective: per layer the fp64 sum of its first `n` per-sample maxima,
+    then `n` itself.  stats: (L, width) fp32 -> (L + 1,) fp64."""
+    _check(stats, "stats")
+    rows, width = stats.shape
+    if out is None:
+        out = torch.empty(rows + 1, dtype=torch.float64, device=stats.device)
+    _check(out, "out", torch.float64)
+    check_call(_lib_().fq_stat_rows_sum(_ptr(stats), rows, int(n), width, _ptr(out), _stream(stats)))
+    return out
+
+
+def mean_from_sums(sums, out=None):
+    """(L + 1,) fp64 [sum_0 .. sum_{L-1}, count] (summed over the ranks) -> (L,) fp32 batch means of the global batch."""
+    _check(sums, "sums", torch.float64)
+    rows = sums.numel() - 1
+    if out is None:
+        out = torch.empty(rows, dtype=torch.float32, device=sums.device)
+    _check(out, "out")
+    check_call(_lib_().fq_mean_from_sums(_ptr(sums), rows, _ptr(out), _stream(sums)))
+    return out
+
+
 def batch_mean_rows(v, out=None):
     """Row-wise `batch_mean`: v (rows, n) contiguous -> (rows,)."""
     _check(v, "v")
@@ -214,8 +245,9 @@ _PREZEROED = 0x100
 
 class StatArena(object):
     """Per-forward pool of pre-zeroed per-sample statistic rows: ONE zeroing launch per forward instead of one memset
-    per producer kernel (~27 per mobilenet forward).  quantize/fuse.py owns the instance; producers call `take(n)`."""
-    current = None
+    per producer kernel (~27 per mobilenet forward).  quantize/fuse.py owns the instance; producers call `take(n)`.
+    The forward under way is tracked per thread (two nets evaluated from two threads keep their own arenas)."""
+    _tls = threading.local()
 
     def __init__(self, slots, device):
         self.slots, self.device = slots, device
@@ -230,15 +262,15 @@ class StatArena(object):
         else:
             self.buf.zero_()
         self.next = 0
-        StatArena.current = self
+        StatArena._tls.current = self
 
     def end(self):
-        if StatArena.current is self:
-            StatArena.current = None
+        if getattr(StatArena._tls, "current", None) is self:
+            StatArena._tls.current = None
 
     @staticmethod
     def take(n, device):
-        a = StatArena.current
+        a = getattr(StatArena._tls, "current", None)
         if a is None or a.next >= a.slots or n > a.width or a.device != device:
             return None
         row = a.buf[a.next, :n]

@@ -1,17 +1,17 @@
-"""`convert_model`, `convert_to_relu6`, `default_convert_fn` — reference: quantize/convert/convert.py:35-137.
+"""`convert_model(net, exclude=[], convert_fn=default_convert_fn, custom_fn={})`, `convert_to_relu6(net, exclude=[])`,
+`default_convert_fn` — reference API: quantize/convert/convert.py:35-137.
 
-`convert_model(net, exclude, convert_fn, custom_fn)` walks the net with `net.apply`, dispatches on the EXACT block type
-(`convert_fn.get(type(m))`, per-instance override `custom_fn[m]`, identity-based `exclude`, :58-63) and injects the same
-control methods on the net: `update_ema`, `collect_quantized_blocks`, `quantize_input`, `enable_quantize`,
-`disable_quantize`, `fix_params`.
+`convert_model` walks the net, applies to every block the converter registered for its EXACT type (`custom_fn[block]`
+overrides per instance, `exclude` is matched by identity, :58-63) and gives the net the reference's control methods:
+`update_ema(momentum=0.9)`, `collect_quantized_blocks()`, `quantize_input(enable=True, online=True)`,
+`enable_quantize()`, `disable_quantize()`, `fix_params()`.  Here they are bound methods of one `NetControls` object
+per net (`net._fq_controls`).
 
 MI355X-first difference in `update_ema` (:66-79): the L per-block scalars (`input_max`, `current_input_max`, `act_max`,
 `current_act_max`) are re-homed into two contiguous device vectors (an "arena"; each block's Parameter becomes a view),
 so one calibration step is ONE `fq_ema_update` launch over L scalars and — across GPUs — ONE small collective
 (dist.py), with no host round trip.  The arithmetic per scalar is the reference's: (1-m)*current + m*state in fp32.
 """
-import types
-
 import torch
 
 from ...mx.gluon import nn
@@ -25,12 +25,15 @@ from .convert_bn import bypass_bn
 
 __all__ = ["convert_model", "convert_to_relu6", 'default_convert_fn']
 
+# block type -> converter (None = leave alone); the commented alternatives are the reference's own
 default_convert_fn = {
     nn.Conv2D: gen_conv2d_converter(),
     nn.Dense: gen_dense_converter(),
-    nn.Activation: None,  # convert_relu_to_relu6,  # gen_act_converter(),
-    nn.BatchNorm: None  # bypass_bn
+    nn.Activation: None,     # convert_relu_to_relu6 / gen_act_converter()
+    nn.BatchNorm: None,      # bypass_bn
 }
+
+_QUANTISABLE = (nn.Dense, nn.Conv2D, nn.Activation)
 
 
 class _Arena(object):
@@ -76,106 +79,108 @@ def _calibration_slots(blocks):
     return slots
 
 
-def convert_model(net, exclude=[], convert_fn=default_convert_fn, custom_fn={}):
-    """
-    Convert the model to the one with simulated quantization.
-    :param net: gluon Block
-        The net to convert.
-    :param exclude: list of Block
-        Blocks that want to exclude.
-    :param convert_fn: dict with (module, func) key-value pairs
-        `module`: Block type; `func`: function `func(module) -> None` applied to blocks of exactly that type.
-    :param custom_fn: dict with (block instance, func) pairs overriding `convert_fn` for single blocks.
-    :return: the converted net (converted in place).
-    """
-    # Convert network (:58-63)
-    def _convert(m):
-        if not any(m is e for e in exclude):
-            fn = custom_fn[m] if m in custom_fn else convert_fn.get(type(m))
-            if fn is not None:
-                fn(m)
-    net.apply(_convert)
+class NetControls(object):
+    """The control surface `convert_model` installs on a net."""
 
-    # Add a method to collect all quantized blocks (:82-89)
-    def _collect_quantized_blocks(self):
-        blocks = []
+    # name on the net -> method here
+    EXPORTS = {"collect_quantized_blocks": "blocks", "calibration_arena": "arena", "update_ema": "update_ema",
+               "quantize_input": "quantize_input", "enable_quantize": "enable", "disable_quantize": "disable",
+               "fix_params": "fix_params"}
 
-        def _collect_blocks(m):
-            if type(m) in (nn.Dense, nn.Conv2D, nn.Activation) and hasattr(m, 'quantize_args'):
-                blocks.append(m)
-        net.apply(_collect_blocks)
-        return blocks
-    net.collect_quantized_blocks = types.MethodType(_collect_quantized_blocks, net)
+    def __init__(self, net):
+        self.net = net
 
-    def _calibration_arena(self):
+    def install(self):
+        for public, mine in self.EXPORTS.items():
+            setattr(self.net, public, getattr(self, mine))
+        self.net._fq_controls = self
+        return self.net
+
+    # :82-89
+    def blocks(self):
+        found = []
+        self.net.apply(lambda m: found.append(m) if type(m) in _QUANTISABLE and hasattr(m, 'quantize_args') else None)
+        return found
+
+    def arena(self):
         """Bind (or re-bind after `reset_ctx`) the contiguous calibration vectors; returns the arena or None."""
-        slots = _calibration_slots(self.collect_quantized_blocks())
+        slots = _calibration_slots(self.blocks())
         if not slots:
             return None
-        arena = getattr(self, "_fq_arena", None)
+        arena = getattr(self.net, "_fq_arena", None)
         if arena is None or not arena.valid(slots):
             device = getattr(slots[0][0], slots[0][1]).data()._t.device
             ops.require_hip(device, "update_ema: calibration state")
-            arena = _Arena(slots, device)
-            self._fq_arena = arena
+            arena = self.net._fq_arena = _Arena(slots, device)
         return arena
-    net.calibration_arena = types.MethodType(_calibration_arena, net)
 
-    # Add method to update ema for `input_max` / `act_max` (and fake-bn statistics) (:66-79)
-    def _update_ema(self, momentum=0.9):
-        arena = self.calibration_arena()
+    # :66-79
+    def update_ema(self, momentum=0.9):
+        arena = self.arena()
         if arena is not None:
-            sync = getattr(self, "_fq_calibration_sync", None)
+            sync = getattr(self.net, "_fq_calibration_sync", None)
             if sync is not None:
-                sync(self, arena)        # multi-GPU: current_* <- statistic of the GLOBAL batch (dist.py)
+                sync(self.net, arena)        # multi-GPU: current_* <- statistic of the GLOBAL batch (dist.py)
             ops.ema_update(arena.state, arena.cur, momentum)
-        for qblocks in self.collect_quantized_blocks():
-            # if fake bn (vectors; not on any BASELINE config): the reference's own expression on NDArrays
-            if getattr(qblocks, "running_mean", None) is not None and hasattr(qblocks, "current_mean"):
-                qblocks.running_mean.set_data((1 - momentum) * qblocks.current_mean + momentum * qblocks.running_mean.data())
-            if getattr(qblocks, "running_var", None) is not None and hasattr(qblocks, "current_var"):
-                qblocks.running_var.set_data((1 - momentum) * qblocks.current_var + momentum * qblocks.running_var.data())
-    net.update_ema = types.MethodType(_update_ema, net)
+        keep, fresh = momentum, 1 - momentum
+        for blk in self.blocks():            # fake-BN vectors (not on any BASELINE config): plain NDArray arithmetic
+            for moving, batch in (("running_mean", "current_mean"), ("running_var", "current_var")):
+                param = getattr(blk, moving, None)
+                if param is not None and hasattr(blk, batch):
+                    param.set_data(fresh * getattr(blk, batch) + keep * param.data())
 
-    # Add method to control the mode of input quantization as online or offline (:92-102)
-    def _quantize_input(self, enable=True, online=True):
-        for qblocks in self.collect_quantized_blocks():
-            if type(qblocks) in (nn.Dense, nn.Conv2D):
-                assert (not enable) or qblocks.quantize_args.quantize_input
-                qblocks.quantize_input = enable
-                qblocks.quantize_input_offline = not online
-            elif type(qblocks) == nn.Activation:
-                assert (not enable) or qblocks.quantize_args.quantize_act
-                qblocks.quantize_act = enable
-                qblocks.quantize_act_offline = not online
-    net.quantize_input = types.MethodType(_quantize_input, net)
+    # :92-102
+    def quantize_input(self, enable=True, online=True):
+        for blk in self.blocks():
+            if type(blk) is nn.Activation:
+                if enable and not blk.quantize_args.quantize_act:
+                    raise AssertionError("%s was converted with quantize_act=False" % blk.name)
+                blk.quantize_act, blk.quantize_act_offline = enable, not online
+            elif type(blk) in (nn.Dense, nn.Conv2D):
+                if enable and not blk.quantize_args.quantize_input:
+                    raise AssertionError("%s was converted with quantize_input=False" % blk.name)
+                blk.quantize_input, blk.quantize_input_offline = enable, not online
 
-    # Add method to control enable/disable quantization (:105-114)
-    def _enable_quantize(self):
-        for qblocks in self.collect_quantized_blocks():
-            if type(qblocks) in (nn.Dense, nn.Conv2D, nn.Activation):
-                qblocks.enable_quantize = True
+    # :105-114
+    def _switch(self, on):
+        for blk in self.blocks():
+            blk.enable_quantize = on
 
-    def _disable_quantize(self):
-        for qblocks in self.collect_quantized_blocks():
-            if type(qblocks) in (nn.Dense, nn.Conv2D, nn.Activation):
-                qblocks.enable_quantize = False
-    net.enable_quantize = types.MethodType(_enable_quantize, net)
-    net.disable_quantize = types.MethodType(_disable_quantize, net)
+    def enable(self):
+        self._switch(True)
 
-    # Add method to fixed parameters(weights and bias) (:117-121) — Conv2D only, as in the reference
-    def _fix_params(self):
-        for m in net.collect_quantized_blocks():
-            if isinstance(m, nn.Conv2D):
-                m.fixed_params = 0
-    net.fix_params = types.MethodType(_fix_params, net)
+    def disable(self):
+        self._switch(False)
 
-    return net
+    # :117-121 — convolutions only, as in the reference (a Dense never freezes)
+    def fix_params(self):
+        for blk in self.blocks():
+            if isinstance(blk, nn.Conv2D):
+                blk.fixed_params = 0
+                blk.__dict__.pop("_fq_pw_cache", None)      # integer codes of the previous freeze
+
+
+def convert_model(net, exclude=[], convert_fn=default_convert_fn, custom_fn={}):
+    """
+    Convert the model to the one with simulated quantization (in place; the net is also returned).
+    :param net: gluon Block to convert.
+    :param exclude: list of blocks to leave alone (matched by identity).
+    :param convert_fn: dict {block type: func(block) -> None}, applied to blocks of exactly that type.
+    :param custom_fn: dict {block instance: func(block) -> None}, overrides `convert_fn` for single blocks.
+    """
+    def visit(block):
+        if any(block is e for e in exclude):
+            return
+        fn = custom_fn[block] if block in custom_fn else convert_fn.get(type(block))
+        if fn is not None:
+            fn(block)
+    net.apply(visit)
+    return NetControls(net).install()
 
 
 def convert_to_relu6(net, exclude=[]):
-    """Convert ReLUs in net to ReLU6 (:124-137)."""
-    def _convert_to_relu6(m):
-        if isinstance(m, nn.Activation) and m._act_type == "relu" and not any(m is e for e in exclude):
-            convert_relu_to_relu6(m)
-    return net.apply(_convert_to_relu6)
+    """Every relu Activation of the net (except `exclude`, by identity) becomes a ReLU6 (:124-137)."""
+    def visit(block):
+        if isinstance(block, nn.Activation) and block._act_type == "relu" and not any(block is e for e in exclude):
+            convert_relu_to_relu6(block)
+    return net.apply(visit)

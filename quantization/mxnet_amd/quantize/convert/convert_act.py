@@ -1,9 +1,10 @@
-"""`gen_act_converter`, `convert_relu_to_relu6` — reference: quantize/convert/convert_act.py:32-79.
+"""`gen_act_converter(width=8, quantize_act=True)` and `convert_relu_to_relu6(block)` — reference API:
+quantize/convert/convert_act.py:32-79.
 
-Activation-OUTPUT fake-quant: statistic = mean_n max_{chw} act (no abs, :50), unsigned, and NO epsilon in the divide
-(:54) — so an all-zero activation yields NaN exactly like the reference.  Served by the same HIP entry points with
-FQ_ACT_NO_ABS | FQ_ACT_NO_EPS.  (The CLI maps `nn.Activation: None`; this exists for API completeness.)"""
-import types
+Activation-OUTPUT fake-quantisation: the statistic is mean_n max_{chw} act WITHOUT abs (:50), the range is unsigned and
+the divide has NO epsilon (:54), so an all-zero activation yields NaN exactly as the reference does.  Served by the same
+HIP entry points as the convolution inputs with FQ_ACT_NO_ABS | FQ_ACT_NO_EPS.  (The CLI maps `nn.Activation: None`;
+this converter exists for API completeness.)"""
 from collections import namedtuple
 
 import torch
@@ -13,64 +14,62 @@ from ...mx import autograd
 from ...mx.gluon.nn import Activation
 from ... import ops
 from .._state import DeviceScalar
+from ._blocks import OUTPUT_RANGE, contiguous, rebind_forward
 
 __all__ = ["convert_relu_to_relu6", 'gen_act_converter']
 
 QuantizedArgs = namedtuple("ActQuantizedArgs", "width quantize_act")
 
+_OUTPUT_FLAGS = dict(no_abs=True, no_eps=True)
 
-def _relu6_forward(self, F, x):
+
+def _clipped_relu(self, F, x):
+    """relu followed by min(., 6)"""
     return F.clip(F.Activation(x, act_type=self._act_type, name='fwd'), 0., 6.)
 
 
 def convert_relu_to_relu6(m):
-    assert isinstance(m, Activation) and m._act_type == "relu"
-    m.hybrid_forward = types.MethodType(_relu6_forward, m)
+    if not (isinstance(m, Activation) and m._act_type == "relu"):
+        raise AssertionError("convert_relu_to_relu6 expects a relu Activation")
+    rebind_forward(m, _clipped_relu, keep_origin=False)
 
 
-def _act_forward(self, F, x, act_max=None):
-    # Normal Activation
-    act = self.origin_forward(F, x)
+def _scalar_slot(block, like):
+    slot = getattr(block, "_fq_cur", None)
+    if slot is None or slot.device != like.device:
+        slot = block._fq_cur = torch.zeros(1, dtype=torch.float32, device=like.device)
+    return slot
 
-    # Simulate quantization (:49-54)
-    if self.enable_quantize and self.quantize_args.quantize_act:
-        t = act._t if act._t.is_contiguous() else act._t.contiguous()
-        cur = getattr(self, "_fq_cur", None)
-        if cur is None or cur.device != t.device:
-            cur = torch.zeros(1, dtype=torch.float32, device=t.device)
-            self._fq_cur = cur
-        flags = ops.act_flags(no_abs=True, no_eps=True)
-        if self.quantize_act:
-            if self.quantize_act_offline:
-                y, _, _ = ops.fake_quant_offline(t, act_max._t, self.quantize_args.width, flags, cur_out=cur)
-            else:
-                y, _, _ = ops.fake_quant_online(t, self.quantize_args.width, flags, cur_out=cur)
-            act = NDArray(autograd.ste_link(t, y))                # identity backward; no-op unless recording
+
+def _quantised_activation(self, F, x, act_max=None):
+    out = self.origin_forward(F, x)
+    args = self.quantize_args
+    if not (self.enable_quantize and args.quantize_act):
+        return out
+    t = contiguous(out._t)
+    cur = _scalar_slot(self, t)
+    flags = ops.act_flags(**_OUTPUT_FLAGS)
+    if not self.quantize_act:                                  # statistic only (the reference still computes it, :50)
+        ops.batch_mean(ops.absmax_per_sample(t, no_abs=True), out=cur)
+    else:
+        if self.quantize_act_offline:
+            y = ops.fake_quant_offline(t, act_max._t, args.width, flags, cur_out=cur)[0]
         else:
-            ops.batch_mean(ops.absmax_per_sample(t, no_abs=True), out=cur)
-        self.current_act_max = DeviceScalar(cur)
-
-    return act
-
-
-def _add_quantize_act_params(m):
-    m.quantize_act_offline = False
-    m.current_act_max = 0.
-    m.act_max = m.params.get("act_max",
-                             shape=(1,), init="zeros",
-                             allow_deferred_init=True,
-                             differentiable=False)
+            y = ops.fake_quant_online(t, args.width, flags, cur_out=cur)[0]
+        out = NDArray(autograd.ste_link(t, y))                 # identity backward; a no-op unless recording
+    self.current_act_max = DeviceScalar(cur)
+    return out
 
 
 def gen_act_converter(width=8, quantize_act=True):
+    settings = QuantizedArgs(width=width, quantize_act=quantize_act)
+
     def _converter(m):
-        assert isinstance(m, Activation)
-
-        _add_quantize_act_params(m)
-
-        m.origin_forward = m.hybrid_forward
-        m.hybrid_forward = types.MethodType(_act_forward, m)
-        m.quantize_args = QuantizedArgs(width=width, quantize_act=quantize_act)
-        m.enable_quantize = True
+        if not isinstance(m, Activation):
+            raise AssertionError("gen_act_converter expects an Activation block")
+        OUTPUT_RANGE.attach(m)
+        rebind_forward(m, _quantised_activation)
+        m.quantize_args = settings
         m.quantize_act = quantize_act
+        m.enable_quantize = True
     return _converter

@@ -1,8 +1,9 @@
-"""`gen_conv2d_converter` — reference: quantize/convert/convert_conv2d.py:38-177.
+"""`gen_conv2d_converter(weight_width=8, quant_type="layer", quantize_input=True, input_signed=False, input_width=8,
+fake_bn=False, wino_quantize="none")` — reference API and arithmetic: quantize/convert/convert_conv2d.py:38-177.
 
-The patched `hybrid_forward` keeps the reference's control flow line for line (fake-BN fold :47-51, activation branch
-:53-66, weight branch :68-99 with layer/group/channel and the Winograd-domain variant, the `fixed_params` state machine
-:101-105, `origin_forward` :108).  What changes is WHERE the arithmetic runs:
+What the converted block computes is the reference's, step for step: fake-BN fold (:47-51), activation branch (:53-66),
+weight branch per layer / group / channel with the Winograd-domain variant (:68-99), the `fixed_params` state machine
+-1 -> 0 -> 1 (:101-105, :174) and then the stock convolution (:108).  Where it runs is different:
 
   reference                                                   here
   ---------                                                   ----
@@ -11,8 +12,10 @@ The patched `hybrid_forward` keeps the reference's control flow line for line (f
     = clip, div, round, mul as 4 NDArray passes               stays in a device scalar (no per-layer host sync)
   weight.abs().reshape((num,-1)).max(axis=1) ...  (:70-95)    fq_weight_fake_quant(rows = 1 | G | Cout)
   nd.dot(G, w^T) ..., np.linalg.pinv per call     (:71-83)    fq_wino_weight_fake_quant (pinv cached per variant)
+
+After `quantize.fuse.fuse_inference` a depthwise 3x3 / pointwise 1x1 block hands its input straight to the convolution
+kernel that quantises on load (`depthwise_fused`, `pointwise_fused` below) instead of running an apply pass.
 """
-import types
 from collections import namedtuple
 
 import torch
@@ -23,6 +26,7 @@ from ...mx.ndarray import NDArray
 from ...mx.gluon.nn import Conv2D
 from ... import ops
 from .._state import DeviceScalar
+from ._blocks import INPUT_RANGE, BatchNormTerms, contiguous, rebind_forward
 
 __all__ = ['gen_conv2d_converter']
 
@@ -31,168 +35,176 @@ QuantizedArgs = namedtuple("ConvQuantizedArgs",
                            "wt_width quant_type "
                            "fake_bn wino_quantize")
 
-
-def _cur_slot(m, like):
-    """(1,) device tensor receiving this block's `current_input_max` (a slice of the net's arena once
-    `net.update_ema()` has bound one — convert.py)."""
-    t = getattr(m, "_fq_cur", None)
-    if t is None or t.device != like.device:
-        t = torch.zeros(1, dtype=torch.float32, device=like.device)
-        m._fq_cur = t
-    return t
+WINOGRAD_VARIANTS = ("F23", "F43", "F63")
 
 
-def _fake_quant_input(m, x, input_max, flags, width):
-    """Activation branch shared by Conv2D and Dense (convert_conv2d.py:55-66, convert_dense.py:40-49)."""
-    x_in = x
-    t = x._t if x._t.is_contiguous() else x._t.contiguous()
-    cur = _cur_slot(m, t)
-    stat_ws = getattr(m, "_fq_stat_ws", None)
-    if stat_ws is not None and (stat_ws.device != t.device or stat_ws.numel() < t.shape[0]):
-        stat_ws = None
-    gstat = getattr(m, "_fq_global_stat", None)
-    # per-sample max|x| already produced by a fused producer (quantize/fuse.py)?  Exactly what the statistic pass
-    # would compute, so using it changes no result — it only removes a pass over x.
-    hint = x._fq_stat if x._t is t else None
-    if hint is not None and (hint.numel() != t.shape[0] or hint.device != t.device):
-        hint = None
-    if gstat is not None and stat_ws is not None:
-        # batch sharded over ranks (dist.py): statistic pass -> all-gather -> GLOBAL batch mean -> apply pass
-        n = t.shape[0]
-        per_sample = hint if hint is not None else ops.absmax_per_sample(t, out=stat_ws[:n])
-        gstat(per_sample, n, cur)
-        if m.quantize_input:
-            thr = input_max._t if m.quantize_input_offline else cur
-            y, _, _ = ops.fake_quant_offline(t, thr, width, flags, want_stat=False)
-            x = NDArray(y)
-    elif hint is not None:
-        if m.quantize_input:
-            if m.quantize_input_offline:
-                y, _, _ = ops.fake_quant_offline(t, input_max._t, width, flags, want_stat=False)
-                ops.batch_mean(hint, out=cur)
-            else:
-                y, _, _ = ops.fake_quant_online_prestat(t, hint, width, flags, cur_out=cur)
-            x = NDArray(y)
+# ---- activation branch ---------------------------------------------------------------------------------------------------
+def current_slot(block, like):
+    """(1,) device tensor receiving this block's `current_input_max` (a slice of the net's arena once `net.update_ema()`
+    has bound one — convert.py)."""
+    slot = getattr(block, "_fq_cur", None)
+    if slot is None or slot.device != like.device:
+        slot = block._fq_cur = torch.zeros(1, dtype=torch.float32, device=like.device)
+    return slot
+
+
+class _InputView(object):
+    """What the activation branch needs to know about one input: the contiguous tensor, where the batch statistic goes,
+    the per-sample statistic when a fused producer already computed it (bit-identical to the statistic pass, so using it
+    changes no result), and the multi-GPU calibration hooks of dist.py."""
+
+    def __init__(self, block, x):
+        self.t = contiguous(x._t)
+        self.n = self.t.shape[0]
+        self.cur = current_slot(block, self.t)
+        rows = getattr(block, "_fq_stat_ws", None)
+        if rows is not None and (rows.device != self.t.device or rows.numel() < self.n):
+            rows = None
+        self.rows = rows                                            # this block's row of the net's statistic matrix
+        self.exchange = getattr(block, "_fq_global_stat", None)     # strict mode: all-gather before the apply pass
+        hint = x._fq_stat if x._t is self.t else None
+        if hint is not None and (hint.numel() != self.n or hint.device != self.t.device):
+            hint = None
+        self.hint = hint
+
+    def per_sample(self):
+        """max|x[n]| for every sample; lands in the net's statistic matrix when one is bound (calibration under dist.py
+        reads the rows back for its single collective)."""
+        if self.hint is None:
+            return ops.absmax_per_sample(self.t, out=None if self.rows is None else self.rows[:self.n])
+        if self.rows is not None:
+            self.rows[:self.n].copy_(self.hint)
+            return self.rows[:self.n]
+        return self.hint
+
+    def finish(self, block):
+        block._fq_last_n = self.n
+        block.current_input_max = DeviceScalar(self.cur)
+
+
+def fake_quant_block_input(block, x, input_max, flags, width):
+    """Activation branch shared by Conv2D and Dense (convert_conv2d.py:55-66, convert_dense.py:40-49): produces
+    `current_input_max` in every mode and the fake-quantised input when the block quantises it."""
+    v = _InputView(block, x)
+    wanted = block.quantize_input
+    offline = block.quantize_input_offline
+    y = None
+    if v.exchange is not None and v.rows is not None:
+        # batch sharded over ranks, strict mode: statistic -> all-gather -> GLOBAL batch mean -> apply pass
+        v.exchange(v.per_sample(), v.n, v.cur)
+        if wanted:
+            y = ops.fake_quant_offline(v.t, input_max._t if offline else v.cur, width, flags, want_stat=False)[0]
+    elif v.hint is not None or (v.rows is not None and getattr(block, "_fq_keep_rows", False)):
+        stat = v.per_sample()
+        if wanted and not offline:
+            y = ops.fake_quant_online_prestat(v.t, stat, width, flags, cur_out=v.cur)[0]
         else:
-            ops.batch_mean(hint, out=cur)
-    elif m.quantize_input:
-        if m.quantize_input_offline:
-            y, _, _ = ops.fake_quant_offline(t, input_max._t, width, flags, cur_out=cur,
-                                             want_stat=getattr(m, "track_input_stat", True), stat_ws=stat_ws)
-        else:
-            y, _, _ = ops.fake_quant_online(t, width, flags, cur_out=cur, stat_ws=stat_ws)
-        x = NDArray(y)
-    else:
+            ops.batch_mean(stat, out=v.cur)
+            if wanted:
+                y = ops.fake_quant_offline(v.t, input_max._t, width, flags, want_stat=False)[0]
+    elif not wanted:
         # the reference still computes the statistic whenever quantize_args.quantize_input is set (:55-56)
-        per_sample = ops.absmax_per_sample(t, out=None if stat_ws is None else stat_ws[:t.shape[0]])
-        ops.batch_mean(per_sample, out=cur)
-    m._fq_last_n = t.shape[0]
-    m.current_input_max = DeviceScalar(cur)
-    if x is not x_in:
-        # under autograd.record(): straight-through link to the un-quantised input (ste_func.py:43-44, identity)
-        x = NDArray(autograd.ste_link(t, x._t))
-    return x
-
-
-def _fused_input_params(m, x, input_max, flags, width):
-    """Activation branch when the convolution itself quantises on load (quantize/fuse.py, depthwise 3x3): produce the
-    statistic / threshold exactly as `_fake_quant_input` would, but NO apply pass.  Returns kwargs for ops.dwconv3x3."""
-    t = x._t if x._t.is_contiguous() else x._t.contiguous()
-    n = t.shape[0]
-    cur = _cur_slot(m, t)
-    stat_ws = getattr(m, "_fq_stat_ws", None)
-    if stat_ws is not None and (stat_ws.device != t.device or stat_ws.numel() < n):
-        stat_ws = None
-    gstat = getattr(m, "_fq_global_stat", None)
-    hint = x._fq_stat if x._t is t else None
-    if hint is not None and (hint.numel() != n or hint.device != t.device):
-        hint = None
-    online = m.quantize_input and not m.quantize_input_offline
-    need_stat = online or gstat is not None or getattr(m, "track_input_stat", True)
-    per_sample = None
-    if need_stat:
-        per_sample = hint if hint is not None else \
-            ops.absmax_per_sample(t, out=None if stat_ws is None else stat_ws[:n])
-    kw = {}
-    if gstat is not None and stat_ws is not None:
-        gstat(per_sample, n, cur)
-        if m.quantize_input:
-            kw = dict(in_thr=input_max._t if m.quantize_input_offline else cur, width=width, flags=flags)
-    elif online:
-        kw = dict(in_stat=per_sample, width=width, flags=flags, cur_out=cur)      # the kernel writes cur
+        ops.batch_mean(v.per_sample(), out=v.cur)
+    elif offline:
+        y = ops.fake_quant_offline(v.t, input_max._t, width, flags, cur_out=v.cur, stat_ws=v.rows,
+                                   want_stat=getattr(block, "track_input_stat", True))[0]
     else:
-        if per_sample is not None:
-            ops.batch_mean(per_sample, out=cur)
-        if m.quantize_input:
-            kw = dict(in_thr=input_max._t, width=width, flags=flags)
-    m._fq_last_n = n
-    m.current_input_max = DeviceScalar(cur)
-    return kw
+        y = ops.fake_quant_online(v.t, width, flags, cur_out=v.cur, stat_ws=v.rows)[0]
+    v.finish(block)
+    if y is None:
+        return x
+    # under autograd.record(): straight-through link to the un-quantised input (ste_func.py:43-44, identity)
+    return NDArray(autograd.ste_link(v.t, y))
 
 
-def _dw_fused_conv(m, x, weight_q, bias, quant_kw):
-    """Depthwise 3x3 through fq_dwconv3x3: quantise-on-load + the BatchNorm / activation that followed this block +
-    the per-sample statistic of the output for the next fake-quant."""
-    fz = m._fq_dw_fused
-    t = x._t if x._t.is_contiguous() else x._t.contiguous()
-    w = weight_q._t if weight_q._t.is_contiguous() else weight_q._t.contiguous()
-    b = None if bias is None else bias._t
+def fused_input_plan(block, x, input_max, flags, width):
+    """Activation branch when the convolution itself quantises on load (quantize/fuse.py): the statistic / threshold are
+    produced exactly as `fake_quant_block_input` would, but there is NO apply pass.  Returns the keyword arguments that
+    tell ops.dwconv3x3 / ops.pwconv_i8 how to quantise ({} = do not)."""
+    v = _InputView(block, x)
+    wanted = block.quantize_input
+    online = wanted and not block.quantize_input_offline
+    stat = None
+    if online or v.exchange is not None or getattr(block, "track_input_stat", True):
+        stat = v.per_sample()
+    plan = {}
+    if v.exchange is not None and v.rows is not None:
+        v.exchange(stat, v.n, v.cur)
+        if wanted:
+            plan = dict(in_thr=input_max._t if block.quantize_input_offline else v.cur, width=width, flags=flags)
+    elif online:
+        plan = dict(in_stat=stat, width=width, flags=flags, cur_out=v.cur)         # the kernel writes `cur`
+    else:
+        if stat is not None:
+            ops.batch_mean(stat, out=v.cur)
+        if wanted:
+            plan = dict(in_thr=input_max._t, width=width, flags=flags)
+    v.finish(block)
+    return plan
+
+
+# ---- convolutions taken over by quantize/fuse.py ---------------------------------------------------------------------------
+def depthwise_fused(block, x, weight_q, bias, plan):
+    """Depthwise 3x3 through fq_dwconv3x3: quantise-on-load + the BatchNorm / activation that followed this block + the
+    per-sample statistic of the output for the next fake-quant."""
+    fz = block._fq_dw_fused
     scale, shift = fz["constants"]() if fz["bn"] is not None else (None, None)
-    y, stat = ops.dwconv3x3(t, w, b, stride=m._kwargs["stride"][0], bn_scale=scale, bn_shift=shift, act=fz["act"],
-                            **quant_kw)
+    y, stat = ops.dwconv3x3(contiguous(x._t), contiguous(weight_q._t), None if bias is None else bias._t,
+                            stride=block._kwargs["stride"][0], bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
     out = NDArray(y)
     out._fq_stat = stat
     return out
 
 
-def _rows_per_scale(m, qa):
-    cout = m._kwargs["num_filter"]
-    if qa.quant_type == "channel":
-        return 1
-    if qa.quant_type == "group" and m._kwargs["num_group"] == cout:
-        return 1
-    return cout
+def _weight_rows_per_scale(block, args):
+    cout = block._kwargs["num_filter"]
+    per_channel = args.quant_type == "channel" or (args.quant_type == "group" and block._kwargs["num_group"] == cout)
+    return 1 if per_channel else cout
 
 
-def _pw_fused_conv(m, F, x, weight_raw, weight_q, bias, quant_kw, weights_quantised):
-    """1x1 convolution taken over by quantize/fuse.py.  When both operands are quantised to <= 8 bits the convolution
-    runs on the integer codes (fq_pwconv_i8: exact int32 sums on the int8 matrix cores, quantise-on-load, BN / activation
-    / statistic on store); otherwise the library convolution runs and only BN + activation + statistic are fused."""
-    fz = m._fq_pw_fused
-    qa = m.quantize_args
+def _pointwise_weight_codes(block, args, weight_raw, weight_q):
+    """int8 codes / scales / row sums of the weights THIS forward uses: the raw weights while they are (re-)quantised every
+    forward or being frozen right now, the frozen (already fake-quantised) ones afterwards.  Frozen codes are kept until
+    the parameter's storage or in-place version changes (set_data / load_parameters / a second fix_params)."""
+    param_t = block.weight.data()._t
+    key = (param_t.data_ptr(), param_t._version)
+    held = getattr(block, "_fq_pw_cache", None)
+    if block.fixed_params == 1 and held is not None and held[3] == key:
+        return held[:3]
+    src = weight_raw if block.fixed_params != 1 or held is None else weight_q
+    codes = ops.weight_codes(contiguous(src._t), _weight_rows_per_scale(block, args), args.wt_width)
+    if block.fixed_params == 1:
+        block._fq_pw_cache = tuple(codes) + (key,)
+    return codes
+
+
+def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quantised):
+    """1x1 convolution taken over by quantize/fuse.py.  When both operands are quantised to <= 8 bits it runs on the
+    integer codes (fq_pwconv_i8: exact int32 sums on the int8 matrix cores, quantise-on-load, BN / activation / statistic
+    on store); otherwise the library convolution runs and only BN + activation + statistic are fused."""
+    fz = block._fq_pw_fused
+    args = block.quantize_args
     scale, shift = fz["constants"]() if fz["bn"] is not None else (None, None)
-    int8_ok = bool(quant_kw) and weights_quantised and qa.in_width <= 8 and qa.wt_width <= 8 \
-        and not getattr(m, "_fq_no_int8", False)
-    if int8_ok:
-        t = x._t if x._t.is_contiguous() else x._t.contiguous()
-        cache = getattr(m, "_fq_pw_cache", None)
-        if m.fixed_params == 1 and cache is not None and cache[3] == m.weight.data()._t.data_ptr():
-            codes, scales, rowsum = cache[:3]
-        else:
-            # codes of the weights being used by THIS forward: the raw weights while they are (re-)quantised every
-            # forward or being frozen right now, the frozen (already fake-quantised) ones afterwards
-            src = weight_raw if m.fixed_params != 1 or cache is None else weight_q
-            wsrc = src._t if src._t.is_contiguous() else src._t.contiguous()
-            codes, scales, rowsum = ops.weight_codes(wsrc, _rows_per_scale(m, qa), qa.wt_width)
-            if m.fixed_params == 1:
-                m._fq_pw_cache = (codes, scales, rowsum, m.weight.data()._t.data_ptr())
-        b = None if bias is None else bias._t
-        y, stat = ops.pwconv_i8(t, codes, scales, rowsum, b, bn_scale=scale, bn_shift=shift, act=fz["act"], **quant_kw)
+    on_codes = bool(plan) and weights_quantised and args.in_width <= 8 and args.wt_width <= 8 \
+        and not getattr(block, "_fq_no_int8", False)
+    if on_codes:
+        codes, scales, rowsum = _pointwise_weight_codes(block, args, weight_raw, weight_q)
+        y, stat = ops.pwconv_i8(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
+                                bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
     else:
-        if quant_kw:          # input is to be quantised but the integer path does not apply: explicit apply pass
-            t = x._t if x._t.is_contiguous() else x._t.contiguous()
-            if "in_stat" in quant_kw:
-                yq, _, _ = ops.fake_quant_online_prestat(t, quant_kw["in_stat"], quant_kw["width"], quant_kw["flags"],
-                                                         cur_out=quant_kw.get("cur_out"))
+        if plan:          # input is to be quantised but the integer path does not apply: explicit apply pass
+            t = contiguous(x._t)
+            if "in_stat" in plan:
+                xq = ops.fake_quant_online_prestat(t, plan["in_stat"], plan["width"], plan["flags"],
+                                                   cur_out=plan.get("cur_out"))[0]
             else:
-                yq, _, _ = ops.fake_quant_offline(t, quant_kw["in_thr"], quant_kw["width"], quant_kw["flags"],
-                                                  want_stat=False)
-            x = NDArray(yq)
-        out = m.origin_forward(F, x, weight_q, bias)
+                xq = ops.fake_quant_offline(t, plan["in_thr"], plan["width"], plan["flags"], want_stat=False)[0]
+            x = NDArray(xq)
+        out = block.origin_forward(F, x, weight_q, bias)
         if fz["bn"] is None and fz["act"] == "none":
             return out
-        c = out.shape[1]
         if scale is None:
+            c = out.shape[1]
             scale = torch.ones(c, dtype=torch.float32, device=out._t.device)
             shift = torch.zeros(c, dtype=torch.float32, device=out._t.device)
         y, stat = ops.bn_act_stat(out._t.contiguous(), scale, shift, fz["act"])
@@ -201,140 +213,113 @@ def _pw_fused_conv(m, F, x, weight_raw, weight_q, bias, quant_kw, weights_quanti
     return res
 
 
-def _conv2d_forward(self, F, x, weight, bias=None, input_max=None,
+# ---- weight branch -----------------------------------------------------------------------------------------------------------
+def _fake_quant_weight(block, args, weight):
+    """convert_conv2d.py:68-95: one scale per layer / per group (G in {1, Cout}) / per output channel; per-channel 3x3
+    filters go through the Winograd domain when asked to (:71-83)."""
+    w = contiguous(weight._t)
+    if args.quant_type == 'channel' and args.wino_quantize != 'none' and block._kwargs['kernel'] == (3, 3):
+        wq = ops.wino_weight_fake_quant(w, args.wino_quantize, args.wt_width)
+        return NDArray(autograd.wino_link(w, wq, *ops.winograd_matrices(args.wino_quantize)))   # transform's gradient
+    if args.quant_type == 'channel':
+        rows = block._kwargs['num_filter']
+    elif args.quant_type == 'group':
+        rows = block._kwargs['num_group']
+        if rows not in (1, w.shape[0]):
+            # the reference broadcasts a (G,1,1,1) scale against (Cout,Cin/g,kh,kw): MXNet raises here too
+            raise ValueError("group-wise weight quantisation needs num_group in {1, num_filter} "
+                             "(got num_group=%d, num_filter=%d): operands could not be broadcast" % (rows, w.shape[0]))
+    else:
+        rows = 1
+    # identity backward (ste_func.py:43-44); a no-op unless autograd is recording
+    return NDArray(autograd.ste_link(w, ops.weight_fake_quant(w, rows, args.wt_width)))
+
+
+# ---- the converted forward ---------------------------------------------------------------------------------------------------
+def _quantised_conv(self, F, x, weight, bias=None, input_max=None,
                     gamma=None, beta=None, running_mean=None, running_var=None):
-    qa = self.quantize_args
-    fz = getattr(self, "_fq_dw_fused", None)
-    fzp = getattr(self, "_fq_pw_fused", None)
-    if (fz is not None or fzp is not None) and autograd.is_recording():
+    args = self.quantize_args
+    dw = getattr(self, "_fq_dw_fused", None)
+    pw = getattr(self, "_fq_pw_fused", None)
+    taken_over = dw is not None or pw is not None
+    if taken_over and autograd.is_recording():
         raise RuntimeError("this net was rewired by quantize.fuse.fuse_inference (inference only): call "
                            "quantize.fuse.unfuse(net) before recording gradients")
-    weight_raw = weight
-    quant_kw = {}
-    # Fake bn (:47-51)
-    if self.fixed_params != 1 and qa.fake_bn:
-        w_shape = weight.shape
-        cout = w_shape[0]
-        weight = (weight.reshape(cout, -1) * gamma.reshape(-1, 1) /
-                  F.sqrt(running_var + 1e-10).reshape(-1, 1)).reshape(w_shape)
-        bias = gamma * (bias - running_mean) / F.sqrt(running_var + 1e-10) + beta
+    frozen = self.fixed_params == 1
+    weight_raw, plan = weight, {}
 
+    if args.fake_bn and not frozen:                                            # :47-51
+        terms = BatchNormTerms(gamma, beta, running_mean, running_var)
+        weight, bias = terms.fold_weight(F, weight), terms.fold_bias(F, bias)
+
+    weight_q = weight
     if self.enable_quantize:
-        # Quantize input (:55-66)
-        if qa.quantize_input:
-            if fz is None and fzp is None:
-                x = _fake_quant_input(self, x, input_max, ops.act_flags(signed=qa.in_signed), qa.in_width)
+        if args.quantize_input:                                                # :55-66
+            flags = ops.act_flags(signed=args.in_signed)
+            if taken_over:
+                plan = fused_input_plan(self, x, input_max, flags, args.in_width)
             else:
-                quant_kw = _fused_input_params(self, x, input_max, ops.act_flags(signed=qa.in_signed), qa.in_width)
+                x = fake_quant_block_input(self, x, input_max, flags, args.in_width)
+        if not frozen:                                                         # :68-99
+            weight_q = _fake_quant_weight(self, args, weight)
 
-        # Simulate quantization for weight (:68-99)
-        if self.fixed_params != 1:
-            wt = weight._t if weight._t.is_contiguous() else weight._t.contiguous()
-            if qa.quant_type == 'channel':
-                if qa.wino_quantize != 'none' and self._kwargs['kernel'] == (3, 3):
-                    wq = ops.wino_weight_fake_quant(wt, qa.wino_quantize, qa.wt_width)
-                    wq = autograd.wino_link(wt, wq, *ops.winograd_matrices(qa.wino_quantize))
-                    wt = None                                          # already linked (with the transform's gradient)
-                else:
-                    wq = ops.weight_fake_quant(wt, self._kwargs['num_filter'], qa.wt_width)
-            elif qa.quant_type == 'group':
-                num = self._kwargs['num_group']
-                if num not in (1, wt.shape[0]):
-                    # the reference broadcasts a (G,1,1,1) scale against (Cout,Cin/g,kh,kw): MXNet raises here too
-                    raise ValueError("group-wise weight quantisation needs num_group in {1, num_filter} "
-                                     "(got num_group=%d, num_filter=%d): operands could not be broadcast"
-                                     % (num, wt.shape[0]))
-                wq = ops.weight_fake_quant(wt, num, qa.wt_width)
-            else:
-                wq = ops.weight_fake_quant(wt, 1, qa.wt_width)
-            # identity backward (ste_func.py:43-44); a no-op unless autograd is recording
-            weight_q = NDArray(wq if wt is None else autograd.ste_link(wt, wq))
-        else:
-            weight_q = weight
-    else:
-        weight_q = weight
-
-    # Freeze (:101-105)
-    if self.fixed_params == 0:
+    if self.fixed_params == 0:                                                 # :101-105: freeze what was just computed
         self.fixed_params = 1
         self.weight.set_data(weight_q)
         if bias is not None:
             self.bias.set_data(bias)
 
-    # Normal convolution (:108) — MIOpen through torch; not the path this project replaces
-    if fz is not None:
-        return _dw_fused_conv(self, x, weight_q, bias, quant_kw)
-    if fzp is not None:
-        return _pw_fused_conv(self, F, x, weight_raw, weight_q, bias, quant_kw, bool(self.enable_quantize))
-    act = self.origin_forward(F, x, weight_q, bias)
-
-    return act
+    if dw is not None:
+        return depthwise_fused(self, x, weight_q, bias, plan)
+    if pw is not None:
+        return pointwise_fused(self, F, x, weight_raw, weight_q, bias, plan, bool(self.enable_quantize))
+    return self.origin_forward(F, x, weight_q, bias)                           # :108 — MIOpen through torch
 
 
-def _add_quantize_input_params(m):
-    m.quantize_input_offline = False
-    m.current_input_max = 0.
-    m.input_max = m.params.get("input_max",
-                               shape=(1,), init="zeros",
-                               allow_deferred_init=True,
-                               differentiable=False)
+# ---- converter -----------------------------------------------------------------------------------------------------------------
+_FAKE_BN_PARAMS = (("gamma", "ones", True), ("beta", "zeros", True),
+                   ("running_mean", "zeros", False), ("running_var", "ones", False))
 
 
-def _add_fake_bn_params(m):
-    in_channels = m._kwargs['num_filter']
-    m.gamma = m.params.get('gamma',
-                           shape=(in_channels,), init="ones",
-                           allow_deferred_init=True,
-                           differentiable=True)
-    m.beta = m.params.get('beta',
-                          shape=(in_channels,), init="zeros",
-                          allow_deferred_init=True,
-                          differentiable=True)
-    m.running_mean = m.params.get('running_mean',
-                                  shape=(in_channels,),
-                                  init="zeros",
-                                  allow_deferred_init=True,
-                                  differentiable=False)
-    m.running_var = m.params.get('running_var',
-                                 shape=(in_channels,),
-                                 init="ones",
-                                 allow_deferred_init=True,
-                                 differentiable=False)
+def _attach_fake_bn(block):
+    """The four BatchNorm vectors as Parameters of the convolution (:122-141) and the pre-hook that records the batch
+    statistics of the un-folded convolution for `update_ema` while training (:144-154)."""
+    channels = block._kwargs['num_filter']
+    for name, init, trainable in _FAKE_BN_PARAMS:
+        setattr(block, name, block.params.get(name, shape=(channels,), init=init, differentiable=trainable,
+                                              allow_deferred_init=True))
 
-
-def _add_fake_bn_ema_hook(m):
     @torch.no_grad()
-    def _ema_hook(m, x):
-        x = x[0]
-        weight = m.weight.data()
-        bias = nd.zeros(shape=weight.shape[0], ctx=weight.context) if m.bias is None else m.bias.data()
-        y = nd.Convolution(x, weight, bias, **m._kwargs)
-        num_samples = y.shape[0] * y.shape[2] * y.shape[3]
-        m.current_mean = y.sum(axis=(0, 2, 3)) / num_samples
-        diff_square = (y - m.current_mean.reshape(1, -1, 1, 1)) ** 2
-        m.current_var = diff_square.sum(axis=(0, 2, 3)) / num_samples
-    m.register_forward_pre_hook(_ema_hook)
+    def record_batch_stats(blk, inputs):
+        w = blk.weight.data()
+        b = blk.bias.data() if blk.bias is not None else nd.zeros(shape=w.shape[0], ctx=w.context)
+        y = nd.Convolution(inputs[0], w, b, **blk._kwargs)
+        count = y.shape[0] * y.shape[2] * y.shape[3]
+        blk.current_mean = y.sum(axis=(0, 2, 3)) / count
+        centred = (y - blk.current_mean.reshape(1, -1, 1, 1)) ** 2
+        blk.current_var = centred.sum(axis=(0, 2, 3)) / count
+    block.register_forward_pre_hook(record_batch_stats)
 
 
 def gen_conv2d_converter(weight_width=8, quant_type="layer",
                          quantize_input=True, input_signed=False, input_width=8,
                          fake_bn=False, wino_quantize="none"):
-    assert wino_quantize in ("none", "F23", "F43", "F63")
+    if wino_quantize != "none" and wino_quantize not in WINOGRAD_VARIANTS:
+        raise AssertionError("wino_quantize must be 'none' or one of %s" % (WINOGRAD_VARIANTS,))
+    settings = QuantizedArgs(in_signed=input_signed, in_width=input_width, wt_width=weight_width,
+                             quantize_input=quantize_input, fake_bn=fake_bn, quant_type=quant_type,
+                             wino_quantize=wino_quantize)
 
     def _converter(m):
-        assert isinstance(m, Conv2D)
-
+        if not isinstance(m, Conv2D):
+            raise AssertionError("gen_conv2d_converter expects a Conv2D block")
         if quantize_input:
-            _add_quantize_input_params(m)
+            INPUT_RANGE.attach(m)
         if fake_bn:
-            _add_fake_bn_params(m)
-            _add_fake_bn_ema_hook(m)
-        m.origin_forward = m.hybrid_forward
-        m.hybrid_forward = types.MethodType(_conv2d_forward, m)
-        m.quantize_args = QuantizedArgs(in_signed=input_signed, in_width=input_width, wt_width=weight_width,
-                                        quantize_input=quantize_input, fake_bn=fake_bn, quant_type=quant_type,
-                                        wino_quantize=wino_quantize)
-        m.fixed_params = -1
-        m.enable_quantize = True
+            _attach_fake_bn(m)
+        rebind_forward(m, _quantised_conv)
+        m.quantize_args = settings
         m.quantize_input = quantize_input
+        m.enable_quantize = True
+        m.fixed_params = -1              # -1: quantise weights every forward; 0: freeze on the next forward; 1: frozen
     return _converter

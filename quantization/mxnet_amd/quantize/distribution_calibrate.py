@@ -37,7 +37,7 @@ def collect_feature_maps(net, bins, loader, ctx, tqdm_desc="Collect FM", sync=No
     :param loader: iterable of (X, y) batches
     :param ctx: context the batches are moved to
     :param tqdm_desc: str
-    :param sync: optional multi-GPU hook `(stage, tensor) -> None` (dist.py): called with ("max", fm_max vector) after
+    :param sync: optional multi-GPU hook `(stage, tensor) -> None` (dist.py): called with ("range", fm_max vector) after
         the first batch and ("hist", all histograms) at the end, so every rank ends with the global statistics.
     :return: (hist_collector, fm_max_collector) keyed by block, as in the reference.
     """
@@ -53,37 +53,50 @@ def collect_feature_maps(net, bins, loader, ctx, tqdm_desc="Collect FM", sync=No
 
     """ Collect feature maps """
     state = {}
-    first = True
+    range_shared = sync is None
+
+    def share_range():
+        # The FIRST batch fixes every layer's range (:97-101).  Under sharding that is global batch 0, which rank 0 holds:
+        # its ranges are broadcast, so the counts every rank adds up are those one device would have produced.  A rank
+        # whose shard is empty still takes part (with placeholders), so all ranks issue the same collectives.
+        device = ctx.torch_device if hasattr(ctx, "torch_device") else None
+        order = [m for m in quantized_blocks if m in state] or quantized_blocks
+        mine = [state[m].fm_max if m in state else torch.zeros(1, dtype=torch.float32, device=device) for m in order]
+        packed = torch.cat(mine)
+        sync("range", packed)
+        for i, m in enumerate(order):
+            st = state.get(m)
+            if st is None:
+                st = state[m] = _LayerHist(bins, packed.device)
+            st.fm_max = packed[i:i + 1].clone()
+
     with tqdm(total=len(loader), desc=tqdm_desc) as pbar:
         for X, _ in loader:
             X = X.as_in_context(ctx)
             _ = net(X)
+            inputs = {}
             for m, fms in fm_collector.items():
                 t = fms[0]._t if len(fms) == 1 else torch.cat([f._t for f in fms], dim=0)     # :94
-                t = t if t.is_contiguous() else t.contiguous()
-                st = state.get(m)
-                if st is None:
+                inputs[m] = t if t.is_contiguous() else t.contiguous()
+                if m not in state:
                     st = state[m] = _LayerHist(bins, t.device)
-                    st.fm_max = ops.global_max(t)                 # first chunk sets the range (:97-101)
-            if first and sync is not None and state:
-                packed = torch.cat([state[m].fm_max for m in fm_collector])
-                sync("max", packed)
-                for i, m in enumerate(fm_collector):
-                    state[m].fm_max = packed[i:i + 1].clone()
-            first = False
-            for m, fms in fm_collector.items():
-                t = fms[0]._t if len(fms) == 1 else torch.cat([f._t for f in fms], dim=0)
-                t = t if t.is_contiguous() else t.contiguous()
+                    st.fm_max = ops.global_max(inputs[m])         # first chunk sets the range (:97-101)
+            if not range_shared:
+                share_range()
+                range_shared = True
+            for m, t in inputs.items():
                 st = state[m]
                 ops.histogram_accumulate(t, st.fm_max, st.hist, st.neg)       # :39-45 and :103-104
             fm_collector.clear()
             pbar.update(1)
+    if not range_shared:                      # this rank's shard was empty
+        share_range()
 
     """ Delete hooks """
     for h in hooks:
         h.detach()
 
-    if sync is not None and state:
+    if sync is not None:
         order = [m for m in quantized_blocks if m in state]
         packed = torch.stack([state[m].hist for m in order])
         sync("hist", packed)

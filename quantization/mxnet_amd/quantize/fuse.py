@@ -38,21 +38,25 @@ def _act_kind(b):
     return None
 
 
+def _tensors_key(*tensors):
+    """identity of parameter storage AND content: `set_data` / `load_parameters` / an optimiser step write in place (same
+    pointer), but every in-place write bumps the tensor's version counter"""
+    return tuple((t.data_ptr(), t._version) for t in tensors)
+
+
 def _bn_constants(bn):
-    g, b = bn.gamma.data()._t, bn.beta.data()._t
+    g0, b = bn.gamma.data()._t, bn.beta.data()._t
     mean, var = bn.running_mean.data()._t, bn.running_var.data()._t
-    if bn._kwargs.get("fix_gamma", False):
-        g = torch.ones_like(g)
+    g = torch.ones_like(g0) if bn._kwargs.get("fix_gamma", False) else g0
     scale = g / torch.sqrt(var + bn._kwargs["eps"])
     shift = b - mean * scale
-    key = (bn.gamma.data()._t.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr())
-    return scale.contiguous(), shift.contiguous(), key
+    return scale.contiguous(), shift.contiguous(), _tensors_key(g0, b, mean, var)
 
 
 def _fused_bn_forward(self, F, x, gamma, beta, running_mean, running_var):
     st = self._fq_fused
-    key = (gamma._t.data_ptr(), beta._t.data_ptr(), running_mean._t.data_ptr(), running_var._t.data_ptr())
-    if st["key"] != key:                       # parameters moved (reset_ctx / load): recompute the constants
+    key = _tensors_key(gamma._t, beta._t, running_mean._t, running_var._t)
+    if st["key"] != key:                       # parameters moved or rewritten (reset_ctx / load / set_data): recompute
         st["scale"], st["shift"], st["key"] = _bn_constants(self)
     t = x._t if x._t.is_contiguous() else x._t.contiguous()
     y, stat = ops.bn_act_stat(t, st["scale"], st["shift"], st["act"], want_stat=True)
@@ -128,16 +132,16 @@ def _flatten_keep_stat_forward(self, F, x):
 
 
 def _plain_dw_forward(self, F, x, weight, bias=None):
-    from .convert.convert_conv2d import _dw_fused_conv
-    return _dw_fused_conv(self, x, weight, bias, {})
+    from .convert.convert_conv2d import depthwise_fused
+    return depthwise_fused(self, x, weight, bias, {})
 
 
 def _bn_constants_getter(bn):
     cache = {"key": None, "val": None}
 
     def get():
-        key = (bn.gamma.data()._t.data_ptr(), bn.beta.data()._t.data_ptr(), bn.running_mean.data()._t.data_ptr(),
-               bn.running_var.data()._t.data_ptr(), bn.__dict__.get("_fq_refresh", 0))
+        key = _tensors_key(bn.gamma.data()._t, bn.beta.data()._t, bn.running_mean.data()._t,
+                           bn.running_var.data()._t) + (bn.__dict__.get("_fq_refresh", 0),)
         if cache["key"] != key:
             scale, shift, _ = _bn_constants(bn)
             cache["key"], cache["val"] = key, (scale, shift)
@@ -311,6 +315,7 @@ def refresh(net):
         if hasattr(b, "_fq_fused"):
             b._fq_fused["key"] = None
             b._fq_refresh = b.__dict__.get("_fq_refresh", 0) + 1
+        b.__dict__.pop("_fq_pw_cache", None)
     net.apply(visit)
 
 

@@ -1,55 +1,49 @@
-"""`qparams_init` — reference: quantize/initialize/initialize.py:31-75.
+"""`qparams_init(net, conv_name="conv", bn_name="batchnorm")` — behaviour of the reference's
+quantize/initialize/initialize.py:31-75, written on this project's block machinery (convert/_blocks.py).
 
-`input_max` / `act_max` start at 0 (so the naive-EMA estimate carries the (1 - 0.9^k) bias of the reference);
-with fake-BN the conv adopts its sibling BatchNorm's gamma/beta/running stats, found by name
-(`name.replace(conv_name, bn_name)`), and gains a bias if it had none."""
+Every calibrated range starts at 0 (so the naive-EMA estimate carries the reference's (1 - 0.9^k) bias).  A convolution
+converted with `fake_bn=True` adopts the vectors of the BatchNorm that follows it — found by the reference's naming rule
+`conv.name.replace(conv_name, bn_name)` — and gains a zero bias when it had none.
+"""
 from ...mx.gluon import nn
 from ...mx.initializer import Constant
+from ..convert._blocks import BatchNormTerms, ensure_bias
 
 __all__ = ["qparams_init"]
 
 
-def qparams_init(net, conv_name="conv", bn_name="batchnorm"):
-    blocks = net.collect_quantized_blocks()
-    params = net.collect_params()
-
-    for m in blocks:
-        # If fake bn, recalculate weight and initialize some related params (:46-70)
-        if isinstance(m, nn.Conv2D) and hasattr(m, "gamma"):
-            name = m.name
-
-            # Get params of batchnorm
-            gamma = params[name.replace(conv_name, bn_name) + "_gamma"].data()
-            beta = params[name.replace(conv_name, bn_name) + "_beta"].data()
-            mean = params[name.replace(conv_name, bn_name) + "_running_mean"].data()
-            var = params[name.replace(conv_name, bn_name) + "_running_var"].data()
-            ctx = m.weight.list_ctx()[0]
-
-            # Store params of bn at conv
-            m.gamma.initialize(Constant(gamma), ctx=ctx)
-            m.beta.initialize(Constant(beta), ctx=ctx)
-            m.running_mean.initialize(Constant(mean), ctx=ctx)
-            m.running_var.initialize(Constant(var), ctx=ctx)
-
-            # Enable bias if need
-            cout = m.weight.shape[0]
-            if m.bias is None:
-                m._kwargs['no_bias'] = False
-                m.bias = m.params.get('bias',
-                                      shape=(cout,), init="zeros",
-                                      allow_deferred_init=True)
-                m.bias.initialize(ctx=ctx)
-
-        if type(m) in (nn.Conv2D, nn.Dense) and m.quantize_args.quantize_input:
-            m.input_max.initialize(Constant(0), ctx=_ctx_of(m))
-        if type(m) == nn.Activation and m.quantize_args.quantize_act:
-            m.act_max.initialize(Constant(0))
-    return net
-
-
-def _ctx_of(m):
-    w = getattr(m, "weight", None)
+def _home_ctx(block):
+    """context of the block's weight when it already has one (ranges are created next to it)"""
+    weight = getattr(block, "weight", None)
+    if weight is None:
+        return None
     try:
-        return w.list_ctx()[0] if w is not None else None
+        return weight.list_ctx()[0]
     except Exception:
         return None
+
+
+def _adopt_batchnorm(conv, every_param, conv_name, bn_name):
+    terms = BatchNormTerms.of_sibling(conv, every_param, conv_name, bn_name)
+    if terms is None:
+        raise KeyError("fake_bn: no BatchNorm named %s* for convolution %s"
+                       % (conv.name.replace(conv_name, bn_name), conv.name))
+    ctx = _home_ctx(conv)
+    for field, value in zip(BatchNormTerms.FIELDS, (terms.gamma, terms.beta, terms.mean, terms.var)):
+        getattr(conv, field).initialize(Constant(value), ctx=ctx)
+    ensure_bias(conv, ctx)
+
+
+def qparams_init(net, conv_name="conv", bn_name="batchnorm"):
+    every_param = net.collect_params()
+    for block in net.collect_quantized_blocks():
+        kind = type(block)
+        if kind is nn.Activation:
+            if block.quantize_args.quantize_act:
+                block.act_max.initialize(Constant(0))
+            continue
+        if isinstance(block, nn.Conv2D) and hasattr(block, "gamma"):
+            _adopt_batchnorm(block, every_param, conv_name, bn_name)
+        if kind in (nn.Conv2D, nn.Dense) and block.quantize_args.quantize_input:
+            block.input_max.initialize(Constant(0), ctx=_home_ctx(block))
+    return net

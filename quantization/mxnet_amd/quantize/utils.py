@@ -1,20 +1,17 @@
-"""`collect_qparams` / `print_all_qparams` — reference: quantize/utils.py:30-52."""
+"""`collect_qparams(net)` / `print_all_qparams(net)` — reference API: quantize/utils.py:30-52.
+The calibrated ranges are the Parameters named `*_min` / `*_max` (every quantised block's `input_max`, an activation's
+`act_max`), reported in net order."""
 from collections import OrderedDict
 
 __all__ = ['collect_qparams', 'print_all_qparams']
 
+_RANGE_SUFFIXES = ("_min", "_max")
+
 
 def collect_qparams(net):
-    """All parameters whose name ends in `_min` / `_max` (e.g. every block's `input_max`), in net order."""
-    ret = OrderedDict()
-    quant_params = net.collect_params(".*[min|max]")
-    for param in quant_params:
-        if param.endswith(("_min", "_max")):
-            ret[param] = quant_params[param]
-    return ret
+    return OrderedDict((name, p) for name, p in net.collect_params().items() if name.endswith(_RANGE_SUFFIXES))
 
 
 def print_all_qparams(net):
-    qparams = collect_qparams(net)
-    for param in qparams:
-        print("{}:\t\t{:+.4f}".format(param, qparams[param].data().asscalar()))
+    for name, p in collect_qparams(net).items():
+        print("{}:\t\t{:+.4f}".format(name, p.data().asscalar()))

@@ -1,6 +1,9 @@
 """Worker for tests/test_distributed.py: launched by torch.distributed.run with world_size 2 on CPU (gloo).
-Runs the product's calibration host logic (EMA sync, KL sync, eval counters) with the oracle standing in for the HIP
-entry points, and writes what each rank ended with to <out>/rank<r>.npz."""
+Runs the product's calibration host logic (both EMA collective modes, KL sync, eval counters) with the oracle standing in
+for the HIP entry points, and writes what each rank ended with to <out>/rank<r>.npz.
+
+    dist_worker.py <out_dir> <local_bs> <case>      case: strict | strict_ragged | step | step_ragged | step_short
+"""
 import os
 import sys
 
@@ -15,7 +18,6 @@ from oracle.patch import oracle_ops  # noqa: E402
 from quantization.mxnet_amd import mx, dist as fqdist  # noqa: E402
 from quantization.mxnet_amd.quantize.distribution_calibrate import collect_feature_maps  # noqa: E402
 from test_host_logic import tiny_net  # noqa: E402
-from quantization.mxnet_amd.mx.gluon import nn  # noqa: E402
 from quantization.mxnet_amd.quantize import convert  # noqa: E402
 from quantization.mxnet_amd.quantize.initialize import qparams_init  # noqa: E402
 
@@ -36,35 +38,60 @@ def batches(n_batches, bs, seed=9):
     return [(rng.standard_normal((bs, 3, 8, 8)) * (1 + 0.25 * i)).astype(np.float32) for i in range(n_batches)]
 
 
+def calib_steps(case, local_bs, world):
+    """The global batches of the calibration, as the list of per-rank shards of every step (None = no batch)."""
+    steps = []
+    glob = batches(4, local_bs * world)
+    for step, g in enumerate(glob):
+        if case.endswith("_ragged") and step == 3:
+            g = g[:local_bs + 1]                           # last global batch: rank 0 full, rank 1 one sample
+        shards = [g[r * local_bs:(r + 1) * local_bs] for r in range(world)]
+        if case == "step_short" and step == 3:
+            shards = [g[:local_bs]] + [None] * (world - 1)  # odd batch count: only rank 0 has a batch in the last step
+        steps.append(shards)
+    return steps
+
+
+def kl_batches(case, local_bs):
+    return batches(1 if case == "step_short" else (3 if case.endswith("_ragged") else 4), local_bs, seed=21)
+
+
 def main():
-    out_dir, local_bs, ragged = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    out_dir, local_bs, case = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     rank, _, world = fqdist.init("gloo")
     with oracle_ops():
         # ---- naive-EMA calibration on the rank's shard of each global batch -------------------------------------
         net = make_net()
-        fqdist.attach_calibration_sync(net, local_bs)
+        fqdist.attach_calibration_sync(net, local_bs, strict=case.startswith("strict"))
         net.quantize_input(enable=True, online=True)
         blocks = net.collect_quantized_blocks()
-        ema = []
-        for step, glob in enumerate(batches(4, local_bs * world)):
-            if ragged and step == 3:
-                glob = glob[:local_bs + 1]                 # last global batch: rank 0 full, rank 1 one sample
-            mine = glob[rank * local_bs:(rank + 1) * local_bs]
-            net(mx.nd.array(mine))
-            net.update_ema()
+        ema, rows = [], []
+        for shards in calib_steps(case, local_bs, world):
+            mine = shards[rank]
+            if mine is None or len(mine) == 0:
+                fqdist.empty_calibration_step(net)
+                rows.append(np.zeros((len(blocks), 0), np.float32))
+            else:
+                net(mx.nd.array(mine))
+                rows.append(net._fq_stat_matrix[:, :len(mine)].numpy().copy())
+                net.update_ema()
             ema.append([b.input_max.data().asscalar() for b in blocks])
-        # ---- KL collection ------------------------------------------------------------------------------------------
+        # ---- KL collection: batches strided over the ranks like the loader does -----------------------------------
         net2 = make_net()
         net2.disable_quantize()
-        all_b = batches(4, local_bs, seed=21)
-        loader = [(mx.nd.array(b), None) for i, b in enumerate(all_b) if i % world == rank]
+        loader = [(mx.nd.array(b), None) for i, b in enumerate(kl_batches(case, local_bs)) if i % world == rank]
         hists, maxes = collect_feature_maps(net2, 64, loader, mx.cpu(), sync=fqdist.kl_sync)
         b2 = net2.collect_quantized_blocks()
         counters = torch.tensor([float(rank + 1), 10.0])
         fqdist.allreduce_eval_counters(counters)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ema=np.asarray(ema, np.float32),
-             hist=np.stack([hists[b] for b in b2]), fm_max=np.asarray([maxes[b] for b in b2], np.float32),
-             counters=counters.numpy())
+    rows_padded = np.zeros((len(rows), len(blocks), local_bs), np.float32)
+    counts = np.zeros(len(rows), np.int64)
+    for i, r in enumerate(rows):
+        rows_padded[i, :, :r.shape[1]] = r
+        counts[i] = r.shape[1]
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ema=np.asarray(ema, np.float32), rows=rows_padded,
+             counts=counts, hist=np.stack([hists[b] for b in b2]),
+             fm_max=np.asarray([maxes[b] for b in b2], np.float32), counters=counters.numpy())
     fqdist.shutdown()
 
 
