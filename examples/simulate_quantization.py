@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Simulated-quantisation CLI — same flags, flow and printed banners as the reference's
-examples/simulate_quantization.py (:45-119 flags, :178-353 flow), running on MI355X through libfakequant.
+"""Simulated-quantisation CLI for MI355X: evaluates a model-zoo network with fake-quantised weights and activations
+through libfakequant, optionally after calibrating the activation ranges (naive EMA or KL).
+
+The command line — every flag, default and help text in REFERENCE_FLAGS below — is the interface of the reference's
+examples/simulate_quantization.py (hey-yahei/Quantization.MXNet, MIT licence, (c) YaHei; flags :49-103), kept so that the
+reference's commands and scripts run unchanged.  The program behind it is this project's own:
 
     python examples/simulate_quantization.py --model=mobilenet1.0 --use-gpu=0
     python examples/simulate_quantization.py --model=resnet50_v1 --quant-type=channel --quantize-input-offline \
@@ -8,9 +12,12 @@ examples/simulate_quantization.py (:45-119 flags, :178-353 flow), running on MI3
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/simulate_quantization.py \
            --model=mobilenetv2_1.0 --quant-type=channel --weight-bits-width=4 --quantize-input-offline   # 8 x MI355X
 
-Differences that are deliberate: no `.asscalar()` per layer, accuracy counters on the device instead of a
-per-sample Python loop (:139-142), KL histograms + search on the device, optional one-process-per-GPU sharding
-(`torchrun`), synthetic datasets / seeded weights when ImageNet / gluoncv checkpoints are absent (no network here).
+What happens, in the reference's order (its __main__, :178-353): build the net -> `convert_model` with the converters the
+flags describe, minus the excluded blocks -> `qparams_init` -> [calibrate: KL histograms + threshold search, or EMA of
+the online statistic over `--calib-epoch` passes of a class-balanced sample of the training set] -> freeze the weights
+-> evaluate top-1 / class-averaged accuracy.  Deliberate differences: no `.asscalar()` per layer, accuracy
+counters and KL histograms / search on the device, optional one-process-per-GPU sharding (`torchrun`), synthetic datasets
+and seeded weights when ImageNet / gluoncv checkpoints are absent (there is no network here).
 """
 import argparse
 import os
@@ -32,102 +39,125 @@ from quantization.mxnet_amd.quantize import convert  # noqa: E402
 from quantization.mxnet_amd.quantize.initialize import qparams_init  # noqa: E402
 from quantization.mxnet_amd.quantize.distribution_calibrate import kl_calibrate_many, collect_feature_maps  # noqa: E402
 
-T = vision.transforms
-CIFAR10, ImageNet = vision.CIFAR10, vision.ImageNet
+# ---- the command line ------------------------------------------------------------------------------------------------------
+# (flags, argparse keywords).  REFERENCE_FLAGS is the reference's interface, entry for entry; EXTRA_FLAGS are additions.
+REFERENCE_FLAGS = [
+    (['--model'], dict(type=str, default=None, help='type of model to use. see vision_model for options. (required)')),
+    (['--print-model'], dict(action='store_true', help='print the architecture of model.')),
+    (['--list-models'], dict(action='store_true', help='list all models supported for --model.')),
+    (['--use-gpu'], dict(type=int, default=-1,
+                         help='run model on gpu. (default: cpu — which this build refuses: HIP device required)')),
+    (['--dataset'], dict(type=str, default="imagenet", choices=['imagenet', 'cifar10'],
+                         help='dataset to evaluate (default: imagenet)')),
+    (['--use-gn'], dict(action='store_true', help='whether to use group norm.')),
+    (['--batch-norm'], dict(action='store_true', help='enable batch normalization or not in vgg. default is false.')),
+    (['--use-se'], dict(action='store_true', help='use SE layers or not in resnext. default is false.')),
+    (['--last-gamma'], dict(action='store_true',
+                            help='whether to init gamma of the last BN layer in each bottleneck to 0.')),
+    (['--merge-bn'], dict(action='store_true', help='merge batchnorm into convolution or not. (default: False)')),
+    (['--weight-bits-width'], dict(type=int, default=8, help='bits width of weight to quantize into.')),
+    (['--input-signed'], dict(type=str, default="false",
+                              help='quantize inputs into int(true) or uint(fasle). (default: false)')),
+    (['--input-bits-width'], dict(type=int, default=8, help='bits width of input to quantize into.')),
+    (['--quant-type'], dict(type=str, default="layer", choices=['layer', 'group', 'channel'],
+                            help='quantize weights on layer/group/channel. (default: layer)')),
+    (['-j', '--num-data-workers'], dict(dest='num_workers', default=4, type=int,
+                                        help='number of preprocessing workers (default: 4)')),
+    (['--batch-size'], dict(type=int, default=128, help='evaluate batch size per device (CPU/GPU). (default: 128)')),
+    (['--num-sample'], dict(type=int, default=5, help='number of samples for every class in trainset. (default: 5)')),
+    (['--quantize-input-offline'], dict(action='store_true',
+                                        help='calibrate via EMA on trainset and quantize input offline.')),
+    (['--calib-mode'], dict(type=str, default="naive", choices=['naive', 'kl'],
+                            help='how to calibrate inputs. (default: naive)')),
+    (['--calib-epoch'], dict(type=int, default=3,
+                             help='number of epoches to calibrate via EMA on trainset. (default: 3)')),
+    (['--disable-cudnn-autotune'], dict(action='store_true',
+                                        help='disable MIOpen find/benchmark mode to pick the best convolution algorithm.')),
+    (['--eval-per-calib'], dict(action='store_true', help='evaluate once after every calibration.')),
+    (['--exclude-first-conv'], dict(type=str, default="true", choices=['false', 'true'],
+                                    help='exclude first convolution layer when quantize. (default: true)')),
+    (['--fixed-random-seed'], dict(type=int, default=7,
+                                   help='set random_seed for numpy to provide reproducibility. (default: 7)')),
+    (['--wino_quantize'], dict(type=str, default="none", choices=['none', 'F23', 'F43', 'F63'],
+                               help='quantize weights for Conv2D in Winograd domain (default: none)')),
+]
+EXTRA_FLAGS = [
+    (['--pretrained'], dict(type=str, default="true",
+                            help="'true' (look for a local checkpoint, else seeded weights), 'false', or a parameter file")),
+    (['--save-qparams'], dict(type=str, default=None,
+                              help='write the calibrated parameters (incl. every input_max) to this file')),
+    (['--load-qparams'], dict(type=str, default=None,
+                              help='load thresholds written by --save-qparams instead of calibrating')),
+    (['--no-fuse'], dict(action='store_true',
+                         help='keep BatchNorm / ReLU / depthwise convolution as separate library ops '
+                              '(default: quantize.fuse.fuse_inference folds them into the fake-quant kernels)')),
+    (['--synthetic-on-device'], dict(action='store_true',
+                                     help='(synthetic datasets only) generate normalised image batches directly on the GPU '
+                                          'instead of image by image on the host, so the reported speed is the '
+                                          'network\'s, not the data pipeline\'s; sample values differ from the host '
+                                          'pipeline\'s (both are random)')),
+    (['--export-scale-table'], dict(type=str, default=None,
+                                    help='after calibration write an ncnn-style int8 scale table (per-channel weight scales '
+                                         'after BN folding, one input scale per layer; quantize/freeze/scale_table.py)')),
+    (['--strict-global-batch'], dict(action='store_true',
+                                     help='(multi-GPU naive calibration) reproduce ONE device that sees the global batch bit '
+                                          'for bit: one small all-gather per quantised layer per forward instead of the '
+                                          'default single all-reduce per calibration step (dist.py)')),
+]
+
+
+def banner(title, lines=(), show=True):
+    if show:
+        print('*' * 25 + ' ' + title + ' ' + '*' * 25)
+        for line in lines:
+            print(line)
+        print('*' * (25 * 2 + 2 + len(title)))
+        print()
 
 
 def parse_args(argv=None):
     parser = argparse.ArgumentParser(description='Simulate for quantization.')
-    parser.add_argument('--model', type=str, default=None,
-                        help='type of model to use. see vision_model for options. (required)')
-    parser.add_argument('--print-model', action='store_true',
-                        help='print the architecture of model.')
-    parser.add_argument('--list-models', action='store_true',
-                        help='list all models supported for --model.')
-    parser.add_argument('--use-gpu', type=int, default=-1,
-                        help='run model on gpu. (default: cpu — which this build refuses: HIP device required)')
-    parser.add_argument('--dataset', type=str, default="imagenet",
-                        choices=['imagenet', 'cifar10'],
-                        help='dataset to evaluate (default: imagenet)')
-    parser.add_argument('--use-gn', action='store_true',
-                        help='whether to use group norm.')
-    parser.add_argument('--batch-norm', action='store_true',
-                        help='enable batch normalization or not in vgg. default is false.')
-    parser.add_argument('--use-se', action='store_true',
-                        help='use SE layers or not in resnext. default is false.')
-    parser.add_argument('--last-gamma', action='store_true',
-                        help='whether to init gamma of the last BN layer in each bottleneck to 0.')
-    parser.add_argument('--merge-bn', action='store_true',
-                        help='merge batchnorm into convolution or not. (default: False)')
-    parser.add_argument('--weight-bits-width', type=int, default=8,
-                        help='bits width of weight to quantize into.')
-    parser.add_argument('--input-signed', type=str, default="false",
-                        help='quantize inputs into int(true) or uint(fasle). (default: false)')
-    parser.add_argument('--input-bits-width', type=int, default=8,
-                        help='bits width of input to quantize into.')
-    parser.add_argument('--quant-type', type=str, default="layer",
-                        choices=['layer', 'group', 'channel'],
-                        help='quantize weights on layer/group/channel. (default: layer)')
-    parser.add_argument('-j', '--num-data-workers', dest='num_workers', default=4, type=int,
-                        help='number of preprocessing workers (default: 4)')
-    parser.add_argument('--batch-size', type=int, default=128,
-                        help='evaluate batch size per device (CPU/GPU). (default: 128)')
-    parser.add_argument('--num-sample', type=int, default=5,
-                        help='number of samples for every class in trainset. (default: 5)')
-    parser.add_argument('--quantize-input-offline', action='store_true',
-                        help='calibrate via EMA on trainset and quantize input offline.')
-    parser.add_argument('--calib-mode', type=str, default="naive",
-                        choices=['naive', 'kl'],
-                        help='how to calibrate inputs. (default: naive)')
-    parser.add_argument('--calib-epoch', type=int, default=3,
-                        help='number of epoches to calibrate via EMA on trainset. (default: 3)')
-    parser.add_argument('--disable-cudnn-autotune', action='store_true',
-                        help='disable MIOpen find/benchmark mode to pick the best convolution algorithm.')
-    parser.add_argument('--eval-per-calib', action='store_true',
-                        help='evaluate once after every calibration.')
-    parser.add_argument('--exclude-first-conv', type=str, default="true",
-                        choices=['false', 'true'],
-                        help='exclude first convolution layer when quantize. (default: true)')
-    parser.add_argument('--fixed-random-seed', type=int, default=7,
-                        help='set random_seed for numpy to provide reproducibility. (default: 7)')
-    parser.add_argument('--wino_quantize', type=str, default="none",
-                        choices=['none', 'F23', 'F43', 'F63'],
-                        help='quantize weights for Conv2D in Winograd domain (default: none)')
-    # additions (not in the reference)
-    parser.add_argument('--pretrained', type=str, default="true",
-                        help="'true' (look for a local checkpoint, else seeded weights), 'false', or a parameter file")
-    parser.add_argument('--save-qparams', type=str, default=None,
-                        help='write the calibrated parameters (incl. every input_max) to this file')
-    parser.add_argument('--no-fuse', action='store_true',
-                        help='keep BatchNorm / ReLU / depthwise convolution as separate library ops '
-                             '(default: quantize.fuse.fuse_inference folds them into the fake-quant kernels)')
-    parser.add_argument('--synthetic-on-device', action='store_true',
-                        help='(synthetic datasets only) generate normalised image batches directly on the GPU instead '
-                             'of image by image on the host, so the reported speed is the network\'s, not the data '
-                             'pipeline\'s; sample values differ from the host pipeline\'s (both are random)')
-    parser.add_argument('--export-scale-table', type=str, default=None,
-                        help='after calibration write an ncnn-style int8 scale table (per-channel weight scales after '
-                             'BN folding, one input scale per layer; quantize/freeze/scale_table.py) to this file')
-    parser.add_argument('--load-qparams', type=str, default=None,
-                        help='load thresholds written by --save-qparams instead of calibrating')
+    for flags, kw in REFERENCE_FLAGS + EXTRA_FLAGS:
+        parser.add_argument(*flags, **kw)
     opt = parser.parse_args(argv)
-
     if opt.list_models:
-        for key in get_model_list():
-            print(key)
-        exit(0)
-    elif opt.model is None:
-        print("error: --model is required")
-        exit(2)
-
-    if fqdist.rank() == 0 and int(os.environ.get("RANK", "0")) == 0:
+        print("\n".join(get_model_list()))
+        raise SystemExit(0)
+    if opt.model is None:
+        parser.error("--model is required")
+    if opt.use_gn:
+        parser.error("--use-gn: the model zoo of this build has no GroupNorm variants (gluoncv.nn.GroupNorm is absent)")
+    if int(os.environ.get("RANK", "0")) == 0:
         print()
-        print('*'*25 + ' Settings ' + '*'*25)
-        for k, v in opt.__dict__.items():
-            print("{0: <25}: {1}".format(k, v))
-        print('*'*(25*2+len(' Setting ')))
-        print()
+        banner('Settings', ["{0: <25}: {1}".format(k, v) for k, v in vars(opt).items()])
     return opt
+
+
+# ---- data ------------------------------------------------------------------------------------------------------------------
+class UniformSampler(Sampler):
+    """`num_per_class` indices of every class, in the order of ONE shuffled pass over the labels (the reference's sampler,
+    :151-175: the same `np.random.shuffle` draw, so the same indices for the same seed — and the same on every rank)."""
+
+    def __init__(self, classes, num_per_class, labels):
+        self._classes, self._num_per_class = int(classes), int(num_per_class)
+        self._labels = np.asarray(labels).astype(np.int64)
+
+    def __len__(self):
+        return self._classes * self._num_per_class
+
+    def __iter__(self):
+        order = np.arange(len(self._labels))
+        np.random.shuffle(order)
+        shuffled = self._labels[order]
+        keep = []
+        for c in range(self._classes):
+            where = np.flatnonzero(shuffled == c)[:self._num_per_class]
+            if where.size < self._num_per_class:
+                raise ValueError("Number of samples for class {} is {} < {}".format(c, float(where.size),
+                                                                                    self._num_per_class))
+            keep.append(where)
+        # first-come order of the shuffled pass (every kept position precedes the point where the last class fills up)
+        return iter(order[np.sort(np.concatenate(keep))].tolist())
 
 
 class DeviceSyntheticLoader(object):
@@ -137,15 +167,16 @@ class DeviceSyntheticLoader(object):
 
     def __init__(self, n_images, batch_size, shape, classes, ctx, seed, rank=0, world_size=1):
         self._n, self._b, self._shape, self._classes = int(n_images), int(batch_size), tuple(shape), int(classes)
-        self._dev, self._seed, self._rank, self._world = ctx.torch_device, int(seed), int(rank), int(world_size)
-        self._batches = [i for i in range((self._n + self._b - 1) // self._b) if i % self._world == self._rank]
+        self._dev, self._seed = ctx.torch_device, int(seed)
+        self.total_batches = (self._n + self._b - 1) // self._b
+        self._mine = range(int(rank), self.total_batches, int(world_size))
 
     def __len__(self):
-        return len(self._batches)
+        return len(self._mine)
 
     def __iter__(self):
         g = torch.Generator(device=self._dev)
-        for i in self._batches:
+        for i in self._mine:
             b = min(self._b, self._n - i * self._b)
             g.manual_seed(self._seed * 1000003 + i)
             X = torch.randn((b,) + self._shape, device=self._dev, generator=g)
@@ -153,78 +184,250 @@ class DeviceSyntheticLoader(object):
             yield mx.nd.NDArray(X), mx.nd.NDArray(y)
 
 
+def _total_batches(loader):
+    """Batches of the WHOLE (unsharded) loader: every rank must take ceil(total / world) calibration steps."""
+    if hasattr(loader, "total_batches"):
+        return loader.total_batches
+    return getattr(loader, "_total_batches", len(loader) * fqdist.world_size())
+
+
+# ---- evaluation ------------------------------------------------------------------------------------------------------------
 def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"):
-    """reference :122-148.  Counters live on the device: [n_correct, total, correct[c], label[c]]; one all-reduce."""
+    """One pass over `dataloader`: top-1 accuracy and class-averaged accuracy (the quantities of the reference's
+    `evaluate`, :122-148).  The counters [n_correct, total, correct[c], label[c]] live on the device (fq_eval_counters)
+    and cross the ranks in one all-reduce; with `update_ema` every batch is a calibration step."""
     dev = ctx.torch_device
     counters = torch.zeros(2 + 2 * num_class, dtype=torch.float32, device=dev)
-    n_images, t0 = 0, time.perf_counter()
-    with tqdm(total=len(dataloader), desc=tqdm_desc, disable=fqdist.rank() != 0) as pbar:
-        for i, (X, y) in enumerate(dataloader):
-            X = X.as_in_context(ctx)
-            y = y.as_in_context(ctx)._t.long()
-            outputs = net(X)
+    seen, started = 0, time.perf_counter()
+    steps = fqdist.calibration_steps(_total_batches(dataloader)) if update_ema and fqdist.world_size() > 1 else None
+    done = 0
+    with tqdm(total=len(dataloader), desc=tqdm_desc, disable=fqdist.rank() != 0) as bar:
+        for X, y in dataloader:
+            labels = y.as_in_context(ctx)._t.long()
+            logits = net(X.as_in_context(ctx))
             if update_ema:
                 net.update_ema()
-            ops.eval_counters(outputs._t, y, counters)       # argmax + per-class counters, one launch (fq_eval_counters)
-            n_images += int(y.numel())
-            pbar.update(1)
-    torch.cuda.synchronize(dev) if dev.type == "cuda" else None
-    elapsed = time.perf_counter() - t0
+            ops.eval_counters(logits._t, labels, counters)
+            seen += int(labels.numel())
+            done += 1
+            bar.update(1)
+    while steps is not None and done < steps:          # this rank's shard ran out first: keep the collectives in step
+        fqdist.empty_calibration_step(net)
+        done += 1
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - started
     fqdist.allreduce_eval_counters(counters)
     c = counters.cpu().numpy()
-    eval_acc = float(c[0] / max(c[1], 1.0))
-    eval_acc_avg = float((c[2:2 + num_class] / (c[2 + num_class:] + 1e-10)).mean())
-    evaluate.last_images_per_sec = n_images * fqdist.world_size() / max(elapsed, 1e-9)
-    return eval_acc, eval_acc_avg
+    evaluate.last_images_per_sec = seen * fqdist.world_size() / max(elapsed, 1e-9)
+    per_class = c[2:2 + num_class] / (c[2 + num_class:] + 1e-10)
+    return float(c[0] / max(c[1], 1.0)), float(per_class.mean())
 
 
-class UniformSampler(Sampler):
-    """`num_per_class` indices per class from one shuffled pass (reference :151-175); numpy's global RNG, so every
-    rank (same seed) draws the same sequence."""
-
-    def __init__(self, classes, num_per_class, labels):
-        self._classes = classes
-        self._num_per_class = num_per_class
-        self._labels = labels
-
-    def __iter__(self):
-        sample_indices = []
-        label_counter = np.zeros(self._classes)
-        shuffle_indices = np.arange(len(self._labels))
-        np.random.shuffle(shuffle_indices)
-        for idx in shuffle_indices:
-            label = self._labels[idx]
-            if label_counter[label] < self._num_per_class:
-                sample_indices.append(idx)
-                label_counter[label] += 1
-            if label_counter.sum() == self._classes * self._num_per_class:
-                break
-        for idx, cnt in enumerate(label_counter):
-            if cnt < self._num_per_class:
-                raise ValueError("Number of samples for class {} is {} < {}".format(idx, cnt, self._num_per_class))
-        return iter(sample_indices)
-
-    def __len__(self):
-        return self._classes * self._num_per_class
+evaluate.last_images_per_sec = 0.0
 
 
-def banner(title, lines=(), rank0=True):
-    if not rank0:
-        return
-    print('*' * 25 + ' ' + title + ' ' + '*' * 25)
-    for line in lines:
-        print(line)
-    print('*' * (25 * 2 + 2 + len(title)))
-    print()
+# ---- the program -----------------------------------------------------------------------------------------------------------
+class Simulation(object):
+    def __init__(self, opt, ctx, rank=0, world=1):
+        self.opt, self.ctx, self.rank, self.world = opt, ctx, rank, world
+        self.chief = rank == 0
+        self.classes = 10 if opt.dataset == 'cifar10' else 1000
+        self.signed = opt.input_signed == 'true'
+        self.net = None
+        self.last_result = None
+
+    # -- model ---------------------------------------------------------------------------------------------------------
+    def build_net(self):
+        opt = self.opt
+        pretrained = {"true": True, "false": False}.get(opt.pretrained.lower(), opt.pretrained)
+        zoo_args = dict(pretrained=pretrained, classes=self.classes)
+        if opt.model.startswith('vgg'):
+            zoo_args['batch_norm'] = opt.batch_norm
+        if opt.model.startswith('resnext'):
+            zoo_args['use_se'] = opt.use_se
+        if opt.last_gamma:
+            zoo_args['last_gamma'] = True
+        self.net = get_model(opt.model, **zoo_args)
+        if opt.print_model:
+            banner(opt.model, [repr(self.net)], self.chief)
+
+    def excluded_blocks(self):
+        net, name, out = self.net, self.opt.model, []
+        if self.opt.exclude_first_conv == 'true':
+            out += [net.features[0], net.features[1]]
+        if name.startswith('mobilenetv2_'):
+            out.append(net.output[0])
+        if name.startswith('cifar_resnet'):
+            first_unit = net.features[2][0].body
+            out += [first_unit[0], first_unit[1]]
+        return out
+
+    def quantise_net(self):
+        opt = self.opt
+        shared = dict(quantize_input=True, input_signed=self.signed, input_width=opt.input_bits_width,
+                      weight_width=opt.weight_bits_width, quant_type=opt.quant_type)
+        converters = {
+            nn.Conv2D: convert.gen_conv2d_converter(fake_bn=opt.merge_bn, wino_quantize=opt.wino_quantize, **shared),
+            nn.Dense: convert.gen_dense_converter(**shared),
+            nn.BatchNorm: convert.bypass_bn if opt.merge_bn else None,
+            nn.Activation: None,
+        }
+        skip = self.excluded_blocks()
+        banner('Exclude blocks', [b.name for b in skip], self.chief)
+        convert.convert_model(self.net, exclude=skip, convert_fn=converters)
+        qparams_init(self.net)
+        self.net.collect_params().reset_ctx(self.ctx)
+        if not opt.no_fuse and self.ctx.device_type == "gpu":
+            from quantization.mxnet_amd.quantize import fuse
+            n_fused = fuse.fuse_inference(self.net)
+            if self.chief:
+                print("[fuse] %d BatchNorm / depthwise blocks folded into fused HIP passes (--no-fuse to disable)" % n_fused)
+
+    # -- data ----------------------------------------------------------------------------------------------------------
+    def _transform(self):
+        T = vision.transforms
+        if self.opt.dataset == 'imagenet':
+            return T.Compose([T.Resize(256, keep_ratio=True), T.CenterCrop(224), T.ToTensor(),
+                              T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+        return T.Compose([T.ToTensor(), T.Normalize([0.4914, 0.4822, 0.4465], [0.2023, 0.1994, 0.2010])])
+
+    def make_loaders(self):
+        opt = self.opt
+        shard = fqdist.shard_loader_kwargs()
+        dataset = vision.ImageNet if opt.dataset == 'imagenet' else vision.CIFAR10
+        needs_calibration_data = opt.quantize_input_offline and not opt.load_qparams
+        eval_set = dataset(train=False).transform_first(self._transform())
+        self.train_loader = None
+        if opt.synthetic_on_device:
+            side = 224 if opt.dataset == 'imagenet' else 32
+            self.eval_loader = DeviceSyntheticLoader(len(eval_set), opt.batch_size, (3, side, side), self.classes,
+                                                     self.ctx, 7, **shard)
+            if needs_calibration_data:
+                self.train_loader = DeviceSyntheticLoader(self.classes * opt.num_sample, opt.batch_size,
+                                                          (3, side, side), self.classes, self.ctx, 11, **shard)
+            return
+        self.eval_loader = DataLoader(dataset=eval_set, batch_size=opt.batch_size, num_workers=opt.num_workers,
+                                      last_batch='keep', **shard)
+        if needs_calibration_data:
+            train_set = dataset(train=True).transform_first(self._transform())
+            labels = [item[1] for item in train_set._data.items] if opt.dataset == 'imagenet' \
+                else train_set._data._label
+            sampler = UniformSampler(self.classes, opt.num_sample, labels)
+            self.train_loader = DataLoader(dataset=train_set, batch_size=opt.batch_size, sampler=sampler,
+                                           num_workers=opt.num_workers, last_batch='keep', **shard)
+            self.train_loader._total_batches = (len(sampler) + opt.batch_size - 1) // opt.batch_size
+
+    # -- calibration ---------------------------------------------------------------------------------------------------
+    def calibrate_kl(self):
+        """Histograms of every quantised block's fp32 input, then the KL threshold search (reference :296-315)."""
+        net, opt = self.net, self.opt
+        title = ' KL Calibration '
+        if self.chief:
+            print('*' * 25 + title + '*' * 25)
+        net.disable_quantize()                   # fp32 inputs and fp32 weights while collecting
+        levels = 2 ** (opt.input_bits_width - 1 if self.signed else opt.input_bits_width)
+        bins = 2048
+        hists, ranges = collect_feature_maps(net, bins=bins, loader=self.train_loader, ctx=self.ctx,
+                                             sync=fqdist.kl_sync if self.world > 1 else None)
+        blocks = net.collect_quantized_blocks()
+        best = kl_calibrate_many([hists[b] for b in blocks], levels=levels, min_bins=levels, bins=bins,
+                                 device=self.ctx.torch_device)
+        for i, (blk, best_bins) in enumerate(zip(blocks, best)):
+            threshold = (best_bins + 0.5) * (ranges[blk] / bins)
+            if self.chief:
+                print(f"({i+1}/{len(blocks)})\tBest threshold for {blk.name}: {threshold}")
+            blk.input_max.set_data(nd.array([threshold], ctx=self.ctx))
+        net.enable_quantize()
+        if self.chief:
+            print('*' * (25 * 2 + len(title)))
+            print()
+
+    def calibrate_naive(self):
+        """EMA of the online statistic over `--calib-epoch` passes of the calibration sample (reference :317-334)."""
+        net, opt = self.net, self.opt
+        title = ' Naive Calibration '
+        if self.chief:
+            print('*' * 25 + title + '*' * 25)
+        if self.world > 1:
+            fqdist.attach_calibration_sync(net, opt.batch_size, strict=opt.strict_global_batch)
+        for epoch in range(1, opt.calib_epoch + 1):
+            net.quantize_input(enable=True, online=True)      # integer inputs and weights, ranges from the current batch
+            evaluate(net, self.classes, self.train_loader, ctx=self.ctx, update_ema=True,
+                     tqdm_desc="Calib[{}/{}]".format(epoch, opt.calib_epoch))
+            if opt.eval_per_calib:
+                if self.world > 1:
+                    fqdist.detach_calibration_sync(net)       # offline evaluation exchanges nothing per batch
+                net.quantize_input(enable=True, online=False)
+                self.report(*evaluate(net, self.classes, self.eval_loader, ctx=self.ctx,
+                                      tqdm_desc="Eval[{}/{}]".format(epoch, opt.calib_epoch)))
+                if self.chief:
+                    print()
+                if self.world > 1 and epoch < opt.calib_epoch:
+                    fqdist.attach_calibration_sync(net, opt.batch_size, strict=opt.strict_global_batch)
+        if self.world > 1:
+            fqdist.detach_calibration_sync(net)
+        if self.chief:
+            for blk in net.collect_quantized_blocks():
+                print(f"Best threshold for {blk.name}: {blk.input_max.data().asscalar()}")
+            print('*' * (25 * 2 + len(title)))
+            print()
+
+    # -- evaluation ----------------------------------------------------------------------------------------------------
+    def report(self, acc, avg_acc):
+        self.last_result = (acc, avg_acc)
+        if self.chief:
+            print('{0: <8}: {1:2.2f}%'.format('acc', acc * 100))
+            print('{0: <8}: {1:2.2f}%'.format('avg_acc', avg_acc * 100))
+            print('{0: <8}: {1:.1f} images/sec on {2} GPU(s)'.format('speed', evaluate.last_images_per_sec, self.world))
+
+    def final_evaluation(self, online):
+        self.net.fix_params()
+        self.net.quantize_input(enable=True, online=online)
+        acc, avg_acc = evaluate(self.net, self.classes, self.eval_loader, ctx=self.ctx)
+        if self.chief:
+            print('*' * 25 + ' Result ' + '*' * 25)
+        self.report(acc, avg_acc)
+        if self.chief:
+            print('*' * (25 * 2 + len(' Result ')))
+            print()
+        return acc, avg_acc
+
+    def execute(self):
+        opt = self.opt
+        np.random.seed(opt.fixed_random_seed)        # identical on every rank: same weights, same sampler draws
+        torch.backends.cudnn.benchmark = False       # MIOpen find mode: measured no gain, +60 s start-up (DESIGN.md)
+        self.build_net()
+        self.quantise_net()
+        self.make_loaders()
+        if not opt.quantize_input_offline:
+            return self.final_evaluation(online=True) + (self.net,)
+        if opt.load_qparams:
+            self.net.load_parameters(opt.load_qparams, ctx=self.ctx, allow_missing=True, ignore_extra=True)
+        elif opt.calib_mode == "kl":
+            self.calibrate_kl()
+        else:
+            self.calibrate_naive()
+        if opt.save_qparams and self.chief:
+            self.net.save_parameters(opt.save_qparams)
+        if opt.export_scale_table and self.chief:
+            from quantization.mxnet_amd.quantize.freeze import export_scale_table
+            export_scale_table(self.net, opt.export_scale_table, weight_width=8, input_width=8,
+                               json_path=opt.export_scale_table + ".json")
+        if opt.eval_per_calib and self.last_result is not None:
+            return self.last_result + (self.net,)      # already evaluated after the last calibration pass
+        return self.final_evaluation(online=False) + (self.net,)
+
+
+def run(opt, ctx, rank=0, world=1):
+    """-> (acc, avg_acc, net)"""
+    return Simulation(opt, ctx, rank, world).execute()
 
 
 def main(argv=None):
     rank, local_rank, world = fqdist.init()
     opt = parse_args(argv)
-    if world > 1:
-        ctx = gpu(local_rank)
-    else:
-        ctx = gpu(opt.use_gpu) if opt.use_gpu != -1 else cpu()
+    ctx = gpu(local_rank) if world > 1 else (gpu(opt.use_gpu) if opt.use_gpu != -1 else cpu())
     if ctx.device_type == "cpu":
         raise SystemExit("error: this build runs the fake-quant path on an MI355X only (no CPU fallback); "
                          "pass --use-gpu=<id>")
@@ -232,195 +435,6 @@ def main(argv=None):
         return run(opt, ctx, rank, world)
     finally:
         fqdist.shutdown()
-
-
-def run(opt, ctx, rank=0, world=1):
-    r0 = rank == 0
-
-    # set random_seed for numpy (identical on every rank: same weights, same sampler draws)
-    np.random.seed(opt.fixed_random_seed)
-    torch.backends.cudnn.benchmark = not opt.disable_cudnn_autotune and False   # measured: no gain, +60 s
-
-    # get model (:188-204)
-    model_name = opt.model
-    classes = 10 if opt.dataset == 'cifar10' else 1000
-    pretrained = {"true": True, "false": False}.get(opt.pretrained.lower(), opt.pretrained)
-    kwargs = {'pretrained': pretrained, 'classes': classes}
-    if opt.use_gn:
-        raise NotImplementedError("--use-gn needs gluoncv.nn.GroupNorm, which is not part of this build")
-    if model_name.startswith('vgg'):
-        kwargs['batch_norm'] = opt.batch_norm
-    elif model_name.startswith('resnext'):
-        kwargs['use_se'] = opt.use_se
-    if opt.last_gamma:
-        kwargs['last_gamma'] = True
-    net = get_model(model_name, **kwargs)
-
-    if opt.print_model and r0:
-        banner(opt.model, [repr(net)])
-
-    # convert model to quantization version (:213-250)
-    convert_fn = {
-        nn.Conv2D: convert.gen_conv2d_converter(
-            quantize_input=True,
-            wino_quantize=opt.wino_quantize,
-            fake_bn=opt.merge_bn,
-            input_signed=opt.input_signed == 'true',
-            weight_width=opt.weight_bits_width,
-            input_width=opt.input_bits_width,
-            quant_type=opt.quant_type
-        ),
-        nn.Dense: convert.gen_dense_converter(
-            quantize_input=True,
-            input_signed=opt.input_signed == 'true',
-            weight_width=opt.weight_bits_width,
-            input_width=opt.input_bits_width,
-            quant_type=opt.quant_type
-        ),
-        nn.Activation: None,
-        nn.BatchNorm: convert.bypass_bn if opt.merge_bn else None
-    }
-    exclude_blocks = []
-    if opt.exclude_first_conv == 'true':
-        exclude_blocks.extend([net.features[0], net.features[1]])
-    if model_name.startswith('mobilenetv2_'):
-        exclude_blocks.append(net.output[0])
-    if model_name.startswith('cifar_resnet'):
-        exclude_blocks.extend([net.features[2][0].body[0], net.features[2][0].body[1]])
-    banner('Exclude blocks', [b.name for b in exclude_blocks], r0)
-    convert.convert_model(net, exclude=exclude_blocks, convert_fn=convert_fn)
-
-    # initialize for quantization parameters and reset context (:253-255)
-    qparams_init(net)
-    net.collect_params().reset_ctx(ctx)
-    if not opt.no_fuse and ctx.device_type == "gpu":
-        from quantization.mxnet_amd.quantize import fuse
-        n_fused = fuse.fuse_inference(net)
-        if r0:
-            print("[fuse] %d BatchNorm / depthwise blocks folded into fused HIP passes (--no-fuse to disable)" % n_fused)
-
-    # construct transformer (:258-269)
-    if opt.dataset == 'imagenet':
-        eval_transformer = T.Compose([
-            T.Resize(256, keep_ratio=True),
-            T.CenterCrop(224),
-            T.ToTensor(),
-            T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
-        ])
-    else:
-        eval_transformer = T.Compose([
-            T.ToTensor(),
-            T.Normalize([0.4914, 0.4822, 0.4465], [0.2023, 0.1994, 0.2010])
-        ])
-
-    # fetch dataset and dataloader (:272-292); batches are strided across ranks
-    dataset = ImageNet if opt.dataset == 'imagenet' else CIFAR10
-    shard = fqdist.shard_loader_kwargs()
-    eval_dataset = dataset(train=False).transform_first(eval_transformer)
-    eval_loader = DataLoader(dataset=eval_dataset, batch_size=opt.batch_size, num_workers=opt.num_workers,
-                             last_batch='keep', **shard)
-    if opt.synthetic_on_device:
-        hw_in = 224 if opt.dataset == 'imagenet' else 32
-        eval_loader = DeviceSyntheticLoader(len(eval_dataset), opt.batch_size, (3, hw_in, hw_in), classes, ctx, 7, **shard)
-        if opt.quantize_input_offline and not opt.load_qparams:
-            train_loader = DeviceSyntheticLoader(classes * opt.num_sample, opt.batch_size, (3, hw_in, hw_in), classes, ctx,
-                                                 11, **shard)
-    if opt.quantize_input_offline and not opt.load_qparams and not opt.synthetic_on_device:
-        train_dataset = dataset(train=True).transform_first(eval_transformer)
-        if opt.dataset == 'imagenet':
-            train_labels = [item[1] for item in train_dataset._data.items]
-        elif opt.dataset == 'cifar10':
-            train_labels = train_dataset._data._label
-        train_loader = DataLoader(dataset=train_dataset, batch_size=opt.batch_size,
-                                  sampler=UniformSampler(classes, opt.num_sample, train_labels),
-                                  num_workers=opt.num_workers, last_batch='keep', **shard)
-
-    def report(acc, avg_acc):
-        if r0:
-            print('{0: <8}: {1:2.2f}%'.format('acc', acc * 100))
-            print('{0: <8}: {1:2.2f}%'.format('avg_acc', avg_acc * 100))
-            print('{0: <8}: {1:.1f} images/sec on {2} GPU(s)'.format('speed', evaluate.last_images_per_sec, world))
-
-    # calibrate for input ranges and evaluate for simulation (:294-353)
-    if opt.quantize_input_offline:
-        if opt.load_qparams:
-            net.load_parameters(opt.load_qparams, ctx=ctx, allow_missing=True, ignore_extra=True)
-        elif opt.calib_mode == "kl":
-            if r0:
-                print('*' * 25 + ' KL Calibration ' + '*' * 25)
-            net.disable_quantize()      # calibrate with fp32_input and fp32_weight inference
-            input_levels = 2 ** ((opt.input_bits_width - 1) if opt.input_signed == "true" else opt.input_bits_width)
-            min_bins, bins = input_levels, 2048
-            # collect feature maps: histograms accumulate on the device; ranks exchange max (first batch) + counts (end)
-            hist_collector, fm_max_collector = collect_feature_maps(net, bins=bins, loader=train_loader, ctx=ctx,
-                                                                    sync=fqdist.kl_sync if world > 1 else None)
-            # do calibration: all layers in one launch
-            quantized_blocks = net.collect_quantized_blocks()
-            n_quantized_blocks = len(quantized_blocks)
-            best = kl_calibrate_many([hist_collector[m] for m in quantized_blocks], levels=input_levels,
-                                     min_bins=min_bins, bins=bins, device=ctx.torch_device)
-            thresholds = {}
-            for i, (m, best_bins) in enumerate(zip(quantized_blocks, best)):
-                thresholds[m] = (best_bins + 0.5) * (fm_max_collector[m] / bins)
-                if r0:
-                    print(f"({i+1}/{n_quantized_blocks})\tBest threshold for {m.name}: {thresholds[m]}")
-            # update input_max
-            for m, th in thresholds.items():
-                m.input_max.set_data(nd.array([th], ctx=ctx))
-            net.enable_quantize()
-            if r0:
-                print('*' * (25 * 2 + len(' KL Calibration ')))
-                print()
-        else:
-            if r0:
-                print('*' * 25 + ' Naive Calibration ' + '*' * 25)
-            if world > 1:
-                fqdist.attach_calibration_sync(net, opt.batch_size)
-            for i in range(opt.calib_epoch):
-                net.quantize_input(enable=True, online=True)    # calibrate with int_input and int_weight inference
-                _ = evaluate(net, classes, train_loader, ctx=ctx, update_ema=True,
-                             tqdm_desc="Calib[{}/{}]".format(i+1, opt.calib_epoch))
-                if opt.eval_per_calib:
-                    net.quantize_input(enable=True, online=False)
-                    acc, avg_acc = evaluate(net, classes, eval_loader, ctx=ctx, update_ema=False,
-                                            tqdm_desc="Eval[{}/{}]".format(i + 1, opt.calib_epoch))
-                    report(acc, avg_acc)
-                    if r0:
-                        print()
-            if world > 1:
-                fqdist.detach_calibration_sync(net)
-            if r0:
-                for m in net.collect_quantized_blocks():
-                    print(f"Best threshold for {m.name}: {m.input_max.data().asscalar()}")
-                print('*' * (25 * 2 + len(' Naive Calibration ')))
-                print()
-        if opt.save_qparams and r0:
-            net.save_parameters(opt.save_qparams)
-        if opt.export_scale_table and r0:
-            from quantization.mxnet_amd.quantize.freeze import export_scale_table
-            export_scale_table(net, opt.export_scale_table, weight_width=8, input_width=8,
-                               json_path=opt.export_scale_table + ".json")
-        if not opt.eval_per_calib:
-            net.fix_params()
-            net.quantize_input(enable=True, online=False)
-            acc, avg_acc = evaluate(net, classes, eval_loader, ctx=ctx, update_ema=False)
-            if r0:
-                print('*' * 25 + ' Result ' + '*' * 25)
-            report(acc, avg_acc)
-            if r0:
-                print('*' * (25 * 2 + len(' Result ')))
-                print()
-    else:
-        net.fix_params()
-        net.quantize_input(enable=True, online=True)
-        acc, avg_acc = evaluate(net, classes, eval_loader, ctx=ctx, update_ema=False)
-        if r0:
-            print('*'*25 + ' Result ' + '*'*25)
-        report(acc, avg_acc)
-        if r0:
-            print('*'*(25*2 + len(' Result ')))
-            print()
-    return acc, avg_acc, net
 
 
 if __name__ == "__main__":

@@ -22,8 +22,9 @@ from .. import ops
 __all__ = ['Conv2D', 'quantize', 'dequantize']
 
 
-def _int2tuple(x):
-    return (x, ) * 2 if isinstance(x, int) else x
+def _pair(v):
+    """an int means the same value for height and width"""
+    return (v, v) if isinstance(v, int) else tuple(v)
 
 
 def quantize(F, x, out_type='int8'):
@@ -49,31 +50,28 @@ def dequantize(F, x, scale):
 
 
 class Conv2D(nn.HybridBlock):
+    """Constructor signature of the reference's block (nn/quantized_conv.py:80-84).  `_input_range` / `_weight_range`
+    (None, or a (min, max) pair) fix the quantisation ranges instead of taking them from the tensors (:112-120)."""
+
     def __init__(self, channels, kernel_size, strides, padding, in_channels, groups=1,
                  activation=None, use_bias=True, quantized=False,
                  input_dtype='float32', weight_dtype='float32',
                  weight_initializer=None, bias_initializer='zeros',
                  prefix=None, params=None):
         super(Conv2D, self).__init__(prefix, params)
+        if in_channels % groups or channels % groups:
+            raise AssertionError("groups=%d must divide in_channels=%d and channels=%d" % (groups, in_channels, channels))
+        self._groups = groups
+        self._kernel_size, self._strides, self._padding = _pair(kernel_size), _pair(strides), _pair(padding)
+        self._quantized, self._input_dtype, self._weight_dtype = quantized, input_dtype, weight_dtype
+        self._input_range = self._weight_range = None
         with self.name_scope():
-            self._channels = channels
-            self._in_channels = in_channels
-            self._groups = groups
-            assert in_channels % groups == 0 and channels % groups == 0
-            self._kernel_size = _int2tuple(kernel_size)
-            self._strides = _int2tuple(strides)
-            self._padding = _int2tuple(padding)
-            self._quantized = quantized
-            self._input_dtype = input_dtype
-            self._weight_dtype = weight_dtype
-            self._input_range = None
-            self._weight_range = None
-
-            self.weight = self.params.get('weight', shape=(channels, in_channels // groups, *self._kernel_size),
-                                          init=weight_initializer, allow_deferred_init=True)
-            self.bias = self.params.get('bias', shape=(channels, ),
-                                        init=bias_initializer, allow_deferred_init=True) if use_bias else None
-            self.act = nn.Activation(activation, prefix=activation + '_') if activation is not None else None
+            self.weight = self.params.get('weight', init=weight_initializer, allow_deferred_init=True,
+                                          shape=(channels, in_channels // groups) + self._kernel_size)
+            self.bias = None
+            if use_bias:
+                self.bias = self.params.get('bias', init=bias_initializer, allow_deferred_init=True, shape=(channels,))
+            self.act = None if activation is None else nn.Activation(activation, prefix=activation + '_')
 
     def _alias(self):
         return "conv2d"
@@ -137,17 +135,15 @@ class Conv2D(nn.HybridBlock):
         return y
 
     def __repr__(self):
-        s = '{name}({mapping}, kernel_size={}, stride={}'.format(self._kernel_size, self._strides)
-        len_kernel_size = len(self._kernel_size)
-        if self._padding != (0,) * len_kernel_size:
-            s += ', padding={}'.format(self._padding)
+        cout, cin_g = self.weight.shape[0], self.weight.shape[1]
+        parts = ["%s -> %s" % (cin_g if cin_g else None, cout), "kernel_size=%s" % (self._kernel_size,),
+                 "stride=%s" % (self._strides,)]
+        if any(self._padding):
+            parts.append("padding=%s" % (self._padding,))
         if self._groups != 1:
-            s += ', groups={}'.format(self._groups)
+            parts.append("groups=%d" % self._groups)
         if self.bias is None:
-            s += ', bias=False'
+            parts.append("bias=False")
         if self.act:
-            s += ', {}'.format(self.act)
-        s += ')'
-        shape = self.weight.shape
-        return s.format(name=self.__class__.__name__,
-                        mapping='{0} -> {1}'.format(shape[1] if shape[1] else None, shape[0]))
+            parts.append(str(self.act))
+        return "%s(%s)" % (type(self).__name__, ", ".join(parts))

@@ -17,29 +17,31 @@ from ... import ops
 __all__ = ['LinearQuantizeSTE']
 
 
+def _scale_vector(scale, device):
+    """one fp32 scale per leading row, as a flat device tensor"""
+    if isinstance(scale, NDArray):
+        return scale._t.reshape(-1).contiguous()
+    if isinstance(scale, torch.Tensor):
+        return scale.reshape(-1).contiguous()
+    if isinstance(scale, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(scale, dtype=np.float32).reshape(-1)).to(device)
+    if isinstance(scale, (numbers.Number, np.generic)) or hasattr(scale, "asscalar"):
+        return torch.tensor([float(np.float32(float(scale)))], dtype=torch.float32, device=device)
+    raise TypeError("unsupported scale type %r" % type(scale))
+
+
 class LinearQuantizeSTE(autograd.Function):
+    """Straight-through estimator around the fake-quantiser: the gradient of the output IS the gradient of the input."""
+
     def __init__(self, scale, clip_max=None, clip_min=None):
         super(LinearQuantizeSTE, self).__init__()
-        self.clip_max = clip_max
-        self.clip_min = clip_min if clip_min is not None else 0.
-        self.scale = scale
+        self.scale, self.clip_max = scale, clip_max
+        self.clip_min = 0. if clip_min is None else clip_min          # the reference's default lower bound (:34)
 
     def forward(self, x):
         t = x._t if isinstance(x, NDArray) else x
-        scale = self.scale
-        if isinstance(scale, NDArray):
-            st = scale._t.reshape(-1).contiguous()
-        elif isinstance(scale, torch.Tensor):
-            st = scale.reshape(-1).contiguous()
-        elif isinstance(scale, np.ndarray):
-            st = torch.from_numpy(np.ascontiguousarray(scale, dtype=np.float32).reshape(-1)).to(t.device)
-        elif isinstance(scale, (numbers.Number, np.generic)) or hasattr(scale, "asscalar"):
-            st = torch.tensor([float(np.float32(float(scale)))], dtype=torch.float32, device=t.device)
-        else:
-            raise TypeError("unsupported scale type %r" % type(scale))
-        clip_max = None if self.clip_max is None else float(self.clip_max)
-        y = ops.ste_forward(t.contiguous(), st, clip_max, float(self.clip_min))
-        return NDArray(y)
+        hi = None if self.clip_max is None else float(self.clip_max)
+        return NDArray(ops.ste_forward(t.contiguous(), _scale_vector(self.scale, t.device), hi, float(self.clip_min)))
 
     def backward(self, dy):
         return dy
