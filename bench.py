@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py — the driver's benchmark contract.
 
-Workload (BASELINE.json configs[1]): int8-simulated **mobilenet1.0**, ImageNet-shaped input (128, 3, 224, 224) per GPU,
-per-layer W8A8, ONLINE input quantisation, first conv + BN excluded — i.e. what
-`examples/simulate_quantization.py --model=mobilenet1.0` evaluates (reference: simulate_quantization.py:346-348 ->
-evaluate :122-148).  One step = one forward of the converted net over one resident batch + the on-device accuracy
-counters.  Random-init (seed 7) weights and synthetic N(0,1) images: no network for checkpoints or ImageNet.
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on): int8-simulated **mobilenet1.0**,
+ImageNet-shaped input (128, 3, 224, 224) per GPU, per-layer W8A8, ONLINE input quantisation, first conv + BN excluded —
+what `examples/simulate_quantization.py --model=mobilenet1.0` evaluates (reference: its evaluate(), :122-148, called at
+:346-348).  One step = one forward of the converted net over one resident batch + the on-device accuracy counters.
+Random-init (seed 7) weights and synthetic N(0,1) images: there is no network for checkpoints or ImageNet.  The other
+BASELINE configurations are reachable with flags (they are parity-test cases; their lines are kept under profiles/):
 
     python bench.py --gpus N --steps K --warmup W
+    python bench.py --model resnet50_v1 --quant-type channel [--offline] [--wino F43]
+    python bench.py --model mobilenetv2_1.0 --quant-type channel --weight-bits 4 --offline
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Prints ONE JSON line: images/sec for the whole job, plus
-  "roofline":     the dominant fake-quant kernel (`act_apply_kernel`, online): algorithmic bytes (8 B/elem: read x, write
-                  y — SURVEY.md 8d) / its HIP-event-timed duration inside the timed region, against 8 TB/s;
-  "cpu_baseline": the same workload on the host cores through the oracle (a "port": the reference's MXNet path
-                  cannot run here), on a bounded sample of images.
+  "roofline":     the kernel family with the largest share of the step: algorithmic bytes per launch / its
+                  HIP-event-timed duration inside the timed region, against 8 TB/s; every family under "kernels", and the
+                  whole step's algorithmic bytes over its wall time under "whole_step";
+  "cpu_baseline": the same workload on the host cores — the converted net with the C++/OpenMP restatement of the
+                  reference's arithmetic (oracle/libfq_host.so) doing the fake-quant on ALL cores and torch-CPU the
+                  convolutions — on a bounded sample, with the fake-quant-only figures (the reference's pass-by-pass op
+                  chain and the fused form, all cores; the numpy chain on one thread) beside it.
 """
 import argparse
 import json
@@ -30,26 +36,47 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (/opt/skills/guides/MI355X_MICROARCH.md)
+DEFAULT_STEPS = 400         # ~0.6 s of timed region for the default workload (1.4-1.5 ms per step)
+
+KERNEL_NAMES = {
+    "apply_online": "act_apply_kernel<ONLINE> (fake-quant apply pass, 8 B/elem)",
+    "apply_offline": "act_apply_kernel<OFFLINE> (8 B/elem)",
+    "stat": "absmax_per_sample_kernel (statistic pass, 4 B/elem)",
+    "dwconv": "dwconv3x3_{cols4,cols,}_kernel (depthwise 3x3 with fake-quant on load + BN/ReLU/statistic on store, "
+              "4 B/in-elem + 4 B/out-elem)",
+    "bn_act": "bn_act_stat_kernel (BatchNorm + ReLU + statistic in one pass, 8 B/elem)",
+    "stem": "stem_conv3x3s2_kernel (un-quantised first conv + BN + ReLU + statistic, 4 B/in-elem + 4 B/out-elem)",
+    "pool": "gap_stat_kernel (global average pool + statistic, 4 B/in-elem + 4 B/out-elem)",
+    "pwconv": "pwconv_{stream,chunk,tile}_kernel (1x1 conv on int8 codes: fake-quant on load, exact int32 MFMA sums, "
+              "BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
+    "weight": "weight fake-quant kernels (8 B/elem)",
+    "histogram": "histogram_kernel (4 B/elem)",
+    "global_max": "minmax_kernel (4 B/elem)",
+}
 
 
-def build_net(model, classes, ctx, seed=7, fuse=True):
+def build_net(model, classes, ctx, seed=7, fuse=True, quant_type="layer", weight_bits=8, input_bits=8, signed=False,
+              wino="none", freeze=True):
     from quantization.mxnet_amd.mx.gluon import nn
     from quantization.mxnet_amd.mx.gluon.model_zoo import get_model
     from quantization.mxnet_amd.quantize import convert
     from quantization.mxnet_amd.quantize.initialize import qparams_init
     np.random.seed(seed)
     net = get_model(model, pretrained=False, classes=classes)
-    convert_fn = {
-        nn.Conv2D: convert.gen_conv2d_converter(quantize_input=True, weight_width=8, input_width=8,
-                                                input_signed=False, quant_type="layer"),
-        nn.Dense: convert.gen_dense_converter(quantize_input=True, weight_width=8, input_width=8,
-                                              input_signed=False, quant_type="layer"),
-        nn.Activation: None, nn.BatchNorm: None}
-    exclude = [net.features[0], net.features[1]]
+    common = dict(quantize_input=True, weight_width=weight_bits, input_width=input_bits, input_signed=signed,
+                  quant_type=quant_type)
+    convert_fn = {nn.Conv2D: convert.gen_conv2d_converter(wino_quantize=wino, **common),
+                  nn.Dense: convert.gen_dense_converter(**common), nn.Activation: None, nn.BatchNorm: None}
+    exclude = [net.features[0], net.features[1]]                 # --exclude-first-conv=true, the CLI default
+    if model.startswith("mobilenetv2_"):
+        exclude.append(net.output[0])
+    if model.startswith("cifar_resnet"):
+        exclude += [net.features[2][0].body[0], net.features[2][0].body[1]]
     convert.convert_model(net, exclude=exclude, convert_fn=convert_fn)
     qparams_init(net)
     net.collect_params().reset_ctx(ctx)
-    net.fix_params()
+    if freeze:
+        net.fix_params()
     net.quantize_input(enable=True, online=True)
     if fuse and ctx.device_type == "gpu":
         from quantization.mxnet_amd.quantize import fuse as _fuse
@@ -62,7 +89,6 @@ def headline_tensor(dev, ops):
     12 algorithmic B/elem: two reads and one write, no credit for Infinity-Cache hits) on the largest
     MobileNet activation, (128, 64, 112, 112) fp32 = 411 MB, measured with HIP events on the launch stream after the
     benchmark's timed region (median of 20).  Reported beside `roofline`, which describes the dominant kernel of the step."""
-    import torch
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     x = torch.relu(torch.randn(128, 64, 112, 112, device=dev, generator=g)) * 2.0
@@ -87,38 +113,89 @@ def headline_tensor(dev, ops):
             "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms": round(ms, 4)}
 
 
-def cpu_baseline(model, classes, hw, sample_images, budget_s=25.0):
-    """Oracle leg: identical converted net on the host, fake-quant through oracle/ (numpy restatement of the
-    reference's op chain), conv/FC through torch-CPU.  Bounded sample; reports images/sec."""
+# the activation tensors entering mobilenet1.0's 27 quantised blocks, per image (C, H, W)
+MOBILENET_ACTS = [(32, 112, 112)] * 2 + [(64, 112, 112), (64, 56, 56)] + [(128, 56, 56)] * 3 + [(128, 28, 28)] + \
+    [(256, 28, 28)] * 3 + [(256, 14, 14)] + [(512, 14, 14)] * 11 + [(512, 7, 7)] + [(1024, 7, 7)] * 2 + [(1024, 1, 1)]
+
+
+def cpu_baseline(args, classes, hw, budget_s=20.0):
+    """Oracle leg (test infrastructure, never the product path): (1) the same converted net on the host, fake-quant by the
+    C++/OpenMP restatement on all cores, convolutions by torch-CPU — images/sec on a bounded sample; (2) the fake-quant
+    work alone over the 27 MobileNet activation shapes: the reference's pass-by-pass op chain and the fused form on all
+    cores, and the numpy op chain on one thread."""
     from quantization.mxnet_amd import mx
-    from oracle.patch import oracle_ops
-    net = build_net(model, classes, mx.cpu())
+    from oracle.patch import host_ops
+    from oracle import host as H
+    from oracle import fq_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    H.set_threads(0)
+    net = build_net(args.model, classes, mx.cpu(), quant_type=args.quant_type, weight_bits=args.weight_bits,
+                    input_bits=args.input_bits, signed=args.input_signed, wino=args.wino)
     rng = np.random.default_rng(7)
-    done, t_total = 0, 0.0
-    with oracle_ops():
-        x = mx.nd.array(rng.standard_normal((2, 3, hw, hw)).astype(np.float32))
-        net(x)                                      # first forward freezes the weights (fixed_params 0 -> 1)
-        bs = 4
-        while done < sample_images and t_total < budget_s:
-            x = mx.nd.array(rng.standard_normal((bs, 3, hw, hw)).astype(np.float32))
+    bs, done, t_total = 32, 0, 0.0
+    with host_ops():
+        net(mx.nd.array(rng.standard_normal((2, 3, hw, hw)).astype(np.float32)))   # freezes the weights (0 -> 1)
+        x = mx.nd.array(rng.standard_normal((bs, 3, hw, hw)).astype(np.float32))
+        net(x)                                                                       # warm (allocator, thread pools)
+        while t_total < budget_s * 0.5 and done < 4096:
             t0 = time.perf_counter()
             net(x)
             t_total += time.perf_counter() - t0
             done += bs
-    return {"value": round(done / t_total, 3), "unit": "images/sec", "cores": int(torch.get_num_threads()),
-            "kind": "port",
-            "sample": "%d images (batches of 4) of the same int8-sim %s forward; fake-quant = numpy oracle "
-                      "(1 thread), conv/FC = torch-CPU (%d threads); %.1f s" % (done, model, torch.get_num_threads(),
-                                                                                t_total)}
+    out = {"value": round(done / t_total, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+           "threads": {"openmp_fake_quant": H.threads(), "torch_conv": torch.get_num_threads()},
+           "sample": "%d images (batches of %d) of the same int8-sim %s forward on the host: fake-quant = C++/OpenMP "
+                     "restatement of the reference's arithmetic (oracle/libfq_host.so, %d threads), conv/FC = torch-CPU "
+                     "(%d threads); %.1f s" % (done, bs, args.model, H.threads(), torch.get_num_threads(), t_total)}
+    # (2) fake-quant only, 27-layer sweep at batch 16, buffers allocated and touched before timing
+    n = 16
+    biggest = max(c * h * w for c, h, w in MOBILENET_ACTS) * n
+    src = np.maximum(rng.standard_normal(biggest, dtype=np.float32), 0) * np.float32(1.7)
+    y = np.zeros(biggest, np.float32)
+    tmp = np.zeros(2 * biggest, np.float32)
+    t_chain = t_fused = 0.0
+    for c, h, w in MOBILENET_ACTS:
+        k = n * c * h * w
+        xs, ys = src[:k].reshape(n, c, h, w), y[:k].reshape(n, c, h, w)
+        t0 = time.perf_counter()
+        H.unfused_chain(xs, tmp=tmp, out=ys)
+        t1 = time.perf_counter()
+        H._call("fq_fake_quant_online_host", xs, ys, n, c * h * w, H._i(8), H._u(0), np.empty(1, np.float32), None, None,
+                None)
+        t2 = time.perf_counter()
+        t_chain += t1 - t0
+        t_fused += t2 - t1
+    xs = src[:2 * 64 * 112 * 112].reshape(2, 64, 112, 112)
+    t0 = time.perf_counter()
+    O.unfused_reference_chain(xs)
+    t_np = time.perf_counter() - t0
+    per_img = sum(c * h * w for c, h, w in MOBILENET_ACTS)
+    out["fake_quant_only"] = {
+        "what": "online fake-quant of the 27 mobilenet1.0 activation tensors (4.99 M elements per image), batch 16",
+        "reference_op_chain_all_cores_images_per_sec": round(n / t_chain, 2),
+        "fused_all_cores_images_per_sec": round(n / t_fused, 2),
+        "numpy_op_chain_1_thread_images_per_sec": round(xs.size / t_np / per_img, 3),
+        "threads": H.threads()}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=DEFAULT_STEPS)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="mobilenet1.0")
     ap.add_argument("--batch-size", type=int, default=128, help="per GPU (CLI default, simulate_quantization.py:81)")
+    ap.add_argument("--quant-type", default="layer", choices=["layer", "group", "channel"])
+    ap.add_argument("--weight-bits", type=int, default=8)
+    ap.add_argument("--input-bits", type=int, default=8)
+    ap.add_argument("--input-signed", action="store_true")
+    ap.add_argument("--wino", default="none", choices=["none", "F23", "F43", "F63"])
+    ap.add_argument("--offline", action="store_true",
+                    help="offline input quantisation: two naive-EMA calibration steps fix the thresholds, then the timed "
+                         "steps run with them (the evaluation phase of --quantize-input-offline)")
+    ap.add_argument("--rotate", type=int, default=4, help="distinct resident input batches cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-every", type=int, default=10,
                     help="bracket the library's kernels with HIP events in every n-th timed step (default 10)")
@@ -130,7 +207,6 @@ def main():
                     help="keep BatchNorm / ReLU as separate torch ops (no quantize.fuse.fuse_inference)")
     ap.add_argument("--autotune", action="store_true",
                     help="MIOpen find/benchmark mode (measured: no gain for these shapes, +60 s of search)")
-    ap.add_argument("--cpu-sample", type=int, default=64)
     ap.add_argument("--graph", type=int, default=int(os.environ.get("FQ_BENCH_GRAPH", "0")),
                     help="replay the step from a hipGraph (no per-kernel events then; roofline measured in extra steps)")
     args = ap.parse_args()
@@ -138,13 +214,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the fake-quant path has no CPU fallback)")
-    # test-only knobs for exercising the N > 1 path on a one-GPU box: every rank on device 0, gloo instead of RCCL
+    # test-only knobs for exercising the N > 1 path on a one-GPU box: every rank on device 0, optionally gloo
     share_gpu = os.environ.get("FQ_BENCH_SHARE_GPU", "0") == "1"
     backend = os.environ.get("FQ_BENCH_BACKEND", "nccl")
     if share_gpu:
@@ -166,17 +241,30 @@ def main():
     classes = 10 if args.model.startswith("cifar") else 1000
     hw = 32 if args.model.startswith("cifar") else 224
     ctx = mx.gpu(local_rank)
-    net = build_net(args.model, classes, ctx, fuse=not args.no_fuse)
+    net = build_net(args.model, classes, ctx, fuse=not args.no_fuse and not args.offline, quant_type=args.quant_type,
+                    weight_bits=args.weight_bits, input_bits=args.input_bits, signed=args.input_signed, wino=args.wino,
+                    freeze=not args.offline)
     nblocks = len(net.collect_quantized_blocks())
 
     torch.manual_seed(7 + rank)
-    X = mx.nd.NDArray(torch.randn(args.batch_size, 3, hw, hw, device=dev))
-    y = torch.randint(0, classes, (args.batch_size,), device=dev)
+    rotate = max(1, args.rotate)
+    batches = [mx.nd.NDArray(torch.randn(args.batch_size, 3, hw, hw, device=dev)) for _ in range(rotate)]
+    labels = [torch.randint(0, classes, (args.batch_size,), device=dev) for _ in range(rotate)]
     counters = torch.zeros(2 + 2 * classes, dtype=torch.float32, device=dev)   # n_correct, total, correct[c], label[c]
+    if args.offline:
+        for i in range(2):                            # naive-EMA calibration (simulate_quantization.py:320-323)
+            net(batches[i % rotate])
+            net.update_ema()
+        net.fix_params()
+        net.quantize_input(enable=True, online=False)
+        if not args.no_fuse:
+            net(batches[0])                           # the freezing forward
+            from quantization.mxnet_amd.quantize import fuse as _fuse
+            _fuse.fuse_inference(net)
 
-    def step():
-        out = net(X)._t
-        ops.eval_counters(out, y, counters)           # the eval loop's argmax + counters (fq_eval_counters, one launch)
+    def step(i):
+        out = net(batches[i % rotate])._t
+        ops.eval_counters(out, labels[i % rotate], counters)      # the eval loop's argmax + counters, one launch
         return out
 
     def barrier():
@@ -184,22 +272,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1) if args.graph else args.warmup):
-        step()
+    for i in range(max(args.warmup, 1) if args.graph else args.warmup):
+        step(i)
     torch.cuda.synchronize()
 
     graph = None
     if args.graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            step()
+            step(0)
         graph.replay()
         torch.cuda.synchronize()
 
     # Kernel events are SAMPLED inside the timed region (every `event_every`-th step): bracketing all ~45 launches of a
-    # step costs ~35 % of THAT step (two marker packets per launch; measured 78.4 k images/s with every 4th step
-    # bracketed against 85.4 k with none), and the cost is charged to `value`.  Every 10th step keeps >= 3 profiled steps
-    # (~40 launches of each producer family) at the default --steps 30.
+    # step costs ~35 % of THAT step (two marker packets per launch), and the cost is charged to `value`.
     event_every = 0 if (args.no_kernel_events or graph is not None) else max(1, args.event_every)
     profiled_steps = 0
     if event_every:
@@ -214,7 +300,7 @@ def main():
             if on:
                 ops.profile_enable(True)
                 profiled_steps += 1
-            step()
+            step(i)
             if on:
                 ops.profile_enable(False)
     barrier()
@@ -225,16 +311,15 @@ def main():
         ops.profile_reset()
         ops.profile_enable(True)
         profiled_steps = min(args.steps, 10)
-        for _ in range(profiled_steps):
-            step()
+        for i in range(profiled_steps):
+            step(i)
         torch.cuda.synchronize()
         ops.profile_enable(False)
         prof = ops.profile_read()
     ops.profile_reset()
-    # A bracketing event pair adds a fixed cost to every launch it times (two marker packets + dispatch latency).
-    # It is measured live around a one-element kernel whose own duration is known from the rocprofv3 trace, and removed.
-    null_kernel_us = 3.4          # fill_kernel average in profiles/r1_bench_kernel_stats.csv (rocprofv3)
-    ev_overhead_ms = max(ops.profile_event_overhead_ms(dev) - null_kernel_us * 1e-3, 0.0)
+    # A bracketing event pair adds a fixed cost to every launch it times (two marker packets + dispatch latency): the
+    # median pair around a one-element kernel minus that kernel's own back-to-back cost, both measured NOW on this device.
+    ev_overhead_ms, null_kernel_ms = ops.profile_event_overhead_ms(dev)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -244,64 +329,74 @@ def main():
 
     if rank == 0:
         images = world * args.batch_size * args.steps
-        # every HIP kernel family of the fake-quant path, timed by HIP events inside the timed region
-        names = {"apply_online": "act_apply_kernel<ONLINE> (fake-quant apply pass, 8 B/elem)",
-                 "apply_offline": "act_apply_kernel<OFFLINE> (8 B/elem)",
-                 "stat": "absmax_per_sample_kernel (statistic pass, 4 B/elem)",
-                 "dwconv": "dwconv3x3_*_kernel (depthwise 3x3 with fake-quant on load + BN/ReLU/statistic on store, "
-                           "4 B/in-elem + 4 B/out-elem)",
-                 "bn_act": "stem_conv3x3s2_kernel / bn_act_stat_kernel (un-quantised first conv + BN + ReLU + statistic, "
-                           "4 B/in-elem + 4 B/out-elem; lone BN + ReLU + statistic passes, 8 B/elem)",
-                 "pwconv": "pwconv_stream_kernel / pwconv_chunk_kernel (+ quant_transpose_i8 + pwconv_i8 for K=1024): 1x1 "
-                           "conv on int8 codes, fake-quant on load, exact int32 MFMA sums, BN/ReLU/statistic on store; "
-                           "4 B/in-elem + 4 B/out-elem",
-                 "weight": "weight fake-quant kernels (8 B/elem)", "histogram": "histogram_kernel (4 B/elem)"}
+        ms_per_step = elapsed / args.steps * 1e3
         kernels = {}
+        step_bytes = 0.0
         for key, rec in prof.items():
             if not rec["launches"]:
                 continue
             ms = max(rec["ms"] - ev_overhead_ms * rec["launches"], 1e-9)
             gbs = rec["bytes"] / (ms * 1e-3) / 1e9
-            kernels[key] = {"kernel": names.get(key, key), "achieved": round(gbs, 1),
+            step_bytes += rec["bytes"] / max(profiled_steps, 1)
+            kernels[key] = {"kernel": KERNEL_NAMES.get(key, key), "achieved": round(gbs, 1),
                             "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": rec["launches"],
                             "avg_launch_us": round(ms * 1e3 / rec["launches"], 3),
                             "avg_launch_us_raw_events": round(rec["ms"] * 1e3 / rec["launches"], 3),
                             "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["launches"], 1),
                             "ms_per_step": round(ms / max(profiled_steps, 1), 4)}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
-        traffic = None
+        traffic, traffic_src = None, None
+        default_workload = (args.model == "mobilenet1.0" and args.quant_type == "layer" and not args.offline
+                            and args.weight_bits == 8 and args.input_bits == 8 and not args.no_fuse)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if dominant and os.path.exists(tpath):
+        if dominant and default_workload and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath))
+                traffic = rec.get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
+                traffic_src = "NOT measured in this run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes around " \
+                              "this command, committed as profiles/pmc_traffic.json (%s)" % rec.get("source", "")
             except Exception:
                 traffic = None
         dk = kernels.get(dominant, {"achieved": 0.0, "frac": 0.0, "kernel": None})
+        whole = step_bytes / (ms_per_step * 1e-3) / 1e9 if step_bytes else 0.0
+        flavour = "%s W%dA%d, %s input quant" % ({"layer": "per-layer", "group": "per-group", "channel": "per-channel"}
+                                                  [args.quant_type], args.weight_bits, args.input_bits,
+                                                  "offline" if args.offline else "online")
+        if args.wino != "none":
+            flavour += ", Winograd-domain %s weights" % args.wino
         line = {
-            "metric": "images/sec int8-sim %s (per-layer W8A8, online input quant)"
-                      % ("MobileNet1.0" if args.model == "mobilenet1.0" else args.model),
+            "metric": "images/sec int8-sim %s (%s)" % ("MobileNet1.0" if args.model == "mobilenet1.0" else args.model,
+                                                       flavour),
             "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s ImageNet-shaped (%d,3,%d,%d)/GPU, per-layer W8A8, online input quant, first "
-                                   "conv excluded, %d fake-quantised blocks, eval forward + accuracy counters"
-                                   % (args.model, args.batch_size, hw, hw, nblocks),
+            "config": {"workload": "%s ImageNet-shaped (%d,3,%d,%d)/GPU, %s, first conv excluded, %d fake-quantised "
+                                   "blocks, eval forward + accuracy counters, %d resident input batches cycled"
+                                   % (args.model, args.batch_size, hw, hw, flavour, nblocks, rotate),
                        "global_batch": world * args.batch_size, "parallelism": "dp%d (replicated weights, sharded "
                        "batch, no data-path collective; counters all-reduced once)" % world,
                        "hipgraph": bool(args.graph), "fused_producers": not args.no_fuse},
             "roofline": {"bound": "hbm", "kernel": dk["kernel"], "achieved": dk["achieved"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dk["frac"], "traffic": traffic,
+                         "unit": "GB/s", "frac": dk["frac"], "traffic": traffic, "traffic_source": traffic_src,
                          "dominant_by": "largest HIP-event time per step among this library's kernels",
                          "event_sampling": "HIP events bracket every library launch in %d of the %d timed steps"
                                            % (profiled_steps, args.steps),
-                         "event_pair_overhead_us_removed": round(ev_overhead_ms * 1e3, 3), "kernels": kernels},
+                         "event_pair_overhead_us_removed": round(ev_overhead_ms * 1e3, 3),
+                         "null_kernel_us_measured": round(null_kernel_ms * 1e3, 3),
+                         "whole_step": {"algorithmic_bytes_per_step": round(step_bytes, 1), "achieved": round(whole, 1),
+                                        "frac": round(whole / HBM_PEAK_GBS, 4),
+                                        "what": "sum of the algorithmic bytes of every library launch of one step / "
+                                                "ms_per_step (library convolutions and launch gaps included in the time)"},
+                         "kernels": kernels},
+            "consistency": {"timed_region_s": round(elapsed, 4)},
         }
+        if elapsed < 0.5:
+            line["consistency"]["warning"] = "timed region shorter than 0.5 s: raise --steps"
+            sys.stderr.write("bench.py: timed region %.3f s < 0.5 s — raise --steps for a stable figure\n" % elapsed)
         if world == 1 and not args.no_headline:
             line["headline_tensor"] = headline_tensor(dev, ops)
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.model, classes, hw, args.cpu_sample)
-        elif world == 1:
-            line["cpu_baseline"] = None
+        if world == 1:
+            line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args, classes, hw)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

@@ -60,15 +60,22 @@ int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront)
 #define FQ_KERNEL_WEIGHT 3        /* weight kernels                : 8 B/elem                                       */
 #define FQ_KERNEL_HISTOGRAM 4     /* histogram_kernel              : 4 B/elem                                       */
 #define FQ_KERNEL_BN_ACT 5        /* bn_act_stat_kernel            : 8 B/elem                                       */
-#define FQ_KERNEL_DWCONV 6        /* dwconv3x3_kernel              : 4 B/in elem + 4 B/out elem                     */
-#define FQ_KERNEL_PWCONV 7        /* pwconv_i8_kernel              : 4 B/in elem + 4 B/out elem                     */
-#define FQ_KERNEL_COUNT 8
+#define FQ_KERNEL_DWCONV 6        /* dwconv3x3_*_kernel            : 4 B/in elem + 4 B/out elem                     */
+#define FQ_KERNEL_PWCONV 7        /* pwconv_{stream,chunk,tile}_kernel (32x32x32 int8 MFMA; pwconv_fused / quant_transpose_i8 +
+                                     pwconv_i8 for the remaining shapes): 4 B/in elem + 4 B/out elem                 */
+#define FQ_KERNEL_STEM 8          /* stem_conv3x3s2_kernel         : 4 B/in elem + 4 B/out elem                     */
+#define FQ_KERNEL_POOL 9          /* gap_stat_kernel               : 4 B/in elem + 4 B/out elem                     */
+#define FQ_KERNEL_GLOBAL_MAX 10   /* minmax_kernel (calibration)   : 4 B/elem                                       */
+#define FQ_KERNEL_COUNT 11
 int fq_profile_enable(int on);
 int fq_profile_reset(void);
 int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes);
-/* Median elapsed time (ms) of an event pair bracketing a one-element fill kernel on `stream`: the fixed cost the
- * event pair adds to every bracketed launch (marker packets + dispatch latency).  `scratch`: >= 4 device bytes.   */
-int fq_profile_calibrate(void* scratch, int repeats, double* median_ms, fqStream_t stream);
+/* The fixed cost an event pair adds to a bracketed launch, measured on `stream`:
+ *   pair_ms        <- median elapsed time of an event pair around ONE one-element fill kernel (`repeats` samples);
+ *   null_kernel_ms <- elapsed time of `repeats` back-to-back launches of that kernel inside ONE event pair / repeats, i.e.
+ *                     what the kernel itself (dispatch included) costs when nothing brackets it.
+ * pair_ms - null_kernel_ms is what bench.py removes from every bracketed launch.  `scratch`: >= 4 device bytes.          */
+int fq_profile_calibrate(void* scratch, int repeats, double* pair_ms, double* null_kernel_ms, fqStream_t stream);
 
 /* ---- activations ---------------------------------------------------------------------------------------------
  * x is (n, inner) = (N, C*H*W).  `ws` is a caller workspace of fq_act_workspace_bytes(n) bytes.                  */
@@ -189,7 +196,8 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
  * After fake-quantisation both operands of a convolution are integers times a scale: x_q = cx * sx (cx in [0, 2^w-1]
  * or [-(2^(w-1)-1), 2^(w-1)-1]) and w_q[co,:] = cw * sw[co].  For a 1x1 convolution the reference's fp32
  * F.Convolution computes  sum_ci w_q * x_q  with fp32 rounding at every step; the SAME sum is  sx*sw[co] * sum_ci cw*cx,
- * and the integer sum is exact on the int8 matrix cores (v_mfma_i32_16x16x64_i8, int32 accumulate).  This entry point
+ * and the integer sum is exact on the int8 matrix cores (int32 accumulate; v_mfma_i32_32x32x32_i8 in the stream /
+ * chunk / tile forms that take the MobileNet / ResNet shapes, v_mfma_i32_16x16x64_i8 in the generic forms).  This entry point
  * does that, with the fake-quant of x folded into the load and BatchNorm / activation / per-sample statistic into the
  * store (same contract as fq_dwconv3x3):
  *   cx   = roundf(clip(x, lo, max_) / (max_/levels + eps))          bit-identical to the fake-quant kernels
@@ -201,8 +209,10 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
  * unsigned activations).  Needs in_width <= 8.                                                                       */
 int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_scale, int width, int64_t row_pad,
                     int64_t rows_pad, int8_t* codes, float* scales, int32_t* rowsum, void* ws, fqStream_t stream);
-/* Two launches: (A) quantise + transpose x into int8 codes [(n*hw)][cin_pad] in `ws` (fq_pwconv_workspace_bytes),
- * (B) the integer GEMM with both operands K-contiguous + epilogue.  Online mode requires out_current_max.            */
+/* One launch for the shapes of the stream / chunk / tile / panel forms (csrc/fq_pw_*.hip; chosen by shape, FQ_PW_FORM
+ * forces one for tuning); every other shape takes two: (A) quantise + transpose x into int8 codes [(n*hw)][cin_pad] in
+ * `ws` (fq_pwconv_workspace_bytes), (B) the integer GEMM with both operands K-contiguous + epilogue.  Online mode
+ * requires out_current_max.                                                                                          */
 size_t fq_pwconv_workspace_bytes(int64_t n, int64_t cin_pad, int64_t hw);
 int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
                  float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,

@@ -344,3 +344,75 @@ def oracle_ops():
     finally:
         for name, fn in saved.items():
             setattr(ops, name, fn)
+
+
+# ---- the same stand-in with the C++/OpenMP restatement doing the heavy passes (bench.py's cpu_baseline leg) -------------------
+def _host_fns():
+    from . import host as H
+
+    def _a(t):
+        return t.detach().contiguous().numpy()
+
+    def h_absmax_per_sample(x, no_abs=False, out=None):
+        r = torch.from_numpy(H.absmax_per_sample(_a(x), no_abs))
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+    def _finish(y, cur, codes, out, cur_out, want_codes):
+        yt = torch.from_numpy(y)
+        if out is not None:
+            out.copy_(yt)
+            yt = out
+        ct = torch.tensor([cur], dtype=torch.float32) if cur is not None else None
+        if cur_out is not None and ct is not None:
+            cur_out.copy_(ct)
+        return yt, (cur_out if cur_out is not None else ct), (torch.from_numpy(codes) if want_codes else None)
+
+    def h_fake_quant_online(x, width=8, flags=0, out=None, cur_out=None, want_codes=False, stat_ws=None):
+        y, cur, codes = H.fake_quant_online(_a(x), width, flags, want_codes)
+        return _finish(y, cur, codes, out, cur_out, want_codes)
+
+    def h_fake_quant_online_prestat(x, stat, width=8, flags=0, out=None, cur_out=None, want_codes=False):
+        y, cur, codes = H.fake_quant_online_prestat(_a(x), _a(stat), width, flags, want_codes)
+        return _finish(y, cur, codes, out, cur_out, want_codes)
+
+    def h_fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, want_stat=True, want_codes=False,
+                             stat_ws=None):
+        want = cur_out is not None and want_stat
+        y, cur, codes = H.fake_quant_offline(_a(x), float(_a(threshold).reshape(-1)[0]), width, flags, want_codes, want)
+        return _finish(y, cur, codes, out, cur_out if want else None, want_codes)
+
+    def h_weight_fake_quant(w, rows, width=8, out=None, want_scales=False):
+        wq, scales = H.weight_fake_quant(_a(w), int(rows), width)
+        wq = torch.from_numpy(wq)
+        if out is not None:
+            out.copy_(wq)
+            wq = out
+        return (wq, torch.from_numpy(scales)) if want_scales else wq
+
+    def h_eval_counters(logits, labels, counters):
+        counters.copy_(torch.from_numpy(H.eval_counters(_a(logits), _a(labels), _a(counters))))
+        return counters
+
+    return {"absmax_per_sample": h_absmax_per_sample, "fake_quant_online": h_fake_quant_online,
+            "fake_quant_online_prestat": h_fake_quant_online_prestat, "fake_quant_offline": h_fake_quant_offline,
+            "weight_fake_quant": h_weight_fake_quant, "eval_counters": h_eval_counters}
+
+
+@contextlib.contextmanager
+def host_ops():
+    """`with host_ops(): ...` — like oracle_ops(), with the per-element passes done by oracle/libfq_host.so on all host
+    cores (same results, pinned in tests/test_host_oracle.py); everything else stays with the numpy restatement."""
+    from quantization.mxnet_amd import ops
+    fast = _host_fns()
+    with oracle_ops():
+        saved = {name: getattr(ops, name) for name in fast}
+        for name, fn in fast.items():
+            setattr(ops, name, fn)
+        try:
+            yield
+        finally:
+            for name, fn in saved.items():
+                setattr(ops, name, fn)

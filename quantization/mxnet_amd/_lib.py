@@ -27,7 +27,7 @@ EXPORTS = {
     "fq_profile_reset": (_int, []),
     "fq_profile_read": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                                ctypes.POINTER(ctypes.c_double)]),
-    "fq_profile_calibrate": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_double), _vp]),
+    "fq_profile_calibrate": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]),
     "fq_act_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "fq_absmax_per_sample": (_int, [_vp, _i64, _i64, _uint, _vp, _vp]),
     "fq_batch_mean": (_int, [_vp, _i64, _vp, _vp]),

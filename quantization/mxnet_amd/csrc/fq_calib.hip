@@ -208,6 +208,7 @@ int fq_global_max(const float* x, int64_t numel, float* out, fqStream_t stream) 
   FQ_REQUIRE(numel > 0, "fq_global_max: empty tensor");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, out, (int64_t)1, -INFINITY);
+  ProfScope prof(FQ_KERNEL_GLOBAL_MAX, 4.0 * (double)numel, st);
   const int grid = grid_for((numel + kChunk - 1) / kChunk);
   hipLaunchKernelGGL((minmax_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, x, numel,
                      aligned16(x) ? 1 : 0, (float*)nullptr, out);

@@ -129,17 +129,22 @@ int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* 
   return FQ_OK;
 }
 
-int fq_profile_calibrate(void* scratch, int repeats, double* median_ms, fqStream_t stream) {
-  FQ_REQUIRE(scratch && median_ms && repeats > 0 && repeats <= 4096, "fq_profile_calibrate: bad arguments");
+int fq_profile_calibrate(void* scratch, int repeats, double* pair_ms, double* null_kernel_ms, fqStream_t stream) {
+  FQ_REQUIRE(scratch && pair_ms && null_kernel_ms && repeats > 0 && repeats <= 4096, "fq_profile_calibrate: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  // Enqueue every bracketed launch back to back (a busy queue, like the timed region), synchronise once at the end.
-  std::vector<hipEvent_t> ev((size_t)repeats * 2);
+  // (a) every bracketed launch enqueued back to back (a busy queue, like the timed region), synchronised once at the end
+  std::vector<hipEvent_t> ev((size_t)repeats * 2 + 2);
   for (auto& e : ev) FQ_HIP(hipEventCreate(&e));
   for (int i = 0; i < repeats; ++i) {
     FQ_HIP(hipEventRecord(ev[2 * i], st));
     hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, (float*)scratch, (int64_t)1, 0.0f);
     FQ_HIP(hipEventRecord(ev[2 * i + 1], st));
   }
+  // (b) the same launches with ONE pair around all of them
+  FQ_HIP(hipEventRecord(ev[2 * repeats], st));
+  for (int i = 0; i < repeats; ++i)
+    hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, st, (float*)scratch, (int64_t)1, 0.0f);
+  FQ_HIP(hipEventRecord(ev[2 * repeats + 1], st));
   FQ_HIP(hipEventSynchronize(ev.back()));
   std::vector<float> ts;
   for (int i = 0; i < repeats; ++i) {
@@ -147,9 +152,12 @@ int fq_profile_calibrate(void* scratch, int repeats, double* median_ms, fqStream
     FQ_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
     ts.push_back(t);
   }
+  float all = 0.f;
+  FQ_HIP(hipEventElapsedTime(&all, ev[2 * repeats], ev[2 * repeats + 1]));
   for (auto& e : ev) (void)hipEventDestroy(e);
   std::sort(ts.begin(), ts.end());
-  *median_ms = ts[ts.size() / 2];
+  *pair_ms = ts[ts.size() / 2];
+  *null_kernel_ms = (double)all / repeats;
   return FQ_OK;
 }
 

@@ -121,7 +121,7 @@ int fq_stem_conv3x3s2(const float* x, const float* w_tap_major, const float* bia
   const int Ho = (int)((h + 2 - 3) / 2 + 1), Wo = (int)((w + 2 - 3) / 2 + 1);
   const int64_t hwo = (int64_t)Ho * Wo;
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
-  ProfScope prof(FQ_KERNEL_BN_ACT, 4.0 * ((double)n * cin * h * w + (double)n * cout * hwo), st);
+  ProfScope prof(FQ_KERNEL_STEM, 4.0 * ((double)n * cin * h * w + (double)n * cout * hwo), st);
   const int tiles = (int)((hwo + kBlock - 1) / kBlock);
   // enough workgroups to fill the chip, as few statistic atomics per sample as that allows
   int tiles_per_wg = 1;

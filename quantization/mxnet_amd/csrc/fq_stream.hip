@@ -601,6 +601,7 @@ int fq_global_avg_pool_stat(const float* x, float* y, int64_t n, int64_t c, int6
   const bool prezeroed = (flags & FQ_STAT_PREZEROED) != 0;
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   const int64_t planes = n * c;
+  ProfScope prof(FQ_KERNEL_POOL, 4.0 * ((double)planes * hw + (double)planes), st);
   hipLaunchKernelGGL(gap_stat_kernel, dim3((unsigned)((planes + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, x, y, planes,
                      (int)c, (int)hw, stat_out);
   FQ_LAUNCH_CHECK();

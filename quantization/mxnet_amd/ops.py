@@ -82,7 +82,7 @@ def device_info():
 
 
 KERNEL_IDS = {"stat": 0, "apply_online": 1, "apply_offline": 2, "weight": 3, "histogram": 4, "bn_act": 5,
-              "dwconv": 6, "pwconv": 7}
+              "dwconv": 6, "pwconv": 7, "stem": 8, "pool": 9, "global_max": 10}
 
 
 def profile_enable(on=True):
@@ -105,13 +105,14 @@ def profile_read():
 
 
 def profile_event_overhead_ms(device=None, repeats=200):
-    """Fixed cost of one bracketing event pair around a trivial kernel (see fq_profile_calibrate)."""
+    """(overhead_ms, null_kernel_ms): the fixed cost a bracketing event pair adds to a launch = median pair around a
+    trivial kernel minus that kernel's own back-to-back cost, both measured now on this device (fq_profile_calibrate)."""
     device = default_device() if device is None else device
     scratch = torch.zeros(4, dtype=torch.float32, device=device)
-    ms = ctypes.c_double(0)
-    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    check_call(_lib_().fq_profile_calibrate(_ptr(scratch), int(repeats), ctypes.byref(ms), st))
-    return ms.value
+    pair, null = ctypes.c_double(0), ctypes.c_double(0)
+    check_call(_lib_().fq_profile_calibrate(_ptr(scratch), int(repeats), ctypes.byref(pair), ctypes.byref(null),
+                                            _stream(scratch)))
+    return max(pair.value - null.value, 0.0), null.value
 
 
 def act_flags(signed=False, lo_neg_max=None, no_abs=False, no_eps=False):

@@ -213,7 +213,7 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True):
         """GlobalAvgPool2D [-> Flatten] -> quantised Dense: pool and statistic in one launch, carried through Flatten."""
         if not isinstance(container, (nn.Sequential, nn.HybridSequential)):
             return
-        kids = list(container._children.values())
+        kids = list(container._children.values()) + after_features.get(id(container), [])
         for i, b in enumerate(kids):
             if type(b) is not nn.GlobalAvgPool2D or hasattr(b, "_fq_gap_fused"):
                 continue
@@ -276,6 +276,12 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True):
                 bypass(nxt)
             fused[0] += 1
 
+    # the model zoo's nets compute `output(features(x))`: what follows the last block of `features` is `output`
+    after_features = {}
+    feats, head = getattr(net, "features", None), getattr(net, "output", None)
+    if isinstance(feats, (nn.Sequential, nn.HybridSequential)) and head is not None:
+        after_features[id(feats)] = list(head._children.values()) \
+            if isinstance(head, (nn.Sequential, nn.HybridSequential)) else [head]
     if stem:
         net.apply(visit_stem)
     if depthwise:

@@ -23,8 +23,14 @@ def family(n):
         return 'histogram'
     if 'dwconv3x3' in n:
         return 'dwconv'
-    if 'bn_act_stat_kernel' in n or 'stem_conv3x3s2_kernel' in n:
+    if 'stem_conv3x3s2_kernel' in n:
+        return 'stem'
+    if 'bn_act_stat_kernel' in n:
         return 'bn_act'
+    if 'gap_stat_kernel' in n:
+        return 'pool'
+    if 'minmax_kernel' in n:
+        return 'global_max'
     if 'pwconv_' in n or 'quant_transpose_i8_kernel' in n:
         return 'pwconv'
     if 'weight_codes_kernel' in n or 'weight_rows_lds_kernel' in n or 'weight_apply_kernel' in n:
