@@ -193,7 +193,7 @@ def weight_codes(w, rows_per_scale, width=8):
 
 
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-              bn_scale=None, bn_shift=None, act=None, want_stat=True):
+              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None):
     signed, lo_neg, _, _ = _flags(flags)
     if in_stat is not None:
         in_max = O.batch_mean(_np(in_stat).reshape(-1)[:x.shape[0]])

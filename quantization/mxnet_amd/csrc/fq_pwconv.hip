@@ -41,7 +41,8 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
   FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_pwconv_i8: bn_scale and bn_shift go together");
   PwCall c;
   c.prezeroed = (act & FQ_STAT_PREZEROED) != 0;
-  act &= ~FQ_STAT_PREZEROED;
+  const int forced_form = (act >> 12) & 15;             // FQ_PW_FORM(f): tests and tuning runs name the form per call
+  act &= ~(FQ_STAT_PREZEROED | FQ_PW_FORM(15));
   FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_pwconv_i8: unknown activation %d", act);
   FQ_REQUIRE(aligned16(wcodes) && aligned16(ws) && aligned16(x), "fq_pwconv_i8: x, wcodes and ws must be 16-byte aligned");
   c.x = x; c.wcodes = wcodes; c.wscale = wscale; c.wsum = wsum; c.bias = bias; c.y = y;
@@ -52,11 +53,13 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
   c.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;      // unsigned codes are stored re-centred so they fit int8
   c.out_current_max = out_current_max; c.bn_scale = bn_scale; c.bn_shift = bn_shift; c.act = act;
   c.stat_out = stat_out; c.ws = ws; c.st = (hipStream_t)stream;
-  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 2 panel, 3 stream, 4 chunk, 5 tile
-  c.form = pw_form;
+  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 2 panel, 3 stream, 4 chunk, 5 tile, 6 wreg
+  c.form = forced_form ? forced_form : pw_form;
   ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), c.st);
   bool taken = false;
   if (int rc = pw_try_stream(c, &taken)) return rc;
+  if (taken) return FQ_OK;
+  if (int rc = pw_try_wreg(c, &taken)) return rc;
   if (taken) return FQ_OK;
   if (int rc = pw_try_tile(c, &taken)) return rc;
   if (taken) return FQ_OK;

@@ -432,8 +432,11 @@ def weight_codes(w, rows_per_scale, width=8):
     return codes, scales, rowsum
 
 
+PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "panel": 2, "stream": 3, "chunk": 4, "tile": 5, "wreg": 6}
+
+
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-              bn_scale=None, bn_shift=None, act=None, want_stat=True):
+              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None):
     """1x1 convolution on the integer codes (int8 MFMA, exact int32 accumulation) with quantise-on-load and fused
     BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations.  Returns (y, stat or None)."""
     _check(x, "x")
@@ -455,8 +458,8 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, hw), dtype=torch.uint8, device=x.device)
     check_call(_lib_().fq_pwconv_i8(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin,
                                     cin_pad, cout, hw, _ptr(in_stat), _ptr(in_thr), int(width), int(flags),
-                                    _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat),
-                                    _ptr(ws), _stream(x)))
+                                    _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift),
+                                    _ACTS[act] | zflag | (PW_FORMS[form] << 12), _ptr(stat), _ptr(ws), _stream(x)))
     return y, stat
 
 

@@ -296,13 +296,13 @@ def test_fused_caches_follow_in_place_parameter_updates(gpu):
         r = np.random.default_rng(17)
         for b in net.collect_quantized_blocks():
             if isinstance(b, nn.Conv2D) and b._kwargs["kernel"] == (1, 1):
-                w = b.weight.data().asnumpy()
-                b.weight.set_data(mx.nd.array((w * r.uniform(0.5, 1.5, w.shape)).astype(np.float32), ctx=gpu))
+                shape = b.weight.shape                # NEW values (the current ones differ: frozen vs raw)
+                b.weight.set_data(mx.nd.array((r.standard_normal(shape) * 0.05).astype(np.float32), ctx=gpu))
 
         def bn(m):
             if type(m) is nn.BatchNorm:
-                v = m.running_var.data().asnumpy()
-                m.running_var.set_data(mx.nd.array((v * r.uniform(0.5, 2.0, v.shape)).astype(np.float32), ctx=gpu))
+                shape = m.running_var.shape
+                m.running_var.set_data(mx.nd.array(r.uniform(0.5, 2.0, shape).astype(np.float32), ctx=gpu))
         net.apply(bn)
     a = fresh()
     a(X)
