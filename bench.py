@@ -128,8 +128,11 @@ def cpu_baseline(args, classes, hw, budget_s=20.0):
     from oracle import host as H
     from oracle import fq_oracle as O
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    H.set_threads(0)
+    # one thread per physical core of the machine, SMT siblings left idle (measured on the 2 x 64-core / 256-thread host:
+    # 256 OpenMP threads are several times SLOWER than 64-128 on these passes)
+    threads = int(os.environ.get("FQ_HOST_THREADS", max(1, cores // 2)))
+    torch.set_num_threads(threads)
+    H.set_threads(threads)
     net = build_net(args.model, classes, mx.cpu(), quant_type=args.quant_type, weight_bits=args.weight_bits,
                     input_bits=args.input_bits, signed=args.input_signed, wino=args.wino)
     rng = np.random.default_rng(7)
@@ -143,7 +146,8 @@ def cpu_baseline(args, classes, hw, budget_s=20.0):
             net(x)
             t_total += time.perf_counter() - t0
             done += bs
-    out = {"value": round(done / t_total, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+    out = {"value": round(done / t_total, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+           "host_logical_cpus": cores,
            "threads": {"openmp_fake_quant": H.threads(), "torch_conv": torch.get_num_threads()},
            "sample": "%d images (batches of %d) of the same int8-sim %s forward on the host: fake-quant = C++/OpenMP "
                      "restatement of the reference's arithmetic (oracle/libfq_host.so, %d threads), conv/FC = torch-CPU "

@@ -213,8 +213,8 @@ int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_
  * forces one for tuning); every other shape takes two: (A) quantise + transpose x into int8 codes [(n*hw)][cin_pad] in
  * `ws` (fq_pwconv_workspace_bytes), (B) the integer GEMM with both operands K-contiguous + epilogue.  Online mode
  * requires out_current_max.                                                                                          */
-/* OR into `act`: take this form instead of the shape-based choice (1 two kernels, 2 panel, 3 stream, 4 chunk, 5 tile,
- * 6 register-stationary); FQ_INVALID when the shape does not fit it.  For parity tests and tuning runs.                */
+/* OR into `act`: take this form instead of the shape-based choice (1 two kernels, 2 panel, 3 stream, 4 chunk, 5 tile);
+ * FQ_INVALID when the shape does not fit it.  For parity tests and tuning runs.                */
 #define FQ_PW_FORM(f) ((f) << 12)
 size_t fq_pwconv_workspace_bytes(int64_t n, int64_t cin_pad, int64_t hw);
 int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,

@@ -47,6 +47,14 @@ constexpr float kEps = 1e-10f;   // ste_func.py:39,41
 
 inline float clipf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
+// Threads for a loop over `work` elements: small tensors are not worth waking 256 threads for (a fork/join of a full team
+// costs tens of microseconds; the tail layers hold a few hundred thousand elements).
+inline int team(int64_t work) {
+  const int64_t want = work / 32768;
+  const int mx = omp_get_max_threads();
+  return (int)(want < 1 ? 1 : (want > mx ? mx : want));
+}
+
 // C roundf (half away from zero) in a form the compiler vectorises: x - trunc(x) is exact, so comparing it with 0.5 decides
 // the tie exactly as roundf does; NaN and infinities pass through (the comparison is false).
 inline float round_half_away(float x) {
@@ -90,8 +98,8 @@ void per_sample_stat(const float* x, int64_t n, int64_t inner, bool use_abs, flo
   const int64_t kPiece = 1 << 16;
   const int64_t pieces = (inner + kPiece - 1) / kPiece;
   const float init = use_abs ? 0.0f : -INFINITY;
-  for (int64_t s = 0; s < n; ++s) out[s] = init;
-#pragma omp parallel for collapse(2) schedule(static)
+  std::vector<float> part((size_t)(n * pieces));
+#pragma omp parallel for collapse(2) schedule(static) num_threads(team(n * inner))
   for (int64_t s = 0; s < n; ++s)
     for (int64_t p = 0; p < pieces; ++p) {
       const float* b = x + s * inner + p * kPiece;
@@ -101,13 +109,17 @@ void per_sample_stat(const float* x, int64_t n, int64_t inner, bool use_abs, flo
         for (int64_t i = 0; i < cnt; ++i) m = fmaxf(m, fabsf(b[i]));
       else
         for (int64_t i = 0; i < cnt; ++i) m = fmaxf(m, b[i]);
-#pragma omp critical(fq_stat)
-      out[s] = fmaxf(out[s], m);
+      part[(size_t)(s * pieces + p)] = m;
     }
+  for (int64_t s = 0; s < n; ++s) {
+    float m = init;
+    for (int64_t p = 0; p < pieces; ++p) m = fmaxf(m, part[(size_t)(s * pieces + p)]);
+    out[s] = m;
+  }
 }
 
 void apply_quant(const float* x, float* y, int32_t* codes, int64_t numel, const QP& q) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team(numel))
   for (int64_t i = 0; i < numel; ++i) {
     const float k = code_of(x[i], q);
     if (codes) codes[i] = (int32_t)k;
@@ -245,20 +257,20 @@ int fq_unfused_chain_host(const float* x, float* y, int64_t n, int64_t inner, in
   }
   float* a = tmp;
   float* b = tmp + numel;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team(numel))
   for (int64_t i = 0; i < numel; ++i) a[i] = fabsf(x[i]);                     // F.abs(x)
   std::vector<float> stat((size_t)n);
   per_sample_stat(a, n, inner, false, stat.data());                            // F.max(..., axis=(1,2,3))
   const float max_ = batch_mean(stat.data(), n);                               // .mean().asscalar()
   if (out_current_max) out_current_max[0] = max_;
   const QP q = make_qp(max_, act_levels(width, flags), (flags & FQ_ACT_LO_NEG_MAX) != 0, kEps);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team(numel))
   for (int64_t i = 0; i < numel; ++i) a[i] = clipf(x[i], q.lo, q.hi);         // x.clip(min_, max_)
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team(numel))
   for (int64_t i = 0; i < numel; ++i) b[i] = a[i] / q.denom;                  // / (scale + 1e-10)
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team(numel))
   for (int64_t i = 0; i < numel; ++i) a[i] = round_half_away(b[i]);                    // .round()
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(team(numel))
   for (int64_t i = 0; i < numel; ++i) y[i] = a[i] * q.scale;                  // * scale
   return FQ_OK;
 }

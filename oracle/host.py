@@ -34,6 +34,8 @@ def lib():
         build()
         _lib = ctypes.CDLL(_PATH)
         _lib.fq_last_error_host.restype = ctypes.c_char_p
+        # default team: the physical cores of one socket at most (FQ_HOST_THREADS overrides; set_threads(0) = all)
+        _lib.fq_set_threads_host(int(os.environ.get("FQ_HOST_THREADS", min(os.cpu_count() or 1, 64))))
     return _lib
 
 

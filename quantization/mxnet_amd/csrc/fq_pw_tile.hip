@@ -21,8 +21,11 @@ struct PwtGeom {
   int zoff;
 };
 
+#ifndef FQ_PWT_LB
+#define FQ_PWT_LB 2                 // wavefronts per SIMD the register allocation aims at (3 spills ~400 registers)
+#endif
 template <int KT, bool BLDS>
-__global__ __launch_bounds__(kBlock, 3) void pwconv_tile_kernel(
+__global__ __launch_bounds__(kBlock, FQ_PWT_LB) void pwconv_tile_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwtGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,

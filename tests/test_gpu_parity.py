@@ -444,37 +444,20 @@ def test_pwconv_i8_chunked_form_vs_oracle(dev, ops, case, mode):
 
 
 # Every form of fq_pwconv_i8 named explicitly (FQ_PW_FORM bits of the call), on shapes it accepts — the shape-based choice
-# above reaches: stream (K <= 256 with the whole weight matrix in LDS), wreg (K = 256 / 512 / 1024), panel and two_kernels
+# above reaches: stream (K <= 256 with the whole weight matrix in LDS), chunk / tile (K = 256 / 512 / 1024), panel and two_kernels
 # (every other shape: 24->40, 3->8, 96->576, 1024->1000, 960->320, 144->24, 16->96 of PW_CASES).
 FORM_CASES = [
     ("two_kernels", (2, 24, 40, 5, 7)), ("two_kernels", (2, 512, 512, 7, 7)), ("two_kernels", (2, 960, 320, 7, 7)),
     ("panel", (2, 144, 24, 14, 14)), ("panel", (2, 96, 576, 6, 6)), ("panel", (3, 64, 128, 14, 14)),
     ("stream", (2, 32, 64, 28, 28)), ("stream", (2, 128, 256, 14, 14)), ("stream", (3, 256, 256, 9, 7)),
     ("chunk", (5, 512, 512, 7, 7)), ("chunk", (40, 256, 512, 14, 14)), ("chunk", (3, 512, 1024, 7, 7)),
-    ("tile", (3, 1024, 1024, 7, 7)), ("tile", (3, 256, 512, 5, 6)), ("tile", (5, 512, 1024, 7, 7)),
-    ("wreg", (3, 1024, 1024, 7, 7)), ("wreg", (3, 256, 512, 5, 6)), ("wreg", (5, 512, 1024, 7, 7)),
-    ("wreg", (9, 512, 512, 14, 14)), ("wreg", (2, 1024, 256, 14, 14)), ("wreg", (1, 256, 1024, 3, 3))]
+    ("tile", (3, 1024, 1024, 7, 7)), ("tile", (3, 256, 512, 5, 6)), ("tile", (5, 512, 1024, 7, 7))]
 
 
 @pytest.mark.parametrize("form,case", FORM_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in FORM_CASES])
 @pytest.mark.parametrize("mode", ["online_u8_bn_relu", "offline_s8_channel_w4", "dense_quirk_bias"])
 def test_pwconv_i8_every_form_vs_oracle(dev, ops, form, case, mode):
     _pwconv_case(dev, ops, case, mode, form=form)
-
-
-WREG_VARIANTS = [  # (K, Cout, FQ_PWR_CW, FQ_PWR_NW): every instantiation of the register-stationary kernel
-    (256, 512, 4, 4), (256, 1024, 4, 8), (512, 512, 2, 4), (512, 512, 2, 8), (512, 512, 4, 4), (1024, 256, 1, 4),
-    (1024, 256, 1, 8), (1024, 256, 2, 4)]
-
-
-@pytest.mark.parametrize("k,cout,cw,nw", WREG_VARIANTS, ids=["K%d_C%d_cw%d_nw%d" % v for v in WREG_VARIANTS])
-def test_pwconv_i8_wreg_instantiations_vs_oracle(dev, ops, monkeypatch, k, cout, cw, nw):
-    monkeypatch.setenv("FQ_PWR_CW", str(cw))
-    monkeypatch.setenv("FQ_PWR_NW", str(nw))
-    monkeypatch.setenv("FQ_PWR_MIN_TILES", "1")
-    _pwconv_case(dev, ops, (7, k, cout, 7, 7), "online_u8_bn_relu", form="wreg")      # 343 columns: ragged last tile
-    monkeypatch.setenv("FQ_PWR_MIN_TILES", "4")
-    _pwconv_case(dev, ops, (3, k, cout, 14, 14), "offline_s8_channel_w4", form="wreg")
 
 
 def _pwconv_case(dev, ops, case, mode, form=None):

@@ -16,19 +16,15 @@ from quantization.mxnet_amd._lib import FakeQuantError  # noqa: E402
 MOBILENET = [(256, 512, 14), (512, 512, 14), (512, 1024, 7), (1024, 1024, 7)]
 RESNET = [(256, 1024, 14), (1024, 256, 14), (1024, 512, 14), (512, 2048, 7), (256, 64, 56), (64, 256, 56), (512, 128, 28),
           (128, 512, 28), (2048, 512, 7)]
-VARIANTS = [("auto", None, {}), ("chunk", "chunk", {}), ("tile", "tile", {}),
-            ("wreg default", "wreg", {}),
-            ("wreg nw8", "wreg", {"FQ_PWR_NW": "8"}),
-            ("wreg cw2x nw4", "wreg", {"FQ_PWR_CW": "x2"}),
-            ("wreg 2wg/cu", "wreg", {"FQ_PWR_WG_PER_CU": "2"}),
-            ("wreg min_tiles 1", "wreg", {"FQ_PWR_MIN_TILES": "1"}),
-            ("wreg min_tiles 4", "wreg", {"FQ_PWR_MIN_TILES": "4"})]
+VARIANTS = [("auto", None, {}), ("chunk", "chunk", {}), ("tile", "tile", {}), ("stream", "stream", {}),
+            ("panel", "panel", {}), ("two_kernels", "two_kernels", {})]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", default="mobilenet")
     ap.add_argument("--iters", type=int, default=15)
+    ap.add_argument("--hot", action="store_true", help="no cache flush between calls")
     args = ap.parse_args()
     layers = {"mobilenet": MOBILENET, "resnet": RESNET, "all": MOBILENET + RESNET}[args.layers]
     dev = torch.device("cuda", 0)
@@ -47,11 +43,6 @@ def main():
         ref = None
         print("%4d->%4d @%dx%d  %.1f MB algorithmic" % (cin, cout, hw, hw, nbytes / 1e6))
         for name, form, env in VARIANTS:
-            env = dict(env)
-            if env.get("FQ_PWR_CW") == "x2":
-                env["FQ_PWR_CW"] = str(2 * max(1, 32 // (cin // 32)))
-            for k in ("FQ_PWR_CW", "FQ_PWR_NW", "FQ_PWR_WG_PER_CU", "FQ_PWR_MIN_TILES"):
-                os.environ.pop(k, None)
             os.environ.update(env)
 
             def run():
@@ -67,7 +58,8 @@ def main():
             same = torch.equal(y, ref[0]) and torch.equal(st, ref[1])
             ts = []
             for _ in range(args.iters):
-                flush.fill_(1.0)
+                if not args.hot:
+                    flush.fill_(1.0)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 run()
@@ -78,8 +70,6 @@ def main():
             med = ts[len(ts) // 2]
             print("    %-20s %8.1f us  %7.1f GB/s  %.3f of 8 TB/s   identical=%s" % (name, med * 1e3, nbytes / med / 1e6,
                                                                                     nbytes / med / 1e6 / 8000.0, same))
-        for k in ("FQ_PWR_CW", "FQ_PWR_NW", "FQ_PWR_WG_PER_CU", "FQ_PWR_MIN_TILES"):
-            os.environ.pop(k, None)
 
 
 if __name__ == "__main__":
