@@ -137,6 +137,12 @@ int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t in
 int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                    const float* shift, int act, float* stat_out, fqStream_t stream);
 
+/* The residual tail of a ResNet unit — `(x + residual).relu()` in the gluon model zoo's BasicBlockV1 / BottleneckV1, two
+ * more elementwise passes followed by one statistic pass per quantised consumer — in one pass: y = act(a + b) over
+ * (n, inner) with stat_out[n] (may be NULL) <- max|y[n]|.  act / FQ_STAT_PREZEROED as in fq_bn_act_stat.  12 B/elem.     */
+int fq_add_act_stat(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
+                    fqStream_t stream);
+
 /* Global average pooling (gluon GlobalAvgPool2D -> F.Pooling(global_pool=True, pool_type='avg'), the block in front of
  * the classifier of every model of the zoo) with the per-sample statistic the following quantised Dense needs
  * (convert_dense.py:40-41): x (n, c, hw) -> y (n, c) = fp32(sum over hw accumulated in fp64, in order) / fp32(hw);

@@ -295,6 +295,18 @@ int fq_bn_act_stat_host(const float* x, float* y, int64_t n, int64_t c, int64_t 
   return FQ_OK;
 }
 
+int fq_add_act_stat_host(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
+                         fqStream_t) {
+  REQUIRE(a && b && y && n > 0 && inner > 0, "fq_add_act_stat_host: bad arguments");
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  zero_stat(stat_out, n, prezeroed);
+#pragma omp parallel for schedule(static) num_threads(team(n * inner))
+  for (int64_t i = 0; i < n * inner; ++i) y[i] = act_of(a[i] + b[i], act);
+  stat_of_output(y, n, inner, stat_out);
+  return FQ_OK;
+}
+
 int fq_global_avg_pool_stat_host(const float* x, float* y, int64_t n, int64_t c, int64_t hw, int flags,
                                  float* stat_out, fqStream_t) {
   REQUIRE(x && y && n > 0 && c > 0 && hw > 0, "fq_global_avg_pool_stat_host: bad arguments");

@@ -157,6 +157,15 @@ def bn_act(x, scale, shift, act="relu", want_stat=False):
     return (y, stat) if want_stat else y
 
 
+def add_act(a, b, act="relu", want_stat=False):
+    a, b = _f32(a), _f32(b)
+    n = a.shape[0]
+    y = np.empty_like(a)
+    stat = np.zeros(n, F32) if want_stat else None
+    _call("fq_add_act_stat_host", a, b, y, n, a.size // n, _i(_ACTS[act]), stat, None)
+    return (y, stat) if want_stat else y
+
+
 def global_avg_pool(x, want_stat=False):
     x = _f32(x)
     n, c = x.shape[0], x.shape[1]

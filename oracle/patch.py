@@ -142,6 +142,19 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     return _t(y), stat
 
 
+def add_act_stat(a, b, act="relu", out=None, want_stat=True):
+    y = (_np(a).astype(F32) + _np(b).astype(F32)).astype(F32)
+    if act == "relu":
+        y = np.maximum(y, F32(0))
+    elif act == "relu6":
+        y = np.minimum(np.maximum(y, F32(0)), F32(6))
+    yt = _t(y)
+    if out is not None:
+        out.copy_(yt)
+        yt = out
+    return yt, (_t(_stat(yt, False)) if want_stat else None)
+
+
 def global_avg_pool_stat(x, want_stat=True):
     y = O.global_avg_pool(_np(x))
     stat = _t(np.abs(y).reshape(y.shape[0], -1).max(axis=1).astype(F32)) if want_stat else None
@@ -325,7 +338,7 @@ def default_device(what="this call"):
     return torch.device("cpu")
 
 
-_REPLACED = ["require_hip", "default_device", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
+_REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
              "bn_act_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]

@@ -263,6 +263,76 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K2m: residual tail of a ResNet unit, `(x + residual).relu()` (gluon model zoo), with the per-sample statistic of the
+// result for the quantised convolutions that consume it: y = act(a + b), stat_out[n] = max|y[n]|.  12 B/elem (two reads,
+// one write) instead of add (12) + relu (8) + one statistic pass per consumer (4 each).  Flat streaming kernel over
+// (n, inner) with the chunking of K1 / K2.
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT, bool STATS, bool VEC, int U>
+__global__ __launch_bounds__(kBlock) void add_act_stat_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ y, int64_t inner,
+                                                              int chunks_per_sample, int64_t total_chunks,
+                                                              float* __restrict__ stat_out) {
+  constexpr int kCh = kBlock * kVec * U;
+  __shared__ float red[4];
+  const ChunkRange rg = block_range(total_chunks);
+  int64_t cur_s = -1;
+  float m = 0.0f;
+  auto one = [&](float p, float r) __attribute__((always_inline)) {
+    float v = p + r;
+    if (ACT == FQ_ACT_RELU) v = fmaxf(v, 0.0f);
+    if (ACT == FQ_ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+    return v;
+  };
+  for (int64_t c = rg.begin; c < rg.end; ++c) {
+    const int64_t s = c / chunks_per_sample;
+    if (STATS && s != cur_s) {
+      if (cur_s >= 0) {
+        m = block_max(m, red);
+        if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+      }
+      cur_s = s;
+      m = 0.0f;
+    }
+    const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kCh;
+    const int64_t gbase = s * inner + off0;
+    const int64_t rem = inner - off0;
+    if (VEC && rem >= kCh) {
+      const f4* pa = reinterpret_cast<const f4*>(a + gbase);
+      const f4* pb = reinterpret_cast<const f4*>(b + gbase);
+      f4* o = reinterpret_cast<f4*>(y + gbase);
+      f4 va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        va[u] = pa[threadIdx.x + u * kBlock];
+        vb[u] = pb[threadIdx.x + u * kBlock];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        f4 q;
+        q.x = one(va[u].x, vb[u].x);
+        q.y = one(va[u].y, vb[u].y);
+        q.z = one(va[u].z, vb[u].z);
+        q.w = one(va[u].w, vb[u].w);
+        if (STATS) m = fmaxf(m, stat4<true>(q));
+        o[threadIdx.x + u * kBlock] = q;
+      }
+    } else {
+      const int cnt = (int)(rem < kCh ? rem : kCh);
+      for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        const float q = one(a[gbase + i], b[gbase + i]);
+        if (STATS) m = fmaxf(m, fabsf(q));
+        y[gbase + i] = q;
+      }
+    }
+  }
+  if (STATS && cur_s >= 0) {
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K11: global average pooling (gluon GlobalAvgPool2D = F.Pooling(global_pool=True, pool_type='avg')) with the per-sample
 // max|y| the following Dense layer's input quantiser needs (convert_dense.py:40-41) - one launch instead of the library
 // reduction + memset + statistic pass.  y[n][c] = fp32(sum over the plane in fp64, in order) / fp32(hw): deterministic,
@@ -592,6 +662,47 @@ int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, c
 #undef FQ_BN_V
 #undef FQ_BN_U
 #undef FQ_BN
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+int fq_add_act_stat(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
+                    fqStream_t stream) {
+  FQ_REQUIRE(a && b && y, "fq_add_act_stat: null pointer");
+  FQ_REQUIRE(n > 0 && inner > 0 && n < (1ll << 31), "fq_add_act_stat: bad shape (n=%lld inner=%lld)", (long long)n,
+             (long long)inner);
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_add_act_stat: unknown activation %d", act);
+  hipStream_t st = (hipStream_t)stream;
+  if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  const bool small = use_small_chunks(n, inner);
+  const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
+  const bool vec = (inner % kVec == 0) && aligned16(a) && aligned16(b) && aligned16(y);
+  const int grid = grid_for(ck.total);
+  ProfScope prof(FQ_KERNEL_BN_ACT, 12.0 * (double)n * (double)inner, st);
+#define FQ_ADD(A, S, V, UU)                                                                                       \
+  hipLaunchKernelGGL((add_act_stat_kernel<A, S, V, UU>), dim3(grid), dim3(kBlock), 0, st, a, b, y, inner,         \
+                     ck.chunks_per_sample, ck.total, stat_out)
+#define FQ_ADD_U(A, S, V)                                                 \
+  do {                                                                    \
+    if (small) FQ_ADD(A, S, V, kSmallUnroll); else FQ_ADD(A, S, V, kUnroll); \
+  } while (0)
+#define FQ_ADD_V(A, S)                                    \
+  do {                                                    \
+    if (vec) FQ_ADD_U(A, S, true); else FQ_ADD_U(A, S, false); \
+  } while (0)
+#define FQ_ADD_S(A)                                          \
+  do {                                                       \
+    if (stat_out) FQ_ADD_V(A, true); else FQ_ADD_V(A, false); \
+  } while (0)
+  if (act == FQ_ACT_RELU) FQ_ADD_S(FQ_ACT_RELU);
+  else if (act == FQ_ACT_RELU6) FQ_ADD_S(FQ_ACT_RELU6);
+  else FQ_ADD_S(FQ_ACT_NONE);
+#undef FQ_ADD_S
+#undef FQ_ADD_V
+#undef FQ_ADD_U
+#undef FQ_ADD
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

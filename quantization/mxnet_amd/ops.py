@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["add_act_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -307,6 +307,20 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     stat, zflag = _stat_target(n, x.device, want_stat)
     check_call(_lib_().fq_bn_act_stat(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,
                                       _ptr(stat), _stream(x)))
+    return y, stat
+
+
+def add_act_stat(a, b, act="relu", out=None, want_stat=True):
+    """`(a + b).relu()` — the residual tail of the model zoo's ResNet units — with the per-sample max|y| of the result for
+    the quantised consumers (fq_add_act_stat).  Returns (y, stat or None)."""
+    _check(a, "a")
+    _check(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("shape mismatch: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    n, inner = _n_inner(a)
+    y = torch.empty_like(a) if out is None else _check(out, "out")
+    stat, zflag = _stat_target(n, a.device, want_stat)
+    check_call(_lib_().fq_add_act_stat(_ptr(a), _ptr(b), _ptr(y), n, inner, _ACTS[act] | zflag, _ptr(stat), _stream(a)))
     return y, stat
 
 

@@ -136,6 +136,32 @@ def _plain_dw_forward(self, F, x, weight, bias=None):
     return depthwise_fused(self, x, weight, bias, {})
 
 
+def _residual_unit_forward(self, x):
+    """`(body(x) + shortcut(x)).relu()` of the model zoo's ResNet units with the add, the ReLU and the per-sample
+    statistic of the result in ONE pass (fq_add_act_stat) — both quantised consumers of the sum (the next unit's first
+    convolution and, at a stage boundary, its shortcut convolution) then skip their statistic pass."""
+    from ..mx import autograd
+    if autograd.is_recording():
+        raise RuntimeError("this net was rewired by quantize.fuse.fuse_inference (inference only): call "
+                           "quantize.fuse.unfuse(net) before recording gradients")
+    shortcut = x if self.downsample is None else self.downsample(x)
+    h = self.body(x)
+    a = h._t if h._t.is_contiguous() else h._t.contiguous()
+    b = shortcut._t if shortcut._t.is_contiguous() else shortcut._t.contiguous()
+    y, stat = ops.add_act_stat(a, b, "relu", want_stat=True)
+    out = NDArray(y)
+    out._fq_stat = stat
+    return out
+
+
+def _is_residual_unit(b):
+    """a block whose forward IS the zoo's `(x + residual).relu()` (BasicBlockV1 / BottleneckV1 and subclasses)"""
+    from ..mx.gluon import model_zoo as zoo
+    fwd = getattr(type(b), "forward", None)
+    return fwd in (zoo.BasicBlockV1.forward, zoo.BottleneckV1.forward) and hasattr(b, "body") \
+        and "forward" not in b.__dict__
+
+
 def _bn_constants_getter(bn):
     cache = {"key": None, "val": None}
 
@@ -149,7 +175,7 @@ def _bn_constants_getter(bn):
     return get
 
 
-def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True):
+def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual=True):
     """Returns the number of blocks fused (BatchNorms folded + depthwise / pointwise convolutions taken over)."""
     fused = [0]
 
@@ -282,6 +308,12 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True):
     if isinstance(feats, (nn.Sequential, nn.HybridSequential)) and head is not None:
         after_features[id(feats)] = list(head._children.values()) \
             if isinstance(head, (nn.Sequential, nn.HybridSequential)) else [head]
+    def visit_residual(b):
+        if _is_residual_unit(b) and not hasattr(b, "_fq_residual_fused"):
+            b._fq_residual_fused = True
+            b.forward = types.MethodType(_residual_unit_forward, b)
+            fused[0] += 1
+
     if stem:
         net.apply(visit_stem)
     if depthwise:
@@ -290,6 +322,8 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True):
         net.apply(visit_pw)
     net.apply(visit_gap)
     net.apply(visit)
+    if residual:
+        net.apply(visit_residual)
     _install_stat_arena(net, fused[0])
     return fused[0]
 
@@ -337,6 +371,9 @@ def unfuse(net):
             del blk._fq_bypassed_orig
 
     def visit(b):
+        if hasattr(b, "_fq_residual_fused"):
+            del b.forward                                   # the class's own forward again
+            del b._fq_residual_fused
         if hasattr(b, "_fq_gap_fused"):
             st = b._fq_gap_fused
             b.hybrid_forward = st["orig"]

@@ -420,6 +420,27 @@ def test_dwconv3x3_vs_oracle(dev, ops, shape, stride, mode):
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
 
 
+# ---- residual tail: (a + b).relu() + statistic ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(4, 256, 56, 56), (3, 64, 7, 7), (2, 10, 5, 3), (5, 2048, 7, 7), (1, 16, 32, 32)])
+@pytest.mark.parametrize("act", ["relu", "relu6", "none"])
+def test_add_act_stat_vs_oracle(dev, ops, shape, act):
+    from oracle import host as H
+    rng = np.random.default_rng(sum(shape))
+    a = (rng.standard_normal(shape) * 3).astype(np.float32)
+    b = (rng.standard_normal(shape) * 3).astype(np.float32)
+    y, stat = ops.add_act_stat(T(a, dev), T(b, dev), act)
+    want, wstat = H.add_act(a, b, act, want_stat=True)
+    _eq(N(y), want, "a + b, activation")
+    _eq(N(stat), wstat, "statistic")
+    ref = a + b
+    ref = np.maximum(ref, 0) if act != "none" else ref
+    ref = np.minimum(ref, 6) if act == "relu6" else ref
+    _eq(want, ref.astype(np.float32), "host twin vs numpy")
+    y2, none = ops.add_act_stat(T(a, dev)[:, :, 1:].contiguous(), T(b, dev)[:, :, 1:].contiguous(), act, want_stat=False)
+    assert none is None
+    _eq(N(y2), want[:, :, 1:], "unaligned / no statistic")
+
+
 # ---- pointwise convolution on integer codes (int8 MFMA) ---------------------------------------------------------------
 PW_CASES = [  # (n, cin, cout, h, w)
     (2, 32, 64, 28, 28), (3, 64, 128, 14, 14), (2, 128, 128, 9, 12), (2, 128, 256, 14, 14), (5, 512, 512, 7, 7),

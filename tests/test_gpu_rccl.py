@@ -1,0 +1,62 @@
+"""The RCCL code path of dist.py executed on real hardware: two ranks that SHARE GPU 0 (the pool's boxes have a single
+device) over torch.distributed's "nccl" backend.  RCCL may refuse two ranks on one device ("Duplicate GPU detected"); the
+outcome is recorded either way in gpurun_out/rccl_smoke.txt, and the test is skipped — not passed — when it refuses."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_on_one_gpu_over_rccl(gpu, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker as W
+    from quantization.mxnet_amd import mx
+    local_bs, world = 3, 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "nccl_worker.py"), str(tmp_path), str(local_bs)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    log = os.path.join(ROOT, "gpurun_out", "rccl_smoke.txt")
+    os.makedirs(os.path.dirname(log), exist_ok=True)
+    with open(log, "w") as f:
+        f.write("command: %s\nreturn code: %d\n--- stderr (tail) ---\n%s\n" % (" ".join(cmd), res.returncode,
+                                                                             res.stderr[-4000:]))
+    if res.returncode != 0:
+        refused = any(k in res.stderr for k in ("Duplicate GPU", "duplicate GPU", "invalid usage", "ncclInvalidUsage"))
+        if refused:
+            pytest.skip("RCCL refuses two ranks on one device on this box (see gpurun_out/rccl_smoke.txt)")
+        raise AssertionError(res.stderr[-3000:])
+    r = [np.load(os.path.join(tmp_path, "rank%d.npz" % i)) for i in range(world)]
+    for k in ("strict", "step", "counters"):
+        np.testing.assert_array_equal(r[0][k], r[1][k], "ranks disagree on " + k)
+    np.testing.assert_array_equal(r[0]["counters"], [3.0, 20.0])
+    # strict mode == ONE device on the global batch, through the same kernels
+    net = W.make_net()
+    net.collect_params().reset_ctx(gpu)
+    net.quantize_input(enable=True, online=True)
+    blocks = net.collect_quantized_blocks()
+    ema = []
+    for shards in W.calib_steps("strict", local_bs, world):
+        net(mx.nd.array(np.concatenate(shards), ctx=gpu))
+        net.update_ema()
+        ema.append([float(b.input_max.data().asscalar()) for b in blocks])
+    np.testing.assert_array_equal(r[0]["strict"], np.asarray(ema, np.float32))
+    np.testing.assert_array_equal(r[0]["step"][:, 0], np.asarray(ema, np.float32)[:, 0])
+    with open(log, "a") as f:
+        f.write("RCCL path executed: strict and one-collective-per-step modes agree across ranks; strict equals one device\n")
