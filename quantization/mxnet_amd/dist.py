@@ -105,7 +105,7 @@ def _strict_attach(net, blocks, stats, device, max_local_batch):
         return _global_mean(per_sample, int(n_local), pack, gathered, out)
 
     for b in blocks:
-        b._fq_global_stat = _hook if W > 1 else None
+        b._fq_global_stat = _hook if (dist.is_available() and dist.is_initialized()) else None
         b._fq_keep_rows = False
     net._fq_calibration_sync = None          # current_input_max already is the global statistic when update_ema runs
 
@@ -134,7 +134,7 @@ class _StepCollective(object):
         n_local = 0 if self.skip else int(self.blocks[0]._fq_last_n)
         self.skip = False
         ops.stat_rows_sum(self.stats, n_local, out=self.record)
-        if world_size() > 1:
+        if dist.is_available() and dist.is_initialized():      # (also with one rank: the collective is still issued)
             dist.all_reduce(self.record, op=dist.ReduceOp.SUM)
         ops.mean_from_sums(self.record, out=self.means)
         arena.cur.index_copy_(0, self._slots(arena), self.means)

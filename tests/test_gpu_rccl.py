@@ -22,6 +22,37 @@ def _free_port():
     return p
 
 
+def _single_device_ema(gpu, local_bs, world, case="strict"):
+    import dist_worker as W
+    from quantization.mxnet_amd import mx
+    net = W.make_net()
+    net.collect_params().reset_ctx(gpu)
+    net.quantize_input(enable=True, online=True)
+    blocks = net.collect_quantized_blocks()
+    ema = []
+    for shards in W.calib_steps(case, local_bs, world):
+        net(mx.nd.array(np.concatenate(shards), ctx=gpu))
+        net.update_ema()
+        ema.append([float(b.input_max.data().asscalar()) for b in blocks])
+    return np.asarray(ema, np.float32)
+
+
+def test_collectives_execute_on_rccl_with_one_rank(gpu, tmp_path):
+    """World size 1 over the "nccl" backend: the all-gather (strict mode), the fp64 all-reduce (one collective per step) and
+    the counter all-reduce really go through RCCL on the device; with one rank both modes must equal the plain run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_worker.py"), str(tmp_path), "6"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r = np.load(os.path.join(tmp_path, "rank0.npz"))
+    want = _single_device_ema(gpu, 6, 1)
+    np.testing.assert_array_equal(r["strict"], want)
+    np.testing.assert_array_equal(r["step"], want)
+    np.testing.assert_array_equal(r["counters"], [1.0, 10.0])
+
+
 def test_two_ranks_on_one_gpu_over_rccl(gpu, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker as W

@@ -4,8 +4,7 @@ import sys,json
 try:
     d=json.loads(sys.stdin.read()); print('$*', d['value'], d['ms_per_step'], {k:(v['ms_per_step'],v['frac']) for k,v in d['roofline']['kernels'].items() if k in ('pwconv','dwconv','pool','stem')})
 except Exception as e: print('$*', 'failed', e)"; }
-L=quantization/mxnet_amd/csrc/build
-run FQ_PW_FORM=0
-run FQ_LIB_PATH=$L/lib_pwt2.so
-run FQ_PW_FORM=0
-run FQ_LIB_PATH=$L/lib_pwt2.so
+run FQ_X=0
+for v in 4 6 12 16; do run FQ_DW_WG_PER_CU=$v; done
+for v in 2 3 4; do run FQ_PWS_WG_PER_CU=$v; done
+run FQ_X=0
