@@ -312,6 +312,28 @@ __device__ __forceinline__ int pack4_codes(int k0, int k1, int k2, int k3, int u
   return (int)(u ^ 0x80808080u);
 }
 
+// Buffer addressing: address = (scalar 48-bit base in the resource) + (ONE 32-bit lane offset) + (scalar offset).  The
+// fused producers read 16-64 values per lane that differ only by a wave-uniform stride (channel planes): with flat
+// addressing hipcc carries a 64-bit VGPR pair and two VALU adds per access, with a buffer resource the stride lives in an
+// SGPR and all accesses of a lane share one offset register.  `bytes` (<= 4 GiB - 1) bounds the range: loads past it
+// return 0 and stores past it are dropped, so the resource is re-based per workgroup for tensors beyond 4 GiB.
+typedef __amdgpu_buffer_rsrc_t fq_rsrc;
+__device__ __forceinline__ fq_rsrc make_rsrc(const void* base, int64_t bytes) {
+  const unsigned nb = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)(bytes < 0 ? 0 : bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld_f32(fq_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ v4i buf_ld_v4i(fq_rsrc r, unsigned voff, unsigned soff) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(v4i, t);
+}
+__device__ __forceinline__ void buf_st_f32(fq_rsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
 template <bool USE_ABS>
 __device__ __forceinline__ float stat_of(float v) {
   return USE_ABS ? fabsf(v) : v;

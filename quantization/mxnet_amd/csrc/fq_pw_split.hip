@@ -1,0 +1,323 @@
+// libfakequant — K2m pointwise (1x1) convolution on int8 codes for the deep layers: one (pixel tile, channel group) per
+// workgroup (see fq_common.h for the list of translation units and the design rules)
+#include "fq_pw.h"
+
+namespace {
+
+// K2m: split form.  The deep layers (K = 256 ... 2048 on 14x14 / 7x7 planes) have FEW pixels (784 or 196 tiles of 32)
+// and big weight matrices; their tensors sit in the Infinity Cache, so what bounds them is how many independent
+// instruction streams the chip has to overlap loads, quantisation, matrix work and stores (profiles/r2_pw_experiments.txt:
+// one wavefront per SIMD issues an instruction every ~4 cycles and nothing overlaps).  This form cuts the work into
+// tiles x channel groups so that ~800-1600 workgroups (3-6 per CU, 3 wavefronts per SIMD) are resident at once:
+//   1. the four wavefronts of a workgroup each quantise a quarter of the tile's K/32 channel slabs (lane = pixel, as
+//      K2h/K2j; up to 64 dword loads per lane in flight before the first quantisation) into an LDS panel of B fragments;
+//      workgroups of different channel groups quantise the same tile redundantly (cheap: VALU is idle here, the tile
+//      comes from L2) instead of synchronising;
+//   2. every wavefront multiplies CW 32-channel tiles AT ONCE (CW independent accumulators share each B fragment read
+//      from the panel), A fragments straight from L2 out of the fragment-major copy of fq_weight_codes through a ring of
+//      D K-steps in flight (CW x D 16-byte loads per lane: K2j kept two, and waited on L2 in every step);
+//   3. store with lane = pixel (two full lines per store instruction), per-channel constants from LDS.
+// One barrier per workgroup.  Work item -> (tile, group) with the group fastest, so that a tile's workgroups run at the
+// same time on different XCDs (item i runs on XCD i % 8) and each XCD's L2 keeps only the groups it serves.
+struct PwSplitGeom {
+  int Cin, Cout, HW, CS;     // CS: channel groups (workgroups) per tile = Cout / (128 * CW)
+  int64_t cols, tiles, items;   // items = tiles * CS
+  int zoff;
+};
+
+// LB: wavefronts per SIMD the register allocation aims at (3: <= 168 registers, 4: <= 128) - with one tile per workgroup the
+// whole grid should be resident at once (a second round of a few left-over workgroups costs a whole workgroup latency)
+template <int KT, int CW, int D, int LB>
+__global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
+    const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
+    const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSplitGeom g,
+    const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
+    float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
+    float* __restrict__ stat_out) {
+  constexpr int kSlots = 8;
+  constexpr int SLABS = KT / 4;                                         // slabs each wavefront quantises
+  constexpr int RB = SLABS < 4 ? SLABS : 4;                             // slabs (16 loads each) in flight per lane
+  constexpr int NCH = 4 * CW * 32;                                      // output channels of one workgroup
+  constexpr int RS = D + 1;                                             // ring slots
+  extern __shared__ __attribute__((aligned(16))) unsigned char pwsp_smem[];
+  __shared__ unsigned k_stat[kSlots];
+  v4i* panel = reinterpret_cast<v4i*>(pwsp_smem);                       // [KT][64] B fragments of the tile
+  float* c_sxw = reinterpret_cast<float*>(pwsp_smem + (size_t)KT * 1024);
+  float* c_bsc = c_sxw + NCH;
+  float* c_bsh = c_bsc + NCH;
+  float* c_bias = c_bsh + NCH;
+  int* c_zs = reinterpret_cast<int*>(c_bias + NCH);
+
+  const int lane = threadIdx.x & 63;
+  // the wavefront index as a SCALAR, so that everything derived from it lives in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int h = lane >> 5, pl = lane & 31;
+  const unsigned HW = (unsigned)g.HW, cols = (unsigned)g.cols;
+  const unsigned plane4 = HW * 4u;                                      // bytes between two channels of one sample
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
+  // XCD-aware order: workgroup b runs on XCD b % 8 (each XCD has its own L2), and a 32-pixel tile of a 14x14 / 7x7 plane
+  // is 128 bytes that are NOT line-aligned, so neighbouring tiles share their first / last cache line of every channel:
+  // give every XCD a CONTIGUOUS range of (tile, group) items so that both halves of such a line meet in one L2
+  unsigned item;
+  {
+    const unsigned per = ((unsigned)g.items + 7u) >> 3;
+    item = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || item >= (unsigned)g.items) return;
+  }
+  const unsigned tile = item / (unsigned)g.CS, cg = item - tile * (unsigned)g.CS;
+  const int ch0 = (int)cg * NCH;                                        // first output channel of this workgroup
+  const unsigned s_base = (tile * 32u) / HW;                            // first sample the tile touches
+  unsigned smp, p;
+  {
+    unsigned j = tile * 32u + (unsigned)pl;
+    j = j < cols ? j : cols - 1;                                        // lanes past the end copy the last pixel
+    smp = j / HW;
+    p = j - smp * HW;
+  }
+  // Buffer addressing (fq_common.h): resources based at the tile's first sample; a lane's 16 * SLABS loads share ONE
+  // offset register (its pixel, and the half of a slab it owns), the channel stride is a scalar offset.
+  const int64_t x_samp = (int64_t)g.Cin * HW * 4, y_samp = (int64_t)g.Cout * HW * 4;
+  const int64_t n_samp = (int64_t)(cols / HW);
+  const fq_rsrc xr = make_rsrc(reinterpret_cast<const char*>(x) + s_base * x_samp, (n_samp - s_base) * x_samp);
+  const unsigned xo = ((smp - s_base) * (unsigned)g.Cin + 16u * h) * plane4 + p * 4u;
+  auto issue = [&](int kt, float (&v)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = buf_ld_f32(xr, xo, (unsigned)(kt * 32 + i) * plane4);
+  };
+
+  PW_STAMP(0);
+#ifdef FQ_PW_TRACE
+  if (threadIdx.x == 0 && g_pw_trace != nullptr)
+    g_pw_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) |
+                                             (unsigned long long)__builtin_amdgcn_s_getreg(63492);
+#endif
+  float buf[RB][16];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) issue(wave + 4 * i, buf[i]);             // in flight during the set-up
+  FQ_PIN();
+  const float max_ = in_stat != nullptr ? batch_mean_dev(in_stat, n) : in_thr[0];
+  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  if (in_stat != nullptr && cur_max_out != nullptr && item == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+  const float sx = q.scale;
+  if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
+  for (int i = threadIdx.x; i < NCH; i += kBlock) {
+    const int ic = ch0 + i;                                             // < Cout: the host requires Cout % NCH == 0
+    c_sxw[i] = sx * wscale[ic];
+    c_zs[i] = g.zoff * wsum[ic];
+    c_bias[i] = bias != nullptr ? bias[ic] : 0.0f;
+    c_bsc[i] = has_bn ? bn_scale[ic] : 1.0f;
+    c_bsh[i] = has_bn ? bn_shift[ic] : 0.0f;
+  }
+  PW_STAMP(1);
+  auto quant_to_panel = [&](int kt, const float (&v)[16]) __attribute__((always_inline)) {
+    v4i f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      f[d] = pack4_codes(fq_code_int(v[4 * d + 0], q), fq_code_int(v[4 * d + 1], q), fq_code_int(v[4 * d + 2], q),
+                         fq_code_int(v[4 * d + 3], q), 128 - g.zoff);
+    asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));   // pin the arithmetic here (see K2h)
+    panel[(kt << 6) + lane] = f;
+  };
+  // ---- 1. my quarter of the slabs -> LDS panel ------------------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < SLABS; ++j) {
+    quant_to_panel(wave + 4 * j, buf[j % RB]);
+    FQ_PIN();
+    if (j + RB < SLABS) {
+      issue(wave + 4 * (j + RB), buf[j % RB]);
+      FQ_PIN();
+    }
+  }
+  // ---- 2. CW channel tiles at once; the first D K-steps of A fragments are requested before the barrier ---------------
+  // A fragment (channel tile ct, slab kt) = 1 KB at wfrag + (ct * KT + kt) * 1024
+  const int ctl0 = wave * CW;                                           // first channel tile inside the workgroup
+  const fq_rsrc wr = make_rsrc(wfrag + (((int64_t)((int)cg * 4 * CW + ctl0) * KT) << 10), (int64_t)CW * KT * 1024);
+  const unsigned loff = (unsigned)lane * 16u;
+  auto a_frag = [&](int c, int kt) __attribute__((always_inline)) {
+    return buf_ld_v4i(wr, loff, (unsigned)((c * KT + kt) << 10));
+  };
+  v4i ring[RS][CW];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) ring[d][c] = a_frag(c, d < KT ? d : KT - 1);
+  }
+  FQ_PIN();
+  PW_STAMP(2);
+  __syncthreads();                                                      // panel, constants and the statistic table
+  PW_STAMP(3);
+  auto run = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+    constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
+    // accumulators start at zero (the first MFMA takes the constant): initialising them with the +128 re-centring terms
+    // keeps a second set of 16 * CW registers alive next to the destination of the first MFMAs; the terms are added as
+    // integers in the epilogue instead (one VALU per output)
+    v16i acc[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][i] = 0;
+    constexpr int BA = LB >= 4 ? 1 : 2;                          // B fragments read ahead (LDS latency vs registers)
+    v4i bq[BA + 1];
+#pragma unroll
+    for (int d = 0; d < BA; ++d) bq[d] = panel[(d << 6) + lane];
+    FQ_PIN();
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt + D < KT) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) ring[(kt + D) % RS][c] = a_frag(c, kt + D);
+      }
+      if (kt + BA < KT) bq[(kt + BA) % (BA + 1)] = panel[((kt + BA) << 6) + lane];
+#pragma unroll
+      for (int c = 0; c < CW; ++c)
+        acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[kt % RS][c], bq[kt % (BA + 1)], acc[c], 0, 0, 0);
+      FQ_PIN();                                  // keep the ring as written (else every load is hoisted to the top)
+    }
+    PW_STAMP(4);
+    // ---- 3. epilogue: lane = pixel, two full lines per store instruction -------------------------------------------------
+    const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp + (int64_t)(ch0 + ctl0 * 32) * plane4,
+                                 (n_samp - s_base) * y_samp - (int64_t)(ch0 + ctl0 * 32) * plane4);
+    const unsigned yo = ((smp - s_base) * (unsigned)g.Cout + 4u * h) * plane4 + p * 4u;
+    float m = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      FQ_PIN();                                  // constants of one channel tile at a time (else all are read up front)
+      const int cb = (ctl0 + c) * 32 + 4 * h;                           // channel inside the workgroup's group
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int c0 = cb + 8 * gq;
+        const v4i zs = *reinterpret_cast<const v4i*>(c_zs + c0);
+        const f4 sxw = *reinterpret_cast<const f4*>(c_sxw + c0);
+        const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
+        const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
+        f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
+        if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = (float)(acc[c][4 * gq + r] + zs[r]) * sxw[r];
+          if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) v = v + bch[r];
+          if (BN_M == 1 || (BN_M < 0 && has_bn)) {
+            v = v * bsc[r];
+            v = v + bsh[r];
+          }
+          v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
+          buf_st_f32(yr, yo, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
+          m = fmaxf(m, fabsf(v));
+        }
+      }
+    }
+    if (has_stat) {
+      const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)smp);
+      if (__all(smp == s0)) {
+        const float wm = wave_max(m);
+        if (lane == 0) {
+          const unsigned slot = s0 - s_base;
+          if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+          else atomic_max_f32(stat_out + s0, wm);
+        }
+      } else {
+        const unsigned slot = smp - s_base;
+        if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+        else atomic_max_f32(stat_out + smp, m);
+      }
+    }
+  };
+  using std::integral_constant;
+  if (bias == nullptr && has_bn && act == FQ_ACT_RELU)
+    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
+  else if (bias == nullptr && has_bn && act == FQ_ACT_RELU6)
+    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{});
+  else if (bias == nullptr && has_bn && act == FQ_ACT_NONE)
+    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{});
+  else
+    run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});
+  if (has_stat) {
+    __syncthreads();
+    if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < cols / HW)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+  }
+  PW_STAMP(5);
+}
+
+}  // namespace
+
+namespace fqi {
+
+// split form (K2m): grid = tiles x channel groups.  Shapes: K = 256 / 512 / 1024 / 2048 without padding, Cout a multiple
+// of 128 (one channel tile per wavefront), 256 (two) or 512 (four).
+// Measured against the other forms on every MobileNet / ResNet-50 shape it accepts (tools/pwforms.py, tools/kprof.sh;
+// profiles/r2_pw_split.txt): faster everywhere except on the largest planes (128 -> 128 @56x56: 12544 tiles), where the
+// streaming form's persistent wavefronts win by a few per cent.
+static bool pw_split_pays(const PwCall& a) {
+  static const int mode = env_int("FQ_PWS_AUTO", 1);                    // tuning: 0 never, 1 by shape, 2 always
+  return mode == 2 || (mode == 1 && (a.n * a.hw + 31) / 32 <= (int64_t)num_cu() * 16);
+}
+
+// split form (K2m): grid = tiles x channel groups.  Shapes: K = 256 / 512 / 1024 / 2048 without padding, Cout a multiple
+// of 128 (one channel tile per wavefront), 256 (two) or 512 (four).
+static bool pw_split_pays(const PwCall& a) {
+  static const int on = env_int("FQ_PWS_AUTO", 0);
+  return on == 2 || (on == 1 && (a.n * a.hw + 31) / 32 < (int64_t)num_cu() * 4);
+}
+
+// split form (K2m): grid = tiles x channel groups.  Shapes: K = 256 / 512 / 1024 / 2048 without padding, Cout a multiple
+// of 128 (one channel tile per wavefront), 256 (two) or 512 (four).
+int pw_try_split(const PwCall& a, bool* taken) {
+  *taken = false;
+  const int kt = (int)((a.cin + 31) / 32);
+  const int64_t tiles = (a.n * a.hw + 31) / 32;
+  const bool shape_ok = a.cin % 32 == 0 && a.cin_pad == a.cin && a.cout % 128 == 0 &&
+                        (kt == 4 || kt == 8 || kt == 16 || kt == 32 || kt == 64);
+  bool want = a.form == 6;
+  if (a.form == 0 && shape_ok) want = pw_split_pays(a);
+  if (want && shape_ok) {
+    // channel tiles per wavefront (cw) and wavefronts per SIMD (lb): the grid = tiles * Cout / (128 * cw) workgroups should
+    // fit the chip in ONE round (lb workgroups per CU) and fill it
+    // (measured in the model: two channel tiles per wavefront at four wavefronts per SIMD is the best or within 3 % of it
+    // on every shape; four tiles only pay for K = 1024 on 7x7 planes)
+    int cw = a.cout % 256 == 0 ? 2 : 1;
+    int lb = 4;
+    const int tune = env_int("FQ_PWS_CFG", 0);                           // tuning: 10 * lb + cw, read per call
+    if (tune > 0 && a.cout % (128 * (tune % 10)) == 0) {
+      cw = tune % 10;
+      lb = tune / 10;
+    }
+    PwSplitGeom t;
+    t.Cin = (int)a.cin; t.Cout = (int)a.cout; t.HW = (int)a.hw; t.CS = (int)(a.cout / (128 * cw));
+    t.cols = a.n * a.hw; t.tiles = tiles; t.zoff = a.zoff;
+    t.items = tiles * t.CS;
+    const int64_t grid = (t.items + 7) / 8 * 8;                           // padded to whole rounds over the 8 XCDs
+    FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8: too many tiles for the split form");
+    const size_t ldst = (size_t)kt * 1024 + (size_t)(4 * cw * 32) * 5 * sizeof(float);
+    const int64_t rows_pad = (a.cout + 63) / 64 * 64;
+    const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;               // second half of fq_weight_codes' buffer
+    if (int rc = pw_zero_stat(a)) return rc;
+    bool launched = false;
+#define FQ_PWS_CASE(KT_, CW_, D_, LB_)                                                                                 \
+  if (kt == KT_ && cw == CW_ && lb == LB_) {                                                                           \
+    static const bool attr_ok =                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_split_kernel<KT_, CW_, D_, LB_>),                    \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;                      \
+    FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the split kernel");                       \
+    hipLaunchKernelGGL((pwconv_split_kernel<KT_, CW_, D_, LB_>), dim3((unsigned)grid), dim3(kBlock), ldst, a.st, a.x,  \
+                       wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels,   \
+                       a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out);                  \
+    launched = true;                                                                                                   \
+  }
+#define FQ_PWS_KT(KT_)                                                                                                 \
+  FQ_PWS_CASE(KT_, 1, (KT_ < 7 ? KT_ : 7), 3) FQ_PWS_CASE(KT_, 2, (KT_ < 5 ? KT_ : 5), 3) FQ_PWS_CASE(KT_, 4, 2, 3)               \
+  FQ_PWS_CASE(KT_, 1, (KT_ < 7 ? KT_ : 7), 4) FQ_PWS_CASE(KT_, 2, 3, 4) FQ_PWS_CASE(KT_, 4, 1, 4)
+    FQ_PWS_KT(4) FQ_PWS_KT(8) FQ_PWS_KT(16) FQ_PWS_KT(32) FQ_PWS_KT(64)
+#undef FQ_PWS_KT
+#undef FQ_PWS_CASE
+    FQ_REQUIRE(launched, "fq_pwconv_i8: no instantiation of the split form for K/32=%d, %d tiles per wavefront, %d "
+               "wavefronts per SIMD", kt, cw, lb);
+    FQ_LAUNCH_CHECK();
+    *taken = true;
+    return FQ_OK;
+  }
+  FQ_REQUIRE(a.form != 6, "fq_pwconv_i8: FQ_PW_FORM=6 but the shape does not fit the split kernel");
+  return FQ_OK;
+}
+
+}  // namespace fqi

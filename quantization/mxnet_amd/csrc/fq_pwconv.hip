@@ -53,10 +53,12 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
   c.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;      // unsigned codes are stored re-centred so they fit int8
   c.out_current_max = out_current_max; c.bn_scale = bn_scale; c.bn_shift = bn_shift; c.act = act;
   c.stat_out = stat_out; c.ws = ws; c.st = (hipStream_t)stream;
-  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 2 panel, 3 stream, 4 chunk, 5 tile
+  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 2 panel, 3 stream, 4 chunk, 5 tile, 6 split
   c.form = forced_form ? forced_form : pw_form;
   ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), c.st);
   bool taken = false;
+  if (int rc = pw_try_split(c, &taken)) return rc;
+  if (taken) return FQ_OK;
   if (int rc = pw_try_stream(c, &taken)) return rc;
   if (taken) return FQ_OK;
   if (int rc = pw_try_tile(c, &taken)) return rc;

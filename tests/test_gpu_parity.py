@@ -472,7 +472,12 @@ FORM_CASES = [
     ("panel", (2, 144, 24, 14, 14)), ("panel", (2, 96, 576, 6, 6)), ("panel", (3, 64, 128, 14, 14)),
     ("stream", (2, 32, 64, 28, 28)), ("stream", (2, 128, 256, 14, 14)), ("stream", (3, 256, 256, 9, 7)),
     ("chunk", (5, 512, 512, 7, 7)), ("chunk", (40, 256, 512, 14, 14)), ("chunk", (3, 512, 1024, 7, 7)),
-    ("tile", (3, 1024, 1024, 7, 7)), ("tile", (3, 256, 512, 5, 6)), ("tile", (5, 512, 1024, 7, 7))]
+    ("tile", (3, 1024, 1024, 7, 7)), ("tile", (3, 256, 512, 5, 6)), ("tile", (5, 512, 1024, 7, 7)),
+    # split: K/32 = 8 / 16 / 32 / 64; one, two and four channel tiles per wavefront (Cout 128 / 256 / 512+); a ragged last
+    # tile; tiles that span many samples (1x1 planes: more samples than statistic slots)
+    ("split", (3, 1024, 1024, 7, 7)), ("split", (3, 256, 512, 5, 6)), ("split", (5, 512, 1024, 7, 7)),
+    ("split", (2, 512, 512, 14, 14)), ("split", (2, 256, 128, 9, 7)), ("split", (2, 2048, 512, 7, 7)),
+    ("split", (2, 512, 256, 7, 7)), ("split", (70, 512, 512, 1, 1))]
 
 
 @pytest.mark.parametrize("form,case", FORM_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in FORM_CASES])

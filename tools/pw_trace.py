@@ -16,9 +16,7 @@ OUT = os.path.join(ROOT, "build_tools", "libfakequant_trace.so")
 
 def build():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = B.command(OUT)
-    cmd.insert(1, "-DFQ_PW_TRACE=1")
-    subprocess.check_call(cmd)
+    B.build_library(defines=["-DFQ_PW_TRACE=1"], out=OUT, amalgamate=True)
 
 
 def main():
@@ -34,6 +32,7 @@ def main():
     shapes = [tuple(args[:3])] if len(args) >= 3 else [(32, 64, 112), (128, 128, 56), (256, 256, 28), (512, 512, 14), (1024, 1024, 7)]
     dev = torch.device("cuda", 0)
     n = 128
+    form = sys.argv[sys.argv.index("--form") + 1] if "--form" in sys.argv else None
     for cin, cout, hw in shapes:
         torch.manual_seed(7)
         x = torch.relu(torch.randn(n, cin, hw, hw, device=dev))
@@ -45,7 +44,7 @@ def main():
         codes, scales, rowsum = ops.weight_codes(w, cout, 8)
         buf = torch.zeros(8 * 65536 * 4, dtype=torch.int64, device=dev)
         run = lambda: ops.pwconv_i8(x, codes, scales, rowsum, in_stat=stat, width=8, flags=0, cur_out=cur, bn_scale=sc,
-                                    bn_shift=sh, act="relu")
+                                    bn_shift=sh, act="relu", form=form)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -77,12 +76,16 @@ def main():
         print("%d->%d %dx%d: %d workgroups on %d distinct CUs; kernel span %.1f us" % (cin, cout, hw, hw, len(t),
               len(set(cuid.tolist())), st[:, 5].max()))
         names = ["start", "setup done", "phase1 issued", "phase1 barrier", "gemm(block0) done", "end"]
+        if form == "split":
+            names = ["start", "set-up done", "quantise done", "barrier passed", "multiply done", "end"]
         if "--chunk" in sys.argv:
             names = ["start", "batch mean done", "chunk0 in LDS", "Q phase done (batch 0)", "chunks done (batch 0)", "end"]
         for i, nm in enumerate(names):
             print("   %-18s min %7.2f  median %7.2f  max %7.2f us" % (nm, st[:, i].min(), np.median(st[:, i]), st[:, i].max()))
         d = np.diff(st, axis=1)
         dn = ["setup", "phase1 (load+quant+LDS)", "barrier wait", "gemm block0", "epilogue(+other blocks)"]
+        if form == "split":
+            dn = ["set-up (mean, constants)", "quantise -> panel", "barrier wait", "multiply", "epilogue + statistic"]
         if "--chunk" in sys.argv:
             dn = ["batch mean", "chunk 0 -> LDS", "Q phase", "chunk loop", "other batches + stat"]
         for i, nm in enumerate(dn):
