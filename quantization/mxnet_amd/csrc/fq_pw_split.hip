@@ -243,8 +243,6 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
 
 namespace fqi {
 
-// split form (K2m): grid = tiles x channel groups.  Shapes: K = 256 / 512 / 1024 / 2048 without padding, Cout a multiple
-// of 128 (one channel tile per wavefront), 256 (two) or 512 (four).
 // Measured against the other forms on every MobileNet / ResNet-50 shape it accepts (tools/pwforms.py, tools/kprof.sh;
 // profiles/r2_pw_split.txt): faster everywhere except on the largest planes (128 -> 128 @56x56: 12544 tiles), where the
 // streaming form's persistent wavefronts win by a few per cent.
@@ -253,14 +251,7 @@ static bool pw_split_pays(const PwCall& a) {
   return mode == 2 || (mode == 1 && (a.n * a.hw + 31) / 32 <= (int64_t)num_cu() * 16);
 }
 
-// split form (K2m): grid = tiles x channel groups.  Shapes: K = 256 / 512 / 1024 / 2048 without padding, Cout a multiple
-// of 128 (one channel tile per wavefront), 256 (two) or 512 (four).
-static bool pw_split_pays(const PwCall& a) {
-  static const int on = env_int("FQ_PWS_AUTO", 0);
-  return on == 2 || (on == 1 && (a.n * a.hw + 31) / 32 < (int64_t)num_cu() * 4);
-}
-
-// split form (K2m): grid = tiles x channel groups.  Shapes: K = 256 / 512 / 1024 / 2048 without padding, Cout a multiple
+// split form (K2m): grid = tiles x channel groups.  Shapes: K = 128 / 256 / 512 / 1024 / 2048 without padding, Cout a multiple
 // of 128 (one channel tile per wavefront), 256 (two) or 512 (four).
 int pw_try_split(const PwCall& a, bool* taken) {
   *taken = false;
