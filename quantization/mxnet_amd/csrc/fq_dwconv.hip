@@ -4,6 +4,14 @@
 
 namespace {
 
+// Experiment hook: cap the scalar registers of the depthwise kernels (-DFQ_DW_SGPR=80).  A 256-thread workgroup is admitted
+// 8 per CU only with <= 80 SGPRs (MI355X_MICROARCH.md, residency); hipcc uses up to 106 when not told otherwise.
+#ifdef FQ_DW_SGPR
+#define FQ_DW_ATTR __attribute__((amdgpu_num_sgpr(FQ_DW_SGPR)))
+#else
+#define FQ_DW_ATTR
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // K2c: depthwise 3x3 (pad 1, stride S) with quantise-on-load and BN / activation / statistic epilogue.
 // A workgroup step ("tile") is P whole planes (small planes) or a strip of output rows of one plane (large planes).
@@ -25,7 +33,7 @@ struct DwGeom {
 };
 
 template <int S, bool QUANT, bool ONLINE>
-__global__ __launch_bounds__(kBlock) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+__global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                            const float* __restrict__ bias, float* __restrict__ y,
                                                            DwGeom g, int64_t tiles, const float* __restrict__ in_stat,
                                                            int n, const float* __restrict__ in_thr, float levels,
@@ -198,7 +206,7 @@ struct DwColGeom {
 };
 
 template <int S, bool QUANT, bool ONLINE>
-__global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
+__global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
     const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
     float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
     const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out,
@@ -210,14 +218,21 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
   __shared__ unsigned k_stat[kStatSlots];
   if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
   PW_STAMP(0);
+  // The quantisation parameters are derived AFTER the first block's loads have been issued (ensure_q below): the batch
+  // statistic is a dependent chain of two cold loads + an fp64 tree (~2.8 us per workgroup, tools/dw_trace.py) that
+  // otherwise sits in front of the first useful load of every workgroup.
   QParams q;
   q.lo = q.hi = q.denom = q.scale = 0.0f;
   q.rden = 0.0;
-  if (QUANT) {
-    const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
-    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
-    if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
-  }
+  bool q_ready = !QUANT;
+  auto ensure_q = [&]() __attribute__((always_inline)) {
+    if (QUANT && !q_ready) {
+      const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+      q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+      if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
+      q_ready = true;
+    }
+  };
   PW_STAMP(1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg_in_wave = lane / g.SEG;
@@ -315,6 +330,8 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
       for (int k = 0; k < D; ++k) raw[k] = ldrow(1 + k);
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
       float b1 = ldrow(0);
+      FQ_PIN();
+      ensure_q();
       if (QUANT) b1 = fq_code(b1, q) * q.scale;
       float b0 = __shfl_up(b1, 1, 64), b2 = __shfl_down(b1, 1, 64);
       const int rend = g.Ho;                              // same trip count for every lane of the grid
@@ -379,6 +396,8 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
         rc0[k] = ld_a(2 * k + 1);
         rc1[k] = ld_b(2 * k + 1);
       }
+      FQ_PIN();
+      ensure_q();
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
       const int rend = g.Ho;
       int r0 = 0;
@@ -433,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols_kernel(
 // (stride 1 only).  Halo lanes load and quantise like the others; their neighbours pick up .w / .x by shuffle.
 // ---------------------------------------------------------------------------------------------------------------
 template <int S, bool QUANT, bool ONLINE>
-__global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
+__global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
     const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
     float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
     const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out,
@@ -449,6 +468,8 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_cols4_kernel(
   constexpr int kStatSlots = 16;
   __shared__ unsigned k_stat[kStatSlots];
   if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
+  // (deriving q after the first block's loads, as K2d does, was measured 3-5 % SLOWER here: the row bursts of these large
+  // planes already hide the prologue, and the extra live state costs registers)
   QParams q;
   q.lo = q.hi = q.denom = q.scale = 0.0f;
   q.rden = 0.0;
@@ -701,8 +722,11 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     const int64_t segs_per_block = (int64_t)cg.segs * (kBlock / 64);
     const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
     FQ_REQUIRE(total_segs < (1ll << 31) - 1024, "fq_dwconv3x3: tensor too large for 32-bit segment indices");
-    // every workgroup resident at once (8 per CU), each walking a contiguous range of blocks
-    static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 8);
+    // every workgroup resident at once, each walking a contiguous range of blocks.  6 per CU: the kernels use ~100 scalar
+    // registers, and a CU admits 256-thread workgroups 8 at a time only up to 80 (MI355X_MICROARCH.md, residency) - with
+    // 8 per CU asked for, a quarter of the grid ran as a second, thin round (14x14 layers: 31.7 -> 28.0 us; capping the
+    // scalar registers with -DFQ_DW_SGPR=80 instead makes all 8 resident and is no faster)
+    static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 6);
     const int grid = (int)(nblk < (int64_t)num_cu() * dw_wg_per_cu ? nblk : (int64_t)num_cu() * dw_wg_per_cu);
     const float levels = act_levels(in_width, in_flags);
     const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
@@ -743,8 +767,11 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     const int64_t segs_per_block = (int64_t)cg.segs * (kBlock / 64);
     const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
     FQ_REQUIRE(total_segs < (1ll << 31) - 1024, "fq_dwconv3x3: tensor too large for 32-bit segment indices");
-    // every workgroup resident at once (8 per CU), each walking a contiguous range of blocks
-    static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 8);
+    // every workgroup resident at once, each walking a contiguous range of blocks.  6 per CU: the kernels use ~100 scalar
+    // registers, and a CU admits 256-thread workgroups 8 at a time only up to 80 (MI355X_MICROARCH.md, residency) - with
+    // 8 per CU asked for, a quarter of the grid ran as a second, thin round (14x14 layers: 31.7 -> 28.0 us; capping the
+    // scalar registers with -DFQ_DW_SGPR=80 instead makes all 8 resident and is no faster)
+    static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 6);
     const int grid = (int)(nblk < (int64_t)num_cu() * dw_wg_per_cu ? nblk : (int64_t)num_cu() * dw_wg_per_cu);
     const float levels = act_levels(in_width, in_flags);
     const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
