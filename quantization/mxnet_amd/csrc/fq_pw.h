@@ -31,6 +31,7 @@ struct PwCall {
 };
 
 int pw_try_stream(const PwCall& c, bool* taken);    // K2h  fq_pw_stream.hip
+bool pw_stream_shape_ok(const PwCall& c);           //      shapes the streaming form takes
 int pw_try_tile(const PwCall& c, bool* taken);      // K2j  fq_pw_tile.hip
 int pw_try_split(const PwCall& c, bool* taken);     // K2m  fq_pw_split.hip
 int pw_try_chunk(const PwCall& c, bool* taken);     // K2i  fq_pw_chunk.hip

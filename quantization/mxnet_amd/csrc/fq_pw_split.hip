@@ -20,7 +20,8 @@ namespace {
 // One barrier per workgroup.  Work item -> (tile, group) with the group fastest, so that a tile's workgroups run at the
 // same time on different XCDs (item i runs on XCD i % 8) and each XCD's L2 keeps only the groups it serves.
 struct PwSplitGeom {
-  int Cin, Cout, HW, CS;     // CS: channel groups (workgroups) per tile = Cout / (128 * CW)
+  int Cin, Cout, HW, CS;     // CS: channel groups (workgroups) per tile = ceil(Cout / (128 * CW))
+  int CTM;                   // 32-channel tiles present in the weight buffer (rows_pad / 32; rows >= Cout are zero)
   int64_t cols, tiles, items;   // items = tiles * CS
   int zoff;
 };
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
     float* __restrict__ stat_out) {
   constexpr int kSlots = 8;
-  constexpr int SLABS = KT / 4;                                         // slabs each wavefront quantises
+  constexpr int SLABS = (KT + 3) / 4;                                   // slabs a wavefront quantises (kt = wave + 4j < KT)
   constexpr int RB = SLABS < 4 ? SLABS : 4;                             // slabs (16 loads each) in flight per lane
   constexpr int NCH = 4 * CW * 32;                                      // output channels of one workgroup
   constexpr int RS = D + 1;                                             // ring slots
@@ -75,7 +76,9 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
     p = j - smp * HW;
   }
   // Buffer addressing (fq_common.h): resources based at the tile's first sample; a lane's 16 * SLABS loads share ONE
-  // offset register (its pixel, and the half of a slab it owns), the channel stride is a scalar offset.
+  // offset register (its pixel, and the half of a slab it owns), the channel stride is a scalar offset.  Channels of a
+  // padded slab (Cin % 32 != 0) read the next sample's values, or 0 past the end of the tensor: whatever code they get
+  // meets a zero weight code (fq_weight_codes pads K with zeros).
   const int64_t x_samp = (int64_t)g.Cin * HW * 4, y_samp = (int64_t)g.Cout * HW * 4;
   const int64_t n_samp = (int64_t)(cols / HW);
   const fq_rsrc xr = make_rsrc(reinterpret_cast<const char*>(x) + s_base * x_samp, (n_samp - s_base) * x_samp);
@@ -91,9 +94,13 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
     g_pw_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) |
                                              (unsigned long long)__builtin_amdgcn_s_getreg(63492);
 #endif
+  // (slabs that are padding altogether - cin_pad is a multiple of 64 - are neither loaded nor written to the panel: whatever
+  // bytes the panel holds there meet zero weight codes)
+  const int kt_real = (g.Cin + 31) >> 5;
   float buf[RB][16];
 #pragma unroll
-  for (int i = 0; i < RB; ++i) issue(wave + 4 * i, buf[i]);             // in flight during the set-up
+  for (int i = 0; i < RB; ++i)
+    if (wave + 4 * i < kt_real) issue(wave + 4 * i, buf[i]);            // in flight during the set-up
   FQ_PIN();
   const float max_ = in_stat != nullptr ? batch_mean_dev(in_stat, n) : in_thr[0];
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
@@ -101,12 +108,13 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
   const float sx = q.scale;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
   for (int i = threadIdx.x; i < NCH; i += kBlock) {
-    const int ic = ch0 + i;                                             // < Cout: the host requires Cout % NCH == 0
-    c_sxw[i] = sx * wscale[ic];
-    c_zs[i] = g.zoff * wsum[ic];
-    c_bias[i] = bias != nullptr ? bias[ic] : 0.0f;
-    c_bsc[i] = has_bn ? bn_scale[ic] : 1.0f;
-    c_bsh[i] = has_bn ? bn_shift[ic] : 0.0f;
+    const bool ok = ch0 + i < g.Cout;                                   // channels past Cout: all-zero constants
+    const int ic = ok ? ch0 + i : 0;
+    c_sxw[i] = ok ? sx * wscale[ic] : 0.0f;
+    c_zs[i] = ok ? g.zoff * wsum[ic] : 0;
+    c_bias[i] = ok && bias != nullptr ? bias[ic] : 0.0f;
+    c_bsc[i] = has_bn && ok ? bn_scale[ic] : (ok ? 1.0f : 0.0f);
+    c_bsh[i] = has_bn && ok ? bn_shift[ic] : 0.0f;
   }
   PW_STAMP(1);
   auto quant_to_panel = [&](int kt, const float (&v)[16]) __attribute__((always_inline)) {
@@ -121,17 +129,20 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
   // ---- 1. my quarter of the slabs -> LDS panel ------------------------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < SLABS; ++j) {
-    quant_to_panel(wave + 4 * j, buf[j % RB]);
+    if (wave + 4 * j < kt_real) quant_to_panel(wave + 4 * j, buf[j % RB]);
     FQ_PIN();
     if (j + RB < SLABS) {
-      issue(wave + 4 * (j + RB), buf[j % RB]);
+      if (wave + 4 * (j + RB) < kt_real) issue(wave + 4 * (j + RB), buf[j % RB]);
       FQ_PIN();
     }
   }
   // ---- 2. CW channel tiles at once; the first D K-steps of A fragments are requested before the barrier ---------------
   // A fragment (channel tile ct, slab kt) = 1 KB at wfrag + (ct * KT + kt) * 1024
+  // Channel tiles past the padded weight buffer read zeros through the bound of the resource; tiles past Cout are not stored.
   const int ctl0 = wave * CW;                                           // first channel tile inside the workgroup
-  const fq_rsrc wr = make_rsrc(wfrag + (((int64_t)((int)cg * 4 * CW + ctl0) * KT) << 10), (int64_t)CW * KT * 1024);
+  const int ctg0 = (int)cg * 4 * CW + ctl0;                             // ... and in the layer
+  const int ct_here = g.CTM - ctg0 < CW ? (g.CTM - ctg0 < 0 ? 0 : g.CTM - ctg0) : CW;
+  const fq_rsrc wr = make_rsrc(wfrag + (((int64_t)ctg0 * KT) << 10), (int64_t)ct_here * KT * 1024);
   const unsigned loff = (unsigned)lane * 16u;
   auto a_frag = [&](int c, int kt) __attribute__((always_inline)) {
     return buf_ld_v4i(wr, loff, (unsigned)((c * KT + kt) << 10));
@@ -146,6 +157,7 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
   PW_STAMP(2);
   __syncthreads();                                                      // panel, constants and the statistic table
   PW_STAMP(3);
+  const int cvalid = g.Cout - (ch0 + ctl0 * 32);                       // valid output channels from this wavefront's first tile on
   auto run = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
     // accumulators start at zero (the first MFMA takes the constant): initialising them with the +128 re-centring terms
@@ -175,13 +187,15 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
     }
     PW_STAMP(4);
     // ---- 3. epilogue: lane = pixel, two full lines per store instruction -------------------------------------------------
-    const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp + (int64_t)(ch0 + ctl0 * 32) * plane4,
-                                 (n_samp - s_base) * y_samp - (int64_t)(ch0 + ctl0 * 32) * plane4);
+    // The resource is bounded below 2 GiB, so a lane offset of 0x80000000 is out of range for it: that is how the channels
+    // past Cout of a PARTIAL channel tile are masked (the hardware drops the store; no branch, no exec juggling).
+    int64_t y_bytes = (n_samp - s_base) * y_samp - (int64_t)(ch0 + ctl0 * 32) * plane4;
+    y_bytes = y_bytes < 0x7FFFFFFFll ? y_bytes : 0x7FFFFFFFll;
+    const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp + (int64_t)(ch0 + ctl0 * 32) * plane4, y_bytes);
     const unsigned yo = ((smp - s_base) * (unsigned)g.Cout + 4u * h) * plane4 + p * 4u;
     float m = 0.0f;
-#pragma unroll
-    for (int c = 0; c < CW; ++c) {
-      FQ_PIN();                                  // constants of one channel tile at a time (else all are read up front)
+    auto store_tile = [&](int c, int cv, auto masked_c) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked_c)::value;
       const int cb = (ctl0 + c) * 32 + 4 * h;                           // channel inside the workgroup's group
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
@@ -201,10 +215,18 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
             v = v + bsh[r];
           }
           v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
-          buf_st_f32(yr, yo, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
-          m = fmaxf(m, fabsf(v));
+          const unsigned off = MASKED ? (8 * gq + 4 * h + r < cv ? yo : 0x80000000u) : yo;
+          buf_st_f32(yr, off, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
+          m = fmaxf(m, fabsf(v));                  // channels past Cout have all-zero constants: v == 0
         }
       }
+    };
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      FQ_PIN();                                  // constants of one channel tile at a time (else all are read up front)
+      const int cv = cvalid - c * 32;            // valid channels of this tile (wave-uniform)
+      if (cv >= 32) store_tile(c, cv, std::false_type{});
+      else if (cv > 0) store_tile(c, cv, std::true_type{});
     }
     if (has_stat) {
       const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)smp);
@@ -223,7 +245,9 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
     }
   };
   using std::integral_constant;
-  if (bias == nullptr && has_bn && act == FQ_ACT_RELU)
+  if (cvalid <= 0) {
+    // nothing to multiply (a channel group wider than the layer): this wavefront only helped to quantise the tile
+  } else if (bias == nullptr && has_bn && act == FQ_ACT_RELU)
     run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
   else if (bias == nullptr && has_bn && act == FQ_ACT_RELU6)
     run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{});
@@ -243,44 +267,46 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
 
 namespace fqi {
 
-// Measured against the other forms on every MobileNet / ResNet-50 shape it accepts (tools/pwforms.py, tools/kprof.sh;
-// profiles/r2_pw_split.txt): faster everywhere except on the largest planes (128 -> 128 @56x56: 12544 tiles), where the
-// streaming form's persistent wavefronts win by a few per cent.
-static bool pw_split_pays(const PwCall& a) {
-  static const int mode = env_int("FQ_PWS_AUTO", 1);                    // tuning: 0 never, 1 by shape, 2 always
-  return mode == 2 || (mode == 1 && (a.n * a.hw + 31) / 32 <= (int64_t)num_cu() * 16);
-}
-
-// split form (K2m): grid = tiles x channel groups.  Shapes: K = 128 / 256 / 512 / 1024 / 2048 without padding, Cout a multiple
-// of 128 (one channel tile per wavefront), 256 (two) or 512 (four).
+// split form (K2m): grid = tiles x channel groups.  Takes every Cout and every Cin whose padded row length (cin_pad, the
+// row stride fq_weight_codes was given) is one of the instantiated K/32 below: the MobileNet, MobileNetV2 and ResNet-50
+// channel counts.  Measured against the other forms on every such shape (tools/pwforms.py, tools/kprof.sh;
+// profiles/r2_pw_split.txt): faster everywhere except on the largest planes (> 4096 tiles of 32 pixels), where the streaming
+// form's persistent wavefronts with LDS-resident weights win by a few per cent - so with more tiles than that it only
+// takes what the streaming form cannot.
 int pw_try_split(const PwCall& a, bool* taken) {
   *taken = false;
-  const int kt = (int)((a.cin + 31) / 32);
+  const int kt = (int)(a.cin_pad / 32);
   const int64_t tiles = (a.n * a.hw + 31) / 32;
-  const bool shape_ok = a.cin % 32 == 0 && a.cin_pad == a.cin && a.cout % 128 == 0 &&
-                        (kt == 4 || kt == 8 || kt == 16 || kt == 32 || kt == 64);
+  const int64_t rows_pad = (a.cout + 63) / 64 * 64;
+  static const int kts[] = {2, 4, 6, 8, 10, 12, 16, 18, 30, 32, 64};
+  bool shape_ok = false;
+  for (int k : kts) shape_ok = shape_ok || k == kt;
+  // a tile's stores must stay below 2 GiB from its first sample (out-of-range lane offsets mask partial channel tiles)
+  shape_ok = shape_ok && (32 / a.hw + 2) * a.cout * a.hw * 4 < (1ll << 31) && a.cin * a.hw * 4 * (32 / a.hw + 2) < (1ll << 31);
+  static const int mode = env_int("FQ_PWS_AUTO", 1);                    // tuning: 0 never, 1 by shape, 2 always
   bool want = a.form == 6;
-  if (a.form == 0 && shape_ok) want = pw_split_pays(a);
+  if (a.form == 0 && shape_ok)
+    want = mode == 2 || (mode == 1 && (tiles <= (int64_t)num_cu() * 16 || !pw_stream_shape_ok(a)));
   if (want && shape_ok) {
-    // channel tiles per wavefront (cw) and wavefronts per SIMD (lb): the grid = tiles * Cout / (128 * cw) workgroups should
-    // fit the chip in ONE round (lb workgroups per CU) and fill it
-    // (measured in the model: two channel tiles per wavefront at four wavefronts per SIMD is the best or within 3 % of it
-    // on every shape; four tiles only pay for K = 1024 on 7x7 planes)
-    int cw = a.cout % 256 == 0 ? 2 : 1;
+    // channel tiles per wavefront (cw) and wavefronts per SIMD (lb).  Measured in the model: two tiles per wavefront at
+    // four wavefronts per SIMD is the best or within 3 % of it on every shape (the grid then fills the chip in one or two
+    // resident rounds); narrow layers take one tile per wavefront so that all four wavefronts have channels.
+    int cw = a.cout > 128 ? 2 : 1;
     int lb = 4;
     const int tune = env_int("FQ_PWS_CFG", 0);                           // tuning: 10 * lb + cw, read per call
-    if (tune > 0 && a.cout % (128 * (tune % 10)) == 0) {
+    if (tune > 0) {
       cw = tune % 10;
       lb = tune / 10;
     }
     PwSplitGeom t;
-    t.Cin = (int)a.cin; t.Cout = (int)a.cout; t.HW = (int)a.hw; t.CS = (int)(a.cout / (128 * cw));
+    t.Cin = (int)a.cin; t.Cout = (int)a.cout; t.HW = (int)a.hw;
+    t.CS = (int)((a.cout + 128 * cw - 1) / (128 * cw));
+    t.CTM = (int)(rows_pad / 32);
     t.cols = a.n * a.hw; t.tiles = tiles; t.zoff = a.zoff;
     t.items = tiles * t.CS;
     const int64_t grid = (t.items + 7) / 8 * 8;                           // padded to whole rounds over the 8 XCDs
     FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8: too many tiles for the split form");
     const size_t ldst = (size_t)kt * 1024 + (size_t)(4 * cw * 32) * 5 * sizeof(float);
-    const int64_t rows_pad = (a.cout + 63) / 64 * 64;
     const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;               // second half of fq_weight_codes' buffer
     if (int rc = pw_zero_stat(a)) return rc;
     bool launched = false;
@@ -295,11 +321,16 @@ int pw_try_split(const PwCall& a, bool* taken) {
                        a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out);                  \
     launched = true;                                                                                                   \
   }
-#define FQ_PWS_KT(KT_)                                                                                                 \
-  FQ_PWS_CASE(KT_, 1, (KT_ < 7 ? KT_ : 7), 3) FQ_PWS_CASE(KT_, 2, (KT_ < 5 ? KT_ : 5), 3) FQ_PWS_CASE(KT_, 4, 2, 3)               \
-  FQ_PWS_CASE(KT_, 1, (KT_ < 7 ? KT_ : 7), 4) FQ_PWS_CASE(KT_, 2, 3, 4) FQ_PWS_CASE(KT_, 4, 1, 4)
-    FQ_PWS_KT(4) FQ_PWS_KT(8) FQ_PWS_KT(16) FQ_PWS_KT(32) FQ_PWS_KT(64)
+    // every K: the two default configurations; the power-of-two K of the deep MobileNet / ResNet layers also carry the
+    // alternatives that tools/pwforms.py and FQ_PWS_CFG compare (three wavefronts per SIMD, four channel tiles)
+#define FQ_PWS_KT(KT_) FQ_PWS_CASE(KT_, 1, (KT_ < 7 ? KT_ : 7), 4) FQ_PWS_CASE(KT_, 2, (KT_ < 3 ? KT_ : 3), 4)
+#define FQ_PWS_KT_TUNE(KT_) \
+  FQ_PWS_CASE(KT_, 1, 7, 3) FQ_PWS_CASE(KT_, 2, 5, 3) FQ_PWS_CASE(KT_, 4, 2, 3)
+    FQ_PWS_KT(2) FQ_PWS_KT(4) FQ_PWS_KT(6) FQ_PWS_KT(8) FQ_PWS_KT(10) FQ_PWS_KT(12) FQ_PWS_KT(16) FQ_PWS_KT(18)
+    FQ_PWS_KT(30) FQ_PWS_KT(32) FQ_PWS_KT(64)
+    FQ_PWS_KT_TUNE(8) FQ_PWS_KT_TUNE(16) FQ_PWS_KT_TUNE(32) FQ_PWS_KT_TUNE(64)
 #undef FQ_PWS_KT
+#undef FQ_PWS_KT_TUNE
 #undef FQ_PWS_CASE
     FQ_REQUIRE(launched, "fq_pwconv_i8: no instantiation of the split form for K/32=%d, %d tiles per wavefront, %d "
                "wavefronts per SIMD", kt, cw, lb);

@@ -231,14 +231,21 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
 
 namespace fqi {
 
+bool pw_stream_shape_ok(const PwCall& c) {
+  const int kt = (int)((c.cin + 31) / 32);
+  const int ct = (int)((c.cout + 31) / 32);
+  const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 5 * sizeof(float);
+  const bool kt_ok = kt == 1 || kt == 2 || kt == 3 || kt == 4 || kt == 6 || kt == 8;
+  return c.cin % 16 == 0 && c.cout % 32 == 0 && kt_ok && lds <= 72 * 1024;
+}
+
 // streaming form: the whole weight matrix in LDS, activations straight from NCHW into MFMA registers
 int pw_try_stream(const PwCall& c, bool* taken) {
   *taken = false;
   const int kt = (int)((c.cin + 31) / 32);
   const int ct = (int)((c.cout + 31) / 32);
   const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 5 * sizeof(float);
-  const bool kt_ok = kt == 1 || kt == 2 || kt == 3 || kt == 4 || kt == 6 || kt == 8;
-  const bool shape_ok = c.cin % 16 == 0 && c.cout % 32 == 0 && kt_ok && lds <= 72 * 1024;
+  const bool shape_ok = pw_stream_shape_ok(c);
   if (!((c.form == 0 || c.form == 3) && shape_ok)) {
     FQ_REQUIRE(c.form != 3, "fq_pwconv_i8: FQ_PW_FORM=3 but the shape does not fit the streaming kernel");
     return FQ_OK;

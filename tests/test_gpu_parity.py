@@ -477,7 +477,13 @@ FORM_CASES = [
     # tile; tiles that span many samples (1x1 planes: more samples than statistic slots)
     ("split", (3, 1024, 1024, 7, 7)), ("split", (3, 256, 512, 5, 6)), ("split", (5, 512, 1024, 7, 7)),
     ("split", (2, 512, 512, 14, 14)), ("split", (2, 256, 128, 9, 7)), ("split", (2, 2048, 512, 7, 7)),
-    ("split", (2, 512, 256, 7, 7)), ("split", (70, 512, 512, 1, 1))]
+    ("split", (2, 512, 256, 7, 7)), ("split", (70, 512, 512, 1, 1)),
+    # ... padded K (Cin % 32 != 0: 24 -> 64, 144 -> 192, 960 -> 960 = 30 slabs, 3 -> 64), partial and missing channel tiles
+    # (Cout 40, 24, 320, 8, 1000), every remaining K/32 instantiation (2, 4, 6, 10, 12, 18, 30)
+    ("split", (2, 24, 40, 5, 7)), ("split", (2, 96, 576, 6, 6)), ("split", (2, 144, 24, 14, 14)),
+    ("split", (2, 960, 320, 7, 7)), ("split", (2, 16, 96, 9, 9)), ("split", (1, 3, 8, 4, 4)),
+    ("split", (2, 384, 64, 14, 14)), ("split", (2, 576, 160, 7, 7)), ("split", (2, 320, 1280, 7, 7)),
+    ("split", (4, 1024, 1000, 1, 1))]
 
 
 @pytest.mark.parametrize("form,case", FORM_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in FORM_CASES])

@@ -14,6 +14,8 @@ from quantization.mxnet_amd import ops  # noqa: E402
 from quantization.mxnet_amd._lib import FakeQuantError  # noqa: E402
 
 MOBILENET = [(256, 512, 14), (512, 512, 14), (512, 1024, 7), (1024, 1024, 7)]
+MBV2 = [(16, 96, 112), (24, 144, 56), (144, 24, 56), (144, 32, 28), (192, 32, 28), (192, 64, 14), (64, 384, 14), (384, 64, 14),
+        (384, 96, 14), (96, 576, 14), (576, 96, 14), (576, 160, 7), (160, 960, 7), (960, 160, 7), (960, 320, 7), (320, 1280, 7)]
 MID = [(128, 128, 56), (128, 256, 28), (256, 256, 28)]
 RESNET = [(256, 1024, 14), (1024, 256, 14), (1024, 512, 14), (512, 2048, 7), (256, 64, 56), (64, 256, 56), (512, 128, 28),
           (128, 512, 28), (2048, 512, 7)]
@@ -21,7 +23,7 @@ VARIANTS = [("auto", None, {}), ("chunk", "chunk", {}), ("tile", "tile", {}), ("
             ("panel", "panel", {}), ("two_kernels", "two_kernels", {}), ("split", "split", {}),
             ("split lb3 cw1", "split", {"FQ_PWS_CFG": "31"}), ("split lb3 cw2", "split", {"FQ_PWS_CFG": "32"}),
             ("split lb3 cw4", "split", {"FQ_PWS_CFG": "34"}), ("split lb4 cw1", "split", {"FQ_PWS_CFG": "41"}),
-            ("split lb4 cw2", "split", {"FQ_PWS_CFG": "42"}), ("split lb4 cw4", "split", {"FQ_PWS_CFG": "44"})]
+            ("split lb4 cw2", "split", {"FQ_PWS_CFG": "42"})]
 
 
 def main():
@@ -30,7 +32,7 @@ def main():
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--hot", action="store_true", help="no cache flush between calls")
     args = ap.parse_args()
-    layers = {"mobilenet": MOBILENET, "resnet": RESNET, "mid": MID, "all": MOBILENET + RESNET}[args.layers]
+    layers = {"mobilenet": MOBILENET, "resnet": RESNET, "mid": MID, "mbv2": MBV2, "all": MOBILENET + RESNET}[args.layers]
     dev = torch.device("cuda", 0)
     n = 128
     flush = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=dev)
