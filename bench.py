@@ -47,7 +47,7 @@ KERNEL_NAMES = {
     "bn_act": "bn_act_stat_kernel (BatchNorm + ReLU + statistic in one pass, 8 B/elem)",
     "stem": "stem_conv3x3s2_kernel (un-quantised first conv + BN + ReLU + statistic, 4 B/in-elem + 4 B/out-elem)",
     "pool": "gap_stat_kernel (global average pool + statistic, 4 B/in-elem + 4 B/out-elem)",
-    "pwconv": "pwconv_{stream,chunk,tile}_kernel (1x1 conv on int8 codes: fake-quant on load, exact int32 MFMA sums, "
+    "pwconv": "pwconv_{split,stream}_kernel (1x1 conv on int8 codes: fake-quant on load, exact int32 MFMA sums, "
               "BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
     "weight": "weight fake-quant kernels (8 B/elem)",
     "histogram": "histogram_kernel (4 B/elem)",

@@ -10,10 +10,9 @@
 //   fq_dwconv.hip      K2c/K2d/K2e depthwise 3x3 with quantise-on-load (LDS tiles / 1 column per lane / 4 columns per lane)
 //   fq_stem.hip        K2s first convolution 3x3 s2 (3 -> 32)
 //   fq_pw_stream.hip   K2h pointwise on int8 codes, weights resident in LDS
-//   fq_pw_chunk.hip    K2i pointwise, weights streamed through LDS in chunks
-//   fq_pw_tile.hip     K2j pointwise for few-tile layers, and the weight-code kernel (fq_weight_codes)
-//   fq_pw_generic.hip  K2f/K2g pointwise for every other shape (quantise+transpose + GEMM, or one LDS-panel launch)
-//   fq_pwconv.hip      fq_pwconv_i8: shape-based choice between the pointwise forms
+//   fq_pw_split.hip    K2m pointwise, one (pixel tile, channel group) per workgroup: every layer from 28x28 planes down
+//   fq_pw_generic.hip  K2f pointwise for every other shape (quantise + transpose, then an integer GEMM)
+//   fq_pwconv.hip      fq_pwconv_i8: shape-based choice between the pointwise forms; the weight-code kernel (fq_weight_codes)
 //   fq_weights.hip     K3 weight fake-quant (layer / group / channel), generic STE, K4 Winograd-domain weights
 //   fq_calib.hip       K5 EMA, K6 global max, K7 histogram, K8 KL threshold search
 //   fq_codes.hip       K9 int-code quantise / dequantise, K10 exact int8 GEMM (nn.Conv2D(quantized=True))
@@ -124,7 +123,10 @@ constexpr int kBlock = 256;                       // 4 wavefronts
 constexpr int kVec = 4;                           // floats per lane per access (16 B)
 constexpr int kUnroll = 8;                        // independent 16 B accesses in flight per lane
 constexpr int kChunk = kBlock * kVec * kUnroll;   // 8192 floats = 32 KiB per workgroup step
-constexpr int kMaxBlocksPerCU = 8;
+#ifndef FQ_MAX_WG_PER_CU
+#define FQ_MAX_WG_PER_CU 8
+#endif
+constexpr int kMaxBlocksPerCU = FQ_MAX_WG_PER_CU;   // grid cap of the streaming kernels (tuning: -DFQ_MAX_WG_PER_CU=6)
 constexpr float kEps = 1e-10f;                    // ste_func.py:39,41
 
 inline int grid_for(int64_t work_items) {

@@ -27,15 +27,12 @@ struct PwCall {
   bool prezeroed;
   void* ws;
   hipStream_t st;
-  int form;                      // FQ_PW_FORM: 0 auto, 1 two kernels, 2 panel, 3 stream, 4 chunk, 5 tile, 6 split
+  int form;                      // FQ_PW_FORM: 0 auto, 1 two kernels, 3 stream, 6 split
 };
 
 int pw_try_stream(const PwCall& c, bool* taken);    // K2h  fq_pw_stream.hip
 bool pw_stream_shape_ok(const PwCall& c);           //      shapes the streaming form takes
-int pw_try_tile(const PwCall& c, bool* taken);      // K2j  fq_pw_tile.hip
 int pw_try_split(const PwCall& c, bool* taken);     // K2m  fq_pw_split.hip
-int pw_try_chunk(const PwCall& c, bool* taken);     // K2i  fq_pw_chunk.hip
-int pw_try_panel(const PwCall& c, bool* taken);     // K2g  fq_pw_generic.hip
 int pw_two_kernels(const PwCall& c);                // K2f  fq_pw_generic.hip (takes every shape)
 
 inline int pw_zero_stat(const PwCall& c) {

@@ -10,12 +10,12 @@ namespace {
 // one wavefront per SIMD issues an instruction every ~4 cycles and nothing overlaps).  This form cuts the work into
 // tiles x channel groups so that ~800-1600 workgroups (3-6 per CU, 3 wavefronts per SIMD) are resident at once:
 //   1. the four wavefronts of a workgroup each quantise a quarter of the tile's K/32 channel slabs (lane = pixel, as
-//      K2h/K2j; up to 64 dword loads per lane in flight before the first quantisation) into an LDS panel of B fragments;
+//      K2h; up to 64 dword loads per lane in flight before the first quantisation) into an LDS panel of B fragments;
 //      workgroups of different channel groups quantise the same tile redundantly (cheap: VALU is idle here, the tile
 //      comes from L2) instead of synchronising;
 //   2. every wavefront multiplies CW 32-channel tiles AT ONCE (CW independent accumulators share each B fragment read
 //      from the panel), A fragments straight from L2 out of the fragment-major copy of fq_weight_codes through a ring of
-//      D K-steps in flight (CW x D 16-byte loads per lane: K2j kept two, and waited on L2 in every step);
+//      D K-steps in flight (CW x D 16-byte loads per lane; round 1's tile form kept two, and waited on L2 in every step);
 //   3. store with lane = pixel (two full lines per store instruction), per-channel constants from LDS.
 // One barrier per workgroup.  Work item -> (tile, group) with the group fastest, so that a tile's workgroups run at the
 // same time on different XCDs (item i runs on XCD i % 8) and each XCD's L2 keeps only the groups it serves.

@@ -1,6 +1,54 @@
-// libfakequant — fq_pwconv_i8: argument checks and the shape-based choice between the pointwise forms
+// libfakequant — fq_pwconv_i8: argument checks and the shape-based choice between the pointwise forms; fq_weight_codes
 // (see fq_common.h for the list of translation units and the design rules)
 #include "fq_pw.h"
+
+namespace {
+
+// weight codes: one workgroup per (padded) row: code = roundf(w / (s + eps)), zero padding, row sums
+__global__ __launch_bounds__(kBlock) void weight_codes_kernel(const float* __restrict__ w, int rows, int row_len,
+                                                              int rows_per_scale, float levels, int row_pad,
+                                                              const float* __restrict__ gmax,
+                                                              int8_t* __restrict__ codes, float* __restrict__ scales,
+                                                              int* __restrict__ rowsum, int8_t* __restrict__ frag) {
+  // `frag` (second half of the codes buffer): the same codes in MFMA-fragment order for v_mfma_i32_32x32x32_i8 with the
+  // weights as the A operand: fragment (ct = row / 32, kt = k / 32) is 1 KB = 64 lanes x 16 bytes, lane = row % 32 +
+  // 32 * ((k % 32) / 16), byte = k % 16 - so a wavefront fetches one fragment with ONE fully coalesced 16-byte load
+  __shared__ int red[4];
+  const int r = blockIdx.x;
+  int8_t* dst = codes + (int64_t)r * row_pad;
+  const int kts = row_pad >> 5;
+  auto frag_at = [&](int i) -> int8_t* {
+    const int kt = i >> 5, hs = (i >> 4) & 1, b = i & 15;
+    return frag + ((((int64_t)(r >> 5) * kts + kt) << 6) + (r & 31) + 32 * hs) * 16 + b;
+  };
+  if (r >= rows) {                                                     // padded row
+    for (int i = threadIdx.x; i < row_pad; i += kBlock) {
+      dst[i] = 0;
+      *frag_at(i) = 0;
+    }
+    return;
+  }
+  const float s = gmax[r / rows_per_scale] / levels;
+  const float d = s + kEps;
+  int acc = 0;
+  for (int i = threadIdx.x; i < row_pad; i += kBlock) {
+    int c = 0;
+    if (i < row_len) c = (int)roundf(w[(int64_t)r * row_len + i] / d);
+    dst[i] = (int8_t)c;
+    *frag_at(i) = (int8_t)c;
+    acc += c;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rowsum[r] = red[0] + red[1] + red[2] + red[3];
+    scales[r] = s;
+  }
+}
+
+}  // namespace
 
 using namespace fqi;
 
@@ -53,21 +101,43 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
   c.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;      // unsigned codes are stored re-centred so they fit int8
   c.out_current_max = out_current_max; c.bn_scale = bn_scale; c.bn_shift = bn_shift; c.act = act;
   c.stat_out = stat_out; c.ws = ws; c.st = (hipStream_t)stream;
-  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 2 panel, 3 stream, 4 chunk, 5 tile, 6 split
+  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split
   c.form = forced_form ? forced_form : pw_form;
+  FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6, "fq_pwconv_i8: unknown form %d (1 two kernels, 3 "
+             "stream, 6 split; the panel / chunk / tile forms 2, 4, 5 were retired in favour of the split form)", c.form);
   ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), c.st);
   bool taken = false;
   if (int rc = pw_try_split(c, &taken)) return rc;
   if (taken) return FQ_OK;
   if (int rc = pw_try_stream(c, &taken)) return rc;
   if (taken) return FQ_OK;
-  if (int rc = pw_try_tile(c, &taken)) return rc;
-  if (taken) return FQ_OK;
-  if (int rc = pw_try_chunk(c, &taken)) return rc;
-  if (taken) return FQ_OK;
-  if (int rc = pw_try_panel(c, &taken)) return rc;
-  if (taken) return FQ_OK;
   return pw_two_kernels(c);
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_scale, int width, int64_t row_pad,
+                    int64_t rows_pad, int8_t* codes, float* scales, int32_t* rowsum, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(w && codes && scales && rowsum && ws, "fq_weight_codes: null pointer");
+  FQ_REQUIRE(rows > 0 && row_len > 0 && rows_per_scale > 0 && rows % rows_per_scale == 0,
+             "fq_weight_codes: bad shape (rows=%lld row_len=%lld rows_per_scale=%d)", (long long)rows,
+             (long long)row_len, rows_per_scale);
+  FQ_REQUIRE(width >= 2 && width <= 8, "fq_weight_codes: width %d does not fit int8 codes", width);
+  FQ_REQUIRE(row_pad >= row_len && rows_pad >= rows && rows_pad < (1ll << 31) && row_pad % 32 == 0 && rows_pad % 32 == 0,
+             "fq_weight_codes: bad padding (row_pad and rows_pad must be multiples of 32)");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t groups = rows / rows_per_scale;
+  float* gmax = (float*)ws;
+  FQ_HIP(hipMemsetAsync(gmax, 0, groups * sizeof(float), st));
+  if (int rc = launch_absmax(w, groups, (int64_t)rows_per_scale * row_len, true, gmax, st)) return rc;
+  const float levels = (float)((1 << (width - 1)) - 1);
+  hipLaunchKernelGGL(weight_codes_kernel, dim3((unsigned)rows_pad), dim3(kBlock), 0, st, w, (int)rows, (int)row_len,
+                     rows_per_scale, levels, (int)row_pad, gmax, codes, scales, (int*)rowsum,
+                     codes + rows_pad * row_pad);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
 }
 
 }  // extern "C"

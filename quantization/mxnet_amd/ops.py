@@ -446,7 +446,7 @@ def weight_codes(w, rows_per_scale, width=8):
     return codes, scales, rowsum
 
 
-PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "panel": 2, "stream": 3, "chunk": 4, "tile": 5, "split": 6}
+PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6}
 
 
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,

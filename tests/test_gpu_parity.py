@@ -457,22 +457,20 @@ def test_pwconv_i8_vs_oracle(dev, ops, case, mode):
 
 @pytest.mark.parametrize("case,mode", [((84, 512, 512, 14, 14), "online_u8_bn_relu"),
                                        ((86, 256, 512, 14, 14), "offline_s8_channel_w4")],
-                         ids=["chunk<16,8>", "chunk<8,8>"])
-def test_pwconv_i8_chunked_form_vs_oracle(dev, ops, case, mode):
-    """>= 512 tiles of 32 columns: the shapes fq_pwconv_i8 sends through the chunked-weights kernel (the small cases
-    above take the tile form for these channel counts); 86 * 196 columns also end in a ragged tile."""
+                         ids=["512->512@14x14x84", "256->512@14x14x86"])
+def test_pwconv_i8_many_tiles_vs_oracle(dev, ops, case, mode):
+    """Hundreds of 32-column tiles (several resident rounds of the split form's workgroups, XCD-contiguous work order);
+    86 * 196 columns also end in a ragged tile."""
     _pwconv_case(dev, ops, case, mode)
 
 
 # Every form of fq_pwconv_i8 named explicitly (FQ_PW_FORM bits of the call), on shapes it accepts — the shape-based choice
-# above reaches: stream (K <= 256 with the whole weight matrix in LDS), chunk / tile (K = 256 / 512 / 1024), panel and two_kernels
-# (every other shape: 24->40, 3->8, 96->576, 1024->1000, 960->320, 144->24, 16->96 of PW_CASES).
+# above reaches: split (every shape whose padded K/32 is instantiated and that has <= 4096 tiles or that the streaming form
+# cannot take), stream (K <= 256 with the whole weight matrix in LDS, large planes), two_kernels (everything else).
 FORM_CASES = [
     ("two_kernels", (2, 24, 40, 5, 7)), ("two_kernels", (2, 512, 512, 7, 7)), ("two_kernels", (2, 960, 320, 7, 7)),
-    ("panel", (2, 144, 24, 14, 14)), ("panel", (2, 96, 576, 6, 6)), ("panel", (3, 64, 128, 14, 14)),
+    ("two_kernels", (2, 144, 24, 14, 14)), ("two_kernels", (2, 448, 96, 6, 6)),
     ("stream", (2, 32, 64, 28, 28)), ("stream", (2, 128, 256, 14, 14)), ("stream", (3, 256, 256, 9, 7)),
-    ("chunk", (5, 512, 512, 7, 7)), ("chunk", (40, 256, 512, 14, 14)), ("chunk", (3, 512, 1024, 7, 7)),
-    ("tile", (3, 1024, 1024, 7, 7)), ("tile", (3, 256, 512, 5, 6)), ("tile", (5, 512, 1024, 7, 7)),
     # split: K/32 = 8 / 16 / 32 / 64; one, two and four channel tiles per wavefront (Cout 128 / 256 / 512+); a ragged last
     # tile; tiles that span many samples (1x1 planes: more samples than statistic slots)
     ("split", (3, 1024, 1024, 7, 7)), ("split", (3, 256, 512, 5, 6)), ("split", (5, 512, 1024, 7, 7)),

@@ -78,22 +78,14 @@ def main():
         names = ["start", "setup done", "phase1 issued", "phase1 barrier", "gemm(block0) done", "end"]
         if form == "split":
             names = ["start", "set-up done", "quantise done", "barrier passed", "multiply done", "end"]
-        if "--chunk" in sys.argv:
-            names = ["start", "batch mean done", "chunk0 in LDS", "Q phase done (batch 0)", "chunks done (batch 0)", "end"]
         for i, nm in enumerate(names):
             print("   %-18s min %7.2f  median %7.2f  max %7.2f us" % (nm, st[:, i].min(), np.median(st[:, i]), st[:, i].max()))
         d = np.diff(st, axis=1)
         dn = ["setup", "phase1 (load+quant+LDS)", "barrier wait", "gemm block0", "epilogue(+other blocks)"]
         if form == "split":
             dn = ["set-up (mean, constants)", "quantise -> panel", "barrier wait", "multiply", "epilogue + statistic"]
-        if "--chunk" in sys.argv:
-            dn = ["batch mean", "chunk 0 -> LDS", "Q phase", "chunk loop", "other batches + stat"]
         for i, nm in enumerate(dn):
             print("   d %-24s median %7.2f  p90 %7.2f us" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
-        if "--chunk" in sys.argv:
-            t67 = (t[:, 6:8].astype(np.float64) - t0) / 100.0
-            print("   chunk 0 of batch 0: mfma+epilogue %.2f us, commit+barrier %.2f us (medians)"
-                  % (np.median(t67[:, 0] - st[:, 3]), np.median(t67[:, 1] - t67[:, 0])))
         late = (st[:, 0] > 1.0).sum()
         print("   workgroups starting later than 1 us after the first: %d" % late)
 

@@ -19,8 +19,7 @@ MBV2 = [(16, 96, 112), (24, 144, 56), (144, 24, 56), (144, 32, 28), (192, 32, 28
 MID = [(128, 128, 56), (128, 256, 28), (256, 256, 28)]
 RESNET = [(256, 1024, 14), (1024, 256, 14), (1024, 512, 14), (512, 2048, 7), (256, 64, 56), (64, 256, 56), (512, 128, 28),
           (128, 512, 28), (2048, 512, 7)]
-VARIANTS = [("auto", None, {}), ("chunk", "chunk", {}), ("tile", "tile", {}), ("stream", "stream", {}),
-            ("panel", "panel", {}), ("two_kernels", "two_kernels", {}), ("split", "split", {}),
+VARIANTS = [("auto", None, {}), ("stream", "stream", {}), ("two_kernels", "two_kernels", {}), ("split", "split", {}),
             ("split lb3 cw1", "split", {"FQ_PWS_CFG": "31"}), ("split lb3 cw2", "split", {"FQ_PWS_CFG": "32"}),
             ("split lb3 cw4", "split", {"FQ_PWS_CFG": "34"}), ("split lb4 cw1", "split", {"FQ_PWS_CFG": "41"}),
             ("split lb4 cw2", "split", {"FQ_PWS_CFG": "42"})]
