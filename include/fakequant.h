@@ -66,7 +66,8 @@ int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront)
 #define FQ_KERNEL_STEM 8          /* stem_conv3x3s2_kernel         : 4 B/in elem + 4 B/out elem                     */
 #define FQ_KERNEL_POOL 9          /* gap_stat_kernel               : 4 B/in elem + 4 B/out elem                     */
 #define FQ_KERNEL_GLOBAL_MAX 10   /* minmax_kernel (calibration)   : 4 B/elem                                       */
-#define FQ_KERNEL_COUNT 11
+#define FQ_KERNEL_CONV3X3 11      /* conv3x3_i8_kernel             : 4 B/in elem + 4 B/out elem                     */
+#define FQ_KERNEL_COUNT 12
 int fq_profile_enable(int on);
 int fq_profile_reset(void);
 int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes);
@@ -228,6 +229,19 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
                  const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
                  const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
                  fqStream_t stream);
+
+/* Dense 3x3 convolution (stride 1, padding 1, no groups / dilation) on the integer codes: the same identity as
+ * fq_pwconv_i8 with K = 9 * Cin, i.e. what the reference's fp32 F.Convolution of the two fake-quantised tensors computes
+ * (nn/quantized_conv.py:134-151 spells the integer form out), here exact in int32.  Same contract as fq_pwconv_i8
+ * (quantise-on-load, bias / folded BatchNorm / activation / per-sample statistic on store, FQ_STAT_PREZEROED).
+ * x: (n, cin, h, w) fp32;  y: (n, cout, h, w) fp32;  cin in {64, 128, 256, 512};  cout >= 32.
+ * wcodes: the buffer fq_weight_codes writes for the weights PERMUTED to (cout, 3, 3, cin), i.e. rows = cout, row_len =
+ * row_pad = 9 * cin (K ordered tap-major so that a 32-channel slab never straddles two taps), rows_pad = cout rounded up
+ * to 64; wscale / wsum as there.                                                                                      */
+int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                  float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* in_stat,
+                  const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                  const float* bn_shift, int act, float* stat_out, fqStream_t stream);
 
 /* Generic LinearQuantizeSTE.forward (ste_func.py:37-41) for API completeness: x viewed as (rows, row_len) with one
  * scale per row read from the DEVICE array `scales` (rows = 1: scalar scale; rows = Cout: (Cout,1,1,1) broadcast):

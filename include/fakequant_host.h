@@ -71,6 +71,12 @@ int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale,
                       const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
                       float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
                       void* ws, fqStream_t stream);
+/* wcodes: row-major [rows_pad][9 * cin] codes of the weights permuted to (cout, 3, 3, cin) (fq_weight_codes_host). */
+int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                       const float* bias, float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
+                       const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                       float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                       fqStream_t stream);
 int fq_ste_forward_host(const float* x, float* y, int64_t rows, int64_t row_len, const float* scales, int has_clip,
                         float clip_lo, float clip_hi, float eps, fqStream_t stream);
 int fq_weight_fake_quant_host(const float* w, float* w_q, int64_t rows, int64_t row_len, int width,

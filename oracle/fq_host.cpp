@@ -532,6 +532,68 @@ int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale,
   return FQ_OK;
 }
 
+// Dense 3x3 convolution (stride 1, pad 1) on the integer codes: exact integer sums over (ky, kx, ci), zero padding = code 0.
+// wcodes rows are ordered (tap, ci) - the weights were permuted to (cout, 3, 3, cin) before fq_weight_codes_host.
+int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                       const float* bias, float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
+                       const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                       float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                       fqStream_t) {
+  REQUIRE(x && wcodes && wscale && wsum && y, "fq_conv3x3_i8_host: null pointer");
+  REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "fq_conv3x3_i8_host: bad shape");
+  REQUIRE((in_stat != nullptr) != (in_thr != nullptr), "fq_conv3x3_i8_host: give in_stat OR in_thr");
+  REQUIRE(in_width >= 2 && in_width <= 8, "fq_conv3x3_i8_host: input width does not fit int8 codes");
+  REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_conv3x3_i8_host: bn_scale and bn_shift go together");
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  zero_stat(stat_out, n, prezeroed);
+  const float max_ = in_stat ? batch_mean(in_stat, n) : in_thr[0];
+  if (in_stat && out_current_max) out_current_max[0] = max_;
+  const QP q = make_qp(max_, act_levels(in_width, in_flags), (in_flags & FQ_ACT_LO_NEG_MAX) != 0, kEps);
+  const float sx = q.scale;
+  (void)wsum;
+  const int64_t hw = h * w, k9 = 9 * cin;
+#pragma omp parallel
+  {
+    std::vector<int32_t> cx((size_t)(cin * (h + 2) * (w + 2)));        // zero-padded codes of one sample
+    std::vector<int32_t> acc((size_t)hw);
+#pragma omp for schedule(static)
+    for (int64_t s = 0; s < n; ++s) {
+      std::fill(cx.begin(), cx.end(), 0);
+      for (int64_t ci = 0; ci < cin; ++ci)
+        for (int64_t r = 0; r < h; ++r)
+          for (int64_t c = 0; c < w; ++c)
+            cx[(size_t)((ci * (h + 2) + r + 1) * (w + 2) + c + 1)] = (int32_t)code_of(x[((s * cin + ci) * h + r) * w + c], q);
+      for (int64_t co = 0; co < cout; ++co) {
+        std::fill(acc.begin(), acc.end(), 0);
+        const int8_t* wr = wcodes + co * k9;
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          for (int64_t ci = 0; ci < cin; ++ci) {
+            const int32_t wv = wr[tap * cin + ci];
+            if (wv == 0) continue;
+            const int32_t* src = &cx[(size_t)((ci * (h + 2) + ky) * (w + 2) + kx)];
+            for (int64_t r = 0; r < h; ++r)
+              for (int64_t c = 0; c < w; ++c) acc[(size_t)(r * w + c)] += wv * src[r * (w + 2) + c];
+          }
+        }
+        const float sxw = sx * wscale[co];
+        for (int64_t p = 0; p < hw; ++p) {
+          float v = (float)acc[(size_t)p] * sxw;
+          if (bias) v = v + bias[co];
+          if (bn_scale) {
+            v = v * bn_scale[co];
+            v = v + bn_shift[co];
+          }
+          y[(s * cout + co) * hw + p] = act_of(v, act);
+        }
+      }
+    }
+  }
+  stat_of_output(y, n, cout * hw, stat_out);
+  return FQ_OK;
+}
+
 // ---- weights ------------------------------------------------------------------------------------------------------
 // LinearQuantizeSTE.forward, ste_func.py:37-41
 int fq_ste_forward_host(const float* x, float* y, int64_t rows, int64_t row_len, const float* scales, int has_clip,

@@ -26,7 +26,7 @@ EPS = F32(1e-10)          # ste_func.py:39,41  `scale + 1e-10`  (fp32 add: numpy
 __all__ = ["roundf", "absmax_per_sample", "batch_mean", "act_scale", "ste_codes", "ste_forward",
            "conv_input_fake_quant", "dense_input_fake_quant", "act_output_fake_quant", "weight_fake_quant",
            "winograd_G", "wino_weight_fake_quant", "ema_update", "discrete_histogram", "kl_calibrate",
-           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act", "dwconv3x3", "weight_codes", "pwconv_i8"]
+           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act", "dwconv3x3", "weight_codes", "pwconv_i8", "conv3x3_i8"]
 
 
 def roundf(x):
@@ -465,6 +465,37 @@ def pwconv_i8(x, w, rows_per_scale, wt_width, in_max, signed=False, width=8, lo_
     if bias is not None:
         y = (y + np.asarray(bias, dtype=F32)[None, :, None]).astype(F32)
     y = y.reshape((N, cw.shape[0]) + x.shape[2:])
+    if bn_scale is not None:
+        return bn_act(y, bn_scale, bn_shift, act or "none")
+    if act == "relu":
+        y = np.maximum(y, F32(0))
+    elif act == "relu6":
+        y = np.minimum(np.maximum(y, F32(0)), F32(6))
+    return y.astype(F32)
+
+
+def conv3x3_i8(x, w, rows_per_scale, wt_width, in_max, signed=False, width=8, lo_neg_max=None, bias=None,
+               bn_scale=None, bn_shift=None, act=None):
+    """Arithmetic of `fq_conv3x3_i8` (dense 3x3, stride 1, zero padding 1): integer codes of x and w, EXACT integer sums
+    over (ci, ky, kx) - the integer form nn/quantized_conv.py:134-151 spells out -, one fp32 multiply by sx*sw[co], bias,
+    folded BN, activation.  w: (cout, cin, 3, 3)."""
+    x = np.asarray(x, dtype=F32)
+    lo_neg = signed if lo_neg_max is None else lo_neg_max
+    sx = act_scale(in_max, signed, width)
+    cx = ste_codes(x, sx, in_max, F32(-F32(in_max)) if lo_neg else F32(0)).astype(np.int64)
+    cw, sw = weight_codes(w, rows_per_scale, wt_width)
+    N, C, H, W = x.shape
+    cw = cw.reshape(-1, C, 3, 3).astype(np.int64)
+    pad = np.zeros((N, C, H + 2, W + 2), np.int64)
+    pad[:, :, 1:-1, 1:-1] = cx
+    isum = np.zeros((N, cw.shape[0], H, W), np.int64)
+    for ky in range(3):
+        for kx in range(3):
+            isum += np.einsum("oc,nchw->nohw", cw[:, :, ky, kx], pad[:, :, ky:ky + H, kx:kx + W])
+    sxw = (F32(sx) * sw).astype(F32)
+    y = (isum.astype(F32) * sxw[None, :, None, None]).astype(F32)
+    if bias is not None:
+        y = (y + np.asarray(bias, dtype=F32)[None, :, None, None]).astype(F32)
     if bn_scale is not None:
         return bn_act(y, bn_scale, bn_shift, act or "none")
     if act == "relu":

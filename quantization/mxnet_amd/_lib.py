@@ -49,6 +49,8 @@ EXPORTS = {
     "fq_pwconv_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "fq_pwconv_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                             _vp, _int, _vp, _vp, _vp]),
+    "fq_conv3x3_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
+                             _vp, _int, _vp, _vp]),
     "fq_fake_quant_offline": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp, _vp]),
     "fq_ste_forward": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _f32, _f32, _f32, _vp]),
     "fq_weight_workspace_bytes": (ctypes.c_size_t, [_i64]),

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["add_act_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["add_act_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -82,7 +82,7 @@ def device_info():
 
 
 KERNEL_IDS = {"stat": 0, "apply_online": 1, "apply_offline": 2, "weight": 3, "histogram": 4, "bn_act": 5,
-              "dwconv": 6, "pwconv": 7, "stem": 8, "pool": 9, "global_max": 10}
+              "dwconv": 6, "pwconv": 7, "stem": 8, "pool": 9, "global_max": 10, "conv3x3": 11}
 
 
 def profile_enable(on=True):
@@ -474,6 +474,44 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
                                     cin_pad, cout, hw, _ptr(in_stat), _ptr(in_thr), int(width), int(flags),
                                     _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift),
                                     _ACTS[act] | zflag | (PW_FORMS[form] << 12), _ptr(stat), _ptr(ws), _stream(x)))
+    return y, stat
+
+
+def weight_codes_3x3(w, rows_per_scale, width=8):
+    """Codes of a dense 3x3 weight (Cout, Cin, 3, 3) in the K order `conv3x3_i8` multiplies in: (tap, ci), i.e. the codes of
+    the weight permuted to (Cout, 3, 3, Cin).  Scales and row sums do not depend on the order inside a row."""
+    _check(w, "w")
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("expected a (Cout, Cin, 3, 3) weight, got %s" % (tuple(w.shape),))
+    return weight_codes(w.permute(0, 2, 3, 1).contiguous(), rows_per_scale, width)
+
+
+def conv3x3_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
+               bn_scale=None, bn_shift=None, act=None, want_stat=True):
+    """Dense 3x3 convolution (stride 1, padding 1) on the integer codes (int8 MFMA, exact int32 accumulation) with
+    quantise-on-load and fused BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; wcodes / wscale / wsum
+    from `weight_codes_3x3`.  Returns (y, stat or None)."""
+    _check(x, "x")
+    _check(wcodes, "wcodes", torch.int8)
+    _check(wscale, "wscale")
+    _check(wsum, "wsum", torch.int32)
+    for name, t in (("bias", bias), ("in_stat", in_stat), ("in_thr", in_thr), ("bn_scale", bn_scale),
+                    ("bn_shift", bn_shift), ("cur_out", cur_out)):
+        if t is not None:
+            _check(t, name)
+    if x.dim() != 4:
+        raise ValueError("expected (N, Cin, H, W) activations, got %s" % (tuple(x.shape),))
+    n, cin, h, w = x.shape
+    cout = wscale.numel()
+    if wcodes.shape[1] != 9 * cin:
+        raise ValueError("weight codes have rows of %d, expected 9 * Cin = %d" % (wcodes.shape[1], 9 * cin))
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    stat, zflag = _stat_target(n, x.device, want_stat)
+    if in_stat is not None and cur_out is None:
+        cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check_call(_lib_().fq_conv3x3_i8(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin, cout,
+                                     h, w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(cur_out),
+                                     _ptr(bn_scale), _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _stream(x)))
     return y, stat
 
 

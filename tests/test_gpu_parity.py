@@ -544,6 +544,75 @@ def _pwconv_case(dev, ops, case, mode, form=None):
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
 
 
+# ---- dense 3x3 convolution on integer codes (int8 MFMA, implicit GEMM over (tap, ci)) -----------------------------------
+C3_CASES = [  # (n, cin, cout, h, w): every K/32 (2, 4, 8, 16), both wavefront arrangements (Cout < 128 / >= 128), partial
+    # channel tiles (Cout 96, 160), planes narrower than / as wide as / wider than a pixel tile, ragged last blocks, blocks
+    # that span several samples (3x3 and 7x7 planes)
+    (2, 64, 64, 9, 11), (3, 128, 128, 7, 7), (2, 256, 256, 5, 6), (1, 512, 512, 7, 7), (2, 64, 128, 14, 14),
+    (5, 64, 96, 3, 3), (2, 128, 160, 28, 28), (1, 64, 64, 56, 56), (9, 256, 32, 4, 4), (1, 128, 64, 1, 50)]
+
+
+@pytest.mark.parametrize("case", C3_CASES, ids=["%dx%d->%d@%dx%d" % c for c in C3_CASES])
+@pytest.mark.parametrize("mode", ["online_u8_bn_relu", "offline_s8_channel_w4", "online_s8_bias"])
+def test_conv3x3_i8_vs_oracle(dev, ops, case, mode):
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + 7)
+    x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+    if "s8" not in mode:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * rng.uniform(0.05, 1.0, (cout, 1, 1, 1))).astype(np.float32)
+    per_channel = "channel" in mode
+    wt_width = 4 if "w4" in mode else 8
+    rps = 1 if per_channel else cout
+    codes, scales, rowsum = ops.weight_codes_3x3(T(wt, dev), rps, wt_width)
+    ocodes, oscales = O.weight_codes(wt, rps, wt_width)
+    _eq(N(scales), oscales, "weight scales")
+    _eq(N(rowsum), ocodes.sum(axis=1).astype(np.int32), "row sums")
+    _eq(N(codes)[:cout], ocodes.reshape(cout, cin, 3, 3).transpose(0, 2, 3, 1).reshape(cout, -1).astype(np.int8),
+        "weight codes in (tap, ci) order")
+    kw, okw = {}, {}
+    signed = "s8" in mode
+    if mode.startswith("online"):
+        stat = O.absmax_per_sample(x)
+        kw.update(in_stat=T(stat, dev), width=8, flags=ops.act_flags(signed=signed))
+        okw.update(in_max=O.batch_mean(stat), signed=signed, width=8)
+    else:
+        thr = np.float32(2.3)
+        kw.update(in_thr=T(np.float32([thr]), dev), width=8, flags=ops.act_flags(signed=True))
+        okw.update(in_max=thr, signed=True, width=8)
+    if "bn_relu" in mode:
+        sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+        sh = rng.standard_normal(cout).astype(np.float32)
+        kw.update(bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu")
+        okw.update(bn_scale=sc, bn_shift=sh, act="relu")
+    if "bias" in mode:
+        b = rng.standard_normal(cout).astype(np.float32)
+        kw.update(bias=T(b, dev))
+        okw.update(bias=b)
+    cur = torch.zeros(1, device=dev)
+    y, stat_out = ops.conv3x3_i8(T(x, dev), codes, scales, rowsum, cur_out=cur, **kw)
+    want = O.conv3x3_i8(x, wt, rps, wt_width, **okw)
+    got = N(y)
+    _eq(got, want, "dense 3x3 int8 convolution (exact integer sums)")
+    _eq(N(stat_out), O.absmax_per_sample(got), "statistic")
+    if mode.startswith("online"):
+        _eq(N(cur), np.float32([okw["in_max"]]), "current_input_max")
+    # the host twin (full-size oracle of the net tests) agrees as well
+    from oracle import host as H
+    hy = H.conv3x3_i8(x, wt, rps, wt_width, **okw)
+    _eq(hy, want, "host twin vs numpy oracle")
+    # the reference's formulation: fp32 convolution of the two dequantised tensors, equal up to fp32 summation noise
+    wq = O.weight_fake_quant(wt, "channel" if per_channel else "layer", wt_width)[0]
+    xq = O.ste_forward(x, O.act_scale(okw["in_max"], okw["signed"], okw["width"]), okw["in_max"],
+                       -okw["in_max"] if okw["signed"] else 0.0)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(xq.astype(np.float64)), torch.from_numpy(wq.astype(np.float64)),
+                                     padding=1).numpy()
+    if "bias" in mode:
+        ref = ref + okw["bias"].reshape(1, -1, 1, 1)
+    if "bn_relu" not in mode:
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
 def test_division_by_double_reciprocal_is_ieee_exact(dev, ops):
     """fq_code divides with (float)((double)c * RN_f64(1/d)) (csrc: ieee_div_by).  Stress it where it could matter: inputs
     placed 0, +-1, +-2 ulp around every k + 0.5 rounding tie of the quotient, for many divisors, signed and unsigned."""
