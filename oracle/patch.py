@@ -236,6 +236,46 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     return _t(y.astype(F32)), stat
 
 
+def weight_codes_3x3(w, rows_per_scale, width=8):
+    return weight_codes(w.permute(0, 2, 3, 1).contiguous(), rows_per_scale, width)
+
+
+def conv3x3_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
+               bn_scale=None, bn_shift=None, act=None, want_stat=True):
+    """codes rows are ordered (tap, ci) (weight_codes_3x3)"""
+    signed, lo_neg, _, _ = _flags(flags)
+    if in_stat is not None:
+        in_max = O.batch_mean(_np(in_stat).reshape(-1)[:x.shape[0]])
+        if cur_out is not None:
+            cur_out.copy_(_t(np.asarray([in_max], dtype=F32)))
+    else:
+        in_max = F32(_np(in_thr).reshape(-1)[0])
+    a = _np(x)
+    n, cin, h, w = a.shape
+    sx = O.act_scale(in_max, signed, width)
+    cx = O.ste_codes(a, sx, in_max, F32(-in_max) if lo_neg else F32(0)).astype(np.int64)
+    sw = _np(wscale)
+    cout = sw.size
+    cw = _np(wcodes)[:cout, :9 * cin].astype(np.int64).reshape(cout, 3, 3, cin)
+    pad = np.zeros((n, cin, h + 2, w + 2), np.int64)
+    pad[:, :, 1:-1, 1:-1] = cx
+    isum = np.zeros((n, cout, h, w), np.int64)
+    for ky in range(3):
+        for kx in range(3):
+            isum += np.einsum("oc,nchw->nohw", cw[:, ky, kx, :], pad[:, :, ky:ky + h, kx:kx + w])
+    y = (isum.astype(F32) * (F32(sx) * sw).astype(F32)[None, :, None, None]).astype(F32)
+    if bias is not None:
+        y = (y + _np(bias)[None, :, None, None]).astype(F32)
+    if bn_scale is not None:
+        y = O.bn_act(y, _np(bn_scale), _np(bn_shift), act or "none")
+    elif act == "relu":
+        y = np.maximum(y, F32(0))
+    elif act == "relu6":
+        y = np.minimum(np.maximum(y, F32(0)), F32(6))
+    stat = _t(np.abs(y).reshape(n, -1).max(axis=1).astype(F32)) if want_stat else None
+    return _t(y.astype(F32)), stat
+
+
 def fake_quant_offline(x, threshold, width=8, flags=0, out=None, cur_out=None, want_stat=True, want_codes=False,
                        stat_ws=None):
     thr = F32(_np(threshold).reshape(-1)[0])
@@ -339,7 +379,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "weight_codes_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

@@ -172,14 +172,15 @@ def _pointwise_weight_codes(block, args, weight_raw, weight_q):
     if block.fixed_params == 1 and held is not None and held[3] == key:
         return held[:3]
     src = weight_raw if block.fixed_params != 1 or held is None else weight_q
-    codes = ops.weight_codes(contiguous(src._t), _weight_rows_per_scale(block, args), args.wt_width)
+    make = ops.weight_codes_3x3 if block._fq_pw_fused.get("kind") == "3x3" else ops.weight_codes
+    codes = make(contiguous(src._t), _weight_rows_per_scale(block, args), args.wt_width)
     if block.fixed_params == 1:
         block._fq_pw_cache = tuple(codes) + (key,)
     return codes
 
 
 def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quantised):
-    """1x1 convolution taken over by quantize/fuse.py.  When both operands are quantised to <= 8 bits it runs on the
+    """1x1 (or dense 3x3, `kind`) convolution taken over by quantize/fuse.py.  When both operands are quantised to <= 8 bits it runs on the
     integer codes (fq_pwconv_i8: exact int32 sums on the int8 matrix cores, quantise-on-load, BN / activation / statistic
     on store); otherwise the library convolution runs and only BN + activation + statistic are fused."""
     fz = block._fq_pw_fused
@@ -189,8 +190,9 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
         and not getattr(block, "_fq_no_int8", False)
     if on_codes:
         codes, scales, rowsum = _pointwise_weight_codes(block, args, weight_raw, weight_q)
-        y, stat = ops.pwconv_i8(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
-                                bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
+        conv = ops.conv3x3_i8 if fz.get("kind") == "3x3" else ops.pwconv_i8
+        y, stat = conv(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
+                       bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
     else:
         if plan:          # input is to be quantised but the integer path does not apply: explicit apply pass
             t = contiguous(x._t)

@@ -88,6 +88,21 @@ def _is_pw1x1(b):
             and not b.quantize_args.fake_bn)
 
 
+def _is_dense3x3(b):
+    """A converted dense 3x3 convolution (stride 1, padding 1) whose integer form fq_conv3x3_i8 takes: the 3x3 layers of the
+    ResNet units.  Not when the weights are quantised in the Winograd domain (they are no integer multiples of one scale in
+    the spatial domain then)."""
+    if type(b) is not nn.Conv2D or not hasattr(b, "quantize_args"):
+        return False
+    k = b._kwargs
+    a = b.quantize_args
+    wino = a.quant_type == "channel" and a.wino_quantize != "none"
+    cin = b.weight.shape[1] if b.weight.shape is not None and len(b.weight.shape) == 4 else 0
+    return (k["kernel"] == (3, 3) and k["pad"] == (1, 1) and k["dilate"] == (1, 1) and k["stride"] == (1, 1)
+            and k["num_group"] == 1 and k["layout"] == "NCHW" and b.act is None and not a.fake_bn and not wino
+            and cin in (64, 128, 256, 512) and k["num_filter"] >= 32)
+
+
 def _is_stem3x3s2(b):
     """The un-quantised first convolution of the ImageNet MobileNets: Conv2D(3 -> 32, 3x3, stride 2, pad 1)."""
     if type(b) is not nn.Conv2D or hasattr(b, "quantize_args"):
@@ -266,7 +281,8 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             return
         kids = list(container._children.values())
         for i, b in enumerate(kids):
-            if not _is_pw1x1(b) or hasattr(b, "_fq_pw_fused") or hasattr(b, "_fq_dw_fused"):
+            dense3 = _is_dense3x3(b)
+            if not (_is_pw1x1(b) or dense3) or hasattr(b, "_fq_pw_fused") or hasattr(b, "_fq_dw_fused"):
                 continue
             bn = kids[i + 1] if i + 1 < len(kids) else None
             if not (type(bn) is nn.BatchNorm and not hasattr(bn, "_fq_fused") and bn._kwargs.get("axis", 1) == 1
@@ -275,7 +291,8 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             nxt = kids[i + 2] if bn is not None and i + 2 < len(kids) else (kids[i + 1] if bn is None and i + 1 < len(kids) else None)
             act = _act_kind(nxt) if nxt is not None else None
             b._fq_pw_fused = {"bn": bn, "act": act or "none", "act_block": nxt if act else None,
-                              "constants": _bn_constants_getter(bn) if bn is not None else None}
+                              "constants": _bn_constants_getter(bn) if bn is not None else None,
+                              "kind": "3x3" if dense3 else "1x1"}
             if bn is not None:
                 bn._fq_fused = {"taken_by_conv": True, "orig": bn.hybrid_forward, "act_block": None}
                 bn.hybrid_forward = types.MethodType(_identity_forward, bn)

@@ -248,19 +248,47 @@ def test_fused_inference_keeps_every_block_exact(gpu, model, classes, hw, batch,
                              y=y.detach().clone(), stat=stat.detach().clone(),
                              k={a: (b.detach().clone() if torch.is_tensor(b) else b) for a, b in k.items()}))
         return y, stat
+    c3_calls = []
+    real_c3 = ops.conv3x3_i8
+
+    def spy_c3(x, codes, scales, rowsum, bias=None, **k):
+        y, stat = real_c3(x, codes, scales, rowsum, bias, **k)
+        c3_calls.append(dict(x=x.detach().clone(), codes=codes.detach().clone(), scales=scales.detach().clone(),
+                             rowsum=rowsum.detach().clone(), bias=None if bias is None else bias.detach().clone(),
+                             y=y.detach().clone(), stat=stat.detach().clone(),
+                             k={a: (b.detach().clone() if torch.is_tensor(b) else b) for a, b in k.items()}))
+        return y, stat
     ops.dwconv3x3 = spy_dw
     ops.pwconv_i8 = spy_pw
+    ops.conv3x3_i8 = spy_c3
     try:
         out = net(X).asnumpy()
     finally:
         ops.dwconv3x3 = real_dw
         ops.pwconv_i8 = real_pw
+        ops.conv3x3_i8 = real_c3
     args = dict(signed=False, in_w=8, wt=kw.get("wt", 8), quant_type=kw.get("quant_type", "layer"), wino="none")
     _check_records(spy.records, offline=False, allow_empty=True, **args)   # (mobilenetv2: every block is taken over)
     n_dw = sum(1 for b in spy.blocks if hasattr(b, "_fq_dw_fused"))
     n_pw = sum(1 for b in spy.blocks if hasattr(b, "_fq_pw_fused"))
-    assert len(dw_calls) == n_dw and len(pw_calls) == n_pw and len(spy.records) + n_dw + n_pw == len(spy.blocks)
+    assert len(dw_calls) == n_dw and len(pw_calls) + len(c3_calls) == n_pw
+    assert len(spy.records) + n_dw + n_pw == len(spy.blocks)
+    # the 3x3 layers with 64 ... 512 input channels run on the integer codes: the ResNet-50 bottlenecks, the last stage of
+    # the CIFAR ResNet-20
+    assert (len(c3_calls) > 0) == (model in ("resnet50_v1", "cifar_resnet20_v1"))
     from oracle import patch as OP
+    for call in c3_calls:
+        k = call["k"]
+        x_raw = call["x"].cpu()
+        per_sample = O.absmax_per_sample(x_raw.numpy())
+        assert np.array_equal(k["in_stat"].cpu().numpy(), per_sample)
+        assert k["cur_out"].cpu().numpy()[0] == O.batch_mean(per_sample)
+        cpu_k = {a: (b.cpu() if torch.is_tensor(b) else b) for a, b in k.items()}
+        cpu_k["cur_out"] = torch.zeros(1)
+        want, want_stat = OP.conv3x3_i8(x_raw, call["codes"].cpu(), call["scales"].cpu(), call["rowsum"].cpu(),
+                                        None if call["bias"] is None else call["bias"].cpu(), **cpu_k)
+        assert np.array_equal(call["y"].cpu().numpy(), want.numpy()), "3x3 int8 conv differs from the oracle"
+        assert np.array_equal(call["stat"].cpu().numpy(), want_stat.numpy())
     for call in pw_calls:
         k = call["k"]
         x_raw = call["x"].cpu()
