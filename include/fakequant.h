@@ -230,6 +230,16 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
                  const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
                  fqStream_t stream);
 
+/* The same for a STRIDED 1x1 convolution (stride 2 in both directions, no padding: the shortcut and first convolutions
+ * of the ResNet stages): x is (n, cin, h, w), y is (n, cout, ceil(h/2), ceil(w/2)) - the kernel reads every second pixel of
+ * every second row, nothing is subsampled beforehand.  stride = 1 is fq_pwconv_i8 with hw = h * w.  Strided calls need a
+ * shape the split form takes (cin_pad / 32 in {2, 4, 6, 8, 10, 12, 16, 18, 30, 32, 64}), FQ_ERR_INVALID otherwise.    */
+int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                         const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h,
+                         int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,
+                         unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
+                         int act, float* stat_out, void* ws, fqStream_t stream);
+
 /* Dense 3x3 convolution (stride 1, padding 1, no groups / dilation) on the integer codes: the same identity as
  * fq_pwconv_i8 with K = 9 * Cin, i.e. what the reference's fp32 F.Convolution of the two fake-quantised tensors computes
  * (nn/quantized_conv.py:134-151 spells the integer form out), here exact in int32.  Same contract as fq_pwconv_i8

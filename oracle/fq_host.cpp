@@ -532,6 +532,26 @@ int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale,
   return FQ_OK;
 }
 
+// Strided 1x1 convolution: the stride-1 arithmetic on the subsampled input x[:, :, ::s, ::s].
+int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                              const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout,
+                              int64_t h, int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,
+                              unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
+                              int act, float* stat_out, void* ws, fqStream_t stream) {
+  REQUIRE(x && h > 0 && w > 0 && (stride == 1 || stride == 2), "fq_pwconv_i8_strided_host: bad arguments");
+  const int64_t ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+  if (stride == 1)
+    return fq_pwconv_i8_host(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, h * w, in_stat, in_thr, in_width,
+                             in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, ws, stream);
+  std::vector<float> sub((size_t)(n * cin * ho * wo));
+#pragma omp parallel for schedule(static)
+  for (int64_t pc = 0; pc < n * cin; ++pc)
+    for (int64_t r = 0; r < ho; ++r)
+      for (int64_t c = 0; c < wo; ++c) sub[(size_t)((pc * ho + r) * wo + c)] = x[(pc * h + r * stride) * w + c * stride];
+  return fq_pwconv_i8_host(sub.data(), wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, ho * wo, in_stat, in_thr,
+                           in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, ws, stream);
+}
+
 // Dense 3x3 convolution (stride 1, pad 1) on the integer codes: exact integer sums over (ky, kx, ci), zero padding = code 0.
 // wcodes rows are ordered (tap, ci) - the weights were permuted to (cout, 3, 3, cin) before fq_weight_codes_host.
 int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,

@@ -450,10 +450,13 @@ def weight_codes(w, rows_per_scale, width=8):
 
 
 def pwconv_i8(x, w, rows_per_scale, wt_width, in_max, signed=False, width=8, lo_neg_max=None, bias=None,
-              bn_scale=None, bn_shift=None, act=None):
-    """Arithmetic of `fq_pwconv_i8`: integer codes of x and w, EXACT integer dot products, one fp32 multiply by
-    sx*sw[co], bias, folded BN, activation."""
+              bn_scale=None, bn_shift=None, act=None, stride=1):
+    """Arithmetic of `fq_pwconv_i8` (`_strided`): integer codes of x and w, EXACT integer dot products, one fp32 multiply
+    by sx*sw[co], bias, folded BN, activation.  A stride only subsamples the input (in_max is the statistic of the WHOLE
+    input, as the reference's fake-quant in front of the convolution sees it)."""
     x = np.asarray(x, dtype=F32)
+    if stride != 1:
+        x = np.ascontiguousarray(x[:, :, ::stride, ::stride])
     lo_neg = signed if lo_neg_max is None else lo_neg_max
     sx = act_scale(in_max, signed, width)
     cx = ste_codes(x, sx, in_max, F32(-F32(in_max)) if lo_neg else F32(0)).astype(np.int64)

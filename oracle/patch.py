@@ -205,9 +205,15 @@ def weight_codes(w, rows_per_scale, width=8):
     return _t(padded), _t(scales), _t(codes.sum(axis=1).astype(np.int32))
 
 
+def pwconv_strided_supported(cin):
+    return True
+
+
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None):
+              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1):
     signed, lo_neg, _, _ = _flags(flags)
+    if stride != 1:
+        x = x[:, :, ::stride, ::stride].contiguous()
     if in_stat is not None:
         in_max = O.batch_mean(_np(in_stat).reshape(-1)[:x.shape[0]])
         if cur_out is not None:
@@ -379,7 +385,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "weight_codes_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

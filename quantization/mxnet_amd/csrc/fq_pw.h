@@ -14,7 +14,9 @@ struct PwCall {
   const int32_t* wsum;
   const float* bias;
   float* y;
-  int64_t n, cin, cin_pad, cout, hw;
+  int64_t n, cin, cin_pad, cout, hw;   // hw: pixels of an OUTPUT plane
+  int stride;                    // 1, or 2 (split form only): the input plane is h_in x w_in, the output w_out wide
+  int64_t h_in, w_in, w_out;
   const float* in_stat;          // online: per-sample statistic of x
   const float* in_thr;           // offline: threshold
   float levels;

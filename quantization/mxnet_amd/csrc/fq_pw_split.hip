@@ -22,6 +22,7 @@ namespace {
 struct PwSplitGeom {
   int Cin, Cout, HW, CS;     // CS: channel groups (workgroups) per tile = ceil(Cout / (128 * CW))
   int CTM;                   // 32-channel tiles present in the weight buffer (rows_pad / 32; rows >= Cout are zero)
+  int S, Wo, Win, HWin;      // stride (1 or 2): HW / Wo describe the OUTPUT plane, Win / HWin the input plane
   int64_t cols, tiles, items;   // items = tiles * CS
   int zoff;
 };
@@ -79,13 +80,21 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
   // offset register (its pixel, and the half of a slab it owns), the channel stride is a scalar offset.  Channels of a
   // padded slab (Cin % 32 != 0) read the next sample's values, or 0 past the end of the tensor: whatever code they get
   // meets a zero weight code (fq_weight_codes pads K with zeros).
-  const int64_t x_samp = (int64_t)g.Cin * HW * 4, y_samp = (int64_t)g.Cout * HW * 4;
+  // A strided (2 x 2) 1x1 convolution reads every second pixel of every second row: only the lane's input offset and the
+  // input plane size differ from the stride-1 case.
+  const unsigned plane4_in = (unsigned)g.HWin * 4u;
+  const int64_t x_samp = (int64_t)g.Cin * g.HWin * 4, y_samp = (int64_t)g.Cout * HW * 4;
   const int64_t n_samp = (int64_t)(cols / HW);
   const fq_rsrc xr = make_rsrc(reinterpret_cast<const char*>(x) + s_base * x_samp, (n_samp - s_base) * x_samp);
-  const unsigned xo = ((smp - s_base) * (unsigned)g.Cin + 16u * h) * plane4 + p * 4u;
+  unsigned p_in = p;
+  if (g.S != 1) {
+    const unsigned ho = p / (unsigned)g.Wo, wo = p - ho * (unsigned)g.Wo;
+    p_in = ho * (unsigned)(g.S * g.Win) + wo * (unsigned)g.S;
+  }
+  const unsigned xo = ((smp - s_base) * (unsigned)g.Cin + 16u * h) * plane4_in + p_in * 4u;
   auto issue = [&](int kt, float (&v)[16]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = buf_ld_f32(xr, xo, (unsigned)(kt * 32 + i) * plane4);
+    for (int i = 0; i < 16; ++i) v[i] = buf_ld_f32(xr, xo, (unsigned)(kt * 32 + i) * plane4_in);
   };
 
   PW_STAMP(0);
@@ -282,10 +291,11 @@ int pw_try_split(const PwCall& a, bool* taken) {
   bool shape_ok = false;
   for (int k : kts) shape_ok = shape_ok || k == kt;
   // a tile's stores must stay below 2 GiB from its first sample (out-of-range lane offsets mask partial channel tiles)
-  shape_ok = shape_ok && (32 / a.hw + 2) * a.cout * a.hw * 4 < (1ll << 31) && a.cin * a.hw * 4 * (32 / a.hw + 2) < (1ll << 31);
+  const int64_t hw_in = a.stride == 1 ? a.hw : a.h_in * a.w_in;
+  shape_ok = shape_ok && (32 / a.hw + 2) * a.cout * a.hw * 4 < (1ll << 31) && a.cin * hw_in * 4 * (32 / a.hw + 2) < (1ll << 31);
   static const int mode = env_int("FQ_PWS_AUTO", 1);                    // tuning: 0 never, 1 by shape, 2 always
-  bool want = a.form == 6;
-  if (a.form == 0 && shape_ok)
+  bool want = a.form == 6 || a.stride != 1;                             // (only this form reads strided inputs)
+  if (a.form == 0 && shape_ok && a.stride == 1)
     want = mode == 2 || (mode == 1 && (tiles <= (int64_t)num_cu() * 16 || !pw_stream_shape_ok(a)));
   if (want && shape_ok) {
     // channel tiles per wavefront (cw) and wavefronts per SIMD (lb).  Measured in the model: two tiles per wavefront at
@@ -302,6 +312,7 @@ int pw_try_split(const PwCall& a, bool* taken) {
     t.Cin = (int)a.cin; t.Cout = (int)a.cout; t.HW = (int)a.hw;
     t.CS = (int)((a.cout + 128 * cw - 1) / (128 * cw));
     t.CTM = (int)(rows_pad / 32);
+    t.S = a.stride; t.Wo = (int)a.w_out; t.Win = (int)a.w_in; t.HWin = (int)hw_in;
     t.cols = a.n * a.hw; t.tiles = tiles; t.zoff = a.zoff;
     t.items = tiles * t.CS;
     const int64_t grid = (t.items + 7) / 8 * 8;                           // padded to whole rounds over the 8 XCDs
@@ -338,7 +349,8 @@ int pw_try_split(const PwCall& a, bool* taken) {
     *taken = true;
     return FQ_OK;
   }
-  FQ_REQUIRE(a.form != 6, "fq_pwconv_i8: FQ_PW_FORM=6 but the shape does not fit the split kernel");
+  FQ_REQUIRE(a.form != 6 && a.stride == 1, "fq_pwconv_i8: %s but the shape does not fit the split kernel (padded Cin / 32 "
+             "= %d is not instantiated)", a.stride == 1 ? "FQ_PW_FORM=6" : "a strided call", kt);
   return FQ_OK;
 }
 

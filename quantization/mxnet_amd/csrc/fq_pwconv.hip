@@ -70,11 +70,12 @@ size_t fq_pwconv_workspace_bytes(int64_t n, int64_t cin_pad, int64_t hw) {
   return (size_t)cols_pad * (size_t)cin_pad + 64;
 }
 
-int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
-                 float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
-                 const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
-                 const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
-                 fqStream_t stream) {
+static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                           const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
+                           int stride, int64_t h_in, int64_t w_in, int64_t w_out, const float* in_stat,
+                           const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                           const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
+                           fqStream_t stream) {
   FQ_REQUIRE(x && wcodes && wscale && wsum && y && ws, "fq_pwconv_i8: null pointer");
   FQ_REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && hw < (1ll << 30) && n * hw < (1ll << 31) - 512,
              "fq_pwconv_i8: bad shape");
@@ -95,6 +96,7 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
   FQ_REQUIRE(aligned16(wcodes) && aligned16(ws) && aligned16(x), "fq_pwconv_i8: x, wcodes and ws must be 16-byte aligned");
   c.x = x; c.wcodes = wcodes; c.wscale = wscale; c.wsum = wsum; c.bias = bias; c.y = y;
   c.n = n; c.cin = cin; c.cin_pad = cin_pad; c.cout = cout; c.hw = hw;
+  c.stride = stride; c.h_in = h_in; c.w_in = w_in; c.w_out = w_out;
   c.in_stat = in_stat; c.in_thr = in_thr;
   c.levels = act_levels(in_width, in_flags);
   c.lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
@@ -105,6 +107,7 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
   c.form = forced_form ? forced_form : pw_form;
   FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6, "fq_pwconv_i8: unknown form %d (1 two kernels, 3 "
              "stream, 6 split; the panel / chunk / tile forms 2, 4, 5 were retired in favour of the split form)", c.form);
+  FQ_REQUIRE(stride == 1 || c.form == 0 || c.form == 6, "fq_pwconv_i8_strided: only the split form reads strided inputs");
   ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), c.st);
   bool taken = false;
   if (int rc = pw_try_split(c, &taken)) return rc;
@@ -112,6 +115,27 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
   if (int rc = pw_try_stream(c, &taken)) return rc;
   if (taken) return FQ_OK;
   return pw_two_kernels(c);
+}
+
+int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                 float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                 const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                 const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
+                 fqStream_t stream) {
+  return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, hw, 1, 0, 0, 0, in_stat, in_thr,
+                         in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, ws, stream);
+}
+
+int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                         const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h,
+                         int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,
+                         unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
+                         int act, float* stat_out, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(h > 0 && w > 0 && (stride == 1 || stride == 2), "fq_pwconv_i8_strided: bad plane %lld x %lld or stride %d",
+             (long long)h, (long long)w, stride);
+  const int64_t ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+  return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, ho * wo, stride, h, w, wo, in_stat,
+                         in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, ws, stream);
 }
 
 }  // extern "C"

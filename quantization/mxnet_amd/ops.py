@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["add_act_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["add_act_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -449,10 +449,19 @@ def weight_codes(w, rows_per_scale, width=8):
 PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6}
 
 
+SPLIT_KT = (2, 4, 6, 8, 10, 12, 16, 18, 30, 32, 64)     # padded Cin / 32 the split form of fq_pwconv_i8 is built for
+
+
+def pwconv_strided_supported(cin):
+    """Strided 1x1 convolutions run on the integer codes only through the split form (include/fakequant.h)."""
+    return ((int(cin) + 63) // 64 * 64) // 32 in SPLIT_KT
+
+
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None):
+              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1):
     """1x1 convolution on the integer codes (int8 MFMA, exact int32 accumulation) with quantise-on-load and fused
-    BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations.  Returns (y, stat or None)."""
+    BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; stride 1 or 2 (no padding).  Returns (y, stat
+    or None)."""
     _check(x, "x")
     _check(wcodes, "wcodes", torch.int8)
     _check(wscale, "wscale")
@@ -462,13 +471,26 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
         if t is not None:
             _check(t, name)
     n, cin = x.shape[0], x.shape[1]
-    hw = x.numel() // (n * cin)
     cout = wscale.numel()
     cin_pad = wcodes.shape[1]
-    y = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-    stat, zflag = _stat_target(n, x.device, want_stat)
     if in_stat is not None and cur_out is None:
         cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+    stat, zflag = _stat_target(n, x.device, want_stat)
+    if stride != 1:
+        if x.dim() != 4:
+            raise ValueError("a strided 1x1 convolution needs (N, Cin, H, W) activations, got %s" % (tuple(x.shape),))
+        h, w = x.shape[2], x.shape[3]
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, ho * wo), dtype=torch.uint8, device=x.device)
+        check_call(_lib_().fq_pwconv_i8_strided(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n,
+                                                cin, cin_pad, cout, h, w, int(stride), _ptr(in_stat), _ptr(in_thr),
+                                                int(width), int(flags), _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift),
+                                                _ACTS[act] | zflag | (PW_FORMS[form] << 12), _ptr(stat), _ptr(ws),
+                                                _stream(x)))
+        return y, stat
+    hw = x.numel() // (n * cin)
+    y = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, hw), dtype=torch.uint8, device=x.device)
     check_call(_lib_().fq_pwconv_i8(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin,
                                     cin_pad, cout, hw, _ptr(in_stat), _ptr(in_thr), int(width), int(flags),

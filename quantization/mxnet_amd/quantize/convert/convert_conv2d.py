@@ -190,9 +190,13 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
         and not getattr(block, "_fq_no_int8", False)
     if on_codes:
         codes, scales, rowsum = _pointwise_weight_codes(block, args, weight_raw, weight_q)
-        conv = ops.conv3x3_i8 if fz.get("kind") == "3x3" else ops.pwconv_i8
-        y, stat = conv(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
-                       bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
+        if fz.get("kind") == "3x3":
+            y, stat = ops.conv3x3_i8(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
+                                     bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
+        else:
+            y, stat = ops.pwconv_i8(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
+                                    bn_scale=scale, bn_shift=shift, act=fz["act"], stride=block._kwargs["stride"][0],
+                                    **plan)
     else:
         if plan:          # input is to be quantised but the integer path does not apply: explicit apply pass
             t = contiguous(x._t)

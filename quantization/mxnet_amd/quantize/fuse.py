@@ -80,12 +80,18 @@ def _is_dw3x3(b):
 
 
 def _is_pw1x1(b):
+    """A converted 1x1 convolution fq_pwconv_i8 can take: stride 1, or stride 2 (the shortcut / first convolutions of the
+    ResNet stages) when the input channel count is one the strided form is built for."""
     if type(b) is not nn.Conv2D or not hasattr(b, "quantize_args"):
         return False
     k = b._kwargs
-    return (k["kernel"] == (1, 1) and k["pad"] == (0, 0) and k["dilate"] == (1, 1) and k["stride"] == (1, 1)
-            and k["num_group"] == 1 and k["layout"] == "NCHW" and b.act is None
-            and not b.quantize_args.fake_bn)
+    if not (k["kernel"] == (1, 1) and k["pad"] == (0, 0) and k["dilate"] == (1, 1) and k["num_group"] == 1
+            and k["layout"] == "NCHW" and b.act is None and not b.quantize_args.fake_bn):
+        return False
+    if k["stride"] == (1, 1):
+        return True
+    cin = b.weight.shape[1] if b.weight.shape is not None and len(b.weight.shape) == 4 else 0
+    return k["stride"] == (2, 2) and cin > 0 and ops.pwconv_strided_supported(cin)
 
 
 def _is_dense3x3(b):

@@ -544,6 +544,51 @@ def _pwconv_case(dev, ops, case, mode, form=None):
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
 
 
+PW_S2_CASES = [(2, 256, 512, 14, 14), (3, 512, 1024, 7, 7), (2, 64, 128, 9, 11), (2, 1024, 2048, 5, 5), (3, 256, 128, 28, 28),
+               (4, 96, 40, 6, 7)]
+
+
+@pytest.mark.parametrize("case", PW_S2_CASES, ids=["%dx%d->%d@%dx%d" % c for c in PW_S2_CASES])
+@pytest.mark.parametrize("mode", ["online_u8_bn_relu", "offline_s8_channel_w4"])
+def test_pwconv_i8_stride2_vs_oracle(dev, ops, case, mode):
+    """The shortcut / first 1x1 convolutions of the ResNet stages: stride 2, no padding, odd and even planes.  The batch
+    statistic is the one of the WHOLE input (what the reference's fake-quant in front of the convolution sees)."""
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + 3)
+    x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+    if "s8" not in mode:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * rng.uniform(0.05, 1.0, (cout, 1, 1, 1))).astype(np.float32)
+    per_channel = "channel" in mode
+    wt_width = 4 if "w4" in mode else 8
+    rps = 1 if per_channel else cout
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), rps, wt_width)
+    kw, okw = {}, {}
+    if mode.startswith("online"):
+        stat = O.absmax_per_sample(x)
+        kw.update(in_stat=T(stat, dev), width=8, flags=0)
+        okw.update(in_max=O.batch_mean(stat), signed=False, width=8)
+    else:
+        thr = np.float32(2.3)
+        kw.update(in_thr=T(np.float32([thr]), dev), width=8, flags=ops.act_flags(signed=True))
+        okw.update(in_max=thr, signed=True, width=8)
+    if "bn_relu" in mode:
+        sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+        sh = rng.standard_normal(cout).astype(np.float32)
+        kw.update(bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu")
+        okw.update(bn_scale=sc, bn_shift=sh, act="relu")
+    y, stat_out = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, cur_out=torch.zeros(1, device=dev), stride=2, **kw)
+    want = O.pwconv_i8(x, wt, rps, wt_width, stride=2, **okw)
+    assert tuple(y.shape) == want.shape == (n, cout, (h + 1) // 2, (w + 1) // 2)
+    _eq(N(y), want, "strided pointwise int8 convolution")
+    _eq(N(stat_out), O.absmax_per_sample(want), "statistic")
+    from oracle import host as H
+    _eq(H.pwconv_i8(x, wt, rps, wt_width, stride=2, **okw), want, "host twin vs numpy oracle")
+    with pytest.raises(Exception):     # a strided call on a shape only the generic form would take
+        ops.pwconv_i8(torch.zeros(1, 448, 4, 4, device=dev), *ops.weight_codes(torch.ones(32, 448, 1, 1, device=dev), 32, 8),
+                      in_thr=T(np.float32([1.0]), dev), stride=2)
+
+
 # ---- dense 3x3 convolution on integer codes (int8 MFMA, implicit GEMM over (tap, ci)) -----------------------------------
 C3_CASES = [  # (n, cin, cout, h, w): every K/32 (2, 4, 8, 16), both wavefront arrangements (Cout < 128 / >= 128), partial
     # channel tiles (Cout 96, 160), planes narrower than / as wide as / wider than a pixel tile, ragged last blocks, blocks

@@ -23,7 +23,7 @@ for r in rows:
 tot = sum(sum(v) for v in g.values()) / steps
 for (name, grid), v in sorted(g.items(), key=lambda kv: -sum(kv[1])):
     per_step = sum(v) / steps
-    if per_step < min_us or flt not in name:
+    if per_step < min_us or flt not in name or len(v) < 0.9 * steps:     # (less than once per step: library warm-up / search)
         continue
     v.sort()
     print("  %-44s wgs %6d  calls/step %5.1f  median %7.1f us  per step %7.1f us" % (name[:44], grid, len(v) / steps, v[len(v) // 2], per_step))
