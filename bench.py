@@ -49,6 +49,8 @@ KERNEL_NAMES = {
     "pool": "gap_stat_kernel (global average pool + statistic, 4 B/in-elem + 4 B/out-elem)",
     "pwconv": "pwconv_{split,stream}_kernel (1x1 conv on int8 codes: fake-quant on load, exact int32 MFMA sums, "
               "BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
+    "conv3x3": "conv3x3_i8_kernel (dense 3x3 conv on int8 codes: implicit GEMM over (tap, ci), fake-quant on load, exact "
+               "int32 MFMA sums, BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
     "weight": "weight fake-quant kernels (8 B/elem)",
     "histogram": "histogram_kernel (4 B/elem)",
     "global_max": "minmax_kernel (4 B/elem)",
