@@ -188,11 +188,13 @@ int fq_stem_conv3x3s2(const float* x, const float* w_tap_major, const float* bia
  * folded into the load and BatchNorm/activation/statistic folded into the store — per depthwise layer x is read once
  * and y written once (the reference: fake-quant 4 passes, F.Convolution, BatchNorm, ReLU, next layer's statistic).
  *   xq   = in_thr/in_stat given ? roundf(clip(x, lo, max_)/(max_/levels + eps)) * (max_/levels) : x
- *          with max_ = in_thr[0] (offline / pre-reduced) or the batch mean of in_stat[0..n) (online) — bit-identical to
- *          fq_fake_quant_offline / _online_prestat;
+ *          with max_ = in_thr[0] (offline / pre-reduced) when in_thr is given, else the batch mean of in_stat[0..n)
+ *          (online) — bit-identical to fq_fake_quant_offline / _online_prestat.  BOTH may be given: in_thr quantises and
+ *          the batch mean of in_stat is only written to out_current_max (the reference computes `current_input_max` in
+ *          every mode, convert_conv2d.py:56) — the same holds for fq_pwconv_i8(_strided) and fq_conv3x3_i8;
  *   acc  = sum over ky,kx (row-major) of fmaf(w[c][ky][kx], xq[..], acc), zero padding, + bias[c] if given;
  *   y    = act(acc * bn_scale[c] + bn_shift[c]) if bn_scale given else act(acc);
- *   stat_out[n] (may be NULL) <- max|y[n]|;  out_current_max (may be NULL; online only) <- max_.
+ *   stat_out[n] (may be NULL) <- max|y[n]|;  out_current_max (may be NULL) <- batch mean of in_stat when in_stat is given.
  * x: (n, c, h, w);  w: (c, 1, 3, 3);  y: (n, c, ho, wo), ho = (h - 1) / stride + 1.                                 */
 int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
                  int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,

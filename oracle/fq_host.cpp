@@ -403,7 +403,7 @@ int fq_dwconv3x3_host(const float* x, const float* w, const float* bias, float* 
                       float* stat_out, fqStream_t) {
   REQUIRE(x && w && y && n > 0 && c > 0 && h > 0 && wdt > 0, "fq_dwconv3x3_host: bad arguments");
   REQUIRE(stride == 1 || stride == 2, "fq_dwconv3x3_host: stride must be 1 or 2");
-  REQUIRE(!(in_stat && in_thr), "fq_dwconv3x3_host: give in_stat OR in_thr");
+  // in_stat alone: online; in_thr alone: offline; both: offline, the statistic only feeds out_current_max
   REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_dwconv3x3_host: bn_scale and bn_shift go together");
   const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
   act &= ~FQ_STAT_PREZEROED;
@@ -411,8 +411,8 @@ int fq_dwconv3x3_host(const float* x, const float* w, const float* bias, float* 
   const bool quant = in_stat || in_thr;
   QP q = {0, 0, 1, 1};
   if (quant) {
-    const float max_ = in_stat ? batch_mean(in_stat, n) : in_thr[0];
-    if (in_stat && out_current_max) out_current_max[0] = max_;
+    const float max_ = in_thr ? in_thr[0] : batch_mean(in_stat, n);
+    if (in_stat && out_current_max) out_current_max[0] = in_thr ? batch_mean(in_stat, n) : max_;
     q = make_qp(max_, act_levels(in_width, in_flags), (in_flags & FQ_ACT_LO_NEG_MAX) != 0,
                 (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps);
   }
@@ -486,14 +486,14 @@ int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale,
                       void*, fqStream_t) {
   REQUIRE(x && wcodes && wscale && wsum && y, "fq_pwconv_i8_host: null pointer");
   REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && cin_pad >= cin, "fq_pwconv_i8_host: bad shape");
-  REQUIRE((in_stat != nullptr) != (in_thr != nullptr), "fq_pwconv_i8_host: give in_stat OR in_thr");
+  REQUIRE(in_stat != nullptr || in_thr != nullptr, "fq_pwconv_i8_host: give in_stat, in_thr or both");
   REQUIRE(in_width >= 2 && in_width <= 8, "fq_pwconv_i8_host: input width does not fit int8 codes");
   REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_pwconv_i8_host: bn_scale and bn_shift go together");
   const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
   act &= ~FQ_STAT_PREZEROED;
   zero_stat(stat_out, n, prezeroed);
-  const float max_ = in_stat ? batch_mean(in_stat, n) : in_thr[0];
-  if (in_stat && out_current_max) out_current_max[0] = max_;
+  const float max_ = in_thr ? in_thr[0] : batch_mean(in_stat, n);
+  if (in_stat && out_current_max) out_current_max[0] = in_thr ? batch_mean(in_stat, n) : max_;
   const QP q = make_qp(max_, act_levels(in_width, in_flags), (in_flags & FQ_ACT_LO_NEG_MAX) != 0, kEps);
   const float sx = q.scale;
   (void)wsum;   // the device kernel stores unsigned codes re-centred by 128 and adds 128 * wsum back: same integer sum
@@ -561,14 +561,14 @@ int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale
                        fqStream_t) {
   REQUIRE(x && wcodes && wscale && wsum && y, "fq_conv3x3_i8_host: null pointer");
   REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "fq_conv3x3_i8_host: bad shape");
-  REQUIRE((in_stat != nullptr) != (in_thr != nullptr), "fq_conv3x3_i8_host: give in_stat OR in_thr");
+  REQUIRE(in_stat != nullptr || in_thr != nullptr, "fq_conv3x3_i8_host: give in_stat, in_thr or both");
   REQUIRE(in_width >= 2 && in_width <= 8, "fq_conv3x3_i8_host: input width does not fit int8 codes");
   REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_conv3x3_i8_host: bn_scale and bn_shift go together");
   const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
   act &= ~FQ_STAT_PREZEROED;
   zero_stat(stat_out, n, prezeroed);
-  const float max_ = in_stat ? batch_mean(in_stat, n) : in_thr[0];
-  if (in_stat && out_current_max) out_current_max[0] = max_;
+  const float max_ = in_thr ? in_thr[0] : batch_mean(in_stat, n);
+  if (in_stat && out_current_max) out_current_max[0] = in_thr ? batch_mean(in_stat, n) : max_;
   const QP q = make_qp(max_, act_levels(in_width, in_flags), (in_flags & FQ_ACT_LO_NEG_MAX) != 0, kEps);
   const float sx = q.scale;
   (void)wsum;

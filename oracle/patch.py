@@ -186,7 +186,7 @@ def dwconv3x3(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8, fla
         in_max = O.batch_mean(_np(in_stat).reshape(-1)[:x.shape[0]])
         if cur_out is not None:
             cur_out.copy_(_t(np.asarray([in_max], dtype=F32)))
-    elif in_thr is not None:
+    if in_thr is not None:                    # offline (the statistic, when given too, only fed cur_out)
         in_max = F32(_np(in_thr).reshape(-1)[0])
     y = O.dwconv3x3(_np(x), _np(w), None if bias is None else _np(bias), stride, in_max, signed, width, lo_neg,
                     None if bn_scale is None else _np(bn_scale), None if bn_shift is None else _np(bn_shift),
@@ -218,7 +218,7 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
         in_max = O.batch_mean(_np(in_stat).reshape(-1)[:x.shape[0]])
         if cur_out is not None:
             cur_out.copy_(_t(np.asarray([in_max], dtype=F32)))
-    else:
+    if in_thr is not None:                    # offline (the statistic, when given too, only fed cur_out)
         in_max = F32(_np(in_thr).reshape(-1)[0])
     a = _np(x)
     sx = O.act_scale(in_max, signed, width)
@@ -254,7 +254,7 @@ def conv3x3_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wi
         in_max = O.batch_mean(_np(in_stat).reshape(-1)[:x.shape[0]])
         if cur_out is not None:
             cur_out.copy_(_t(np.asarray([in_max], dtype=F32)))
-    else:
+    if in_thr is not None:                    # offline (the statistic, when given too, only fed cur_out)
         in_max = F32(_np(in_thr).reshape(-1)[0])
     a = _np(x)
     n, cin, h, w = a.shape

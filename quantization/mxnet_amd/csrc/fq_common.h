@@ -251,6 +251,25 @@ __device__ __forceinline__ float batch_mean_dev(const float* __restrict__ v, int
   return (float)acc / (float)n;
 }
 
+// The threshold a fused consumer quantises with, and the reference's `current_input_max` side output (convert_conv2d.py:56
+// computes the batch statistic in EVERY mode).  Online (no in_thr): the mean of the per-sample maxima is the threshold and
+// workgroup 0 writes it out.  Offline: the stored threshold quantises; when the per-sample maxima are given as well, ONE
+// wavefront of workgroup 0 derives their mean for `cur_max_out` - instead of a one-workgroup kernel launch per layer in
+// front of every consumer (53 launches of ~4 us per ResNet-50 / MobileNetV2 forward).  Call with the whole workgroup.
+__device__ __forceinline__ float input_threshold(const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr,
+                                                 float* __restrict__ cur_max_out, bool first_wg) {
+  if (in_thr != nullptr) {
+    if (in_stat != nullptr && cur_max_out != nullptr && first_wg && threadIdx.x < 64) {
+      const float cm = batch_mean_dev(in_stat, n);
+      if (threadIdx.x == 0) cur_max_out[0] = cm;
+    }
+    return in_thr[0];
+  }
+  const float m = batch_mean_dev(in_stat, n);
+  if (cur_max_out != nullptr && first_wg && threadIdx.x == 0) cur_max_out[0] = m;
+  return m;
+}
+
 struct QParams {
   float lo, hi;      // clip bounds
   float denom;       // scale + eps

@@ -95,9 +95,8 @@ __global__ __launch_bounds__(kBlock, LB) void conv3x3_i8_kernel(
   float bufa[16], bufb[16];
   if (wave < NU) issue(wave, bufa);                                     // in flight during the set-up
   FQ_PIN();
-  const float max_ = in_stat != nullptr ? batch_mean_dev(in_stat, n) : in_thr[0];
+  const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, item == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
-  if (in_stat != nullptr && cur_max_out != nullptr && item == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
   const float sx = q.scale;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
   for (int i = threadIdx.x; i < NCH; i += kBlock) {
@@ -287,8 +286,9 @@ int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, con
              "512 (got %lld): slabs of 32 channels must not straddle taps and 9 * Cin codes must sum within int32",
              (long long)cin);
   FQ_REQUIRE(cout >= 32, "fq_conv3x3_i8: Cout must be at least 32, got %lld", (long long)cout);
-  FQ_REQUIRE((in_stat != nullptr) != (in_thr != nullptr), "fq_conv3x3_i8: give in_stat (online) OR in_thr (offline)");
-  FQ_REQUIRE(in_stat == nullptr || out_current_max != nullptr, "fq_conv3x3_i8: online mode needs out_current_max");
+  FQ_REQUIRE(in_stat != nullptr || in_thr != nullptr, "fq_conv3x3_i8: give in_stat (online), in_thr (offline) or both "
+             "(offline, the statistic only feeds out_current_max)");
+  FQ_REQUIRE(in_thr != nullptr || out_current_max != nullptr, "fq_conv3x3_i8: online mode needs out_current_max");
   FQ_REQUIRE(in_width >= 2 && in_width <= 8, "fq_conv3x3_i8: input width %d does not fit int8 codes", in_width);
   FQ_REQUIRE(!(in_flags & (FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "fq_conv3x3_i8: unsupported activation flags");
   FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_conv3x3_i8: bn_scale and bn_shift go together");

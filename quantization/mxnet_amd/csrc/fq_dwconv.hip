@@ -48,9 +48,8 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_kernel(const floa
   q.lo = q.hi = q.denom = q.scale = 0.0f;
   q.rden = 0.0;
   if (QUANT) {
-    const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+    const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
     q = make_qparams(max_, levels, lo_neg_max != 0, eps);
-    if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
   }
   const int lds_elems = g.P * g.IR * g.WS;
   const int plane_in = g.H * g.W, plane_out = g.Ho * g.Wo;
@@ -227,9 +226,8 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
   bool q_ready = !QUANT;
   auto ensure_q = [&]() __attribute__((always_inline)) {
     if (QUANT && !q_ready) {
-      const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+      const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
       q = make_qparams(max_, levels, lo_neg_max != 0, eps);
-      if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
       q_ready = true;
     }
   };
@@ -474,9 +472,8 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
   q.lo = q.hi = q.denom = q.scale = 0.0f;
   q.rden = 0.0;
   if (QUANT) {
-    const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+    const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
     q = make_qparams(max_, levels, lo_neg_max != 0, eps);
-    if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg_in_wave = lane / g.SEG;
@@ -693,7 +690,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
              "fq_dwconv3x3: bad shape (n=%lld c=%lld h=%lld w=%lld)", (long long)n, (long long)c, (long long)h,
              (long long)wdt);
   FQ_REQUIRE(stride == 1 || stride == 2, "fq_dwconv3x3: stride must be 1 or 2, got %d", stride);
-  FQ_REQUIRE(!(in_stat && in_thr), "fq_dwconv3x3: give in_stat (online) OR in_thr (offline), not both");
+  // in_stat alone: online; in_thr alone: offline; both: offline, the statistic only feeds out_current_max
   FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_dwconv3x3: bn_scale and bn_shift go together");
   const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
   act &= ~FQ_STAT_PREZEROED;
@@ -739,11 +736,11 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
                      bn_shift, act, stat_out)
     if (stride == 1) {
       if (!quant) FQ_DWC4(1, false, false);
-      else if (in_stat) FQ_DWC4(1, true, true);
+      else if (!in_thr) FQ_DWC4(1, true, true);
       else FQ_DWC4(1, true, false);
     } else {
       if (!quant) FQ_DWC4(2, false, false);
-      else if (in_stat) FQ_DWC4(2, true, true);
+      else if (!in_thr) FQ_DWC4(2, true, true);
       else FQ_DWC4(2, true, false);
     }
 #undef FQ_DWC4
@@ -784,11 +781,11 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
                      bn_shift, act, stat_out)
     if (stride == 1) {
       if (!quant) FQ_DWC(1, false, false);
-      else if (in_stat) FQ_DWC(1, true, true);
+      else if (!in_thr) FQ_DWC(1, true, true);
       else FQ_DWC(1, true, false);
     } else {
       if (!quant) FQ_DWC(2, false, false);
-      else if (in_stat) FQ_DWC(2, true, true);
+      else if (!in_thr) FQ_DWC(2, true, true);
       else FQ_DWC(2, true, false);
     }
 #undef FQ_DWC
@@ -850,11 +847,11 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
                      stat_out)
   if (stride == 1) {
     if (!quant) FQ_DW(1, false, false);
-    else if (in_stat) FQ_DW(1, true, true);
+    else if (!in_thr) FQ_DW(1, true, true);
     else FQ_DW(1, true, false);
   } else {
     if (!quant) FQ_DW(2, false, false);
-    else if (in_stat) FQ_DW(2, true, true);
+    else if (!in_thr) FQ_DW(2, true, true);
     else FQ_DW(2, true, false);
   }
 #undef FQ_DW

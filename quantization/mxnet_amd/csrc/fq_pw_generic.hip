@@ -35,9 +35,8 @@ __global__ __launch_bounds__(kBlock) void quant_transpose_i8_kernel(
     int64_t tiles, const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels,
     int lo_neg_max, float eps, int zoff, float* __restrict__ cur_max_out) {
   __shared__ int lds[64 * 17];
-  const float max_ = ONLINE ? batch_mean_dev(in_stat, n) : in_thr[0];
+  const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
-  if (ONLINE && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
   const int c = threadIdx.x & 15;            // pixel quad
   const int rq = threadIdx.x >> 4;           // channel quad (0..15)
   const bool hw_vec = (HW & 3) == 0;
@@ -264,7 +263,7 @@ int pw_two_kernels(const PwCall& a) {
     const int ptiles = (int)((a.hw + 63) / 64), ctiles = (int)(a.cin_pad / 64);
     const int64_t tiles = a.n * ptiles * ctiles;
     const int grid = grid_for(tiles);
-    if (a.in_stat)
+    if (a.in_thr == nullptr)
       hipLaunchKernelGGL((quant_transpose_i8_kernel<true>), dim3(grid), dim3(kBlock), 0, a.st, a.x, codes, (int)a.cin,
                          (int)a.cin_pad, (int)a.hw, ptiles, ctiles, tiles, a.in_stat, (int)a.n, a.in_thr, a.levels,
                          a.lo_neg, kEps, a.zoff, a.out_current_max);
@@ -292,7 +291,7 @@ int pw_two_kernels(const PwCall& a) {
   int64_t grid64 = tiles < (int64_t)num_cu() * 32 ? tiles : (int64_t)num_cu() * 32;
   grid64 = grid64 / g.passes * g.passes;                  // multiple of the channel blocks (tiles is one already)
   const int grid = (int)(grid64 < g.passes ? g.passes : grid64);
-  const float* sx_src = a.in_stat ? a.out_current_max : a.in_thr;
+  const float* sx_src = a.in_thr ? a.in_thr : a.out_current_max;      // offline: the stored threshold; online: kernel A wrote the batch mean
   hipLaunchKernelGGL((pwconv_i8_kernel<0>), dim3(grid), dim3(kBlock), 0, a.st, (const int8_t*)codes, a.wcodes, a.wscale,
                      (const int*)a.wsum, a.bias, a.y, g, tiles, sx_src, a.levels, a.bn_scale, a.bn_shift, a.act,
                      a.stat_out);

@@ -111,9 +111,8 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
   for (int i = 0; i < RB; ++i)
     if (wave + 4 * i < kt_real) issue(wave + 4 * i, buf[i]);            // in flight during the set-up
   FQ_PIN();
-  const float max_ = in_stat != nullptr ? batch_mean_dev(in_stat, n) : in_thr[0];
+  const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, item == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
-  if (in_stat != nullptr && cur_max_out != nullptr && item == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
   const float sx = q.scale;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
   for (int i = threadIdx.x; i < NCH; i += kBlock) {

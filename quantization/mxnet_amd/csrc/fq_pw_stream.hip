@@ -85,9 +85,8 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   issue(nxt, 0, bufa);                                                  // in flight during the whole set-up
   FQ_PIN();
 
-  const float max_ = in_stat != nullptr ? batch_mean_dev(in_stat, n) : in_thr[0];
+  const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, blockIdx.x == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
-  if (in_stat != nullptr && cur_max_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) cur_max_out[0] = max_;
   const float sx = q.scale;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
   // weights -> fragment order: fragment (ct, kt), lane (row % 32) + 32 * (16-byte chunk % 2)

@@ -81,9 +81,9 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
              "fq_pwconv_i8: bad shape");
   FQ_REQUIRE(cin_pad >= cin && cin_pad % 64 == 0 && cin_pad <= 8192, "fq_pwconv_i8: cin_pad=%lld must be a multiple "
              "of 64 covering cin=%lld", (long long)cin_pad, (long long)cin);
-  FQ_REQUIRE((in_stat != nullptr) != (in_thr != nullptr), "fq_pwconv_i8: give in_stat (online) OR in_thr (offline): the "
-             "integer path needs a quantised input");
-  FQ_REQUIRE(in_stat == nullptr || out_current_max != nullptr, "fq_pwconv_i8: online mode needs out_current_max (the "
+  FQ_REQUIRE(in_stat != nullptr || in_thr != nullptr, "fq_pwconv_i8: give in_stat (online), in_thr (offline) or both "
+             "(offline, the statistic only feeds out_current_max): the integer path needs a quantised input");
+  FQ_REQUIRE(in_thr != nullptr || out_current_max != nullptr, "fq_pwconv_i8: online mode needs out_current_max (the "
              "GEMM reads the batch statistic from it)");
   FQ_REQUIRE(in_width >= 2 && in_width <= 8, "fq_pwconv_i8: input width %d does not fit int8 codes", in_width);
   FQ_REQUIRE(!(in_flags & (FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "fq_pwconv_i8: unsupported activation flags");

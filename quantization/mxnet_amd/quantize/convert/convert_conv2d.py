@@ -134,11 +134,14 @@ def fused_input_plan(block, x, input_max, flags, width):
             plan = dict(in_thr=input_max._t if block.quantize_input_offline else v.cur, width=width, flags=flags)
     elif online:
         plan = dict(in_stat=stat, width=width, flags=flags, cur_out=v.cur)         # the kernel writes `cur`
-    else:
+    elif wanted:
+        # offline: the stored threshold quantises; the kernel derives `current_input_max` from the statistic on the side
+        # (one wavefront of its first workgroup) instead of a separate one-workgroup launch in front of every block
+        plan = dict(in_thr=input_max._t, width=width, flags=flags)
         if stat is not None:
-            ops.batch_mean(stat, out=v.cur)
-        if wanted:
-            plan = dict(in_thr=input_max._t, width=width, flags=flags)
+            plan.update(in_stat=stat, cur_out=v.cur)
+    elif stat is not None:
+        ops.batch_mean(stat, out=v.cur)
     v.finish(block)
     return plan
 
@@ -200,10 +203,12 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
     else:
         if plan:          # input is to be quantised but the integer path does not apply: explicit apply pass
             t = contiguous(x._t)
-            if "in_stat" in plan:
+            if "in_thr" not in plan:
                 xq = ops.fake_quant_online_prestat(t, plan["in_stat"], plan["width"], plan["flags"],
                                                    cur_out=plan.get("cur_out"))[0]
             else:
+                if "in_stat" in plan:
+                    ops.batch_mean(plan["in_stat"], out=plan["cur_out"])
                 xq = ops.fake_quant_offline(t, plan["in_thr"], plan["width"], plan["flags"], want_stat=False)[0]
             x = NDArray(xq)
         out = block.origin_forward(F, x, weight_q, bias)

@@ -589,6 +589,35 @@ def test_pwconv_i8_stride2_vs_oracle(dev, ops, case, mode):
                       in_thr=T(np.float32([1.0]), dev), stride=2)
 
 
+def test_offline_consumers_report_the_batch_statistic_on_the_side(dev, ops):
+    """Offline mode with the per-sample maxima passed as well: the stored threshold quantises, `current_input_max` (which the
+    reference computes in every mode, convert_conv2d.py:56) comes out of the same launch - for every fused consumer."""
+    rng = np.random.default_rng(41)
+    thr = T(np.float32([1.7]), dev)
+
+    def check(run, x):
+        stat = O.absmax_per_sample(x)
+        cur = torch.full((1,), -1.0, device=dev)
+        y_both, s_both = run(dict(in_thr=thr, in_stat=T(stat, dev), cur_out=cur))
+        y_off, s_off = run(dict(in_thr=thr))
+        assert torch.equal(y_both, y_off) and torch.equal(s_both, s_off)
+        _eq(N(cur), np.float32([O.batch_mean(stat)]), "current_input_max")
+
+    for n, cin, cout, h, w, form in [(3, 512, 256, 7, 7, "split"), (2, 64, 128, 28, 28, "stream"), (2, 448, 96, 6, 6, "two_kernels")]:
+        x = np.maximum(rng.standard_normal((n, cin, h, w)) * 2, 0).astype(np.float32)
+        wt = (rng.standard_normal((cout, cin, 1, 1)) * 0.2).astype(np.float32)
+        codes = ops.weight_codes(T(wt, dev), cout, 8)
+        check(lambda kw: ops.pwconv_i8(T(x, dev), *codes, width=8, flags=0, act="relu", form=form, **kw), x)
+    for n, c, h, w, stride in [(2, 64, 112, 112, 1), (3, 128, 14, 14, 2), (3, 256, 7, 7, 1)]:      # the three depthwise forms
+        x = np.maximum(rng.standard_normal((n, c, h, w)) * 2, 0).astype(np.float32)
+        wt = (rng.standard_normal((c, 1, 3, 3)) * 0.3).astype(np.float32)
+        check(lambda kw: ops.dwconv3x3(T(x, dev), T(wt, dev), stride=stride, width=8, flags=0, act="relu", **kw), x)
+    x = np.maximum(rng.standard_normal((2, 64, 9, 9)) * 2, 0).astype(np.float32)
+    wt = (rng.standard_normal((64, 64, 3, 3)) * 0.2).astype(np.float32)
+    codes = ops.weight_codes_3x3(T(wt, dev), 64, 8)
+    check(lambda kw: ops.conv3x3_i8(T(x, dev), *codes, width=8, flags=0, act="relu", **kw), x)
+
+
 # ---- dense 3x3 convolution on integer codes (int8 MFMA, implicit GEMM over (tap, ci)) -----------------------------------
 C3_CASES = [  # (n, cin, cout, h, w): every K/32 (2, 4, 8, 16), both wavefront arrangements (Cout < 128 / >= 128), partial
     # channel tiles (Cout 96, 160), planes narrower than / as wide as / wider than a pixel tile, ragged last blocks, blocks
