@@ -235,12 +235,17 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
 /* The same for a STRIDED 1x1 convolution (stride 2 in both directions, no padding: the shortcut and first convolutions
  * of the ResNet stages): x is (n, cin, h, w), y is (n, cout, ceil(h/2), ceil(w/2)) - the kernel reads every second pixel of
  * every second row, nothing is subsampled beforehand.  stride = 1 is fq_pwconv_i8 with hw = h * w.  Strided calls need a
- * shape the split form takes (cin_pad / 32 in {2, 4, 6, 8, 10, 12, 16, 18, 30, 32, 64}), FQ_ERR_INVALID otherwise.    */
+ * shape the split form takes (cin_pad / 32 in {2, 4, 6, 8, 10, 12, 16, 18, 30, 32, 64}), FQ_ERR_INVALID otherwise.
+ * `residual` (may be NULL; y's shape): the shortcut of a residual unit, added after BatchNorm and before the activation,
+ *   y = act((acc * sx * sw + bias) * bn_scale + bn_shift + residual)
+ * - the `(body(x) + shortcut).relu()` tail of the ResNet units and the `out + x` of MobileNetV2's linear bottlenecks in the
+ * epilogue of the unit's last 1x1 convolution (its output is then never written and read back: 8 instead of 16 bytes per
+ * element).  Needs a shape the split or the streaming form takes.                                                   */
 int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                          const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h,
                          int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,
                          unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
-                         int act, float* stat_out, void* ws, fqStream_t stream);
+                         int act, float* stat_out, const float* residual, void* ws, fqStream_t stream);
 
 /* Dense 3x3 convolution (stride 1, padding 1, no groups / dilation) on the integer codes: the same identity as
  * fq_pwconv_i8 with K = 9 * Cin, i.e. what the reference's fp32 F.Convolution of the two fake-quantised tensors computes

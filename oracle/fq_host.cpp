@@ -479,11 +479,11 @@ int fq_weight_codes_host(const float* w, int64_t rows, int64_t row_len, int rows
   return FQ_OK;
 }
 
-int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
-                      const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
-                      const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
-                      float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
-                      void*, fqStream_t) {
+static int pwconv_i8_impl(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                          const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
+                          const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                          float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                          const float* residual) {
   REQUIRE(x && wcodes && wscale && wsum && y, "fq_pwconv_i8_host: null pointer");
   REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && cin_pad >= cin, "fq_pwconv_i8_host: bad shape");
   REQUIRE(in_stat != nullptr || in_thr != nullptr, "fq_pwconv_i8_host: give in_stat, in_thr or both");
@@ -523,6 +523,7 @@ int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale,
               v = v * bn_scale[co];
               v = v + bn_shift[co];
             }
+            if (residual) v = v + residual[(s * cout + co) * hw + p0 + p];
             y[(s * cout + co) * hw + p0 + p] = act_of(v, act);
           }
         }
@@ -532,24 +533,34 @@ int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale,
   return FQ_OK;
 }
 
-// Strided 1x1 convolution: the stride-1 arithmetic on the subsampled input x[:, :, ::s, ::s].
+int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                      const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
+                      const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                      float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                      void*, fqStream_t) {
+  return pwconv_i8_impl(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, hw, in_stat, in_thr, in_width, in_flags,
+                        out_current_max, bn_scale, bn_shift, act, stat_out, nullptr);
+}
+
+// Strided 1x1 convolution: the stride-1 arithmetic on the subsampled input x[:, :, ::s, ::s]; optional residual operand of
+// y's shape, added after BatchNorm and before the activation.
 int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                               const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout,
                               int64_t h, int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,
                               unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
-                              int act, float* stat_out, void* ws, fqStream_t stream) {
+                              int act, float* stat_out, const float* residual, void*, fqStream_t) {
   REQUIRE(x && h > 0 && w > 0 && (stride == 1 || stride == 2), "fq_pwconv_i8_strided_host: bad arguments");
   const int64_t ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
   if (stride == 1)
-    return fq_pwconv_i8_host(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, h * w, in_stat, in_thr, in_width,
-                             in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, ws, stream);
+    return pwconv_i8_impl(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, h * w, in_stat, in_thr, in_width,
+                          in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual);
   std::vector<float> sub((size_t)(n * cin * ho * wo));
 #pragma omp parallel for schedule(static)
   for (int64_t pc = 0; pc < n * cin; ++pc)
     for (int64_t r = 0; r < ho; ++r)
       for (int64_t c = 0; c < wo; ++c) sub[(size_t)((pc * ho + r) * wo + c)] = x[(pc * h + r * stride) * w + c * stride];
-  return fq_pwconv_i8_host(sub.data(), wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, ho * wo, in_stat, in_thr,
-                           in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, ws, stream);
+  return pwconv_i8_impl(sub.data(), wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, ho * wo, in_stat, in_thr,
+                        in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual);
 }
 
 // Dense 3x3 convolution (stride 1, pad 1) on the integer codes: exact integer sums over (ky, kx, ci), zero padding = code 0.

@@ -450,10 +450,10 @@ def weight_codes(w, rows_per_scale, width=8):
 
 
 def pwconv_i8(x, w, rows_per_scale, wt_width, in_max, signed=False, width=8, lo_neg_max=None, bias=None,
-              bn_scale=None, bn_shift=None, act=None, stride=1):
+              bn_scale=None, bn_shift=None, act=None, stride=1, residual=None):
     """Arithmetic of `fq_pwconv_i8` (`_strided`): integer codes of x and w, EXACT integer dot products, one fp32 multiply
-    by sx*sw[co], bias, folded BN, activation.  A stride only subsamples the input (in_max is the statistic of the WHOLE
-    input, as the reference's fake-quant in front of the convolution sees it)."""
+    by sx*sw[co], bias, folded BN, [+ residual,] activation.  A stride only subsamples the input (in_max is the statistic of
+    the WHOLE input, as the reference's fake-quant in front of the convolution sees it)."""
     x = np.asarray(x, dtype=F32)
     if stride != 1:
         x = np.ascontiguousarray(x[:, :, ::stride, ::stride])
@@ -468,6 +468,11 @@ def pwconv_i8(x, w, rows_per_scale, wt_width, in_max, signed=False, width=8, lo_
     if bias is not None:
         y = (y + np.asarray(bias, dtype=F32)[None, :, None]).astype(F32)
     y = y.reshape((N, cw.shape[0]) + x.shape[2:])
+    if residual is not None:                 # the tail of a residual unit: BN, then the shortcut, then the activation
+        if bn_scale is not None:
+            y = bn_act(y, bn_scale, bn_shift, "none")
+        y = (y + np.asarray(residual, dtype=F32)).astype(F32)
+        bn_scale = None
     if bn_scale is not None:
         return bn_act(y, bn_scale, bn_shift, act or "none")
     if act == "relu":

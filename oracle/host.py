@@ -220,11 +220,11 @@ def weight_codes(w, rows_per_scale, width=8):
 
 
 def pwconv_i8(x, w, rows_per_scale, wt_width, in_max=None, in_stat=None, signed=False, width=8, lo_neg_max=None,
-              bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=False, stride=1):
+              bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=False, stride=1, residual=None):
     x = _f32(x)
-    if stride != 1:
+    if stride != 1 or residual is not None:
         return _pwconv_i8_strided(x, w, rows_per_scale, wt_width, in_max, in_stat, signed, width, lo_neg_max, bias,
-                                  bn_scale, bn_shift, act, want_stat, stride)
+                                  bn_scale, bn_shift, act, want_stat, stride, residual)
     n, cin = x.shape[0], x.shape[1]
     hw = x.size // (n * cin)
     codes, scales, rowsum = weight_codes(w, rows_per_scale, wt_width)
@@ -241,7 +241,7 @@ def pwconv_i8(x, w, rows_per_scale, wt_width, in_max=None, in_stat=None, signed=
 
 
 def _pwconv_i8_strided(x, w, rows_per_scale, wt_width, in_max, in_stat, signed, width, lo_neg_max, bias, bn_scale,
-                       bn_shift, act, want_stat, stride):
+                       bn_shift, act, want_stat, stride, residual=None):
     n, cin, h, wd = x.shape
     codes, scales, rowsum = weight_codes(w, rows_per_scale, wt_width)
     cout = np.asarray(w).shape[0]
@@ -252,7 +252,8 @@ def _pwconv_i8_strided(x, w, rows_per_scale, wt_width, in_max, in_stat, signed, 
     _call("fq_pwconv_i8_strided_host", x, codes, scales, rowsum, None if bias is None else _f32(bias), y, n, cin,
           codes.shape[1], cout, h, wd, _i(stride), None if in_stat is None else _f32(in_stat), thr, _i(width),
           _u(act_flags(signed, lo_neg_max)), cur, None if bn_scale is None else _f32(bn_scale),
-          None if bn_shift is None else _f32(bn_shift), _i(_ACTS[act]), stat, None, None)
+          None if bn_shift is None else _f32(bn_shift), _i(_ACTS[act]), stat,
+          None if residual is None else _f32(residual), None, None)
     return (y, stat) if want_stat else y
 
 

@@ -210,7 +210,7 @@ def pwconv_strided_supported(cin):
 
 
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1):
+              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None):
     signed, lo_neg, _, _ = _flags(flags)
     if stride != 1:
         x = x[:, :, ::stride, ::stride].contiguous()
@@ -232,6 +232,11 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     if bias is not None:
         y = (y + _np(bias)[None, :, None]).astype(F32)
     y = y.reshape((n, cout) + a.shape[2:])
+    if residual is not None:
+        if bn_scale is not None:
+            y = O.bn_act(y, _np(bn_scale), _np(bn_shift), "none")
+        y = (y + _np(residual)).astype(F32)
+        bn_scale = None
     if bn_scale is not None:
         y = O.bn_act(y, _np(bn_scale), _np(bn_shift), act or "none")
     elif act == "relu":

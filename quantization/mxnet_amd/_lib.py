@@ -50,7 +50,7 @@ EXPORTS = {
     "fq_pwconv_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                             _vp, _int, _vp, _vp, _vp]),
     "fq_pwconv_i8_strided": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,
-                                    _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
+                                    _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "fq_conv3x3_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                              _vp, _int, _vp, _vp]),
     "fq_fake_quant_offline": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp, _vp]),

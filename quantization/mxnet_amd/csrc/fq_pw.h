@@ -26,6 +26,7 @@ struct PwCall {
   const float* bn_shift;
   int act;
   float* stat_out;
+  const float* residual;         // (n, cout, hw) tensor added after BatchNorm, before the activation (split / stream forms)
   bool prezeroed;
   void* ws;
   hipStream_t st;

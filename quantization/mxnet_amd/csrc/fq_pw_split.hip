@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSplitGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
-    float* __restrict__ stat_out) {
+    float* __restrict__ stat_out, const float* __restrict__ residual) {
   constexpr int kSlots = 8;
   constexpr int SLABS = (KT + 3) / 4;                                   // slabs a wavefront quantises (kt = wave + 4j < KT)
   constexpr int RB = SLABS < 4 ? SLABS : 4;                             // slabs (16 loads each) in flight per lane
@@ -200,11 +200,20 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
     int64_t y_bytes = (n_samp - s_base) * y_samp - (int64_t)(ch0 + ctl0 * 32) * plane4;
     y_bytes = y_bytes < 0x7FFFFFFFll ? y_bytes : 0x7FFFFFFFll;
     const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp + (int64_t)(ch0 + ctl0 * 32) * plane4, y_bytes);
+    // the residual operand (the shortcut of a ResNet / MobileNetV2 unit) has y's shape: same offsets, added after BatchNorm
+    const bool has_res = residual != nullptr;
+    const fq_rsrc rr = make_rsrc(reinterpret_cast<const char*>(has_res ? residual : y) + s_base * y_samp +
+                                 (int64_t)(ch0 + ctl0 * 32) * plane4, has_res ? y_bytes : 0);
     const unsigned yo = ((smp - s_base) * (unsigned)g.Cout + 4u * h) * plane4 + p * 4u;
     float m = 0.0f;
     auto store_tile = [&](int c, int cv, auto masked_c) __attribute__((always_inline)) {
       constexpr bool MASKED = decltype(masked_c)::value;
       const int cb = (ctl0 + c) * 32 + 4 * h;                           // channel inside the workgroup's group
+      float res[16];
+      if (has_res) {                             // all 16 in flight before the first use (channels past Cout read 0)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) res[i] = buf_ld_f32(rr, yo, (unsigned)(c * 32 + 8 * (i >> 2) + (i & 3)) * plane4);
+      }
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int c0 = cb + 8 * gq;
@@ -222,6 +231,7 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
             v = v * bsc[r];
             v = v + bsh[r];
           }
+          if (has_res) v = v + res[4 * gq + r];
           v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
           const unsigned off = MASKED ? (8 * gq + 4 * h + r < cv ? yo : 0x80000000u) : yo;
           buf_st_f32(yr, off, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
@@ -328,7 +338,7 @@ int pw_try_split(const PwCall& a, bool* taken) {
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the split kernel");                       \
     hipLaunchKernelGGL((pwconv_split_kernel<KT_, CW_, D_, LB_>), dim3((unsigned)grid), dim3(kBlock), ldst, a.st, a.x,  \
                        wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels,   \
-                       a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out);                  \
+                       a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out, a.residual);      \
     launched = true;                                                                                                   \
   }
     // every K: the two default configurations; the power-of-two K of the deep MobileNet / ResNet layers also carry the

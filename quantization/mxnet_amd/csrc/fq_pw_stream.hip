@@ -23,13 +23,15 @@ struct PwsGeom {
   int zoff;
 };
 
-template <int KT>
+// RES: a residual operand of y's shape is added after BatchNorm, before the activation (compile-time: the loads of the
+// residual would otherwise cost the plain instantiations their occupancy)
+template <int KT, bool RES>
 __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wc, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwsGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
-    float* __restrict__ stat_out) {
+    float* __restrict__ stat_out, const float* __restrict__ residual) {
   constexpr int kSlots = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char pws_smem[];
   __shared__ unsigned k_stat[kSlots];
@@ -134,6 +136,14 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
         const v4i z = *reinterpret_cast<const v4i*>(c_zs + cb + 8 * gq);
         acc[4 * gq + 0] = z.x; acc[4 * gq + 1] = z.y; acc[4 * gq + 2] = z.z; acc[4 * gq + 3] = z.w;
       }
+      // residual operand (the shortcut of a ResNet unit; y's shape): requested before the MFMAs, added after BatchNorm
+      float res[RES ? 16 : 1];
+      if (RES) {
+        const fq_rsrc rr = make_rsrc(residual, (int64_t)(cols / HW) * g.Cout * plane * 4);      // (host: y is below 4 GB)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          res[i] = buf_ld_f32(rr, yoff, (unsigned)((ct * 32 + 8 * (i >> 2) + (i & 3)) * plane * 4));
+      }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(ldsA[((ct * KT + kt) << 6) + lane], bfrag[kt], acc, 0, 0, 0);
@@ -153,6 +163,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
             v = v * bsc[r];
             v = v + bsh[r];
           }
+          if (RES) v = v + res[4 * gq + r];
           v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
           // no masks: lanes past the end hold a copy of the last pixel (clamped loads) and re-store its values, and the
           // host guarantees Cout % 32 == 0
@@ -263,20 +274,25 @@ int pw_try_stream(const PwCall& c, bool* taken) {
   const int64_t need = (s.tiles + 3) / 4;
   if (grid > need) grid = need;
   if (int rc = pw_zero_stat(c)) return rc;
-#define FQ_PWS_CASE(KT_)                                                                                               \
-  case KT_: {                                                                                                          \
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_>),         \
+#define FQ_PWS_LAUNCH(KT_, RES_)                                                                                       \
+  {                                                                                                                    \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_, RES_>),   \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess; \
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the streaming kernel");                   \
-    hipLaunchKernelGGL((pwconv_stream_kernel<KT_>), dim3((unsigned)grid), dim3(kBlock), lds, c.st, c.x, c.wcodes,      \
-                       c.wscale, (const int*)c.wsum, c.bias, c.y, s, c.in_stat, (int)c.n, c.in_thr, c.levels, c.lo_neg, \
-                       kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out);                            \
-  } break;
+    hipLaunchKernelGGL((pwconv_stream_kernel<KT_, RES_>), dim3((unsigned)grid), dim3(kBlock), lds, c.st, c.x,          \
+                       c.wcodes, c.wscale, (const int*)c.wsum, c.bias, c.y, s, c.in_stat, (int)c.n, c.in_thr, c.levels, \
+                       c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out, c.residual);      \
+  }
+#define FQ_PWS_CASE(KT_)                                                                                               \
+  case KT_:                                                                                                            \
+    if (c.residual != nullptr) FQ_PWS_LAUNCH(KT_, true) else FQ_PWS_LAUNCH(KT_, false)                                 \
+    break;
   switch (kt) {
     FQ_PWS_CASE(1) FQ_PWS_CASE(2) FQ_PWS_CASE(3) FQ_PWS_CASE(4) FQ_PWS_CASE(6) FQ_PWS_CASE(8)
     default: break;
   }
 #undef FQ_PWS_CASE
+#undef FQ_PWS_LAUNCH
   FQ_LAUNCH_CHECK();
   *taken = true;
   return FQ_OK;

@@ -74,8 +74,8 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
                            const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
                            int stride, int64_t h_in, int64_t w_in, int64_t w_out, const float* in_stat,
                            const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
-                           const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
-                           fqStream_t stream) {
+                           const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                           const float* residual, void* ws, fqStream_t stream) {
   FQ_REQUIRE(x && wcodes && wscale && wsum && y && ws, "fq_pwconv_i8: null pointer");
   FQ_REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && hw < (1ll << 30) && n * hw < (1ll << 31) - 512,
              "fq_pwconv_i8: bad shape");
@@ -102,18 +102,21 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   c.lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
   c.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;      // unsigned codes are stored re-centred so they fit int8
   c.out_current_max = out_current_max; c.bn_scale = bn_scale; c.bn_shift = bn_shift; c.act = act;
-  c.stat_out = stat_out; c.ws = ws; c.st = (hipStream_t)stream;
+  c.stat_out = stat_out; c.residual = residual; c.ws = ws; c.st = (hipStream_t)stream;
   static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split
   c.form = forced_form ? forced_form : pw_form;
   FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6, "fq_pwconv_i8: unknown form %d (1 two kernels, 3 "
              "stream, 6 split; the panel / chunk / tile forms 2, 4, 5 were retired in favour of the split form)", c.form);
   FQ_REQUIRE(stride == 1 || c.form == 0 || c.form == 6, "fq_pwconv_i8_strided: only the split form reads strided inputs");
+  FQ_REQUIRE(residual == nullptr || c.form != 1, "fq_pwconv_i8_strided: the two-kernel form takes no residual operand");
   ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), c.st);
   bool taken = false;
   if (int rc = pw_try_split(c, &taken)) return rc;
   if (taken) return FQ_OK;
   if (int rc = pw_try_stream(c, &taken)) return rc;
   if (taken) return FQ_OK;
+  FQ_REQUIRE(residual == nullptr, "fq_pwconv_i8_strided: a residual operand needs a shape the split or the streaming "
+             "form takes");
   return pw_two_kernels(c);
 }
 
@@ -123,19 +126,20 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
                  const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
                  fqStream_t stream) {
   return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, hw, 1, 0, 0, 0, in_stat, in_thr,
-                         in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, ws, stream);
+                         in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, nullptr, ws, stream);
 }
 
 int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                          const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h,
                          int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,
                          unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
-                         int act, float* stat_out, void* ws, fqStream_t stream) {
+                         int act, float* stat_out, const float* residual, void* ws, fqStream_t stream) {
   FQ_REQUIRE(h > 0 && w > 0 && (stride == 1 || stride == 2), "fq_pwconv_i8_strided: bad plane %lld x %lld or stride %d",
              (long long)h, (long long)w, stride);
   const int64_t ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
   return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, ho * wo, stride, h, w, wo, in_stat,
-                         in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, ws, stream);
+                         in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, ws,
+                         stream);
 }
 
 }  // extern "C"

@@ -458,16 +458,16 @@ def pwconv_strided_supported(cin):
 
 
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1):
+              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None):
     """1x1 convolution on the integer codes (int8 MFMA, exact int32 accumulation) with quantise-on-load and fused
-    BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; stride 1 or 2 (no padding).  Returns (y, stat
-    or None)."""
+    BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; stride 1 or 2 (no padding); `residual` (the
+    output's shape) is added after BatchNorm and before the activation.  Returns (y, stat or None)."""
     _check(x, "x")
     _check(wcodes, "wcodes", torch.int8)
     _check(wscale, "wscale")
     _check(wsum, "wsum", torch.int32)
     for name, t in (("bias", bias), ("in_stat", in_stat), ("in_thr", in_thr), ("bn_scale", bn_scale),
-                    ("bn_shift", bn_shift), ("cur_out", cur_out)):
+                    ("bn_shift", bn_shift), ("cur_out", cur_out), ("residual", residual)):
         if t is not None:
             _check(t, name)
     n, cin = x.shape[0], x.shape[1]
@@ -476,18 +476,20 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     if in_stat is not None and cur_out is None:
         cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
     stat, zflag = _stat_target(n, x.device, want_stat)
-    if stride != 1:
+    if stride != 1 or residual is not None:
         if x.dim() != 4:
             raise ValueError("a strided 1x1 convolution needs (N, Cin, H, W) activations, got %s" % (tuple(x.shape),))
         h, w = x.shape[2], x.shape[3]
         ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
         y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+        if residual is not None and tuple(residual.shape) != tuple(y.shape):
+            raise ValueError("the residual must have the output's shape %s, got %s" % (tuple(y.shape), tuple(residual.shape)))
         ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, ho * wo), dtype=torch.uint8, device=x.device)
         check_call(_lib_().fq_pwconv_i8_strided(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n,
                                                 cin, cin_pad, cout, h, w, int(stride), _ptr(in_stat), _ptr(in_thr),
                                                 int(width), int(flags), _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift),
-                                                _ACTS[act] | zflag | (PW_FORMS[form] << 12), _ptr(stat), _ptr(ws),
-                                                _stream(x)))
+                                                _ACTS[act] | zflag | (PW_FORMS[form] << 12), _ptr(stat), _ptr(residual),
+                                                _ptr(ws), _stream(x)))
         return y, stat
     hw = x.numel() // (n * cin)
     y = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)

@@ -197,9 +197,16 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
             y, stat = ops.conv3x3_i8(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
                                      bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
         else:
+            # the tail of a residual unit (quantize/fuse.py): the shortcut is added in this convolution's epilogue
+            res = getattr(block, "_fq_residual", None)
+            extra = {}
+            if res is not None and block._kwargs["stride"][0] == 1 and tuple(res["t"].shape[2:]) == tuple(x._t.shape[2:]) \
+                    and res["t"].shape[1] == block._kwargs["num_filter"]:
+                extra = dict(residual=res["t"])
+                res["used"] = True
             y, stat = ops.pwconv_i8(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
-                                    bn_scale=scale, bn_shift=shift, act=fz["act"], stride=block._kwargs["stride"][0],
-                                    **plan)
+                                    bn_scale=scale, bn_shift=shift, act=res["act"] if extra else fz["act"],
+                                    stride=block._kwargs["stride"][0], **extra, **plan)
     else:
         if plan:          # input is to be quantised but the integer path does not apply: explicit apply pass
             t = contiguous(x._t)

@@ -157,22 +157,77 @@ def _plain_dw_forward(self, F, x, weight, bias=None):
     return depthwise_fused(self, x, weight, bias, {})
 
 
+def _tail_conv(seq):
+    """The 1x1 convolution that ends a unit's body (followed only by the BatchNorm it folded), when fq_pwconv_i8 can take the
+    unit's shortcut as its residual operand: taken over by fuse_inference, stride 1, no activation of its own."""
+    kids = list(seq._children.values()) if isinstance(seq, (nn.Sequential, nn.HybridSequential)) else []
+    if kids and isinstance(kids[-1], (nn.Sequential, nn.HybridSequential)):      # MobileNetV2: the last conv + BN pair
+        return _tail_conv(kids[-1])
+    if len(kids) < 2 or type(kids[-1]) is not nn.BatchNorm:
+        return None
+    conv, bn = kids[-2], kids[-1]
+    fz = getattr(conv, "_fq_pw_fused", None)
+    if fz is None or fz.get("kind") != "1x1" or fz["bn"] is not bn or fz["act"] != "none":
+        return None
+    return conv if conv._kwargs["stride"] == (1, 1) else None
+
+
+def _with_residual(conv, shortcut, act, run):
+    """Runs `run()` with the shortcut handed to `conv` (convert_conv2d.pointwise_fused adds it in the convolution's epilogue
+    when that call runs on the integer codes).  Returns (output, True) when it was consumed there."""
+    t = shortcut._t if shortcut._t.is_contiguous() else shortcut._t.contiguous()
+    conv._fq_residual = {"t": t, "act": act, "used": False}
+    try:
+        out = run()
+        return out, conv._fq_residual["used"]
+    finally:
+        conv._fq_residual = None
+
+
 def _residual_unit_forward(self, x):
-    """`(body(x) + shortcut(x)).relu()` of the model zoo's ResNet units with the add, the ReLU and the per-sample
-    statistic of the result in ONE pass (fq_add_act_stat) — both quantised consumers of the sum (the next unit's first
-    convolution and, at a stage boundary, its shortcut convolution) then skip their statistic pass."""
+    """`(body(x) + shortcut(x)).relu()` of the model zoo's ResNet units.  When the body ends in a 1x1 convolution that runs on
+    the integer codes (BottleneckV1), the add and the ReLU happen in THAT convolution's epilogue (fq_pwconv_i8_strided's
+    residual operand: the convolution's output is never written and read back); otherwise one pass adds, applies the ReLU
+    and takes the per-sample statistic (fq_add_act_stat).  Either way both quantised consumers of the sum (the next unit's
+    first convolution and, at a stage boundary, its shortcut convolution) skip their statistic pass."""
     from ..mx import autograd
     if autograd.is_recording():
         raise RuntimeError("this net was rewired by quantize.fuse.fuse_inference (inference only): call "
                            "quantize.fuse.unfuse(net) before recording gradients")
     shortcut = x if self.downsample is None else self.downsample(x)
-    h = self.body(x)
+    tail = _tail_conv(self.body)
+    if tail is not None:
+        h, consumed = _with_residual(tail, shortcut, "relu", lambda: self.body(x))
+        if consumed:
+            return h
+    else:
+        h = self.body(x)
     a = h._t if h._t.is_contiguous() else h._t.contiguous()
     b = shortcut._t if shortcut._t.is_contiguous() else shortcut._t.contiguous()
     y, stat = ops.add_act_stat(a, b, "relu", want_stat=True)
     out = NDArray(y)
     out._fq_stat = stat
     return out
+
+
+def _linear_bottleneck_forward(self, x):
+    """MobileNetV2's `out(x) + x`: the add moves into the epilogue of the projection convolution (no activation)."""
+    from ..mx import autograd
+    if autograd.is_recording():
+        raise RuntimeError("this net was rewired by quantize.fuse.fuse_inference (inference only): call "
+                           "quantize.fuse.unfuse(net) before recording gradients")
+    tail = _tail_conv(self.out) if self.use_shortcut else None
+    if tail is None:
+        out = self.out(x)
+        return out + x if self.use_shortcut else out
+    out, consumed = _with_residual(tail, x, "none", lambda: self.out(x))
+    return out if consumed else out + x
+
+
+def _is_linear_bottleneck(b):
+    from ..mx.gluon import model_zoo as zoo
+    return getattr(type(b), "forward", None) is zoo.LinearBottleneck.forward and hasattr(b, "out") \
+        and "forward" not in b.__dict__
 
 
 def _is_residual_unit(b):
@@ -335,6 +390,10 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
         if _is_residual_unit(b) and not hasattr(b, "_fq_residual_fused"):
             b._fq_residual_fused = True
             b.forward = types.MethodType(_residual_unit_forward, b)
+            fused[0] += 1
+        elif _is_linear_bottleneck(b) and b.use_shortcut and not hasattr(b, "_fq_residual_fused"):
+            b._fq_residual_fused = True
+            b.forward = types.MethodType(_linear_bottleneck_forward, b)
             fused[0] += 1
 
     if stem:

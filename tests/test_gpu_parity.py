@@ -544,6 +544,51 @@ def _pwconv_case(dev, ops, case, mode, form=None):
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
 
 
+PW_RES_CASES = [("split", (2, 256, 1024, 14, 14)), ("split", (3, 512, 2048, 7, 7)), ("stream", (2, 64, 256, 28, 28)),
+                ("split", (2, 144, 24, 14, 14)), ("split", (3, 384, 64, 7, 7)), (None, (2, 128, 512, 9, 11))]
+
+
+@pytest.mark.parametrize("form,case", PW_RES_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in PW_RES_CASES])
+@pytest.mark.parametrize("mode", ["online_u8_bn_relu", "offline_s8_channel_w4_bn_none"])
+def test_pwconv_i8_residual_vs_oracle(dev, ops, form, case, mode):
+    """The tail of a residual unit in the epilogue of its last 1x1 convolution: y = act(BN(conv) + shortcut) (ResNet: ReLU,
+    MobileNetV2: no activation); partial channel tiles (24, 64 channels) included."""
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + 11)
+    x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+    if "s8" not in mode:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * rng.uniform(0.05, 1.0, (cout, 1, 1, 1))).astype(np.float32)
+    res = (rng.standard_normal((n, cout, h, w)) * 3).astype(np.float32)
+    per_channel = "channel" in mode
+    wt_width = 4 if "w4" in mode else 8
+    rps = 1 if per_channel else cout
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), rps, wt_width)
+    kw, okw = {}, {}
+    if mode.startswith("online"):
+        stat = O.absmax_per_sample(x)
+        kw.update(in_stat=T(stat, dev), width=8, flags=0)
+        okw.update(in_max=O.batch_mean(stat), signed=False, width=8)
+    else:
+        thr = np.float32(2.3)
+        kw.update(in_thr=T(np.float32([thr]), dev), width=8, flags=ops.act_flags(signed=True))
+        okw.update(in_max=thr, signed=True, width=8)
+    act = "relu" if "relu" in mode else None
+    sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    y, stat_out = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, cur_out=torch.zeros(1, device=dev), bn_scale=T(sc, dev),
+                                bn_shift=T(sh, dev), act=act, residual=T(res, dev), form=form, **kw)
+    want = O.pwconv_i8(x, wt, rps, wt_width, bn_scale=sc, bn_shift=sh, act=act, residual=res, **okw)
+    _eq(N(y), want, "pointwise int8 convolution with a residual operand")
+    _eq(N(stat_out), O.absmax_per_sample(want), "statistic")
+    # ... which is what the separate passes compute
+    plain = O.pwconv_i8(x, wt, rps, wt_width, bn_scale=sc, bn_shift=sh, act=None, **okw)
+    two_pass = (plain + res).astype(np.float32)
+    _eq(want, np.maximum(two_pass, 0) if act == "relu" else two_pass, "oracle: fused tail == convolution, then add, then act")
+    from oracle import host as H
+    _eq(H.pwconv_i8(x, wt, rps, wt_width, bn_scale=sc, bn_shift=sh, act=act, residual=res, **okw), want, "host twin")
+
+
 PW_S2_CASES = [(2, 256, 512, 14, 14), (3, 512, 1024, 7, 7), (2, 64, 128, 9, 11), (2, 1024, 2048, 5, 5), (3, 256, 128, 28, 28),
                (4, 96, 40, 6, 7)]
 
