@@ -12,7 +12,7 @@ from ...mx.gluon.nn import Dense
 from ... import ops
 from .._state import DeviceScalar
 from ._blocks import INPUT_RANGE, contiguous, rebind_forward
-from .convert_conv2d import fake_quant_block_input, current_slot
+from .convert_conv2d import fake_quant_block_input, fused_input_plan, current_slot
 
 __all__ = ['gen_dense_converter']
 
@@ -45,10 +45,38 @@ def _quantised_weight(block, weight, args):
     return NDArray(autograd.ste_link(w, held[1]))              # identity backward; a no-op unless recording
 
 
+def _dense_weight_codes(block, weight, args):
+    """int8 codes / scales / row sums of the (units, in_units) weight, kept until the parameter changes."""
+    w = contiguous(weight._t)
+    key = (weight._t.data_ptr(), weight._t._version, args.quant_type, args.wt_width, str(w.device))
+    held = block.__dict__.get("_fq_wcodes_cache")
+    if held is None or held[0] != key:
+        rows = 1 if args.quant_type == 'channel' else block._units
+        held = block.__dict__["_fq_wcodes_cache"] = (key, ops.weight_codes(w, rows, args.wt_width))
+    return held[1]
+
+
+def _dense_on_codes(block, x, weight, bias, input_max, args, flags):
+    """quantize/fuse.py: a Dense whose input and weight are both quantised to <= 8 bits IS a 1x1 convolution on a 1x1 plane:
+    fq_pwconv_i8 quantises on load (no apply pass) and sums the integer codes exactly (the reference: fp32 FullyConnected of
+    the two fake-quantised operands)."""
+    plan = fused_input_plan(block, x, input_max, flags, args.in_width)
+    codes, scales, rowsum = _dense_weight_codes(block, weight, args)
+    t = contiguous(x._t)
+    y, _ = ops.pwconv_i8(t.reshape(t.shape[0], -1, 1, 1), codes, scales, rowsum, None if bias is None else bias._t,
+                         want_stat=False, **plan)
+    return NDArray(y.reshape(y.shape[0], -1))
+
+
 def _quantised_dense(self, F, x, weight, bias=None, input_max=None):
     args = self.quantize_args
     if not self.enable_quantize:
         return self.origin_forward(F, x, weight, bias)
+    if getattr(self, "_fq_dense_int8", False) and args.quantize_input and self.quantize_input \
+            and args.in_width <= 8 and args.wt_width <= 8 and all(d == 1 for d in x.shape[2:]) \
+            and self.act is None and not autograd.is_recording():
+        flags = ops.act_flags(signed=args.in_signed, lo_neg_max=False)          # [0, max] always: the clip_min quirk
+        return _dense_on_codes(self, x, weight, bias, input_max, args, flags)
     if args.quantize_input:
         flags = ops.act_flags(signed=args.in_signed, lo_neg_max=False)          # [0, max] always: the clip_min quirk
         flattened = all(d == 1 for d in x.shape[2:])

@@ -251,8 +251,11 @@ def _bn_constants_getter(bn):
     return get
 
 
-def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual=True):
-    """Returns the number of blocks fused (BatchNorms folded + depthwise / pointwise convolutions taken over)."""
+def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual=True, dense_int8=False):
+    """Returns the number of blocks fused (BatchNorms folded + depthwise / pointwise convolutions taken over).
+    `dense_int8`: also run the quantised classifier on the integer codes (fq_pwconv_i8 on a 1x1 plane: exact sums, no apply
+    pass).  Off by default: at batch 128 the 1024 -> 1000 layer has 4 pixel tiles, i.e. 16-32 workgroups, and takes 23-28 us
+    against 16.5 us for the apply pass + rocBLAS (measured in the benchmark step)."""
     fused = [0]
 
     def bypass(blk):
@@ -396,6 +399,12 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             b.forward = types.MethodType(_linear_bottleneck_forward, b)
             fused[0] += 1
 
+    def visit_dense(b):
+        if type(b) is nn.Dense and hasattr(b, "quantize_args") and dense_int8 and not hasattr(b, "_fq_dense_int8"):
+            b._fq_dense_int8 = True                # convert_dense: the classifier on the integer codes
+            fused[0] += 1
+
+    net.apply(visit_dense)
     if stem:
         net.apply(visit_stem)
     if depthwise:
@@ -453,6 +462,9 @@ def unfuse(net):
             del blk._fq_bypassed_orig
 
     def visit(b):
+        if hasattr(b, "_fq_dense_int8"):
+            del b._fq_dense_int8
+            b.__dict__.pop("_fq_wcodes_cache", None)
         if hasattr(b, "_fq_residual_fused"):
             del b.forward                                   # the class's own forward again
             del b._fq_residual_fused
