@@ -449,7 +449,10 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
 // Lane p of a segment: p = 0 left-halo lane, 1..L compute lanes (input columns 4(p-1)..4(p-1)+3), L+1 right-halo lane
 // (stride 1 only).  Halo lanes load and quantise like the others; their neighbours pick up .w / .x by shuffle.
 // ---------------------------------------------------------------------------------------------------------------
-template <int S, bool QUANT, bool ONLINE>
+// NT: nontemporal LOADS - an input beyond the 256 MB Infinity Cache is dead after this pass and should not displace the
+// output, which the consumer does find there (measured in the model: 64 @112x112 stride 2, 411 MB in / 103 MB out, 110 -> 99 us;
+// with nontemporal stores too, or on the 205 MB inputs of the stride-1 layers, the step gets slower)
+template <int S, bool QUANT, bool ONLINE, bool NT>
 __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
     const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
     float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
     float m = 0.0f;
     auto ldrow = [&](int row) -> f4 {
       const int rc = row < last_row ? row : last_row;
-      return keep4(xs[(int64_t)rc * rowq], ld_ok && row <= last_row);
+      return keep4(ld4<NT>(xs + (int64_t)rc * rowq), ld_ok && row <= last_row);
     };
     auto quant4 = [&](f4 v) -> f4 { return QUANT ? fq_code4(v, q) * q.scale : v; };
     auto finish = [&](float acc) -> float {
@@ -730,10 +733,19 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
     if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
+    static const int dw_nt_mb = env_int("FQ_DW_NT_MB", 300);              // nontemporal loads above this many MB of input
+    const bool nt = 4.0 * (double)n * c * h * wdt > 1e6 * dw_nt_mb;
 #define FQ_DWC4(SS, Q, O)                                                                                         \
-  hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, cg,       \
-                     total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,         \
-                     bn_shift, act, stat_out)
+  do {                                                                                                            \
+    if (nt)                                                                                                       \
+      hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O, true>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, \
+                         cg, total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,  \
+                         bn_shift, act, stat_out);                                                                 \
+    else                                                                                                          \
+      hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O, false>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, \
+                         cg, total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,  \
+                         bn_shift, act, stat_out);                                                                 \
+  } while (0)
     if (stride == 1) {
       if (!quant) FQ_DWC4(1, false, false);
       else if (!in_thr) FQ_DWC4(1, true, true);
