@@ -109,7 +109,8 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
              "stream, 6 split; the panel / chunk / tile forms 2, 4, 5 were retired in favour of the split form)", c.form);
   FQ_REQUIRE(stride == 1 || c.form == 0 || c.form == 6, "fq_pwconv_i8_strided: only the split form reads strided inputs");
   FQ_REQUIRE(residual == nullptr || c.form != 1, "fq_pwconv_i8_strided: the two-kernel form takes no residual operand");
-  ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), c.st);
+  // algorithmic bytes: the input pixels the outputs need, the outputs, and the residual operand when there is one
+  ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (residual ? 2.0 : 1.0) * (double)n * cout * hw), c.st);
   bool taken = false;
   if (int rc = pw_try_split(c, &taken)) return rc;
   if (taken) return FQ_OK;
