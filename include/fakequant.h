@@ -137,6 +137,12 @@ int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t in
 #define FQ_STAT_PREZEROED 0x100
 int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                    const float* shift, int act, float* stat_out, fqStream_t stream);
+/* The same followed by a 3x3 / stride 2 / padding 1 max pooling, in one pass (the head of the ImageNet ResNets behind
+ * their first convolution: BatchNorm -> ReLU -> MaxPool2D(3, 2, 1)):  y[n, c, ho, wo] = max over the window of
+ * act(x * scale[c] + shift[c]), padding never wins;  y: (n, c, (h-1)/2+1, w/2);  stat_out[n] <- max|y[n]|.  w % 4 == 0.
+ * 4 B/in elem + 4 B/out elem instead of 8 + 5 (+ the consumer's statistic pass).                                    */
+int fq_bn_act_maxpool_stat(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, const float* scale,
+                           const float* shift, int act, float* stat_out, fqStream_t stream);
 
 /* The residual tail of a ResNet unit — `(x + residual).relu()` in the gluon model zoo's BasicBlockV1 / BottleneckV1, two
  * more elementwise passes followed by one statistic pass per quantised consumer — in one pass: y = act(a + b) over

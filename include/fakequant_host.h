@@ -47,6 +47,8 @@ int fq_fake_quant_online_prestat_host(const float* x, float* y, int64_t n, int64
                                       fqStream_t stream);
 int fq_bn_act_stat_host(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                         const float* shift, int act, float* stat_out, fqStream_t stream);
+int fq_bn_act_maxpool_stat_host(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w,
+                                const float* scale, const float* shift, int act, float* stat_out, fqStream_t stream);
 int fq_add_act_stat_host(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
                          fqStream_t stream);
 int fq_global_avg_pool_stat_host(const float* x, float* y, int64_t n, int64_t c, int64_t hw, int flags,

@@ -295,6 +295,35 @@ int fq_bn_act_stat_host(const float* x, float* y, int64_t n, int64_t c, int64_t 
   return FQ_OK;
 }
 
+// BatchNorm + activation, then MaxPool2D(3, stride 2, padding 1): padding never wins
+int fq_bn_act_maxpool_stat_host(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w,
+                                const float* scale, const float* shift, int act, float* stat_out, fqStream_t) {
+  REQUIRE(x && y && scale && shift && n > 0 && c > 0 && h > 0 && w > 0, "fq_bn_act_maxpool_stat_host: bad arguments");
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  zero_stat(stat_out, n, prezeroed);
+  const int64_t ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t pl = 0; pl < n * c; ++pl) {
+    const float sc = scale[pl % c], sh = shift[pl % c];
+    for (int64_t r = 0; r < ho; ++r)
+      for (int64_t q = 0; q < wo; ++q) {
+        float m = -INFINITY;
+        for (int64_t ky = 0; ky < 3; ++ky)
+          for (int64_t kx = 0; kx < 3; ++kx) {
+            const int64_t iy = 2 * r - 1 + ky, ix = 2 * q - 1 + kx;
+            if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
+            float t = x[(pl * h + iy) * w + ix] * sc;
+            t = t + sh;
+            m = std::max(m, act_of(t, act));
+          }
+        y[(pl * ho + r) * wo + q] = m;
+      }
+  }
+  stat_of_output(y, n, c * ho * wo, stat_out);
+  return FQ_OK;
+}
+
 int fq_add_act_stat_host(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
                          fqStream_t) {
   REQUIRE(a && b && y && n > 0 && inner > 0, "fq_add_act_stat_host: bad arguments");

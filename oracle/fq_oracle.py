@@ -26,7 +26,7 @@ EPS = F32(1e-10)          # ste_func.py:39,41  `scale + 1e-10`  (fp32 add: numpy
 __all__ = ["roundf", "absmax_per_sample", "batch_mean", "act_scale", "ste_codes", "ste_forward",
            "conv_input_fake_quant", "dense_input_fake_quant", "act_output_fake_quant", "weight_fake_quant",
            "winograd_G", "wino_weight_fake_quant", "ema_update", "discrete_histogram", "kl_calibrate",
-           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act", "dwconv3x3", "weight_codes", "pwconv_i8", "conv3x3_i8"]
+           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act", "dwconv3x3", "weight_codes", "pwconv_i8", "conv3x3_i8", "bn_act_maxpool"]
 
 
 def roundf(x):
@@ -333,6 +333,21 @@ def bn_act(x, scale, shift, act="relu"):
     elif act == "relu6":
         y = np.minimum(np.maximum(y, F32(0)), F32(6))
     return y.astype(F32)
+
+
+def bn_act_maxpool(x, scale, shift, act="relu"):
+    """`bn_act` followed by MaxPool2D(3, stride 2, padding 1) (padding never wins): the arithmetic of
+    `fq_bn_act_maxpool_stat`."""
+    y = bn_act(x, scale, shift, act)
+    N, C, H, W = y.shape
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    pad = np.full((N, C, 2 * ho + 1, 2 * wo + 1), -np.inf, F32)
+    pad[:, :, 1:H + 1, 1:W + 1] = y
+    out = np.full((N, C, ho, wo), -np.inf, F32)
+    for ky in range(3):
+        for kx in range(3):
+            out = np.maximum(out, pad[:, :, ky:ky + 2 * ho:2, kx:kx + 2 * wo:2])
+    return out.astype(F32)
 
 
 def global_avg_pool(x):

@@ -157,6 +157,15 @@ def bn_act(x, scale, shift, act="relu", want_stat=False):
     return (y, stat) if want_stat else y
 
 
+def bn_act_maxpool(x, scale, shift, act="relu", want_stat=False):
+    x = _f32(x)
+    n, c, h, w = x.shape
+    y = np.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), F32)
+    stat = np.zeros(n, F32) if want_stat else None
+    _call("fq_bn_act_maxpool_stat_host", x, y, n, c, h, w, _f32(scale), _f32(shift), _i(_ACTS[act]), stat, None)
+    return (y, stat) if want_stat else y
+
+
 def add_act(a, b, act="relu", want_stat=False):
     a, b = _f32(a), _f32(b)
     n = a.shape[0]

@@ -142,6 +142,12 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     return _t(y), stat
 
 
+def bn_act_maxpool_stat(x, scale, shift, act="relu", want_stat=True):
+    y = O.bn_act_maxpool(_np(x), _np(scale), _np(shift), act)
+    stat = _t(np.abs(y).reshape(y.shape[0], -1).max(axis=1).astype(F32)) if want_stat else None
+    return _t(y), stat
+
+
 def add_act_stat(a, b, act="relu", out=None, want_stat=True):
     y = (_np(a).astype(F32) + _np(b).astype(F32)).astype(F32)
     if act == "relu":
@@ -390,7 +396,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

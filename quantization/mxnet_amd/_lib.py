@@ -38,6 +38,7 @@ EXPORTS = {
     "fq_fake_quant_online": (_int, [_vp, _vp, _i64, _i64, _int, _uint, _vp, _vp, _vp, _vp]),
     "fq_fake_quant_online_prestat": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp]),
     "fq_bn_act_stat": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
+    "fq_bn_act_maxpool_stat": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "fq_add_act_stat": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
     "fq_global_avg_pool_stat": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "fq_gemm_i8_codes": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp]),

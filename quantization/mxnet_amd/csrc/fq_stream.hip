@@ -444,6 +444,63 @@ __global__ __launch_bounds__(kBlock) void eval_counters_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K2p: BatchNorm + activation + 3x3 / stride 2 / pad 1 max pooling + per-sample statistic in one pass: the head of the
+// ImageNet ResNets behind their (un-quantised, library) first convolution.  The three passes it replaces move 411 + 411
+// (BN + ReLU), 411 + 103 (pooling) and 103 MB (the consumer's statistic) at batch 128; this one reads 411 and writes 103.
+// A thread produces TWO adjacent outputs of one row from a 3 x 5 input window: per input row one 16-byte load (columns 4q ..
+// 4q+3, coalesced along the row) and the left neighbour column 4q-1 (same cache line as the previous thread's load).
+// Padding never wins a maximum (-inf); BatchNorm and the activation are applied to every input BEFORE the maximum, exactly
+// as the separate passes do (a negative BatchNorm scale would otherwise turn the maximum around).
+// ---------------------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void bn_act_maxpool_stat_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                     int C, int H, int W, int Ho, int Wo,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     float* __restrict__ stat_out) {
+  __shared__ float red[4];
+  const int smp = blockIdx.y;
+  const int Wq = Wo >> 1;                                               // output pairs per row (host: W % 4 == 0)
+  const int64_t items = (int64_t)C * Ho * Wq;
+  const float* xs = x + (int64_t)smp * C * H * W;
+  float* ys = y + (int64_t)smp * C * Ho * Wo;
+  float m = 0.0f;
+  for (int64_t it = (int64_t)blockIdx.x * kBlock + threadIdx.x; it < items; it += (int64_t)gridDim.x * kBlock) {
+    const int wq = (int)(it % Wq);
+    const int64_t pr = it / Wq;
+    const int ho = (int)(pr % Ho);
+    const int ch = (int)(pr / Ho);
+    const float sc = scale[ch], sh = shift[ch];
+    const float* xp = xs + (int64_t)ch * H * W + 4 * wq;
+    float o0 = -INFINITY, o1 = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = 2 * ho - 1 + k;
+      const bool rin = r >= 0 && r < H;
+      const int rc = r < 0 ? 0 : (r < H ? r : H - 1);
+      const f4 v = *reinterpret_cast<const f4*>(xp + (int64_t)rc * W);
+      const float lraw = xp[(int64_t)rc * W - (wq > 0 ? 1 : 0)];        // column 4q-1 (q = 0: padding, masked below)
+      auto f = [&](float t) {
+        t = t * sc;
+        t = t + sh;
+        return act_rt(t, ACT);
+      };
+      const float a0 = f(v.x), a1 = f(v.y), a2 = f(v.z), a3 = f(v.w);
+      const float l = wq > 0 ? f(lraw) : -INFINITY;
+      const float r0 = fmaxf(fmaxf(l, a0), a1), r1 = fmaxf(fmaxf(a1, a2), a3);
+      o0 = rin ? fmaxf(o0, r0) : o0;
+      o1 = rin ? fmaxf(o1, r1) : o1;
+    }
+    *reinterpret_cast<float2*>(ys + ((int64_t)ch * Ho + ho) * Wo + 2 * wq) = make_float2(o0, o1);
+    m = fmaxf(m, fmaxf(fabsf(o0), fabsf(o1)));
+  }
+  if (stat_out != nullptr) {
+    m = block_max(m, red);
+    if (threadIdx.x == 0) atomic_max_f32(stat_out + smp, m);
+  }
+}
+
 }  // namespace
 
 namespace fqi {
@@ -622,6 +679,36 @@ int fq_fake_quant_online_prestat(const float* x, float* y, int64_t n, int64_t in
                                            out_current_max, (hipStream_t)stream);
   return launch_apply<true, false, false>(x, y, nullptr, n, inner, stat, nullptr, levels, flags, nullptr,
                                           out_current_max, (hipStream_t)stream);
+}
+
+int fq_bn_act_maxpool_stat(const float* x, float* y, int64_t n, int64_t c, int64_t h, int64_t w, const float* scale,
+                           const float* shift, int act, float* stat_out, fqStream_t stream) {
+  FQ_REQUIRE(x && y && scale && shift, "fq_bn_act_maxpool_stat: null pointer");
+  FQ_REQUIRE(n > 0 && n < 65536 && c > 0 && h > 0 && w > 0 && w % 4 == 0 && c * h * w < (1ll << 31),
+             "fq_bn_act_maxpool_stat: bad shape (n=%lld c=%lld h=%lld w=%lld; w must be a multiple of 4)", (long long)n,
+             (long long)c, (long long)h, (long long)w);
+  FQ_REQUIRE(aligned16(x) && aligned16(y), "fq_bn_act_maxpool_stat: x and y must be 16-byte aligned");
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_bn_act_maxpool_stat: unknown activation %d", act);
+  hipStream_t st = (hipStream_t)stream;
+  const int Ho = (int)((h - 1) / 2 + 1), Wo = (int)(w / 2);
+  if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+  const int64_t items = c * Ho * (Wo / 2);
+  int64_t bx = (items + kBlock - 1) / kBlock;
+  const int64_t cap = ((int64_t)num_cu() * kMaxBlocksPerCU + n - 1) / n;     // all workgroups resident, few atomics per sample
+  if (bx > cap) bx = cap < 1 ? 1 : cap;
+  ProfScope prof(FQ_KERNEL_BN_ACT, 4.0 * ((double)n * c * h * w + (double)n * c * Ho * Wo), st);
+  const dim3 grid((unsigned)bx, (unsigned)n);
+#define FQ_BMP(A)                                                                                                  \
+  hipLaunchKernelGGL((bn_act_maxpool_stat_kernel<A>), grid, dim3(kBlock), 0, st, x, y, (int)c, (int)h, (int)w, Ho, Wo, \
+                     scale, shift, stat_out)
+  if (act == FQ_ACT_RELU) FQ_BMP(FQ_ACT_RELU);
+  else if (act == FQ_ACT_RELU6) FQ_BMP(FQ_ACT_RELU6);
+  else FQ_BMP(FQ_ACT_NONE);
+#undef FQ_BMP
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
 }
 
 int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,

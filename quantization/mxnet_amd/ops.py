@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["add_act_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -307,6 +307,24 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
     stat, zflag = _stat_target(n, x.device, want_stat)
     check_call(_lib_().fq_bn_act_stat(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,
                                       _ptr(stat), _stream(x)))
+    return y, stat
+
+
+def bn_act_maxpool_stat(x, scale, shift, act="relu", want_stat=True):
+    """BatchNorm (per-channel scale/shift) + activation + MaxPool2D(3, stride 2, padding 1) + per-sample max|y| in one
+    pass.  x: (N, C, H, W) with W % 4 == 0; returns (y (N, C, (H-1)//2+1, W//2), stat (N,) or None)."""
+    _check(x, "x")
+    _check(scale, "scale")
+    _check(shift, "shift")
+    if x.dim() != 4 or x.shape[3] % 4:
+        raise ValueError("bn_act_maxpool_stat wants (N, C, H, W) with W a multiple of 4, got %s" % (tuple(x.shape),))
+    n, c, h, w = x.shape
+    if scale.numel() != c or shift.numel() != c:
+        raise ValueError("scale/shift must have %d elements" % c)
+    y = torch.empty((n, c, (h - 1) // 2 + 1, w // 2), dtype=torch.float32, device=x.device)
+    stat, zflag = _stat_target(n, x.device, want_stat)
+    check_call(_lib_().fq_bn_act_maxpool_stat(_ptr(x), _ptr(y), n, c, h, w, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,
+                                              _ptr(stat), _stream(x)))
     return y, stat
 
 

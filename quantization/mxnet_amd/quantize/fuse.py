@@ -59,10 +59,30 @@ def _fused_bn_forward(self, F, x, gamma, beta, running_mean, running_var):
     if st["key"] != key:                       # parameters moved or rewritten (reset_ctx / load / set_data): recompute
         st["scale"], st["shift"], st["key"] = _bn_constants(self)
     t = x._t if x._t.is_contiguous() else x._t.contiguous()
-    y, stat = ops.bn_act_stat(t, st["scale"], st["shift"], st["act"], want_stat=True)
+    if st.get("pool") is not None and t.dim() == 4 and t.shape[3] % 4 == 0:
+        # BatchNorm -> activation -> MaxPool2D(3, 2, 1) (the head of the ImageNet ResNets) in one pass
+        y, stat = ops.bn_act_maxpool_stat(t, st["scale"], st["shift"], st["act"], want_stat=True)
+        st["pool"]._fq_pool_done = True
+    else:
+        y, stat = ops.bn_act_stat(t, st["scale"], st["shift"], st["act"], want_stat=True)
     out = NDArray(y)
     out._fq_stat = stat
     return out
+
+
+def _pool_after_bn_forward(self, F, x):
+    """MaxPool2D whose work the preceding BatchNorm already did (quantize/fuse.py); pools itself when it did not (W % 4)."""
+    if self.__dict__.pop("_fq_pool_done", False):
+        return x
+    return self._fq_pool_fused["orig"](F, x)
+
+
+def _is_maxpool_3x3s2p1(b):
+    if type(b) is not nn.MaxPool2D or b.hybrid_forward.__func__ is not nn.MaxPool2D.hybrid_forward:
+        return False
+    k = b._kwargs
+    return (k["kernel"] == (3, 3) and k["stride"] == (2, 2) and k["pad"] == (1, 1) and not k["global_pool"]
+            and k["pooling_convention"] == "valid")
 
 
 def _identity_forward(self, F, x, *args, **kwargs):
@@ -376,11 +396,16 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             act = _act_kind(nxt) if nxt is not None else None
             if act and hasattr(nxt, "_fq_bypassed_orig"):
                 act = None
+            pool = kids[i + 2] if act and i + 2 < len(kids) and _is_maxpool_3x3s2p1(kids[i + 2]) \
+                and not hasattr(kids[i + 2], "_fq_pool_fused") else None
             b._fq_fused = {"act": act or "none", "key": None, "scale": None, "shift": None,
-                           "orig": b.hybrid_forward, "act_block": nxt if act else None}
+                           "orig": b.hybrid_forward, "act_block": nxt if act else None, "pool": pool}
             b.hybrid_forward = types.MethodType(_fused_bn_forward, b)
             if act:
                 bypass(nxt)
+            if pool is not None:
+                pool._fq_pool_fused = {"orig": pool.hybrid_forward}
+                pool.hybrid_forward = types.MethodType(_pool_after_bn_forward, pool)
             fused[0] += 1
 
     # the model zoo's nets compute `output(features(x))`: what follows the last block of `features` is `output`
@@ -462,6 +487,10 @@ def unfuse(net):
             del blk._fq_bypassed_orig
 
     def visit(b):
+        if hasattr(b, "_fq_pool_fused"):
+            b.hybrid_forward = b._fq_pool_fused["orig"]
+            del b._fq_pool_fused
+            b.__dict__.pop("_fq_pool_done", None)
         if hasattr(b, "_fq_dense_int8"):
             del b._fq_dense_int8
             b.__dict__.pop("_fq_wcodes_cache", None)

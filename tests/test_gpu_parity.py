@@ -441,6 +441,25 @@ def test_add_act_stat_vs_oracle(dev, ops, shape, act):
     _eq(N(y2), want[:, :, 1:], "unaligned / no statistic")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 112, 112), (3, 5, 9, 12), (1, 3, 8, 8), (2, 4, 7, 4), (130, 2, 6, 8)])
+@pytest.mark.parametrize("act", ["relu", "none", "relu6"])
+def test_bn_act_maxpool_stat_vs_oracle(dev, ops, shape, act):
+    """BatchNorm -> activation -> MaxPool2D(3, 2, 1) in one pass (the head of the ImageNet ResNets): odd and even heights,
+    negative BatchNorm scales (the maximum must be taken AFTER the affine map), more samples than workgroups per sample."""
+    from oracle import host as H
+    rng = np.random.default_rng(sum(shape) + len(act))
+    x = (rng.standard_normal(shape) * 3).astype(np.float32)
+    sc = rng.standard_normal(shape[1]).astype(np.float32)
+    sh = rng.standard_normal(shape[1]).astype(np.float32)
+    y, stat = ops.bn_act_maxpool_stat(T(x, dev), T(sc, dev), T(sh, dev), act)
+    want = O.bn_act_maxpool(x, sc, sh, act)
+    _eq(N(y), want, "BN + act + max pooling")
+    _eq(N(stat), O.absmax_per_sample(want), "statistic")
+    _eq(H.bn_act_maxpool(x, sc, sh, act), want, "host twin vs numpy oracle")
+    ref = torch.nn.functional.max_pool2d(torch.from_numpy(O.bn_act(x, sc, sh, act)), 3, 2, 1).numpy()
+    _eq(want, ref, "oracle vs torch's pooling of the oracle's BN + act")
+
+
 # ---- pointwise convolution on integer codes (int8 MFMA) ---------------------------------------------------------------
 PW_CASES = [  # (n, cin, cout, h, w)
     (2, 32, 64, 28, 28), (3, 64, 128, 14, 14), (2, 128, 128, 9, 12), (2, 128, 256, 14, 14), (5, 512, 512, 7, 7),
