@@ -214,7 +214,9 @@ def main():
     ap.add_argument("--autotune", action="store_true",
                     help="MIOpen find/benchmark mode (measured: no gain for these shapes, +60 s of search)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("FQ_BENCH_GRAPH", "0")),
-                    help="replay the step from a hipGraph (no per-kernel events then; roofline measured in extra steps)")
+                    help="1: replay the step from hipGraphs, one per resident input batch (the steps that carry kernel "
+                         "events still run eagerly).  0 (default): every step launched from the host - the stream is "
+                         "GPU-bound either way (measured in one call: 100.4 / 99.9 k images/s eager, 98.9 / 98.2 k replayed)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -278,50 +280,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(max(args.warmup, 1) if args.graph else args.warmup):
+    for i in range(max(args.warmup, rotate) if args.graph else args.warmup):
         step(i)
     torch.cuda.synchronize()
 
-    graph = None
+    # hipGraph replay of the step (one captured graph per resident input batch): the ~45 launches of a step are
+    # launch-latency-sensitive (1.3 ms of kernels); replay removes the host from the loop.  The steps that carry the kernel
+    # events of the roofline leg (every `event_every`-th) still run eagerly INSIDE the timed region.
+    graphs, graph_error = None, None
     if args.graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step(0)
-        graph.replay()
-        torch.cuda.synchronize()
+        try:
+            graphs = []
+            for b in range(rotate):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    step(b)
+                graphs.append(g)
+            for g in graphs:
+                g.replay()
+            torch.cuda.synchronize()
+        except Exception as e:                       # capture is an optimisation: fall back to eager launches, and say so
+            graphs, graph_error = None, "%s: %s" % (type(e).__name__, str(e)[:200])
+            torch.cuda.synchronize()
 
     # Kernel events are SAMPLED inside the timed region (every `event_every`-th step): bracketing all ~45 launches of a
     # step costs ~35 % of THAT step (two marker packets per launch), and the cost is charged to `value`.
-    event_every = 0 if (args.no_kernel_events or graph is not None) else max(1, args.event_every)
+    event_every = 0 if args.no_kernel_events else max(1, args.event_every)
     profiled_steps = 0
     if event_every:
         ops.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            on = bool(event_every) and (i % event_every == 0)
-            if on:
-                ops.profile_enable(True)
-                profiled_steps += 1
+        on = bool(event_every) and (i % event_every == 0)
+        if on:
+            ops.profile_enable(True)
+            profiled_steps += 1
             step(i)
-            if on:
-                ops.profile_enable(False)
+            ops.profile_enable(False)
+        elif graphs is not None:
+            graphs[i % rotate].replay()
+        else:
+            step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if graph is None:
-        prof = ops.profile_read()
-    else:
-        ops.profile_reset()
-        ops.profile_enable(True)
-        profiled_steps = min(args.steps, 10)
-        for i in range(profiled_steps):
-            step(i)
-        torch.cuda.synchronize()
-        ops.profile_enable(False)
-        prof = ops.profile_read()
+    prof = ops.profile_read()
     ops.profile_reset()
     # A bracketing event pair adds a fixed cost to every launch it times (two marker packets + dispatch latency): the
     # median pair around a one-element kernel minus that kernel's own back-to-back cost, both measured NOW on this device.
@@ -381,7 +384,8 @@ def main():
                                    % (args.model, args.batch_size, hw, hw, flavour, nblocks, rotate),
                        "global_batch": world * args.batch_size, "parallelism": "dp%d (replicated weights, sharded "
                        "batch, no data-path collective; counters all-reduced once)" % world,
-                       "hipgraph": bool(args.graph), "fused_producers": not args.no_fuse},
+                       "hipgraph": graphs is not None, "hipgraph_error": graph_error,
+                       "fused_producers": not args.no_fuse},
             "roofline": {"bound": "hbm", "kernel": dk["kernel"], "achieved": dk["achieved"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dk["frac"], "traffic": traffic, "traffic_source": traffic_src,
                          "dominant_by": "largest HIP-event time per step among this library's kernels",
