@@ -189,6 +189,12 @@ int fq_eval_counters(const float* logits, const int64_t* labels, int64_t n, int6
 int fq_stem_conv3x3s2(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
                       int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
                       float* stat_out, fqStream_t stream);
+/* The same for the first convolution of the ImageNet ResNets: 7x7, stride 2, padding 3, 3 -> 64 channels
+ * (w_tap_major: [3][7][7][64]).  Both run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 accumulates as an fmaf chain in
+ * ascending k, so the results are those of the fmaf chain over (ci, ky, kx) bit for bit).                              */
+int fq_stem_conv7x7s2(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
+                      int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
+                      float* stat_out, fqStream_t stream);
 
 /* Depthwise 3x3 convolution (pad 1, dilation 1, stride 1|2, one filter per channel) with the fake-quant of its INPUT
  * folded into the load and BatchNorm/activation/statistic folded into the store — per depthwise layer x is read once

@@ -392,16 +392,17 @@ int fq_eval_counters_host(const float* logits, const int64_t* labels, int64_t n,
   return FQ_OK;
 }
 
-int fq_stem_conv3x3s2_host(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n,
-                           int64_t cin, int64_t cout, int64_t h, int64_t w, const float* bn_scale,
-                           const float* bn_shift, int act, float* stat_out, fqStream_t) {
-  REQUIRE(x && w_tap_major && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "fq_stem_conv3x3s2_host: bad "
-          "arguments");
-  REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_stem_conv3x3s2_host: bn_scale and bn_shift go together");
+// first convolution K x K, stride 2, padding K / 2: an fmaf chain over (ci, ky, kx), then bias, folded BN, activation
+static int stem_conv_impl(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
+                          int64_t cout, int64_t h, int64_t w, int ks, const float* bn_scale, const float* bn_shift, int act,
+                          float* stat_out) {
+  REQUIRE(x && w_tap_major && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "fq_stem_conv_host: bad arguments");
+  REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_stem_conv_host: bn_scale and bn_shift go together");
   const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
   act &= ~FQ_STAT_PREZEROED;
   zero_stat(stat_out, n, prezeroed);
-  const int64_t ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+  const int64_t pad = ks / 2;
+  const int64_t ho = (h + 2 * pad - ks) / 2 + 1, wo = (w + 2 * pad - ks) / 2 + 1;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int64_t s = 0; s < n; ++s)
     for (int64_t co = 0; co < cout; ++co)
@@ -409,11 +410,11 @@ int fq_stem_conv3x3s2_host(const float* x, const float* w_tap_major, const float
         for (int64_t ox = 0; ox < wo; ++ox) {
           float acc = 0.0f;
           for (int64_t ci = 0; ci < cin; ++ci)
-            for (int ky = 0; ky < 3; ++ky)
-              for (int kx = 0; kx < 3; ++kx) {
-                const int64_t iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+            for (int ky = 0; ky < ks; ++ky)
+              for (int kx = 0; kx < ks; ++kx) {
+                const int64_t iy = oy * 2 - pad + ky, ix = ox * 2 - pad + kx;
                 const float v = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? x[((s * cin + ci) * h + iy) * w + ix] : 0.0f;
-                acc = __builtin_fmaf(w_tap_major[((ci * 3 + ky) * 3 + kx) * cout + co], v, acc);
+                acc = __builtin_fmaf(w_tap_major[((ci * ks + ky) * ks + kx) * cout + co], v, acc);
               }
           if (bias) acc = acc + bias[co];
           if (bn_scale) {
@@ -424,6 +425,18 @@ int fq_stem_conv3x3s2_host(const float* x, const float* w_tap_major, const float
         }
   stat_of_output(y, n, cout * ho * wo, stat_out);
   return FQ_OK;
+}
+
+int fq_stem_conv3x3s2_host(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n,
+                           int64_t cin, int64_t cout, int64_t h, int64_t w, const float* bn_scale,
+                           const float* bn_shift, int act, float* stat_out, fqStream_t) {
+  return stem_conv_impl(x, w_tap_major, bias, y, n, cin, cout, h, w, 3, bn_scale, bn_shift, act, stat_out);
+}
+
+int fq_stem_conv7x7s2_host(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n,
+                           int64_t cin, int64_t cout, int64_t h, int64_t w, const float* bn_scale,
+                           const float* bn_shift, int act, float* stat_out, fqStream_t) {
+  return stem_conv_impl(x, w_tap_major, bias, y, n, cin, cout, h, w, 7, bn_scale, bn_shift, act, stat_out);
 }
 
 int fq_dwconv3x3_host(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,

@@ -26,7 +26,7 @@ EPS = F32(1e-10)          # ste_func.py:39,41  `scale + 1e-10`  (fp32 add: numpy
 __all__ = ["roundf", "absmax_per_sample", "batch_mean", "act_scale", "ste_codes", "ste_forward",
            "conv_input_fake_quant", "dense_input_fake_quant", "act_output_fake_quant", "weight_fake_quant",
            "winograd_G", "wino_weight_fake_quant", "ema_update", "discrete_histogram", "kl_calibrate",
-           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act", "dwconv3x3", "weight_codes", "pwconv_i8", "conv3x3_i8", "bn_act_maxpool"]
+           "kl_threshold", "quantize_codes", "dequantize", "qconv2d_forward", "unfused_reference_chain", "bn_act", "dwconv3x3", "weight_codes", "pwconv_i8", "conv3x3_i8", "bn_act_maxpool", "stem_conv_s2"]
 
 
 def roundf(x):
@@ -388,22 +388,23 @@ def eval_counters(logits, labels, counters=None):
     return out
 
 
-def stem_conv3x3s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None):
-    """Arithmetic of `fq_stem_conv3x3s2` (the un-quantised first convolution; reference: mxnet F.Convolution called by
-    gluon/nn/conv_layers.py, then the separate BatchNorm / Activation blocks): dense 3x3, stride 2, pad 1,
-    acc = fmaf(w[co][ci][ky][kx], x, acc) over ci, ky, kx in that order (fmaf emulated as in `dwconv3x3`), + bias, folded
-    BN (separately rounded mul, add), activation."""
+def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None):
+    """Arithmetic of `fq_stem_conv3x3s2` / `fq_stem_conv7x7s2` (the un-quantised first convolution; reference: mxnet
+    F.Convolution called by gluon/nn/conv_layers.py, then the separate BatchNorm / Activation blocks): dense K x K (K from
+    w), stride 2, pad K // 2, acc = fmaf(w[co][ci][ky][kx], x, acc) over ci, ky, kx in that order (fmaf emulated as in
+    `dwconv3x3`), + bias, folded BN (separately rounded mul, add), activation."""
     x = np.asarray(x, dtype=F32)
     w = np.asarray(w, dtype=F32)
     N, C, H, W = x.shape
-    Co = w.shape[0]
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    xp = np.zeros((N, C, H + 2, W + 2), F32)
-    xp[:, :, 1:-1, 1:-1] = x
+    Co, ks = w.shape[0], w.shape[2]
+    pad = ks // 2
+    Ho, Wo = (H + 2 * pad - ks) // 2 + 1, (W + 2 * pad - ks) // 2 + 1
+    xp = np.zeros((N, C, H + 2 * pad + 1, W + 2 * pad + 1), F32)
+    xp[:, :, pad:pad + H, pad:pad + W] = x
     acc = np.zeros((N, Co, Ho, Wo), F32)
     for ci in range(C):
-        for ky in range(3):
-            for kx in range(3):
+        for ky in range(ks):
+            for kx in range(ks):
                 tap = xp[:, ci, ky:ky + (Ho - 1) * 2 + 1:2, kx:kx + (Wo - 1) * 2 + 1:2]
                 acc = (w[None, :, ci, ky, kx, None, None].astype(np.float64) * tap[:, None].astype(np.float64)
                        + acc.astype(np.float64)).astype(F32)
@@ -416,6 +417,9 @@ def stem_conv3x3s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None):
     elif act == "relu6":
         acc = np.minimum(np.maximum(acc, F32(0)), F32(6))
     return acc.astype(F32)
+
+
+stem_conv3x3s2 = stem_conv_s2          # (the 3x3 -> 32 case had its own name first)
 
 
 def dwconv3x3(x, w, bias=None, stride=1, in_max=None, signed=False, width=8, lo_neg_max=None, bn_scale=None,

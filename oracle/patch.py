@@ -176,12 +176,15 @@ def eval_counters(logits, labels, counters):
     return counters
 
 
-def stem_conv3x3s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None):
-    y = O.stem_conv3x3s2(_np(x), _np(w), None if bias is None else _np(bias),
+def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None):
+    y = O.stem_conv_s2(_np(x), _np(w), None if bias is None else _np(bias),
                          None if bn_scale is None else _np(bn_scale), None if bn_shift is None else _np(bn_shift),
                          None if act in (None, "none") else act)
     stat = _t(np.abs(y).reshape(y.shape[0], -1).max(axis=1).astype(F32)) if want_stat else None
     return _t(y), stat
+
+
+stem_conv3x3s2 = stem_conv_s2
 
 
 def dwconv3x3(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None, bn_scale=None,
@@ -396,7 +399,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

@@ -44,6 +44,7 @@ EXPORTS = {
     "fq_gemm_i8_codes": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
     "fq_eval_counters": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "fq_stem_conv3x3s2": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
+    "fq_stem_conv7x7s2": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "fq_dwconv3x3": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _uint, _vp, _vp, _vp, _int,
                             _vp, _vp]),
     "fq_weight_codes": (_int, [_vp, _i64, _i64, _int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

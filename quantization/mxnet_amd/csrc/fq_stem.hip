@@ -102,35 +102,256 @@ __global__ __launch_bounds__(kBlock) void stem_conv3x3s2_kernel(
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// K2q: the same first convolution (K x K, stride 2, padding K/2, 3 input channels) on the fp32 MATRIX cores, for 3x3 -> 32
+// (MobileNets) and 7x7 -> 64 (ResNets).  v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate, so this buys no FLOPs - it buys
+// instruction slots: one MFMA replaces 64 v_fma per lane-pair and the VALU is left with addresses and the epilogue (the VALU
+// form above issues 864 FMAs + 216 LDS reads per pixel-wave and reaches ~35 % of the vector peak).  It is BIT-IDENTICAL to the
+// VALU form and its oracle: the instruction accumulates as an fmaf chain in ascending k (tools/mfma_f32_probe.hip: 1024 of
+// 1024 outputs bit-equal), and k runs over (ci, ky, kx) exactly as the chain above; padded taps multiply a zero.
+// GEMM view: D[co][pixel] += W[co][k] * X[k][pixel].  A tile is 32 consecutive output pixels; lane l supplies, per step s,
+// W[co = l % 32][k = 2 s + l / 32] (3x3: 14 registers per wavefront for good; 7x7: LDS) and X[k][pixel l % 32]: ONE 4-byte
+// buffer load per lane and step, gathered straight from NCHW (each input pixel is used by ~K^2 / 4 outputs: L1 / L2 serve the
+// repeats), taps outside the image masked by an out-of-range offset (the load returns 0).  D comes out lane = pixel, register =
+// channel - the layout of the pointwise kernels: BatchNorm / activation / statistic on store, 128-byte lines per channel.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <int KS, int COUT>
+__global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wt /*[3][KS][KS][COUT]*/, const float* __restrict__ bias,
+    float* __restrict__ y, int H, int W, int Ho, int Wo, int tiles_per_img, int64_t total_tiles,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
+  constexpr int K = 3 * KS * KS, NS = (K + 1) / 2, CT = COUT / 32, PAD = KS / 2;
+  constexpr bool WREG = NS * CT <= 16;                                  // weights in registers (3x3 -> 32), else LDS
+  constexpr int CH = NS < 16 ? NS : 16;                                 // steps whose loads are in flight together
+  constexpr int kSlots = 8;
+  __shared__ __attribute__((aligned(16))) float wl[NS * 2 * COUT];      // [k][co], zero row for the padded k
+  __shared__ __attribute__((aligned(16))) float c_bias[COUT], c_bsc[COUT], c_bsh[COUT];   // per-channel epilogue constants
+  __shared__ unsigned k_stat[kSlots];
+  for (int i = threadIdx.x; i < NS * 2 * COUT; i += kBlock) wl[i] = i < K * COUT ? wt[i] : 0.0f;
+  for (int i = threadIdx.x; i < COUT; i += kBlock) {
+    c_bias[i] = bias != nullptr ? bias[i] : 0.0f;
+    c_bsc[i] = bn_scale != nullptr ? bn_scale[i] : 1.0f;
+    c_bsh[i] = bn_scale != nullptr ? bn_shift[i] : 0.0f;
+  }
+  if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int h = lane >> 5, pl = lane & 31;
+  const int HWo = Ho * Wo;
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
+  const int64_t nwaves = (int64_t)gridDim.x * 4, wid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t t_begin = total_tiles * wid / nwaves, t_end = total_tiles * (wid + 1) / nwaves;
+  const unsigned s_base = (unsigned)((total_tiles * ((int64_t)blockIdx.x * 4) / nwaves) / tiles_per_img);
+  float areg[WREG ? NS * CT : 1];
+  if (WREG) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) areg[c * NS + s] = wl[(2 * s + h) * COUT + c * 32 + pl];
+  }
+  const unsigned x_img = (unsigned)(3 * H * W) * 4u, W4 = (unsigned)W * 4u, HW4 = (unsigned)(H * W) * 4u;
+
+  struct Pix { unsigned smp, jp; int pixoff; unsigned ym, xm; };
+  auto pix_of = [&](int64_t t) __attribute__((always_inline)) {
+    Pix r;
+    const int64_t tc = t < total_tiles ? t : total_tiles - 1;
+    r.smp = (unsigned)(tc / tiles_per_img);
+    unsigned jp = (unsigned)(tc - (int64_t)r.smp * tiles_per_img) * 32u + (unsigned)pl;
+    jp = jp < (unsigned)HWo ? jp : (unsigned)HWo - 1;                   // lanes past the end copy the last pixel
+    r.jp = jp;
+    const int oy = (int)(jp / (unsigned)Wo), ox = (int)(jp - (unsigned)oy * (unsigned)Wo);
+    const int iy0 = 2 * oy - PAD, ix0 = 2 * ox - PAD;
+    r.pixoff = (iy0 * W + ix0) * 4;
+    unsigned ym = 0, xm = 0;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      ym |= (iy0 + k >= 0 && iy0 + k < H) ? (1u << k) : 0u;
+      xm |= (ix0 + k >= 0 && ix0 + k < W) ? (1u << k) : 0u;
+    }
+    r.ym = ym;
+    r.xm = xm;
+    return r;
+  };
+  // the lane's input value of step s: tap k = 2 s + h, i.e. (ci, ky, kx); an invalid tap (outside the image, or the padded
+  // k) gets an offset the resource bounds out
+  auto issue = [&](const fq_rsrc& xr, const Pix& px, int s) __attribute__((always_inline)) {
+    const int k0 = 2 * s, k1 = 2 * s + 1;
+    const int ky0 = (k0 / KS) % KS, kx0 = k0 % KS, ci0 = k0 / (KS * KS);
+    const int ky1 = k1 < K ? (k1 / KS) % KS : 0, kx1 = k1 < K ? k1 % KS : 0, ci1 = k1 < K ? k1 / (KS * KS) : 0;
+    const unsigned t0 = (unsigned)ci0 * HW4 + (unsigned)ky0 * W4 + (unsigned)kx0 * 4u;
+    const unsigned t1 = (unsigned)ci1 * HW4 + (unsigned)ky1 * W4 + (unsigned)kx1 * 4u;
+    const bool v0 = ((px.ym >> ky0) & (px.xm >> kx0) & 1u) != 0u;
+    const bool v1 = k1 < K && ((px.ym >> ky1) & (px.xm >> kx1) & 1u) != 0u;
+    const bool v = h ? v1 : v0;
+    const unsigned off = (unsigned)px.pixoff + (h ? t1 : t0);
+    return buf_ld_f32(xr, v ? off : 0x80000000u, 0u);
+  };
+  auto rsrc_of = [&](const Pix& px) __attribute__((always_inline)) {
+    return make_rsrc(reinterpret_cast<const char*>(x) + (int64_t)px.smp * x_img, x_img);
+  };
+
+  float bbuf[2][CH];
+  Pix cur = pix_of(t_begin);
+  if (t_begin < t_end) {
+    const fq_rsrc xr = rsrc_of(cur);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) bbuf[0][i] = issue(xr, cur, i);
+  }
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    const Pix nxt = pix_of(t + 1);
+    const fq_rsrc xr = rsrc_of(cur), xn = rsrc_of(nxt);
+    v16f acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][i] = 0.0f;
+    // chunks of CH steps: the loads of chunk c + 1 (or of the next tile's first chunk) are issued before chunk c's MFMAs
+    constexpr int NCHUNK = (NS + CH - 1) / CH;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+      float (&mine)[CH] = bbuf[c & 1];
+      float (&other)[CH] = bbuf[(c + 1) & 1];
+      if (c + 1 < NCHUNK) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if ((c + 1) * CH + i < NS) other[i] = issue(xr, cur, (c + 1) * CH + i);
+      } else {
+        static_assert(NCHUNK % 2 == 1 || true, "");
+#pragma unroll
+        for (int i = 0; i < CH; ++i) other[i] = issue(xn, nxt, i);
+      }
+      FQ_PIN();
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int s = c * CH + i;
+        if (s < NS) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const float a = WREG ? areg[ct * NS + s] : wl[(2 * s + h) * COUT + ct * 32 + pl];
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, mine[i], acc[ct], 0, 0, 0);
+          }
+        }
+      }
+      FQ_PIN();
+    }
+    // the next tile's first chunk must sit in bbuf[0]: NCHUNK odd leaves it in bbuf[1]
+    if (NCHUNK % 2 == 1) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) bbuf[0][i] = bbuf[1][i];
+    }
+    // ---- epilogue: lane = pixel, register = channel 8 gq + 4 h + r; constants four at a time from LDS, buffer stores --
+    float m = 0.0f;
+    const unsigned HWo4 = (unsigned)HWo * 4u;
+    const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + (int64_t)cur.smp * COUT * HWo4, (int64_t)COUT * HWo4);
+    const unsigned yo = (unsigned)(4 * h) * HWo4 + cur.jp * 4u;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int c0 = ct * 32 + 8 * gq + 4 * h;
+        const f4 bch = *reinterpret_cast<const f4*>(c_bias + c0);
+        const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
+        const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[ct][4 * gq + r];
+          if (bias != nullptr) v = v + bch[r];
+          if (has_bn) {
+            v = v * bsc[r];
+            v = v + bsh[r];
+          }
+          v = act_rt(v, act);
+          buf_st_f32(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
+          m = fmaxf(m, fabsf(v));
+        }
+      }
+    if (has_stat) {                               // a tile lies within one sample
+      const float wm = wave_max(m);
+      if (lane == 0) {
+        const unsigned slot = cur.smp - s_base;
+        if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+        else atomic_max_f32(stat_out + cur.smp, wm);
+      }
+    }
+    cur = nxt;
+  }
+  if (has_stat) {
+    __syncthreads();
+    const int64_t n_samples = total_tiles / tiles_per_img;
+    if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && (int64_t)s_base + threadIdx.x < n_samples)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
-int fq_stem_conv3x3s2(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
-                      int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
-                      float* stat_out, fqStream_t stream) {
-  FQ_REQUIRE(x && w_tap_major && y, "fq_stem_conv3x3s2: null pointer");
-  FQ_REQUIRE(n > 0 && n < 65536 && h > 0 && w > 0 && h < (1 << 15) && w < (1 << 15), "fq_stem_conv3x3s2: bad shape");
-  FQ_REQUIRE(cin == 3 && cout == 32, "fq_stem_conv3x3s2: only 3 -> 32 channels is built (got %lld -> %lld)",
-             (long long)cin, (long long)cout);
-  FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_stem_conv3x3s2: bn_scale and bn_shift go together");
+// shared by both entry points: ksize 3 (3 -> 32) or 7 (3 -> 64)
+static int stem_launch(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
+                       int64_t cout, int64_t h, int64_t w, int ksize, const float* bn_scale, const float* bn_shift, int act,
+                       float* stat_out, fqStream_t stream, const char* who) {
+  FQ_REQUIRE(x && w_tap_major && y, "%s: null pointer", who);
+  FQ_REQUIRE(n > 0 && n < 65536 && h > 0 && w > 0 && h < (1 << 15) && w < (1 << 15) && 3 * h * w * 4 < (1ll << 31),
+             "%s: bad shape", who);
+  FQ_REQUIRE(cin == 3 && ((ksize == 3 && cout == 32) || (ksize == 7 && cout == 64)), "%s: only 3 -> 32 channels with a "
+             "3x3 kernel and 3 -> 64 with a 7x7 kernel are built (got %lld -> %lld, %dx%d)", who, (long long)cin,
+             (long long)cout, ksize, ksize);
+  FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "%s: bn_scale and bn_shift go together", who);
   const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
   act &= ~FQ_STAT_PREZEROED;
-  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_stem_conv3x3s2: unknown activation %d", act);
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "%s: unknown activation %d", who, act);
   hipStream_t st = (hipStream_t)stream;
-  const int Ho = (int)((h + 2 - 3) / 2 + 1), Wo = (int)((w + 2 - 3) / 2 + 1);
+  const int pad = ksize / 2;
+  const int Ho = (int)((h + 2 * pad - ksize) / 2 + 1), Wo = (int)((w + 2 * pad - ksize) / 2 + 1);
   const int64_t hwo = (int64_t)Ho * Wo;
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   ProfScope prof(FQ_KERNEL_STEM, 4.0 * ((double)n * cin * h * w + (double)n * cout * hwo), st);
-  const int tiles = (int)((hwo + kBlock - 1) / kBlock);
-  // enough workgroups to fill the chip, as few statistic atomics per sample as that allows
-  int tiles_per_wg = 1;
-  while (tiles_per_wg < 8 && n * ((tiles + 2 * tiles_per_wg - 1) / (2 * tiles_per_wg)) >= (int64_t)num_cu() * 8) tiles_per_wg *= 2;
-  const dim3 grid((unsigned)((tiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)n);
-  hipLaunchKernelGGL((stem_conv3x3s2_kernel<3, 32>), grid, dim3(kBlock), 0, st, x, w_tap_major, bias, y, (int)h, (int)w,
-                     Ho, Wo, tiles_per_wg, bn_scale, bn_shift, act, stat_out);
+  static const int form = env_int("FQ_STEM_FORM", 0);                   // tuning: 0 auto, 1 VALU form (3x3 only), 2 MFMA form
+  if (ksize == 3 && form == 1) {
+    const int tiles = (int)((hwo + kBlock - 1) / kBlock);
+    // enough workgroups to fill the chip, as few statistic atomics per sample as that allows
+    int tiles_per_wg = 1;
+    while (tiles_per_wg < 8 && n * ((tiles + 2 * tiles_per_wg - 1) / (2 * tiles_per_wg)) >= (int64_t)num_cu() * 8) tiles_per_wg *= 2;
+    const dim3 grid((unsigned)((tiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)n);
+    hipLaunchKernelGGL((stem_conv3x3s2_kernel<3, 32>), grid, dim3(kBlock), 0, st, x, w_tap_major, bias, y, (int)h, (int)w,
+                       Ho, Wo, tiles_per_wg, bn_scale, bn_shift, act, stat_out);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+  }
+  const int tiles_per_img = (int)((hwo + 31) / 32);
+  const int64_t total = (int64_t)tiles_per_img * n;
+  // persistent workgroups, all resident: four per CU for the 3x3 form (86 -> 77 us against the VALU form's 86 in the
+  // MobileNet step; six: 89), two for the 7x7 form (208 registers + 38 KB of weights in LDS)
+  static const int wg_tune = env_int("FQ_STEM_WG_PER_CU", 0);
+  const int wg_per_cu = wg_tune > 0 ? wg_tune : (ksize == 3 ? 4 : 2);
+  int64_t grid = (int64_t)num_cu() * wg_per_cu;
+  if (grid > (total + 3) / 4) grid = (total + 3) / 4;
+  if (ksize == 3)
+    hipLaunchKernelGGL((stem_mfma_kernel<3, 32>), dim3((unsigned)grid), dim3(kBlock), 0, st, x, w_tap_major, bias, y, (int)h,
+                       (int)w, Ho, Wo, tiles_per_img, total, bn_scale, bn_shift, act, stat_out);
+  else
+    hipLaunchKernelGGL((stem_mfma_kernel<7, 64>), dim3((unsigned)grid), dim3(kBlock), 0, st, x, w_tap_major, bias, y, (int)h,
+                       (int)w, Ho, Wo, tiles_per_img, total, bn_scale, bn_shift, act, stat_out);
   FQ_LAUNCH_CHECK();
   return FQ_OK;
+}
+
+int fq_stem_conv3x3s2(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
+                      int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
+                      float* stat_out, fqStream_t stream) {
+  return stem_launch(x, w_tap_major, bias, y, n, cin, cout, h, w, 3, bn_scale, bn_shift, act, stat_out, stream,
+                     "fq_stem_conv3x3s2");
+}
+
+int fq_stem_conv7x7s2(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
+                      int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
+                      float* stat_out, fqStream_t stream) {
+  return stem_launch(x, w_tap_major, bias, y, n, cin, cout, h, w, 7, bn_scale, bn_shift, act, stat_out, stream,
+                     "fq_stem_conv7x7s2");
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import check_call, FakeQuantError
 
-__all__ = ["add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -394,14 +394,15 @@ def eval_counters(logits, labels, counters):
     return counters
 
 
-def stem_conv3x3s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None):
-    """The un-quantised first convolution (3x3, stride 2, pad 1, 3 -> 32 channels) with fused BatchNorm / activation /
-    per-sample statistic.  w: (32, 3, 3, 3) as the Conv2D parameter holds it; pass `w_tap_major` (= w.permute(1,2,3,0)
-    contiguous) to skip the permutation.  Returns (y, stat (N,) or None)."""
+def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None):
+    """The un-quantised first convolution - 3x3 / stride 2 / pad 1 / 3 -> 32 channels (MobileNets) or 7x7 / stride 2 / pad 3 /
+    3 -> 64 (ResNets) - with fused BatchNorm / activation / per-sample statistic.  w: (Cout, 3, K, K) as the Conv2D parameter
+    holds it; pass `w_tap_major` (= w.permute(1,2,3,0) contiguous) to skip the permutation.  Returns (y, stat (N,) or None)."""
     _check(x, "x")
     _check(w, "w")
-    if x.dim() != 4 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[1] != x.shape[1]:
-        raise ValueError("stem_conv3x3s2 wants x (N,C,H,W) and w (Cout,C,3,3); got %s and %s" % (tuple(x.shape), tuple(w.shape)))
+    if x.dim() != 4 or w.dim() != 4 or w.shape[2] != w.shape[3] or w.shape[2] not in (3, 7) or w.shape[1] != x.shape[1]:
+        raise ValueError("stem_conv_s2 wants x (N,C,H,W) and w (Cout,C,K,K), K = 3 or 7; got %s and %s"
+                         % (tuple(x.shape), tuple(w.shape)))
     for name, t in (("bias", bias), ("bn_scale", bn_scale), ("bn_shift", bn_shift), ("w_tap_major", w_tap_major)):
         if t is not None:
             _check(t, name)
@@ -409,17 +410,25 @@ def stem_conv3x3s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want
     if act not in _ACTS:
         raise ValueError("unknown activation %r" % (act,))
     n, cin, h, wd = x.shape
-    cout = w.shape[0]
+    cout, ks = w.shape[0], w.shape[2]
+    pad = ks // 2
     wt = w_tap_major if w_tap_major is not None else w.permute(1, 2, 3, 0).contiguous()
-    y = torch.empty((n, cout, (h - 1) // 2 + 1, (wd - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, cout, (h + 2 * pad - ks) // 2 + 1, (wd + 2 * pad - ks) // 2 + 1), dtype=torch.float32,
+                    device=x.device)
     stat, zflag = _stat_target(n, x.device, want_stat)
-    check_call(_lib_().fq_stem_conv3x3s2(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), n, cin, cout, h, wd, _ptr(bn_scale),
-                                         _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _stream(x)))
+    entry = _lib_().fq_stem_conv3x3s2 if ks == 3 else _lib_().fq_stem_conv7x7s2
+    check_call(entry(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), n, cin, cout, h, wd, _ptr(bn_scale), _ptr(bn_shift),
+                     _ACTS[act] | zflag, _ptr(stat), _stream(x)))
     return y, stat
 
 
+stem_conv3x3s2 = stem_conv_s2          # the 3x3 -> 32 case had its own name first
+
+
 def stem_conv_supported(cin, cout, kernel, stride, pad):
-    return cin == 3 and cout == 32 and tuple(kernel) == (3, 3) and tuple(stride) == (2, 2) and tuple(pad) == (1, 1)
+    k, s, p = tuple(kernel), tuple(stride), tuple(pad)
+    return cin == 3 and s == (2, 2) and ((cout == 32 and k == (3, 3) and p == (1, 1)) or
+                                         (cout == 64 and k == (7, 7) and p == (3, 3)))
 
 
 def dwconv3x3(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None, bn_scale=None,

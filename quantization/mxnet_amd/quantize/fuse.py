@@ -77,6 +77,23 @@ def _pool_after_bn_forward(self, F, x):
     return self._fq_pool_fused["orig"](F, x)
 
 
+def _pool_stat_forward(self, F, x):
+    """MaxPool2D(3, 2, 1) behind a fused producer (the ResNets' first convolution): pooling + the per-sample statistic of the
+    pooled tensor in one pass (fq_bn_act_maxpool_stat with the identity BatchNorm: x * 1 + 0 is x)."""
+    t = x._t if x._t.is_contiguous() else x._t.contiguous()
+    if t.dim() != 4 or t.shape[3] % 4 or not t.is_cuda:
+        return self._fq_pool_fused["orig"](F, x)
+    st = self._fq_pool_fused
+    c = t.shape[1]
+    if st.get("ones") is None or st["ones"].numel() != c or st["ones"].device != t.device:
+        st["ones"] = torch.ones(c, dtype=torch.float32, device=t.device)
+        st["zeros"] = torch.zeros(c, dtype=torch.float32, device=t.device)
+    y, stat = ops.bn_act_maxpool_stat(t, st["ones"], st["zeros"], "none", want_stat=True)
+    out = NDArray(y)
+    out._fq_stat = stat
+    return out
+
+
 def _is_maxpool_3x3s2p1(b):
     if type(b) is not nn.MaxPool2D or b.hybrid_forward.__func__ is not nn.MaxPool2D.hybrid_forward:
         return False
@@ -130,7 +147,8 @@ def _is_dense3x3(b):
 
 
 def _is_stem3x3s2(b):
-    """The un-quantised first convolution of the ImageNet MobileNets: Conv2D(3 -> 32, 3x3, stride 2, pad 1)."""
+    """The un-quantised first convolution of the ImageNet nets: Conv2D(3 -> 32, 3x3, stride 2, pad 1) of the MobileNets,
+    Conv2D(3 -> 64, 7x7, stride 2, pad 3) of the ResNets."""
     if type(b) is not nn.Conv2D or hasattr(b, "quantize_args"):
         return False
     if b.hybrid_forward.__func__ is not nn.Conv2D.hybrid_forward:
@@ -151,8 +169,8 @@ def _stem_forward(self, F, x, weight, bias=None):
     if st["constants"] is not None:
         scale, shift = st["constants"]()
     t = x._t if x._t.is_contiguous() else x._t.contiguous()
-    y, stat = ops.stem_conv3x3s2(t, w, None if bias is None else bias._t, bn_scale=scale, bn_shift=shift,
-                                 act=st["act"], want_stat=True, w_tap_major=st["wt"])
+    y, stat = ops.stem_conv_s2(t, w, None if bias is None else bias._t, bn_scale=scale, bn_shift=shift,
+                               act=st["act"], want_stat=True, w_tap_major=st["wt"])
     out = NDArray(y)
     out._fq_stat = stat
     return out
@@ -332,6 +350,13 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
                 bn.hybrid_forward = types.MethodType(_identity_forward, bn)
             if act:
                 bypass(nxt)
+            # the ResNets pool right behind it: pooling + the statistic of the pooled tensor in one pass
+            j = i + 1 + (1 if bn is not None else 0) + (1 if act else 0)
+            pool = kids[j] if j < len(kids) and _is_maxpool_3x3s2p1(kids[j]) and not hasattr(kids[j], "_fq_pool_fused") \
+                else None
+            if pool is not None:
+                pool._fq_pool_fused = {"orig": pool.hybrid_forward}
+                pool.hybrid_forward = types.MethodType(_pool_stat_forward, pool)
             fused[0] += 1
 
     def visit_gap(container):

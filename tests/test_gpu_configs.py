@@ -212,7 +212,7 @@ def test_config2_mobilenet_fused_producers_full_batch_against_host_twins(gpu):
     net(mx_small(X))                                                     # freeze the weights on a small batch first
     assert fuse.fuse_inference(net, dense_int8=True) > 0           # (the classifier on the integer codes as well)
     seen = {"dw": 0, "pw": 0, "stem": 0, "gap": 0}
-    real = {k: getattr(ops, k) for k in ("dwconv3x3", "pwconv_i8", "stem_conv3x3s2", "global_avg_pool_stat")}
+    real = {k: getattr(ops, k) for k in ("dwconv3x3", "pwconv_i8", "stem_conv_s2", "global_avg_pool_stat")}
 
     def np_(t):
         return None if t is None else t.detach().cpu().numpy()
@@ -248,8 +248,8 @@ def test_config2_mobilenet_fused_producers_full_batch_against_host_twins(gpu):
         return y, stat
 
     def stem(x, w, bias=None, **k):
-        y, stat = real["stem_conv3x3s2"](x, w, bias, **k)
-        want, wstat = H.stem_conv3x3s2(np_(x), np_(w), np_(bias), np_(k["bn_scale"]), np_(k["bn_shift"]), k["act"],
+        y, stat = real["stem_conv_s2"](x, w, bias, **k)
+        want, wstat = H.stem_conv_s2(np_(x), np_(w), np_(bias), np_(k["bn_scale"]), np_(k["bn_shift"]), k["act"],
                                        want_stat=True)
         _same(np_(y), want, "stem convolution")
         _same(np_(stat), wstat, "stem statistic")
@@ -263,7 +263,7 @@ def test_config2_mobilenet_fused_producers_full_batch_against_host_twins(gpu):
         _same(np_(stat), wstat, "pooling statistic")
         seen["gap"] += 1
         return y, stat
-    ops.dwconv3x3, ops.pwconv_i8, ops.stem_conv3x3s2, ops.global_avg_pool_stat = dw, pw, stem, gap
+    ops.dwconv3x3, ops.pwconv_i8, ops.stem_conv_s2, ops.global_avg_pool_stat = dw, pw, stem, gap
     try:
         out = net(X)
     finally:
