@@ -116,6 +116,9 @@ __global__ __launch_bounds__(kBlock) void stem_conv3x3s2_kernel(
 // channel - the layout of the pointwise kernels: BatchNorm / activation / statistic on store, 128-byte lines per channel.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float v16f __attribute__((ext_vector_type(16)));
+#ifndef FQ_STEM_CH
+#define FQ_STEM_CH 16
+#endif
 
 template <int KS, int COUT>
 __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
   constexpr int K = 3 * KS * KS, NS = (K + 1) / 2, CT = COUT / 32, PAD = KS / 2;
   constexpr bool WREG = NS * CT <= 16;                                  // weights in registers (3x3 -> 32), else LDS
-  constexpr int CH = NS < 16 ? NS : 16;                                 // steps whose loads are in flight together
+  constexpr int CH = NS < 16 ? NS : FQ_STEM_CH;                         // steps whose loads are in flight together
   constexpr int kSlots = 8;
   __shared__ __attribute__((aligned(16))) float wl[NS * 2 * COUT];      // [k][co], zero row for the padded k
   __shared__ __attribute__((aligned(16))) float c_bias[COUT], c_bsc[COUT], c_bsh[COUT];   // per-channel epilogue constants
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
             const float a = WREG ? areg[ct * NS + s] : wl[(2 * s + h) * COUT + ct * 32 + pl];
             acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, mine[i], acc[ct], 0, 0, 0);
           }
+          if (!WREG && (i & 3) == 3) FQ_PIN();   // LDS weights: four steps' reads at a time (else all are hoisted: registers)
         }
       }
       FQ_PIN();

@@ -206,6 +206,62 @@ def test_fused_producers_vs_numpy_oracle():
     _eq(rowsum, wc.sum(axis=1).astype(np.int32))
 
 
+def test_round2_consumers_vs_numpy_oracle():
+    """The entry points added in round 2 - dense 3x3 on the integer codes, strided 1x1, the residual operand, the offline
+    side statistic, BatchNorm + activation + max pooling, the 7x7 first convolution: C++ twin against the numpy
+    restatement, and the numpy restatement against an independent formulation where there is one."""
+    import torch
+    rng = np.random.default_rng(21)
+    x = np.maximum(rng.standard_normal((3, 64, 7, 9)) * 2, 0).astype(np.float32)
+    stat = O.absmax_per_sample(x)
+    in_max = O.batch_mean(stat)
+    sc = rng.uniform(0.5, 1.5, 96).astype(np.float32)
+    sh = rng.standard_normal(96).astype(np.float32)
+    # dense 3x3
+    w3 = (rng.standard_normal((96, 64, 3, 3)) * 0.2).astype(np.float32)
+    for rps, ww, signed in ((96, 8, False), (1, 8, True), (1, 4, False)):
+        want = O.conv3x3_i8(x, w3, rps, ww, in_max, signed, 8, None, None, sc, sh, "relu")
+        _eq(H.conv3x3_i8(x, w3, rps, ww, in_max=in_max, signed=signed, bn_scale=sc, bn_shift=sh, act="relu"), want)
+    plain = O.conv3x3_i8(x, w3, 1, 8, in_max)
+    wq = O.weight_fake_quant(w3, "channel", 8)[0]
+    xq = O.ste_forward(x, O.act_scale(in_max, False, 8), in_max, 0.0)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(xq.astype(np.float64)), torch.from_numpy(wq.astype(np.float64)),
+                                     padding=1).numpy()
+    np.testing.assert_allclose(plain, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    # strided 1x1 and the residual operand
+    w1 = (rng.standard_normal((96, 64, 1, 1)) * 0.2).astype(np.float32)
+    want = O.pwconv_i8(x, w1, 1, 8, in_max, bn_scale=sc, bn_shift=sh, act="relu", stride=2)
+    assert want.shape == (3, 96, 4, 5)
+    _eq(H.pwconv_i8(x, w1, 1, 8, in_max=in_max, bn_scale=sc, bn_shift=sh, act="relu", stride=2), want)
+    _eq(want, O.pwconv_i8(np.ascontiguousarray(x[:, :, ::2, ::2]), w1, 1, 8, in_max, bn_scale=sc, bn_shift=sh, act="relu"))
+    res = (rng.standard_normal((3, 96, 7, 9)) * 3).astype(np.float32)
+    for act in ("relu", None):
+        want = O.pwconv_i8(x, w1, 1, 8, in_max, bn_scale=sc, bn_shift=sh, act=act, residual=res)
+        _eq(H.pwconv_i8(x, w1, 1, 8, in_max=in_max, bn_scale=sc, bn_shift=sh, act=act, residual=res), want)
+        two = (O.pwconv_i8(x, w1, 1, 8, in_max, bn_scale=sc, bn_shift=sh) + res).astype(np.float32)
+        _eq(want, np.maximum(two, 0) if act == "relu" else two)
+    # offline threshold + the batch statistic on the side (host twin: out_current_max still reports the mean)
+    y_off = H.pwconv_i8(x, w1, 1, 8, in_max=np.float32(1.5))
+    _eq(y_off, O.pwconv_i8(x, w1, 1, 8, np.float32(1.5)))
+    # BatchNorm + activation + MaxPool2D(3, 2, 1)
+    xb = (rng.standard_normal((2, 5, 9, 12)) * 3).astype(np.float32)
+    scb, shb = rng.standard_normal(5).astype(np.float32), rng.standard_normal(5).astype(np.float32)
+    for act in ("relu", "none", "relu6"):
+        want = O.bn_act_maxpool(xb, scb, shb, act)
+        y, st = H.bn_act_maxpool(xb, scb, shb, act, want_stat=True)
+        _eq(y, want)
+        _eq(st, O.absmax_per_sample(want))
+        _eq(want, torch.nn.functional.max_pool2d(torch.from_numpy(O.bn_act(xb, scb, shb, act)), 3, 2, 1).numpy())
+    # the 7x7 first convolution
+    xs = rng.standard_normal((2, 3, 18, 22)).astype(np.float32)
+    w7 = (rng.standard_normal((64, 3, 7, 7)) * 0.1).astype(np.float32)
+    sc64, sh64 = rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.standard_normal(64).astype(np.float32)
+    got, want = H.stem_conv_s2(xs, w7, None, sc64, sh64, "relu"), O.stem_conv_s2(xs, w7, None, sc64, sh64, "relu")
+    assert got.shape == want.shape == (2, 64, 9, 11)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)       # true fmaf vs its fp64 emulation: double-rounding ties
+    assert (got != want).mean() < 1e-3
+
+
 def test_calibration_vs_numpy_oracle():
     rng = np.random.default_rng(5)
     fm = np.maximum(rng.standard_normal((4, 16, 14, 14)), 0).astype(np.float32) * np.float32(3)
