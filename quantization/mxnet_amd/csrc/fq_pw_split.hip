@@ -29,17 +29,19 @@ struct PwSplitGeom {
 
 // LB: wavefronts per SIMD the register allocation aims at (3: <= 168 registers, 4: <= 128) - with one tile per workgroup the
 // whole grid should be resident at once (a second round of a few left-over workgroups costs a whole workgroup latency)
-template <int KT, int CW, int D, int LB>
-__global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
+// NW: wavefronts per workgroup.  4: 128 * CW output channels per workgroup; 8 (wide layers): 256 * CW - half as many channel
+// groups quantise the same tile, i.e. half the redundant loads and quantiser VALU.
+template <int KT, int CW, int D, int LB, int NW>
+__global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSplitGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
     float* __restrict__ stat_out, const float* __restrict__ residual) {
   constexpr int kSlots = 8;
-  constexpr int SLABS = (KT + 3) / 4;                                   // slabs a wavefront quantises (kt = wave + 4j < KT)
+  constexpr int SLABS = (KT + NW - 1) / NW;                             // slabs a wavefront quantises (kt = wave + NW j < KT)
   constexpr int RB = SLABS < 4 ? SLABS : 4;                             // slabs (16 loads each) in flight per lane
-  constexpr int NCH = 4 * CW * 32;                                      // output channels of one workgroup
+  constexpr int NCH = NW * CW * 32;                                     // output channels of one workgroup
   constexpr int RS = D + 1;                                             // ring slots
   extern __shared__ __attribute__((aligned(16))) unsigned char pwsp_smem[];
   __shared__ unsigned k_stat[kSlots];
@@ -109,13 +111,13 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
   float buf[RB][16];
 #pragma unroll
   for (int i = 0; i < RB; ++i)
-    if (wave + 4 * i < kt_real) issue(wave + 4 * i, buf[i]);            // in flight during the set-up
+    if (wave + NW * i < kt_real) issue(wave + NW * i, buf[i]);          // in flight during the set-up
   FQ_PIN();
   const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, item == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   const float sx = q.scale;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
-  for (int i = threadIdx.x; i < NCH; i += kBlock) {
+  for (int i = threadIdx.x; i < NCH; i += NW * 64) {
     const bool ok = ch0 + i < g.Cout;                                   // channels past Cout: all-zero constants
     const int ic = ok ? ch0 + i : 0;
     c_sxw[i] = ok ? sx * wscale[ic] : 0.0f;
@@ -137,10 +139,10 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
   // ---- 1. my quarter of the slabs -> LDS panel ------------------------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < SLABS; ++j) {
-    if (wave + 4 * j < kt_real) quant_to_panel(wave + 4 * j, buf[j % RB]);
+    if (wave + NW * j < kt_real) quant_to_panel(wave + NW * j, buf[j % RB]);
     FQ_PIN();
     if (j + RB < SLABS) {
-      if (wave + 4 * (j + RB) < kt_real) issue(wave + 4 * (j + RB), buf[j % RB]);
+      if (wave + NW * (j + RB) < kt_real) issue(wave + NW * (j + RB), buf[j % RB]);
       FQ_PIN();
     }
   }
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(kBlock, LB) void pwconv_split_kernel(
   // A fragment (channel tile ct, slab kt) = 1 KB at wfrag + (ct * KT + kt) * 1024
   // Channel tiles past the padded weight buffer read zeros through the bound of the resource; tiles past Cout are not stored.
   const int ctl0 = wave * CW;                                           // first channel tile inside the workgroup
-  const int ctg0 = (int)cg * 4 * CW + ctl0;                             // ... and in the layer
+  const int ctg0 = (int)cg * NW * CW + ctl0;                            // ... and in the layer
   const int ct_here = g.CTM - ctg0 < CW ? (g.CTM - ctg0 < 0 ? 0 : g.CTM - ctg0) : CW;
   const fq_rsrc wr = make_rsrc(wfrag + (((int64_t)ctg0 * KT) << 10), (int64_t)ct_here * KT * 1024);
   const unsigned loff = (unsigned)lane * 16u;
@@ -312,6 +314,13 @@ int pw_try_split(const PwCall& a, bool* taken) {
     // resident rounds); narrow layers take one tile per wavefront so that all four wavefronts have channels.
     int cw = a.cout > 128 ? 2 : 1;
     int lb = 4;
+    // eight wavefronts per workgroup for wide layers with FEW tiles (7x7 planes: 196): a tile is then quantised by half as
+    // many channel groups (measured in the model: 1024 -> 1024 @7x7 31.2 -> 25.8 us, 512 -> 1024 @7x7 19.8 -> 18.5; the 14x14
+    // layers with their 784 tiles get 5 % slower)
+    static const int nw_tune = env_int("FQ_PWS_NW", 0);
+    const bool nw8_built = kt == 8 || kt == 16 || kt == 32 || kt == 64;
+    int nw = (nw_tune == 4 || nw_tune == 8) ? nw_tune : ((a.cout >= 512 && tiles <= (int64_t)num_cu()) ? 8 : 4);
+    if (!nw8_built) nw = 4;
     const int tune = env_int("FQ_PWS_CFG", 0);                           // tuning: 10 * lb + cw, read per call
     if (tune > 0) {
       cw = tune % 10;
@@ -319,28 +328,31 @@ int pw_try_split(const PwCall& a, bool* taken) {
     }
     PwSplitGeom t;
     t.Cin = (int)a.cin; t.Cout = (int)a.cout; t.HW = (int)a.hw;
-    t.CS = (int)((a.cout + 128 * cw - 1) / (128 * cw));
+    if (lb != 4 || cw != 2) nw = 4;                                      // (the tuning configurations are built for 4)
+    t.CS = (int)((a.cout + 32 * nw * cw - 1) / (32 * nw * cw));
     t.CTM = (int)(rows_pad / 32);
     t.S = a.stride; t.Wo = (int)a.w_out; t.Win = (int)a.w_in; t.HWin = (int)hw_in;
     t.cols = a.n * a.hw; t.tiles = tiles; t.zoff = a.zoff;
     t.items = tiles * t.CS;
     const int64_t grid = (t.items + 7) / 8 * 8;                           // padded to whole rounds over the 8 XCDs
     FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8: too many tiles for the split form");
-    const size_t ldst = (size_t)kt * 1024 + (size_t)(4 * cw * 32) * 5 * sizeof(float);
+    const size_t ldst = (size_t)kt * 1024 + (size_t)(nw * cw * 32) * 5 * sizeof(float);
     const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;               // second half of fq_weight_codes' buffer
     if (int rc = pw_zero_stat(a)) return rc;
     bool launched = false;
-#define FQ_PWS_CASE(KT_, CW_, D_, LB_)                                                                                 \
-  if (kt == KT_ && cw == CW_ && lb == LB_) {                                                                           \
+#define FQ_PWS_CASE_NW(KT_, CW_, D_, LB_, NW_)                                                                         \
+  if (kt == KT_ && cw == CW_ && lb == LB_ && nw == NW_) {                                                              \
     static const bool attr_ok =                                                                                        \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_split_kernel<KT_, CW_, D_, LB_>),                    \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_split_kernel<KT_, CW_, D_, LB_, NW_>),               \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;                      \
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the split kernel");                       \
-    hipLaunchKernelGGL((pwconv_split_kernel<KT_, CW_, D_, LB_>), dim3((unsigned)grid), dim3(kBlock), ldst, a.st, a.x,  \
+    hipLaunchKernelGGL((pwconv_split_kernel<KT_, CW_, D_, LB_, NW_>), dim3((unsigned)grid), dim3(NW_ * 64), ldst, a.st, \
+                       a.x,                                                                                            \
                        wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels,   \
                        a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out, a.residual);      \
     launched = true;                                                                                                   \
   }
+#define FQ_PWS_CASE(KT_, CW_, D_, LB_) FQ_PWS_CASE_NW(KT_, CW_, D_, LB_, 4)
     // every K: the two default configurations; the power-of-two K of the deep MobileNet / ResNet layers also carry the
     // alternatives that tools/pwforms.py and FQ_PWS_CFG compare (three wavefronts per SIMD, four channel tiles)
 #define FQ_PWS_KT(KT_) FQ_PWS_CASE(KT_, 1, (KT_ < 7 ? KT_ : 7), 4) FQ_PWS_CASE(KT_, 2, (KT_ < 3 ? KT_ : 3), 4)
@@ -349,9 +361,11 @@ int pw_try_split(const PwCall& a, bool* taken) {
     FQ_PWS_KT(2) FQ_PWS_KT(4) FQ_PWS_KT(6) FQ_PWS_KT(8) FQ_PWS_KT(10) FQ_PWS_KT(12) FQ_PWS_KT(16) FQ_PWS_KT(18)
     FQ_PWS_KT(30) FQ_PWS_KT(32) FQ_PWS_KT(64)
     FQ_PWS_KT_TUNE(8) FQ_PWS_KT_TUNE(16) FQ_PWS_KT_TUNE(32) FQ_PWS_KT_TUNE(64)
+    FQ_PWS_CASE_NW(8, 2, 3, 4, 8) FQ_PWS_CASE_NW(16, 2, 3, 4, 8) FQ_PWS_CASE_NW(32, 2, 3, 4, 8) FQ_PWS_CASE_NW(64, 2, 3, 4, 8)
 #undef FQ_PWS_KT
 #undef FQ_PWS_KT_TUNE
 #undef FQ_PWS_CASE
+#undef FQ_PWS_CASE_NW
     FQ_REQUIRE(launched, "fq_pwconv_i8: no instantiation of the split form for K/32=%d, %d tiles per wavefront, %d "
                "wavefronts per SIMD", kt, cw, lb);
     FQ_LAUNCH_CHECK();
