@@ -406,9 +406,19 @@ __global__ __launch_bounds__(kBlock) void gap_stat_lds_kernel(const float* __res
 __global__ __launch_bounds__(kBlock) void eval_counters_kernel(const float* __restrict__ logits,
                                                                const long long* __restrict__ labels, int64_t n,
                                                                int classes, float* __restrict__ counters) {
+  // counters[0] (correct) and counters[1] (total) are ONE address each for the whole batch: same-address global atomics
+  // serialise in L2 (128 samples x 2 of them were most of this kernel's 11 us), so the workgroup's four samples are summed in
+  // LDS first and one thread adds the two sums
+  __shared__ unsigned wg_total, wg_correct;
+  if (threadIdx.x == 0) {
+    wg_total = 0u;
+    wg_correct = 0u;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int64_t smp = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (smp >= n) return;
+  const int64_t smp_raw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const bool live = smp_raw < n;
+  const int64_t smp = live ? smp_raw : n - 1;
   const float* row = logits + smp * classes;
   float best = 0.0f;
   int bidx = 0x7FFFFFFF;
@@ -424,23 +434,41 @@ __global__ __launch_bounds__(kBlock) void eval_counters_kernel(const float* __re
       bnan = vnan;
     }
   };
-  for (int i = lane; i < classes; i += 64) take(row[i], i);
+  // eight independent loads in flight per lane (one load per iteration made this kernel sixteen dependent L2 round trips)
+  for (int base = 0; base < classes; base += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 64 + lane;
+      v[u] = row[i < classes ? i : classes - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 64 + lane;
+      if (i < classes) take(v[u], i);
+    }
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const float ov = __shfl_xor(best, off, 64);
     const int oi = __shfl_xor(bidx, off, 64);
     if (oi != 0x7FFFFFFF) take(ov, oi);
   }
-  if (lane == 0) {
+  if (lane == 0 && live) {
     const long long gt = labels[smp];
-    atomicAdd(counters + 1, 1.0f);
+    atomicAdd(&wg_total, 1u);
     if (gt >= 0 && gt < classes) {
       atomicAdd(counters + 2 + classes + gt, 1.0f);
       if ((long long)bidx == gt) {
-        atomicAdd(counters, 1.0f);
+        atomicAdd(&wg_correct, 1u);
         atomicAdd(counters + 2 + gt, 1.0f);
       }
     }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (wg_total) atomicAdd(counters + 1, (float)wg_total);          // small integers: exact in fp32
+    if (wg_correct) atomicAdd(counters, (float)wg_correct);
   }
 }
 
