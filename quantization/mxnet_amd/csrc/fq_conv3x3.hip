@@ -303,13 +303,14 @@ int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, con
   const int64_t row_pad = (9 * cin + 63) / 64 * 64, rows_pad = (cout + 63) / 64 * 64;
   FQ_REQUIRE(row_pad == 9 * cin, "fq_conv3x3_i8: 9 * Cin must be a multiple of 64");
   const int8_t* wfrag = wcodes + rows_pad * row_pad;                      // fragment-major copy (fq_weight_codes)
-  // wavefront arrangement: four channel tiles per workgroup when the layer has them, else two and two pixel halves;
-  // pixel tiles per wavefront so that the grid has at least ~3 workgroups per CU
+  // wavefront arrangement: four channel tiles per workgroup when the layer has them, else two and two pixel halves
   const int wc = cout >= 128 ? 4 : 2;
   const int wp = 4 / wc;
   const int64_t cs = (cout + 32 * wc - 1) / (32 * wc);
-  int ptw = 4;
-  while (ptw > 1 && ((cols + 32 * ptw * wp - 1) / (32 * ptw * wp)) * cs < (int64_t)num_cu() * 3) ptw >>= 1;
+  // two pixel tiles per wavefront: measured best (or equal) on all four ResNet-50 stages in the model - 63 / 39 / 33 / 34 us
+  // at 56x56 / 28x28 / 14x14 / 7x7 against 67 / 45 / 34 / 46 with four and 78 / 44 / 39 / 41 with one
+  int ptw = 2;
+  while (ptw > 1 && ((cols + 32 * ptw * wp - 1) / (32 * ptw * wp)) * cs < (int64_t)num_cu()) ptw >>= 1;
   const int tune = env_int("FQ_C3_PTW", 0);
   if (tune == 1 || tune == 2 || tune == 4) ptw = tune;
   const int pt = ptw * wp;
