@@ -33,15 +33,16 @@ struct C3Geom {
   int zoff;
 };
 
-template <int KT, int PTW, int WC, int D, int LB>
-__global__ __launch_bounds__(kBlock, LB) void conv3x3_i8_kernel(
+// NW wavefronts per workgroup (4, or 8 for wide layers with few pixel blocks: half as many channel groups quantise a region)
+template <int KT, int PTW, int WC, int D, int LB, int NW>
+__global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, C3Geom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
     float* __restrict__ stat_out) {
   constexpr int kSlots = 8;
-  constexpr int WP = 4 / WC;                                            // wavefronts along the pixel direction
+  constexpr int WP = NW / WC;                                           // wavefronts along the pixel direction
   constexpr int PT = PTW * WP;                                          // pixel tiles of a workgroup
   constexpr int NCH = WC * 32;                                          // output channels of a workgroup
   constexpr int RS = D + 1;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(kBlock, LB) void conv3x3_i8_kernel(
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   const float sx = q.scale;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
-  for (int i = threadIdx.x; i < NCH; i += kBlock) {
+  for (int i = threadIdx.x; i < NCH; i += NW * 64) {
     const bool ok = ch0 + i < g.Cout;
     const int ic = ok ? ch0 + i : 0;
     c_sxw[i] = ok ? sx * wscale[ic] : 0.0f;
@@ -118,15 +119,15 @@ __global__ __launch_bounds__(kBlock, LB) void conv3x3_i8_kernel(
     const int rt = u / KT, kt = u - rt * KT;
     *reinterpret_cast<v4i*>(panel + (size_t)(rt * 32 + pl) * g.ROW + kt * 32 + 16 * h) = f;
   };
-  for (int u = wave; u < NU; u += 8) {
-    if (u + 4 < NU) issue(u + 4, bufb);
+  for (int u = wave; u < NU; u += 2 * NW) {
+    if (u + NW < NU) issue(u + NW, bufb);
     FQ_PIN();
     quant_to_panel(u, bufa);
     FQ_PIN();
-    if (u + 4 < NU) {
-      if (u + 8 < NU) issue(u + 8, bufa);
+    if (u + NW < NU) {
+      if (u + 2 * NW < NU) issue(u + 2 * NW, bufa);
       FQ_PIN();
-      quant_to_panel(u + 4, bufb);
+      quant_to_panel(u + NW, bufb);
       FQ_PIN();
     }
   }
@@ -304,8 +305,14 @@ int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, con
   FQ_REQUIRE(row_pad == 9 * cin, "fq_conv3x3_i8: 9 * Cin must be a multiple of 64");
   const int8_t* wfrag = wcodes + rows_pad * row_pad;                      // fragment-major copy (fq_weight_codes)
   // wavefront arrangement: four channel tiles per workgroup when the layer has them, else two and two pixel halves
-  const int wc = cout >= 128 ? 4 : 2;
-  const int wp = 4 / wc;
+  // eight wavefronts (256 channels per workgroup) for wide layers on small planes: half the channel groups
+  static const int nw_tune = env_int("FQ_C3_NW", 0);
+  // (measured in the ResNet-50 step: 256 @14x14 32.8 -> 28.6 us; 512 @7x7, where only 196 workgroups would remain, 34.1 -> 35.1)
+  const bool nw8_fills = ((cols + 63) / 64) * ((cout + 255) / 256) >= (int64_t)num_cu();
+  int nw = (nw_tune == 4 || nw_tune == 8) ? nw_tune : ((cout >= 256 && (kt == 8 || kt == 16) && nw8_fills) ? 8 : 4);
+  if (cout < 256 || !(kt == 8 || kt == 16)) nw = 4;
+  const int wc = nw == 8 ? 8 : (cout >= 128 ? 4 : 2);
+  const int wp = nw / wc;
   const int64_t cs = (cout + 32 * wc - 1) / (32 * wc);
   // two pixel tiles per wavefront: measured best (or equal) on all four ResNet-50 stages in the model - 63 / 39 / 33 / 34 us
   // at 56x56 / 28x28 / 14x14 / 7x7 against 67 / 45 / 34 / 46 with four and 78 / 44 / 39 / 41 with one
@@ -328,23 +335,27 @@ int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, con
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   ProfScope prof(FQ_KERNEL_CONV3X3, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), st);
   bool launched = false;
-#define FQ_C3_CASE(KT_, PTW_, WC_, D_, LB_)                                                                            \
-  if (kt == KT_ && ptw == PTW_ && wc == WC_) {                                                                         \
+#define FQ_C3_CASE_NW(KT_, PTW_, WC_, D_, LB_, NW_)                                                                    \
+  if (kt == KT_ && ptw == PTW_ && wc == WC_ && nw == NW_) {                                                            \
     static const bool attr_ok =                                                                                        \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_i8_kernel<KT_, PTW_, WC_, D_, LB_>),                \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_i8_kernel<KT_, PTW_, WC_, D_, LB_, NW_>),           \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;                     \
     FQ_REQUIRE(attr_ok, "fq_conv3x3_i8: cannot raise the dynamic LDS limit");                                          \
-    hipLaunchKernelGGL((conv3x3_i8_kernel<KT_, PTW_, WC_, D_, LB_>), dim3((unsigned)grid), dim3(kBlock), lds, st, x,   \
+    hipLaunchKernelGGL((conv3x3_i8_kernel<KT_, PTW_, WC_, D_, LB_, NW_>), dim3((unsigned)grid), dim3(NW_ * 64), lds, st, \
+                       x,                                                                                              \
                        wfrag, wscale, (const int*)wsum, bias, y, g, in_stat, (int)n, in_thr, levels, lo_neg, kEps,     \
                        out_current_max, bn_scale, bn_shift, act, stat_out);                                            \
     launched = true;                                                                                                   \
   }
+#define FQ_C3_CASE(KT_, PTW_, WC_, D_, LB_) FQ_C3_CASE_NW(KT_, PTW_, WC_, D_, LB_, 4)
 #define FQ_C3_KT(KT_)                                                                                                  \
   FQ_C3_CASE(KT_, 1, 4, 6, 4) FQ_C3_CASE(KT_, 2, 4, 4, 4) FQ_C3_CASE(KT_, 4, 4, 3, 3)                                  \
   FQ_C3_CASE(KT_, 1, 2, 6, 4) FQ_C3_CASE(KT_, 2, 2, 4, 4) FQ_C3_CASE(KT_, 4, 2, 3, 3)
   FQ_C3_KT(2) FQ_C3_KT(4) FQ_C3_KT(8) FQ_C3_KT(16)
+  FQ_C3_CASE_NW(8, 1, 8, 6, 4, 8) FQ_C3_CASE_NW(8, 2, 8, 4, 4, 8) FQ_C3_CASE_NW(16, 1, 8, 6, 4, 8) FQ_C3_CASE_NW(16, 2, 8, 4, 4, 8)
 #undef FQ_C3_KT
 #undef FQ_C3_CASE
+#undef FQ_C3_CASE_NW
   FQ_REQUIRE(launched, "fq_conv3x3_i8: no instantiation for K/32=%d, %d pixel tiles per wavefront, %d channel tiles per "
              "workgroup", kt, ptw, wc);
   FQ_LAUNCH_CHECK();
