@@ -23,11 +23,13 @@ def family(n):
         return 'histogram'
     if 'dwconv3x3' in n:
         return 'dwconv'
-    if 'stem_conv3x3s2_kernel' in n:
+    if 'stem_conv3x3s2_kernel' in n or 'stem_mfma_kernel' in n:
         return 'stem'
-    if 'bn_act_stat_kernel' in n:
+    if 'conv3x3_i8_kernel' in n:
+        return 'conv3x3'
+    if 'bn_act_stat_kernel' in n or 'bn_act_maxpool_stat_kernel' in n or 'add_act_stat_kernel' in n:
         return 'bn_act'
-    if 'gap_stat_kernel' in n:
+    if 'gap_stat_kernel' in n or 'gap_stat_lds_kernel' in n:
         return 'pool'
     if 'minmax_kernel' in n:
         return 'global_max'
