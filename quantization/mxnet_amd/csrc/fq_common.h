@@ -385,6 +385,59 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 constexpr int kPolNtLoad = 1, kPolNtStore = 2, kPolReverse = 4;
 
+__device__ __forceinline__ f4 buf_ld_v4f(fq_rsrc r, unsigned voff, unsigned soff) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_st_v4f(fq_rsrc r, unsigned voff, unsigned soff, f4 v) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)voff, (int)soff, 0);
+}
+
+// max over the wavefront of NON-NEGATIVE floats (|x| statistics), the same in every lane: four DPP steps inside the rows
+// of 16 lanes, then the four row results through scalar registers (non-negative floats order like their bit patterns).
+// wave_max() above goes through six ds_bpermute round trips with lane arithmetic (~1.2 us per call in the depthwise
+// kernels, tools/dw_trace.py); this is ~12 instructions without the LDS pipeline.
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  int b = __builtin_bit_cast(int, v);
+#define FQ_WMAX_STEP(ctrl)                                                      \
+  do {                                                                          \
+    const int o = __builtin_amdgcn_update_dpp(b, b, ctrl, 0xF, 0xF, false);     \
+    b = o > b ? o : b;                                                          \
+  } while (0)
+  FQ_WMAX_STEP(0xB1);       // quad_perm [1,0,3,2]
+  FQ_WMAX_STEP(0x4E);       // quad_perm [2,3,0,1]
+  FQ_WMAX_STEP(0x141);      // row_half_mirror
+  FQ_WMAX_STEP(0x140);      // row_mirror
+#undef FQ_WMAX_STEP
+  const int r0 = __builtin_amdgcn_readlane(b, 0), r1 = __builtin_amdgcn_readlane(b, 16),
+            r2 = __builtin_amdgcn_readlane(b, 32), r3 = __builtin_amdgcn_readlane(b, 48);
+  const int m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+  return __builtin_bit_cast(float, m01 > m23 ? m01 : m23);
+}
+
+// n / d and n % d for n < 2^31 by one multiplication (d fixed per launch; host: fast_div_for).  k = 31 + ceil(log2 d),
+// M = ceil(2^k / d) < 2^32: M * d - 2^k < d and n < 2^31 make floor(n * M / 2^k) == floor(n / d).
+struct FastDiv {
+  unsigned d, M, sh;     // sh = k - 32
+};
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) { return f.d == 1u ? n : __umulhi(n, f.M) >> f.sh; }
+__device__ __forceinline__ unsigned fast_mod(unsigned n, const FastDiv& f) { return n - fast_div(n, f) * f.d; }
+inline FastDiv fast_div_for(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  f.M = 0;
+  f.sh = 0;
+  if (d > 1) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned k = 31 + l;
+    f.M = (unsigned)(((1ull << k) + d - 1) / d);
+    f.sh = k - 32;
+  }
+  return f;
+}
+
 template <bool NT>
 __device__ __forceinline__ f4 ld4(const f4* p) {
   if (NT) return __builtin_nontemporal_load(p);
@@ -428,6 +481,36 @@ __device__ __forceinline__ float act_rt(float v, int act) {
   if (act == FQ_ACT_RELU) v = fmaxf(v, 0.0f);
   if (act == FQ_ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
   return v;
+}
+
+// Lane i <- lane i-1 / lane i+1 of the wavefront in ONE VALU instruction (DPP wave shift, usually folded into the consuming
+// FMA's operand); lane 0 / lane 63 receive 0.  __shfl_up / __shfl_down by 1 go through ds_bpermute: lane-id arithmetic,
+// a select, and an LDS-pipeline round trip in the middle of the dependency chain (tools/dpp_probe.hip: same data movement).
+__device__ __forceinline__ float lane_prev(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_next(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+// Epilogue of the depthwise kernels.  EPI 0: bias / BN / activation decided at run time (hipcc turns the wave-uniform
+// branches into four selects per output); EPI 1 / 2: the fused-inference case - BN, no bias, ReLU / ReLU6 - in 3 / 4
+// instructions.  Same operations in the same order either way.
+constexpr int kEpiRuntime = 0, kEpiBnRelu = 1, kEpiBnRelu6 = 2;
+template <int EPI>
+__device__ __forceinline__ float dw_finish(float acc, bool has_bias, float bch, bool has_bn, float bsc, float bsh, int act) {
+  if (EPI == kEpiRuntime) {
+    if (has_bias) acc = acc + bch;
+    if (has_bn) {
+      acc = acc * bsc;
+      acc = acc + bsh;
+    }
+    return act_rt(acc, act);
+  }
+  acc = acc * bsc;
+  acc = acc + bsh;
+  acc = fmaxf(acc, 0.0f);
+  return EPI == kEpiBnRelu6 ? fminf(acc, 6.0f) : acc;
 }
 
 #ifdef FQ_PW_TRACE

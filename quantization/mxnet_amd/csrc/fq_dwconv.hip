@@ -204,7 +204,7 @@ struct DwColGeom {
   int segs;     // segments per wavefront
 };
 
-template <int S, bool QUANT, bool ONLINE>
+template <int S, bool QUANT, bool ONLINE, int EPI>
 __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
     const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
     float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
       };
       auto emit = [&](int r, float c1, float& a0, float& a1, float& a2, float& b0, float& b1, float& b2) {
         if (QUANT) c1 = fq_code(c1, q) * q.scale;
-        const float c0 = __shfl_up(c1, 1, 64), c2 = __shfl_down(c1, 1, 64);
+        const float c0 = lane_prev(c1), c2 = lane_next(c1);
         float acc = 0.0f;
         acc = fmaf(w00, a0, acc);
         acc = fmaf(w01, a1, acc);
@@ -312,12 +312,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
         acc = fmaf(w20, c0, acc);
         acc = fmaf(w21, c1, acc);
         acc = fmaf(w22, c2, acc);
-        if (bias != nullptr) acc = acc + bch;
-        if (has_bn) {
-          acc = acc * bsc;
-          acc = acc + bsh;
-        }
-        acc = act_rt(acc, act);
+        acc = dw_finish<EPI>(acc, bias != nullptr, bch, has_bn, bsc, bsh, act);
         m = fmaxf(m, keep(fabsf(acc), is_out));
         if (is_out) yp[(int64_t)r * g.Wo] = acc;
         a0 = b0; a1 = b1; a2 = b2;
@@ -331,7 +326,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
       FQ_PIN();
       ensure_q();
       if (QUANT) b1 = fq_code(b1, q) * q.scale;
-      float b0 = __shfl_up(b1, 1, 64), b2 = __shfl_down(b1, 1, 64);
+      float b0 = lane_prev(b1), b2 = lane_next(b1);
       const int rend = g.Ho;                              // same trip count for every lane of the grid
       int r0 = 0;
       for (; r0 + D <= rend; r0 += D) {
@@ -365,7 +360,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
           c1 = fq_code(c1, q) * q.scale;
           c2 = fq_code(c2, q) * q.scale;
         }
-        const float b0 = __shfl_up(b2, 1, 64), c0 = __shfl_up(c2, 1, 64);
+        const float b0 = lane_prev(b2), c0 = lane_prev(c2);
         float acc = 0.0f;
         acc = fmaf(w00, a0, acc);
         acc = fmaf(w01, a1, acc);
@@ -376,12 +371,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
         acc = fmaf(w20, c0, acc);
         acc = fmaf(w21, c1, acc);
         acc = fmaf(w22, c2, acc);
-        if (bias != nullptr) acc = acc + bch;
-        if (has_bn) {
-          acc = acc * bsc;
-          acc = acc + bsh;
-        }
-        acc = act_rt(acc, act);
+        acc = dw_finish<EPI>(acc, bias != nullptr, bch, has_bn, bsc, bsh, act);
         m = fmaxf(m, keep(fabsf(acc), is_out));
         if (is_out) yp[(int64_t)r * g.Wo] = acc;
         a0 = c0; a1 = c1; a2 = c2;
@@ -443,6 +433,477 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K2o: small planes (H rows known at compile time, a plane row fits one wavefront): a wavefront holds EVERY input row of
+// its planes in registers and requests the rows, weights and constants of its NEXT block before it works on the current
+// one (K2d restarts its prefetch ring in every block: two exposed memory latencies + the weight gather per 14 row steps).
+// These layers are bound by instruction issue, not by memory (ablation without loads and stores: 21 of 25 us on
+// 512x14x14, profiles/r2_dw_planes.txt), so the form is built around the instruction count per output:
+//   * CPL = 2 columns per lane where W is even: 8-byte loads and stores, and the 3x3 sums of the two outputs run as ONE
+//     chain of packed fp32 FMAs (v_pk_fma_f32: two IEEE FMAs per lane per instruction, same order as the scalar chain);
+//   * no halo lanes: a plane takes W / CPL lanes, its edge lanes replace the neighbour's value by 0 (one select);
+//   * horizontal neighbours by DPP wave shifts (lane_prev / lane_next), epilogue fixed at compile time (EPI).
+// Buffer addressing: idle lanes and the tail read 0 and store nothing through an out-of-range offset, row strides sit in
+// scalar registers.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 buf_ld_2f32(fq_rsrc r, unsigned voff, unsigned soff) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_st_2f32(fq_rsrc r, unsigned voff, unsigned soff, f2 v) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ f2 splat2(float v) { return (f2){v, v}; }
+
+template <int EPI>
+__device__ __forceinline__ f2 dw_finish2(f2 acc, bool has_bias, float bch, bool has_bn, float bsc, float bsh, int act) {
+  if (EPI == kEpiRuntime) {
+    acc.x = dw_finish<EPI>(acc.x, has_bias, bch, has_bn, bsc, bsh, act);
+    acc.y = dw_finish<EPI>(acc.y, has_bias, bch, has_bn, bsc, bsh, act);
+    return acc;
+  }
+  acc = acc * splat2(bsc);
+  acc = acc + splat2(bsh);
+  acc.x = fmaxf(acc.x, 0.0f);
+  acc.y = fmaxf(acc.y, 0.0f);
+  if (EPI == kEpiBnRelu6) {
+    acc.x = fminf(acc.x, 6.0f);
+    acc.y = fminf(acc.y, 6.0f);
+  }
+  return acc;
+}
+
+template <int S, int H, int CPL>
+struct DwPlanesBlk {
+  static constexpr int kIn = (S == 2 || CPL == 2) ? 2 : 1;     // input columns per lane
+  float raw[kIn * H];      // row-major: (column 0[, column 1]) of rows 0..H-1
+  float w[9];
+  float bch, bsc, bsh;
+};
+
+template <int S, bool QUANT, bool ONLINE, int H, int CPL, int EPI>
+__global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_planes_kernel(
+    const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
+    float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
+    const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
+  static_assert(S == 1 || CPL == 2, "stride 2 reads two input columns per lane");
+  typedef DwPlanesBlk<S, H, CPL> Blk;
+  constexpr int KIN = Blk::kIn;
+  constexpr int HO = (H - 1) / S + 1;
+  constexpr int kStatSlots = 16;
+  constexpr unsigned kOob = 0x80000000u;                 // beyond every resource of this kernel (host: tensors < 2 GiB)
+  __shared__ unsigned k_stat[kStatSlots];
+  if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
+  PW_STAMP(0);
+  const int lane = threadIdx.x & 63;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int seg_in_wave = lane / g.SEG;                   // g.SEG lanes per plane: W / CPL (stride 1), Wo (stride 2)
+  const int pos = lane - seg_in_wave * g.SEG;
+  const bool lane_used = seg_in_wave < g.segs;
+  const bool first = pos == 0, last = pos == g.SEG - 1;   // edge lanes of a plane: no left / right neighbour
+  const unsigned segs_per_block = (unsigned)g.segs * (kBlock / 64);
+  const unsigned tsegs = (unsigned)total_segs, C_u = (unsigned)g.C;           // one segment per plane: tsegs planes
+  const unsigned nblk = (tsegs + segs_per_block - 1) / segs_per_block;
+  const unsigned blk_begin = (unsigned)((uint64_t)nblk * blockIdx.x / gridDim.x);
+  const unsigned blk_end = (unsigned)((uint64_t)nblk * (blockIdx.x + 1) / gridDim.x);
+  const unsigned n_samples = tsegs / C_u;
+  unsigned s_base;
+  {
+    const unsigned seg0 = blk_begin * segs_per_block;
+    s_base = (seg0 < tsegs ? seg0 : tsegs - 1) / C_u;
+  }
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr, has_bias = bias != nullptr;
+  const unsigned plane_in = (unsigned)(H * g.W), plane_out = (unsigned)(HO * g.Wo);
+  const unsigned row_in = (unsigned)g.W * 4u, row_out = (unsigned)g.Wo * 4u;
+  const fq_rsrc rx = make_rsrc(x, (int64_t)tsegs * plane_in * 4), ry = make_rsrc(y, (int64_t)tsegs * plane_out * 4);
+  const fq_rsrc rw = make_rsrc(wgt, (int64_t)g.C * 36);
+  const unsigned ic0 = (unsigned)pos * KIN;               // first input column of this lane
+  const unsigned oc0 = S == 1 ? ic0 : (unsigned)pos;      // first output column of this lane
+
+  auto issue = [&](unsigned blk, Blk& b) __attribute__((always_inline)) {
+    const unsigned seg = blk * segs_per_block + wave * (unsigned)g.segs + (unsigned)seg_in_wave;
+    const bool seg_ok = lane_used && seg < tsegs;
+    const unsigned xoff = seg_ok ? (seg * plane_in + ic0) * 4u : kOob;
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+      if (KIN == 1) {
+        b.raw[r] = buf_ld_f32(rx, xoff, (unsigned)r * row_in);
+      } else {
+        const f2 v = buf_ld_2f32(rx, xoff, (unsigned)r * row_in);
+        b.raw[2 * r] = v.x;
+        b.raw[2 * r + 1] = v.y;
+      }
+    }
+    const unsigned ch = seg_ok ? seg % C_u : 0u;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) b.w[k] = buf_ld_f32(rw, ch * 36u, (unsigned)k * 4u);
+    b.bch = has_bias ? bias[ch] : 0.0f;
+    b.bsc = has_bn ? bn_scale[ch] : 1.0f;
+    b.bsh = has_bn ? bn_shift[ch] : 0.0f;
+  };
+
+  Blk nxt;
+  FQ_PIN();
+  PW_STAMP(6);
+  if (blk_begin < blk_end) issue(blk_begin, nxt);
+  FQ_PIN();
+  PW_STAMP(7);
+  QParams q;
+  q.lo = q.hi = q.denom = q.scale = 0.0f;
+  q.rden = 0.0;
+  if (QUANT) {                                            // behind the first block's loads (two dependent cold loads + an fp64 tree)
+    const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
+    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  }
+  PW_STAMP(1);
+  __syncthreads();                                        // statistic table zeroed
+  for (unsigned blk = blk_begin; blk < blk_end; ++blk) {
+    if (blk == blk_begin + 1) PW_STAMP(2);
+#ifdef FQ_PW_TRACE
+    if (blk == blk_begin) {                               // trace build: separate "first block's data arrives" from "first pass through the code"
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PW_STAMP(4);
+    }
+#endif
+    Blk cur = nxt;
+    FQ_PIN();
+    if (blk + 1 < blk_end) issue(blk + 1, nxt);
+    FQ_PIN();
+    const unsigned seg = blk * segs_per_block + wave * (unsigned)g.segs + (unsigned)seg_in_wave;
+    const bool is_out = lane_used && seg < tsegs;
+    const unsigned yoff = is_out ? (seg * plane_out + oc0) * 4u : kOob;
+    const unsigned sample = (seg < tsegs ? seg : tsegs - 1) / C_u;
+    float m = 0.0f;
+    auto fq = [&](float v) -> float { return QUANT ? fq_code(v, q) * q.scale : v; };
+    // the value the lane on the left / right holds.  The shift is taken by EVERY lane and masked afterwards: under a
+    // branch the edge lanes would be switched off, and a DPP read from a switched-off lane returns 0
+    auto left_of = [&](float v) -> float {
+      const float t = lane_prev(v);
+      return first ? 0.0f : t;
+    };
+    auto right_of = [&](float v) -> float {
+      const float t = lane_next(v);
+      return last ? 0.0f : t;
+    };
+    if (S == 1 && CPL == 2) {
+      // two outputs per lane: (L, q0, q1) and (q0, q1, R) per input row, summed as one packed chain
+      f2 aL = {0.f, 0.f}, aC = {0.f, 0.f}, aR = {0.f, 0.f};     // row r-1: (L, q0), (q0, q1), (q1, R)
+      f2 bL, bC, bR;
+      {
+        const float q0 = fq(cur.raw[0]), q1 = fq(cur.raw[1]);
+        bL = (f2){left_of(q1), q0};
+        bC = (f2){q0, q1};
+        bR = (f2){q1, right_of(q0)};
+      }
+#pragma unroll
+      for (int r = 0; r < H; ++r) {
+        f2 cL = {0.f, 0.f}, cC = {0.f, 0.f}, cR = {0.f, 0.f};
+        if (r + 1 < H) {
+          const float q0 = fq(cur.raw[2 * r + 2]), q1 = fq(cur.raw[2 * r + 3]);
+          cL = (f2){left_of(q1), q0};
+          cC = (f2){q0, q1};
+          cR = (f2){q1, right_of(q0)};
+        }
+        f2 acc = {0.f, 0.f};
+        acc = __builtin_elementwise_fma(splat2(cur.w[0]), aL, acc);
+        acc = __builtin_elementwise_fma(splat2(cur.w[1]), aC, acc);
+        acc = __builtin_elementwise_fma(splat2(cur.w[2]), aR, acc);
+        acc = __builtin_elementwise_fma(splat2(cur.w[3]), bL, acc);
+        acc = __builtin_elementwise_fma(splat2(cur.w[4]), bC, acc);
+        acc = __builtin_elementwise_fma(splat2(cur.w[5]), bR, acc);
+        acc = __builtin_elementwise_fma(splat2(cur.w[6]), cL, acc);
+        acc = __builtin_elementwise_fma(splat2(cur.w[7]), cC, acc);
+        acc = __builtin_elementwise_fma(splat2(cur.w[8]), cR, acc);
+        acc = dw_finish2<EPI>(acc, has_bias, cur.bch, has_bn, cur.bsc, cur.bsh, act);
+        m = fmaxf(m, fmaxf(fabsf(acc.x), fabsf(acc.y)));
+        buf_st_2f32(ry, yoff, (unsigned)r * row_out, acc);
+        aL = bL; aC = bC; aR = bR;
+        bL = cL; bC = cC; bR = cR;
+      }
+    } else {
+      auto finish = [&](int r, float acc) __attribute__((always_inline)) {
+        acc = dw_finish<EPI>(acc, has_bias, cur.bch, has_bn, cur.bsc, cur.bsh, act);
+        m = fmaxf(m, fabsf(acc));
+        buf_st_f32(ry, yoff, (unsigned)r * row_out, acc);
+      };
+      auto window = [&](float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2) -> float {
+        float acc = 0.0f;
+        acc = fmaf(cur.w[0], a0, acc);
+        acc = fmaf(cur.w[1], a1, acc);
+        acc = fmaf(cur.w[2], a2, acc);
+        acc = fmaf(cur.w[3], b0, acc);
+        acc = fmaf(cur.w[4], b1, acc);
+        acc = fmaf(cur.w[5], b2, acc);
+        acc = fmaf(cur.w[6], c0, acc);
+        acc = fmaf(cur.w[7], c1, acc);
+        acc = fmaf(cur.w[8], c2, acc);
+        return acc;
+      };
+      if (S == 1) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        float b1 = fq(cur.raw[0]);
+        float b0 = left_of(b1), b2 = right_of(b1);
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+          if (r + 1 < H) {
+            c1 = fq(cur.raw[r + 1]);
+            c0 = left_of(c1);
+            c2 = right_of(c1);
+          }
+          finish(r, window(a0, a1, a2, b0, b1, b2, c0, c1, c2));
+          a0 = b0; a1 = b1; a2 = b2;
+          b0 = c0; b1 = c1; b2 = c2;
+        }
+      } else {
+        // output row r: input rows 2r-1 (a), 2r (b), 2r+1 (c); per row: left = the left lane's odd column, centre / right own
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < HO; ++r) {
+          const float b1 = fq(cur.raw[4 * r]), b2 = fq(cur.raw[4 * r + 1]);
+          const float b0 = left_of(b2);
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+          if (2 * r + 1 < H) {
+            c1 = fq(cur.raw[4 * r + 2]);
+            c2 = fq(cur.raw[4 * r + 3]);
+            c0 = left_of(c2);
+          }
+          finish(r, window(a0, a1, a2, b0, b1, b2, c0, c1, c2));
+          a0 = c0; a1 = c1; a2 = c2;
+        }
+      }
+    }
+    if (has_stat) {
+      m = is_out ? m : 0.0f;
+      const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sample);
+      const bool wave_uniform = __all(!is_out || sample == s0);
+      if (wave_uniform) {
+        const float wm = wave_max(m);
+        if (lane == 0 && __float_as_uint(wm) != 0u) {
+          const unsigned slot = s0 - s_base;
+          if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+          else atomic_max_f32(stat_out + s0, wm);
+        }
+      } else if (is_out) {
+        const unsigned slot = sample - s_base;
+        if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+        else atomic_max_f32(stat_out + sample, m);
+      }
+    }
+  }
+  PW_STAMP(3);
+  if (has_stat) {
+    __syncthreads();
+    if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < n_samples)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+  }
+  PW_STAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2p: small planes through an LDS transpose.  The column-walking forms above read and write a plane row by row: every
+// memory instruction of a wavefront touches 56-byte pieces of 4-9 different planes (9-18 cache lines, each of them again
+// by the next two rows), and the kernel is bound by the rate at which the CU's memory pipeline takes such instructions
+// (tools/dw_trace.py: 26 loads per wavefront take 2.5 us to ISSUE when 12 wavefronts per CU do it together; no loads /
+// no stores ablation: 21 of 25 us remain).  Here a wavefront moves its P planes (one contiguous P * H * W * 4 byte range)
+// with 16 bytes per lane on consecutive addresses - every cache line is touched once, by one instruction:
+//   A  flat range -> registers (requested ONE BLOCK AHEAD) -> quantise (no neighbours needed) -> wavefront-private LDS tile
+//   B  lane = (plane, column pair): walk down the rows reading the tile (8 bytes per lane and row), 3x3 sums as packed
+//      fp32 FMA chains, epilogue, result written over the tile row just consumed
+//   C  tile -> registers -> flat 16-byte stores
+// No workgroup barrier: a wavefront only ever touches its own tile (LDS operations of a wavefront complete in order).
+// ---------------------------------------------------------------------------------------------------------------
+struct DwFlatGeom {
+  int C;
+  unsigned planes;          // n * c
+  unsigned per, rem;        // workgroup b works on blocks [b * per + min(b, rem), ...) - per + (b < rem) of them
+  FastDiv by_c;             // plane % C, plane / C
+};
+
+template <bool QUANT, bool ONLINE, int H, int W, int EPI>
+__global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
+    const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
+    float* __restrict__ y, DwFlatGeom g, const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr,
+    float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out, const float* __restrict__ bn_scale,
+    const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
+  static_assert(W % 2 == 0 && (H * W) % 4 == 0 && W / 2 <= 32, "even rows of whole 16-byte groups");
+  constexpr int LPP = W / 2;               // lanes per plane in phase B
+  constexpr int P = 64 / LPP;              // planes per wavefront and block
+  constexpr int PF4 = H * W / 4;           // 16-byte groups per plane
+  constexpr int NF4 = P * PF4;             // ... per wavefront and block
+  constexpr int NL = (NF4 + 63) / 64;      // 16-byte accesses per lane
+  constexpr unsigned kPlaneBytes = H * W * 4;
+  constexpr int kStatSlots = 16;
+  constexpr unsigned kOob = 0x80000000u;   // beyond every resource of this kernel (host: tensors < 2 GiB)
+  __shared__ f4 tile[kBlock / 64][NL * 64];
+  __shared__ unsigned k_stat[kStatSlots];
+  if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
+  PW_STAMP(0);
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned b = blockIdx.x;
+  const unsigned blk_begin = b * g.per + (b < g.rem ? b : g.rem);
+  const unsigned blk_end = blk_begin + g.per + (b < g.rem ? 1u : 0u);
+  const unsigned planes = g.planes;
+  const unsigned n_samples = (unsigned)n;
+  unsigned s_base;
+  {
+    const unsigned p0 = blk_begin * (P * (kBlock / 64));
+    s_base = fast_div(p0 < planes ? p0 : planes - 1, g.by_c);
+  }
+  const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr, has_bias = bias != nullptr;
+  const fq_rsrc rx = make_rsrc(x, (int64_t)planes * kPlaneBytes), ry = make_rsrc(y, (int64_t)planes * kPlaneBytes);
+  const fq_rsrc rw = make_rsrc(wgt, (int64_t)g.C * 36);
+  // phase B coordinates of this lane
+  const unsigned j = lane / LPP, pos = lane - j * LPP;
+  const bool b_lane = lane < P * LPP;
+  const bool first = pos == 0, last = pos == LPP - 1;
+  float* const my_tile = reinterpret_cast<float*>(tile[wave]);
+
+  struct Blk {
+    f4 raw[NL];
+    f4 w03, w47;
+    float w8, bch, bsc, bsh;
+  };
+  auto issue = [&](unsigned blk, Blk& k) __attribute__((always_inline)) {
+    const unsigned base = (blk * (kBlock / 64) + wave) * P;                  // first plane of this wavefront (uniform)
+    const unsigned left = base < planes ? planes - base : 0u;
+    const unsigned lim = (left < (unsigned)P ? left : (unsigned)P) * PF4;      // 16-byte groups that exist
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      k.raw[i] = buf_ld_v4f(rx, (lane + 64u * i) < lim ? lane * 16u : kOob, base * kPlaneBytes + 1024u * i);
+    const unsigned ch = (b_lane && j < left) ? fast_mod(base + j, g.by_c) : 0u;
+    k.w03 = buf_ld_v4f(rw, ch * 36u, 0);
+    k.w47 = buf_ld_v4f(rw, ch * 36u, 16);
+    k.w8 = buf_ld_f32(rw, ch * 36u, 32);
+    k.bch = has_bias ? bias[ch] : 0.0f;
+    k.bsc = has_bn ? bn_scale[ch] : 1.0f;
+    k.bsh = has_bn ? bn_shift[ch] : 0.0f;
+  };
+
+  Blk nxt;
+  FQ_PIN();
+  PW_STAMP(6);
+  if (blk_begin < blk_end) issue(blk_begin, nxt);
+  FQ_PIN();
+  PW_STAMP(7);
+  QParams q;
+  q.lo = q.hi = q.denom = q.scale = 0.0f;
+  q.rden = 0.0;
+  if (QUANT) {                                            // behind the first block's requests
+    const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
+    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  }
+  PW_STAMP(1);
+  __syncthreads();                                        // statistic table zeroed
+  for (unsigned blk = blk_begin; blk < blk_end; ++blk) {
+    if (blk == blk_begin + 1) PW_STAMP(2);
+    Blk cur = nxt;
+    FQ_PIN();
+    if (blk + 1 < blk_end) issue(blk + 1, nxt);
+    FQ_PIN();
+    const unsigned base = (blk * (kBlock / 64) + wave) * P;
+    const unsigned left = base < planes ? planes - base : 0u;
+    const unsigned lim = (left < (unsigned)P ? left : (unsigned)P) * PF4;
+    // ---- A: quantise in flat order, stage ---------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      f4 v = cur.raw[i];
+      if (QUANT) v = fq_code4(v, q) * q.scale;
+      tile[wave][lane + 64 * i] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- B: 3x3 on the tile, in place ----------------------------------------------------------------------------------
+    float m = 0.0f;
+    const bool is_out = b_lane && j < left;
+    if (b_lane) {
+      float* lp = my_tile + j * (H * W) + pos * 2;
+      auto left_of = [&](float v) -> float {              // (every lane takes the shift; the edge lanes drop it afterwards)
+        const float t = lane_prev(v);
+        return first ? 0.0f : t;
+      };
+      auto right_of = [&](float v) -> float {
+        const float t = lane_next(v);
+        return last ? 0.0f : t;
+      };
+      const f2 w0 = splat2(cur.w03.x), w1 = splat2(cur.w03.y), w2 = splat2(cur.w03.z), w3 = splat2(cur.w03.w),
+               w4 = splat2(cur.w47.x), w5 = splat2(cur.w47.y), w6 = splat2(cur.w47.z), w7 = splat2(cur.w47.w),
+               w8 = splat2(cur.w8);
+      f2 aL = {0.f, 0.f}, aC = {0.f, 0.f}, aR = {0.f, 0.f};     // row r-1: (L, q0), (q0, q1), (q1, R)
+      f2 bL, bC, bR;
+      {
+        const f2 v = *reinterpret_cast<const f2*>(lp);
+        bL = (f2){left_of(v.y), v.x};
+        bC = v;
+        bR = (f2){v.y, right_of(v.x)};
+      }
+#pragma unroll
+      for (int r = 0; r < H; ++r) {
+        f2 cL = {0.f, 0.f}, cC = {0.f, 0.f}, cR = {0.f, 0.f};
+        if (r + 1 < H) {
+          const f2 v = *reinterpret_cast<const f2*>(lp + (r + 1) * W);
+          cL = (f2){left_of(v.y), v.x};
+          cC = v;
+          cR = (f2){v.y, right_of(v.x)};
+        }
+        f2 acc = {0.f, 0.f};
+        acc = __builtin_elementwise_fma(w0, aL, acc);
+        acc = __builtin_elementwise_fma(w1, aC, acc);
+        acc = __builtin_elementwise_fma(w2, aR, acc);
+        acc = __builtin_elementwise_fma(w3, bL, acc);
+        acc = __builtin_elementwise_fma(w4, bC, acc);
+        acc = __builtin_elementwise_fma(w5, bR, acc);
+        acc = __builtin_elementwise_fma(w6, cL, acc);
+        acc = __builtin_elementwise_fma(w7, cC, acc);
+        acc = __builtin_elementwise_fma(w8, cR, acc);
+        acc = dw_finish2<EPI>(acc, has_bias, cur.bch, has_bn, cur.bsc, cur.bsh, act);
+        m = fmaxf(m, fmaxf(fabsf(acc.x), fabsf(acc.y)));
+        *reinterpret_cast<f2*>(lp + r * W) = acc;            // row r of the tile was read in the previous step
+        aL = bL; aC = bC; aR = bR;
+        bL = cL; bC = cC; bR = cR;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- C: flat stores ---------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      buf_st_v4f(ry, (lane + 64u * i) < lim ? lane * 16u : kOob, base * kPlaneBytes + 1024u * i, tile[wave][lane + 64 * i]);
+    if (has_stat) {
+      m = is_out ? m : 0.0f;
+      const unsigned sample = fast_div(base + (is_out ? j : 0u), g.by_c);
+      const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sample);
+      const bool wave_uniform = __all(!is_out || sample == s0);
+      if (wave_uniform) {
+        const float wm = wave_max_nonneg(m);
+        if (lane == 0 && __float_as_uint(wm) != 0u) {
+          const unsigned slot = s0 - s_base;
+          if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
+          else atomic_max_f32(stat_out + s0, wm);
+        }
+      } else if (is_out) {
+        const unsigned slot = sample - s_base;
+        if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+        else atomic_max_f32(stat_out + sample, m);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                      // (the next block's phase A overwrites the tile)
+  }
+  PW_STAMP(3);
+  if (has_stat) {
+    __syncthreads();
+    if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < n_samples)
+      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+  }
+  PW_STAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K2e: the same sliding window with FOUR input columns per lane (16-byte loads, 16-byte stores for stride 1 / 8-byte
 // for stride 2) — needs W % 4 == 0.  With 4-byte accesses the kernel above cannot keep enough bytes in flight
 // (PMC: 38 % of wave cycles parked on vmcnt at 4.1 TB/s); this form has 4x the bytes per outstanding load.
@@ -452,7 +913,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
 // NT: nontemporal LOADS - an input beyond the 256 MB Infinity Cache is dead after this pass and should not displace the
 // output, which the consumer does find there (measured in the model: 64 @112x112 stride 2, 411 MB in / 103 MB out, 110 -> 99 us;
 // with nontemporal stores too, or on the 205 MB inputs of the stride-1 layers, the step gets slower)
-template <int S, bool QUANT, bool ONLINE, bool NT>
+template <int S, bool QUANT, bool ONLINE, bool NT, int EPI>
 __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
     const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
     float* __restrict__ y, DwColGeom g, int64_t total_segs, const float* __restrict__ in_stat, int n,
@@ -537,14 +998,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
       return keep4(ld4<NT>(xs + (int64_t)rc * rowq), ld_ok && row <= last_row);
     };
     auto quant4 = [&](f4 v) -> f4 { return QUANT ? fq_code4(v, q) * q.scale : v; };
-    auto finish = [&](float acc) -> float {
-      if (bias != nullptr) acc = acc + bch;
-      if (has_bn) {
-        acc = acc * bsc;
-        acc = acc + bsh;
-      }
-      return act_rt(acc, act);
-    };
+    auto finish = [&](float acc) -> float { return dw_finish<EPI>(acc, bias != nullptr, bch, has_bn, bsc, bsh, act); };
 
     if (S == 1) {
       // a, b, c: rows r-1, r, r+1 as (left, v.x, v.y, v.z, v.w, right)
@@ -554,16 +1008,16 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
       for (int k = 0; k < D; ++k) raw[k] = ldrow(1 + k);
       {
         const f4 v = quant4(ldrow(0));
-        b[0] = __shfl_up(v.w, 1, 64);
+        b[0] = lane_prev(v.w);
         b[1] = v.x; b[2] = v.y; b[3] = v.z; b[4] = v.w;
-        b[5] = __shfl_down(v.x, 1, 64);
+        b[5] = lane_next(v.x);
       }
       auto emit = [&](int r, f4 craw) {
         const f4 v = quant4(craw);
         float c[6];
-        c[0] = __shfl_up(v.w, 1, 64);
+        c[0] = lane_prev(v.w);
         c[1] = v.x; c[2] = v.y; c[3] = v.z; c[4] = v.w;
-        c[5] = __shfl_down(v.x, 1, 64);
+        c[5] = lane_next(v.x);
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -612,8 +1066,8 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
       }
       auto emit2 = [&](int r, f4 braw, f4 craw) {
         const f4 vb = quant4(braw), vc = quant4(craw);
-        const float b[5] = {__shfl_up(vb.w, 1, 64), vb.x, vb.y, vb.z, vb.w};
-        const float c[5] = {__shfl_up(vc.w, 1, 64), vc.x, vc.y, vc.z, vc.w};
+        const float b[5] = {lane_prev(vb.w), vb.x, vb.y, vb.z, vb.w};
+        const float c[5] = {lane_prev(vc.w), vc.x, vc.y, vc.z, vc.w};
         float o[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -700,10 +1154,107 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
   FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_dwconv3x3: unknown activation %d", act);
   const bool quant = in_stat != nullptr || in_thr != nullptr;
   if (quant) FQ_REQUIRE(in_width >= 2 && in_width <= 16, "fq_dwconv3x3: width %d out of range", in_width);
+  static const int epi_on = env_int("FQ_DW_EPI", 1);    // 0: always the run-time epilogue (A/B)
+  const int epi = (epi_on && bn_scale != nullptr && bias == nullptr)
+                      ? (act == FQ_ACT_RELU ? kEpiBnRelu : act == FQ_ACT_RELU6 ? kEpiBnRelu6 : kEpiRuntime)
+                      : kEpiRuntime;
   hipStream_t st = (hipStream_t)stream;
   static const int form = env_int("FQ_DW_FORM", 0);     // 0 auto, 1 LDS tiles, 2 sliding window 1 col/lane, 3: 4 cols/lane
   const bool can4 = (wdt % 4 == 0) && aligned16(x) && aligned16(y) && ((h * wdt) % 4 == 0) &&
                     (stride == 1 || ((wdt / 2) % 2 == 0));
+  // 14x14 stride 1: flat 16-byte accesses through an LDS transpose (K2p)
+  static const int flat_on = env_int("FQ_DW_FLAT", 1);
+  if ((form == 5 || (form == 0 && flat_on)) && h == 14 && wdt == 14 && stride == 1 && aligned16(x) && aligned16(y) &&
+      n * c * h * wdt * 4 < (1ll << 31)) {
+    constexpr int kP = 64 / 7;                             // planes per wavefront and block
+    DwFlatGeom fg;
+    fg.C = (int)c;
+    fg.planes = (unsigned)(n * c);
+    fg.by_c = fast_div_for((unsigned)c);
+    const int64_t nblk = (n * c + kP * (kBlock / 64) - 1) / (kP * (kBlock / 64));
+    static const int fl_wg_per_cu = env_int("FQ_DW_FLAT_WG_PER_CU", 4);
+    const int grid = (int)(nblk < (int64_t)num_cu() * fl_wg_per_cu ? nblk : (int64_t)num_cu() * fl_wg_per_cu);
+    fg.per = (unsigned)(nblk / grid);
+    fg.rem = (unsigned)(nblk % grid);
+    const float levels = act_levels(in_width, in_flags);
+    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+    if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+    ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * 2.0 * (double)n * c * h * wdt, st);
+#define FQ_DWF_E(Q, O, E)                                                                                         \
+  hipLaunchKernelGGL((dwconv3x3_flat_kernel<Q, O, 14, 14, E>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, fg, \
+                     in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale, bn_shift, act,      \
+                     stat_out)
+#define FQ_DWF(Q, O)                                                                                              \
+  do {                                                                                                            \
+    if (epi == kEpiBnRelu) FQ_DWF_E(Q, O, kEpiBnRelu);                                                            \
+    else if (epi == kEpiBnRelu6) FQ_DWF_E(Q, O, kEpiBnRelu6);                                                     \
+    else FQ_DWF_E(Q, O, kEpiRuntime);                                                                             \
+  } while (0)
+    if (!quant) FQ_DWF(false, false);
+    else if (!in_thr) FQ_DWF(true, true);
+    else FQ_DWF(true, false);
+#undef FQ_DWF
+#undef FQ_DWF_E
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+  }
+  // small planes: whole planes in registers, pipelined across blocks (K2o)
+  static const int planes_on = env_int("FQ_DW_PLANES", 1);
+  static const int planes_cpl = env_int("FQ_DW_PLANES_CPL", 2);          // 1: one column per lane even where W is even (A/B)
+  const int64_t ho_ = (h - 1) / stride + 1, wo_ = (wdt - 1) / stride + 1;
+  const bool al8 = ((((uintptr_t)x) | ((uintptr_t)y)) & 7) == 0;
+  const bool two_cols = wdt % 2 == 0 && al8 && (stride == 2 || planes_cpl == 2);
+  const bool can_planes = (h == 14 || h == 7) && wdt <= 64 && (stride == 1 || (two_cols && h == 14)) &&
+                          n * c * h * wdt * 4 < (1ll << 31);
+  if ((form == 4 || (form == 0 && planes_on)) && can_planes) {
+    DwColGeom cg;
+    cg.C = (int)c;
+    cg.H = (int)h;
+    cg.W = (int)wdt;
+    cg.Ho = (int)ho_;
+    cg.Wo = (int)wo_;
+    cg.nsegx = 1;
+    cg.sw = cg.Wo;
+    cg.SEG = stride == 2 ? cg.Wo : (two_cols ? cg.W / 2 : cg.W);       // lanes per plane (no halo lanes)
+    cg.segs = 64 / cg.SEG;
+    const int64_t total_segs = n * c;
+    const int64_t segs_per_block = (int64_t)cg.segs * (kBlock / 64);
+    const int64_t nblk = (total_segs + segs_per_block - 1) / segs_per_block;
+    static const int pl_wg_per_cu = env_int("FQ_DW_PLANES_WG_PER_CU", 5);
+    const int grid = (int)(nblk < (int64_t)num_cu() * pl_wg_per_cu ? nblk : (int64_t)num_cu() * pl_wg_per_cu);
+    const float levels = act_levels(in_width, in_flags);
+    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+    if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+    ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
+#define FQ_DWP_E(SS, Q, O, HH, CP, E)                                                                             \
+  hipLaunchKernelGGL((dwconv3x3_planes_kernel<SS, Q, O, HH, CP, E>), dim3(grid), dim3(kBlock), 0, st, x, w, bias,  \
+                     y, cg, total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,  \
+                     bn_shift, act, stat_out)
+#define FQ_DWP(SS, Q, O, HH, CP)                                                                                  \
+  do {                                                                                                            \
+    if (epi == kEpiBnRelu) FQ_DWP_E(SS, Q, O, HH, CP, kEpiBnRelu);                                                \
+    else if (epi == kEpiBnRelu6) FQ_DWP_E(SS, Q, O, HH, CP, kEpiBnRelu6);                                         \
+    else FQ_DWP_E(SS, Q, O, HH, CP, kEpiRuntime);                                                                 \
+  } while (0)
+#define FQ_DWP_Q(SS, HH, CP)                                                                                      \
+  do {                                                                                                            \
+    if (!quant) FQ_DWP(SS, false, false, HH, CP);                                                                 \
+    else if (!in_thr) FQ_DWP(SS, true, true, HH, CP);                                                             \
+    else FQ_DWP(SS, true, false, HH, CP);                                                                         \
+  } while (0)
+    if (stride == 2) FQ_DWP_Q(2, 14, 2);
+    else if (h == 14 && two_cols) FQ_DWP_Q(1, 14, 2);
+    else if (h == 14) FQ_DWP_Q(1, 14, 1);
+    else if (two_cols) FQ_DWP_Q(1, 7, 2);
+    else FQ_DWP_Q(1, 7, 1);
+#undef FQ_DWP_Q
+#undef FQ_DWP
+#undef FQ_DWP_E
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+  }
   if ((form == 3 || form == 0) && can4) {
     DwColGeom cg;
     cg.C = (int)c;
@@ -735,16 +1286,20 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
     static const int dw_nt_mb = env_int("FQ_DW_NT_MB", 300);              // nontemporal loads above this many MB of input
     const bool nt = 4.0 * (double)n * c * h * wdt > 1e6 * dw_nt_mb;
+#define FQ_DWC4_E(SS, Q, O, NT_, E)                                                                               \
+  hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O, NT_, E>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y,  \
+                     cg, total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,     \
+                     bn_shift, act, stat_out)
+#define FQ_DWC4_N(SS, Q, O, NT_)                                                                                  \
+  do {                                                                                                            \
+    if (epi == kEpiBnRelu) FQ_DWC4_E(SS, Q, O, NT_, kEpiBnRelu);                                                  \
+    else if (epi == kEpiBnRelu6) FQ_DWC4_E(SS, Q, O, NT_, kEpiBnRelu6);                                           \
+    else FQ_DWC4_E(SS, Q, O, NT_, kEpiRuntime);                                                                   \
+  } while (0)
 #define FQ_DWC4(SS, Q, O)                                                                                         \
   do {                                                                                                            \
-    if (nt)                                                                                                       \
-      hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O, true>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, \
-                         cg, total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,  \
-                         bn_shift, act, stat_out);                                                                 \
-    else                                                                                                          \
-      hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O, false>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, \
-                         cg, total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,  \
-                         bn_shift, act, stat_out);                                                                 \
+    if (nt) FQ_DWC4_N(SS, Q, O, true);                                                                            \
+    else FQ_DWC4_N(SS, Q, O, false);                                                                              \
   } while (0)
     if (stride == 1) {
       if (!quant) FQ_DWC4(1, false, false);
@@ -756,6 +1311,8 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
       else FQ_DWC4(2, true, false);
     }
 #undef FQ_DWC4
+#undef FQ_DWC4_N
+#undef FQ_DWC4_E
     FQ_LAUNCH_CHECK();
     return FQ_OK;
   }
@@ -787,10 +1344,16 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
     if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
-#define FQ_DWC(SS, Q, O)                                                                                          \
-  hipLaunchKernelGGL((dwconv3x3_cols_kernel<SS, Q, O>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, cg,        \
+#define FQ_DWC_E(SS, Q, O, E)                                                                                     \
+  hipLaunchKernelGGL((dwconv3x3_cols_kernel<SS, Q, O, E>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, cg,     \
                      total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,         \
                      bn_shift, act, stat_out)
+#define FQ_DWC(SS, Q, O)                                                                                          \
+  do {                                                                                                            \
+    if (epi == kEpiBnRelu) FQ_DWC_E(SS, Q, O, kEpiBnRelu);                                                        \
+    else if (epi == kEpiBnRelu6) FQ_DWC_E(SS, Q, O, kEpiBnRelu6);                                                 \
+    else FQ_DWC_E(SS, Q, O, kEpiRuntime);                                                                         \
+  } while (0)
     if (stride == 1) {
       if (!quant) FQ_DWC(1, false, false);
       else if (!in_thr) FQ_DWC(1, true, true);
@@ -801,6 +1364,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
       else FQ_DWC(2, true, false);
     }
 #undef FQ_DWC
+#undef FQ_DWC_E
     FQ_LAUNCH_CHECK();
     return FQ_OK;
   }

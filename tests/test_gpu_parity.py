@@ -369,7 +369,8 @@ def test_bn_act_stat_vs_oracle(dev, ops, shape, act):
 
 # ---- fused depthwise 3x3: quantise-on-load + BN/act/statistic epilogue ------------------------------------------------
 DW_SHAPES = [(2, 8, 7, 7), (3, 16, 14, 14), (2, 32, 28, 28), (2, 8, 56, 56), (2, 4, 112, 112), (1, 3, 9, 11),
-             (2, 5, 13, 6), (4, 1024, 7, 7), (2, 6, 70, 70), (1, 2, 113, 113)]
+             (2, 5, 13, 6), (4, 1024, 7, 7), (2, 6, 70, 70), (1, 2, 113, 113),
+             (2, 6, 14, 20), (3, 5, 7, 10), (1, 3, 14, 62), (5, 4, 7, 3), (70, 33, 14, 14), (37, 20, 7, 7)]   # whole-plane form (K2o)
 
 
 @pytest.mark.parametrize("shape", DW_SHAPES)
