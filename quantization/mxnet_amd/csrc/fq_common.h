@@ -210,6 +210,28 @@ __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
     atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
+// Buffer addressing: address = (scalar 48-bit base in the resource) + (ONE 32-bit lane offset) + (scalar offset).  The
+// fused producers read 16-64 values per lane that differ only by a wave-uniform stride (channel planes): with flat
+// addressing hipcc carries a 64-bit VGPR pair and two VALU adds per access, with a buffer resource the stride lives in an
+// SGPR and all accesses of a lane share one offset register.  `bytes` (<= 4 GiB - 1) bounds the range: loads past it
+// return 0 and stores past it are dropped, so the resource is re-based per workgroup for tensors beyond 4 GiB.
+typedef __amdgpu_buffer_rsrc_t fq_rsrc;
+__device__ __forceinline__ fq_rsrc make_rsrc(const void* base, int64_t bytes) {
+  const unsigned nb = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)(bytes < 0 ? 0 : bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld_f32(fq_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ v4i buf_ld_v4i(fq_rsrc r, unsigned voff, unsigned soff) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(v4i, t);
+}
+__device__ __forceinline__ void buf_st_f32(fq_rsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
 // Deterministic batch mean: fp64 accumulate in sample order, one rounding to fp32, fp32 divide (oracle: batch_mean).
 __device__ __forceinline__ float batch_mean_seq(const float* __restrict__ v, int n) {
   double acc = 0.0;
@@ -266,6 +288,69 @@ __device__ __forceinline__ float input_threshold(const float* __restrict__ in_st
     return in_thr[0];
   }
   const float m = batch_mean_dev(in_stat, n);
+  if (cur_max_out != nullptr && first_wg && threadIdx.x == 0) cur_max_out[0] = m;
+  return m;
+}
+
+// The same in two steps.  The threshold is the head of every consumer's dependency chain (statistic -> mean -> quantiser
+// parameters -> first code): its loads are requested FIRST, ahead of the activation loads of the workgroup's first tile, and
+// turned into the threshold while those are in flight.  Queued behind them (64 loads per lane in the pointwise form) the
+// statistic arrived 5-6 us into a 13 us workgroup (tools/pw_trace.py).  Buffer loads: lanes past n read 0 (adding 0 is
+// exact and zeros do not take part in the exponent range), a null pointer is an empty buffer.
+struct ThresholdReq {
+  float s[4];        // in_stat[lane + 64 k]
+  float thr;         // in_thr[0]
+};
+__device__ __forceinline__ ThresholdReq threshold_request(const float* __restrict__ in_stat, int n,
+                                                          const float* __restrict__ in_thr, bool first_wg) {
+  ThresholdReq r;
+  const bool want_stat = in_stat != nullptr && (in_thr == nullptr || first_wg);
+  const fq_rsrc rs = make_rsrc(in_stat, want_stat ? (int64_t)n * 4 : 0);
+  const fq_rsrc rt = make_rsrc(in_thr, in_thr != nullptr ? 4 : 0);
+  const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.s[k] = buf_ld_f32(rs, (lane + 64u * k) * 4u, 0);
+  r.thr = buf_ld_f32(rt, 0, 0);
+  return r;
+}
+__device__ __forceinline__ float batch_mean_from(const ThresholdReq& r, const float* __restrict__ v, int n) {
+  if (n > 256) return batch_mean_dev(v, n);
+  double acc = 0.0;
+  unsigned emin = 255u, emax = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float f = r.s[k];
+    acc += (double)f;
+    unsigned e = (__float_as_uint(f) >> 23) & 0xFFu;
+    if ((__float_as_uint(f) & 0x7FFFFFFFu) != 0u) {
+      e = e < 1u ? 1u : e;
+      emin = e < emin ? e : emin;
+      emax = e > emax ? e : emax;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    acc += __shfl_xor(acc, off, 64);
+    const unsigned a = (unsigned)__shfl_xor((int)emin, off, 64), b = (unsigned)__shfl_xor((int)emax, off, 64);
+    emin = a < emin ? a : emin;
+    emax = b > emax ? b : emax;
+  }
+  const int logn = 32 - __clz(n > 1 ? n - 1 : 1);
+  const bool exact = emax == 0u || (emax < 255u && (int)(emax - emin) + 24 + logn <= 53);
+  if (!exact) return batch_mean_seq(v, n);
+  return (float)acc / (float)n;
+}
+__device__ __forceinline__ float threshold_finish(const ThresholdReq& r, const float* __restrict__ in_stat, int n,
+                                                  const float* __restrict__ in_thr, float* __restrict__ cur_max_out,
+                                                  bool first_wg) {
+  if (in_thr != nullptr) {
+    if (in_stat != nullptr && cur_max_out != nullptr && first_wg && threadIdx.x < 64) {
+      const float cm = batch_mean_from(r, in_stat, n);
+      if (threadIdx.x == 0) cur_max_out[0] = cm;
+    }
+    return r.thr;
+  }
+  const float m = batch_mean_from(r, in_stat, n);
   if (cur_max_out != nullptr && first_wg && threadIdx.x == 0) cur_max_out[0] = m;
   return m;
 }
@@ -333,28 +418,6 @@ __device__ __forceinline__ int pack4_codes(int k0, int k1, int k2, int k3, int u
   return (int)(u ^ 0x80808080u);
 }
 
-// Buffer addressing: address = (scalar 48-bit base in the resource) + (ONE 32-bit lane offset) + (scalar offset).  The
-// fused producers read 16-64 values per lane that differ only by a wave-uniform stride (channel planes): with flat
-// addressing hipcc carries a 64-bit VGPR pair and two VALU adds per access, with a buffer resource the stride lives in an
-// SGPR and all accesses of a lane share one offset register.  `bytes` (<= 4 GiB - 1) bounds the range: loads past it
-// return 0 and stores past it are dropped, so the resource is re-based per workgroup for tensors beyond 4 GiB.
-typedef __amdgpu_buffer_rsrc_t fq_rsrc;
-__device__ __forceinline__ fq_rsrc make_rsrc(const void* base, int64_t bytes) {
-  const unsigned nb = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)(bytes < 0 ? 0 : bytes);
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)nb, 0x00020000);
-}
-__device__ __forceinline__ float buf_ld_f32(fq_rsrc r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ v4i buf_ld_v4i(fq_rsrc r, unsigned voff, unsigned soff) {
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-  return __builtin_bit_cast(v4i, t);
-}
-__device__ __forceinline__ void buf_st_f32(fq_rsrc r, unsigned voff, unsigned soff, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
-}
-
 template <bool USE_ABS>
 __device__ __forceinline__ float stat_of(float v) {
   return USE_ABS ? fabsf(v) : v;
@@ -386,7 +449,6 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 constexpr int kPolNtLoad = 1, kPolNtStore = 2, kPolReverse = 4;
 
 __device__ __forceinline__ f4 buf_ld_v4f(fq_rsrc r, unsigned voff, unsigned soff) {
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
   return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ void buf_st_v4f(fq_rsrc r, unsigned voff, unsigned soff, f4 v) {

@@ -447,7 +447,6 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 buf_ld_2f32(fq_rsrc r, unsigned voff, unsigned soff) {
-  typedef unsigned v2u __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ void buf_st_2f32(fq_rsrc r, unsigned voff, unsigned soff, f2 v) {
@@ -545,16 +544,16 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_planes_kernel(
   };
 
   Blk nxt;
+  ThresholdReq treq;
+  if (QUANT) treq = threshold_request(in_stat, n, ONLINE ? nullptr : in_thr, blockIdx.x == 0);   // first in the memory queue
   FQ_PIN();
-  PW_STAMP(6);
   if (blk_begin < blk_end) issue(blk_begin, nxt);
   FQ_PIN();
-  PW_STAMP(7);
   QParams q;
   q.lo = q.hi = q.denom = q.scale = 0.0f;
   q.rden = 0.0;
-  if (QUANT) {                                            // behind the first block's loads (two dependent cold loads + an fp64 tree)
-    const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
+  if (QUANT) {                                            // while the first block is on its way
+    const float max_ = threshold_finish(treq, in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
     q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   }
   PW_STAMP(1);
@@ -784,6 +783,8 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
   };
 
   Blk nxt;
+  ThresholdReq treq;
+  if (QUANT) treq = threshold_request(in_stat, n, ONLINE ? nullptr : in_thr, blockIdx.x == 0);   // first in the memory queue
   FQ_PIN();
   PW_STAMP(6);
   if (blk_begin < blk_end) issue(blk_begin, nxt);
@@ -792,8 +793,8 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
   QParams q;
   q.lo = q.hi = q.denom = q.scale = 0.0f;
   q.rden = 0.0;
-  if (QUANT) {                                            // behind the first block's requests
-    const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
+  if (QUANT) {                                            // while the first block is on its way
+    const float max_ = threshold_finish(treq, in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
     q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   }
   PW_STAMP(1);

@@ -108,12 +108,13 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
   // (slabs that are padding altogether - cin_pad is a multiple of 64 - are neither loaded nor written to the panel: whatever
   // bytes the panel holds there meet zero weight codes)
   const int kt_real = (g.Cin + 31) >> 5;
+  const ThresholdReq treq = threshold_request(in_stat, n, in_thr, item == 0);   // first in the memory queue
   float buf[RB][16];
 #pragma unroll
   for (int i = 0; i < RB; ++i)
     if (wave + NW * i < kt_real) issue(wave + NW * i, buf[i]);          // in flight during the set-up
   FQ_PIN();
-  const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, item == 0);
+  const float max_ = threshold_finish(treq, in_stat, n, in_thr, cur_max_out, item == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   const float sx = q.scale;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
