@@ -721,22 +721,30 @@ struct DwFlatGeom {
   FastDiv by_c;             // plane % C, plane / C
 };
 
-template <bool QUANT, bool ONLINE, int H, int W, int EPI>
+template <int S, bool QUANT, bool ONLINE, int H, int W, int EPI>
 __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
     const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
     float* __restrict__ y, DwFlatGeom g, const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr,
     float levels, int lo_neg_max, float eps, float* __restrict__ cur_max_out, const float* __restrict__ bn_scale,
     const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
-  static_assert(W % 2 == 0 && (H * W) % 4 == 0 && W / 2 <= 32, "even rows of whole 16-byte groups");
-  constexpr int LPP = W / 2;               // lanes per plane in phase B
-  constexpr int P = 64 / LPP;              // planes per wavefront and block
-  constexpr int PF4 = H * W / 4;           // 16-byte groups per plane
-  constexpr int NF4 = P * PF4;             // ... per wavefront and block
-  constexpr int NL = (NF4 + 63) / 64;      // 16-byte accesses per lane
-  constexpr unsigned kPlaneBytes = H * W * 4;
+  // phase B shapes: PAIR - stride 1, even W: two columns per lane, packed FMA chains, in place;
+  //                 ONE  - stride 1, odd W: one column per lane, in place;  DOWN - stride 2 (even W): one OUTPUT column per lane
+  constexpr bool PAIR = S == 1 && W % 2 == 0, DOWN = S == 2;
+  static_assert(S == 1 || W % 2 == 0, "stride 2 reads column pairs");
+  constexpr int HO = (H - 1) / S + 1, WO = (W - 1) / S + 1;
+  constexpr int IN = H * W, OUT = HO * WO;           // floats per plane
+  constexpr int LPP = DOWN ? WO : (PAIR ? W / 2 : W);      // lanes per plane in phase B
+  constexpr int PMAX = 64 / LPP;
+  // planes per wavefront and block: the flat ranges must be whole 16-byte groups (planes of 49 floats: multiples of 4 planes)
+  constexpr int P = (IN % 4 == 0 && OUT % 4 == 0) ? PMAX : PMAX / 4 * 4;
+  static_assert(P >= 1 && (P * IN) % 4 == 0 && (P * OUT) % 4 == 0, "no 16-byte flat range for this plane size");
+  constexpr bool TAIL_OK = IN % 4 == 0 && OUT % 4 == 0;  // else the host only takes tensors of whole blocks (planes % P == 0)
+  constexpr int NFI = P * IN / 4, NFO = P * OUT / 4;   // 16-byte groups per wavefront and block, in / out
+  constexpr int NLI = (NFI + 63) / 64, NLO = (NFO + 63) / 64;
   constexpr int kStatSlots = 16;
   constexpr unsigned kOob = 0x80000000u;   // beyond every resource of this kernel (host: tensors < 2 GiB)
-  __shared__ f4 tile[kBlock / 64][NL * 64];
+  __shared__ f4 tile[kBlock / 64][NLI * 64];
+  __shared__ f4 otile[kBlock / 64][DOWN ? NLO * 64 : 1];  // stride 1 writes its results over the tile rows already consumed
   __shared__ unsigned k_stat[kStatSlots];
   if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
   PW_STAMP(0);
@@ -753,26 +761,28 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
     s_base = fast_div(p0 < planes ? p0 : planes - 1, g.by_c);
   }
   const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr, has_bias = bias != nullptr;
-  const fq_rsrc rx = make_rsrc(x, (int64_t)planes * kPlaneBytes), ry = make_rsrc(y, (int64_t)planes * kPlaneBytes);
+  const fq_rsrc rx = make_rsrc(x, (int64_t)planes * IN * 4), ry = make_rsrc(y, (int64_t)planes * OUT * 4);
   const fq_rsrc rw = make_rsrc(wgt, (int64_t)g.C * 36);
   // phase B coordinates of this lane
   const unsigned j = lane / LPP, pos = lane - j * LPP;
   const bool b_lane = lane < P * LPP;
   const bool first = pos == 0, last = pos == LPP - 1;
   float* const my_tile = reinterpret_cast<float*>(tile[wave]);
+  float* const my_out = DOWN ? reinterpret_cast<float*>(otile[wave]) : my_tile;
 
   struct Blk {
-    f4 raw[NL];
+    f4 raw[NLI];
     f4 w03, w47;
     float w8, bch, bsc, bsh;
   };
   auto issue = [&](unsigned blk, Blk& k) __attribute__((always_inline)) {
     const unsigned base = (blk * (kBlock / 64) + wave) * P;                  // first plane of this wavefront (uniform)
     const unsigned left = base < planes ? planes - base : 0u;
-    const unsigned lim = (left < (unsigned)P ? left : (unsigned)P) * PF4;      // 16-byte groups that exist
+    const unsigned np = left < (unsigned)P ? left : (unsigned)P;
+    const unsigned lim = TAIL_OK ? np * (IN / 4) : (np == (unsigned)P ? (unsigned)NFI : 0u);   // 16-byte groups that exist
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      k.raw[i] = buf_ld_v4f(rx, (lane + 64u * i) < lim ? lane * 16u : kOob, base * kPlaneBytes + 1024u * i);
+    for (int i = 0; i < NLI; ++i)
+      k.raw[i] = buf_ld_v4f(rx, (lane + 64u * i) < lim ? lane * 16u : kOob, base * (IN * 4u) + 1024u * i);
     const unsigned ch = (b_lane && j < left) ? fast_mod(base + j, g.by_c) : 0u;
     k.w03 = buf_ld_v4f(rw, ch * 36u, 0);
     k.w47 = buf_ld_v4f(rw, ch * 36u, 16);
@@ -807,10 +817,11 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
     FQ_PIN();
     const unsigned base = (blk * (kBlock / 64) + wave) * P;
     const unsigned left = base < planes ? planes - base : 0u;
-    const unsigned lim = (left < (unsigned)P ? left : (unsigned)P) * PF4;
+    const unsigned np = left < (unsigned)P ? left : (unsigned)P;
+    const unsigned lim_out = TAIL_OK ? np * (OUT / 4) : (np == (unsigned)P ? (unsigned)NFO : 0u);
     // ---- A: quantise in flat order, stage ---------------------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
+    for (int i = 0; i < NLI; ++i) {
       f4 v = cur.raw[i];
       if (QUANT) v = fq_code4(v, q) * q.scale;
       tile[wave][lane + 64 * i] = v;
@@ -818,11 +829,10 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- B: 3x3 on the tile, in place ----------------------------------------------------------------------------------
+    // ---- B: 3x3 on the tile ----------------------------------------------------------------------------------------------
     float m = 0.0f;
     const bool is_out = b_lane && j < left;
     if (b_lane) {
-      float* lp = my_tile + j * (H * W) + pos * 2;
       auto left_of = [&](float v) -> float {              // (every lane takes the shift; the edge lanes drop it afterwards)
         const float t = lane_prev(v);
         return first ? 0.0f : t;
@@ -831,41 +841,97 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
         const float t = lane_next(v);
         return last ? 0.0f : t;
       };
-      const f2 w0 = splat2(cur.w03.x), w1 = splat2(cur.w03.y), w2 = splat2(cur.w03.z), w3 = splat2(cur.w03.w),
-               w4 = splat2(cur.w47.x), w5 = splat2(cur.w47.y), w6 = splat2(cur.w47.z), w7 = splat2(cur.w47.w),
-               w8 = splat2(cur.w8);
-      f2 aL = {0.f, 0.f}, aC = {0.f, 0.f}, aR = {0.f, 0.f};     // row r-1: (L, q0), (q0, q1), (q1, R)
-      f2 bL, bC, bR;
-      {
-        const f2 v = *reinterpret_cast<const f2*>(lp);
-        bL = (f2){left_of(v.y), v.x};
-        bC = v;
-        bR = (f2){v.y, right_of(v.x)};
-      }
-#pragma unroll
-      for (int r = 0; r < H; ++r) {
-        f2 cL = {0.f, 0.f}, cC = {0.f, 0.f}, cR = {0.f, 0.f};
-        if (r + 1 < H) {
-          const f2 v = *reinterpret_cast<const f2*>(lp + (r + 1) * W);
-          cL = (f2){left_of(v.y), v.x};
-          cC = v;
-          cR = (f2){v.y, right_of(v.x)};
+      if (PAIR) {
+        float* lp = my_tile + j * IN + pos * 2;
+        const f2 w0 = splat2(cur.w03.x), w1 = splat2(cur.w03.y), w2 = splat2(cur.w03.z), w3 = splat2(cur.w03.w),
+                 w4 = splat2(cur.w47.x), w5 = splat2(cur.w47.y), w6 = splat2(cur.w47.z), w7 = splat2(cur.w47.w),
+                 w8 = splat2(cur.w8);
+        f2 aL = {0.f, 0.f}, aC = {0.f, 0.f}, aR = {0.f, 0.f};     // row r-1: (L, q0), (q0, q1), (q1, R)
+        f2 bL, bC, bR;
+        {
+          const f2 v = *reinterpret_cast<const f2*>(lp);
+          bL = (f2){left_of(v.y), v.x};
+          bC = v;
+          bR = (f2){v.y, right_of(v.x)};
         }
-        f2 acc = {0.f, 0.f};
-        acc = __builtin_elementwise_fma(w0, aL, acc);
-        acc = __builtin_elementwise_fma(w1, aC, acc);
-        acc = __builtin_elementwise_fma(w2, aR, acc);
-        acc = __builtin_elementwise_fma(w3, bL, acc);
-        acc = __builtin_elementwise_fma(w4, bC, acc);
-        acc = __builtin_elementwise_fma(w5, bR, acc);
-        acc = __builtin_elementwise_fma(w6, cL, acc);
-        acc = __builtin_elementwise_fma(w7, cC, acc);
-        acc = __builtin_elementwise_fma(w8, cR, acc);
-        acc = dw_finish2<EPI>(acc, has_bias, cur.bch, has_bn, cur.bsc, cur.bsh, act);
-        m = fmaxf(m, fmaxf(fabsf(acc.x), fabsf(acc.y)));
-        *reinterpret_cast<f2*>(lp + r * W) = acc;            // row r of the tile was read in the previous step
-        aL = bL; aC = bC; aR = bR;
-        bL = cL; bC = cC; bR = cR;
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+          f2 cL = {0.f, 0.f}, cC = {0.f, 0.f}, cR = {0.f, 0.f};
+          if (r + 1 < H) {
+            const f2 v = *reinterpret_cast<const f2*>(lp + (r + 1) * W);
+            cL = (f2){left_of(v.y), v.x};
+            cC = v;
+            cR = (f2){v.y, right_of(v.x)};
+          }
+          f2 acc = {0.f, 0.f};
+          acc = __builtin_elementwise_fma(w0, aL, acc);
+          acc = __builtin_elementwise_fma(w1, aC, acc);
+          acc = __builtin_elementwise_fma(w2, aR, acc);
+          acc = __builtin_elementwise_fma(w3, bL, acc);
+          acc = __builtin_elementwise_fma(w4, bC, acc);
+          acc = __builtin_elementwise_fma(w5, bR, acc);
+          acc = __builtin_elementwise_fma(w6, cL, acc);
+          acc = __builtin_elementwise_fma(w7, cC, acc);
+          acc = __builtin_elementwise_fma(w8, cR, acc);
+          acc = dw_finish2<EPI>(acc, has_bias, cur.bch, has_bn, cur.bsc, cur.bsh, act);
+          m = fmaxf(m, fmaxf(fabsf(acc.x), fabsf(acc.y)));
+          *reinterpret_cast<f2*>(lp + r * W) = acc;          // row r of the tile was read in the previous step
+          aL = bL; aC = bC; aR = bR;
+          bL = cL; bC = cC; bR = cR;
+        }
+      } else {
+        auto window = [&](float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2) -> float {
+          float acc = 0.0f;
+          acc = fmaf(cur.w03.x, a0, acc);
+          acc = fmaf(cur.w03.y, a1, acc);
+          acc = fmaf(cur.w03.z, a2, acc);
+          acc = fmaf(cur.w03.w, b0, acc);
+          acc = fmaf(cur.w47.x, b1, acc);
+          acc = fmaf(cur.w47.y, b2, acc);
+          acc = fmaf(cur.w47.z, c0, acc);
+          acc = fmaf(cur.w47.w, c1, acc);
+          acc = fmaf(cur.w8, c2, acc);
+          acc = dw_finish<EPI>(acc, has_bias, cur.bch, has_bn, cur.bsc, cur.bsh, act);
+          m = fmaxf(m, fabsf(acc));
+          return acc;
+        };
+        if (!DOWN) {
+          float* lp = my_tile + j * IN + pos;
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+          float b1 = lp[0];
+          float b0 = left_of(b1), b2 = right_of(b1);
+#pragma unroll
+          for (int r = 0; r < H; ++r) {
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            if (r + 1 < H) {
+              c1 = lp[(r + 1) * W];
+              c0 = left_of(c1);
+              c2 = right_of(c1);
+            }
+            lp[r * W] = window(a0, a1, a2, b0, b1, b2, c0, c1, c2);
+            a0 = b0; a1 = b1; a2 = b2;
+            b0 = c0; b1 = c1; b2 = c2;
+          }
+        } else {
+          // output row r: input rows 2r-1 (a), 2r (b), 2r+1 (c); per row: left = the left lane's odd column, centre / right own
+          const float* lp = my_tile + j * IN + pos * 2;
+          float* op = my_out + j * OUT + pos;
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < HO; ++r) {
+            const f2 vb = *reinterpret_cast<const f2*>(lp + (2 * r) * W);
+            const float b0 = left_of(vb.y);
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            if (2 * r + 1 < H) {
+              const f2 vc = *reinterpret_cast<const f2*>(lp + (2 * r + 1) * W);
+              c1 = vc.x;
+              c2 = vc.y;
+              c0 = left_of(vc.y);
+            }
+            op[r * WO] = window(a0, a1, a2, b0, vb.x, vb.y, c0, c1, c2);
+            a0 = c0; a1 = c1; a2 = c2;
+          }
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -873,8 +939,10 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- C: flat stores ---------------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      buf_st_v4f(ry, (lane + 64u * i) < lim ? lane * 16u : kOob, base * kPlaneBytes + 1024u * i, tile[wave][lane + 64 * i]);
+    for (int i = 0; i < NLO; ++i) {
+      const f4 v = DOWN ? otile[wave][lane + 64 * i] : tile[wave][lane + 64 * i];
+      buf_st_v4f(ry, (lane + 64u * i) < lim_out ? lane * 16u : kOob, base * (OUT * 4u) + 1024u * i, v);
+    }
     if (has_stat) {
       m = is_out ? m : 0.0f;
       const unsigned sample = fast_div(base + (is_out ? j : 0u), g.by_c);
@@ -1163,42 +1231,57 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
   static const int form = env_int("FQ_DW_FORM", 0);     // 0 auto, 1 LDS tiles, 2 sliding window 1 col/lane, 3: 4 cols/lane
   const bool can4 = (wdt % 4 == 0) && aligned16(x) && aligned16(y) && ((h * wdt) % 4 == 0) &&
                     (stride == 1 || ((wdt / 2) % 2 == 0));
-  // 14x14 stride 1: flat 16-byte accesses through an LDS transpose (K2p)
-  static const int flat_on = env_int("FQ_DW_FLAT", 1);
-  if ((form == 5 || (form == 0 && flat_on)) && h == 14 && wdt == 14 && stride == 1 && aligned16(x) && aligned16(y) &&
-      n * c * h * wdt * 4 < (1ll << 31)) {
-    constexpr int kP = 64 / 7;                             // planes per wavefront and block
-    DwFlatGeom fg;
-    fg.C = (int)c;
-    fg.planes = (unsigned)(n * c);
-    fg.by_c = fast_div_for((unsigned)c);
-    const int64_t nblk = (n * c + kP * (kBlock / 64) - 1) / (kP * (kBlock / 64));
-    static const int fl_wg_per_cu = env_int("FQ_DW_FLAT_WG_PER_CU", 4);
-    const int grid = (int)(nblk < (int64_t)num_cu() * fl_wg_per_cu ? nblk : (int64_t)num_cu() * fl_wg_per_cu);
-    fg.per = (unsigned)(nblk / grid);
-    fg.rem = (unsigned)(nblk % grid);
-    const float levels = act_levels(in_width, in_flags);
-    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
-    const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
-    if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
-    ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * 2.0 * (double)n * c * h * wdt, st);
-#define FQ_DWF_E(Q, O, E)                                                                                         \
-  hipLaunchKernelGGL((dwconv3x3_flat_kernel<Q, O, 14, 14, E>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, fg, \
-                     in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale, bn_shift, act,      \
+  // 14x14 (stride 1 and 2) and 7x7 planes: flat 16-byte accesses through an LDS transpose (K2p)
+  static const int flat_on = env_int("FQ_DW_FLAT", 7);                   // tuning: bit 0 14x14 s1, bit 1 14x14 s2, bit 2 7x7
+  {
+    const int kind = (h == 14 && wdt == 14) ? (stride == 1 ? 0 : 1) : (h == 7 && wdt == 7 && stride == 1 ? 2 : -1);
+    const int kP = kind == 0 ? 9 : 8;                      // planes per wavefront and block (dwconv3x3_flat_kernel: P)
+    const bool whole = kind == 0 || (n * c) % kP == 0;     // planes of 49 floats: no 16-byte tail
+    if (kind >= 0 && (form == 5 || (form == 0 && ((flat_on >> kind) & 1))) && whole && aligned16(x) && aligned16(y) &&
+        n * c * h * wdt * 4 < (1ll << 31)) {
+      DwFlatGeom fg;
+      fg.C = (int)c;
+      fg.planes = (unsigned)(n * c);
+      fg.by_c = fast_div_for((unsigned)c);
+      const int64_t nblk = (n * c + kP * (kBlock / 64) - 1) / (kP * (kBlock / 64));
+      static const int fl_tune = env_int("FQ_DW_FLAT_WG_PER_CU", 0);
+      // three workgroups per CU, each with one block in work and one requested: measured best for all three shapes
+      // (512 x 14x14: 2 / 3 / 4 / 6 per CU = 22.2 / 19.6 / 20.7 / 21.9 us; 1024 x 7x7: 16.1 / 14.6 / 17.3 (8) / 16.4 us)
+      const int fl_wg_per_cu = fl_tune > 0 ? fl_tune : 3;
+      const int grid = (int)(nblk < (int64_t)num_cu() * fl_wg_per_cu ? nblk : (int64_t)num_cu() * fl_wg_per_cu);
+      fg.per = (unsigned)(nblk / grid);
+      fg.rem = (unsigned)(nblk % grid);
+      const float levels = act_levels(in_width, in_flags);
+      const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+      const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
+      const int64_t ho = (h - 1) / stride + 1, wo = (wdt - 1) / stride + 1;
+      if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
+      ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * ho * wo), st);
+#define FQ_DWF_E(SS, HH, Q, O, E)                                                                                 \
+  hipLaunchKernelGGL((dwconv3x3_flat_kernel<SS, Q, O, HH, HH, E>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y, \
+                     fg, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale, bn_shift, act,  \
                      stat_out)
-#define FQ_DWF(Q, O)                                                                                              \
+#define FQ_DWF(SS, HH, Q, O)                                                                                      \
   do {                                                                                                            \
-    if (epi == kEpiBnRelu) FQ_DWF_E(Q, O, kEpiBnRelu);                                                            \
-    else if (epi == kEpiBnRelu6) FQ_DWF_E(Q, O, kEpiBnRelu6);                                                     \
-    else FQ_DWF_E(Q, O, kEpiRuntime);                                                                             \
+    if (epi == kEpiBnRelu) FQ_DWF_E(SS, HH, Q, O, kEpiBnRelu);                                                    \
+    else if (epi == kEpiBnRelu6) FQ_DWF_E(SS, HH, Q, O, kEpiBnRelu6);                                             \
+    else FQ_DWF_E(SS, HH, Q, O, kEpiRuntime);                                                                     \
   } while (0)
-    if (!quant) FQ_DWF(false, false);
-    else if (!in_thr) FQ_DWF(true, true);
-    else FQ_DWF(true, false);
+#define FQ_DWF_Q(SS, HH)                                                                                          \
+  do {                                                                                                            \
+    if (!quant) FQ_DWF(SS, HH, false, false);                                                                     \
+    else if (!in_thr) FQ_DWF(SS, HH, true, true);                                                                 \
+    else FQ_DWF(SS, HH, true, false);                                                                             \
+  } while (0)
+      if (kind == 0) FQ_DWF_Q(1, 14);
+      else if (kind == 1) FQ_DWF_Q(2, 14);
+      else FQ_DWF_Q(1, 7);
+#undef FQ_DWF_Q
 #undef FQ_DWF
 #undef FQ_DWF_E
-    FQ_LAUNCH_CHECK();
-    return FQ_OK;
+      FQ_LAUNCH_CHECK();
+      return FQ_OK;
+    }
   }
   // small planes: whole planes in registers, pipelined across blocks (K2o)
   static const int planes_on = env_int("FQ_DW_PLANES", 1);
