@@ -120,11 +120,22 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #define FQ_STEM_CH 16
 #endif
 
-template <int KS, int COUT>
+// Tile bookkeeping is 32-bit and incremental (host: fewer than 2^31 tiles; the wavefront's range, the divisions by the
+// tiles per image and by the output width arrive as per / rem and multiplicative inverses).  With 64-bit tile indices hipcc
+// expanded two 64-bit divisions per tile on the SCALAR unit: ~640 of the ~1000 instructions of a tile.
+struct StemGeom {
+  int H, W, Ho, Wo;
+  unsigned tiles_per_img, total_tiles, n_samples;
+  unsigned per, rem;        // wavefront w works on tiles [w * per + min(w, rem), ...) - per + (w < rem) of them
+  FastDiv by_tpi, by_wo;
+};
+
+template <int KS, int COUT, int EPI>
 __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wt /*[3][KS][KS][COUT]*/, const float* __restrict__ bias,
-    float* __restrict__ y, int H, int W, int Ho, int Wo, int tiles_per_img, int64_t total_tiles,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act, float* __restrict__ stat_out) {
+    float* __restrict__ y, StemGeom g, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
+    float* __restrict__ stat_out) {
+  const int H = g.H, W = g.W, Ho = g.Ho, Wo = g.Wo;
   constexpr int K = 3 * KS * KS, NS = (K + 1) / 2, CT = COUT / 32, PAD = KS / 2;
   constexpr bool WREG = NS * CT <= 16;                                  // weights in registers (3x3 -> 32), else LDS
   constexpr int CH = NS < 16 ? NS : FQ_STEM_CH;                         // steps whose loads are in flight together
@@ -145,9 +156,9 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
   const int h = lane >> 5, pl = lane & 31;
   const int HWo = Ho * Wo;
   const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
-  const int64_t nwaves = (int64_t)gridDim.x * 4, wid = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t t_begin = total_tiles * wid / nwaves, t_end = total_tiles * (wid + 1) / nwaves;
-  const unsigned s_base = (unsigned)((total_tiles * ((int64_t)blockIdx.x * 4) / nwaves) / tiles_per_img);
+  const unsigned wid = blockIdx.x * 4u + (unsigned)wave, wid0 = blockIdx.x * 4u;
+  const unsigned t_begin = wid * g.per + (wid < g.rem ? wid : g.rem), t_end = t_begin + g.per + (wid < g.rem ? 1u : 0u);
+  const unsigned s_base = fast_div(wid0 * g.per + (wid0 < g.rem ? wid0 : g.rem), g.by_tpi);
   float areg[WREG ? NS * CT : 1];
   if (WREG) {
 #pragma unroll
@@ -157,15 +168,16 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
   }
   const unsigned x_img = (unsigned)(3 * H * W) * 4u, W4 = (unsigned)W * 4u, HW4 = (unsigned)(H * W) * 4u;
 
-  struct Pix { unsigned smp, jp; int pixoff; unsigned ym, xm; };
-  auto pix_of = [&](int64_t t) __attribute__((always_inline)) {
+  struct Pix { unsigned smp, tin, jp; int pixoff; unsigned ym, xm; };
+  // (smp, tin) = image and tile inside the image; past the last tile the last one is repeated (its loads are never used)
+  auto pix_at = [&](unsigned smp, unsigned tin) __attribute__((always_inline)) {
     Pix r;
-    const int64_t tc = t < total_tiles ? t : total_tiles - 1;
-    r.smp = (unsigned)(tc / tiles_per_img);
-    unsigned jp = (unsigned)(tc - (int64_t)r.smp * tiles_per_img) * 32u + (unsigned)pl;
+    r.smp = smp;
+    r.tin = tin;
+    unsigned jp = tin * 32u + (unsigned)pl;
     jp = jp < (unsigned)HWo ? jp : (unsigned)HWo - 1;                   // lanes past the end copy the last pixel
     r.jp = jp;
-    const int oy = (int)(jp / (unsigned)Wo), ox = (int)(jp - (unsigned)oy * (unsigned)Wo);
+    const int oy = (int)fast_div(jp, g.by_wo), ox = (int)(jp - (unsigned)oy * (unsigned)Wo);
     const int iy0 = 2 * oy - PAD, ix0 = 2 * ox - PAD;
     r.pixoff = (iy0 * W + ix0) * 4;
     unsigned ym = 0, xm = 0;
@@ -177,6 +189,17 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     r.ym = ym;
     r.xm = xm;
     return r;
+  };
+  auto pix_next = [&](const Pix& p, bool more) __attribute__((always_inline)) {
+    unsigned smp = p.smp, tin = p.tin;
+    if (more) {
+      ++tin;
+      if (tin == g.tiles_per_img) {
+        tin = 0;
+        ++smp;
+      }
+    }
+    return pix_at(smp, tin);
   };
   // the lane's input value of step s: tap k = 2 s + h, i.e. (ci, ky, kx); an invalid tap (outside the image, or the padded
   // k) gets an offset the resource bounds out
@@ -197,14 +220,19 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
   };
 
   float bbuf[2][CH];
-  Pix cur = pix_of(t_begin);
+  Pix cur;
+  {
+    const unsigned tc = t_begin < g.total_tiles ? t_begin : g.total_tiles - 1;
+    const unsigned smp0 = fast_div(tc, g.by_tpi);
+    cur = pix_at(smp0, tc - smp0 * g.tiles_per_img);
+  }
   if (t_begin < t_end) {
     const fq_rsrc xr = rsrc_of(cur);
 #pragma unroll
     for (int i = 0; i < CH; ++i) bbuf[0][i] = issue(xr, cur, i);
   }
-  for (int64_t t = t_begin; t < t_end; ++t) {
-    const Pix nxt = pix_of(t + 1);
+  for (unsigned t = t_begin; t < t_end; ++t) {
+    const Pix nxt = pix_next(cur, t + 1 < g.total_tiles);
     const fq_rsrc xr = rsrc_of(cur), xn = rsrc_of(nxt);
     v16f acc[CT];
 #pragma unroll
@@ -261,19 +289,13 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[ct][4 * gq + r];
-          if (bias != nullptr) v = v + bch[r];
-          if (has_bn) {
-            v = v * bsc[r];
-            v = v + bsh[r];
-          }
-          v = act_rt(v, act);
+          float v = dw_finish<EPI>(acc[ct][4 * gq + r], bias != nullptr, bch[r], has_bn, bsc[r], bsh[r], act);
           buf_st_f32(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
           m = fmaxf(m, fabsf(v));
         }
       }
     if (has_stat) {                               // a tile lies within one sample
-      const float wm = wave_max(m);
+      const float wm = wave_max_nonneg(m);
       if (lane == 0) {
         const unsigned slot = cur.smp - s_base;
         if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
@@ -284,8 +306,7 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
   }
   if (has_stat) {
     __syncthreads();
-    const int64_t n_samples = total_tiles / tiles_per_img;
-    if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && (int64_t)s_base + threadIdx.x < n_samples)
+    if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < g.n_samples)
       atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
   }
 }
@@ -334,12 +355,29 @@ static int stem_launch(const float* x, const float* w_tap_major, const float* bi
   const int wg_per_cu = wg_tune > 0 ? wg_tune : (ksize == 3 ? 4 : 2);
   int64_t grid = (int64_t)num_cu() * wg_per_cu;
   if (grid > (total + 3) / 4) grid = (total + 3) / 4;
-  if (ksize == 3)
-    hipLaunchKernelGGL((stem_mfma_kernel<3, 32>), dim3((unsigned)grid), dim3(kBlock), 0, st, x, w_tap_major, bias, y, (int)h,
-                       (int)w, Ho, Wo, tiles_per_img, total, bn_scale, bn_shift, act, stat_out);
-  else
-    hipLaunchKernelGGL((stem_mfma_kernel<7, 64>), dim3((unsigned)grid), dim3(kBlock), 0, st, x, w_tap_major, bias, y, (int)h,
-                       (int)w, Ho, Wo, tiles_per_img, total, bn_scale, bn_shift, act, stat_out);
+  FQ_REQUIRE(total < (1ll << 31), "%s: too many tiles", who);
+  StemGeom g;
+  g.H = (int)h; g.W = (int)w; g.Ho = Ho; g.Wo = Wo;
+  g.tiles_per_img = (unsigned)tiles_per_img; g.total_tiles = (unsigned)total; g.n_samples = (unsigned)n;
+  g.per = (unsigned)(total / (grid * 4)); g.rem = (unsigned)(total % (grid * 4));
+  g.by_tpi = fast_div_for((unsigned)tiles_per_img);
+  g.by_wo = fast_div_for((unsigned)Wo);
+  const int epi = (bn_scale != nullptr && bias == nullptr)
+                      ? (act == FQ_ACT_RELU ? kEpiBnRelu : act == FQ_ACT_RELU6 ? kEpiBnRelu6 : kEpiRuntime)
+                      : kEpiRuntime;
+#define FQ_STEM_LAUNCH(KS_, CO_, E_)                                                                                \
+  hipLaunchKernelGGL((stem_mfma_kernel<KS_, CO_, E_>), dim3((unsigned)grid), dim3(kBlock), 0, st, x, w_tap_major, bias, \
+                     y, g, bn_scale, bn_shift, act, stat_out)
+#define FQ_STEM_EPI(KS_, CO_)                                                                                       \
+  do {                                                                                                              \
+    if (epi == kEpiBnRelu) FQ_STEM_LAUNCH(KS_, CO_, kEpiBnRelu);                                                    \
+    else if (epi == kEpiBnRelu6) FQ_STEM_LAUNCH(KS_, CO_, kEpiBnRelu6);                                             \
+    else FQ_STEM_LAUNCH(KS_, CO_, kEpiRuntime);                                                                     \
+  } while (0)
+  if (ksize == 3) FQ_STEM_EPI(3, 32);
+  else FQ_STEM_EPI(7, 64);
+#undef FQ_STEM_EPI
+#undef FQ_STEM_LAUNCH
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }
