@@ -30,12 +30,13 @@ struct PwCall {
   bool prezeroed;
   void* ws;
   hipStream_t st;
-  int form;                      // FQ_PW_FORM: 0 auto, 1 two kernels, 3 stream, 6 split
+  int form;                      // FQ_PW_FORM: 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample
 };
 
 int pw_try_stream(const PwCall& c, bool* taken);    // K2h  fq_pw_stream.hip
 bool pw_stream_shape_ok(const PwCall& c);           //      shapes the streaming form takes
 int pw_try_split(const PwCall& c, bool* taken);     // K2m  fq_pw_split.hip
+int pw_try_sample(const PwCall& c, bool* taken);    // K2s  fq_pw_sample.hip (14x14 planes)
 int pw_two_kernels(const PwCall& c);                // K2f  fq_pw_generic.hip (takes every shape)
 
 inline int pw_zero_stat(const PwCall& c) {

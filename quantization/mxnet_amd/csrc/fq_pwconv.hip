@@ -103,15 +103,20 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   c.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;      // unsigned codes are stored re-centred so they fit int8
   c.out_current_max = out_current_max; c.bn_scale = bn_scale; c.bn_shift = bn_shift; c.act = act;
   c.stat_out = stat_out; c.residual = residual; c.ws = ws; c.st = (hipStream_t)stream;
-  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split
+  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample
   c.form = forced_form ? forced_form : pw_form;
-  FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6, "fq_pwconv_i8: unknown form %d (1 two kernels, 3 "
-             "stream, 6 split; the panel / chunk / tile forms 2, 4, 5 were retired in favour of the split form)", c.form);
+  FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6 || c.form == 7, "fq_pwconv_i8: unknown form %d (1 two "
+             "kernels, 3 stream, 6 split, 7 sample; the panel / chunk / tile forms 2, 4, 5 were retired in favour of the split "
+             "form)", c.form);
   FQ_REQUIRE(stride == 1 || c.form == 0 || c.form == 6, "fq_pwconv_i8_strided: only the split form reads strided inputs");
   FQ_REQUIRE(residual == nullptr || c.form != 1, "fq_pwconv_i8_strided: the two-kernel form takes no residual operand");
   // algorithmic bytes: the input pixels the outputs need, the outputs, and the residual operand when there is one
   ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (residual ? 2.0 : 1.0) * (double)n * cout * hw), c.st);
   bool taken = false;
+  if (int rc = pw_try_sample(c, &taken)) return rc;
+  if (taken) return FQ_OK;
+  FQ_REQUIRE(c.form != 7, "fq_pwconv_i8: the sample form takes 14x14 planes, stride 1, no residual, Cin 256 or 512, Cout a "
+             "multiple of 256");
   if (int rc = pw_try_split(c, &taken)) return rc;
   if (taken) return FQ_OK;
   if (int rc = pw_try_stream(c, &taken)) return rc;

@@ -473,7 +473,7 @@ def weight_codes(w, rows_per_scale, width=8):
     return codes, scales, rowsum
 
 
-PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6}
+PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6, "sample": 7}
 
 
 SPLIT_KT = (2, 4, 6, 8, 10, 12, 16, 18, 30, 32, 64)     # padded Cin / 32 the split form of fq_pwconv_i8 is built for

@@ -76,12 +76,20 @@ def main():
         print("%d->%d %dx%d: %d workgroups on %d distinct CUs; kernel span %.1f us" % (cin, cout, hw, hw, len(t),
               len(set(cuid.tolist())), st[:, 5].max()))
         names = ["start", "setup done", "phase1 issued", "phase1 barrier", "gemm(block0) done", "end"]
+        if form == "sample":
+            names = ["start", "set-up done", "chunk loop done", "stores issued", "statistic done", "end"]
+            tt = t.astype(np.float64)
+            for a, b_, nm in [(1, 6, "first chunk quantised + barrier"), (6, 7, "first half of the chunks"), (7, 2, "second half of the chunks")]:
+                dd = (tt[:, b_] - tt[:, a]) / 100.0
+                print("   sample form: %-36s median %7.2f  p90 %7.2f us" % (nm, np.median(dd), np.percentile(dd, 90)))
         if form == "split":
             names = ["start", "set-up done", "quantise done", "barrier passed", "multiply done", "end"]
         for i, nm in enumerate(names):
             print("   %-18s min %7.2f  median %7.2f  max %7.2f us" % (nm, st[:, i].min(), np.median(st[:, i]), st[:, i].max()))
         d = np.diff(st, axis=1)
         dn = ["setup", "phase1 (load+quant+LDS)", "barrier wait", "gemm block0", "epilogue(+other blocks)"]
+        if form == "sample":
+            dn = ["set-up (threshold, constants)", "chunk loop", "epilogue + stores", "statistic", "-"]
         if form == "split":
             dn = ["set-up (mean, constants)", "quantise -> panel", "barrier wait", "multiply", "epilogue + statistic"]
         for i, nm in enumerate(dn):
