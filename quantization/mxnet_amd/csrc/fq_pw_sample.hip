@@ -103,19 +103,24 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
 #pragma unroll
     for (int c = 0; c < CTW; ++c) ring[d][c] = a_frag(c, d < KT ? d : KT - 1);
   FQ_PIN();
-  // ---- threshold, constants ----------------------------------------------------------------------------------------------------
+  // ---- per-channel constants (one channel per thread: NCH == threads), requested BEFORE the threshold is waited for - the
+  // only one that needs it is sx * wscale ------------------------------------------------------------------------------------------
+  static_assert(NCH == NW * 64, "one channel per thread");
+  const int ic = ch0 + (int)threadIdx.x;                                // < Cout (host: Cout % 512 == 0)
+  const float k_ws = wscale[ic];
+  const int k_zs = g.zoff * wsum[ic];
+  const float k_bias = bias != nullptr ? bias[ic] : 0.0f;
+  const float k_bsc = has_bn ? bn_scale[ic] : 1.0f;
+  const float k_bsh = has_bn ? bn_shift[ic] : 0.0f;
+  FQ_PIN();
   const float max_ = threshold_finish(treq, in_stat, n, in_thr, cur_max_out, b == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   const float sx = q.scale;
-  for (int i = threadIdx.x; i < NCH; i += NW * 64) {
-    const bool ok = ch0 + i < g.Cout;                                   // channels past Cout: all-zero constants
-    const int ic = ok ? ch0 + i : 0;
-    c_sxw[i] = ok ? sx * wscale[ic] : 0.0f;
-    c_zs[i] = ok ? g.zoff * wsum[ic] : 0;
-    c_bias[i] = ok && bias != nullptr ? bias[ic] : 0.0f;
-    c_bsc[i] = has_bn && ok ? bn_scale[ic] : (ok ? 1.0f : 0.0f);
-    c_bsh[i] = has_bn && ok ? bn_shift[ic] : 0.0f;
-  }
+  c_sxw[threadIdx.x] = sx * k_ws;
+  c_zs[threadIdx.x] = k_zs;
+  c_bias[threadIdx.x] = k_bias;
+  c_bsc[threadIdx.x] = k_bsc;
+  c_bsh[threadIdx.x] = k_bsh;
   PW_STAMP(1);
   // panel: [pixel][32 codes], 40 words per pixel quad = 4 pixels x 8 words + 8 words of padding; a thread writes the two
   // codes (16 bits) of its channel pair for each of its four pixels.  Threads without an item (pixel quads past the half
@@ -211,27 +216,35 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
         const f4 bch = *reinterpret_cast<const f4*>(c_bias + c0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          // pixel tiles two at a time: they share the channel's constants, so scale / BatchNorm run as packed fp32
+          // instructions (two IEEE operations each: the same values as the scalar form)
 #pragma unroll
-          for (int pt = 0; pt < kSmpPT; ++pt) {
-            float v = (float)(acc[pt][c][4 * gq + r] + zs[r]) * sxw[r];
+          for (int pp = 0; pp < kSmpPT; pp += 2) {
+            f2 v = (f2){(float)(acc[pp][c][4 * gq + r] + zs[r]), (float)(acc[pp + 1][c][4 * gq + r] + zs[r])};
+            v = v * (f2){sxw[r], sxw[r]};
             if (FAST) {
-              v = v * bsc[r];
-              v = v + bsh[r];
-              v = fmaxf(v, 0.0f);
+              v = v * (f2){bsc[r], bsc[r]};
+              v = v + (f2){bsh[r], bsh[r]};
+              v.x = fmaxf(v.x, 0.0f);
+              v.y = fmaxf(v.y, 0.0f);
             } else {
-              if (bias != nullptr) v = v + bch[r];
+              if (bias != nullptr) v = v + (f2){bch[r], bch[r]};
               if (has_bn) {
-                v = v * bsc[r];
-                v = v + bsh[r];
+                v = v * (f2){bsc[r], bsc[r]};
+                v = v + (f2){bsh[r], bsh[r]};
               }
-              v = act_rt(v, act);
+              v.x = act_rt(v.x, act);
+              v.y = act_rt(v.y, act);
             }
-            if (pt == kSmpPT - 1) {
-              buf_st_f32(yr, po_last, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
-              m = fmaxf(m, last_ok ? fabsf(v) : 0.0f);
+            const unsigned so = (unsigned)(c * 32 + 8 * gq + r) * plane4;
+            buf_st_f32(yr, po0 + 32u * pp * 4u, so, v.x);
+            if (pp + 1 == kSmpPT - 1) {
+              buf_st_f32(yr, po_last, so, v.y);
+              m = fmaxf(fmaxf(m, fabsf(v.x)), last_ok ? fabsf(v.y) : 0.0f);
             } else {
-              buf_st_f32(yr, po0 + 32u * pt * 4u, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
-              m = fmaxf(m, fabsf(v));
+              buf_st_f32(yr, po0 + 32u * (pp + 1) * 4u, so, v.y);
+              m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
             }
           }
         }
