@@ -20,19 +20,21 @@ namespace {
 // one barrier per chunk (two panels), then the epilogue of the split form.  Every activation is read ONCE and quantised ONCE,
 // the vector ALU (the quantiser is ~8.5 instructions per value at ~4.3 cycles each, tools/valu_probe.hip) and the matrix
 // pipe work at the same time.
-constexpr int kSmpHW = 196;
-constexpr int kSmpPT = 4;                               // 32-pixel tiles of a half plane (100 or 96 pixels)
+constexpr int kSmpPT = 4;                               // 32-pixel tiles of a pixel block (96..128 pixels)
 constexpr int kSmpPanelWords = 32 * 40;                 // 32 pixel quads x (4 pixels x 8 words + 8 words of padding)
 
 struct PwSampleGeom {
-  int Cin, Cout, CS;         // CS: channel groups of 512
+  int Cin, Cout, CS;         // CS: channel groups of 256 * CTW
   int CTM;                   // 32-channel tiles present in the weight buffer
   int n;                     // samples
   int zoff;
+  int HW;                    // pixels of a plane (a multiple of 4)
+  int nb, qbase, qextra;     // pixel blocks per plane: block k holds qbase + (k < qextra) groups of four pixels (24..32)
 };
 
-template <int KT>
-__global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
+// (one channel tile per wavefront: 64 accumulator registers - built for two workgroups per CU, whose phases then overlap)
+template <int KT, int CTW>
+__global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSampleGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
   // eight wavefronts, two per SIMD (256 registers each): 4 x 2 accumulator tiles = 128 registers.  (Four wavefronts with
   // 4 x 4 tiles and the whole register file each were tried: 12.4 us for the chunk loop instead of 15.9, but a lone wavefront
   // per SIMD exposes every latency of the set-up and the epilogue - 4.7 + 8.4 us instead of 3.7 + 5.1.)
-  constexpr int NW = 8, CTW = 2;
-  constexpr int NCH = NW * CTW * 32;                                    // output channels of one workgroup (512)
+  constexpr int NW = 8;
+  constexpr int NCH = NW * CTW * 32;                                    // output channels of one workgroup (256 or 512)
 #ifndef FQ_PWSMP_HEAD
 #define FQ_PWSMP_HEAD 40
 #define FQ_PWSMP_SLICE 5
@@ -50,7 +52,10 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
 #ifndef FQ_PWSMP_PF
 #define FQ_PWSMP_PF 4
 #endif
-  constexpr int PF = FQ_PWSMP_PF < KT ? FQ_PWSMP_PF : KT;               // chunks requested ahead (16 registers each)
+  // chunks requested ahead (8 registers each); one fewer with one channel tile per wavefront, which then fits 128 registers
+  // = two workgroups per CU
+  constexpr int PF_ = CTW == 1 ? FQ_PWSMP_PF - 1 : FQ_PWSMP_PF;
+  constexpr int PF = PF_ < KT ? PF_ : KT;
   __shared__ __attribute__((aligned(16))) unsigned panel[2][kSmpPanelWords];
   __shared__ __attribute__((aligned(16))) float c_sxw[NCH], c_bsc[NCH], c_bsh[NCH], c_bias[NCH];
   __shared__ __attribute__((aligned(16))) int c_zs[NCH];
@@ -63,12 +68,14 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
   // workgroup b runs on XCD b % 8; slot = its position inside the XCD's share: (sample, channel group, pixel half)
   const unsigned b = blockIdx.x;
   const unsigned xcd = b & 7u, slot = b >> 3;
-  const unsigned ph = slot & 1u, cg = (slot >> 1) % (unsigned)g.CS;
-  const unsigned smp = ((slot >> 1) / (unsigned)g.CS) * 8u + xcd;
+  const unsigned ph = slot % (unsigned)g.nb, cg = (slot / (unsigned)g.nb) % (unsigned)g.CS;
+  const unsigned smp = (slot / (unsigned)(g.nb * g.CS)) * 8u + xcd;
   if (smp >= (unsigned)g.n) return;
   const int ch0 = (int)cg * NCH;
-  const unsigned pix0 = ph ? 100u : 0u, npix = ph ? 96u : 100u;         // this half: 25 or 24 pixel quads
-  const unsigned nquad = npix >> 2;
+  // this block: nquad groups of four pixels from pixel pix0 on (14x14: two blocks of 25 and 24; 28x28: seven of 28)
+  const unsigned nquad = (unsigned)g.qbase + (ph < (unsigned)g.qextra ? 1u : 0u);
+  const unsigned pix0 = (ph * (unsigned)g.qbase + (ph < (unsigned)g.qextra ? ph : (unsigned)g.qextra)) * 4u, npix = nquad * 4u;
+  const unsigned plane4 = (unsigned)g.HW * 4u;                          // bytes of a plane
 
   PW_STAMP(0);
   const ThresholdReq treq = threshold_request(in_stat, n, in_thr, b == 0);          // first in the memory queue
@@ -77,11 +84,11 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
   const unsigned kq = ((unsigned)wave & 1u) * 8u + ((unsigned)lane & 7u);           // channel pair 0..15
   const unsigned pq = ((unsigned)wave >> 1) * 8u + ((unsigned)lane >> 3);           // pixel quad 0..31
   const bool ld_lane = pq < nquad;
-  const fq_rsrc xr = make_rsrc(reinterpret_cast<const char*>(x) + (int64_t)smp * g.Cin * (kSmpHW * 4), (int64_t)g.Cin * (kSmpHW * 4));
-  const unsigned xo = ld_lane ? (kq * 2u * kSmpHW + pix0 + pq * 4u) * 4u : 0x80000000u;
+  const fq_rsrc xr = make_rsrc(reinterpret_cast<const char*>(x) + (int64_t)smp * g.Cin * plane4, (int64_t)g.Cin * plane4);
+  const unsigned xo = ld_lane ? kq * 2u * plane4 + (pix0 + pq * 4u) * 4u : 0x80000000u;
   auto issue = [&](int kt, f4 (&v)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) v[j] = buf_ld_v4f(xr, xo, (unsigned)(kt * 32 + j) * (kSmpHW * 4u));
+    for (int j = 0; j < 2; ++j) v[j] = buf_ld_v4f(xr, xo, (unsigned)(kt * 32 + j) * plane4);
   };
   f4 buf[PF][2];
 #pragma unroll
@@ -105,8 +112,8 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
   FQ_PIN();
   // ---- per-channel constants (one channel per thread: NCH == threads), requested BEFORE the threshold is waited for - the
   // only one that needs it is sx * wscale ------------------------------------------------------------------------------------------
-  static_assert(NCH == NW * 64, "one channel per thread");
-  const int ic = ch0 + (int)threadIdx.x;                                // < Cout (host: Cout % 512 == 0)
+  static_assert(NCH <= NW * 64, "one channel per thread");
+  const int ic = ch0 + (int)(threadIdx.x < NCH ? threadIdx.x : 0u);     // < Cout (host: Cout % NCH == 0)
   const float k_ws = wscale[ic];
   const int k_zs = g.zoff * wsum[ic];
   const float k_bias = bias != nullptr ? bias[ic] : 0.0f;
@@ -116,11 +123,13 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
   const float max_ = threshold_finish(treq, in_stat, n, in_thr, cur_max_out, b == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   const float sx = q.scale;
-  c_sxw[threadIdx.x] = sx * k_ws;
-  c_zs[threadIdx.x] = k_zs;
-  c_bias[threadIdx.x] = k_bias;
-  c_bsc[threadIdx.x] = k_bsc;
-  c_bsh[threadIdx.x] = k_bsh;
+  if (threadIdx.x < NCH) {
+    c_sxw[threadIdx.x] = sx * k_ws;
+    c_zs[threadIdx.x] = k_zs;
+    c_bias[threadIdx.x] = k_bias;
+    c_bsc[threadIdx.x] = k_bsc;
+    c_bsh[threadIdx.x] = k_bsh;
+  }
   PW_STAMP(1);
   // panel: [pixel][32 codes], 40 words per pixel quad = 4 pixels x 8 words + 8 words of padding; a thread writes the two
   // codes (16 bits) of its channel pair for each of its four pixels.  Threads without an item (pixel quads past the half
@@ -192,7 +201,6 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
   PW_STAMP(2);
   // ---- epilogue: lane = pixel, register = channel 8 gq + 4 h + r of the tile ----------------------------------------------------
   const int cvalid = g.Cout - (ch0 + ctl0 * 32);
-  const unsigned plane4 = kSmpHW * 4u;
   float m = 0.0f;
   auto epilogue = [&](auto fast_c) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_c)::value;                      // BatchNorm + ReLU, no bias: fixed at compile time
@@ -275,32 +283,47 @@ __global__ __launch_bounds__(512, 1) void pwconv_sample_kernel(
 
 namespace fqi {
 
-// sample form (K2s): 14x14 planes, stride 1, no residual operand, Cin a multiple of 32 with K / 32 in {8, 16}, Cout a multiple
-// of 512.  grid = samples x channel groups x 2 pixel halves (rounded to whole rounds over the 8 XCDs).
+// sample form (K2s): stride 1, no residual operand, planes of a multiple of 4 pixels that cut into blocks of 96..128 pixels
+// (14x14: two, 28x28: seven), Cin a multiple of 32 with K / 32 in {4, 8, 16}, Cout a multiple of 256.
+// grid = samples x channel groups x pixel blocks (rounded to whole rounds over the 8 XCDs).
 int pw_try_sample(const PwCall& a, bool* taken) {
   *taken = false;
-  static const int mode = env_int("FQ_PWSMP", 1);                       // tuning: 0 never, 1 by shape
+  static const int mode = env_int("FQ_PWSMP", 1);                       // tuning: 0 never, 1 planes up to 1024 pixels, 2 every shape it takes
   const int kt = (int)(a.cin_pad / 32);
-  const bool shape_ok = a.hw == kSmpHW && a.stride == 1 && a.residual == nullptr && a.cin == a.cin_pad && (kt == 8 || kt == 16) &&
-                        a.cout % 512 == 0 && a.n < (1 << 20) && aligned16(a.x);
-  if (!shape_ok || !(a.form == 7 || (a.form == 0 && mode == 1))) return FQ_OK;
+  const int64_t quads = a.hw / 4;
+  const int nb = (int)((quads + 31) / 32);                              // fewest blocks of at most 32 pixel groups
+  const bool shape_ok = a.hw % 4 == 0 && nb >= 1 && quads / nb >= 24 && a.stride == 1 && a.residual == nullptr &&
+                        a.cin == a.cin_pad && (kt == 4 || kt == 8 || kt == 16) && a.cout % 256 == 0 && a.n < (1 << 20) &&
+                        a.cin * a.hw * 4 < (1ll << 31) && aligned16(a.x);
+  // by shape: the small and middle planes (measured in the model against the split form: 512 -> 512 @14x14 32.0 -> 25.2 us,
+  // 256 -> 512 @14x14 24.0 -> 20.7, 256 -> 256 @28x28 48.0 -> 39.7, 128 -> 256 @28x28 38.8 -> 33.7); the streaming form keeps
+  // the large planes
+  const bool by_shape = a.form == 0 && (mode == 2 || (mode == 1 && a.hw <= 1024));
+  if (!shape_ok || !(a.form == 7 || by_shape)) return FQ_OK;
   const int64_t rows_pad = (a.cout + 31) / 32 * 32;
+  static const int ctw_tune = env_int("FQ_PWSMP_CTW", 0);               // tuning: 1 = 256 channels per workgroup everywhere
+  const int ctw = (a.cout % 512 == 0 && ctw_tune != 1) ? 2 : 1;
   PwSampleGeom t;
   t.Cin = (int)a.cin;
   t.Cout = (int)a.cout;
-  t.CS = (int)(a.cout / 512);
+  t.CS = (int)(a.cout / (256 * ctw));
   t.CTM = (int)(rows_pad / 32);
   t.n = (int)a.n;
   t.zoff = a.zoff;
-  const int64_t grid = (a.n + 7) / 8 * t.CS * 2 * 8;
+  t.HW = (int)a.hw;
+  t.nb = nb;
+  t.qbase = (int)(quads / nb);
+  t.qextra = (int)(quads % nb);
+  const int64_t grid = (a.n + 7) / 8 * t.CS * nb * 8;
+  FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8: too many workgroups for the sample form");
   const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;                // second half of fq_weight_codes' buffer
   if (int rc = pw_zero_stat(a)) return rc;
-#define FQ_PWSMP_CASE(KT_)                                                                                             \
-  if (kt == KT_)                                                                                                       \
-    hipLaunchKernelGGL((pwconv_sample_kernel<KT_>), dim3((unsigned)grid), dim3(512), 0, a.st, a.x, wfrag, a.wscale,    \
-                       (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, a.lo_neg, kEps,     \
-                       a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out);
-  FQ_PWSMP_CASE(8) FQ_PWSMP_CASE(16)
+#define FQ_PWSMP_CASE(KT_, CTW_)                                                                                       \
+  if (kt == KT_ && ctw == CTW_)                                                                                        \
+    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_>), dim3((unsigned)grid), dim3(512), 0, a.st, a.x, wfrag,         \
+                       a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, a.lo_neg, \
+                       kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out);
+  FQ_PWSMP_CASE(4, 1) FQ_PWSMP_CASE(4, 2) FQ_PWSMP_CASE(8, 1) FQ_PWSMP_CASE(8, 2) FQ_PWSMP_CASE(16, 1) FQ_PWSMP_CASE(16, 2)
 #undef FQ_PWSMP_CASE
   FQ_LAUNCH_CHECK();
   *taken = true;

@@ -504,7 +504,10 @@ FORM_CASES = [
     ("split", (4, 1024, 1000, 1, 1)),
     # sample (14x14 planes, half a sample per workgroup): K/32 = 8 and 16, one and two channel groups of 512, a sample count that
     # leaves XCD shares ragged
-    ("sample", (3, 512, 512, 14, 14)), ("sample", (9, 256, 512, 14, 14)), ("sample", (17, 256, 1024, 14, 14))]
+    ("sample", (3, 512, 512, 14, 14)), ("sample", (9, 256, 512, 14, 14)), ("sample", (17, 256, 1024, 14, 14)),
+    # ... 256 channels per workgroup, 28x28 planes in seven blocks of 112 pixels, one block of 100, K/32 = 4
+    ("sample", (2, 512, 256, 14, 14)), ("sample", (3, 128, 256, 28, 28)), ("sample", (2, 256, 256, 28, 28)),
+    ("sample", (5, 128, 512, 10, 10)), ("sample", (2, 256, 768, 16, 24))]
 
 
 @pytest.mark.parametrize("form,case", FORM_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in FORM_CASES])
