@@ -42,12 +42,13 @@ KERNEL_NAMES = {
     "apply_online": "act_apply_kernel<ONLINE> (fake-quant apply pass, 8 B/elem)",
     "apply_offline": "act_apply_kernel<OFFLINE> (8 B/elem)",
     "stat": "absmax_per_sample_kernel (statistic pass, 4 B/elem)",
-    "dwconv": "dwconv3x3_{cols4,cols,}_kernel (depthwise 3x3 with fake-quant on load + BN/ReLU/statistic on store, "
-              "4 B/in-elem + 4 B/out-elem)",
+    "dwconv": "dwconv3x3_{cols4,flat,planes,cols,}_kernel (depthwise 3x3 with fake-quant on load + BN/ReLU/statistic on "
+              "store, 4 B/in-elem + 4 B/out-elem)",
     "bn_act": "bn_act_stat_kernel (BatchNorm + ReLU + statistic in one pass, 8 B/elem)",
-    "stem": "stem_conv3x3s2_kernel (un-quantised first conv + BN + ReLU + statistic, 4 B/in-elem + 4 B/out-elem)",
+    "stem": "stem_mfma_kernel (un-quantised first conv on the fp32 matrix cores + BN + ReLU + statistic, 4 B/in-elem + "
+            "4 B/out-elem)",
     "pool": "gap_stat_kernel (global average pool + statistic, 4 B/in-elem + 4 B/out-elem)",
-    "pwconv": "pwconv_{split,stream}_kernel (1x1 conv on int8 codes: fake-quant on load, exact int32 MFMA sums, "
+    "pwconv": "pwconv_{stream,sample,split}_kernel (1x1 conv on int8 codes: fake-quant on load, exact int32 MFMA sums, "
               "BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
     "conv3x3": "conv3x3_i8_kernel (dense 3x3 conv on int8 codes: implicit GEMM over (tap, ci), fake-quant on load, exact "
                "int32 MFMA sums, BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
