@@ -36,7 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (/opt/skills/guides/MI355X_MICROARCH.md)
-DEFAULT_STEPS = 400         # ~0.6 s of timed region for the default workload (1.4-1.5 ms per step)
+DEFAULT_STEPS = 500         # ~0.6 s of timed region for the default workload (1.16-1.21 ms per step)
 
 KERNEL_NAMES = {
     "apply_online": "act_apply_kernel<ONLINE> (fake-quant apply pass, 8 B/elem)",
