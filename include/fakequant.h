@@ -61,9 +61,9 @@ int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront)
 #define FQ_KERNEL_HISTOGRAM 4     /* histogram_kernel              : 4 B/elem                                       */
 #define FQ_KERNEL_BN_ACT 5        /* bn_act_stat_kernel            : 8 B/elem                                       */
 #define FQ_KERNEL_DWCONV 6        /* dwconv3x3_*_kernel            : 4 B/in elem + 4 B/out elem                     */
-#define FQ_KERNEL_PWCONV 7        /* pwconv_{split,stream}_kernel (32x32x32 int8 MFMA; quant_transpose_i8 + pwconv_i8 for the
-                                     remaining shapes)             : 4 B/in elem + 4 B/out elem                     */
-#define FQ_KERNEL_STEM 8          /* stem_conv3x3s2_kernel         : 4 B/in elem + 4 B/out elem                     */
+#define FQ_KERNEL_PWCONV 7        /* pwconv_{stream,sample,split}_kernel (32x32x32 int8 MFMA; quant_transpose_i8 + pwconv_i8
+                                     for the remaining shapes)     : 4 B/in elem + 4 B/out elem                     */
+#define FQ_KERNEL_STEM 8          /* stem_mfma_kernel              : 4 B/in elem + 4 B/out elem                     */
 #define FQ_KERNEL_POOL 9          /* gap_stat_kernel               : 4 B/in elem + 4 B/out elem                     */
 #define FQ_KERNEL_GLOBAL_MAX 10   /* minmax_kernel (calibration)   : 4 B/elem                                       */
 #define FQ_KERNEL_CONV3X3 11      /* conv3x3_i8_kernel             : 4 B/in elem + 4 B/out elem                     */
@@ -217,8 +217,8 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
  * After fake-quantisation both operands of a convolution are integers times a scale: x_q = cx * sx (cx in [0, 2^w-1]
  * or [-(2^(w-1)-1), 2^(w-1)-1]) and w_q[co,:] = cw * sw[co].  For a 1x1 convolution the reference's fp32
  * F.Convolution computes  sum_ci w_q * x_q  with fp32 rounding at every step; the SAME sum is  sx*sw[co] * sum_ci cw*cx,
- * and the integer sum is exact on the int8 matrix cores (int32 accumulate; v_mfma_i32_32x32x32_i8 in the split /
- * stream forms that take the MobileNet / MobileNetV2 / ResNet shapes, v_mfma_i32_16x16x64_i8 in the generic form).  This entry point
+ * and the integer sum is exact on the int8 matrix cores (int32 accumulate; v_mfma_i32_32x32x32_i8 in the stream / sample /
+ * split forms that take the MobileNet / MobileNetV2 / ResNet shapes, v_mfma_i32_16x16x64_i8 in the generic form).  This entry point
  * does that, with the fake-quant of x folded into the load and BatchNorm / activation / per-sample statistic into the
  * store (same contract as fq_dwconv3x3):
  *   cx   = roundf(clip(x, lo, max_) / (max_/levels + eps))          bit-identical to the fake-quant kernels
@@ -230,11 +230,11 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
  * unsigned activations).  Needs in_width <= 8.                                                                       */
 int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_scale, int width, int64_t row_pad,
                     int64_t rows_pad, int8_t* codes, float* scales, int32_t* rowsum, void* ws, fqStream_t stream);
-/* One launch for the shapes of the split and stream forms (csrc/fq_pw_split.hip, fq_pw_stream.hip; chosen by shape,
- * FQ_PW_FORM forces one for tuning); every other shape takes two: (A) quantise + transpose x into int8 codes [(n*hw)][cin_pad] in
+/* One launch for the shapes of the stream, sample and split forms (csrc/fq_pw_stream.hip, fq_pw_sample.hip,
+ * fq_pw_split.hip; chosen by shape, FQ_PW_FORM forces one for tuning); every other shape takes two: (A) quantise + transpose x into int8 codes [(n*hw)][cin_pad] in
  * `ws` (fq_pwconv_workspace_bytes), (B) the integer GEMM with both operands K-contiguous + epilogue.  Online mode
  * requires out_current_max.                                                                                          */
-/* OR into `act`: take this form instead of the shape-based choice (1 two kernels, 3 stream, 6 split); FQ_INVALID when
+/* OR into `act`: take this form instead of the shape-based choice (1 two kernels, 3 stream, 6 split, 7 sample); FQ_INVALID when
  * the shape does not fit it.  For parity tests and tuning runs.                                  */
 #define FQ_PW_FORM(f) ((f) << 12)
 size_t fq_pwconv_workspace_bytes(int64_t n, int64_t cin_pad, int64_t hw);

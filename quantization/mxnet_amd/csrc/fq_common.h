@@ -7,10 +7,13 @@
 //   fq_core.hip        errors, event timing (fq_profile_*), device info, streaming policy
 //   fq_stream.hip      K1 per-sample statistic, K1b batch means, K2 fake-quant apply, K2b BatchNorm+activation+statistic,
 //                      K11 global average pool + statistic, K12 evaluation counters
-//   fq_dwconv.hip      K2c/K2d/K2e depthwise 3x3 with quantise-on-load (LDS tiles / 1 column per lane / 4 columns per lane)
-//   fq_stem.hip        K2s first convolution 3x3 s2 (3 -> 32)
-//   fq_pw_stream.hip   K2h pointwise on int8 codes, weights resident in LDS
-//   fq_pw_split.hip    K2m pointwise, one (pixel tile, channel group) per workgroup: every layer from 28x28 planes down
+//   fq_dwconv.hip      K2c/K2d/K2e depthwise 3x3 with quantise-on-load (LDS tiles / 1 column per lane / 4 columns per lane),
+//                      K2o whole small planes in registers, K2p 14x14 / 7x7 planes as flat 16-byte ranges through an LDS transpose
+//   fq_stem.hip        K2s first convolution 3x3 s2 (3 -> 32) on the vector ALU, K2q 3x3 / 7x7 on the fp32 matrix cores
+//   fq_conv3x3.hip     K2n dense 3x3 on int8 codes (implicit GEMM over tap and channel)
+//   fq_pw_stream.hip   K2h pointwise on int8 codes, weights resident in LDS (largest planes)
+//   fq_pw_sample.hip   K2r pointwise, one block of 96..128 pixels x 256 / 512 channels per workgroup, output-stationary
+//   fq_pw_split.hip    K2m pointwise, one (pixel tile, channel group) per workgroup: every other layer from 28x28 planes down
 //   fq_pw_generic.hip  K2f pointwise for every other shape (quantise + transpose, then an integer GEMM)
 //   fq_pwconv.hip      fq_pwconv_i8: shape-based choice between the pointwise forms; the weight-code kernel (fq_weight_codes)
 //   fq_weights.hip     K3 weight fake-quant (layer / group / channel), generic STE, K4 Winograd-domain weights

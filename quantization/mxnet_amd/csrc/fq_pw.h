@@ -36,7 +36,7 @@ struct PwCall {
 int pw_try_stream(const PwCall& c, bool* taken);    // K2h  fq_pw_stream.hip
 bool pw_stream_shape_ok(const PwCall& c);           //      shapes the streaming form takes
 int pw_try_split(const PwCall& c, bool* taken);     // K2m  fq_pw_split.hip
-int pw_try_sample(const PwCall& c, bool* taken);    // K2s  fq_pw_sample.hip (14x14 planes)
+int pw_try_sample(const PwCall& c, bool* taken);    // K2r  fq_pw_sample.hip (14x14 planes)
 int pw_two_kernels(const PwCall& c);                // K2f  fq_pw_generic.hip (takes every shape)
 
 inline int pw_zero_stat(const PwCall& c) {

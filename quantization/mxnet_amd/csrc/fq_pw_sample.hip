@@ -1,10 +1,10 @@
-// libfakequant — K2s pointwise (1x1) convolution on int8 codes for 14x14 planes: one SAMPLE per workgroup, output-stationary
+// libfakequant — K2r pointwise (1x1) convolution on int8 codes for 14x14 planes: one SAMPLE per workgroup, output-stationary
 // (see fq_common.h for the list of translation units and the design rules)
 #include "fq_pw.h"
 
 namespace {
 
-// K2s: sample form.  The split form (K2m) cuts a 14x14 layer into 32-pixel tiles: 128-byte pieces of every channel plane that
+// K2r: sample form.  The split form (K2m) cuts a 14x14 layer into 32-pixel tiles: 128-byte pieces of every channel plane that
 // are not line-aligned (a plane is 784 bytes), requested 4 bytes per lane, every tile quantised once per channel group, the
 // whole weight matrix streamed through L1 once per tile; a workgroup lives 13 us, 6 of them waiting for its activations,
 // and the layer takes two resident rounds of them (profiles/r2_pw_experiments.txt, E).  Here a workgroup of eight wavefronts
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
 
 namespace fqi {
 
-// sample form (K2s): stride 1, no residual operand, planes of a multiple of 4 pixels that cut into blocks of 96..128 pixels
+// sample form (K2r): stride 1, no residual operand, planes of a multiple of 4 pixels that cut into blocks of 96..128 pixels
 // (14x14: two, 28x28: seven), Cin a multiple of 32 with K / 32 in {4, 8, 16}, Cout a multiple of 256.
 // grid = samples x channel groups x pixel blocks (rounded to whole rounds over the 8 XCDs).
 int pw_try_sample(const PwCall& a, bool* taken) {
