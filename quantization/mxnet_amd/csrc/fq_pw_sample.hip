@@ -20,7 +20,6 @@ namespace {
 // one barrier per chunk (two panels), then the epilogue of the split form.  Every activation is read ONCE and quantised ONCE,
 // the vector ALU (the quantiser is ~8.5 instructions per value at ~4.3 cycles each, tools/valu_probe.hip) and the matrix
 // pipe work at the same time.
-constexpr int kSmpPT = 4;                               // 32-pixel tiles of a pixel block (96..128 pixels)
 constexpr int kSmpPanelWords = 32 * 40;                 // 32 pixel quads x (4 pixels x 8 words + 8 words of padding)
 
 struct PwSampleGeom {
@@ -33,8 +32,10 @@ struct PwSampleGeom {
 };
 
 // (one channel tile per wavefront: 64 accumulator registers - built for two workgroups per CU, whose phases then overlap)
-template <int KT, int CTW>
-__global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
+// PT: 32-pixel tiles of a block - 4 (96..128 pixels), or 2 for planes of fewer than 64 pixels taken whole (7x7: the plane is
+// not a multiple of four pixels; its last pixel is requested by a 4-byte load of its own).
+template <int KT, int CTW, int PT>
+__global__ __launch_bounds__(512, (CTW == 1 || PT == 2) ? 2 : 1) void pwconv_sample_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSampleGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
 #endif
   // chunks requested ahead (8 registers each); one fewer with one channel tile per wavefront, which then fits 128 registers
   // = two workgroups per CU
-  constexpr int PF_ = CTW == 1 ? FQ_PWSMP_PF - 1 : FQ_PWSMP_PF;
+  constexpr int PF_ = PT == 2 ? 2 : (CTW == 1 ? FQ_PWSMP_PF - 1 : FQ_PWSMP_PF);   // (small planes: a chunk is 6 KB)
   constexpr int PF = PF_ < KT ? PF_ : KT;
   __shared__ __attribute__((aligned(16))) unsigned panel[2][kSmpPanelWords];
   __shared__ __attribute__((aligned(16))) float c_sxw[NCH], c_bsc[NCH], c_bsh[NCH], c_bias[NCH];
@@ -74,7 +75,9 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
   const int ch0 = (int)cg * NCH;
   // this block: nquad groups of four pixels from pixel pix0 on (14x14: two blocks of 25 and 24; 28x28: seven of 28)
   const unsigned nquad = (unsigned)g.qbase + (ph < (unsigned)g.qextra ? 1u : 0u);
-  const unsigned pix0 = (ph * (unsigned)g.qbase + (ph < (unsigned)g.qextra ? ph : (unsigned)g.qextra)) * 4u, npix = nquad * 4u;
+  const unsigned pix0 = (ph * (unsigned)g.qbase + (ph < (unsigned)g.qextra ? ph : (unsigned)g.qextra)) * 4u;
+  const unsigned tail = (unsigned)g.HW & 3u;                            // (only whole planes may be ragged: nb == 1)
+  const unsigned npix = tail ? (unsigned)g.HW : nquad * 4u;
   const unsigned plane4 = (unsigned)g.HW * 4u;                          // bytes of a plane
 
   PW_STAMP(0);
@@ -85,12 +88,23 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
   const unsigned pq = ((unsigned)wave >> 1) * 8u + ((unsigned)lane >> 3);           // pixel quad 0..31
   const bool ld_lane = pq < nquad;
   const fq_rsrc xr = make_rsrc(reinterpret_cast<const char*>(x) + (int64_t)smp * g.Cin * plane4, (int64_t)g.Cin * plane4);
-  const unsigned xo = ld_lane ? kq * 2u * plane4 + (pix0 + pq * 4u) * 4u : 0x80000000u;
-  auto issue = [&](int kt, f4 (&v)[2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) v[j] = buf_ld_v4f(xr, xo, (unsigned)(kt * 32 + j) * plane4);
+  // a ragged plane's last group holds `tail` pixels: one 4-byte load per pixel... only tail == 1 is built (7x7)
+  const bool rag_lane = tail != 0u && pq + 1u == nquad;
+  const unsigned xoff = kq * 2u * plane4 + (pix0 + pq * 4u) * 4u;
+  const unsigned xo = (ld_lane && !rag_lane) ? xoff : 0x80000000u;
+  const unsigned xo1 = (ld_lane && rag_lane) ? xoff : 0x80000000u;
+  struct Chunk {
+    f4 v[2];
+    float r[PT == 2 ? 2 : 1];                                           // the ragged form's single pixels (0 for every other lane)
   };
-  f4 buf[PF][2];
+  auto issue = [&](int kt, Chunk& c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      c.v[j] = buf_ld_v4f(xr, xo, (unsigned)(kt * 32 + j) * plane4);
+      if (PT == 2) c.r[j] = buf_ld_f32(xr, xo1, (unsigned)(kt * 32 + j) * plane4);
+    }
+  };
+  Chunk buf[PF];
 #pragma unroll
   for (int i = 0; i < PF; ++i) issue(i, buf[i]);
   FQ_PIN();
@@ -136,7 +150,12 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
   // plane) loaded zeros and write the code of 0 into the padding quads of the last tile (whose products are never stored) -
   // unconditional stores keep the quantiser in the same basic block as the MFMAs, which is what lets the two interleave.
   const unsigned pw_off = pq * 160u + kq * 2u;                          // bytes; + 32 * (pixel inside the quad)
-  auto quant_to_panel = [&](int kt, const f4 (&v)[2]) __attribute__((always_inline)) {
+  auto quant_to_panel = [&](int kt, const Chunk& c) __attribute__((always_inline)) {
+    f4 v[2] = {c.v[0], c.v[1]};
+    if (PT == 2) {                                                      // (whole groups got 0 in r, the ragged lane 0 in v)
+      v[0].x = rag_lane ? c.r[0] : v[0].x;
+      v[1].x = rag_lane ? c.r[1] : v[1].x;
+    }
     unsigned char* dst = reinterpret_cast<unsigned char*>(panel[kt & 1]) + pw_off;
     const int ub = 128 - g.zoff;
     auto pair = [&](float a, float b2) -> unsigned short {
@@ -150,9 +169,9 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
   };
   // B fragment of pixel tile pt for this lane: pixel 32 pt + pl of the half, bytes 16 h .. 16 h + 15 of its 32 codes
   const unsigned bq_off = ((unsigned)pl >> 2) * 40u + ((unsigned)pl & 3u) * 8u + 4u * (unsigned)h;      // + pt * 8 quads * 40
-  v16i acc[kSmpPT][CTW];
+  v16i acc[PT][CTW];
 #pragma unroll
-  for (int pt = 0; pt < kSmpPT; ++pt)
+  for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
     for (int c = 0; c < CTW; ++c)
 #pragma unroll
@@ -172,11 +191,11 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
     if (kt == 0) PW_STAMP(6);
     if (kt == KT / 2) PW_STAMP(7);
     const unsigned* pb = &panel[kt & 1][bq_off];
-    v4i bfrag[kSmpPT];
+    v4i bfrag[PT];
 #pragma unroll
-    for (int pt = 0; pt < kSmpPT; ++pt) bfrag[pt] = *reinterpret_cast<const v4i*>(pb + pt * 320);
+    for (int pt = 0; pt < PT; ++pt) bfrag[pt] = *reinterpret_cast<const v4i*>(pb + pt * 320);
 #pragma unroll
-    for (int pt = 0; pt < kSmpPT; ++pt)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
       for (int c = 0; c < CTW; ++c)
         acc[pt][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[kt % (AD + 1)][c], bfrag[pt], acc[pt][c], 0, 0, 0);
@@ -189,10 +208,10 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
       for (int c = 0; c < CTW; ++c) ring[(kt + AD) % (AD + 1)][c] = a_frag(c, kt + AD);
     }
     // the schedule: B fragments, then one MFMA followed by a slice of vector work, eight times
-    __builtin_amdgcn_sched_group_barrier(0x100, kSmpPT, 0);             // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x100, PT, 0);             // DS reads
     __builtin_amdgcn_sched_group_barrier(0x002, FQ_PWSMP_HEAD, 0);      // vector work behind which the B fragments arrive
 #pragma unroll
-    for (int i = 0; i < kSmpPT * CTW; ++i) {
+    for (int i = 0; i < PT * CTW; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // one MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, FQ_PWSMP_SLICE, 0);   // a slice of the quantiser's vector instructions
     }
@@ -208,9 +227,9 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
     const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + ((int64_t)smp * g.Cout + ch0 + ctl0 * 32) * plane4, y_bytes);
     // channel tiles are whole (host: Cout % 512 == 0); only the LAST pixel tile of a half has pixels past its end (offset out
     // of range: the store is dropped) - the other three take no mask at all
-    const bool last_ok = 32u * (kSmpPT - 1) + (unsigned)pl < npix;
+    const bool last_ok = 32u * (PT - 1) + (unsigned)pl < npix;
     const unsigned po0 = (unsigned)(4 * h) * plane4 + (pix0 + (unsigned)pl) * 4u;
-    const unsigned po_last = last_ok ? po0 + 32u * (kSmpPT - 1) * 4u : 0x80000000u;
+    const unsigned po_last = last_ok ? po0 + 32u * (PT - 1) * 4u : 0x80000000u;
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
       const int cb = (ctl0 + c) * 32 + 4 * h;
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
           // pixel tiles two at a time: they share the channel's constants, so scale / BatchNorm run as packed fp32
           // instructions (two IEEE operations each: the same values as the scalar form)
 #pragma unroll
-          for (int pp = 0; pp < kSmpPT; pp += 2) {
+          for (int pp = 0; pp < PT; pp += 2) {
             f2 v = (f2){(float)(acc[pp][c][4 * gq + r] + zs[r]), (float)(acc[pp + 1][c][4 * gq + r] + zs[r])};
             v = v * (f2){sxw[r], sxw[r]};
             if (FAST) {
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
             }
             const unsigned so = (unsigned)(c * 32 + 8 * gq + r) * plane4;
             buf_st_f32(yr, po0 + 32u * pp * 4u, so, v.x);
-            if (pp + 1 == kSmpPT - 1) {
+            if (pp + 1 == PT - 1) {
               buf_st_f32(yr, po_last, so, v.y);
               m = fmaxf(fmaxf(m, fabsf(v.x)), last_ok ? fabsf(v.y) : 0.0f);
             } else {
@@ -283,22 +302,27 @@ __global__ __launch_bounds__(512, CTW == 1 ? 2 : 1) void pwconv_sample_kernel(
 
 namespace fqi {
 
-// sample form (K2r): stride 1, no residual operand, planes of a multiple of 4 pixels that cut into blocks of 96..128 pixels
-// (14x14: two, 28x28: seven), Cin a multiple of 32 with K / 32 in {4, 8, 16}, Cout a multiple of 256.
+// sample form (K2r): stride 1, no residual operand, Cout a multiple of 256, Cin a multiple of 32, and either
+//   planes of a multiple of 4 pixels that cut into blocks of 96..128 pixels (14x14: two, 28x28: seven), K / 32 in {4, 8, 16}, or
+//   whole planes of 45..64 pixels with 0 or 1 pixel past a multiple of four (7x7, 8x8), K / 32 in {16, 32}.
 // grid = samples x channel groups x pixel blocks (rounded to whole rounds over the 8 XCDs).
 int pw_try_sample(const PwCall& a, bool* taken) {
   *taken = false;
-  static const int mode = env_int("FQ_PWSMP", 1);                       // tuning: 0 never, 1 planes up to 1024 pixels, 2 every shape it takes
+  static const int mode = env_int("FQ_PWSMP", 1);                       // tuning: 0 never, 1 blocked planes up to 1024 pixels, 2 every shape it takes
   const int kt = (int)(a.cin_pad / 32);
-  const int64_t quads = a.hw / 4;
-  const int nb = (int)((quads + 31) / 32);                              // fewest blocks of at most 32 pixel groups
-  const bool shape_ok = a.hw % 4 == 0 && nb >= 1 && quads / nb >= 24 && a.stride == 1 && a.residual == nullptr &&
-                        a.cin == a.cin_pad && (kt == 4 || kt == 8 || kt == 16) && a.cout % 256 == 0 && a.n < (1 << 20) &&
-                        a.cin * a.hw * 4 < (1ll << 31) && aligned16(a.x);
+  const bool small = a.hw <= 64;                                        // one block of two pixel tiles
+  const int64_t quads = (a.hw + 3) / 4;
+  const int nb = small ? 1 : (int)((quads + 31) / 32);                  // fewest blocks of at most 32 pixel groups
+  const bool plane_ok = small ? (a.hw >= 45 && a.hw % 4 <= 1 && (kt == 16 || kt == 32))
+                              : (a.hw % 4 == 0 && quads / nb >= 24 && (kt == 4 || kt == 8 || kt == 16));
+  const bool shape_ok = plane_ok && a.stride == 1 && a.residual == nullptr && a.cin == a.cin_pad && a.cout % 256 == 0 &&
+                        a.n < (1 << 20) && a.cin * a.hw * 4 < (1ll << 31) && (small || aligned16(a.x));
   // by shape: the small and middle planes (measured in the model against the split form: 512 -> 512 @14x14 32.0 -> 25.2 us,
   // 256 -> 512 @14x14 24.0 -> 20.7, 256 -> 256 @28x28 48.0 -> 39.7, 128 -> 256 @28x28 38.8 -> 33.7); the streaming form keeps
   // the large planes
-  const bool by_shape = a.form == 0 && (mode == 2 || (mode == 1 && a.hw <= 1024));
+  // (whole small planes are built and tested, but not chosen: 1024 -> 1024 @7x7 27.9 us against the split form's 26.6,
+  // 512 -> 1024 @7x7 19.9 against 20.4 - 32 chunks with a barrier each)
+  const bool by_shape = a.form == 0 && (mode == 2 || (mode == 1 && a.hw <= 1024 && !small));
   if (!shape_ok || !(a.form == 7 || by_shape)) return FQ_OK;
   const int64_t rows_pad = (a.cout + 31) / 32 * 32;
   static const int ctw_tune = env_int("FQ_PWSMP_CTW", 0);               // tuning: 1 = 256 channels per workgroup everywhere
@@ -314,16 +338,18 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   t.nb = nb;
   t.qbase = (int)(quads / nb);
   t.qextra = (int)(quads % nb);
+  const int pt = small ? 2 : 4;
   const int64_t grid = (a.n + 7) / 8 * t.CS * nb * 8;
   FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8: too many workgroups for the sample form");
   const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;                // second half of fq_weight_codes' buffer
   if (int rc = pw_zero_stat(a)) return rc;
-#define FQ_PWSMP_CASE(KT_, CTW_)                                                                                       \
-  if (kt == KT_ && ctw == CTW_)                                                                                        \
-    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_>), dim3((unsigned)grid), dim3(512), 0, a.st, a.x, wfrag,         \
+#define FQ_PWSMP_CASE(KT_, CTW_, PT_)                                                                                  \
+  if (kt == KT_ && ctw == CTW_ && pt == PT_)                                                                           \
+    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_, PT_>), dim3((unsigned)grid), dim3(512), 0, a.st, a.x, wfrag,    \
                        a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, a.lo_neg, \
                        kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out);
-  FQ_PWSMP_CASE(4, 1) FQ_PWSMP_CASE(4, 2) FQ_PWSMP_CASE(8, 1) FQ_PWSMP_CASE(8, 2) FQ_PWSMP_CASE(16, 1) FQ_PWSMP_CASE(16, 2)
+  FQ_PWSMP_CASE(4, 1, 4) FQ_PWSMP_CASE(4, 2, 4) FQ_PWSMP_CASE(8, 1, 4) FQ_PWSMP_CASE(8, 2, 4) FQ_PWSMP_CASE(16, 1, 4)
+  FQ_PWSMP_CASE(16, 2, 4) FQ_PWSMP_CASE(16, 1, 2) FQ_PWSMP_CASE(16, 2, 2) FQ_PWSMP_CASE(32, 1, 2) FQ_PWSMP_CASE(32, 2, 2)
 #undef FQ_PWSMP_CASE
   FQ_LAUNCH_CHECK();
   *taken = true;

@@ -507,7 +507,10 @@ FORM_CASES = [
     ("sample", (3, 512, 512, 14, 14)), ("sample", (9, 256, 512, 14, 14)), ("sample", (17, 256, 1024, 14, 14)),
     # ... 256 channels per workgroup, 28x28 planes in seven blocks of 112 pixels, one block of 100, K/32 = 4
     ("sample", (2, 512, 256, 14, 14)), ("sample", (3, 128, 256, 28, 28)), ("sample", (2, 256, 256, 28, 28)),
-    ("sample", (5, 128, 512, 10, 10)), ("sample", (2, 256, 768, 16, 24))]
+    ("sample", (5, 128, 512, 10, 10)), ("sample", (2, 256, 768, 16, 24)),
+    # ... whole small planes in two pixel tiles: 7x7 (49 pixels: the last one has a load of its own) and 8x8, K/32 = 16 and 32
+    ("sample", (5, 512, 1024, 7, 7)), ("sample", (3, 1024, 1024, 7, 7)), ("sample", (2, 512, 256, 8, 8)),
+    ("sample", (9, 1024, 512, 7, 7))]
 
 
 @pytest.mark.parametrize("form,case", FORM_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in FORM_CASES])
