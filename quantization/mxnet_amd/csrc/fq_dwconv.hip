@@ -1232,11 +1232,14 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
   const bool can4 = (wdt % 4 == 0) && aligned16(x) && aligned16(y) && ((h * wdt) % 4 == 0) &&
                     (stride == 1 || ((wdt / 2) % 2 == 0));
   // 14x14 (stride 1 and 2) and 7x7 planes: flat 16-byte accesses through an LDS transpose (K2p)
-  static const int flat_on = env_int("FQ_DW_FLAT", 7);                   // tuning: bit 0 14x14 s1, bit 1 14x14 s2, bit 2 7x7
+  // tuning: bit 0 14x14 s1, bit 1 14x14 s2, bit 2 7x7, bit 3 28x28 s1, bit 4 28x28 s2
+  static const int flat_on = env_int("FQ_DW_FLAT", 31);                  // (28x28: 40.1 -> 34.6 us stride 1, ~30 -> 26.9 us stride 2)
   {
-    const int kind = (h == 14 && wdt == 14) ? (stride == 1 ? 0 : 1) : (h == 7 && wdt == 7 && stride == 1 ? 2 : -1);
-    const int kP = kind == 0 ? 9 : 8;                      // planes per wavefront and block (dwconv3x3_flat_kernel: P)
-    const bool whole = kind == 0 || (n * c) % kP == 0;     // planes of 49 floats: no 16-byte tail
+    const int kind = (h == 14 && wdt == 14) ? (stride == 1 ? 0 : 1)
+                     : (h == 7 && wdt == 7 && stride == 1) ? 2
+                     : (h == 28 && wdt == 28) ? (stride == 1 ? 3 : 4) : -1;
+    const int kP = kind == 0 ? 9 : kind >= 3 ? 4 : 8;      // planes per wavefront and block (dwconv3x3_flat_kernel: P)
+    const bool whole = kind == 0 || kind >= 3 || (n * c) % kP == 0;     // planes of 49 floats: no 16-byte tail
     if (kind >= 0 && (form == 5 || (form == 0 && ((flat_on >> kind) & 1))) && whole && aligned16(x) && aligned16(y) &&
         n * c * h * wdt * 4 < (1ll << 31)) {
       DwFlatGeom fg;
@@ -1275,7 +1278,9 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
   } while (0)
       if (kind == 0) FQ_DWF_Q(1, 14);
       else if (kind == 1) FQ_DWF_Q(2, 14);
-      else FQ_DWF_Q(1, 7);
+      else if (kind == 2) FQ_DWF_Q(1, 7);
+      else if (kind == 3) FQ_DWF_Q(1, 28);
+      else FQ_DWF_Q(2, 28);
 #undef FQ_DWF_Q
 #undef FQ_DWF
 #undef FQ_DWF_E
