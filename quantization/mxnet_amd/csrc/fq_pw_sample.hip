@@ -34,13 +34,14 @@ struct PwSampleGeom {
 // (one channel tile per wavefront: 64 accumulator registers - built for two workgroups per CU, whose phases then overlap)
 // PT: 32-pixel tiles of a block - 4 (96..128 pixels), or 2 for planes of fewer than 64 pixels taken whole (7x7: the plane is
 // not a multiple of four pixels; its last pixel is requested by a 4-byte load of its own).
-template <int KT, int CTW, int PT>
+// RES: a residual operand of y's shape is added after BatchNorm, before the activation (the shortcut of a ResNet unit).
+template <int KT, int CTW, int PT, bool RES>
 __global__ __launch_bounds__(512, (CTW == 1 || PT == 2) ? 2 : 1) void pwconv_sample_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSampleGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
-    float* __restrict__ stat_out) {
+    float* __restrict__ stat_out, const float* __restrict__ residual) {
   // eight wavefronts, two per SIMD (256 registers each): 4 x 2 accumulator tiles = 128 registers.  (Four wavefronts with
   // 4 x 4 tiles and the whole register file each were tried: 12.4 us for the chunk loop instead of 15.9, but a lone wavefront
   // per SIMD exposes every latency of the set-up and the epilogue - 4.7 + 8.4 us instead of 3.7 + 5.1.)
@@ -225,6 +226,8 @@ __global__ __launch_bounds__(512, (CTW == 1 || PT == 2) ? 2 : 1) void pwconv_sam
     constexpr bool FAST = decltype(fast_c)::value;                      // BatchNorm + ReLU, no bias: fixed at compile time
     const int64_t y_bytes = (int64_t)g.Cout * plane4 - (int64_t)(ch0 + ctl0 * 32) * plane4;
     const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + ((int64_t)smp * g.Cout + ch0 + ctl0 * 32) * plane4, y_bytes);
+    const fq_rsrc rr = make_rsrc(reinterpret_cast<const char*>(RES ? residual : y) + ((int64_t)smp * g.Cout + ch0 + ctl0 * 32) * plane4,
+                                 RES ? y_bytes : 0);
     // channel tiles are whole (host: Cout % 512 == 0); only the LAST pixel tile of a half has pixels past its end (offset out
     // of range: the store is dropped) - the other three take no mask at all
     const bool last_ok = 32u * (PT - 1) + (unsigned)pl < npix;
@@ -241,6 +244,15 @@ __global__ __launch_bounds__(512, (CTW == 1 || PT == 2) ? 2 : 1) void pwconv_sam
         const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
         const f4 bch = *reinterpret_cast<const f4*>(c_bias + c0);
+        float res[RES ? 4 * PT : 1];
+        if (RES) {                                 // the 4 x PT values of this group in flight before the first use
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+              res[RES ? r * PT + pt : 0] = buf_ld_f32(rr, pt == PT - 1 ? po_last : po0 + 32u * pt * 4u,
+                                                     (unsigned)(c * 32 + 8 * gq + r) * plane4);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           typedef float f2 __attribute__((ext_vector_type(2)));
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(512, (CTW == 1 || PT == 2) ? 2 : 1) void pwconv_sam
             if (FAST) {
               v = v * (f2){bsc[r], bsc[r]};
               v = v + (f2){bsh[r], bsh[r]};
+              if (RES) v = v + (f2){res[RES ? r * PT + pp : 0], res[RES ? r * PT + pp + 1 : 0]};
               v.x = fmaxf(v.x, 0.0f);
               v.y = fmaxf(v.y, 0.0f);
             } else {
@@ -261,6 +274,7 @@ __global__ __launch_bounds__(512, (CTW == 1 || PT == 2) ? 2 : 1) void pwconv_sam
                 v = v * (f2){bsc[r], bsc[r]};
                 v = v + (f2){bsh[r], bsh[r]};
               }
+              if (RES) v = v + (f2){res[RES ? r * PT + pp : 0], res[RES ? r * PT + pp + 1 : 0]};
               v.x = act_rt(v.x, act);
               v.y = act_rt(v.y, act);
             }
@@ -313,16 +327,18 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   const bool small = a.hw <= 64;                                        // one block of two pixel tiles
   const int64_t quads = (a.hw + 3) / 4;
   const int nb = small ? 1 : (int)((quads + 31) / 32);                  // fewest blocks of at most 32 pixel groups
-  const bool plane_ok = small ? (a.hw >= 45 && a.hw % 4 <= 1 && (kt == 16 || kt == 32))
-                              : (a.hw % 4 == 0 && quads / nb >= 24 && (kt == 4 || kt == 8 || kt == 16));
-  const bool shape_ok = plane_ok && a.stride == 1 && a.residual == nullptr && a.cin == a.cin_pad && a.cout % 256 == 0 &&
+  const bool plane_ok = small ? (a.hw >= 45 && a.hw % 4 <= 1 && (kt == 16 || kt == 32) && a.residual == nullptr)
+                              : (a.hw % 4 == 0 && quads / nb >= 24 && (kt == 4 || kt == 8 || kt == 16 || kt == 32));
+  const bool shape_ok = plane_ok && a.stride == 1 && a.cin == a.cin_pad && a.cout % 256 == 0 &&
                         a.n < (1 << 20) && a.cin * a.hw * 4 < (1ll << 31) && (small || aligned16(a.x));
   // by shape: the small and middle planes (measured in the model against the split form: 512 -> 512 @14x14 32.0 -> 25.2 us,
   // 256 -> 512 @14x14 24.0 -> 20.7, 256 -> 256 @28x28 48.0 -> 39.7, 128 -> 256 @28x28 38.8 -> 33.7); the streaming form keeps
   // the large planes
   // (whole small planes are built and tested, but not chosen: 1024 -> 1024 @7x7 27.9 us against the split form's 26.6,
   // 512 -> 1024 @7x7 19.9 against 20.4 - 32 chunks with a barrier each)
-  const bool by_shape = a.form == 0 && (mode == 2 || (mode == 1 && a.hw <= 1024 && !small));
+  // (nor with a residual operand: ResNet-50 128 -> 512 @28x28 103.9 us against the split form's 99.0, 256 -> 1024 @14x14 55.1
+  // against 51.0; without one, 1024 -> 256 @14x14: 30.2 against 34.8)
+  const bool by_shape = a.form == 0 && (mode == 2 || (mode == 1 && a.hw <= 1024 && !small && a.residual == nullptr));
   if (!shape_ok || !(a.form == 7 || by_shape)) return FQ_OK;
   const int64_t rows_pad = (a.cout + 31) / 32 * 32;
   static const int ctw_tune = env_int("FQ_PWSMP_CTW", 0);               // tuning: 1 = 256 channels per workgroup everywhere
@@ -343,14 +359,27 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8: too many workgroups for the sample form");
   const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;                // second half of fq_weight_codes' buffer
   if (int rc = pw_zero_stat(a)) return rc;
-#define FQ_PWSMP_CASE(KT_, CTW_, PT_)                                                                                  \
-  if (kt == KT_ && ctw == CTW_ && pt == PT_)                                                                           \
-    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_, PT_>), dim3((unsigned)grid), dim3(512), 0, a.st, a.x, wfrag,    \
-                       a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, a.lo_neg, \
-                       kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out);
+  const bool res = a.residual != nullptr;
+  bool launched = false;
+#define FQ_PWSMP_CASE_R(KT_, CTW_, PT_, RES_)                                                                          \
+  if (kt == KT_ && ctw == CTW_ && pt == PT_ && res == RES_) {                                                          \
+    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_, PT_, RES_>), dim3((unsigned)grid), dim3(512), 0, a.st, a.x,     \
+                       wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels,    \
+                       a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out, a.residual);      \
+    launched = true;                                                                                                   \
+  }
+#define FQ_PWSMP_CASE(KT_, CTW_, PT_) FQ_PWSMP_CASE_R(KT_, CTW_, PT_, false)
   FQ_PWSMP_CASE(4, 1, 4) FQ_PWSMP_CASE(4, 2, 4) FQ_PWSMP_CASE(8, 1, 4) FQ_PWSMP_CASE(8, 2, 4) FQ_PWSMP_CASE(16, 1, 4)
-  FQ_PWSMP_CASE(16, 2, 4) FQ_PWSMP_CASE(16, 1, 2) FQ_PWSMP_CASE(16, 2, 2) FQ_PWSMP_CASE(32, 1, 2) FQ_PWSMP_CASE(32, 2, 2)
+  FQ_PWSMP_CASE(16, 2, 4) FQ_PWSMP_CASE(32, 1, 4) FQ_PWSMP_CASE(32, 2, 4)
+  FQ_PWSMP_CASE(16, 1, 2) FQ_PWSMP_CASE(16, 2, 2) FQ_PWSMP_CASE(32, 1, 2) FQ_PWSMP_CASE(32, 2, 2)
+  // with a residual operand: the last 1x1 convolutions of the ResNet bottlenecks (128 -> 512 @28x28, 256 -> 1024 @14x14)
+  FQ_PWSMP_CASE_R(4, 2, 4, true) FQ_PWSMP_CASE_R(8, 2, 4, true) FQ_PWSMP_CASE_R(16, 2, 4, true)
 #undef FQ_PWSMP_CASE
+#undef FQ_PWSMP_CASE_R
+  if (!launched) {                                                     // (a combination that is not built: another form takes it)
+    FQ_REQUIRE(a.form != 7, "fq_pwconv_i8: this K / channel-group / residual combination of the sample form is not built");
+    return FQ_OK;
+  }
   FQ_LAUNCH_CHECK();
   *taken = true;
   return FQ_OK;

@@ -510,7 +510,7 @@ FORM_CASES = [
     ("sample", (5, 128, 512, 10, 10)), ("sample", (2, 256, 768, 16, 24)),
     # ... whole small planes in two pixel tiles: 7x7 (49 pixels: the last one has a load of its own) and 8x8, K/32 = 16 and 32
     ("sample", (5, 512, 1024, 7, 7)), ("sample", (3, 1024, 1024, 7, 7)), ("sample", (2, 512, 256, 8, 8)),
-    ("sample", (9, 1024, 512, 7, 7))]
+    ("sample", (9, 1024, 512, 7, 7)), ("sample", (3, 1024, 256, 14, 14))]
 
 
 @pytest.mark.parametrize("form,case", FORM_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in FORM_CASES])
@@ -574,7 +574,8 @@ def _pwconv_case(dev, ops, case, mode, form=None):
 
 
 PW_RES_CASES = [("split", (2, 256, 1024, 14, 14)), ("split", (3, 512, 2048, 7, 7)), ("stream", (2, 64, 256, 28, 28)),
-                ("split", (2, 144, 24, 14, 14)), ("split", (3, 384, 64, 7, 7)), (None, (2, 128, 512, 9, 11))]
+                ("split", (2, 144, 24, 14, 14)), ("split", (3, 384, 64, 7, 7)), (None, (2, 128, 512, 9, 11)),
+                ("sample", (3, 256, 1024, 14, 14)), ("sample", (2, 128, 512, 28, 28)), ("sample", (2, 512, 512, 14, 14))]
 
 
 @pytest.mark.parametrize("form,case", PW_RES_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in PW_RES_CASES])
