@@ -150,7 +150,9 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     c_bsh[i] = bn_scale != nullptr ? bn_shift[i] : 0.0f;
   }
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
+  PW_STAMP(0);
   __syncthreads();
+  PW_STAMP(1);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int h = lane >> 5, pl = lane & 31;
@@ -232,6 +234,8 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     for (int i = 0; i < CH; ++i) bbuf[0][i] = issue(xr, cur, i);
   }
   for (unsigned t = t_begin; t < t_end; ++t) {
+    if (t == t_begin + 1) PW_STAMP(2);
+    if (t == t_begin + (t_end - t_begin) / 2) PW_STAMP(3);
     const Pix nxt = pix_next(cur, t + 1 < g.total_tiles);
     const fq_rsrc xr = rsrc_of(cur), xn = rsrc_of(nxt);
     v16f acc[CT];
@@ -304,11 +308,13 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     }
     cur = nxt;
   }
+  PW_STAMP(4);
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < g.n_samples)
       atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
   }
+  PW_STAMP(5);
 }
 
 }  // namespace
