@@ -1233,9 +1233,12 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
                     (stride == 1 || ((wdt / 2) % 2 == 0));
   // 14x14 (stride 1 and 2) and 7x7 planes: flat 16-byte accesses through an LDS transpose (K2p)
   // tuning: bit 0 14x14 s1, bit 1 14x14 s2, bit 2 7x7, bit 3 28x28 s1
-  // (28x28: 40.1 -> 34.6 us stride 1.  Stride 2 on 28x28 - bit 4 - is NOT taken: its tiles need 69.7 KB of static LDS, and
-  // beyond 64 KB per workgroup the results were not reproducible from run to run (tests/test_gpu_configs.py caught it at full
-  // size; the 64-plane parity case passed); it stays with the four-columns-per-lane form.)
+  // (28x28: 40.1 -> 34.6 us stride 1.  Stride 2 on 28x28 - bit 4 - is NOT built: at full size its results were not reproducible
+  // from run to run as soon as two workgroups shared a CU (zeros in the first element of some 16-byte output groups of the
+  // first two planes of a wavefront; one workgroup per CU: exact).  Neither the 69.7 KB of static LDS of its separate output
+  // tile (a variant writing the outputs over consumed input rows, 53 KB, failed the same way) nor anything else found explains
+  // it; tests/test_gpu_configs.py caught it, tools/dw_determinism.py checks the shapes that ARE taken, six runs each, against
+  // the column-walking forms.  It stays with the four-columns-per-lane form.)
   static const int flat_on = env_int("FQ_DW_FLAT", 15) & 15;
   {
     const int kind = (h == 14 && wdt == 14) ? (stride == 1 ? 0 : 1)

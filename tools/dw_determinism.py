@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Run-to-run determinism and agreement of the depthwise forms at full MobileNet sizes: every shape is computed REPS times by
+the form the shape-based choice takes and compared bit for bit with the first run and with the column-walking forms
+(FQ_DW_FLAT=0 FQ_DW_PLANES=0 in a child process)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SHAPES = [(128, 256, 28, 1), (128, 256, 28, 2), (128, 512, 14, 1), (128, 512, 14, 2), (128, 1024, 7, 1), (96, 576, 14, 1),
+          (128, 960, 7, 1), (128, 384, 14, 2)]
+REPS = 6
+
+
+def main():
+    import numpy as np
+    import torch
+    from quantization.mxnet_amd import ops
+    child = os.environ.get("FQ_DW_DET_CHILD") == "1"
+    dev = torch.device("cuda", 0)
+    bad = 0
+    for n, c, hw, s in SHAPES:
+        torch.manual_seed(n + c + hw + s)
+        x = torch.relu(torch.randn(n, c, hw, hw, device=dev))
+        w = torch.randn(c, 1, 3, 3, device=dev) * 0.3
+        sc = torch.rand(c, device=dev) + 0.5
+        sh = torch.randn(c, device=dev)
+        stat = ops.absmax_per_sample(x)
+
+        def run():
+            cur = torch.empty(1, device=dev)
+            y, st = ops.dwconv3x3(x, w, None, stride=s, in_stat=stat, width=8, flags=0, cur_out=cur, bn_scale=sc, bn_shift=sh,
+                                  act="relu")
+            return y, st
+        y0, st0 = run()
+        path = "/tmp/dwdet_%d_%d_%d_%d.npy" % (n, c, hw, s)
+        if child:
+            np.save(path, y0.cpu().numpy())
+            continue
+        diffs = []
+        for _ in range(REPS - 1):
+            y, st = run()
+            diffs.append(int((y != y0).sum().item()) + int((st != st0).sum().item()))
+        ref = np.load(path)
+        vs = int((ref != y0.cpu().numpy()).sum())
+        print("%4d x %4d @%2dx%-2d stride %d: repeats differ %s, against the column-walking forms %d" % (n, c, hw, hw, s, diffs, vs))
+        bad += sum(diffs) + vs
+    if not child:
+        print("OK" if bad == 0 else "MISMATCH")
+        sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    if os.environ.get("FQ_DW_DET_CHILD") != "1":
+        env = dict(os.environ, FQ_DW_DET_CHILD="1", FQ_DW_FLAT="0", FQ_DW_PLANES="0")
+        subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, check=True)
+    main()
