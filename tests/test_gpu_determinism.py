@@ -1,0 +1,17 @@
+"""Run-to-run determinism of the forms that move data through wavefront-private LDS tiles (depthwise flat form, pointwise sample
+form) at FULL size: a 28x28 stride-2 variant of the flat form passed every small parity case and still changed 3000-7000 of
+6.4 M outputs from run to run once two workgroups shared a CU (profiles/r2_dw_planes.txt) - only full-size repeats show that."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tool", ["dw_determinism.py", "pw_determinism.py"])
+def test_full_size_repeats_are_bit_identical(tool):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
