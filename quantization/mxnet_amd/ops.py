@@ -488,7 +488,9 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
               bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None):
     """1x1 convolution on the integer codes (int8 MFMA, exact int32 accumulation) with quantise-on-load and fused
     BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; stride 1 or 2 (no padding); `residual` (the
-    output's shape) is added after BatchNorm and before the activation.  Returns (y, stat or None)."""
+    output's shape) is added after BatchNorm and before the activation.  `form` names one of PW_FORMS ("stream", "sample",
+    "split", "two_kernels") instead of the library's shape-based choice - for parity tests and tuning; a shape the named form
+    does not take raises.  Returns (y, stat or None)."""
     _check(x, "x")
     _check(wcodes, "wcodes", torch.int8)
     _check(wscale, "wscale")
