@@ -235,6 +235,54 @@ __device__ __forceinline__ void buf_st_f32(fq_rsrc r, unsigned voff, unsigned so
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 
+// Wavefront-wide reductions of the batch-mean prologue without the LDS pipeline: four DPP steps inside the rows of 16 lanes
+// (quad swaps, half-row and row mirrors: after each step every lane of the group holds the group's result), then the four row
+// results through scalar registers.  The six __shfl_xor rounds they replace are six ds_bpermute round trips plus lane
+// arithmetic in the dependency chain of EVERY consumer kernel's first code.  The sum is only used where every order of the
+// additions is exact (batch_mean_dev), so the changed order changes nothing.
+#define FQ_DPP_I32(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xF, 0xF, false)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#define FQ_WSUM_STEP(ctrl)                                                                   \
+  do {                                                                                       \
+    const long long b = __builtin_bit_cast(long long, v);                                    \
+    const int lo = FQ_DPP_I32((int)(b & 0xFFFFFFFFll), ctrl), hi = FQ_DPP_I32((int)(b >> 32), ctrl); \
+    v += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);                   \
+  } while (0)
+  FQ_WSUM_STEP(0xB1);       // quad_perm [1,0,3,2]
+  FQ_WSUM_STEP(0x4E);       // quad_perm [2,3,0,1]
+  FQ_WSUM_STEP(0x141);      // row_half_mirror
+  FQ_WSUM_STEP(0x140);      // row_mirror
+#undef FQ_WSUM_STEP
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = (int)(b & 0xFFFFFFFFll), hi = (int)(b >> 32);
+  double r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    r[k] = __builtin_bit_cast(double, ((long long)__builtin_amdgcn_readlane(hi, 16 * k) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane(lo, 16 * k));
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  int b = (int)v;                                         // (values are exponent fields: small and non-negative)
+#define FQ_WMIN_STEP(ctrl) do { const int o = FQ_DPP_I32(b, ctrl); b = o < b ? o : b; } while (0)
+  FQ_WMIN_STEP(0xB1); FQ_WMIN_STEP(0x4E); FQ_WMIN_STEP(0x141); FQ_WMIN_STEP(0x140);
+#undef FQ_WMIN_STEP
+  const int r0 = __builtin_amdgcn_readlane(b, 0), r1 = __builtin_amdgcn_readlane(b, 16), r2 = __builtin_amdgcn_readlane(b, 32),
+            r3 = __builtin_amdgcn_readlane(b, 48);
+  const int m01 = r0 < r1 ? r0 : r1, m23 = r2 < r3 ? r2 : r3;
+  return (unsigned)(m01 < m23 ? m01 : m23);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  int b = (int)v;
+#define FQ_WMAX_STEP(ctrl) do { const int o = FQ_DPP_I32(b, ctrl); b = o > b ? o : b; } while (0)
+  FQ_WMAX_STEP(0xB1); FQ_WMAX_STEP(0x4E); FQ_WMAX_STEP(0x141); FQ_WMAX_STEP(0x140);
+#undef FQ_WMAX_STEP
+  const int r0 = __builtin_amdgcn_readlane(b, 0), r1 = __builtin_amdgcn_readlane(b, 16), r2 = __builtin_amdgcn_readlane(b, 32),
+            r3 = __builtin_amdgcn_readlane(b, 48);
+  const int m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+  return (unsigned)(m01 > m23 ? m01 : m23);
+}
+
 // Deterministic batch mean: fp64 accumulate in sample order, one rounding to fp32, fp32 divide (oracle: batch_mean).
 __device__ __forceinline__ float batch_mean_seq(const float* __restrict__ v, int n) {
   double acc = 0.0;
@@ -263,13 +311,9 @@ __device__ __forceinline__ float batch_mean_dev(const float* __restrict__ v, int
       emax = e > emax ? e : emax;
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    acc += __shfl_xor(acc, off, 64);
-    const unsigned a = (unsigned)__shfl_xor((int)emin, off, 64), b = (unsigned)__shfl_xor((int)emax, off, 64);
-    emin = a < emin ? a : emin;
-    emax = b > emax ? b : emax;
-  }
+  acc = wave_sum_f64(acc);
+  emin = wave_min_u32(emin);
+  emax = wave_max_u32(emax);
   const int logn = 32 - __clz(n > 1 ? n - 1 : 1);
   const bool exact = emax == 0u || (emax < 255u && (int)(emax - emin) + 24 + logn <= 53);
   if (!exact) return batch_mean_seq(v, n);
@@ -331,13 +375,9 @@ __device__ __forceinline__ float batch_mean_from(const ThresholdReq& r, const fl
       emax = e > emax ? e : emax;
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    acc += __shfl_xor(acc, off, 64);
-    const unsigned a = (unsigned)__shfl_xor((int)emin, off, 64), b = (unsigned)__shfl_xor((int)emax, off, 64);
-    emin = a < emin ? a : emin;
-    emax = b > emax ? b : emax;
-  }
+  acc = wave_sum_f64(acc);
+  emin = wave_min_u32(emin);
+  emax = wave_max_u32(emax);
   const int logn = 32 - __clz(n > 1 ? n - 1 : 1);
   const bool exact = emax == 0u || (emax < 255u && (int)(emax - emin) + 24 + logn <= 53);
   if (!exact) return batch_mean_seq(v, n);
