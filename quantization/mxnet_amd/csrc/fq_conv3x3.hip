@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
       if (has_stat) {
         const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)smp[t]);
         if (__all(smp[t] == s0)) {
-          const float wm = wave_max(m);
+          const float wm = wave_max_nonneg(m);
           if (lane == 0) {
             const unsigned slot = s0 - s_base;
             if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
       const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane(sample);
       const bool wave_uniform = __all(!is_out || (unsigned)sample == s0);
       if (wave_uniform) {
-        const float wm = wave_max(is_out ? m : 0.0f);
+        const float wm = wave_max_nonneg(is_out ? m : 0.0f);
         if (lane == 0 && __float_as_uint(wm) != 0u) {
           const unsigned slot = s0 - s_base;
           if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_planes_kernel(
       const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sample);
       const bool wave_uniform = __all(!is_out || sample == s0);
       if (wave_uniform) {
-        const float wm = wave_max(m);
+        const float wm = wave_max_nonneg(m);
         if (lane == 0 && __float_as_uint(wm) != 0u) {
           const unsigned slot = s0 - s_base;
           if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));
@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
       const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane(sample);
       const bool wave_uniform = __all(!is_out || (unsigned)sample == s0);
       if (wave_uniform) {
-        const float wm = wave_max(is_out ? m : 0.0f);
+        const float wm = wave_max_nonneg(is_out ? m : 0.0f);
         if (lane == 0 && __float_as_uint(wm) != 0u) {
           const unsigned slot = s0 - s_base;
           if (slot < (unsigned)kStatSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));

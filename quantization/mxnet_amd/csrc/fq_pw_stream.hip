@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
       const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)px.smp);
       const bool uniform = __all(!px.valid || px.smp == s0);
       if (uniform) {
-        const float wm = wave_max(px.valid ? m : 0.0f);
+        const float wm = wave_max_nonneg(px.valid ? m : 0.0f);
         if (lane == 0) {
           const unsigned slot = s0 - s_base;
           if (slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(wm));

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void gap_stat_lds_kernel(const float* __res
   if (stat_out != nullptr) {
     const int64_t s0 = p0 / c, s1 = (p0 + np - 1) / c;
     if (s0 == s1) {
-      const float m = wave_max(lane < np ? fabsf(v) : 0.0f);
+      const float m = wave_max_nonneg(lane < np ? fabsf(v) : 0.0f);
       if (lane == 0) atomic_max_f32(stat_out + s0, m);
     } else if (lane < np) {
       atomic_max_f32(stat_out + (p0 + lane) / c, fabsf(v));

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void weight_rows_lds_kernel(const float* __
     const float* row = tile + r * row_len;
     float m = 0.0f;
     for (int i = lane; i < row_len; i += 64) m = fmaxf(m, fabsf(row[i]));
-    m = wave_max(m);
+    m = wave_max_nonneg(m);
     if (lane == 0) {
       const float s = m / levels;
       sc[r] = s;
