@@ -213,9 +213,15 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
       constexpr bool MASKED = decltype(masked_c)::value;
       const int cb = (ctl0 + c) * 32 + 4 * h;                           // channel inside the workgroup's group
       float res[16];
-      if (has_res) {                             // all 16 in flight before the first use (channels past Cout read 0)
+      if (has_res) {                             // all 16 in flight before the first use
+        // channels past Cout of a PARTIAL tile get the same out-of-range offset as their stores and so read 0: the
+        // resource runs to the end of the tensor, an unmasked load would fetch the NEXT sample's channels 0.. and, with
+        // all-zero constants, carry that foreign value into the statistic `m` below
 #pragma unroll
-        for (int i = 0; i < 16; ++i) res[i] = buf_ld_f32(rr, yo, (unsigned)(c * 32 + 8 * (i >> 2) + (i & 3)) * plane4);
+        for (int i = 0; i < 16; ++i) {
+          const unsigned off = MASKED ? (8 * (i >> 2) + 4 * h + (i & 3) < cv ? yo : 0x80000000u) : yo;
+          res[i] = buf_ld_f32(rr, off, (unsigned)(c * 32 + 8 * (i >> 2) + (i & 3)) * plane4);
+        }
       }
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {

@@ -23,6 +23,10 @@ everything here is additive.  The path shards over independent images; the excha
 
 Transport: `torch.distributed` — backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.  All messages
 are latency-bound (<= 434 KB), so they go on the compute stream with RCCL's defaults; no bucketing is needed.
+
+Test knobs (the pool's GPU boxes have ONE device and RCCL refuses two ranks on it): FQ_DIST_BACKEND=gloo selects gloo
+although a GPU is present — device tensors are then staged through the host around each collective — and
+FQ_DIST_SHARE_GPU=1 puts every rank on device 0, so that the N > 1 flows run through the real kernels on such a box.
 """
 import os
 
@@ -54,9 +58,11 @@ def init(backend=None):
     if world <= 1:
         return 0, int(os.environ.get("LOCAL_RANK", "0")), 1
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FQ_DIST_SHARE_GPU", "0") == "1":
+        local = 0
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("FQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -71,6 +77,42 @@ def shutdown():
         dist.destroy_process_group()
 
 
+# ---- transport ---------------------------------------------------------------------------------------------------------
+def _via_host(t):
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce(t, op=None):
+    op = dist.ReduceOp.SUM if op is None else op
+    if _via_host(t):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def broadcast(t, src=0):
+    if _via_host(t):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def all_gather_into(gathered, piece):
+    if _via_host(piece):
+        h = torch.empty(gathered.shape, dtype=gathered.dtype)
+        dist.all_gather_into_tensor(h, piece.detach().cpu())
+        gathered.copy_(h)
+    else:
+        dist.all_gather_into_tensor(gathered, piece)
+    return gathered
+
+
 def calibration_steps(total_batches):
     """Steps every rank must take so that all of them issue the same collectives: ceil(total / world)."""
     w = world_size()
@@ -83,93 +125,159 @@ def shard_loader_kwargs():
 
 
 # ---- naive-EMA calibration ------------------------------------------------------------------------------------------
+def _calibrated_blocks(net):
+    """Blocks that own a calibration scalar, in net order: convolutions / Dense (`input_max`) and quantised Activations
+    (`act_max`) — both kinds of slot live in the net's arena and both must end a step identical on every rank."""
+    return [b for b in net.collect_quantized_blocks()
+            if getattr(b, "input_max", None) is not None or getattr(b, "act_max", None) is not None]
+
+
+class _CalibrationSync(object):
+    """What both modes share: the blocks, the (L x max_local_batch) statistic matrix whose row l receives layer l's
+    per-sample maxima, and the step's local sample count — taken from the INPUT BATCH by a forward pre-hook on the net
+    (not from whatever some block saw last), 0 when this rank ran no forward in the step."""
+
+    def __init__(self, net, blocks, stats, device):
+        self.blocks, self.stats, self.device = blocks, stats, device
+        self.n_step = 0
+        self._handle = net.register_forward_pre_hook(self._note_batch)
+
+    def _note_batch(self, _net, inputs):
+        self.n_step = int(inputs[0].shape[0])
+        if self.n_step > self.stats.shape[1]:
+            raise ValueError("calibration batch of %d samples but attach_calibration_sync was given max_local_batch=%d"
+                             % (self.n_step, self.stats.shape[1]))
+
+    def take_step_count(self):
+        n, self.n_step = self.n_step, 0
+        for b in self.blocks:                      # a block that ran this step saw the same batch as the net
+            seen = getattr(b, "_fq_last_n", None)
+            if n and seen not in (None, 0, n):
+                raise RuntimeError("%s saw %d samples in a step whose input batch has %d: the calibration collective "
+                                   "assumes one batch size per step" % (b.name, seen, n))
+            b._fq_last_n = 0
+        return n
+
+    def detach(self):
+        self._handle.detach()
+
+
+class _LayerCollective(_CalibrationSync):
+    """STRICT mode: one all-gather per quantised layer per forward, between its statistic pass and its apply pass."""
+
+    def __init__(self, net, blocks, stats, device):
+        super(_LayerCollective, self).__init__(net, blocks, stats, device)
+        W = world_size()
+        self.pack = torch.zeros(1 + stats.shape[1], dtype=torch.float32, device=device)
+        self.gathered = torch.zeros(W * self.pack.numel(), dtype=torch.float32, device=device)
+        self.order = []                  # id of every block whose exchange ran in the current forward, in call order
+        self.last_order = None
+        by_id = {id(b): b for b in blocks}
+        self.by_id = by_id
+        live = dist.is_available() and dist.is_initialized()
+        for b in blocks:
+            b._fq_global_stat = self._hook_for(b) if live else None
+            b._fq_keep_rows = False
+
+    def _hook_for(self, block):
+        def _hook(per_sample, n_local, out):
+            self.order.append(id(block))
+            return _global_mean(per_sample, int(n_local), self.pack, self.gathered, out)
+        return _hook
+
+    def _note_batch(self, _net, inputs):
+        super(_LayerCollective, self)._note_batch(_net, inputs)
+        self.order = []
+
+    def __call__(self, net, arena):
+        """From `net.update_ema()`.  A rank that ran a forward already holds the global statistic in every slot.  A rank
+        WITHOUT a batch in this step issues the same all-gathers now, in the order the forward issues them (the order
+        its own last forward recorded; the net's block order before any forward) with an empty record each — so every
+        rank takes part in the same 27-53 collectives and ends the step with the same `current_*` values."""
+        n = self.take_step_count()
+        if n:
+            self.last_order = list(self.order)
+            return
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        slot = {}
+        for j, (blk, _pattr, _cattr, _pub) in enumerate(arena.slots):
+            slot[id(blk)] = arena.cur[j:j + 1]
+        order = self.last_order if self.last_order else [id(b) for b in self.blocks]
+        for bid in order:
+            _global_mean(None, 0, self.pack, self.gathered, slot[bid])
+
+
+class _StepCollective(_CalibrationSync):
+    """The default mode: ONE all-reduce per calibration step, issued from `net.update_ema()`."""
+
+    def __init__(self, net, blocks, stats, device):
+        super(_StepCollective, self).__init__(net, blocks, stats, device)
+        self.record = torch.zeros(len(blocks) + 1, dtype=torch.float64, device=device)
+        self.means = torch.zeros(len(blocks), dtype=torch.float32, device=device)
+        self.slot_index = None
+        for b in blocks:
+            b._fq_global_stat = None
+            b._fq_keep_rows = True           # the converter leaves each layer's per-sample maxima in its row of `stats`
+
+    def _slots(self, arena):
+        if self.slot_index is None or self.slot_index.numel() != len(self.blocks):
+            where = {id(blk): j for j, (blk, _pattr, _cattr, _pub) in enumerate(arena.slots)}
+            self.slot_index = torch.tensor([where[id(b)] for b in self.blocks], dtype=torch.long,
+                                           device=self.means.device)
+        return self.slot_index
+
+    def __call__(self, net, arena):
+        n_local = self.take_step_count()
+        ops.stat_rows_sum(self.stats, n_local, out=self.record)
+        if dist.is_available() and dist.is_initialized():      # (also with one rank: the collective is still issued)
+            all_reduce(self.record)
+        ops.mean_from_sums(self.record, out=self.means)
+        arena.cur.index_copy_(0, self._slots(arena), self.means)
+
+
 def _global_mean(per_sample, n_local, pack, gathered, out):
     """All-gather one layer's per-sample maxima (+ the local count) and form the GLOBAL batch mean in global sample
     order (rank-major) with the same ordered fp64 mean as the single-device kernel.  One collective, no host sync:
     the (possibly ragged) per-rank counts travel inside the records and are consumed on the device."""
     pack.zero_()
     pack[0] = float(n_local)
-    pack[1:1 + n_local].copy_(per_sample[:n_local])
-    dist.all_gather_into_tensor(gathered, pack)
+    if n_local:
+        pack[1:1 + n_local].copy_(per_sample[:n_local])
+    all_gather_into(gathered, pack)
     ops.batch_mean_gathered(gathered.view(world_size(), -1), out=out)
     return out
-
-
-def _strict_attach(net, blocks, stats, device, max_local_batch):
-    """Per-layer exchange between the statistic pass and the apply pass (see the module docstring)."""
-    W = world_size()
-    pack = torch.zeros(1 + int(max_local_batch), dtype=torch.float32, device=device)
-    gathered = torch.zeros(W * pack.numel(), dtype=torch.float32, device=device)
-
-    def _hook(per_sample, n_local, out):
-        return _global_mean(per_sample, int(n_local), pack, gathered, out)
-
-    for b in blocks:
-        b._fq_global_stat = _hook if (dist.is_available() and dist.is_initialized()) else None
-        b._fq_keep_rows = False
-    net._fq_calibration_sync = None          # current_input_max already is the global statistic when update_ema runs
-
-
-class _StepCollective(object):
-    """The default mode: ONE all-reduce per calibration step, issued from `net.update_ema()`."""
-
-    def __init__(self, net, blocks, stats, device):
-        self.blocks, self.stats = blocks, stats
-        self.record = torch.zeros(len(blocks) + 1, dtype=torch.float64, device=device)
-        self.means = torch.zeros(len(blocks), dtype=torch.float32, device=device)
-        self.slot_index = None
-        self.skip = False                    # set by empty_calibration_step: this rank saw no batch in this step
-
-    def _slots(self, arena):
-        if self.slot_index is None or self.slot_index.numel() != len(self.blocks):
-            where = {}
-            for j, (blk, pattr, _, _) in enumerate(arena.slots):
-                if pattr == "input_max":
-                    where[id(blk)] = j
-            self.slot_index = torch.tensor([where[id(b)] for b in self.blocks], dtype=torch.long,
-                                           device=self.means.device)
-        return self.slot_index
-
-    def __call__(self, net, arena):
-        n_local = 0 if self.skip else int(self.blocks[0]._fq_last_n)
-        self.skip = False
-        ops.stat_rows_sum(self.stats, n_local, out=self.record)
-        if dist.is_available() and dist.is_initialized():      # (also with one rank: the collective is still issued)
-            dist.all_reduce(self.record, op=dist.ReduceOp.SUM)
-        ops.mean_from_sums(self.record, out=self.means)
-        arena.cur.index_copy_(0, self._slots(arena), self.means)
 
 
 def attach_calibration_sync(net, max_local_batch, strict=False):
     """Make every rank end each calibration step with the statistics of the GLOBAL batch (module docstring: default =
     one all-reduce per step; strict = per-layer all-gather, bit-identical to one device that sees the global batch)."""
-    blocks = [b for b in net.collect_quantized_blocks() if getattr(b, "input_max", None) is not None]
-    device = blocks[0].input_max.data()._t.device
+    detach_calibration_sync(net)
+    blocks = _calibrated_blocks(net)
+    first = blocks[0]
+    device = (first.input_max if getattr(first, "input_max", None) is not None else first.act_max).data()._t.device
     stats = torch.zeros(len(blocks), int(max_local_batch), dtype=torch.float32, device=device)
     for i, b in enumerate(blocks):
         b._fq_stat_ws = stats[i]
         b._fq_last_n = 0
     net._fq_stat_matrix = stats
-    if strict:
-        _strict_attach(net, blocks, stats, device, max_local_batch)
-    else:
-        for b in blocks:
-            b._fq_global_stat = None
-            b._fq_keep_rows = True           # the converter leaves each layer's per-sample maxima in its row of `stats`
-        net._fq_calibration_sync = _StepCollective(net, blocks, stats, device)
+    net._fq_calibration_sync = (_LayerCollective if strict else _StepCollective)(net, blocks, stats, device)
     return net
 
 
 def empty_calibration_step(net, momentum=0.9):
-    """A rank whose shard has no batch in this step still takes part in the step's collective (an empty record) and
-    applies the same EMA update as the others."""
+    """A rank whose shard has no batch in this step still takes part in the step's collective(s) — an empty record per
+    collective, in both modes — and applies the same EMA update as the others."""
     sync = getattr(net, "_fq_calibration_sync", None)
-    if isinstance(sync, _StepCollective):
-        sync.skip = True
+    if sync is not None:
+        sync.n_step = 0
     net.update_ema(momentum)
 
 
 def detach_calibration_sync(net):
+    sync = getattr(net, "_fq_calibration_sync", None)
+    if sync is not None:
+        sync.detach()
     for b in net.collect_quantized_blocks():
         b._fq_global_stat = None
         b._fq_keep_rows = False
@@ -184,9 +292,9 @@ def kl_sync(stage, tensor):
     if not is_distributed():
         return
     if stage == "range":
-        dist.broadcast(tensor, src=0)
+        broadcast(tensor, src=0)
     elif stage == "hist":
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+        all_reduce(tensor)
     else:
         raise ValueError(stage)
 
@@ -195,5 +303,5 @@ def kl_sync(stage, tensor):
 def allreduce_eval_counters(counters):
     """[test_num_correct, total, correct_counter[classes], label_counter[classes]] summed over ranks."""
     if is_distributed():
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+        all_reduce(counters)
     return counters

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check_call, FakeQuantError
+from ._lib import FakeQuantError
 
 __all__ = ["add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
@@ -24,15 +24,31 @@ def _lib_():
     return _lib.LIB
 
 
+_DEVICE_TLS = threading.local()
+
+
 def _stream(t):
     """HIP stream handle for a launch on `t`'s device.  The library launches on whatever device is CURRENT for the
     calling thread (kernels, memsets and the cached compute-unit count follow it), so the tensor's device is made current
-    here — every entry point evaluates `_stream(x)` as an argument of its C call, i.e. before the call happens.  A process
-    that only ever uses one GPU (the normal case: one process per GPU) never takes the branch."""
+    here — every entry point evaluates `_stream(x)` as an argument of its C call, i.e. before the call happens — and
+    `check_call`, which every entry point wraps around that call, puts the caller's device back.  A process that only
+    ever uses one GPU (the normal case: one process per GPU) never takes the branch."""
     dev = t.device
-    if dev.index is not None and dev.index != torch.cuda.current_device():
+    now = torch.cuda.current_device()
+    if dev.index is not None and dev.index != now:
+        if getattr(_DEVICE_TLS, "restore", None) is None:
+            _DEVICE_TLS.restore = now
         torch.cuda.set_device(dev)
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def check_call(ret):
+    """Status check of _lib.check_call + the device switch of `_stream` undone (the launch is already enqueued)."""
+    prev = getattr(_DEVICE_TLS, "restore", None)
+    if prev is not None:
+        _DEVICE_TLS.restore = None
+        torch.cuda.set_device(prev)
+    _lib.check_call(ret)
 
 
 def _ptr(t):
@@ -473,6 +489,16 @@ def weight_codes(w, rows_per_scale, width=8):
     return codes, scales, rowsum
 
 
+def weight_codes_reproduce(w, codes, scales):
+    """True when code * scale gives back `w` bit for bit (w: the (rows, ...) fp32 weight the codes were derived from).
+    Used after re-deriving codes from already fake-quantised (frozen) weights: fl(fl(127 s) / 127) need not equal s, and
+    the convolution must multiply what the reference would — the frozen weights themselves.  Synchronises; rare path."""
+    rows = w.shape[0]
+    w2 = w.reshape(rows, -1)
+    back = codes[:rows, :w2.shape[1]].to(torch.float32) * scales.reshape(rows, 1)
+    return bool(torch.equal(back, w2))
+
+
 PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6, "sample": 7}
 
 
@@ -502,6 +528,9 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     n, cin = x.shape[0], x.shape[1]
     cout = wscale.numel()
     cin_pad = wcodes.shape[1]
+    if (cin + 63) // 64 * 64 != cin_pad:
+        raise ValueError("x has %d channels but the weight codes were made for a row length that pads to %d"
+                         % (cin, cin_pad))
     if in_stat is not None and cur_out is None:
         cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
     stat, zflag = _stat_target(n, x.device, want_stat)

@@ -158,6 +158,7 @@ class NetControls(object):
             if isinstance(blk, nn.Conv2D):
                 blk.fixed_params = 0
                 blk.__dict__.pop("_fq_pw_cache", None)      # integer codes of the previous freeze
+                blk.__dict__.pop("_fq_no_int8", None)       # ... and its verdict on re-derived codes
 
 
 def convert_model(net, exclude=[], convert_fn=default_convert_fn, custom_fn={}):

@@ -47,16 +47,38 @@ def _quantised_activation(self, F, x, act_max=None):
     if not (self.enable_quantize and args.quantize_act):
         return out
     t = contiguous(out._t)
+    n = t.shape[0]
     cur = _scalar_slot(self, t)
     flags = ops.act_flags(**_OUTPUT_FLAGS)
-    if not self.quantize_act:                                  # statistic only (the reference still computes it, :50)
-        ops.batch_mean(ops.absmax_per_sample(t, no_abs=True), out=cur)
-    else:
-        if self.quantize_act_offline:
-            y = ops.fake_quant_offline(t, act_max._t, args.width, flags, cur_out=cur)[0]
+    # batch sharded over ranks (dist.py): the per-sample maxima land in this block's row of the net's statistic matrix;
+    # strict mode exchanges them before the apply pass, the default mode reads the rows back at `update_ema`
+    rows = getattr(self, "_fq_stat_ws", None)
+    if rows is not None and (rows.device != t.device or rows.numel() < n):
+        rows = None
+    exchange = getattr(self, "_fq_global_stat", None) if rows is not None else None
+    y = None
+    if exchange is not None or (rows is not None and getattr(self, "_fq_keep_rows", False)):
+        stat = ops.absmax_per_sample(t, no_abs=True, out=rows[:n])
+        if exchange is not None:
+            exchange(stat, n, cur)
+            if self.quantize_act:
+                y = ops.fake_quant_offline(t, act_max._t if self.quantize_act_offline else cur, args.width, flags,
+                                           want_stat=False)[0]
+        elif self.quantize_act and not self.quantize_act_offline:
+            y = ops.fake_quant_online_prestat(t, stat, args.width, flags, cur_out=cur)[0]
         else:
-            y = ops.fake_quant_online(t, args.width, flags, cur_out=cur)[0]
+            ops.batch_mean(stat, out=cur)
+            if self.quantize_act:
+                y = ops.fake_quant_offline(t, act_max._t, args.width, flags, want_stat=False)[0]
+    elif not self.quantize_act:                                # statistic only (the reference still computes it, :50)
+        ops.batch_mean(ops.absmax_per_sample(t, no_abs=True), out=cur)
+    elif self.quantize_act_offline:
+        y = ops.fake_quant_offline(t, act_max._t, args.width, flags, cur_out=cur)[0]
+    else:
+        y = ops.fake_quant_online(t, args.width, flags, cur_out=cur)[0]
+    if y is not None:
         out = NDArray(autograd.ste_link(t, y))                 # identity backward; a no-op unless recording
+    self._fq_last_n = n
     self.current_act_max = DeviceScalar(cur)
     return out
 

@@ -166,17 +166,29 @@ def _weight_rows_per_scale(block, args):
 
 
 def _pointwise_weight_codes(block, args, weight_raw, weight_q):
-    """int8 codes / scales / row sums of the weights THIS forward uses: the raw weights while they are (re-)quantised every
-    forward or being frozen right now, the frozen (already fake-quantised) ones afterwards.  Frozen codes are kept until
-    the parameter's storage or in-place version changes (set_data / load_parameters / a second fix_params)."""
+    """int8 codes / scales / row sums of the weights THIS forward uses, or None when the integer path must not be taken.
+    While the weights are (re-)quantised every forward, or being frozen right now, they come from the raw weights — the
+    same division the fake-quant performs.  Frozen codes are kept until the parameter's storage or in-place version
+    changes (set_data / load_parameters / reset_ctx / a second fix_params).  After such a change the block is still frozen
+    and its parameter already holds fake-quantised values (the reference convolves with them as they are,
+    convert_conv2d.py:96-97): codes re-derived from them are accepted only if code * scale reproduces the parameter bit for
+    bit; otherwise the block leaves the integer path (library convolution of the frozen weights)."""
     param_t = block.weight.data()._t
     key = (param_t.data_ptr(), param_t._version)
     held = getattr(block, "_fq_pw_cache", None)
     if block.fixed_params == 1 and held is not None and held[3] == key:
         return held[:3]
-    src = weight_raw if block.fixed_params != 1 or held is None else weight_q
-    make = ops.weight_codes_3x3 if block._fq_pw_fused.get("kind") == "3x3" else ops.weight_codes
-    codes = make(contiguous(src._t), _weight_rows_per_scale(block, args), args.wt_width)
+    three = block._fq_pw_fused.get("kind") == "3x3"
+    make = ops.weight_codes_3x3 if three else ops.weight_codes
+    rederived = block.fixed_params == 1 and held is not None
+    src = contiguous((weight_q if rederived else weight_raw)._t)
+    codes = make(src, _weight_rows_per_scale(block, args), args.wt_width)
+    if rederived:
+        ref = src.permute(0, 2, 3, 1).contiguous() if three else src
+        if not ops.weight_codes_reproduce(ref, codes[0], codes[1]):
+            block._fq_no_int8 = True
+            block.__dict__.pop("_fq_pw_cache", None)
+            return None
     if block.fixed_params == 1:
         block._fq_pw_cache = tuple(codes) + (key,)
     return codes
@@ -191,8 +203,10 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
     scale, shift = fz["constants"]() if fz["bn"] is not None else (None, None)
     on_codes = bool(plan) and weights_quantised and args.in_width <= 8 and args.wt_width <= 8 \
         and not getattr(block, "_fq_no_int8", False)
+    held = _pointwise_weight_codes(block, args, weight_raw, weight_q) if on_codes else None
+    on_codes = held is not None
     if on_codes:
-        codes, scales, rowsum = _pointwise_weight_codes(block, args, weight_raw, weight_q)
+        codes, scales, rowsum = held
         if fz.get("kind") == "3x3":
             y, stat = ops.conv3x3_i8(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
                                      bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)

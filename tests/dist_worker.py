@@ -2,7 +2,8 @@
 Runs the product's calibration host logic (both EMA collective modes, KL sync, eval counters) with the oracle standing in
 for the HIP entry points, and writes what each rank ended with to <out>/rank<r>.npz.
 
-    dist_worker.py <out_dir> <local_bs> <case>      case: strict | strict_ragged | step | step_ragged | step_short
+    dist_worker.py <out_dir> <local_bs> <case>      case: strict | strict_ragged | strict_short | strict_act | step | step_ragged | step_short | step_act
+(`*_act`: the net's Activations are converted too — their `act_max` slots take part in the same collectives)
 """
 import os
 import sys
@@ -22,15 +23,33 @@ from quantization.mxnet_amd.quantize import convert  # noqa: E402
 from quantization.mxnet_amd.quantize.initialize import qparams_init  # noqa: E402
 
 
-def make_net(seed=3):
+def make_net(seed=3, with_act=False):
     rng = np.random.default_rng(seed)
     shapes = {"tiny_conv0_weight": (8, 3, 3, 3), "tiny_conv1_weight": (8, 1, 3, 3), "tiny_conv1_bias": (8,),
               "tiny_conv2_weight": (12, 8, 1, 1), "tiny_dense0_weight": (5, 12), "tiny_dense0_bias": (5,)}
     params = {k: (rng.standard_normal(s) * 0.4).astype(np.float32) for k, s in shapes.items()}
     net = tiny_net(params)
-    convert.convert_model(net, exclude=[net[0]])
+    if with_act:
+        from quantization.mxnet_amd.mx.gluon import nn
+        fns = dict(convert.default_convert_fn)
+        fns[nn.Activation] = convert.gen_act_converter()
+        convert.convert_model(net, exclude=[net[0], net[1]], convert_fn=fns)
+    else:
+        convert.convert_model(net, exclude=[net[0]])
     qparams_init(net)
     return net
+
+
+def calibration_scalars(net):
+    """Every calibration scalar of the net in block order: input_max of conv / Dense blocks, act_max of Activations."""
+    out = []
+    for b in net.collect_quantized_blocks():
+        p = getattr(b, "input_max", None)
+        if p is None:
+            p = getattr(b, "act_max", None)
+        if p is not None:
+            out.append(p.data().asscalar())
+    return out
 
 
 def batches(n_batches, bs, seed=9):
@@ -46,14 +65,14 @@ def calib_steps(case, local_bs, world):
         if case.endswith("_ragged") and step == 3:
             g = g[:local_bs + 1]                           # last global batch: rank 0 full, rank 1 one sample
         shards = [g[r * local_bs:(r + 1) * local_bs] for r in range(world)]
-        if case == "step_short" and step == 3:
+        if case.endswith("_short") and step == 3:
             shards = [g[:local_bs]] + [None] * (world - 1)  # odd batch count: only rank 0 has a batch in the last step
         steps.append(shards)
     return steps
 
 
 def kl_batches(case, local_bs):
-    return batches(1 if case == "step_short" else (3 if case.endswith("_ragged") else 4), local_bs, seed=21)
+    return batches(1 if case.endswith("_short") else (3 if case.endswith("_ragged") else 4), local_bs, seed=21)
 
 
 def main():
@@ -61,10 +80,10 @@ def main():
     rank, _, world = fqdist.init("gloo")
     with oracle_ops():
         # ---- naive-EMA calibration on the rank's shard of each global batch -------------------------------------
-        net = make_net()
+        net = make_net(with_act=case.endswith("_act"))
         fqdist.attach_calibration_sync(net, local_bs, strict=case.startswith("strict"))
         net.quantize_input(enable=True, online=True)
-        blocks = net.collect_quantized_blocks()
+        blocks = [b for b in net.collect_quantized_blocks() if hasattr(b, "_fq_stat_ws")]
         ema, rows = [], []
         for shards in calib_steps(case, local_bs, world):
             mine = shards[rank]
@@ -75,7 +94,7 @@ def main():
                 net(mx.nd.array(mine))
                 rows.append(net._fq_stat_matrix[:, :len(mine)].numpy().copy())
                 net.update_ema()
-            ema.append([b.input_max.data().asscalar() for b in blocks])
+            ema.append(calibration_scalars(net))
         # ---- KL collection: batches strided over the ranks like the loader does -----------------------------------
         net2 = make_net()
         net2.disable_quantize()

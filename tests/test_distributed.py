@@ -38,15 +38,14 @@ def _single_process(local_bs, world, case):
     from quantization.mxnet_amd import mx
     from quantization.mxnet_amd.quantize.distribution_calibrate import collect_feature_maps
     with oracle_ops():
-        net = W.make_net()
+        net = W.make_net(with_act=case.endswith("_act"))
         net.quantize_input(enable=True, online=True)
-        blocks = net.collect_quantized_blocks()
         ema = []
         for shards in W.calib_steps(case, local_bs, world):
             glob = np.concatenate([s for s in shards if s is not None and len(s)])
             net(mx.nd.array(glob))
             net.update_ema()
-            ema.append([b.input_max.data().asscalar() for b in blocks])
+            ema.append(W.calibration_scalars(net))
         net2 = W.make_net()
         net2.disable_quantize()
         b2 = net2.collect_quantized_blocks()
@@ -71,7 +70,7 @@ def _run_two_ranks(tmp_path, local_bs, case):
     return r
 
 
-@pytest.mark.parametrize("case", ["strict", "strict_ragged"])
+@pytest.mark.parametrize("case", ["strict", "strict_ragged", "strict_short", "strict_act"])
 def test_strict_mode_equals_one_device_on_the_global_batch(tmp_path, case):
     local_bs, world = 3, 2
     r = _run_two_ranks(tmp_path, local_bs, case)
@@ -81,7 +80,7 @@ def test_strict_mode_equals_one_device_on_the_global_batch(tmp_path, case):
     np.testing.assert_array_equal(r[0]["hist"], hist)
 
 
-@pytest.mark.parametrize("case", ["step", "step_ragged", "step_short"])
+@pytest.mark.parametrize("case", ["step", "step_ragged", "step_short", "step_act"])
 def test_one_collective_per_step_gives_the_ema_of_the_global_batch_mean(tmp_path, case):
     local_bs, world = 3, 2
     r = _run_two_ranks(tmp_path, local_bs, case)

@@ -1,0 +1,135 @@
+"""The N > 1 paths through the REAL kernels on a one-GPU box: two ranks that share GPU 0 and talk over gloo (RCCL refuses
+two ranks on one device - profiles/r2_rccl_smoke.txt; FQ_*_BACKEND=gloo stages device tensors through the host around each
+collective, everything else is the production code).
+
+  * `bench.py --gpus 2` typed WITHOUT a launcher: the parent starts its own ranks before touching a GPU, passes rank 0's
+    JSON line through and exits with the children's status (what the driver's multi-GPU bench would type);
+  * the CLI's calibration flows (examples/simulate_quantization.py) - naive EMA in both collective modes and KL - on two
+    ranks: thresholds and accuracies equal ONE process bit for bit (strict mode: one device on the global batch; KL: one
+    device walking the same batches; default mode: the EMA of the global batch means recomputed from one process'
+    per-sample statistics), including a rank WITHOUT a batch in the last step."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_launches_its_own_ranks(gpu):
+    env = dict(os.environ, FQ_BENCH_SHARE_GPU="1", FQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--no-cpu-baseline", "--max-repeats", "4"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 2
+    assert rec["config"]["global_batch"] == 256
+    assert rec["scaling"] == "weak" and rec["unit"] == "images/sec" and rec["value"] > 0
+    assert rec["repeats"] == 4 and rec["consistency"]["blocks"] == 4
+    # counters summed over BOTH ranks in one all-reduce: every step either rank ran (warm-up + 4 blocks of 3) x 128 images
+    assert rec["eval_counters"]["images"] == 2 * 128 * (2 + 4 * 3)
+    assert abs(rec["value"] - 256 * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-3
+    assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec and "headline_tensor" not in rec
+
+
+def test_bench_refuses_more_ranks_than_devices(gpu):
+    import torch
+    want = torch.cuda.device_count() + 1
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("FQ_BENCH_SHARE_GPU", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "GPU(s)" in res.stderr
+
+
+def _two_ranks(tmp_path, flow):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FQ_DIST_BACKEND="gloo", FQ_DIST_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "gpu_cli_worker.py"), str(tmp_path), flow]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stderr[-4000:]
+    r = [np.load(os.path.join(tmp_path, "rank%d.npz" % i)) for i in range(2)]
+    assert int(r[0]["world"]) == 2 and int(r[0]["device"]) == int(r[1]["device"]) == 0
+    np.testing.assert_array_equal(r[0]["thr"], r[1]["thr"], "the two ranks ended calibration with different thresholds")
+    assert float(r[0]["acc"]) == float(r[1]["acc"]) and float(r[0]["avg"]) == float(r[1]["avg"])
+    return r[0]
+
+
+def test_cli_naive_calibration_strict_two_ranks_equals_one_device(gpu, tmp_path):
+    """--strict-global-batch: thresholds AND the offline evaluation equal one device that sees the global batches."""
+    import gpu_cli_worker as W
+    r = _two_ranks(tmp_path, "naive_strict")
+    cli = W.cli_module()
+    thr, acc, avg, _ = W.run_flow(cli, "naive_strict", gpu, 0, 1, W.global_batches("calib", 2), W.global_batches("eval", 2),
+                                  2 * W.LOCAL_BS)
+    assert np.all(thr > 0)
+    np.testing.assert_array_equal(r["thr"], thr)
+    assert float(r["acc"]) == acc and float(r["avg"]) == avg
+
+
+def test_cli_naive_calibration_one_collective_per_step_two_ranks(gpu, tmp_path):
+    """Default mode: every rank's forward runs on its local batch; the step's ONE all-reduce gives the batch mean of the
+    global batch.  Expected values: one process runs the same local batches, the per-sample statistics of every layer are
+    read back, and the ordered mean + the reference's EMA are formed on the host by the oracle."""
+    import torch
+    import gpu_cli_worker as W
+    from quantization.mxnet_amd import mx, dist as fqdist
+    r = _two_ranks(tmp_path, "naive_step")
+    cli = W.cli_module()
+    opt = W.options(cli, "naive_step")
+    sim = cli.Simulation(opt, gpu, 0, 1)
+    np.random.seed(opt.fixed_random_seed)
+    sim.build_net()
+    sim.quantise_net()
+    net = sim.net
+    fqdist.attach_calibration_sync(net, W.LOCAL_BS)                 # one process: rows are kept, no collective
+    net.quantize_input(enable=True, online=True)
+    loc = W.local_batches("calib")
+    layers = net._fq_stat_matrix.shape[0]
+    state = np.zeros(layers, np.float32)
+    for s in range(0, len(loc), 2):
+        rows = []
+        for x, _ in loc[s:s + 2]:                                   # rank 0's batch, then rank 1's
+            net(mx.nd.array(x, ctx=gpu))
+            torch.cuda.synchronize()
+            rows.append(net._fq_stat_matrix[:, :len(x)].cpu().numpy().copy())
+        cur = np.asarray([O.batch_mean(np.concatenate([q[l] for q in rows])) for l in range(layers)], np.float32)
+        state = O.ema_update(state, cur, 0.9)
+    fqdist.detach_calibration_sync(net)
+    np.testing.assert_array_equal(r["thr"], state)
+
+
+def test_cli_kl_calibration_two_ranks_equals_one_device(gpu, tmp_path):
+    """KL: ranges from global batch 0 (broadcast), exact histograms summed in one all-reduce, the search on every rank:
+    thresholds and the offline evaluation equal one device walking the same batches in the same order."""
+    import gpu_cli_worker as W
+    r = _two_ranks(tmp_path, "kl")
+    cli = W.cli_module()
+    thr, acc, avg, _ = W.run_flow(cli, "kl", gpu, 0, 1, W.local_batches("calib"), W.local_batches("eval"), W.LOCAL_BS)
+    assert np.all(thr > 0)
+    np.testing.assert_array_equal(r["thr"], thr)
+    assert float(r["acc"]) == acc and float(r["avg"]) == avg

@@ -619,6 +619,33 @@ def test_pwconv_i8_residual_vs_oracle(dev, ops, form, case, mode):
     _eq(H.pwconv_i8(x, wt, rps, wt_width, bn_scale=sc, bn_shift=sh, act=act, residual=res, **okw), want, "host twin")
 
 
+@pytest.mark.parametrize("case", [(3, 144, 24, 14, 14), (4, 192, 40, 7, 7), (3, 144, 24, 56, 56)],
+                         ids=lambda c: "%dx%d->%d@%dx%d" % c)
+def test_pwconv_i8_residual_partial_tile_statistic_ignores_the_next_sample(dev, ops, case):
+    """A partial channel tile (Cout % 32 != 0) with a residual operand that DWARFS the convolution: the lanes
+    of the channels past Cout must not pick up the next sample's residual (the buffer resource runs to the end of the
+    tensor) - it would not be stored, but it would win the per-sample statistic.  Sample 0's statistic is the tell-tale:
+    its masked lanes would read sample 1, whose residual is made 1000x larger here."""
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + 3)
+    x = np.maximum(rng.standard_normal((n, cin, h, w)), 0).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * 0.01).astype(np.float32)
+    res = (rng.standard_normal((n, cout, h, w)) * 100).astype(np.float32)
+    res[1:] *= 1000.0
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), cout, 8)
+    stat = O.absmax_per_sample(x)
+    sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    for form in ("split", None):
+        y, stat_out = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, cur_out=torch.zeros(1, device=dev),
+                                    bn_scale=T(sc, dev), bn_shift=T(sh, dev), act=None, residual=T(res, dev), form=form,
+                                    in_stat=T(stat, dev), width=8, flags=0)
+        want = O.pwconv_i8(x, wt, cout, 8, bn_scale=sc, bn_shift=sh, act=None, residual=res,
+                           in_max=O.batch_mean(stat), signed=False, width=8)
+        _eq(N(y), want, "output (form %s)" % form)
+        _eq(N(stat_out), O.absmax_per_sample(want), "per-sample statistic (form %s)" % form)
+
+
 PW_S2_CASES = [(2, 256, 512, 14, 14), (3, 512, 1024, 7, 7), (2, 64, 128, 9, 11), (2, 1024, 2048, 5, 5), (3, 256, 128, 28, 28),
                (4, 96, 40, 6, 7)]
 
