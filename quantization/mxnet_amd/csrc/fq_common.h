@@ -494,9 +494,37 @@ constexpr int kPolNtLoad = 1, kPolNtStore = 2, kPolReverse = 4;
 __device__ __forceinline__ f4 buf_ld_v4f(fq_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
-__device__ __forceinline__ void buf_st_v4f(fq_rsrc r, unsigned voff, unsigned soff, f4 v) {
+// 16-byte buffer store.  HAZARD (found in round 3, profiles/r3_dw_flat_race.txt): `buffer_store_dwordx4 v[a:a+3], voff,
+// rsrc, sN offen` reads its data registers for several cycles after it issues, and a VALU instruction that follows it
+// directly and writes v[a] can overtake that read - lanes 12-15 of every 16 then store the NEW value of v[a] (seen: the next
+// store's address offset) in the first dword.  LLVM's hazard recogniser inserts the wait state for stores wider than 8
+// bytes only when soffset is NOT a register (GCNHazardRecognizer::createsVALUHazard), so with a scalar offset nothing
+// protects the data registers; whether a VALU write lands there is up to the register allocator, and whether it overtakes
+// the read is up to how busy the CU's memory pipeline is (never with 4 wavefronts per CU, 0.05 % of the outputs with 8-12).
+// Two ways to stay clear of it: `buf_st_v4f` (one store: the inline asm USES the data registers, so they stay allocated
+// across it, and holds two wait states - the number LLVM applies on gfx940+ where it does see the hazard), or a burst of
+// `buf_st_v4f_unguarded` followed by ONE `hold_store_data(all the data)` (the asm statements of a guarded store are ordered
+// against each other, which would serialise the LDS reads feeding a burst).  tools/isa_lint.py checks the built library.
+#ifndef FQ_BUFST_NOPS
+#define FQ_BUFST_NOPS 1
+#endif
+__device__ __forceinline__ void buf_st_v4f_unguarded(fq_rsrc r, unsigned voff, unsigned soff, f4 v) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, (int)voff, (int)soff, 0);
+}
+template <int N>
+__device__ __forceinline__ void hold_store_data(const f4 (&v)[N]) {
+#if FQ_BUFST_NOPS >= 0
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : : "v"(v[i]));
+  asm volatile("s_nop %0" : : "n"(FQ_BUFST_NOPS));
+#endif
+}
+__device__ __forceinline__ void buf_st_v4f(fq_rsrc r, unsigned voff, unsigned soff, f4 v) {
+  buf_st_v4f_unguarded(r, voff, soff, v);
+#if FQ_BUFST_NOPS >= 0
+  asm volatile("s_nop %1" : : "v"(v), "n"(FQ_BUFST_NOPS));
+#endif
 }
 
 // max over the wavefront of NON-NEGATIVE floats (|x| statistics), the same in every lane: four DPP steps inside the rows

@@ -714,6 +714,28 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_planes_kernel(
 //   C  tile -> registers -> flat 16-byte stores
 // No workgroup barrier: a wavefront only ever touches its own tile (LDS operations of a wavefront complete in order).
 // ---------------------------------------------------------------------------------------------------------------
+// Phase boundary of the flat form.  Default: compiler-level ordering only (LDS operations of one wavefront execute in
+// order).  tools/dw_race_repro.py builds the alternatives to bisect the 28x28 stride-2 irreproducibility:
+//   -DFQ_DWF_SYNC   a workgroup barrier;  -DFQ_DWF_DRAIN  s_waitcnt vmcnt(0) lgkmcnt(0) before going on
+#if defined(FQ_DWF_SYNC)
+#define FQ_DWF_PHASE() __syncthreads()
+#elif defined(FQ_DWF_DRAIN)
+#define FQ_DWF_PHASE()                                             \
+  do {                                                             \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_wave_barrier();                               \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");         \
+  } while (0)
+#else
+#define FQ_DWF_PHASE()                                             \
+  do {                                                             \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         \
+    __builtin_amdgcn_wave_barrier();                               \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");         \
+  } while (0)
+#endif
+
 struct DwFlatGeom {
   int C;
   unsigned planes;          // n * c
@@ -747,6 +769,10 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
   __shared__ f4 otile[kBlock / 64][DOWN ? NLO * 64 : 1];  // stride 1 writes its results over the tile rows already consumed
   __shared__ unsigned k_stat[kStatSlots];
   if (threadIdx.x < kStatSlots) k_stat[threadIdx.x] = 0u;
+#ifdef FQ_DWF_PADLDS                                      // bisect: more static LDS = fewer workgroups per CU
+  __shared__ unsigned lds_pad[FQ_DWF_PADLDS / 4];
+  if (threadIdx.x == 0 && n < 0) lds_pad[n & 15] = 1u;
+#endif
   PW_STAMP(0);
   const unsigned lane = threadIdx.x & 63u;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -811,9 +837,15 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
   __syncthreads();                                        // statistic table zeroed
   for (unsigned blk = blk_begin; blk < blk_end; ++blk) {
     if (blk == blk_begin + 1) PW_STAMP(2);
+#ifdef FQ_DWF_NOPREFETCH                                  // bisect: no block requested ahead
+    if (blk != blk_begin) issue(blk, nxt);
+    FQ_PIN();
+    Blk cur = nxt;
+#else
     Blk cur = nxt;
     FQ_PIN();
     if (blk + 1 < blk_end) issue(blk + 1, nxt);
+#endif
     FQ_PIN();
     const unsigned base = (blk * (kBlock / 64) + wave) * P;
     const unsigned left = base < planes ? planes - base : 0u;
@@ -826,13 +858,21 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
       if (QUANT) v = fq_code4(v, q) * q.scale;
       tile[wave][lane + 64 * i] = v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    FQ_DWF_PHASE();
     // ---- B: 3x3 on the tile ----------------------------------------------------------------------------------------------
     float m = 0.0f;
     const bool is_out = b_lane && j < left;
     if (b_lane) {
+#ifdef FQ_DWF_NODPP                                       // bisect: ds_bpermute shuffles instead of DPP wave shifts
+      auto left_of = [&](float v) -> float {
+        const float t = __shfl_up(v, 1);
+        return first ? 0.0f : t;
+      };
+      auto right_of = [&](float v) -> float {
+        const float t = __shfl_down(v, 1);
+        return last ? 0.0f : t;
+      };
+#else
       auto left_of = [&](float v) -> float {              // (every lane takes the shift; the edge lanes drop it afterwards)
         const float t = lane_prev(v);
         return first ? 0.0f : t;
@@ -841,6 +881,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
         const float t = lane_next(v);
         return last ? 0.0f : t;
       };
+#endif
       if (PAIR) {
         float* lp = my_tile + j * IN + pos * 2;
         const f2 w0 = splat2(cur.w03.x), w1 = splat2(cur.w03.y), w2 = splat2(cur.w03.z), w3 = splat2(cur.w03.w),
@@ -934,14 +975,16 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    FQ_DWF_PHASE();
     // ---- C: flat stores ---------------------------------------------------------------------------------------------------
+    {
+      f4 ov[NLO];
 #pragma unroll
-    for (int i = 0; i < NLO; ++i) {
-      const f4 v = DOWN ? otile[wave][lane + 64 * i] : tile[wave][lane + 64 * i];
-      buf_st_v4f(ry, (lane + 64u * i) < lim_out ? lane * 16u : kOob, base * (OUT * 4u) + 1024u * i, v);
+      for (int i = 0; i < NLO; ++i) ov[i] = DOWN ? otile[wave][lane + 64 * i] : tile[wave][lane + 64 * i];
+#pragma unroll
+      for (int i = 0; i < NLO; ++i)
+        buf_st_v4f_unguarded(ry, (lane + 64u * i) < lim_out ? lane * 16u : kOob, base * (OUT * 4u) + 1024u * i, ov[i]);
+      hold_store_data(ov);              // fq_common.h: nothing may write a store's data registers right behind it
     }
     if (has_stat) {
       m = is_out ? m : 0.0f;
@@ -961,7 +1004,11 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
         else atomic_max_f32(stat_out + sample, m);
       }
     }
+#if defined(FQ_DWF_SYNC) || defined(FQ_DWF_DRAIN)
+    FQ_DWF_PHASE();
+#else
     __builtin_amdgcn_wave_barrier();                      // (the next block's phase A overwrites the tile)
+#endif
   }
   PW_STAMP(3);
   if (has_stat) {
@@ -1231,19 +1278,20 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
   static const int form = env_int("FQ_DW_FORM", 0);     // 0 auto, 1 LDS tiles, 2 sliding window 1 col/lane, 3: 4 cols/lane
   const bool can4 = (wdt % 4 == 0) && aligned16(x) && aligned16(y) && ((h * wdt) % 4 == 0) &&
                     (stride == 1 || ((wdt / 2) % 2 == 0));
-  // 14x14 (stride 1 and 2) and 7x7 planes: flat 16-byte accesses through an LDS transpose (K2p)
-  // tuning: bit 0 14x14 s1, bit 1 14x14 s2, bit 2 7x7, bit 3 28x28 s1
-  // (28x28: 40.1 -> 34.6 us stride 1.  Stride 2 on 28x28 - bit 4 - is NOT built: at full size its results were not reproducible
-  // from run to run as soon as two workgroups shared a CU (zeros in the first element of some 16-byte output groups of the
-  // first two planes of a wavefront; one workgroup per CU: exact).  Neither the 69.7 KB of static LDS of its separate output
-  // tile (a variant writing the outputs over consumed input rows, 53 KB, failed the same way) nor anything else found explains
-  // it; tests/test_gpu_configs.py caught it, tools/dw_determinism.py checks the shapes that ARE taken, six runs each, against
-  // the column-walking forms.  It stays with the four-columns-per-lane form.)
-  static const int flat_on = env_int("FQ_DW_FLAT", 15) & 15;
+  // 14x14 (stride 1 and 2), 7x7 and 28x28 (stride 1 and 2) planes: flat 16-byte accesses through an LDS transpose (K2p)
+  // tuning: bit 0 14x14 s1, bit 1 14x14 s2, bit 2 7x7, bit 3 28x28 s1, bit 4 28x28 s2
+  // (28x28: 40.1 -> 34.6 us stride 1.  Stride 2 on 28x28 was dropped in round 2 because 0.05 % of its outputs changed from run
+  // to run at full size; round 3 found the cause - NOT a data race: a VALU write of a 16-byte buffer store's data register
+  // right behind the store, a hazard hipcc does not guard when soffset is a register (fq_common.h at buf_st_v4f,
+  // profiles/r3_dw_flat_race.txt, tools/dw_race_repro.py, tools/isa_lint.py) - every instantiation of this kernel had the
+  // pattern one instruction further away.  With the stores guarded the form is exact at every occupancy; it is built and
+  // tested (FQ_DW_FLAT=31) but not chosen by shape: inside the model it is no faster than the four-columns-per-lane form
+  // (28.3 us against ~25; whole step 1.1967 against 1.1919 ms, profiles/r3_dw_flat_race.txt).)
+  static const int flat_on = env_int("FQ_DW_FLAT", 15) & 31;
   {
     const int kind = (h == 14 && wdt == 14) ? (stride == 1 ? 0 : 1)
                      : (h == 7 && wdt == 7 && stride == 1) ? 2
-                     : (h == 28 && wdt == 28 && stride == 1) ? 3 : -1;
+                     : (h == 28 && wdt == 28) ? (stride == 1 ? 3 : 4) : -1;
     const int kP = kind == 0 ? 9 : kind >= 3 ? 4 : 8;      // planes per wavefront and block (dwconv3x3_flat_kernel: P)
     const bool whole = kind == 0 || kind >= 3 || (n * c) % kP == 0;     // planes of 49 floats: no 16-byte tail
     if (kind >= 0 && (form == 5 || (form == 0 && ((flat_on >> kind) & 1))) && whole && aligned16(x) && aligned16(y) &&
@@ -1285,6 +1333,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
       if (kind == 0) FQ_DWF_Q(1, 14);
       else if (kind == 1) FQ_DWF_Q(2, 14);
       else if (kind == 2) FQ_DWF_Q(1, 7);
+      else if (kind == 4) FQ_DWF_Q(2, 28);
       else FQ_DWF_Q(1, 28);
 #undef FQ_DWF_Q
 #undef FQ_DWF

@@ -11,7 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tool", ["dw_determinism.py", "pw_determinism.py"])
-def test_full_size_repeats_are_bit_identical(tool):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], capture_output=True, text=True, timeout=900)
+@pytest.mark.parametrize("tool,env", [("dw_determinism.py", {}), ("dw_determinism.py", {"FQ_DW_FLAT": "31"}),
+                                      ("pw_determinism.py", {})],
+                         ids=["depthwise", "depthwise-28x28s2-flat", "pointwise"])
+def test_full_size_repeats_are_bit_identical(tool, env):
+    """50 repeats per shape, half of them beside a competing stream (tools/dw_determinism.py).  FQ_DW_FLAT=31 also sends
+    28x28 stride 2 through the flat form - the instantiation whose irreproducibility led to the store-data hazard
+    (profiles/r3_dw_flat_race.txt); it is exact now that the 16-byte buffer stores are guarded."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **env))
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Run-to-run determinism and agreement of the depthwise forms at full MobileNet sizes: every shape is computed REPS times by
 the form the shape-based choice takes and compared bit for bit with the first run and with the column-walking forms
-(FQ_DW_FLAT=0 FQ_DW_PLANES=0 in a child process)."""
+(FQ_DW_FLAT=0 FQ_DW_PLANES=0 in a child process).  Half of the repeats run beside a second stream that keeps the CUs busy with
+matrix products (another occupancy and another memory-pipeline load than the quiet box: the store-data hazard of round 3,
+profiles/r3_dw_flat_race.txt, only showed under load)."""
 import os
 import subprocess
 import sys
@@ -10,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SHAPES = [(128, 256, 28, 1), (128, 256, 28, 2), (128, 512, 14, 1), (128, 512, 14, 2), (128, 1024, 7, 1), (96, 576, 14, 1),
           (128, 960, 7, 1), (128, 384, 14, 2)]
-REPS = 6
+REPS = 50
 
 
 def main():
@@ -38,13 +40,21 @@ def main():
         if child:
             np.save(path, y0.cpu().numpy())
             continue
-        diffs = []
-        for _ in range(REPS - 1):
+        diffs = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream()
+        a = torch.randn(2048, 2048, device=dev)
+        for r in range(REPS - 1):
+            if r % 2:                                         # a competing stream during every second repeat
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        a @ a
             y, st = run()
-            diffs.append(int((y != y0).sum().item()) + int((st != st0).sum().item()))
+            diffs += (y != y0).sum() + (st != st0).sum()
+        torch.cuda.synchronize()
+        diffs = [int(diffs.item())]
         ref = np.load(path)
         vs = int((ref != y0.cpu().numpy()).sum())
-        print("%4d x %4d @%2dx%-2d stride %d: repeats differ %s, against the column-walking forms %d" % (n, c, hw, hw, s, diffs, vs))
+        print("%4d x %4d @%2dx%-2d stride %d: outputs differing over the repeats %s, against the column-walking forms %d" % (n, c, hw, hw, s, diffs, vs))
         bad += sum(diffs) + vs
     if not child:
         print("OK" if bad == 0 else "MISMATCH")
