@@ -1,10 +1,12 @@
 """Build libfakequant.so in-tree with plain hipcc for gfx950 (no JIT cache: the .so travels with the repo snapshot).
 
-    python -m quantization.mxnet_amd.csrc.build [--force] [--amalgamate] [-DNAME[=V] ...] [-o OUT]
+    python -m quantization.mxnet_amd.csrc.build [--force] [--amalgamate] [-DNAME[=V] ...] [--only UNIT[,UNIT]] [-o OUT]
 
 Every `fq_*.hip` translation unit is compiled to an object under `csrc/build/` (in parallel, only when it or a header
 changed) and the objects are linked into one shared library.  `--amalgamate` compiles all units as ONE translation unit
-instead (used by the trace build `-DFQ_PW_TRACE`, whose `__device__` debug symbols must exist once).
+instead (used by the trace build `-DFQ_PW_TRACE`, whose `__device__` debug symbols must exist once).  `--only fq_pw_sample`
+(tuning variants): the defines apply to the named units only, every other object is the default build's - a variant then
+costs one compilation instead of thirteen.
 
 Flags that matter for parity: `-ffp-contract=off` (HIP defaults to fast contraction; a fused multiply-add would change
 Winograd/EMA/interpolation results against the oracle) and NO fast-math (IEEE fp32 division and roundf decide the
@@ -57,9 +59,13 @@ def _run(cmd, verbose):
     subprocess.check_call(cmd)
 
 
-def build_library(force=False, verbose=True, defines=(), out=OUT, amalgamate=False, jobs=None):
-    """Returns the path of the library.  `defines` (e.g. ["-DFQ_PW_TRACE"]) select a separate object directory."""
+def build_library(force=False, verbose=True, defines=(), out=OUT, amalgamate=False, jobs=None, only=()):
+    """Returns the path of the library.  `defines` (e.g. ["-DFQ_PW_TRACE"]) select a separate object directory; with
+    `only` (unit names without extension) they apply to those units and the rest is taken from the default objects."""
     defines = list(defines)
+    only = set(only)
+    if only:
+        build_library(verbose=verbose)                       # the default objects must exist and be current
     if not force and not defines and out == OUT and up_to_date(out):
         return out
     tag = hashlib.sha1(" ".join(defines).encode()).hexdigest()[:8] if defines else "default"
@@ -76,9 +82,11 @@ def build_library(force=False, verbose=True, defines=(), out=OUT, amalgamate=Fal
         return out
     todo, objs = [], []
     for s in sources():
-        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        unit = os.path.basename(s)[:-4]
+        mine = not only or unit in only
+        o = os.path.join(objdir if mine else os.path.join(OBJ_DIR, "default"), unit + ".o")
         objs.append(o)
-        if force or not _newer(o, [s] + hdrs):
+        if mine and (force or not _newer(o, [s] + hdrs)):
             todo.append([cc] + FLAGS + defines + ["-c", s, "-o", o])
     jobs = jobs or min(len(todo) or 1, os.cpu_count() or 4)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
@@ -92,6 +100,7 @@ if __name__ == "__main__":
     out = OUT
     if "-o" in argv:
         out = os.path.abspath(argv[argv.index("-o") + 1])
+    only = argv[argv.index("--only") + 1].split(",") if "--only" in argv else ()
     build_library(force="--force" in argv, defines=[a for a in argv if a.startswith("-D")], out=out,
-                  amalgamate="--amalgamate" in argv)
+                  amalgamate="--amalgamate" in argv, only=only)
     print(out)

@@ -461,6 +461,39 @@ __device__ __forceinline__ int pack4_codes(int k0, int k1, int k2, int k3, int u
   return (int)(u ^ 0x80808080u);
 }
 
+// ---- the integer code in 5 instructions when the quotient cannot be negative (round 3) ------------------------------------
+// v_cvt_rpi_i32_f32 is floor(x + 0.5) evaluated EXACTLY (no fp32 rounding of the sum): on gfx950 it equals (int)roundf(x)
+// for every one of the 1 200 142 337 non-negative fp32 values up to 70000, pred(0.5) included (tools/cvt_rpi_probe.hip,
+// profiles/r3_cvt_rpi_probe.txt).  For x < 0 it rounds halves UP (roundf: away from zero) and NaN gives INT_MAX ((int) of a
+// NaN: 0), so it only stands in for `fq_code_int` when the clip range starts at 0 and the divisor is positive - unsigned
+// activations (every BASELINE configuration) and the Dense quirk's [0, max] - which is a property of the launch, decided
+// once per kernel (`fq_nonneg`).  clip + divide (3) + round-and-convert = 5 instructions instead of 7, and with non-negative
+// codes the four bytes of a dword merge with three shift-ors and ONE xor (mask 0x80808080 for unsigned codes stored
+// re-centred, 0 for signed ones) instead of four additions, three shift-ors and an xor: 6 instead of 9 per value.
+#ifdef FQ_NO_NONNEG                                       // A/B builds: always the general quantiser
+__device__ __forceinline__ bool fq_nonneg(const QParams&) { return false; }
+#else
+__device__ __forceinline__ bool fq_nonneg(const QParams& q) { return q.lo == 0.0f && q.denom > 0.0f; }
+#endif
+__device__ __forceinline__ unsigned fq_nonneg_xor(int ubias) { return ubias == 0 ? 0x80808080u : 0u; }
+__device__ __forceinline__ int fq_code_nonneg(float x, const QParams& q) {
+  const float Q = ieee_div_by(fq_clip(x, q), q.rden);
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(Q));
+  return r;
+}
+template <bool NONNEG>
+__device__ __forceinline__ int fq_pack4(float a, float b, float c, float d, const QParams& q, int ubias, unsigned nn_xor) {
+  if (NONNEG) {
+    unsigned u = (unsigned)fq_code_nonneg(a, q);
+    u |= (unsigned)fq_code_nonneg(b, q) << 8;
+    u |= (unsigned)fq_code_nonneg(c, q) << 16;
+    u |= (unsigned)fq_code_nonneg(d, q) << 24;
+    return (int)(u ^ nn_xor);
+  }
+  return pack4_codes(fq_code_int(a, q), fq_code_int(b, q), fq_code_int(c, q), fq_code_int(d, q), ubias);
+}
+
 template <bool USE_ABS>
 __device__ __forceinline__ float stat_of(float v) {
   return USE_ABS ? fabsf(v) : v;

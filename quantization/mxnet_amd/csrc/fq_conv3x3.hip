@@ -109,28 +109,34 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
     c_bsc[i] = has_bn && ok ? bn_scale[ic] : (ok ? 1.0f : 0.0f);
     c_bsh[i] = has_bn && ok ? bn_shift[ic] : 0.0f;
   }
-  auto quant_to_panel = [&](int u, const float (&v)[16]) __attribute__((always_inline)) {
+  const int ubias = 128 - g.zoff;
+  const unsigned nn_xor = fq_nonneg_xor(ubias);
+  auto quant_to_panel = [&](int u, const float (&v)[16], auto nn_c) __attribute__((always_inline)) {
     v4i f;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
-      f[d] = pack4_codes(fq_code_int(v[4 * d + 0], q), fq_code_int(v[4 * d + 1], q), fq_code_int(v[4 * d + 2], q),
-                         fq_code_int(v[4 * d + 3], q), 128 - g.zoff);
+      f[d] = fq_pack4<decltype(nn_c)::value>(v[4 * d + 0], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3], q, ubias, nn_xor);
     asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
     const int rt = u / KT, kt = u - rt * KT;
     *reinterpret_cast<v4i*>(panel + (size_t)(rt * 32 + pl) * g.ROW + kt * 32 + 16 * h) = f;
   };
-  for (int u = wave; u < NU; u += 2 * NW) {
-    if (u + NW < NU) issue(u + NW, bufb);
-    FQ_PIN();
-    quant_to_panel(u, bufa);
-    FQ_PIN();
-    if (u + NW < NU) {
-      if (u + 2 * NW < NU) issue(u + 2 * NW, bufa);
+  // (non-negative quotients - unsigned activations - take the 5-instruction quantiser of fq_common.h)
+  auto fill_panel = [&](auto nn_c) __attribute__((always_inline)) {
+    for (int u = wave; u < NU; u += 2 * NW) {
+      if (u + NW < NU) issue(u + NW, bufb);
       FQ_PIN();
-      quant_to_panel(u + NW, bufb);
+      quant_to_panel(u, bufa, nn_c);
       FQ_PIN();
+      if (u + NW < NU) {
+        if (u + 2 * NW < NU) issue(u + 2 * NW, bufa);
+        FQ_PIN();
+        quant_to_panel(u + NW, bufb, nn_c);
+        FQ_PIN();
+      }
     }
-  }
+  };
+  if (fq_nonneg(q)) fill_panel(std::true_type{});
+  else fill_panel(std::false_type{});
 
   // ---- 2. this wavefront's channel tile x PTW pixel tiles ---------------------------------------------------------------
   const int wc = wave % WC, wp = wave / WC;

@@ -128,25 +128,31 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     c_bsh[i] = has_bn && ok ? bn_shift[ic] : 0.0f;
   }
   PW_STAMP(1);
-  auto quant_to_panel = [&](int kt, const float (&v)[16]) __attribute__((always_inline)) {
+  const int ubias = 128 - g.zoff;
+  const unsigned nn_xor = fq_nonneg_xor(ubias);
+  auto quant_to_panel = [&](int kt, const float (&v)[16], auto nn_c) __attribute__((always_inline)) {
     v4i f;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
-      f[d] = pack4_codes(fq_code_int(v[4 * d + 0], q), fq_code_int(v[4 * d + 1], q), fq_code_int(v[4 * d + 2], q),
-                         fq_code_int(v[4 * d + 3], q), 128 - g.zoff);
+      f[d] = fq_pack4<decltype(nn_c)::value>(v[4 * d + 0], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3], q, ubias, nn_xor);
     asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));   // pin the arithmetic here (see K2h)
     panel[(kt << 6) + lane] = f;
   };
   // ---- 1. my quarter of the slabs -> LDS panel ------------------------------------------------------------------------
+  // (non-negative quotients - unsigned activations - take the 5-instruction quantiser of fq_common.h)
+  auto fill_panel = [&](auto nn_c) __attribute__((always_inline)) {
 #pragma unroll
-  for (int j = 0; j < SLABS; ++j) {
-    if (wave + NW * j < kt_real) quant_to_panel(wave + NW * j, buf[j % RB]);
-    FQ_PIN();
-    if (j + RB < SLABS) {
-      if (wave + NW * (j + RB) < kt_real) issue(wave + NW * (j + RB), buf[j % RB]);
+    for (int j = 0; j < SLABS; ++j) {
+      if (wave + NW * j < kt_real) quant_to_panel(wave + NW * j, buf[j % RB], nn_c);
       FQ_PIN();
+      if (j + RB < SLABS) {
+        if (wave + NW * (j + RB) < kt_real) issue(wave + NW * (j + RB), buf[j % RB]);
+        FQ_PIN();
+      }
     }
-  }
+  };
+  if (fq_nonneg(q)) fill_panel(std::true_type{});
+  else fill_panel(std::false_type{});
   // ---- 2. CW channel tiles at once; the first D K-steps of A fragments are requested before the barrier ---------------
   // A fragment (channel tile ct, slab kt) = 1 KB at wfrag + (ct * KT + kt) * 1024
   // Channel tiles past the padded weight buffer read zeros through the bound of the resource; tiles past Cout are not stored.

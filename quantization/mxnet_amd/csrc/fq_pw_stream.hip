@@ -109,13 +109,15 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   __syncthreads();
 
   v4i bfrag[KT];
-  auto quant = [&](int kt, const float (&v)[16]) __attribute__((always_inline)) {
+  const int ubias = 128 - g.zoff;
+  const unsigned nn_xor = fq_nonneg_xor(ubias);
+  auto quant = [&](int kt, const float (&v)[16], auto nn_c) __attribute__((always_inline)) {
     const bool gvalid = kt * 32 + 16 * h < g.Cin;
     v4i f;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const int packed = pack4_codes(fq_code_int(v[4 * d + 0], q), fq_code_int(v[4 * d + 1], q),
-                                     fq_code_int(v[4 * d + 2], q), fq_code_int(v[4 * d + 3], q), 128 - g.zoff);
+      const int packed = fq_pack4<decltype(nn_c)::value>(v[4 * d + 0], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3], q, ubias,
+                                                         nn_xor);
       f[d] = gvalid ? packed : 0;
     }
     // pin the quantisation HERE: it is pure arithmetic whose results are only needed by the MFMAs, and the optimiser
@@ -155,20 +157,27 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
         f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
         if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
+        // two channels at a time: scale / bias / BatchNorm as packed fp32 instructions (two IEEE operations each - the same
+        // values as the scalar form; the kernel is bound by vector-instruction issue, profiles/r2_pmc_sq.txt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = (float)acc[4 * gq + r] * sxw[r];
-          if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) v = v + bch[r];
+        for (int r = 0; r < 4; r += 2) {
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          f2 v = (f2){(float)acc[4 * gq + r], (float)acc[4 * gq + r + 1]};
+          v = v * (f2){sxw[r], sxw[r + 1]};
+          if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) v = v + (f2){bch[r], bch[r + 1]};
           if (BN_M == 1 || (BN_M < 0 && has_bn)) {
-            v = v * bsc[r];
-            v = v + bsh[r];
+            v = v * (f2){bsc[r], bsc[r + 1]};
+            v = v + (f2){bsh[r], bsh[r + 1]};
           }
-          if (RES) v = v + res[4 * gq + r];
-          v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
+          if (RES) v = v + (f2){res[4 * gq + r], res[4 * gq + r + 1]};
+          v.x = ACT_M < 0 ? act_rt(v.x, act) : act_rt(v.x, ACT_M);
+          v.y = ACT_M < 0 ? act_rt(v.y, act) : act_rt(v.y, ACT_M);
           // no masks: lanes past the end hold a copy of the last pixel (clamped loads) and re-store its values, and the
           // host guarantees Cout % 32 == 0
-          *reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff) = v;
-          m = fmaxf(m, fabsf(v));
+          char* yb = reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff;
+          *reinterpret_cast<float*>(yb) = v.x;
+          *reinterpret_cast<float*>(yb + plane * 4) = v.y;
+          m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
         }
       }
     }
@@ -190,7 +199,8 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     }
   };
   // one tile: its first slab is already in `first`; the prefetch of the following slab / tile alternates buffers
-  auto run_tile = [&](int64_t t, float (&first)[16], float (&second)[16], auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+  auto run_tile = [&](int64_t t, float (&first)[16], float (&second)[16], auto bias_c, auto bn_c, auto act_c,
+                      auto nn_c) __attribute__((always_inline)) {
     const Pix cur = nxt;
     const int64_t tn = t + 1 < g.tiles ? t + 1 : g.tiles - 1;
     nxt = pix_of(tn);
@@ -201,33 +211,40 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
       if (kt + 1 < KT) issue(cur, kt + 1, other);
       else issue(nxt, 0, other);
       FQ_PIN();
-      quant(kt, mine);
+      quant(kt, mine, nn_c);
       FQ_PIN();
     }
     tile_done(cur, bias_c, bn_c, act_c);
     FQ_PIN();
   };
-  auto run_all = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+  auto run_all = [&](auto bias_c, auto bn_c, auto act_c, auto nn_c) __attribute__((always_inline)) {
     if (KT & 1) {                                                       // the buffers swap roles from tile to tile
       int64_t t = t_begin;
       for (; t + 1 < t_end; t += 2) {
-        run_tile(t, bufa, bufb, bias_c, bn_c, act_c);
-        run_tile(t + 1, bufb, bufa, bias_c, bn_c, act_c);
+        run_tile(t, bufa, bufb, bias_c, bn_c, act_c, nn_c);
+        run_tile(t + 1, bufb, bufa, bias_c, bn_c, act_c, nn_c);
       }
-      if (t < t_end) run_tile(t, bufa, bufb, bias_c, bn_c, act_c);
+      if (t < t_end) run_tile(t, bufa, bufb, bias_c, bn_c, act_c, nn_c);
     } else {
-      for (int64_t t = t_begin; t < t_end; ++t) run_tile(t, bufa, bufb, bias_c, bn_c, act_c);
+      for (int64_t t = t_begin; t < t_end; ++t) run_tile(t, bufa, bufb, bias_c, bn_c, act_c, nn_c);
     }
   };
+  // the compile-time epilogues (BatchNorm, no bias, fixed activation: the fused-inference case) come with the 5-instruction
+  // quantiser of non-negative quotients (fq_common.h); signed activations take the generic instantiation
   using std::integral_constant;
-  if (bias == nullptr && has_bn && act == FQ_ACT_RELU)
-    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
-  else if (bias == nullptr && has_bn && act == FQ_ACT_RELU6)
-    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{});
-  else if (bias == nullptr && has_bn && act == FQ_ACT_NONE)
-    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{});
+  using std::true_type;
+  using std::false_type;
+  const bool nn = fq_nonneg(q);
+  if (nn && bias == nullptr && has_bn && act == FQ_ACT_RELU)
+    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, true_type{});
+  else if (nn && bias == nullptr && has_bn && act == FQ_ACT_RELU6)
+    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{}, true_type{});
+  else if (nn && bias == nullptr && has_bn && act == FQ_ACT_NONE)
+    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{}, true_type{});
+  else if (nn)
+    run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, true_type{});
   else
-    run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});
+    run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, false_type{});
 
   if (has_stat) {
     __syncthreads();
