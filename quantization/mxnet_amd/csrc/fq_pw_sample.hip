@@ -43,11 +43,20 @@ struct PwSampleGeom {
 };
 
 // (one channel tile per wavefront: 64 accumulator registers - built for two workgroups per CU, whose phases then overlap)
-// PT: 32-pixel tiles of a block - 4 (96..128 pixels), or 2 for planes of fewer than 64 pixels taken whole (7x7: the plane is
-// not a multiple of four pixels; its last pixel is requested by a 4-byte load of its own).
+// PT: 32-pixel tiles of an ITEM - 4 (96..128 pixels) or 2 (up to 64 pixels).  A chunk is always 4096 values, 8 per thread:
+//     PT = 4: 32 channels x 128 pixels, one K-step of 32 per chunk;  PT = 2: 64 channels x 64 pixels, KS = 2 K-steps per chunk.
+// NI: items per workgroup (round 3).  The form is output-stationary: an item's outputs leave at its end, and with one item
+//     per workgroup and one workgroup per CU the whole chip first only loads and then only stores (tools/pw_ablate.py,
+//     profiles/r3_pw_ablate.txt: 512 -> 512 @14x14 25.1 us; without the stores 18.1, without the loads 20.6, without both 14.2,
+//     without MFMAs AND quantiser 23.0 - loads and stores do not overlap).  With NI = 2 the workgroup's block is cut into two
+//     items of <= 64 pixels so that the stores of the first are in flight while the second loads - built, bit-exact, and
+//     measured SLOWER on every layer (31.1 against 24.8 us on 512 -> 512 @14x14: twice the A fragments from L2, an epilogue
+//     in the middle of the MFMA stream): kept as a tuning build only (-DFQ_PWSMP_BUILD_NI2, FQ_PWSMP_NI=2).
+//     Planes of fewer than 64 pixels taken whole (7x7; the plane is not a multiple of four pixels: its last pixel is requested
+//     by a 4-byte load of its own) are one item of PT = 2.
 // RES: a residual operand of y's shape is added after BatchNorm, before the activation (the shortcut of a ResNet unit).
-template <int KT, int CTW, int PT, bool RES>
-__global__ __launch_bounds__(512, (CTW == 1 && PT == 4 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 || PT == 2) ? 2 : 1)) void pwconv_sample_kernel(
+template <int KT, int CTW, int PT, bool RES, int NI>
+__global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 || PT == 2) ? 2 : 1)) void pwconv_sample_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSampleGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
@@ -58,6 +67,11 @@ __global__ __launch_bounds__(512, (CTW == 1 && PT == 4 && FQ_PWSMP_LB4) ? 4 : ((
   // per SIMD exposes every latency of the set-up and the epilogue - 4.7 + 8.4 us instead of 3.7 + 5.1.)
   constexpr int NW = 8;
   constexpr int NCH = NW * CTW * 32;                                    // output channels of one workgroup (256 or 512)
+  constexpr int KS = 4 / PT;                                            // K-steps of 32 channels per chunk
+  constexpr int KI = KT / KS;                                           // chunks per item
+  constexpr int TI = NI * KI;                                           // chunk iterations of the workgroup
+  static_assert(PT == 4 || PT == 2, "pixel tiles per item");
+  static_assert(KT % KS == 0, "K / 32 must be a multiple of the K-steps per chunk");
 #ifndef FQ_PWSMP_HEAD
 #define FQ_PWSMP_HEAD 40
 #define FQ_PWSMP_SLICE 5
@@ -69,12 +83,11 @@ __global__ __launch_bounds__(512, (CTW == 1 && PT == 4 && FQ_PWSMP_LB4) ? 4 : ((
 #ifndef FQ_PWSMP_PF
 #define FQ_PWSMP_PF 4
 #endif
-  // chunks requested ahead (8 registers each); one fewer with one channel tile per wavefront, which then fits 128 registers
-  // = two workgroups per CU
-  // (128 registers with one channel tile per wavefront = TWO workgroups per CU, whose load and store phases then overlap:
-  // 256 -> 256 @28x28 43.9 -> 39.3 us; K / 32 >= 16 only fits them with two chunks ahead)
-  constexpr int PF_ = PT == 2 ? 2 : (CTW == 1 ? (KT >= 16 ? FQ_PWSMP_PF - 2 : FQ_PWSMP_PF - 1) : FQ_PWSMP_PF);   // (small planes: a chunk is 6 KB)
-  constexpr int PF = PF_ < KT ? PF_ : KT;
+  // chunks requested ahead (8 registers each); fewer with one channel tile per wavefront, which then fits 128 registers
+  // = TWO workgroups per CU, whose load and store phases overlap (256 -> 256 @28x28 43.9 -> 39.3 us; K / 32 >= 16 only fits
+  // them with two chunks ahead)
+  constexpr int PF_ = CTW == 1 ? ((KT >= 16 || NI == 2) ? FQ_PWSMP_PF - 2 : FQ_PWSMP_PF - 1) : FQ_PWSMP_PF;
+  constexpr int PF = PF_ < TI ? PF_ : TI;
   __shared__ __attribute__((aligned(16))) unsigned panel[2][kSmpPanelWords];
   __shared__ __attribute__((aligned(16))) float c_sxw[NCH], c_bsc[NCH], c_bsh[NCH], c_bias[NCH];
   __shared__ __attribute__((aligned(16))) int c_zs[NCH];
@@ -84,47 +97,65 @@ __global__ __launch_bounds__(512, (CTW == 1 && PT == 4 && FQ_PWSMP_LB4) ? 4 : ((
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int h = lane >> 5, pl = lane & 31;
   const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
-  // workgroup b runs on XCD b % 8; slot = its position inside the XCD's share: (sample, channel group, pixel half)
+  // workgroup b runs on XCD b % 8; slot = its position inside the XCD's share: (sample, channel group, pixel block)
   const unsigned b = blockIdx.x;
   const unsigned xcd = b & 7u, slot = b >> 3;
   const unsigned ph = slot % (unsigned)g.nb, cg = (slot / (unsigned)g.nb) % (unsigned)g.CS;
   const unsigned smp = (slot / (unsigned)(g.nb * g.CS)) * 8u + xcd;
   if (smp >= (unsigned)g.n) return;
   const int ch0 = (int)cg * NCH;
-  // this block: nquad groups of four pixels from pixel pix0 on (14x14: two blocks of 25 and 24; 28x28: seven of 28)
+  // this block: nquad groups of four pixels from pixel pix0 on (14x14: two blocks of 25 and 24; 28x28: seven of 28);
+  // item i of the block: quads [iq0[i], iq0[i] + inq[i])
   const unsigned nquad = (unsigned)g.qbase + (ph < (unsigned)g.qextra ? 1u : 0u);
   const unsigned pix0 = (ph * (unsigned)g.qbase + (ph < (unsigned)g.qextra ? ph : (unsigned)g.qextra)) * 4u;
-  const unsigned tail = (unsigned)g.HW & 3u;                            // (only whole planes may be ragged: nb == 1)
-  const unsigned npix = tail ? (unsigned)g.HW : nquad * 4u;
+  const unsigned tail = (unsigned)g.HW & 3u;                            // (only whole planes may be ragged: nb == 1, NI == 1)
   const unsigned plane4 = (unsigned)g.HW * 4u;                          // bytes of a plane
+  unsigned inq[NI], ipix0[NI], inpix[NI];
+  {
+    unsigned q0 = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      inq[i] = (nquad - q0 + (unsigned)(NI - i) - 1u) / (unsigned)(NI - i);    // the remaining quads split evenly
+      ipix0[i] = pix0 + q0 * 4u;
+      inpix[i] = (tail && NI == 1) ? (unsigned)g.HW : inq[i] * 4u;
+      q0 += inq[i];
+    }
+  }
 
   PW_STAMP(0);
   const ThresholdReq treq = threshold_request(in_stat, n, in_thr, b == 0);          // first in the memory queue
   // ---- loads: thread -> (kq: 2 channels of the chunk, pq: 4 pixels).  A wavefront covers 8 channel pairs x 8 pixel quads:
   // per load instruction 8 channel rows x 128 contiguous bytes ------------------------------------------------------------------
-  const unsigned kq = ((unsigned)wave & 1u) * 8u + ((unsigned)lane & 7u);           // channel pair 0..15
-  const unsigned pq = ((unsigned)wave >> 1) * 8u + ((unsigned)lane >> 3);           // pixel quad 0..31
-  const bool ld_lane = pq < nquad;
+  const unsigned kq = ((unsigned)wave % (2u * KS)) * 8u + ((unsigned)lane & 7u);    // channel pair 0 .. 16 KS - 1
+  const unsigned pq = ((unsigned)wave / (2u * KS)) * 8u + ((unsigned)lane >> 3);    // pixel quad 0 .. 8 PT - 1
   const fq_rsrc xr = make_rsrc(reinterpret_cast<const char*>(x) + (int64_t)smp * g.Cin * plane4, (int64_t)g.Cin * plane4);
   // a ragged plane's last group holds `tail` pixels: one 4-byte load per pixel... only tail == 1 is built (7x7)
-  const bool rag_lane = tail != 0u && pq + 1u == nquad;
-  const unsigned xoff = kq * 2u * plane4 + (pix0 + pq * 4u) * 4u;
-  const unsigned xo = (ld_lane && !rag_lane) ? xoff : 0x80000000u;
-  const unsigned xo1 = (ld_lane && rag_lane) ? xoff : 0x80000000u;
+  const bool rag_lane = NI == 1 && tail != 0u && pq + 1u == nquad;
+  // (the item's first pixel goes into the SCALAR offset of its loads: with it in the lane offset the scalar offsets of
+  // item 1 equal those of item 0 and hipcc keeps all of them alive across the loop - 106 SGPRs and spills)
+  unsigned xo[NI], xo1 = 0x80000000u;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const unsigned off = kq * 2u * plane4 + (pix0 + pq * 4u) * 4u;
+    xo[i] = (pq < inq[i] && !rag_lane) ? off : 0x80000000u;
+    if (i == 0 && pq < inq[i] && rag_lane) xo1 = off;
+  }
   struct Chunk {
     f4 v[2];
-    float r[PT == 2 ? 2 : 1];                                           // the ragged form's single pixels (0 for every other lane)
+    float r[PT == 2 && NI == 1 ? 2 : 1];                                // the ragged form's single pixels (0 for every other lane)
   };
-  auto issue = [&](int kt, Chunk& c) __attribute__((always_inline)) {
+  constexpr bool RAGGED = PT == 2 && NI == 1;
+  auto issue = [&](int it, Chunk& c) __attribute__((always_inline)) {  // `it`: chunk iteration = item * KI + chunk of the item
+    const int item = it / KI, ki = it % KI;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (FQ_PWSMP_ABL & 8) {
-        c.v[j] = (f4){(float)kt, (float)lane, 1.0f, 2.0f};
-        if (PT == 2) c.r[j] = 0.0f;
+        c.v[j] = (f4){(float)it, (float)lane, 1.0f, 2.0f};
+        if (RAGGED) c.r[j] = 0.0f;
         continue;
       }
-      c.v[j] = buf_ld_v4f(xr, xo, (unsigned)(kt * 32 + j) * plane4);
-      if (PT == 2) c.r[j] = buf_ld_f32(xr, xo1, (unsigned)(kt * 32 + j) * plane4);
+      c.v[j] = buf_ld_v4f(xr, xo[item], (unsigned)(ki * KS * 32 + j) * plane4 + (ipix0[item] - pix0) * 4u);
+      if (RAGGED) c.r[j] = buf_ld_f32(xr, xo1, (unsigned)(ki * KS * 32 + j) * plane4);
     }
   };
   Chunk buf[PF];
@@ -142,11 +173,16 @@ __global__ __launch_bounds__(512, (CTW == 1 && PT == 4 && FQ_PWSMP_LB4) ? 4 : ((
     return buf_ld_v4i(wr, loff, (unsigned)((c * KT + kt) << 10));
   };
   constexpr int AD = 2;                                                 // A fragments requested ahead (chunks)
-  v4i ring[AD + 1][CTW];
+  v4i ring[AD + 1][KS][CTW];
+  auto a_chunk = [&](int it, v4i (&dst)[KS][CTW]) __attribute__((always_inline)) {
+    const int ki = (it < TI ? it : TI - 1) % KI;
 #pragma unroll
-  for (int d = 0; d < AD; ++d)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int c = 0; c < CTW; ++c) ring[d][c] = a_frag(c, d < KT ? d : KT - 1);
+      for (int c = 0; c < CTW; ++c) dst[ks][c] = a_frag(c, ki * KS + ks);
+  };
+#pragma unroll
+  for (int d = 0; d < AD; ++d) a_chunk(d, ring[d]);
   FQ_PIN();
   // ---- per-channel constants (one channel per thread: NCH == threads), requested BEFORE the threshold is waited for - the
   // only one that needs it is sx * wscale ------------------------------------------------------------------------------------------
@@ -169,22 +205,22 @@ __global__ __launch_bounds__(512, (CTW == 1 && PT == 4 && FQ_PWSMP_LB4) ? 4 : ((
     c_bsh[threadIdx.x] = k_bsh;
   }
   PW_STAMP(1);
-  // panel: [h][pixel][16 codes]; a thread writes the two codes (16 bits) of its channel pair for each of its four pixels: a
-  // wavefront's 2-byte stores fall into 16 words spread over 16 banks, two lanes per word and two words per bank (a 2-way
-  // conflict costs a store nothing: its cycles are set by moving address and data to the LDS).  Threads without an item
-  // (pixel quads past the half plane) loaded zeros and write the code of 0 for the padding pixels of the last tile (whose
-  // products are never stored) - unconditional stores keep the quantiser in the same basic block as the MFMAs, which is
-  // what lets the two interleave.
-  const unsigned pw_off = (kq >> 3) * 2048u + pq * 64u + (kq & 7u) * 2u;            // bytes; + 16 * (pixel inside the quad)
+  // panel: [K-step of the chunk][h][pixel of the item][16 codes]; a thread writes the two codes (16 bits) of its channel pair
+  // for each of its four pixels: a wavefront's 2-byte stores fall into 16 words spread over 16 banks, two lanes per word and
+  // two words per bank (a 2-way conflict costs a store nothing: its cycles are set by moving address and data to the LDS).
+  // Threads without an item (pixel quads past the item) loaded zeros and write the code of 0 for the padding pixels of the
+  // last tile (whose products are never stored) - unconditional stores keep the quantiser in the same basic block as the
+  // MFMAs, which is what lets the two interleave.
+  const unsigned pw_off = ((kq >> 4) * (PT * 64u) + ((kq >> 3) & 1u) * (PT * 32u) + pq * 4u) * 16u + (kq & 7u) * 2u;   // bytes; + 16 * (pixel inside the quad)
   const int ub = 128 - g.zoff;
   const unsigned nn_xor16 = fq_nonneg_xor(ub) & 0xFFFFu;
-  auto quant_to_panel = [&](int kt, const Chunk& c, auto nn_c) __attribute__((always_inline)) {
+  auto quant_to_panel = [&](int it, const Chunk& c, auto nn_c) __attribute__((always_inline)) {
     f4 v[2] = {c.v[0], c.v[1]};
-    if (PT == 2) {                                                      // (whole groups got 0 in r, the ragged lane 0 in v)
+    if (RAGGED) {                                                       // (whole groups got 0 in r, the ragged lane 0 in v)
       v[0].x = rag_lane ? c.r[0] : v[0].x;
       v[1].x = rag_lane ? c.r[1] : v[1].x;
     }
-    unsigned char* dst = reinterpret_cast<unsigned char*>(panel[kt & 1]) + pw_off;
+    unsigned char* dst = reinterpret_cast<unsigned char*>(panel[it & 1]) + pw_off;
     auto pair = [&](float a, float b2) -> unsigned short {
       if (FQ_PWSMP_ABL & 2) return (unsigned short)(__float_as_uint(a) ^ (__float_as_uint(b2) >> 7));
       if (decltype(nn_c)::value) {                                      // 5-instruction quantiser of non-negative quotients
@@ -199,81 +235,32 @@ __global__ __launch_bounds__(512, (CTW == 1 && PT == 4 && FQ_PWSMP_LB4) ? 4 : ((
     *reinterpret_cast<unsigned short*>(dst + 32) = pair(v[0].z, v[1].z);
     *reinterpret_cast<unsigned short*>(dst + 48) = pair(v[0].w, v[1].w);
   };
-  // B fragment of pixel tile pt for this lane: pixel 32 pt + pl of the block, codes 16 h .. 16 h + 15 of the chunk
-  const unsigned bq_off = (unsigned)h * 512u + (unsigned)pl * 4u;                  // words; + pt * 128
+  // B fragment (K-step ks, pixel tile pt) of this lane: pixel 32 pt + pl of the item, codes 16 h .. 16 h + 15 of the step
+  const unsigned bq_off = (unsigned)h * (PT * 128u) + (unsigned)pl * 4u;            // words; + ks * PT * 256 + pt * 128
   v16i acc[PT][CTW];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-    for (int c = 0; c < CTW; ++c)
+      for (int c = 0; c < CTW; ++c)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[pt][c][i] = 0;
-
-  // The loop is software-pipelined inside every wavefront: the MFMAs of chunk kt are issued alternately with slices of the
-  // quantisation of chunk kt + 1 - with the two phases one after the other, separated by the barrier, the
-  // matrix pipe idles while the wavefronts quantise and the vector ALU while they multiply (measured on the first version of
-  // this form: the chunk time was the SUM of the two).  Writing panel[(kt + 1) & 1] during the multiplication of chunk kt is
-  // safe: its last readers (chunk kt - 1) are behind the barrier of this iteration.
-  auto chunk_loop = [&](auto nn_c) __attribute__((always_inline)) {
-    constexpr bool NN = decltype(nn_c)::value;
-    // vector instructions per chunk: ~56 with the short quantiser, ~80 with the general one
-    constexpr int HEAD = NN ? FQ_PWSMP_HEAD_NN : FQ_PWSMP_HEAD, SLICE = NN ? FQ_PWSMP_SLICE_NN : FQ_PWSMP_SLICE;
-    quant_to_panel(0, buf[0], nn_c);
-    if (PF < KT) issue(PF, buf[0]);
-    FQ_PIN();
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      if (!(FQ_PWSMP_ABL & 4) || kt == 0)
-        __syncthreads();                                                // panel[kt & 1] complete (and, first time, the constants)
-      if (kt == 0) PW_STAMP(6);
-      if (kt == KT / 2) PW_STAMP(7);
-      const unsigned* pb = &panel[kt & 1][bq_off];
-      v4i bfrag[PT];
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt) bfrag[pt] = *reinterpret_cast<const v4i*>(pb + pt * 128);
-#pragma unroll
-      for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) {
-          if (FQ_PWSMP_ABL & 1) acc[pt][c][kt & 15] += bfrag[pt][kt & 3] ^ ring[kt % (AD + 1)][c][kt & 3];
-          else acc[pt][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[kt % (AD + 1)][c], bfrag[pt], acc[pt][c], 0, 0, 0);
-        }
-      if (kt + 1 < KT) {
-        quant_to_panel(kt + 1, buf[(kt + 1) % PF], nn_c);
-        if (kt + 1 + PF < KT) issue(kt + 1 + PF, buf[(kt + 1) % PF]);
-      }
-      if (kt + AD < KT) {
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) ring[(kt + AD) % (AD + 1)][c] = a_frag(c, kt + AD);
-      }
-      // the schedule: B fragments, then one MFMA followed by a slice of vector work, eight times
-      __builtin_amdgcn_sched_group_barrier(0x100, PT, 0);               // DS reads
-      __builtin_amdgcn_sched_group_barrier(0x002, HEAD, 0);             // vector work behind which the B fragments arrive
-#pragma unroll
-      for (int i = 0; i < PT * CTW; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, SLICE, 0);          // a slice of the quantiser's vector instructions
-      }
-      FQ_PIN();
-    }
+        for (int i = 0; i < 16; ++i) acc[pt][c][i] = 0;
   };
-  if (FQ_PWSMP_ABL & 64) __syncthreads();
-  else if (fq_nonneg(q)) chunk_loop(std::true_type{});
-  else chunk_loop(std::false_type{});
-  PW_STAMP(2);
-  // ---- epilogue: lane = pixel, register = channel 8 gq + 4 h + r of the tile ----------------------------------------------------
+  zero_acc();
+
+  // ---- epilogue of one item: lane = pixel, register = channel 8 gq + 4 h + r of the tile ---------------------------------------
   const int cvalid = g.Cout - (ch0 + ctl0 * 32);
   float m = 0.0f;
-  auto epilogue = [&](auto fast_c) __attribute__((always_inline)) {
+  auto epilogue = [&](int item, auto fast_c) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_c)::value;                      // BatchNorm + ReLU, no bias: fixed at compile time
     const int64_t y_bytes = (int64_t)g.Cout * plane4 - (int64_t)(ch0 + ctl0 * 32) * plane4;
     const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + ((int64_t)smp * g.Cout + ch0 + ctl0 * 32) * plane4, y_bytes);
     const fq_rsrc rr = make_rsrc(reinterpret_cast<const char*>(RES ? residual : y) + ((int64_t)smp * g.Cout + ch0 + ctl0 * 32) * plane4,
                                  RES ? y_bytes : 0);
-    // channel tiles are whole (host: Cout % 512 == 0); only the LAST pixel tile of a half has pixels past its end (offset out
-    // of range: the store is dropped) - the other three take no mask at all
-    const bool last_ok = 32u * (PT - 1) + (unsigned)pl < npix;
-    const unsigned po0 = (unsigned)(4 * h) * plane4 + (pix0 + (unsigned)pl) * 4u;
+    // channel tiles are whole (host: Cout % NCH == 0); only the LAST pixel tile of an item has pixels past its end (offset out
+    // of range: the store is dropped) - the others take no mask at all
+    const bool last_ok = 32u * (PT - 1) + (unsigned)pl < inpix[item];
+    const unsigned po0 = (unsigned)(4 * h) * plane4 + (ipix0[item] + (unsigned)pl) * 4u;
     const unsigned po_last = last_ok ? po0 + 32u * (PT - 1) * 4u : 0x80000000u;
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
@@ -338,10 +325,81 @@ __global__ __launch_bounds__(512, (CTW == 1 && PT == 4 && FQ_PWSMP_LB4) ? 4 : ((
       }
     }
   };
-  if (cvalid > 0) {
-    if (bias == nullptr && has_bn && act == FQ_ACT_RELU) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
-  }
+  const bool fast_epi = bias == nullptr && has_bn && act == FQ_ACT_RELU;
+  auto finish_item = [&](int item) __attribute__((always_inline)) {
+    if (cvalid > 0) {
+      if (fast_epi) epilogue(item, std::true_type{});
+      else epilogue(item, std::false_type{});
+    }
+  };
+
+  // The loop is software-pipelined inside every wavefront: the MFMAs of chunk `it` are issued alternately with slices of the
+  // quantisation of chunk it + 1 - with the two phases one after the other, separated by the barrier, the
+  // matrix pipe idles while the wavefronts quantise and the vector ALU while they multiply (measured on the first version of
+  // this form: the chunk time was the SUM of the two).  Writing panel[(it + 1) & 1] during the multiplication of chunk `it` is
+  // safe: its last readers (chunk it - 1) are behind the barrier of this iteration.  The chunk sequence runs THROUGH the item
+  // boundary: the first chunk of item i + 1 is quantised during the last multiplication of item i, its loads were requested
+  // PF chunks earlier, and item i's epilogue sits between the two iterations.
+  auto chunk_loop = [&](auto nn_c) __attribute__((always_inline)) {
+    constexpr bool NN = decltype(nn_c)::value;
+    // vector instructions per chunk: ~56 with the short quantiser, ~80 with the general one
+    constexpr int HEAD = NN ? FQ_PWSMP_HEAD_NN : FQ_PWSMP_HEAD, SLICE = NN ? FQ_PWSMP_SLICE_NN : FQ_PWSMP_SLICE;
+    quant_to_panel(0, buf[0], nn_c);
+    if (PF < TI) issue(PF, buf[0]);
+    FQ_PIN();
+    // (two nested loops, both unrolled: one loop with the epilogue behind a test of `it` is too large for hipcc's
+    // unroller, and the register arrays indexed by `it` then live in scratch memory)
+#pragma unroll
+    for (int item = 0; item < NI; ++item) {
+    if (item > 0) {                                                     // item boundary: the finished item leaves
+      finish_item(item - 1);
+      zero_acc();
+      FQ_PIN();
+    }
+#pragma unroll
+    for (int ki = 0; ki < KI; ++ki) {
+      const int it = item * KI + ki;
+      if (!(FQ_PWSMP_ABL & 4) || it == 0)
+        __syncthreads();                                                // panel[it & 1] complete (and, first time, the constants)
+      if (it == 0) PW_STAMP(6);
+      if (it == TI / 2) PW_STAMP(7);
+      const unsigned* pb = &panel[it & 1][bq_off];
+      v4i bfrag[KS][PT];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) bfrag[ks][pt] = *reinterpret_cast<const v4i*>(pb + ks * (PT * 256) + pt * 128);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+          for (int c = 0; c < CTW; ++c) {
+            if (FQ_PWSMP_ABL & 1) acc[pt][c][it & 15] += bfrag[ks][pt][it & 3] ^ ring[it % (AD + 1)][ks][c][it & 3];
+            else acc[pt][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[it % (AD + 1)][ks][c], bfrag[ks][pt], acc[pt][c], 0, 0, 0);
+          }
+      if (it + 1 < TI) {
+        quant_to_panel(it + 1, buf[(it + 1) % PF], nn_c);
+        if (it + 1 + PF < TI) issue(it + 1 + PF, buf[(it + 1) % PF]);
+      }
+      if (it + AD < TI) a_chunk(it + AD, ring[(it + AD) % (AD + 1)]);
+      // the schedule: B fragments, then one MFMA followed by a slice of vector work, eight times
+      __builtin_amdgcn_sched_group_barrier(0x100, KS * PT, 0);          // DS reads
+      __builtin_amdgcn_sched_group_barrier(0x002, HEAD, 0);             // vector work behind which the B fragments arrive
+#pragma unroll
+      for (int i = 0; i < KS * PT * CTW; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, SLICE, 0);          // a slice of the quantiser's vector instructions
+      }
+      FQ_PIN();
+    }
+    }
+  };
+  if (FQ_PWSMP_ABL & 64) __syncthreads();
+  else if (fq_nonneg(q)) chunk_loop(std::true_type{});
+  else chunk_loop(std::false_type{});
+  PW_STAMP(2);
+  finish_item(NI - 1);
   PW_STAMP(3);
   if (has_stat) {                                                       // the whole workgroup is one sample
     // ONE atomic per workgroup: with one per wavefront (4096 atomics on 128 addresses) the kernel got 3.5-6 us slower
@@ -388,7 +446,9 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   if (!shape_ok || !(a.form == 7 || by_shape)) return FQ_OK;
   const int64_t rows_pad = (a.cout + 31) / 32 * 32;
   static const int ctw_tune = env_int("FQ_PWSMP_CTW", 0);               // tuning: 1 = 256 channels per workgroup everywhere
-  const int ctw = (a.cout % 512 == 0 && ctw_tune != 1) ? 2 : 1;
+  // two channel tiles per wavefront (512 channels per workgroup, every value quantised once) from K = 512 up; below that
+  // two workgroups of 256 channels per CU are faster (256 -> 512 @14x14: 20.1 -> 18.4 us; 512 -> 512: 25.2 against 25.7)
+  const int ctw = (a.cout % 512 == 0 && ctw_tune != 1 && (kt >= 16 || ctw_tune == 2 || a.residual != nullptr)) ? 2 : 1;
   PwSampleGeom t;
   t.Cin = (int)a.cin;
   t.Cout = (int)a.cout;
@@ -400,26 +460,41 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   t.nb = nb;
   t.qbase = (int)(quads / nb);
   t.qextra = (int)(quads % nb);
-  const int pt = small ? 2 : 4;
+  const bool res = a.residual != nullptr;
+  // items per workgroup: blocked planes are cut into two items of two pixel tiles each (NI = 2, PT = 2: the first item's
+  // stores overlap the second item's loads) or taken as one item of four (NI = 1, PT = 4; round 2)
+  // MEASURED (profiles/r3_pw_experiments.txt): two items are SLOWER everywhere - 512 -> 512 @14x14 31.1 us against 24.8,
+  // 256 -> 256 @28x28 46.8 against 40.5, 128 -> 256 @28x28 36.7 against 34.3, 256 -> 512 @14x14 21.0 against 18.6 - so one item
+  // is what the shape-based choice takes; the two-item instantiations are only built with -DFQ_PWSMP_BUILD_NI2 (tuning).
+  static const int ni_tune = env_int("FQ_PWSMP_NI", 0);                 // tuning: 2 = two items (needs FQ_PWSMP_BUILD_NI2)
+  const int ni = (!small && ni_tune == 2 && !res) ? 2 : 1;
+  const int pt = (small || ni == 2) ? 2 : 4;
   const int64_t grid = (a.n + 7) / 8 * t.CS * nb * 8;
   FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8: too many workgroups for the sample form");
   const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;                // second half of fq_weight_codes' buffer
   if (int rc = pw_zero_stat(a)) return rc;
-  const bool res = a.residual != nullptr;
   bool launched = false;
-#define FQ_PWSMP_CASE_R(KT_, CTW_, PT_, RES_)                                                                          \
-  if (kt == KT_ && ctw == CTW_ && pt == PT_ && res == RES_) {                                                          \
-    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_, PT_, RES_>), dim3((unsigned)grid), dim3(512), 0, a.st, a.x,     \
-                       wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels,    \
-                       a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out, a.residual);      \
+#define FQ_PWSMP_CASE_R(KT_, CTW_, PT_, RES_, NI_)                                                                     \
+  if (kt == KT_ && ctw == CTW_ && pt == PT_ && res == RES_ && ni == NI_) {                                             \
+    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_, PT_, RES_, NI_>), dim3((unsigned)grid), dim3(512), 0, a.st,     \
+                       a.x, wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr,         \
+                       a.levels, a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out,          \
+                       a.residual);                                                                                    \
     launched = true;                                                                                                   \
   }
-#define FQ_PWSMP_CASE(KT_, CTW_, PT_) FQ_PWSMP_CASE_R(KT_, CTW_, PT_, false)
-  FQ_PWSMP_CASE(4, 1, 4) FQ_PWSMP_CASE(4, 2, 4) FQ_PWSMP_CASE(8, 1, 4) FQ_PWSMP_CASE(8, 2, 4) FQ_PWSMP_CASE(16, 1, 4)
-  FQ_PWSMP_CASE(16, 2, 4) FQ_PWSMP_CASE(32, 1, 4) FQ_PWSMP_CASE(32, 2, 4)
-  FQ_PWSMP_CASE(16, 1, 2) FQ_PWSMP_CASE(16, 2, 2) FQ_PWSMP_CASE(32, 1, 2) FQ_PWSMP_CASE(32, 2, 2)
+#define FQ_PWSMP_CASE(KT_, CTW_, PT_, NI_) FQ_PWSMP_CASE_R(KT_, CTW_, PT_, false, NI_)
+  // one item of four pixel tiles (round 2)
+  FQ_PWSMP_CASE(4, 1, 4, 1) FQ_PWSMP_CASE(4, 2, 4, 1) FQ_PWSMP_CASE(8, 1, 4, 1) FQ_PWSMP_CASE(8, 2, 4, 1)
+  FQ_PWSMP_CASE(16, 1, 4, 1) FQ_PWSMP_CASE(16, 2, 4, 1) FQ_PWSMP_CASE(32, 1, 4, 1) FQ_PWSMP_CASE(32, 2, 4, 1)
+#ifdef FQ_PWSMP_BUILD_NI2
+  // two items of two pixel tiles
+  FQ_PWSMP_CASE(4, 1, 2, 2) FQ_PWSMP_CASE(4, 2, 2, 2) FQ_PWSMP_CASE(8, 1, 2, 2) FQ_PWSMP_CASE(8, 2, 2, 2)
+  FQ_PWSMP_CASE(16, 1, 2, 2) FQ_PWSMP_CASE(16, 2, 2, 2) FQ_PWSMP_CASE(32, 1, 2, 2) FQ_PWSMP_CASE(32, 2, 2, 2)
+#endif
+  // whole small planes
+  FQ_PWSMP_CASE(16, 1, 2, 1) FQ_PWSMP_CASE(16, 2, 2, 1) FQ_PWSMP_CASE(32, 1, 2, 1) FQ_PWSMP_CASE(32, 2, 2, 1)
   // with a residual operand: the last 1x1 convolutions of the ResNet bottlenecks (128 -> 512 @28x28, 256 -> 1024 @14x14)
-  FQ_PWSMP_CASE_R(4, 2, 4, true) FQ_PWSMP_CASE_R(8, 2, 4, true) FQ_PWSMP_CASE_R(16, 2, 4, true)
+  FQ_PWSMP_CASE_R(4, 2, 4, true, 1) FQ_PWSMP_CASE_R(8, 2, 4, true, 1) FQ_PWSMP_CASE_R(16, 2, 4, true, 1)
 #undef FQ_PWSMP_CASE
 #undef FQ_PWSMP_CASE_R
   if (!launched) {                                                     // (a combination that is not built: another form takes it)
