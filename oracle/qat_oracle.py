@@ -11,8 +11,12 @@ w -= lr_t*m/(sqrt(v)+eps); gradients rescaled by 1/batch_size).
 
 It is deliberately independent of the facade: a functional torch-CPU graph (torch is only the differentiator of the
 float convolution / dense / BN / loss), every fake-quant is the numpy oracle (`fq_oracle`) behind an identity-backward
-node.  Parity pinned by: the quantisers' own golden vectors (tests/test_oracle_golden.py); the step as a whole has no
-reference-generated fixture (MXNet cannot run here) — "parity unpinned" for the composition, stated in DESIGN.md.
+node.  Parity pinned by: the quantisers' own golden vectors (tests/test_oracle_golden.py) AND, since round 3, the composed
+step itself: tests/golden/g11_qat.npz holds three configurations x four steps made by the REFERENCE'S OWN `convert_model` /
+`LinearQuantizeSTE` / fake-BN pre-hook / `update_ema` under `autograd.record()` (tools/gen_golden.py::gen_qat; the stand-in
+supplies convolution / BatchNorm / loss and the tape), and tests/test_qat_golden.py holds this restatement to it: loss,
+logits, moving statistics 2e-6, gradients 2e-5, `input_max` bit for bit.  Not covered by a reference-made fixture: the
+optimiser (MXNet's Adam rule is written out below from optimizer.py; the fixture has no optimiser step).
 
 The net is described by a list of layer dicts (see tests/test_qat.py):
   {"op": "conv", "w": name, "stride": s, "pad": p, "groups": g, "quant": True/False}

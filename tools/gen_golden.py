@@ -558,6 +558,144 @@ def gen_fake_bn(mx, convert, initialize, ref, out):
     np.savez_compressed(os.path.join(out, "g10_fake_bn.npz"), **cases)
 
 
+def _qat_net(mx, params):
+    """conv3x3(3->8) bn relu | dw3x3 s2 (8) bn relu | pw1x1(8->16) bn relu | pool | dense(16->10) - the net of
+    tests/test_qat.py, parameters given."""
+    nn = mx.gluon.nn
+    from quantization.mxnet_amd.mx.gluon.block import reset_naming
+    reset_naming()
+    net = nn.HybridSequential()
+    net.add(nn.Conv2D(8, 3, 1, 1, use_bias=False, in_channels=3), nn.BatchNorm(in_channels=8), nn.Activation("relu"),
+            nn.Conv2D(8, 3, 2, 1, groups=8, use_bias=False, in_channels=8), nn.BatchNorm(in_channels=8),
+            nn.Activation("relu"),
+            nn.Conv2D(16, 1, 1, 0, use_bias=False, in_channels=8), nn.BatchNorm(in_channels=16), nn.Activation("relu"),
+            nn.GlobalAvgPool2D(), nn.Flatten(), nn.Dense(10, in_units=16))
+    net.initialize()
+    kids = list(net._children.values())
+    A = lambda a: mx.nd.array(np.array(a, copy=True))          # (nd.array may alias the numpy buffer; BatchNorm updates in place)
+    for i, ci in enumerate((0, 3, 6)):
+        kids[ci].weight.set_data(A(params["c%d_w" % i]))
+        bn = kids[ci + 1]
+        bn.gamma.set_data(A(params["b%d_g" % i]))
+        bn.beta.set_data(A(params["b%d_b" % i]))
+        bn.running_mean.set_data(A(params["b%d_m" % i]))
+        bn.running_var.set_data(A(params["b%d_v" % i]))
+    kids[11].weight.set_data(A(params["d_w"]))
+    kids[11].bias.set_data(A(params["d_b"]))
+    return net, kids
+
+
+def gen_qat(mx, convert, initialize, out):
+    """G11: the quantisation-aware-training step made by the REFERENCE'S OWN code under `autograd.record()`:
+    `convert_model` with its converters (`LinearQuantizeSTE.forward/backward`, ste_func.py:30-44; the fake-BN fold and its
+    batch-statistic pre-hook `_add_fake_bn_ema_hook`, convert_conv2d.py:47-51,144-154), `net.update_ema()`
+    (convert.py:66-79) - the notebook's loop body (examples/quantize_aware_training_cifar10.ipynb cell 15) WITHOUT the
+    optimiser: the parameters stay put, every step sees a new batch, so nothing in the fixture depends on this project's
+    Trainer.  What the stand-in supplies: convolution / dense / BatchNorm(train) / softmax-cross-entropy and their
+    gradients (torch CPU) and the tape.  Per step: per-sample loss, logits, the gradient of every parameter, and after
+    `update_ema` every `input_max` and every moving statistic.
+      A  ordinary BatchNorm net, W8A8 per layer and per channel, online for two steps, OFFLINE in the third
+      B  the notebook's configuration (cells 6-7): per-channel W4A4, fake_bn=True, BatchNorm bypassed, first conv + BN
+         excluded, input quantisers off for two steps, then on OFFLINE with the EMA'd thresholds"""
+    nn = mx.gluon.nn
+    autograd, gluon = mx.autograd, mx.gluon
+    rng = np.random.default_rng(SEED + 8)
+    params = {"c0_w": rng.standard_normal((8, 3, 3, 3)) * 0.4, "c1_w": rng.standard_normal((8, 1, 3, 3)) * 0.4,
+              "c2_w": rng.standard_normal((16, 8, 1, 1)) * 0.4, "d_w": rng.standard_normal((10, 16)) * 0.4,
+              "d_b": rng.standard_normal(10) * 0.1}
+    for i, c in enumerate((8, 8, 16)):
+        params["b%d_g" % i] = rng.uniform(0.5, 1.5, c)
+        params["b%d_b" % i] = rng.standard_normal(c) * 0.1
+        params["b%d_m" % i] = rng.standard_normal(c) * 0.1
+        params["b%d_v" % i] = rng.uniform(0.5, 1.5, c)
+    params = {k: np.asarray(v, dtype=np.float32) for k, v in params.items()}
+    steps = 4
+    Xs = [rng.standard_normal((6, 3, 12, 12)).astype(np.float32) * np.float32(1.0 + 0.3 * s) for s in range(steps)]
+    ys = [rng.integers(0, 10, 6).astype(np.float32) for _ in range(steps)]
+    cases = {"steps": np.int64(steps), "xs": np.stack(Xs), "ys": np.stack(ys)}
+    for k, v in params.items():
+        cases["param/" + k] = v.copy()
+    loss_func = gluon.loss.SoftmaxCrossEntropyLoss()
+
+    def run(tag, net, named, offline_at, enable_before):
+        blocks = net.collect_quantized_blocks()
+        for s in range(steps):
+            if s == offline_at:
+                net.quantize_input(enable=True, online=False)
+            for p in net.collect_params().values():              # fresh gradients every step (grad_req 'write')
+                if p._data is not None and p.data()._t.grad is not None:
+                    p.data()._t.grad = None
+            with autograd.record():
+                outputs = net(mx.nd.array(Xs[s]))
+                loss = loss_func(outputs, mx.nd.array(ys[s]))
+            net.update_ema()
+            loss.backward()
+            cases["%s/step%d/loss" % (tag, s)] = loss.asnumpy()
+            cases["%s/step%d/logits" % (tag, s)] = outputs.asnumpy()
+            for k, p in named.items():
+                g = p.data()._t.grad
+                if g is not None:
+                    cases["%s/step%d/grad/%s" % (tag, s, k)] = g.detach().numpy().copy()
+                cases["%s/step%d/value/%s" % (tag, s, k)] = p.data().asnumpy().copy()
+            cases["%s/step%d/input_max" % (tag, s)] = np.asarray(
+                [b.input_max.data().asnumpy()[0] for b in blocks if getattr(b, "input_max", None) is not None], np.float32)
+
+    for qt in ("layer", "channel"):
+        net, kids = _qat_net(mx, params)
+        convert.convert_model(net, convert_fn={nn.Conv2D: convert.gen_conv2d_converter(quant_type=qt),
+                                               nn.Dense: convert.gen_dense_converter(quant_type=qt),
+                                               nn.Activation: None, nn.BatchNorm: None})
+        initialize.qparams_init(net)
+        net.quantize_input(enable=True, online=True)
+        named = {"c0_w": kids[0].weight, "c1_w": kids[3].weight, "c2_w": kids[6].weight, "d_w": kids[11].weight,
+                 "d_b": kids[11].bias}
+        for i, ci in enumerate((1, 4, 7)):
+            named.update({"b%d_g" % i: kids[ci].gamma, "b%d_b" % i: kids[ci].beta, "b%d_m" % i: kids[ci].running_mean,
+                          "b%d_v" % i: kids[ci].running_var})
+        run("bn_" + qt, net, named, offline_at=2, enable_before=True)
+
+    nb = dict(params)
+    nb["c1_b"] = (rng.standard_normal(8) * 0.05).astype(np.float32)
+    nb["c2_b"] = (rng.standard_normal(16) * 0.05).astype(np.float32)
+    cases["param/c1_b"], cases["param/c2_b"] = nb["c1_b"].copy(), nb["c2_b"].copy()
+    reset = __import__("quantization.mxnet_amd.mx.gluon.block", fromlist=["reset_naming"]).reset_naming
+    reset()
+    net = nn.HybridSequential()
+    net.add(nn.Conv2D(8, 3, 1, 1, use_bias=False, in_channels=3), nn.BatchNorm(in_channels=8), nn.Activation("relu"),
+            nn.Conv2D(8, 3, 2, 1, groups=8, use_bias=True, in_channels=8), nn.BatchNorm(in_channels=8),
+            nn.Activation("relu"),
+            nn.Conv2D(16, 1, 1, 0, use_bias=True, in_channels=8), nn.BatchNorm(in_channels=16), nn.Activation("relu"),
+            nn.GlobalAvgPool2D(), nn.Flatten(), nn.Dense(10, in_units=16))
+    net.initialize()
+    kids = list(net._children.values())
+    A = lambda a: mx.nd.array(np.array(a, copy=True))
+    for i, ci in enumerate((0, 3, 6)):
+        kids[ci].weight.set_data(A(nb["c%d_w" % i]))
+        if i:
+            kids[ci].bias.set_data(A(nb["c%d_b" % i]))
+        bn = kids[ci + 1]
+        bn.gamma.set_data(A(nb["b%d_g" % i]))
+        bn.beta.set_data(A(nb["b%d_b" % i]))
+        bn.running_mean.set_data(A(nb["b%d_m" % i]))
+        bn.running_var.set_data(A(nb["b%d_v" % i]))
+    kids[11].weight.set_data(A(nb["d_w"]))
+    kids[11].bias.set_data(A(nb["d_b"]))
+    converter = {nn.Conv2D: convert.gen_conv2d_converter(quant_type="channel", fake_bn=True, input_width=4, weight_width=4),
+                 nn.Dense: convert.gen_dense_converter(quant_type="channel", input_width=4, weight_width=4),
+                 nn.Activation: None, nn.BatchNorm: convert.bypass_bn}
+    convert.convert_model(net, exclude=[kids[0], kids[1]], convert_fn=converter)
+    net.quantize_input(enable=False)
+    initialize.qparams_init(net)
+    named = {"c0_w": kids[0].weight, "b0_g": kids[1].gamma, "b0_b": kids[1].beta, "b0_m": kids[1].running_mean,
+             "b0_v": kids[1].running_var, "d_w": kids[11].weight, "d_b": kids[11].bias}
+    for i, ci in ((1, 3), (2, 6)):
+        c = kids[ci]
+        named.update({"c%d_w" % i: c.weight, "c%d_b" % i: c.bias, "b%d_g" % i: c.gamma, "b%d_b" % i: c.beta,
+                      "b%d_m" % i: c.running_mean, "b%d_v" % i: c.running_var})
+    run("notebook", net, named, offline_at=2, enable_before=False)
+    np.savez_compressed(os.path.join(out, "g11_qat.npz"), **cases)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -596,6 +734,9 @@ def main():
     if want("g10"):
         gen_fake_bn(mx, convert, initialize, args.ref, args.out)
         print("g10 done", flush=True)
+    if want("g11"):
+        gen_qat(mx, convert, initialize, args.out)
+        print("g11 done", flush=True)
     with open(os.path.join(args.out, "PROVENANCE.txt"), "w") as f:
         import scipy
         import torch
