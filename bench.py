@@ -11,6 +11,11 @@ BASELINE configurations are reachable with flags (they are parity-test cases; th
     python bench.py --gpus N --steps K --warmup W
     python bench.py --model resnet50_v1 --quant-type channel [--offline] [--wino F43]
     python bench.py --model mobilenetv2_1.0 --quant-type channel --weight-bits 4 --offline
+    python bench.py --phase calib-naive --model mobilenetv2_1.0 --quant-type channel --weight-bits 4    (config 4's calibration:
+                    a step = forward with ONLINE scales and the weights re-quantised + net.update_ema())
+    python bench.py --phase calib-kl --model resnet50_v1 --quant-type channel                           (config 3's calibration:
+                    a step = forward with quantisation disabled + one 2048-bin histogram per quantised block;
+                    the threshold search over all layers is timed once, after the steps)
     N > 1: either  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...  (one rank
     per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plainly  python bench.py --gpus N:
     with no WORLD_SIZE in the environment the process — before it touches any GPU — starts that launcher itself
@@ -140,25 +145,47 @@ def cpu_baseline(args, classes, hw, budget_s=20.0):
     threads = int(os.environ.get("FQ_HOST_THREADS", max(1, cores // 2)))
     torch.set_num_threads(threads)
     H.set_threads(threads)
+    phase = getattr(args, "phase", "eval")
     net = build_net(args.model, classes, mx.cpu(), quant_type=args.quant_type, weight_bits=args.weight_bits,
-                    input_bits=args.input_bits, signed=args.input_signed, wino=args.wino)
+                    input_bits=args.input_bits, signed=args.input_signed, wino=args.wino, freeze=phase == "eval")
     rng = np.random.default_rng(7)
-    bs, done, t_total = 32, 0, 0.0
+    bs, done, t_total = (32 if phase == "eval" else 8), 0, 0.0
     with host_ops():
-        net(mx.nd.array(rng.standard_normal((2, 3, hw, hw)).astype(np.float32)))   # freezes the weights (0 -> 1)
+        if phase == "eval":
+            net(mx.nd.array(rng.standard_normal((2, 3, hw, hw)).astype(np.float32)))   # freezes the weights (0 -> 1)
         x = mx.nd.array(rng.standard_normal((bs, 3, hw, hw)).astype(np.float32))
-        net(x)                                                                       # warm (allocator, thread pools)
-        while t_total < budget_s * 0.5 and done < 4096:
-            t0 = time.perf_counter()
-            net(x)
-            t_total += time.perf_counter() - t0
-            done += bs
+        if phase == "calib-kl":
+            # the same calibration on the host: forward with quantisation disabled, every block's input histogrammed by the
+            # C++/OpenMP twin of the device kernel (the reference: single-threaded numpy over a host copy)
+            from quantization.mxnet_amd.quantize.distribution_calibrate import collect_feature_maps
+            net.disable_quantize()
+            collect_feature_maps(net, 2048, [(x, None)], mx.cpu())                   # warm
+            while t_total < budget_s * 0.5 and done < 1024:
+                t0 = time.perf_counter()
+                collect_feature_maps(net, 2048, [(x, None), (x, None)], mx.cpu())
+                t_total += time.perf_counter() - t0
+                done += 2 * bs
+        else:
+            net(x)                                                                   # warm (allocator, thread pools)
+            while t_total < budget_s * 0.5 and done < 4096:
+                t0 = time.perf_counter()
+                net(x)
+                if phase == "calib-naive":
+                    net.update_ema()
+                t_total += time.perf_counter() - t0
+                done += bs
     out = {"value": round(done / t_total, 3), "unit": "images/sec", "cores": threads, "kind": "port",
            "host_logical_cpus": cores,
            "threads": {"openmp_fake_quant": H.threads(), "torch_conv": torch.get_num_threads()},
-           "sample": "%d images (batches of %d) of the same int8-sim %s forward on the host: fake-quant = C++/OpenMP "
+           "sample": "%d images (batches of %d) of the same int8-sim %s %s on the host: fake-quant%s = C++/OpenMP "
                      "restatement of the reference's arithmetic (oracle/libfq_host.so, %d threads), conv/FC = torch-CPU "
-                     "(%d threads); %.1f s" % (done, bs, args.model, H.threads(), torch.get_num_threads(), t_total)}
+                     "(%d threads); %.1f s" % (done, bs, args.model,
+                                               {"eval": "forward", "calib-naive": "naive-EMA calibration step",
+                                                "calib-kl": "KL histogram collection"}[phase],
+                                               " / histograms" if phase == "calib-kl" else "", H.threads(),
+                                               torch.get_num_threads(), t_total)}
+    if phase != "eval":
+        return out
     # (2) fake-quant only, 27-layer sweep at batch 16, buffers allocated and touched before timing
     n = 16
     biggest = max(c * h * w for c, h, w in MOBILENET_ACTS) * n
@@ -234,6 +261,10 @@ def main():
     ap.add_argument("--offline", action="store_true",
                     help="offline input quantisation: two naive-EMA calibration steps fix the thresholds, then the timed "
                          "steps run with them (the evaluation phase of --quantize-input-offline)")
+    ap.add_argument("--phase", default="eval", choices=["eval", "calib-naive", "calib-kl"],
+                    help="eval (default): the evaluation forward; calib-naive: naive-EMA calibration steps "
+                         "(simulate_quantization.py:317-334); calib-kl: histogram collection of the KL calibration "
+                         "(:296-315, quantize/distribution_calibrate.py:50-114)")
     ap.add_argument("--rotate", type=int, default=4, help="distinct resident input batches cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--min-block-s", type=float, default=0.5,
@@ -289,9 +320,12 @@ def main():
     classes = 10 if args.model.startswith("cifar") else 1000
     hw = 32 if args.model.startswith("cifar") else 224
     ctx = mx.gpu(local_rank)
+    calib = args.phase != "eval"
+    if calib and args.offline:
+        raise SystemExit("bench.py: --offline describes the evaluation phase; a calibration phase produces the thresholds")
     net = build_net(args.model, classes, ctx, fuse=not args.no_fuse and not args.offline, quant_type=args.quant_type,
                     weight_bits=args.weight_bits, input_bits=args.input_bits, signed=args.input_signed, wino=args.wino,
-                    freeze=not args.offline)
+                    freeze=not args.offline and not calib)
     nblocks = len(net.collect_quantized_blocks())
 
     torch.manual_seed(7 + rank)
@@ -309,26 +343,69 @@ def main():
             net(batches[0])                           # the freezing forward
             from quantization.mxnet_amd.quantize import fuse as _fuse
             _fuse.fuse_inference(net)
+    from quantization.mxnet_amd import dist as fqdist
+    if args.phase == "calib-naive" and distributed:
+        # ONE all-reduce of L + 1 doubles per calibration step (dist.py; north_star's collective)
+        fqdist.attach_calibration_sync(net, args.batch_size)
+    if args.phase == "calib-kl":
+        net.disable_quantize()                        # fp32 inputs and weights while collecting (:298)
+    kl_extra = {}
 
     def step(i):
+        if args.phase == "calib-naive":               # evaluate(..., update_ema=True): forward, then the EMA of the thresholds
+            out = net(batches[i % rotate])._t
+            net.update_ema()
+            return out
         out = net(batches[i % rotate])._t
         ops.eval_counters(out, labels[i % rotate], counters)      # the eval loop's argmax + counters, one launch
         return out
+
+    class _KLBatches(object):
+        """The loader `collect_feature_maps` walks: `count` resident batches; kernel events are switched on for every
+        `event_every`-th of them, exactly as in the other phases."""
+
+        def __init__(self, first, count, sample_events):
+            self.first, self.count, self.sample_events = first, count, sample_events
+            self.profiled = 0
+
+        def __len__(self):
+            return self.count
+
+        def __iter__(self):
+            for i in range(self.first, self.first + self.count):
+                on = self.sample_events and (i % self.sample_events == 0)
+                ops.profile_enable(bool(on))
+                self.profiled += 1 if on else 0
+                yield batches[i % rotate], None
+            ops.profile_enable(False)
+
+    def kl_block(first, count, sample_events):
+        """`count` calibration batches through the product's own collect_feature_maps (hooks, first-batch ranges, exact
+        uint64 histograms on the device, one synchronisation and the fp32 conversion at the end)."""
+        from quantization.mxnet_amd.quantize.distribution_calibrate import collect_feature_maps
+        loader = _KLBatches(first, count, sample_events)
+        hists, ranges = collect_feature_maps(net, 2048, loader, ctx, sync=fqdist.kl_sync if distributed else None)
+        kl_extra["hists"], kl_extra["ranges"] = hists, ranges
+        return loader.profiled
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(max(args.warmup, rotate) if args.graph else args.warmup):
-        step(i)
+    if args.phase == "calib-kl":
+        if args.warmup:
+            kl_block(0, args.warmup, 0)
+    else:
+        for i in range(max(args.warmup, rotate) if args.graph else args.warmup):
+            step(i)
     torch.cuda.synchronize()
 
     # hipGraph replay of the step (one captured graph per resident input batch): the ~45 launches of a step are
     # launch-latency-sensitive (1.3 ms of kernels); replay removes the host from the loop.  The steps that carry the kernel
     # events of the roofline leg (every `event_every`-th) still run eagerly INSIDE the timed region.
     graphs, graph_error = None, None
-    if args.graph:
+    if args.graph and args.phase == "eval":
         try:
             graphs = []
             for b in range(rotate):
@@ -361,17 +438,20 @@ def main():
         nonlocal profiled_steps
         barrier()
         t0 = time.perf_counter()
-        for i in range(first_step, first_step + args.steps):
-            on = bool(event_every) and (i % event_every == 0)
-            if on:
-                ops.profile_enable(True)
-                profiled_steps += 1
-                step(i)
-                ops.profile_enable(False)
-            elif graphs is not None:
-                graphs[i % rotate].replay()
-            else:
-                step(i)
+        if args.phase == "calib-kl":
+            profiled_steps += kl_block(first_step, args.steps, event_every)
+        else:
+            for i in range(first_step, first_step + args.steps):
+                on = bool(event_every) and (i % event_every == 0)
+                if on:
+                    ops.profile_enable(True)
+                    profiled_steps += 1
+                    step(i)
+                    ops.profile_enable(False)
+                elif graphs is not None:
+                    graphs[i % rotate].replay()
+                else:
+                    step(i)
         barrier()
         dt = time.perf_counter() - t0
         if distributed:
@@ -388,6 +468,20 @@ def main():
         while sum(blocks) < args.min_region_s and len(blocks) < args.max_repeats:
             blocks.append(timed_block(len(blocks) * args.steps))
     elapsed = float(np.median(blocks))
+    kl_search_ms, thresholds = None, None
+    if args.phase == "calib-kl":
+        # the threshold search over all layers: ONE launch (reference: ~1.4 s of Python per layer); once per calibration
+        from quantization.mxnet_amd.quantize.distribution_calibrate import kl_calibrate_many
+        blocks_q = net.collect_quantized_blocks()
+        levels = 2 ** (args.input_bits - 1 if args.input_signed else args.input_bits)
+        hs = [kl_extra["hists"][b] for b in blocks_q]
+        kl_calibrate_many(hs, levels=levels, min_bins=levels, bins=2048, device=dev)          # warm
+        torch.cuda.synchronize()
+        t_kl = time.perf_counter()
+        best = kl_calibrate_many(hs, levels=levels, min_bins=levels, bins=2048, device=dev)
+        torch.cuda.synchronize()
+        kl_search_ms = (time.perf_counter() - t_kl) * 1e3
+        thresholds = [float((bb + 0.5) * (kl_extra["ranges"][b] / 2048)) for bb, b in zip(best, blocks_q)]
     prof = ops.profile_read()
     ops.profile_reset()
     # A bracketing event pair adds a fixed cost to every launch it times (two marker packets + dispatch latency): the
@@ -437,17 +531,27 @@ def main():
                                                   "offline" if args.offline else "online")
         if args.wino != "none":
             flavour += ", Winograd-domain %s weights" % args.wino
+        what_step = {"eval": "eval forward + accuracy counters",
+                     "calib-naive": "naive-EMA calibration step: forward with ONLINE scales, weights re-quantised every "
+                                    "forward (fixed_params = -1), then net.update_ema()",
+                     "calib-kl": "KL calibration batch: forward with quantisation disabled + one 2048-bin histogram per "
+                                 "quantised block (collect_feature_maps, ranges fixed by the first batch)"}[args.phase]
+        metric_head = {"eval": "images/sec int8-sim", "calib-naive": "images/sec naive-EMA calibration of int8-sim",
+                       "calib-kl": "images/sec KL-calibration histogram collection of int8-sim"}[args.phase]
         line = {
-            "metric": "images/sec int8-sim %s (%s)" % ("MobileNet1.0" if args.model == "mobilenet1.0" else args.model,
-                                                       flavour),
+            "metric": "%s %s (%s)" % (metric_head, "MobileNet1.0" if args.model == "mobilenet1.0" else args.model, flavour),
             "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s ImageNet-shaped (%d,3,%d,%d)/GPU, %s, first conv excluded, %d fake-quantised "
-                                   "blocks, eval forward + accuracy counters, %d resident input batches cycled"
-                                   % (args.model, args.batch_size, hw, hw, flavour, nblocks, rotate),
+                                   "blocks, %s, %d resident input batches cycled"
+                                   % (args.model, args.batch_size, hw, hw, flavour, nblocks, what_step, rotate),
+                       "phase": args.phase,
                        "global_batch": world * args.batch_size, "parallelism": "dp%d (replicated weights, sharded "
-                       "batch, no data-path collective; counters all-reduced once)" % world,
+                       "batch; %s)" % (world, {"eval": "no data-path collective; counters all-reduced once",
+                                               "calib-naive": "ONE all-reduce of L+1 doubles per calibration step",
+                                               "calib-kl": "ranges broadcast after the first batch, ONE all-reduce of the "
+                                                           "exact histograms at the end"}[args.phase]),
                        "hipgraph": graphs is not None, "hipgraph_error": graph_error,
                        "fused_producers": not args.no_fuse},
             "roofline": {"bound": "hbm", "kernel": dk["kernel"], "achieved": dk["achieved"], "peak": HBM_PEAK_GBS,
@@ -475,7 +579,14 @@ def main():
                               "what": "fq_eval_counters over every step run so far (warm-up included), summed over "
                                       "the ranks in ONE all-reduce after the timed region"},
         }
-        if world == 1 and not args.no_headline:
+        if args.phase != "eval":
+            del line["eval_counters"]
+        if args.phase == "calib-kl":
+            line["kl_search"] = {"ms": round(kl_search_ms, 3), "layers": nblocks,
+                                 "what": "fq_kl_search over all layers' histograms in one launch + the read-back of "
+                                         "best_bins, once per calibration (outside the per-batch figure)",
+                                 "thresholds_first_last": [round(thresholds[0], 6), round(thresholds[-1], 6)]}
+        if world == 1 and not args.no_headline and args.phase == "eval":
             line["headline_tensor"] = headline_tensor(dev, ops)
         if world == 1:
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args, classes, hw)

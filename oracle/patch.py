@@ -469,7 +469,23 @@ def _host_fns():
         counters.copy_(torch.from_numpy(H.eval_counters(_a(logits), _a(labels), _a(counters))))
         return counters
 
-    return {"absmax_per_sample": h_absmax_per_sample, "fake_quant_online": h_fake_quant_online,
+    def h_global_max(x):
+        return torch.tensor([H.global_max(_a(x))], dtype=torch.float32)
+
+    def h_histogram_accumulate(x, max_dev, hist, neg_count=None):
+        mx = float(_a(max_dev).reshape(-1)[0])
+        if mx > 0:
+            h, neg = H.histogram_accumulate(_a(x).reshape(-1), mx, hist.numel())
+            hist += torch.from_numpy(h.astype(np.int64))
+            if neg_count is not None:
+                neg_count += int(neg)
+        return hist
+
+    def h_kl_search(hist, levels, min_bins):
+        return torch.from_numpy(H.kl_search(_a(hist), levels, min_bins))
+
+    return {"global_max": h_global_max, "histogram_accumulate": h_histogram_accumulate, "kl_search": h_kl_search,
+            "absmax_per_sample": h_absmax_per_sample, "fake_quant_online": h_fake_quant_online,
             "fake_quant_online_prestat": h_fake_quant_online_prestat, "fake_quant_offline": h_fake_quant_offline,
             "weight_fake_quant": h_weight_fake_quant, "eval_counters": h_eval_counters}
 
