@@ -294,6 +294,26 @@ int fq_wino_weight_fake_quant(const float* w, float* w_q, int64_t cout, int64_t 
                               const float* GI, const float* GTI, int width, float* scales_out, void* ws,
                               fqStream_t stream);
 
+/* ---- multi-GPU calibration collectives over RCCL ------------------------------------------------
+ * The reference is single-device; sharding the calibration / evaluation batch over the GPUs of a node needs three tiny
+ * exchanges (all <= 434 KB, latency-bound, issued on the compute stream): the all-reduce(sum) of L + 1 doubles per
+ * naive-EMA calibration step (fq_stat_rows_sum -> HERE -> fq_mean_from_sums, then fq_ema_update: every rank applies
+ * `_update_ema`, convert.py:66-79, with the batch mean of the GLOBAL batch), the all-reduce of the exact int64 KL
+ * histograms (distribution_calibrate.py:103-104) and of the evaluation counters (simulate_quantization.py:123-147).
+ * One process per GPU, one communicator per process, on the HIP device current at fq_comm_init.  librccl.so is bound at
+ * run time (no link-time dependency).  Rank 0 calls fq_comm_unique_id and ships the 128 bytes to the other ranks by any
+ * channel it has (kvstore, MPI, a file); every rank then calls fq_comm_init(rank, world, id).                          */
+#define FQ_COMM_UNIQUE_ID_BYTES 128
+#define FQ_COMM_SUM 0
+#define FQ_COMM_MAX 1
+int fq_comm_unique_id(void* id128);
+int fq_comm_init(int rank, int world, const void* id128);
+int fq_comm_world(void);   /* ranks of the live communicator, 0 when there is none */
+int fq_allreduce_f32(float* buf, int64_t count, int op, fqStream_t stream);   /* in place, device pointer */
+int fq_allreduce_f64(double* buf, int64_t count, int op, fqStream_t stream);
+int fq_allreduce_i64(int64_t* buf, int64_t count, int op, fqStream_t stream);
+int fq_comm_destroy(void);
+
 /* ---- calibration -------------------------------------------------------------------------------------------------
  * Replaces `_update_ema` (convert.py:66-79) for L scalars at once: state <- (1-m)*current + m*state.            */
 int fq_ema_update(float* state, const float* current, int64_t count, double momentum, fqStream_t stream);

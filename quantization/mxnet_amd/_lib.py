@@ -60,6 +60,13 @@ EXPORTS = {
     "fq_weight_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "fq_weight_fake_quant": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
     "fq_wino_weight_fake_quant": (_int, [_vp, _vp, _i64, _i64, _int, c_f32p, c_f32p, c_f32p, _int, _vp, _vp, _vp]),
+    "fq_comm_unique_id": (_int, [_vp]),
+    "fq_comm_init": (_int, [_int, _int, _vp]),
+    "fq_comm_world": (_int, []),
+    "fq_allreduce_f32": (_int, [_vp, _i64, _int, _vp]),
+    "fq_allreduce_f64": (_int, [_vp, _i64, _int, _vp]),
+    "fq_allreduce_i64": (_int, [_vp, _i64, _int, _vp]),
+    "fq_comm_destroy": (_int, []),
     "fq_ema_update": (_int, [_vp, _vp, _i64, ctypes.c_double, _vp]),
     "fq_global_max": (_int, [_vp, _i64, _vp, _vp]),
     "fq_histogram_accumulate": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _vp]),

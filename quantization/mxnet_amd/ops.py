@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import FakeQuantError
 
-__all__ = ["add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -681,6 +681,41 @@ def wino_weight_fake_quant(w, variant, width=8, out=None, want_scales=False, GI=
                                                  GI.ctypes.data_as(fp), GTI.ctypes.data_as(fp), int(width),
                                                  _ptr(scales), ctypes.c_void_p(0), _stream(w)))
     return (wq, scales) if want_scales else wq
+
+
+# ---- RCCL collectives of the C ABI (for integrators without torch.distributed; dist.py itself uses torch.distributed) ------
+COMM_SUM, COMM_MAX = 0, 1
+
+
+def comm_unique_id():
+    """128 opaque bytes made by rank 0 (ncclGetUniqueId); ship them to every other rank, then `comm_init` everywhere."""
+    buf = ctypes.create_string_buffer(128)
+    check_call(_lib_().fq_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(rank, world, unique_id):
+    if len(unique_id) != 128:
+        raise ValueError("the unique id is 128 bytes (got %d)" % len(unique_id))
+    check_call(_lib_().fq_comm_init(int(rank), int(world), ctypes.create_string_buffer(bytes(unique_id), 128)))
+
+
+def comm_world():
+    return int(_lib_().fq_comm_world())
+
+
+def comm_allreduce(t, op=COMM_SUM):
+    """In-place all-reduce of a contiguous fp32 / fp64 / int64 device tensor over the library's RCCL communicator."""
+    fn = {torch.float32: "fq_allreduce_f32", torch.float64: "fq_allreduce_f64", torch.int64: "fq_allreduce_i64"}.get(t.dtype)
+    if fn is None:
+        raise TypeError("comm_allreduce takes fp32, fp64 or int64 tensors (got %s)" % t.dtype)
+    _check(t, "t", t.dtype)
+    check_call(getattr(_lib_(), fn)(_ptr(t), t.numel(), int(op), _stream(t)))
+    return t
+
+
+def comm_destroy():
+    check_call(_lib_().fq_comm_destroy())
 
 
 def ema_update(state, current, momentum=0.9):

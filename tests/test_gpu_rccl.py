@@ -91,3 +91,62 @@ def test_two_ranks_on_one_gpu_over_rccl(gpu, tmp_path):
     np.testing.assert_array_equal(r[0]["step"][:, 0], np.asarray(ema, np.float32)[:, 0])
     with open(log, "a") as f:
         f.write("RCCL path executed: strict and one-collective-per-step modes agree across ranks; strict equals one device\n")
+
+
+def test_c_abi_collectives_over_rccl_with_one_rank(gpu):
+    """fq_comm_unique_id / fq_comm_init / fq_allreduce_{f32,f64,i64} / fq_comm_destroy (the collectives an
+    integrator without torch.distributed binds) really go through librccl on the device; with one rank an all-reduce is
+    the identity, and the calibration step built from them - fq_stat_rows_sum -> all-reduce -> fq_mean_from_sums ->
+    fq_ema_update - equals the single-device batch mean + EMA.  Runs in a child process (a communicator per process)."""
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from quantization.mxnet_amd import ops
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+assert ops.comm_world() == 0
+uid = ops.comm_unique_id()
+assert len(uid) == 128
+ops.comm_init(0, 1, uid)
+assert ops.comm_world() == 1
+a = torch.arange(1000, dtype=torch.float32, device=dev) * 0.5
+b = torch.arange(54, dtype=torch.float64, device=dev) + 0.25
+c = torch.arange(53 * 2048, dtype=torch.int64, device=dev)
+for t in (a, b, c):
+    want = t.clone()
+    ops.comm_allreduce(t, ops.COMM_SUM)
+    ops.comm_allreduce(t, ops.COMM_MAX)
+    torch.cuda.synchronize()
+    assert torch.equal(t, want), t.dtype
+# one calibration step through the C ABI only
+stats = torch.rand(5, 8, device=dev)
+rec = torch.zeros(6, dtype=torch.float64, device=dev)
+ops.stat_rows_sum(stats, 8, out=rec)
+ops.comm_allreduce(rec)
+means = torch.zeros(5, device=dev)
+ops.mean_from_sums(rec, out=means)
+want = torch.stack([ops.batch_mean(stats[i].contiguous())[0] for i in range(5)])
+assert torch.equal(means, want)
+try:
+    ops.comm_init(0, 1, uid)
+    raise SystemExit("second fq_comm_init did not fail")
+except Exception as e:
+    assert "already exists" in str(e), e
+ops.comm_destroy()
+assert ops.comm_world() == 0
+ops.comm_destroy()
+print("C-ABI collectives ok")
+""" % ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "C-ABI collectives ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+def test_c_abi_collectives_validate_arguments():
+    from quantization.mxnet_amd import _lib
+    import ctypes
+    assert _lib.LIB.fq_comm_world() == 0
+    rc = _lib.LIB.fq_allreduce_f32(ctypes.c_void_p(8), 4, 0, None)
+    assert rc != 0 and b"fq_comm_init first" in _lib.LIB.fq_last_error()
+    rc = _lib.LIB.fq_comm_init(3, 2, ctypes.create_string_buffer(128))
+    assert rc != 0 and b"rank 3 of 2" in _lib.LIB.fq_last_error()

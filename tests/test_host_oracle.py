@@ -33,7 +33,10 @@ def test_host_library_exports_every_declared_symbol():
     dev = re.sub(r"/\*.*?\*/", "", dev, flags=re.S)
     skip = {"fq_device_info", "fq_profile_enable", "fq_profile_reset", "fq_profile_read", "fq_profile_calibrate",
             "fq_act_workspace_bytes", "fq_pwconv_workspace_bytes", "fq_weight_workspace_bytes",
-            "fq_kl_workspace_bytes"}
+            "fq_kl_workspace_bytes",
+            # transport, not arithmetic: the RCCL collectives of multi-GPU calibration
+            "fq_comm_unique_id", "fq_comm_init", "fq_comm_world", "fq_allreduce_f32", "fq_allreduce_f64",
+            "fq_allreduce_i64", "fq_comm_destroy"}
     for name in sorted(set(re.findall(r"\b(fq_[a-z0-9_]+)\s*\(", dev)) - skip):
         assert name + "_host" in declared, "no host twin for " + name
 
