@@ -272,6 +272,27 @@ int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, con
                   const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
                   const float* bn_shift, int act, float* stat_out, fqStream_t stream);
 
+/* The same convolution for weights that are NOT integer multiples of one scale per output channel: the filters the
+ * reference obtains under Winograd-domain quantisation (convert_conv2d.py:71-83: U^ = STE(s)(G g G^T) lives on the int8
+ * grid, the spatial filter g^ = GI U^ GTI that F.Convolution then multiplies does not) - BASELINE config 5.  The filter is
+ * split into THREE int8 slices by fq_weight_slices: per output channel p = 2^e, the smallest power of two with
+ * max|g^| <= p * 2^20;  m = rint(g^ / p)  (|m| <= 2^20, exact division);  m = d1 2^14 + d2 2^7 + d3, digits in [-64, 64].
+ * Every slice is an exact int32 convolution on the matrix cores over the SAME quantised activations; the epilogue forms
+ * T = (S1 << 14) + (S2 << 7) + S3 in 64 bits and y = fp32(fp64(T) * fp64(sx * p)), then bias / BatchNorm / activation /
+ * statistic as fq_conv3x3_i8.  The sum over the 9 * Cin products is exact; the only error is the filter's representation,
+ * p / 2 <= 2^-20 of its channel maximum per weight - the order of the rounding an fp32 convolution of the same two tensors
+ * accumulates over 576 ... 4608 products (each product and partial sum rounds at 2^-24 there; parity test: within
+ * 3e-6 of the largest output of the fp64 convolution).
+ * fq_weight_slices: w (rows, row_len) fp32, here the filter permuted to (cout, 3, 3, cin);  codes: 3 buffers of
+ * 2 * rows_pad * row_pad bytes each (row-major codes, then fq_weight_codes' fragment-major copy), slice 1 = d1 first;
+ * pscale[rows] = p;  rowsum[3][rows];  ws: rows floats.  cout % 32 == 0.                                                  */
+int fq_weight_slices(const float* w, int64_t rows, int64_t row_len, int64_t row_pad, int64_t rows_pad, int8_t* codes,
+                     float* pscale, int32_t* rowsum, void* ws, fqStream_t stream);
+int fq_conv3x3_i8_sliced(const float* x, const int8_t* wslices, const float* pscale, const int32_t* wsum, const float* bias,
+                         float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* in_stat,
+                         const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                         const float* bn_scale, const float* bn_shift, int act, float* stat_out, fqStream_t stream);
+
 /* Generic LinearQuantizeSTE.forward (ste_func.py:37-41) for API completeness: x viewed as (rows, row_len) with one
  * scale per row read from the DEVICE array `scales` (rows = 1: scalar scale; rows = Cout: (Cout,1,1,1) broadcast):
  *   y = roundf( (has_clip ? clip(x, clip_lo, clip_hi) : x) / (scales[r] + eps) ) * scales[r].                    */

@@ -87,6 +87,13 @@ int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale
                        const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
                        float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
                        fqStream_t stream);
+int fq_weight_slices_host(const float* w, int64_t rows, int64_t row_len, int64_t row_pad, int64_t rows_pad, int8_t* codes,
+                          float* pscale, int32_t* rowsum, void* ws, fqStream_t stream);
+int fq_conv3x3_i8_sliced_host(const float* x, const int8_t* wslices, const float* pscale, const int32_t* wsum,
+                              const float* bias, float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
+                              const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                              float* out_current_max, const float* bn_scale, const float* bn_shift, int act,
+                              float* stat_out, fqStream_t stream);
 int fq_ste_forward_host(const float* x, float* y, int64_t rows, int64_t row_len, const float* scales, int has_clip,
                         float clip_lo, float clip_hi, float eps, fqStream_t stream);
 int fq_weight_fake_quant_host(const float* w, float* w_q, int64_t rows, int64_t row_len, int width,

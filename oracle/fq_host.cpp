@@ -667,6 +667,103 @@ int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale
   return FQ_OK;
 }
 
+// fq_weight_slices: per row p = 2^e (smallest power of two with max|w| <= p * 2^20), m = rint(w / p), balanced base-128
+// digits; codes: 3 buffers of 2 * rows_pad * row_pad bytes - the row-major digits in the first half (the fragment-major
+// second half is a device layout and stays zero here).
+int fq_weight_slices_host(const float* w, int64_t rows, int64_t row_len, int64_t row_pad, int64_t rows_pad, int8_t* codes,
+                          float* pscale, int32_t* rowsum, void*, fqStream_t) {
+  REQUIRE(w && codes && pscale && rowsum && rows > 0 && row_len > 0 && row_pad >= row_len && rows_pad >= rows,
+          "fq_weight_slices_host: bad arguments");
+  const int64_t slice = 2 * rows_pad * row_pad;
+  memset(codes, 0, (size_t)(3 * slice));
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; ++r) {
+    float mx = 0.0f;
+    for (int64_t i = 0; i < row_len; ++i) mx = std::max(mx, std::fabs(w[r * row_len + i]));
+    int e = 0;
+    if (mx > 0.0f) {
+      (void)std::frexp(mx, &e);
+      if (std::ldexp(1.0f, e - 1) == mx) e -= 1;
+    }
+    const float p = mx > 0.0f ? std::ldexp(1.0f, e - 20) : 1.0f;
+    int32_t a[3] = {0, 0, 0};
+    for (int64_t i = 0; i < row_len; ++i) {
+      const int m = (int)std::rint(w[r * row_len + i] / p);
+      const int d3 = ((m + 64) & 127) - 64;
+      const int m1 = (m - d3) >> 7;
+      const int d2 = ((m1 + 64) & 127) - 64;
+      const int d1 = (m1 - d2) >> 7;
+      codes[0 * slice + r * row_pad + i] = (int8_t)d1;
+      codes[1 * slice + r * row_pad + i] = (int8_t)d2;
+      codes[2 * slice + r * row_pad + i] = (int8_t)d3;
+      a[0] += d1; a[1] += d2; a[2] += d3;
+    }
+    for (int sl = 0; sl < 3; ++sl) rowsum[sl * rows + r] = a[sl];
+    pscale[r] = p;
+  }
+  return FQ_OK;
+}
+
+// The sliced dense 3x3 convolution: T = sum (d1 2^14 + d2 2^7 + d3) * cx exactly (64 bits), y = fp32(fp64(T) * fp64(sx * p)).
+int fq_conv3x3_i8_sliced_host(const float* x, const int8_t* wslices, const float* pscale, const int32_t* wsum,
+                              const float* bias, float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
+                              const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                              float* out_current_max, const float* bn_scale, const float* bn_shift, int act,
+                              float* stat_out, fqStream_t) {
+  REQUIRE(x && wslices && pscale && wsum && y, "fq_conv3x3_i8_sliced_host: null pointer");
+  REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "fq_conv3x3_i8_sliced_host: bad shape");
+  REQUIRE(in_stat != nullptr || in_thr != nullptr, "fq_conv3x3_i8_sliced_host: give in_stat, in_thr or both");
+  REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_conv3x3_i8_sliced_host: bn_scale and bn_shift go together");
+  const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  zero_stat(stat_out, n, prezeroed);
+  const float max_ = in_thr ? in_thr[0] : batch_mean(in_stat, n);
+  if (in_stat && out_current_max) out_current_max[0] = in_thr ? batch_mean(in_stat, n) : max_;
+  const QP q = make_qp(max_, act_levels(in_width, in_flags), (in_flags & FQ_ACT_LO_NEG_MAX) != 0, kEps);
+  const float sx = q.scale;
+  const int64_t hw = h * w, k9 = 9 * cin;
+  const int64_t rows_pad = (cout + 63) / 64 * 64, slice = 2 * rows_pad * k9;
+#pragma omp parallel
+  {
+    std::vector<int32_t> cx((size_t)(cin * (h + 2) * (w + 2)));
+    std::vector<int64_t> acc((size_t)hw);
+#pragma omp for schedule(static)
+    for (int64_t s = 0; s < n; ++s) {
+      std::fill(cx.begin(), cx.end(), 0);
+      for (int64_t ci = 0; ci < cin; ++ci)
+        for (int64_t r = 0; r < h; ++r)
+          for (int64_t c = 0; c < w; ++c)
+            cx[(size_t)((ci * (h + 2) + r + 1) * (w + 2) + c + 1)] = (int32_t)code_of(x[((s * cin + ci) * h + r) * w + c], q);
+      for (int64_t co = 0; co < cout; ++co) {
+        std::fill(acc.begin(), acc.end(), 0);
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          for (int64_t ci = 0; ci < cin; ++ci) {
+            const int64_t at = co * k9 + tap * cin + ci;
+            const int64_t m = ((int64_t)wslices[at] << 14) + ((int64_t)wslices[slice + at] << 7) + (int64_t)wslices[2 * slice + at];
+            if (m == 0) continue;
+            const int32_t* src = &cx[(size_t)((ci * (h + 2) + ky) * (w + 2) + kx)];
+            for (int64_t r = 0; r < h; ++r)
+              for (int64_t c = 0; c < w; ++c) acc[(size_t)(r * w + c)] += m * src[r * (w + 2) + c];
+          }
+        }
+        const float sxp = sx * pscale[co];
+        for (int64_t p = 0; p < hw; ++p) {
+          float v = (float)((double)acc[(size_t)p] * (double)sxp);
+          if (bias) v = v + bias[co];
+          if (bn_scale) {
+            v = v * bn_scale[co];
+            v = v + bn_shift[co];
+          }
+          y[(s * cout + co) * hw + p] = act_of(v, act);
+        }
+      }
+    }
+  }
+  stat_of_output(y, n, cout * hw, stat_out);
+  return FQ_OK;
+}
+
 // ---- weights ------------------------------------------------------------------------------------------------------
 // LinearQuantizeSTE.forward, ste_func.py:37-41
 int fq_ste_forward_host(const float* x, float* y, int64_t rows, int64_t row_len, const float* scales, int has_clip,

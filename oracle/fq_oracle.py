@@ -532,6 +532,64 @@ def conv3x3_i8(x, w, rows_per_scale, wt_width, in_max, signed=False, width=8, lo
     return y.astype(F32)
 
 
+def weight_slices(w):
+    """Arithmetic of `fq_weight_slices` for a (rows, ...) fp32 filter: per row p = 2^e (smallest power of two with
+    max|w| <= p * 2^20), m = rint(w / p) as int64 (|m| <= 2^20).  Returns (m, p); the three int8 digits of m in balanced base
+    128 are `slice_digits(m)`."""
+    w = np.asarray(w, dtype=F32)
+    rows = w.shape[0]
+    flat = w.reshape(rows, -1)
+    mx = np.abs(flat).max(axis=1)
+    p = np.ones(rows, F32)
+    nz = mx > 0
+    f, e = np.frexp(mx[nz])                                    # mx = f * 2^e, 0.5 <= f < 1
+    e = np.where(f == 0.5, e - 1, e)                           # a power of two itself
+    p[nz] = np.ldexp(F32(1), e - 20).astype(F32)
+    m = np.rint((flat / p[:, None]).astype(F32)).astype(np.int64)
+    return m.reshape(w.shape), p
+
+
+def slice_digits(m):
+    d3 = ((m + 64) & 127) - 64
+    m1 = (m - d3) >> 7
+    d2 = ((m1 + 64) & 127) - 64
+    d1 = (m1 - d2) >> 7
+    return d1, d2, d3
+
+
+def conv3x3_i8_sliced(x, w, in_max, signed=False, width=8, lo_neg_max=None, bias=None, bn_scale=None, bn_shift=None,
+                      act=None):
+    """Arithmetic of `fq_conv3x3_i8_sliced`: integer codes of x, the filter as m * p per output channel (`weight_slices`),
+    T = sum m * cx EXACTLY (= (S1 << 14) + (S2 << 7) + S3 of the three digit slices), y = fp32(fp64(T) * fp64(sx * p)), then
+    bias / folded BN / activation.  w: (cout, cin, 3, 3) - the filter the convolution is to multiply (under Winograd-domain
+    quantisation: `wino_weight_fake_quant`'s output, convert_conv2d.py:79-83)."""
+    x = np.asarray(x, dtype=F32)
+    lo_neg = signed if lo_neg_max is None else lo_neg_max
+    sx = act_scale(in_max, signed, width)
+    cx = ste_codes(x, sx, in_max, F32(-F32(in_max)) if lo_neg else F32(0)).astype(np.int64)
+    m, p = weight_slices(w)
+    d1, d2, d3 = slice_digits(m)
+    assert np.array_equal((d1 << 14) + (d2 << 7) + d3, m) and max(np.abs(d).max() for d in (d1, d2, d3)) <= 65
+    N, C, H, W = x.shape
+    pad = np.zeros((N, C, H + 2, W + 2), np.int64)
+    pad[:, :, 1:-1, 1:-1] = cx
+    T = np.zeros((N, m.shape[0], H, W), np.int64)
+    for ky in range(3):
+        for kx in range(3):
+            T += np.einsum("oc,nchw->nohw", m[:, :, ky, kx], pad[:, :, ky:ky + H, kx:kx + W])
+    sxp = (F32(sx) * p).astype(F32)
+    y = (T.astype(np.float64) * sxp.astype(np.float64)[None, :, None, None]).astype(F32)
+    if bias is not None:
+        y = (y + np.asarray(bias, dtype=F32)[None, :, None, None]).astype(F32)
+    if bn_scale is not None:
+        return bn_act(y, bn_scale, bn_shift, act or "none")
+    if act == "relu":
+        y = np.maximum(y, F32(0))
+    elif act == "relu6":
+        y = np.minimum(np.maximum(y, F32(0)), F32(6))
+    return y.astype(F32)
+
+
 # ---- the reference's UNFUSED op chain, pass by pass (used as the CPU baseline workload) -------------------
 def unfused_reference_chain(x, signed=False, width=8):
     """What `_conv2d_forward` + `LinearQuantizeSTE.forward` execute on the reference's CPU path for one activation

@@ -295,6 +295,31 @@ def conv3x3_i8(x, w, rows_per_scale, wt_width, in_max=None, in_stat=None, signed
     return (y, stat) if want_stat else y
 
 
+def conv3x3_i8_sliced(x, w, in_max=None, in_stat=None, signed=False, width=8, lo_neg_max=None, bias=None, bn_scale=None,
+                      bn_shift=None, act=None, want_stat=False, want_slices=False):
+    """w: (cout, cin, 3, 3), any fp32 filter (under Winograd-domain quantisation: the back-transformed one): three int8
+    digit slices of the filter permuted to (cout, 3, 3, cin) (fq_weight_slices_host), then the exact sliced convolution."""
+    x = _f32(x)
+    n, cin, h, wd = x.shape
+    wp = np.ascontiguousarray(np.transpose(_f32(w), (0, 2, 3, 1)))
+    cout = wp.shape[0]
+    rows_pad = (cout + 63) // 64 * 64
+    codes = np.zeros((3, 2 * rows_pad * 9 * cin), np.int8)
+    pscale = np.empty(cout, F32)
+    rowsum = np.empty((3, cout), np.int32)
+    _call("fq_weight_slices_host", wp, cout, 9 * cin, 9 * cin, rows_pad, codes, pscale, rowsum, None, None)
+    y = np.empty((n, cout, h, wd), F32)
+    stat = np.zeros(n, F32) if want_stat else None
+    thr = None if in_max is None else np.asarray([in_max], F32).reshape(1)
+    cur = np.empty(1, F32)
+    _call("fq_conv3x3_i8_sliced_host", x, codes, pscale, rowsum, None if bias is None else _f32(bias), y, n, cin, cout, h, wd,
+          None if in_stat is None else _f32(in_stat), thr, _i(width), _u(act_flags(signed, lo_neg_max)), cur,
+          None if bn_scale is None else _f32(bn_scale), None if bn_shift is None else _f32(bn_shift), _i(_ACTS[act]), stat,
+          None)
+    out = (y, stat) if want_stat else y
+    return (out, codes, pscale, rowsum) if want_slices else out
+
+
 def ste_forward(x, scales, clip_max=None, clip_min=None, eps=1e-10):
     x = _f32(x)
     scales = _f32(scales).reshape(-1)

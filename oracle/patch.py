@@ -260,10 +260,47 @@ def weight_codes_3x3(w, rows_per_scale, width=8):
     return weight_codes(w.permute(0, 2, 3, 1).contiguous(), rows_per_scale, width)
 
 
+def weight_slices_3x3(w):
+    """(codes [3, 2 * rows_pad * row_pad] int8 with the row-major digits in the first half of every slice, pscale, rowsum)"""
+    wp = _np(w).transpose(0, 2, 3, 1)
+    rows = wp.shape[0]
+    flat = wp.reshape(rows, -1)
+    row_pad = (flat.shape[1] + 63) // 64 * 64
+    rows_pad = (rows + 63) // 64 * 64
+    m, p = O.weight_slices(flat)
+    codes = np.zeros((3, 2 * rows_pad * row_pad), np.int8)
+    rowsum = np.zeros((3, rows), np.int32)
+    for sl, d in enumerate(O.slice_digits(m)):
+        codes[sl, :rows_pad * row_pad].reshape(rows_pad, row_pad)[:rows, :flat.shape[1]] = d.astype(np.int8)
+        rowsum[sl] = d.sum(axis=1)
+    return _t(codes), _t(p), _t(rowsum)
+
+
 def conv3x3_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
                bn_scale=None, bn_shift=None, act=None, want_stat=True):
-    """codes rows are ordered (tap, ci) (weight_codes_3x3)"""
+    """codes rows are ordered (tap, ci) (weight_codes_3x3); three digit slices when they come from weight_slices_3x3"""
     signed, lo_neg, _, _ = _flags(flags)
+    if wcodes.dim() == 2 and wcodes.shape[0] == 3 and wsum.dim() == 2:
+        if in_stat is not None:
+            in_max = O.batch_mean(_np(in_stat).reshape(-1)[:x.shape[0]])
+            if cur_out is not None:
+                cur_out.copy_(_t(np.asarray([in_max], dtype=F32)))
+        if in_thr is not None:
+            in_max = F32(_np(in_thr).reshape(-1)[0])
+        a = _np(x)
+        n, cin, h, w = a.shape
+        p = _np(wscale)
+        cout = p.size
+        rows_pad = (cout + 63) // 64 * 64
+        d = [_np(wcodes)[sl, :rows_pad * 9 * cin].reshape(rows_pad, 9 * cin)[:cout].astype(np.int64) for sl in range(3)]
+        m = ((d[0] << 14) + (d[1] << 7) + d[2]).reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
+        wt = (m.astype(np.float64) * p.astype(np.float64)[:, None, None, None]).astype(F32)      # exact: |m| <= 2^20
+        y = O.conv3x3_i8_sliced(a, wt, in_max, signed=signed, width=width, lo_neg_max=lo_neg,
+                                bias=None if bias is None else _np(bias),
+                                bn_scale=None if bn_scale is None else _np(bn_scale),
+                                bn_shift=None if bn_shift is None else _np(bn_shift), act=act)
+        stat = _t(np.abs(y).reshape(n, -1).max(axis=1).astype(F32)) if want_stat else None
+        return _t(y.astype(F32)), stat
     if in_stat is not None:
         in_max = O.batch_mean(_np(in_stat).reshape(-1)[:x.shape[0]])
         if cur_out is not None:
@@ -399,7 +436,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

@@ -55,6 +55,9 @@ EXPORTS = {
                                     _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "fq_conv3x3_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                              _vp, _int, _vp, _vp]),
+    "fq_conv3x3_i8_sliced": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp,
+                                    _vp, _vp, _int, _vp, _vp]),
+    "fq_weight_slices": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fq_fake_quant_offline": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _uint, _vp, _vp, _vp, _vp]),
     "fq_ste_forward": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _f32, _f32, _f32, _vp]),
     "fq_weight_workspace_bytes": (ctypes.c_size_t, [_i64]),

@@ -23,6 +23,15 @@ namespace {
 //   4. epilogue as K2m: lane = pixel, BatchNorm / activation / per-sample statistic on store.
 // The halo makes a block's quantisation work (32 PT + 2 W + 2) / (32 PT) of its pixels (1.45 at 56x56 with PT = 8, 1.5 at
 // 7x7 with PT = 1) and channel groups repeat it - cheap next to the 9 * Cin * 32 multiply-adds per pixel and group.
+//
+// NSL = 3 (round 3): weights that are NOT integer multiples of one scale per channel - the Winograd-domain quantisation of
+// the reference (convert_conv2d.py:71-83: the int8 grid lives in the Winograd domain, the spatial filter is GI U^ GTI) - as
+// THREE int8 slices.  Per output channel p = 2^e with 2^e >= max|w| * 2^-20; m = rint(w / p) (|m| <= 2^20, the division is
+// exact) is written in balanced base 128, m = d1 2^14 + d2 2^7 + d3 with digits in [-64, 64]; every slice is an exact int32
+// convolution S_i = sum d_i * cx on the matrix cores, and the epilogue combines T = (S1 << 14) + (S2 << 7) + S3 in 64 bits:
+// y = fp32(T * (sx * p)).  The activations are quantised once and their fragments are shared by the three slices.  The
+// weights are represented to p / 2 <= 2^-20 of the channel maximum and the sum over 9 * Cin products is EXACT: an error of the
+// order an fp32 convolution of the same tensors accumulates by rounding every product and partial sum (fq_weight_slices below).
 struct C3Geom {
   int Cin, Cout, H, W, HW;
   int CS;                    // channel groups per pixel block = ceil(Cout / (32 * WC))
@@ -31,10 +40,12 @@ struct C3Geom {
   int ROW;                   // bytes per region pixel in the panel
   int64_t cols, items;       // n * HW; pixel blocks * CS
   int zoff;
+  int64_t slice_bytes;       // NSL = 3: bytes between the code buffers of two slices; rows between their row sums
+  int slice_rows;
 };
 
 // NW wavefronts per workgroup (4, or 8 for wide layers with few pixel blocks: half as many channel groups quantise a region)
-template <int KT, int PTW, int WC, int D, int LB, int NW>
+template <int KT, int PTW, int WC, int D, int LB, int NW, int NSL>
 __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, C3Geom g,
@@ -54,7 +65,7 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   float* c_bsc = c_sxw + NCH;
   float* c_bsh = c_bsc + NCH;
   float* c_bias = c_bsh + NCH;
-  int* c_zs = reinterpret_cast<int*>(c_bias + NCH);
+  int* c_zs = reinterpret_cast<int*>(c_bias + NCH);                     // [NSL][NCH]
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar (see K2m)
@@ -104,7 +115,8 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
     const bool ok = ch0 + i < g.Cout;
     const int ic = ok ? ch0 + i : 0;
     c_sxw[i] = ok ? sx * wscale[ic] : 0.0f;
-    c_zs[i] = ok ? g.zoff * wsum[ic] : 0;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) c_zs[sl * NCH + i] = ok ? g.zoff * wsum[sl * g.slice_rows + ic] : 0;
     c_bias[i] = ok && bias != nullptr ? bias[ic] : 0.0f;
     c_bsc[i] = has_bn && ok ? bn_scale[ic] : (ok ? 1.0f : 0.0f);
     c_bsh[i] = has_bn && ok ? bn_shift[ic] : 0.0f;
@@ -141,12 +153,18 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   // ---- 2. this wavefront's channel tile x PTW pixel tiles ---------------------------------------------------------------
   const int wc = wave % WC, wp = wave / WC;
   const int ctg = (int)cg * WC + wc;                                    // channel tile in the layer
-  const fq_rsrc wr = make_rsrc(wfrag + (((int64_t)ctg * NS) << 10), ctg < g.CTM ? (int64_t)NS * 1024 : 0);
+  // (NSL slices: one resource over all of them - the host checks that they lie within 2 GiB - and the slice in the scalar offset)
+  const fq_rsrc wr = make_rsrc(wfrag + (((int64_t)ctg * NS) << 10),
+                               ctg < g.CTM ? (int64_t)(NSL - 1) * g.slice_bytes + (int64_t)NS * 1024 : 0);
   const unsigned loff = (unsigned)lane * 16u;
-  auto a_frag = [&](int s) __attribute__((always_inline)) { return buf_ld_v4i(wr, loff, (unsigned)(s << 10)); };
-  v4i ring[RS];
+  auto a_frag = [&](int s, int sl) __attribute__((always_inline)) {
+    return buf_ld_v4i(wr, loff, (unsigned)(s << 10) + (unsigned)sl * (unsigned)g.slice_bytes);
+  };
+  v4i ring[RS][NSL];
 #pragma unroll
-  for (int d = 0; d < D; ++d) ring[d] = a_frag(d < NS ? d : NS - 1);
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) ring[d][sl] = a_frag(d < NS ? d : NS - 1, sl);
   // per pixel tile: the lane's pixel, its nine tap-validity bits, its panel row
   unsigned smp[PTW], pp[PTW], tapmask[PTW], rbase[PTW];
 #pragma unroll
@@ -174,11 +192,13 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   const int zb = g.zoff ? (int)0x80808080u : 0;                         // four codes "0" in the stored representation
   auto run = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
-    v16i acc[PTW];
+    v16i acc[NSL][PTW];
 #pragma unroll
-    for (int t = 0; t < PTW; ++t)
+    for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = 0;
+      for (int t = 0; t < PTW; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[sl][t][i] = 0;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int shift = ((tap / 3 - 1) * (int)W + (tap % 3 - 1)) * g.ROW;   // wave-uniform
@@ -194,7 +214,10 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
         constexpr int dummy = 0;
         (void)dummy;
         const int s = tap * KT + kt;
-        if (s + D < NS) ring[(s + D) % RS] = a_frag(s + D);
+        if (s + D < NS) {
+#pragma unroll
+          for (int sl = 0; sl < NSL; ++sl) ring[(s + D) % RS][sl] = a_frag(s + D, sl);
+        }
         v4i b[PTW];
 #pragma unroll
         for (int t = 0; t < PTW; ++t) {
@@ -205,8 +228,10 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
           b[t][3] = tv[t] ? raw[3] : zb;
         }
 #pragma unroll
-        for (int t = 0; t < PTW; ++t)
-          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[s % RS], b[t], acc[t], 0, 0, 0);
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+          for (int t = 0; t < PTW; ++t)
+            acc[sl][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[s % RS][sl], b[t], acc[sl][t], 0, 0, 0);
         FQ_PIN();
       }
     }
@@ -224,7 +249,9 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int c0 = cb + 8 * gq;
-        const v4i zs = *reinterpret_cast<const v4i*>(c_zs + c0);
+        v4i zs[NSL];
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) zs[sl] = *reinterpret_cast<const v4i*>(c_zs + sl * NCH + c0);
         const f4 sxw = *reinterpret_cast<const f4*>(c_sxw + c0);
         const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
@@ -232,7 +259,15 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
         if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = (float)(acc[t][4 * gq + r] + zs[r]) * sxw[r];
+          float v;
+          if (NSL == 1) {
+            v = (float)(acc[0][t][4 * gq + r] + zs[0][r]) * sxw[r];
+          } else {                                 // T = (S1 << 14) + (S2 << 7) + S3 exactly, then ONE rounding chain
+            long long T = 0;
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) T = (T << 7) + (long long)(acc[sl][t][4 * gq + r] + zs[sl][r]);
+            v = (float)((double)T * (double)sxw[r]);
+          }
           if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) v = v + bch[r];
           if (BN_M == 1 || (BN_M < 0 && has_bn)) {
             v = v * bsc[r];
@@ -275,16 +310,79 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   }
 }
 
+// fq_weight_slices: one workgroup per (padded) row.  p = 2^e, the smallest power of two with max|w| <= p * 2^20;
+// m = rint(w / p) (exact division; |m| <= 2^20); balanced base-128 digits d3 = ((m + 64) mod 128) - 64, ... so that
+// m = d1 2^14 + d2 2^7 + d3 with |d_i| <= 64 (d1: |m| / 2^14 + 1 <= 65).  Slice s: row-major codes, then the fragment-major
+// copy (weight_codes_kernel's layout), row sums for the re-centring of unsigned activation codes.
+__global__ __launch_bounds__(kBlock) void weight_slices_kernel(const float* __restrict__ w, int rows, int row_len, int row_pad,
+                                                               int rows_pad, const float* __restrict__ rmax,
+                                                               int8_t* __restrict__ codes, float* __restrict__ pscale,
+                                                               int* __restrict__ rowsum) {
+  __shared__ int red[3][4];
+  const int r = blockIdx.x;
+  const int kts = row_pad >> 5;
+  const int64_t slice = 2ll * rows_pad * row_pad;
+  auto put = [&](int sl, int i, int c) {
+    int8_t* base = codes + sl * slice;
+    base[(int64_t)r * row_pad + i] = (int8_t)c;
+    const int kt = i >> 5, hs = (i >> 4) & 1, b = i & 15;
+    base[(int64_t)rows_pad * row_pad + ((((int64_t)(r >> 5) * kts + kt) << 6) + (r & 31) + 32 * hs) * 16 + b] = (int8_t)c;
+  };
+  if (r >= rows) {
+    for (int i = threadIdx.x; i < row_pad; i += kBlock)
+      for (int sl = 0; sl < 3; ++sl) put(sl, i, 0);
+    return;
+  }
+  const float mx = rmax[r];
+  int e = 0;
+  if (mx > 0.0f) {
+    (void)frexpf(mx, &e);                                              // mx = f * 2^e, 0.5 <= f < 1  ->  mx < 2^e
+    if (ldexpf(1.0f, e - 1) == mx) e -= 1;                              // a power of two itself: mx = 2^(e-1)
+  }
+  const float p = mx > 0.0f ? ldexpf(1.0f, e - 20) : 1.0f;
+  int a0 = 0, a1 = 0, a2 = 0;
+  for (int i = threadIdx.x; i < row_pad; i += kBlock) {
+    int d1 = 0, d2 = 0, d3 = 0;
+    if (i < row_len) {
+      const int m = (int)rintf(w[(int64_t)r * row_len + i] / p);
+      d3 = ((m + 64) & 127) - 64;
+      const int m1 = (m - d3) >> 7;
+      d2 = ((m1 + 64) & 127) - 64;
+      d1 = (m1 - d2) >> 7;
+    }
+    put(0, i, d1);
+    put(1, i, d2);
+    put(2, i, d3);
+    a0 += d1; a1 += d2; a2 += d3;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_xor(a0, off, 64);
+    a1 += __shfl_xor(a1, off, 64);
+    a2 += __shfl_xor(a2, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a0;
+    red[1][threadIdx.x >> 6] = a1;
+    red[2][threadIdx.x >> 6] = a2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int sl = 0; sl < 3; ++sl) rowsum[sl * rows + r] = red[sl][0] + red[sl][1] + red[sl][2] + red[sl][3];
+    pscale[r] = p;
+  }
+}
+
 }  // namespace
 
 using namespace fqi;
 
-extern "C" {
+namespace {
 
-int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
-                  float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* in_stat,
-                  const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
-                  const float* bn_shift, int act, float* stat_out, fqStream_t stream) {
+int conv3x3_launch(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                   float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* in_stat,
+                   const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                   const float* bn_shift, int act, float* stat_out, fqStream_t stream, int nsl) {
   FQ_REQUIRE(x && wcodes && wscale && wsum && y, "fq_conv3x3_i8: null pointer");
   FQ_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0 && n * h * w < (1ll << 31) - 4096 && w < 4096,
              "fq_conv3x3_i8: bad shape");
@@ -316,7 +414,8 @@ int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, con
   // (measured in the ResNet-50 step: 256 @14x14 32.8 -> 28.6 us; 512 @7x7, where only 196 workgroups would remain, 34.1 -> 35.1)
   const bool nw8_fills = ((cols + 63) / 64) * ((cout + 255) / 256) >= (int64_t)num_cu();
   int nw = (nw_tune == 4 || nw_tune == 8) ? nw_tune : ((cout >= 256 && (kt == 8 || kt == 16) && nw8_fills) ? 8 : 4);
-  if (cout < 256 || !(kt == 8 || kt == 16)) nw = 4;
+  if (cout < 256 || !(kt == 8 || kt == 16) || nsl != 1) nw = 4;          // (the sliced form is built for four wavefronts)
+  if (nsl != 1) FQ_REQUIRE(cout % 32 == 0, "fq_conv3x3_i8_sliced: Cout must be a multiple of 32, got %lld", (long long)cout);
   const int wc = nw == 8 ? 8 : (cout >= 128 ? 4 : 2);
   const int wp = nw / wc;
   const int64_t cs = (cout + 32 * wc - 1) / (32 * wc);
@@ -332,38 +431,85 @@ int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, con
   g.CS = (int)cs; g.CTM = (int)(rows_pad / 32);
   g.RP = 32 * pt + 2 * (int)w + 2; g.RT = (g.RP + 31) / 32; g.ROW = (int)cin + 16;
   g.cols = cols; g.items = ((cols + 32 * pt - 1) / (32 * pt)) * cs; g.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;
+  g.slice_bytes = 2 * rows_pad * row_pad; g.slice_rows = (int)cout;
+  FQ_REQUIRE(nsl == 1 || 3 * g.slice_bytes < (1ll << 31), "fq_conv3x3_i8_sliced: the three weight slices must lie within 2 GiB");
   const int64_t grid = (g.items + 7) / 8 * 8;
   FQ_REQUIRE(grid < (1ll << 31), "fq_conv3x3_i8: too many pixel blocks");
-  const size_t lds = (size_t)g.RT * 32 * g.ROW + (size_t)(32 * wc) * 5 * sizeof(float);
+  const size_t lds = (size_t)g.RT * 32 * g.ROW + (size_t)(32 * wc) * (4 + nsl) * sizeof(float);
   FQ_REQUIRE(lds <= 150 * 1024, "fq_conv3x3_i8: the region of %d pixels x %d channels does not fit LDS", g.RP, (int)cin);
   const float levels = act_levels(in_width, in_flags);
   const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   ProfScope prof(FQ_KERNEL_CONV3X3, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), st);
   bool launched = false;
-#define FQ_C3_CASE_NW(KT_, PTW_, WC_, D_, LB_, NW_)                                                                    \
-  if (kt == KT_ && ptw == PTW_ && wc == WC_ && nw == NW_) {                                                            \
+#define FQ_C3_CASE_NS(KT_, PTW_, WC_, D_, LB_, NW_, NSL_)                                                               \
+  if (kt == KT_ && ptw == PTW_ && wc == WC_ && nw == NW_ && nsl == NSL_) {                                             \
     static const bool attr_ok =                                                                                        \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_i8_kernel<KT_, PTW_, WC_, D_, LB_, NW_>),           \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_i8_kernel<KT_, PTW_, WC_, D_, LB_, NW_, NSL_>),     \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;                     \
     FQ_REQUIRE(attr_ok, "fq_conv3x3_i8: cannot raise the dynamic LDS limit");                                          \
-    hipLaunchKernelGGL((conv3x3_i8_kernel<KT_, PTW_, WC_, D_, LB_, NW_>), dim3((unsigned)grid), dim3(NW_ * 64), lds, st, \
+    hipLaunchKernelGGL((conv3x3_i8_kernel<KT_, PTW_, WC_, D_, LB_, NW_, NSL_>), dim3((unsigned)grid), dim3(NW_ * 64), lds, st, \
                        x,                                                                                              \
                        wfrag, wscale, (const int*)wsum, bias, y, g, in_stat, (int)n, in_thr, levels, lo_neg, kEps,     \
                        out_current_max, bn_scale, bn_shift, act, stat_out);                                            \
     launched = true;                                                                                                   \
   }
+#define FQ_C3_CASE_NW(KT_, PTW_, WC_, D_, LB_, NW_) FQ_C3_CASE_NS(KT_, PTW_, WC_, D_, LB_, NW_, 1)
 #define FQ_C3_CASE(KT_, PTW_, WC_, D_, LB_) FQ_C3_CASE_NW(KT_, PTW_, WC_, D_, LB_, 4)
+  // three weight slices (Winograd-domain quantised filters): one or two pixel tiles per wavefront, two wavefronts per SIMD
+#define FQ_C3_SLICED(KT_)                                                                                              \
+  FQ_C3_CASE_NS(KT_, 1, 4, 3, 2, 4, 3) FQ_C3_CASE_NS(KT_, 2, 4, 2, 2, 4, 3)                                            \
+  FQ_C3_CASE_NS(KT_, 1, 2, 3, 2, 4, 3) FQ_C3_CASE_NS(KT_, 2, 2, 2, 2, 4, 3)
 #define FQ_C3_KT(KT_)                                                                                                  \
   FQ_C3_CASE(KT_, 1, 4, 6, 4) FQ_C3_CASE(KT_, 2, 4, 4, 4) FQ_C3_CASE(KT_, 4, 4, 3, 3)                                  \
   FQ_C3_CASE(KT_, 1, 2, 6, 4) FQ_C3_CASE(KT_, 2, 2, 4, 4) FQ_C3_CASE(KT_, 4, 2, 3, 3)
   FQ_C3_KT(2) FQ_C3_KT(4) FQ_C3_KT(8) FQ_C3_KT(16)
   FQ_C3_CASE_NW(8, 1, 8, 6, 4, 8) FQ_C3_CASE_NW(8, 2, 8, 4, 4, 8) FQ_C3_CASE_NW(16, 1, 8, 6, 4, 8) FQ_C3_CASE_NW(16, 2, 8, 4, 4, 8)
+  FQ_C3_SLICED(2) FQ_C3_SLICED(4) FQ_C3_SLICED(8) FQ_C3_SLICED(16)
+#undef FQ_C3_SLICED
 #undef FQ_C3_KT
 #undef FQ_C3_CASE
 #undef FQ_C3_CASE_NW
+#undef FQ_C3_CASE_NS
   FQ_REQUIRE(launched, "fq_conv3x3_i8: no instantiation for K/32=%d, %d pixel tiles per wavefront, %d channel tiles per "
              "workgroup", kt, ptw, wc);
+  FQ_LAUNCH_CHECK();
+  return FQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                  float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* in_stat,
+                  const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                  const float* bn_shift, int act, float* stat_out, fqStream_t stream) {
+  return conv3x3_launch(x, wcodes, wscale, wsum, bias, y, n, cin, cout, h, w, in_stat, in_thr, in_width, in_flags,
+                        out_current_max, bn_scale, bn_shift, act, stat_out, stream, 1);
+}
+
+int fq_conv3x3_i8_sliced(const float* x, const int8_t* wslices, const float* pscale, const int32_t* wsum, const float* bias,
+                         float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* in_stat,
+                         const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                         const float* bn_scale, const float* bn_shift, int act, float* stat_out, fqStream_t stream) {
+  return conv3x3_launch(x, wslices, pscale, wsum, bias, y, n, cin, cout, h, w, in_stat, in_thr, in_width, in_flags,
+                        out_current_max, bn_scale, bn_shift, act, stat_out, stream, 3);
+}
+
+int fq_weight_slices(const float* w, int64_t rows, int64_t row_len, int64_t row_pad, int64_t rows_pad, int8_t* codes,
+                     float* pscale, int32_t* rowsum, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(w && codes && pscale && rowsum && ws, "fq_weight_slices: null pointer");
+  FQ_REQUIRE(rows > 0 && row_len > 0, "fq_weight_slices: bad shape (rows=%lld row_len=%lld)", (long long)rows,
+             (long long)row_len);
+  FQ_REQUIRE(row_pad >= row_len && rows_pad >= rows && rows_pad < (1ll << 31) && row_pad % 32 == 0 && rows_pad % 32 == 0,
+             "fq_weight_slices: bad padding (row_pad and rows_pad must be multiples of 32)");
+  hipStream_t st = (hipStream_t)stream;
+  float* rmax = (float*)ws;
+  FQ_HIP(hipMemsetAsync(rmax, 0, rows * sizeof(float), st));
+  if (int rc = launch_absmax(w, rows, row_len, true, rmax, st)) return rc;
+  hipLaunchKernelGGL(weight_slices_kernel, dim3((unsigned)rows_pad), dim3(kBlock), 0, st, w, (int)rows, (int)row_len,
+                     (int)row_pad, (int)rows_pad, rmax, codes, pscale, (int*)rowsum);
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import FakeQuantError
 
-__all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -568,11 +568,33 @@ def weight_codes_3x3(w, rows_per_scale, width=8):
     return weight_codes(w.permute(0, 2, 3, 1).contiguous(), rows_per_scale, width)
 
 
+def weight_slices_3x3(w):
+    """Three int8 slices of a dense 3x3 filter that is not on one integer grid per channel (Winograd-domain quantised weights,
+    include/fakequant.h at fq_weight_slices), in conv3x3_i8's K order.  Returns (codes [3, 2 * rows_pad * row_pad] int8,
+    pscale (cout,), rowsum (3, cout) int32)."""
+    _check(w, "w")
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("expected a (Cout, Cin, 3, 3) weight, got %s" % (tuple(w.shape),))
+    wp = w.permute(0, 2, 3, 1).contiguous()
+    rows = wp.shape[0]
+    row_len = wp.numel() // rows
+    row_pad = (row_len + 63) // 64 * 64
+    rows_pad = (rows + 63) // 64 * 64
+    codes = torch.empty((3, 2 * rows_pad * row_pad), dtype=torch.int8, device=w.device)
+    pscale = torch.empty(rows, dtype=torch.float32, device=w.device)
+    rowsum = torch.empty((3, rows), dtype=torch.int32, device=w.device)
+    ws = _workspace(w.device, max(4 * rows, _lib_().fq_weight_workspace_bytes(rows)))
+    check_call(_lib_().fq_weight_slices(_ptr(wp), rows, row_len, row_pad, rows_pad, _ptr(codes), _ptr(pscale), _ptr(rowsum),
+                                        _ptr(ws), _stream(wp)))
+    return codes, pscale, rowsum
+
+
 def conv3x3_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
                bn_scale=None, bn_shift=None, act=None, want_stat=True):
     """Dense 3x3 convolution (stride 1, padding 1) on the integer codes (int8 MFMA, exact int32 accumulation) with
     quantise-on-load and fused BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; wcodes / wscale / wsum
-    from `weight_codes_3x3`.  Returns (y, stat or None)."""
+    from `weight_codes_3x3` - or from `weight_slices_3x3` (three int8 slices of a filter that is not on one integer grid:
+    Winograd-domain quantised weights; fq_conv3x3_i8_sliced).  Returns (y, stat or None)."""
     _check(x, "x")
     _check(wcodes, "wcodes", torch.int8)
     _check(wscale, "wscale")
@@ -585,12 +607,23 @@ def conv3x3_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wi
         raise ValueError("expected (N, Cin, H, W) activations, got %s" % (tuple(x.shape),))
     n, cin, h, w = x.shape
     cout = wscale.numel()
-    if wcodes.shape[1] != 9 * cin:
+    sliced = wcodes.dim() == 2 and wcodes.shape[0] == 3 and wsum.dim() == 2        # from `weight_slices_3x3`
+    if sliced:
+        rows_pad = (cout + 63) // 64 * 64
+        if wcodes.shape[1] != 2 * rows_pad * 9 * cin or (9 * cin) % 64:
+            raise ValueError("weight slices do not match Cin = %d, Cout = %d" % (cin, cout))
+    elif wcodes.shape[1] != 9 * cin:
         raise ValueError("weight codes have rows of %d, expected 9 * Cin = %d" % (wcodes.shape[1], 9 * cin))
     y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
     stat, zflag = _stat_target(n, x.device, want_stat)
     if in_stat is not None and cur_out is None:
         cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+    if sliced:
+        check_call(_lib_().fq_conv3x3_i8_sliced(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin,
+                                                cout, h, w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags),
+                                                _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift), _ACTS[act] | zflag,
+                                                _ptr(stat), _stream(x)))
+        return y, stat
     check_call(_lib_().fq_conv3x3_i8(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin, cout,
                                      h, w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(cur_out),
                                      _ptr(bn_scale), _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _stream(x)))

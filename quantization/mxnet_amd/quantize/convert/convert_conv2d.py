@@ -179,6 +179,14 @@ def _pointwise_weight_codes(block, args, weight_raw, weight_q):
     if block.fixed_params == 1 and held is not None and held[3] == key:
         return held[:3]
     three = block._fq_pw_fused.get("kind") == "3x3"
+    if block._fq_pw_fused.get("sliced"):
+        # Winograd-domain quantised 3x3 filters (convert_conv2d.py:71-83): the filter the convolution multiplies is
+        # weight_q itself (already GI U^ GTI), cut into three int8 digit slices - nothing to verify, the slices ARE the
+        # filter to p / 2 <= 2^-20 of its channel maximum (include/fakequant.h at fq_weight_slices)
+        codes = ops.weight_slices_3x3(contiguous(weight_q._t))
+        if block.fixed_params == 1:
+            block._fq_pw_cache = tuple(codes) + (key,)
+        return codes
     make = ops.weight_codes_3x3 if three else ops.weight_codes
     rederived = block.fixed_params == 1 and held is not None
     src = contiguous((weight_q if rederived else weight_raw)._t)

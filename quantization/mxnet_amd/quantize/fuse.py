@@ -133,17 +133,23 @@ def _is_pw1x1(b):
 
 def _is_dense3x3(b):
     """A converted dense 3x3 convolution (stride 1, padding 1) whose integer form fq_conv3x3_i8 takes: the 3x3 layers of the
-    ResNet units.  Not when the weights are quantised in the Winograd domain (they are no integer multiples of one scale in
-    the spatial domain then)."""
+    ResNet units.  Under Winograd-domain weight quantisation the spatial filter is not an integer multiple of one scale per
+    channel: it then goes through the three-slice form (fq_weight_slices + fq_conv3x3_i8_sliced; `_wino_sliced`), which
+    needs whole 32-channel tiles."""
     if type(b) is not nn.Conv2D or not hasattr(b, "quantize_args"):
         return False
     k = b._kwargs
     a = b.quantize_args
-    wino = a.quant_type == "channel" and a.wino_quantize != "none"
     cin = b.weight.shape[1] if b.weight.shape is not None and len(b.weight.shape) == 4 else 0
     return (k["kernel"] == (3, 3) and k["pad"] == (1, 1) and k["dilate"] == (1, 1) and k["stride"] == (1, 1)
-            and k["num_group"] == 1 and k["layout"] == "NCHW" and b.act is None and not a.fake_bn and not wino
-            and cin in (64, 128, 256, 512) and k["num_filter"] >= 32)
+            and k["num_group"] == 1 and k["layout"] == "NCHW" and b.act is None and not a.fake_bn
+            and cin in (64, 128, 256, 512) and k["num_filter"] >= 32
+            and (not _wino_sliced(b) or k["num_filter"] % 32 == 0))
+
+
+def _wino_sliced(b):
+    a = b.quantize_args
+    return a.quant_type == "channel" and a.wino_quantize != "none"
 
 
 def _is_stem3x3s2(b):
@@ -401,7 +407,7 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             act = _act_kind(nxt) if nxt is not None else None
             b._fq_pw_fused = {"bn": bn, "act": act or "none", "act_block": nxt if act else None,
                               "constants": _bn_constants_getter(bn) if bn is not None else None,
-                              "kind": "3x3" if dense3 else "1x1"}
+                              "kind": "3x3" if dense3 else "1x1", "sliced": bool(dense3 and _wino_sliced(b))}
             if bn is not None:
                 bn._fq_fused = {"taken_by_conv": True, "orig": bn.hybrid_forward, "act_block": None}
                 bn.hybrid_forward = types.MethodType(_identity_forward, bn)

@@ -212,8 +212,9 @@ def test_nn_conv2d_int_code_path_on_gpu(gpu, golden):
 @pytest.mark.parametrize("model,classes,hw,batch,kw", [("mobilenet1.0", 1000, 64, 4, dict()),
                                                        ("mobilenetv2_1.0", 1000, 64, 4, dict(quant_type="channel", wt=4)),
                                                        ("resnet50_v1", 1000, 64, 2, dict(quant_type="channel")),
+                                                       ("resnet50_v1", 1000, 64, 2, dict(quant_type="channel", wino="F43")),
                                                        ("cifar_resnet20_v1", 10, 32, 8, dict())],
-                         ids=["mobilenet1.0", "mobilenetv2_1.0", "resnet50_v1", "cifar_resnet20_v1"])
+                         ids=["mobilenet1.0", "mobilenetv2_1.0", "resnet50_v1", "resnet50_v1-wino-F43", "cifar_resnet20_v1"])
 def test_fused_inference_keeps_every_block_exact(gpu, model, classes, hw, batch, kw):
     """quantize/fuse.py: BN+ReLU(+statistic) in one pass, consumer skips its statistic pass.  Every quantised block
     must still be exactly oracle(its actual input); logits stay within BN-formula rounding of the unfused net."""
@@ -222,6 +223,8 @@ def test_fused_inference_keeps_every_block_exact(gpu, model, classes, hw, batch,
     net = _build(model, classes, gpu, **kw)
     rng = np.random.default_rng(7)
     X = mx.nd.array(rng.standard_normal((batch, 3, hw, hw)).astype(np.float32), ctx=gpu)
+    raw3x3 = {id(b): b.weight.data()._t.detach().cpu().numpy().copy() for b in net.collect_quantized_blocks()
+              if getattr(b, "_kwargs", {}).get("kernel") == (3, 3)}
     net.fix_params()
     net.quantize_input(enable=True, online=True)
     ref = net(X).asnumpy()
@@ -267,7 +270,7 @@ def test_fused_inference_keeps_every_block_exact(gpu, model, classes, hw, batch,
         ops.dwconv3x3 = real_dw
         ops.pwconv_i8 = real_pw
         ops.conv3x3_i8 = real_c3
-    args = dict(signed=False, in_w=8, wt=kw.get("wt", 8), quant_type=kw.get("quant_type", "layer"), wino="none")
+    args = dict(signed=False, in_w=8, wt=kw.get("wt", 8), quant_type=kw.get("quant_type", "layer"), wino=kw.get("wino", "none"))
     _check_records(spy.records, offline=False, allow_empty=True, **args)   # (mobilenetv2: every block is taken over)
     n_dw = sum(1 for b in spy.blocks if hasattr(b, "_fq_dw_fused"))
     # (a quantised Dense is a 1x1 convolution on a 1x1 plane: it goes through fq_pwconv_i8 as well)
@@ -278,6 +281,24 @@ def test_fused_inference_keeps_every_block_exact(gpu, model, classes, hw, batch,
     # the CIFAR ResNet-20
     assert (len(c3_calls) > 0) == (model in ("resnet50_v1", "cifar_resnet20_v1"))
     from oracle import patch as OP
+    if kw.get("wino", "none") != "none":
+        # config 5: the 3x3 layers of the bottlenecks leave MIOpen - the filter they multiply is the oracle's Winograd-domain
+        # fake-quantised filter (convert_conv2d.py:71-83), cut into three int8 digit slices whose value m * p reproduces it to
+        # p / 2 <= 2^-20 of the channel maximum
+        assert len(c3_calls) == 16 and all(c["codes"].dim() == 2 and c["codes"].shape[0] == 3 for c in c3_calls)
+        wino_blocks = [b for b in spy.blocks if id(b) in raw3x3 and getattr(b, "_fq_pw_fused", {}).get("sliced")]
+        assert len(wino_blocks) == 16
+        for b, call in zip(wino_blocks, c3_calls):
+            want_w = O.wino_weight_fake_quant(raw3x3[id(b)], kw["wino"], 8)[0]
+            assert np.array_equal(b.weight.data()._t.cpu().numpy(), want_w), "frozen Winograd-domain filter"
+            cout, cin = want_w.shape[:2]
+            rows_pad = (cout + 63) // 64 * 64
+            codes = call["codes"].cpu().numpy().astype(np.int64)
+            d = [codes[sl, :rows_pad * 9 * cin].reshape(rows_pad, 9 * cin)[:cout] for sl in range(3)]
+            m = ((d[0] << 14) + (d[1] << 7) + d[2]).reshape(cout, 3, 3, cin).transpose(0, 3, 1, 2)
+            p = call["scales"].cpu().numpy().astype(np.float64)
+            err = np.abs(m * p[:, None, None, None] - want_w.astype(np.float64)).reshape(cout, -1).max(axis=1)
+            assert np.all(err <= 2.0 ** -20 * np.abs(want_w).reshape(cout, -1).max(axis=1) + 1e-30)
     for call in c3_calls:
         k = call["k"]
         x_raw = call["x"].cpu()

@@ -789,6 +789,75 @@ def test_conv3x3_i8_vs_oracle(dev, ops, case, mode):
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
 
 
+C3S_CASES = [c for c in C3_CASES if c[2] % 32 == 0]
+
+
+@pytest.mark.parametrize("case", C3S_CASES, ids=["%dx%d->%d@%dx%d" % c for c in C3S_CASES])
+@pytest.mark.parametrize("mode", ["online_u8_bn_relu_wino", "offline_s8_bias"])
+def test_conv3x3_i8_sliced_vs_oracle(dev, ops, case, mode):
+    """fq_weight_slices + fq_conv3x3_i8_sliced (BASELINE config 5: filters under Winograd-domain quantisation are not on one
+    integer grid per channel): the three int8 digit slices and their power-of-two scale against the oracle, the convolution
+    bit for bit against the oracle's exact integer form, and within 2^-20 of the fp64 convolution of the very tensors the
+    reference's F.Convolution multiplies (fake-quantised activations x the given filter)."""
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + 19)
+    x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+    signed = "s8" in mode
+    if not signed:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * rng.uniform(0.02, 1.0, (cout, 1, 1, 1))).astype(np.float32)
+    if "wino" in mode:                                   # the filters config 5 really multiplies
+        wt = O.wino_weight_fake_quant(wt, "F43", 8)[0]
+    if cout >= 64:
+        wt[1] = 0.0                                      # an all-zero filter
+        wt[2, 0, 0, 0] = np.float32(2.0) ** -3           # its maximum a power of two
+        wt[2] = np.clip(wt[2], -0.125, 0.125)
+    codes, pscale, rowsum = ops.weight_slices_3x3(T(wt, dev))
+    m, p = O.weight_slices(wt.transpose(0, 2, 3, 1).reshape(cout, -1))
+    _eq(N(pscale), p, "per-channel power-of-two scale")
+    rows_pad = (cout + 63) // 64 * 64
+    for sl, d in enumerate(O.slice_digits(m)):
+        got = N(codes)[sl, :rows_pad * 9 * cin].reshape(rows_pad, 9 * cin)[:cout]
+        _eq(got, d.astype(np.int8), "digit slice %d" % sl)
+        _eq(N(rowsum)[sl], d.sum(axis=1).astype(np.int32), "row sums of slice %d" % sl)
+    kw, okw = {}, {}
+    if mode.startswith("online"):
+        stat = O.absmax_per_sample(x)
+        kw.update(in_stat=T(stat, dev), width=8, flags=ops.act_flags(signed=signed))
+        okw.update(in_max=O.batch_mean(stat), signed=signed, width=8)
+    else:
+        thr = np.float32(2.3)
+        kw.update(in_thr=T(np.float32([thr]), dev), width=8, flags=ops.act_flags(signed=True))
+        okw.update(in_max=thr, signed=True, width=8)
+    if "bn_relu" in mode:
+        sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+        sh = rng.standard_normal(cout).astype(np.float32)
+        kw.update(bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu")
+        okw.update(bn_scale=sc, bn_shift=sh, act="relu")
+    if "bias" in mode:
+        b = rng.standard_normal(cout).astype(np.float32)
+        kw.update(bias=T(b, dev))
+        okw.update(bias=b)
+    cur = torch.zeros(1, device=dev)
+    y, stat_out = ops.conv3x3_i8(T(x, dev), codes, pscale, rowsum, cur_out=cur, **kw)
+    want = O.conv3x3_i8_sliced(x, wt, **okw)
+    got = N(y)
+    _eq(got, want, "sliced dense 3x3 convolution (exact integer sums of three digit slices)")
+    _eq(N(stat_out), O.absmax_per_sample(got), "statistic")
+    if "bn_relu" not in mode:
+        # against the real thing: fp64 convolution of the fake-quantised activations with the filter as given
+        xq = O.ste_forward(x, O.act_scale(okw["in_max"], okw["signed"], 8), okw["in_max"],
+                           -okw["in_max"] if okw["signed"] else 0.0)
+        ref = torch.nn.functional.conv2d(torch.from_numpy(xq.astype(np.float64)), torch.from_numpy(wt.astype(np.float64)),
+                                         padding=1).numpy()
+        if "bias" in mode:
+            ref = ref + okw["bias"].reshape(1, -1, 1, 1)
+        err = np.abs(got - ref).max()
+        bound = 2.0 ** -20 * np.abs(wt).reshape(cout, -1).max(axis=1).max() * 9 * cin * np.abs(xq).max() + 1e-6 * np.abs(ref).max()
+        assert err <= bound, (err, bound)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6 * max(np.abs(ref).max(), 1e-6))
+
+
 def test_division_by_double_reciprocal_is_ieee_exact(dev, ops):
     """fq_code divides with (float)((double)c * RN_f64(1/d)) (csrc: ieee_div_by).  Stress it where it could matter: inputs
     placed 0, +-1, +-2 ulp around every k + 0.5 rounding tie of the quotient, for many divisors, signed and unsigned."""

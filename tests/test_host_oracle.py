@@ -301,3 +301,29 @@ def test_thread_count_does_not_change_results():
     assert c1 == c2
     _eq(y1, y2)
     _eq(h1, h2)
+
+
+def test_sliced_conv3x3_host_twin_equals_numpy_oracle():
+    """fq_weight_slices_host / fq_conv3x3_i8_sliced_host (the three-slice form of BASELINE config 5's 3x3 layers) against the
+    numpy restatement: digits, power-of-two scales, row sums and the convolution, bit for bit."""
+    rng = np.random.default_rng(23)
+    for (n, cin, cout, h, w), signed in (((2, 64, 64, 5, 7), False), ((1, 128, 32, 4, 4), True)):
+        x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+        if not signed:
+            x = np.maximum(x, 0)
+        wt = O.wino_weight_fake_quant((rng.standard_normal((cout, cin, 3, 3)) * 0.2).astype(np.float32), "F43", 8)[0]
+        wt[1] = 0.0
+        stat = O.absmax_per_sample(x)
+        sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        sh = rng.standard_normal(cout).astype(np.float32)
+        (y, st), codes, pscale, rowsum = H.conv3x3_i8_sliced(x, wt, in_stat=stat, signed=signed, bn_scale=sc, bn_shift=sh,
+                                                              act="relu", want_stat=True, want_slices=True)
+        m, p = O.weight_slices(wt.transpose(0, 2, 3, 1).reshape(cout, -1))
+        np.testing.assert_array_equal(pscale, p)
+        rows_pad = (cout + 63) // 64 * 64
+        for sl, d in enumerate(O.slice_digits(m)):
+            np.testing.assert_array_equal(codes[sl, :rows_pad * 9 * cin].reshape(rows_pad, -1)[:cout], d.astype(np.int8))
+            np.testing.assert_array_equal(rowsum[sl], d.sum(axis=1).astype(np.int32))
+        want = O.conv3x3_i8_sliced(x, wt, O.batch_mean(stat), signed=signed, bn_scale=sc, bn_shift=sh, act="relu")
+        np.testing.assert_array_equal(y, want)
+        np.testing.assert_array_equal(st, O.absmax_per_sample(want))
