@@ -259,6 +259,29 @@ int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wsca
                          unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
                          int act, float* stat_out, const float* residual, void* ws, fqStream_t stream);
 
+/* ---- int8 hand-over between fused convolutions under OFFLINE input quantisation (round 3) ------------------------------
+ * When the consumer quantises its input with a STORED threshold (`--quantize-input-offline`: convert_conv2d.py:58 takes
+ * `input_max`, known before the producer runs), the producer's epilogue can apply the consumer's LinearQuantizeSTE
+ * (ste_func.py:41) itself and hand over the integer codes - 1 byte per element instead of 4 written and 4 read - in the
+ * layout the matrix cores consume:
+ *   C16 code tensor of an (n, C, h, w) activation: int8 [n][ceil(C/16)][h*w][16], byte = (code + 128 - zoff) ^ 0x80 with
+ *   zoff = 128 for unsigned codes, 0 for signed ones (what fq_pwconv_i8 builds in LDS from fp32 input); channels past C
+ *   hold the code 0.  A pixel's 16 channels are ONE 16-byte vector: a consumer lane loads a B fragment with one instruction
+ *   (NCHW fp32: 16 loads and 16 quantisations), a producer lane stores a channel tile with 4 instructions instead of 16.
+ * fq_pwconv_i8_c16 is fq_pwconv_i8_strided with either side as a C16 tensor (not both):
+ *   x_is_c16 != 0: x is a C16 tensor quantised with in_thr / in_width / in_flags (in_thr required; in_stat, when given, only
+ *                  feeds out_current_max - the reference computes `current_input_max` in every mode);
+ *   out_thr != NULL: y is a C16 tensor holding the codes of act(BN(conv)) under the CONSUMER's out_thr[0] / out_width /
+ *                  out_flags; stat_out still receives max|act(BN(conv))| of the fp32 values (no residual operand then).
+ * The values are those of the fp32 hand-over bit for bit: codes are a function of the same fp32 numbers and the same
+ * threshold (tests/test_gpu_c16.py: a net with hand-overs == the same net without, logits bit-equal).                     */
+int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                     const float* bias, void* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                     int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                     float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                     const float* residual, const float* out_thr, int out_width, unsigned out_flags, void* ws,
+                     fqStream_t stream);
+
 /* Dense 3x3 convolution (stride 1, padding 1, no groups / dilation) on the integer codes: the same identity as
  * fq_pwconv_i8 with K = 9 * Cin, i.e. what the reference's fp32 F.Convolution of the two fake-quantised tensors computes
  * (nn/quantized_conv.py:134-151 spells the integer form out), here exact in int32.  Same contract as fq_pwconv_i8
@@ -271,6 +294,14 @@ int fq_conv3x3_i8(const float* x, const int8_t* wcodes, const float* wscale, con
                   float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* in_stat,
                   const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
                   const float* bn_shift, int act, float* stat_out, fqStream_t stream);
+
+/* fq_conv3x3_i8 with C16 code tensors on either side or both (see fq_pwconv_i8_c16): the 3x3 convolution in the middle
+ * of a ResNet bottleneck takes the codes its 1x1 predecessor wrote and writes the codes its 1x1 successor reads.            */
+int fq_conv3x3_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                      const float* bias, void* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
+                      const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                      const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* out_thr,
+                      int out_width, unsigned out_flags, fqStream_t stream);
 
 /* The same convolution for weights that are NOT integer multiples of one scale per output channel: the filters the
  * reference obtains under Winograd-domain quantisation (convert_conv2d.py:71-83: U^ = STE(s)(G g G^T) lives on the int8

@@ -525,8 +525,8 @@ static int pwconv_i8_impl(const float* x, const int8_t* wcodes, const float* wsc
                           const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
                           const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
                           float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
-                          const float* residual) {
-  REQUIRE(x && wcodes && wscale && wsum && y, "fq_pwconv_i8_host: null pointer");
+                          const float* residual, const int32_t* xcodes = nullptr) {
+  REQUIRE((x || xcodes) && wcodes && wscale && wsum && y, "fq_pwconv_i8_host: null pointer");
   REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && cin_pad >= cin, "fq_pwconv_i8_host: bad shape");
   REQUIRE(in_stat != nullptr || in_thr != nullptr, "fq_pwconv_i8_host: give in_stat, in_thr or both");
   REQUIRE(in_width >= 2 && in_width <= 8, "fq_pwconv_i8_host: input width does not fit int8 codes");
@@ -547,7 +547,9 @@ static int pwconv_i8_impl(const float* x, const int8_t* wcodes, const float* wsc
       for (int64_t p0 = 0; p0 < hw; p0 += 64) {
         const int64_t pc = std::min<int64_t>(64, hw - p0);
         for (int64_t ci = 0; ci < cin; ++ci)
-          for (int64_t p = 0; p < pc; ++p) cx[(size_t)(ci * 64 + p)] = (int32_t)code_of(x[(s * cin + ci) * hw + p0 + p], q);
+          for (int64_t p = 0; p < pc; ++p)
+            cx[(size_t)(ci * 64 + p)] = xcodes ? xcodes[(s * cin + ci) * hw + p0 + p]
+                                               : (int32_t)code_of(x[(s * cin + ci) * hw + p0 + p], q);
         for (int64_t co = 0; co < cout; ++co) {
           const int8_t* wr = wcodes + co * cin_pad;
           int32_t acc[64];
@@ -607,12 +609,12 @@ int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float*
 
 // Dense 3x3 convolution (stride 1, pad 1) on the integer codes: exact integer sums over (ky, kx, ci), zero padding = code 0.
 // wcodes rows are ordered (tap, ci) - the weights were permuted to (cout, 3, 3, cin) before fq_weight_codes_host.
-int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
-                       const float* bias, float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
-                       const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
-                       float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
-                       fqStream_t) {
-  REQUIRE(x && wcodes && wscale && wsum && y, "fq_conv3x3_i8_host: null pointer");
+static int conv3x3_i8_impl(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                           const float* bias, float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
+                           const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                           float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                           const int32_t* xcodes) {
+  REQUIRE((x || xcodes) && wcodes && wscale && wsum && y, "fq_conv3x3_i8_host: null pointer");
   REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "fq_conv3x3_i8_host: bad shape");
   REQUIRE(in_stat != nullptr || in_thr != nullptr, "fq_conv3x3_i8_host: give in_stat, in_thr or both");
   REQUIRE(in_width >= 2 && in_width <= 8, "fq_conv3x3_i8_host: input width does not fit int8 codes");
@@ -636,7 +638,8 @@ int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale
       for (int64_t ci = 0; ci < cin; ++ci)
         for (int64_t r = 0; r < h; ++r)
           for (int64_t c = 0; c < w; ++c)
-            cx[(size_t)((ci * (h + 2) + r + 1) * (w + 2) + c + 1)] = (int32_t)code_of(x[((s * cin + ci) * h + r) * w + c], q);
+            cx[(size_t)((ci * (h + 2) + r + 1) * (w + 2) + c + 1)] =
+                xcodes ? xcodes[((s * cin + ci) * h + r) * w + c] : (int32_t)code_of(x[((s * cin + ci) * h + r) * w + c], q);
       for (int64_t co = 0; co < cout; ++co) {
         std::fill(acc.begin(), acc.end(), 0);
         const int8_t* wr = wcodes + co * k9;
@@ -664,6 +667,116 @@ int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale
     }
   }
   stat_of_output(y, n, cout * hw, stat_out);
+  return FQ_OK;
+}
+
+int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                       const float* bias, float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
+                       const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                       float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                       fqStream_t) {
+  return conv3x3_i8_impl(x, wcodes, wscale, wsum, bias, y, n, cin, cout, h, w, in_stat, in_thr, in_width, in_flags,
+                         out_current_max, bn_scale, bn_shift, act, stat_out, nullptr);
+}
+
+// ---- C16 code tensors (include/fakequant.h at fq_pwconv_i8_c16): [n][ceil(C/16)][pixels][16], byte = (code + 128 - zoff) ^ 0x80
+static void c16_decode(const int8_t* t, int64_t n, int64_t c, int64_t hw, int zoff, int32_t* codes) {
+  const int64_t cb = (c + 15) / 16;
+#pragma omp parallel for schedule(static)
+  for (int64_t s = 0; s < n; ++s)
+    for (int64_t ch = 0; ch < c; ++ch)
+      for (int64_t p = 0; p < hw; ++p) {
+        const int b = ((uint8_t)t[((s * cb + ch / 16) * hw + p) * 16 + ch % 16]) ^ 0x80;     // code + 128 - zoff (mod 256)
+        codes[(s * c + ch) * hw + p] = zoff == 128 ? b : (int)(int8_t)(uint8_t)((b - 128) & 255);
+      }
+}
+
+static void c16_encode(const float* y, int64_t n, int64_t c, int64_t hw, const float* thr, int width, unsigned flags,
+                       int8_t* t) {
+  const QP q2 = make_qp(thr[0], act_levels(width, flags), (flags & FQ_ACT_LO_NEG_MAX) != 0, kEps);
+  const int zoff = (flags & FQ_ACT_SIGNED) ? 0 : 128;
+  const int64_t cb = (c + 15) / 16;
+#pragma omp parallel for schedule(static)
+  for (int64_t s = 0; s < n; ++s)
+    for (int64_t ch = 0; ch < cb * 16; ++ch)
+      for (int64_t p = 0; p < hw; ++p) {
+        const int code = ch < c ? (int)code_of(y[(s * c + ch) * hw + p], q2) : 0;
+        t[((s * cb + ch / 16) * hw + p) * 16 + ch % 16] = (int8_t)(uint8_t)(((code + 128 - zoff) & 255) ^ 0x80);
+      }
+}
+
+int fq_pwconv_i8_c16_host(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                          const float* bias, void* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h,
+                          int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                          float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                          const float* residual, const float* out_thr, int out_width, unsigned out_flags, void*, fqStream_t) {
+  REQUIRE(x && y && h > 0 && w > 0 && (stride == 1 || stride == 2), "fq_pwconv_i8_c16_host: bad arguments");
+  REQUIRE(x_is_c16 || out_thr, "fq_pwconv_i8_c16_host: neither side is a C16 tensor");
+  REQUIRE(!x_is_c16 || in_thr, "fq_pwconv_i8_c16_host: a C16 input needs in_thr");
+  const int64_t ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+  std::vector<int32_t> codes, sub_c;
+  std::vector<float> sub_x, tmp;
+  const float* xf = (const float*)x;
+  const int32_t* xc = nullptr;
+  if (x_is_c16) {
+    codes.resize((size_t)(n * cin * h * w));
+    c16_decode((const int8_t*)x, n, cin, h * w, (in_flags & FQ_ACT_SIGNED) ? 0 : 128, codes.data());
+    xc = codes.data();
+    xf = nullptr;
+  }
+  if (stride != 1) {
+    if (xc) {
+      sub_c.resize((size_t)(n * cin * ho * wo));
+      for (int64_t pc = 0; pc < n * cin; ++pc)
+        for (int64_t r = 0; r < ho; ++r)
+          for (int64_t c = 0; c < wo; ++c) sub_c[(size_t)((pc * ho + r) * wo + c)] = xc[(pc * h + r * stride) * w + c * stride];
+      xc = sub_c.data();
+    } else {
+      sub_x.resize((size_t)(n * cin * ho * wo));
+      for (int64_t pc = 0; pc < n * cin; ++pc)
+        for (int64_t r = 0; r < ho; ++r)
+          for (int64_t c = 0; c < wo; ++c) sub_x[(size_t)((pc * ho + r) * wo + c)] = xf[(pc * h + r * stride) * w + c * stride];
+      xf = sub_x.data();
+    }
+  }
+  float* yf = (float*)y;
+  if (out_thr) {
+    REQUIRE(residual == nullptr, "fq_pwconv_i8_c16_host: a residual operand goes with fp32 output");
+    tmp.resize((size_t)(n * cout * ho * wo));
+    yf = tmp.data();
+  }
+  if (int rc = pwconv_i8_impl(xf, wcodes, wscale, wsum, bias, yf, n, cin, cin_pad, cout, ho * wo, in_stat, in_thr, in_width,
+                              in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, xc))
+    return rc;
+  if (out_thr) c16_encode(yf, n, cout, ho * wo, out_thr, out_width, out_flags, (int8_t*)y);
+  return FQ_OK;
+}
+
+int fq_conv3x3_i8_c16_host(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                           const float* bias, void* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
+                           const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                           float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                           const float* out_thr, int out_width, unsigned out_flags, fqStream_t) {
+  REQUIRE(x && y, "fq_conv3x3_i8_c16_host: null pointer");
+  REQUIRE(x_is_c16 || out_thr, "fq_conv3x3_i8_c16_host: neither side is a C16 tensor");
+  REQUIRE(!x_is_c16 || in_thr, "fq_conv3x3_i8_c16_host: a C16 input needs in_thr");
+  std::vector<int32_t> codes;
+  std::vector<float> tmp;
+  const int32_t* xc = nullptr;
+  if (x_is_c16) {
+    codes.resize((size_t)(n * cin * h * w));
+    c16_decode((const int8_t*)x, n, cin, h * w, (in_flags & FQ_ACT_SIGNED) ? 0 : 128, codes.data());
+    xc = codes.data();
+  }
+  float* yf = (float*)y;
+  if (out_thr) {
+    tmp.resize((size_t)(n * cout * h * w));
+    yf = tmp.data();
+  }
+  if (int rc = conv3x3_i8_impl(x_is_c16 ? nullptr : (const float*)x, wcodes, wscale, wsum, bias, yf, n, cin, cout, h, w,
+                               in_stat, in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, xc))
+    return rc;
+  if (out_thr) c16_encode(yf, n, cout, h * w, out_thr, out_width, out_flags, (int8_t*)y);
   return FQ_OK;
 }
 

@@ -532,6 +532,31 @@ def conv3x3_i8(x, w, rows_per_scale, wt_width, in_max, signed=False, width=8, lo
     return y.astype(F32)
 
 
+def to_c16(codes, zoff):
+    """Integer codes (n, C, h, w) -> the C16 code tensor of include/fakequant.h: int8 [n][ceil(C/16)][h*w][16], byte =
+    (code + 128 - zoff) ^ 0x80 (unsigned codes re-centred by 128, signed ones as they are); channels past C hold code 0."""
+    codes = np.asarray(codes).astype(np.int64)
+    n, c, h, w = codes.shape
+    cb = (c + 15) // 16
+    full = np.zeros((n, cb * 16, h * w), np.int64)
+    full[:, :c] = codes.reshape(n, c, h * w)
+    b = ((full + 128 - zoff) & 255) ^ 0x80
+    return b.astype(np.uint8).view(np.int8).reshape(n, cb, 16, h * w).transpose(0, 1, 3, 2).copy()
+
+
+def from_c16(t, c, h, w, zoff):
+    """The inverse of `to_c16`: -> integer codes (n, c, h, w)."""
+    t = np.asarray(t).view(np.uint8).astype(np.int64)
+    n, cb = t.shape[:2]
+    b = t ^ 0x80                                               # = (code + 128 - zoff) mod 256
+    if zoff == 128:
+        codes = b                                              # unsigned codes 0 .. 255
+    else:
+        v = (b - 128) & 255                                    # signed: the two's complement byte of the code
+        codes = np.where(v >= 128, v - 256, v)
+    return codes.reshape(n, cb, h * w, 16).transpose(0, 1, 3, 2).reshape(n, cb * 16, h, w)[:, :c]
+
+
 def weight_slices(w):
     """Arithmetic of `fq_weight_slices` for a (rows, ...) fp32 filter: per row p = 2^e (smallest power of two with
     max|w| <= p * 2^20), m = rint(w / p) as int64 (|m| <= 2^20).  Returns (m, p); the three int8 digits of m in balanced base

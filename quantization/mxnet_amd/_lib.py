@@ -53,8 +53,12 @@ EXPORTS = {
                             _vp, _int, _vp, _vp, _vp]),
     "fq_pwconv_i8_strided": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,
                                     _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
+    "fq_pwconv_i8_c16": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,
+                                _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _uint, _vp, _vp]),
     "fq_conv3x3_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                              _vp, _int, _vp, _vp]),
+    "fq_conv3x3_i8_c16": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp,
+                                 _vp, _vp, _int, _vp, _vp, _int, _uint, _vp]),
     "fq_conv3x3_i8_sliced": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp,
                                     _vp, _vp, _int, _vp, _vp]),
     "fq_weight_slices": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

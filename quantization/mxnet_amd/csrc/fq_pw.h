@@ -31,11 +31,18 @@ struct PwCall {
   void* ws;
   hipStream_t st;
   int form;                      // FQ_PW_FORM: 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample
+  // C16 code tensors (fq_pwconv_i8_c16): x / y are [n][ceil(C/16)][pixels][16 codes] instead of fp32 NCHW
+  bool in_c16 = false;
+  const float* out_thr = nullptr;   // non-null: y is a C16 tensor holding the CONSUMER's codes for this threshold
+  float out_levels = 0.0f;
+  int out_lo_neg = 0, out_zoff = 0;
 };
 
 int pw_try_stream(const PwCall& c, bool* taken);    // K2h  fq_pw_stream.hip
 bool pw_stream_shape_ok(const PwCall& c);           //      shapes the streaming form takes
 int pw_try_split(const PwCall& c, bool* taken);     // K2m  fq_pw_split.hip
+int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t grid, size_t lds, const int8_t* wfrag,
+                      bool* launched);
 int pw_try_sample(const PwCall& c, bool* taken);    // K2r  fq_pw_sample.hip (14x14 planes)
 int pw_two_kernels(const PwCall& c);                // K2f  fq_pw_generic.hip (takes every shape)
 

@@ -1,0 +1,38 @@
+// libfakequant — K2m split form with C16 code tensors on either side (fq_pwconv_i8_c16): the instantiations
+// (see fq_common.h for the list of translation units and the design rules; the kernel: fq_pw_split_kernel.h)
+#include "fq_pw_split_kernel.h"
+
+namespace fqi {
+
+// IN16 / OUT16 variants of the two default configurations of every K (four wavefronts per SIMD, one or two channel tiles per
+// wavefront).  Both sides at once is not built: in the nets of BASELINE.json a 1x1 convolution either opens a unit (fp32 in,
+// codes out to the 3x3 / depthwise convolution) or closes it (codes in, fp32 out for the residual add).
+int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t grid, size_t lds, const int8_t* wfrag,
+                      bool* launched) {
+  const PwSplitGeom& t = *static_cast<const PwSplitGeom*>(geom);
+  const bool in16 = a.in_c16, out16 = a.out_thr != nullptr;
+  FQ_REQUIRE(!(in16 && out16), "fq_pwconv_i8_c16: codes in AND codes out is not built");
+  FQ_REQUIRE(!in16 || a.in_thr != nullptr, "fq_pwconv_i8_c16: a C16 input was quantised with a stored threshold: give in_thr");
+#define FQ_PWS16_CASE(KT_, CW_, D_, IN_, OUT_)                                                                         \
+  if (kt == KT_ && cw == CW_ && in16 == IN_ && out16 == OUT_) {                                                        \
+    static const bool attr_ok =                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_split_kernel<KT_, CW_, D_, 4, 4, IN_, OUT_>),        \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;                      \
+    FQ_REQUIRE(attr_ok, "fq_pwconv_i8_c16: cannot raise the dynamic LDS limit of the split kernel");                   \
+    hipLaunchKernelGGL((pwconv_split_kernel<KT_, CW_, D_, 4, 4, IN_, OUT_>), dim3((unsigned)grid), dim3(256), lds, a.st, \
+                       a.x, wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, \
+                       a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out, a.residual,       \
+                       a.out_thr);                                                                                     \
+    *launched = true;                                                                                                  \
+  }
+#define FQ_PWS16_KT(KT_)                                                                                               \
+  FQ_PWS16_CASE(KT_, 1, (KT_ < 7 ? KT_ : 7), true, false) FQ_PWS16_CASE(KT_, 2, (KT_ < 3 ? KT_ : 3), true, false)       \
+  FQ_PWS16_CASE(KT_, 1, (KT_ < 7 ? KT_ : 7), false, true) FQ_PWS16_CASE(KT_, 2, (KT_ < 3 ? KT_ : 3), false, true)
+  FQ_PWS16_KT(2) FQ_PWS16_KT(4) FQ_PWS16_KT(6) FQ_PWS16_KT(8) FQ_PWS16_KT(10) FQ_PWS16_KT(12) FQ_PWS16_KT(16)
+  FQ_PWS16_KT(18) FQ_PWS16_KT(30) FQ_PWS16_KT(32) FQ_PWS16_KT(64)
+#undef FQ_PWS16_KT
+#undef FQ_PWS16_CASE
+  return FQ_OK;
+}
+
+}  // namespace fqi

@@ -75,7 +75,8 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
                            int stride, int64_t h_in, int64_t w_in, int64_t w_out, const float* in_stat,
                            const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
                            const float* bn_scale, const float* bn_shift, int act, float* stat_out,
-                           const float* residual, void* ws, fqStream_t stream) {
+                           const float* residual, void* ws, fqStream_t stream, bool in_c16 = false,
+                           const float* out_thr = nullptr, int out_width = 8, unsigned out_flags = 0) {
   FQ_REQUIRE(x && wcodes && wscale && wsum && y && ws, "fq_pwconv_i8: null pointer");
   FQ_REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && hw < (1ll << 30) && n * hw < (1ll << 31) - 512,
              "fq_pwconv_i8: bad shape");
@@ -103,18 +104,30 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   c.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;      // unsigned codes are stored re-centred so they fit int8
   c.out_current_max = out_current_max; c.bn_scale = bn_scale; c.bn_shift = bn_shift; c.act = act;
   c.stat_out = stat_out; c.residual = residual; c.ws = ws; c.st = (hipStream_t)stream;
+  c.in_c16 = in_c16; c.out_thr = out_thr;
+  if (out_thr != nullptr) {
+    FQ_REQUIRE(out_width >= 2 && out_width <= 8, "fq_pwconv_i8_c16: output width %d does not fit int8 codes", out_width);
+    FQ_REQUIRE(!(out_flags & (FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "fq_pwconv_i8_c16: unsupported output flags");
+    c.out_levels = act_levels(out_width, out_flags);
+    c.out_lo_neg = (out_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    c.out_zoff = (out_flags & FQ_ACT_SIGNED) ? 0 : 128;
+  }
   static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample
-  c.form = forced_form ? forced_form : pw_form;
+  c.form = (in_c16 || out_thr) ? 6 : (forced_form ? forced_form : pw_form);
   FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6 || c.form == 7, "fq_pwconv_i8: unknown form %d (1 two "
              "kernels, 3 stream, 6 split, 7 sample; the panel / chunk / tile forms 2, 4, 5 were retired in favour of the split "
              "form)", c.form);
   FQ_REQUIRE(stride == 1 || c.form == 0 || c.form == 6, "fq_pwconv_i8_strided: only the split form reads strided inputs");
   FQ_REQUIRE(residual == nullptr || c.form != 1, "fq_pwconv_i8_strided: the two-kernel form takes no residual operand");
   // algorithmic bytes: the input pixels the outputs need, the outputs, and the residual operand when there is one
+  // (SURVEY.md 8d's definition - 4 B per input and per output element - also when a side is a C16 code tensor: the line of
+  // such a run says so and `frac` then measures what the hand-over saves)
   ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (residual ? 2.0 : 1.0) * (double)n * cout * hw), c.st);
   bool taken = false;
-  if (int rc = pw_try_sample(c, &taken)) return rc;
-  if (taken) return FQ_OK;
+  if (!(in_c16 || out_thr)) {
+    if (int rc = pw_try_sample(c, &taken)) return rc;
+    if (taken) return FQ_OK;
+  }
   FQ_REQUIRE(c.form != 7, "fq_pwconv_i8: the sample form takes stride 1, no residual, Cout a multiple of 256 and planes that "
              "cut into blocks of 96..128 pixels (Cin 128 ... 1024; a residual operand with 512 channels per workgroup) or whole planes "
              "of 45..64 pixels (Cin 512 / 1024, no residual)");
@@ -147,6 +160,25 @@ int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wsca
   return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, ho * wo, stride, h, w, wo, in_stat,
                          in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, ws,
                          stream);
+}
+
+int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                     const float* bias, void* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                     int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                     float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                     const float* residual, const float* out_thr, int out_width, unsigned out_flags, void* ws,
+                     fqStream_t stream) {
+  FQ_REQUIRE(h > 0 && w > 0 && (stride == 1 || stride == 2), "fq_pwconv_i8_c16: bad plane %lld x %lld or stride %d",
+             (long long)h, (long long)w, stride);
+  FQ_REQUIRE(x_is_c16 || out_thr != nullptr, "fq_pwconv_i8_c16: neither side is a C16 tensor (use fq_pwconv_i8)");
+  const int64_t ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+  const int64_t cbi = (cin + 15) / 16, cbo = (cout + 15) / 16;
+  FQ_REQUIRE(!x_is_c16 || (32 / (ho * wo) + 2) * cbi * h * w * 16 < (1ll << 31), "fq_pwconv_i8_c16: input plane too large");
+  FQ_REQUIRE(out_thr == nullptr || (32 / (ho * wo) + 2) * cbo * ho * wo * 16 < (1ll << 31),
+             "fq_pwconv_i8_c16: output plane too large");
+  return pwconv_dispatch((const float*)x, wcodes, wscale, wsum, bias, (float*)y, n, cin, cin_pad, cout, ho * wo, stride, h,
+                         w, wo, in_stat, in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out,
+                         residual, ws, stream, x_is_c16 != 0, out_thr, out_width, out_flags);
 }
 
 }  // extern "C"

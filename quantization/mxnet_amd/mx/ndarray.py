@@ -61,7 +61,9 @@ class NDArray(object):
     """Thin wrapper: one torch tensor, MXNet method names."""
     # _fq_stat: optional side channel — per-sample max|x| left by a fused producer (quantize/fuse.py) so that the
     # consuming fake-quant can skip its statistic pass.  Never set by the generic ops.
-    __slots__ = ("_t", "_fq_stat")
+    # _fq_c16: optional ops.Codes16 — `_t` then holds the int8 codes a fused producer handed to its single fused consumer
+    # (offline input quantisation; quantize/convert/convert_conv2d.handover_target).  Never set by the generic ops.
+    __slots__ = ("_t", "_fq_stat", "_fq_c16")
     __array_priority__ = 1000.0
     __array_ufunc__ = None
 
@@ -69,6 +71,7 @@ class NDArray(object):
         assert isinstance(t, torch.Tensor), type(t)
         self._t = t
         self._fq_stat = None
+        self._fq_c16 = None
 
     # -- plumbing ---------------------------------------------------------------------------
     @property

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import FakeQuantError
 
-__all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "Codes16", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -499,6 +499,26 @@ def weight_codes_reproduce(w, codes, scales):
     return bool(torch.equal(back, w2))
 
 
+class Codes16(object):
+    """An (n, C, h, w) activation handed over as integer codes in the C16 layout of include/fakequant.h: int8
+    [n][ceil(C / 16)][h * w][16], byte = (code + 128 - zoff) ^ 0x80.  `thr` / `width` / `flags` describe the quantiser that
+    made the codes - the CONSUMER's stored threshold (offline input quantisation)."""
+    __slots__ = ("t", "shape", "thr", "width", "flags")
+
+    def __init__(self, t, shape, thr, width, flags):
+        self.t, self.shape, self.thr, self.width, self.flags = t, tuple(int(d) for d in shape), thr, int(width), int(flags)
+
+    @staticmethod
+    def empty(shape, device, thr, width, flags):
+        n, c, h, w = shape
+        t = torch.empty((n, (c + 15) // 16, h * w, 16), dtype=torch.int8, device=device)
+        return Codes16(t, shape, thr, width, flags)
+
+    def matches(self, thr, width, flags):
+        return self.thr.data_ptr() == thr.data_ptr() and self.width == int(width) and \
+            (self.flags & 3) == (int(flags) & 3)
+
+
 PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6, "sample": 7}
 
 
@@ -511,13 +531,24 @@ def pwconv_strided_supported(cin):
 
 
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None):
+              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None, out_codes=None):
     """1x1 convolution on the integer codes (int8 MFMA, exact int32 accumulation) with quantise-on-load and fused
     BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; stride 1 or 2 (no padding); `residual` (the
     output's shape) is added after BatchNorm and before the activation.  `form` names one of PW_FORMS ("stream", "sample",
     "split", "two_kernels") instead of the library's shape-based choice - for parity tests and tuning; a shape the named form
-    does not take raises.  Returns (y, stat or None)."""
-    _check(x, "x")
+    does not take raises.  Returns (y, stat or None).
+
+    Offline hand-over (fq_pwconv_i8_c16): `x` may be a `Codes16` (made with this call's in_thr / width / flags), and
+    `out_codes=dict(thr=<consumer's threshold tensor>, width=8, flags=0)` makes `y` a `Codes16` of the consumer's codes."""
+    in16 = isinstance(x, Codes16)
+    if in16:
+        if in_thr is None or not x.matches(in_thr, width, flags):
+            raise ValueError("the C16 input was quantised with another threshold / width / signedness than this call names")
+        xs = x.shape
+        _check(x.t, "x", torch.int8)
+    else:
+        _check(x, "x")
+        xs = tuple(x.shape)
     _check(wcodes, "wcodes", torch.int8)
     _check(wscale, "wscale")
     _check(wsum, "wsum", torch.int32)
@@ -525,15 +556,39 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
                     ("bn_shift", bn_shift), ("cur_out", cur_out), ("residual", residual)):
         if t is not None:
             _check(t, name)
-    n, cin = x.shape[0], x.shape[1]
+    n, cin = xs[0], xs[1]
+    dev = x.t.device if in16 else x.device
     cout = wscale.numel()
     cin_pad = wcodes.shape[1]
     if (cin + 63) // 64 * 64 != cin_pad:
         raise ValueError("x has %d channels but the weight codes were made for a row length that pads to %d"
                          % (cin, cin_pad))
     if in_stat is not None and cur_out is None:
-        cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
-    stat, zflag = _stat_target(n, x.device, want_stat)
+        cur_out = torch.empty(1, dtype=torch.float32, device=dev)
+    stat, zflag = _stat_target(n, dev, want_stat)
+    if in16 or out_codes is not None:
+        if len(xs) != 4:
+            raise ValueError("a C16 hand-over needs (N, Cin, H, W) activations, got %s" % (xs,))
+        h, w = xs[2], xs[3]
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        if out_codes is not None:
+            if residual is not None:
+                raise ValueError("a residual operand goes with fp32 output")
+            othr = _check(out_codes["thr"], "out_codes['thr']")
+            y = Codes16.empty((n, cout, ho, wo), dev, othr, out_codes.get("width", 8), out_codes.get("flags", 0))
+            yp, ow, of = _ptr(y.t), y.width, y.flags
+        else:
+            y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=dev)
+            if residual is not None and tuple(residual.shape) != tuple(y.shape):
+                raise ValueError("the residual must have the output's shape %s, got %s" % (tuple(y.shape), tuple(residual.shape)))
+            othr, yp, ow, of = None, _ptr(y), 8, 0
+        ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, ho * wo), dtype=torch.uint8, device=dev)
+        check_call(_lib_().fq_pwconv_i8_c16(_ptr(x.t if in16 else x), 1 if in16 else 0, _ptr(wcodes), _ptr(wscale), _ptr(wsum),
+                                            _ptr(bias), yp, n, cin, cin_pad, cout, h, w, int(stride), _ptr(in_stat),
+                                            _ptr(in_thr), int(width), int(flags), _ptr(cur_out), _ptr(bn_scale),
+                                            _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _ptr(residual), _ptr(othr),
+                                            int(ow), int(of), _ptr(ws), _stream(wcodes)))
+        return y, stat
     if stride != 1 or residual is not None:
         if x.dim() != 4:
             raise ValueError("a strided 1x1 convolution needs (N, Cin, H, W) activations, got %s" % (tuple(x.shape),))
@@ -590,12 +645,21 @@ def weight_slices_3x3(w):
 
 
 def conv3x3_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-               bn_scale=None, bn_shift=None, act=None, want_stat=True):
+               bn_scale=None, bn_shift=None, act=None, want_stat=True, out_codes=None):
     """Dense 3x3 convolution (stride 1, padding 1) on the integer codes (int8 MFMA, exact int32 accumulation) with
     quantise-on-load and fused BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; wcodes / wscale / wsum
     from `weight_codes_3x3` - or from `weight_slices_3x3` (three int8 slices of a filter that is not on one integer grid:
-    Winograd-domain quantised weights; fq_conv3x3_i8_sliced).  Returns (y, stat or None)."""
-    _check(x, "x")
+    Winograd-domain quantised weights; fq_conv3x3_i8_sliced).  Offline hand-over as in `pwconv_i8`: `x` may be a `Codes16`,
+    `out_codes=dict(thr=..., width=8, flags=0)` makes `y` one (fq_conv3x3_i8_c16).  Returns (y, stat or None)."""
+    in16 = isinstance(x, Codes16)
+    if in16:
+        if in_thr is None or not x.matches(in_thr, width, flags):
+            raise ValueError("the C16 input was quantised with another threshold / width / signedness than this call names")
+        xs = x.shape
+        _check(x.t, "x", torch.int8)
+    else:
+        _check(x, "x")
+        xs = tuple(x.shape)
     _check(wcodes, "wcodes", torch.int8)
     _check(wscale, "wscale")
     _check(wsum, "wsum", torch.int32)
@@ -603,9 +667,10 @@ def conv3x3_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wi
                     ("bn_shift", bn_shift), ("cur_out", cur_out)):
         if t is not None:
             _check(t, name)
-    if x.dim() != 4:
-        raise ValueError("expected (N, Cin, H, W) activations, got %s" % (tuple(x.shape),))
-    n, cin, h, w = x.shape
+    if len(xs) != 4:
+        raise ValueError("expected (N, Cin, H, W) activations, got %s" % (xs,))
+    n, cin, h, w = xs
+    dev = x.t.device if in16 else x.device
     cout = wscale.numel()
     sliced = wcodes.dim() == 2 and wcodes.shape[0] == 3 and wsum.dim() == 2        # from `weight_slices_3x3`
     if sliced:
@@ -614,10 +679,25 @@ def conv3x3_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wi
             raise ValueError("weight slices do not match Cin = %d, Cout = %d" % (cin, cout))
     elif wcodes.shape[1] != 9 * cin:
         raise ValueError("weight codes have rows of %d, expected 9 * Cin = %d" % (wcodes.shape[1], 9 * cin))
-    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
-    stat, zflag = _stat_target(n, x.device, want_stat)
+    stat, zflag = _stat_target(n, dev, want_stat)
     if in_stat is not None and cur_out is None:
-        cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+        cur_out = torch.empty(1, dtype=torch.float32, device=dev)
+    if in16 or out_codes is not None:
+        if sliced:
+            raise ValueError("the three-slice form takes fp32 tensors on both sides")
+        if out_codes is not None:
+            othr = _check(out_codes["thr"], "out_codes['thr']")
+            y = Codes16.empty((n, cout, h, w), dev, othr, out_codes.get("width", 8), out_codes.get("flags", 0))
+            yp, ow, of = _ptr(y.t), y.width, y.flags
+        else:
+            y = torch.empty((n, cout, h, w), dtype=torch.float32, device=dev)
+            othr, yp, ow, of = None, _ptr(y), 8, 0
+        check_call(_lib_().fq_conv3x3_i8_c16(_ptr(x.t if in16 else x), 1 if in16 else 0, _ptr(wcodes), _ptr(wscale),
+                                             _ptr(wsum), _ptr(bias), yp, n, cin, cout, h, w, _ptr(in_stat), _ptr(in_thr),
+                                             int(width), int(flags), _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift),
+                                             _ACTS[act] | zflag, _ptr(stat), _ptr(othr), int(ow), int(of), _stream(wcodes)))
+        return y, stat
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=dev)
     if sliced:
         check_call(_lib_().fq_conv3x3_i8_sliced(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin,
                                                 cout, h, w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags),

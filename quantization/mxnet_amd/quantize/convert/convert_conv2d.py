@@ -202,6 +202,42 @@ def _pointwise_weight_codes(block, args, weight_raw, weight_q):
     return codes
 
 
+def handover_target(block):
+    """The consumer this fused convolution may hand integer codes to (quantize/fuse.py links `next`), when the consumer will
+    quantise with its STORED threshold in this very forward - offline input quantisation (convert_conv2d.py:58 takes
+    `input_max`) - and runs on the integer codes itself.  Returns the keyword `out_codes` of ops.pwconv_i8 / conv3x3_i8 or
+    None."""
+    from .. import fuse as _fuse
+    nxt = block._fq_pw_fused.get("next")
+    if nxt is None or not _fuse.HANDOVER or autograd.is_recording():
+        return None
+    a = nxt.quantize_args
+    ok = (nxt.enable_quantize and a.quantize_input and nxt.quantize_input and nxt.quantize_input_offline
+          and a.in_width <= 8 and a.wt_width <= 8 and not getattr(nxt, "_fq_no_int8", False)
+          and getattr(nxt, "input_max", None) is not None and getattr(nxt, "_fq_global_stat", None) is None)
+    if not ok:
+        return None
+    return dict(thr=nxt.input_max.data()._t, width=a.in_width, flags=ops.act_flags(signed=a.in_signed))
+
+
+def _handed_over(x):
+    """ops.Codes16 riding on an NDArray a producer handed over, else None."""
+    return getattr(x, "_fq_c16", None)
+
+
+def codes16_to_fake_quant(c16):
+    """Fallback for a consumer that received codes but cannot run on them after all: the fake-quantised fp32 tensor the
+    codes stand for, code * scale (torch ops; never taken on the BASELINE configurations)."""
+    n, c, h, w = c16.shape
+    signed = bool(c16.flags & 1)
+    b = (c16.t.to(torch.int16) & 255) ^ 0x80
+    codes = (b - 128).to(torch.int8).to(torch.float32) if signed else b.to(torch.float32)
+    levels = float((1 << (c16.width - 1)) - 1) if signed else float((1 << c16.width) - 1)
+    scale = c16.thr.reshape(()) / levels
+    t = codes.reshape(n, -1, h * w, 16).permute(0, 1, 3, 2).reshape(n, -1, h, w)[:, :c]
+    return (t * scale).contiguous()
+
+
 def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quantised):
     """1x1 (or dense 3x3, `kind`) convolution taken over by quantize/fuse.py.  When both operands are quantised to <= 8 bits it runs on the
     integer codes (fq_pwconv_i8: exact int32 sums on the int8 matrix cores, quantise-on-load, BN / activation / statistic
@@ -213,21 +249,34 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
         and not getattr(block, "_fq_no_int8", False)
     held = _pointwise_weight_codes(block, args, weight_raw, weight_q) if on_codes else None
     on_codes = held is not None
+    c16_in = _handed_over(x)
+    if c16_in is not None and not (on_codes and "in_thr" in plan):
+        x = NDArray(codes16_to_fake_quant(c16_in))      # (cannot run on the codes after all: their fp32 meaning, no apply pass)
+        plan, c16_in = {}, None
     if on_codes:
         codes, scales, rowsum = held
+        x_arg = c16_in if c16_in is not None else contiguous(x._t)
         if fz.get("kind") == "3x3":
-            y, stat = ops.conv3x3_i8(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
-                                     bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
+            out_codes = None if fz.get("sliced") else handover_target(block)
+            y, stat = ops.conv3x3_i8(x_arg, codes, scales, rowsum, None if bias is None else bias._t,
+                                     bn_scale=scale, bn_shift=shift, act=fz["act"],
+                                     **({} if fz.get("sliced") or out_codes is None else dict(out_codes=out_codes)), **plan)
         else:
             # the tail of a residual unit (quantize/fuse.py): the shortcut is added in this convolution's epilogue
             res = getattr(block, "_fq_residual", None)
             extra = {}
-            if res is not None and block._kwargs["stride"][0] == 1 and tuple(res["t"].shape[2:]) == tuple(x._t.shape[2:]) \
+            xshape = c16_in.shape if c16_in is not None else tuple(x._t.shape)
+            if res is not None and block._kwargs["stride"][0] == 1 and tuple(res["t"].shape[2:]) == tuple(xshape[2:]) \
                     and res["t"].shape[1] == block._kwargs["num_filter"]:
                 extra = dict(residual=res["t"])
                 res["used"] = True
-            y, stat = ops.pwconv_i8(contiguous(x._t), codes, scales, rowsum, None if bias is None else bias._t,
-                                    bn_scale=scale, bn_shift=shift, act=res["act"] if extra else fz["act"],
+            if not extra:
+                out_codes = handover_target(block)
+                if out_codes is not None:
+                    extra = dict(out_codes=out_codes)
+            y, stat = ops.pwconv_i8(x_arg, codes, scales, rowsum, None if bias is None else bias._t,
+                                    bn_scale=scale, bn_shift=shift,
+                                    act=res["act"] if "residual" in extra else fz["act"],
                                     stride=block._kwargs["stride"][0], **extra, **plan)
     else:
         if plan:          # input is to be quantised but the integer path does not apply: explicit apply pass
@@ -248,7 +297,11 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
             scale = torch.ones(c, dtype=torch.float32, device=out._t.device)
             shift = torch.zeros(c, dtype=torch.float32, device=out._t.device)
         y, stat = ops.bn_act_stat(out._t.contiguous(), scale, shift, fz["act"])
-    res = NDArray(y)
+    if isinstance(y, ops.Codes16):
+        res = NDArray(y.t)                              # the codes travel on the NDArray; only the linked consumer reads them
+        res._fq_c16 = y
+    else:
+        res = NDArray(y)
     res._fq_stat = stat
     return res
 

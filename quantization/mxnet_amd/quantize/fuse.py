@@ -102,6 +102,12 @@ def _is_maxpool_3x3s2p1(b):
             and k["pooling_convention"] == "valid")
 
 
+import os as _os
+
+HANDOVER = _os.environ.get("FQ_HANDOVER", "1") != "0"      # int8 C16 hand-over between fused convolutions under offline input quantisation (tests switch it off to
+                     # compare: the logits are bit-equal either way)
+
+
 def _identity_forward(self, F, x, *args, **kwargs):
     return x
 
@@ -414,6 +420,19 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             if act:
                 bypass(nxt)
             fused[0] += 1
+        # int8 hand-over (round 3): a fused convolution whose output goes to ONE consumer - the next convolution of the same
+        # Sequential, behind the BatchNorm / activation it folded - may write that consumer's integer codes instead of fp32
+        # when the consumer quantises with a stored threshold (decided per forward, convert_conv2d.handover_target)
+        kids = list(container._children.values())
+        for i, b in enumerate(kids):
+            fz = getattr(b, "_fq_pw_fused", None)
+            if fz is None or fz.get("sliced"):
+                continue
+            j = i + 1 + (1 if fz["bn"] is not None else 0) + (1 if fz["act_block"] is not None else 0)
+            nxt = kids[j] if j < len(kids) else None
+            nz = getattr(nxt, "_fq_pw_fused", None)
+            if nz is not None and not nz.get("sliced") and type(nxt) is nn.Conv2D:
+                fz["next"] = nxt
 
     def visit(container):
         kids = list(container._children.values())

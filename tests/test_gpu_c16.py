@@ -1,0 +1,180 @@
+"""int8 hand-over between fused convolutions under OFFLINE input quantisation (include/fakequant.h at fq_pwconv_i8_c16): C16 code
+tensors instead of fp32 NCHW between a producer and its single consumer.  The codes are a function of the same fp32 values and
+the same stored threshold, so everything is checked for EQUALITY:
+  * a producer's C16 output == oracle codes of its own fp32 output under the consumer's threshold, statistic unchanged;
+  * a consumer fed with C16 codes == the same consumer fed with the fp32 tensor and in_thr;
+  * a whole net with hand-overs == the same net without them, logits bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(gpu):
+    return gpu.torch_device
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from quantization.mxnet_amd import ops as _ops
+    return _ops
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+PW_CASES = [(2, 64, 64, 14, 14, 1), (3, 16, 96, 9, 11, 1), (2, 144, 24, 7, 7, 1), (2, 96, 40, 5, 6, 1), (2, 256, 512, 8, 8, 2),
+            (1, 320, 1280, 7, 7, 1), (4, 960, 160, 3, 3, 1), (1, 32, 192, 28, 28, 1)]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=["%dx%d->%d@%dx%d/s%d" % c for c in PW_CASES])
+@pytest.mark.parametrize("signed_out", [False, True], ids=["u8-out", "s8-out"])
+def test_pointwise_producer_writes_the_consumers_codes(dev, ops, case, signed_out):
+    n, cin, cout, h, w, stride = case
+    rng = np.random.default_rng(sum(case) + 3)
+    x = np.maximum(rng.standard_normal((n, cin, h, w)) * 2, 0).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * 0.2).astype(np.float32)
+    sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), 1, 8)
+    thr_in = T(np.float32([2.7]), dev)
+    act = None if signed_out else "relu6"
+    kw = dict(in_thr=thr_in, width=8, flags=0, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act=act, stride=stride)
+    y, stat = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, form="split", **kw)
+    thr_out = np.float32(1.9)
+    oflags = ops.act_flags(signed=signed_out)
+    yc, stat_c = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, out_codes=dict(thr=T(np.float32([thr_out]), dev), width=8,
+                                                                                flags=oflags), **kw)
+    assert isinstance(yc, ops.Codes16) and yc.shape == tuple(y.shape)
+    yf = y.cpu().numpy()
+    want = O.ste_codes(yf, O.act_scale(thr_out, signed_out, 8), thr_out, np.float32(-thr_out) if signed_out else np.float32(0))
+    assert np.array_equal(yc.t.cpu().numpy(), O.to_c16(want.astype(np.int64), 0 if signed_out else 128)), "C16 codes"
+    assert torch.equal(stat, stat_c), "the statistic is that of the fp32 values"
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=["%dx%d->%d@%dx%d/s%d" % c for c in PW_CASES])
+@pytest.mark.parametrize("mode", ["u8_bn_relu", "s8_res"])
+def test_pointwise_consumer_of_codes_equals_consumer_of_fp32(dev, ops, case, mode):
+    n, cin, cout, h, w, stride = case
+    rng = np.random.default_rng(sum(case) + 5)
+    signed = "s8" in mode
+    x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+    if not signed:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * 0.2).astype(np.float32)
+    sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), cout, 8)
+    thr = np.float32(2.3)
+    thr_t = T(np.float32([thr]), dev)
+    flags = ops.act_flags(signed=signed)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    kw = dict(in_thr=thr_t, width=8, flags=flags, bn_scale=T(sc, dev), bn_shift=T(sh, dev), stride=stride,
+              act="relu" if "relu" in mode else None)
+    if "res" in mode:
+        kw["residual"] = T((rng.standard_normal((n, cout, ho, wo)) * 3).astype(np.float32), dev)
+    stat_in = T(O.absmax_per_sample(x), dev)
+    cur_a, cur_b = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    want, want_stat = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, form="split", in_stat=stat_in, cur_out=cur_a, **kw)
+    cx = O.ste_codes(x, O.act_scale(thr, signed, 8), thr, np.float32(-thr) if signed else np.float32(0))
+    xc = ops.Codes16(T(O.to_c16(cx.astype(np.int64), 0 if signed else 128), dev), x.shape, thr_t, 8, flags)
+    got, got_stat = ops.pwconv_i8(xc, codes, scales, rowsum, in_stat=stat_in, cur_out=cur_b, **kw)
+    assert torch.equal(got, want), "output of the consumer fed with codes"
+    assert torch.equal(got_stat, want_stat) and torch.equal(cur_a, cur_b)
+    with pytest.raises(ValueError, match="another threshold"):
+        ops.pwconv_i8(xc, codes, scales, rowsum, in_thr=T(np.float32([thr]), dev), width=8, flags=flags)
+
+
+C3_CASES = [(2, 64, 64, 9, 11), (3, 128, 128, 7, 7), (2, 256, 256, 5, 6), (1, 512, 512, 7, 7), (2, 64, 128, 14, 14),
+            (5, 64, 96, 3, 3), (2, 128, 160, 28, 28), (1, 64, 64, 56, 56)]
+
+
+@pytest.mark.parametrize("case", C3_CASES, ids=["%dx%d->%d@%dx%d" % c for c in C3_CASES])
+@pytest.mark.parametrize("signed", [False, True], ids=["u8", "s8"])
+def test_dense3x3_with_codes_on_both_sides(dev, ops, case, signed):
+    """The 3x3 convolution in the middle of a bottleneck: C16 in == fp32 in, C16 out == oracle codes of the fp32 output, and
+    both at once == the codes of the all-fp32 call."""
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + 9)
+    x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+    if not signed:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    codes, scales, rowsum = ops.weight_codes_3x3(T(wt, dev), 1, 8)
+    thr = np.float32(2.3)
+    thr_t = T(np.float32([thr]), dev)
+    flags = ops.act_flags(signed=signed)
+    kw = dict(in_thr=thr_t, width=8, flags=flags, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu")
+    want, want_stat = ops.conv3x3_i8(T(x, dev), codes, scales, rowsum, **kw)
+    cx = O.ste_codes(x, O.act_scale(thr, signed, 8), thr, np.float32(-thr) if signed else np.float32(0))
+    xc = ops.Codes16(T(O.to_c16(cx.astype(np.int64), 0 if signed else 128), dev), x.shape, thr_t, 8, flags)
+    got, got_stat = ops.conv3x3_i8(xc, codes, scales, rowsum, **kw)
+    assert torch.equal(got, want) and torch.equal(got_stat, want_stat), "codes in"
+    thr2 = np.float32(1.1)
+    oc = dict(thr=T(np.float32([thr2]), dev), width=8, flags=0)
+    wantc = O.to_c16(O.ste_codes(want.cpu().numpy(), O.act_scale(thr2, False, 8), thr2, np.float32(0)).astype(np.int64), 128)
+    for src, what in ((T(x, dev), "codes out"), (xc, "codes in and out")):
+        yc, st = ops.conv3x3_i8(src, codes, scales, rowsum, out_codes=oc, **kw)
+        assert np.array_equal(yc.t.cpu().numpy(), wantc), what
+        assert torch.equal(st, want_stat), what
+
+
+@pytest.mark.parametrize("model,kw", [("resnet50_v1", dict(quant_type="channel")), ("cifar_resnet20_v1", dict())],
+                         ids=["resnet50_v1", "cifar_resnet20_v1"])
+def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
+    """Offline input quantisation, fused producers: every 1x1 -> 3x3 -> 1x1 chain of the units hands int8 codes over.  The
+    logits equal those of the same net with the hand-over switched off BIT FOR BIT, every block's `current_input_max`
+    included; under online quantisation nothing is handed over."""
+    from quantization.mxnet_amd import mx, ops
+    from quantization.mxnet_amd.quantize import fuse
+    from test_gpu_net import _build
+    classes, hw, batch = (1000, 64, 4) if model.startswith("resnet50") else (10, 32, 8)
+    net = _build(model, classes, gpu, **kw)
+    rng = np.random.default_rng(3)
+    xs = [mx.nd.array(rng.standard_normal((batch, 3, hw, hw)).astype(np.float32), ctx=gpu) for _ in range(3)]
+    net.quantize_input(enable=True, online=True)
+    for x in xs[:2]:                                   # naive-EMA calibration: thresholds
+        net(x)
+        net.update_ema()
+    net.fix_params()
+    net.quantize_input(enable=True, online=False)
+    net(xs[2])                                         # the freezing forward
+    fuse.fuse_inference(net)
+    calls = {"c16_out": 0, "c16_in": 0}
+    real_pw, real_c3 = ops.pwconv_i8, ops.conv3x3_i8
+
+    def count(fn):
+        def wrapped(x, *a, **k):
+            calls["c16_in"] += isinstance(x, ops.Codes16)
+            calls["c16_out"] += k.get("out_codes") is not None
+            return fn(x, *a, **k)
+        return wrapped
+    ops.pwconv_i8, ops.conv3x3_i8 = count(real_pw), count(real_c3)
+    try:
+        fuse.HANDOVER = True
+        with_codes = net(xs[2]).asnumpy()
+        cur_with = [float(b.current_input_max) for b in net.collect_quantized_blocks()]
+        n_out, n_in = calls["c16_out"], calls["c16_in"]
+        fuse.HANDOVER = False
+        calls.update(c16_out=0, c16_in=0)
+        without = net(xs[2]).asnumpy()
+        cur_without = [float(b.current_input_max) for b in net.collect_quantized_blocks()]
+        assert calls["c16_out"] == 0 and calls["c16_in"] == 0
+        fuse.HANDOVER = True
+        net.quantize_input(enable=True, online=True)
+        calls.update(c16_out=0, c16_in=0)
+        net(xs[2])
+        assert calls["c16_out"] == 0 and calls["c16_in"] == 0, "online quantisation: the threshold is not known to the producer"
+    finally:
+        ops.pwconv_i8, ops.conv3x3_i8 = real_pw, real_c3
+        fuse.HANDOVER = True
+    assert n_out == n_in and n_out >= (32 if model.startswith("resnet50") else 1), (n_out, n_in)
+    assert np.array_equal(with_codes, without), "logits with int8 hand-overs differ from the fp32 hand-over"
+    assert cur_with == cur_without

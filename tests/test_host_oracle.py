@@ -327,3 +327,45 @@ def test_sliced_conv3x3_host_twin_equals_numpy_oracle():
         want = O.conv3x3_i8_sliced(x, wt, O.batch_mean(stat), signed=signed, bn_scale=sc, bn_shift=sh, act="relu")
         np.testing.assert_array_equal(y, want)
         np.testing.assert_array_equal(st, O.absmax_per_sample(want))
+
+
+def test_c16_hand_over_host_twins_equal_the_fp32_path():
+    """fq_pwconv_i8_c16_host / fq_conv3x3_i8_c16_host: a C16 input gives the output of the fp32 input under the same stored
+    threshold, a C16 output holds the oracle's codes of the fp32 output (the layout: oracle.to_c16)."""
+    rng = np.random.default_rng(31)
+    n, cin, cout, h, w = 2, 64, 40, 5, 6
+    x = np.maximum(rng.standard_normal((n, cin, h, w)) * 2, 0).astype(np.float32)
+    thr, thr2 = np.float32(2.1), np.float32(1.3)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    cx = O.ste_codes(x, O.act_scale(thr, False, 8), thr, np.float32(0)).astype(np.int64)
+    xc = O.to_c16(cx, 128)
+    for kind in ("1x1", "3x3"):
+        wt = (rng.standard_normal((cout, cin, 1, 1) if kind == "1x1" else (cout, cin, 3, 3)) * 0.2).astype(np.float32)
+        if kind == "1x1":
+            want = H.pwconv_i8(x, wt, 1, 8, in_max=thr, bn_scale=sc, bn_shift=sh, act="relu")
+            codes, scales = O.weight_codes(wt.reshape(cout, cin), 1, 8)
+            cpad = np.zeros((64, 64), np.int8)
+            cpad[:cout, :cin] = codes
+        else:
+            want = H.conv3x3_i8(x, wt, 1, 8, in_max=thr, bn_scale=sc, bn_shift=sh, act="relu")
+            codes, scales = O.weight_codes(wt.transpose(0, 2, 3, 1).reshape(cout, -1), 1, 8)
+            cpad = np.zeros((64, 9 * cin), np.int8)
+            cpad[:cout] = codes
+        rowsum = cpad[:cout].astype(np.int32).sum(axis=1).astype(np.int32)
+        wantc = O.to_c16(O.ste_codes(want, O.act_scale(thr2, False, 8), thr2, np.float32(0)).astype(np.int64), 128)
+        for x_in, is16 in ((x, 0), (xc, 1)):
+            for out16 in (False, True):
+                if not is16 and not out16:
+                    continue
+                y = np.zeros(wantc.shape, np.int8) if out16 else np.empty((n, cout, h, w), np.float32)
+                common = [scales.astype(np.float32), rowsum, None, y, n, cin]
+                tail = [None, np.asarray([thr], np.float32), H._i(8), H._u(0), np.empty(1, np.float32), sc, sh, H._i(1), None]
+                othr = np.asarray([thr2], np.float32) if out16 else None
+                if kind == "1x1":
+                    H._call("fq_pwconv_i8_c16_host", x_in, H._i(is16), cpad, *common, 64, cout, h, w, H._i(1), *tail, None, othr,
+                            H._i(8), H._u(0), None, None)
+                else:
+                    H._call("fq_conv3x3_i8_c16_host", x_in, H._i(is16), cpad, *common, cout, h, w, *tail, othr, H._i(8), H._u(0),
+                            None)
+                np.testing.assert_array_equal(y, wantc if out16 else want, "%s in16=%d out16=%d" % (kind, is16, out16))
