@@ -303,6 +303,16 @@ int fq_conv3x3_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const f
                       const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* out_thr,
                       int out_width, unsigned out_flags, fqStream_t stream);
 
+/* fq_dwconv3x3 between TWO C16 code tensors: the depthwise layer of a MobileNetV2 unit, whose input the expansion
+ * convolution wrote as codes (under this layer's in_thr / in_width / in_flags) and whose output the projection convolution
+ * reads as codes (under out_thr / out_width / out_flags).  x^ = code * (in_thr / levels), then fq_dwconv3x3's arithmetic
+ * (fmaf chain over (ky, kx), bias, BatchNorm, activation, stat_out <- max|y[n]| of the fp32 values), then the consumer's
+ * quantiser.  in_stat, when given, only feeds out_current_max.                                                            */
+int fq_dwconv3x3_c16(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t c, int64_t h, int64_t wdt,
+                     int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                     float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                     const float* out_thr, int out_width, unsigned out_flags, fqStream_t stream);
+
 /* The same convolution for weights that are NOT integer multiples of one scale per output channel: the filters the
  * reference obtains under Winograd-domain quantisation (convert_conv2d.py:71-83: U^ = STE(s)(G g G^T) lives on the int8
  * grid, the spatial filter g^ = GI U^ GTI that F.Convolution then multiplies does not) - BASELINE config 5.  The filter is

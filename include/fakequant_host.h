@@ -98,6 +98,10 @@ int fq_conv3x3_i8_c16_host(const void* x, int x_is_c16, const int8_t* wcodes, co
                            const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
                            float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
                            const float* out_thr, int out_width, unsigned out_flags, fqStream_t stream);
+int fq_dwconv3x3_c16_host(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t c, int64_t h,
+                          int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                          float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                          const float* out_thr, int out_width, unsigned out_flags, fqStream_t stream);
 int fq_weight_slices_host(const float* w, int64_t rows, int64_t row_len, int64_t row_pad, int64_t rows_pad, int8_t* codes,
                           float* pscale, int32_t* rowsum, void* ws, fqStream_t stream);
 int fq_conv3x3_i8_sliced_host(const float* x, const int8_t* wslices, const float* pscale, const int32_t* wsum,

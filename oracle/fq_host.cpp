@@ -780,6 +780,30 @@ int fq_conv3x3_i8_c16_host(const void* x, int x_is_c16, const int8_t* wcodes, co
   return FQ_OK;
 }
 
+// Depthwise 3x3 between two C16 code tensors: x^ = code * sx (what the fake-quant of the fp32 tensor gives), the arithmetic
+// of fq_dwconv3x3_host on it, then the consumer's codes.
+int fq_dwconv3x3_c16_host(const void* x, const float* w, const float* bias, void* y, int64_t n, int64_t c, int64_t h,
+                          int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                          float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                          const float* out_thr, int out_width, unsigned out_flags, fqStream_t) {
+  REQUIRE(x && w && y && in_thr && out_thr && n > 0 && c > 0 && h > 0 && wdt > 0, "fq_dwconv3x3_c16_host: bad arguments");
+  REQUIRE(stride == 1 || stride == 2, "fq_dwconv3x3_c16_host: stride must be 1 or 2");
+  const QP q = make_qp(in_thr[0], act_levels(in_width, in_flags), (in_flags & FQ_ACT_LO_NEG_MAX) != 0, kEps);
+  if (in_stat && out_current_max) out_current_max[0] = batch_mean(in_stat, n);
+  std::vector<int32_t> codes((size_t)(n * c * h * wdt));
+  c16_decode((const int8_t*)x, n, c, h * wdt, (in_flags & FQ_ACT_SIGNED) ? 0 : 128, codes.data());
+  std::vector<float> xq(codes.size());
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)codes.size(); ++i) xq[(size_t)i] = (float)codes[(size_t)i] * q.scale;
+  const int64_t ho = (h - 1) / stride + 1, wo = (wdt - 1) / stride + 1;
+  std::vector<float> yf((size_t)(n * c * ho * wo));
+  if (int rc = fq_dwconv3x3_host(xq.data(), w, bias, yf.data(), n, c, h, wdt, stride, nullptr, nullptr, in_width, in_flags,
+                                 nullptr, bn_scale, bn_shift, act, stat_out, nullptr))
+    return rc;
+  c16_encode(yf.data(), n, c, ho * wo, out_thr, out_width, out_flags, (int8_t*)y);
+  return FQ_OK;
+}
+
 // fq_weight_slices: per row p = 2^e (smallest power of two with max|w| <= p * 2^20), m = rint(w / p), balanced base-128
 // digits; codes: 3 buffers of 2 * rows_pad * row_pad bytes - the row-major digits in the first half (the fragment-major
 // second half is a device layout and stays zero here).

@@ -47,6 +47,8 @@ EXPORTS = {
     "fq_stem_conv7x7s2": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "fq_dwconv3x3": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _uint, _vp, _vp, _vp, _int,
                             _vp, _vp]),
+    "fq_dwconv3x3_c16": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _uint, _vp, _vp, _vp, _int,
+                                _vp, _vp, _int, _uint, _vp]),
     "fq_weight_codes": (_int, [_vp, _i64, _i64, _int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fq_pwconv_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "fq_pwconv_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,

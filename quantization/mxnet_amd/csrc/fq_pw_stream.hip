@@ -21,17 +21,21 @@ struct PwsGeom {
   int Cin, K, Cout, CT, HW;   // K: row stride of the weight codes (cin_pad); CT = ceil(Cout / 32)
   int64_t cols, tiles;        // n * HW, ceil(cols / 32)
   int zoff;
+  // OUT16 (fq_pwconv_i8_c16): y is a C16 code tensor with CBo = Cout / 16 blocks holding the CONSUMER's codes
+  int CBo;
+  float out_levels;
+  int out_lo_neg, out_zoff;
 };
 
 // RES: a residual operand of y's shape is added after BatchNorm, before the activation (compile-time: the loads of the
 // residual would otherwise cost the plain instantiations their occupancy)
-template <int KT, bool RES>
+template <int KT, bool RES, bool OUT16 = false>
 __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wc, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwsGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
-    float* __restrict__ stat_out, const float* __restrict__ residual) {
+    float* __restrict__ stat_out, const float* __restrict__ residual, const float* __restrict__ out_thr) {
   constexpr int kSlots = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char pws_smem[];
   __shared__ unsigned k_stat[kSlots];
@@ -90,6 +94,11 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, blockIdx.x == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   const float sx = q.scale;
+  QParams q2;
+  q2.lo = q2.hi = q2.denom = q2.scale = 0.0f;
+  q2.rden = 0.0;
+  if (OUT16) q2 = make_qparams(out_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
+  const int ubias2 = 128 - g.out_zoff;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
   // weights -> fragment order: fragment (ct, kt), lane (row % 32) + 32 * (16-byte chunk % 2)
   for (int idx = threadIdx.x; idx < nch * KT * 2; idx += kBlock) {
@@ -157,6 +166,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
         f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
         if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
+        float vq[4];
         // two channels at a time: scale / bias / BatchNorm as packed fp32 instructions (two IEEE operations each - the same
         // values as the scalar form; the kernel is bound by vector-instruction issue, profiles/r2_pmc_sq.txt)
 #pragma unroll
@@ -174,10 +184,22 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
           v.y = ACT_M < 0 ? act_rt(v.y, act) : act_rt(v.y, ACT_M);
           // no masks: lanes past the end hold a copy of the last pixel (clamped loads) and re-store its values, and the
           // host guarantees Cout % 32 == 0
-          char* yb = reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff;
-          *reinterpret_cast<float*>(yb) = v.x;
-          *reinterpret_cast<float*>(yb + plane * 4) = v.y;
+          if (OUT16) {
+            vq[r] = v.x;
+            vq[r + 1] = v.y;
+          } else {
+            char* yb = reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff;
+            *reinterpret_cast<float*>(yb) = v.x;
+            *reinterpret_cast<float*>(yb + plane * 4) = v.y;
+          }
           m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+        }
+        if (OUT16) {   // channels 8 gq + 4 h .. + 3 of the lane's pixel = bytes 8 (gq & 1) + 4 h .. of block 2 ct + gq / 2
+          const int packed = pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
+                                         fq_code_int(vq[3], q2), ubias2);
+          char* yb = reinterpret_cast<char*>(y) + (((int64_t)px.smp * g.CBo + 2 * ct + (gq >> 1)) * plane + px.p) * 16 +
+                     8 * (gq & 1) + 4 * h;
+          *reinterpret_cast<int*>(yb) = packed;
         }
       }
     }
@@ -273,13 +295,17 @@ int pw_try_stream(const PwCall& c, bool* taken) {
   const int ct = (int)((c.cout + 31) / 32);
   const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 5 * sizeof(float);
   const bool shape_ok = pw_stream_shape_ok(c);
-  if (!((c.form == 0 || c.form == 3) && shape_ok)) {
+  const bool out16 = c.out_thr != nullptr;
+  // (C16 output: large planes only - the split form is faster on few tiles and takes partial channel tiles; no C16 input here)
+  if (out16 && !(shape_ok && !c.in_c16 && c.stride == 1 && c.residual == nullptr && (c.n * c.hw + 31) / 32 > 4096)) return FQ_OK;
+  if (!((c.form == 0 || c.form == 3 || out16) && shape_ok) || c.in_c16) {
     FQ_REQUIRE(c.form != 3, "fq_pwconv_i8: FQ_PW_FORM=3 but the shape does not fit the streaming kernel");
     return FQ_OK;
   }
   PwsGeom s;
   s.Cin = (int)c.cin; s.K = (int)c.cin_pad; s.Cout = (int)c.cout; s.CT = ct; s.HW = (int)c.hw;
   s.cols = c.n * c.hw; s.tiles = (s.cols + 31) / 32; s.zoff = c.zoff;
+  s.CBo = (int)(c.cout / 16); s.out_levels = c.out_levels; s.out_lo_neg = c.out_lo_neg; s.out_zoff = c.out_zoff;
   // persistent workgroups: as many as stay resident (LDS / 2 per SIMD by registers), each wave a contiguous range
   // (measured, tools/pwbench.py: 3 per CU for the 126-VGPR instantiations KT <= 2, 2 above)
   int per_cu = (int)((160 * 1024) / (lds + 1024));
@@ -291,18 +317,20 @@ int pw_try_stream(const PwCall& c, bool* taken) {
   const int64_t need = (s.tiles + 3) / 4;
   if (grid > need) grid = need;
   if (int rc = pw_zero_stat(c)) return rc;
-#define FQ_PWS_LAUNCH(KT_, RES_)                                                                                       \
+#define FQ_PWS_LAUNCH(KT_, RES_, O16_)                                                                                 \
   {                                                                                                                    \
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_, RES_>),   \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_, RES_, O16_>), \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess; \
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the streaming kernel");                   \
-    hipLaunchKernelGGL((pwconv_stream_kernel<KT_, RES_>), dim3((unsigned)grid), dim3(kBlock), lds, c.st, c.x,          \
+    hipLaunchKernelGGL((pwconv_stream_kernel<KT_, RES_, O16_>), dim3((unsigned)grid), dim3(kBlock), lds, c.st, c.x,    \
                        c.wcodes, c.wscale, (const int*)c.wsum, c.bias, c.y, s, c.in_stat, (int)c.n, c.in_thr, c.levels, \
-                       c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out, c.residual);      \
+                       c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out, c.residual,       \
+                       c.out_thr);                                                                                     \
   }
 #define FQ_PWS_CASE(KT_)                                                                                               \
   case KT_:                                                                                                            \
-    if (c.residual != nullptr) FQ_PWS_LAUNCH(KT_, true) else FQ_PWS_LAUNCH(KT_, false)                                 \
+    if (out16) FQ_PWS_LAUNCH(KT_, false, true)                                                                         \
+    else if (c.residual != nullptr) FQ_PWS_LAUNCH(KT_, true, false) else FQ_PWS_LAUNCH(KT_, false, false)              \
     break;
   switch (kt) {
     FQ_PWS_CASE(1) FQ_PWS_CASE(2) FQ_PWS_CASE(3) FQ_PWS_CASE(4) FQ_PWS_CASE(6) FQ_PWS_CASE(8)

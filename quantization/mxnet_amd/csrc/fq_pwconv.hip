@@ -127,6 +127,9 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   if (!(in_c16 || out_thr)) {
     if (int rc = pw_try_sample(c, &taken)) return rc;
     if (taken) return FQ_OK;
+  } else if (out_thr && !in_c16) {                      // C16 output on the largest planes: the streaming form writes it too
+    if (int rc = pw_try_stream(c, &taken)) return rc;
+    if (taken) return FQ_OK;
   }
   FQ_REQUIRE(c.form != 7, "fq_pwconv_i8: the sample form takes stride 1, no residual, Cout a multiple of 256 and planes that "
              "cut into blocks of 96..128 pixels (Cin 128 ... 1024; a residual operand with 512 channels per workgroup) or whole planes "

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import FakeQuantError
 
-__all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "Codes16", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "dwconv3x3_c16", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "Codes16", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -466,6 +466,36 @@ def dwconv3x3(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8, fla
     check_call(_lib_().fq_dwconv3x3(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, c, h, wd, int(stride), _ptr(in_stat),
                                     _ptr(in_thr), int(width), int(flags), _ptr(cur_out), _ptr(bn_scale),
                                     _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _stream(x)))
+    return y, stat
+
+
+def dwconv3x3_c16(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None, bn_scale=None,
+                  bn_shift=None, act=None, want_stat=True, out_codes=None):
+    """Depthwise 3x3 between two `Codes16` tensors (fq_dwconv3x3_c16): x was quantised with in_thr / width / flags, the
+    result carries the consumer's codes (`out_codes=dict(thr=..., width=8, flags=0)`).  Returns (Codes16, stat or None)."""
+    if not isinstance(x, Codes16) or in_thr is None or not x.matches(in_thr, width, flags):
+        raise ValueError("dwconv3x3_c16 wants a Codes16 input quantised with this call's in_thr / width / signedness")
+    if out_codes is None:
+        raise ValueError("dwconv3x3_c16 writes codes: give out_codes")
+    _check(x.t, "x", torch.int8)
+    _check(w, "w")
+    n, c, h, wd = x.shape
+    if w.dim() != 4 or tuple(w.shape[1:]) != (1, 3, 3) or w.shape[0] != c:
+        raise ValueError("dwconv3x3_c16 wants w (C,1,3,3); got %s for C = %d" % (tuple(w.shape), c))
+    for name, t in (("bias", bias), ("in_stat", in_stat), ("in_thr", in_thr), ("bn_scale", bn_scale),
+                    ("bn_shift", bn_shift), ("cur_out", cur_out)):
+        if t is not None:
+            _check(t, name)
+    dev = x.t.device
+    ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+    othr = _check(out_codes["thr"], "out_codes['thr']")
+    y = Codes16.empty((n, c, ho, wo), dev, othr, out_codes.get("width", 8), out_codes.get("flags", 0))
+    if in_stat is not None and cur_out is None:
+        cur_out = torch.empty(1, dtype=torch.float32, device=dev)
+    stat, zflag = _stat_target(n, dev, want_stat)
+    check_call(_lib_().fq_dwconv3x3_c16(_ptr(x.t), _ptr(w), _ptr(bias), _ptr(y.t), n, c, h, wd, int(stride), _ptr(in_stat),
+                                        _ptr(in_thr), int(width), int(flags), _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift),
+                                        _ACTS[act] | zflag, _ptr(stat), _ptr(othr), y.width, y.flags, _stream(w)))
     return y, stat
 
 

@@ -149,9 +149,24 @@ def fused_input_plan(block, x, input_max, flags, width):
 # ---- convolutions taken over by quantize/fuse.py ---------------------------------------------------------------------------
 def depthwise_fused(block, x, weight_q, bias, plan):
     """Depthwise 3x3 through fq_dwconv3x3: quantise-on-load + the BatchNorm / activation that followed this block + the
-    per-sample statistic of the output for the next fake-quant."""
+    per-sample statistic of the output for the next fake-quant.  Between two 1x1 convolutions under offline input
+    quantisation (a MobileNetV2 unit) it reads the codes the expansion wrote and writes the codes the projection reads
+    (fq_dwconv3x3_c16)."""
     fz = block._fq_dw_fused
     scale, shift = fz["constants"]() if fz["bn"] is not None else (None, None)
+    c16_in = getattr(x, "_fq_c16", None)
+    if c16_in is not None:
+        out_codes = handover_target(block, fz) if "in_thr" in plan else None
+        if out_codes is not None:
+            yc, stat = ops.dwconv3x3_c16(c16_in, contiguous(weight_q._t), None if bias is None else bias._t,
+                                         stride=block._kwargs["stride"][0], bn_scale=scale, bn_shift=shift, act=fz["act"],
+                                         out_codes=out_codes, **plan)
+            out = NDArray(yc.t)
+            out._fq_c16 = yc
+            out._fq_stat = stat
+            return out
+        x = NDArray(codes16_to_fake_quant(c16_in))      # (the producer's hand-over cannot be honoured after all)
+        plan = {}
     y, stat = ops.dwconv3x3(contiguous(x._t), contiguous(weight_q._t), None if bias is None else bias._t,
                             stride=block._kwargs["stride"][0], bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
     out = NDArray(y)
@@ -202,21 +217,31 @@ def _pointwise_weight_codes(block, args, weight_raw, weight_q):
     return codes
 
 
-def handover_target(block):
+_DW_C16_MIN_PIXELS = 56 * 56
+
+
+def _consumer_takes_codes(nxt):
+    a = nxt.quantize_args
+    return (nxt.enable_quantize and a.quantize_input and nxt.quantize_input and nxt.quantize_input_offline
+            and a.in_width <= 8 and a.wt_width <= 8 and not getattr(nxt, "_fq_no_int8", False)
+            and getattr(nxt, "input_max", None) is not None and getattr(nxt, "_fq_global_stat", None) is None)
+
+
+def handover_target(block, fz=None):
     """The consumer this fused convolution may hand integer codes to (quantize/fuse.py links `next`), when the consumer will
     quantise with its STORED threshold in this very forward - offline input quantisation (convert_conv2d.py:58 takes
-    `input_max`) - and runs on the integer codes itself.  Returns the keyword `out_codes` of ops.pwconv_i8 / conv3x3_i8 or
-    None."""
+    `input_max`) - and runs on the integer codes itself.  A depthwise consumer (fq_dwconv3x3_c16 reads AND writes codes)
+    counts only while it can hand over to its own consumer.  Returns the keyword `out_codes` of ops.pwconv_i8 /
+    conv3x3_i8 / dwconv3x3_c16, or None."""
     from .. import fuse as _fuse
-    nxt = block._fq_pw_fused.get("next")
-    if nxt is None or not _fuse.HANDOVER or autograd.is_recording():
+    fz = fz if fz is not None else block._fq_pw_fused
+    nxt = fz.get("next")
+    if nxt is None or not _fuse.HANDOVER or autograd.is_recording() or not _consumer_takes_codes(nxt):
+        return None
+    dw = getattr(nxt, "_fq_dw_fused", None)
+    if dw is not None and (handover_target(nxt, dw) is None or not fz.get("c16_pays", True)):
         return None
     a = nxt.quantize_args
-    ok = (nxt.enable_quantize and a.quantize_input and nxt.quantize_input and nxt.quantize_input_offline
-          and a.in_width <= 8 and a.wt_width <= 8 and not getattr(nxt, "_fq_no_int8", False)
-          and getattr(nxt, "input_max", None) is not None and getattr(nxt, "_fq_global_stat", None) is None)
-    if not ok:
-        return None
     return dict(thr=nxt.input_max.data()._t, width=a.in_width, flags=ops.act_flags(signed=a.in_signed))
 
 
@@ -271,6 +296,12 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                 extra = dict(residual=res["t"])
                 res["used"] = True
             if not extra:
+                # through a depthwise consumer the hand-over pays on the large planes only (measured, MobileNetV2 batch 128:
+                # fq_dwconv3x3_c16 102 us against 158 at 112x112 stride 2 and 49 against 61 at 56x56 stride 2, but 23 against
+                # 18 at 14x14 where the flat fp32 form is at its best) - profiles/r3_handover.txt
+                xs = c16_in.shape if c16_in is not None else tuple(x._t.shape)
+                s_ = block._kwargs["stride"][0]
+                fz["c16_pays"] = len(xs) == 4 and ((xs[2] - 1) // s_ + 1) * ((xs[3] - 1) // s_ + 1) >= _DW_C16_MIN_PIXELS
                 out_codes = handover_target(block)
                 if out_codes is not None:
                     extra = dict(out_codes=out_codes)

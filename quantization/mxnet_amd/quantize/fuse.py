@@ -422,17 +422,29 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             fused[0] += 1
         # int8 hand-over (round 3): a fused convolution whose output goes to ONE consumer - the next convolution of the same
         # Sequential, behind the BatchNorm / activation it folded - may write that consumer's integer codes instead of fp32
-        # when the consumer quantises with a stored threshold (decided per forward, convert_conv2d.handover_target)
+        # when the consumer quantises with a stored threshold (decided per forward, convert_conv2d.handover_target).
+        # 1x1 / dense 3x3 -> 1x1 / dense 3x3 (ResNet bottlenecks) and 1x1 -> depthwise -> 1x1 (MobileNetV2 units; the
+        # depthwise kernel on codes reads AND writes them, so its link counts only when it has a consumer of its own).
         kids = list(container._children.values())
-        for i, b in enumerate(kids):
-            fz = getattr(b, "_fq_pw_fused", None)
-            if fz is None or fz.get("sliced"):
-                continue
+
+        def after(i, fz):
             j = i + 1 + (1 if fz["bn"] is not None else 0) + (1 if fz["act_block"] is not None else 0)
-            nxt = kids[j] if j < len(kids) else None
-            nz = getattr(nxt, "_fq_pw_fused", None)
-            if nz is not None and not nz.get("sliced") and type(nxt) is nn.Conv2D:
+            return kids[j] if j < len(kids) else None
+
+        for i, b in enumerate(kids):
+            fz = getattr(b, "_fq_pw_fused", None) or getattr(b, "_fq_dw_fused", None)
+            if fz is None or fz.get("sliced") or not hasattr(b, "quantize_args"):
+                continue
+            nxt = after(i, fz)
+            if type(nxt) is not nn.Conv2D or not hasattr(nxt, "quantize_args"):
+                continue
+            if hasattr(b, "_fq_dw_fused"):
+                if getattr(nxt, "_fq_pw_fused", None) is not None and nxt._fq_pw_fused.get("kind") == "1x1":
+                    fz["next"] = nxt
+            elif getattr(nxt, "_fq_pw_fused", None) is not None and not nxt._fq_pw_fused.get("sliced"):
                 fz["next"] = nxt
+            elif getattr(nxt, "_fq_dw_fused", None) is not None and fz.get("kind") == "1x1":
+                fz["next"] = nxt                  # (honoured only while the depthwise block hands over too)
 
     def visit(container):
         kids = list(container._children.values())

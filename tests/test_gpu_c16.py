@@ -28,7 +28,7 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-PW_CASES = [(2, 64, 64, 14, 14, 1), (3, 16, 96, 9, 11, 1), (2, 144, 24, 7, 7, 1), (2, 96, 40, 5, 6, 1), (2, 256, 512, 8, 8, 2),
+PW_CASES = [(12, 16, 96, 112, 112, 1), (2, 64, 64, 14, 14, 1), (3, 16, 96, 9, 11, 1), (2, 144, 24, 7, 7, 1), (2, 96, 40, 5, 6, 1), (2, 256, 512, 8, 8, 2),
             (1, 320, 1280, 7, 7, 1), (4, 960, 160, 3, 3, 1), (1, 32, 192, 28, 28, 1)]
 
 
@@ -90,6 +90,42 @@ def test_pointwise_consumer_of_codes_equals_consumer_of_fp32(dev, ops, case, mod
         ops.pwconv_i8(xc, codes, scales, rowsum, in_thr=T(np.float32([thr]), dev), width=8, flags=flags)
 
 
+DW_CASES = [(2, 96, 112, 112, 2), (2, 144, 56, 56, 1), (3, 24, 9, 11, 1), (2, 192, 28, 28, 2), (3, 384, 14, 14, 1),
+            (2, 960, 7, 7, 1), (4, 40, 5, 6, 2), (1, 16, 70, 70, 1)]
+
+
+@pytest.mark.parametrize("case", DW_CASES, ids=["%dx%d@%dx%d/s%d" % c for c in DW_CASES])
+@pytest.mark.parametrize("signed", [False, True], ids=["u8", "s8"])
+def test_depthwise_between_two_code_tensors(dev, ops, case, signed):
+    """fq_dwconv3x3_c16: codes in (the threshold of this layer), codes out (the threshold of the next) == the oracle's codes of
+    what fq_dwconv3x3 computes from the fp32 tensor under the same stored threshold; the statistic is that of the fp32
+    values."""
+    n, c, h, w, stride = case
+    rng = np.random.default_rng(sum(case) + 13)
+    x = (rng.standard_normal((n, c, h, w)) * 2).astype(np.float32)
+    if not signed:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((c, 1, 3, 3)) * 0.4).astype(np.float32)
+    sc = rng.uniform(0.3, 1.5, c).astype(np.float32)
+    sh = rng.standard_normal(c).astype(np.float32)
+    thr, thr2 = np.float32(2.3), np.float32(1.7)
+    thr_t = T(np.float32([thr]), dev)
+    flags = ops.act_flags(signed=signed)
+    stat_in = T(O.absmax_per_sample(x), dev)
+    cur_a, cur_b = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    kw = dict(stride=stride, in_stat=stat_in, in_thr=thr_t, width=8, flags=flags, bn_scale=T(sc, dev), bn_shift=T(sh, dev),
+              act="relu6")
+    want, want_stat = ops.dwconv3x3(T(x, dev), T(wt, dev), cur_out=cur_a, **kw)
+    cx = O.ste_codes(x, O.act_scale(thr, signed, 8), thr, np.float32(-thr) if signed else np.float32(0))
+    xc = ops.Codes16(T(O.to_c16(cx.astype(np.int64), 0 if signed else 128), dev), x.shape, thr_t, 8, flags)
+    yc, st = ops.dwconv3x3_c16(xc, T(wt, dev), cur_out=cur_b, out_codes=dict(thr=T(np.float32([thr2]), dev), width=8, flags=0),
+                               **kw)
+    wantc = O.to_c16(O.ste_codes(want.cpu().numpy(), O.act_scale(thr2, False, 8), thr2, np.float32(0)).astype(np.int64), 128)
+    assert yc.shape == tuple(want.shape)
+    assert np.array_equal(yc.t.cpu().numpy(), wantc), "codes of the depthwise output"
+    assert torch.equal(st, want_stat) and torch.equal(cur_a, cur_b)
+
+
 C3_CASES = [(2, 64, 64, 9, 11), (3, 128, 128, 7, 7), (2, 256, 256, 5, 6), (1, 512, 512, 7, 7), (2, 64, 128, 14, 14),
             (5, 64, 96, 3, 3), (2, 128, 160, 28, 28), (1, 64, 64, 56, 56)]
 
@@ -126,8 +162,9 @@ def test_dense3x3_with_codes_on_both_sides(dev, ops, case, signed):
         assert torch.equal(st, want_stat), what
 
 
-@pytest.mark.parametrize("model,kw", [("resnet50_v1", dict(quant_type="channel")), ("cifar_resnet20_v1", dict())],
-                         ids=["resnet50_v1", "cifar_resnet20_v1"])
+@pytest.mark.parametrize("model,kw", [("resnet50_v1", dict(quant_type="channel")), ("cifar_resnet20_v1", dict()),
+                                      ("mobilenetv2_1.0", dict(quant_type="channel", wt=4))],
+                         ids=["resnet50_v1", "cifar_resnet20_v1", "mobilenetv2_1.0-w4"])
 def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
     """Offline input quantisation, fused producers: every 1x1 -> 3x3 -> 1x1 chain of the units hands int8 codes over.  The
     logits equal those of the same net with the hand-over switched off BIT FOR BIT, every block's `current_input_max`
@@ -135,7 +172,8 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
     from quantization.mxnet_amd import mx, ops
     from quantization.mxnet_amd.quantize import fuse
     from test_gpu_net import _build
-    classes, hw, batch = (1000, 64, 4) if model.startswith("resnet50") else (10, 32, 8)
+    classes, hw, batch = (10, 32, 8) if model.startswith("cifar") else ((1000, 224, 2) if model.startswith("mobilenetv2")
+                                                                       else (1000, 64, 4))
     net = _build(model, classes, gpu, **kw)
     rng = np.random.default_rng(3)
     xs = [mx.nd.array(rng.standard_normal((batch, 3, hw, hw)).astype(np.float32), ctx=gpu) for _ in range(3)]
@@ -148,7 +186,7 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
     net(xs[2])                                         # the freezing forward
     fuse.fuse_inference(net)
     calls = {"c16_out": 0, "c16_in": 0}
-    real_pw, real_c3 = ops.pwconv_i8, ops.conv3x3_i8
+    real_pw, real_c3, real_dw = ops.pwconv_i8, ops.conv3x3_i8, ops.dwconv3x3_c16
 
     def count(fn):
         def wrapped(x, *a, **k):
@@ -156,7 +194,7 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
             calls["c16_out"] += k.get("out_codes") is not None
             return fn(x, *a, **k)
         return wrapped
-    ops.pwconv_i8, ops.conv3x3_i8 = count(real_pw), count(real_c3)
+    ops.pwconv_i8, ops.conv3x3_i8, ops.dwconv3x3_c16 = count(real_pw), count(real_c3), count(real_dw)
     try:
         fuse.HANDOVER = True
         with_codes = net(xs[2]).asnumpy()
@@ -173,8 +211,10 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
         net(xs[2])
         assert calls["c16_out"] == 0 and calls["c16_in"] == 0, "online quantisation: the threshold is not known to the producer"
     finally:
-        ops.pwconv_i8, ops.conv3x3_i8 = real_pw, real_c3
+        ops.pwconv_i8, ops.conv3x3_i8, ops.dwconv3x3_c16 = real_pw, real_c3, real_dw
         fuse.HANDOVER = True
-    assert n_out == n_in and n_out >= (32 if model.startswith("resnet50") else 1), (n_out, n_in)
+    # resnet50: 16 units x (1x1 -> 3x3 -> 1x1); mobilenetv2: 16 units with an expansion x (1x1 -> depthwise -> 1x1)
+    # (through a depthwise consumer only on planes of 56x56 pixels and more: the three large units at 224x224)
+    assert n_out == n_in and n_out >= {"resnet50_v1": 32, "mobilenetv2_1.0": 6}.get(model, 1), (n_out, n_in)
     assert np.array_equal(with_codes, without), "logits with int8 hand-overs differ from the fp32 hand-over"
     assert cur_with == cur_without
