@@ -295,7 +295,7 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                     and res["t"].shape[1] == block._kwargs["num_filter"]:
                 extra = dict(residual=res["t"])
                 res["used"] = True
-            if not extra:
+            if not extra and c16_in is None:       # (a 1x1 convolution reads OR writes codes: both at once is not built)
                 # through a depthwise consumer the hand-over pays on the large planes only (measured, MobileNetV2 batch 128:
                 # fq_dwconv3x3_c16 102 us against 158 at 112x112 stride 2 and 49 against 61 at 56x56 stride 2, but 23 against
                 # 18 at 14x14 where the flat fp32 form is at its best) - profiles/r3_handover.txt
