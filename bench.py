@@ -61,6 +61,8 @@ KERNEL_NAMES = {
               "BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
     "conv3x3": "conv3x3_i8_kernel (dense 3x3 conv on int8 codes: implicit GEMM over (tap, ci), fake-quant on load, exact "
                "int32 MFMA sums, BN/ReLU/statistic on store; 4 B/in-elem + 4 B/out-elem)",
+    "dense": "pwconv_rows_kernel (the classifier on the int8 codes + the evaluation counters of its logits; 4 B/in-elem + "
+             "4 B/out-elem, latency-bound)",
     "weight": "weight fake-quant kernels (8 B/elem)",
     "histogram": "histogram_kernel (4 B/elem)",
     "global_max": "minmax_kernel (4 B/elem)",
@@ -350,14 +352,20 @@ def main():
     if args.phase == "calib-kl":
         net.disable_quantize()                        # fp32 inputs and weights while collecting (:298)
     kl_extra = {}
+    from quantization.mxnet_amd.quantize import fuse as _fuse_mod
+    head = _fuse_mod.eval_head(net, counters) if args.phase == "eval" and not args.no_fuse \
+        and os.environ.get("FQ_BENCH_HEAD", "1") != "0" else None
 
     def step(i):
         if args.phase == "calib-naive":               # evaluate(..., update_ema=True): forward, then the EMA of the thresholds
             out = net(batches[i % rotate])._t
             net.update_ema()
             return out
+        if head is not None:
+            head.labels = labels[i % rotate]          # the classifier's launch counts as well (fq_dense_i8_eval)
         out = net(batches[i % rotate])._t
-        ops.eval_counters(out, labels[i % rotate], counters)      # the eval loop's argmax + counters, one launch
+        if head is None or not head.take():
+            ops.eval_counters(out, labels[i % rotate], counters)      # the eval loop's argmax + counters, one launch
         return out
 
     class _KLBatches(object):

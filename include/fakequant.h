@@ -67,7 +67,8 @@ int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront)
 #define FQ_KERNEL_POOL 9          /* gap_stat_kernel               : 4 B/in elem + 4 B/out elem                     */
 #define FQ_KERNEL_GLOBAL_MAX 10   /* minmax_kernel (calibration)   : 4 B/elem                                       */
 #define FQ_KERNEL_CONV3X3 11      /* conv3x3_i8_kernel             : 4 B/in elem + 4 B/out elem                     */
-#define FQ_KERNEL_COUNT 12
+#define FQ_KERNEL_DENSE 12        /* pwconv_rows_kernel (the classifier on the codes: planes of one pixel; latency-bound)  */
+#define FQ_KERNEL_COUNT 13
 int fq_profile_enable(int on);
 int fq_profile_reset(void);
 int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes);
@@ -234,8 +235,10 @@ int fq_weight_codes(const float* w, int64_t rows, int64_t row_len, int rows_per_
  * fq_pw_split.hip; chosen by shape, FQ_PW_FORM forces one for tuning); every other shape takes two: (A) quantise + transpose x into int8 codes [(n*hw)][cin_pad] in
  * `ws` (fq_pwconv_workspace_bytes), (B) the integer GEMM with both operands K-contiguous + epilogue.  Online mode
  * requires out_current_max.                                                                                          */
-/* OR into `act`: take this form instead of the shape-based choice (1 two kernels, 3 stream, 6 split, 7 sample); FQ_INVALID when
- * the shape does not fit it.  For parity tests and tuning runs.                                  */
+/* Planes of ONE pixel (hw == 1: a Dense layer behind global pooling, convert_dense.py:37-70) take the rows form
+ * (csrc/fq_pw_rows.hip): x is (n, cin) row-major, y (n, cout); needs cin % 4 == 0.
+ * OR into `act`: take this form instead of the shape-based choice (1 two kernels, 3 stream, 6 split, 7 sample, 8 rows);
+ * FQ_INVALID when the shape does not fit it.  For parity tests and tuning runs.                                  */
 #define FQ_PW_FORM(f) ((f) << 12)
 size_t fq_pwconv_workspace_bytes(int64_t n, int64_t cin_pad, int64_t hw);
 int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
@@ -243,6 +246,19 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
                  const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
                  const float* bn_scale, const float* bn_shift, int act, float* stat_out, void* ws,
                  fqStream_t stream);
+
+/* The quantised classifier AND the evaluation counters of its logits in one launch - the tail of an evaluation step of the
+ * reference CLI: `outputs = net(X)` ends in the converted Dense (convert_dense.py:37-70: input fake-quant with the [0, max]
+ * clip, weight fake-quant, FullyConnected), then simulate_quantization.py:122-148 counts.  Same values as fq_pwconv_i8 with
+ * hw = 1 (y: (n, cout) logits, written as well) followed by fq_eval_counters(y, labels, n, cout, counters) - the argmax rule,
+ * the label range rule and the counter layout are fq_eval_counters'.  `eval_ws`: fq_dense_i8_eval_workspace_bytes(n, cout)
+ * bytes, 8-byte aligned, ZEROED ONCE by the caller before the first call; every call leaves it zeroed where it must be.  Not
+ * to be shared by calls that may run concurrently on different streams.  Needs cin % 4 == 0.                          */
+size_t fq_dense_i8_eval_workspace_bytes(int64_t n, int64_t cout);
+int fq_dense_i8_eval(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                     float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, const float* in_stat,
+                     const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                     const int64_t* labels, float* counters, void* eval_ws, void* ws, fqStream_t stream);
 
 /* The same for a STRIDED 1x1 convolution (stride 2 in both directions, no padding: the shortcut and first convolutions
  * of the ResNet stages): x is (n, cin, h, w), y is (n, cout, ceil(h/2), ceil(w/2)) - the kernel reads every second pixel of

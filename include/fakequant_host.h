@@ -81,6 +81,12 @@ int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float*
                               int64_t h, int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,
                               unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
                               int act, float* stat_out, const float* residual, void* ws, fqStream_t stream);
+/* fq_pwconv_i8_host on planes of one pixel, then fq_eval_counters_host on the logits it wrote (eval_ws, ws: unused). */
+int fq_dense_i8_eval_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                          const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout,
+                          const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                          float* out_current_max, const int64_t* labels, float* counters, void* eval_ws, void* ws,
+                          fqStream_t stream);
 /* wcodes: row-major [rows_pad][9 * cin] codes of the weights permuted to (cout, 3, 3, cin) (fq_weight_codes_host). */
 int fq_conv3x3_i8_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                        const float* bias, float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,

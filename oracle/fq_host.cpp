@@ -586,6 +586,19 @@ int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale,
                         out_current_max, bn_scale, bn_shift, act, stat_out, nullptr);
 }
 
+// The classifier on the codes + the evaluation counters of its logits (include/fakequant.h at fq_dense_i8_eval):
+// fq_pwconv_i8 with planes of one pixel, then fq_eval_counters on what it wrote.
+int fq_dense_i8_eval_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                          const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout,
+                          const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                          float* out_current_max, const int64_t* labels, float* counters, void*, void*, fqStream_t) {
+  REQUIRE(labels && counters, "fq_dense_i8_eval_host: null pointer");
+  if (int rc = pwconv_i8_impl(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, 1, in_stat, in_thr, in_width,
+                              in_flags, out_current_max, nullptr, nullptr, FQ_ACT_NONE, nullptr, nullptr))
+    return rc;
+  return fq_eval_counters_host(y, labels, n, cout, counters, nullptr);
+}
+
 // Strided 1x1 convolution: the stride-1 arithmetic on the subsampled input x[:, :, ::s, ::s]; optional residual operand of
 // y's shape, added after BatchNorm and before the activation.
 int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,

@@ -422,6 +422,23 @@ def gemm_i8_codes(xcodes, wcodes, n, l, zoff=0):
     return out
 
 
+def dense_i8_eval(x, w, rows_per_scale, wt_width, labels, counters=None, in_max=None, in_stat=None, signed=False, width=8,
+                  lo_neg_max=False, bias=None):
+    """fq_dense_i8_eval_host: x (n, cin), w (units, cin); returns (logits, counters)."""
+    x = _f32(x)
+    n, cin = x.shape
+    codes, scales, rowsum = weight_codes(w, rows_per_scale, wt_width)
+    cout = np.asarray(w).shape[0]
+    y = np.empty((n, cout), F32)
+    thr = None if in_max is None else np.asarray([in_max], F32).reshape(1)
+    cur = np.empty(1, F32)
+    out = np.zeros(2 + 2 * cout, F32) if counters is None else _f32(counters).copy()
+    _call("fq_dense_i8_eval_host", x, codes, scales, rowsum, None if bias is None else _f32(bias), y, n, cin,
+          codes.shape[1], cout, None if in_stat is None else _f32(in_stat), thr, _i(width),
+          _u(act_flags(signed, lo_neg_max)), cur, np.ascontiguousarray(labels, np.int64), out, None, None, None)
+    return y, out
+
+
 def eval_counters(logits, labels, counters=None):
     logits = _f32(logits)
     n, classes = logits.shape

@@ -256,6 +256,15 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     return _t(y.astype(F32)), stat
 
 
+def dense_i8_eval(x, wcodes, wscale, wsum, labels, counters, bias=None, in_stat=None, in_thr=None, width=8, flags=0,
+                  cur_out=None):
+    y, _ = pwconv_i8(x.reshape(x.shape[0], -1, 1, 1), wcodes, wscale, wsum, bias=bias, in_stat=in_stat, in_thr=in_thr,
+                     width=width, flags=flags, cur_out=cur_out, want_stat=False)
+    y = y.reshape(y.shape[0], -1)
+    eval_counters(y, labels, counters)
+    return y
+
+
 def weight_codes_3x3(w, rows_per_scale, width=8):
     return weight_codes(w.permute(0, 2, 3, 1).contiguous(), rows_per_scale, width)
 
@@ -436,7 +445,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "dense_i8_eval", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
 

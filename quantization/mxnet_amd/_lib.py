@@ -53,6 +53,9 @@ EXPORTS = {
     "fq_pwconv_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "fq_pwconv_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                             _vp, _int, _vp, _vp, _vp]),
+    "fq_dense_i8_eval_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "fq_dense_i8_eval": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp, _vp,
+                                _vp, _vp, _vp]),
     "fq_pwconv_i8_strided": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,
                                     _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "fq_pwconv_i8_c16": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,

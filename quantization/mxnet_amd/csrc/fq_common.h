@@ -200,7 +200,16 @@ __device__ __forceinline__ float block_min(float v, float* red) {
 }
 
 // Order-preserving atomics on fp32 through integer atomics (no CAS loop).
+// (-DFQ_DBG_NOSTAT: an ablation build that drops every statistic atomic - wrong statistics, for timing only)
+#ifdef FQ_DBG_NOSTAT
+#define FQ_STAT_FLUSH_MAX(p, v) ((void)(p), (void)(v))
+#else
+#define FQ_STAT_FLUSH_MAX(p, v) atomicMax((p), (v))
+#endif
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+#ifdef FQ_DBG_NOSTAT
+  return;
+#endif
   if (v >= 0.0f)
     atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
   else

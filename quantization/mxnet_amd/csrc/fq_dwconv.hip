@@ -427,7 +427,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < (unsigned)n_samples)
-      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+      FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
   }
   PW_STAMP(5);
 }
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_planes_kernel(
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < n_samples)
-      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+      FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
   }
   PW_STAMP(5);
 }
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < n_samples)
-      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+      FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
   }
   PW_STAMP(5);
 }
@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < (unsigned)n_samples)
-      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+      FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
   }
 }
 

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void pwconv_i8_kernel(
       }
       __syncthreads();
       if (threadIdx.x < kStatSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < (unsigned)(g.cols / HW))
-        atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+        FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
     }
   }
 }

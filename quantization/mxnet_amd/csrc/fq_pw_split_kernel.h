@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < cols / HW)
-      atomicMax(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
+      FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
   }
   PW_STAMP(5);
 }

@@ -76,7 +76,9 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
                            const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
                            const float* bn_scale, const float* bn_shift, int act, float* stat_out,
                            const float* residual, void* ws, fqStream_t stream, bool in_c16 = false,
-                           const float* out_thr = nullptr, int out_width = 8, unsigned out_flags = 0) {
+                           const float* out_thr = nullptr, int out_width = 8, unsigned out_flags = 0,
+                           const long long* eval_labels = nullptr, float* eval_counters = nullptr,
+                           void* eval_ws = nullptr) {
   FQ_REQUIRE(x && wcodes && wscale && wsum && y && ws, "fq_pwconv_i8: null pointer");
   FQ_REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && hw < (1ll << 30) && n * hw < (1ll << 31) - 512,
              "fq_pwconv_i8: bad shape");
@@ -112,18 +114,26 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
     c.out_lo_neg = (out_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
     c.out_zoff = (out_flags & FQ_ACT_SIGNED) ? 0 : 128;
   }
-  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample
-  c.form = (in_c16 || out_thr) ? 6 : (forced_form ? forced_form : pw_form);
-  FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6 || c.form == 7, "fq_pwconv_i8: unknown form %d (1 two "
-             "kernels, 3 stream, 6 split, 7 sample; the panel / chunk / tile forms 2, 4, 5 were retired in favour of the split "
-             "form)", c.form);
+  c.eval_labels = eval_labels; c.eval_counters = eval_counters; c.eval_ws = eval_ws;
+  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample, 8 rows
+  c.form = (in_c16 || out_thr) ? 6 : (eval_labels ? 8 : (forced_form ? forced_form : pw_form));
+  FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6 || c.form == 7 || c.form == 8, "fq_pwconv_i8: unknown "
+             "form %d (1 two kernels, 3 stream, 6 split, 7 sample, 8 rows; the panel / chunk / tile forms 2, 4, 5 were retired "
+             "in favour of the split form)", c.form);
   FQ_REQUIRE(stride == 1 || c.form == 0 || c.form == 6, "fq_pwconv_i8_strided: only the split form reads strided inputs");
   FQ_REQUIRE(residual == nullptr || c.form != 1, "fq_pwconv_i8_strided: the two-kernel form takes no residual operand");
   // algorithmic bytes: the input pixels the outputs need, the outputs, and the residual operand when there is one
   // (SURVEY.md 8d's definition - 4 B per input and per output element - also when a side is a C16 code tensor: the line of
   // such a run says so and `frac` then measures what the hand-over saves)
-  ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * ((double)n * cin * hw + (residual ? 2.0 : 1.0) * (double)n * cout * hw), c.st);
+  // (the classifier - planes of one pixel - is accounted on its own: 1 MB of latency-bound work is no pointwise layer)
+  ProfScope prof(hw == 1 ? FQ_KERNEL_DENSE : FQ_KERNEL_PWCONV,
+                 4.0 * ((double)n * cin * hw + (residual ? 2.0 : 1.0) * (double)n * cout * hw), c.st);
   bool taken = false;
+  if (hw == 1 && !(in_c16 || out_thr)) {
+    if (int rc = pw_try_rows(c, &taken)) return rc;
+    if (taken) return FQ_OK;
+  }
+  FQ_REQUIRE(c.form != 8, "fq_pwconv_i8: the rows form takes planes of one pixel");
   if (!(in_c16 || out_thr)) {
     if (int rc = pw_try_sample(c, &taken)) return rc;
     if (taken) return FQ_OK;
@@ -182,6 +192,21 @@ int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const fl
   return pwconv_dispatch((const float*)x, wcodes, wscale, wsum, bias, (float*)y, n, cin, cin_pad, cout, ho * wo, stride, h,
                          w, wo, in_stat, in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out,
                          residual, ws, stream, x_is_c16 != 0, out_thr, out_width, out_flags);
+}
+
+size_t fq_dense_i8_eval_workspace_bytes(int64_t n, int64_t cout) {
+  return n > 0 && cout > 0 ? pw_rows_eval_ws_bytes(n, cout) : 0;
+}
+
+int fq_dense_i8_eval(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                     float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, const float* in_stat,
+                     const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                     const int64_t* labels, float* counters, void* eval_ws, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(labels && counters && eval_ws, "fq_dense_i8_eval: null pointer (labels, counters, eval_ws)");
+  FQ_REQUIRE((reinterpret_cast<uintptr_t>(eval_ws) & 7u) == 0, "fq_dense_i8_eval: eval_ws must be 8-byte aligned");
+  return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, 1, 1, 0, 0, 0, in_stat, in_thr, in_width,
+                         in_flags, out_current_max, nullptr, nullptr, FQ_ACT_NONE, nullptr, nullptr, ws, stream, false,
+                         nullptr, 8, 0, (const long long*)labels, counters, eval_ws);
 }
 
 }  // extern "C"

@@ -366,18 +366,43 @@ __global__ __launch_bounds__(kBlock) void gap_stat_kernel(const float* __restric
 // The same result for the small planes this block actually sees (7x7, 8x8): a wavefront owns 64 consecutive planes = one
 // contiguous run of 64 * hw floats, which it reads COALESCED into its quarter of an LDS tile (a lane reading its own plane
 // straight from memory touches a different 128-byte line per lane and load: 30 us for 25.7 MB); lane l then adds up plane
-// l from LDS in the same order as above.  Statistic: one atomic per wavefront when its 64 planes lie in one sample.
+// l from LDS in the same order as above.
+//
+// Statistic: the atomics are the expensive part of this short kernel.  Same-address atomics from workgroups on DIFFERENT XCDs
+// cost a trip through the fabric each and queue up behind one another (tools/atomic_probe.hip, profiles/r3_atomic_probe.txt):
+// with a wavefront per 64 planes and workgroups dealt round-robin to the XCDs, the 16 atomics of a 1024-channel sample made
+// 8 of this kernel's 12 us.  So (a) the workgroup's four wavefronts meet in LDS when their 256 planes lie in one sample, and
+// (b) workgroup b works on slice (b % 8) * (grid / 8) + b / 8: the workgroups of a sample sit on ONE XCD.
+template <int PPW>      // planes per wavefront: 64 or 32 (lanes >= PPW only load)
 __global__ __launch_bounds__(kBlock) void gap_stat_lds_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               int64_t planes, int c, int hw, float* __restrict__ stat_out) {
-  extern __shared__ __attribute__((aligned(16))) float gap_tile[];     // 4 wavefronts x 64 planes x hw
+  extern __shared__ __attribute__((aligned(16))) float gap_tile[];     // 4 wavefronts x PPW planes x hw
+  __shared__ float wmax[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* mine = gap_tile + (size_t)wave * 64 * hw;
-  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * 64;            // first plane of this wavefront
-  if (p0 >= planes) return;
-  const int np = (int)(planes - p0 < 64 ? planes - p0 : 64);
+  float* mine = gap_tile + (size_t)wave * PPW * hw;
+  const unsigned per_xcd = gridDim.x >> 3;                             // host: the grid is a multiple of 8
+  const int64_t slice = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const int64_t wg0 = slice * 4 * PPW;                                 // first plane of this workgroup
+  const int64_t p0 = wg0 + (int64_t)wave * PPW;                        // ... of this wavefront
+  const int np = p0 >= planes ? 0 : (int)(planes - p0 < PPW ? planes - p0 : PPW);
   const float* src = x + p0 * hw;
   const int cnt = np * hw;
-  for (int i = lane; i < cnt; i += 64) mine[i] = src[i];               // wave-private tile: no barrier needed
+  if ((cnt & 3) == 0 && ((PPW * hw) & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+    // 16 bytes per lane and load, four loads in flight (a wavefront's run is PPW * hw floats from a 16-byte aligned start)
+    const f4* s4 = reinterpret_cast<const f4*>(src);
+    f4* m4 = reinterpret_cast<f4*>(mine);
+    const int c4 = cnt >> 2;
+    for (int i = lane; i < c4; i += 256) {
+      f4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = s4[i + 64 * u < c4 ? i + 64 * u : i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + 64 * u < c4) m4[i + 64 * u] = v[u];
+    }
+  } else {
+    for (int i = lane; i < cnt; i += 64) mine[i] = src[i];             // wave-private tile: no barrier needed
+  }
   float v = 0.0f;
   if (lane < np) {
     const float* p = mine + lane * hw;
@@ -386,14 +411,22 @@ __global__ __launch_bounds__(kBlock) void gap_stat_lds_kernel(const float* __res
     v = (float)acc / (float)hw;
     y[p0 + lane] = v;
   }
-  if (stat_out != nullptr) {
-    const int64_t s0 = p0 / c, s1 = (p0 + np - 1) / c;
-    if (s0 == s1) {
-      const float m = wave_max_nonneg(lane < np ? fabsf(v) : 0.0f);
-      if (lane == 0) atomic_max_f32(stat_out + s0, m);
-    } else if (lane < np) {
-      atomic_max_f32(stat_out + (p0 + lane) / c, fabsf(v));
-    }
+  if (stat_out == nullptr) return;
+  const int64_t wg_last = (wg0 + 4 * PPW < planes ? wg0 + 4 * PPW : planes) - 1;
+  if (wg0 < planes && wg0 / c == wg_last / c) {                          // the whole workgroup lies in one sample
+    const float m = wave_max_nonneg(lane < np ? fabsf(v) : 0.0f);
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_max_f32(stat_out + wg0 / c, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+    return;
+  }
+  if (np == 0) return;
+  const int64_t s0 = p0 / c, s1 = (p0 + np - 1) / c;
+  if (s0 == s1) {
+    const float m = wave_max_nonneg(lane < np ? fabsf(v) : 0.0f);
+    if (lane == 0) atomic_max_f32(stat_out + s0, m);
+  } else if (lane < np) {
+    atomic_max_f32(stat_out + (p0 + lane) / c, fabsf(v));
   }
 }
 
@@ -863,8 +896,15 @@ int fq_global_avg_pool_stat(const float* x, float* y, int64_t n, int64_t c, int6
   const int64_t planes = n * c;
   ProfScope prof(FQ_KERNEL_POOL, 4.0 * ((double)planes * hw + (double)planes), st);
   if (hw <= 64) {                                                       // 64 KB of LDS at most
-    hipLaunchKernelGGL(gap_stat_lds_kernel, dim3((unsigned)((planes + kBlock - 1) / kBlock)), dim3(kBlock),
-                       (size_t)kBlock * hw * sizeof(float), st, x, y, planes, (int)c, (int)hw, stat_out);
+    static const int ppw_env = env_int("FQ_GAP_PPW", 64);               // tuning: 32 = twice the wavefronts
+    const int ppw = ppw_env == 32 ? 32 : 64;
+    const int64_t per_wg = 4 * ppw;
+    const dim3 grid((unsigned)(((planes + per_wg - 1) / per_wg + 7) / 8 * 8));     // whole rounds over the 8 XCDs
+    const size_t lds = (size_t)per_wg * hw * sizeof(float);
+    if (ppw == 64)
+      hipLaunchKernelGGL(gap_stat_lds_kernel<64>, grid, dim3(kBlock), lds, st, x, y, planes, (int)c, (int)hw, stat_out);
+    else
+      hipLaunchKernelGGL(gap_stat_lds_kernel<32>, grid, dim3(kBlock), lds, st, x, y, planes, (int)c, (int)hw, stat_out);
     FQ_LAUNCH_CHECK();
     return FQ_OK;
   }

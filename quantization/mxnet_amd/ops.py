@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import FakeQuantError
 
-__all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "dwconv3x3_c16", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "Codes16", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
+__all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "dense_i8_eval", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "dwconv3x3_c16", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "Codes16", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
            "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
 
@@ -98,7 +98,7 @@ def device_info():
 
 
 KERNEL_IDS = {"stat": 0, "apply_online": 1, "apply_offline": 2, "weight": 3, "histogram": 4, "bn_act": 5,
-              "dwconv": 6, "pwconv": 7, "stem": 8, "pool": 9, "global_max": 10, "conv3x3": 11}
+              "dwconv": 6, "pwconv": 7, "stem": 8, "pool": 9, "global_max": 10, "conv3x3": 11, "dense": 12}
 
 
 def profile_enable(on=True):
@@ -393,6 +393,50 @@ def gemm_i8_codes(xcodes, wcodes, n, l, zoff):
     return out
 
 
+_EVAL_WS = {}
+
+
+def dense_i8_eval(x, wcodes, wscale, wsum, labels, counters, bias=None, in_stat=None, in_thr=None, width=8, flags=0,
+                  cur_out=None):
+    """The quantised classifier on the integer codes AND the evaluation counters of its logits in one launch
+    (fq_dense_i8_eval): `pwconv_i8` on planes of one pixel followed by `eval_counters`, same values.  x: (N, Cin[, 1, 1])
+    fp32; labels (N,) int64; counters as `eval_counters`.  Returns the logits (N, units)."""
+    _check(x, "x")
+    _check(wcodes, "wcodes", torch.int8)
+    _check(wscale, "wscale")
+    _check(wsum, "wsum", torch.int32)
+    _check(counters, "counters")
+    require_hip(labels.device, "labels")
+    for name, t in (("bias", bias), ("in_stat", in_stat), ("in_thr", in_thr), ("cur_out", cur_out)):
+        if t is not None:
+            _check(t, name)
+    n, cin = x.shape[0], x.shape[1]
+    cout, cin_pad = wscale.numel(), wcodes.shape[1]
+    if x.numel() != n * cin:
+        raise ValueError("dense_i8_eval wants (N, Cin) or (N, Cin, 1, 1) activations, got %s" % (tuple(x.shape),))
+    if (cin + 63) // 64 * 64 != cin_pad:
+        raise ValueError("x has %d channels but the weight codes were made for a row length that pads to %d"
+                         % (cin, cin_pad))
+    if labels.dim() != 1 or labels.shape[0] != n or labels.dtype != torch.int64:
+        raise ValueError("dense_i8_eval wants labels (N,) int64")
+    if counters.numel() != 2 + 2 * cout:
+        raise ValueError("counters must hold 2 + 2 * %d floats" % cout)
+    if in_stat is not None and cur_out is None:
+        cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+    nbytes = _lib_().fq_dense_i8_eval_workspace_bytes(n, cout)
+    key = (str(x.device), int(nbytes), int(torch.cuda.current_stream(x.device).cuda_stream))
+    ews = _EVAL_WS.get(key)
+    if ews is None:
+        ews = _EVAL_WS[key] = torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device=x.device)   # zeroed once, kept zeroed
+    y = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, 1), dtype=torch.uint8, device=x.device)
+    lb = labels.contiguous()
+    check_call(_lib_().fq_dense_i8_eval(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin,
+                                        cin_pad, cout, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(cur_out),
+                                        lb.data_ptr(), _ptr(counters), ews.data_ptr(), _ptr(ws), _stream(x)))
+    return y
+
+
 def eval_counters(logits, labels, counters):
     """counters ([n_correct, total, correct[c], label[c]], float32, 2 + 2*classes) += the batch's evaluation counts
     (reference CLI :122-148).  logits (N, classes) fp32, labels (N,) int64.  Returns `counters`."""
@@ -549,7 +593,7 @@ class Codes16(object):
             (self.flags & 3) == (int(flags) & 3)
 
 
-PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6, "sample": 7}
+PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6, "sample": 7, "rows": 8}
 
 
 SPLIT_KT = (2, 4, 6, 8, 10, 12, 16, 18, 30, 32, 64)     # padded Cin / 32 the split form of fq_pwconv_i8 is built for

@@ -63,6 +63,13 @@ def _dense_on_codes(block, x, weight, bias, input_max, args, flags):
     plan = fused_input_plan(block, x, input_max, flags, args.in_width)
     codes, scales, rowsum = _dense_weight_codes(block, weight, args)
     t = contiguous(x._t)
+    head = block.__dict__.get("_fq_eval_head")
+    if head is not None and head.labels is not None and plan and t.shape[1] % 4 == 0:
+        # the evaluation loop's counters in the same launch (quantize/fuse.py: EvalHead)
+        y = ops.dense_i8_eval(t.reshape(t.shape[0], -1), codes, scales, rowsum, head.labels, head.counters,
+                              bias=None if bias is None else bias._t, **plan)
+        head.labels, head.counted = None, True
+        return NDArray(y)
     y, _ = ops.pwconv_i8(t.reshape(t.shape[0], -1, 1, 1), codes, scales, rowsum, None if bias is None else bias._t,
                          want_stat=False, **plan)
     return NDArray(y.reshape(y.shape[0], -1))

@@ -22,7 +22,7 @@ from ..mx.gluon import nn
 from ..mx.ndarray import NDArray
 from .. import ops
 
-__all__ = ["fuse_inference", "unfuse", "refresh"]
+__all__ = ["fuse_inference", "unfuse", "refresh", "eval_head", "EvalHead"]
 
 
 def _is_relu6_block(b):
@@ -301,11 +301,14 @@ def _bn_constants_getter(bn):
     return get
 
 
-def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual=True, dense_int8=False):
+def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual=True, dense_int8=None):
     """Returns the number of blocks fused (BatchNorms folded + depthwise / pointwise convolutions taken over).
     `dense_int8`: also run the quantised classifier on the integer codes (fq_pwconv_i8 on a 1x1 plane: exact sums, no apply
-    pass).  Off by default: at batch 128 the 1024 -> 1000 layer has 4 pixel tiles, i.e. 16-32 workgroups, and takes 23-28 us
-    against 16.5 us for the apply pass + rocBLAS (measured in the benchmark step)."""
+    pass).  On by default since round 3's rows form (csrc/fq_pw_rows.hip; FQ_DENSE_INT8=0 turns the default off): the forms
+    made for convolution planes took 23-28 us for the 1024 -> 1000 layer at batch 128 against 16.5 us for the apply pass +
+    rocBLAS, which is why it used to be opt-in."""
+    if dense_int8 is None:
+        dense_int8 = DENSE_INT8
     fused = [0]
 
     def bypass(blk):
@@ -537,6 +540,39 @@ def refresh(net):
     net.apply(visit)
 
 
+DENSE_INT8 = _os.environ.get("FQ_DENSE_INT8", "1") != "0"
+
+
+class EvalHead(object):
+    """The evaluation counters of the reference CLI (simulate_quantization.py:122-148) riding on the classifier's launch
+    (fq_dense_i8_eval).  Per batch: `head.labels = y` before `net(X)`; `head.take()` afterwards says whether that forward
+    counted (the caller runs `ops.eval_counters` itself when it did not: Dense not on the integer path in this mode)."""
+    __slots__ = ("block", "counters", "labels", "counted")
+
+    def __init__(self, block, counters):
+        self.block, self.counters, self.labels, self.counted = block, counters, None, False
+
+    def take(self):
+        done, self.counted, self.labels = self.counted, False, None
+        return done
+
+    def release(self):
+        self.block.__dict__.pop("_fq_eval_head", None)
+
+
+def eval_head(net, counters):
+    """An EvalHead when the logits `net` returns are the output of a Dense that `fuse_inference(dense_int8=True)` put on the
+    integer codes (the model zoo's `net.output`: a Dense, or a container ending in one), else None."""
+    out = getattr(net, "output", None)
+    while isinstance(out, (nn.Sequential, nn.HybridSequential)) and len(out._children):
+        out = list(out._children.values())[-1]
+    if type(out) is not nn.Dense or not getattr(out, "_fq_dense_int8", False):
+        return None
+    head = EvalHead(out, counters)
+    out.__dict__["_fq_eval_head"] = head
+    return head
+
+
 def unfuse(net):
     if hasattr(net, "_fq_arena_hooks"):
         for h in net._fq_arena_hooks:
@@ -556,6 +592,7 @@ def unfuse(net):
         if hasattr(b, "_fq_dense_int8"):
             del b._fq_dense_int8
             b.__dict__.pop("_fq_wcodes_cache", None)
+            b.__dict__.pop("_fq_eval_head", None)
         if hasattr(b, "_fq_residual_fused"):
             del b.forward                                   # the class's own forward again
             del b._fq_residual_fused

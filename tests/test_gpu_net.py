@@ -450,3 +450,41 @@ def test_quantized_conv2d_is_exact_beyond_the_fp32_accumulator_limit(gpu):
     np.testing.assert_array_equal(seen[0].reshape(want.shape), want)  # exact integers
     # the block's fp32 output cannot carry integers above 2^24 exactly: one rounding of int -> fp32 and one of the product
     np.testing.assert_allclose(y, want.astype(np.float64) * np.float64(np.float32(in_scale * w_scale)), rtol=2.5e-7)
+
+
+@pytest.mark.parametrize("model,offline", [("mobilenet1.0", False), ("resnet50_v1", True)], ids=["mobilenet1.0-online", "resnet50_v1-offline"])
+def test_eval_head_counts_in_the_classifier_launch(gpu, model, offline):
+    """quantize/fuse.py EvalHead: with the labels bound, the classifier's launch (fq_dense_i8_eval) adds exactly what
+    `ops.eval_counters` adds to the same logits; without labels the forward counts nothing; logits do not change."""
+    from quantization.mxnet_amd import mx, ops
+    from quantization.mxnet_amd.quantize import fuse
+    net = _build(model, 1000, gpu)
+    rng = np.random.default_rng(3)
+    batch, hw = 6, 64
+    if offline:
+        net(mx.nd.array(rng.standard_normal((batch, 3, hw, hw)).astype(np.float32), ctx=gpu))
+        net.update_ema()
+    net.fix_params()
+    net.quantize_input(enable=True, online=not offline)
+    assert fuse.fuse_inference(net) > 0
+    dev = gpu.torch_device
+    c_head = torch.zeros(2002, device=dev)
+    c_ref = torch.zeros(2002, device=dev)
+    head = fuse.eval_head(net, c_head)
+    assert head is not None and getattr(head.block, "_fq_dense_int8", False)
+    for i in range(3):
+        X = mx.nd.array(rng.standard_normal((batch, 3, hw, hw)).astype(np.float32), ctx=gpu)
+        labels = torch.from_numpy(rng.integers(0, 1000, batch).astype(np.int64)).to(dev)
+        ref = net(X)._t.clone()
+        assert not head.take()                                       # no labels bound: nothing counted
+        if i == 1:
+            labels[0] = int(ref[0].argmax())                          # at least one correct prediction
+        ops.eval_counters(ref, labels, c_ref)
+        head.labels = labels
+        out = net(X)._t
+        assert head.take() and head.labels is None
+        assert torch.equal(out, ref)
+    assert torch.equal(c_head, c_ref) and float(c_ref[1]) == 3 * batch and float(c_ref[0]) >= 1
+    head.release()
+    assert "_fq_eval_head" not in head.block.__dict__
+    fuse.unfuse(net)

@@ -510,7 +510,11 @@ FORM_CASES = [
     ("sample", (5, 128, 512, 10, 10)), ("sample", (2, 256, 768, 16, 24)),
     # ... whole small planes in two pixel tiles: 7x7 (49 pixels: the last one has a load of its own) and 8x8, K/32 = 16 and 32
     ("sample", (5, 512, 1024, 7, 7)), ("sample", (3, 1024, 1024, 7, 7)), ("sample", (2, 512, 256, 8, 8)),
-    ("sample", (9, 1024, 512, 7, 7)), ("sample", (3, 1024, 256, 14, 14))]
+    ("sample", (9, 1024, 512, 7, 7)), ("sample", (3, 1024, 256, 14, 14)),
+    # rows (planes of one pixel = the classifier): the model zoo's heads at batch 128, a partial sample tile, a partial unit
+    # tile with padded K (100 -> 128), K in two rounds of slabs (2048), fewer slabs than wavefronts (64)
+    ("rows", (128, 1024, 1000, 1, 1)), ("rows", (70, 512, 512, 1, 1)), ("rows", (33, 100, 37, 1, 1)),
+    ("rows", (1, 2048, 1000, 1, 1)), ("rows", (3, 64, 10, 1, 1)), ("rows", (40, 1280, 1000, 1, 1))]
 
 
 @pytest.mark.parametrize("form,case", FORM_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in FORM_CASES])
@@ -955,6 +959,74 @@ def test_eval_counters_vs_oracle(dev, ops, n, classes):
         want = O.eval_counters(logits, labels, want)
     _eq(N(counters), want, "evaluation counters")
     assert N(counters)[1] == 2 * n
+
+
+DENSE_EVAL_CASES = [(128, 1024, 1000), (7, 64, 10), (70, 100, 37), (1, 512, 3), (33, 2048, 1000)]
+
+
+@pytest.mark.parametrize("n,cin,units", DENSE_EVAL_CASES, ids=["%dx%d->%d" % c for c in DENSE_EVAL_CASES])
+@pytest.mark.parametrize("mode", ["online", "offline_channel_w4"])
+def test_dense_i8_eval_vs_oracle(dev, ops, n, cin, units, mode):
+    """fq_dense_i8_eval = the classifier on the codes + the evaluation counters of its logits in ONE launch: logits equal the
+    oracle's integer form, counters equal the oracle's counters of those logits, accumulated over three calls that reuse the
+    library-side workspace (it must come back zeroed).  Ties (two identical weight rows: the first index wins, whichever
+    workgroup finishes last), a NaN logit (a NaN bias: the maximum), out-of-range labels, partial sample and unit tiles."""
+    from oracle import host as H
+    rng = np.random.default_rng(n + cin * 7 + units)
+    per_channel = "channel" in mode
+    wt_width = 4 if "w4" in mode else 8
+    wt = (rng.standard_normal((units, cin)) * rng.uniform(0.05, 1.0, (units, 1))).astype(np.float32)
+    if units > 40:
+        wt[5] = np.abs(wt[5]) + 1                                     # (inputs are >= 0: unit 5 is every sample's maximum ...)
+        wt[37] = wt[5]                                                # ... with equal logits in another unit tile
+        wt[6] = wt[5]                                                 # ... and inside its own
+    b = rng.standard_normal(units).astype(np.float32)
+    if units > 40:
+        b[37] = b[6] = b[5] = np.float32(5)
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), 1 if per_channel else units, wt_width)
+    counters = torch.zeros(2 + 2 * units, device=dev)
+    want_c = None
+    for call in range(3):
+        x = np.maximum(rng.standard_normal((n, cin)) * 2, 0).astype(np.float32)
+        bias = b.copy()
+        if call == 2 and units > 2:
+            bias[2] = np.nan                                          # every prediction of this call is unit 2
+        labels = rng.integers(0, units, n).astype(np.int64)
+        if n > 3:
+            labels[1] = units + 3                                     # only `total` moves
+            labels[2] = 5 if units > 5 else 0
+            x[2] = 0
+            if units > 40:
+                labels[3] = 5                                         # units 5 / 6 / 37 tie for the maximum: 5 wins
+        kw, okw = {}, {}
+        stat = O.absmax_per_sample(x)
+        flags = ops.act_flags(signed=False, lo_neg_max=False)
+        if mode.startswith("online"):
+            kw.update(in_stat=T(stat, dev), width=8, flags=flags)
+            okw.update(in_max=O.batch_mean(stat), signed=False, width=8)
+        else:
+            thr = np.float32(3.1)
+            kw.update(in_thr=T(np.float32([thr]), dev), in_stat=T(stat, dev), width=8, flags=flags)
+            okw.update(in_max=thr, signed=False, width=8)
+        cur = torch.zeros(1, device=dev)
+        y = ops.dense_i8_eval(T(x, dev), codes, scales, rowsum, torch.from_numpy(labels).to(dev), counters, bias=T(bias, dev),
+                              cur_out=cur, **kw)
+        want = O.pwconv_i8(x.reshape(n, cin, 1, 1), wt.reshape(units, cin, 1, 1), 1 if per_channel else units, wt_width,
+                           bias=bias, **okw).reshape(n, units)
+        _eq(N(y), want, "logits of call %d" % call)
+        _eq(N(cur), np.float32([O.batch_mean(stat)]), "current_input_max")
+        want_c = O.eval_counters(want, labels, want_c)
+        _eq(N(counters), want_c, "counters after call %d" % call)
+        # the two-launch formulation and the host twin give the same
+        y2, _ = ops.pwconv_i8(T(x, dev).reshape(n, cin, 1, 1), codes, scales, rowsum, bias=T(bias, dev), want_stat=False, **kw)
+        _eq(N(y2).reshape(n, units), want, "fq_pwconv_i8 on planes of one pixel")
+        if call == 0:
+            hy, hc = H.dense_i8_eval(x, wt, 1 if per_channel else units, wt_width, labels, None, bias=bias, **okw)
+            _eq(hy, want, "host twin: logits")
+            _eq(hc, O.eval_counters(want, labels, None), "host twin: counters")
+    assert N(counters)[1] == 3 * n
+    if units > 40 and n > 3:
+        assert N(counters)[2 + 5] >= 2                                # the tie went to the first index (calls 0 and 1)
 
 
 @pytest.mark.parametrize("n,l,k,cout,zoff", [(2, 49, 27, 32, 128), (3, 100, 288, 70, 0), (1, 7, 9, 5, 128),

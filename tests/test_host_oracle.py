@@ -33,7 +33,7 @@ def test_host_library_exports_every_declared_symbol():
     dev = re.sub(r"/\*.*?\*/", "", dev, flags=re.S)
     skip = {"fq_device_info", "fq_profile_enable", "fq_profile_reset", "fq_profile_read", "fq_profile_calibrate",
             "fq_act_workspace_bytes", "fq_pwconv_workspace_bytes", "fq_weight_workspace_bytes",
-            "fq_kl_workspace_bytes",
+            "fq_kl_workspace_bytes", "fq_dense_i8_eval_workspace_bytes",
             # transport, not arithmetic: the RCCL collectives of multi-GPU calibration
             "fq_comm_unique_id", "fq_comm_init", "fq_comm_world", "fq_allreduce_f32", "fq_allreduce_f64",
             "fq_allreduce_i64", "fq_comm_destroy"}
@@ -369,3 +369,22 @@ def test_c16_hand_over_host_twins_equal_the_fp32_path():
                     H._call("fq_conv3x3_i8_c16_host", x_in, H._i(is16), cpad, *common, cout, h, w, *tail, othr, H._i(8), H._u(0),
                             None)
                 np.testing.assert_array_equal(y, wantc if out16 else want, "%s in16=%d out16=%d" % (kind, is16, out16))
+
+
+def test_dense_i8_eval_twin_equals_the_two_oracle_steps():
+    """fq_dense_i8_eval_host = the oracle's pointwise convolution on planes of one pixel + the oracle's evaluation counters."""
+    rng = np.random.default_rng(12)
+    n, cin, units = 37, 100, 41
+    x = np.maximum(rng.standard_normal((n, cin)) * 2, 0).astype(np.float32)
+    w = rng.standard_normal((units, cin)).astype(np.float32)
+    w[7] = w[3]                                                       # a tie: the first index wins
+    b = rng.standard_normal(units).astype(np.float32)
+    b[7] = b[3]
+    labels = rng.integers(0, units, n).astype(np.int64)
+    labels[0] = units + 1
+    stat = O.absmax_per_sample(x)
+    y, c = H.dense_i8_eval(x, w, units, 8, labels, None, in_stat=stat, signed=False, width=8, bias=b)
+    want = O.pwconv_i8(x.reshape(n, cin, 1, 1), w.reshape(units, cin, 1, 1), units, 8, O.batch_mean(stat), signed=False, width=8,
+                       bias=b).reshape(n, units)
+    assert np.array_equal(y, want)
+    assert np.array_equal(c, O.eval_counters(want, labels, None))
