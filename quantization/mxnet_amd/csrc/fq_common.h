@@ -200,7 +200,9 @@ __device__ __forceinline__ float block_min(float v, float* red) {
 }
 
 // Order-preserving atomics on fp32 through integer atomics (no CAS loop).
-// (-DFQ_DBG_NOSTAT: an ablation build that drops every statistic atomic - wrong statistics, for timing only)
+// (-DFQ_DBG_NOSTAT: an ablation build that drops every statistic atomic.  Its statistics are all zero, hence every threshold,
+// hence every activation: kernels then run 2-6 us faster for reasons that have nothing to do with atomics - see
+// profiles/r3_atomic_probe.txt before reading anything into its timings.)
 #ifdef FQ_DBG_NOSTAT
 #define FQ_STAT_FLUSH_MAX(p, v) ((void)(p), (void)(v))
 #else

@@ -368,11 +368,12 @@ __global__ __launch_bounds__(kBlock) void gap_stat_kernel(const float* __restric
 // straight from memory touches a different 128-byte line per lane and load: 30 us for 25.7 MB); lane l then adds up plane
 // l from LDS in the same order as above.
 //
-// Statistic: the atomics are the expensive part of this short kernel.  Same-address atomics from workgroups on DIFFERENT XCDs
-// cost a trip through the fabric each and queue up behind one another (tools/atomic_probe.hip, profiles/r3_atomic_probe.txt):
-// with a wavefront per 64 planes and workgroups dealt round-robin to the XCDs, the 16 atomics of a 1024-channel sample made
-// 8 of this kernel's 12 us.  So (a) the workgroup's four wavefronts meet in LDS when their 256 planes lie in one sample, and
-// (b) workgroup b works on slice (b % 8) * (grid / 8) + b / 8: the workgroups of a sample sit on ONE XCD.
+// Statistic: the atomics are the expensive part of this short kernel.  Atomics to ONE 128-byte line are served one after the
+// other, ~10 ns each, whichever XCD they come from (tools/atomic_probe.hip, profiles/r3_atomic_probe.txt), and the 128
+// statistic slots of a batch are four lines: with one atomic per wavefront the 2048 of them kept this 9 us kernel alive for
+// another 3 (sent when the wavefronts finish, i.e. all at the end; the long kernels spread theirs over their run time and
+// show no such tail).  So the workgroup's four wavefronts meet in LDS when their 256 planes lie in one sample: 512 atomics.
+// (Workgroup b works on slice (b % 8) * (grid / 8) + b / 8 - the workgroups of a sample on one XCD; measured neutral.)
 template <int PPW>      // planes per wavefront: 64 or 32 (lanes >= PPW only load)
 __global__ __launch_bounds__(kBlock) void gap_stat_lds_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               int64_t planes, int c, int hw, float* __restrict__ stat_out) {
