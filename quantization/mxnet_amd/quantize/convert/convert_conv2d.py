@@ -205,7 +205,16 @@ def _pointwise_weight_codes(block, args, weight_raw, weight_q):
     make = ops.weight_codes_3x3 if three else ops.weight_codes
     rederived = block.fixed_params == 1 and held is not None
     src = contiguous((weight_q if rederived else weight_raw)._t)
-    codes = make(src, _weight_rows_per_scale(block, args), args.wt_width)
+    live = None if rederived else block.__dict__.get("_fq_pw_live")
+    if live is not None and live[0] is weight_raw._t and live[1] == weight_raw._t._version:
+        codes = live[2]                                # not frozen (calibration): the codes of this very parameter version
+    else:
+        codes = make(src, _weight_rows_per_scale(block, args), args.wt_width)
+        if not rederived and block.fixed_params != 1 and weight_raw._t is param_t:
+            # kept while the parameter is the same tensor in the same in-place version, as `_fake_quant_weight` does
+            block.__dict__["_fq_pw_live"] = (weight_raw._t, weight_raw._t._version, codes)
+    if block.fixed_params == 1:
+        block.__dict__.pop("_fq_pw_live", None)
     if rederived:
         ref = src.permute(0, 2, 3, 1).contiguous() if three else src
         if not ops.weight_codes_reproduce(ref, codes[0], codes[1]):
@@ -340,7 +349,24 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
 # ---- weight branch -----------------------------------------------------------------------------------------------------------
 def _fake_quant_weight(block, args, weight):
     """convert_conv2d.py:68-95: one scale per layer / per group (G in {1, Cout}) / per output channel; per-channel 3x3
-    filters go through the Winograd domain when asked to (:71-83)."""
+    filters go through the Winograd domain when asked to (:71-83).
+
+    The reference recomputes this on every forward; here the result is kept while the source is the same tensor object in
+    the same in-place version (an optimiser step, `set_data` or `load_parameters` change one or the other) - identical
+    values, ~150 of the ~200 launches of a MobileNetV2 calibration step gone.  Not while gradients are recorded (the
+    straight-through link belongs to that forward's tape) and not for folded fake-BN weights (a fresh tensor per forward)."""
+    keep = not args.fake_bn and not autograd.is_recording()
+    if keep:
+        held = block.__dict__.get("_fq_wq_cache")
+        if held is not None and held[0] is weight._t and held[1] == weight._t._version:
+            return held[2]
+    out = _fake_quant_weight_now(block, args, weight)
+    if keep:
+        block.__dict__["_fq_wq_cache"] = (weight._t, weight._t._version, out)      # (holds the source: its address cannot be reused)
+    return out
+
+
+def _fake_quant_weight_now(block, args, weight):
     w = contiguous(weight._t)
     if args.quant_type == 'channel' and args.wino_quantize != 'none' and block._kwargs['kernel'] == (3, 3):
         wq = ops.wino_weight_fake_quant(w, args.wino_quantize, args.wt_width)

@@ -37,23 +37,23 @@ def _quantised_weight(block, weight, args):
     """Per-layer or per-unit fake-quantised weight, kept until the parameter's storage or in-place version changes
     (an optimiser step / set_data bumps it)."""
     w = contiguous(weight._t)
-    key = (weight._t.data_ptr(), weight._t._version, args.quant_type, args.wt_width, str(w.device))
+    key = (weight._t._version, args.quant_type, args.wt_width)
     held = block.__dict__.get("_fq_wq_cache")
-    if held is None or held[0] != key:
+    if held is None or held[0] is not weight._t or held[1] != key:      # (the entry holds its source: no address reuse)
         rows = block._units if args.quant_type == 'channel' else 1
-        held = block.__dict__["_fq_wq_cache"] = (key, ops.weight_fake_quant(w, rows, args.wt_width))
-    return NDArray(autograd.ste_link(w, held[1]))              # identity backward; a no-op unless recording
+        held = block.__dict__["_fq_wq_cache"] = (weight._t, key, ops.weight_fake_quant(w, rows, args.wt_width))
+    return NDArray(autograd.ste_link(w, held[2]))              # identity backward; a no-op unless recording
 
 
 def _dense_weight_codes(block, weight, args):
     """int8 codes / scales / row sums of the (units, in_units) weight, kept until the parameter changes."""
     w = contiguous(weight._t)
-    key = (weight._t.data_ptr(), weight._t._version, args.quant_type, args.wt_width, str(w.device))
+    key = (weight._t._version, args.quant_type, args.wt_width)
     held = block.__dict__.get("_fq_wcodes_cache")
-    if held is None or held[0] != key:
+    if held is None or held[0] is not weight._t or held[1] != key:
         rows = 1 if args.quant_type == 'channel' else block._units
-        held = block.__dict__["_fq_wcodes_cache"] = (key, ops.weight_codes(w, rows, args.wt_width))
-    return held[1]
+        held = block.__dict__["_fq_wcodes_cache"] = (weight._t, key, ops.weight_codes(w, rows, args.wt_width))
+    return held[2]
 
 
 def _dense_on_codes(block, x, weight, bias, input_max, args, flags):

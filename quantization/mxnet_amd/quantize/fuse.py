@@ -618,6 +618,7 @@ def unfuse(net):
             del b._fq_pw_fused
             if hasattr(b, "_fq_pw_cache"):
                 del b._fq_pw_cache
+            b.__dict__.pop("_fq_pw_live", None)
         if hasattr(b, "_fq_fused"):
             st = b._fq_fused
             b.hybrid_forward = st["orig"]

@@ -375,3 +375,50 @@ def test_scale_table_export(tmp_path):
     # the block's own widths when none are forced: unsigned 8-bit input -> 255 levels
     own = {e["name"]: e for e in export_scale_table(net)}
     np.testing.assert_allclose(own[conv.name]["scales"], [255.0 / 2.5], rtol=1e-6)
+
+
+def test_weight_fake_quant_is_reused_until_the_parameter_changes():
+    """The reference re-quantises every weight on every forward (convert_conv2d.py:68-99, convert_dense.py:52-63); the product
+    keeps the result while the parameter is the same tensor in the same in-place version: same values, one computation.  An
+    in-place update (an optimiser step), `set_data` and a recording forward each compute afresh."""
+    from quantization.mxnet_amd import ops
+    from quantization.mxnet_amd.mx import autograd
+    rng = np.random.default_rng(5)
+    params = {"tiny_conv0_weight": rng.standard_normal((8, 3, 3, 3)).astype(np.float32),
+              "tiny_conv1_weight": rng.standard_normal((8, 1, 3, 3)).astype(np.float32),
+              "tiny_conv1_bias": rng.standard_normal(8).astype(np.float32),
+              "tiny_conv2_weight": rng.standard_normal((12, 8, 1, 1)).astype(np.float32),
+              "tiny_dense0_weight": rng.standard_normal((5, 12)).astype(np.float32),
+              "tiny_dense0_bias": rng.standard_normal(5).astype(np.float32)}
+    x = mx.nd.array(np.abs(rng.standard_normal((2, 3, 6, 6))).astype(np.float32))
+    with oracle_ops():
+        net = tiny_net(params)
+        convert_fn = {nn.Conv2D: convert.gen_conv2d_converter(), nn.Dense: convert.gen_dense_converter(),
+                      nn.Activation: None, nn.BatchNorm: None}
+        convert.convert_model(net, exclude=[net[0]], convert_fn=convert_fn)
+        qparams_init(net)
+        calls = []
+        real = ops.weight_fake_quant
+
+        def counting(w, *a, **k):
+            calls.append(tuple(w.shape))
+            return real(w, *a, **k)
+        ops.weight_fake_quant = counting
+        try:
+            y0 = net(x).asnumpy()
+            assert len(calls) == 3                                    # two converted convolutions + the Dense
+            y1 = net(x).asnumpy()
+            assert len(calls) == 3 and np.array_equal(y0, y1)         # nothing re-quantised
+            net[4].weight.data()._t.mul_(2.0)                         # in-place update of ONE parameter
+            y2 = net(x).asnumpy()
+            assert len(calls) == 4 and calls[-1] == (12, 8, 1, 1) and not np.array_equal(y2, y0)
+            net[2].weight.set_data(mx.nd.array(params["tiny_conv1_weight"] * 0.5))
+            net(x)
+            assert len(calls) == 5 and calls[-1] == (8, 1, 3, 3)
+            with autograd.record():                                   # a recording forward owns its straight-through links
+                net(x)
+            assert len(calls) == 7                                    # (the Dense keeps its cache: its link is made per forward)
+            net(x)
+            assert len(calls) == 7
+        finally:
+            ops.weight_fake_quant = real

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from quantization.mxnet_amd.csrc import build as B  # noqa: E402
 
-OUT = os.path.join(ROOT, "build_tools", "libfakequant_trace.so")
+OUT = os.path.join(ROOT, "quantization", "mxnet_amd", "csrc", "build", "libfakequant_trace.so")   # (csrc/build travels to the GPU box)
 
 
 def build():
