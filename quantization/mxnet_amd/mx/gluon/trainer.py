@@ -47,43 +47,65 @@ class Trainer(object):
         self._lr = float(lr)
 
     def step(self, batch_size, ignore_stale_grad=False):
+        """One update of every Parameter that received a gradient.  The arithmetic is the per-parameter rule of the module
+        docstring, operation by operation and in that order; it is ISSUED through torch's multi-tensor (`_foreach_*`) kernels -
+        ~15 launches per step instead of 13 per parameter (800 of the ~2000 launches of a CIFAR ResNet-20 QAT step)."""
         rescale = self._rescale_user / float(batch_size)
-        with torch.no_grad():
-            for p in self._params:
-                if p._data is None:
+        live = []
+        for p in self._params:
+            if p._data is None:
+                continue
+            w = p._data._t
+            if w.grad is None:
+                if ignore_stale_grad:
                     continue
-                w = p._data._t
-                g = w.grad
-                if g is None:
-                    if ignore_stale_grad:
-                        continue
-                    raise UserWarning("Gradient of Parameter `%s` has not been updated by backward since the last "
-                                      "`step`; pass ignore_stale_grad=True to skip it" % p.name)
-                g = g * rescale
-                if self._clip is not None:
-                    g = g.clamp(-float(self._clip), float(self._clip))
-                if self._wd:
-                    g = g + self._wd * w
-                key = id(p)
-                if self._opt == "sgd":
-                    if self._momentum:
-                        mom = self._state.get(key)
+                raise UserWarning("Gradient of Parameter `%s` has not been updated by backward since the last "
+                                  "`step`; pass ignore_stale_grad=True to skip it" % p.name)
+            live.append((p, w))
+        if not live:
+            return
+        with torch.no_grad():
+            ws = [w for _, w in live]
+            gs = torch._foreach_mul([w.grad for w in ws], rescale)                   # g' = rescale * g
+            if self._clip is not None:
+                gs = [g.clamp_(-float(self._clip), float(self._clip)) for g in gs]
+            if self._wd:
+                torch._foreach_add_(gs, torch._foreach_mul(ws, self._wd))            # + wd * w
+            if self._opt == "sgd":
+                if self._momentum:
+                    moms = []
+                    for p, w in live:
+                        mom = self._state.get(id(p))
                         if mom is None:
-                            mom = self._state[key] = torch.zeros_like(w)
-                        mom.mul_(self._momentum).sub_(self._lr * g)
-                        w.add_(mom)
-                    else:
-                        w.sub_(self._lr * g)
+                            mom = self._state[id(p)] = torch.zeros_like(w)
+                        moms.append(mom)
+                    torch._foreach_mul_(moms, self._momentum)
+                    torch._foreach_sub_(moms, torch._foreach_mul(gs, self._lr))      # mom = momentum * mom - lr * g'
+                    torch._foreach_add_(ws, moms)
                 else:
-                    st = self._state.get(key)
+                    torch._foreach_sub_(ws, torch._foreach_mul(gs, self._lr))
+            else:
+                ms, vs, by_t = [], [], {}
+                for i, (p, w) in enumerate(live):
+                    st = self._state.get(id(p))
                     if st is None:
-                        st = self._state[key] = (torch.zeros_like(w), torch.zeros_like(w))
-                    t = self._t[key] = self._t.get(key, 0) + 1
-                    m, v = st
-                    m.mul_(self._beta1).add_((1.0 - self._beta1) * g)
-                    v.mul_(self._beta2).add_((1.0 - self._beta2) * g * g)
+                        st = self._state[id(p)] = (torch.zeros_like(w), torch.zeros_like(w))
+                    t = self._t[id(p)] = self._t.get(id(p), 0) + 1
+                    ms.append(st[0])
+                    vs.append(st[1])
+                    by_t.setdefault(t, []).append(i)
+                torch._foreach_mul_(ms, self._beta1)
+                torch._foreach_add_(ms, torch._foreach_mul(gs, 1.0 - self._beta1))   # m = b1 m + (1 - b1) g'
+                torch._foreach_mul_(vs, self._beta2)
+                torch._foreach_add_(vs, torch._foreach_mul(torch._foreach_mul(gs, 1.0 - self._beta2), gs))   # ((1 - b2) g') g'
+                den = torch._foreach_sqrt(vs)
+                torch._foreach_add_(den, self._eps)
+                for t, idx in by_t.items():                          # (one group unless some parameters skipped steps)
                     lr_t = self._lr * math.sqrt(1.0 - self._beta2 ** t) / (1.0 - self._beta1 ** t)
-                    w.sub_(lr_t * m / (v.sqrt() + self._eps))
+                    num = torch._foreach_mul([ms[i] for i in idx], lr_t)
+                    torch._foreach_div_(num, [den[i] for i in idx])                  # (lr_t m) / (sqrt(v) + eps)
+                    torch._foreach_sub_([ws[i] for i in idx], num)
+            for w in ws:
                 w.grad = None                      # 'write': the next backward starts a fresh buffer
 
     def allreduce_grads(self):

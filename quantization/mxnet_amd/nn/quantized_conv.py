@@ -8,8 +8,10 @@ What differs is the machinery: the quantise / dequantise stages are HIP kernels 
 ranges and scales stay in device scalars — no `.asscalar()`), and the reference's Python im2col double loop + fp32 `dot`
 (:34-52, :134-151; 12 544 slices per 112x112 map) is, for dense convolutions (groups == 1, int8 weights), an im2col of the CODES
 followed by `fq_gemm_i8_codes`: int8 x int8 -> exact int32 on the matrix cores (v_mfma_i32_32x32x32_i8), for any
-accumulator size.  Grouped / depthwise convolutions (K = 9 per group) and uint8 weights keep one grouped convolution on
-the integer codes held in fp32, exact under the same condition as the reference's own fp32 dot (|accumulator| < 2^24,
+accumulator size.  Grouped convolutions with int8 weights: when 255 * 127 * K < 2^24 (K = the dot length of one output;
+depthwise: 9) ONE grouped convolution on the integer codes held in fp32 is exact whatever the summation order, beyond that
+the groups go through the integer GEMM one by one, as the reference's loop does (:129-151) - exact int32 in every case.
+uint8 weights keep the fp32 formulation, exact under the same condition as the reference's own fp32 dot (|accumulator| < 2^24,
 :140-144).
 """
 import torch
@@ -99,25 +101,39 @@ class Conv2D(nn.HybridBlock):
                 bi, _ = ops.quantize_codes(b.contiguous(), "scale", rng)
                 b = bi.to(torch.float32)
             x, w = xi._t.to(torch.float32), wi._t.to(torch.float32)
-        if self._quantized and self._groups == 1 and self._weight_dtype == 'int8' and self._weight_range is None:
-            # Dense convolution on the int8 matrix cores: im2col of the CODES (the reference's slices,
-            # :34-52), then fq_gemm_i8_codes - exact int32 for any accumulator size, where the fp32 formulation below
-            # (and the reference's own fp32 `dot`, :140-144) is only exact below 2^24.
+        int8_codes = self._quantized and self._weight_dtype == 'int8' and self._weight_range is None
+        k_group = w.shape[1] * w.shape[2] * w.shape[3]                  # dot length of one output: (Cin / groups) * kh * kw
+        # 255 * 127 * K < 2^24: every partial sum of the integer codes is exact in fp32 in any order
+        fp32_exact = 255 * 127 * k_group < 2 ** 24
+        if int8_codes and (self._groups == 1 or not fp32_exact):
+            # Convolution on the int8 matrix cores: im2col of the CODES (the reference's slices, :34-52),
+            # then fq_gemm_i8_codes - exact int32 for any accumulator size, where the fp32 formulation below (and the
+            # reference's own fp32 `dot`, :140-144) is only exact below 2^24.  Grouped convolutions whose dot length could
+            # pass 2^24 go group by group, as the reference's loop does (:129-151).
             n, _, hp, wp = x.shape
             kh, kw = self._kernel_size
             ho, wo = (hp - kh) // self._strides[0] + 1, (wp - kw) // self._strides[1] + 1
             zoff = 128 if self._input_dtype == 'uint8' and self._input_range is None else 0
             if self._input_range is not None:
                 zoff = 128 if float(self._input_range[0]) >= 0 else 0   # `_quantize`: codes in [0,255] or [-127,127]
-            cols = TF.unfold(x, (kh, kw), stride=self._strides)          # (n, C*kh*kw, L): small exact integers
-            xc = (cols.transpose(1, 2).reshape(n * ho * wo, -1) - float(zoff)).to(torch.int8)
-            wc = w.reshape(w.shape[0], -1).to(torch.int8)
-            y = ops.gemm_i8_codes(xc.contiguous(), wc.contiguous(), n, ho * wo, zoff).reshape(n, -1, ho, wo)
+            g = self._groups
+            cin_g, cout_g = x.shape[1] // g, w.shape[0] // g
+            parts = []
+            for gi in range(g):
+                xg = x if g == 1 else x[:, gi * cin_g:(gi + 1) * cin_g]
+                wg = w if g == 1 else w[gi * cout_g:(gi + 1) * cout_g]
+                cols = TF.unfold(xg, (kh, kw), stride=self._strides)     # (n, C*kh*kw, L): small exact integers
+                xc = (cols.transpose(1, 2).reshape(n * ho * wo, -1) - float(zoff)).to(torch.int8)
+                wc = wg.reshape(wg.shape[0], -1).to(torch.int8)
+                parts.append(ops.gemm_i8_codes(xc.contiguous(), wc.contiguous(), n, ho * wo, zoff).reshape(n, -1, ho, wo))
+            y = parts[0] if g == 1 else torch.cat(parts, dim=1)
             if b is not None:
                 y = y + b.to(torch.int32).reshape(1, -1, 1, 1)
         else:
-            # Grouped / depthwise (K = 9 per group: nothing for a matrix core) and the float path: correlation with
-            # the stride of the reference's window loop (:42-47); integer codes held in fp32, exact below 2^24
+            # The float path, and grouped / depthwise convolutions with short dot products (depthwise: K = 9 - nothing for a
+            # matrix core) and uint8 weights: ONE grouped correlation with the stride of the reference's window loop
+            # (:42-47) on the integer codes held in fp32 - exact when 255 * 127 * K < 2^24 (every int8-weight case that
+            # reaches this branch), as exact as the reference's own fp32 dot otherwise
             y = TF.conv2d(x, w, None, stride=self._strides, padding=0, groups=self._groups)
             if self._quantized:
                 y = y.to(torch.int32)                                  # (:144) cast back to int32

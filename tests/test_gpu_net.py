@@ -488,3 +488,51 @@ def test_eval_head_counts_in_the_classifier_launch(gpu, model, offline):
     head.release()
     assert "_fq_eval_head" not in head.block.__dict__
     fuse.unfuse(net)
+
+
+@pytest.mark.parametrize("groups,cin,expect_gemm", [(2, 256, True), (4, 64, False), (32, 32, False)],
+                         ids=["2-groups-long-dot", "4-groups-short-dot", "depthwise"])
+def test_quantized_grouped_conv2d_is_exact(gpu, groups, cin, expect_gemm):
+    """nn.Conv2D(quantized=True, groups > 1) with int8 weights (reference: a Python loop over the groups, nn/quantized_conv.py:
+    129-151): saturated codes; a dot length whose integer accumulator passes 2^24 (128 * 9 = 1152 terms) goes through the int8
+    matrix cores group by group, shorter ones through ONE grouped convolution that is exact in fp32 - the block returns
+    in_scale * w_scale times the EXACT integer correlation either way."""
+    from quantization.mxnet_amd import mx, ops
+    from quantization.mxnet_amd.nn import Conv2D
+    rng = np.random.default_rng(groups + cin)
+    cout = 2 * groups
+    x = np.full((2, cin, 5, 5), 3.0, np.float32)
+    x[:, :, ::2, ::3] = rng.uniform(2.5, 3.0, x[:, :, ::2, ::3].shape).astype(np.float32)
+    x[0, 0, 0, 0] = 0.0                                              # uint8 range [0, 3]
+    w = np.full((cout, cin // groups, 3, 3), 0.5, np.float32)
+    w[::2] = rng.uniform(0.45, 0.5, w[::2].shape).astype(np.float32)
+    w[1, 0, 0, 0] = -0.5                                             # int8 symmetric range 0.5
+    conv = Conv2D(cout, 3, 1, 0, in_channels=cin, groups=groups, use_bias=False, quantized=True, input_dtype='uint8',
+                  weight_dtype='int8')
+    conv.initialize(ctx=gpu)
+    conv.weight.set_data(mx.nd.array(w, ctx=gpu))
+    calls = []
+    real = ops.gemm_i8_codes
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    ops.gemm_i8_codes = spy
+    try:
+        y = conv(mx.nd.array(x, ctx=gpu)).asnumpy()
+    finally:
+        ops.gemm_i8_codes = real
+    assert (len(calls) == groups) if expect_gemm else (len(calls) == 0)
+    in_scale = np.float32(np.float32(3.0 - 0.0) / np.float32(255))
+    w_scale = np.float32(np.float32(0.5) / np.float32(127))
+    xc = np.round(x / in_scale).astype(np.int64)
+    wc = np.round(w / w_scale).astype(np.int64)
+    cg, og = cin // groups, cout // groups
+    want = np.zeros((2, cout, 3, 3), np.int64)
+    for g in range(groups):
+        for i in range(3):
+            for j in range(3):
+                want[:, g * og:(g + 1) * og, i, j] = np.einsum("ncij,ocij->no", xc[:, g * cg:(g + 1) * cg, i:i + 3, j:j + 3],
+                                                               wc[g * og:(g + 1) * og])
+    assert (np.abs(want).max() > 2 ** 24) == expect_gemm
+    np.testing.assert_allclose(y, want.astype(np.float64) * np.float64(np.float32(in_scale * w_scale)), rtol=2.5e-7)
