@@ -274,8 +274,8 @@ def main():
     ap.add_argument("--min-region-s", type=float, default=1.0,
                     help="total time to cover with repeated blocks when one block is shorter than --min-block-s")
     ap.add_argument("--max-repeats", type=int, default=100)
-    ap.add_argument("--event-every", type=int, default=10,
-                    help="bracket the library's kernels with HIP events in every n-th timed step (default 10)")
+    ap.add_argument("--event-every", type=int, default=25,
+                    help="bracket the library's kernels with HIP events in every n-th timed step (default 25: 20 steps of the default 500; a bracketed step costs ~35 % more and, with --streams > 1, runs alone)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (roofline fields become empty)")
     ap.add_argument("--no-headline", action="store_true",
@@ -288,6 +288,11 @@ def main():
                     help="1: replay the step from hipGraphs, one per resident input batch (the steps that carry kernel "
                          "events still run eagerly).  0 (default): every step launched from the host - the stream is "
                          "GPU-bound either way (measured in one call: 100.4 / 99.9 k images/s eager, 98.9 / 98.2 k replayed)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("FQ_BENCH_STREAMS", "3")),
+                    help="evaluation steps in flight: step i runs on HIP stream i %% S (same net; per-forward device state is "
+                         "kept per stream), so that the ramp and the tail of one batch's ~30 kernels fill with the other batch's work "
+                         "(independent batches; every step's kernels, results and counters are what they are with S = 1).  "
+                         "1: one stream, the figure of rounds 1-3; the line reports that too (`single_stream`)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -325,26 +330,37 @@ def main():
     calib = args.phase != "eval"
     if calib and args.offline:
         raise SystemExit("bench.py: --offline describes the evaluation phase; a calibration phase produces the thresholds")
-    net = build_net(args.model, classes, ctx, fuse=not args.no_fuse and not args.offline, quant_type=args.quant_type,
-                    weight_bits=args.weight_bits, input_bits=args.input_bits, signed=args.input_signed, wino=args.wino,
-                    freeze=not args.offline and not calib)
-    nblocks = len(net.collect_quantized_blocks())
-
     torch.manual_seed(7 + rank)
     rotate = max(1, args.rotate)
     batches = [mx.nd.NDArray(torch.randn(args.batch_size, 3, hw, hw, device=dev)) for _ in range(rotate)]
     labels = [torch.randint(0, classes, (args.batch_size,), device=dev) for _ in range(rotate)]
     counters = torch.zeros(2 + 2 * classes, dtype=torch.float32, device=dev)   # n_correct, total, correct[c], label[c]
-    if args.offline:
-        for i in range(2):                            # naive-EMA calibration (simulate_quantization.py:320-323)
-            net(batches[i % rotate])
-            net.update_ema()
-        net.fix_params()
-        net.quantize_input(enable=True, online=False)
-        if not args.no_fuse:
-            net(batches[0])                           # the freezing forward
-            from quantization.mxnet_amd.quantize import fuse as _fuse
-            _fuse.fuse_inference(net)
+
+    def prepare_net():
+        """One replica of the net in the state the timed steps need (same seed: the same weights in every replica)."""
+        net = build_net(args.model, classes, ctx, fuse=not args.no_fuse and not args.offline, quant_type=args.quant_type,
+                        weight_bits=args.weight_bits, input_bits=args.input_bits, signed=args.input_signed, wino=args.wino,
+                        freeze=not args.offline and not calib)
+        if args.offline:
+            for i in range(2):                            # naive-EMA calibration (simulate_quantization.py:320-323)
+                net(batches[i % rotate])
+                net.update_ema()
+            net.fix_params()
+            net.quantize_input(enable=True, online=False)
+            if not args.no_fuse:
+                net(batches[0])                           # the freezing forward
+                from quantization.mxnet_amd.quantize import fuse as _fuse
+                _fuse.fuse_inference(net)
+        return net
+
+    # Steps in flight (--streams): evaluation only, eager launches only.  ONE net: a forward on a side stream keeps its
+    # per-forward device state (statistic arena, batch-statistic slots, workspaces) per stream (quantize/fuse.py,
+    # quantize/convert/_blocks.py: scalar_slot), so forwards of independent batches may overlap on the device
+    n_streams = max(1, args.streams) if args.phase == "eval" and not args.graph else 1
+    net = prepare_net()
+    nets = [net] * n_streams
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+    nblocks = len(net.collect_quantized_blocks())
     from quantization.mxnet_amd import dist as fqdist
     if args.phase == "calib-naive" and distributed:
         # ONE all-reduce of L + 1 doubles per calibration step (dist.py; north_star's collective)
@@ -353,20 +369,27 @@ def main():
         net.disable_quantize()                        # fp32 inputs and weights while collecting (:298)
     kl_extra = {}
     from quantization.mxnet_amd.quantize import fuse as _fuse_mod
-    head = _fuse_mod.eval_head(net, counters) if args.phase == "eval" and not args.no_fuse \
-        and os.environ.get("FQ_BENCH_HEAD", "1") != "0" else None
+    use_head = args.phase == "eval" and not args.no_fuse and os.environ.get("FQ_BENCH_HEAD", "1") != "0"
+    heads = [_fuse_mod.eval_head(net, counters) if use_head else None] * n_streams
 
-    def step(i):
+    def eval_step(i, lane):
+        head = heads[lane]
+        if head is not None:
+            head.labels = labels[i % rotate]          # the classifier's launch counts as well (fq_dense_i8_eval)
+        out = nets[lane](batches[i % rotate])._t
+        if head is None or not head.take():
+            ops.eval_counters(out, labels[i % rotate], counters)      # the eval loop's argmax + counters, one launch
+        return out
+
+    def step(i, lane=0):
         if args.phase == "calib-naive":               # evaluate(..., update_ema=True): forward, then the EMA of the thresholds
             out = net(batches[i % rotate])._t
             net.update_ema()
             return out
-        if head is not None:
-            head.labels = labels[i % rotate]          # the classifier's launch counts as well (fq_dense_i8_eval)
-        out = net(batches[i % rotate])._t
-        if head is None or not head.take():
-            ops.eval_counters(out, labels[i % rotate], counters)      # the eval loop's argmax + counters, one launch
-        return out
+        if streams[lane] is None:
+            return eval_step(i, lane)
+        with torch.cuda.stream(streams[lane]):
+            return eval_step(i, lane)
 
     class _KLBatches(object):
         """The loader `collect_feature_maps` walks: `count` resident batches; kernel events are switched on for every
@@ -401,12 +424,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if n_streams > 1:
+        torch.cuda.synchronize()                      # (the lanes are non-blocking streams: nothing orders them behind the default one)
+        step(0, 0)                                    # set-up: the weight codes are made once, by the first forward ...
+        torch.cuda.synchronize()
+        for lane in range(1, n_streams):              # ... and every stream gets its arena, slots and workspaces
+            step(0, lane)
     if args.phase == "calib-kl":
         if args.warmup:
             kl_block(0, args.warmup, 0)
     else:
         for i in range(max(args.warmup, rotate) if args.graph else args.warmup):
-            step(i)
+            step(i, i % n_streams)
     torch.cuda.synchronize()
 
     # hipGraph replay of the step (one captured graph per resident input batch): the ~45 launches of a step are
@@ -449,9 +478,12 @@ def main():
         if args.phase == "calib-kl":
             profiled_steps += kl_block(first_step, args.steps, event_every)
         else:
+            sampled = []
             for i in range(first_step, first_step + args.steps):
                 on = bool(event_every) and (i % event_every == 0)
-                if on:
+                if on and n_streams > 1:
+                    sampled.append(i)                 # two steps in flight: the sampled steps run at the END of the block, alone
+                elif on:
                     ops.profile_enable(True)
                     profiled_steps += 1
                     step(i)
@@ -459,7 +491,17 @@ def main():
                 elif graphs is not None:
                     graphs[i % rotate].replay()
                 else:
-                    step(i)
+                    step(i, i % n_streams)
+            if sampled:
+                # ONE drain, then the steps that carry kernel events one after the other on one stream - still inside the
+                # timed region and charged to `value` (a drain in front of and behind every sampled step cost more than the
+                # second stream gained)
+                torch.cuda.synchronize()
+                ops.profile_enable(True)
+                for i in sampled:
+                    profiled_steps += 1
+                    step(i, 0)
+                ops.profile_enable(False)
         barrier()
         dt = time.perf_counter() - t0
         if distributed:
@@ -476,6 +518,19 @@ def main():
         while sum(blocks) < args.min_region_s and len(blocks) < args.max_repeats:
             blocks.append(timed_block(len(blocks) * args.steps))
     elapsed = float(np.median(blocks))
+    # the same steps on ONE stream (the figure of rounds 1-3), no kernel events: one block, reported beside `value`
+    single_s = None
+    if n_streams > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, 0)
+        barrier()
+        single_s = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([single_s], dtype=torch.float64, device=dev)
+            all_reduce(t, dist.ReduceOp.MAX)
+            single_s = float(t.item())
     kl_search_ms, thresholds = None, None
     if args.phase == "calib-kl":
         # the threshold search over all layers: ONE launch (reference: ~1.4 s of Python per layer); once per calibration
@@ -561,7 +616,12 @@ def main():
                                                "calib-kl": "ranges broadcast after the first batch, ONE all-reduce of the "
                                                            "exact histograms at the end"}[args.phase]),
                        "hipgraph": graphs is not None, "hipgraph_error": graph_error,
-                       "fused_producers": not args.no_fuse},
+                       "fused_producers": not args.no_fuse,
+                       "streams": n_streams,
+                       "streams_what": "step i runs on HIP stream i % S (one net; per-forward device state per stream): "
+                                       "independent batches, S in flight; the steps that carry kernel events run at the end "
+                                       "of their block, alone on one stream (inside the timed region)" if n_streams > 1
+                                       else "one stream"},
             "roofline": {"bound": "hbm", "kernel": dk["kernel"], "achieved": dk["achieved"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dk["frac"], "frac_raw_events": dk["frac_raw_events"],
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -587,6 +647,10 @@ def main():
                               "what": "fq_eval_counters over every step run so far (warm-up included), summed over "
                                       "the ranks in ONE all-reduce after the timed region"},
         }
+        if single_s is not None:
+            line["single_stream"] = {"value": round(images / single_s, 2), "ms_per_step": round(single_s / args.steps * 1e3, 4),
+                                     "what": "the same %d steps launched on ONE stream (--streams 1), one block, no kernel "
+                                             "events" % args.steps}
         if args.phase != "eval":
             del line["eval_counters"]
         if args.phase == "calib-kl":

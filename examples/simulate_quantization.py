@@ -20,6 +20,7 @@ counters and KL histograms / search on the device, optional one-process-per-GPU 
 and seeded weights when ImageNet / gluoncv checkpoints are absent (there is no network here).
 """
 import argparse
+import contextlib
 import os
 import sys
 import time
@@ -99,6 +100,11 @@ EXTRA_FLAGS = [
     (['--export-scale-table'], dict(type=str, default=None,
                                     help='after calibration write an ncnn-style int8 scale table (per-channel weight scales '
                                          'after BN folding, one input scale per layer; quantize/freeze/scale_table.py)')),
+    (['--eval-streams'], dict(type=int, default=3,
+                              help='batches in flight during evaluation, one HIP stream each (quantize/fuse.py keeps the '
+                                   'per-forward device state per stream): the ramp and the tail of one batch\'s kernels fill '
+                                   'with the next batch\'s work; results are those of one batch at a time.  Calibration passes '
+                                   '(update_ema) always run one batch at a time.  (default: 3)')),
     (['--strict-global-batch'], dict(action='store_true',
                                      help='(multi-GPU naive calibration) reproduce ONE device that sees the global batch bit '
                                           'for bit: one small all-gather per quantised layer per forward instead of the '
@@ -192,25 +198,50 @@ def _total_batches(loader):
 
 
 # ---- evaluation ------------------------------------------------------------------------------------------------------------
-def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"):
+def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval", streams=1):
     """One pass over `dataloader`: top-1 accuracy and class-averaged accuracy (the quantities of the reference's
-    `evaluate`, :122-148).  The counters [n_correct, total, correct[c], label[c]] live on the device (fq_eval_counters)
-    and cross the ranks in one all-reduce; with `update_ema` every batch is a calibration step."""
+    `evaluate`, :122-148).  The counters [n_correct, total, correct[c], label[c]] live on the device (fq_eval_counters; in
+    the classifier's own launch when the net is fused: quantize.fuse.EvalHead) and cross the ranks in one all-reduce; with
+    `update_ema` every batch is a calibration step.  `streams` > 1 (evaluation only): that many batches in flight."""
+    from quantization.mxnet_amd.quantize import fuse as _fuse
     dev = ctx.torch_device
     counters = torch.zeros(2 + 2 * num_class, dtype=torch.float32, device=dev)
     seen, started = 0, time.perf_counter()
     steps = fqdist.calibration_steps(_total_batches(dataloader)) if update_ema and fqdist.world_size() > 1 else None
     done = 0
-    with tqdm(total=len(dataloader), desc=tqdm_desc, disable=fqdist.rank() != 0) as bar:
-        for X, y in dataloader:
-            labels = y.as_in_context(ctx)._t.long()
-            logits = net(X.as_in_context(ctx))
-            if update_ema:
-                net.update_ema()
-            ops.eval_counters(logits._t, labels, counters)
-            seen += int(labels.numel())
-            done += 1
-            bar.update(1)
+    lanes = [torch.cuda.Stream(dev) for _ in range(streams)] if streams > 1 and not update_ema and dev.type == "cuda" else None
+    head = _fuse.eval_head(net, counters) if dev.type == "cuda" else None
+    try:
+        with tqdm(total=len(dataloader), desc=tqdm_desc, disable=fqdist.rank() != 0) as bar:
+            for X, y in dataloader:
+                lane = lanes[done % len(lanes)] if lanes else None
+                if lane is not None:
+                    # the lanes are non-blocking streams: what the default stream has issued so far - the calibrated thresholds,
+                    # this batch if the loader made it on the device - must be complete before the lane reads it, and the
+                    # batch's memory must not go back to the default stream's pool while the lane still reads it
+                    lane.wait_stream(torch.cuda.current_stream(dev))
+                    for t in (X._t, y._t):
+                        if t.is_cuda:
+                            t.record_stream(lane)
+                with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()):
+                    labels = y.as_in_context(ctx)._t.long()
+                    if head is not None:
+                        head.labels = labels
+                    logits = net(X.as_in_context(ctx))
+                    if update_ema:
+                        net.update_ema()
+                    if head is None or not head.take():
+                        ops.eval_counters(logits._t, labels, counters)
+                seen += int(labels.numel())
+                done += 1
+                bar.update(1)
+                if lanes and done == 1:
+                    # what the first forward creates once - frozen weights, weight codes, folded BatchNorm constants - is read
+                    # by the forwards on the other streams: wait for it
+                    torch.cuda.synchronize(dev)
+    finally:
+        if head is not None:
+            head.release()
     while steps is not None and done < steps:          # this rank's shard ran out first: keep the collectives in step
         fqdist.empty_calibration_step(net)
         done += 1
@@ -360,7 +391,7 @@ class Simulation(object):
                     fqdist.detach_calibration_sync(net)       # offline evaluation exchanges nothing per batch
                 net.quantize_input(enable=True, online=False)
                 self.report(*evaluate(net, self.classes, self.eval_loader, ctx=self.ctx,
-                                      tqdm_desc="Eval[{}/{}]".format(epoch, opt.calib_epoch)))
+                                      tqdm_desc="Eval[{}/{}]".format(epoch, opt.calib_epoch), streams=opt.eval_streams))
                 if self.chief:
                     print()
                 if self.world > 1 and epoch < opt.calib_epoch:
@@ -384,7 +415,7 @@ class Simulation(object):
     def final_evaluation(self, online):
         self.net.fix_params()
         self.net.quantize_input(enable=True, online=online)
-        acc, avg_acc = evaluate(self.net, self.classes, self.eval_loader, ctx=self.ctx)
+        acc, avg_acc = evaluate(self.net, self.classes, self.eval_loader, ctx=self.ctx, streams=self.opt.eval_streams)
         if self.chief:
             print('*' * 25 + ' Result ' + '*' * 25)
         self.report(acc, avg_acc)

@@ -9,7 +9,8 @@ ranges and scales stay in device scalars — no `.asscalar()`), and the referenc
 (:34-52, :134-151; 12 544 slices per 112x112 map) is, for dense convolutions (groups == 1, int8 weights), an im2col of the CODES
 followed by `fq_gemm_i8_codes`: int8 x int8 -> exact int32 on the matrix cores (v_mfma_i32_32x32x32_i8), for any
 accumulator size.  Grouped convolutions with int8 weights: when 255 * 127 * K < 2^24 (K = the dot length of one output;
-depthwise: 9) ONE grouped convolution on the integer codes held in fp32 is exact whatever the summation order, beyond that
+depthwise: 9) the reference's im2col + dot as ONE batched fp32 matrix product of the integer codes is exact whatever the
+summation order (the library convolution is not: its Winograd kernels transform the operands), beyond that
 the groups go through the integer GEMM one by one, as the reference's loop does (:129-151) - exact int32 in every case.
 uint8 weights keep the fp32 formulation, exact under the same condition as the reference's own fp32 dot (|accumulator| < 2^24,
 :140-144).
@@ -129,17 +130,26 @@ class Conv2D(nn.HybridBlock):
             y = parts[0] if g == 1 else torch.cat(parts, dim=1)
             if b is not None:
                 y = y + b.to(torch.int32).reshape(1, -1, 1, 1)
+        elif self._quantized:
+            # Grouped / depthwise convolutions with short dot products (depthwise: K = 9 - nothing for a matrix core) and
+            # uint8 weights: the reference's im2col + dot (:129-151) for all groups at once - the window slices of the integer
+            # codes held in fp32 times the weight matrix of each group, as ONE batched matrix product.  Products and partial
+            # sums are integers: exact in any summation order while 255 * 127 * K < 2^24 (every int8-weight case that reaches
+            # this branch), as exact as the reference's own fp32 dot otherwise.  (Not the library convolution: its Winograd
+            # kernels transform the operands and are not exact on integers.)
+            n, _, hp, wp = x.shape
+            kh, kw = self._kernel_size
+            ho, wo = (hp - kh) // self._strides[0] + 1, (wp - kw) // self._strides[1] + 1
+            g = self._groups
+            cols = TF.unfold(x, (kh, kw), stride=self._strides).reshape(n, g, k_group, ho * wo)
+            y = torch.matmul(w.reshape(1, g, w.shape[0] // g, k_group), cols).reshape(n, w.shape[0], ho, wo)
+            y = y.to(torch.int32)                                      # (:144) cast back to int32
+            if b is not None:
+                y = y + b.to(torch.int32).reshape(1, -1, 1, 1)
         else:
-            # The float path, and grouped / depthwise convolutions with short dot products (depthwise: K = 9 - nothing for a
-            # matrix core) and uint8 weights: ONE grouped correlation with the stride of the reference's window loop
-            # (:42-47) on the integer codes held in fp32 - exact when 255 * 127 * K < 2^24 (every int8-weight case that
-            # reaches this branch), as exact as the reference's own fp32 dot otherwise
+            # The float path: correlation with the stride of the reference's window loop (:42-47)
             y = TF.conv2d(x, w, None, stride=self._strides, padding=0, groups=self._groups)
-            if self._quantized:
-                y = y.to(torch.int32)                                  # (:144) cast back to int32
-                if b is not None:
-                    y = y + b.to(torch.int32).reshape(1, -1, 1, 1)
-            elif b is not None:
+            if b is not None:
                 y = y + b.reshape(1, -1, 1, 1)
         y = NDArray(y)
         if self.act is not None:

@@ -84,3 +84,30 @@ class BatchNormTerms(object):
 
 def contiguous(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+def on_side_stream(t):
+    """True when the launches for `t` go to a HIP stream other than the device's default one: a forward of an evaluation
+    loop that keeps several batches in flight (one stream each).  Such a forward writes its batch statistic into a slot of
+    its own (`scalar_slot`), so that forwards in flight do not meet in a block's `current_*_max`; calibration (`update_ema`)
+    reads the forwards of the default stream, which is where it runs."""
+    import torch
+    return t.is_cuda and torch.cuda.current_stream(t.device) != torch.cuda.default_stream(t.device)
+
+
+def scalar_slot(block, like):
+    """(1,) device tensor receiving this block's current batch statistic (`current_input_max` / `current_act_max`): the
+    block's own slot - a slice of the net's calibration arena once `net.update_ema()` has bound one (convert.py) - or, on a
+    side stream, a slot private to (block, stream).  Returns (slot, side)."""
+    import torch
+    if on_side_stream(like):
+        side = block.__dict__.setdefault("_fq_cur_side", {})
+        key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream)
+        slot = side.get(key)
+        if slot is None:
+            slot = side[key] = torch.zeros(1, dtype=torch.float32, device=like.device)
+        return slot, True
+    slot = getattr(block, "_fq_cur", None)
+    if slot is None or slot.device != like.device:
+        slot = block._fq_cur = torch.zeros(1, dtype=torch.float32, device=like.device)
+    return slot, False

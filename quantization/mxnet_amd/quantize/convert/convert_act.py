@@ -14,7 +14,7 @@ from ...mx import autograd
 from ...mx.gluon.nn import Activation
 from ... import ops
 from .._state import DeviceScalar
-from ._blocks import OUTPUT_RANGE, contiguous, rebind_forward
+from ._blocks import OUTPUT_RANGE, contiguous, rebind_forward, scalar_slot
 
 __all__ = ["convert_relu_to_relu6", 'gen_act_converter']
 
@@ -34,13 +34,6 @@ def convert_relu_to_relu6(m):
     rebind_forward(m, _clipped_relu, keep_origin=False)
 
 
-def _scalar_slot(block, like):
-    slot = getattr(block, "_fq_cur", None)
-    if slot is None or slot.device != like.device:
-        slot = block._fq_cur = torch.zeros(1, dtype=torch.float32, device=like.device)
-    return slot
-
-
 def _quantised_activation(self, F, x, act_max=None):
     out = self.origin_forward(F, x)
     args = self.quantize_args
@@ -48,7 +41,7 @@ def _quantised_activation(self, F, x, act_max=None):
         return out
     t = contiguous(out._t)
     n = t.shape[0]
-    cur = _scalar_slot(self, t)
+    cur, side = scalar_slot(self, t)
     flags = ops.act_flags(**_OUTPUT_FLAGS)
     # batch sharded over ranks (dist.py): the per-sample maxima land in this block's row of the net's statistic matrix;
     # strict mode exchanges them before the apply pass, the default mode reads the rows back at `update_ema`
@@ -79,7 +72,8 @@ def _quantised_activation(self, F, x, act_max=None):
     if y is not None:
         out = NDArray(autograd.ste_link(t, y))                 # identity backward; a no-op unless recording
     self._fq_last_n = n
-    self.current_act_max = DeviceScalar(cur)
+    if not side:
+        self.current_act_max = DeviceScalar(cur)
     return out
 
 

@@ -26,7 +26,7 @@ from ...mx.ndarray import NDArray
 from ...mx.gluon.nn import Conv2D
 from ... import ops
 from .._state import DeviceScalar
-from ._blocks import INPUT_RANGE, BatchNormTerms, contiguous, rebind_forward
+from ._blocks import INPUT_RANGE, BatchNormTerms, contiguous, rebind_forward, scalar_slot
 
 __all__ = ['gen_conv2d_converter']
 
@@ -40,12 +40,8 @@ WINOGRAD_VARIANTS = ("F23", "F43", "F63")
 
 # ---- activation branch ---------------------------------------------------------------------------------------------------
 def current_slot(block, like):
-    """(1,) device tensor receiving this block's `current_input_max` (a slice of the net's arena once `net.update_ema()`
-    has bound one — convert.py)."""
-    slot = getattr(block, "_fq_cur", None)
-    if slot is None or slot.device != like.device:
-        slot = block._fq_cur = torch.zeros(1, dtype=torch.float32, device=like.device)
-    return slot
+    """(1,) device tensor receiving this block's `current_input_max` (`_blocks.scalar_slot`)."""
+    return scalar_slot(block, like)[0]
 
 
 class _InputView(object):
@@ -56,7 +52,7 @@ class _InputView(object):
     def __init__(self, block, x):
         self.t = contiguous(x._t)
         self.n = self.t.shape[0]
-        self.cur = current_slot(block, self.t)
+        self.cur, self.side = scalar_slot(block, self.t)
         rows = getattr(block, "_fq_stat_ws", None)
         if rows is not None and (rows.device != self.t.device or rows.numel() < self.n):
             rows = None
@@ -78,6 +74,8 @@ class _InputView(object):
         return self.hint
 
     def finish(self, block):
+        if self.side:                                    # a batch in flight beside others: nothing of the block changes
+            return
         block._fq_last_n = self.n
         block.current_input_max = DeviceScalar(self.cur)
 

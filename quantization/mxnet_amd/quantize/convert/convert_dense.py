@@ -11,7 +11,7 @@ from ...mx import autograd
 from ...mx.gluon.nn import Dense
 from ... import ops
 from .._state import DeviceScalar
-from ._blocks import INPUT_RANGE, contiguous, rebind_forward
+from ._blocks import INPUT_RANGE, contiguous, rebind_forward, scalar_slot
 from .convert_conv2d import fake_quant_block_input, fused_input_plan, current_slot
 
 __all__ = ['gen_dense_converter']
@@ -23,9 +23,10 @@ def _quantise_unflattened_input(block, x, input_max, flags, width):
     """`F.max(F.abs(x), axis=1)` on an (N, C, H, W) input reduces over C only and `.mean()` then averages N*H*W values
     (:41): statistic through torch's exact amax, ordered mean and apply pass in HIP."""
     t = contiguous(x._t)
-    cur = current_slot(block, t)
+    cur, side = scalar_slot(block, t)
     ops.batch_mean(t.abs().amax(dim=1).reshape(-1).contiguous(), out=cur)
-    block.current_input_max = DeviceScalar(cur)
+    if not side:
+        block.current_input_max = DeviceScalar(cur)
     if not block.quantize_input:
         return x
     threshold = input_max._t if block.quantize_input_offline else cur

@@ -513,20 +513,26 @@ def _install_stat_arena(net, producers):
     """One zeroing launch per forward for all producers' per-sample statistic rows (ops.StatArena)."""
     if producers <= 0 or hasattr(net, "_fq_arena_hooks"):
         return
-    state = {"arena": None}
+    state = {}                                          # (device, stream) -> arena: forwards in flight on different streams
+    live = []                                           # ... (an evaluation loop with several batches in flight) do not share rows
 
     def pre(block, args):
         x = args[0]
         dev = x._t.device
         if dev.type != "cuda":
+            live.append(None)
             return
-        if state["arena"] is None or state["arena"].device != dev:
-            state["arena"] = ops.StatArena(producers + 8, dev)
-        state["arena"].begin(x.shape[0])
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        arena = state.get(key)
+        if arena is None:
+            arena = state[key] = ops.StatArena(producers + 8, dev)
+        arena.begin(x.shape[0])
+        live.append(arena)
 
     def post(block, args, out):
-        if state["arena"] is not None:
-            state["arena"].end()
+        arena = live.pop() if live else None
+        if arena is not None:
+            arena.end()
     net._fq_arena_hooks = (net.register_forward_pre_hook(pre), net.register_forward_hook(post))
 
 

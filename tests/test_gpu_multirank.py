@@ -32,12 +32,13 @@ def _free_port():
     return p
 
 
-def test_bench_launches_its_own_ranks(gpu):
+@pytest.mark.parametrize("streams", [2, 1])
+def test_bench_launches_its_own_ranks(gpu, streams):
     env = dict(os.environ, FQ_BENCH_SHARE_GPU="1", FQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-           "--no-cpu-baseline", "--max-repeats", "4"]
+           "--no-cpu-baseline", "--max-repeats", "4", "--streams", str(streams)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -47,8 +48,11 @@ def test_bench_launches_its_own_ranks(gpu):
     assert rec["config"]["global_batch"] == 256
     assert rec["scaling"] == "weak" and rec["unit"] == "images/sec" and rec["value"] > 0
     assert rec["repeats"] == 4 and rec["consistency"]["blocks"] == 4
-    # counters summed over BOTH ranks in one all-reduce: every step either rank ran (warm-up + 4 blocks of 3) x 128 images
-    assert rec["eval_counters"]["images"] == 2 * 128 * (2 + 4 * 3)
+    # counters summed over BOTH ranks in one all-reduce: every step either rank ran (warm-up + 4 blocks of 3) x 128 images;
+    # with two steps in flight also the set-up forward of each stream and the one-stream block of 3 steps
+    extra = (2 + 3) if streams == 2 else 0
+    assert rec["eval_counters"]["images"] == 2 * 128 * (2 + 4 * 3 + extra)
+    assert rec["config"]["streams"] == streams and ("single_stream" in rec) == (streams == 2)
     assert abs(rec["value"] - 256 * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-3
     assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec and "headline_tensor" not in rec
 

@@ -536,3 +536,54 @@ def test_quantized_grouped_conv2d_is_exact(gpu, groups, cin, expect_gemm):
                                                                wc[g * og:(g + 1) * og])
     assert (np.abs(want).max() > 2 ** 24) == expect_gemm
     np.testing.assert_allclose(y, want.astype(np.float64) * np.float64(np.float32(in_scale * w_scale)), rtol=2.5e-7)
+
+
+@pytest.mark.parametrize("model,offline", [("mobilenet1.0", False), ("resnet50_v1", True)], ids=["mobilenet1.0-online", "resnet50_v1-offline"])
+def test_forwards_in_flight_on_several_streams_equal_sequential_forwards(gpu, model, offline):
+    """An evaluation loop may keep several independent batches in flight, one HIP stream each (bench.py --streams): a forward
+    on a side stream takes its statistic arena, its batch-statistic slots and its workspaces per stream, so the forwards
+    overlap on the device and give what they give one after the other - logits bit for bit, counters equal - and leave the
+    blocks' `current_input_max` (the calibration state of the default stream) alone."""
+    from quantization.mxnet_amd import mx, ops
+    from quantization.mxnet_amd.quantize import fuse
+    net = _build(model, 1000, gpu)
+    rng = np.random.default_rng(11)
+    batch, hw = 8, 64
+    xs = [mx.nd.array(rng.standard_normal((batch, 3, hw, hw)).astype(np.float32) * (1 + i), ctx=gpu) for i in range(6)]
+    if offline:
+        net(xs[0])
+        net.update_ema()
+    net.fix_params()
+    net.quantize_input(enable=True, online=not offline)
+    assert fuse.fuse_inference(net) > 0
+    dev = gpu.torch_device
+    labels = [torch.from_numpy(rng.integers(0, 1000, batch).astype(np.int64)).to(dev) for _ in xs]
+    c_seq = torch.zeros(2002, device=dev)
+    c_par = torch.zeros(2002, device=dev)
+    head = fuse.eval_head(net, c_seq)
+    ref = []
+    for x, lb in zip(xs, labels):                       # one after the other on the default stream
+        head.labels = lb
+        ref.append(net(x)._t.clone())
+        assert head.take()
+    blocks = net.collect_quantized_blocks()
+    cur_before = [float(b.current_input_max) for b in blocks if hasattr(b, "current_input_max")]
+    torch.cuda.synchronize()
+    head.counters = c_par
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    outs = []
+    for rep in range(3):                                # ... and with three in flight, three times over
+        outs = []
+        for i, (x, lb) in enumerate(zip(xs, labels)):
+            with torch.cuda.stream(streams[i % 3]):
+                head.labels = lb
+                outs.append(net(x)._t)
+                assert head.take()
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            assert torch.equal(o, r)
+    assert torch.equal(c_par, 3 * c_seq)
+    cur_after = [float(b.current_input_max) for b in blocks if hasattr(b, "current_input_max")]
+    assert cur_after == cur_before
+    head.release()
+    fuse.unfuse(net)

@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "build_tools", "libfakequant_trace.so")
+OUT = os.path.join(ROOT, "quantization", "mxnet_amd", "csrc", "build", "libfakequant_trace.so")
 
 
 def main():
