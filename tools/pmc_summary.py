@@ -33,6 +33,8 @@ def family(n):
         return 'pool'
     if 'minmax_kernel' in n:
         return 'global_max'
+    if 'pwconv_rows_kernel' in n:
+        return 'dense'                       # the classifier on the codes: its own family (bench.py: FQ_KERNEL_DENSE)
     if 'pwconv_' in n or 'quant_transpose_i8_kernel' in n:
         return 'pwconv'
     if 'weight_codes_kernel' in n or 'weight_rows_lds_kernel' in n or 'weight_apply_kernel' in n:
