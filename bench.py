@@ -284,10 +284,13 @@ def main():
                     help="keep BatchNorm / ReLU as separate torch ops (no quantize.fuse.fuse_inference)")
     ap.add_argument("--autotune", action="store_true",
                     help="MIOpen find/benchmark mode (measured: no gain for these shapes, +60 s of search)")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("FQ_BENCH_GRAPH", "0")),
-                    help="1: replay the step from hipGraphs, one per resident input batch (the steps that carry kernel "
-                         "events still run eagerly).  0 (default): every step launched from the host - the stream is "
-                         "GPU-bound either way (measured in one call: 100.4 / 99.9 k images/s eager, 98.9 / 98.2 k replayed)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("FQ_BENCH_GRAPH", "1")),
+                    help="1 (default): replay the evaluation step from hipGraphs, one per (stream, resident input batch); the "
+                         "steps that carry kernel events still run eagerly.  The host needs ~1.05 ms to launch the ~32 kernels "
+                         "of a step from Python - as long as the GPU needs for them: on ONE stream replay changes nothing (the "
+                         "host runs ahead of a GPU-bound stream: 108.0 vs 109.3 k images/s), with several batches in flight the "
+                         "eager host becomes the limit (100.7 k on a box with a slow host) and replay lifts it (127.7-128.8 k in "
+                         "the same call).  0: every step launched from the host")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FQ_BENCH_STREAMS", "3")),
                     help="evaluation steps in flight: step i runs on HIP stream i %% S (same net; per-forward device state is "
                          "kept per stream), so that the ramp and the tail of one batch's ~30 kernels fill with the other batch's work "
@@ -356,7 +359,7 @@ def main():
     # Steps in flight (--streams): evaluation only, eager launches only.  ONE net: a forward on a side stream keeps its
     # per-forward device state (statistic arena, batch-statistic slots, workspaces) per stream (quantize/fuse.py,
     # quantize/convert/_blocks.py: scalar_slot), so forwards of independent batches may overlap on the device
-    n_streams = max(1, args.streams) if args.phase == "eval" and not args.graph else 1
+    n_streams = max(1, args.streams) if args.phase == "eval" else 1
     net = prepare_net()
     nets = [net] * n_streams
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
@@ -434,9 +437,16 @@ def main():
         if args.warmup:
             kl_block(0, args.warmup, 0)
     else:
-        for i in range(max(args.warmup, rotate) if args.graph else args.warmup):
+        for i in range(args.warmup):
             step(i, i % n_streams)
     torch.cuda.synchronize()
+
+    def replay(lane, b):
+        if streams[lane] is None:
+            graphs[lane][b].replay()
+        else:
+            with torch.cuda.stream(streams[lane]):
+                graphs[lane][b].replay()
 
     # hipGraph replay of the step (one captured graph per resident input batch): the ~45 launches of a step are
     # launch-latency-sensitive (1.3 ms of kernels); replay removes the host from the loop.  The steps that carry the kernel
@@ -444,14 +454,23 @@ def main():
     graphs, graph_error = None, None
     if args.graph and args.phase == "eval":
         try:
-            graphs = []
-            for b in range(rotate):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    step(b)
-                graphs.append(g)
-            for g in graphs:
-                g.replay()
+            # one graph per (stream, resident batch): a forward's per-stream buffers are baked into its graph, so a graph is
+            # replayed on the stream it was captured on; the graphs of a stream share one memory pool (they never overlap)
+            graphs = [[None] * rotate for _ in range(n_streams)]
+            for lane in range(n_streams):
+                pool = torch.cuda.graph_pool_handle()
+                for b in range(rotate):
+                    g = torch.cuda.CUDAGraph()
+                    if streams[lane] is None:
+                        with torch.cuda.graph(g, pool=pool):
+                            eval_step(b, lane)
+                    else:
+                        with torch.cuda.graph(g, pool=pool, stream=streams[lane]):
+                            eval_step(b, lane)
+                    graphs[lane][b] = g
+            for lane in range(n_streams):
+                for b in range(rotate):
+                    replay(lane, b)
             torch.cuda.synchronize()
         except Exception as e:                       # capture is an optimisation: fall back to eager launches, and say so
             graphs, graph_error = None, "%s: %s" % (type(e).__name__, str(e)[:200])
@@ -489,7 +508,7 @@ def main():
                     step(i)
                     ops.profile_enable(False)
                 elif graphs is not None:
-                    graphs[i % rotate].replay()
+                    replay(i % n_streams, i % rotate)
                 else:
                     step(i, i % n_streams)
             if sampled:
@@ -524,7 +543,10 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(i, 0)
+            if graphs is not None:
+                replay(0, i % rotate)
+            else:
+                step(i, 0)
         barrier()
         single_s = time.perf_counter() - t0
         if distributed:

@@ -86,13 +86,26 @@ def contiguous(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def on_side_stream(t):
-    """True when the launches for `t` go to a HIP stream other than the device's default one: a forward of an evaluation
-    loop that keeps several batches in flight (one stream each).  Such a forward writes its batch statistic into a slot of
-    its own (`scalar_slot`), so that forwards in flight do not meet in a block's `current_*_max`; calibration (`update_ema`)
-    reads the forwards of the default stream, which is where it runs."""
+def _stream_of(t):
+    """(key, side) of the stream the launches for `t` go to: key = (device index, stream handle); side = not the device's
+    default stream, i.e. a forward of an evaluation loop that keeps several batches in flight (one stream each).  Inside a
+    fused net's forward the answer is the one quantize/fuse.py looked up once for the whole forward."""
     import torch
-    return t.is_cuda and torch.cuda.current_stream(t.device) != torch.cuda.default_stream(t.device)
+    from ... import ops
+    fwd = getattr(ops.StatArena._tls, "forward", None)
+    if fwd is not None and fwd[0] == t.device:
+        return fwd[1], fwd[2]
+    if not t.is_cuda:
+        return None, False
+    cur = torch.cuda.current_stream(t.device)
+    return (t.device.index, cur.cuda_stream), cur != torch.cuda.default_stream(t.device)
+
+
+def on_side_stream(t):
+    """True when the launches for `t` go to a HIP stream other than the device's default one.  Such a forward writes its
+    batch statistic into a slot of its own (`scalar_slot`), so that forwards in flight do not meet in a block's
+    `current_*_max`; calibration (`update_ema`) reads the forwards of the default stream, which is where it runs."""
+    return _stream_of(t)[1]
 
 
 def scalar_slot(block, like):
@@ -100,12 +113,12 @@ def scalar_slot(block, like):
     block's own slot - a slice of the net's calibration arena once `net.update_ema()` has bound one (convert.py) - or, on a
     side stream, a slot private to (block, stream).  Returns (slot, side)."""
     import torch
-    if on_side_stream(like):
-        side = block.__dict__.setdefault("_fq_cur_side", {})
-        key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream)
-        slot = side.get(key)
+    key, side = _stream_of(like)
+    if side:
+        slots = block.__dict__.setdefault("_fq_cur_side", {})
+        slot = slots.get(key)
         if slot is None:
-            slot = side[key] = torch.zeros(1, dtype=torch.float32, device=like.device)
+            slot = slots[key] = torch.zeros(1, dtype=torch.float32, device=like.device)
         return slot, True
     slot = getattr(block, "_fq_cur", None)
     if slot is None or slot.device != like.device:

@@ -522,17 +522,21 @@ def _install_stat_arena(net, producers):
         if dev.type != "cuda":
             live.append(None)
             return
-        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        cur = torch.cuda.current_stream(dev)
+        key = (dev.index, cur.cuda_stream)
         arena = state.get(key)
         if arena is None:
             arena = state[key] = ops.StatArena(producers + 8, dev)
         arena.begin(x.shape[0])
         live.append(arena)
+        # what every block of this forward would otherwise ask torch for again (27 x two stream look-ups per forward)
+        ops.StatArena._tls.forward = (dev, key, cur != torch.cuda.default_stream(dev))
 
     def post(block, args, out):
         arena = live.pop() if live else None
         if arena is not None:
             arena.end()
+        ops.StatArena._tls.forward = None
     net._fq_arena_hooks = (net.register_forward_pre_hook(pre), net.register_forward_hook(post))
 
 

@@ -49,8 +49,11 @@ def test_bench_launches_its_own_ranks(gpu, streams):
     assert rec["scaling"] == "weak" and rec["unit"] == "images/sec" and rec["value"] > 0
     assert rec["repeats"] == 4 and rec["consistency"]["blocks"] == 4
     # counters summed over BOTH ranks in one all-reduce: every step either rank ran (warm-up + 4 blocks of 3) x 128 images;
-    # with two steps in flight also the set-up forward of each stream and the one-stream block of 3 steps
+    # with two steps in flight also the set-up forward of each stream and the one-stream block of 3 steps; with hipGraph replay
+    # the first replay of every captured graph (streams x 4 resident batches)
     extra = (2 + 3) if streams == 2 else 0
+    assert rec["config"]["hipgraph"] is True and rec["config"]["hipgraph_error"] is None
+    extra += streams * 4
     assert rec["eval_counters"]["images"] == 2 * 128 * (2 + 4 * 3 + extra)
     assert rec["config"]["streams"] == streams and ("single_stream" in rec) == (streams == 2)
     assert abs(rec["value"] - 256 * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-3

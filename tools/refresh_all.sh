@@ -13,7 +13,7 @@ i=0
 for cfg in "--model resnet50_v1 --quant-type channel" "--model resnet50_v1 --quant-type channel --offline" \
            "--model resnet50_v1 --quant-type channel --wino F43" "--model mobilenetv2_1.0 --quant-type channel --weight-bits 4 --offline"; do
   i=$((i+1))
-  python3 bench.py $cfg --steps 100 --no-cpu-baseline --no-headline $( [[ "$cfg" == *mobilenetv2* ]] && echo --graph 1 ) >> $O/${TAG}_other_configs.jsonl 2>> $O/other.err
+  python3 bench.py $cfg --steps 100 --no-cpu-baseline --no-headline >> $O/${TAG}_other_configs.jsonl 2>> $O/other.err
   ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg$i -o bench -- python3 $R/bench.py $cfg --steps 30 --warmup 6 --no-cpu-baseline --no-headline --no-kernel-events > /dev/null 2>> $O/other.err )
   cp $(find $O/trace_cfg$i -name '*kernel_stats.csv' | head -1) $O/${TAG}_cfg${i}_kernel_stats.csv
   rm -rf $O/trace_cfg$i
