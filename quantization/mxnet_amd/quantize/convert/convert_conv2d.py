@@ -18,6 +18,8 @@ kernel that quantises on load (`depthwise_fused`, `pointwise_fused` below) inste
 """
 from collections import namedtuple
 
+import os
+
 import torch
 
 from ...mx import nd
@@ -224,7 +226,11 @@ def _pointwise_weight_codes(block, args, weight_raw, weight_q):
     return codes
 
 
-_DW_C16_MIN_PIXELS = 56 * 56
+# Smallest output plane on which a depthwise layer takes (and hands on) codes.  Alone on the GPU fq_dwconv3x3_c16 loses to the
+# flat fp32 form below 56x56 (23.0 vs 17.8 us at 14x14: fixed costs, not bytes); with several batches in flight those fixed
+# costs are covered by the other batches' kernels and the halved bytes win on every plane (MobileNetV2 offline, three in
+# flight: 87.1 k images/s with 3136, 90.7 k with 784, 93.6 k with 196, 94.1 k with 49; one batch at a time: 72.1 -> 71.1 k).
+_DW_C16_MIN_PIXELS = int(os.environ.get("FQ_DW_C16_MIN_PIXELS", "1"))
 
 
 def _consumer_takes_codes(nxt):
@@ -303,9 +309,9 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                 extra = dict(residual=res["t"])
                 res["used"] = True
             if not extra and c16_in is None:       # (a 1x1 convolution reads OR writes codes: both at once is not built)
-                # through a depthwise consumer the hand-over pays on the large planes only (measured, MobileNetV2 batch 128:
-                # fq_dwconv3x3_c16 102 us against 158 at 112x112 stride 2 and 49 against 61 at 56x56 stride 2, but 23 against
-                # 18 at 14x14 where the flat fp32 form is at its best) - profiles/r3_handover.txt
+                # through a depthwise consumer: on every plane by default, `_DW_C16_MIN_PIXELS` above says why and what a batch
+                # alone on the GPU would prefer (fq_dwconv3x3_c16 102 us against 158 at 112x112 stride 2 and 49 against 61 at
+                # 56x56 stride 2, but 23 against 18 at 14x14 where the flat fp32 form is at its best) - profiles/r3_handover.txt
                 xs = c16_in.shape if c16_in is not None else tuple(x._t.shape)
                 s_ = block._kwargs["stride"][0]
                 fz["c16_pays"] = len(xs) == 4 and ((xs[2] - 1) // s_ + 1) * ((xs[3] - 1) // s_ + 1) >= _DW_C16_MIN_PIXELS

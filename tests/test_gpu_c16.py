@@ -220,7 +220,7 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
         fuse.HANDOVER = True
         torch.backends.cudnn.deterministic = was_deterministic
     # resnet50: 16 units x (1x1 -> 3x3 -> 1x1); mobilenetv2: 16 units with an expansion x (1x1 -> depthwise -> 1x1)
-    # (through a depthwise consumer only on planes of 56x56 pixels and more: the three large units at 224x224)
-    assert n_out == n_in and n_out >= {"resnet50_v1": 32, "mobilenetv2_1.0": 6}.get(model, 1), (n_out, n_in)
+    # (through the depthwise layer of every unit: 2 hand-overs per unit)
+    assert n_out == n_in and n_out >= {"resnet50_v1": 32, "mobilenetv2_1.0": 32}.get(model, 1), (n_out, n_in)
     assert np.array_equal(with_codes, without), "logits with int8 hand-overs differ from the fp32 hand-over"
     assert cur_with == cur_without

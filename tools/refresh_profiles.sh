@@ -7,6 +7,10 @@ TAG=${1:-r2}
 R=$(pwd); OUT=$R/gpurun_out/refresh; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-headline > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/trace.err
+# the same steps one batch at a time and launched eagerly: with batches in flight a kernel's wall duration includes the time it
+# shares the CUs with another batch's kernels (the durations of a step then add up to more than the step); this table is the
+# one the event-timed per-kernel figures of the line (taken on steps that run alone) are to be compared with
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o bench -- python3 $R/bench.py --steps 100 --warmup 5 --streams 1 --graph 0 --no-cpu-baseline --no-headline > $OUT/${TAG}_bench_line_one_stream_under_rocprof.json 2> $OUT/trace1.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-headline --no-kernel-events > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-headline --no-kernel-events > /dev/null 2> $OUT/pmc_write.err
 cd $R
@@ -14,4 +18,5 @@ F=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $OU
 python3 tools/pmc_summary.py $F $W $OUT/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around bench.py --steps 5 --warmup 2, $TAG" > $OUT/${TAG}_pmc_bench.txt
 python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+cp $(find $OUT/trace1 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats_one_stream.csv
 tail -c 600 $OUT/${TAG}_bench_line.json; cat $OUT/${TAG}_pmc_bench.txt; head -24 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-170
