@@ -60,9 +60,9 @@ class ListLoader(object):
         return iter(self._mine)
 
 
-def options(cli, flow):
+def options(cli, flow, extra=()):
     argv = ["--model", MODEL, "--use-gpu", "0", "--batch-size", str(LOCAL_BS), "--quantize-input-offline",
-            "--calib-epoch", "1", "--pretrained", "false"]
+            "--calib-epoch", "1", "--pretrained", "false"] + list(extra)
     if flow == "kl":
         argv += ["--calib-mode", "kl"]
     if flow == "naive_strict":
@@ -70,10 +70,10 @@ def options(cli, flow):
     return cli.parse_args(argv)
 
 
-def run_flow(cli, flow, ctx, rank, world, calib, evalb, batch_size):
+def run_flow(cli, flow, ctx, rank, world, calib, evalb, batch_size, extra=()):
     """build -> convert -> calibrate -> freeze -> offline evaluation, exactly `Simulation.execute` with the two loaders
     replaced.  Returns (thresholds of every quantised block, acc, avg_acc)."""
-    opt = options(cli, flow)
+    opt = options(cli, flow, extra)
     opt.batch_size = batch_size
     sim = cli.Simulation(opt, ctx, rank, world)
     np.random.seed(opt.fixed_random_seed)

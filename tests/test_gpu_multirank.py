@@ -140,3 +140,24 @@ def test_cli_kl_calibration_two_ranks_equals_one_device(gpu, tmp_path):
     assert np.all(thr > 0)
     np.testing.assert_array_equal(r["thr"], thr)
     assert float(r["acc"]) == acc and float(r["avg"]) == avg
+
+
+@pytest.mark.parametrize("extra", [(), ("--no-fuse",)], ids=["fused", "no-fuse"])
+def test_cli_evaluation_with_batches_in_flight_equals_one_at_a_time(gpu, extra):
+    """`--eval-streams 3` (the default: three evaluation batches in flight, one HIP stream each, freezing forward first and
+    alone) against `--eval-streams 1`: same thresholds, same accuracies, and - since the nets are random - the same LOGITS
+    on a batch evaluated afterwards, for the fused net and for the plain converted one."""
+    import gpu_cli_worker as W
+    from quantization.mxnet_amd import mx
+    cli = W.cli_module()
+    evalb = W.local_batches("eval") + W.local_batches("calib")[:5]            # eight batches: every lane several times
+    res = []
+    for streams in (1, 3):
+        thr, acc, avg, net = W.run_flow(cli, "naive_step", gpu, 0, 1, W.local_batches("calib"), evalb, W.LOCAL_BS,
+                                        extra=("--eval-streams", str(streams)) + tuple(extra))
+        x = mx.nd.array(evalb[0][0], ctx=gpu)
+        res.append((thr, acc, avg, net(x).asnumpy()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+
