@@ -648,8 +648,12 @@ def main():
                          "unit": "GB/s", "frac": dk["frac"], "frac_raw_events": dk["frac_raw_events"],
                          "traffic": traffic, "traffic_source": traffic_src,
                          "dominant_by": "largest HIP-event time per step among this library's kernels",
-                         "event_sampling": "HIP events bracket every library launch in %d of the %d timed steps"
-                                           % (profiled_steps, args.steps * len(blocks)),
+                         "event_sampling": "HIP events bracket every library launch in %d of the %d timed steps%s"
+                                           % (profiled_steps, args.steps * len(blocks),
+                                              "; these steps run ALONE on one stream at the end of their block, so the "
+                                              "per-kernel figures are those of kernels that do not share the GPU with another "
+                                              "batch (compare with a rocprofv3 table of --streams 1 --graph 0)"
+                                              if n_streams > 1 or graphs is not None else ""),
                          "event_pair_overhead_us_removed": round(ev_overhead_ms * 1e3, 3),
                          "null_kernel_us_measured": round(null_kernel_ms * 1e3, 3),
                          "whole_step": {"algorithmic_bytes_per_step": round(step_bytes, 1), "achieved": round(whole, 1),

@@ -17,6 +17,7 @@ cd $R
 F=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
 python3 tools/pmc_summary.py $F $W $OUT/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around bench.py --steps 5 --warmup 2, $TAG" > $OUT/${TAG}_pmc_bench.txt
 python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
-cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats.csv
-cp $(find $OUT/trace1 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats_one_stream.csv
+# (the table the line's per-kernel event figures agree with keeps the plain name)
+cp $(find $OUT/trace1 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats_default_in_flight.csv
 tail -c 600 $OUT/${TAG}_bench_line.json; cat $OUT/${TAG}_pmc_bench.txt; head -24 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-170
