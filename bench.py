@@ -363,6 +363,10 @@ def main():
     net = prepare_net()
     nets = [net] * n_streams
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+    if n_streams > 1:
+        # the explicit declaration the blocks ask for before a forward on a non-default stream may keep its batch statistic
+        # to itself (quantize/convert/_blocks.py: _stream_of); held for the rest of the process: evaluation only
+        ops.batches_in_flight().__enter__()
     nblocks = len(net.collect_quantized_blocks())
     from quantization.mxnet_amd import dist as fqdist
     if args.phase == "calib-naive" and distributed:
@@ -585,17 +589,22 @@ def main():
         for key, rec in prof.items():
             if not rec["launches"]:
                 continue
-            ms = max(rec["ms"] - ev_overhead_ms * rec["launches"], 1e-9)
-            gbs = rec["bytes"] / (ms * 1e-3) / 1e9
+            # `frac` / `achieved` / `avg_launch_us` are the RAW HIP-event figures: they are the ones a rocprofv3 kernel table of
+            # the same process confirms (tools/refresh_profiles.sh prints both and fails beyond 3 %).  The figure with the
+            # measured cost of an event pair removed is kept beside them as `*_overhead_corrected` (round 3 reported that one
+            # as `frac`; rocprofv3 did not support it: 39.2 us corrected vs 41.65 us in the table).
+            ms_raw = max(rec["ms"], 1e-9)
+            ms_cor = max(rec["ms"] - ev_overhead_ms * rec["launches"], 1e-9)
+            gbs = rec["bytes"] / (ms_raw * 1e-3) / 1e9
+            gbs_cor = rec["bytes"] / (ms_cor * 1e-3) / 1e9
             step_bytes += rec["bytes"] / max(profiled_steps, 1)
-            gbs_raw = rec["bytes"] / (max(rec["ms"], 1e-9) * 1e-3) / 1e9
             kernels[key] = {"kernel": KERNEL_NAMES.get(key, key), "achieved": round(gbs, 1),
                             "frac": round(gbs / HBM_PEAK_GBS, 4),
-                            "frac_raw_events": round(gbs_raw / HBM_PEAK_GBS, 4), "launches": rec["launches"],
-                            "avg_launch_us": round(ms * 1e3 / rec["launches"], 3),
-                            "avg_launch_us_raw_events": round(rec["ms"] * 1e3 / rec["launches"], 3),
+                            "frac_overhead_corrected": round(gbs_cor / HBM_PEAK_GBS, 4), "launches": rec["launches"],
+                            "avg_launch_us": round(ms_raw * 1e3 / rec["launches"], 3),
+                            "avg_launch_us_overhead_corrected": round(ms_cor * 1e3 / rec["launches"], 3),
                             "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["launches"], 1),
-                            "ms_per_step": round(ms / max(profiled_steps, 1), 4)}
+                            "ms_per_step": round(ms_raw / max(profiled_steps, 1), 4)}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
         traffic, traffic_src = None, None
         default_workload = (args.model == "mobilenet1.0" and args.quant_type == "layer" and not args.offline
@@ -609,7 +618,7 @@ def main():
                               "this command, committed as profiles/pmc_traffic.json (%s)" % rec.get("source", "")
             except Exception:
                 traffic = None
-        dk = kernels.get(dominant, {"achieved": 0.0, "frac": 0.0, "frac_raw_events": 0.0, "kernel": None})
+        dk = kernels.get(dominant, {"achieved": 0.0, "frac": 0.0, "frac_overhead_corrected": 0.0, "kernel": None})
         whole = step_bytes / (ms_per_step * 1e-3) / 1e9 if step_bytes else 0.0
         flavour = "%s W%dA%d, %s input quant" % ({"layer": "per-layer", "group": "per-group", "channel": "per-channel"}
                                                   [args.quant_type], args.weight_bits, args.input_bits,
@@ -645,8 +654,13 @@ def main():
                                        "of their block, alone on one stream (inside the timed region)" if n_streams > 1
                                        else "one stream"},
             "roofline": {"bound": "hbm", "kernel": dk["kernel"], "achieved": dk["achieved"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dk["frac"], "frac_raw_events": dk["frac_raw_events"],
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "unit": "GB/s", "frac": dk["frac"],
+                         "frac_what": "algorithmic bytes / RAW HIP-event time of the family's launches (what rocprofv3's "
+                                      "AverageNs of the same process confirms); frac_overhead_corrected removes the measured "
+                                      "cost of an event pair and is NOT the judged figure",
+                         "frac_overhead_corrected": dk["frac_overhead_corrected"],
+                         "traffic": traffic, "traffic_is_stored_constant": traffic is not None,
+                         "traffic_source": traffic_src,
                          "dominant_by": "largest HIP-event time per step among this library's kernels",
                          "event_sampling": "HIP events bracket every library launch in %d of the %d timed steps%s"
                                            % (profiled_steps, args.steps * len(blocks),
@@ -654,7 +668,7 @@ def main():
                                               "per-kernel figures are those of kernels that do not share the GPU with another "
                                               "batch (compare with a rocprofv3 table of --streams 1 --graph 0)"
                                               if n_streams > 1 or graphs is not None else ""),
-                         "event_pair_overhead_us_removed": round(ev_overhead_ms * 1e3, 3),
+                         "event_pair_overhead_us_measured": round(ev_overhead_ms * 1e3, 3),
                          "null_kernel_us_measured": round(null_kernel_ms * 1e3, 3),
                          "whole_step": {"algorithmic_bytes_per_step": round(step_bytes, 1), "achieved": round(whole, 1),
                                         "frac": round(whole / HBM_PEAK_GBS, 4),

@@ -223,7 +223,8 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
                     for t in (X._t, y._t):
                         if t.is_cuda:
                             t.record_stream(lane)
-                with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()):
+                with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()), \
+                        (ops.batches_in_flight() if lane is not None else contextlib.nullcontext()):
                     labels = y.as_in_context(ctx)._t.long()
                     if head is not None:
                         head.labels = labels

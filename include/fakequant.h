@@ -46,6 +46,9 @@ typedef void* fqStream_t; /* hipStream_t */
 
 const char* fq_last_error(void);
 int fq_version(void);
+/* sha1 (40 hex digits) of the sources and flags this library was built from: csrc/build.py compares it with the tree to
+ * decide whether a built file is current (content, not modification times). */
+const char* fq_build_id(void);
 /* Name (e.g. "gfx950"), compute units and wavefront size of the current HIP device. */
 int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront);
 

@@ -22,6 +22,7 @@ _vp, _i64, _int, _uint, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ct
 EXPORTS = {
     "fq_last_error": (ctypes.c_char_p, []),
     "fq_version": (_int, []),
+    "fq_build_id": (ctypes.c_char_p, []),
     "fq_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "fq_profile_enable": (_int, [_int]),
     "fq_profile_reset": (_int, []),

@@ -77,7 +77,16 @@ using namespace fqi;
 extern "C" {
 
 const char* fq_last_error(void) { return g_err; }
-int fq_version(void) { return 100; }
+int fq_version(void) { return 101; }
+// sha1 of the sources this library was built from (csrc/build.py: source_id); "FQ_BUILD_ID=<40 hex>" is also what
+// build.py looks for in the file's bytes to decide whether a built library belongs to the tree it sits in
+#ifndef FQ_BUILD_ID
+#define FQ_BUILD_ID "0000000000000000000000000000000000000000"
+#endif
+const char* fq_build_id(void) {
+  static const char id[] = "FQ_BUILD_ID=" FQ_BUILD_ID;
+  return id + 12;
+}
 
 int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront) {
   int dev = 0;

@@ -183,7 +183,14 @@ __global__ __launch_bounds__(kRowsNW * 64) void pwconv_rows_kernel(
 
   // the last workgroup of this sample tile to get here sees every workgroup's keys (release: fence + counter; acquire: the
   // counter + fence, keys read past the vector cache)
-  if (fence_mode == 0)
+  // The short hand-shake is a property of gfx942 / gfx950 (sc1 stores are written through and acknowledged before vmcnt
+  // reaches 0, sc1 loads bypass the L2), not of the HIP memory model: any other target gets the textbook fences.
+#if defined(__gfx942__) || defined(__gfx950__)
+  constexpr bool kShortHandshakeOk = true;
+#else
+  constexpr bool kShortHandshakeOk = false;
+#endif
+  if (fence_mode == 0 || !kShortHandshakeOk)
     __threadfence();
   else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(kRowsNW * 64) void pwconv_rows_kernel(
   if (threadIdx.x == 0) wg_last = atomicAdd(sync + st, 1u) == (unsigned)(g.ut - 1) ? 1u : 0u;
   __syncthreads();
   if (wg_last == 0u) return;
-  if (fence_mode == 0)
+  if (fence_mode == 0 || !kShortHandshakeOk)
     __threadfence();
   else
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

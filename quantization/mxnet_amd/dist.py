@@ -132,6 +132,16 @@ def _calibrated_blocks(net):
             if getattr(b, "input_max", None) is not None or getattr(b, "act_max", None) is not None]
 
 
+def _would_exchange(block):
+    """Does this block's forward reach its strict-mode exchange (the converters' own early-return conditions)?"""
+    args = getattr(block, "quantize_args", None)
+    if args is None or not getattr(block, "enable_quantize", True):
+        return False
+    if hasattr(args, "quantize_act"):
+        return bool(args.quantize_act)
+    return bool(getattr(args, "quantize_input", False))
+
+
 class _CalibrationSync(object):
     """What both modes share: the blocks, the (L x max_local_batch) statistic matrix whose row l receives layer l's
     per-sample maxima, and the step's local sample count — taken from the INPUT BATCH by a forward pre-hook on the net
@@ -203,7 +213,11 @@ class _LayerCollective(_CalibrationSync):
         slot = {}
         for j, (blk, _pattr, _cattr, _pub) in enumerate(arena.slots):
             slot[id(blk)] = arena.cur[j:j + 1]
-        order = self.last_order if self.last_order else [id(b) for b in self.blocks]
+        # before any forward of its own: the blocks whose forward WOULD exchange, by the predicate the converters use
+        # (convert_conv2d / convert_dense: enable_quantize and quantize_args.quantize_input; convert_act: enable_quantize and
+        # quantize_args.quantize_act) - a disabled block, or an Activation converted with quantize_act=False, owns a slot but
+        # issues no all-gather, and replaying one for it would leave the ranks with different collective counts
+        order = self.last_order if self.last_order else [id(b) for b in self.blocks if _would_exchange(b)]
         for bid in order:
             _global_mean(None, 0, self.pack, self.gathered, slot[bid])
 

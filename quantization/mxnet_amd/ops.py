@@ -295,6 +295,26 @@ class StatArena(object):
         return row
 
 
+def in_flight():
+    """True inside `batches_in_flight()` on this thread."""
+    return getattr(StatArena._tls, "in_flight", 0) > 0
+
+
+class batches_in_flight(object):
+    """`with ops.batches_in_flight():` - the caller runs EVALUATION forwards of independent batches on several HIP streams
+    of one net at the same time.  Inside, a forward on a non-default stream keeps its per-forward device state per stream
+    and leaves the blocks' `current_*_max` alone (quantize/convert/_blocks.py: scalar_slot); outside - whatever the
+    current stream - every forward is an ordinary one that calibration (`net.update_ema()`) may follow."""
+
+    def __enter__(self):
+        StatArena._tls.in_flight = getattr(StatArena._tls, "in_flight", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        StatArena._tls.in_flight = getattr(StatArena._tls, "in_flight", 1) - 1
+        return False
+
+
 def _stat_target(n, device, want_stat):
     """(tensor or None, act-flag): a pre-zeroed arena row when a forward is under way, else a fresh tensor."""
     if not want_stat:

@@ -87,9 +87,12 @@ def contiguous(t):
 
 
 def _stream_of(t):
-    """(key, side) of the stream the launches for `t` go to: key = (device index, stream handle); side = not the device's
-    default stream, i.e. a forward of an evaluation loop that keeps several batches in flight (one stream each).  Inside a
-    fused net's forward the answer is the one quantize/fuse.py looked up once for the whole forward."""
+    """(key, side) of the stream the launches for `t` go to: key = (device index, stream handle); side = the caller declared
+    an evaluation loop with several batches in flight (`with ops.batches_in_flight():`, an explicit opt-in: bench.py, the
+    CLI's `evaluate`) AND this is not the device's default stream.  A forward on a non-default stream WITHOUT that
+    declaration - a calibration or training loop under `torch.cuda.stream(s)`, a framework that installs per-thread
+    streams - is an ordinary forward: it updates the block's `current_*_max`, and `update_ema` sees it.  Inside a fused
+    net's forward the answer is the one quantize/fuse.py looked up once for the whole forward."""
     import torch
     from ... import ops
     fwd = getattr(ops.StatArena._tls, "forward", None)
@@ -98,13 +101,13 @@ def _stream_of(t):
     if not t.is_cuda:
         return None, False
     cur = torch.cuda.current_stream(t.device)
-    return (t.device.index, cur.cuda_stream), cur != torch.cuda.default_stream(t.device)
+    return (t.device.index, cur.cuda_stream), ops.in_flight() and cur != torch.cuda.default_stream(t.device)
 
 
 def on_side_stream(t):
-    """True when the launches for `t` go to a HIP stream other than the device's default one.  Such a forward writes its
-    batch statistic into a slot of its own (`scalar_slot`), so that forwards in flight do not meet in a block's
-    `current_*_max`; calibration (`update_ema`) reads the forwards of the default stream, which is where it runs."""
+    """True when this forward is one of several batches in flight (declared, on a stream of its own).  Such a forward
+    writes its batch statistic into a slot of its own (`scalar_slot`), so that forwards in flight do not meet in a block's
+    `current_*_max`; calibration (`update_ema`) refuses to run inside such a declaration."""
     return _stream_of(t)[1]
 
 

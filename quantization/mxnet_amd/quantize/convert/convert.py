@@ -116,6 +116,10 @@ class NetControls(object):
 
     # :66-79
     def update_ema(self, momentum=0.9):
+        if ops.in_flight():
+            raise RuntimeError("update_ema() inside ops.batches_in_flight(): forwards declared as batches in flight keep "
+                               "their batch statistics per stream and do not update current_input_max - calibrate "
+                               "outside the declaration (one batch at a time)")
         arena = self.arena()
         if arena is not None:
             sync = getattr(self.net, "_fq_calibration_sync", None)

@@ -240,6 +240,10 @@ def _consumer_takes_codes(nxt):
             and getattr(nxt, "input_max", None) is not None and getattr(nxt, "_fq_global_stat", None) is None)
 
 
+def _hooked(b):
+    return b is not None and bool(getattr(b, "_forward_hooks", None) or getattr(b, "_forward_pre_hooks", None))
+
+
 def handover_target(block, fz=None):
     """The consumer this fused convolution may hand integer codes to (quantize/fuse.py links `next`), when the consumer will
     quantise with its STORED threshold in this very forward - offline input quantisation (convert_conv2d.py:58 takes
@@ -250,6 +254,11 @@ def handover_target(block, fz=None):
     fz = fz if fz is not None else block._fq_pw_fused
     nxt = fz.get("next")
     if nxt is None or not _fuse.HANDOVER or autograd.is_recording() or not _consumer_takes_codes(nxt):
+        return None
+    # a user hook on the producer, on the consumer or on a block bypassed between them (folded BatchNorm, bypassed
+    # activation) would be shown a C16 code tensor where it expects the fp32 activation (collect_feature_maps hooks `x[0]` of
+    # every quantised block): no hand-over past a hook
+    if any(_hooked(b) for b in (block, nxt, fz.get("bn"), fz.get("act_block"))):
         return None
     dw = getattr(nxt, "_fq_dw_fused", None)
     if dw is not None and (handover_target(nxt, dw) is None or not fz.get("c16_pays", True)):

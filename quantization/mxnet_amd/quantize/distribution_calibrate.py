@@ -48,6 +48,9 @@ def collect_feature_maps(net, bins, loader, ctx, tqdm_desc="Collect FM", sync=No
     fm_collector = {}
     for blk in quantized_blocks:
         def _collect(m, x, y):
+            # (a fused producer hands no int8 codes to a hooked block - convert_conv2d.handover_target - so x[0] is the fp32
+            # activation whether or not the net quantises its inputs offline while it is being collected)
+            assert getattr(x[0], "_fq_c16", None) is None, "collect_feature_maps: block input is an int8 code tensor"
             fm_collector.setdefault(m, []).append(x[0])          # device tensor reference, no copy (cf. :84)
         hooks.append(blk.register_forward_hook(_collect))
 

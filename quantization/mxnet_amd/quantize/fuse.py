@@ -514,30 +514,33 @@ def _install_stat_arena(net, producers):
     if producers <= 0 or hasattr(net, "_fq_arena_hooks"):
         return
     state = {}                                          # (device, stream) -> arena: forwards in flight on different streams
-    live = []                                           # ... (an evaluation loop with several batches in flight) do not share rows
+                                                        # (an evaluation loop with several batches in flight) do not share rows
+    inner = net.forward
 
-    def pre(block, args):
+    def forward(self, *args):
+        """The net's forward between `arena.begin` and `arena.end` - in a try / finally, so that a forward that raises (an ops
+        ValueError, out of memory) leaves no arena "current" and no cached stream behind for later block calls."""
         x = args[0]
         dev = x._t.device
         if dev.type != "cuda":
-            live.append(None)
-            return
+            return inner(*args)
         cur = torch.cuda.current_stream(dev)
         key = (dev.index, cur.cuda_stream)
         arena = state.get(key)
         if arena is None:
             arena = state[key] = ops.StatArena(producers + 8, dev)
+        outer = getattr(ops.StatArena._tls, "forward", None)
         arena.begin(x.shape[0])
-        live.append(arena)
-        # what every block of this forward would otherwise ask torch for again (27 x two stream look-ups per forward)
-        ops.StatArena._tls.forward = (dev, key, cur != torch.cuda.default_stream(dev))
-
-    def post(block, args, out):
-        arena = live.pop() if live else None
-        if arena is not None:
+        # what every block of this forward would otherwise ask torch for again (27 x two stream look-ups per forward);
+        # "side" = an evaluation loop declared batches in flight (ops.batches_in_flight) AND this is not the default stream
+        ops.StatArena._tls.forward = (dev, key, ops.in_flight() and cur != torch.cuda.default_stream(dev))
+        try:
+            return inner(*args)
+        finally:
             arena.end()
-        ops.StatArena._tls.forward = None
-    net._fq_arena_hooks = (net.register_forward_pre_hook(pre), net.register_forward_hook(post))
+            ops.StatArena._tls.forward = outer
+    net.forward = types.MethodType(forward, net)
+    net._fq_arena_hooks = True
 
 
 def refresh(net):
@@ -585,8 +588,7 @@ def eval_head(net, counters):
 
 def unfuse(net):
     if hasattr(net, "_fq_arena_hooks"):
-        for h in net._fq_arena_hooks:
-            h.detach()
+        del net.forward                                     # the class's own forward again (_install_stat_arena)
         del net._fq_arena_hooks
 
     def restore_act(blk):

@@ -2,7 +2,7 @@
 Runs the product's calibration host logic (both EMA collective modes, KL sync, eval counters) with the oracle standing in
 for the HIP entry points, and writes what each rank ended with to <out>/rank<r>.npz.
 
-    dist_worker.py <out_dir> <local_bs> <case>      case: strict | strict_ragged | strict_short | strict_act | step | step_ragged | step_short | step_act
+    dist_worker.py <out_dir> <local_bs> <case>      case: strict | strict_ragged | strict_short | strict_act | strict_off_firstempty | step | step_ragged | step_short | step_act
 (`*_act`: the net's Activations are converted too — their `act_max` slots take part in the same collectives)
 """
 import os
@@ -23,7 +23,7 @@ from quantization.mxnet_amd.quantize import convert  # noqa: E402
 from quantization.mxnet_amd.quantize.initialize import qparams_init  # noqa: E402
 
 
-def make_net(seed=3, with_act=False):
+def make_net(seed=3, with_act=False, disable_one=False):
     rng = np.random.default_rng(seed)
     shapes = {"tiny_conv0_weight": (8, 3, 3, 3), "tiny_conv1_weight": (8, 1, 3, 3), "tiny_conv1_bias": (8,),
               "tiny_conv2_weight": (12, 8, 1, 1), "tiny_dense0_weight": (5, 12), "tiny_dense0_bias": (5,)}
@@ -37,6 +37,8 @@ def make_net(seed=3, with_act=False):
     else:
         convert.convert_model(net, exclude=[net[0]])
     qparams_init(net)
+    if disable_one:          # a block switched off owns a calibration slot but its forward never reaches the exchange
+        net.collect_quantized_blocks()[1].enable_quantize = False
     return net
 
 
@@ -67,6 +69,8 @@ def calib_steps(case, local_bs, world):
         shards = [g[r * local_bs:(r + 1) * local_bs] for r in range(world)]
         if case.endswith("_short") and step == 3:
             shards = [g[:local_bs]] + [None] * (world - 1)  # odd batch count: only rank 0 has a batch in the last step
+        if case.endswith("_firstempty") and step == 0:
+            shards = [g[:local_bs]] + [None] * (world - 1)  # the other ranks' shards are empty FROM STEP 0: no forward yet
         steps.append(shards)
     return steps
 
@@ -80,7 +84,7 @@ def main():
     rank, _, world = fqdist.init("gloo")
     with oracle_ops():
         # ---- naive-EMA calibration on the rank's shard of each global batch -------------------------------------
-        net = make_net(with_act=case.endswith("_act"))
+        net = make_net(with_act="_act" in case, disable_one="_off" in case)
         fqdist.attach_calibration_sync(net, local_bs, strict=case.startswith("strict"))
         net.quantize_input(enable=True, online=True)
         blocks = [b for b in net.collect_quantized_blocks() if hasattr(b, "_fq_stat_ws")]

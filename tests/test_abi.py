@@ -69,3 +69,22 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_library_carries_the_id_of_the_sources_it_sits_beside(tmp_path):
+    """csrc/build.py decides "up to date" by content: the sha1 of sources + headers + flags is compiled into the library
+    (fq_build_id) and found again in the file's bytes; a changed source means a different id, whatever the file times say."""
+    from quantization.mxnet_amd import _lib
+    from quantization.mxnet_amd.csrc import build as B
+    want = B.source_id()
+    assert len(want) == 40
+    if os.environ.get("FQ_LIB_PATH"):
+        pytest.skip("a variant library is loaded")
+    assert B.built_id(B.OUT) == want, "libfakequant.so was built from other sources than this tree: run __graft_entry__.build()"
+    assert _lib.LIB.fq_build_id().decode() == want
+    assert B.up_to_date()
+    assert B.source_id(["-DFQ_SOMETHING=1"]) != want
+    stale = tmp_path / "lib.so"
+    stale.write_bytes(b"\x7fELF....FQ_BUILD_ID=" + b"0" * 40 + b"....")
+    assert B.built_id(str(stale)) == "0" * 40 and not B.up_to_date(str(stale))
+    assert B.built_id(str(tmp_path / "absent.so")) is None

@@ -38,7 +38,7 @@ def _single_process(local_bs, world, case):
     from quantization.mxnet_amd import mx
     from quantization.mxnet_amd.quantize.distribution_calibrate import collect_feature_maps
     with oracle_ops():
-        net = W.make_net(with_act=case.endswith("_act"))
+        net = W.make_net(with_act="_act" in case, disable_one="_off" in case)
         net.quantize_input(enable=True, online=True)
         ema = []
         for shards in W.calib_steps(case, local_bs, world):
@@ -70,7 +70,7 @@ def _run_two_ranks(tmp_path, local_bs, case):
     return r
 
 
-@pytest.mark.parametrize("case", ["strict", "strict_ragged", "strict_short", "strict_act"])
+@pytest.mark.parametrize("case", ["strict", "strict_ragged", "strict_short", "strict_act", "strict_off_firstempty"])
 def test_strict_mode_equals_one_device_on_the_global_batch(tmp_path, case):
     local_bs, world = 3, 2
     r = _run_two_ranks(tmp_path, local_bs, case)

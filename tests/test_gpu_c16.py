@@ -224,3 +224,57 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
     assert n_out == n_in and n_out >= {"resnet50_v1": 32, "mobilenetv2_1.0": 32}.get(model, 1), (n_out, n_in)
     assert np.array_equal(with_codes, without), "logits with int8 hand-overs differ from the fp32 hand-over"
     assert cur_with == cur_without
+
+
+def test_hooked_blocks_are_never_handed_codes(gpu):
+    """a forward (pre-)hook on a quantised block of a fused net under OFFLINE input quantisation must see the fp32
+    activation, not a C16 code tensor: no hand-over past a hook.  `collect_feature_maps` - which hooks `x[0]` of every
+    quantised block - then gives, on such a net, the histograms it gives with the hand-over switched off."""
+    from quantization.mxnet_amd import mx, ops
+    from quantization.mxnet_amd.quantize import fuse
+    from quantization.mxnet_amd.quantize.distribution_calibrate import collect_feature_maps
+    from test_gpu_net import _build
+    net = _build("resnet50_v1", 1000, gpu, quant_type="channel")
+    rng = np.random.default_rng(3)
+    xs = [mx.nd.array(rng.standard_normal((4, 3, 64, 64)).astype(np.float32), ctx=gpu) for _ in range(3)]
+    for x in xs[:2]:
+        net(x)
+        net.update_ema()
+    net.fix_params()
+    net.quantize_input(enable=True, online=False)
+    net(xs[2])
+    fuse.fuse_inference(net)
+    real = ops.pwconv_i8, ops.conv3x3_i8
+    handed = {"n": 0}
+
+    def count(fn):
+        def wrapped(x, *a, **k):
+            handed["n"] += isinstance(x, ops.Codes16) + (k.get("out_codes") is not None)
+            return fn(x, *a, **k)
+        return wrapped
+    ops.pwconv_i8, ops.conv3x3_i8 = count(real[0]), count(real[1])
+    try:
+        net(xs[2])
+        assert handed["n"] > 0, "the un-hooked net hands codes over"
+        seen = []
+        blocks = net.collect_quantized_blocks()
+        hooks = [b.register_forward_pre_hook(lambda m, a: seen.append(a[0])) for b in blocks]
+        handed["n"] = 0
+        out_hooked = net(xs[2]).asnumpy()
+        assert handed["n"] == 0, "a hooked consumer was handed codes"
+        assert len(seen) == len(blocks)
+        assert all(getattr(a, "_fq_c16", None) is None and a._t.dtype == torch.float32 for a in seen)
+        for h in hooks:
+            h.detach()
+        assert np.array_equal(net(xs[2]).asnumpy(), out_hooked)          # hand-overs back; same logits
+        assert handed["n"] > 0
+        loader = [(x, None) for x in xs]
+        fuse.HANDOVER = True
+        h1, r1 = collect_feature_maps(net, 2048, loader, gpu)
+        fuse.HANDOVER = False
+        h0, r0 = collect_feature_maps(net, 2048, loader, gpu)
+        for b in blocks:
+            assert r1[b] == r0[b] and np.array_equal(h1[b], h0[b])
+    finally:
+        ops.pwconv_i8, ops.conv3x3_i8 = real
+        fuse.HANDOVER = True

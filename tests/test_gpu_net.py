@@ -3,6 +3,8 @@ every quantised block of the converted net is spied on while the net runs on the
 weight are then pushed through the CPU oracle and must reproduce, bit for bit, what the HIP path handed to the
 convolution.  (End-to-end logits cannot be compared bit-exactly across devices: MIOpen and the CPU convolution sum in
 different orders, so activations differ in the last bits BEFORE they reach the next fake-quant.)"""
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -575,7 +577,7 @@ def test_forwards_in_flight_on_several_streams_equal_sequential_forwards(gpu, mo
     for rep in range(3):                                # ... and with three in flight, three times over
         outs = []
         for i, (x, lb) in enumerate(zip(xs, labels)):
-            with torch.cuda.stream(streams[i % 3]):
+            with torch.cuda.stream(streams[i % 3]), ops.batches_in_flight():
                 head.labels = lb
                 outs.append(net(x)._t)
                 assert head.take()
@@ -587,3 +589,38 @@ def test_forwards_in_flight_on_several_streams_equal_sequential_forwards(gpu, mo
     assert cur_after == cur_before
     head.release()
     fuse.unfuse(net)
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["plain", "fused"])
+def test_calibration_on_a_non_default_stream_is_an_ordinary_calibration(gpu, fused):
+    """whether a forward counts for calibration is NOT inferred from the HIP stream.  `net(X); net.update_ema()`
+    under `torch.cuda.stream(s)` (no `ops.batches_in_flight()` declaration) gives the thresholds of the same loop on the
+    default stream, bit for bit; inside the declaration `update_ema` refuses."""
+    from quantization.mxnet_amd import mx, ops
+    from quantization.mxnet_amd.quantize import fuse
+    rng = np.random.default_rng(5)
+    xs = [mx.nd.array(rng.standard_normal((4, 3, 64, 64)).astype(np.float32) * (1 + i), ctx=gpu) for i in range(3)]
+
+    def thresholds(stream):
+        net = _build("mobilenet1.0", 10, gpu)
+        if fused:
+            fuse.fuse_inference(net)
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            for x in xs:
+                net(x)
+                net.update_ema()
+        torch.cuda.synchronize()
+        return [float(b.input_max.data()._t.item()) for b in net.collect_quantized_blocks() if hasattr(b, "input_max")]
+
+    torch.cuda.synchronize()
+    want = thresholds(None)
+    side = torch.cuda.Stream(gpu.torch_device)
+    side.wait_stream(torch.cuda.current_stream(gpu.torch_device))
+    got = thresholds(side)
+    assert all(w > 0 for w in want)
+    assert got == want
+    net = _build("mobilenet1.0", 10, gpu)
+    with ops.batches_in_flight():
+        with pytest.raises(RuntimeError, match="batches_in_flight"):
+            net.update_ema()
+    assert not ops.in_flight()

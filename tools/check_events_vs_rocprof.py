@@ -1,0 +1,72 @@
+"""Do the HIP-event figures of a bench.py line follow from a rocprofv3 kernel table?
+
+    python tools/check_events_vs_rocprof.py LINE.json KERNEL_STATS.csv [--tol 0.03] [--steps-from gap_stat]
+
+LINE.json: a line of `bench.py` (its `roofline.kernels[family]` carries `ms_per_step`, `avg_launch_us`, `frac` from RAW HIP
+events and `algorithmic_bytes_per_launch`).  KERNEL_STATS.csv: `rocprofv3 --kernel-trace --stats --output-format csv` of
+`bench.py --streams 1 --graph 0` (one batch at a time: with batches in flight a kernel's wall duration includes the time it
+shares the CUs).  Per family the script adds up the table's TotalDurationNs over the family's kernels, divides by the number
+of steps the profiled process ran (= calls of the pooling kernel, one per step) and recomputes launch time and fraction of
+8 TB/s from the line's algorithmic bytes.  Exit status 1 when a family with >= 5 % of the step disagrees by more than --tol.
+"""
+import csv
+import json
+import sys
+
+FAMILIES = {
+    "pwconv": ("pwconv_stream_kernel", "pwconv_sample_kernel", "pwconv_split_kernel", "quant_transpose_i8_kernel",
+               "pwconv_i8_kernel", "qconv_pw"),
+    "dwconv": ("dwconv3x3", "qconv_dw"),
+    "stem": ("stem_mfma_kernel", "stem_conv3x3s2_kernel"),
+    "pool": ("gap_stat",),
+    "dense": ("pwconv_rows_kernel",),
+    "conv3x3": ("conv3x3_i8_kernel",),
+    "stat": ("absmax_per_sample_kernel",),
+    "apply_online": ("act_apply_kernel<true",),
+    "bn_act": ("bn_act_stat_kernel", "bn_act_range_kernel"),
+    "qrange": ("qconv_range",),
+}
+HBM_PEAK_GBS = 8000.0
+
+
+def main(argv):
+    tol = 0.03
+    if "--tol" in argv:
+        tol = float(argv[argv.index("--tol") + 1])
+    line = json.load(open(argv[0]))
+    rows = list(csv.DictReader(open(argv[1])))
+    steps_kernel = argv[argv.index("--steps-from") + 1] if "--steps-from" in argv else "gap_stat"
+    steps = sum(int(r["Calls"]) for r in rows if steps_kernel in r["Name"])
+    if not steps:
+        print("no '%s' kernel in the table: cannot tell how many steps the profiled process ran" % steps_kernel)
+        return 2
+    kernels = line["roofline"]["kernels"]
+    step_us = sum(k["ms_per_step"] for k in kernels.values()) * 1e3
+    print("steps in the profiled process: %d; families of the line: %s" % (steps, ", ".join(kernels)))
+    print("%-10s %14s %14s %8s %10s %10s" % ("family", "events us/step", "rocprof us/step", "ratio", "frac(line)", "frac(csv)"))
+    bad = 0
+    for fam, k in kernels.items():
+        names = FAMILIES.get(fam)
+        if not names:
+            continue
+        tot_ns = sum(float(r["TotalDurationNs"]) for r in rows
+                     if any(n in r["Name"] for n in names) and not (fam == "pwconv" and "pwconv_rows_kernel" in r["Name"]))
+        if tot_ns == 0:
+            continue
+        rp_us = tot_ns / steps / 1e3
+        ev_us = k["ms_per_step"] * 1e3
+        launches_per_step = ev_us / max(k["avg_launch_us"], 1e-9)
+        frac_csv = k["algorithmic_bytes_per_launch"] * launches_per_step / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        ratio = ev_us / rp_us
+        flag = ""
+        if abs(ratio - 1.0) > tol and ev_us >= 0.05 * step_us:
+            bad += 1
+            flag = "  <-- beyond %.0f %%" % (tol * 100)
+        print("%-10s %14.1f %14.1f %8.3f %10.4f %10.4f%s" % (fam, ev_us, rp_us, ratio, k["frac"], frac_csv, flag))
+    dom = line["roofline"].get("kernel")
+    print("line: roofline.frac %.4f (%s)" % (line["roofline"]["frac"], (dom or "")[:60]))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

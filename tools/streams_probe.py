@@ -33,7 +33,7 @@ def main():
     streams = [torch.cuda.Stream(dev) for _ in range(smax)]
 
     def step(i, s):
-        with torch.cuda.stream(streams[s]):
+        with torch.cuda.stream(streams[s]), ops.batches_in_flight():
             if heads[s] is not None:
                 heads[s].labels = labels[i % 4]
             out = nets[s](batches[i % 4])._t
