@@ -81,6 +81,14 @@ int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* 
  *                     what the kernel itself (dispatch included) costs when nothing brackets it.
  * pair_ms - null_kernel_ms is what bench.py removes from every bracketed launch.  `scratch`: >= 4 device bytes.          */
 int fq_profile_calibrate(void* scratch, int repeats, double* pair_ms, double* null_kernel_ms, fqStream_t stream);
+/* What an event pair measures BEYOND a kernel's own begin -> end time (dispatch in front of the first wave, the marker behind
+ * the last): a one-wavefront kernel spinning `spin_us` on the wall clock is launched `repeats` times in a busy queue, each
+ * launch bracketed by an ordinary event pair AND given its own start / stop events (hipExtLaunchKernelGGL: the dispatch
+ * packet's begin / end timestamps, what rocprofv3's kernel tables are made of);  overhead_ms <- median of (pair elapsed -
+ * dispatch begin -> end), spin_ms <- the kernel's own median clock distance.  Raw event time minus overhead_ms per launch is
+ * the figure rocprofv3 shows (tools/check_events_vs_rocprof.py).  Synchronises.  scratch: repeats * 16 device bytes.       */
+int fq_profile_launch_overhead(void* scratch, int repeats, double spin_us, double* overhead_ms, double* spin_ms,
+                               fqStream_t stream);
 
 /* ---- activations ---------------------------------------------------------------------------------------------
  * x is (n, inner) = (N, C*H*W).  `ws` is a caller workspace of fq_act_workspace_bytes(n) bytes.                  */
@@ -424,6 +432,45 @@ int fq_quantize_codes(const float* x, int32_t* codes, int64_t numel, int mode, f
                       fqStream_t stream);
 /* y <- float(codes) * scale_dev[0]  (dequantize, :74-76) */
 int fq_dequantize(const int32_t* codes, float* y, int64_t numel, const float* scale_dev, fqStream_t stream);
+
+/* ---- nn.Conv2D(quantized=True): the reference's stand-alone quantised convolution (nn/quantized_conv.py:106-159) ---------
+ * `Conv2D.hybrid_forward` with quantized=True, as one call per forward:  pad -> `quantize(inputs, input_dtype)` (ONE global
+ * range: int8 [-max|x|, max|x|], scale max/127; uint8 [min, max] of the padded tensor, scale (max - min)/255, no zero point,
+ * no epsilon, :54-72) -> `quantize(weight, weight_dtype)` -> int32 bias codes clip(b, +-s 2^31)/s with s = in_scale * w_scale
+ * (:122-127) -> integer correlation per group (the im2col + dot of :129-151, here exact in wrapping int32 for any accumulator
+ * size) -> activation on the integers -> `dequantize` by s (:157-158).  y = float(relu?(sum + bias_code)) * s, bit for bit
+ * what oracle.qconv2d_forward computes.  No im2col tensor, no int32 code tensor: the quantiser sits on the convolution's loads.
+ *   1x1 stride 1 no padding, groups 1          -> the pointwise forms on the int8 matrix cores (fq_pwconv_i8's kernels)
+ *   3x3 stride 1 padding 1, groups 1, Cin 64.. -> the implicit-GEMM kernel of fq_conv3x3_i8
+ *   3x3 stride 1|2 padding 1, depthwise        -> the depthwise forms of fq_dwconv3x3 on integer codes (no bias)
+ *   anything else, uint8 / fixed-range weights -> an exact one-output-per-thread kernel (force_direct != 0 asks for it)
+ * followed by a conditional exact recomputation that returns at once unless the range record says the fast kernel's 8-bit
+ * representation did not hold for this input (a code span of 257 values, a clip range without the padding zero).
+ *
+ * fq_qconv_weights_prepare: once per weight version.  wbuf: fq_qconv_weights_bytes(...) bytes, 16-byte aligned; ws: 16 bytes.
+ *   weight_mode FQ_CODES_INT8 / FQ_CODES_UINT8 / FQ_CODES_RANGE (`_weight_range` = [w_min, w_max]); only int8 weights take the
+ *   fast kernels (the caller passes force_direct for the others).
+ * fq_qconv2d_forward: x (n, cin, h, w) fp32 UNPADDED; w (cout, cin/groups, kh, kw) fp32 (read by the direct form); bias fp32
+ *   (cout) or NULL; y (n, cout, ho, wo) fp32 with ho = (h + 2 ph - kh)/sh + 1.  input_mode FQ_CODES_INT8 / UINT8, or
+ *   FQ_CODES_RANGE with `_input_range` = [in_min, in_max].  in_stat (may be NULL; n floats): per-sample max of a NON-NEGATIVE
+ *   x as a fused producer left it (BatchNorm + ReLU) - the range is then [0, max] without a pass over x (needs padding > 0 or
+ *   int8 mode: otherwise the true minimum matters).  act: FQ_ACT_NONE / FQ_ACT_RELU [| FQ_STAT_PREZEROED].  bn_scale /
+ *   bn_shift (may be NULL): an inference BatchNorm behind the block folded into the store, y' = y * bn_scale[c] + bn_shift[c]
+ *   (separately rounded, as fq_bn_act_stat), then act on y' instead (not for the depthwise form).  stat_out (may be NULL): per-sample
+ *   max|y'|.  ws: fq_qconv_workspace_bytes(cout) bytes, 16-byte aligned, initialised ONCE by fq_qconv_workspace_init (every
+ *   forward leaves it initialised); not to be shared by forwards that may run concurrently.                                */
+size_t fq_qconv_weights_bytes(int64_t cin, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw, int groups);
+/* which kernel family a geometry takes: 0 direct, 1 pointwise (matrix cores), 2 dense 3x3 (matrix cores), 3 depthwise 3x3 */
+int fq_qconv_kind(int64_t cin, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw, int groups);
+int fq_qconv_weights_prepare(const float* w, int64_t cin, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                             int groups, int weight_mode, float w_min, float w_max, void* wbuf, void* ws,
+                             fqStream_t stream);
+size_t fq_qconv_workspace_bytes(int64_t cout);
+int fq_qconv_workspace_init(void* ws, fqStream_t stream);
+int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const float* bias, float* y, int64_t n, int64_t cin,
+                       int64_t h, int64_t wdt, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw, int groups,
+                       int input_mode, float in_min, float in_max, const float* in_stat, int act, const float* bn_scale,
+                       const float* bn_shift, float* stat_out, void* ws, int force_direct, fqStream_t stream);
 
 #ifdef __cplusplus
 }

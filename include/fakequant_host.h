@@ -133,6 +133,15 @@ int fq_quantize_codes_host(const float* x, int32_t* codes, int64_t numel, int mo
                            fqStream_t stream);
 int fq_dequantize_host(const int32_t* codes, float* y, int64_t numel, const float* scale_dev, fqStream_t stream);
 
+int fq_qconv_weights_prepare_host(const float* w, int64_t cin, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                  int groups, int weight_mode, float w_min, float w_max, void* wbuf, void* ws,
+                                  fqStream_t stream);
+int fq_qconv2d_forward_host(const float* x, const float* w, const void* wbuf, const float* bias, float* y, int64_t n,
+                            int64_t cin, int64_t h, int64_t wdt, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                            int groups, int input_mode, float in_min, float in_max, const float* in_stat, int act,
+                            const float* bn_scale, const float* bn_shift, float* stat_out, void* ws, int force_direct,
+                            fqStream_t stream);
+
 /* The reference's UNFUSED op chain for one activation tensor, pass by pass, as MXNet's CPU NDArray ops would run it
  * (convert_conv2d.py:56-66, ste_func.py:41): abs (temp) -> per-sample max -> mean -> clip (temp) -> divide (temp) ->
  * round (temp) -> multiply; each pass an OpenMP loop over the whole tensor.  Same results as

@@ -1175,4 +1175,133 @@ int fq_dequantize_host(const int32_t* codes, float* y, int64_t numel, const floa
   return FQ_OK;
 }
 
+// nn/quantized_conv.py:106-159 (`Conv2D.hybrid_forward`, quantized=True) - the twin of fq_qconv2d_forward: pad, ONE global
+// range per tensor (:63-72; int8 [-max|x|, max|x|], uint8 [min, max] of the PADDED tensor, fixed `_input_range`), codes
+// round(clip(x) / scale) with scale = max/127 if symmetric else (max - min)/255 - no zero point, no epsilon (:54-61) -, int32
+// bias codes (:122-127), integer correlation per group (the im2col + dot of :129-151 as exact integer sums in wrapping int32,
+// the reference's cast, :144), activation on the integers, dequantise by in_scale * w_scale (:157-158).
+// wbuf: 8 floats written by fq_qconv_weights_prepare_host = {w_max, w_min, w_scale, ...}.
+int fq_qconv_weights_prepare_host(const float* w, int64_t cin, int64_t cout, int kh, int kw, int, int, int, int, int groups,
+                                  int weight_mode, float w_min, float w_max, void* wbuf, void*, fqStream_t) {
+  REQUIRE(w && wbuf && cin > 0 && cout > 0 && groups > 0 && cin % groups == 0 && kh > 0 && kw > 0,
+          "fq_qconv_weights_prepare_host: bad arguments");
+  REQUIRE(weight_mode >= FQ_CODES_INT8 && weight_mode <= FQ_CODES_RANGE, "unknown out type: %d", weight_mode);
+  const int64_t numel = cout * (cin / groups) * kh * kw;
+  float mn = w_min, mx = w_max;
+  if (weight_mode == FQ_CODES_INT8) {
+    float m = 0.0f;
+    for (int64_t i = 0; i < numel; ++i) m = fmaxf(m, fabsf(w[i]));
+    mx = m;
+    mn = -m;
+  } else if (weight_mode == FQ_CODES_UINT8) {
+    mx = -INFINITY;
+    mn = INFINITY;
+    for (int64_t i = 0; i < numel; ++i) {
+      mx = fmaxf(mx, w[i]);
+      mn = fminf(mn, w[i]);
+    }
+  }
+  float* rec = (float*)wbuf;
+  rec[0] = mx;
+  rec[1] = mn;
+  rec[2] = (mx == -mn) ? (mx / 127.0f) : ((mx - mn) / 255.0f);
+  for (int i = 3; i < 8; ++i) rec[i] = 0.0f;
+  return FQ_OK;
+}
+
+int fq_qconv2d_forward_host(const float* x, const float* w, const void* wbuf, const float* bias, float* y, int64_t n,
+                            int64_t cin, int64_t h, int64_t wdt, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                            int groups, int input_mode, float in_min, float in_max, const float* in_stat, int act,
+                            const float* bn_scale, const float* bn_shift, float* stat_out, void*, int, fqStream_t) {
+  REQUIRE(x && w && wbuf && y && n > 0 && cin > 0 && cout > 0 && h > 0 && wdt > 0 && groups > 0 && cin % groups == 0 &&
+              cout % groups == 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0,
+          "fq_qconv2d_forward_host: bad arguments");
+  REQUIRE(input_mode >= FQ_CODES_INT8 && input_mode <= FQ_CODES_RANGE, "unknown out type: %d", input_mode);
+  act &= ~FQ_STAT_PREZEROED;
+  const int64_t numel = n * cin * h * wdt;
+  float mn = in_min, mx = in_max;
+  if (in_stat != nullptr) {
+    mx = 0.0f;
+    for (int64_t i = 0; i < n; ++i) mx = fmaxf(mx, in_stat[i]);
+    mn = input_mode == FQ_CODES_INT8 ? -mx : 0.0f;
+  } else if (input_mode == FQ_CODES_INT8) {
+    float m = 0.0f;
+#pragma omp parallel for reduction(max : m) schedule(static)
+    for (int64_t i = 0; i < numel; ++i) m = fmaxf(m, fabsf(x[i]));
+    mx = m;
+    mn = -m;
+  } else if (input_mode == FQ_CODES_UINT8) {
+    float hi = -INFINITY, lo = INFINITY;
+#pragma omp parallel for reduction(max : hi) reduction(min : lo) schedule(static)
+    for (int64_t i = 0; i < numel; ++i) {
+      hi = fmaxf(hi, x[i]);
+      lo = fminf(lo, x[i]);
+    }
+    if (ph > 0 || pw > 0) {                    // the zeros of the padding belong to the tensor whose range is taken (:108-113)
+      hi = fmaxf(hi, 0.0f);
+      lo = fminf(lo, 0.0f);
+    }
+    mx = hi;
+    mn = lo;
+  }
+  const float xs = (mx == -mn) ? (mx / 127.0f) : ((mx - mn) / 255.0f);
+  const float* wrec = (const float*)wbuf;
+  const float wh = wrec[0], wl = wrec[1], ws_ = wrec[2];
+  const float deq = xs * ws_;
+  const float b_max = deq * 2147483648.0f;
+  const int64_t cin_g = cin / groups, cout_g = cout / groups;
+  const int64_t ho = (h + 2 * ph - kh) / sh + 1, wo = (wdt + 2 * pw - kw) / sw + 1;
+  const int zero_code = (int)round_half_away(clipf(0.0f, mn, mx) / xs);
+  // the codes of x once (the direct kernel of the device library quantises where it reads: same values)
+  std::vector<int32_t> cx((size_t)numel);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < numel; ++i) cx[(size_t)i] = (int32_t)round_half_away(clipf(x[i], mn, mx) / xs);
+  const int64_t wnumel = cout * cin_g * kh * kw;
+  std::vector<int32_t> cw((size_t)wnumel);
+  for (int64_t i = 0; i < wnumel; ++i) cw[(size_t)i] = (int32_t)round_half_away(clipf(w[i], wl, wh) / ws_);
+  if (stat_out != nullptr)
+    for (int64_t s = 0; s < n; ++s) stat_out[s] = 0.0f;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int64_t s = 0; s < n; ++s)
+    for (int64_t co = 0; co < cout; ++co) {
+      const int64_t g = co / cout_g;
+      uint32_t bcode = 0;
+      if (bias != nullptr) bcode = (uint32_t)(int64_t)round_half_away(clipf(bias[co], -b_max, b_max) / deq);
+      float m = 0.0f;
+      for (int64_t oh = 0; oh < ho; ++oh)
+        for (int64_t ow = 0; ow < wo; ++ow) {
+          uint32_t acc = 0;
+          for (int64_t ci = 0; ci < cin_g; ++ci) {
+            const int32_t* xp = cx.data() + ((s * cin + g * cin_g + ci) * h) * wdt;
+            const int32_t* wp = cw.data() + (co * cin_g + ci) * kh * kw;
+            for (int ky = 0; ky < kh; ++ky) {
+              const int64_t ih = oh * sh - ph + ky;
+              for (int kx = 0; kx < kw; ++kx) {
+                const int64_t iw = ow * sw - pw + kx;
+                const bool in = ih >= 0 && ih < h && iw >= 0 && iw < wdt;
+                const int32_t c = in ? xp[ih * wdt + iw] : zero_code;
+                acc += (uint32_t)c * (uint32_t)wp[ky * kw + kx];
+              }
+            }
+          }
+          acc += bcode;
+          int32_t v = (int32_t)acc;
+          if (act == FQ_ACT_RELU && bn_scale == nullptr) v = v > 0 ? v : 0;       // on the integers (:154-155)
+          float out = (float)v * deq;
+          if (bn_scale != nullptr) {           // a BatchNorm folded behind the block: the activation follows IT
+            out = out * bn_scale[co];
+            out = out + bn_shift[co];
+            if (act == FQ_ACT_RELU) out = fmaxf(out, 0.0f);
+          }
+          y[((s * cout + co) * ho + oh) * wo + ow] = out;
+          m = fmaxf(m, fabsf(out));
+        }
+      if (stat_out != nullptr) {
+#pragma omp critical
+        stat_out[s] = fmaxf(stat_out[s], m);
+      }
+    }
+  return FQ_OK;
+}
+
 }  // extern "C"

@@ -280,21 +280,32 @@ def dequantize(codes, scale):
     return (np.asarray(codes).astype(F32) * F32(scale)).astype(F32)
 
 
-def qconv2d_forward(x, w, b, stride, padding, groups, input_dtype="uint8", weight_dtype="int8", quantized=True):
+def qconv2d_forward(x, w, b, stride, padding, groups, input_dtype="uint8", weight_dtype="int8", quantized=True,
+                    input_range=None, weight_range=None, act=None, in_stat=None, bn_scale=None, bn_shift=None):
     """`Conv2D.hybrid_forward` (nn/quantized_conv.py:106-159) with the im2col + dot done as an exact integer
-    correlation (the reference's fp32 dot is exact while |acc| < 2^24, :140-144)."""
+    correlation (the reference's fp32 dot is exact while |acc| < 2^24, :140-144): pad, per-tensor codes of the PADDED
+    input and of the weight (`quantize`, or `_quantize` with the fixed `_input_range` / `_weight_range`, :112-120), int32
+    bias codes (:122-127), per-group correlation, `act` ("relu") on the integers (:154-155), dequantise (:157-158).
+    Project additions (None in the reference's block): `in_stat` - per-sample maxima of a non-negative input, its range is
+    then [0, max(in_stat)] (int8: [-max, max]); `bn_scale` / `bn_shift` - an inference BatchNorm folded behind the
+    dequantisation, multiply and add separately rounded, the activation then applies to that value."""
     x = np.asarray(x, dtype=F32)
     ph, pw = padding
     x = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
     if quantized:
-        xi, in_s = quantize_codes(x, input_dtype)
-        wi, w_s = quantize_codes(w, weight_dtype)
+        if in_stat is not None:
+            mx = np.asarray(in_stat, dtype=F32).max().astype(F32) if len(in_stat) else F32(0)
+            mx = np.maximum(mx, F32(0))
+            input_range = (F32(-mx), mx) if input_dtype == "int8" else (F32(0), mx)
+        xi, in_s = quantize_codes(x, input_dtype, fixed_range=input_range)
+        wi, w_s = quantize_codes(w, weight_dtype, fixed_range=weight_range)
         bi = None
         if b is not None:
             b_scale = F32(in_s * w_s)
             b_max = F32(F32(in_s * w_s) * F32(2 ** 31))
             bc = np.minimum(np.maximum(np.asarray(b, dtype=F32), -b_max), b_max)
-            bi = roundf((bc / b_scale).astype(F32)).astype(np.int64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                bi = roundf((bc / b_scale).astype(F32)).astype(np.int64)
         xa, wa = xi.astype(np.int64), wi.astype(np.int64)
     else:
         xa, wa, bi = x.astype(np.float64), np.asarray(w, dtype=np.float64), None if b is None else np.asarray(b, np.float64)
@@ -308,16 +319,35 @@ def qconv2d_forward(x, w, b, stride, padding, groups, input_dtype="uint8", weigh
     cpg_out = Co // groups
     for g in range(groups):
         xs = xa[:, g * Cg:(g + 1) * Cg]
+        wg = wa[g * cpg_out:(g + 1) * cpg_out].reshape(cpg_out, -1)
+        if oh * ow > 64:            # larger planes: tap by tap over whole planes (same integer sums, any order)
+            acc = np.zeros((N, cpg_out, oh, ow), dtype=xa.dtype)
+            wg4 = wa[g * cpg_out:(g + 1) * cpg_out]
+            for ky in range(kh):
+                for kx in range(kw):
+                    win = xs[:, :, ky:ky + (oh - 1) * sh + 1:sh, kx:kx + (ow - 1) * sw + 1:sw]
+                    acc += np.einsum("nchw,oc->nohw", win, wg4[:, :, ky, kx])
+            y[:, g * cpg_out:(g + 1) * cpg_out] = acc
+            continue
         for i in range(oh):
             for j in range(ow):
                 win = xs[:, :, i * sh:i * sh + kh, j * sw:j * sw + kw].reshape(N, -1)
-                wg = wa[g * cpg_out:(g + 1) * cpg_out].reshape(cpg_out, -1)
                 y[:, g * cpg_out:(g + 1) * cpg_out, i, j] = win @ wg.T
     if bi is not None:
         y = y + bi.reshape(1, -1, 1, 1)
     if quantized:
-        return dequantize(y.astype(np.int32), F32(in_s * w_s))
-    return y.astype(F32)
+        yi = y.astype(np.int32)                      # (:144) wraps like the cast
+        if act == "relu" and bn_scale is None:
+            yi = np.maximum(yi, 0)
+        out = dequantize(yi, F32(in_s * w_s))
+        if bn_scale is not None:
+            out = (out * np.asarray(bn_scale, dtype=F32).reshape(1, -1, 1, 1)).astype(F32)
+            out = (out + np.asarray(bn_shift, dtype=F32).reshape(1, -1, 1, 1)).astype(F32)
+            if act == "relu":
+                out = np.maximum(out, F32(0))
+        return out
+    out = y.astype(F32)
+    return np.maximum(out, F32(0)) if act == "relu" else out
 
 
 # ---- fused producer (project addition; quantize/fuse.py) ---------------------------------------------------------

@@ -445,3 +445,31 @@ def eval_counters(logits, labels, counters=None):
     out = np.zeros(2 + 2 * classes, F32) if counters is None else _f32(counters).copy()
     _call("fq_eval_counters_host", logits, np.ascontiguousarray(labels, np.int64), n, classes, out, None)
     return out
+
+
+_QMODES = {"int8": 0, "uint8": 1}
+
+
+def qconv2d_forward(x, w, b, stride, padding, groups, input_dtype="uint8", weight_dtype="int8", input_range=None,
+                    weight_range=None, act=None, in_stat=None, bn_scale=None, bn_shift=None, want_stat=False):
+    """fq_qconv_weights_prepare_host + fq_qconv2d_forward_host: fq_oracle.qconv2d_forward(quantized=True) at full size."""
+    x, w = _f32(x), _f32(w)
+    n, cin, h, wd = x.shape
+    cout, cin_g, kh, kw = w.shape
+    sh, sw = stride
+    ph, pw = padding
+    wbuf = np.zeros(16, F32)
+    wm = 2 if weight_range is not None else _QMODES[weight_dtype]
+    wlo, whi = (float(weight_range[0]), float(weight_range[1])) if weight_range is not None else (0.0, 0.0)
+    _call("fq_qconv_weights_prepare_host", w, cin, cout, _i(kh), _i(kw), _i(sh), _i(sw), _i(ph), _i(pw), _i(groups), _i(wm),
+          wlo, whi, wbuf, None, None)
+    ho, wo = (h + 2 * ph - kh) // sh + 1, (wd + 2 * pw - kw) // sw + 1
+    y = np.empty((n, cout, ho, wo), F32)
+    im = 2 if input_range is not None else _QMODES[input_dtype]
+    ilo, ihi = (float(input_range[0]), float(input_range[1])) if input_range is not None else (0.0, 0.0)
+    stat = np.empty(n, F32) if want_stat else None
+    _call("fq_qconv2d_forward_host", x, w, wbuf, None if b is None else _f32(b), y, n, cin, h, wd, cout, _i(kh), _i(kw),
+          _i(sh), _i(sw), _i(ph), _i(pw), _i(groups), _i(im), ilo, ihi, None if in_stat is None else _f32(in_stat),
+          _i(_ACTS[act]), None if bn_scale is None else _f32(bn_scale), None if bn_shift is None else _f32(bn_shift), stat,
+          None, _i(0), None)
+    return (y, stat) if want_stat else y

@@ -436,6 +436,37 @@ def dequantize(codes, scale_dev):
     return _t(O.dequantize(_np(codes), F32(_np(scale_dev).reshape(-1)[0])))
 
 
+class _QconvWeights(object):
+    """stand-in for the opaque device buffer of ops.qconv_weights"""
+
+    def __init__(self, dtype, rng):
+        self.dtype, self.rng = dtype, rng
+
+
+def qconv_weights(w, strides, padding, groups, weight_dtype="int8", weight_range=None):
+    if weight_range is None and weight_dtype not in ("int8", "uint8"):
+        raise ValueError("unknown out type: %s" % (weight_dtype,))
+    return _QconvWeights(weight_dtype, weight_range)
+
+
+def qconv_workspace(cout, device):
+    return torch.zeros(1)
+
+
+def qconv2d(x, w, wbuf, bias, strides, padding, groups, ws, input_dtype="uint8", input_range=None, act="none", in_stat=None,
+            bn_scale=None, bn_shift=None, want_stat=False, force_direct=False, out=None):
+    if input_range is None and input_dtype not in ("int8", "uint8"):
+        raise ValueError("unknown out type: %s" % (input_dtype,))
+    y = O.qconv2d_forward(_np(x), _np(w), None if bias is None else _np(bias), tuple(strides), tuple(padding), groups,
+                          input_dtype=input_dtype, weight_dtype=wbuf.dtype, input_range=input_range, weight_range=wbuf.rng,
+                          act=None if act == "none" else act, in_stat=None if in_stat is None else _np(in_stat),
+                          bn_scale=None if bn_scale is None else _np(bn_scale),
+                          bn_shift=None if bn_shift is None else _np(bn_shift))
+    if want_stat:
+        return _t(y), _t(np.abs(y).reshape(y.shape[0], -1).max(axis=1).astype(F32))
+    return _t(y)
+
+
 def require_hip(device, what="tensor"):
     return None
 
@@ -447,7 +478,7 @@ def default_device(what="this call"):
 _REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
              "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "dense_i8_eval", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
-             "hist_to_float", "kl_search", "quantize_codes", "dequantize"]
+             "hist_to_float", "kl_search", "quantize_codes", "dequantize", "qconv_weights", "qconv_workspace", "qconv2d"]
 
 
 @contextlib.contextmanager

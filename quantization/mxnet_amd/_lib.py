@@ -29,6 +29,8 @@ EXPORTS = {
     "fq_profile_read": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                                ctypes.POINTER(ctypes.c_double)]),
     "fq_profile_calibrate": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]),
+    "fq_profile_launch_overhead": (_int, [_vp, _int, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                                          ctypes.POINTER(ctypes.c_double), _vp]),
     "fq_act_workspace_bytes": (ctypes.c_size_t, [_i64]),
     "fq_absmax_per_sample": (_int, [_vp, _i64, _i64, _uint, _vp, _vp]),
     "fq_batch_mean": (_int, [_vp, _i64, _vp, _vp]),
@@ -88,6 +90,14 @@ EXPORTS = {
     "fq_kl_search": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "fq_quantize_codes": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp]),
     "fq_dequantize": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "fq_qconv_weights_bytes": (ctypes.c_size_t, [_i64, _i64, _int, _int, _int, _int, _int, _int, _int]),
+    "fq_qconv_kind": (_int, [_i64, _i64, _int, _int, _int, _int, _int, _int, _int]),
+    "fq_qconv_weights_prepare": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32, _vp,
+                                        _vp, _vp]),
+    "fq_qconv_workspace_bytes": (ctypes.c_size_t, [_i64]),
+    "fq_qconv_workspace_init": (_int, [_vp, _vp]),
+    "fq_qconv2d_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int,
+                                  _int, _int, _f32, _f32, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp]),
 }
 
 FQ_ACT_SIGNED, FQ_ACT_LO_NEG_MAX, FQ_ACT_NO_ABS, FQ_ACT_NO_EPS = 1, 2, 4, 8

@@ -94,7 +94,7 @@ def prune(verbose=True):
         tag = os.path.basename(d)
         for f in sorted(os.listdir(d)):
             unit = f.split(".")[0]
-            stale = (f.endswith(".o") and unit not in units and unit != "fq_all") or ".o." in f
+            stale = (f.endswith(".o") and unit not in units and unit != "fq_all") or (".o." in f and not f.endswith(".o.id"))
             if stale:
                 os.remove(os.path.join(d, f))
                 removed.append(os.path.join(tag, f))

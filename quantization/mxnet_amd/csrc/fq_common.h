@@ -91,6 +91,12 @@ struct ProfScope {
     (void)hipEventRecord(r.b, st);
     prof_push(r);
   }
+  void cancel() {                    // nothing was launched after all: no record
+    if (!on) return;
+    on = false;
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
 };
 
 // defined in fq_stream.hip; used by the weight paths too
@@ -425,6 +431,44 @@ __device__ __forceinline__ QParams make_qparams(float max_, float levels, bool l
   q.rden = 1.0 / (double)q.denom;
   return q;
 }
+
+// ---- range mode: the per-tensor quantiser of the reference's stand-alone block, nn.Conv2D(quantized=True) ----------------
+// nn/quantized_conv.py:54-72: ONE global range for the whole tensor - int8: [-max|x|, max|x|], scale = max / 127; uint8:
+// [min x, max x], scale = (max - min) / 255 and NO zero point, so the codes round(clip(x) / scale) lie in [L, H] with
+// L = round(min / scale), wherever that is - no epsilon.  The fused convolution kernels take it as a third value of their
+// `lo_neg_max` argument: kRangeMode says that `in_thr` points to a RANGE RECORD (fq_qconv_range writes it) instead of a
+// threshold, and - in the kernels on the matrix cores - that `bias` holds the reference's int32 bias codes (:122-127),
+// added to the integer sum.  Codes are stored as (code + ubias) ^ 0x80 per byte with ubias = -L (0 <= code - L <= 255),
+// i.e. re-centred by zoff = 128 - ubias; the epilogue's zoff * rowsum term puts the integer sum right, in wrapping int32
+// arithmetic like the reference's cast.  The two launch-time cases are the record's special cases (unsigned from 0:
+// ubias 0; symmetric: ubias 128).
+constexpr int kRangeMode = 2;
+constexpr int kRecHi = 0, kRecLo = 1, kRecDenom = 2, kRecMul = 3, kRecUbias = 4, kRecFlags = 5, kRecScale = 6, kRecLcode = 7;
+constexpr int kRecFloats = 8;        // hi, lo, divisor, multiply-back scale (1 for kernels that keep CODES in fp32), ubias
+                                     // (int), flags (int: 1 = codes do not fit a byte / fp32-exact sums not guaranteed: the
+                                     // exact direct kernel recomputes), scale, L (int)
+// QParams + zoff of a launch: the threshold form (make_qparams) or, in range mode, the record's
+__device__ __forceinline__ QParams make_qparams_rt(float max_, float levels, int lo_neg_max, float eps,
+                                                   const float* __restrict__ in_thr, int& zoff) {
+  if (lo_neg_max == kRangeMode) {
+    QParams q;
+    q.hi = max_;                                  // == in_thr[kRecHi]
+    q.lo = in_thr[kRecLo];
+    q.denom = in_thr[kRecDenom];
+    q.scale = in_thr[kRecMul];
+    q.rden = 1.0 / (double)q.denom;
+    zoff = 128 - __float_as_int(in_thr[kRecUbias]);
+    return q;
+  }
+  return make_qparams(max_, levels, lo_neg_max != 0, eps);
+}
+__device__ __forceinline__ QParams make_qparams_rt(float max_, float levels, int lo_neg_max, float eps,
+                                                   const float* __restrict__ in_thr) {
+  int unused = 0;
+  return make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr, unused);
+}
+// four codes "0" in the stored representation (zero padding of a 3x3 convolution: clip range always contains 0)
+__device__ __forceinline__ int stored_zero4(int ubias) { return (int)(((unsigned)(ubias & 255) * 0x01010101u) ^ 0x80808080u); }
 
 // Correctly rounded fp32 quotient c / d for a divisor that is the same for the whole kernel, in 3 instructions instead
 // of the ~11 of the IEEE division expansion:  (float)((double)c * RN_f64(1/d))  ==  RN_f32(c / d)  for ALL fp32 c, d.

@@ -85,7 +85,8 @@ int conv3x3_launch(const float* x, const int8_t* wcodes, const float* wscale, co
                    float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* in_stat,
                    const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
                    const float* bn_shift, int act, float* stat_out, fqStream_t stream, int nsl, bool in_c16 = false,
-                   const float* out_thr = nullptr, int out_width = 8, unsigned out_flags = 0) {
+                   const float* out_thr = nullptr, int out_width = 8, unsigned out_flags = 0, bool range = false) {
+  // range: in_thr is a range record (fq_common.h: kRangeMode) and bias holds int32 codes (nn.Conv2D(quantized=True))
   FQ_REQUIRE(x && wcodes && wscale && wsum && y, "fq_conv3x3_i8: null pointer");
   const bool c16 = in_c16 || out_thr != nullptr;
   FQ_REQUIRE(!c16 || nsl == 1, "fq_conv3x3_i8_c16: the three-slice form takes fp32 tensors");
@@ -153,7 +154,7 @@ int conv3x3_launch(const float* x, const int8_t* wcodes, const float* wscale, co
   const size_t lds = (size_t)g.RT * 32 * g.ROW + (size_t)(32 * wc) * (4 + nsl) * sizeof(float);
   FQ_REQUIRE(lds <= 150 * 1024, "fq_conv3x3_i8: the region of %d pixels x %d channels does not fit LDS", g.RP, (int)cin);
   const float levels = act_levels(in_width, in_flags);
-  const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+  const int lo_neg = range ? kRangeMode : ((in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0);
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   ProfScope prof(FQ_KERNEL_CONV3X3, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), st);
   bool launched = false;
@@ -203,6 +204,19 @@ int conv3x3_launch(const float* x, const int8_t* wcodes, const float* wscale, co
 }
 
 }  // namespace
+
+namespace fqi {
+// dense 3x3 (stride 1, padding 1) of nn.Conv2D(quantized=True): quantise on load with the range record, int32 bias codes
+bool conv3x3_range_shape_ok(int64_t cin, int64_t cout) {
+  return (cin == 64 || cin == 128 || cin == 256 || cin == 512) && cout >= 32;
+}
+int conv3x3_range_call(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const int32_t* ibias,
+                       float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* rec,
+                       const float* bn_scale, const float* bn_shift, int act, float* stat_out, hipStream_t st) {
+  return conv3x3_launch(x, wcodes, wscale, wsum, reinterpret_cast<const float*>(ibias), y, n, cin, cout, h, w, nullptr, rec,
+                        8, 0, nullptr, bn_scale, bn_shift, act, stat_out, (fqStream_t)st, 1, false, nullptr, 8, 0, true);
+}
+}  // namespace fqi
 
 extern "C" {
 

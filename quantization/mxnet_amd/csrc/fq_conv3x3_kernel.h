@@ -124,20 +124,25 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   if (wave < NU) issue(wave, bufa);                                     // in flight during the set-up
   FQ_PIN();
   const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, item == 0);
-  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  int zoff = g.zoff;
+  const QParams q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr, zoff);
   const float sx = q.scale;
+  // range mode (nn.Conv2D(quantized=True)): `bias` holds int32 codes that join the integer sum (one slice only)
+  const int* ibias = lo_neg_max == kRangeMode ? reinterpret_cast<const int*>(bias) : nullptr;
+  const float* fbias = lo_neg_max == kRangeMode ? nullptr : bias;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
   for (int i = threadIdx.x; i < NCH; i += NW * 64) {
     const bool ok = ch0 + i < g.Cout;
     const int ic = ok ? ch0 + i : 0;
     c_sxw[i] = ok ? sx * wscale[ic] : 0.0f;
 #pragma unroll
-    for (int sl = 0; sl < NSL; ++sl) c_zs[sl * NCH + i] = ok ? g.zoff * wsum[sl * g.slice_rows + ic] : 0;
-    c_bias[i] = ok && bias != nullptr ? bias[ic] : 0.0f;
+    for (int sl = 0; sl < NSL; ++sl)
+      c_zs[sl * NCH + i] = ok ? zoff * wsum[sl * g.slice_rows + ic] + (sl == 0 && ibias != nullptr ? ibias[ic] : 0) : 0;
+    c_bias[i] = ok && fbias != nullptr ? fbias[ic] : 0.0f;
     c_bsc[i] = has_bn && ok ? bn_scale[ic] : (ok ? 1.0f : 0.0f);
     c_bsh[i] = has_bn && ok ? bn_shift[ic] : 0.0f;
   }
-  const int ubias = 128 - g.zoff;
+  const int ubias = 128 - zoff;
   const unsigned nn_xor = fq_nonneg_xor(ubias);
   auto quant_to_panel = [&](int u, const float (&v)[16], auto nn_c) __attribute__((always_inline)) {
     v4i f;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   FQ_PIN();
   __syncthreads();                                                      // panel, constants and the statistic table
   const int cvalid = g.Cout - (ch0 + wc * 32);                          // valid channels of this wavefront's tile
-  const int zb = g.zoff ? (int)0x80808080u : 0;                         // four codes "0" in the stored representation
+  const int zb = stored_zero4(ubias);                                   // four codes "0" in the stored representation
   auto run = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
     v16i acc[NSL][PTW];
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
         const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
         f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
-        if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
+        if (BIAS_M == 1 || (BIAS_M < 0 && fbias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
         float vq[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
             for (int sl = 0; sl < NSL; ++sl) T = (T << 7) + (long long)(acc[sl][t][4 * gq + r] + zs[sl][r]);
             v = (float)((double)T * (double)sxw[r]);
           }
-          if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) v = v + bch[r];
+          if (BIAS_M == 1 || (BIAS_M < 0 && fbias != nullptr)) v = v + bch[r];
           if (BN_M == 1 || (BN_M < 0 && has_bn)) {
             v = v * bsc[r];
             v = v + bsh[r];
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   using std::integral_constant;
   if (cvalid <= 0) {
     // a channel group wider than the layer: this wavefront only helped to quantise the region
-  } else if (bias == nullptr && has_bn && act == FQ_ACT_RELU)
+  } else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
     run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
   else
     run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});

@@ -1,6 +1,7 @@
 // libfakequant — errors, event timing, device info, streaming policy
 // (see fq_common.h for the list of translation units and the design rules)
 #include "fq_common.h"
+#include <hip/hip_ext.h>
 
 namespace fqi {
 
@@ -138,6 +139,22 @@ int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* 
   return FQ_OK;
 }
 
+}  // extern "C"
+
+namespace {
+__global__ void spin_kernel(unsigned long long* __restrict__ t, unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long t1 = t0;
+  while (t1 - t0 < ticks) t1 = wall_clock64();
+  if (threadIdx.x == 0) {
+    t[0] = t0;
+    t[1] = t1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
 int fq_profile_calibrate(void* scratch, int repeats, double* pair_ms, double* null_kernel_ms, fqStream_t stream) {
   FQ_REQUIRE(scratch && pair_ms && null_kernel_ms && repeats > 0 && repeats <= 4096, "fq_profile_calibrate: bad arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -167,6 +184,52 @@ int fq_profile_calibrate(void* scratch, int repeats, double* pair_ms, double* nu
   std::sort(ts.begin(), ts.end());
   *pair_ms = ts[ts.size() / 2];
   *null_kernel_ms = (double)all / repeats;
+  return FQ_OK;
+}
+
+// What an event pair measures beyond the kernel's own begin -> end time (command-processor dispatch in front of the first
+// wave, the end-of-pipe marker behind the last one).  A one-wavefront kernel that spins `spin_us` on the wall clock is
+// launched `repeats` times, back to back in a busy queue, each launch BOTH bracketed by an ordinary event pair (what
+// ProfScope does) AND given its own start / stop events through hipExtLaunchKernelGGL - those carry the dispatch packet's
+// begin / end timestamps, the very figures rocprofv3's kernel tables are made of;
+//   overhead_ms <- median over the repeats of (event-pair elapsed time - dispatch begin -> end time).
+// tools/check_events_vs_rocprof.py holds (raw event time - this) against rocprofv3's table.  Synchronises.
+// scratch: repeats * 16 bytes (the kernel also stores its own first and last clock reading: spin_ms is their median distance).
+int fq_profile_launch_overhead(void* scratch, int repeats, double spin_us, double* overhead_ms, double* spin_ms,
+                               fqStream_t stream) {
+  FQ_REQUIRE(scratch && overhead_ms && spin_ms && repeats > 0 && repeats <= 4096 && spin_us > 0 && spin_us < 1e5,
+             "fq_profile_launch_overhead: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int dev = 0, khz = 0;
+  FQ_HIP(hipGetDevice(&dev));
+  FQ_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+  FQ_REQUIRE(khz > 0, "fq_profile_launch_overhead: the device reports no wall clock rate");
+  const unsigned long long ticks = (unsigned long long)(spin_us * 1e-3 * khz);
+  std::vector<hipEvent_t> ev((size_t)repeats * 4);
+  for (auto& e : ev) FQ_HIP(hipEventCreate(&e));
+  unsigned long long* t = (unsigned long long*)scratch;
+  for (int i = 0; i < repeats; ++i) {
+    FQ_HIP(hipEventRecord(ev[4 * i], st));
+    hipExtLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, ev[4 * i + 2], ev[4 * i + 3], 0, t + 2 * i, ticks);
+    FQ_HIP(hipEventRecord(ev[4 * i + 1], st));
+  }
+  FQ_LAUNCH_CHECK();
+  FQ_HIP(hipStreamSynchronize(st));
+  std::vector<unsigned long long> host((size_t)repeats * 2);
+  FQ_HIP(hipMemcpy(host.data(), t, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<double> over, own;
+  for (int i = 0; i < repeats; ++i) {
+    float pair = 0.f, disp = 0.f;
+    FQ_HIP(hipEventElapsedTime(&pair, ev[4 * i], ev[4 * i + 1]));
+    FQ_HIP(hipEventElapsedTime(&disp, ev[4 * i + 2], ev[4 * i + 3]));
+    over.push_back((double)pair - (double)disp);
+    own.push_back((double)(host[2 * i + 1] - host[2 * i]) / (double)khz);
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  std::sort(over.begin(), over.end());
+  std::sort(own.begin(), own.end());
+  *overhead_ms = over[over.size() / 2];
+  *spin_ms = own[own.size() / 2];
   return FQ_OK;
 }
 

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_kernel(const floa
   q.rden = 0.0;
   if (QUANT) {
     const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
-    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr);
   }
   const int lds_elems = g.P * g.IR * g.WS;
   const int plane_in = g.H * g.W, plane_out = g.Ho * g.Wo;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols_kernel(
   auto ensure_q = [&]() __attribute__((always_inline)) {
     if (QUANT && !q_ready) {
       const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
-      q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+      q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr);
       q_ready = true;
     }
   };
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_planes_kernel(
   q.rden = 0.0;
   if (QUANT) {                                            // while the first block is on its way
     const float max_ = threshold_finish(treq, in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
-    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr);
   }
   PW_STAMP(1);
   __syncthreads();                                        // statistic table zeroed
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
   q.rden = 0.0;
   if (QUANT) {                                            // while the first block is on its way
     const float max_ = threshold_finish(treq, in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
-    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr);
   }
   PW_STAMP(1);
   __syncthreads();                                        // statistic table zeroed
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
   q.rden = 0.0;
   if (QUANT) {
     const float max_ = input_threshold(in_stat, n, ONLINE ? nullptr : in_thr, cur_max_out, blockIdx.x == 0);
-    q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+    q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg_in_wave = lane / g.SEG;
@@ -1252,12 +1252,14 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
 
 }  // namespace
 
-extern "C" {
+// in_flags bit of the library's own callers: `in_thr` is a range record (fq_common.h: kRangeMode), the weights are integer
+// codes held in fp32 and the quantiser hands on CODES (multiply-back scale 1): the depthwise layer of nn.Conv2D(quantized=True)
+constexpr unsigned kFlagRangeRecord = 0x100u;
 
-int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
-                 int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
-                 float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
-                 fqStream_t stream) {
+static int dwconv3x3_impl(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
+                          int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                          float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                          fqStream_t stream) {
   FQ_REQUIRE(x && w && y, "fq_dwconv3x3: null pointer");
   FQ_REQUIRE(n > 0 && c > 0 && h > 0 && wdt > 0 && n * c < (1ll << 31) && h * wdt < (1ll << 28),
              "fq_dwconv3x3: bad shape (n=%lld c=%lld h=%lld w=%lld)", (long long)n, (long long)c, (long long)h,
@@ -1309,7 +1311,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
       fg.per = (unsigned)(nblk / grid);
       fg.rem = (unsigned)(nblk % grid);
       const float levels = act_levels(in_width, in_flags);
-      const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+      const int lo_neg = (in_flags & kFlagRangeRecord) ? kRangeMode : ((in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0);
       const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
       const int64_t ho = (h - 1) / stride + 1, wo = (wdt - 1) / stride + 1;
       if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
@@ -1367,7 +1369,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     static const int pl_wg_per_cu = env_int("FQ_DW_PLANES_WG_PER_CU", 5);
     const int grid = (int)(nblk < (int64_t)num_cu() * pl_wg_per_cu ? nblk : (int64_t)num_cu() * pl_wg_per_cu);
     const float levels = act_levels(in_width, in_flags);
-    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    const int lo_neg = (in_flags & kFlagRangeRecord) ? kRangeMode : ((in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0);
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
     if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
@@ -1423,7 +1425,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 6);
     const int grid = (int)(nblk < (int64_t)num_cu() * dw_wg_per_cu ? nblk : (int64_t)num_cu() * dw_wg_per_cu);
     const float levels = act_levels(in_width, in_flags);
-    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    const int lo_neg = (in_flags & kFlagRangeRecord) ? kRangeMode : ((in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0);
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
     if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
@@ -1483,7 +1485,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
     static const int dw_wg_per_cu = env_int("FQ_DW_WG_PER_CU", 6);
     const int grid = (int)(nblk < (int64_t)num_cu() * dw_wg_per_cu ? nblk : (int64_t)num_cu() * dw_wg_per_cu);
     const float levels = act_levels(in_width, in_flags);
-    const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    const int lo_neg = (in_flags & kFlagRangeRecord) ? kRangeMode : ((in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0);
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
     if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
@@ -1556,7 +1558,7 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
   size_t lds = (size_t)((g.P * g.IR * g.WS + 3) / 4 * 4 + 16) * sizeof(float);
   const int grid = grid_for(tiles);
   const float levels = act_levels(in_width, in_flags);
-  const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+  const int lo_neg = (in_flags & kFlagRangeRecord) ? kRangeMode : ((in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0);
   const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * g.Ho * g.Wo), st);
@@ -1576,6 +1578,27 @@ int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, in
 #undef FQ_DW
   FQ_LAUNCH_CHECK();
   return FQ_OK;
+}
+
+namespace fqi {
+// depthwise 3x3 of nn.Conv2D(quantized=True): x quantised on load with the range record `rec` (codes, not values, enter the
+// sums), wcodes_f32 = the int8 weight codes as fp32, y = act(sum * svec[c] + zero[c]) with svec = in_scale * w_scale
+int dw_range_call(const float* x, const float* wcodes_f32, float* y, int64_t n, int64_t c, int64_t h, int64_t wdt, int stride,
+                  const float* rec, const float* svec, const float* zero, int act, float* stat_out, hipStream_t st) {
+  return dwconv3x3_impl(x, wcodes_f32, nullptr, y, n, c, h, wdt, stride, nullptr, rec, 8, kFlagRangeRecord, nullptr, svec,
+                        zero, act, stat_out, (fqStream_t)st);
+}
+}  // namespace fqi
+
+extern "C" {
+
+int fq_dwconv3x3(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
+                 int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                 float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                 fqStream_t stream) {
+  FQ_REQUIRE(!(in_flags & ~(FQ_ACT_SIGNED | FQ_ACT_LO_NEG_MAX | FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "fq_dwconv3x3: unknown flags");
+  return dwconv3x3_impl(x, w, bias, y, n, c, h, wdt, stride, in_stat, in_thr, in_width, in_flags, out_current_max, bn_scale,
+                        bn_shift, act, stat_out, stream);
 }
 
 }  // extern "C"

@@ -188,18 +188,23 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
   // only one that needs it is sx * wscale ------------------------------------------------------------------------------------------
   static_assert(NCH <= NW * 64, "one channel per thread");
   const int ic = ch0 + (int)(threadIdx.x < NCH ? threadIdx.x : 0u);     // < Cout (host: Cout % NCH == 0)
+  // range mode (nn.Conv2D(quantized=True)): `bias` holds int32 codes that join the integer sum
+  const int* ibias = lo_neg_max == kRangeMode ? reinterpret_cast<const int*>(bias) : nullptr;
+  const float* fbias = lo_neg_max == kRangeMode ? nullptr : bias;
   const float k_ws = wscale[ic];
-  const int k_zs = g.zoff * wsum[ic];
-  const float k_bias = bias != nullptr ? bias[ic] : 0.0f;
+  const int k_wsum = wsum[ic];
+  const int k_ib = ibias != nullptr ? ibias[ic] : 0;
+  const float k_bias = fbias != nullptr ? fbias[ic] : 0.0f;
   const float k_bsc = has_bn ? bn_scale[ic] : 1.0f;
   const float k_bsh = has_bn ? bn_shift[ic] : 0.0f;
   FQ_PIN();
   const float max_ = threshold_finish(treq, in_stat, n, in_thr, cur_max_out, b == 0);
-  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  int zoff = g.zoff;
+  const QParams q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr, zoff);
   const float sx = q.scale;
   if (threadIdx.x < NCH) {
     c_sxw[threadIdx.x] = sx * k_ws;
-    c_zs[threadIdx.x] = k_zs;
+    c_zs[threadIdx.x] = zoff * k_wsum + k_ib;
     c_bias[threadIdx.x] = k_bias;
     c_bsc[threadIdx.x] = k_bsc;
     c_bsh[threadIdx.x] = k_bsh;
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
   // last tile (whose products are never stored) - unconditional stores keep the quantiser in the same basic block as the
   // MFMAs, which is what lets the two interleave.
   const unsigned pw_off = ((kq >> 4) * (PT * 64u) + ((kq >> 3) & 1u) * (PT * 32u) + pq * 4u) * 16u + (kq & 7u) * 2u;   // bytes; + 16 * (pixel inside the quad)
-  const int ub = 128 - g.zoff;
+  const int ub = 128 - zoff;
   const unsigned nn_xor16 = fq_nonneg_xor(ub) & 0xFFFFu;
   auto quant_to_panel = [&](int it, const Chunk& c, auto nn_c) __attribute__((always_inline)) {
     f4 v[2] = {c.v[0], c.v[1]};
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
               v.x = fmaxf(v.x, 0.0f);
               v.y = fmaxf(v.y, 0.0f);
             } else {
-              if (bias != nullptr) v = v + (f2){bch[r], bch[r]};
+              if (fbias != nullptr) v = v + (f2){bch[r], bch[r]};
               if (has_bn) {
                 v = v * (f2){bsc[r], bsc[r]};
                 v = v + (f2){bsh[r], bsh[r]};
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
       }
     }
   };
-  const bool fast_epi = bias == nullptr && has_bn && act == FQ_ACT_RELU;
+  const bool fast_epi = fbias == nullptr && has_bn && act == FQ_ACT_RELU;
   auto finish_item = [&](int item) __attribute__((always_inline)) {
     if (cvalid > 0) {
       if (fast_epi) epilogue(item, std::true_type{});

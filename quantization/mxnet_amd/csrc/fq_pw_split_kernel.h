@@ -135,20 +135,24 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     if (wave + NW * i < kt_real) issue(wave + NW * i, buf[i]);          // in flight during the set-up
   FQ_PIN();
   const float max_ = threshold_finish(treq, in_stat, n, in_thr, cur_max_out, item == 0);
-  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  int zoff = g.zoff;
+  const QParams q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr, zoff);
   const float sx = q.scale;
+  // range mode (nn.Conv2D(quantized=True)): `bias` holds int32 codes that join the integer sum
+  const int* ibias = lo_neg_max == kRangeMode ? reinterpret_cast<const int*>(bias) : nullptr;
+  const float* fbias = lo_neg_max == kRangeMode ? nullptr : bias;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
   for (int i = threadIdx.x; i < NCH; i += NW * 64) {
     const bool ok = ch0 + i < g.Cout;                                   // channels past Cout: all-zero constants
     const int ic = ok ? ch0 + i : 0;
     c_sxw[i] = ok ? sx * wscale[ic] : 0.0f;
-    c_zs[i] = ok ? g.zoff * wsum[ic] : 0;
-    c_bias[i] = ok && bias != nullptr ? bias[ic] : 0.0f;
+    c_zs[i] = ok ? zoff * wsum[ic] + (ibias != nullptr ? ibias[ic] : 0) : 0;
+    c_bias[i] = ok && fbias != nullptr ? fbias[ic] : 0.0f;
     c_bsc[i] = has_bn && ok ? bn_scale[ic] : (ok ? 1.0f : 0.0f);
     c_bsh[i] = has_bn && ok ? bn_shift[ic] : 0.0f;
   }
   PW_STAMP(1);
-  const int ubias = 128 - g.zoff;
+  const int ubias = 128 - zoff;
   const unsigned nn_xor = fq_nonneg_xor(ubias);
   auto quant_to_panel = [&](int kt, const float (&v)[16], auto nn_c) __attribute__((always_inline)) {
     v4i f;
@@ -274,12 +278,12 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
         const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
         f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
-        if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
+        if (BIAS_M == 1 || (BIAS_M < 0 && fbias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
         float vq[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = (float)(acc[c][4 * gq + r] + zs[r]) * sxw[r];
-          if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) v = v + bch[r];
+          if (BIAS_M == 1 || (BIAS_M < 0 && fbias != nullptr)) v = v + bch[r];
           if (BN_M == 1 || (BN_M < 0 && has_bn)) {
             v = v * bsc[r];
             v = v + bsh[r];
@@ -330,11 +334,11 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
   using std::integral_constant;
   if (cvalid <= 0) {
     // nothing to multiply (a channel group wider than the layer): this wavefront only helped to quantise the tile
-  } else if (bias == nullptr && has_bn && act == FQ_ACT_RELU)
+  } else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
     run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
-  else if (bias == nullptr && has_bn && act == FQ_ACT_RELU6)
+  else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
     run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{});
-  else if (bias == nullptr && has_bn && act == FQ_ACT_NONE)
+  else if (fbias == nullptr && has_bn && act == FQ_ACT_NONE)
     run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{});
   else
     run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});

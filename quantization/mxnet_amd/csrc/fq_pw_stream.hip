@@ -92,8 +92,12 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   FQ_PIN();
 
   const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, blockIdx.x == 0);
-  const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
+  int zoff = g.zoff;
+  const QParams q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr, zoff);
   const float sx = q.scale;
+  // range mode (nn.Conv2D(quantized=True)): `bias` holds int32 codes that join the integer sum
+  const int* ibias = lo_neg_max == kRangeMode ? reinterpret_cast<const int*>(bias) : nullptr;
+  const float* fbias = lo_neg_max == kRangeMode ? nullptr : bias;
   QParams q2;
   q2.lo = q2.hi = q2.denom = q2.scale = 0.0f;
   q2.rden = 0.0;
@@ -110,15 +114,15 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     const bool ok = i < g.Cout;
     const int ic = ok ? i : 0;
     c_sxw[i] = sx * wscale[ic];
-    c_zs[i] = ok ? g.zoff * wsum[ic] : 0;
-    c_bias[i] = bias != nullptr ? bias[ic] : 0.0f;
+    c_zs[i] = ok ? zoff * wsum[ic] + (ibias != nullptr ? ibias[ic] : 0) : 0;
+    c_bias[i] = fbias != nullptr ? fbias[ic] : 0.0f;
     c_bsc[i] = has_bn ? bn_scale[ic] : 1.0f;
     c_bsh[i] = has_bn ? bn_shift[ic] : 0.0f;
   }
   __syncthreads();
 
   v4i bfrag[KT];
-  const int ubias = 128 - g.zoff;
+  const int ubias = 128 - zoff;
   const unsigned nn_xor = fq_nonneg_xor(ubias);
   auto quant = [&](int kt, const float (&v)[16], auto nn_c) __attribute__((always_inline)) {
     const bool gvalid = kt * 32 + 16 * h < g.Cin;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
         const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
         f4 bch = (f4){0.f, 0.f, 0.f, 0.f};
-        if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
+        if (BIAS_M == 1 || (BIAS_M < 0 && fbias != nullptr)) bch = *reinterpret_cast<const f4*>(c_bias + c0);
         float vq[4];
         // two channels at a time: scale / bias / BatchNorm as packed fp32 instructions (two IEEE operations each - the same
         // values as the scalar form; the kernel is bound by vector-instruction issue, profiles/r2_pmc_sq.txt)
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
           typedef float f2 __attribute__((ext_vector_type(2)));
           f2 v = (f2){(float)acc[4 * gq + r], (float)acc[4 * gq + r + 1]};
           v = v * (f2){sxw[r], sxw[r + 1]};
-          if (BIAS_M == 1 || (BIAS_M < 0 && bias != nullptr)) v = v + (f2){bch[r], bch[r + 1]};
+          if (BIAS_M == 1 || (BIAS_M < 0 && fbias != nullptr)) v = v + (f2){bch[r], bch[r + 1]};
           if (BN_M == 1 || (BN_M < 0 && has_bn)) {
             v = v * (f2){bsc[r], bsc[r + 1]};
             v = v + (f2){bsh[r], bsh[r + 1]};
@@ -257,11 +261,11 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   using std::true_type;
   using std::false_type;
   const bool nn = fq_nonneg(q);
-  if (nn && bias == nullptr && has_bn && act == FQ_ACT_RELU)
+  if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU)
     run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, true_type{});
-  else if (nn && bias == nullptr && has_bn && act == FQ_ACT_RELU6)
+  else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
     run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{}, true_type{});
-  else if (nn && bias == nullptr && has_bn && act == FQ_ACT_NONE)
+  else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_NONE)
     run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{}, true_type{});
   else if (nn)
     run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, true_type{});

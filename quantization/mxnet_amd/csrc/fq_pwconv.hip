@@ -78,8 +78,11 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
                            const float* residual, void* ws, fqStream_t stream, bool in_c16 = false,
                            const float* out_thr = nullptr, int out_width = 8, unsigned out_flags = 0,
                            const long long* eval_labels = nullptr, float* eval_counters = nullptr,
-                           void* eval_ws = nullptr) {
-  FQ_REQUIRE(x && wcodes && wscale && wsum && y && ws, "fq_pwconv_i8: null pointer");
+                           void* eval_ws = nullptr, bool* range_taken = nullptr) {
+  // range_taken != nullptr: range mode (fq_common.h: kRangeMode) - in_thr is a range record, bias holds int32 codes; only
+  // the one-launch forms serve it and *range_taken says whether one took the shape
+  const bool range = range_taken != nullptr;
+  FQ_REQUIRE(x && wcodes && wscale && wsum && y && (ws || range), "fq_pwconv_i8: null pointer");
   FQ_REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && hw < (1ll << 30) && n * hw < (1ll << 31) - 512,
              "fq_pwconv_i8: bad shape");
   FQ_REQUIRE(cin_pad >= cin && cin_pad % 64 == 0 && cin_pad <= 8192, "fq_pwconv_i8: cin_pad=%lld must be a multiple "
@@ -97,12 +100,13 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   act &= ~(FQ_STAT_PREZEROED | FQ_PW_FORM(15));
   FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_pwconv_i8: unknown activation %d", act);
   FQ_REQUIRE(aligned16(wcodes) && aligned16(ws) && aligned16(x), "fq_pwconv_i8: x, wcodes and ws must be 16-byte aligned");
+  if (range) *range_taken = true;
   c.x = x; c.wcodes = wcodes; c.wscale = wscale; c.wsum = wsum; c.bias = bias; c.y = y;
   c.n = n; c.cin = cin; c.cin_pad = cin_pad; c.cout = cout; c.hw = hw;
   c.stride = stride; c.h_in = h_in; c.w_in = w_in; c.w_out = w_out;
   c.in_stat = in_stat; c.in_thr = in_thr;
   c.levels = act_levels(in_width, in_flags);
-  c.lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+  c.lo_neg = range ? kRangeMode : ((in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0);
   c.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;      // unsigned codes are stored re-centred so they fit int8
   c.out_current_max = out_current_max; c.bn_scale = bn_scale; c.bn_shift = bn_shift; c.act = act;
   c.stat_out = stat_out; c.residual = residual; c.ws = ws; c.st = (hipStream_t)stream;
@@ -129,7 +133,7 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   ProfScope prof(hw == 1 ? FQ_KERNEL_DENSE : FQ_KERNEL_PWCONV,
                  4.0 * ((double)n * cin * hw + (residual ? 2.0 : 1.0) * (double)n * cout * hw), c.st);
   bool taken = false;
-  if (hw == 1 && !(in_c16 || out_thr)) {
+  if (hw == 1 && !(in_c16 || out_thr) && !range) {      // (the rows form is not built for range records)
     if (int rc = pw_try_rows(c, &taken)) return rc;
     if (taken) return FQ_OK;
   }
@@ -150,6 +154,11 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   if (taken) return FQ_OK;
   FQ_REQUIRE(residual == nullptr, "fq_pwconv_i8_strided: a residual operand needs a shape the split or the streaming "
              "form takes");
+  if (range) {                                          // (the two-kernel form is not built for range records)
+    *range_taken = false;
+    prof.cancel();
+    return FQ_OK;
+  }
   return pw_two_kernels(c);
 }
 
@@ -193,6 +202,24 @@ int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const fl
                          w, wo, in_stat, in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out,
                          residual, ws, stream, x_is_c16 != 0, out_thr, out_width, out_flags);
 }
+
+}  // extern "C"
+
+namespace fqi {
+// 1x1 convolution of nn.Conv2D(quantized=True) (fq_qconv.hip): x quantised on load with the range record `rec`, int32 bias
+// codes in the integer sum, y = act(float(sum) * (rec scale * wscale[co])) [BatchNorm folded when given]
+int pw_range_call(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const int32_t* ibias,
+                  float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w, int stride,
+                  const float* rec, const float* bn_scale, const float* bn_shift, int act, float* stat_out, hipStream_t st,
+                  bool* taken) {
+  const int64_t ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+  return pwconv_dispatch(x, wcodes, wscale, wsum, reinterpret_cast<const float*>(ibias), y, n, cin, cin_pad, cout, ho * wo,
+                         stride, h, w, wo, nullptr, rec, 8, 0, nullptr, bn_scale, bn_shift, act, stat_out, nullptr, nullptr,
+                         (fqStream_t)st, false, nullptr, 8, 0, nullptr, nullptr, nullptr, taken);
+}
+}  // namespace fqi
+
+extern "C" {
 
 size_t fq_dense_i8_eval_workspace_bytes(int64_t n, int64_t cout) {
   return n > 0 && cout > 0 ? pw_rows_eval_ws_bytes(n, cout) : 0;

@@ -4,17 +4,22 @@ Same constructor and semantics: per-tensor quantise input and weight to int32 co
 global range, scale = max/127 if symmetric else (max-min)/255, NO zero-point), int32 bias at scale in_s*w_s clipped to
 +-scale*2^31 (:122-127), integer correlation, optional activation, `dequantize` by in_s*w_s (:74-76, :158).
 
-What differs is the machinery: the quantise / dequantise stages are HIP kernels (`fq_quantize_codes`, `fq_dequantize`;
-ranges and scales stay in device scalars — no `.asscalar()`), and the reference's Python im2col double loop + fp32 `dot`
-(:34-52, :134-151; 12 544 slices per 112x112 map) is, for dense convolutions (groups == 1, int8 weights), an im2col of the CODES
-followed by `fq_gemm_i8_codes`: int8 x int8 -> exact int32 on the matrix cores (v_mfma_i32_32x32x32_i8), for any
-accumulator size.  Grouped convolutions with int8 weights: when 255 * 127 * K < 2^24 (K = the dot length of one output;
-depthwise: 9) the reference's im2col + dot as ONE batched fp32 matrix product of the integer codes is exact whatever the
-summation order (the library convolution is not: its Winograd kernels transform the operands), beyond that
-the groups go through the integer GEMM one by one, as the reference's loop does (:129-151) - exact int32 in every case.
-uint8 weights keep the fp32 formulation, exact under the same condition as the reference's own fp32 dot (|accumulator| < 2^24,
-:140-144).
+What differs is the machinery.  With `quantized=True` a forward is ONE call into the library (`ops.qconv2d` ->
+`fq_qconv2d_forward`, csrc/fq_qconv.hip): a 4 B/elem pass for the input's global range, one small launch for the range
+record / int32 bias codes / per-channel constants, and the convolution with the quantiser ON ITS LOADS - the 1x1 layers on
+the int8 matrix cores (the pointwise forms of the model path in range mode), dense 3x3 (Cin 64 ... 512) on the implicit-GEMM
+kernel, depthwise 3x3 on the depthwise forms with integer codes in the fp32 chain (exact: 9 taps), every other geometry
+on an exact one-output-per-thread kernel - integer sums in wrapping int32 for ANY accumulator size, where the reference's
+fp32 `dot` (:140-144) is exact only below 2^24.  No padded copy, no im2col tensor, no int32 code tensor, no casts; ranges and
+scales stay in device scalars (no `.asscalar()`).  The weights' codes are kept while the Parameter is the same tensor in the
+same in-place version (the reference re-quantises them every forward: identical values).
+
+Two corners keep the round-3 formulation (an im2col of the CODES + `fq_gemm_i8_codes`, or the fp32-held integer product):
+an `activation` other than relu (the reference applies it to the int32 tensor before `dequantize`), and
+`FQ_QCONV_LEGACY=1` (A/B runs).
 """
+import os
+
 import torch
 import torch.nn.functional as TF
 
@@ -79,7 +84,43 @@ class Conv2D(nn.HybridBlock):
     def _alias(self):
         return "conv2d"
 
+    # ---- quantized=True: one library call per forward ---------------------------------------------------------------------
+    def _fused_ok(self):
+        act = None if self.act is None else self.act._act_type
+        return self._quantized and act in (None, "relu") and os.environ.get("FQ_QCONV_LEGACY", "0") != "1"
+
+    def _prepared_weights(self, w):
+        """ops.qconv_weights of the weight, kept until the Parameter's storage or in-place version changes."""
+        key = (w._version, self._weight_dtype, None if self._weight_range is None else tuple(self._weight_range))
+        held = self.__dict__.get("_fq_qw")
+        if held is None or held[0] is not w or held[1] != key:
+            buf = ops.qconv_weights(w, self._strides, self._padding, self._groups, self._weight_dtype, self._weight_range)
+            held = self.__dict__["_fq_qw"] = (w, key, buf)
+        return held[2]
+
+    def _workspace(self, device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else None
+        slots = self.__dict__.setdefault("_fq_qws", {})
+        ws = slots.get(key)
+        if ws is None:
+            ws = slots[key] = ops.qconv_workspace(self.weight.shape[0], device)
+        return ws
+
+    def _forward_fused(self, inputs, weight, bias):
+        x = inputs._t if inputs._t.is_contiguous() else inputs._t.contiguous()
+        w = weight._t if weight._t.is_contiguous() else weight._t.contiguous()
+        ops.require_hip(x.device, "nn.Conv2D(quantized=True) input")
+        b = None if bias is None else bias._t.contiguous()
+        # (uint8 / fixed-range weights are not on one symmetric int8 grid: the exact direct kernel takes them)
+        direct = self._weight_dtype != 'int8' or self._weight_range is not None
+        y = ops.qconv2d(x, w, self._prepared_weights(w), b, self._strides, self._padding, self._groups,
+                        self._workspace(x.device), input_dtype=self._input_dtype, input_range=self._input_range,
+                        act="none" if self.act is None else "relu", force_direct=direct)
+        return NDArray(y)
+
     def hybrid_forward(self, F, inputs, weight, bias=None):
+        if self._fused_ok():
+            return self._forward_fused(inputs, weight, bias)
         # Pad (:108-109)
         ph, pw = self._padding
         x = TF.pad(inputs._t, (pw, pw, ph, ph), mode="constant", value=0.0).contiguous()

@@ -15,7 +15,8 @@ from ._lib import FakeQuantError
 
 __all__ = ["comm_unique_id", "comm_init", "comm_world", "comm_allreduce", "comm_destroy", "add_act_stat", "bn_act_maxpool_stat", "stat_rows_sum", "mean_from_sums", "fake_quant_online_prestat", "bn_act_stat", "stem_conv3x3s2", "stem_conv_s2", "stem_conv_supported", "eval_counters", "dense_i8_eval", "gemm_i8_codes", "global_avg_pool_stat", "dwconv3x3", "dwconv3x3_c16", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "Codes16", "batch_mean_rows", "batch_mean_gathered", "ste_forward", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "weight_fake_quant",
            "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate", "hist_to_float",
-           "kl_search", "quantize_codes", "dequantize", "winograd_matrices", "device_info", "act_flags"]
+           "kl_search", "quantize_codes", "dequantize", "qconv_kind", "qconv_weights", "qconv_workspace", "qconv2d",
+           "batches_in_flight", "in_flight", "winograd_matrices", "device_info", "act_flags"]
 
 _WS = {}
 
@@ -129,6 +130,17 @@ def profile_event_overhead_ms(device=None, repeats=200):
     check_call(_lib_().fq_profile_calibrate(_ptr(scratch), int(repeats), ctypes.byref(pair), ctypes.byref(null),
                                             _stream(scratch)))
     return max(pair.value - null.value, 0.0), null.value
+
+
+def profile_launch_overhead_ms(device=None, repeats=200, spin_us=30.0):
+    """(overhead_ms, spin_ms): what an event pair measures beyond a kernel's own begin -> end time, measured now on this
+    device with a kernel that times itself on the wall clock (fq_profile_launch_overhead)."""
+    device = default_device() if device is None else device
+    scratch = torch.zeros(4 * int(repeats), dtype=torch.float32, device=device)
+    over, own = ctypes.c_double(0), ctypes.c_double(0)
+    check_call(_lib_().fq_profile_launch_overhead(_ptr(scratch), int(repeats), float(spin_us), ctypes.byref(over),
+                                                  ctypes.byref(own), _stream(scratch)))
+    return max(over.value, 0.0), own.value
 
 
 def act_flags(signed=False, lo_neg_max=None, no_abs=False, no_eps=False):
@@ -1005,3 +1017,81 @@ def dequantize(codes, scale_dev):
     y = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
     check_call(_lib_().fq_dequantize(_ptr(codes), _ptr(y), codes.numel(), _ptr(scale_dev), _stream(codes)))
     return y
+
+
+# ---- nn.Conv2D(quantized=True): one call per forward (include/fakequant.h at fq_qconv2d_forward) -------------------------------
+QCONV_KINDS = {0: "direct", 1: "pointwise", 2: "dense3x3", 3: "depthwise3x3"}
+
+
+def _geom(shape_w, strides, padding, groups):
+    cout, cin_g, kh, kw = (int(v) for v in shape_w)
+    return (cin_g * int(groups), cout, kh, kw, int(strides[0]), int(strides[1]), int(padding[0]), int(padding[1]), int(groups))
+
+
+def qconv_kind(shape_w, strides, padding, groups):
+    """Which kernel family a geometry takes ("direct", "pointwise", "dense3x3", "depthwise3x3")."""
+    return QCONV_KINDS[_lib_().fq_qconv_kind(*_geom(shape_w, strides, padding, groups))]
+
+
+def qconv_weights(w, strides, padding, groups, weight_dtype="int8", weight_range=None):
+    """`quantize(F, weight, weight_dtype)` / `_quantize(F, weight, *_weight_range)` (nn/quantized_conv.py:117-120) once per
+    weight version: the weights' range record, and - for the geometries with a fused kernel - their int8 codes in the layout
+    that kernel reads.  Returns an opaque device buffer for `qconv2d`."""
+    _check(w, "weight")
+    if w.dim() != 4:
+        raise ValueError("weight must be (cout, cin / groups, kh, kw)")
+    if weight_range is None and weight_dtype not in ("int8", "uint8"):
+        raise ValueError("unknown out type: %s" % (weight_dtype,))
+    g = _geom(w.shape, strides, padding, groups)
+    nbytes = _lib_().fq_qconv_weights_bytes(*g)
+    if nbytes == 0:
+        raise ValueError("bad convolution geometry %r" % (g,))
+    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=w.device)
+    ws = _workspace(w.device, 64)
+    mode = _lib.FQ_CODES_RANGE if weight_range is not None else _CODE_MODES[weight_dtype]
+    lo, hi = (float(weight_range[0]), float(weight_range[1])) if weight_range is not None else (0.0, 0.0)
+    check_call(_lib_().fq_qconv_weights_prepare(_ptr(w), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], mode, lo, hi,
+                                                _ptr(buf), _ptr(ws), _stream(w)))
+    return buf
+
+
+def qconv_workspace(cout, device):
+    """Per-(block, stream) state of `qconv2d`: running {min, max}, the range record, bias codes, per-channel constants.
+    Initialised once; every forward leaves it initialised."""
+    ws = torch.empty(int(_lib_().fq_qconv_workspace_bytes(int(cout))), dtype=torch.uint8, device=device)
+    check_call(_lib_().fq_qconv_workspace_init(_ptr(ws), _stream(ws)))
+    return ws
+
+
+def qconv2d(x, w, wbuf, bias, strides, padding, groups, ws, input_dtype="uint8", input_range=None, act="none", in_stat=None,
+            bn_scale=None, bn_shift=None, want_stat=False, force_direct=False, out=None):
+    """`Conv2D.hybrid_forward` with quantized=True (nn/quantized_conv.py:106-159) on the UNPADDED fp32 input: range of the
+    padded tensor, quantise-on-load integer convolution, int32 bias, activation on the integers, dequantise - one call.
+    Returns y, or (y, per-sample max|y|) with want_stat."""
+    _check(x, "x")
+    _check(w, "weight")
+    if x.dim() != 4 or w.dim() != 4:
+        raise ValueError("x must be (n, cin, h, w) and weight (cout, cin / groups, kh, kw)")
+    if input_range is None and input_dtype not in ("int8", "uint8"):
+        raise ValueError("unknown out type: %s" % (input_dtype,))
+    if act not in ("none", "relu"):
+        raise ValueError("activation %r: the block applies its activation to the int32 sums (none or relu)" % (act,))
+    g = _geom(w.shape, strides, padding, groups)
+    n, cin, h, wd = (int(v) for v in x.shape)
+    if cin != g[0]:
+        raise ValueError("input has %d channels, the weight wants %d" % (cin, g[0]))
+    ho = (h + 2 * g[6] - g[2]) // g[4] + 1
+    wo = (wd + 2 * g[7] - g[3]) // g[5] + 1
+    if ho <= 0 or wo <= 0:
+        raise ValueError("kernel larger than the padded input")
+    y = torch.empty((n, g[1], ho, wo), dtype=torch.float32, device=x.device) if out is None else _check(out, "out")
+    stat, zflag = _stat_target(n, x.device, want_stat)
+    mode = _lib.FQ_CODES_RANGE if input_range is not None else _CODE_MODES[input_dtype]
+    lo, hi = (float(input_range[0]), float(input_range[1])) if input_range is not None else (0.0, 0.0)
+    if bias is not None:
+        _check(bias, "bias")
+    check_call(_lib_().fq_qconv2d_forward(_ptr(x), _ptr(w), _ptr(wbuf), _ptr(bias), _ptr(y), n, cin, h, wd, g[1], g[2], g[3],
+                                          g[4], g[5], g[6], g[7], g[8], mode, lo, hi, _ptr(in_stat), _ACTS[act] | zflag,
+                                          _ptr(bn_scale), _ptr(bn_shift), _ptr(stat), _ptr(ws), 1 if force_direct else 0,
+                                          _stream(x)))
+    return (y, stat) if want_stat else y

@@ -407,13 +407,16 @@ def test_dense_weight_cache_follows_the_parameter(gpu):
     assert not np.allclose(y0, y1)
 
 
-def test_quantized_conv2d_is_exact_beyond_the_fp32_accumulator_limit(gpu):
-    """nn.Conv2D(quantized=True) on the int8 matrix cores: with 128 input channels, 3x3 filters and
-    saturated codes the integer accumulator reaches 1152 * 255 * 127 = 3.7e7 > 2^24, where an fp32 accumulation (the
-    reference's own `dot`, nn/quantized_conv.py:140-144) is no longer exact.  The block must return in_scale * w_scale
-    times the EXACT integer correlation."""
+@pytest.mark.parametrize("legacy", [False, True], ids=["one-call", "legacy-gemm"])
+def test_quantized_conv2d_is_exact_beyond_the_fp32_accumulator_limit(gpu, legacy, monkeypatch):
+    """nn.Conv2D(quantized=True): with 128 input channels, 3x3 filters and saturated codes the integer
+    accumulator reaches 1152 * 255 * 127 = 3.7e7 > 2^24, where an fp32 accumulation (the reference's own `dot`,
+    nn/quantized_conv.py:140-144) is no longer exact.  The block must return in_scale * w_scale times the EXACT integer
+    correlation - through the one-call entry point (fq_qconv2d_forward; this geometry: the exact direct kernel) and through
+    the round-3 formulation kept behind FQ_QCONV_LEGACY=1 (im2col of the codes + the int8 matrix-core GEMM)."""
     from quantization.mxnet_amd import mx
     from quantization.mxnet_amd.nn import Conv2D
+    from oracle import host as H
     rng = np.random.default_rng(9)
     x = np.full((2, 128, 6, 6), 3.0, np.float32)
     x[:, :, ::2, ::3] = rng.uniform(2.5, 3.0, x[:, :, ::2, ::3].shape).astype(np.float32)
@@ -426,18 +429,23 @@ def test_quantized_conv2d_is_exact_beyond_the_fp32_accumulator_limit(gpu):
     conv.initialize(ctx=gpu)
     conv.weight.set_data(mx.nd.array(w, ctx=gpu))
     from quantization.mxnet_amd import ops
-    seen = []
-    real = ops.gemm_i8_codes
+    monkeypatch.setenv("FQ_QCONV_LEGACY", "1" if legacy else "0")
+    seen, fused = [], []
+    real, real_q = ops.gemm_i8_codes, ops.qconv2d
 
     def spy(*a, **k):
         out = real(*a, **k)
         seen.append(out.detach().cpu().numpy().astype(np.int64))
         return out
-    ops.gemm_i8_codes = spy
+
+    def spy_q(*a, **k):
+        fused.append(1)
+        return real_q(*a, **k)
+    ops.gemm_i8_codes, ops.qconv2d = spy, spy_q
     try:
         y = conv(mx.nd.array(x, ctx=gpu)).asnumpy()
     finally:
-        ops.gemm_i8_codes = real
+        ops.gemm_i8_codes, ops.qconv2d = real, real_q
     in_scale = np.float32(np.float32(3.0 - 0.0) / np.float32(255))
     w_scale = np.float32(np.float32(0.5) / np.float32(127))
     xc = np.round(x / in_scale).astype(np.int64)
@@ -448,10 +456,14 @@ def test_quantized_conv2d_is_exact_beyond_the_fp32_accumulator_limit(gpu):
         for j in range(4):
             want[:, :, i, j] = np.einsum("ncij,ocij->no", xc[:, :, i:i + 3, j:j + 3], wc)
     assert np.abs(want).max() > 2 ** 24
-    assert len(seen) == 1                                            # the block went through the int8 matrix-core GEMM
-    np.testing.assert_array_equal(seen[0].reshape(want.shape), want)  # exact integers
-    # the block's fp32 output cannot carry integers above 2^24 exactly: one rounding of int -> fp32 and one of the product
-    np.testing.assert_allclose(y, want.astype(np.float64) * np.float64(np.float32(in_scale * w_scale)), rtol=2.5e-7)
+    if legacy:
+        assert len(seen) == 1 and not fused                           # the block went through the int8 matrix-core GEMM
+        np.testing.assert_array_equal(seen[0].reshape(want.shape), want)  # exact integers
+    else:
+        assert len(fused) == 1 and not seen
+    # fp32(exact integer) * fp32(in_scale * w_scale): what the oracle's block returns, bit for bit
+    np.testing.assert_array_equal(y, H.qconv2d_forward(x, w, None, (1, 1), (0, 0), 1))
+    np.testing.assert_array_equal(y, (want.astype(np.float32) * np.float32(in_scale * w_scale)).astype(np.float32))
 
 
 @pytest.mark.parametrize("model,offline", [("mobilenet1.0", False), ("resnet50_v1", True)], ids=["mobilenet1.0-online", "resnet50_v1-offline"])
@@ -494,13 +506,16 @@ def test_eval_head_counts_in_the_classifier_launch(gpu, model, offline):
 
 @pytest.mark.parametrize("groups,cin,expect_gemm", [(2, 256, True), (4, 64, False), (32, 32, False)],
                          ids=["2-groups-long-dot", "4-groups-short-dot", "depthwise"])
-def test_quantized_grouped_conv2d_is_exact(gpu, groups, cin, expect_gemm):
+@pytest.mark.parametrize("legacy", [False, True], ids=["one-call", "legacy"])
+def test_quantized_grouped_conv2d_is_exact(gpu, groups, cin, expect_gemm, legacy, monkeypatch):
     """nn.Conv2D(quantized=True, groups > 1) with int8 weights (reference: a Python loop over the groups, nn/quantized_conv.py:
-    129-151): saturated codes; a dot length whose integer accumulator passes 2^24 (128 * 9 = 1152 terms) goes through the int8
-    matrix cores group by group, shorter ones through ONE grouped convolution that is exact in fp32 - the block returns
-    in_scale * w_scale times the EXACT integer correlation either way."""
+    129-151): saturated codes, dot lengths below and beyond the point where an fp32 accumulator stops being exact (128 * 9 =
+    1152 terms pass 2^24) - the block returns in_scale * w_scale times the EXACT integer correlation: through the one-call
+    entry point (grouped 3x3 without padding: the exact direct kernel) and through the round-3 formulation
+    (FQ_QCONV_LEGACY=1: the int8 matrix-core GEMM group by group for long dots, one fp32-exact grouped product otherwise)."""
     from quantization.mxnet_amd import mx, ops
     from quantization.mxnet_amd.nn import Conv2D
+    from oracle import host as H
     rng = np.random.default_rng(groups + cin)
     cout = 2 * groups
     x = np.full((2, cin, 5, 5), 3.0, np.float32)
@@ -513,6 +528,7 @@ def test_quantized_grouped_conv2d_is_exact(gpu, groups, cin, expect_gemm):
                   weight_dtype='int8')
     conv.initialize(ctx=gpu)
     conv.weight.set_data(mx.nd.array(w, ctx=gpu))
+    monkeypatch.setenv("FQ_QCONV_LEGACY", "1" if legacy else "0")
     calls = []
     real = ops.gemm_i8_codes
 
@@ -524,7 +540,10 @@ def test_quantized_grouped_conv2d_is_exact(gpu, groups, cin, expect_gemm):
         y = conv(mx.nd.array(x, ctx=gpu)).asnumpy()
     finally:
         ops.gemm_i8_codes = real
-    assert (len(calls) == groups) if expect_gemm else (len(calls) == 0)
+    if legacy:
+        assert (len(calls) == groups) if expect_gemm else (len(calls) == 0)
+    else:
+        assert not calls
     in_scale = np.float32(np.float32(3.0 - 0.0) / np.float32(255))
     w_scale = np.float32(np.float32(0.5) / np.float32(127))
     xc = np.round(x / in_scale).astype(np.int64)
@@ -537,7 +556,8 @@ def test_quantized_grouped_conv2d_is_exact(gpu, groups, cin, expect_gemm):
                 want[:, g * og:(g + 1) * og, i, j] = np.einsum("ncij,ocij->no", xc[:, g * cg:(g + 1) * cg, i:i + 3, j:j + 3],
                                                                wc[g * og:(g + 1) * og])
     assert (np.abs(want).max() > 2 ** 24) == expect_gemm
-    np.testing.assert_allclose(y, want.astype(np.float64) * np.float64(np.float32(in_scale * w_scale)), rtol=2.5e-7)
+    np.testing.assert_array_equal(y, H.qconv2d_forward(x, w, None, (1, 1), (0, 0), groups))
+    np.testing.assert_array_equal(y, (want.astype(np.float32) * np.float32(in_scale * w_scale)).astype(np.float32))
 
 
 @pytest.mark.parametrize("model,offline", [("mobilenet1.0", False), ("resnet50_v1", True)], ids=["mobilenet1.0-online", "resnet50_v1-offline"])

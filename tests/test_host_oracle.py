@@ -33,7 +33,8 @@ def test_host_library_exports_every_declared_symbol():
     dev = re.sub(r"/\*.*?\*/", "", dev, flags=re.S)
     skip = {"fq_device_info", "fq_profile_enable", "fq_profile_reset", "fq_profile_read", "fq_profile_calibrate",
             "fq_act_workspace_bytes", "fq_pwconv_workspace_bytes", "fq_weight_workspace_bytes",
-            "fq_kl_workspace_bytes", "fq_dense_i8_eval_workspace_bytes",
+            "fq_kl_workspace_bytes", "fq_dense_i8_eval_workspace_bytes", "fq_build_id", "fq_profile_launch_overhead",
+            "fq_qconv_weights_bytes", "fq_qconv_kind", "fq_qconv_workspace_bytes", "fq_qconv_workspace_init",
             # transport, not arithmetic: the RCCL collectives of multi-GPU calibration
             "fq_comm_unique_id", "fq_comm_init", "fq_comm_world", "fq_allreduce_f32", "fq_allreduce_f64",
             "fq_allreduce_i64", "fq_comm_destroy"}
@@ -388,3 +389,53 @@ def test_dense_i8_eval_twin_equals_the_two_oracle_steps():
                        bias=b).reshape(n, units)
     assert np.array_equal(y, want)
     assert np.array_equal(c, O.eval_counters(want, labels, None))
+
+
+QCONV_CASES = [
+    # n, cin, h, w, cout, k, stride, pad, groups
+    (2, 2, 5, 5, 10, (3, 3), (1, 1), (1, 1), 1),
+    (2, 4, 9, 7, 6, (3, 3), (2, 2), (1, 1), 2),
+    (1, 6, 11, 11, 9, (5, 5), (2, 1), (2, 2), 3),
+    (3, 8, 8, 8, 8, (3, 3), (2, 2), (1, 1), 8),
+    (2, 16, 6, 6, 24, (1, 1), (1, 1), (0, 0), 1),
+]
+
+
+@pytest.mark.parametrize("case", QCONV_CASES, ids=[str(c) for c in QCONV_CASES])
+def test_qconv2d_twin_equals_numpy_oracle(golden, case):
+    """fq_qconv_weights_prepare_host + fq_qconv2d_forward_host (the twin of the one-call nn.Conv2D(quantized=True) entry
+    point) against oracle.qconv2d_forward - itself pinned by golden G8, the reference's own block - over input / weight
+    dtypes, bias, integer ReLU, fixed ranges, the producer-statistic range and a folded BatchNorm."""
+    n, cin, h, w_, cout, k, st, pad, groups = case
+    rng = np.random.default_rng(n * 100 + cin + h)
+    x = (rng.standard_normal((n, cin, h, w_)) * 1.5 + 0.4).astype(np.float32)
+    w = (rng.standard_normal((cout, cin // groups) + k) * 0.2).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.5).astype(np.float32)
+    for in_dt in ("uint8", "int8"):
+        for w_dt in ("int8", "uint8"):
+            for bias in (None, b):
+                for act in (None, "relu"):
+                    kw = dict(input_dtype=in_dt, weight_dtype=w_dt, act=act)
+                    np.testing.assert_array_equal(H.qconv2d_forward(x, w, bias, st, pad, groups, **kw),
+                                                  O.qconv2d_forward(x, w, bias, st, pad, groups, **kw))
+    for ir, wr in (((-1.0, 1.0), None), ((0.25, 2.0), (-0.3, 0.3))):
+        np.testing.assert_array_equal(H.qconv2d_forward(x, w, b, st, pad, groups, input_range=ir, weight_range=wr),
+                                      O.qconv2d_forward(x, w, b, st, pad, groups, input_range=ir, weight_range=wr))
+    xr = np.maximum(x, 0)
+    stat = xr.reshape(n, -1).max(axis=1)
+    bsc, bsh = (rng.random(cout) + 0.5).astype(np.float32), (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    for in_dt in (("uint8", "int8") if pad != (0, 0) else ("int8",)):
+        kw = dict(input_dtype=in_dt, act="relu", in_stat=stat, bn_scale=bsc, bn_shift=bsh)
+        got, gstat = H.qconv2d_forward(xr, w, None, st, pad, groups, want_stat=True, **kw)
+        want = O.qconv2d_forward(xr, w, None, st, pad, groups, **kw)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(gstat, np.abs(want).reshape(n, -1).max(axis=1))
+        # the statistic of a non-negative tensor IS its range: same result as taking the range from the tensor
+        np.testing.assert_array_equal(want, O.qconv2d_forward(xr, w, None, st, pad, groups, input_dtype=in_dt, act="relu",
+                                                              bn_scale=bsc, bn_shift=bsh))
+    if case == QCONV_CASES[0]:
+        g = golden("g8_quantized_conv")
+        for use_bias in (0, 1):
+            tag = "conv_b%d_g1" % use_bias
+            y = H.qconv2d_forward(g[tag + "/x"], g[tag + "/w"], g[tag + "/b"] if use_bias else None, (1, 1), (1, 1), 1)
+            np.testing.assert_array_equal(y, g[tag + "/y_int"])
