@@ -69,8 +69,36 @@ KERNEL_NAMES = {
 }
 
 
+def is_qconv_model(model):
+    """`quantized_mobilenet1.0` & co: the net the reference builds from nn.Conv2D(quantized=True) blocks
+    (tests/models/quantized_mobilenet.py) - real int8 convolutions behind the stand-alone block, not simulated quantisation."""
+    return model.startswith("quantized_mobilenet")
+
+
+def build_qconv_net(model, classes, ctx, seed=7, fuse=True):
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.nn import quantized_mobilenet as QM, fuse as qfuse
+    np.random.seed(seed)
+    v2 = model.startswith("quantized_mobilenetv2_")
+    mult = float(model[len("quantized_mobilenetv2_" if v2 else "quantized_mobilenet"):] or 1.0)
+    net = (QM.MobileNetV2 if v2 else QM.MobileNet)(mult, classes=classes)
+    net.initialize(mx.init.Xavier(magnitude=2.0), ctx=ctx)
+    net.collect_quantized_blocks = lambda: [b for b in _blocks_of(net) if getattr(b, "_quantized", False)]
+    if fuse and ctx.device_type == "gpu":
+        qfuse.fuse_inference(net)
+    return net
+
+
+def _blocks_of(net):
+    found = []
+    net.apply(found.append)
+    return found
+
+
 def build_net(model, classes, ctx, seed=7, fuse=True, quant_type="layer", weight_bits=8, input_bits=8, signed=False,
               wino="none", freeze=True):
+    if is_qconv_model(model):
+        return build_qconv_net(model, classes, ctx, seed, fuse)
     from quantization.mxnet_amd.mx.gluon import nn
     from quantization.mxnet_amd.mx.gluon.model_zoo import get_model
     from quantization.mxnet_amd.quantize import convert
@@ -151,7 +179,7 @@ def cpu_baseline(args, classes, hw, budget_s=20.0):
     net = build_net(args.model, classes, mx.cpu(), quant_type=args.quant_type, weight_bits=args.weight_bits,
                     input_bits=args.input_bits, signed=args.input_signed, wino=args.wino, freeze=phase == "eval")
     rng = np.random.default_rng(7)
-    bs, done, t_total = (32 if phase == "eval" else 8), 0, 0.0
+    bs, done, t_total = (32 if phase == "eval" and not is_qconv_model(args.model) else 8), 0, 0.0
     with host_ops():
         if phase == "eval":
             net(mx.nd.array(rng.standard_normal((2, 3, hw, hw)).astype(np.float32)))   # freezes the weights (0 -> 1)
@@ -179,14 +207,17 @@ def cpu_baseline(args, classes, hw, budget_s=20.0):
     out = {"value": round(done / t_total, 3), "unit": "images/sec", "cores": threads, "kind": "port",
            "host_logical_cpus": cores,
            "threads": {"openmp_fake_quant": H.threads(), "torch_conv": torch.get_num_threads()},
-           "sample": "%d images (batches of %d) of the same int8-sim %s %s on the host: fake-quant%s = C++/OpenMP "
-                     "restatement of the reference's arithmetic (oracle/libfq_host.so, %d threads), conv/FC = torch-CPU "
-                     "(%d threads); %.1f s" % (done, bs, args.model,
+           "sample": "%d images (batches of %d) of the same %s %s %s on the host: %s%s = C++/OpenMP "
+                     "restatement of the reference's arithmetic (oracle/libfq_host.so, %d threads), %s = torch-CPU "
+                     "(%d threads); %.1f s" % (done, bs, "real-int8" if is_qconv_model(args.model) else "int8-sim", args.model,
                                                {"eval": "forward", "calib-naive": "naive-EMA calibration step",
                                                 "calib-kl": "KL histogram collection"}[phase],
+                                               "the whole nn.Conv2D(quantized=True) block (range, codes, integer convolution, "
+                                               "dequantise)" if is_qconv_model(args.model) else "fake-quant",
                                                " / histograms" if phase == "calib-kl" else "", H.threads(),
-                                               torch.get_num_threads(), t_total)}
-    if phase != "eval":
+                                               "first conv / BatchNorm / ReLU / FC" if is_qconv_model(args.model)
+                                               else "conv/FC", torch.get_num_threads(), t_total)}
+    if phase != "eval" or is_qconv_model(args.model):
         return out
     # (2) fake-quant only, 27-layer sweep at batch 16, buffers allocated and touched before timing
     n = 16
@@ -331,6 +362,10 @@ def main():
     hw = 32 if args.model.startswith("cifar") else 224
     ctx = mx.gpu(local_rank)
     calib = args.phase != "eval"
+    qconv = is_qconv_model(args.model)
+    if qconv and (calib or args.offline or args.quant_type != "layer" or args.wino != "none"):
+        raise SystemExit("bench.py: %s is built from nn.Conv2D(quantized=True) blocks (per-tensor ranges taken from every "
+                         "batch): evaluation phase only, no calibration / threshold / Winograd options" % args.model)
     if calib and args.offline:
         raise SystemExit("bench.py: --offline describes the evaluation phase; a calibration phase produces the thresholds")
     torch.manual_seed(7 + rank)
@@ -626,6 +661,11 @@ def main():
         flavour = "%s W%dA%d, %s input quant" % ({"layer": "per-layer", "group": "per-group", "channel": "per-channel"}
                                                   [args.quant_type], args.weight_bits, args.input_bits,
                                                   "offline" if args.offline else "online")
+        if qconv:
+            flavour = "nn.Conv2D(quantized=True) blocks: per-tensor uint8 inputs / int8 weights from every batch's own range, " \
+                      "exact int32 sums, %s" % ("BatchNorm + ReLU folded into the stores, ranges from the producers' "
+                                                "statistics (nn/fuse.py)" if not args.no_fuse else "separate BatchNorm / "
+                                                "ReLU blocks, one range pass per layer")
         if args.wino != "none":
             flavour += ", Winograd-domain %s weights" % args.wino
         what_step = {"eval": "eval forward + accuracy counters",
@@ -635,14 +675,17 @@ def main():
                                  "quantised block (collect_feature_maps, ranges fixed by the first batch)"}[args.phase]
         metric_head = {"eval": "images/sec int8-sim", "calib-naive": "images/sec naive-EMA calibration of int8-sim",
                        "calib-kl": "images/sec KL-calibration histogram collection of int8-sim"}[args.phase]
+        if qconv:
+            metric_head = "images/sec real-int8 (reference tests/models/quantized_mobilenet.py)"
         line = {
             "metric": "%s %s (%s)" % (metric_head, "MobileNet1.0" if args.model == "mobilenet1.0" else args.model, flavour),
             "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s ImageNet-shaped (%d,3,%d,%d)/GPU, %s, first conv excluded, %d fake-quantised "
+            "config": {"workload": "%s ImageNet-shaped (%d,3,%d,%d)/GPU, %s, first conv %s, %d %s "
                                    "blocks, %s, %d resident input batches cycled"
-                                   % (args.model, args.batch_size, hw, hw, flavour, nblocks, what_step, rotate),
+                                   % (args.model, args.batch_size, hw, hw, flavour, "in fp32" if qconv else "excluded", nblocks,
+                                      "quantised-convolution" if qconv else "fake-quantised", what_step, rotate),
                        "phase": args.phase,
                        "global_batch": world * args.batch_size, "parallelism": "dp%d (replicated weights, sharded "
                        "batch; %s)" % (world, {"eval": "no data-path collective; counters all-reduced once",

@@ -452,13 +452,16 @@ int fq_dequantize(const int32_t* codes, float* y, int64_t numel, const float* sc
  *   fast kernels (the caller passes force_direct for the others).
  * fq_qconv2d_forward: x (n, cin, h, w) fp32 UNPADDED; w (cout, cin/groups, kh, kw) fp32 (read by the direct form); bias fp32
  *   (cout) or NULL; y (n, cout, ho, wo) fp32 with ho = (h + 2 ph - kh)/sh + 1.  input_mode FQ_CODES_INT8 / UINT8, or
- *   FQ_CODES_RANGE with `_input_range` = [in_min, in_max].  in_stat (may be NULL; n floats): per-sample max of a NON-NEGATIVE
- *   x as a fused producer left it (BatchNorm + ReLU) - the range is then [0, max] without a pass over x (needs padding > 0 or
- *   int8 mode: otherwise the true minimum matters).  act: FQ_ACT_NONE / FQ_ACT_RELU [| FQ_STAT_PREZEROED].  bn_scale /
- *   bn_shift (may be NULL): an inference BatchNorm behind the block folded into the store, y' = y * bn_scale[c] + bn_shift[c]
- *   (separately rounded, as fq_bn_act_stat), then act on y' instead (not for the depthwise form).  stat_out (may be NULL): per-sample
- *   max|y'|.  ws: fq_qconv_workspace_bytes(cout) bytes, 16-byte aligned, initialised ONCE by fq_qconv_workspace_init (every
- *   forward leaves it initialised); not to be shared by forwards that may run concurrently.                                */
+ *   FQ_CODES_RANGE with `_input_range` = [in_min, in_max].  in_stat (may be NULL; n floats): per-sample maxima of a NON-NEGATIVE
+ *   x as a fused producer left them in its epilogue (BatchNorm + ReLU): the range pass over x is skipped - max = their maximum;
+ *   the minimum is 0 by construction with padding, and without padding (uint8) it is found by a scan that stops at the first
+ *   zero (stat[0] < 0 = "the producer's layer was recomputed": one full scan instead).  Results are those of the range pass.
+ *   act: FQ_ACT_NONE / FQ_ACT_RELU [| FQ_STAT_PREZEROED]; FQ_ACT_RELU6 only with a folded BatchNorm.  bn_scale / bn_shift (may
+ *   be NULL): an inference BatchNorm behind the block folded into the store, y' = y * bn_scale[c] + bn_shift[c] (separately
+ *   rounded, as fq_bn_act_stat), the activation then applies to y' (as the separate Activation block would).  stat_out (may
+ *   be NULL): per-sample max|y'|, or stat_out[0] = -1 when the layer went through the exact direct kernel.  ws:
+ *   fq_qconv_workspace_bytes(cout) bytes, 16-byte aligned, initialised ONCE by fq_qconv_workspace_init (every forward leaves
+ *   it initialised); not to be shared by forwards that may run concurrently.                                              */
 size_t fq_qconv_weights_bytes(int64_t cin, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw, int groups);
 /* which kernel family a geometry takes: 0 direct, 1 pointwise (matrix cores), 2 dense 3x3 (matrix cores), 3 depthwise 3x3 */
 int fq_qconv_kind(int64_t cin, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw, int groups);

@@ -1220,11 +1220,8 @@ int fq_qconv2d_forward_host(const float* x, const float* w, const void* wbuf, co
   act &= ~FQ_STAT_PREZEROED;
   const int64_t numel = n * cin * h * wdt;
   float mn = in_min, mx = in_max;
-  if (in_stat != nullptr) {
-    mx = 0.0f;
-    for (int64_t i = 0; i < n; ++i) mx = fmaxf(mx, in_stat[i]);
-    mn = input_mode == FQ_CODES_INT8 ? -mx : 0.0f;
-  } else if (input_mode == FQ_CODES_INT8) {
+  (void)in_stat;      // a producer's per-sample maxima spare the device library its range pass and change no result
+  if (input_mode == FQ_CODES_INT8) {
     float m = 0.0f;
 #pragma omp parallel for reduction(max : m) schedule(static)
     for (int64_t i = 0; i < numel; ++i) m = fmaxf(m, fabsf(x[i]));
@@ -1292,6 +1289,7 @@ int fq_qconv2d_forward_host(const float* x, const float* w, const void* wbuf, co
             out = out * bn_scale[co];
             out = out + bn_shift[co];
             if (act == FQ_ACT_RELU) out = fmaxf(out, 0.0f);
+            if (act == FQ_ACT_RELU6) out = fminf(fmaxf(out, 0.0f), 6.0f);
           }
           y[((s * cout + co) * ho + oh) * wo + ow] = out;
           m = fmaxf(m, fabsf(out));

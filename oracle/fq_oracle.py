@@ -286,17 +286,18 @@ def qconv2d_forward(x, w, b, stride, padding, groups, input_dtype="uint8", weigh
     correlation (the reference's fp32 dot is exact while |acc| < 2^24, :140-144): pad, per-tensor codes of the PADDED
     input and of the weight (`quantize`, or `_quantize` with the fixed `_input_range` / `_weight_range`, :112-120), int32
     bias codes (:122-127), per-group correlation, `act` ("relu") on the integers (:154-155), dequantise (:157-158).
-    Project additions (None in the reference's block): `in_stat` - per-sample maxima of a non-negative input, its range is
-    then [0, max(in_stat)] (int8: [-max, max]); `bn_scale` / `bn_shift` - an inference BatchNorm folded behind the
+    Project additions (None in the reference's block): `in_stat` - per-sample maxima of a non-negative input (checked; the
+    device library then skips its range pass, the result is unchanged); `bn_scale` / `bn_shift` - an inference BatchNorm folded behind the
     dequantisation, multiply and add separately rounded, the activation then applies to that value."""
     x = np.asarray(x, dtype=F32)
     ph, pw = padding
     x = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
     if quantized:
         if in_stat is not None:
-            mx = np.asarray(in_stat, dtype=F32).max().astype(F32) if len(in_stat) else F32(0)
-            mx = np.maximum(mx, F32(0))
-            input_range = (F32(-mx), mx) if input_dtype == "int8" else (F32(0), mx)
+            # the per-sample maxima of a non-negative x as a fused producer left them: they spare the library its range pass
+            # and change no result - the range is the tensor's, as always
+            assert input_range is None and (x >= 0).all() and len(in_stat) == x.shape[0]
+            assert np.array_equal(np.asarray(in_stat, dtype=F32), x.reshape(x.shape[0], -1).max(axis=1))
         xi, in_s = quantize_codes(x, input_dtype, fixed_range=input_range)
         wi, w_s = quantize_codes(w, weight_dtype, fixed_range=weight_range)
         bi = None
@@ -345,6 +346,8 @@ def qconv2d_forward(x, w, b, stride, padding, groups, input_dtype="uint8", weigh
             out = (out + np.asarray(bn_shift, dtype=F32).reshape(1, -1, 1, 1)).astype(F32)
             if act == "relu":
                 out = np.maximum(out, F32(0))
+            elif act == "relu6":
+                out = np.minimum(np.maximum(out, F32(0)), F32(6))
         return out
     out = y.astype(F32)
     return np.maximum(out, F32(0)) if act == "relu" else out

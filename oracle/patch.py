@@ -542,6 +542,17 @@ def _host_fns():
             wq = out
         return (wq, torch.from_numpy(scales)) if want_scales else wq
 
+    def h_qconv2d(x, w, wbuf, bias, strides, padding, groups, ws, input_dtype="uint8", input_range=None, act="none",
+                  in_stat=None, bn_scale=None, bn_shift=None, want_stat=False, force_direct=False, out=None):
+        r = H.qconv2d_forward(_a(x), _a(w), None if bias is None else _a(bias), tuple(strides), tuple(padding), groups,
+                              input_dtype=input_dtype, weight_dtype=wbuf.dtype, input_range=input_range,
+                              weight_range=wbuf.rng, act=None if act == "none" else act,
+                              bn_scale=None if bn_scale is None else _a(bn_scale),
+                              bn_shift=None if bn_shift is None else _a(bn_shift), want_stat=want_stat)
+        if want_stat:
+            return torch.from_numpy(r[0]), torch.from_numpy(r[1])
+        return torch.from_numpy(r)
+
     def h_eval_counters(logits, labels, counters):
         counters.copy_(torch.from_numpy(H.eval_counters(_a(logits), _a(labels), _a(counters))))
         return counters
@@ -564,7 +575,7 @@ def _host_fns():
     return {"global_max": h_global_max, "histogram_accumulate": h_histogram_accumulate, "kl_search": h_kl_search,
             "absmax_per_sample": h_absmax_per_sample, "fake_quant_online": h_fake_quant_online,
             "fake_quant_online_prestat": h_fake_quant_online_prestat, "fake_quant_offline": h_fake_quant_offline,
-            "weight_fake_quant": h_weight_fake_quant, "eval_counters": h_eval_counters}
+            "weight_fake_quant": h_weight_fake_quant, "eval_counters": h_eval_counters, "qconv2d": h_qconv2d}
 
 
 @contextlib.contextmanager

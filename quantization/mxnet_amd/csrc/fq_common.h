@@ -718,15 +718,19 @@ __device__ __forceinline__ float lane_next(float v) {
 // branches into four selects per output); EPI 1 / 2: the fused-inference case - BN, no bias, ReLU / ReLU6 - in 3 / 4
 // instructions.  Same operations in the same order either way.
 constexpr int kEpiRuntime = 0, kEpiBnRelu = 1, kEpiBnRelu6 = 2;
+// bit of the kernels' `act` argument (set by the library's own callers, run-time epilogue only): the per-channel `bias` vector
+// MULTIPLIES the sum instead of being added - the dequantisation factor in_scale * w_scale of nn.Conv2D(quantized=True)'s
+// depthwise layer, applied to the exact integer sum before a folded BatchNorm (its own multiply and add stay separate)
+constexpr int kActBiasMul = 0x10;
 template <int EPI>
 __device__ __forceinline__ float dw_finish(float acc, bool has_bias, float bch, bool has_bn, float bsc, float bsh, int act) {
   if (EPI == kEpiRuntime) {
-    if (has_bias) acc = acc + bch;
+    if (has_bias) acc = (act & kActBiasMul) ? acc * bch : acc + bch;
     if (has_bn) {
       acc = acc * bsc;
       acc = acc + bsh;
     }
-    return act_rt(acc, act);
+    return act_rt(acc, act & 15);
   }
   acc = acc * bsc;
   acc = acc + bsh;

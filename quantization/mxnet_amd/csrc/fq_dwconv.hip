@@ -164,12 +164,12 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_kernel(const floa
         acc = fmaf(w20, c0, acc);
         acc = fmaf(w21, c1, acc);
         acc = fmaf(w22, c2, acc);
-        if (bias != nullptr) acc = acc + bch;
+        if (bias != nullptr) acc = (act & kActBiasMul) ? acc * bch : acc + bch;
         if (has_bn) {
           acc = acc * bsc;
           acc = acc + bsh;
         }
-        acc = act_rt(acc, act);
+        acc = act_rt(acc, act & 15);
         *dst = acc;
         m = fmaxf(m, fabsf(acc));
         dst += g.Wo;
@@ -1255,6 +1255,7 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
 // in_flags bit of the library's own callers: `in_thr` is a range record (fq_common.h: kRangeMode), the weights are integer
 // codes held in fp32 and the quantiser hands on CODES (multiply-back scale 1): the depthwise layer of nn.Conv2D(quantized=True)
 constexpr unsigned kFlagRangeRecord = 0x100u;
+constexpr unsigned kFlagBiasMultiplies = 0x200u;      // `bias` is the per-channel dequantisation factor (kActBiasMul)
 
 static int dwconv3x3_impl(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
                           int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
@@ -1272,6 +1273,7 @@ static int dwconv3x3_impl(const float* x, const float* w, const float* bias, flo
   FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_dwconv3x3: unknown activation %d", act);
   const bool quant = in_stat != nullptr || in_thr != nullptr;
   if (quant) FQ_REQUIRE(in_width >= 2 && in_width <= 16, "fq_dwconv3x3: width %d out of range", in_width);
+  if (in_flags & kFlagBiasMultiplies) act |= kActBiasMul;   // (after the range check; bias != NULL: run-time epilogue)
   static const int epi_on = env_int("FQ_DW_EPI", 1);    // 0: always the run-time epilogue (A/B)
   const int epi = (epi_on && bn_scale != nullptr && bias == nullptr)
                       ? (act == FQ_ACT_RELU ? kEpiBnRelu : act == FQ_ACT_RELU6 ? kEpiBnRelu6 : kEpiRuntime)
@@ -1582,11 +1584,13 @@ static int dwconv3x3_impl(const float* x, const float* w, const float* bias, flo
 
 namespace fqi {
 // depthwise 3x3 of nn.Conv2D(quantized=True): x quantised on load with the range record `rec` (codes, not values, enter the
-// sums), wcodes_f32 = the int8 weight codes as fp32, y = act(sum * svec[c] + zero[c]) with svec = in_scale * w_scale
+// sums), wcodes_f32 = the int8 weight codes as fp32, y = act(sum * svec[c]) with svec = in_scale * w_scale, or - a BatchNorm
+// folded behind the block - y = act((sum * svec[c]) * bn_scale[c] + bn_shift[c]), every step separately rounded
 int dw_range_call(const float* x, const float* wcodes_f32, float* y, int64_t n, int64_t c, int64_t h, int64_t wdt, int stride,
-                  const float* rec, const float* svec, const float* zero, int act, float* stat_out, hipStream_t st) {
-  return dwconv3x3_impl(x, wcodes_f32, nullptr, y, n, c, h, wdt, stride, nullptr, rec, 8, kFlagRangeRecord, nullptr, svec,
-                        zero, act, stat_out, (fqStream_t)st);
+                  const float* rec, const float* svec, const float* bn_scale, const float* bn_shift, int act,
+                  float* stat_out, hipStream_t st) {
+  return dwconv3x3_impl(x, wcodes_f32, svec, y, n, c, h, wdt, stride, nullptr, rec, 8, kFlagRangeRecord | kFlagBiasMultiplies,
+                        nullptr, bn_scale, bn_shift, act, stat_out, (fqStream_t)st);
 }
 }  // namespace fqi
 

@@ -22,7 +22,8 @@ int conv3x3_range_call(const float* x, const int8_t* wcodes, const float* wscale
                        float* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, const float* rec,
                        const float* bn_scale, const float* bn_shift, int act, float* stat_out, hipStream_t st);
 int dw_range_call(const float* x, const float* wcodes_f32, float* y, int64_t n, int64_t c, int64_t h, int64_t wdt, int stride,
-                  const float* rec, const float* svec, const float* zero, int act, float* stat_out, hipStream_t st);
+                  const float* rec, const float* svec, const float* bn_scale, const float* bn_shift, int act,
+                  float* stat_out, hipStream_t st);
 }  // namespace fqi
 
 namespace {
@@ -47,15 +48,56 @@ __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict_
                                                               float fix_max, int kind, const float* __restrict__ wrec,
                                                               const float* __restrict__ bias, int cout,
                                                               float* __restrict__ rec, int* __restrict__ ibias,
-                                                              float* __restrict__ svec, float* __restrict__ zero,
-                                                              const float* __restrict__ stat, int nstat) {
-  __shared__ float sh[2];
+                                                              float* __restrict__ svec,
+                                                              const float* __restrict__ stat, int nstat,
+                                                              const float* __restrict__ x, int64_t numel) {
+  __shared__ float sh[4];
+  __shared__ float rng[2];
+  // A fused producer's per-sample maxima of a NON-NEGATIVE tensor (BatchNorm + ReLU in its epilogue) stand in for the range
+  // pass: max = their maximum, and the minimum is 0 as soon as the tensor holds one zero (half of a ReLU's outputs) - found
+  // by the first strides of a scan that only runs to the end, as a plain minimum, when there is none.  Needed for uint8
+  // without padding only (with padding the zero is there by construction; int8 ranges are [-max, max]).  A producer whose
+  // statistic did not survive (stat[0] < 0: its layer was recomputed by the exact kernel) costs one full scan here.
+  if (stat != nullptr) {
+    float smax = 0.0f;
+    for (int i = threadIdx.x; i < nstat; i += kBlock) smax = fmaxf(smax, stat[i]);
+    smax = block_max(smax, sh);
+    if (threadIdx.x == 0) rng[1] = smax;
+    __syncthreads();
+    const bool stale = stat[0] < 0.0f;
+    const bool want_min = mode == FQ_CODES_UINT8 && !padded;
+    if (threadIdx.x == 0) rng[0] = 0.0f;
+    if (stale || want_min) {
+      float lmin = INFINITY, lmax = 0.0f;
+      for (int64_t base = 0; base < numel; base += kBlock * 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = base + threadIdx.x + (int64_t)u * kBlock;
+          if (i < numel) {
+            const float v = x[i];
+            lmin = fminf(lmin, v);
+            lmax = fmaxf(lmax, v);
+          }
+        }
+        if (!stale && __syncthreads_or(lmin <= 0.0f)) break;            // a zero: the minimum of a non-negative tensor
+      }
+      lmin = block_min(lmin, sh);
+      if (threadIdx.x == 0) rng[0] = lmin;
+      lmax = block_max(lmax, sh);
+      if (threadIdx.x == 0 && stale) rng[1] = lmax;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     float mn, mx;
-    if (stat != nullptr) {                       // a fused producer's per-sample max of a non-negative tensor (BN + ReLU)
-      mx = 0.0f;
-      for (int i = 0; i < nstat; ++i) mx = fmaxf(mx, stat[i]);
-      mn = mode == FQ_CODES_INT8 ? -mx : 0.0f;
+    if (stat != nullptr) {
+      mx = rng[1];
+      if (mode == FQ_CODES_INT8) {
+        mx = fmaxf(mx, -rng[0]);                 // (max|x| when the tensor was scanned; rng[0] is 0 otherwise)
+        mn = -mx;
+      } else {
+        mn = padded ? fminf(rng[0], 0.0f) : rng[0];
+      }
     } else if (mode == FQ_CODES_INT8) {
       mx = mm[1];
       mn = -mx;
@@ -105,7 +147,6 @@ __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict_
       ibias[c] = code;
     }
     if (svec != nullptr) svec[c] = b_scale;
-    if (zero != nullptr) zero[c] = 0.0f;
   }
 }
 
@@ -208,8 +249,11 @@ __global__ __launch_bounds__(kBlock) void qconv_direct_kernel(const float* __res
                                                               QconvShape s, const float* __restrict__ rec,
                                                               const float* __restrict__ wrec, int act, int only_if_flagged,
                                                               const float* __restrict__ bn_scale,
-                                                              const float* __restrict__ bn_shift) {
+                                                              const float* __restrict__ bn_shift,
+                                                              float* __restrict__ stat_out) {
   if (only_if_flagged && !(__float_as_int(rec[kRecFlags]) & kFlagFixup)) return;
+  // this kernel keeps no per-sample statistic: a consumer that was promised one takes its range from the tensor instead
+  if (stat_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stat_out[0] = -1.0f;
   const float xh = rec[kRecHi], xl = rec[kRecLo], xs = rec[kRecScale];
   const float wh = wrec[kRecHi], wl = wrec[kRecLo], wsc = wrec[kRecScale];
   const float deq = xs * wsc;
@@ -244,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void qconv_direct_kernel(const float* __res
     if (bn_scale != nullptr) {                 // a BatchNorm folded behind the block: the activation follows IT
       out = out * bn_scale[co];
       out = out + bn_shift[co];
-      if (act == FQ_ACT_RELU) out = fmaxf(out, 0.0f);
+      out = act_rt(out, act);
     }
     y[idx] = out;
   }
@@ -357,13 +401,13 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
   FQ_REQUIRE(h + 2 * ph >= kh && wdt + 2 * pw >= kw, "fq_qconv2d_forward: kernel larger than the padded input");
   FQ_REQUIRE(input_mode >= FQ_CODES_INT8 && input_mode <= FQ_CODES_RANGE, "unknown out type: %d", input_mode);
   FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_qconv2d_forward: bn_scale and bn_shift go together");
-  FQ_REQUIRE(in_stat == nullptr || input_mode == FQ_CODES_INT8 || (input_mode == FQ_CODES_UINT8 && (ph > 0 || pw > 0)),
-             "fq_qconv2d_forward: in_stat gives the maximum of a non-negative tensor; the uint8 range of an UNPADDED tensor "
-             "needs its true minimum (run the range pass)");
+  FQ_REQUIRE(in_stat == nullptr || input_mode != FQ_CODES_RANGE, "fq_qconv2d_forward: in_stat and a fixed range exclude each "
+             "other");
   const bool prezeroed = (act & FQ_STAT_PREZEROED) != 0;
   act &= ~FQ_STAT_PREZEROED;
-  FQ_REQUIRE(act == FQ_ACT_NONE || act == FQ_ACT_RELU, "fq_qconv2d_forward: activation %d (none or relu: the block applies "
-             "it to the int32 sums)", act);
+  FQ_REQUIRE(act == FQ_ACT_NONE || act == FQ_ACT_RELU || (act == FQ_ACT_RELU6 && bn_scale != nullptr),
+             "fq_qconv2d_forward: activation %d (none or relu: the block applies it to the int32 sums; relu6 only behind a "
+             "folded BatchNorm)", act);
   hipStream_t st = (hipStream_t)stream;
   const WLayout L = wlayout(cin, cout, kh, kw, sh, sw, ph, pw, groups);
   const char* wb = (const char*)wbuf;
@@ -374,7 +418,6 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
   const int64_t cpad = (cout + 63) / 64 * 64;
   int* ibias = (int*)((char*)ws + 256);
   float* svec = (float*)(ibias + cpad);
-  float* zero = svec + cpad;
   QconvShape s;
   s.n = (int)n; s.cin = (int)cin; s.h = (int)h; s.w = (int)wdt; s.cout = (int)cout; s.kh = kh; s.kw = kw; s.sh = sh; s.sw = sw;
   s.ph = ph; s.pw = pw; s.groups = groups;
@@ -384,8 +427,6 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
   const int64_t numel = n * cin * h * wdt, out_numel = n * cout * (int64_t)s.ho * s.wo;
   FQ_REQUIRE(numel < (1ll << 40) && out_numel < (1ll << 40), "fq_qconv2d_forward: tensor too large");
   int kind = force_direct ? kKindDirect : L.kind;
-  // the depthwise forms take one multiplier per channel: a fused BatchNorm would need two (dequantise, then scale)
-  if (kind == kKindDw && bn_scale != nullptr) kind = kKindDirect;
   // ---- 1. the input's range (unless given, or known from the producer's per-sample maxima) ----------------------------
   if (input_mode != FQ_CODES_RANGE && in_stat == nullptr) {
     ProfScope prof(FQ_KERNEL_GLOBAL_MAX, 4.0 * (double)numel, st);
@@ -400,7 +441,7 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
   // ---- 2. record + constants ------------------------------------------------------------------------------------------------
   hipLaunchKernelGGL(qconv_finish_kernel, dim3(1), dim3(kBlock), 0, st, input_mode == FQ_CODES_INT8 ? mm + 2 : mm, input_mode,
                      (ph > 0 || pw > 0) ? 1 : 0, in_min, in_max, kind, wrec, bias, (int)cout, rec, ibias,
-                     kind == kKindDw ? svec : (float*)nullptr, kind == kKindDw ? zero : (float*)nullptr, in_stat, (int)n);
+                     kind == kKindDw ? svec : (float*)nullptr, in_stat, (int)n, x, numel);
   FQ_LAUNCH_CHECK();
   // ---- 3. the convolution ---------------------------------------------------------------------------------------------------
   const int* ib = bias != nullptr ? ibias : nullptr;
@@ -418,22 +459,20 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
       return rc;
     fast = true;
   } else if (kind == kKindDw && bias == nullptr) {
-    if (int rc = dw_range_call(x, (const float*)(wb + L.off_codes), y, n, cin, h, wdt, sh, rec, svec, zero, act | zflag,
-                               stat_out, st))
+    if (int rc = dw_range_call(x, (const float*)(wb + L.off_codes), y, n, cin, h, wdt, sh, rec, svec, bn_scale, bn_shift,
+                               act | zflag, stat_out, st))
       return rc;
     fast = true;
   }
   // ---- 4. the exact direct form: the whole layer, or the conditional fix-up behind a fast kernel ------------------------------
   // (symmetric ranges and [0, max] ranges always fit a byte - L = 0 or codes within +-127 - so no fix-up can be asked for; the
   // per-sample statistic of the output is only offered there, where the fast kernel's result is final)
-  const bool representable = input_mode == FQ_CODES_INT8 || in_stat != nullptr;
-  FQ_REQUIRE(stat_out == nullptr || (fast && representable), "fq_qconv2d_forward: the per-sample statistic is produced by the "
-             "fused forms for int8 inputs or ranges taken from in_stat");
+  const bool representable = input_mode == FQ_CODES_INT8 || (in_stat != nullptr && (ph > 0 || pw > 0));
   if (fast && representable) return FQ_OK;
   const int64_t want = (out_numel + kBlock - 1) / kBlock;
   const int grid = (int)(want < (int64_t)num_cu() * 16 ? want : (int64_t)num_cu() * 16);
   hipLaunchKernelGGL(qconv_direct_kernel, dim3(grid), dim3(kBlock), 0, st, x, w, ib, y, s, (const float*)rec, wrec, act,
-                     fast ? 1 : 0, bn_scale, bn_shift);
+                     fast ? 1 : 0, bn_scale, bn_shift, stat_out);
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }

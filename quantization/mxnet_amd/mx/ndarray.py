@@ -63,7 +63,9 @@ class NDArray(object):
     # consuming fake-quant can skip its statistic pass.  Never set by the generic ops.
     # _fq_c16: optional ops.Codes16 — `_t` then holds the int8 codes a fused producer handed to its single fused consumer
     # (offline input quantisation; quantize/convert/convert_conv2d.handover_target).  Never set by the generic ops.
-    __slots__ = ("_t", "_fq_stat", "_fq_c16")
+    # _fq_nonneg: only meaningful beside a `_fq_stat`: the producer applied ReLU / ReLU6, so the tensor is non-negative and the
+    # statistic is its per-sample maximum (what nn.Conv2D(quantized=True) needs to skip its range pass, nn/fuse.py).
+    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg")
     __array_priority__ = 1000.0
     __array_ufunc__ = None
 
@@ -72,6 +74,7 @@ class NDArray(object):
         self._t = t
         self._fq_stat = None
         self._fq_c16 = None
+        self._fq_nonneg = False
 
     # -- plumbing ---------------------------------------------------------------------------
     @property

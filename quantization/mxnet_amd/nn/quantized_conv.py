@@ -113,14 +113,35 @@ class Conv2D(nn.HybridBlock):
         b = None if bias is None else bias._t.contiguous()
         # (uint8 / fixed-range weights are not on one symmetric int8 grid: the exact direct kernel takes them)
         direct = self._weight_dtype != 'int8' or self._weight_range is not None
+        fz = self.__dict__.get("_fq_qfuse")            # nn/fuse.py: BatchNorm [+ ReLU] behind this block folded into the store
+        kw = {}
+        if fz is not None:
+            scale, shift = fz["constants"]()
+            kw = dict(bn_scale=scale, bn_shift=shift, want_stat=True)
+        act = "none" if self.act is None else "relu"
+        if fz is not None:
+            act = fz["act"]
+        in_stat = None
+        if self._input_range is None and x is inputs._t and inputs._fq_stat is not None and inputs._fq_nonneg:
+            from . import fuse as _qfuse
+            if _qfuse.use_producer_stat() and inputs._fq_stat.numel() == x.shape[0]:
+                in_stat = inputs._fq_stat               # the producer's per-sample maxima: no range pass
         y = ops.qconv2d(x, w, self._prepared_weights(w), b, self._strides, self._padding, self._groups,
                         self._workspace(x.device), input_dtype=self._input_dtype, input_range=self._input_range,
-                        act="none" if self.act is None else "relu", force_direct=direct)
-        return NDArray(y)
+                        act=act, force_direct=direct, in_stat=in_stat, **kw)
+        if fz is None:
+            return NDArray(y)
+        out = NDArray(y[0])
+        out._fq_stat = y[1]
+        out._fq_nonneg = act in ("relu", "relu6")
+        return out
 
     def hybrid_forward(self, F, inputs, weight, bias=None):
         if self._fused_ok():
             return self._forward_fused(inputs, weight, bias)
+        if not self._quantized and self.__dict__.get("_fq_qfuse") is not None:
+            from . import fuse as _qfuse
+            return _qfuse.stem_forward(self, inputs, weight)
         # Pad (:108-109)
         ph, pw = self._padding
         x = TF.pad(inputs._t, (pw, pw, ph, ph), mode="constant", value=0.0).contiguous()

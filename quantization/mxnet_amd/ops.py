@@ -1074,8 +1074,9 @@ def qconv2d(x, w, wbuf, bias, strides, padding, groups, ws, input_dtype="uint8",
         raise ValueError("x must be (n, cin, h, w) and weight (cout, cin / groups, kh, kw)")
     if input_range is None and input_dtype not in ("int8", "uint8"):
         raise ValueError("unknown out type: %s" % (input_dtype,))
-    if act not in ("none", "relu"):
-        raise ValueError("activation %r: the block applies its activation to the int32 sums (none or relu)" % (act,))
+    if act not in ("none", "relu") and not (act == "relu6" and bn_scale is not None):
+        raise ValueError("activation %r: the block applies its activation to the int32 sums (none or relu; relu6 only behind "
+                         "a folded BatchNorm)" % (act,))
     g = _geom(w.shape, strides, padding, groups)
     n, cin, h, wd = (int(v) for v in x.shape)
     if cin != g[0]:

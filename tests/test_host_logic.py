@@ -422,3 +422,33 @@ def test_weight_fake_quant_is_reused_until_the_parameter_changes():
             assert len(calls) == 7
         finally:
             ops.weight_fake_quant = real
+
+
+def test_quantized_mobilenet_and_its_producer_fusion_on_the_oracle():
+    """nn/quantized_mobilenet.py (the reference's tests/models/quantized_mobilenet.py) + nn/fuse.py with the oracle standing in
+    for the library: 26 quantised convolutions; fused, every one takes BatchNorm + ReLU into its store and its range from the
+    producer's statistic (the oracle checks that statistic against the tensor); `unfuse` restores the blocks."""
+    from quantization.mxnet_amd import ops
+    from quantization.mxnet_amd.nn import quantized_mobilenet as QM, fuse as qfuse
+    np.random.seed(5)
+    net = QM.MobileNet(1.0, classes=10)
+    net.initialize(mx.init.Xavier(magnitude=2.0))
+    x = mx.nd.array(np.random.default_rng(1).standard_normal((2, 3, 32, 32)).astype(np.float32))
+    with oracle_ops():
+        plain = net(x).asnumpy()
+        assert qfuse.fuse_inference(net) == 27
+        seen = []
+        real = ops.qconv2d
+
+        def spy(*a, **k):
+            seen.append((k.get("in_stat") is not None, k.get("bn_scale") is not None, k.get("act")))
+            return real(*a, **k)
+        ops.qconv2d = spy
+        try:
+            fused = net(x).asnumpy()
+        finally:
+            ops.qconv2d = real
+        assert len(seen) == 26 and all(s == (True, True, "relu") for s in seen)
+        assert np.isfinite(fused).all() and np.abs(fused - plain).max() <= 0.1 * np.abs(plain).max() + 1e-3
+        qfuse.unfuse(net)
+        np.testing.assert_array_equal(net(x).asnumpy(), plain)
