@@ -625,12 +625,11 @@ def main():
         for key, rec in prof.items():
             if not rec["launches"]:
                 continue
-            # `frac` / `achieved` / `avg_launch_us`: HIP-event time of the family's launches minus, per launch, what an event
-            # pair measures BEYOND a kernel's own begin -> end time (dispatch in front of the first wave, the marker behind
-            # the last one) - measured now, on this device, with a kernel that times itself on the wall clock
-            # (fq_profile_launch_overhead).  That is the duration rocprofv3's kernel tables report, and
-            # tools/check_events_vs_rocprof.py holds the two against each other (3 %).  The raw event figures are kept beside
-            # them (`*_raw_events`).  (Round 3 removed pair(null kernel) - back-to-back(null kernel), ~4.6 us: too much.)
+            # `frac` / `achieved` / `avg_launch_us`: HIP-event time of the family's launches minus, per launch, what bracketing
+            # a launch with an event pair adds to its cost inside a stream of back-to-back launches - measured now, on this
+            # device, on a 30 us kernel (fq_profile_launch_overhead; the round-3 figure, pair - null kernel ~ 4.6 us,
+            # over-corrected).  tools/check_events_vs_rocprof.py holds the result against rocprofv3's kernel table (3 %); the
+            # raw event figures are kept beside them (`*_raw_events`).
             ms_raw = max(rec["ms"], 1e-9)
             ms_k = max(rec["ms"] - launch_overhead_ms * rec["launches"], 1e-9)
             gbs = rec["bytes"] / (ms_k * 1e-3) / 1e9
@@ -715,10 +714,8 @@ def main():
                                               "batch (compare with a rocprofv3 table of --streams 1 --graph 0)"
                                               if n_streams > 1 or graphs is not None else ""),
                          "launch_overhead_us_removed": round(launch_overhead_ms * 1e3, 3),
-                         "launch_overhead_what": "median over 200 launches of a %.1f us kernel, each bracketed by an event "
-                                                 "pair AND carrying its own start / stop events (hipExtLaunchKernelGGL: the "
-                                                 "dispatch's begin -> end timestamps, what rocprofv3 reports): pair time - "
-                                                 "dispatch time" % (spin_ms * 1e3),
+                         "launch_overhead_what": "a %.1f us one-wavefront kernel, 200 launches: median event-pair time of the "
+                                                 "bracketed launches - (the same launches inside ONE pair) / 200" % (spin_ms * 1e3),
                          "event_pair_minus_null_kernel_us": round(ev_overhead_ms * 1e3, 3),
                          "null_kernel_us_measured": round(null_kernel_ms * 1e3, 3),
                          "whole_step": {"algorithmic_bytes_per_step": round(step_bytes, 1), "achieved": round(whole, 1),

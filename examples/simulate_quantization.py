@@ -97,6 +97,10 @@ EXTRA_FLAGS = [
                                           'instead of image by image on the host, so the reported speed is the '
                                           'network\'s, not the data pipeline\'s; sample values differ from the host '
                                           'pipeline\'s (both are random)')),
+    (['--synthetic-resident'], dict(type=int, default=8,
+                                    help='(with --synthetic-on-device) distinct synthetic batches kept on the device and cycled '
+                                         '(default 8; 0: draw every batch anew - 19 M normals per ImageNet-shaped batch, a tenth '
+                                         'of a MobileNet step)')),
     (['--export-scale-table'], dict(type=str, default=None,
                                     help='after calibration write an ncnn-style int8 scale table (per-channel weight scales '
                                          'after BN folding, one input scale per layer; quantize/freeze/scale_table.py)')),
@@ -105,6 +109,11 @@ EXTRA_FLAGS = [
                                    'per-forward device state per stream): the ramp and the tail of one batch\'s kernels fill '
                                    'with the next batch\'s work; results are those of one batch at a time.  Calibration passes '
                                    '(update_ema) always run one batch at a time.  (default: 3)')),
+    (['--eval-graph'], dict(type=int, default=1,
+                            help='1 (default): evaluation of a fused net replays a hipGraph of the step per lane (static input / '
+                                 'label buffers the batches are copied into; the first batch of a lane and a ragged last batch '
+                                 'launch eagerly) - the host no longer has to launch every kernel of every batch; 0: every batch '
+                                 'launched from Python.  Same kernels on the same data either way')),
     (['--strict-global-batch'], dict(action='store_true',
                                      help='(multi-GPU naive calibration) reproduce ONE device that sees the global batch bit '
                                           'for bit: one small all-gather per quantised layer per forward instead of the '
@@ -169,24 +178,38 @@ class UniformSampler(Sampler):
 class DeviceSyntheticLoader(object):
     """Stand-in for DataLoader over the synthetic datasets: N(0,1) "normalised images" and uniform labels generated on
     the device, one generator seed per batch index (so every rank count / batch size sees a well-defined sequence);
-    batches are strided across ranks like the real loader's."""
+    batches are strided across ranks like the real loader's.  `resident` > 0: only that many DISTINCT full batches exist
+    (index i shows batch i % resident; generated once, kept on the device) - drawing 19 M normals per batch costs the GPU
+    a tenth of a MobileNet step, and the point of this loader is to report the network's speed, not a generator's; the
+    ragged last batch is always generated."""
 
-    def __init__(self, n_images, batch_size, shape, classes, ctx, seed, rank=0, world_size=1):
+    def __init__(self, n_images, batch_size, shape, classes, ctx, seed, rank=0, world_size=1, resident=0):
         self._n, self._b, self._shape, self._classes = int(n_images), int(batch_size), tuple(shape), int(classes)
         self._dev, self._seed = ctx.torch_device, int(seed)
         self.total_batches = (self._n + self._b - 1) // self._b
         self._mine = range(int(rank), self.total_batches, int(world_size))
+        self._resident, self._kept = int(resident), {}
 
     def __len__(self):
         return len(self._mine)
+
+    def _make(self, g, i, b):
+        g.manual_seed(self._seed * 1000003 + i)
+        X = torch.randn((b,) + self._shape, device=self._dev, generator=g)
+        y = torch.randint(0, self._classes, (b,), device=self._dev, generator=g).float()
+        return X, y
 
     def __iter__(self):
         g = torch.Generator(device=self._dev)
         for i in self._mine:
             b = min(self._b, self._n - i * self._b)
-            g.manual_seed(self._seed * 1000003 + i)
-            X = torch.randn((b,) + self._shape, device=self._dev, generator=g)
-            y = torch.randint(0, self._classes, (b,), device=self._dev, generator=g).float()
+            if self._resident > 0 and b == self._b:
+                k = i % self._resident
+                if k not in self._kept:
+                    self._kept[k] = self._make(g, k, b)
+                X, y = self._kept[k]
+            else:
+                X, y = self._make(g, i, b)
             yield mx.nd.NDArray(X), mx.nd.NDArray(y)
 
 
@@ -198,45 +221,104 @@ def _total_batches(loader):
 
 
 # ---- evaluation ------------------------------------------------------------------------------------------------------------
-def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval", streams=1):
+class _Lane(object):
+    """One evaluation batch in flight: a HIP stream, and - once the lane has run a forward eagerly - a hipGraph of the step
+    (forward + the evaluation counters) over STATIC input / label buffers the loader's batches are copied into, replayed for
+    every later batch of the same shape.  Launching the ~30-100 kernels of a fused step from Python takes the host as long as
+    the GPU needs to run them (bench.py measures it); a replay is one call."""
+
+    def __init__(self, dev, stream):
+        self.dev, self.stream = dev, stream
+        self.x = self.y = self.graph = None
+        self.eager_done = 0
+
+    def ready_for(self, x):
+        return self.graph is not None and tuple(self.x.shape) == tuple(x.shape)
+
+    def capture(self, x, y, step):
+        self.x, self.y = torch.empty_like(x), torch.empty_like(y)
+        self.x.copy_(x)
+        self.y.copy_(y)
+        g = torch.cuda.CUDAGraph()
+        try:
+            if self.stream is None:
+                with torch.cuda.graph(g):
+                    step(self.x, self.y)
+            else:
+                with torch.cuda.graph(g, stream=self.stream):
+                    step(self.x, self.y)
+        except Exception as e:                       # capture is an optimisation: stay with eager launches, and say so once
+            self.graph = False
+            torch.cuda.synchronize(self.dev)
+            print("[eval] hipGraph capture failed (%s: %s): evaluation launches eagerly" % (type(e).__name__, str(e)[:120]))
+            return False
+        self.graph = g
+        return True
+
+
+def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval", streams=1, graph=False):
     """One pass over `dataloader`: top-1 accuracy and class-averaged accuracy (the quantities of the reference's
     `evaluate`, :122-148).  The counters [n_correct, total, correct[c], label[c]] live on the device (fq_eval_counters; in
     the classifier's own launch when the net is fused: quantize.fuse.EvalHead) and cross the ranks in one all-reduce; with
-    `update_ema` every batch is a calibration step.  `streams` > 1 (evaluation only): that many batches in flight."""
+    `update_ema` every batch is a calibration step.  `streams` > 1 (evaluation only): that many batches in flight.  `graph`
+    (evaluation of a fused net only): each lane replays a hipGraph of its step over static buffers the batches are copied
+    into (the first batch of a lane and batches of another shape - the ragged last one - launch eagerly); same kernels on
+    the same data, so the same counters."""
     from quantization.mxnet_amd.quantize import fuse as _fuse
     dev = ctx.torch_device
     counters = torch.zeros(2 + 2 * num_class, dtype=torch.float32, device=dev)
     seen, started = 0, time.perf_counter()
-    steps = fqdist.calibration_steps(_total_batches(dataloader)) if update_ema and fqdist.world_size() > 1 else None
+    steps = fqdist.calibration_steps(_total_batches(dataloader)) if update_ema and fqdist.group_is_live() else None
     done = 0
-    lanes = [torch.cuda.Stream(dev) for _ in range(streams)] if streams > 1 and not update_ema and dev.type == "cuda" else None
-    head = _fuse.eval_head(net, counters) if dev.type == "cuda" else None
+    on_gpu = dev.type == "cuda"
+    n_lanes = streams if streams > 1 and not update_ema and on_gpu else 1
+    lanes = [_Lane(dev, torch.cuda.Stream(dev) if n_lanes > 1 else None) for _ in range(n_lanes)] if on_gpu else None
+    graph = bool(graph) and on_gpu and not update_ema and hasattr(net, "_fq_arena_hooks")
+    head = _fuse.eval_head(net, counters) if on_gpu else None
+    replayed = 0
+
+    def step(xt, labels):
+        """forward + counters of one batch on the current stream"""
+        if head is not None:
+            head.labels = labels
+        logits = net(mx.nd.NDArray(xt))
+        if update_ema:
+            net.update_ema()
+        if head is None or not head.take():
+            ops.eval_counters(logits._t, labels, counters)
+
     try:
         with tqdm(total=len(dataloader), desc=tqdm_desc, disable=fqdist.rank() != 0) as bar:
             for X, y in dataloader:
-                lane = lanes[done % len(lanes)] if lanes else None
-                if lane is not None:
+                lane = lanes[done % n_lanes] if lanes else None
+                side = lane.stream if lane is not None else None
+                if side is not None:
                     # the lanes are non-blocking streams: what the default stream has issued so far - the calibrated thresholds,
                     # this batch if the loader made it on the device - must be complete before the lane reads it, and the
                     # batch's memory must not go back to the default stream's pool while the lane still reads it
-                    lane.wait_stream(torch.cuda.current_stream(dev))
+                    side.wait_stream(torch.cuda.current_stream(dev))
                     for t in (X._t, y._t):
                         if t.is_cuda:
-                            t.record_stream(lane)
-                with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()), \
-                        (ops.batches_in_flight() if lane is not None else contextlib.nullcontext()):
+                            t.record_stream(side)
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), \
+                        (ops.batches_in_flight() if side is not None else contextlib.nullcontext()):
                     labels = y.as_in_context(ctx)._t.long()
-                    if head is not None:
-                        head.labels = labels
-                    logits = net(X.as_in_context(ctx))
-                    if update_ema:
-                        net.update_ema()
-                    if head is None or not head.take():
-                        ops.eval_counters(logits._t, labels, counters)
+                    xt = X.as_in_context(ctx)._t
+                    if graph and lane.graph is not False and lane.eager_done > 0 and done >= n_lanes and \
+                            (lane.ready_for(xt) or (lane.graph is None and lane.capture(xt, labels, step))):
+                        lane.x.copy_(xt, non_blocking=True)
+                        lane.y.copy_(labels, non_blocking=True)
+                        lane.graph.replay()
+                        replayed += 1
+                    else:
+                        step(xt, labels)
+                        lane_done = lane is not None
+                        if lane_done:
+                            lane.eager_done += 1
                 seen += int(labels.numel())
                 done += 1
                 bar.update(1)
-                if lanes and done == 1:
+                if n_lanes > 1 and done == 1:
                     # what the first forward creates once - frozen weights, weight codes, folded BatchNorm constants - is read
                     # by the forwards on the other streams: wait for it
                     torch.cuda.synchronize(dev)
@@ -246,23 +328,28 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
     while steps is not None and done < steps:          # this rank's shard ran out first: keep the collectives in step
         fqdist.empty_calibration_step(net)
         done += 1
-    if dev.type == "cuda":
+    if on_gpu:
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - started
     fqdist.allreduce_eval_counters(counters)
     c = counters.cpu().numpy()
     evaluate.last_images_per_sec = seen * fqdist.world_size() / max(elapsed, 1e-9)
+    evaluate.last_replayed = replayed
     per_class = c[2:2 + num_class] / (c[2 + num_class:] + 1e-10)
     return float(c[0] / max(c[1], 1.0)), float(per_class.mean())
 
 
 evaluate.last_images_per_sec = 0.0
+evaluate.last_replayed = 0
 
 
 # ---- the program -----------------------------------------------------------------------------------------------------------
 class Simulation(object):
     def __init__(self, opt, ctx, rank=0, world=1):
         self.opt, self.ctx, self.rank, self.world = opt, ctx, rank, world
+        # the calibration collectives are attached whenever a process group exists - with several ranks, or with ONE rank of
+        # a forced group (FQ_DIST_FORCE_GROUP=1: how the RCCL branch is exercised end to end on a one-GPU box)
+        self.collective = world > 1 or fqdist.group_is_live()
         self.chief = rank == 0
         self.classes = 10 if opt.dataset == 'cifar10' else 1000
         self.signed = opt.input_signed == 'true'
@@ -334,7 +421,7 @@ class Simulation(object):
         if opt.synthetic_on_device:
             side = 224 if opt.dataset == 'imagenet' else 32
             self.eval_loader = DeviceSyntheticLoader(len(eval_set), opt.batch_size, (3, side, side), self.classes,
-                                                     self.ctx, 7, **shard)
+                                                     self.ctx, 7, resident=opt.synthetic_resident, **shard)
             if needs_calibration_data:
                 self.train_loader = DeviceSyntheticLoader(self.classes * opt.num_sample, opt.batch_size,
                                                           (3, side, side), self.classes, self.ctx, 11, **shard)
@@ -361,7 +448,7 @@ class Simulation(object):
         levels = 2 ** (opt.input_bits_width - 1 if self.signed else opt.input_bits_width)
         bins = 2048
         hists, ranges = collect_feature_maps(net, bins=bins, loader=self.train_loader, ctx=self.ctx,
-                                             sync=fqdist.kl_sync if self.world > 1 else None)
+                                             sync=fqdist.kl_sync if self.collective else None)
         blocks = net.collect_quantized_blocks()
         best = kl_calibrate_many([hists[b] for b in blocks], levels=levels, min_bins=levels, bins=bins,
                                  device=self.ctx.torch_device)
@@ -381,23 +468,24 @@ class Simulation(object):
         title = ' Naive Calibration '
         if self.chief:
             print('*' * 25 + title + '*' * 25)
-        if self.world > 1:
+        if self.collective:
             fqdist.attach_calibration_sync(net, opt.batch_size, strict=opt.strict_global_batch)
         for epoch in range(1, opt.calib_epoch + 1):
             net.quantize_input(enable=True, online=True)      # integer inputs and weights, ranges from the current batch
             evaluate(net, self.classes, self.train_loader, ctx=self.ctx, update_ema=True,
                      tqdm_desc="Calib[{}/{}]".format(epoch, opt.calib_epoch))
             if opt.eval_per_calib:
-                if self.world > 1:
+                if self.collective:
                     fqdist.detach_calibration_sync(net)       # offline evaluation exchanges nothing per batch
                 net.quantize_input(enable=True, online=False)
                 self.report(*evaluate(net, self.classes, self.eval_loader, ctx=self.ctx,
-                                      tqdm_desc="Eval[{}/{}]".format(epoch, opt.calib_epoch), streams=opt.eval_streams))
+                                      tqdm_desc="Eval[{}/{}]".format(epoch, opt.calib_epoch), streams=opt.eval_streams,
+                                      graph=opt.eval_graph))
                 if self.chief:
                     print()
-                if self.world > 1 and epoch < opt.calib_epoch:
+                if self.collective and epoch < opt.calib_epoch:
                     fqdist.attach_calibration_sync(net, opt.batch_size, strict=opt.strict_global_batch)
-        if self.world > 1:
+        if self.collective:
             fqdist.detach_calibration_sync(net)
         if self.chief:
             for blk in net.collect_quantized_blocks():
@@ -416,7 +504,8 @@ class Simulation(object):
     def final_evaluation(self, online):
         self.net.fix_params()
         self.net.quantize_input(enable=True, online=online)
-        acc, avg_acc = evaluate(self.net, self.classes, self.eval_loader, ctx=self.ctx, streams=self.opt.eval_streams)
+        acc, avg_acc = evaluate(self.net, self.classes, self.eval_loader, ctx=self.ctx, streams=self.opt.eval_streams,
+                                graph=self.opt.eval_graph)
         if self.chief:
             print('*' * 25 + ' Result ' + '*' * 25)
         self.report(acc, avg_acc)

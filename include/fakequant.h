@@ -81,12 +81,12 @@ int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* 
  *                     what the kernel itself (dispatch included) costs when nothing brackets it.
  * pair_ms - null_kernel_ms is what bench.py removes from every bracketed launch.  `scratch`: >= 4 device bytes.          */
 int fq_profile_calibrate(void* scratch, int repeats, double* pair_ms, double* null_kernel_ms, fqStream_t stream);
-/* What an event pair measures BEYOND a kernel's own begin -> end time (dispatch in front of the first wave, the marker behind
- * the last): a one-wavefront kernel spinning `spin_us` on the wall clock is launched `repeats` times in a busy queue, each
- * launch bracketed by an ordinary event pair AND given its own start / stop events (hipExtLaunchKernelGGL: the dispatch
- * packet's begin / end timestamps, what rocprofv3's kernel tables are made of);  overhead_ms <- median of (pair elapsed -
- * dispatch begin -> end), spin_ms <- the kernel's own median clock distance.  Raw event time minus overhead_ms per launch is
- * the figure rocprofv3 shows (tools/check_events_vs_rocprof.py).  Synchronises.  scratch: repeats * 16 device bytes.       */
+/* What bracketing a launch with an event pair adds to what the launch costs inside a stream of back-to-back launches, measured
+ * on a kernel long enough (a one-wavefront spin of `spin_us` on the wall clock) that dispatch cannot hide behind it as it does
+ * behind fq_profile_calibrate's one-element kernel:  overhead_ms <- median pair time of `repeats` bracketed launches - (the
+ * same launches inside ONE pair) / repeats;  spin_ms <- the kernel's own median clock distance.  bench.py removes overhead_ms
+ * per launch from the raw event time; tools/check_events_vs_rocprof.py holds the result against rocprofv3's kernel table.
+ * Synchronises.  scratch: repeats * 16 device bytes.                                                                       */
 int fq_profile_launch_overhead(void* scratch, int repeats, double spin_us, double* overhead_ms, double* spin_ms,
                                fqStream_t stream);
 

@@ -1,7 +1,6 @@
 // libfakequant — errors, event timing, device info, streaming policy
 // (see fq_common.h for the list of translation units and the design rules)
 #include "fq_common.h"
-#include <hip/hip_ext.h>
 
 namespace fqi {
 
@@ -187,14 +186,13 @@ int fq_profile_calibrate(void* scratch, int repeats, double* pair_ms, double* nu
   return FQ_OK;
 }
 
-// What an event pair measures beyond the kernel's own begin -> end time (command-processor dispatch in front of the first
-// wave, the end-of-pipe marker behind the last one).  A one-wavefront kernel that spins `spin_us` on the wall clock is
-// launched `repeats` times, back to back in a busy queue, each launch BOTH bracketed by an ordinary event pair (what
-// ProfScope does) AND given its own start / stop events through hipExtLaunchKernelGGL - those carry the dispatch packet's
-// begin / end timestamps, the very figures rocprofv3's kernel tables are made of;
-//   overhead_ms <- median over the repeats of (event-pair elapsed time - dispatch begin -> end time).
-// tools/check_events_vs_rocprof.py holds (raw event time - this) against rocprofv3's table.  Synchronises.
-// scratch: repeats * 16 bytes (the kernel also stores its own first and last clock reading: spin_ms is their median distance).
+// What bracketing a launch with an event pair adds to what the launch costs inside a stream of back-to-back launches -
+// measured on a kernel LONG enough that dispatch cannot hide behind it the way it does behind a one-element kernel
+// (fq_profile_calibrate's pair - null figure, ~4.6 us, over-corrects 30 us kernels by ~2 us: profiles/r4_events_vs_rocprof.txt).
+// A one-wavefront kernel spins `spin_us` on the constant-rate wall clock; (a) `repeats` launches, each bracketed, enqueued back
+// to back: median pair time P; (b) the same launches inside ONE pair: B / repeats;  overhead_ms <- P - B / repeats.
+// (raw event time - overhead per launch) is held against rocprofv3's kernel table by tools/check_events_vs_rocprof.py.
+// spin_ms <- the kernel's own median first-to-last clock distance.  Synchronises.  scratch: repeats * 16 bytes.
 int fq_profile_launch_overhead(void* scratch, int repeats, double spin_us, double* overhead_ms, double* spin_ms,
                                fqStream_t stream) {
   FQ_REQUIRE(scratch && overhead_ms && spin_ms && repeats > 0 && repeats <= 4096 && spin_us > 0 && spin_us < 1e5,
@@ -205,30 +203,34 @@ int fq_profile_launch_overhead(void* scratch, int repeats, double spin_us, doubl
   FQ_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
   FQ_REQUIRE(khz > 0, "fq_profile_launch_overhead: the device reports no wall clock rate");
   const unsigned long long ticks = (unsigned long long)(spin_us * 1e-3 * khz);
-  std::vector<hipEvent_t> ev((size_t)repeats * 4);
+  std::vector<hipEvent_t> ev((size_t)repeats * 2 + 2);
   for (auto& e : ev) FQ_HIP(hipEventCreate(&e));
   unsigned long long* t = (unsigned long long*)scratch;
   for (int i = 0; i < repeats; ++i) {
-    FQ_HIP(hipEventRecord(ev[4 * i], st));
-    hipExtLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, ev[4 * i + 2], ev[4 * i + 3], 0, t + 2 * i, ticks);
-    FQ_HIP(hipEventRecord(ev[4 * i + 1], st));
+    FQ_HIP(hipEventRecord(ev[2 * i], st));
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, t + 2 * i, ticks);
+    FQ_HIP(hipEventRecord(ev[2 * i + 1], st));
   }
+  FQ_HIP(hipEventRecord(ev[2 * repeats], st));
+  for (int i = 0; i < repeats; ++i) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, t + 2 * i, ticks);
+  FQ_HIP(hipEventRecord(ev[2 * repeats + 1], st));
   FQ_LAUNCH_CHECK();
   FQ_HIP(hipStreamSynchronize(st));
   std::vector<unsigned long long> host((size_t)repeats * 2);
   FQ_HIP(hipMemcpy(host.data(), t, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  std::vector<double> over, own;
+  std::vector<double> pair, own;
   for (int i = 0; i < repeats; ++i) {
-    float pair = 0.f, disp = 0.f;
-    FQ_HIP(hipEventElapsedTime(&pair, ev[4 * i], ev[4 * i + 1]));
-    FQ_HIP(hipEventElapsedTime(&disp, ev[4 * i + 2], ev[4 * i + 3]));
-    over.push_back((double)pair - (double)disp);
+    float el = 0.f;
+    FQ_HIP(hipEventElapsedTime(&el, ev[2 * i], ev[2 * i + 1]));
+    pair.push_back((double)el);
     own.push_back((double)(host[2 * i + 1] - host[2 * i]) / (double)khz);
   }
+  float all = 0.f;
+  FQ_HIP(hipEventElapsedTime(&all, ev[2 * repeats], ev[2 * repeats + 1]));
   for (auto& e : ev) (void)hipEventDestroy(e);
-  std::sort(over.begin(), over.end());
+  std::sort(pair.begin(), pair.end());
   std::sort(own.begin(), own.end());
-  *overhead_ms = over[over.size() / 2];
+  *overhead_ms = pair[pair.size() / 2] - (double)all / repeats;
   *spin_ms = own[own.size() / 2];
   return FQ_OK;
 }

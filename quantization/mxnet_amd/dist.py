@@ -35,12 +35,19 @@ import torch.distributed as dist
 
 from . import ops
 
-__all__ = ["init", "is_distributed", "rank", "world_size", "shard_loader_kwargs", "attach_calibration_sync", "detach_calibration_sync", "empty_calibration_step", "calibration_steps",
+__all__ = ["init", "is_distributed", "group_is_live", "rank", "world_size", "shard_loader_kwargs", "attach_calibration_sync", "detach_calibration_sync", "empty_calibration_step", "calibration_steps",
            "kl_sync", "allreduce_eval_counters", "shutdown"]
 
 
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def group_is_live():
+    """A process group exists (also with ONE rank: `FQ_DIST_FORCE_GROUP=1`, or a caller's own init_process_group) - the
+    collectives of calibration and evaluation are then really issued, which is how the RCCL branch is exercised end to end
+    on a one-GPU box (tests/test_gpu_rccl.py)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def rank():
@@ -55,12 +62,16 @@ def init(backend=None):
     """Join the job described by torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
     Returns (rank, local_rank, world).  A no-op for a single process."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and os.environ.get("FQ_DIST_FORCE_GROUP", "0") != "1":
         return 0, int(os.environ.get("LOCAL_RANK", "0")), 1
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("FQ_DIST_SHARE_GPU", "0") == "1":
         local = 0
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world <= 1:                               # a one-rank group (FQ_DIST_FORCE_GROUP=1): env:// needs the full set
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if backend is None:
         backend = os.environ.get("FQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
@@ -79,7 +90,18 @@ def shutdown():
 
 # ---- transport ---------------------------------------------------------------------------------------------------------
 def _via_host(t):
+    _not_while_capturing(t)
     return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _not_while_capturing(t):
+    """Collectives are issued on the compute stream, next to forwards that an evaluation loop may be capturing into
+    hipGraphs (bench.py, the CLI's `evaluate(graph=True)`): a collective that landed inside a capture would be baked into the
+    graph and replayed with every batch - or fail inside RCCL with an error that names neither.  Calibration never captures,
+    evaluation exchanges its counters after the last replay; anything else is refused here."""
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("a torch.distributed collective was issued while the current HIP stream is capturing a graph: "
+                           "calibration steps and the final counter all-reduce must run outside hipGraph capture")
 
 
 def all_reduce(t, op=None):
@@ -303,7 +325,7 @@ def detach_calibration_sync(net):
 # ---- KL calibration ----------------------------------------------------------------------------------------------------
 def kl_sync(stage, tensor):
     """`sync` hook for quantize.distribution_calibrate.collect_feature_maps."""
-    if not is_distributed():
+    if not group_is_live():                      # (a one-rank group still issues them: the transport is what is exercised)
         return
     if stage == "range":
         broadcast(tensor, src=0)
@@ -316,6 +338,6 @@ def kl_sync(stage, tensor):
 # ---- evaluation ------------------------------------------------------------------------------------------------------------
 def allreduce_eval_counters(counters):
     """[test_num_correct, total, correct_counter[classes], label_counter[classes]] summed over ranks."""
-    if is_distributed():
+    if group_is_live():
         all_reduce(counters)
     return counters

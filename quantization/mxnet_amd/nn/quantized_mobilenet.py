@@ -35,7 +35,7 @@ def _add_conv(out, channels=1, kernel=1, stride=1, pad=0, in_channels=3, num_gro
                         quantized=True, input_dtype="uint8", weight_dtype="int8"))
     else:
         out.add(QConv2D(channels, kernel, stride, pad, in_channels=in_channels, groups=num_group, use_bias=False))
-    out.add(nn.BatchNorm(scale=True))
+    out.add(nn.BatchNorm(scale=True, in_channels=channels))     # (the reference leaves the width to deferred initialisation)
     if active:
         out.add(RELU6() if relu6 else nn.Activation('relu'))
 

@@ -97,6 +97,23 @@ def main():
     from quantization.mxnet_amd.mx import gpu
     rank, local, world = fqdist.init()
     ctx = gpu(local)
+    if flow == "all_one_rank":
+        # FQ_DIST_FORCE_GROUP=1, WORLD_SIZE=1: every flow of the CLI with its collectives really issued on a ONE-rank group
+        # (backend "nccl" = RCCL), evaluation with three batches in flight replayed from hipGraphs
+        assert world == 1 and fqdist.group_is_live()
+        import torch.distributed as dist
+        res = {"backend": np.asarray([ord(c) for c in dist.get_backend()])}
+        try:
+            evalb = local_batches("eval") + local_batches("calib")[:5] + local_batches("calib")[6:]
+            for f in ("naive_step", "naive_strict", "kl"):
+                thr, acc, avg, _ = run_flow(cli, f, ctx, 0, 1, local_batches("calib"), evalb, LOCAL_BS,
+                                            extra=("--eval-streams", "3", "--eval-graph", "1"))
+                res[f + "_thr"], res[f + "_acc"], res[f + "_avg"] = thr, np.float64(acc), np.float64(avg)
+                res[f + "_replayed"] = np.int64(cli.evaluate.last_replayed)
+            np.savez(os.path.join(out_dir, "one_rank.npz"), **res)
+        finally:
+            fqdist.shutdown()
+        return
     try:
         thr, acc, avg, _ = run_flow(cli, flow, ctx, rank, world, local_batches("calib"), local_batches("eval"), LOCAL_BS)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), thr=thr, acc=np.float64(acc), avg=np.float64(avg),

@@ -107,6 +107,60 @@ def test_cli_kl_flow_and_qparams_roundtrip_on_cpu_with_oracle(tiny_data, capsys,
     assert thr == thr2 and acc == acc2          # thresholds survive the parameter file (checkpoint/resume row)
 
 
+# The reference's four canned invocations (examples/scripts/simulate_quantization.md:5-23), flag for flag; only the data
+# volume is cut down (tiny_data: 16 validation images, 2 training images per class; --num-sample / --batch-size / one
+# calibration epoch) - the scripts themselves ask for 500 samples per class of the real CIFAR-10.
+CANNED = {
+    "c10_r56_uint4_int4_layer_merge_naive": ["--model=cifar_resnet56_v1", "--input-bits-width=4", "--weight-bits-width=4",
+                                             "--dataset=cifar10", "--merge-bn", "--quantize-input-offline",
+                                             "--calib-mode=naive"],
+    "c10_r56_uint4_int4_layer_merge_kl": ["--model=cifar_resnet56_v1", "--input-bits-width=4", "--weight-bits-width=4",
+                                          "--dataset=cifar10", "--merge-bn", "--quantize-input-offline", "--calib-mode=kl"],
+    "c10_r56_uint4_int4_channel_merge_naive": ["--model=cifar_resnet56_v1", "--quant-type=channel", "--input-bits-width=4",
+                                               "--weight-bits-width=4", "--dataset=cifar10", "--merge-bn",
+                                               "--quantize-input-offline", "--calib-mode=naive"],
+    "c10_r56_uint4_int4_channel_merge_kl": ["--model=cifar_resnet56_v1", "--quant-type=channel", "--input-bits-width=4",
+                                            "--weight-bits-width=4", "--dataset=cifar10", "--merge-bn",
+                                            "--quantize-input-offline", "--calib-mode=kl"],
+}
+CANNED_CUT = ["--num-sample=1", "--batch-size=8", "--calib-epoch=1"]
+
+
+def _check_canned(name, out, acc, net):
+    from quantization.mxnet_amd.mx.gluon import nn
+    assert "Result" in out and 0.0 <= acc <= 1.0
+    blocks = net.collect_quantized_blocks()
+    convs = [b for b in blocks if isinstance(b, nn.Conv2D)]
+    assert len(convs) >= 54 and out.count("Best threshold for") == len(blocks)
+    assert all(b.quantize_input_offline and float(b.input_max.data().asscalar()) > 0 for b in blocks)
+    assert all(b.fixed_params == 1 for b in convs)
+    # --merge-bn: every converted convolution folded its BatchNorm (fake_bn) and carries the folded bias
+    assert all(b.quantize_args.fake_bn and b.bias is not None for b in convs)
+    assert all(b.quantize_args.wt_width == 4 and b.quantize_args.in_width == 4 for b in convs)
+    assert all(b.quantize_args.quant_type == ("channel" if "channel" in name else "layer") for b in convs)
+    assert ("KL Calibration" in out) == name.endswith("_kl")
+
+
+@pytest.mark.parametrize("name", sorted(CANNED))
+def test_canned_reference_invocations_on_cpu_with_oracle(tiny_data, capsys, name):
+    from quantization.mxnet_amd import mx
+    cli = _cli()
+    opt = cli.parse_args(CANNED[name] + CANNED_CUT)
+    with oracle_ops():
+        acc, _, net = cli.run(opt, mx.cpu())
+    _check_canned(name, capsys.readouterr().out, acc, net)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CANNED))
+def test_canned_reference_invocations_on_gpu(tiny_data, capsys, name):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    cli = _cli()
+    acc, _, net = cli.main(CANNED[name] + CANNED_CUT + ["--use-gpu=0"])
+    _check_canned(name, capsys.readouterr().out, acc, net)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--quantize-input-offline", "--calib-epoch", "2", "--quant-type", "channel",
                                         "--weight-bits-width", "4"],

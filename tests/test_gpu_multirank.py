@@ -145,19 +145,25 @@ def test_cli_kl_calibration_two_ranks_equals_one_device(gpu, tmp_path):
 @pytest.mark.parametrize("extra", [(), ("--no-fuse",)], ids=["fused", "no-fuse"])
 def test_cli_evaluation_with_batches_in_flight_equals_one_at_a_time(gpu, extra):
     """`--eval-streams 3` (the default: three evaluation batches in flight, one HIP stream each, freezing forward first and
-    alone) against `--eval-streams 1`: same thresholds, same accuracies, and - since the nets are random - the same LOGITS
-    on a batch evaluated afterwards, for the fused net and for the plain converted one."""
+    alone) against `--eval-streams 1`, each launched eagerly (`--eval-graph 0`) and - the default - replayed from one hipGraph
+    per lane over static input / label buffers (the first batch of a lane and the ragged last batch stay eager): same
+    thresholds, same accuracies, and - since the nets are random - the same LOGITS on a batch evaluated afterwards, for the
+    fused net and for the plain converted one (which never replays)."""
     import gpu_cli_worker as W
     from quantization.mxnet_amd import mx
     cli = W.cli_module()
-    evalb = W.local_batches("eval") + W.local_batches("calib")[:5]            # eight batches: every lane several times
+    # nine batches: every lane several times, the last one ragged (2 samples)
+    evalb = W.local_batches("eval") + W.local_batches("calib")[:5] + W.local_batches("calib")[6:]
+    assert len(evalb) == 9 and len(evalb[-1][0]) == 2
     res = []
-    for streams in (1, 3):
+    for streams, graph in ((1, 0), (3, 0), (1, 1), (3, 1)):
         thr, acc, avg, net = W.run_flow(cli, "naive_step", gpu, 0, 1, W.local_batches("calib"), evalb, W.LOCAL_BS,
-                                        extra=("--eval-streams", str(streams)) + tuple(extra))
+                                        extra=("--eval-streams", str(streams), "--eval-graph", str(graph)) + tuple(extra))
+        want_replays = 0 if (extra or not graph) else (7 if streams == 1 else 5)
+        assert cli.evaluate.last_replayed == want_replays, (streams, graph, cli.evaluate.last_replayed)
         x = mx.nd.array(evalb[0][0], ctx=gpu)
         res.append((thr, acc, avg, net(x).asnumpy()))
-    np.testing.assert_array_equal(res[0][0], res[1][0])
-    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
-    np.testing.assert_array_equal(res[0][3], res[1][3])
-
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0][0], r[0])
+        assert res[0][1] == r[1] and res[0][2] == r[2]
+        np.testing.assert_array_equal(res[0][3], r[3])

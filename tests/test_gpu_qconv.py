@@ -267,9 +267,6 @@ def test_range_from_the_producers_statistic_and_folded_batchnorm(dev, ops):
                      bn_shift=T(bsh, dev), in_stat=T(stat, dev), want_stat=True)
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(gstat, wstat)
-    small = O.qconv2d_forward(x[:1, :, :3, :3], w, None, (1, 1), (0, 0), 1, input_dtype="int8", act="relu", bn_scale=bsc,
-                              bn_shift=bsh, in_stat=stat)
-    np.testing.assert_array_equal(small, want[:1, :, :3, :3])
     # a padded depthwise consumer of a non-negative tensor: [0, max] from the statistic == the range pass
     wd = (rng.standard_normal((cin, 1, 3, 3)) * 0.5).astype(np.float32)
     want = H.qconv2d_forward(x, wd, None, (2, 2), (1, 1), cin)

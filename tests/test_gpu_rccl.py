@@ -150,3 +150,42 @@ def test_c_abi_collectives_validate_arguments():
     assert rc != 0 and b"fq_comm_init first" in _lib.LIB.fq_last_error()
     rc = _lib.LIB.fq_comm_init(3, 2, ctypes.create_string_buffer(128))
     assert rc != 0 and b"rank 3 of 2" in _lib.LIB.fq_last_error()
+
+
+def test_every_cli_flow_on_a_one_rank_rccl_group(gpu, tmp_path):
+    """not only raw collectives but the CLI's FULL flows - naive-EMA calibration with the single
+    all-reduce per step, the strict per-layer all-gathers, the KL range broadcast + histogram all-reduce, the counter
+    all-reduce - on a process group whose backend is "nccl" (RCCL) with ONE rank, followed by the offline evaluation with
+    three batches in flight replayed from hipGraphs (collectives and captured graphs on one device: the transport refuses a
+    collective inside a capture, dist.py).  Thresholds and accuracies equal the same flows without any process group."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_cli_worker as W
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               FQ_DIST_FORCE_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("FQ_DIST_BACKEND", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_cli_worker.py"), str(tmp_path), "all_one_rank"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r = np.load(os.path.join(tmp_path, "one_rank.npz"))
+    assert "".join(chr(c) for c in r["backend"]) == "nccl"
+    cli = W.cli_module()
+    evalb = W.local_batches("eval") + W.local_batches("calib")[:5] + W.local_batches("calib")[6:]
+    for flow in ("naive_step", "naive_strict", "kl"):
+        thr, acc, avg, _ = W.run_flow(cli, flow, gpu, 0, 1, W.local_batches("calib"), evalb, W.LOCAL_BS,
+                                      extra=("--eval-streams", "1", "--eval-graph", "0"))
+        np.testing.assert_array_equal(r[flow + "_thr"], thr, flow)
+        assert float(r[flow + "_acc"]) == acc and float(r[flow + "_avg"]) == avg, flow
+        assert int(r[flow + "_replayed"]) == 5, flow
+
+
+def test_a_collective_inside_a_graph_capture_is_refused(gpu):
+    """dist.py: collectives share the compute stream with forwards an evaluation loop may be capturing; one that lands in a
+    capture is refused with an error that says so (instead of being replayed with every batch)."""
+    import torch
+    from quantization.mxnet_amd import dist as fqdist
+    t = torch.zeros(4, device=gpu.torch_device)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(gpu.torch_device)
+    with pytest.raises(RuntimeError, match="capturing a graph"):
+        with torch.cuda.graph(g, stream=s):
+            fqdist._not_while_capturing(t)
