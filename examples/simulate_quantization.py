@@ -236,17 +236,26 @@ class _Lane(object):
         return self.graph is not None and tuple(self.x.shape) == tuple(x.shape)
 
     def capture(self, x, y, step):
+        """Static buffers, then the step captured with the graph's own begin / end calls on the lane's stream - NOT the
+        `torch.cuda.graph` context, whose device-wide synchronise + gc.collect + empty_cache cost a 0.4 s evaluation pass a
+        third of its time (measured: three lanes, 400 batches)."""
         self.x, self.y = torch.empty_like(x), torch.empty_like(y)
         self.x.copy_(x)
         self.y.copy_(y)
         g = torch.cuda.CUDAGraph()
+        side = self.stream
+        if side is None:                             # one lane on the default stream: capture needs a stream of its own
+            side = self.capture_stream = getattr(self, "capture_stream", None) or torch.cuda.Stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
         try:
+            with torch.cuda.stream(side):
+                g.capture_begin()
+                try:
+                    step(self.x, self.y)
+                finally:
+                    g.capture_end()
             if self.stream is None:
-                with torch.cuda.graph(g):
-                    step(self.x, self.y)
-            else:
-                with torch.cuda.graph(g, stream=self.stream):
-                    step(self.x, self.y)
+                torch.cuda.current_stream(self.dev).wait_stream(side)
         except Exception as e:                       # capture is an optimisation: stay with eager launches, and say so once
             self.graph = False
             torch.cuda.synchronize(self.dev)

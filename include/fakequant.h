@@ -460,7 +460,7 @@ int fq_dequantize(const int32_t* codes, float* y, int64_t numel, const float* sc
  *   be NULL): an inference BatchNorm behind the block folded into the store, y' = y * bn_scale[c] + bn_shift[c] (separately
  *   rounded, as fq_bn_act_stat), the activation then applies to y' (as the separate Activation block would).  stat_out (may
  *   be NULL): per-sample max|y'|, or stat_out[0] = -1 when the layer went through the exact direct kernel.  ws:
- *   fq_qconv_workspace_bytes(cout) bytes, 16-byte aligned, initialised ONCE by fq_qconv_workspace_init (every forward leaves
+ *   fq_qconv_workspace_bytes(cout) bytes, 128-byte aligned, initialised ONCE by fq_qconv_workspace_init (every forward leaves
  *   it initialised); not to be shared by forwards that may run concurrently.                                              */
 size_t fq_qconv_weights_bytes(int64_t cin, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw, int groups);
 /* which kernel family a geometry takes: 0 direct, 1 pointwise (matrix cores), 2 dense 3x3 (matrix cores), 3 depthwise 3x3 */

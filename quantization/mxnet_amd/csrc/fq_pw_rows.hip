@@ -190,10 +190,16 @@ __global__ __launch_bounds__(kRowsNW * 64) void pwconv_rows_kernel(
 #else
   constexpr bool kShortHandshakeOk = false;
 #endif
-  if (fence_mode == 0 || !kShortHandshakeOk)
+  if (fence_mode == 0 || !kShortHandshakeOk) {
     __threadfence();
-  else
+  } else {
+    // the wait the comment above relies on, spelled out: outside threadgroup-split mode hipcc lowers a workgroup-scope
+    // release fence to NOTHING for global memory (found in round 4 by reading the ISA: key store, then straight to
+    // s_barrier), so "this wavefront's key stores have been acknowledged" was never actually waited for.  tools/isa_lint.py
+    // now checks that `s_waitcnt vmcnt(0)` sits directly in front of the barrier and that the key accesses carry sc1.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
   if (threadIdx.x == 0) wg_last = atomicAdd(sync + st, 1u) == (unsigned)(g.ut - 1) ? 1u : 0u;
   __syncthreads();

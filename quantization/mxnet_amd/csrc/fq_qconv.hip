@@ -30,6 +30,8 @@ namespace {
 
 constexpr int kKindDirect = 0, kKindPw = 1, kKindC3 = 2, kKindDw = 3;
 constexpr int kFlagFixup = 1;
+constexpr int kSlots = 16, kSlotStride = 32;            // range-pass lines: 16 x 128 bytes ({min, max} at the head of each)
+constexpr size_t kWsHeader = 2 * kSlots * kSlotStride * 4 + 256;   // two sets of lines | range record | ...
 
 // `_quantize` (nn/quantized_conv.py:54-61): scale of a clip range, and a code
 __device__ __forceinline__ float range_scale(float mn, float mx) { return (mx == -mn) ? (mx / 127.0f) : ((mx - mn) / 255.0f); }
@@ -42,8 +44,10 @@ struct QconvShape {
 };
 
 // ---- the range record and the per-layer constants ----------------------------------------------------------------------
-// mm = {min, max} of the un-padded tensor as the minmax pass left it (int8: {unused, max|x|}); re-initialised here for the
-// next forward.  wrec: the weights' record (fq_qconv_weights_prepare).  One workgroup.
+// mm: kSlots lines of {min, max} as the range pass left them (workgroup b of that pass folds its result into line b % kSlots:
+// same-address atomics are served one after the other, ~10 ns each, so 2048 workgroups on ONE pair of words cost the pass
+// 40 us - profiles/r3_atomic_probe.txt), combined and re-initialised here for the next forward.  wrec: the weights' record
+// (fq_qconv_weights_prepare).  One workgroup.
 __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict__ mm, int mode, int padded, float fix_min,
                                                               float fix_max, int kind, const float* __restrict__ wrec,
                                                               const float* __restrict__ bias, int cout,
@@ -99,11 +103,16 @@ __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict_
         mn = padded ? fminf(rng[0], 0.0f) : rng[0];
       }
     } else if (mode == FQ_CODES_INT8) {
-      mx = mm[1];
+      mx = 0.0f;
+      for (int k = 0; k < kSlots; ++k) mx = fmaxf(mx, mm[k * kSlotStride + 1]);
       mn = -mx;
     } else if (mode == FQ_CODES_UINT8) {
-      mn = mm[0];
-      mx = mm[1];
+      mn = INFINITY;
+      mx = -INFINITY;
+      for (int k = 0; k < kSlots; ++k) {
+        mn = fminf(mn, mm[k * kSlotStride]);
+        mx = fmaxf(mx, mm[k * kSlotStride + 1]);
+      }
       if (padded) {                              // the reference pads BEFORE it takes the range (:108-113)
         mn = fminf(mn, 0.0f);
         mx = fmaxf(mx, 0.0f);
@@ -112,8 +121,10 @@ __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict_
       mn = fix_min;
       mx = fix_max;
     }
-    mm[0] = INFINITY;
-    mm[1] = mode == FQ_CODES_INT8 ? 0.0f : -INFINITY;
+    for (int k = 0; k < kSlots; ++k) {
+      mm[k * kSlotStride] = INFINITY;
+      mm[k * kSlotStride + 1] = mode == FQ_CODES_INT8 ? 0.0f : -INFINITY;
+    }
     const float sc = range_scale(mn, mx);
     const bool sym = mx == -mn;
     const float ql = roundf(mn / sc), qh = roundf(mx / sc);
@@ -150,12 +161,53 @@ __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict_
   }
 }
 
+// two sets of lines: [0, kSlots) for uint8 ranges ({+inf, -inf}), [kSlots, 2 kSlots) for int8 ones ({+inf, 0})
 __global__ void qconv_ws_init_kernel(float* mm) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    mm[0] = INFINITY;
-    mm[1] = -INFINITY;
-    mm[2] = INFINITY;      // (second pair: the int8 initial state differs only in max = 0; see qconv_finish_kernel)
-    mm[3] = 0.0f;
+  const int k = threadIdx.x;
+  if (blockIdx.x == 0 && k < 2 * kSlots) {
+    mm[k * kSlotStride] = INFINITY;
+    mm[k * kSlotStride + 1] = k < kSlots ? -INFINITY : 0.0f;
+  }
+}
+
+// the range pass: K6's walk (fq_common.h: minmax_kernel) with the workgroup's result folded into line blockIdx % kSlots
+template <bool WANT_MIN, bool USE_ABS>
+__global__ __launch_bounds__(kBlock) void qconv_minmax_kernel(const float* __restrict__ x, int64_t numel, int vec_ok,
+                                                              float* __restrict__ mm) {
+  __shared__ float red[4];
+  float mx = USE_ABS ? 0.0f : -INFINITY, mn = INFINITY;
+  auto take = [&](float v) {
+    mx = fmaxf(mx, stat_of<USE_ABS>(v));
+    if (WANT_MIN) mn = fminf(mn, v);
+  };
+  const int64_t chunks = (numel + kChunk - 1) / kChunk;
+  const ChunkRange rg = block_range(chunks);
+  for (int64_t c = rg.begin; c < rg.end; ++c) {
+    const int64_t base = c * (int64_t)kChunk;
+    const int64_t rem = numel - base;
+    if (vec_ok && rem >= kChunk) {
+      const f4* p = reinterpret_cast<const f4*>(x + base);
+      f4 v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) v[u] = p[threadIdx.x + u * kBlock];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        take(v[u].x);
+        take(v[u].y);
+        take(v[u].z);
+        take(v[u].w);
+      }
+    } else {
+      const int cnt = (int)(rem < kChunk ? rem : kChunk);
+      for (int i = threadIdx.x; i < cnt; i += kBlock) take(x[base + i]);
+    }
+  }
+  float* line = mm + (blockIdx.x % kSlots) * kSlotStride;
+  mx = block_max(mx, red);
+  if (threadIdx.x == 0) atomic_max_f32(line + 1, mx);
+  if (WANT_MIN) {
+    mn = block_min(mn, red);
+    if (threadIdx.x == 0) atomic_min_f32(line, mn);
   }
 }
 
@@ -381,7 +433,7 @@ int fq_qconv_weights_prepare(const float* w, int64_t cin, int64_t cout, int kh, 
   return FQ_OK;
 }
 
-size_t fq_qconv_workspace_bytes(int64_t cout) { return cout > 0 ? 256 + (size_t)((cout + 63) / 64 * 64) * 12 : 0; }
+size_t fq_qconv_workspace_bytes(int64_t cout) { return cout > 0 ? kWsHeader + (size_t)((cout + 63) / 64 * 64) * 8 : 0; }
 
 int fq_qconv_workspace_init(void* ws, fqStream_t stream) {
   FQ_REQUIRE(ws, "fq_qconv_workspace_init: null pointer");
@@ -413,10 +465,11 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
   const char* wb = (const char*)wbuf;
   const float* wrec = (const float*)wb;
   // workspace: {min, max} | record | int32 bias codes | per-channel dequantisation factor | zeros
-  float* mm = (float*)ws;
-  float* rec = mm + 8;
+  float* mm = (float*)ws;                                  // uint8 lines; the int8 set follows
+  float* mm8 = mm + kSlots * kSlotStride;
+  float* rec = mm + 2 * kSlots * kSlotStride;
   const int64_t cpad = (cout + 63) / 64 * 64;
-  int* ibias = (int*)((char*)ws + 256);
+  int* ibias = (int*)((char*)ws + kWsHeader);
   float* svec = (float*)(ibias + cpad);
   QconvShape s;
   s.n = (int)n; s.cin = (int)cin; s.h = (int)h; s.w = (int)wdt; s.cout = (int)cout; s.kh = kh; s.kw = kw; s.sh = sh; s.sw = sw;
@@ -432,14 +485,14 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
     ProfScope prof(FQ_KERNEL_GLOBAL_MAX, 4.0 * (double)numel, st);
     const int grid = grid_for((numel + kChunk - 1) / kChunk);
     if (input_mode == FQ_CODES_INT8)
-      hipLaunchKernelGGL((minmax_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, x, numel, aligned16(x) ? 1 : 0,
-                         mm + 2, mm + 3);
+      hipLaunchKernelGGL((qconv_minmax_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, x, numel, aligned16(x) ? 1 : 0,
+                         mm8);
     else
-      hipLaunchKernelGGL((minmax_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, x, numel, aligned16(x) ? 1 : 0, mm,
-                         mm + 1);
+      hipLaunchKernelGGL((qconv_minmax_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, x, numel, aligned16(x) ? 1 : 0,
+                         mm);
   }
   // ---- 2. record + constants ------------------------------------------------------------------------------------------------
-  hipLaunchKernelGGL(qconv_finish_kernel, dim3(1), dim3(kBlock), 0, st, input_mode == FQ_CODES_INT8 ? mm + 2 : mm, input_mode,
+  hipLaunchKernelGGL(qconv_finish_kernel, dim3(1), dim3(kBlock), 0, st, input_mode == FQ_CODES_INT8 ? mm8 : mm, input_mode,
                      (ph > 0 || pw > 0) ? 1 : 0, in_min, in_max, kind, wrec, bias, (int)cout, rec, ibias,
                      kind == kKindDw ? svec : (float*)nullptr, in_stat, (int)n, x, numel);
   FQ_LAUNCH_CHECK();

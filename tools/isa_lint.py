@@ -90,9 +90,43 @@ def lint_text(text):
     return findings
 
 
+def lint_handshake(text, kernel_substr="pwconv_rows_kernelILb1"):
+    """The "last workgroup" hand-shake of the classifier + counters kernel (csrc/fq_pw_rows.hip): its cross-workgroup accesses
+    are agent-scope atomics compiled to sc1 stores / loads, and the release side is an `s_waitcnt vmcnt(0)` directly in front
+    of the barrier that precedes the counter's atomic add (a workgroup-scope fence alone compiles to nothing here).  Returns a
+    list of problems (empty = fine; None = the kernel is not in this code object)."""
+    m = re.search(r"^[0-9a-f]+ <([^>]*%s[^>]*)>:$" % re.escape(kernel_substr), text, re.M)
+    if not m:
+        return None
+    seg = text[m.end():]
+    nxt = re.search(r"^[0-9a-f]+ <", seg, re.M)
+    seg = seg[:nxt.start()] if nxt else seg
+    ins = [l.split("//")[0].strip() for l in seg.splitlines() if l.strip() and not l.strip().startswith(".")]
+    problems = []
+    if not any(re.match(r"global_store_dwordx2 .* sc1", i) for i in ins):
+        problems.append("no sc1 (agent-scope, written through) 64-bit key store")
+    if not any(re.match(r"global_load_dwordx2 .* sc1", i) for i in ins):
+        problems.append("no sc1 (past the vector cache and L2) 64-bit key load")
+    # the release side: an `s_waitcnt vmcnt(0)` of the short hand-shake's own (not the one inside the textbook path's
+    # buffer_wbl2 / buffer_inv pair) with nothing but branches, waits and cache maintenance between it and the barrier
+    ok = False
+    harmless = ("s_nop", "s_cbranch", "s_branch", "s_waitcnt", "buffer_wbl2", "buffer_inv")
+    for k, i in enumerate(ins):
+        if not re.match(r"s_waitcnt .*vmcnt\(0\)", i) or (k > 0 and ins[k - 1].startswith("buffer_wbl2")):
+            continue
+        j = k + 1
+        while j < len(ins) and j <= k + 8 and ins[j].startswith(harmless):
+            j += 1
+        if j < len(ins) and ins[j].startswith("s_barrier"):
+            ok = True
+    if not ok:
+        problems.append("no `s_waitcnt vmcnt(0)` of its own in front of the release barrier: the key stores are not waited for")
+    return problems
+
+
 def main():
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "quantization", "mxnet_amd", "csrc", "libfakequant.so")
-    total, stores = [], 0
+    total, stores, handshake = [], 0, None
     for k, blob in enumerate(code_objects(lib)):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
             f.write(blob)
@@ -100,11 +134,20 @@ def main():
             text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True).stdout
         stores += len(re.findall(r"^\s*(buffer_store_dwordx[34]|global_store_dwordx[34])", text, re.M))
         total += lint_text(text)
+        hs = lint_handshake(text)
+        if hs is not None:
+            handshake = hs
     for kernel, st, wr, slots in total:
         name = subprocess.run(["c++filt", kernel], capture_output=True, text=True).stdout.strip()
         print("HAZARD in %s\n    %s\n    %s   (%d wait state(s) after the store)" % (name[:150], st, wr, slots))
     print("isa_lint: %d wide stores checked, %d unprotected VALU writes of store data" % (stores, len(total)))
-    sys.exit(1 if total else 0)
+    if handshake is None:
+        print("isa_lint: pwconv_rows_kernel<true> not found: its hand-shake was NOT checked")
+    else:
+        for p in handshake:
+            print("HANDSHAKE pwconv_rows_kernel<true>: " + p)
+        print("isa_lint: last-workgroup hand-shake of pwconv_rows_kernel<true>: %s" % ("ok" if not handshake else "BROKEN"))
+    sys.exit(1 if total or handshake or handshake is None else 0)
 
 
 if __name__ == "__main__":
