@@ -97,10 +97,11 @@ EXTRA_FLAGS = [
                                           'instead of image by image on the host, so the reported speed is the '
                                           'network\'s, not the data pipeline\'s; sample values differ from the host '
                                           'pipeline\'s (both are random)')),
-    (['--synthetic-resident'], dict(type=int, default=8,
+    (['--synthetic-resident'], dict(type=int, default=6,
                                     help='(with --synthetic-on-device) distinct synthetic batches kept on the device and cycled '
-                                         '(default 8; 0: draw every batch anew - 19 M normals per ImageNet-shaped batch, a tenth '
-                                         'of a MobileNet step)')),
+                                         '(default 6 - a multiple of the default three evaluation lanes, so that a lane meets two '
+                                         'of them and replays two graphs in place; 0: draw every batch anew - 19 M normals per '
+                                         'ImageNet-shaped batch, a tenth of a MobileNet step)')),
     (['--export-scale-table'], dict(type=str, default=None,
                                     help='after calibration write an ncnn-style int8 scale table (per-channel weight scales '
                                          'after BN folding, one input scale per layer; quantize/freeze/scale_table.py)')),
@@ -189,6 +190,7 @@ class DeviceSyntheticLoader(object):
         self.total_batches = (self._n + self._b - 1) // self._b
         self._mine = range(int(rank), self.total_batches, int(world_size))
         self._resident, self._kept = int(resident), {}
+        self.resident_batches = self._resident > 0         # full batches keep their device addresses (evaluate: graphs in place)
 
     def __len__(self):
         return len(self._mine)
@@ -222,46 +224,74 @@ def _total_batches(loader):
 
 # ---- evaluation ------------------------------------------------------------------------------------------------------------
 class _Lane(object):
-    """One evaluation batch in flight: a HIP stream, and - once the lane has run a forward eagerly - a hipGraph of the step
-    (forward + the evaluation counters) over STATIC input / label buffers the loader's batches are copied into, replayed for
-    every later batch of the same shape.  Launching the ~30-100 kernels of a fused step from Python takes the host as long as
-    the GPU needs to run them (bench.py measures it); a replay is one call."""
+    """One evaluation batch in flight: a HIP stream, and - once the lane has run a forward eagerly - hipGraphs of the step
+    (forward + the evaluation counters), replayed for every later full batch.  Launching the ~30-100 kernels of a fused step
+    from Python takes the host as long as the GPU needs to run them (bench.py measures it); a replay is one call.  Where the
+    graph reads its batch:
+      * a loader whose batches live on the device at stable addresses (`loader.resident_batches`: the synthetic on-device
+        loader) is read IN PLACE - one graph per (lane, batch tensor), at most `MAX_GRAPHS` of them;
+      * any other batch is copied into the lane's static input buffer - for a host batch that IS its host-to-device copy,
+        for a device batch one extra device copy (77 MB for 128 ImageNet images: ~6 % of a MobileNet step)."""
+    MAX_GRAPHS = 16
 
     def __init__(self, dev, stream):
         self.dev, self.stream = dev, stream
-        self.x = self.y = self.graph = None
+        self.graphs, self.full_shape, self.failed = {}, None, False
+        self.capture_stream = None
         self.eager_done = 0
 
-    def ready_for(self, x):
-        return self.graph is not None and tuple(self.x.shape) == tuple(x.shape)
-
-    def capture(self, x, y, step):
-        """Static buffers, then the step captured with the graph's own begin / end calls on the lane's stream - NOT the
-        `torch.cuda.graph` context, whose device-wide synchronise + gc.collect + empty_cache cost a 0.4 s evaluation pass a
-        third of its time (measured: three lanes, 400 batches)."""
-        self.x, self.y = torch.empty_like(x), torch.empty_like(y)
-        self.x.copy_(x)
-        self.y.copy_(y)
+    def _capture(self, xbuf, ybuf, step):
+        """The step captured with the graph's own begin / end calls on the lane's stream - NOT the `torch.cuda.graph`
+        context, whose device-wide synchronise + gc.collect + empty_cache cost a 0.4 s evaluation pass a third of its time."""
         g = torch.cuda.CUDAGraph()
         side = self.stream
         if side is None:                             # one lane on the default stream: capture needs a stream of its own
-            side = self.capture_stream = getattr(self, "capture_stream", None) or torch.cuda.Stream(self.dev)
+            side = self.capture_stream = self.capture_stream or torch.cuda.Stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
         try:
             with torch.cuda.stream(side):
                 g.capture_begin()
                 try:
-                    step(self.x, self.y)
+                    step(xbuf, ybuf)
                 finally:
                     g.capture_end()
             if self.stream is None:
                 torch.cuda.current_stream(self.dev).wait_stream(side)
         except Exception as e:                       # capture is an optimisation: stay with eager launches, and say so once
-            self.graph = False
+            self.failed = True
             torch.cuda.synchronize(self.dev)
             print("[eval] hipGraph capture failed (%s: %s): evaluation launches eagerly" % (type(e).__name__, str(e)[:120]))
+            return None
+        return g
+
+    def replay(self, x, y, step, resident):
+        """True when the batch (x: fp32 tensor on the host or the device, y: labels of any dtype) went through a graph."""
+        if self.failed or self.eager_done == 0:
             return False
-        self.graph = g
+        if self.full_shape is None:
+            self.full_shape = tuple(x.shape)
+        if tuple(x.shape) != self.full_shape:        # the ragged last batch: not worth a graph of its own
+            return False
+        in_place = resident and x.is_cuda
+        key = (x.data_ptr(), y.data_ptr()) if in_place else "static"
+        ent = self.graphs.get(key)
+        if ent is None:
+            if len(self.graphs) >= self.MAX_GRAPHS:
+                return False
+            xbuf = x if in_place else torch.empty(x.shape, dtype=torch.float32, device=self.dev)
+            ybuf = torch.empty(y.shape, dtype=torch.long, device=self.dev)
+            if not in_place:
+                xbuf.copy_(x, non_blocking=True)
+            ybuf.copy_(y, non_blocking=True)
+            g = self._capture(xbuf, ybuf, step)
+            if g is None:
+                return False
+            ent = self.graphs[key] = (g, xbuf, ybuf)
+        g, xbuf, ybuf = ent
+        if not in_place:
+            xbuf.copy_(x, non_blocking=True)
+            ybuf.copy_(y, non_blocking=True)         # (in place: the labels of a resident batch never change)
+        g.replay()
         return True
 
 
@@ -285,6 +315,7 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
     graph = bool(graph) and on_gpu and not update_ema and hasattr(net, "_fq_arena_hooks")
     head = _fuse.eval_head(net, counters) if on_gpu else None
     replayed = 0
+    resident = bool(getattr(dataloader, "resident_batches", False))
 
     def step(xt, labels):
         """forward + counters of one batch on the current stream"""
@@ -311,18 +342,13 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
                             t.record_stream(side)
                 with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), \
                         (ops.batches_in_flight() if side is not None else contextlib.nullcontext()):
-                    labels = y.as_in_context(ctx)._t.long()
-                    xt = X.as_in_context(ctx)._t
-                    if graph and lane.graph is not False and lane.eager_done > 0 and done >= n_lanes and \
-                            (lane.ready_for(xt) or (lane.graph is None and lane.capture(xt, labels, step))):
-                        lane.x.copy_(xt, non_blocking=True)
-                        lane.y.copy_(labels, non_blocking=True)
-                        lane.graph.replay()
+                    if graph and done >= n_lanes and lane.replay(X._t, y._t, step, resident):
+                        labels = y._t
                         replayed += 1
                     else:
-                        step(xt, labels)
-                        lane_done = lane is not None
-                        if lane_done:
+                        labels = y.as_in_context(ctx)._t.long()
+                        step(X.as_in_context(ctx)._t, labels)
+                        if lane is not None:
                             lane.eager_done += 1
                 seen += int(labels.numel())
                 done += 1

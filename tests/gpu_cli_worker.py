@@ -70,7 +70,7 @@ def options(cli, flow, extra=()):
     return cli.parse_args(argv)
 
 
-def run_flow(cli, flow, ctx, rank, world, calib, evalb, batch_size, extra=()):
+def run_flow(cli, flow, ctx, rank, world, calib, evalb, batch_size, extra=(), resident=False):
     """build -> convert -> calibrate -> freeze -> offline evaluation, exactly `Simulation.execute` with the two loaders
     replaced.  Returns (thresholds of every quantised block, acc, avg_acc)."""
     opt = options(cli, flow, extra)
@@ -81,6 +81,7 @@ def run_flow(cli, flow, ctx, rank, world, calib, evalb, batch_size, extra=()):
     sim.quantise_net()
     sim.train_loader = ListLoader(calib, ctx, rank, world)
     sim.eval_loader = ListLoader(evalb, ctx, rank, world)
+    sim.eval_loader.resident_batches = bool(resident)     # device batches at stable addresses: graphs read them in place
     if flow == "kl":
         sim.calibrate_kl()
     else:

@@ -146,7 +146,8 @@ def test_cli_kl_calibration_two_ranks_equals_one_device(gpu, tmp_path):
 def test_cli_evaluation_with_batches_in_flight_equals_one_at_a_time(gpu, extra):
     """`--eval-streams 3` (the default: three evaluation batches in flight, one HIP stream each, freezing forward first and
     alone) against `--eval-streams 1`, each launched eagerly (`--eval-graph 0`) and - the default - replayed from one hipGraph
-    per lane over static input / label buffers (the first batch of a lane and the ragged last batch stay eager): same
+    per lane - over static input / label buffers the batches are copied into, or reading resident batches in place - (the
+    first batch of a lane and the ragged last batch stay eager): same
     thresholds, same accuracies, and - since the nets are random - the same LOGITS on a batch evaluated afterwards, for the
     fused net and for the plain converted one (which never replays)."""
     import gpu_cli_worker as W
@@ -156,9 +157,12 @@ def test_cli_evaluation_with_batches_in_flight_equals_one_at_a_time(gpu, extra):
     evalb = W.local_batches("eval") + W.local_batches("calib")[:5] + W.local_batches("calib")[6:]
     assert len(evalb) == 9 and len(evalb[-1][0]) == 2
     res = []
-    for streams, graph in ((1, 0), (3, 0), (1, 1), (3, 1)):
+    for streams, graph, resident in ((1, 0, False), (3, 0, False), (1, 1, False), (3, 1, False), (3, 1, True)):
+        # (resident: the loader's batches keep their device addresses - one graph per (lane, batch) reads them in place;
+        # otherwise every batch is copied into the lane's static buffer)
         thr, acc, avg, net = W.run_flow(cli, "naive_step", gpu, 0, 1, W.local_batches("calib"), evalb, W.LOCAL_BS,
-                                        extra=("--eval-streams", str(streams), "--eval-graph", str(graph)) + tuple(extra))
+                                        extra=("--eval-streams", str(streams), "--eval-graph", str(graph)) + tuple(extra),
+                                        resident=resident)
         want_replays = 0 if (extra or not graph) else (7 if streams == 1 else 5)
         assert cli.evaluate.last_replayed == want_replays, (streams, graph, cli.evaluate.last_replayed)
         x = mx.nd.array(evalb[0][0], ctx=gpu)

@@ -93,7 +93,9 @@ def test_every_quantised_convolution_of_the_net_equals_the_oracle(gpu, kind, mul
     with Spy(ops) as spy:
         fused = net(x).asnumpy()
     assert len(spy.calls) == n_q
-    assert sum(c["in_stat"] is not None for c in spy.calls) >= (26 if kind == "v1" else 30)
+    # (every consumer of a ReLU / ReLU6 output; with 16 stem channels the first convolution stays with the tensor library
+    # and leaves no statistic for the first depthwise layer)
+    assert sum(c["in_stat"] is not None for c in spy.calls) >= (26 if (kind, mult) == ("v1", 1.0) else 25 if kind == "v1" else 30)
     assert all(c["bn_scale"] is not None and c["stat"] is not None for c in spy.calls)
     _check_calls(spy.calls)
     # the range from the statistic is the range of the range pass: identical logits with the statistic switched off
