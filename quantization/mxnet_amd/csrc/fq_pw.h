@@ -44,6 +44,7 @@ struct PwCall {
 
 int pw_try_stream(const PwCall& c, bool* taken);    // K2h  fq_pw_stream.hip
 bool pw_stream_shape_ok(const PwCall& c);           //      shapes the streaming form takes
+bool pw_stream_thin_takes(const PwCall& c);         //      ... and the thin instantiations (C16 input, ragged Cin / Cout) on large planes
 int pw_try_split(const PwCall& c, bool* taken);     // K2m  fq_pw_split.hip
 int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t grid, size_t lds, const int8_t* wfrag,
                       bool* launched);

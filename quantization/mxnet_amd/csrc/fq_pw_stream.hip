@@ -22,14 +22,21 @@ struct PwsGeom {
   int64_t cols, tiles;        // n * HW, ceil(cols / 32)
   int zoff;
   // OUT16 (fq_pwconv_i8_c16): y is a C16 code tensor with CBo = Cout / 16 blocks holding the CONSUMER's codes
-  int CBo;
+  // IN16: x is a C16 code tensor with CBi = ceil(Cin / 16) blocks (quantised by its producer: no quantiser here)
+  int CBo, CBi;
   float out_levels;
   int out_lo_neg, out_zoff;
 };
 
 // RES: a residual operand of y's shape is added after BatchNorm, before the activation (compile-time: the loads of the
 // residual would otherwise cost the plain instantiations their occupancy)
-template <int KT, bool RES, bool OUT16 = false>
+// IN16 / PART (round 4: the thin layers of MobileNetV2 on its large planes - 32 -> 16, 96 -> 24, 24 -> 144, 144 -> 24 @112x112 /
+// 56x56 - which the split form ran as 12 544 ... 50 176 one-tile workgroups with a prologue each, at 1.0 - 2.0 TB/s):
+// IN16: the input is a C16 code tensor - a lane's 16 codes of a half-slab are ONE 16-byte load, no quantiser;
+// PART: Cin need not be a multiple of 16 (the loads of a ragged half-slab are clamped to the last channel: whatever code
+// they get meets a zero weight code) and Cout need not be a multiple of 32 (channels past Cout get all-zero constants and an
+// out-of-range buffer offset: the hardware drops their stores and returns 0 for their residual loads).
+template <int KT, bool RES, bool OUT16 = false, bool IN16 = false, bool PART = false>
 __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wc, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwsGeom g,
@@ -78,9 +85,25 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     return (unsigned)((((int64_t)px.smp * g.Cin + c0) * plane + px.p) * 4);
   };
   auto issue = [&](const Pix& px, int kt, float (&v)[16]) __attribute__((always_inline)) {
+    if (IN16) {
+      const int blk = 2 * kt + h;                                      // this half-wave's block of 16 channels
+      const bool okb = blk < g.CBi;
+      const unsigned off16 = (unsigned)((((int64_t)px.smp * g.CBi + (okb ? blk : 0)) * plane + px.p) * 16);
+      v4i c = *reinterpret_cast<const v4i*>(reinterpret_cast<const char*>(x) + off16);
+      c = okb ? c : (v4i){0, 0, 0, 0};                                  // (a block past the channels meets zero weight codes)
+      v[0] = __int_as_float(c[0]); v[1] = __int_as_float(c[1]); v[2] = __int_as_float(c[2]); v[3] = __int_as_float(c[3]);
+      return;
+    }
     const int cg = kt * 32 + 16 * h;                                   // this half-wave's 16 channels of slab kt
     const unsigned off = lane_off(px, cg < g.Cin ? 16 * h : 0);        // padded group: read the valid half, discarded
     const char* ub = reinterpret_cast<const char*>(x) + (int64_t)kt * 32 * plane * 4;
+    if (PART) {                                                        // a ragged half-slab: stay inside the sample's channels
+      const int last = g.Cin - 1 - (cg < g.Cin ? cg : kt * 32);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        v[i] = *reinterpret_cast<const float*>(ub + (int64_t)(i < last ? i : (last < 0 ? 0 : last)) * plane * 4 + off);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float*>(ub + (int64_t)i * plane * 4 + off);
   };
@@ -113,11 +136,11 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   for (int i = threadIdx.x; i < nch; i += kBlock) {
     const bool ok = i < g.Cout;
     const int ic = ok ? i : 0;
-    c_sxw[i] = sx * wscale[ic];
+    c_sxw[i] = (!PART || ok) ? sx * wscale[ic] : 0.0f;
     c_zs[i] = ok ? zoff * wsum[ic] + (ibias != nullptr ? ibias[ic] : 0) : 0;
-    c_bias[i] = fbias != nullptr ? fbias[ic] : 0.0f;
-    c_bsc[i] = has_bn ? bn_scale[ic] : 1.0f;
-    c_bsh[i] = has_bn ? bn_shift[ic] : 0.0f;
+    c_bias[i] = (fbias != nullptr && (!PART || ok)) ? fbias[ic] : 0.0f;
+    c_bsc[i] = (!PART || ok) ? (has_bn ? bn_scale[ic] : 1.0f) : 0.0f;
+    c_bsh[i] = (has_bn && (!PART || ok)) ? bn_shift[ic] : 0.0f;
   }
   __syncthreads();
 
@@ -125,6 +148,10 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   const int ubias = 128 - zoff;
   const unsigned nn_xor = fq_nonneg_xor(ubias);
   auto quant = [&](int kt, const float (&v)[16], auto nn_c) __attribute__((always_inline)) {
+    if (IN16) {
+      bfrag[kt] = (v4i){__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
+      return;
+    }
     const bool gvalid = kt * 32 + 16 * h < g.Cin;
     v4i f;
 #pragma unroll
@@ -141,6 +168,10 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   auto tile_done = [&](const Pix& px, auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
     const unsigned yoff = (unsigned)((((int64_t)px.smp * g.Cout + 4 * h) * plane + px.p) * 4);
+    // PART: every store (and residual load) of a channel tile goes through a resource over the whole tensor with an
+    // out-of-range offset for channels past Cout
+    const int64_t n_smp = (int64_t)(cols / HW);
+    const fq_rsrc yrp = make_rsrc(y, PART ? (OUT16 ? n_smp * g.CBo * plane * 16 : n_smp * g.Cout * plane * 4) : 0);
     float m = 0.0f;
 #pragma unroll 1
     for (int ct = 0; ct < g.CT; ++ct) {
@@ -156,8 +187,10 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
       if (RES) {
         const fq_rsrc rr = make_rsrc(residual, (int64_t)(cols / HW) * g.Cout * plane * 4);      // (host: y is below 4 GB)
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          res[i] = buf_ld_f32(rr, yoff, (unsigned)((ct * 32 + 8 * (i >> 2) + (i & 3)) * plane * 4));
+        for (int i = 0; i < 16; ++i) {
+          const bool okc = !PART || ct * 32 + 8 * (i >> 2) + 4 * h + (i & 3) < g.Cout;
+          res[i] = buf_ld_f32(rr, okc ? yoff : 0x80000000u, (unsigned)((ct * 32 + 8 * (i >> 2) + (i & 3)) * plane * 4));
+        }
       }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
@@ -191,6 +224,11 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
           if (OUT16) {
             vq[r] = v.x;
             vq[r + 1] = v.y;
+          } else if (PART) {
+            const int chn = ct * 32 + 8 * gq + 4 * h + r;
+            const unsigned so = (unsigned)((ct * 32 + 8 * gq + r) * plane * 4);
+            buf_st_f32(yrp, chn < g.Cout ? yoff : 0x80000000u, so, v.x);
+            buf_st_f32(yrp, chn + 1 < g.Cout ? yoff : 0x80000000u, so + (unsigned)(plane * 4), v.y);
           } else {
             char* yb = reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff;
             *reinterpret_cast<float*>(yb) = v.x;
@@ -201,9 +239,16 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
         if (OUT16) {   // channels 8 gq + 4 h .. + 3 of the lane's pixel = bytes 8 (gq & 1) + 4 h .. of block 2 ct + gq / 2
           const int packed = pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
                                          fq_code_int(vq[3], q2), ubias2);
-          char* yb = reinterpret_cast<char*>(y) + (((int64_t)px.smp * g.CBo + 2 * ct + (gq >> 1)) * plane + px.p) * 16 +
-                     8 * (gq & 1) + 4 * h;
-          *reinterpret_cast<int*>(yb) = packed;
+          if (PART) {                                  // a whole block past Cout (Cout % 32 == 16) does not exist
+            const int blk = 2 * ct + (gq >> 1);
+            const unsigned o16 = (unsigned)((((int64_t)px.smp * g.CBo + (blk < g.CBo ? blk : 0)) * plane + px.p) * 16 +
+                                            8 * (gq & 1) + 4 * h);
+            buf_st_f32(yrp, blk < g.CBo ? o16 : 0x80000000u, 0, __int_as_float(packed));
+          } else {
+            char* yb = reinterpret_cast<char*>(y) + (((int64_t)px.smp * g.CBo + 2 * ct + (gq >> 1)) * plane + px.p) * 16 +
+                       8 * (gq & 1) + 4 * h;
+            *reinterpret_cast<int*>(yb) = packed;
+          }
         }
       }
     }
@@ -292,7 +337,26 @@ bool pw_stream_shape_ok(const PwCall& c) {
   return c.cin % 16 == 0 && c.cout % 32 == 0 && kt_ok && lds <= 72 * 1024;
 }
 
+// the thin instantiations (IN16 / PART): any Cin up to 192, any Cout (a multiple of 16 for a C16 output)
+static bool pw_stream_thin_ok(const PwCall& c) {
+  const int kt = (int)((c.cin + 31) / 32);
+  const int ct = (int)((c.cout + 31) / 32);
+  const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 5 * sizeof(float);
+  static const int thin = env_int("FQ_PWS_THIN", 1);                    // A/B: 0 leaves these shapes to the split form
+  return thin && kt >= 1 && kt <= 6 && lds <= 72 * 1024 && c.stride == 1 && (c.out_thr == nullptr || c.cout % 16 == 0) &&
+         !(c.in_c16 && c.out_thr != nullptr) && !(c.out_thr != nullptr && c.residual != nullptr) &&
+         (c.n * c.hw + 31) / 32 > 4096 && c.n * c.cout * c.hw * 4 < (1ll << 32) && c.n * c.cin * c.hw * 4 < (1ll << 32);
+}
+
 // streaming form: the whole weight matrix in LDS, activations straight from NCHW into MFMA registers
+bool pw_stream_thin_takes(const PwCall& c) {
+  const bool ragged = c.cin % 16 != 0 || c.cout % 32 != 0;
+  const bool c16 = c.in_c16 || c.out_thr != nullptr;
+  // (form 6 is what every C16 call carries; a fp32 call that NAMES the split form gets the split form)
+  const bool form_ok = c.form == 0 || c.form == 3 || (c.form == 6 && c16);
+  return (c.in_c16 || ragged) && pw_stream_thin_ok(c) && form_ok;
+}
+
 int pw_try_stream(const PwCall& c, bool* taken) {
   *taken = false;
   const int kt = (int)((c.cin + 31) / 32);
@@ -300,16 +364,21 @@ int pw_try_stream(const PwCall& c, bool* taken) {
   const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 5 * sizeof(float);
   const bool shape_ok = pw_stream_shape_ok(c);
   const bool out16 = c.out_thr != nullptr;
-  // (C16 output: large planes only - the split form is faster on few tiles and takes partial channel tiles; no C16 input here)
-  if (out16 && !(shape_ok && !c.in_c16 && c.stride == 1 && c.residual == nullptr && (c.n * c.hw + 31) / 32 > 4096)) return FQ_OK;
-  if (!((c.form == 0 || c.form == 3 || out16) && shape_ok) || c.in_c16) {
-    FQ_REQUIRE(c.form != 3, "fq_pwconv_i8: FQ_PW_FORM=3 but the shape does not fit the streaming kernel");
-    return FQ_OK;
+  // the thin instantiations: C16 input, ragged Cin / Cout - large planes only (more than 4096 tiles), where the split form's
+  // one-tile workgroups are all prologue
+  const bool thin = pw_stream_thin_takes(c);
+  // (C16 output: large planes only - the split form is faster on few tiles)
+  if (!thin) {
+    if (out16 && !(shape_ok && !c.in_c16 && c.stride == 1 && c.residual == nullptr && (c.n * c.hw + 31) / 32 > 4096)) return FQ_OK;
+    if (!((c.form == 0 || c.form == 3 || out16) && shape_ok) || c.in_c16) {
+      FQ_REQUIRE(c.form != 3, "fq_pwconv_i8: FQ_PW_FORM=3 but the shape does not fit the streaming kernel");
+      return FQ_OK;
+    }
   }
   PwsGeom s;
   s.Cin = (int)c.cin; s.K = (int)c.cin_pad; s.Cout = (int)c.cout; s.CT = ct; s.HW = (int)c.hw;
   s.cols = c.n * c.hw; s.tiles = (s.cols + 31) / 32; s.zoff = c.zoff;
-  s.CBo = (int)(c.cout / 16); s.out_levels = c.out_levels; s.out_lo_neg = c.out_lo_neg; s.out_zoff = c.out_zoff;
+  s.CBo = (int)(c.cout / 16); s.CBi = (int)((c.cin + 15) / 16); s.out_levels = c.out_levels; s.out_lo_neg = c.out_lo_neg; s.out_zoff = c.out_zoff;
   // persistent workgroups: as many as stay resident (LDS / 2 per SIMD by registers), each wave a contiguous range
   // (measured, tools/pwbench.py: 3 per CU for the 126-VGPR instantiations KT <= 2, 2 above)
   int per_cu = (int)((160 * 1024) / (lds + 1024));
@@ -336,10 +405,37 @@ int pw_try_stream(const PwCall& c, bool* taken) {
     if (out16) FQ_PWS_LAUNCH(KT_, false, true)                                                                         \
     else if (c.residual != nullptr) FQ_PWS_LAUNCH(KT_, true, false) else FQ_PWS_LAUNCH(KT_, false, false)              \
     break;
-  switch (kt) {
-    FQ_PWS_CASE(1) FQ_PWS_CASE(2) FQ_PWS_CASE(3) FQ_PWS_CASE(4) FQ_PWS_CASE(6) FQ_PWS_CASE(8)
-    default: break;
+#define FQ_PWS_THIN(KT_, RES_, O16_, I16_)                                                                             \
+  {                                                                                                                    \
+    static const bool attr_ok =                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_, RES_, O16_, I16_, true>),         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess;                      \
+    FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the streaming kernel");                   \
+    hipLaunchKernelGGL((pwconv_stream_kernel<KT_, RES_, O16_, I16_, true>), dim3((unsigned)grid), dim3(kBlock), lds,   \
+                       c.st, c.x, c.wcodes, c.wscale, (const int*)c.wsum, c.bias, c.y, s, c.in_stat, (int)c.n, c.in_thr, \
+                       c.levels, c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out,         \
+                       c.residual, c.out_thr);                                                                         \
   }
+#define FQ_PWS_THIN_CASE(KT_)                                                                                          \
+  case KT_:                                                                                                            \
+    if (out16) FQ_PWS_THIN(KT_, false, true, false)                                                                    \
+    else if (c.in_c16 && c.residual != nullptr) FQ_PWS_THIN(KT_, true, false, true)                                    \
+    else if (c.in_c16) FQ_PWS_THIN(KT_, false, false, true)                                                            \
+    else if (c.residual != nullptr) FQ_PWS_THIN(KT_, true, false, false) else FQ_PWS_THIN(KT_, false, false, false)    \
+    break;
+  if (thin) {
+    switch (kt) {
+      FQ_PWS_THIN_CASE(1) FQ_PWS_THIN_CASE(2) FQ_PWS_THIN_CASE(3) FQ_PWS_THIN_CASE(4) FQ_PWS_THIN_CASE(5) FQ_PWS_THIN_CASE(6)
+      default: break;
+    }
+  } else {
+    switch (kt) {
+      FQ_PWS_CASE(1) FQ_PWS_CASE(2) FQ_PWS_CASE(3) FQ_PWS_CASE(4) FQ_PWS_CASE(6) FQ_PWS_CASE(8)
+      default: break;
+    }
+  }
+#undef FQ_PWS_THIN_CASE
+#undef FQ_PWS_THIN
 #undef FQ_PWS_CASE
 #undef FQ_PWS_LAUNCH
   FQ_LAUNCH_CHECK();

@@ -145,6 +145,10 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
     if (int rc = pw_try_stream(c, &taken)) return rc;
     if (taken) return FQ_OK;
   }
+  if (!taken && pw_stream_thin_takes(c)) {              // thin layers on large planes (C16 input, ragged Cin / Cout): round 4
+    if (int rc = pw_try_stream(c, &taken)) return rc;
+    if (taken) return FQ_OK;
+  }
   FQ_REQUIRE(c.form != 7, "fq_pwconv_i8: the sample form takes stride 1, no residual, Cout a multiple of 256 and planes that "
              "cut into blocks of 96..128 pixels (Cin 128 ... 1024; a residual operand with 512 channels per workgroup) or whole planes "
              "of 45..64 pixels (Cin 512 / 1024, no residual)");

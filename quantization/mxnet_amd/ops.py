@@ -1091,6 +1091,19 @@ def qconv2d(x, w, wbuf, bias, strides, padding, groups, ws, input_dtype="uint8",
     lo, hi = (float(input_range[0]), float(input_range[1])) if input_range is not None else (0.0, 0.0)
     if bias is not None:
         _check(bias, "bias")
+        if bias.numel() != g[1]:
+            raise ValueError("bias must have %d elements" % g[1])
+    if (bn_scale is None) != (bn_shift is None):
+        raise ValueError("bn_scale and bn_shift go together")
+    for name, t in (("bn_scale", bn_scale), ("bn_shift", bn_shift)):
+        if t is not None:
+            _check(t, name)
+            if t.numel() != g[1]:
+                raise ValueError("%s must have %d elements (got %d)" % (name, g[1], t.numel()))
+    if in_stat is not None:
+        _check(in_stat, "in_stat")
+        if in_stat.numel() != n:
+            raise ValueError("in_stat must have one entry per sample")
     check_call(_lib_().fq_qconv2d_forward(_ptr(x), _ptr(w), _ptr(wbuf), _ptr(bias), _ptr(y), n, cin, h, wd, g[1], g[2], g[3],
                                           g[4], g[5], g[6], g[7], g[8], mode, lo, hi, _ptr(in_stat), _ACTS[act] | zflag,
                                           _ptr(bn_scale), _ptr(bn_shift), _ptr(stat), _ptr(ws), 1 if force_direct else 0,

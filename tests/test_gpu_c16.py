@@ -28,7 +28,10 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-PW_CASES = [(12, 16, 96, 112, 112, 1), (2, 64, 64, 14, 14, 1), (3, 16, 96, 9, 11, 1), (2, 144, 24, 7, 7, 1), (2, 96, 40, 5, 6, 1), (2, 256, 512, 8, 8, 2),
+# (the first five: more than 4096 tiles of 32 pixels - C16 input and ragged channel counts then take the thin instantiations of
+# the streaming form, round 4, instead of one-tile workgroups of the split form; all of them are compared with the split form)
+PW_CASES = [(12, 16, 96, 112, 112, 1), (11, 32, 16, 112, 112, 1), (43, 96, 24, 56, 56, 1), (43, 24, 144, 56, 56, 1),
+            (43, 144, 24, 56, 56, 1), (2, 64, 64, 14, 14, 1), (3, 16, 96, 9, 11, 1), (2, 144, 24, 7, 7, 1), (2, 96, 40, 5, 6, 1), (2, 256, 512, 8, 8, 2),
             (1, 320, 1280, 7, 7, 1), (4, 960, 160, 3, 3, 1), (1, 32, 192, 28, 28, 1)]
 
 
@@ -278,3 +281,40 @@ def test_hooked_blocks_are_never_handed_codes(gpu):
     finally:
         ops.pwconv_i8, ops.conv3x3_i8 = real
         fuse.HANDOVER = True
+
+
+THIN_CASES = [(11, 24, 144, 112, 112), (11, 16, 24, 112, 112), (43, 144, 24, 56, 56), (43, 40, 72, 56, 56), (42, 160, 48, 57, 57)]
+
+
+@pytest.mark.parametrize("case", THIN_CASES, ids=["%dx%d->%d@%dx%d" % c for c in THIN_CASES])
+@pytest.mark.parametrize("mode", ["online_bn_relu6", "offline_res", "signed_bias"])
+def test_thin_streaming_form_equals_the_split_form(dev, ops, case, mode):
+    """fp32 in, fp32 out, channel counts that are no multiples of 16 / 32, on planes with more than 4096 tiles: the shape-based
+    choice is the streaming form's PART instantiation (weights in LDS, persistent wavefronts, clamped loads of the ragged
+    half-slab, dropped stores past Cout); it must equal the split form bit for bit - outputs, per-sample statistic, batch mean."""
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + len(mode))
+    signed = mode == "signed_bias"
+    x = (rng.standard_normal((n, cin, h, w)) * 2).astype(np.float32)
+    if not signed:
+        x = np.maximum(x, 0)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * 0.2).astype(np.float32)
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), cout, 8)
+    flags = ops.act_flags(signed=signed)
+    kw = dict(width=8, flags=flags)
+    if mode == "online_bn_relu6":
+        kw.update(bn_scale=T(rng.uniform(0.3, 1.5, cout).astype(np.float32), dev),
+                  bn_shift=T(rng.standard_normal(cout).astype(np.float32), dev), act="relu6")
+    elif mode == "offline_res":
+        kw.update(in_thr=T(np.float32([2.1]), dev), bn_scale=T(rng.uniform(0.3, 1.5, cout).astype(np.float32), dev),
+                  bn_shift=T(rng.standard_normal(cout).astype(np.float32), dev),
+                  residual=T((rng.standard_normal((n, cout, h, w)) * 3).astype(np.float32), dev))
+    else:
+        kw.update(bias=T(rng.standard_normal(cout).astype(np.float32), dev), act="relu")
+    stat_in = T(O.absmax_per_sample(x), dev)
+    cur_a, cur_b = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    bias = kw.pop("bias", None)
+    want, want_stat = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, bias, form="split", in_stat=stat_in, cur_out=cur_a, **kw)
+    got, got_stat = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, bias, in_stat=stat_in, cur_out=cur_b, **kw)
+    assert torch.equal(got, want)
+    assert torch.equal(got_stat, want_stat) and torch.equal(cur_a, cur_b)

@@ -17,6 +17,7 @@ def _randomise_bn(net, rng, ctx):
     def visit(b):
         if type(b) is nn.BatchNorm:
             c = b.gamma.shape[0]
+            assert c > 0, "BatchNorm without a known width (give in_channels)"
             b.gamma.set_data(mx.nd.array((rng.random(c) + 0.5).astype(np.float32), ctx=ctx))
             b.beta.set_data(mx.nd.array((rng.standard_normal(c) * 0.3).astype(np.float32), ctx=ctx))
             b.running_mean.set_data(mx.nd.array((rng.standard_normal(c) * 0.2).astype(np.float32), ctx=ctx))
@@ -125,9 +126,9 @@ def test_a_recomputed_layer_invalidates_its_statistic(gpu):
     rng = np.random.default_rng(8)
     seq = nn.HybridSequential()
     seq.add(Conv2D(32, 3, 1, 1, in_channels=32, groups=32, use_bias=False, quantized=True, input_dtype="uint8",
-                   weight_dtype="int8"), nn.BatchNorm(), nn.Activation("relu"),
+                   weight_dtype="int8"), nn.BatchNorm(in_channels=32), nn.Activation("relu"),
             Conv2D(64, 1, 1, 0, in_channels=32, use_bias=False, quantized=True, input_dtype="uint8", weight_dtype="int8"),
-            nn.BatchNorm(), nn.Activation("relu"))
+            nn.BatchNorm(in_channels=64), nn.Activation("relu"))
     seq.initialize(mx.init.Xavier(), ctx=gpu)
     _randomise_bn(seq, rng, gpu)
     seq[0]._input_range = (1.0, 2.0)
@@ -155,9 +156,9 @@ def test_an_unpadded_consumer_of_a_tensor_without_zeros_takes_its_true_minimum(g
     rng = np.random.default_rng(12)
     seq = nn.HybridSequential()
     seq.add(Conv2D(64, 1, 1, 0, in_channels=32, use_bias=False, quantized=True, input_dtype="uint8", weight_dtype="int8"),
-            nn.BatchNorm(), RELU6(),
+            nn.BatchNorm(in_channels=64), RELU6(),
             Conv2D(96, 1, 1, 0, in_channels=64, use_bias=False, quantized=True, input_dtype="uint8", weight_dtype="int8"),
-            nn.BatchNorm(), nn.Activation("relu"))
+            nn.BatchNorm(in_channels=96), nn.Activation("relu"))
     seq.initialize(mx.init.Xavier(), ctx=gpu)
     _randomise_bn(seq, rng, gpu)
     seq[1].beta.set_data(mx.nd.array(np.full(64, 4.0, np.float32), ctx=gpu))       # everything lands in (0, 6]
