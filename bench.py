@@ -491,6 +491,25 @@ def main():
     # launch-latency-sensitive (1.3 ms of kernels); replay removes the host from the loop.  The steps that carry the kernel
     # events of the roofline leg (every `event_every`-th) still run eagerly INSIDE the timed region.
     graphs, graph_error = None, None
+    if args.graph and args.phase == "calib-naive" and not distributed:
+        # one process: the calibration step (forward with online scales + net.update_ema()) holds no collective and no host
+        # synchronisation, so it replays from a hipGraph like the evaluation step does - launching its ~100 kernels from
+        # Python takes longer than running them (2.5 ms against ~1.5 ms for MobileNetV2).  With several ranks the step's
+        # all-reduce stays outside any capture (dist.py refuses one inside) and the step launches eagerly.
+        try:
+            graphs = [[None] * rotate]
+            pool = torch.cuda.graph_pool_handle()
+            for b in range(rotate):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    step(b)
+                graphs[0][b] = g
+            for b in range(rotate):
+                graphs[0][b].replay()
+            torch.cuda.synchronize()
+        except Exception as e:
+            graphs, graph_error = None, "%s: %s" % (type(e).__name__, str(e)[:200])
+            torch.cuda.synchronize()
     if args.graph and args.phase == "eval":
         try:
             # one graph per (stream, resident batch): a forward's per-stream buffers are baked into its graph, so a graph is
@@ -669,7 +688,8 @@ def main():
             flavour += ", Winograd-domain %s weights" % args.wino
         what_step = {"eval": "eval forward + accuracy counters",
                      "calib-naive": "naive-EMA calibration step: forward with ONLINE scales, weights re-quantised every "
-                                    "forward (fixed_params = -1), then net.update_ema()",
+                                    "forward (fixed_params = -1; the library keeps the result while the parameter is "
+                                    "unchanged), then net.update_ema()" + (" - replayed from a hipGraph" if graphs else ""),
                      "calib-kl": "KL calibration batch: forward with quantisation disabled + one 2048-bin histogram per "
                                  "quantised block (collect_feature_maps, ranges fixed by the first batch)"}[args.phase]
         metric_head = {"eval": "images/sec int8-sim", "calib-naive": "images/sec naive-EMA calibration of int8-sim",

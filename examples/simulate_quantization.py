@@ -312,7 +312,9 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
     on_gpu = dev.type == "cuda"
     n_lanes = streams if streams > 1 and not update_ema and on_gpu else 1
     lanes = [_Lane(dev, torch.cuda.Stream(dev) if n_lanes > 1 else None) for _ in range(n_lanes)] if on_gpu else None
-    graph = bool(graph) and on_gpu and not update_ema and hasattr(net, "_fq_arena_hooks")
+    # (a calibration pass replays too when no process group exists: its step - forward with online scales + update_ema -
+    # holds no collective and no host synchronisation; with a group the step's all-reduce must stay outside any capture)
+    graph = bool(graph) and on_gpu and hasattr(net, "_fq_arena_hooks") and not (update_ema and fqdist.group_is_live())
     head = _fuse.eval_head(net, counters) if on_gpu else None
     replayed = 0
     resident = bool(getattr(dataloader, "resident_batches", False))
@@ -342,7 +344,7 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
                             t.record_stream(side)
                 with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), \
                         (ops.batches_in_flight() if side is not None else contextlib.nullcontext()):
-                    if graph and done >= n_lanes and lane.replay(X._t, y._t, step, resident):
+                    if graph and done >= n_lanes and lane.replay(X._t, y._t, step, resident and not update_ema):
                         labels = y._t
                         replayed += 1
                     else:
@@ -508,7 +510,7 @@ class Simulation(object):
         for epoch in range(1, opt.calib_epoch + 1):
             net.quantize_input(enable=True, online=True)      # integer inputs and weights, ranges from the current batch
             evaluate(net, self.classes, self.train_loader, ctx=self.ctx, update_ema=True,
-                     tqdm_desc="Calib[{}/{}]".format(epoch, opt.calib_epoch))
+                     tqdm_desc="Calib[{}/{}]".format(epoch, opt.calib_epoch), graph=opt.eval_graph)
             if opt.eval_per_calib:
                 if self.collective:
                     fqdist.detach_calibration_sync(net)       # offline evaluation exchanges nothing per batch
