@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-4 evidence in one GPU call (run from the repo root on the GPU box): everything tools/refresh_all.sh collects (default
+# workload: rocprofv3 tables with the headline-tensor kernels, PMC traffic incl. the headline tensor, events-vs-rocprof check,
+# other BASELINE configurations, SQ counters, calibration kernels, host baseline), the calibration phases end to end, and the
+# round's additions: the nn.Conv2D(quantized=True) MobileNet (bench line with cpu_baseline, its --no-fuse line, a one-stream
+# rocprofv3 kernel table, the epilogue ablation), CLI vs bench.py, MobileNetV2 with and without the thin streaming form.
+# Copy what should be judged from gpurun_out/refresh*/ into profiles/.
+set -u
+TAG=${1:-r4}
+R=$(pwd); O=$R/gpurun_out/refresh
+bash tools/refresh_all.sh $TAG > gpurun_out/refresh_all.log 2>&1
+bash tools/calib_lines.sh $TAG > gpurun_out/refresh_calib.log 2>&1
+python3 bench.py --model quantized_mobilenet1.0 > $O/${TAG}_qconv_line.json 2> $O/qconv.err
+python3 bench.py --model quantized_mobilenet1.0 --no-fuse --no-cpu-baseline --no-headline > $O/${TAG}_qconv_nofuse_line.json 2>> $O/qconv.err
+python3 bench.py --model quantized_mobilenet1.0 --streams 1 --graph 0 --no-cpu-baseline --no-headline > $O/${TAG}_qconv_line_one_stream.json 2>> $O/qconv.err
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_q -o bench -- python3 $R/bench.py --model quantized_mobilenet1.0 --steps 100 --warmup 5 --streams 1 --graph 0 --no-cpu-baseline --no-headline > $O/${TAG}_qconv_line_one_stream_under_rocprof.json 2>> $O/qconv.err )
+cp $(find $O/trace_q -name '*kernel_stats.csv' | head -1) $O/${TAG}_qconv_kernel_stats.csv; rm -rf $O/trace_q
+python3 tools/check_events_vs_rocprof.py $O/${TAG}_qconv_line_one_stream.json $O/${TAG}_qconv_kernel_stats.csv --steps-from stem_mfma > $O/${TAG}_qconv_events_vs_rocprof.txt 2>&1
+python3 tools/qconv_ablate.py > $O/${TAG}_qconv_ablate.txt 2>&1
+bash tools/cli_vs_bench.sh > $O/${TAG}_cli_vs_bench.txt 2>&1
+for v in 1 0; do
+  FQ_PWS_THIN=$v python3 bench.py --model mobilenetv2_1.0 --quant-type channel --weight-bits 4 --offline --steps 200 --no-cpu-baseline --no-headline 2>/dev/null | python3 -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=l['roofline']['kernels']
+print('FQ_PWS_THIN=$v mobilenetv2_1.0 offline:', l['value'], 'images/s', l['ms_per_step'], 'ms/step', {n:(round(v['ms_per_step'],3), v['frac']) for n,v in k.items()})" >> $O/${TAG}_thin_ab.txt
+done
+ls -la $O | head -80
