@@ -116,7 +116,7 @@ def test_config3_resnet50_per_channel_offline_kl_as_stated(gpu):
     net = _build("resnet50_v1", gpu, quant_type="channel")
     blocks = net.collect_quantized_blocks()
     assert len(blocks) == 53
-    # -- collect: two calibration batches; the oracle histograms every block input as it goes by
+    # -- collect: two calibration batches of 128 (5.1 GB of block inputs each); the oracle histograms every block input as it goes by
     want_hist, want_max = {}, {}
 
     def watch(m, args):
@@ -126,7 +126,7 @@ def test_config3_resnet50_per_channel_offline_kl_as_stated(gpu):
             want_hist[m] = np.zeros(2048, np.uint64)
         H.histogram_accumulate(fm, want_max[m], 2048, want_hist[m])
     hooks = [b.register_forward_pre_hook(watch) for b in blocks]
-    loader = [(_images(gpu, 100 + i, (32, 3, 224, 224)), None) for i in range(2)]
+    loader = [(_images(gpu, 100 + i, (128, 3, 224, 224)), None) for i in range(2)]     # the CLI's batch size (:81)
     net.disable_quantize()
     hists, maxes = collect_feature_maps(net, 2048, loader, gpu)
     for h in hooks:
