@@ -367,6 +367,9 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
         def run(self):
             try:
                 torch.cuda.set_device(dev)
+                # every THREAD launches its first batch eagerly: a tensor-library convolution (MobileNetV2's classifier) met
+                # for the first time by a thread inside a capture - its handle, its solver search - takes the process down
+                self.lane.eager_done = 0
                 with torch.cuda.stream(self.lane.stream), ops.batches_in_flight():
                     while True:
                         item = self.q.get()
