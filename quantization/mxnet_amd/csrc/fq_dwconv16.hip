@@ -83,10 +83,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
       const bool ok = rok && col >= 0 && col < g.W;
       unsigned d = zero_code;
       if (ok) d = xin[((size_t)r * g.W + col) * 4u];
-#pragma unroll
+      if (!SIGNED_IN) d ^= 0x80808080u;                                 // stored bytes -> codes 0..255, ONE instruction per dword:
+#pragma unroll                                                          // (float)((d >> 8c) & 255) is then a single v_cvt_f32_ubyte<c>
       for (int c = 0; c < 4; ++c) {
         const unsigned byte = (d >> (8 * c)) & 255u;
-        const float code = SIGNED_IN ? (float)(int)(int8_t)byte : (float)(byte ^ 0x80u);
+        const float code = SIGNED_IN ? (float)(int)(int8_t)byte : (float)byte;
         row.v[k][c] = code * sx;
       }
     }
@@ -101,11 +102,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
     load_row(-1, ra);                                                   // (the code-0 pattern dequantises to 0)
     load_row(0, rb);
   }
+  if (S == 2) load_row(-1, ra);
+  // the consumer's quantiser: the 5-instruction form (and the mask-free packing) when its quotients cannot be negative - an
+  // unsigned output range from 0, every ReLU / ReLU6 layer - decided once per launch (fq_common.h: fq_nonneg)
+  const bool nn2 = fq_nonneg(q2);
+  const unsigned nn_xor2 = fq_nonneg_xor(ubias2);
   for (int r = 0; r < g.Ho; ++r) {
     if (S == 1) {
       load_row(r + 1, rc);
-    } else {
-      load_row(2 * r - 1, ra);
+    } else {                                                            // (row 2r - 1 is the previous output row's 2r' + 1)
       load_row(2 * r, rb);
       load_row(2 * r + 1, rc);
     }
@@ -129,13 +134,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
       m = fmaxf(m, fabsf(acc));
     }
     if (lane_ok) {
-      const int packed = pack4_codes(fq_code_int(v[0], q2), fq_code_int(v[1], q2), fq_code_int(v[2], q2),
-                                     fq_code_int(v[3], q2), ubias2);
+      const int packed = nn2 ? fq_pack4<true>(v[0], v[1], v[2], v[3], q2, ubias2, nn_xor2)
+                             : fq_pack4<false>(v[0], v[1], v[2], v[3], q2, ubias2, nn_xor2);
       yout[((size_t)r * g.Wo + xo) * 4u] = (unsigned)packed;
     }
     if (S == 1) {
       ra = rb;
       rb = rc;
+    } else {
+      ra = rc;
     }
   }
   if (stat_out != nullptr) {
