@@ -4,6 +4,13 @@
 // rules; the C16 layout: include/fakequant.h at fq_pwconv_i8_c16)
 #include "fq_common.h"
 
+// tuning build: -DFQ_DW16_V=<bits>  1: unconditional loads from clamped addresses + select (62 exec-masked loads otherwise),
+// 2: stride 2 keeps the row it shares with the next output row, 4: the short quantiser for non-negative output ranges.
+// Default: all three (r4: 526 -> 473 us over MobileNetV2's ten depthwise shapes at batch 128, tools/dw16bench.py)
+#ifndef FQ_DW16_V
+#define FQ_DW16_V 7
+#endif
+
 namespace {
 
 using namespace fqi;
@@ -82,12 +89,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
       const int col = xc + k - 1;
       const bool ok = rok && col >= 0 && col < g.W;
       unsigned d = zero_code;
-      if (ok) d = xin[((size_t)r * g.W + col) * 4u];
-      if (!SIGNED_IN) d ^= 0x80808080u;                                 // stored bytes -> codes 0..255, ONE instruction per dword:
-#pragma unroll                                                          // (float)((d >> 8c) & 255) is then a single v_cvt_f32_ubyte<c>
+      if (FQ_DW16_V & 1) {
+        // every load unconditional, from an address clamped into the plane, the padding selected afterwards: a load under a
+        // lane condition is an exec-masked branch of its own (62 of them in this kernel's ISA) with a wait behind it
+        const int rr = r < 0 ? 0 : (r < g.H ? r : g.H - 1), cc = col < 0 ? 0 : (col < g.W ? col : g.W - 1);
+        const unsigned t = xin[((size_t)rr * g.W + cc) * 4u];
+        d = ok ? t : zero_code;
+      } else if (ok) {
+        d = xin[((size_t)r * g.W + col) * 4u];
+      }
+#pragma unroll
       for (int c = 0; c < 4; ++c) {
         const unsigned byte = (d >> (8 * c)) & 255u;
-        const float code = SIGNED_IN ? (float)(int)(int8_t)byte : (float)byte;
+        const float code = SIGNED_IN ? (float)(int)(int8_t)byte : (float)(byte ^ 0x80u);
         row.v[k][c] = code * sx;
       }
     }
@@ -102,15 +116,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
     load_row(-1, ra);                                                   // (the code-0 pattern dequantises to 0)
     load_row(0, rb);
   }
-  if (S == 2) load_row(-1, ra);
-  // the consumer's quantiser: the 5-instruction form (and the mask-free packing) when its quotients cannot be negative - an
-  // unsigned output range from 0, every ReLU / ReLU6 layer - decided once per launch (fq_common.h: fq_nonneg)
-  const bool nn2 = fq_nonneg(q2);
+  if (S == 2 && (FQ_DW16_V & 2)) load_row(-1, ra);
+  const bool nn2 = (FQ_DW16_V & 4) && fq_nonneg(q2);
   const unsigned nn_xor2 = fq_nonneg_xor(ubias2);
   for (int r = 0; r < g.Ho; ++r) {
     if (S == 1) {
       load_row(r + 1, rc);
-    } else {                                                            // (row 2r - 1 is the previous output row's 2r' + 1)
+    } else {
+      if (!(FQ_DW16_V & 2)) load_row(2 * r - 1, ra);                    // (else: the previous output row's 2r' + 1, kept)
       load_row(2 * r, rb);
       load_row(2 * r + 1, rc);
     }
@@ -135,13 +148,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
     }
     if (lane_ok) {
       const int packed = nn2 ? fq_pack4<true>(v[0], v[1], v[2], v[3], q2, ubias2, nn_xor2)
-                             : fq_pack4<false>(v[0], v[1], v[2], v[3], q2, ubias2, nn_xor2);
+                             : pack4_codes(fq_code_int(v[0], q2), fq_code_int(v[1], q2), fq_code_int(v[2], q2),
+                                           fq_code_int(v[3], q2), ubias2);
       yout[((size_t)r * g.Wo + xo) * 4u] = (unsigned)packed;
     }
     if (S == 1) {
       ra = rb;
       rb = rc;
-    } else {
+    } else if (FQ_DW16_V & 2) {
       ra = rc;
     }
   }
