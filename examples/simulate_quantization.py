@@ -22,9 +22,7 @@ and seeded weights when ImageNet / gluoncv checkpoints are absent (there is no n
 import argparse
 import contextlib
 import os
-import queue
 import sys
-import threading
 import time
 
 import numpy as np
@@ -252,7 +250,7 @@ class _Lane(object):
             side.wait_stream(torch.cuda.current_stream(self.dev))
         try:
             with torch.cuda.stream(side):
-                g.capture_begin(capture_error_mode="thread_local")    # (other lanes replay from their own threads meanwhile)
+                g.capture_begin(capture_error_mode="thread_local")
                 try:
                     step(xbuf, ybuf)
                 finally:
@@ -266,9 +264,8 @@ class _Lane(object):
             return None
         return g
 
-    def replay(self, x, y, step, resident, lock=None):
-        """True when the batch (x: fp32 tensor on the host or the device, y: labels of any dtype) went through a graph.
-        `lock`: held while a capture runs the net's Python forward (lanes may be driven by threads of their own)."""
+    def replay(self, x, y, step, resident):
+        """True when the batch (x: fp32 tensor on the host or the device, y: labels of any dtype) went through a graph."""
         if self.failed or self.eager_done == 0:
             return False
         if self.full_shape is None:
@@ -281,13 +278,12 @@ class _Lane(object):
         if ent is None:
             if len(self.graphs) >= self.MAX_GRAPHS:
                 return False
-            with (lock if lock is not None else contextlib.nullcontext()):
-                xbuf = x if in_place else torch.empty(x.shape, dtype=torch.float32, device=self.dev)
-                ybuf = torch.empty(y.shape, dtype=torch.long, device=self.dev)
-                if not in_place:
-                    xbuf.copy_(x, non_blocking=True)
-                ybuf.copy_(y, non_blocking=True)
-                g = self._capture(xbuf, ybuf, step)
+            xbuf = x if in_place else torch.empty(x.shape, dtype=torch.float32, device=self.dev)
+            ybuf = torch.empty(y.shape, dtype=torch.long, device=self.dev)
+            if not in_place:
+                xbuf.copy_(x, non_blocking=True)
+            ybuf.copy_(y, non_blocking=True)
+            g = self._capture(xbuf, ybuf, step)
             if g is None:
                 return False
             ent = self.graphs[key] = (g, xbuf, ybuf)
@@ -334,7 +330,6 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
             ops.eval_counters(logits._t, labels, counters)
 
     producer = torch.cuda.current_stream(dev) if on_gpu else None      # the stream the loader's device work is issued on
-    eager_lock = threading.Lock()        # Python forwards (eager steps, captures) of ONE net run one at a time; replays do not
 
     def run_batch(lane, X, y, index):
         """One batch on its lane (called with the lane's stream current).  Returns True when it went through a graph."""
@@ -347,60 +342,23 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
             for t in (X._t, y._t):
                 if t.is_cuda:
                     t.record_stream(side)
-        if graph and index >= n_lanes and lane.replay(X._t, y._t, step, resident and not update_ema, eager_lock):
+        if graph and index >= n_lanes and lane.replay(X._t, y._t, step, resident and not update_ema):
             return True
-        with eager_lock:
-            step(X.as_in_context(ctx)._t, y.as_in_context(ctx)._t.long())
+        step(X.as_in_context(ctx)._t, y.as_in_context(ctx)._t.long())
         if lane is not None:
             lane.eager_done += 1
         return False
 
-    class _Worker(threading.Thread):
-        """A lane's launches from a host thread of its own: replaying a graph of ~100 kernel nodes keeps the host busy for most
-        of the millisecond the GPU needs to run it, so three lanes fed from ONE thread are host-bound (MobileNetV2: 97 k
-        images/s against 122 k with a thread per lane; hipGraphLaunch releases the interpreter lock)."""
-
-        def __init__(self, lane):
-            super(_Worker, self).__init__(daemon=True)
-            self.lane, self.q, self.error, self.replays = lane, queue.Queue(maxsize=2), None, 0
-
-        def run(self):
-            try:
-                torch.cuda.set_device(dev)
-                # every THREAD launches its first batch eagerly: a tensor-library convolution (MobileNetV2's classifier) met
-                # for the first time by a thread inside a capture - its handle, its solver search - takes the process down
-                self.lane.eager_done = 0
-                with torch.cuda.stream(self.lane.stream), ops.batches_in_flight():
-                    while True:
-                        item = self.q.get()
-                        if item is None:
-                            return
-                        if self.error is None:
-                            self.replays += bool(run_batch(self.lane, *item))
-            except BaseException as e:               # noqa: B902 - handed to the main thread, which re-raises it
-                self.error = e
-                while self.q.get() is not None:      # keep draining so that the producer never blocks on a dead lane
-                    pass
-
-    workers = []
     try:
         with tqdm(total=len(dataloader), desc=tqdm_desc, disable=fqdist.rank() != 0) as bar:
             for X, y in dataloader:
+                # ONE host thread feeds every lane: a replay costs it 0.04 ms against the ~1 ms the GPU needs per batch (a
+                # thread per lane was measured: 126.2 k vs 127.3 k images/s on MobileNetV2, tools/cli_lane_probe.py)
                 lane = lanes[done % n_lanes] if lanes else None
-                if n_lanes > 1 and done >= 1:
-                    if not workers:
-                        workers = [_Worker(ln) for ln in lanes]
-                        for w in workers:
-                            w.start()
-                    w = workers[done % n_lanes]
-                    if w.error is not None:
-                        raise w.error
-                    w.q.put((X, y, done))
-                else:
-                    side = lane.stream if lane is not None else None
-                    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), \
-                            (ops.batches_in_flight() if side is not None else contextlib.nullcontext()):
-                        replayed += bool(run_batch(lane, X, y, done))
+                side = lane.stream if lane is not None else None
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), \
+                        (ops.batches_in_flight() if side is not None else contextlib.nullcontext()):
+                    replayed += bool(run_batch(lane, X, y, done))
                 seen += int(y._t.numel())
                 done += 1
                 bar.update(1)
@@ -409,16 +367,8 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
                     # by the forwards on the other streams: wait for it
                     torch.cuda.synchronize(dev)
     finally:
-        for w in workers:
-            w.q.put(None)
-        for w in workers:
-            w.join()
         if head is not None:
             head.release()
-    for w in workers:
-        if w.error is not None:
-            raise w.error
-        replayed += w.replays
     while steps is not None and done < steps:          # this rank's shard ran out first: keep the collectives in step
         fqdist.empty_calibration_step(net)
         done += 1

@@ -121,9 +121,12 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
     for (int i = 0; i < 16; ++i) v[i] = buf_ld_f32(xr, xo, (unsigned)(kt * 32 + i) * plane4);
   };
   float bufa[16], bufb[16];
+  PW_STAMP(0);
+  const ThresholdReq treq = threshold_request(in_stat, n, in_thr, item == 0);   // first in the memory queue (fq_common.h)
+  FQ_PIN();
   if (wave < NU) issue(wave, bufa);                                     // in flight during the set-up
   FQ_PIN();
-  const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, item == 0);
+  const float max_ = threshold_finish(treq, in_stat, n, in_thr, cur_max_out, item == 0);
   int zoff = g.zoff;
   const QParams q = make_qparams_rt(max_, levels, lo_neg_max, eps, in_thr, zoff);
   const float sx = q.scale;
@@ -172,8 +175,10 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
       }
     }
   };
+  PW_STAMP(6);
   if (fq_nonneg(q)) fill_panel(std::true_type{});
   else fill_panel(std::false_type{});
+  PW_STAMP(7);
 
   // ---- 2. this wavefront's channel tile x PTW pixel tiles ---------------------------------------------------------------
   const int wc = wave % WC, wp = wave / WC;
@@ -212,7 +217,9 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
     rbase[t] = (unsigned)((int)j - jr0) * (unsigned)g.ROW + 16u * h;
   }
   FQ_PIN();
+  PW_STAMP(1);
   __syncthreads();                                                      // panel, constants and the statistic table
+  PW_STAMP(2);
   const int cvalid = g.Cout - (ch0 + wc * 32);                          // valid channels of this wavefront's tile
   const int zb = stored_zero4(ubias);                                   // four codes "0" in the stored representation
   auto run = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
         FQ_PIN();
       }
     }
+    PW_STAMP(3);
     // ---- 3. epilogue (K2m): lane = pixel, channels past Cout masked through out-of-range offsets ----------------------
     int64_t y_bytes = (n_samp - s_base) * y_samp - (int64_t)(ch0 + wc * 32) * plane4;
     y_bytes = y_bytes < 0x7FFFFFFFll ? y_bytes : 0x7FFFFFFFll;
@@ -349,11 +357,13 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
     run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
   else
     run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});
+  PW_STAMP(4);
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < cols / HW)
       FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
   }
+  PW_STAMP(5);
 }
 
 

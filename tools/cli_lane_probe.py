@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Why does the CLI's replayed evaluation of MobileNetV2 (three lanes) run at 97 k images/s when bench.py's runs at 122 k?
-Builds the CLI's net, captures its step per (lane, batch) as the CLI does, then times the SAME replays under loops of increasing
-resemblance to `evaluate`'s: bare round-robin replays; + wait_stream / record_stream per batch; + both context managers."""
+"""The CLI's replayed evaluation of MobileNetV2 against bare replays of the same graphs: `evaluate` at two loader lengths (the
+MARGINAL rate is the steady state; the rest is what a pass pays once: eager first batches, captures), then the same step
+captured per (lane, batch) and replayed under loops of increasing resemblance to `evaluate`'s - bare round-robin replays;
++ wait_stream / record_stream per batch; + both context managers.  r4: evaluate 127.3 k images/s marginal (fixed cost 23 ms per
+pass, ~100 ms more in a process's first pass), bare replays 126.8 k; one lane 85 k; a host thread per lane changed nothing."""
 import importlib.util
 import os
 import sys
@@ -32,7 +34,7 @@ sim.make_loaders()
 sim.calibrate_naive()
 sim.final_evaluation(online=False)                # the CLI's own figure (200 batches)
 print("CLI evaluate: %.0f images/s" % cli.evaluate.last_images_per_sec)
-for streams, graph in ((3, True), (1, True)):
+for streams, graph in ((3, True), (3, False), (1, True)):
     t = {}
     for images in (25600, 128000):
         os.environ["FQ_SYNTH_VAL_IMAGES"] = str(images)
@@ -41,8 +43,8 @@ for streams, graph in ((3, True), (1, True)):
         t0 = time.perf_counter()
         cli.evaluate(sim.net, 1000, sim.eval_loader, ctx, streams=streams, graph=graph, tqdm_desc="probe")
         t[images] = time.perf_counter() - t0
-    print("evaluate(streams=%d): %d images in %.3f s, %d in %.3f s -> marginal %.0f images/s, fixed cost %.0f ms"
-          % (streams, 25600, t[25600], 128000, t[128000], (128000 - 25600) / (t[128000] - t[25600]),
+    print("evaluate(streams=%d, graph=%d): %d images in %.3f s, %d in %.3f s -> marginal %.0f images/s, fixed cost %.0f ms"
+          % (streams, graph, 25600, t[25600], 128000, t[128000], (128000 - 25600) / (t[128000] - t[25600]),
              (t[25600] - 25600 * (t[128000] - t[25600]) / (128000 - 25600)) * 1e3))
 net = sim.net
 counters = torch.zeros(2002, device=dev)

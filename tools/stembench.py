@@ -1,17 +1,30 @@
 #!/usr/bin/env python3
-"""Timing of fq_stem_conv3x3s2 at the benchmark shape (128, 3, 224, 224) -> (128, 32, 112, 112)."""
+"""The first convolutions alone (batch 128, 224x224): 3x3 -> 32 (MobileNets) and 7x7 -> 64 (ResNets), median of 40 launches.
+FQ_LIB_PATH selects a variant library (csrc/build.py --only fq_stem -DFQ_STEM_CH=.. -DFQ_STEM_LB7=..); FQ_STEM_WG_PER_CU the grid."""
 import os
 import sys
+
 import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quantization.mxnet_amd import ops  # noqa: E402
-from kbench import timeit  # noqa: E402
+
 dev = torch.device("cuda", 0)
-torch.manual_seed(1)
-x = torch.randn(128, 3, 224, 224, device=dev)
-w = torch.randn(32, 3, 3, 3, device=dev) * 0.2
-wt = w.permute(1, 2, 3, 0).contiguous()
-sc, sh = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev)
-med, _ = timeit(lambda: ops.stem_conv3x3s2(x, w, bn_scale=sc, bn_shift=sh, act="relu", w_tap_major=wt), 30)
-nbytes = 4 * (x.numel() + 128 * 32 * 112 * 112)
-print("stem 3->32 s2 @224: %.1f us  %.0f GB/s" % (med * 1e3, nbytes / med / 1e6))
+out = []
+for ks, cout in ((3, 32), (7, 64)):
+    x = torch.randn(128, 3, 224, 224, device=dev)
+    w = torch.randn(cout, 3, ks, ks, device=dev) * 0.2
+    sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+    fn = lambda: ops.stem_conv_s2(x, w, None, bn_scale=sc, bn_shift=sh, act="relu")
+    for _ in range(4):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    out.append("%dx%d -> %d: %.1f us" % (ks, ks, cout, sorted(a.elapsed_time(b) for a, b in ev)[20] * 1e3))
+print("%-30s wg/cu %s | %s" % (os.environ.get("FQ_LIB_PATH", "(default)")[-30:], os.environ.get("FQ_STEM_WG_PER_CU", "-"),
+                              "  ".join(out)))
