@@ -770,6 +770,15 @@ def main():
                                  "what": "fq_kl_search over all layers' histograms in one launch + the read-back of "
                                          "best_bins, once per calibration (outside the per-batch figure)",
                                  "thresholds_first_last": [round(thresholds[0], 6), round(thresholds[-1], 6)]}
+            from quantization.mxnet_amd.quantize import distribution_calibrate as _dc
+            lib_ms = sum(k["ms_per_step"] for k in line["roofline"]["kernels"].values())
+            line["split"] = {"this_library_ms_per_step": round(lib_ms, 4),
+                             "tensor_library_and_host_ms_per_step": round(line["ms_per_step"] - lib_ms, 4),
+                             "histograms_in_the_producers_pass": bool(_dc.FUSED_HISTOGRAMS),
+                             "what": "this library: BatchNorm / residual passes (which bin what they store from a collection's "
+                                     "second batch on, FQ_KL_FUSED_HIST=0 switches that off), remaining histogram passes, first-batch "
+                                     "ranges, first convolution, pooling - HIP events on sampled batches; the rest of the batch: "
+                                     "the fp32 convolutions of the un-quantised forward (MIOpen / rocBLAS) and launch gaps"}
         if world == 1 and not args.no_headline and args.phase == "eval":
             line["headline_tensor"] = headline_tensor(dev, ops)
         if world == 1:

@@ -162,6 +162,18 @@ int fq_bn_act_maxpool_stat(const float* x, float* y, int64_t n, int64_t c, int64
 int fq_add_act_stat(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
                     fqStream_t stream);
 
+/* The two producers above while the KL calibration collects feature maps (/root/reference/quantize/distribution_calibrate.py:
+ * 91-106: every quantised block's input is histogrammed once per batch, its range fixed by the first batch, :97-101): the
+ * pass that stores y also adds y's histogram to `hist` - what fq_histogram_accumulate(y, n * inner, hist_max, bins, hist,
+ * neg_count) would add in a pass of its own (4 B/elem read back), same binning, same counts.  stat_out is required here;
+ * bins <= 4096.  The first batch of a collection still takes the separate passes (fq_global_max must see the whole tensor
+ * before anything can be binned).                                                                                        */
+int fq_bn_act_stat_hist(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                        const float* shift, int act, float* stat_out, const float* hist_max, int bins, uint64_t* hist,
+                        uint32_t* neg_count, fqStream_t stream);
+int fq_add_act_stat_hist(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
+                         const float* hist_max, int bins, uint64_t* hist, uint32_t* neg_count, fqStream_t stream);
+
 /* Global average pooling (gluon GlobalAvgPool2D -> F.Pooling(global_pool=True, pool_type='avg'), the block in front of
  * the classifier of every model of the zoo) with the per-sample statistic the following quantised Dense needs
  * (convert_dense.py:40-41): x (n, c, hw) -> y (n, c) = fp32(sum over hw accumulated in fp64, in order) / fp32(hw);

@@ -51,6 +51,12 @@ int fq_bn_act_maxpool_stat_host(const float* x, float* y, int64_t n, int64_t c, 
                                 const float* scale, const float* shift, int act, float* stat_out, fqStream_t stream);
 int fq_add_act_stat_host(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
                          fqStream_t stream);
+/* (the producers that bin what they store: by definition the pass above followed by fq_histogram_accumulate_host over y) */
+int fq_bn_act_stat_hist_host(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                             const float* shift, int act, float* stat_out, const float* hist_max, int bins, uint64_t* hist,
+                             uint32_t* neg_count, fqStream_t stream);
+int fq_add_act_stat_hist_host(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
+                              const float* hist_max, int bins, uint64_t* hist, uint32_t* neg_count, fqStream_t stream);
 int fq_global_avg_pool_stat_host(const float* x, float* y, int64_t n, int64_t c, int64_t hw, int flags,
                                  float* stat_out, fqStream_t stream);
 int fq_gemm_i8_codes_host(const int8_t* xcodes, const int8_t* wcodes, const int32_t* wsum, int32_t* out, int64_t n,

@@ -1060,6 +1060,23 @@ int fq_histogram_accumulate_host(const float* x, int64_t numel, const float* max
   return FQ_OK;
 }
 
+// the producers that bin what they store (fq_bn_act_stat_hist / fq_add_act_stat_hist): the plain pass, then the histogram of
+// its result - which is what the device forms are defined to equal
+int fq_bn_act_stat_hist_host(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                             const float* shift, int act, float* stat_out, const float* hist_max, int bins, uint64_t* hist,
+                             uint32_t* neg_count, fqStream_t stream) {
+  REQUIRE(stat_out && hist_max && hist && bins > 0 && bins <= 4096, "fq_bn_act_stat_hist_host: bad arguments");
+  if (int rc = fq_bn_act_stat_host(x, y, n, c, hw, scale, shift, act, stat_out, stream)) return rc;
+  return fq_histogram_accumulate_host(y, n * c * hw, hist_max, bins, hist, neg_count, stream);
+}
+
+int fq_add_act_stat_hist_host(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
+                              const float* hist_max, int bins, uint64_t* hist, uint32_t* neg_count, fqStream_t stream) {
+  REQUIRE(stat_out && hist_max && hist && bins > 0 && bins <= 4096, "fq_add_act_stat_hist_host: bad arguments");
+  if (int rc = fq_add_act_stat_host(a, b, y, n, inner, act, stat_out, stream)) return rc;
+  return fq_histogram_accumulate_host(y, n * inner, hist_max, bins, hist, neg_count, stream);
+}
+
 int fq_hist_to_float_host(const uint64_t* hist, float* out, int64_t count, fqStream_t) {
   REQUIRE(hist && out && count > 0, "fq_hist_to_float_host: bad arguments");
   for (int64_t i = 0; i < count; ++i) out[i] = (float)hist[i];

@@ -157,6 +157,30 @@ def bn_act(x, scale, shift, act="relu", want_stat=False):
     return (y, stat) if want_stat else y
 
 
+def bn_act_hist(x, scale, shift, act, max_, bins, hist=None):
+    """fq_bn_act_stat_hist_host -> (y, stat, hist uint64, negatives)"""
+    x = _f32(x)
+    n, c = x.shape[0], x.shape[1]
+    y, stat = np.empty_like(x), np.zeros(n, F32)
+    hist = np.zeros(bins, np.uint64) if hist is None else hist
+    neg = np.zeros(1, np.uint32)
+    _call("fq_bn_act_stat_hist_host", x, y, n, c, x.size // (n * c), _f32(scale), _f32(shift), _i(_ACTS[act]), stat,
+          np.asarray([max_], F32), _i(bins), hist, neg, None)
+    return y, stat, hist, int(neg[0])
+
+
+def add_act_hist(a, b, act, max_, bins, hist=None):
+    """fq_add_act_stat_hist_host -> (y, stat, hist uint64, negatives)"""
+    a, b = _f32(a), _f32(b)
+    n = a.shape[0]
+    y, stat = np.empty_like(a), np.zeros(n, F32)
+    hist = np.zeros(bins, np.uint64) if hist is None else hist
+    neg = np.zeros(1, np.uint32)
+    _call("fq_add_act_stat_hist_host", a, b, y, n, a.size // n, _i(_ACTS[act]), stat, np.asarray([max_], F32), _i(bins),
+          hist, neg, None)
+    return y, stat, hist, int(neg[0])
+
+
 def bn_act_maxpool(x, scale, shift, act="relu", want_stat=False):
     x = _f32(x)
     n, c, h, w = x.shape

@@ -135,11 +135,21 @@ def fake_quant_online_prestat(x, stat, width=8, flags=0, out=None, cur_out=None,
     return yt, ct, (_t(codes.astype(np.int32)).reshape(x.shape) if want_codes else None)
 
 
-def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
+def _into_sink(yt, hist):
+    """the producers that bin what they store (fq_*_stat_hist): the separate histogram pass over the result, by definition.
+    Resolved through the patched module so that the host-twin stand-ins (`host_ops`) take over when they are installed."""
+    if hist is not None:
+        from quantization.mxnet_amd import ops as _ops
+        _ops.histogram_accumulate(yt, hist.fm_max, hist.hist, hist.neg)
+
+
+def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True, hist=None):
     a = _np(x)
     y = O.bn_act(a, _np(scale), _np(shift), act)
     stat = _t(np.abs(y).reshape(y.shape[0], -1).max(axis=1).astype(F32)) if want_stat else None
-    return _t(y), stat
+    yt = _t(y)
+    _into_sink(yt, hist)
+    return yt, stat
 
 
 def bn_act_maxpool_stat(x, scale, shift, act="relu", want_stat=True):
@@ -148,7 +158,7 @@ def bn_act_maxpool_stat(x, scale, shift, act="relu", want_stat=True):
     return _t(y), stat
 
 
-def add_act_stat(a, b, act="relu", out=None, want_stat=True):
+def add_act_stat(a, b, act="relu", out=None, want_stat=True, hist=None):
     y = (_np(a).astype(F32) + _np(b).astype(F32)).astype(F32)
     if act == "relu":
         y = np.maximum(y, F32(0))
@@ -158,6 +168,7 @@ def add_act_stat(a, b, act="relu", out=None, want_stat=True):
     if out is not None:
         out.copy_(yt)
         yt = out
+    _into_sink(yt, hist)
     return yt, (_t(_stat(yt, False)) if want_stat else None)
 
 

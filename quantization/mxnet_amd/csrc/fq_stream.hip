@@ -191,14 +191,72 @@ __device__ __forceinline__ float bn_act1(float v, float sc, float sh) {
   return r;
 }
 
-template <int ACT, bool STATS, bool VEC, int U>
+// ---------------------------------------------------------------------------------------------------------------
+// Histogram of a producer's OUTPUT in the producer's own pass (fq_bn_act_stat_hist / fq_add_act_stat_hist): while the KL
+// calibration collects feature maps (distribution_calibrate.py:91-106) every quantised block's input is histogrammed once
+// per batch - 4 B/elem read back right after the BatchNorm / residual pass wrote it.  From the second batch on the range is
+// fixed (the first batch sets it, :97-101), so the producer bins what it stores.  Binning is K7's (fq_calib.hip), to the
+// letter: clip to [0, max], zeros skipped, (int)(c * bins / (max + 1e-5)), index `bins` folded into the last bin; counts
+// are integers, so where they are added up cannot matter.  LDS: one private copy per wavefront (4 * bins counters).
+// ---------------------------------------------------------------------------------------------------------------
+struct LdsHist {
+  unsigned int* mine;
+  float mx, scales;
+  int last;
+  unsigned int neg;
+  __device__ __forceinline__ void init(unsigned int* lh, int bins, const float* __restrict__ max_dev) {
+    for (int i = threadIdx.x; i < 4 * bins; i += kBlock) lh[i] = 0u;
+    __syncthreads();
+    mine = lh + (threadIdx.x >> 6) * bins;
+    mx = max_dev[0];
+    scales = (float)bins / (mx + 1e-5f);
+    last = bins - 1;
+    neg = 0u;
+  }
+  __device__ __forceinline__ void put(float v) {
+    neg += (v < 0.0f) ? 1u : 0u;
+    const float c = __builtin_amdgcn_fmed3f(v, 0.0f, mx);
+    if (c != 0.0f) {
+      int idx = (int)(c * scales);
+      idx = idx < last ? idx : last;
+      atomicAdd(&mine[idx], 1u);
+    }
+  }
+  __device__ __forceinline__ void put4(const f4& q) {
+    put(q.x);
+    put(q.y);
+    put(q.z);
+    put(q.w);
+  }
+  __device__ __forceinline__ void flush(const unsigned int* lh, int bins, unsigned long long* __restrict__ hist,
+                                        unsigned int* __restrict__ neg_count) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < bins; b += kBlock) {
+      const unsigned int c = lh[b] + lh[bins + b] + lh[2 * bins + b] + lh[3 * bins + b];
+      if (c) atomicAdd(&hist[b], (unsigned long long)c);
+    }
+    if (neg_count != nullptr) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) neg += __shfl_xor(neg, off, 64);
+      if ((threadIdx.x & 63) == 0 && neg) atomicAdd(neg_count, neg);
+    }
+  }
+};
+
+template <int ACT, bool STATS, bool VEC, int U, bool HIST = false>
 __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              int64_t inner, int hw, int chunks_per_sample,
                                                              int64_t total_chunks, const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
-                                                             float* __restrict__ stat_out) {
+                                                             float* __restrict__ stat_out,
+                                                             const float* __restrict__ hist_max, int bins,
+                                                             unsigned long long* __restrict__ hist,
+                                                             unsigned int* __restrict__ neg_count) {
   constexpr int kCh = kBlock * kVec * U;
   __shared__ float red[4];
+  extern __shared__ __attribute__((aligned(16))) unsigned int lds_hist[];   // HIST: 4 * bins counters
+  LdsHist lh;
+  if (HIST) lh.init(lds_hist, bins, hist_max);
   const ChunkRange rg = block_range(total_chunks);
   int64_t cur_s = -1;
   float m = 0.0f;
@@ -243,6 +301,7 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
           q.w = bn_act1<ACT>(v[u].w, sc, sh);
           if (STATS) m = fmaxf(m, stat4<true>(q));
           o[i] = q;
+          if (HIST) lh.put4(q);
         }
       }
     } else {
@@ -253,6 +312,7 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
         const float q = bn_act1<ACT>(x[gbase + i], scale[ch], shift[ch]);
         if (STATS) m = fmaxf(m, fabsf(q));
         y[gbase + i] = q;
+        if (HIST) lh.put(q);
       }
     }
   }
@@ -260,6 +320,7 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
     m = block_max(m, red);
     if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
   }
+  if (HIST) lh.flush(lds_hist, bins, hist, neg_count);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -268,13 +329,19 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
 // one write) instead of add (12) + relu (8) + one statistic pass per consumer (4 each).  Flat streaming kernel over
 // (n, inner) with the chunking of K1 / K2.
 // ---------------------------------------------------------------------------------------------------------------
-template <int ACT, bool STATS, bool VEC, int U>
+template <int ACT, bool STATS, bool VEC, int U, bool HIST = false>
 __global__ __launch_bounds__(kBlock) void add_act_stat_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                               float* __restrict__ y, int64_t inner,
                                                               int chunks_per_sample, int64_t total_chunks,
-                                                              float* __restrict__ stat_out) {
+                                                              float* __restrict__ stat_out,
+                                                              const float* __restrict__ hist_max, int bins,
+                                                              unsigned long long* __restrict__ hist,
+                                                              unsigned int* __restrict__ neg_count) {
   constexpr int kCh = kBlock * kVec * U;
   __shared__ float red[4];
+  extern __shared__ __attribute__((aligned(16))) unsigned int lds_hist[];   // HIST: 4 * bins counters
+  LdsHist lh;
+  if (HIST) lh.init(lds_hist, bins, hist_max);
   const ChunkRange rg = block_range(total_chunks);
   int64_t cur_s = -1;
   float m = 0.0f;
@@ -316,6 +383,7 @@ __global__ __launch_bounds__(kBlock) void add_act_stat_kernel(const float* __res
         q.w = one(va[u].w, vb[u].w);
         if (STATS) m = fmaxf(m, stat4<true>(q));
         o[threadIdx.x + u * kBlock] = q;
+        if (HIST) lh.put4(q);
       }
     } else {
       const int cnt = (int)(rem < kCh ? rem : kCh);
@@ -323,6 +391,7 @@ __global__ __launch_bounds__(kBlock) void add_act_stat_kernel(const float* __res
         const float q = one(a[gbase + i], b[gbase + i]);
         if (STATS) m = fmaxf(m, fabsf(q));
         y[gbase + i] = q;
+        if (HIST) lh.put(q);
       }
     }
   }
@@ -330,6 +399,7 @@ __global__ __launch_bounds__(kBlock) void add_act_stat_kernel(const float* __res
     m = block_max(m, red);
     if (threadIdx.x == 0) atomic_max_f32(stat_out + cur_s, m);
   }
+  if (HIST) lh.flush(lds_hist, bins, hist, neg_count);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -773,8 +843,19 @@ int fq_bn_act_maxpool_stat(const float* x, float* y, int64_t n, int64_t c, int64
   return FQ_OK;
 }
 
-int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
-                   const float* shift, int act, float* stat_out, fqStream_t stream) {
+// the grid of a producer that also bins its output: every workgroup ends with up to `bins` 64-bit atomics (K7)
+static int hist_grid(int64_t work_items) {
+  static const int wg_per_cu = env_int("FQ_HISTF_WG_PER_CU", 2);
+  const int64_t cap = (int64_t)num_cu() * wg_per_cu;
+  const int64_t g = work_items < cap ? work_items : cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
+static int bn_act_launch(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                         const float* shift, int act, float* stat_out, const float* hist_max, int bins, uint64_t* hist_,
+                         uint32_t* neg_count_, fqStream_t stream) {
+  unsigned long long* hist = (unsigned long long*)hist_;
+  unsigned int* neg_count = (unsigned int*)neg_count_;
   FQ_REQUIRE(x && y && scale && shift, "fq_bn_act_stat: null pointer");
   FQ_REQUIRE(n > 0 && c > 0 && hw > 0 && c * hw < (1ll << 32) && hw < (1ll << 31),
              "fq_bn_act_stat: bad shape (n=%lld c=%lld hw=%lld)", (long long)n, (long long)c, (long long)hw);
@@ -787,11 +868,17 @@ int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, c
   const bool small = use_small_chunks(n, inner);
   const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
   const bool vec = (inner % kVec == 0) && aligned16(x) && aligned16(y);
-  const int grid = grid_for(ck.total);
+  const bool with_hist = hist != nullptr;
+  const int grid = with_hist ? hist_grid(ck.total) : grid_for(ck.total);
+  const size_t lds = with_hist ? (size_t)4 * bins * sizeof(unsigned int) : 0;
   ProfScope prof(FQ_KERNEL_BN_ACT, 8.0 * (double)n * (double)inner, st);
-#define FQ_BN(A, S, V, UU)                                                                                       \
-  hipLaunchKernelGGL((bn_act_stat_kernel<A, S, V, UU>), dim3(grid), dim3(kBlock), 0, st, x, y, inner, (int)hw,   \
-                     ck.chunks_per_sample, ck.total, scale, shift, stat_out)
+#define FQ_BN_H(A, S, V, UU, H)                                                                                  \
+  hipLaunchKernelGGL((bn_act_stat_kernel<A, S, V, UU, H>), dim3(grid), dim3(kBlock), lds, st, x, y, inner, (int)hw, \
+                     ck.chunks_per_sample, ck.total, scale, shift, stat_out, hist_max, bins, hist, neg_count)
+#define FQ_BN(A, S, V, UU)                                                  \
+  do {                                                                      \
+    if (with_hist) { if (S) FQ_BN_H(A, true, V, UU, true); } else FQ_BN_H(A, S, V, UU, false); \
+  } while (0)
 #define FQ_BN_U(A, S, V)                                                 \
   do {                                                                   \
     if (small) FQ_BN(A, S, V, kSmallUnroll); else FQ_BN(A, S, V, kUnroll); \
@@ -811,12 +898,28 @@ int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, c
 #undef FQ_BN_V
 #undef FQ_BN_U
 #undef FQ_BN
+#undef FQ_BN_H
   FQ_LAUNCH_CHECK();
   return FQ_OK;
 }
 
-int fq_add_act_stat(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
-                    fqStream_t stream) {
+int fq_bn_act_stat(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                   const float* shift, int act, float* stat_out, fqStream_t stream) {
+  return bn_act_launch(x, y, n, c, hw, scale, shift, act, stat_out, nullptr, 0, nullptr, nullptr, stream);
+}
+
+int fq_bn_act_stat_hist(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                        const float* shift, int act, float* stat_out, const float* hist_max, int bins, uint64_t* hist,
+                        uint32_t* neg_count, fqStream_t stream) {
+  FQ_REQUIRE(stat_out && hist_max && hist, "fq_bn_act_stat_hist: null pointer (the statistic is part of this form)");
+  FQ_REQUIRE(bins > 0 && bins <= 4096, "fq_bn_act_stat_hist: bins=%d out of range (1..4096: four private copies in 64 KiB of LDS)", bins);
+  return bn_act_launch(x, y, n, c, hw, scale, shift, act, stat_out, hist_max, bins, hist, neg_count, stream);
+}
+
+static int add_act_launch(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
+                          const float* hist_max, int bins, uint64_t* hist_, uint32_t* neg_count_, fqStream_t stream) {
+  unsigned long long* hist = (unsigned long long*)hist_;
+  unsigned int* neg_count = (unsigned int*)neg_count_;
   FQ_REQUIRE(a && b && y, "fq_add_act_stat: null pointer");
   FQ_REQUIRE(n > 0 && inner > 0 && n < (1ll << 31), "fq_add_act_stat: bad shape (n=%lld inner=%lld)", (long long)n,
              (long long)inner);
@@ -828,11 +931,17 @@ int fq_add_act_stat(const float* a, const float* b, float* y, int64_t n, int64_t
   const bool small = use_small_chunks(n, inner);
   const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
   const bool vec = (inner % kVec == 0) && aligned16(a) && aligned16(b) && aligned16(y);
-  const int grid = grid_for(ck.total);
+  const bool with_hist = hist != nullptr;
+  const int grid = with_hist ? hist_grid(ck.total) : grid_for(ck.total);
+  const size_t lds = with_hist ? (size_t)4 * bins * sizeof(unsigned int) : 0;
   ProfScope prof(FQ_KERNEL_BN_ACT, 12.0 * (double)n * (double)inner, st);
-#define FQ_ADD(A, S, V, UU)                                                                                       \
-  hipLaunchKernelGGL((add_act_stat_kernel<A, S, V, UU>), dim3(grid), dim3(kBlock), 0, st, a, b, y, inner,         \
-                     ck.chunks_per_sample, ck.total, stat_out)
+#define FQ_ADD_H(A, S, V, UU, H)                                                                                  \
+  hipLaunchKernelGGL((add_act_stat_kernel<A, S, V, UU, H>), dim3(grid), dim3(kBlock), lds, st, a, b, y, inner,    \
+                     ck.chunks_per_sample, ck.total, stat_out, hist_max, bins, hist, neg_count)
+#define FQ_ADD(A, S, V, UU)                                                   \
+  do {                                                                        \
+    if (with_hist) { if (S) FQ_ADD_H(A, true, V, UU, true); } else FQ_ADD_H(A, S, V, UU, false); \
+  } while (0)
 #define FQ_ADD_U(A, S, V)                                                 \
   do {                                                                    \
     if (small) FQ_ADD(A, S, V, kSmallUnroll); else FQ_ADD(A, S, V, kUnroll); \
@@ -852,8 +961,21 @@ int fq_add_act_stat(const float* a, const float* b, float* y, int64_t n, int64_t
 #undef FQ_ADD_V
 #undef FQ_ADD_U
 #undef FQ_ADD
+#undef FQ_ADD_H
   FQ_LAUNCH_CHECK();
   return FQ_OK;
+}
+
+int fq_add_act_stat(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
+                    fqStream_t stream) {
+  return add_act_launch(a, b, y, n, inner, act, stat_out, nullptr, 0, nullptr, nullptr, stream);
+}
+
+int fq_add_act_stat_hist(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
+                         const float* hist_max, int bins, uint64_t* hist, uint32_t* neg_count, fqStream_t stream) {
+  FQ_REQUIRE(stat_out && hist_max && hist, "fq_add_act_stat_hist: null pointer (the statistic is part of this form)");
+  FQ_REQUIRE(bins > 0 && bins <= 4096, "fq_add_act_stat_hist: bins=%d out of range (1..4096: four private copies in 64 KiB of LDS)", bins);
+  return add_act_launch(a, b, y, n, inner, act, stat_out, hist_max, bins, hist, neg_count, stream);
 }
 
 int fq_fake_quant_offline(const float* x, float* y, int64_t n, int64_t inner, const float* threshold, int width,

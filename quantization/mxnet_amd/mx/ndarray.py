@@ -65,7 +65,9 @@ class NDArray(object):
     # (offline input quantisation; quantize/convert/convert_conv2d.handover_target).  Never set by the generic ops.
     # _fq_nonneg: only meaningful beside a `_fq_stat`: the producer applied ReLU / ReLU6, so the tensor is non-negative and the
     # statistic is its per-sample maximum (what nn.Conv2D(quantized=True) needs to skip its range pass, nn/fuse.py).
-    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg")
+    # _fq_kl: optional (producer block, histogram sink or None) left by a fused producer while the KL calibration collects
+    # feature maps (quantize/distribution_calibrate.py): who made this tensor, and whether that pass already binned it.
+    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl")
     __array_priority__ = 1000.0
     __array_ufunc__ = None
 
@@ -75,6 +77,7 @@ class NDArray(object):
         self._fq_stat = None
         self._fq_c16 = None
         self._fq_nonneg = False
+        self._fq_kl = None
 
     # -- plumbing ---------------------------------------------------------------------------
     @property
@@ -122,6 +125,7 @@ class NDArray(object):
             return NDArray(self._t.to(other.torch_device, copy=True))
         other._t.copy_(self._t)
         other._fq_stat = None                   # a fused producer's statistic described the OLD contents
+        other._fq_kl = None
         return other
 
     def copy(self):
@@ -171,6 +175,7 @@ class NDArray(object):
     def __setitem__(self, key, value):
         key = _unwrap_key(key)
         self._fq_stat = None
+        self._fq_kl = None
         self._t[key] = value._t if isinstance(value, NDArray) else value
 
     # -- shape ops --------------------------------------------------------------------------
@@ -248,11 +253,13 @@ class NDArray(object):
 
     def __iadd__(self, o):
         self._fq_stat = None
+        self._fq_kl = None
         self._t += _operand(o, self._t)
         return self
 
     def __imul__(self, o):
         self._fq_stat = None
+        self._fq_kl = None
         self._t *= _operand(o, self._t)
         return self
 

@@ -337,9 +337,26 @@ def _stat_target(n, device, want_stat):
     return torch.empty(n, dtype=torch.float32, device=device), 0
 
 
-def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
+HIST_FUSED_MAX_BINS = 4096        # fq_*_stat_hist keep four private copies of the histogram in 64 KiB of LDS
+
+
+def _hist_args(hist, want_stat):
+    """(max, bins, counts, negatives) of a histogram sink (`fm_max` float32[1], `hist` int64[bins], `neg` int32[1]: what
+    distribution_calibrate keeps per collected block) for the producers that bin what they store."""
+    if not want_stat:
+        raise ValueError("a producer bins its output only together with the per-sample statistic")
+    _check(hist.fm_max, "hist.fm_max")
+    _check(hist.hist, "hist.hist", torch.int64)
+    _check(hist.neg, "hist.neg", torch.int32)
+    if not 0 < hist.hist.numel() <= HIST_FUSED_MAX_BINS:
+        raise ValueError("%d bins: the fused form takes 1..%d" % (hist.hist.numel(), HIST_FUSED_MAX_BINS))
+    return _ptr(hist.fm_max), int(hist.hist.numel()), _ptr(hist.hist), _ptr(hist.neg)
+
+
+def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True, hist=None):
     """Fused inference BatchNorm (per-channel scale/shift) + activation + per-sample max|y| in one pass.
-    x: (N, C, ...) ; returns (y, stat (N,) or None)."""
+    x: (N, C, ...) ; returns (y, stat (N,) or None).  `hist` (KL collection, distribution_calibrate.py): a sink whose counts
+    also receive y's histogram in the same pass (fq_bn_act_stat_hist) - what `histogram_accumulate(y, ...)` would add."""
     _check(x, "x")
     _check(scale, "scale")
     _check(shift, "shift")
@@ -353,6 +370,10 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True):
         raise ValueError("unknown activation %r" % (act,))
     y = torch.empty_like(x) if out is None else _check(out, "out")
     stat, zflag = _stat_target(n, x.device, want_stat)
+    if hist is not None:
+        check_call(_lib_().fq_bn_act_stat_hist(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,
+                                               _ptr(stat), *_hist_args(hist, want_stat), _stream(x)))
+        return y, stat
     check_call(_lib_().fq_bn_act_stat(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,
                                       _ptr(stat), _stream(x)))
     return y, stat
@@ -376,9 +397,9 @@ def bn_act_maxpool_stat(x, scale, shift, act="relu", want_stat=True):
     return y, stat
 
 
-def add_act_stat(a, b, act="relu", out=None, want_stat=True):
+def add_act_stat(a, b, act="relu", out=None, want_stat=True, hist=None):
     """`(a + b).relu()` — the residual tail of the model zoo's ResNet units — with the per-sample max|y| of the result for
-    the quantised consumers (fq_add_act_stat).  Returns (y, stat or None)."""
+    the quantised consumers (fq_add_act_stat).  Returns (y, stat or None).  `hist`: as in `bn_act_stat`."""
     _check(a, "a")
     _check(b, "b")
     if a.shape != b.shape:
@@ -386,6 +407,10 @@ def add_act_stat(a, b, act="relu", out=None, want_stat=True):
     n, inner = _n_inner(a)
     y = torch.empty_like(a) if out is None else _check(out, "out")
     stat, zflag = _stat_target(n, a.device, want_stat)
+    if hist is not None:
+        check_call(_lib_().fq_add_act_stat_hist(_ptr(a), _ptr(b), _ptr(y), n, inner, _ACTS[act] | zflag, _ptr(stat),
+                                                *_hist_args(hist, want_stat), _stream(a)))
+        return y, stat
     check_call(_lib_().fq_add_act_stat(_ptr(a), _ptr(b), _ptr(y), n, inner, _ACTS[act] | zflag, _ptr(stat), _stream(a)))
     return y, stat
 

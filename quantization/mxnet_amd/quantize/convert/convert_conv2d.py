@@ -349,7 +349,14 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
             c = out.shape[1]
             scale = torch.ones(c, dtype=torch.float32, device=out._t.device)
             shift = torch.zeros(c, dtype=torch.float32, device=out._t.device)
-        y, stat = ops.bn_act_stat(out._t.contiguous(), scale, shift, fz["act"])
+        from .. import fuse as _fuse                    # (a KL collection past its first batch: this pass bins what it stores)
+        sink = _fuse._kl_sink(block)
+        y, stat = ops.bn_act_stat(out._t.contiguous(), scale, shift, fz["act"], hist=sink)
+        res = NDArray(y)
+        res._fq_stat = stat
+        if _fuse._collection is not None:
+            res._fq_kl = (block, sink)
+        return res
     if isinstance(y, ops.Codes16):
         res = NDArray(y.t)                              # the codes travel on the NDArray; only the linked consumer reads them
         res._fq_c16 = y

@@ -10,6 +10,8 @@ range on the first batch (:97-101), `fq_histogram_accumulate` adds exact uint64 
 summation order.  Return types match the reference: `{block: np.float32 histogram[bins]}`, `{block: np.float32 max}`,
 and `kl_calibrate -> int`.
 """
+import os
+
 import numpy as np
 import torch
 from tqdm import tqdm
@@ -18,6 +20,9 @@ from ..mx.ndarray import NDArray
 from .. import ops
 
 __all__ = ['collect_feature_maps', 'kl_calibrate', 'kl_calibrate_many']
+
+
+FUSED_HISTOGRAMS = os.environ.get("FQ_KL_FUSED_HIST", "1") != "0"     # (0: every histogram in a pass of its own, as round 3)
 
 
 class _LayerHist(object):
@@ -41,6 +46,7 @@ def collect_feature_maps(net, bins, loader, ctx, tqdm_desc="Collect FM", sync=No
         the first batch and ("hist", all histograms) at the end, so every rank ends with the global statistics.
     :return: (hist_collector, fm_max_collector) keyed by block, as in the reference.
     """
+    from . import fuse as _fuse
     quantized_blocks = net.collect_quantized_blocks()
 
     """ Add hooks to quantized blocks """
@@ -53,6 +59,11 @@ def collect_feature_maps(net, bins, loader, ctx, tqdm_desc="Collect FM", sync=No
             assert getattr(x[0], "_fq_c16", None) is None, "collect_feature_maps: block input is an int8 code tensor"
             fm_collector.setdefault(m, []).append(x[0])          # device tensor reference, no copy (cf. :84)
         hooks.append(blk.register_forward_hook(_collect))
+    # Fused producers (quantize/fuse.py) tag what they make with (producer, sink): blocks fed by the same producer see the
+    # same tensor every batch - one range, one histogram (they SHARE a _LayerHist) - and from the second batch on the
+    # producer's own pass adds the counts (ops.bn_act_stat / add_act_stat with `hist=`), so no pass here re-reads the tensor.
+    sinks = _fuse.begin_collection() if FUSED_HISTOGRAMS and bins <= ops.HIST_FUSED_MAX_BINS else None
+    by_producer, ambiguous = {}, set()
 
     """ Collect feature maps """
     state = {}
@@ -73,31 +84,58 @@ def collect_feature_maps(net, bins, loader, ctx, tqdm_desc="Collect FM", sync=No
                 st = state[m] = _LayerHist(bins, packed.device)
             st.fm_max = packed[i:i + 1].clone()
 
-    with tqdm(total=len(loader), desc=tqdm_desc) as pbar:
-        for X, _ in loader:
-            X = X.as_in_context(ctx)
-            _ = net(X)
-            inputs = {}
-            for m, fms in fm_collector.items():
-                t = fms[0]._t if len(fms) == 1 else torch.cat([f._t for f in fms], dim=0)     # :94
-                inputs[m] = t if t.is_contiguous() else t.contiguous()
-                if m not in state:
-                    st = state[m] = _LayerHist(bins, t.device)
-                    st.fm_max = ops.global_max(inputs[m])         # first chunk sets the range (:97-101)
-            if not range_shared:
-                share_range()
-                range_shared = True
-            for m, t in inputs.items():
-                st = state[m]
-                ops.histogram_accumulate(t, st.fm_max, st.hist, st.neg)       # :39-45 and :103-104
-            fm_collector.clear()
-            pbar.update(1)
+    try:
+        with tqdm(total=len(loader), desc=tqdm_desc) as pbar:
+            for X, _ in loader:
+                X = X.as_in_context(ctx)
+                if sinks is not None:
+                    _fuse.collection_calls().clear()
+                _ = net(X)
+                pending = {}          # id(histogram state) -> (state, tensor): ONE separate pass per histogram and batch
+                seen = {}             # producer -> the NDArray it made in this forward
+                for m, fms in fm_collector.items():
+                    tag = getattr(fms[0], "_fq_kl", None) if len(fms) == 1 and sinks is not None else None
+                    if tag is not None and seen.setdefault(tag[0], fms[0]) is not fms[0]:
+                        ambiguous.add(tag[0])                     # one producer, two tensors in a forward: never share
+                        tag = None
+                    st = state.get(m)
+                    if st is None and tag is not None and tag[0] in by_producer:
+                        st = state[m] = by_producer[tag[0]]       # a sibling consumer of the same tensor: one range, one histogram
+                    if st is not None and tag is not None and tag[1] is st:
+                        continue                                  # the producer binned this tensor while it stored it
+                    if st is not None and id(st) in pending:
+                        continue                                  # the sibling's pass below covers the shared histogram
+                    t = fms[0]._t if len(fms) == 1 else torch.cat([f._t for f in fms], dim=0)     # :94
+                    t = t if t.is_contiguous() else t.contiguous()
+                    if st is None:
+                        st = state[m] = _LayerHist(bins, t.device)
+                        st.fm_max = ops.global_max(t)             # first chunk sets the range (:97-101)
+                        if tag is not None:
+                            by_producer[tag[0]] = st
+                    pending[id(st)] = (st, t)
+                if not range_shared:
+                    share_range()
+                    range_shared = True
+                for st, t in pending.values():
+                    ops.histogram_accumulate(t, st.fm_max, st.hist, st.neg)       # :39-45 and :103-104
+                if sinks is not None:
+                    # ranges are fixed: producers that ran exactly once in this forward take over from the next batch
+                    calls = _fuse.collection_calls()
+                    for p in list(sinks):
+                        if calls.get(p, 0) != 1:
+                            raise RuntimeError("collect_feature_maps: a producer that bins its output ran %d times in one "
+                                               "forward (the net changed during the collection)" % calls.get(p, 0))
+                    sinks.update({p: st for p, st in by_producer.items() if calls.get(p, 0) == 1 and p not in ambiguous})
+                fm_collector.clear()
+                pbar.update(1)
+    finally:
+        if sinks is not None:
+            _fuse.end_collection()
+        """ Delete hooks """
+        for h in hooks:
+            h.detach()
     if not range_shared:                      # this rank's shard was empty
         share_range()
-
-    """ Delete hooks """
-    for h in hooks:
-        h.detach()
 
     if sync is not None:
         order = [m for m in quantized_blocks if m in state]

@@ -53,6 +53,38 @@ def _bn_constants(bn):
     return scale.contiguous(), shift.contiguous(), _tensors_key(g0, b, mean, var)
 
 
+# ---- histogram sinks of a feature-map collection (distribution_calibrate.collect_feature_maps) ----------------------------
+# From its second batch on a KL collection knows every collected tensor's range, and which fused producer made it: that
+# producer then bins what it stores (fq_bn_act_stat_hist / fq_add_act_stat_hist) and the collection skips its own pass over
+# the tensor.  {producer block: sink (fm_max, hist, neg)}; None outside a collection.
+_collection = None
+_collection_calls = {}        # producer -> times it ran in the current forward (a sink is only right for exactly one)
+
+
+def begin_collection():
+    global _collection
+    _collection = {}
+    _collection_calls.clear()
+    return _collection
+
+
+def end_collection():
+    global _collection
+    _collection = None
+    _collection_calls.clear()
+
+
+def collection_calls():
+    return _collection_calls
+
+
+def _kl_sink(producer):
+    if _collection is None:
+        return None
+    _collection_calls[producer] = _collection_calls.get(producer, 0) + 1
+    return _collection.get(producer)
+
+
 def _fused_bn_forward(self, F, x, gamma, beta, running_mean, running_var):
     st = self._fq_fused
     key = _tensors_key(gamma._t, beta._t, running_mean._t, running_var._t)
@@ -64,7 +96,13 @@ def _fused_bn_forward(self, F, x, gamma, beta, running_mean, running_var):
         y, stat = ops.bn_act_maxpool_stat(t, st["scale"], st["shift"], st["act"], want_stat=True)
         st["pool"]._fq_pool_done = True
     else:
-        y, stat = ops.bn_act_stat(t, st["scale"], st["shift"], st["act"], want_stat=True)
+        sink = _kl_sink(self)
+        y, stat = ops.bn_act_stat(t, st["scale"], st["shift"], st["act"], want_stat=True, hist=sink)
+        out = NDArray(y)
+        out._fq_stat = stat
+        if _collection is not None:
+            out._fq_kl = (self, sink)
+        return out
     out = NDArray(y)
     out._fq_stat = stat
     return out
@@ -254,9 +292,12 @@ def _residual_unit_forward(self, x):
         h = self.body(x)
     a = h._t if h._t.is_contiguous() else h._t.contiguous()
     b = shortcut._t if shortcut._t.is_contiguous() else shortcut._t.contiguous()
-    y, stat = ops.add_act_stat(a, b, "relu", want_stat=True)
+    sink = _kl_sink(self)
+    y, stat = ops.add_act_stat(a, b, "relu", want_stat=True, hist=sink)
     out = NDArray(y)
     out._fq_stat = stat
+    if _collection is not None:
+        out._fq_kl = (self, sink)
     return out
 
 

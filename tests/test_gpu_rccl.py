@@ -175,7 +175,7 @@ def test_every_cli_flow_on_a_one_rank_rccl_group(gpu, tmp_path):
                                       extra=("--eval-streams", "1", "--eval-graph", "0"))
         np.testing.assert_array_equal(r[flow + "_thr"], thr, flow)
         assert float(r[flow + "_acc"]) == acc and float(r[flow + "_avg"]) == avg, flow
-        assert int(r[flow + "_replayed"]) == 4, flow
+        assert int(r[flow + "_replayed"]) == 5, flow
 
 
 def test_a_collective_inside_a_graph_capture_is_refused(gpu):

@@ -439,3 +439,27 @@ def test_qconv2d_twin_equals_numpy_oracle(golden, case):
             tag = "conv_b%d_g1" % use_bias
             y = H.qconv2d_forward(g[tag + "/x"], g[tag + "/w"], g[tag + "/b"] if use_bias else None, (1, 1), (1, 1), 1)
             np.testing.assert_array_equal(y, g[tag + "/y_int"])
+
+
+def test_producers_that_bin_what_they_store_equal_the_two_passes():
+    """fq_bn_act_stat_hist_host / fq_add_act_stat_hist_host (KL collection, round 4): the plain pass + the histogram of its
+    result, against the numpy restatement of the reference's `_discrete_histogram` (distribution_calibrate.py:27-45)."""
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((3, 5, 7, 7)) * 2).astype(np.float32)
+    sc, sh = (rng.random(5) + 0.5).astype(np.float32), rng.standard_normal(5).astype(np.float32)
+    y0, s0 = H.bn_act(x, sc, sh, "relu", want_stat=True)
+    mx_ = np.float32(y0.max() * 0.7)
+    y, s, h, neg = H.bn_act_hist(x, sc, sh, "relu", mx_, 2048)
+    _eq(y, y0)
+    _eq(s, s0)
+    _eq(h.astype(np.float32), O.discrete_histogram(y0, 2048, mx_)[0])
+    assert neg == 0
+    y, s, h, neg = H.bn_act_hist(x, sc, sh, "none", mx_, 64, hist=h[:64].copy())
+    assert neg == int((y < 0).sum()) and neg > 0
+    b = rng.standard_normal(x.shape).astype(np.float32)
+    y1 = np.maximum(x + b, np.float32(0))
+    y, s, h, neg = H.add_act_hist(x, b, "relu", np.float32(y1.max()), 128)
+    _eq(y, y1)
+    _eq(h.astype(np.float32), O.discrete_histogram(y1, 128, np.float32(y1.max()))[0])
+    with pytest.raises(RuntimeError):
+        H.add_act_hist(x, b, "relu", 1.0, 8192)
