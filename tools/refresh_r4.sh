@@ -24,4 +24,15 @@ import json,sys
 l=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=l['roofline']['kernels']
 print('FQ_PWS_THIN=$v mobilenetv2_1.0 offline:', l['value'], 'images/s', l['ms_per_step'], 'ms/step', {n:(round(v['ms_per_step'],3), v['frac']) for n,v in k.items()})" >> $O/${TAG}_thin_ab.txt
 done
+# KL collection (config 3): the producers bin what they store (default) against one histogram pass per block (round 3)
+for f in 1 0; do
+  FQ_KL_FUSED_HIST=$f python3 bench.py --phase calib-kl --model resnet50_v1 --quant-type channel --steps 12 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=l['roofline']['kernels']
+print('FQ_KL_FUSED_HIST=$f resnet50_v1 KL collection:', l['value'], 'images/s', l['ms_per_step'], 'ms/batch', {n:(round(v['ms_per_step'],3), v['frac']) for n,v in k.items()}, l['split'])" >> $O/${TAG}_kl_fused_ab.txt
+done
+python3 tools/dw16bench.py > $O/${TAG}_dw16bench.txt 2>/dev/null
+python3 tools/c3bench.py > $O/${TAG}_c3bench.txt 2>/dev/null
+python3 tools/stembench.py >> $O/${TAG}_c3bench.txt 2>/dev/null
+python3 tools/cli_lane_probe.py 2>/dev/null | grep "^evaluate\|^mode\|^one lane\|^CLI" > $O/${TAG}_cli_lane_probe.txt
 ls -la $O | head -80

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """The first convolutions alone (batch 128, 224x224): 3x3 -> 32 (MobileNets) and 7x7 -> 64 (ResNets), median of 40 launches.
-FQ_LIB_PATH selects a variant library (csrc/build.py --only fq_stem -DFQ_STEM_CH=.. -DFQ_STEM_LB7=..); FQ_STEM_WG_PER_CU the grid."""
+FQ_LIB_PATH selects a variant library (csrc/build.py --only fq_stem -DFQ_STEM_CH=..); FQ_STEM_WG_PER_CU the grid.  (r4: two to
+four workgroups per CU, 8 or 16 loads in flight, 128 / 168 / 256 registers: 323-375 us for the 7x7 form, none better than the
+default's 324; the 3x3 form 83-87 us.)"""
 import os
 import sys
 
