@@ -7,9 +7,16 @@ events and `algorithmic_bytes_per_launch`).  KERNEL_STATS.csv: `rocprofv3 --kern
 `bench.py --streams 1 --graph 0` (one batch at a time: with batches in flight a kernel's wall duration includes the time it
 shares the CUs).  Per family the script adds up the table's TotalDurationNs over the family's kernels, divides by the number
 of steps the profiled process ran (= calls of the pooling kernel, one per step) and recomputes launch time and fraction of
-8 TB/s from the line's algorithmic bytes.  Exit status 1 when the DOMINANT family (the one `roofline.frac` describes) disagrees
-by more than --tol; the other families are printed with their ratios (the line and the table come from two processes on the
-same box: +-3-5 % between them is what two runs of the same command give).
+8 TB/s from the line's algorithmic bytes.
+
+What the line can promise (measured on four boxes, round 4): an event pair around ONE launch exceeds the kernel's duration in
+rocprofv3's table by 1-2.5 us, depending on the box and the process (inside a rocprofv3 process: ~5 us) - 2-6 % of these
+30-110 us launches; the line's `avg_launch_us_launch_overhead_removed` (raw minus the bracketing cost measured live on a
+self-timing kernel, fq_profile_launch_overhead) lands 0-4.5 % BELOW the table.  Neither is within 3 % everywhere; the table's
+figure lies BETWEEN them on every box.  So the judged `frac` is the raw-event one (the lower bound of the fraction), and this
+script checks the bracket:  removed * (1 - tol) <= rocprof <= raw * (1 + tol)  per family, --tol 0.01 by default.  Exit status
+1 when the DOMINANT family (the one `roofline.frac` describes) falls outside; other families are printed (the line and the
+table come from two processes on the same box).
 """
 import csv
 import json
@@ -32,7 +39,7 @@ HBM_PEAK_GBS = 8000.0
 
 
 def main(argv):
-    tol = 0.03
+    tol = 0.01
     if "--tol" in argv:
         tol = float(argv[argv.index("--tol") + 1])
     line = json.load(open(argv[0]))
@@ -45,7 +52,8 @@ def main(argv):
     kernels = line["roofline"]["kernels"]
     step_us = sum(k["ms_per_step"] for k in kernels.values()) * 1e3
     print("steps in the profiled process: %d; families of the line: %s" % (steps, ", ".join(kernels)))
-    print("%-10s %14s %14s %8s %10s %10s" % ("family", "events us/step", "rocprof us/step", "ratio", "frac(line)", "frac(csv)"))
+    print("%-10s %14s %14s %14s %8s %8s %10s %10s %10s" % ("family", "raw us/step", "removed us/step", "rocprof us/step", "raw/rp",
+                                                          "rem/rp", "frac(line)", "frac(rem)", "frac(csv)"))
     bad = 0
     for fam, k in kernels.items():
         names = FAMILIES.get(fam)
@@ -60,14 +68,18 @@ def main(argv):
         launches_per_step = ev_us / max(k["avg_launch_us"], 1e-9)
         frac_csv = k["algorithmic_bytes_per_launch"] * launches_per_step / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS
         ratio = ev_us / rp_us
+        rem_us = k.get("avg_launch_us_launch_overhead_removed", k["avg_launch_us"]) * launches_per_step
         flag = ""
         is_dom = (line["roofline"].get("kernel") or "") == k.get("kernel")
-        if abs(ratio - 1.0) > tol and ev_us >= 0.05 * step_us:
+        inside = rem_us * (1.0 - tol) <= rp_us <= ev_us * (1.0 + tol)
+        if not inside and ev_us >= 0.05 * step_us:
             bad += 1 if is_dom else 0
-            flag = "  <-- beyond %.0f %%%s" % (tol * 100, " (the dominant family)" if is_dom else "")
+            flag = "  <-- outside [removed, raw]%s" % (" (the dominant family)" if is_dom else "")
         elif is_dom:
             flag = "  (the dominant family)"
-        print("%-10s %14.1f %14.1f %8.3f %10.4f %10.4f%s" % (fam, ev_us, rp_us, ratio, k["frac"], frac_csv, flag))
+        print("%-10s %14.1f %14.1f %14.1f %8.3f %8.3f %10.4f %10.4f %10.4f%s"
+              % (fam, ev_us, rem_us, rp_us, ratio, rem_us / rp_us, k["frac"], k.get("frac_launch_overhead_removed", k["frac"]),
+                 frac_csv, flag))
     dom = line["roofline"].get("kernel")
     print("line: roofline.frac %.4f (%s)" % (line["roofline"]["frac"], (dom or "")[:60]))
     return 1 if bad else 0
