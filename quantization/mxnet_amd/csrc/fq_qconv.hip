@@ -57,23 +57,42 @@ __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict_
                                                               const float* __restrict__ x, int64_t numel) {
   __shared__ float sh[4];
   __shared__ float rng[2];
+  __shared__ float red3[3][4];
+  // (round 4: this one-workgroup kernel sits between every two layers of a fused net - 26 x 5.9 us in the MobileNet step, all of
+  // it dependent round trips; everything it reads is now requested up front and the three reductions share one barrier)
+  const float w_scale = wrec[kRecScale];
+  const float bias0 = (bias != nullptr && ibias != nullptr && (int)threadIdx.x < cout) ? bias[threadIdx.x] : 0.0f;
   // A fused producer's per-sample maxima of a NON-NEGATIVE tensor (BatchNorm + ReLU in its epilogue) stand in for the range
   // pass: max = their maximum, and the minimum is 0 as soon as the tensor holds one zero (half of a ReLU's outputs) - found
   // by the first strides of a scan that only runs to the end, as a plain minimum, when there is none.  Needed for uint8
   // without padding only (with padding the zero is there by construction; int8 ranges are [-max, max]).  A producer whose
   // statistic did not survive (stat[0] < 0: its layer was recomputed by the exact kernel) costs one full scan here.
   if (stat != nullptr) {
+    const bool want_min = mode == FQ_CODES_UINT8 && !padded;
     float smax = 0.0f;
     for (int i = threadIdx.x; i < nstat; i += kBlock) smax = fmaxf(smax, stat[i]);
-    smax = block_max(smax, sh);
-    if (threadIdx.x == 0) rng[1] = smax;
-    __syncthreads();
-    const bool stale = stat[0] < 0.0f;
-    const bool want_min = mode == FQ_CODES_UINT8 && !padded;
-    if (threadIdx.x == 0) rng[0] = 0.0f;
-    if (stale || want_min) {
-      float lmin = INFINITY, lmax = 0.0f;
-      for (int64_t base = 0; base < numel; base += kBlock * 8) {
+    const float s0 = stat[0];
+    float lmin = INFINITY, lmax = 0.0f;
+    if (want_min) {                                                     // the scan's first stride, in flight with the statistic
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = threadIdx.x + (int64_t)u * kBlock;
+        v[u] = i < numel ? x[i] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (threadIdx.x + (int64_t)u * kBlock < numel) {
+          lmin = fminf(lmin, v[u]);
+          lmax = fmaxf(lmax, v[u]);
+        }
+      }
+    }
+    const bool stale = s0 < 0.0f;
+    // the scan goes on while the tensor is to be read in full (stale), or no zero has turned up yet
+    bool more = stale || (want_min && !__syncthreads_or(lmin <= 0.0f));
+    if (more) {
+      for (int64_t base = want_min ? (int64_t)kBlock * 8 : 0; base < numel; base += kBlock * 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int64_t i = base + threadIdx.x + (int64_t)u * kBlock;
@@ -85,12 +104,30 @@ __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict_
         }
         if (!stale && __syncthreads_or(lmin <= 0.0f)) break;            // a zero: the minimum of a non-negative tensor
       }
-      lmin = block_min(lmin, sh);
-      if (threadIdx.x == 0) rng[0] = lmin;
-      lmax = block_max(lmax, sh);
-      if (threadIdx.x == 0 && stale) rng[1] = lmax;
     }
-    __syncthreads();
+    // one exchange for the three reductions
+    {
+      float a0 = smax, a1 = lmin, a2 = lmax;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        a0 = fmaxf(a0, __shfl_xor(a0, off, 64));
+        a1 = fminf(a1, __shfl_xor(a1, off, 64));
+        a2 = fmaxf(a2, __shfl_xor(a2, off, 64));
+      }
+      if ((threadIdx.x & 63) == 0) {
+        red3[0][threadIdx.x >> 6] = a0;
+        red3[1][threadIdx.x >> 6] = a1;
+        red3[2][threadIdx.x >> 6] = a2;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const float bmax = fmaxf(fmaxf(red3[0][0], red3[0][1]), fmaxf(red3[0][2], red3[0][3]));
+        const float bmin = fminf(fminf(red3[1][0], red3[1][1]), fminf(red3[1][2], red3[1][3]));
+        const float bscan = fmaxf(fmaxf(red3[2][0], red3[2][1]), fmaxf(red3[2][2], red3[2][3]));
+        rng[0] = (stale || want_min) ? bmin : 0.0f;
+        rng[1] = stale ? bscan : bmax;
+      }
+    }
   }
   if (threadIdx.x == 0) {
     float mn, mx;
@@ -146,13 +183,14 @@ __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict_
     sh[0] = sc;
   }
   __syncthreads();
-  const float b_scale = sh[0] * wrec[kRecScale];                        // in_scale * w_scale, fp32 (:123)
+  const float b_scale = sh[0] * w_scale;                                // in_scale * w_scale, fp32 (:123)
   const float b_max = b_scale * 2147483648.0f;                          // (:124)
   for (int c = threadIdx.x; c < cout; c += kBlock) {
     if (ibias != nullptr) {
       int code = 0;
       if (bias != nullptr) {                                            // clip, round, cast (:125-127); 2^31 wraps like the cast
-        const float q = roundf(fminf(fmaxf(bias[c], -b_max), b_max) / b_scale);
+        const float bv = c == (int)threadIdx.x ? bias0 : bias[c];
+        const float q = roundf(fminf(fmaxf(bv, -b_max), b_max) / b_scale);
         code = (int)(unsigned)(long long)q;
       }
       ibias[c] = code;
@@ -522,8 +560,12 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
   // per-sample statistic of the output is only offered there, where the fast kernel's result is final)
   const bool representable = input_mode == FQ_CODES_INT8 || (in_stat != nullptr && (ph > 0 || pw > 0));
   if (fast && representable) return FQ_OK;
+  // (as a conditional fix-up - which a record of a [0, max] range with one zero in the tensor never asks for - the launch
+  // returns at once: one workgroup per CU keeps that at ~2 us instead of the 4.6 us of 4096 workgroups; the recomputation
+  // itself, when it does run, walks its outputs with that smaller grid)
   const int64_t want = (out_numel + kBlock - 1) / kBlock;
-  const int grid = (int)(want < (int64_t)num_cu() * 16 ? want : (int64_t)num_cu() * 16);
+  const int64_t cap = (int64_t)num_cu() * (fast ? 1 : 16);
+  const int grid = (int)(want < cap ? want : cap);
   hipLaunchKernelGGL(qconv_direct_kernel, dim3(grid), dim3(kBlock), 0, st, x, w, ib, y, s, (const float*)rec, wrec, act,
                      fast ? 1 : 0, bn_scale, bn_shift, stat_out);
   FQ_LAUNCH_CHECK();
