@@ -416,7 +416,9 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             fused[0] += 1
 
     def visit_gap(container):
-        """GlobalAvgPool2D [-> Flatten] -> quantised Dense: pool and statistic in one launch, carried through Flatten."""
+        """GlobalAvgPool2D [-> Flatten]: pool and statistic in one launch (fq_global_avg_pool_stat), the statistic carried
+        through Flatten to a quantised Dense.  Whatever follows (MobileNetV2: an un-quantised 1x1 convolution), the pooling runs
+        as this library's kernel - the tensor library's mean over (128, 1280, 7, 7) took 52 us of that step against 9-15."""
         if not isinstance(container, (nn.Sequential, nn.HybridSequential)):
             return
         kids = list(container._children.values()) + after_features.get(id(container), [])
@@ -431,9 +433,6 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
                     kids[j].hybrid_forward.__func__ is nn.Flatten.hybrid_forward:
                 flat = kids[j]
                 j += 1
-            cons = kids[j] if j < len(kids) else None
-            if not (type(cons) is nn.Dense and hasattr(cons, "quantize_args") and cons.quantize_args.quantize_input):
-                continue
             b._fq_gap_fused = {"orig": b.hybrid_forward, "flatten": flat,
                                "flatten_orig": None if flat is None else flat.hybrid_forward}
             b.hybrid_forward = types.MethodType(_gap_stat_forward, b)
