@@ -35,4 +35,10 @@ python3 tools/dw16bench.py > $O/${TAG}_dw16bench.txt 2>/dev/null
 python3 tools/c3bench.py > $O/${TAG}_c3bench.txt 2>/dev/null
 python3 tools/stembench.py >> $O/${TAG}_c3bench.txt 2>/dev/null
 python3 tools/cli_lane_probe.py 2>/dev/null | grep "^evaluate\|^mode\|^one lane\|^CLI" > $O/${TAG}_cli_lane_probe.txt
+# per-layer state of the other steps (one stream, eager), the 3x3 kernel's phase stamps, the barrier probe
+BENCH_ARGS="--model mobilenetv2_1.0 --quant-type channel --weight-bits 4 --offline --streams 1 --graph 0" MIN_US=8 bash tools/kprof.sh "" > $O/${TAG}_kprof_mobilenetv2.txt 2>&1
+BENCH_ARGS="--model resnet50_v1 --quant-type channel --streams 1 --graph 0" MIN_US=8 bash tools/kprof.sh "" > $O/${TAG}_kprof_resnet50.txt 2>&1
+BENCH_ARGS="--model resnet50_v1 --quant-type channel --offline --streams 1 --graph 0" MIN_US=8 bash tools/kprof.sh "" > $O/${TAG}_kprof_resnet50_offline.txt 2>&1
+[ -f build_tools/libfakequant_trace.so ] && python3 tools/c3_trace.py > $O/${TAG}_c3_trace.txt 2>/dev/null
+[ -x build_tools/grid_barrier_probe ] && ./build_tools/grid_barrier_probe > $O/${TAG}_grid_barrier_probe.txt 2>&1
 ls -la $O | head -80
