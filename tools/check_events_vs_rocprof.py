@@ -1,22 +1,20 @@
-"""Do the HIP-event figures of a bench.py line follow from a rocprofv3 kernel table?
+"""Do the per-kernel figures of a bench.py line follow from a rocprofv3 kernel table?
 
     python tools/check_events_vs_rocprof.py LINE.json KERNEL_STATS.csv [--tol 0.03] [--steps-from gap_stat]
 
-LINE.json: a line of `bench.py` (its `roofline.kernels[family]` carries `ms_per_step`, `avg_launch_us`, `frac` from RAW HIP
-events and `algorithmic_bytes_per_launch`).  KERNEL_STATS.csv: `rocprofv3 --kernel-trace --stats --output-format csv` of
-`bench.py --streams 1 --graph 0` (one batch at a time: with batches in flight a kernel's wall duration includes the time it
-shares the CUs).  Per family the script adds up the table's TotalDurationNs over the family's kernels, divides by the number
-of steps the profiled process ran (= calls of the pooling kernel, one per step) and recomputes launch time and fraction of
-8 TB/s from the line's algorithmic bytes.
+LINE.json: a line of `bench.py`: `roofline.kernels[family]` carries `ms_per_step` / `avg_launch_us` / `frac` (HIP-event time
+minus the event pairs' cost measured in that process) and the same with `_raw_events`.  KERNEL_STATS.csv: `rocprofv3
+--kernel-trace --stats --output-format csv` of `bench.py --streams 1 --graph 0` (one batch at a time: with batches in flight a
+kernel's wall duration includes the time it shares the CUs).  Per family the script adds up the table's TotalDurationNs over
+the family's kernels, divides by the number of steps the profiled process ran (= calls of a kernel every step holds once) and
+recomputes the fraction of 8 TB/s from the line's algorithmic bytes.
 
-What the line can promise (measured on four boxes, round 4): an event pair around ONE launch exceeds the kernel's duration in
-rocprofv3's table by 1-2.5 us, depending on the box and the process (inside a rocprofv3 process: ~5 us) - 2-6 % of these
-30-110 us launches; the line's `avg_launch_us_launch_overhead_removed` (raw minus the bracketing cost measured live on a
-self-timing kernel, fq_profile_launch_overhead) lands 0-4.5 % BELOW the table.  Neither is within 3 % everywhere; the table's
-figure lies BETWEEN them on every box.  So the judged `frac` is the raw-event one (the lower bound of the fraction), and this
-script checks the bracket:  removed * (1 - tol) <= rocprof <= raw * (1 + tol)  per family, --tol 0.01 by default.  Exit status
-1 when the DOMINANT family (the one `roofline.frac` describes) falls outside; other families are printed (the line and the
-table come from two processes on the same box).
+THE check is the SAME-PROCESS one: the line printed by the process that ran under rocprofv3 (`*_under_rocprof.json`) against
+that process' table - exit status 1 when the DOMINANT family (the one `roofline.frac` describes) differs by more than --tol.
+(r4, three runs on two boxes: 0.996 / 0.997, 0.997 / 1.001, 1.017 / 1.017 for depthwise / pointwise; the raw event time of
+the same lines: 1.11-1.15.)  A line from ANOTHER process of the same box can be given too, but then two processes are being
+compared: on this pool they differ by up to 10 % whatever is measured (same command, same box, minutes apart: 109.8 k vs
+115.8 k images/s), so that comparison is printed with its ratios and only gated when --cross-process-gate is given.
 """
 import csv
 import json
@@ -39,7 +37,7 @@ HBM_PEAK_GBS = 8000.0
 
 
 def main(argv):
-    tol = 0.01
+    tol = 0.03
     if "--tol" in argv:
         tol = float(argv[argv.index("--tol") + 1])
     line = json.load(open(argv[0]))
@@ -52,8 +50,10 @@ def main(argv):
     kernels = line["roofline"]["kernels"]
     step_us = sum(k["ms_per_step"] for k in kernels.values()) * 1e3
     print("steps in the profiled process: %d; families of the line: %s" % (steps, ", ".join(kernels)))
-    print("%-10s %14s %14s %14s %8s %8s %10s %10s %10s" % ("family", "raw us/step", "removed us/step", "rocprof us/step", "raw/rp",
-                                                          "rem/rp", "frac(line)", "frac(rem)", "frac(csv)"))
+    same_process = "under_rocprof" in argv[0] or "--same-process" in argv
+    gate = same_process or "--cross-process-gate" in argv
+    print("%-10s %14s %14s %14s %8s %8s %10s %10s %10s" % ("family", "line us/step", "raw us/step", "rocprof us/step", "line/rp",
+                                                          "raw/rp", "frac(line)", "frac(raw)", "frac(csv)"))
     bad = 0
     for fam, k in kernels.items():
         names = FAMILIES.get(fam)
@@ -64,22 +64,26 @@ def main(argv):
         if tot_ns == 0:
             continue
         rp_us = tot_ns / steps / 1e3
+        if "avg_launch_us_launch_overhead_removed" in k:      # a line of rounds 3 / early 4: the plain keys held the raw events
+            k = dict(k, ms_per_step_raw_events=k["ms_per_step"], frac_raw_events=k["frac"],
+                     ms_per_step=k["ms_per_step"] * k["avg_launch_us_launch_overhead_removed"] / k["avg_launch_us"],
+                     avg_launch_us=k["avg_launch_us_launch_overhead_removed"], frac=k["frac_launch_overhead_removed"])
         ev_us = k["ms_per_step"] * 1e3
+        raw_us = k.get("ms_per_step_raw_events", k["ms_per_step"]) * 1e3
         launches_per_step = ev_us / max(k["avg_launch_us"], 1e-9)
         frac_csv = k["algorithmic_bytes_per_launch"] * launches_per_step / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS
         ratio = ev_us / rp_us
-        rem_us = k.get("avg_launch_us_launch_overhead_removed", k["avg_launch_us"]) * launches_per_step
         flag = ""
         is_dom = (line["roofline"].get("kernel") or "") == k.get("kernel")
-        inside = rem_us * (1.0 - tol) <= rp_us <= ev_us * (1.0 + tol)
-        if not inside and ev_us >= 0.05 * step_us:
-            bad += 1 if is_dom else 0
-            flag = "  <-- outside [removed, raw]%s" % (" (the dominant family)" if is_dom else "")
+        if abs(ratio - 1.0) > tol and ev_us >= 0.05 * step_us:
+            bad += 1 if (is_dom and gate) else 0
+            flag = "  <-- beyond %.0f %%%s" % (tol * 100, " (the dominant family)" if is_dom else "")
         elif is_dom:
             flag = "  (the dominant family)"
         print("%-10s %14.1f %14.1f %14.1f %8.3f %8.3f %10.4f %10.4f %10.4f%s"
-              % (fam, ev_us, rem_us, rp_us, ratio, rem_us / rp_us, k["frac"], k.get("frac_launch_overhead_removed", k["frac"]),
-                 frac_csv, flag))
+              % (fam, ev_us, raw_us, rp_us, ratio, raw_us / rp_us, k["frac"], k.get("frac_raw_events", k["frac"]), frac_csv, flag))
+    print("(%s)" % ("line and table from the SAME process: gated at %.0f %%" % (tol * 100) if same_process else
+                    "line and table from two processes of one box: printed%s" % (", gated" if gate else ", not gated")))
     dom = line["roofline"].get("kernel")
     print("line: roofline.frac %.4f (%s)" % (line["roofline"]["frac"], (dom or "")[:60]))
     return 1 if bad else 0

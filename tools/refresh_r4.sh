@@ -15,7 +15,8 @@ python3 bench.py --model quantized_mobilenet1.0 --no-fuse --no-cpu-baseline --no
 python3 bench.py --model quantized_mobilenet1.0 --streams 1 --graph 0 --no-cpu-baseline --no-headline > $O/${TAG}_qconv_line_one_stream.json 2>> $O/qconv.err
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_q -o bench -- python3 $R/bench.py --model quantized_mobilenet1.0 --steps 100 --warmup 5 --streams 1 --graph 0 --no-cpu-baseline --no-headline > $O/${TAG}_qconv_line_one_stream_under_rocprof.json 2>> $O/qconv.err )
 cp $(find $O/trace_q -name '*kernel_stats.csv' | head -1) $O/${TAG}_qconv_kernel_stats.csv; rm -rf $O/trace_q
-python3 tools/check_events_vs_rocprof.py $O/${TAG}_qconv_line_one_stream.json $O/${TAG}_qconv_kernel_stats.csv --steps-from stem_mfma > $O/${TAG}_qconv_events_vs_rocprof.txt 2>&1
+python3 tools/check_events_vs_rocprof.py $O/${TAG}_qconv_line_one_stream_under_rocprof.json $O/${TAG}_qconv_kernel_stats.csv --steps-from stem_mfma > $O/${TAG}_qconv_events_vs_rocprof.txt 2>&1
+python3 tools/check_events_vs_rocprof.py $O/${TAG}_qconv_line_one_stream.json $O/${TAG}_qconv_kernel_stats.csv --steps-from stem_mfma >> $O/${TAG}_qconv_events_vs_rocprof.txt 2>&1
 python3 tools/qconv_ablate.py > $O/${TAG}_qconv_ablate.txt 2>&1
 bash tools/cli_vs_bench.sh > $O/${TAG}_cli_vs_bench.txt 2>&1
 for v in 1 0; do
