@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-6)                # Config.lr
     ap.add_argument("--offline-at", type=int, default=40, help="switch the input quantisers on, offline (Config.offline_at)")
     ap.add_argument("--width", type=int, default=4)
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: capture the whole step (forward + backward + Adam + update_ema) into a hipGraph once per input-"
+                         "quantisation mode and replay it (the step is ~3700 launches: launching them from Python is what a "
+                         "step costs); the optimiser then keeps its step counter on the device")
     ap.add_argument("--dataset", action="store_true", help="iterate the facade's synthetic CIFAR10 dataset instead of "
                                                            "on-device random batches")
     args = ap.parse_args()
@@ -70,7 +74,7 @@ def main():
     dev = ctx.torch_device
     net = build(args.model, ctx, args.width)
     loss_func = gluon.loss.SoftmaxCrossEntropyLoss()
-    trainer = gluon.Trainer(net.collect_params(), "adam", {"learning_rate": args.lr})
+    trainer = gluon.Trainer(net.collect_params(), "adam", {"learning_rate": args.lr, "capturable": bool(args.graph)})
 
     def batches():
         if args.dataset:
@@ -88,25 +92,51 @@ def main():
             y = torch.randint(0, 10, (args.batch_size,), device=dev, generator=g).float()
             yield mx.nd.NDArray(X), mx.nd.NDArray(y)
 
-    stream = batches()
-    quantize_offline = False
-    losses = []
-    t0 = None
-    for step in range(1, args.warmup + args.steps + 1):
-        if step == args.warmup + 1:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        X, y = next(stream)
+    def train_step(X, y):
         with autograd.record():
             outputs = net(X)
             loss = loss_func(outputs, y)
         net.update_ema()
         loss.backward()
         trainer.step(args.batch_size, ignore_stale_grad=True)        # bypassed BatchNorms never receive a gradient
-        losses.append(loss._t.detach().mean())
+        return loss._t.detach().mean()
+
+    stream = batches()
+    quantize_offline = False
+    losses = []
+    t0 = None
+    graph, eager_left, captures = None, 2, 0
+    Xs = ys = loss_s = None
+    side = torch.cuda.Stream(dev) if args.graph else None
+    for step in range(1, args.warmup + args.steps + 1):
+        if step == args.warmup + 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        X, y = next(stream)
+        if not args.graph:
+            losses.append(train_step(X, y))
+        elif graph is not None:
+            Xs.copy_(X._t)
+            ys.copy_(y._t)
+            graph.replay()
+            losses.append(loss_s.clone())
+        elif eager_left > 0:                                         # the first steps of a mode: eager (lazy state, library warm-up)
+            eager_left -= 1
+            losses.append(train_step(X, y))
+        else:                                                        # capture this step on static buffers; it runs when replayed
+            Xs, ys = X._t.clone(), y._t.clone()
+            side.wait_stream(torch.cuda.current_stream(dev))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                loss_s = train_step(mx.nd.NDArray(Xs), mx.nd.NDArray(ys))
+            torch.cuda.current_stream(dev).wait_stream(side)
+            captures += 1
+            graph.replay()
+            losses.append(loss_s.clone())
         if not quantize_offline and step - args.warmup >= args.offline_at:
             net.quantize_input(enable=True, online=False)
             quantize_offline = True
+            graph, eager_left = None, 2                              # another forward: capture again
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ls = torch.stack(losses).cpu().numpy()
@@ -114,7 +144,7 @@ def main():
     print(json.dumps({
         "what": "QAT fine-tuning step (forward + backward + Adam) of the reference notebook's configuration",
         "model": args.model, "quantised_blocks": len(blocks), "width": args.width, "batch_size": args.batch_size,
-        "steps": args.steps, "offline_at": args.offline_at, "images_per_sec": round(args.steps * args.batch_size / elapsed, 1),
+        "steps": args.steps, "offline_at": args.offline_at, "graph": bool(args.graph), "captures": captures, "images_per_sec": round(args.steps * args.batch_size / elapsed, 1),
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "loss_first": float(ls[args.warmup]),
         "loss_last": float(ls[-1]), "loss_finite": bool(np.isfinite(ls).all()),
         "input_max_range": [float(min(b.input_max.data().asnumpy()[0] for b in blocks)),

@@ -34,10 +34,16 @@ class Trainer(object):
         self._eps = float(op.pop("epsilon", 1e-8))
         self._clip = op.pop("clip_gradient", None)
         self._rescale_user = float(op.pop("rescale_grad", 1.0))
+        op_capturable = op.pop("capturable", False)
         if op:
             raise ValueError("Trainer: unsupported optimizer_params %s" % sorted(op))
         self._state = {}
         self._t = {}
+        # capturable: the step counter and Adam's bias-corrected rate live on the device and are advanced by device
+        # operations inside `step`, so that a whole training step (forward + backward + step) can be captured into a
+        # hipGraph and replayed (examples/qat_finetune.py --graph): a replay runs no Python, a host-side `t` would stay frozen
+        self._capturable = bool(op_capturable)
+        self._dev_t = None
 
     @property
     def learning_rate(self):
@@ -100,6 +106,20 @@ class Trainer(object):
                 torch._foreach_add_(vs, torch._foreach_mul(torch._foreach_mul(gs, 1.0 - self._beta2), gs))   # ((1 - b2) g') g'
                 den = torch._foreach_sqrt(vs)
                 torch._foreach_add_(den, self._eps)
+                if self._capturable:
+                    # lr_t from a step counter on the device (fp64, the host formula's precision): every parameter of a
+                    # captured step takes part in every replay, so one counter serves them all
+                    if self._dev_t is None:
+                        self._dev_t = torch.zeros((), dtype=torch.float64, device=ws[0].device)
+                    self._dev_t += 1.0
+                    b1 = torch.full_like(self._dev_t, self._beta1)
+                    b2 = torch.full_like(self._dev_t, self._beta2)
+                    lr_t = (self._lr * torch.sqrt(1.0 - torch.pow(b2, self._dev_t)) /
+                            (1.0 - torch.pow(b1, self._dev_t))).to(torch.float32)
+                    num = torch._foreach_mul(ms, lr_t)
+                    torch._foreach_div_(num, den)
+                    torch._foreach_sub_(ws, num)
+                    by_t = {}
                 for t, idx in by_t.items():                          # (one group unless some parameters skipped steps)
                     lr_t = self._lr * math.sqrt(1.0 - self._beta2 ** t) / (1.0 - self._beta1 ** t)
                     num = torch._foreach_mul([ms[i] for i in idx], lr_t)

@@ -323,15 +323,27 @@ def _unwrap_key(key):
     return key
 
 
+_scalars = {}          # (device, dtype, value) -> 0-dim tensor: read-only operands, made once
+
+
 def _operand(o, like):
-    """Right-hand operand with MXNet semantics: scalars become fp32(scalar) on the array's device."""
+    """Right-hand operand with MXNet semantics: scalars become fp32(scalar) on the array's device (a DEVICE scalar, so that
+    `x / c` is an IEEE division - with a host scalar the tensor library multiplies by the reciprocal).  Cached per value and
+    filled by a kernel, not copied from the host: an arithmetic expression with a constant is then legal inside a hipGraph
+    capture (examples/qat_finetune.py --graph)."""
     if isinstance(o, NDArray):
         return o._t
     if isinstance(o, torch.Tensor):
         return o
     if isinstance(o, (numbers.Number, np.generic)):
         if like.dtype.is_floating_point:
-            return torch.tensor(float(o), dtype=like.dtype, device=like.device)
+            key = (like.device, like.dtype, float(o))
+            t = _scalars.get(key)
+            if t is None:
+                if len(_scalars) > 4096:
+                    _scalars.clear()
+                t = _scalars[key] = torch.full((), float(o), dtype=like.dtype, device=like.device)
+            return t
         return o
     if isinstance(o, np.ndarray):
         return torch.from_numpy(o).to(like.device)

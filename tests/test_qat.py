@@ -383,3 +383,88 @@ def test_notebook_configuration_on_cpu():
 def test_notebook_configuration_on_gpu(gpu):
     res = _run_notebook_config(gpu, steps=4, offline_at=2)
     _check_notebook(res, 4, 1e-2, 5e-2, 5e-3)
+
+
+def test_capturable_adam_takes_the_same_steps():
+    """`Trainer(..., {'capturable': True})` (examples/qat_finetune.py --graph): the step counter and the bias-corrected rate
+    live on the device; the updates are those of the host-side formula (fp64 on both sides, one fp32 rounding)."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.mx import gluon
+    from quantization.mxnet_amd.mx.gluon import nn
+    nets, trs = [], []
+    for cap in (False, True):
+        np.random.seed(5)
+        d = nn.Dense(3, in_units=4)
+        d.initialize(mx.init.Xavier())
+        nets.append(d)
+        trs.append(gluon.Trainer(d.collect_params(), "adam", {"learning_rate": 1e-2, "wd": 1e-3, "capturable": cap}))
+    nets[1].weight.set_data(nets[0].weight.data())
+    nets[1].bias.set_data(nets[0].bias.data())
+    rng = np.random.default_rng(2)
+    for it in range(5):
+        x = mx.nd.array(rng.standard_normal((6, 4)).astype(np.float32))
+        for d, tr in zip(nets, trs):
+            with mx.autograd.record():
+                out = (d(x) * d(x)).sum()
+            out.backward()
+            tr.step(6)
+        np.testing.assert_allclose(nets[1].weight.data().asnumpy(), nets[0].weight.data().asnumpy(), rtol=2e-7, atol=1e-9)
+        np.testing.assert_allclose(nets[1].bias.data().asnumpy(), nets[0].bias.data().asnumpy(), rtol=2e-7, atol=1e-9)
+    assert float(trs[1]._dev_t) == 5.0
+
+
+@pytest.mark.gpu
+def test_a_captured_training_step_replays_what_the_eager_steps_compute(gpu):
+    """The whole QAT step - forward through the HIP fake-quant kernels, backward, Adam, update_ema - captured into a hipGraph and
+    replayed on new batches (examples/qat_finetune.py --graph 1) against the same steps launched eagerly.  A Dense-only net:
+    its backward has no atomics, so the two must agree to rounding of the rate."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.mx import autograd, gluon
+    from quantization.mxnet_amd.mx.gluon import nn
+    from quantization.mxnet_amd.mx.gluon.block import reset_naming
+    from quantization.mxnet_amd.quantize import convert
+    from quantization.mxnet_amd.quantize.initialize import qparams_init
+    dev = gpu.torch_device
+    rng = np.random.default_rng(4)
+    data = [(rng.standard_normal((8, 16)).astype(np.float32), rng.integers(0, 4, 8).astype(np.float32)) for _ in range(6)]
+
+    def build(cap):
+        reset_naming()
+        np.random.seed(11)
+        net = nn.HybridSequential()
+        net.add(nn.Dense(32, in_units=16, activation="relu"), nn.Dense(4, in_units=32))
+        fn = {nn.Dense: convert.gen_dense_converter(quant_type="layer", input_width=8, weight_width=8)}
+        convert.convert_model(net, exclude=[], convert_fn=fn)
+        net.initialize(mx.init.Xavier())
+        qparams_init(net)
+        net.collect_params().reset_ctx(gpu)
+        return net, gluon.Trainer(net.collect_params(), "adam", {"learning_rate": 1e-3, "capturable": cap})
+    loss_fn = gluon.loss.SoftmaxCrossEntropyLoss()
+
+    def step(net, tr, X, y):
+        with autograd.record():
+            loss = loss_fn(net(X), y)
+        net.update_ema()
+        loss.backward()
+        tr.step(8, ignore_stale_grad=True)
+        return loss._t.detach().mean()
+    net_e, tr_e = build(False)
+    want = [float(step(net_e, tr_e, mx.nd.array(x, ctx=gpu), mx.nd.array(y, ctx=gpu))) for x, y in data]
+    net_g, tr_g = build(True)
+    got = [float(step(net_g, tr_g, mx.nd.array(x, ctx=gpu), mx.nd.array(y, ctx=gpu))) for x, y in data[:2]]
+    Xs, ys = torch.from_numpy(data[2][0]).to(dev), torch.from_numpy(data[2][1]).to(dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+        loss_s = step(net_g, tr_g, mx.nd.NDArray(Xs), mx.nd.NDArray(ys))
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for x, y in data[2:]:
+        Xs.copy_(torch.from_numpy(x))
+        ys.copy_(torch.from_numpy(y))
+        g.replay()
+        got.append(float(loss_s))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    for pe, pg in zip(net_e.collect_params().values(), net_g.collect_params().values()):
+        np.testing.assert_allclose(pg.data().asnumpy(), pe.data().asnumpy(), rtol=1e-5, atol=1e-6, err_msg=pe.name)
+    assert float(tr_g._dev_t) == 6.0
