@@ -305,8 +305,11 @@ def main():
     ap.add_argument("--min-region-s", type=float, default=1.0,
                     help="total time to cover with repeated blocks when one block is shorter than --min-block-s")
     ap.add_argument("--max-repeats", type=int, default=100)
-    ap.add_argument("--event-every", type=int, default=25,
-                    help="bracket the library's kernels with HIP events in every n-th timed step (default 25: 20 steps of the default 500; a bracketed step costs ~35 % more and, with --streams > 1, runs alone)")
+    ap.add_argument("--event-every", type=int, default=None,
+                    help="bracket the library's kernels with HIP events in every n-th timed step (default 50 - calibration "
+                         "phases, whose blocks are a dozen batches with a special first one: 7 -: 10 steps of the "
+                         "default 500 = 130 launches per family; a bracketed step is launched eagerly and, with --streams > 1, "
+                         "runs alone - at every 25th step that cost `value` 4 %%: 126 k against 132 k images/s without events)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (roofline fields become empty)")
     ap.add_argument("--no-headline", action="store_true",
@@ -536,6 +539,8 @@ def main():
 
     # Kernel events are SAMPLED inside the timed region (every `event_every`-th step): bracketing all ~45 launches of a
     # step costs ~35 % of THAT step (two marker packets per launch), and the cost is charged to `value`.
+    if args.event_every is None:
+        args.event_every = 50 if args.phase == "eval" else 7
     event_every = 0 if args.no_kernel_events else max(1, args.event_every)
     profiled_steps = 0
     if event_every:
