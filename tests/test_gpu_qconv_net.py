@@ -170,3 +170,48 @@ def test_an_unpadded_consumer_of_a_tensor_without_zeros_takes_its_true_minimum(g
     a, b = spy.calls
     assert b["in_stat"] is not None and b["x"].min() > 0.5
     _check_calls(spy.calls)
+
+
+def test_quantized_mobilenet_against_the_float_net_and_the_simulated_one(gpu):
+    """The reference's own check of this model (tests/test_quantized_conv.py:60-79, `test_quantized_mobilnet`): the net built from
+    `nn.Conv2D(quantized=True)`, the zoo's float mobilenet1.0 and the SIMULATED-quantisation net (`convert_model` with the first
+    convolution excluded + `qparams_init`) on the same parameters and the same image batch.  The reference prints the three top-20
+    lists; here (random parameters, no model store) the three logit tensors are held against each other: both quantised nets
+    stay close to the float one, and closer to each other's side of it than an unrelated net would - plain and fused."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.mx.gluon.model_zoo import get_model
+    from quantization.mxnet_amd.nn import fuse as qfuse
+    from quantization.mxnet_amd.quantize import convert
+    from quantization.mxnet_amd.quantize.initialize import qparams_init
+    my_net = _build("v1", 1.0, 1000, gpu, seed=11)
+
+    def same_parameters(net):
+        net.initialize(ctx=gpu)
+        mine = list(my_net.collect_params().values())
+        theirs = list(net.collect_params().values())
+        assert len(mine) == len(theirs)
+        for a, b in zip(mine, theirs):                                 # (same creation order, same shapes: a gluoncv file loads)
+            assert a.shape == b.shape, (a.name, b.name)
+            b.set_data(a.data())
+        net.collect_params().reset_ctx(gpu)
+        return net
+    ref_net = same_parameters(get_model("mobilenet1.0", classes=1000))
+    sim_net = same_parameters(get_model("mobilenet1.0", classes=1000))
+    convert.convert_model(sim_net, exclude=[sim_net.features[0]])
+    qparams_init(sim_net)
+    sim_net.collect_params().reset_ctx(gpu)
+    x = mx.nd.array(np.random.default_rng(5).random((4, 3, 224, 224)).astype(np.float32), ctx=gpu)      # nd.uniform, as there
+    ref = ref_net(x).asnumpy()
+    sim = sim_net(x).asnumpy()
+    my = my_net(x).asnumpy()
+    scale = np.abs(ref).max()
+    assert np.isfinite(my).all() and scale > 0
+    # 8-bit per-tensor / per-layer quantisation of 27 layers: a few per cent of the logits' range
+    assert np.abs(my - ref).max() < 0.2 * scale and np.abs(sim - ref).max() < 0.2 * scale
+    assert np.abs(my - sim).max() < 0.2 * scale
+    top = lambda t: np.argsort(-t, axis=1)[:, :20]
+    overlap = lambda a, b: np.mean([len(set(r) & set(s)) / 20.0 for r, s in zip(top(a), top(b))])
+    assert overlap(my, ref) >= 0.6 and overlap(my, sim) >= 0.6, (overlap(my, ref), overlap(my, sim))
+    qfuse.fuse_inference(my_net)
+    fused = my_net(x).asnumpy()
+    assert np.abs(fused - my).max() <= 0.1 * scale and overlap(fused, ref) >= 0.6
