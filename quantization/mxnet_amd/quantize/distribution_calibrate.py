@@ -93,6 +93,14 @@ def collect_feature_maps(net, bins, loader, ctx, tqdm_desc="Collect FM", sync=No
                 _ = net(X)
                 pending = {}          # id(histogram state) -> (state, tensor): ONE separate pass per histogram and batch
                 seen = {}             # producer -> the NDArray it made in this forward
+                if sinks:
+                    # a producer that binned its output into a shared histogram: a block that reads it must have run too
+                    # (a net whose forward skips blocks from batch to batch cannot hand its histograms to the producers)
+                    fed = {id(state[m]) for m in fm_collector if m in state}
+                    for p_, st_ in sinks.items():
+                        if id(st_) not in fed:
+                            raise RuntimeError("collect_feature_maps: a producer binned a tensor no collected block read in "
+                                               "this forward (FQ_KL_FUSED_HIST=0 collects such nets)")
                 for m, fms in fm_collector.items():
                     tag = getattr(fms[0], "_fq_kl", None) if len(fms) == 1 and sinks is not None else None
                     if tag is not None and seen.setdefault(tag[0], fms[0]) is not fms[0]:
