@@ -5,13 +5,13 @@
 namespace fqi {
 
 // IN16 / OUT16 variants of the two default configurations of every K (four wavefronts per SIMD, one or two channel tiles per
-// wavefront).  Both sides at once is not built: in the nets of BASELINE.json a 1x1 convolution either opens a unit (fp32 in,
-// codes out to the 3x3 / depthwise convolution) or closes it (codes in, fp32 out for the residual add).
+// wavefront).  Both sides at once (round 4): the first 1x1 of a ResNet unit whose producer stored the trunk a second time as
+// this convolution's codes (fq_pwconv_i8_c16_dual) reads codes and hands codes to the unit's 3x3 - K = 256 ... 2048 only.
 int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t grid, size_t lds, const int8_t* wfrag,
                       bool* launched) {
   const PwSplitGeom& t = *static_cast<const PwSplitGeom*>(geom);
   const bool in16 = a.in_c16, out16 = a.out_thr != nullptr;
-  FQ_REQUIRE(!(in16 && out16), "fq_pwconv_i8_c16: codes in AND codes out is not built");
+  FQ_REQUIRE(!(in16 && out16) || kt >= 8, "fq_pwconv_i8_c16: codes in AND codes out is built for 256 input channels and more");
   FQ_REQUIRE(!in16 || a.in_thr != nullptr, "fq_pwconv_i8_c16: a C16 input was quantised with a stored threshold: give in_thr");
 #define FQ_PWS16_CASE(KT_, CW_, D_, IN_, OUT_)                                                                         \
   if (kt == KT_ && cw == CW_ && in16 == IN_ && out16 == OUT_) {                                                        \
@@ -30,6 +30,9 @@ int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t
   FQ_PWS16_CASE(KT_, 1, (KT_ < 7 ? KT_ : 7), false, true) FQ_PWS16_CASE(KT_, 2, (KT_ < 3 ? KT_ : 3), false, true)
   FQ_PWS16_KT(2) FQ_PWS16_KT(4) FQ_PWS16_KT(6) FQ_PWS16_KT(8) FQ_PWS16_KT(10) FQ_PWS16_KT(12) FQ_PWS16_KT(16)
   FQ_PWS16_KT(18) FQ_PWS16_KT(30) FQ_PWS16_KT(32) FQ_PWS16_KT(64)
+#define FQ_PWS16_BOTH(KT_) FQ_PWS16_CASE(KT_, 1, 7, true, true) FQ_PWS16_CASE(KT_, 2, 3, true, true)
+  FQ_PWS16_BOTH(8) FQ_PWS16_BOTH(16) FQ_PWS16_BOTH(32) FQ_PWS16_BOTH(64)
+#undef FQ_PWS16_BOTH
 #undef FQ_PWS16_KT
 #undef FQ_PWS16_CASE
   return FQ_OK;

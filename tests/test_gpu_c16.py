@@ -93,6 +93,37 @@ def test_pointwise_consumer_of_codes_equals_consumer_of_fp32(dev, ops, case, mod
         ops.pwconv_i8(xc, codes, scales, rowsum, in_thr=T(np.float32([thr]), dev), width=8, flags=flags)
 
 
+BOTH_CASES = [(3, 256, 64, 56, 56, 1), (2, 512, 128, 28, 28, 1), (5, 1024, 256, 14, 14, 1), (7, 2048, 512, 7, 7, 1), (2, 256, 64, 9, 11, 1),
+              (2, 512, 128, 28, 28, 2)]
+
+
+@pytest.mark.parametrize("case", BOTH_CASES, ids=["%dx%d->%d@%dx%d/s%d" % c for c in BOTH_CASES])
+def test_pointwise_between_two_code_tensors(dev, ops, case):
+    """Codes in AND codes out (round 4: the first 1x1 of a ResNet unit fed by the trunk's code copy, handing codes to the
+    unit's 3x3): == the codes of what the fp32-in / fp32-out call computes, statistic and batch mean unchanged."""
+    n, cin, cout, h, w, stride = case
+    rng = np.random.default_rng(sum(case) + 17)
+    x = np.maximum(rng.standard_normal((n, cin, h, w)) * 2, 0).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * 0.05).astype(np.float32)
+    sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), 1, 8)
+    thr, thr2 = np.float32(2.3), np.float32(1.7)
+    thr_t = T(np.float32([thr]), dev)
+    stat_in = T(O.absmax_per_sample(x), dev)
+    cur_a, cur_b = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    kw = dict(in_thr=thr_t, width=8, flags=0, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu", stride=stride, in_stat=stat_in)
+    want, want_stat = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, form="split", cur_out=cur_a, **kw)
+    cx = O.ste_codes(x, O.act_scale(thr, False, 8), thr, np.float32(0))
+    xc = ops.Codes16(T(O.to_c16(cx.astype(np.int64), 128), dev), x.shape, thr_t, 8, 0)
+    yc, st = ops.pwconv_i8(xc, codes, scales, rowsum, cur_out=cur_b, out_codes=dict(thr=T(np.float32([thr2]), dev), width=8, flags=0),
+                           **kw)
+    wantc = O.to_c16(O.ste_codes(want.cpu().numpy(), O.act_scale(thr2, False, 8), thr2, np.float32(0)).astype(np.int64), 128)
+    assert isinstance(yc, ops.Codes16) and yc.shape == tuple(want.shape)
+    assert np.array_equal(yc.t.cpu().numpy(), wantc), "codes of the output"
+    assert torch.equal(st, want_stat) and torch.equal(cur_a, cur_b)
+
+
 DW_CASES = [(2, 96, 112, 112, 2), (2, 144, 56, 56, 1), (3, 24, 9, 11, 1), (2, 192, 28, 28, 2), (3, 384, 14, 14, 1),
             (2, 960, 7, 7, 1), (4, 40, 5, 6, 2), (1, 16, 70, 70, 1)]
 
