@@ -307,7 +307,7 @@ int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wsca
  *   zoff = 128 for unsigned codes, 0 for signed ones (what fq_pwconv_i8 builds in LDS from fp32 input); channels past C
  *   hold the code 0.  A pixel's 16 channels are ONE 16-byte vector: a consumer lane loads a B fragment with one instruction
  *   (NCHW fp32: 16 loads and 16 quantisations), a producer lane stores a channel tile with 4 instructions instead of 16.
- * fq_pwconv_i8_c16 is fq_pwconv_i8_strided with either side as a C16 tensor (not both):
+ * fq_pwconv_i8_c16 is fq_pwconv_i8_strided with either side as a C16 tensor (both at once from 256 input channels up):
  *   x_is_c16 != 0: x is a C16 tensor quantised with in_thr / in_width / in_flags (in_thr required; in_stat, when given, only
  *                  feeds out_current_max - the reference computes `current_input_max` in every mode);
  *   out_thr != NULL: y is a C16 tensor holding the codes of act(BN(conv)) under the CONSUMER's out_thr[0] / out_width /
@@ -320,6 +320,18 @@ int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const fl
                      float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
                      const float* residual, const float* out_thr, int out_width, unsigned out_flags, void* ws,
                      fqStream_t stream);
+
+/* The closing 1x1 of a residual unit with TWO outputs (round 4): x is a C16 tensor (the unit's 3x3 handed its codes over),
+ * y (n, cout, h, w) fp32 = act(BN(conv) + residual) as fq_pwconv_i8_c16 computes it - the shortcut of the NEXT unit needs these
+ * values - and y16, a C16 tensor of the same shape, = the codes of y under out_thr / out_width / out_flags, the stored threshold of
+ * the next unit's first 1x1, which then reads 1 byte per element instead of 4 (it is itself a codes-in / codes-out call of
+ * fq_pwconv_i8_c16 when it hands over to its 3x3).  Same fp32 values, same codes as quantising y afterwards.  stride 1;
+ * cin_pad in {64, 128, 256, 512}, cout % 32 == 0.                                                                          */
+int fq_pwconv_i8_c16_dual(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                          float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                          const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                          const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual,
+                          const float* out_thr, int out_width, unsigned out_flags, void* ws, fqStream_t stream);
 
 /* Dense 3x3 convolution (stride 1, padding 1, no groups / dilation) on the integer codes: the same identity as
  * fq_pwconv_i8 with K = 9 * Cin, i.e. what the reference's fp32 F.Convolution of the two fake-quantised tensors computes

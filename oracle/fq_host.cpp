@@ -765,6 +765,22 @@ int fq_pwconv_i8_c16_host(const void* x, int x_is_c16, const int8_t* wcodes, con
   return FQ_OK;
 }
 
+// the closing 1x1 of a residual unit with two outputs: the fp32 result, and its codes under the next consumer's threshold
+int fq_pwconv_i8_c16_dual_host(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                               float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                               const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                               float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                               const float* residual, const float* out_thr, int out_width, unsigned out_flags, void* ws,
+                               fqStream_t stream) {
+  REQUIRE(y16 && out_thr && residual && in_thr, "fq_pwconv_i8_c16_dual_host: null pointer");
+  if (int rc = fq_pwconv_i8_c16_host(x, 1, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, h, w, 1, in_stat, in_thr,
+                                     in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, nullptr,
+                                     8, 0, ws, stream))
+    return rc;
+  c16_encode(y, n, cout, h * w, out_thr, out_width, out_flags, (int8_t*)y16);
+  return FQ_OK;
+}
+
 int fq_conv3x3_i8_c16_host(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                            const float* bias, void* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
                            const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,

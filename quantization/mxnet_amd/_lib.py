@@ -65,6 +65,10 @@ EXPORTS = {
                                     _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "fq_pwconv_i8_c16": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,
                                 _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _uint, _vp, _vp]),
+    # x, wcodes, wscale, wsum, bias, y, y16, n, cin, cin_pad, cout, h, w, in_stat, in_thr, in_width, in_flags, cur, bn_scale,
+    # bn_shift, act, stat_out, residual, out_thr, out_width, out_flags, ws, stream
+    "fq_pwconv_i8_c16_dual": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int,
+                                     _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _uint, _vp, _vp]),
     "fq_conv3x3_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                              _vp, _int, _vp, _vp]),
     "fq_conv3x3_i8_c16": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp,

@@ -36,6 +36,10 @@ struct PwCall {
   const float* out_thr = nullptr;   // non-null: y is a C16 tensor holding the CONSUMER's codes for this threshold
   float out_levels = 0.0f;
   int out_lo_neg = 0, out_zoff = 0;
+  // fq_pwconv_i8_c16_dual: y stays fp32 and y16 receives the codes of the same values under dual_thr (out_levels / out_lo_neg /
+  // out_zoff describe that quantiser); C16 input + residual operand only (the closing 1x1 of a ResNet unit)
+  void* y16 = nullptr;
+  const float* dual_thr = nullptr;
   // fq_dense_i8_eval (rows form): the evaluation counters of the logits in the same launch
   const long long* eval_labels = nullptr;
   float* eval_counters = nullptr;

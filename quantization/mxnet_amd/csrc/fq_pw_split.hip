@@ -23,6 +23,8 @@ int pw_try_split(const PwCall& a, bool* taken) {
   shape_ok = shape_ok && (32 / a.hw + 2) * a.cout * a.hw * 4 < (1ll << 31) && a.cin * hw_in * 4 * (32 / a.hw + 2) < (1ll << 31);
   static const int mode = env_int("FQ_PWS_AUTO", 1);                    // tuning: 0 never, 1 by shape, 2 always
   const bool c16 = a.in_c16 || a.out_thr != nullptr;                    // (only this form reads / writes C16 code tensors)
+  FQ_REQUIRE(a.y16 == nullptr || (a.in_c16 && a.out_thr == nullptr && a.stride == 1), "fq_pwconv_i8_c16_dual: a second output "
+             "goes with a C16 input, fp32 y and stride 1");
   bool want = a.form == 6 || a.stride != 1 || c16;                      // (only this form reads strided inputs)
   if (a.form == 0 && shape_ok && a.stride == 1)
     want = mode == 2 || (mode == 1 && (tiles <= (int64_t)num_cu() * 16 || !pw_stream_shape_ok(a)));
@@ -54,6 +56,7 @@ int pw_try_split(const PwCall& a, bool* taken) {
     t.items = tiles * t.CS;
     t.CBi = (int)((a.cin + 15) / 16); t.CBo = (int)((a.cout + 15) / 16);
     t.out_levels = a.out_levels; t.out_lo_neg = a.out_lo_neg; t.out_zoff = a.out_zoff;
+    t.y16 = (char*)a.y16; t.dual_thr = a.dual_thr;
     const int64_t grid = (t.items + 7) / 8 * 8;                           // padded to whole rounds over the 8 XCDs
     FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8: too many tiles for the split form");
     const size_t ldst = (size_t)kt * 1024 + (size_t)(nw * cw * 32) * 5 * sizeof(float);

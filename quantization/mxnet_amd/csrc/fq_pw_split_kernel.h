@@ -34,13 +34,16 @@ struct PwSplitGeom {
   int CBi, CBo;
   float out_levels;
   int out_lo_neg, out_zoff;
+  // DUAL: the second output (C16 codes of y under dual_thr; out_levels / out_lo_neg / out_zoff / CBo describe it)
+  char* y16;
+  const float* dual_thr;
 };
 
 // LB: wavefronts per SIMD the register allocation aims at (3: <= 168 registers, 4: <= 128) - with one tile per workgroup the
 // whole grid should be resident at once (a second round of a few left-over workgroups costs a whole workgroup latency)
 // NW: wavefronts per workgroup.  4: 128 * CW output channels per workgroup; 8 (wide layers): 256 * CW - half as many channel
 // groups quantise the same tile, i.e. half the redundant loads and quantiser VALU.
-template <int KT, int CW, int D, int LB, int NW, bool IN16 = false, bool OUT16 = false>
+template <int KT, int CW, int D, int LB, int NW, bool IN16 = false, bool OUT16 = false, bool DUAL = false>
 __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSplitGeom g,
@@ -249,6 +252,11 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     q2.lo = q2.hi = q2.denom = q2.scale = 0.0f;
     q2.rden = 0.0;
     if (OUT16) q2 = make_qparams(out_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
+    // DUAL (fq_pwconv_i8_c16_dual): y is fp32 AND g.y16 receives the codes of the same values under g.dual_thr - the trunk of a
+    // ResNet stored a second time, 1 B per element, for the next unit's first 1x1 (the shortcut keeps reading the fp32 tensor)
+    if (DUAL) q2 = make_qparams(g.dual_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
+    const fq_rsrc yr16 = make_rsrc(DUAL ? g.y16 + s_base * y_samp16 + (int64_t)cb0 * HW * 16 : reinterpret_cast<char*>(y),
+                                   DUAL ? y16_bytes : 0);
     const int ubias2 = 128 - g.out_zoff;
     // the residual operand (the shortcut of a ResNet / MobileNetV2 unit) has y's shape: same offsets, added after BatchNorm
     const bool has_res = residual != nullptr;
@@ -297,14 +305,14 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
           }
           m = fmaxf(m, fabsf(v));                  // channels past Cout have all-zero constants: v == 0
         }
-        if (OUT16) {
+        if (OUT16 || DUAL) {
           // the four channels 8 gq + 4 h .. + 3 of this lane's pixel are bytes 8 (gq & 1) + 4 h .. of block (c * 2 + gq / 2):
           // the CONSUMER's codes of the values just formed (channels past Cout: v == 0 -> code 0), one 4-byte store
           const int packed = pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
                                          fq_code_int(vq[3], q2), ubias2);
           const bool blk_ok = !MASKED || 16 * (gq >> 1) < cv;             // a whole block past Cout does not exist
-          buf_st_f32(yr, blk_ok ? yo16 : 0x80000000u, (unsigned)((c * 2 + (gq >> 1)) * (int)HW * 16 + 8 * (gq & 1)),
-                     __int_as_float(packed));
+          buf_st_f32(OUT16 ? yr : yr16, blk_ok ? yo16 : 0x80000000u,
+                     (unsigned)((c * 2 + (gq >> 1)) * (int)HW * 16 + 8 * (gq & 1)), __int_as_float(packed));
         }
       }
     };

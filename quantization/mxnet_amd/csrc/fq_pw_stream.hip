@@ -26,6 +26,9 @@ struct PwsGeom {
   int CBo, CBi;
   float out_levels;
   int out_lo_neg, out_zoff;
+  // DUAL (fq_pwconv_i8_c16_dual): y is fp32 AND y16 receives the codes of the same values under dual_thr (CBo / out_* describe it)
+  char* y16;
+  const float* dual_thr;
 };
 
 // RES: a residual operand of y's shape is added after BatchNorm, before the activation (compile-time: the loads of the
@@ -36,7 +39,7 @@ struct PwsGeom {
 // PART: Cin need not be a multiple of 16 (the loads of a ragged half-slab are clamped to the last channel: whatever code
 // they get meets a zero weight code) and Cout need not be a multiple of 32 (channels past Cout get all-zero constants and an
 // out-of-range buffer offset: the hardware drops their stores and returns 0 for their residual loads).
-template <int KT, bool RES, bool OUT16 = false, bool IN16 = false, bool PART = false>
+template <int KT, bool RES, bool OUT16 = false, bool IN16 = false, bool PART = false, bool DUAL = false>
 __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wc, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwsGeom g,
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   q2.lo = q2.hi = q2.denom = q2.scale = 0.0f;
   q2.rden = 0.0;
   if (OUT16) q2 = make_qparams(out_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
+  if (DUAL) q2 = make_qparams(g.dual_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
   const int ubias2 = 128 - g.out_zoff;
   if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
   // weights -> fragment order: fragment (ct, kt), lane (row % 32) + 32 * (16-byte chunk % 2)
@@ -221,9 +225,11 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
           v.y = ACT_M < 0 ? act_rt(v.y, act) : act_rt(v.y, ACT_M);
           // no masks: lanes past the end hold a copy of the last pixel (clamped loads) and re-store its values, and the
           // host guarantees Cout % 32 == 0
-          if (OUT16) {
+          if (OUT16 || DUAL) {
             vq[r] = v.x;
             vq[r + 1] = v.y;
+          }
+          if (OUT16) {
           } else if (PART) {
             const int chn = ct * 32 + 8 * gq + 4 * h + r;
             const unsigned so = (unsigned)((ct * 32 + 8 * gq + r) * plane * 4);
@@ -236,17 +242,17 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
           }
           m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
         }
-        if (OUT16) {   // channels 8 gq + 4 h .. + 3 of the lane's pixel = bytes 8 (gq & 1) + 4 h .. of block 2 ct + gq / 2
+        if (OUT16 || DUAL) {   // channels 8 gq + 4 h .. + 3 of the lane's pixel = bytes 8 (gq & 1) + 4 h .. of block 2 ct + gq / 2
           const int packed = pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
                                          fq_code_int(vq[3], q2), ubias2);
-          if (PART) {                                  // a whole block past Cout (Cout % 32 == 16) does not exist
+          if (PART && !DUAL) {                         // a whole block past Cout (Cout % 32 == 16) does not exist
             const int blk = 2 * ct + (gq >> 1);
             const unsigned o16 = (unsigned)((((int64_t)px.smp * g.CBo + (blk < g.CBo ? blk : 0)) * plane + px.p) * 16 +
                                             8 * (gq & 1) + 4 * h);
             buf_st_f32(yrp, blk < g.CBo ? o16 : 0x80000000u, 0, __int_as_float(packed));
-          } else {
-            char* yb = reinterpret_cast<char*>(y) + (((int64_t)px.smp * g.CBo + 2 * ct + (gq >> 1)) * plane + px.p) * 16 +
-                       8 * (gq & 1) + 4 * h;
+          } else {                                     // (DUAL: the host asks for Cout % 32 == 0)
+            char* yb = (DUAL ? g.y16 : reinterpret_cast<char*>(y)) +
+                       (((int64_t)px.smp * g.CBo + 2 * ct + (gq >> 1)) * plane + px.p) * 16 + 8 * (gq & 1) + 4 * h;
             *reinterpret_cast<int*>(yb) = packed;
           }
         }
@@ -354,6 +360,9 @@ bool pw_stream_thin_takes(const PwCall& c) {
   const bool c16 = c.in_c16 || c.out_thr != nullptr;
   // (form 6 is what every C16 call carries; a fp32 call that NAMES the split form gets the split form)
   const bool form_ok = c.form == 0 || c.form == 3 || (c.form == 6 && c16);
+  // (a second output - fq_pwconv_i8_c16_dual - where the instantiation exists; the split form has the others)
+  const int kt = (int)((c.cin + 31) / 32);
+  if (c.y16 != nullptr && !(c.in_c16 && c.residual != nullptr && c.cout % 32 == 0 && (kt == 2 || kt == 4))) return false;
   return (c.in_c16 || ragged) && pw_stream_thin_ok(c) && form_ok;
 }
 
@@ -379,6 +388,9 @@ int pw_try_stream(const PwCall& c, bool* taken) {
   s.Cin = (int)c.cin; s.K = (int)c.cin_pad; s.Cout = (int)c.cout; s.CT = ct; s.HW = (int)c.hw;
   s.cols = c.n * c.hw; s.tiles = (s.cols + 31) / 32; s.zoff = c.zoff;
   s.CBo = (int)(c.cout / 16); s.CBi = (int)((c.cin + 15) / 16); s.out_levels = c.out_levels; s.out_lo_neg = c.out_lo_neg; s.out_zoff = c.out_zoff;
+  s.y16 = (char*)c.y16; s.dual_thr = c.dual_thr;
+  FQ_REQUIRE(c.y16 == nullptr || (thin && c.in_c16 && c.residual != nullptr && c.cout % 32 == 0 && (kt == 2 || kt == 4)),
+             "fq_pwconv_i8_c16_dual: the streaming form writes a second output for a C16 input with a residual operand, K = 64 / 128");
   // persistent workgroups: as many as stay resident (LDS / 2 per SIMD by registers), each wave a contiguous range
   // (measured, tools/pwbench.py: 3 per CU for the 126-VGPR instantiations KT <= 2, 2 above)
   int per_cu = (int)((160 * 1024) / (lds + 1024));
@@ -416,6 +428,17 @@ int pw_try_stream(const PwCall& c, bool* taken) {
                        c.levels, c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out,         \
                        c.residual, c.out_thr);                                                                         \
   }
+#define FQ_PWS_THIN_DUAL(KT_)                                                                                          \
+  {                                                                                                                    \
+    static const bool attr_ok =                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_, true, false, true, true, true>),  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess;                      \
+    FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the streaming kernel");                   \
+    hipLaunchKernelGGL((pwconv_stream_kernel<KT_, true, false, true, true, true>), dim3((unsigned)grid), dim3(kBlock), lds, \
+                       c.st, c.x, c.wcodes, c.wscale, (const int*)c.wsum, c.bias, c.y, s, c.in_stat, (int)c.n, c.in_thr, \
+                       c.levels, c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out,         \
+                       c.residual, c.out_thr);                                                                         \
+  }
 #define FQ_PWS_THIN_CASE(KT_)                                                                                          \
   case KT_:                                                                                                            \
     if (out16) FQ_PWS_THIN(KT_, false, true, false)                                                                    \
@@ -423,7 +446,9 @@ int pw_try_stream(const PwCall& c, bool* taken) {
     else if (c.in_c16) FQ_PWS_THIN(KT_, false, false, true)                                                            \
     else if (c.residual != nullptr) FQ_PWS_THIN(KT_, true, false, false) else FQ_PWS_THIN(KT_, false, false, false)    \
     break;
-  if (thin) {
+  if (thin && c.y16 != nullptr) {
+    if (kt == 2) FQ_PWS_THIN_DUAL(2) else FQ_PWS_THIN_DUAL(4)
+  } else if (thin) {
     switch (kt) {
       FQ_PWS_THIN_CASE(1) FQ_PWS_THIN_CASE(2) FQ_PWS_THIN_CASE(3) FQ_PWS_THIN_CASE(4) FQ_PWS_THIN_CASE(5) FQ_PWS_THIN_CASE(6)
       default: break;
@@ -435,6 +460,7 @@ int pw_try_stream(const PwCall& c, bool* taken) {
     }
   }
 #undef FQ_PWS_THIN_CASE
+#undef FQ_PWS_THIN_DUAL
 #undef FQ_PWS_THIN
 #undef FQ_PWS_CASE
 #undef FQ_PWS_LAUNCH

@@ -78,7 +78,7 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
                            const float* residual, void* ws, fqStream_t stream, bool in_c16 = false,
                            const float* out_thr = nullptr, int out_width = 8, unsigned out_flags = 0,
                            const long long* eval_labels = nullptr, float* eval_counters = nullptr,
-                           void* eval_ws = nullptr, bool* range_taken = nullptr) {
+                           void* eval_ws = nullptr, bool* range_taken = nullptr, void* y16 = nullptr) {
   // range_taken != nullptr: range mode (fq_common.h: kRangeMode) - in_thr is a range record, bias holds int32 codes; only
   // the one-launch forms serve it and *range_taken says whether one took the shape
   const bool range = range_taken != nullptr;
@@ -110,7 +110,11 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   c.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;      // unsigned codes are stored re-centred so they fit int8
   c.out_current_max = out_current_max; c.bn_scale = bn_scale; c.bn_shift = bn_shift; c.act = act;
   c.stat_out = stat_out; c.residual = residual; c.ws = ws; c.st = (hipStream_t)stream;
-  c.in_c16 = in_c16; c.out_thr = out_thr;
+  c.in_c16 = in_c16; c.out_thr = y16 != nullptr ? nullptr : out_thr;
+  if (y16 != nullptr) {                                 // dual output: y fp32 + y16 codes under out_thr
+    c.y16 = y16;
+    c.dual_thr = out_thr;
+  }
   if (out_thr != nullptr) {
     FQ_REQUIRE(out_width >= 2 && out_width <= 8, "fq_pwconv_i8_c16: output width %d does not fit int8 codes", out_width);
     FQ_REQUIRE(!(out_flags & (FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "fq_pwconv_i8_c16: unsupported output flags");
@@ -120,7 +124,7 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   }
   c.eval_labels = eval_labels; c.eval_counters = eval_counters; c.eval_ws = eval_ws;
   static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample, 8 rows
-  c.form = (in_c16 || out_thr) ? 6 : (eval_labels ? 8 : (forced_form ? forced_form : pw_form));
+  c.form = (in_c16 || c.out_thr) ? 6 : (eval_labels ? 8 : (forced_form ? forced_form : pw_form));
   FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6 || c.form == 7 || c.form == 8, "fq_pwconv_i8: unknown "
              "form %d (1 two kernels, 3 stream, 6 split, 7 sample, 8 rows; the panel / chunk / tile forms 2, 4, 5 were retired "
              "in favour of the split form)", c.form);
@@ -133,6 +137,7 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   ProfScope prof(hw == 1 ? FQ_KERNEL_DENSE : FQ_KERNEL_PWCONV,
                  4.0 * ((double)n * cin * hw + (residual ? 2.0 : 1.0) * (double)n * cout * hw), c.st);
   bool taken = false;
+  out_thr = c.out_thr;                                  // (from here on: "y is a C16 tensor")
   if (hw == 1 && !(in_c16 || out_thr) && !range) {      // (the rows form is not built for range records)
     if (int rc = pw_try_rows(c, &taken)) return rc;
     if (taken) return FQ_OK;
@@ -205,6 +210,24 @@ int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const fl
   return pwconv_dispatch((const float*)x, wcodes, wscale, wsum, bias, (float*)y, n, cin, cin_pad, cout, ho * wo, stride, h,
                          w, wo, in_stat, in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out,
                          residual, ws, stream, x_is_c16 != 0, out_thr, out_width, out_flags);
+}
+
+int fq_pwconv_i8_c16_dual(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                          float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                          const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                          const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual,
+                          const float* out_thr, int out_width, unsigned out_flags, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(h > 0 && w > 0, "fq_pwconv_i8_c16_dual: bad plane %lld x %lld", (long long)h, (long long)w);
+  FQ_REQUIRE(y16 != nullptr && out_thr != nullptr && residual != nullptr && in_thr != nullptr,
+             "fq_pwconv_i8_c16_dual: null pointer (y16, out_thr, residual, in_thr: the closing 1x1 of a residual unit, C16 in)");
+  FQ_REQUIRE(cout % 32 == 0 && (cin_pad == 64 || cin_pad == 128 || cin_pad == 256 || cin_pad == 512),
+             "fq_pwconv_i8_c16_dual: built for 64 / 128 / 256 / 512 input channels and Cout a multiple of 32");
+  const int64_t cbi = (cin + 15) / 16, cbo = (cout + 15) / 16;
+  FQ_REQUIRE((32 / (h * w) + 2) * cbi * h * w * 16 < (1ll << 31) && (32 / (h * w) + 2) * cbo * h * w * 16 < (1ll << 31),
+             "fq_pwconv_i8_c16_dual: plane too large");
+  return pwconv_dispatch((const float*)x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, h * w, 1, h, w, w, in_stat,
+                         in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, ws, stream,
+                         true, out_thr, out_width, out_flags, nullptr, nullptr, nullptr, nullptr, y16);
 }
 
 }  // extern "C"

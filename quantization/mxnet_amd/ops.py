@@ -662,7 +662,8 @@ def pwconv_strided_supported(cin):
 
 
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None, out_codes=None):
+              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None, out_codes=None,
+              side_codes=None):
     """1x1 convolution on the integer codes (int8 MFMA, exact int32 accumulation) with quantise-on-load and fused
     BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; stride 1 or 2 (no padding); `residual` (the
     output's shape) is added after BatchNorm and before the activation.  `form` names one of PW_FORMS ("stream", "sample",
@@ -670,7 +671,9 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     does not take raises.  Returns (y, stat or None).
 
     Offline hand-over (fq_pwconv_i8_c16): `x` may be a `Codes16` (made with this call's in_thr / width / flags), and
-    `out_codes=dict(thr=<consumer's threshold tensor>, width=8, flags=0)` makes `y` a `Codes16` of the consumer's codes."""
+    `out_codes=dict(thr=<consumer's threshold tensor>, width=8, flags=0)` makes `y` a `Codes16` of the consumer's codes.
+    `side_codes=dict(thr=..., width=8, flags=0)` (fq_pwconv_i8_c16_dual; a `Codes16` input with a residual operand, stride 1):
+    y stays fp32 and a third value is returned, the `Codes16` of y under that threshold - the trunk of a ResNet stored twice."""
     in16 = isinstance(x, Codes16)
     if in16:
         if in_thr is None or not x.matches(in_thr, width, flags):
@@ -697,6 +700,22 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     if in_stat is not None and cur_out is None:
         cur_out = torch.empty(1, dtype=torch.float32, device=dev)
     stat, zflag = _stat_target(n, dev, want_stat)
+    if side_codes is not None:
+        if not in16 or residual is None or stride != 1 or out_codes is not None or len(xs) != 4:
+            raise ValueError("side_codes goes with a Codes16 input, a residual operand, stride 1 and fp32 output")
+        h, w = xs[2], xs[3]
+        y = torch.empty((n, cout, h, w), dtype=torch.float32, device=dev)
+        if tuple(residual.shape) != tuple(y.shape):
+            raise ValueError("the residual must have the output's shape %s, got %s" % (tuple(y.shape), tuple(residual.shape)))
+        sthr = _check(side_codes["thr"], "side_codes['thr']")
+        y16 = Codes16.empty((n, cout, h, w), dev, sthr, side_codes.get("width", 8), side_codes.get("flags", 0))
+        ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, h * w), dtype=torch.uint8, device=dev)
+        check_call(_lib_().fq_pwconv_i8_c16_dual(_ptr(x.t), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y),
+                                                 _ptr(y16.t), n, cin, cin_pad, cout, h, w, _ptr(in_stat), _ptr(in_thr),
+                                                 int(width), int(flags), _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift),
+                                                 _ACTS[act] | zflag, _ptr(stat), _ptr(residual), _ptr(sthr), int(y16.width),
+                                                 int(y16.flags), _ptr(ws), _stream(wcodes)))
+        return y, stat, y16
     if in16 or out_codes is not None:
         if len(xs) != 4:
             raise ValueError("a C16 hand-over needs (N, Cin, H, W) activations, got %s" % (xs,))

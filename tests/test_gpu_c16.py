@@ -124,6 +124,47 @@ def test_pointwise_between_two_code_tensors(dev, ops, case):
     assert torch.equal(st, want_stat) and torch.equal(cur_a, cur_b)
 
 
+DUAL_CASES = [(43, 64, 256, 56, 56), (3, 64, 256, 9, 11), (5, 128, 512, 28, 28), (7, 256, 1024, 14, 14), (9, 512, 2048, 7, 7),
+              (43, 128, 512, 56, 56)]
+
+
+@pytest.mark.parametrize("case", DUAL_CASES, ids=["%dx%d->%d@%dx%d" % c for c in DUAL_CASES])
+def test_closing_pointwise_stores_the_trunk_twice(dev, ops, case):
+    """fq_pwconv_i8_c16_dual (round 4): codes in, residual added, fp32 out - and the codes of that output under the NEXT
+    consumer's threshold beside it.  y, statistic and batch mean are those of the one-output call; the side tensor holds the
+    oracle's codes of y.  (The first case runs the streaming form - more than 4096 pixel tiles -, the others the split form.)"""
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + 23)
+    x = np.maximum(rng.standard_normal((n, cin, h, w)) * 2, 0).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    res = (rng.standard_normal((n, cout, h, w)) * 2).astype(np.float32)
+    codes, scales, rowsum = ops.weight_codes(T(wt, dev), 1, 8)
+    thr, thr2 = np.float32(2.3), np.float32(3.1)
+    thr_t = T(np.float32([thr]), dev)
+    stat_in = T(O.absmax_per_sample(x), dev)
+    cx = O.ste_codes(x, O.act_scale(thr, False, 8), thr, np.float32(0))
+    xc = ops.Codes16(T(O.to_c16(cx.astype(np.int64), 128), dev), x.shape, thr_t, 8, 0)
+    cur_a, cur_b = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    kw = dict(in_thr=thr_t, width=8, flags=0, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu", in_stat=stat_in,
+              residual=T(res, dev))
+    want, want_stat = ops.pwconv_i8(xc, codes, scales, rowsum, cur_out=cur_a, **kw)
+    got, got_stat, side = ops.pwconv_i8(xc, codes, scales, rowsum, cur_out=cur_b,
+                                        side_codes=dict(thr=T(np.float32([thr2]), dev), width=8, flags=0), **kw)
+    assert torch.equal(got, want) and torch.equal(got_stat, want_stat) and torch.equal(cur_a, cur_b)
+    wantc = O.to_c16(O.ste_codes(want.cpu().numpy(), O.act_scale(thr2, False, 8), thr2, np.float32(0)).astype(np.int64), 128)
+    assert isinstance(side, ops.Codes16) and side.shape == tuple(want.shape)
+    assert np.array_equal(side.t.cpu().numpy(), wantc), "the side tensor's codes"
+    # ... and a consumer fed with the side tensor computes what it computes from the fp32 trunk
+    w2 = (rng.standard_normal((cout // 4, cout, 1, 1)) * 0.05).astype(np.float32)
+    c2, s2, r2 = ops.weight_codes(T(w2, dev), 1, 8)
+    thr2_t = side.thr
+    a, _ = ops.pwconv_i8(want, c2, s2, r2, in_thr=thr2_t, width=8, flags=0, act="relu", form="split")
+    b, _ = ops.pwconv_i8(side, c2, s2, r2, in_thr=thr2_t, width=8, flags=0, act="relu")
+    assert torch.equal(a, b)
+
+
 DW_CASES = [(2, 96, 112, 112, 2), (2, 144, 56, 56, 1), (3, 24, 9, 11, 1), (2, 192, 28, 28, 2), (3, 384, 14, 14, 1),
             (2, 960, 7, 7, 1), (4, 40, 5, 6, 2), (1, 16, 70, 70, 1)]
 
