@@ -35,7 +35,7 @@ int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t
   FQ_PWS16_BOTH(8) FQ_PWS16_BOTH(16) FQ_PWS16_BOTH(32) FQ_PWS16_BOTH(64)
 #undef FQ_PWS16_BOTH
   // codes in, fp32 out AND a code copy of it (the closing 1x1 of a ResNet unit: K = 64 ... 512, Cout = 256 ... 2048)
-#define FQ_PWS16_DUAL(KT_) FQ_PWS16_CASE_D(KT_, 1, (KT_ < 7 ? KT_ : 7), true, false, true) FQ_PWS16_CASE_D(KT_, 2, (KT_ < 3 ? KT_ : 3), true, false, true)
+#define FQ_PWS16_DUAL(KT_) FQ_PWS16_CASE_D(KT_, 1, (KT_ < 7 ? KT_ : 7), true, false, true) FQ_PWS16_CASE_D(KT_, 2, 2, true, false, true)
   FQ_PWS16_DUAL(2) FQ_PWS16_DUAL(4) FQ_PWS16_DUAL(8) FQ_PWS16_DUAL(16)
 #undef FQ_PWS16_DUAL
 #undef FQ_PWS16_CASE_D

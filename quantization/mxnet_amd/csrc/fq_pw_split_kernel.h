@@ -308,8 +308,12 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
         if (OUT16 || DUAL) {
           // the four channels 8 gq + 4 h .. + 3 of this lane's pixel are bytes 8 (gq & 1) + 4 h .. of block (c * 2 + gq / 2):
           // the CONSUMER's codes of the values just formed (channels past Cout: v == 0 -> code 0), one 4-byte store
-          const int packed = pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
-                                         fq_code_int(vq[3], q2), ubias2);
+          // (DUAL: unsigned codes of a non-negative range only - the five-instruction quantiser of fq_common.h.  One 16-byte
+          // store per lane instead of these four 4-byte ones - the halves exchanged with lane ^ 32 - was built and measured:
+          // slower in every C16-writing kernel, ResNet-50 offline 41.7 -> 40.1 k images/s)
+          const int packed = DUAL ? fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, 0x80808080u)
+                                  : pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
+                                                fq_code_int(vq[3], q2), ubias2);
           const bool blk_ok = !MASKED || 16 * (gq >> 1) < cv;             // a whole block past Cout does not exist
           buf_st_f32(OUT16 ? yr : yr16, blk_ok ? yo16 : 0x80000000u,
                      (unsigned)((c * 2 + (gq >> 1)) * (int)HW * 16 + 8 * (gq & 1)), __int_as_float(packed));

@@ -243,8 +243,11 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
           m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
         }
         if (OUT16 || DUAL) {   // channels 8 gq + 4 h .. + 3 of the lane's pixel = bytes 8 (gq & 1) + 4 h .. of block 2 ct + gq / 2
-          const int packed = pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
-                                         fq_code_int(vq[3], q2), ubias2);
+          // (DUAL: the host only asks for unsigned codes of a non-negative range - the five-instruction quantiser, fq_common.h;
+          // 167 registers: the third workgroup per CU still fits)
+          const int packed = DUAL ? fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, 0x80808080u)
+                                  : pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
+                                                fq_code_int(vq[3], q2), ubias2);
           if (PART && !DUAL) {                         // a whole block past Cout (Cout % 32 == 16) does not exist
             const int blk = 2 * ct + (gq >> 1);
             const unsigned o16 = (unsigned)((((int64_t)px.smp * g.CBo + (blk < g.CBo ? blk : 0)) * plane + px.p) * 16 +

@@ -220,6 +220,8 @@ int fq_pwconv_i8_c16_dual(const void* x, const int8_t* wcodes, const float* wsca
   FQ_REQUIRE(h > 0 && w > 0, "fq_pwconv_i8_c16_dual: bad plane %lld x %lld", (long long)h, (long long)w);
   FQ_REQUIRE(y16 != nullptr && out_thr != nullptr && residual != nullptr && in_thr != nullptr,
              "fq_pwconv_i8_c16_dual: null pointer (y16, out_thr, residual, in_thr: the closing 1x1 of a residual unit, C16 in)");
+  FQ_REQUIRE(!(out_flags & (FQ_ACT_SIGNED | FQ_ACT_LO_NEG_MAX)), "fq_pwconv_i8_c16_dual: the side tensor holds UNSIGNED codes of a "
+             "[0, thr] range (the non-negative quantiser)");
   FQ_REQUIRE(cout % 32 == 0 && (cin_pad == 64 || cin_pad == 128 || cin_pad == 256 || cin_pad == 512),
              "fq_pwconv_i8_c16_dual: built for 64 / 128 / 256 / 512 input channels and Cout a multiple of 32");
   const int64_t cbi = (cin + 15) / 16, cbo = (cout + 15) / 16;

@@ -67,7 +67,9 @@ class NDArray(object):
     # statistic is its per-sample maximum (what nn.Conv2D(quantized=True) needs to skip its range pass, nn/fuse.py).
     # _fq_kl: optional (producer block, histogram sink or None) left by a fused producer while the KL calibration collects
     # feature maps (quantize/distribution_calibrate.py): who made this tensor, and whether that pass already binned it.
-    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl")
+    # _fq_side: optional (consumer block, ops.Codes16) - `_t` is the fp32 trunk of a ResNet and the codes of the SAME values under
+    # that consumer's stored threshold ride beside it (fq_pwconv_i8_c16_dual; quantize/convert/convert_conv2d.pointwise_fused).
+    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl", "_fq_side")
     __array_priority__ = 1000.0
     __array_ufunc__ = None
 
@@ -78,6 +80,7 @@ class NDArray(object):
         self._fq_c16 = None
         self._fq_nonneg = False
         self._fq_kl = None
+        self._fq_side = None
 
     # -- plumbing ---------------------------------------------------------------------------
     @property
@@ -126,6 +129,7 @@ class NDArray(object):
         other._t.copy_(self._t)
         other._fq_stat = None                   # a fused producer's statistic described the OLD contents
         other._fq_kl = None
+        other._fq_side = None
         return other
 
     def copy(self):
@@ -176,6 +180,7 @@ class NDArray(object):
         key = _unwrap_key(key)
         self._fq_stat = None
         self._fq_kl = None
+        self._fq_side = None
         self._t[key] = value._t if isinstance(value, NDArray) else value
 
     # -- shape ops --------------------------------------------------------------------------
@@ -254,12 +259,14 @@ class NDArray(object):
     def __iadd__(self, o):
         self._fq_stat = None
         self._fq_kl = None
+        self._fq_side = None
         self._t += _operand(o, self._t)
         return self
 
     def __imul__(self, o):
         self._fq_stat = None
         self._fq_kl = None
+        self._fq_side = None
         self._t *= _operand(o, self._t)
         return self
 

@@ -267,6 +267,26 @@ def handover_target(block, fz=None):
     return dict(thr=nxt.input_max.data()._t, width=a.in_width, flags=ops.act_flags(signed=a.in_signed))
 
 
+_SIDE_MAX_CIN = int(os.environ.get("FQ_SIDE_MAX_CIN", "512"))      # (A/B: 128 = the 56x56 and 28x28 stages only, 0 = off)
+
+
+def side_target(block, c16_in):
+    """The first 1x1 of the NEXT residual unit (quantize/fuse.py links `side_next`) when this closing 1x1 - codes in, residual
+    operand, fp32 out - may store its output a second time as that block's codes (fq_pwconv_i8_c16_dual): the consumer will
+    quantise with its stored threshold in this very forward and runs on the integer codes.  Hooks are no obstacle: the fp32
+    tensor stays what every block and hook is handed; the codes ride beside it."""
+    from .. import fuse as _fuse
+    nxt = block._fq_pw_fused.get("side_next")
+    if nxt is None or c16_in is None or not _fuse.SIDE_CODES or not _fuse.HANDOVER or autograd.is_recording():
+        return None
+    if not _consumer_takes_codes(nxt) or getattr(nxt, "_fq_pw_fused", None) is None or nxt.quantize_args.in_signed:
+        return None
+    cin, cout = c16_in.shape[1], block._kwargs["num_filter"]
+    if cin not in (64, 128, 256, 512) or cin > _SIDE_MAX_CIN or cout % 32 or cout < 256:
+        return None
+    return nxt
+
+
 def _handed_over(x):
     """ops.Codes16 riding on an NDArray a producer handed over, else None."""
     return getattr(x, "_fq_c16", None)
@@ -297,6 +317,13 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
     held = _pointwise_weight_codes(block, args, weight_raw, weight_q) if on_codes else None
     on_codes = held is not None
     c16_in = _handed_over(x)
+    if c16_in is None and on_codes and "in_thr" in plan:
+        # the trunk of a ResNet arrives as fp32 (`x._t`, which the unit's shortcut reads) with this block's codes of the same
+        # values beside it (`_fq_side`: the previous unit's closing 1x1 stored both, fq_pwconv_i8_c16_dual): read 1 B per element
+        side = getattr(x, "_fq_side", None)
+        if side is not None and side[0] is block and not autograd.is_recording() \
+                and side[1].matches(plan["in_thr"], plan["width"], plan["flags"]):
+            c16_in = side[1]
     if c16_in is not None and not (on_codes and "in_thr" in plan):
         x = NDArray(codes16_to_fake_quant(c16_in))      # (cannot run on the codes after all: their fp32 meaning, no apply pass)
         plan, c16_in = {}, None
@@ -313,11 +340,19 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
             res = getattr(block, "_fq_residual", None)
             extra = {}
             xshape = c16_in.shape if c16_in is not None else tuple(x._t.shape)
+            side_blk = None
             if res is not None and block._kwargs["stride"][0] == 1 and tuple(res["t"].shape[2:]) == tuple(xshape[2:]) \
                     and res["t"].shape[1] == block._kwargs["num_filter"]:
                 extra = dict(residual=res["t"])
                 res["used"] = True
-            if not extra and c16_in is None:       # (a 1x1 convolution reads OR writes codes: both at once is not built)
+                side_blk = side_target(block, c16_in)
+                if side_blk is not None:
+                    a_ = side_blk.quantize_args
+                    extra["side_codes"] = dict(thr=side_blk.input_max.data()._t, width=a_.in_width,
+                                               flags=ops.act_flags(signed=a_.in_signed))
+            # (a 1x1 convolution that READS codes writes codes too from 256 input channels up - the first 1x1 of a ResNet unit
+            # fed by the trunk's code copy; below that the both-sides instantiations are not built)
+            if not extra and (c16_in is None or xshape[1] >= 256):
                 # through a depthwise consumer: on every plane by default, `_DW_C16_MIN_PIXELS` above says why and what a batch
                 # alone on the GPU would prefer (fq_dwconv3x3_c16 102 us against 158 at 112x112 stride 2 and 49 against 61 at
                 # 56x56 stride 2, but 23 against 18 at 14x14 where the flat fp32 form is at its best) - profiles/r3_handover.txt
@@ -327,10 +362,16 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                 out_codes = handover_target(block)
                 if out_codes is not None:
                     extra = dict(out_codes=out_codes)
-            y, stat = ops.pwconv_i8(x_arg, codes, scales, rowsum, None if bias is None else bias._t,
-                                    bn_scale=scale, bn_shift=shift,
-                                    act=res["act"] if "residual" in extra else fz["act"],
-                                    stride=block._kwargs["stride"][0], **extra, **plan)
+            out = ops.pwconv_i8(x_arg, codes, scales, rowsum, None if bias is None else bias._t,
+                                bn_scale=scale, bn_shift=shift,
+                                act=res["act"] if "residual" in extra else fz["act"],
+                                stride=block._kwargs["stride"][0], **extra, **plan)
+            y, stat = out[0], out[1]
+            if side_blk is not None:
+                trunk = NDArray(y)
+                trunk._fq_stat = stat
+                trunk._fq_side = (side_blk, out[2])
+                return trunk
     else:
         if plan:          # input is to be quantised but the integer path does not apply: explicit apply pass
             t = contiguous(x._t)

@@ -144,6 +144,9 @@ import os as _os
 
 HANDOVER = _os.environ.get("FQ_HANDOVER", "1") != "0"      # int8 C16 hand-over between fused convolutions under offline input quantisation (tests switch it off to
                      # compare: the logits are bit-equal either way)
+# round 4: the closing 1x1 of a ResNet unit stores the trunk twice - fp32 for the shortcut, codes for the next unit's first 1x1
+# (fq_pwconv_i8_c16_dual).  Same logits either way (tests/test_gpu_c16.py)
+SIDE_CODES = _os.environ.get("FQ_HANDOVER_SIDE", "1") != "0"
 
 
 def _identity_forward(self, F, x, *args, **kwargs):
@@ -529,6 +532,28 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             b.forward = types.MethodType(_linear_bottleneck_forward, b)
             fused[0] += 1
 
+    def visit_side_links(container):
+        """Consecutive residual units of one stage: the closing 1x1 of the first learns the first 1x1 of the second (`side_next`),
+        for which it may store the trunk a second time as codes (convert_conv2d.side_target; offline input quantisation)."""
+        if not isinstance(container, (nn.Sequential, nn.HybridSequential)):
+            return
+        kids = list(container._children.values())
+        for u, v in zip(kids, kids[1:]):
+            if not (getattr(u, "_fq_residual_fused", False) and getattr(v, "_fq_residual_fused", False)
+                    and hasattr(u, "body") and hasattr(v, "body") and hasattr(v, "downsample")):
+                continue
+            tail = _tail_conv(u.body)
+            body = list(v.body._children.values()) if isinstance(v.body, (nn.Sequential, nn.HybridSequential)) else []
+            first = body[0] if body else None
+            if tail is None or type(first) is not nn.Conv2D or not hasattr(first, "quantize_args"):
+                continue
+            fa, fb = getattr(tail, "_fq_pw_fused", None), getattr(first, "_fq_pw_fused", None)
+            if fa is None or fb is None or fa.get("kind") != "1x1" or fb.get("kind") != "1x1":
+                continue
+            if first._kwargs["kernel"] != (1, 1) or first._kwargs["stride"] != (1, 1):
+                continue
+            fa["side_next"] = first
+
     def visit_dense(b):
         if type(b) is nn.Dense and hasattr(b, "quantize_args") and dense_int8 and not hasattr(b, "_fq_dense_int8"):
             b._fq_dense_int8 = True                # convert_dense: the classifier on the integer codes
@@ -545,6 +570,7 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
     net.apply(visit)
     if residual:
         net.apply(visit_residual)
+        net.apply(visit_side_links)
     _install_stat_arena(net, fused[0])
     return fused[0]
 

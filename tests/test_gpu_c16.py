@@ -271,13 +271,30 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
     def count(fn):
         def wrapped(x, *a, **k):
             calls["c16_in"] += isinstance(x, ops.Codes16)
-            calls["c16_out"] += k.get("out_codes") is not None
+            calls["c16_out"] += (k.get("out_codes") is not None) + (k.get("side_codes") is not None)
+            calls["side"] = calls.get("side", 0) + (k.get("side_codes") is not None)
             return fn(x, *a, **k)
         return wrapped
     ops.pwconv_i8, ops.conv3x3_i8, ops.dwconv3x3_c16 = count(real_pw), count(real_c3), count(real_dw)
     try:
         fuse.HANDOVER = True
         with_codes = net(xs[2]).asnumpy()
+        n_side = calls.get("side", 0)
+        # round 4: the closing 1x1 of a ResNet-50 unit stores the trunk twice when the next unit of its stage opens with a 1x1
+        # (2 + 3 + 5 + 2 pairs of consecutive units); switched off, the logits and every batch statistic stay what they are
+        assert n_side == (12 if model == "resnet50_v1" else 0), n_side
+        fuse.SIDE_CODES = False
+        calls.update(c16_out=0, c16_in=0, side=0)
+        no_side = net(xs[2]).asnumpy()
+        assert calls["side"] == 0 and calls["c16_in"] == calls["c16_out"]
+        assert np.array_equal(no_side, with_codes), "logits with the trunk's code copy differ"
+        assert [float(b.current_input_max) for b in net.collect_quantized_blocks()] == \
+            [float(b.current_input_max) for b in net.collect_quantized_blocks()]
+        cur_no_side = [float(b.current_input_max) for b in net.collect_quantized_blocks()]
+        fuse.SIDE_CODES = True
+        calls.update(c16_out=0, c16_in=0, side=0)
+        with_codes = net(xs[2]).asnumpy()
+        assert cur_no_side == [float(b.current_input_max) for b in net.collect_quantized_blocks()]
         cur_with = [float(b.current_input_max) for b in net.collect_quantized_blocks()]
         n_out, n_in = calls["c16_out"], calls["c16_in"]
         fuse.HANDOVER = False
@@ -293,6 +310,7 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
     finally:
         ops.pwconv_i8, ops.conv3x3_i8, ops.dwconv3x3_c16 = real_pw, real_c3, real_dw
         fuse.HANDOVER = True
+        fuse.SIDE_CODES = True
         torch.backends.cudnn.deterministic = was_deterministic
     # resnet50: 16 units x (1x1 -> 3x3 -> 1x1); mobilenetv2: 16 units with an expansion x (1x1 -> depthwise -> 1x1)
     # (through the depthwise layer of every unit: 2 hand-overs per unit)
