@@ -533,14 +533,26 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             fused[0] += 1
 
     def visit_side_links(container):
-        """Consecutive residual units of one stage: the closing 1x1 of the first learns the first 1x1 of the second (`side_next`),
-        for which it may store the trunk a second time as codes (convert_conv2d.side_target; offline input quantisation)."""
+        """Consecutive residual units - inside a stage, and the last unit of a stage with the first of the next (whose first 1x1
+        is strided; its shortcut convolution keeps reading the fp32 trunk): the closing 1x1 of the first learns the first 1x1 of
+        the second (`side_next`), for which it may store the trunk a second time as codes (convert_conv2d.side_target; offline
+        input quantisation)."""
         if not isinstance(container, (nn.Sequential, nn.HybridSequential)):
             return
         kids = list(container._children.values())
-        for u, v in zip(kids, kids[1:]):
-            if not (getattr(u, "_fq_residual_fused", False) and getattr(v, "_fq_residual_fused", False)
-                    and hasattr(u, "body") and hasattr(v, "body") and hasattr(v, "downsample")):
+
+        def unit(b, last):
+            """b itself when it is a fused residual unit, or - a stage of such units - its last / first one"""
+            if getattr(b, "_fq_residual_fused", False) and hasattr(b, "body") and hasattr(b, "downsample"):
+                return b, False
+            if isinstance(b, (nn.Sequential, nn.HybridSequential)) and len(b._children):
+                inner = list(b._children.values())[-1 if last else 0]
+                if getattr(inner, "_fq_residual_fused", False) and hasattr(inner, "body") and hasattr(inner, "downsample"):
+                    return inner, True
+            return None, False
+        for a_, b_ in zip(kids, kids[1:]):
+            (u, ua), (v, va) = unit(a_, True), unit(b_, False)
+            if u is None or v is None or ua != va:             # (two units of one stage, or two stages)
                 continue
             tail = _tail_conv(u.body)
             body = list(v.body._children.values()) if isinstance(v.body, (nn.Sequential, nn.HybridSequential)) else []
@@ -550,7 +562,7 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             fa, fb = getattr(tail, "_fq_pw_fused", None), getattr(first, "_fq_pw_fused", None)
             if fa is None or fb is None or fa.get("kind") != "1x1" or fb.get("kind") != "1x1":
                 continue
-            if first._kwargs["kernel"] != (1, 1) or first._kwargs["stride"] != (1, 1):
+            if first._kwargs["kernel"] != (1, 1) or first._kwargs["stride"] not in ((1, 1), (2, 2)):
                 continue
             fa["side_next"] = first
 

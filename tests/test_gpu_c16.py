@@ -281,8 +281,9 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
         with_codes = net(xs[2]).asnumpy()
         n_side = calls.get("side", 0)
         # round 4: the closing 1x1 of a ResNet-50 unit stores the trunk twice when the next unit of its stage opens with a 1x1
-        # (2 + 3 + 5 + 2 pairs of consecutive units); switched off, the logits and every batch statistic stay what they are
-        assert n_side == (12 if model == "resnet50_v1" else 0), n_side
+        # (2 + 3 + 5 + 2 pairs of consecutive units, and the 3 stage boundaries, whose consumer is a strided 1x1); switched off, the
+        # logits and every batch statistic stay what they are
+        assert n_side == (15 if model == "resnet50_v1" else 0), n_side
         fuse.SIDE_CODES = False
         calls.update(c16_out=0, c16_in=0, side=0)
         no_side = net(xs[2]).asnumpy()
