@@ -267,6 +267,29 @@ def handover_target(block, fz=None):
     return dict(thr=nxt.input_max.data()._t, width=a.in_width, flags=ops.act_flags(signed=a.in_signed))
 
 
+def _same_quantiser(block, other, plan, codes):
+    """True when `block` would quantise the tensor `codes` stands for exactly as `other` (for which the codes were made) does:
+    same width and signedness, and stored thresholds of EQUAL VALUE - two blocks that always see the same tensor calibrate
+    to the same threshold, naive or KL.  The comparison reads two device scalars: it is made once per (tensor, version) pair
+    and remembered (never during a graph capture: the eager forwards in front of it have asked already)."""
+    from .. import fuse as _fuse
+    if not _fuse.SIDE_CODES or codes.width != int(plan["width"]) or (codes.flags & 3) != (int(plan["flags"]) & 3):
+        return False
+    ta, tb = plan["in_thr"], getattr(other, "input_max", None)
+    if tb is None:
+        return False
+    tb = tb.data()._t
+    if tb.data_ptr() != codes.thr.data_ptr():
+        return False
+    key = (ta.data_ptr(), ta._version, tb.data_ptr(), tb._version)
+    memo = block.__dict__.get("_fq_same_thr")
+    if memo is None or memo[0] != key:
+        if ta.is_cuda and torch.cuda.is_current_stream_capturing():
+            return False
+        memo = block.__dict__["_fq_same_thr"] = (key, bool(torch.equal(ta.reshape(-1)[:1], tb.reshape(-1)[:1])))
+    return memo[1]
+
+
 _SIDE_MAX_CIN = int(os.environ.get("FQ_SIDE_MAX_CIN", "512"))      # (A/B: 128 = the 56x56 and 28x28 stages only, 0 = off)
 
 
@@ -321,9 +344,13 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
         # the trunk of a ResNet arrives as fp32 (`x._t`, which the unit's shortcut reads) with this block's codes of the same
         # values beside it (`_fq_side`: the previous unit's closing 1x1 stored both, fq_pwconv_i8_c16_dual): read 1 B per element
         side = getattr(x, "_fq_side", None)
-        if side is not None and side[0] is block and not autograd.is_recording() \
-                and side[1].matches(plan["in_thr"], plan["width"], plan["flags"]):
-            c16_in = side[1]
+        if side is not None and not autograd.is_recording():
+            if side[0] is block and side[1].matches(plan["in_thr"], plan["width"], plan["flags"]):
+                c16_in = side[1]
+            elif side[0] is not block and _same_quantiser(block, side[0], plan, side[1]):
+                # another reader of the same trunk (the shortcut convolution of a stage's first unit) whose stored threshold
+                # has the very value the codes were made with: the same codes are ITS codes
+                c16_in = ops.Codes16(side[1].t, side[1].shape, plan["in_thr"], plan["width"], plan["flags"])
     if c16_in is not None and not (on_codes and "in_thr" in plan):
         x = NDArray(codes16_to_fake_quant(c16_in))      # (cannot run on the codes after all: their fp32 meaning, no apply pass)
         plan, c16_in = {}, None

@@ -315,7 +315,10 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
         torch.backends.cudnn.deterministic = was_deterministic
     # resnet50: 16 units x (1x1 -> 3x3 -> 1x1); mobilenetv2: 16 units with an expansion x (1x1 -> depthwise -> 1x1)
     # (through the depthwise layer of every unit: 2 hand-overs per unit)
-    assert n_out == n_in and n_out >= {"resnet50_v1": 32, "mobilenetv2_1.0": 32}.get(model, 1), (n_out, n_in)
+    # (+ 3 for ResNet-50: the shortcut convolution of a stage's first unit reads the trunk's code copy too - it has calibrated to
+    # the very threshold of the first 1x1 beside it, both having seen the same tensors)
+    shared = 3 if model == "resnet50_v1" else 0
+    assert n_in == n_out + shared and n_out >= {"resnet50_v1": 32, "mobilenetv2_1.0": 32}.get(model, 1), (n_out, n_in)
     assert np.array_equal(with_codes, without), "logits with int8 hand-overs differ from the fp32 hand-over"
     assert cur_with == cur_without
 
