@@ -13,14 +13,14 @@ int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t
   const bool in16 = a.in_c16, out16 = a.out_thr != nullptr, dual = a.y16 != nullptr;
   FQ_REQUIRE(!(in16 && out16) || kt >= 8, "fq_pwconv_i8_c16: codes in AND codes out is built for 256 input channels and more");
   FQ_REQUIRE(!in16 || a.in_thr != nullptr, "fq_pwconv_i8_c16: a C16 input was quantised with a stored threshold: give in_thr");
-#define FQ_PWS16_CASE(KT_, CW_, D_, IN_, OUT_) FQ_PWS16_CASE_D(KT_, CW_, D_, IN_, OUT_, false)
-#define FQ_PWS16_CASE_D(KT_, CW_, D_, IN_, OUT_, DUAL_)                                                                \
+#define FQ_PWS16_CASE(KT_, CW_, D_, IN_, OUT_) FQ_PWS16_CASE_D(KT_, CW_, D_, 4, IN_, OUT_, false)
+#define FQ_PWS16_CASE_D(KT_, CW_, D_, LB_, IN_, OUT_, DUAL_)                                                           \
   if (kt == KT_ && cw == CW_ && in16 == IN_ && out16 == OUT_ && dual == DUAL_) {                                       \
     static const bool attr_ok =                                                                                        \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_split_kernel<KT_, CW_, D_, 4, 4, IN_, OUT_, DUAL_>), \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_split_kernel<KT_, CW_, D_, LB_, 4, IN_, OUT_, DUAL_>), \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;                      \
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8_c16: cannot raise the dynamic LDS limit of the split kernel");                   \
-    hipLaunchKernelGGL((pwconv_split_kernel<KT_, CW_, D_, 4, 4, IN_, OUT_, DUAL_>), dim3((unsigned)grid), dim3(256), lds, a.st, \
+    hipLaunchKernelGGL((pwconv_split_kernel<KT_, CW_, D_, LB_, 4, IN_, OUT_, DUAL_>), dim3((unsigned)grid), dim3(256), lds, a.st, \
                        a.x, wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, \
                        a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out, a.residual,       \
                        a.out_thr);                                                                                     \
@@ -35,7 +35,14 @@ int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t
   FQ_PWS16_BOTH(8) FQ_PWS16_BOTH(16) FQ_PWS16_BOTH(32) FQ_PWS16_BOTH(64)
 #undef FQ_PWS16_BOTH
   // codes in, fp32 out AND a code copy of it (the closing 1x1 of a ResNet unit: K = 64 ... 512, Cout = 256 ... 2048)
-#define FQ_PWS16_DUAL(KT_) FQ_PWS16_CASE_D(KT_, 1, (KT_ < 7 ? KT_ : 7), true, false, true) FQ_PWS16_CASE_D(KT_, 2, 2, true, false, true)
+#ifndef FQ_PWS16_DUAL_D                 // tuning: ring depth and wavefronts per SIMD of the two-tile dual-output instantiations
+#define FQ_PWS16_DUAL_D 2
+#endif
+#ifndef FQ_PWS16_DUAL_LB
+#define FQ_PWS16_DUAL_LB 4
+#endif
+#define FQ_PWS16_DUAL(KT_) FQ_PWS16_CASE_D(KT_, 1, (KT_ < 7 ? KT_ : 7), 4, true, false, true) \
+  FQ_PWS16_CASE_D(KT_, 2, (KT_ < FQ_PWS16_DUAL_D ? KT_ : FQ_PWS16_DUAL_D), FQ_PWS16_DUAL_LB, true, false, true)
   FQ_PWS16_DUAL(2) FQ_PWS16_DUAL(4) FQ_PWS16_DUAL(8) FQ_PWS16_DUAL(16)
 #undef FQ_PWS16_DUAL
 #undef FQ_PWS16_CASE_D
