@@ -32,6 +32,13 @@ import json,sys
 l=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=l['roofline']['kernels']
 print('FQ_KL_FUSED_HIST=$f resnet50_v1 KL collection:', l['value'], 'images/s', l['ms_per_step'], 'ms/batch', {n:(round(v['ms_per_step'],3), v['frac']) for n,v in k.items()}, l['split'])" >> $O/${TAG}_kl_fused_ab.txt
 done
+# ResNet-50 offline with and without the trunk's code copy (fq_pwconv_i8_c16_dual), alternating; the closing 1x1 alone
+for r in 1 2; do for m in 0 512; do
+  FQ_SIDE_MAX_CIN=$m python3 bench.py --model resnet50_v1 --quant-type channel --offline --steps 200 --no-cpu-baseline --no-headline --no-kernel-events 2>/dev/null | python3 -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FQ_SIDE_MAX_CIN=$m resnet50_v1 offline:', l['value'], 'images/s', l['ms_per_step'], 'ms/step, one batch at a time', l['single_stream']['value'])" >> $O/${TAG}_side_codes_ab_run.txt
+done; done
+python3 tools/dualbench.py >> $O/${TAG}_side_codes_ab_run.txt 2>/dev/null
 python3 tools/dw16bench.py > $O/${TAG}_dw16bench.txt 2>/dev/null
 python3 tools/c3bench.py > $O/${TAG}_c3bench.txt 2>/dev/null
 python3 tools/stembench.py >> $O/${TAG}_c3bench.txt 2>/dev/null
