@@ -216,6 +216,13 @@ int fq_stem_conv3x3s2(const float* x, const float* w_tap_major, const float* bia
 /* The same for the first convolution of the ImageNet ResNets: 7x7, stride 2, padding 3, 3 -> 64 channels
  * (w_tap_major: [3][7][7][64]).  Both run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 accumulates as an fmaf chain in
  * ascending k, so the results are those of the fmaf chain over (ci, ky, kx) bit for bit).                              */
+/* The 3x3 first convolution with a C16 code tensor as output (round 4): y16 (n, cout, ho, wo) holds the codes of
+ * act(BN(conv)) under out_thr / out_width / out_flags - the stored threshold of the layer's single consumer (MobileNetV2's
+ * first 1x1 under offline input quantisation), exactly what quantising fq_stem_conv3x3s2's fp32 output gives; stat_out is the
+ * statistic of the fp32 values.  1 byte per element written instead of 4, and read by the consumer instead of 4.          */
+int fq_stem_conv3x3s2_c16(const float* x, const float* w_tap_major, const float* bias, void* y16, int64_t n, int64_t cin,
+                          int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
+                          float* stat_out, const float* out_thr, int out_width, unsigned out_flags, fqStream_t stream);
 int fq_stem_conv7x7s2(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
                       int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
                       float* stat_out, fqStream_t stream);

@@ -66,6 +66,9 @@ int fq_eval_counters_host(const float* logits, const int64_t* labels, int64_t n,
 int fq_stem_conv3x3s2_host(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n,
                            int64_t cin, int64_t cout, int64_t h, int64_t w, const float* bn_scale,
                            const float* bn_shift, int act, float* stat_out, fqStream_t stream);
+int fq_stem_conv3x3s2_c16_host(const float* x, const float* w_tap_major, const float* bias, void* y16, int64_t n, int64_t cin,
+                               int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
+                               float* stat_out, const float* out_thr, int out_width, unsigned out_flags, fqStream_t stream);
 int fq_stem_conv7x7s2_host(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n,
                            int64_t cin, int64_t cout, int64_t h, int64_t w, const float* bn_scale,
                            const float* bn_shift, int act, float* stat_out, fqStream_t stream);

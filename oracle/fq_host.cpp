@@ -765,6 +765,20 @@ int fq_pwconv_i8_c16_host(const void* x, int x_is_c16, const int8_t* wcodes, con
   return FQ_OK;
 }
 
+// the 3x3 first convolution handing its consumer's codes over: the fp32 layer, then the codes of its output
+int fq_stem_conv3x3s2_c16_host(const float* x, const float* w_tap_major, const float* bias, void* y16, int64_t n, int64_t cin,
+                               int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
+                               float* stat_out, const float* out_thr, int out_width, unsigned out_flags, fqStream_t stream) {
+  REQUIRE(y16 && out_thr, "fq_stem_conv3x3s2_c16_host: null pointer");
+  const int64_t ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  std::vector<float> tmp((size_t)(n * cout * ho * wo));
+  if (int rc = fq_stem_conv3x3s2_host(x, w_tap_major, bias, tmp.data(), n, cin, cout, h, w, bn_scale, bn_shift, act, stat_out,
+                                      stream))
+    return rc;
+  c16_encode(tmp.data(), n, cout, ho * wo, out_thr, out_width, out_flags, (int8_t*)y16);
+  return FQ_OK;
+}
+
 // the closing 1x1 of a residual unit with two outputs: the fp32 result, and its codes under the next consumer's threshold
 int fq_pwconv_i8_c16_dual_host(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
                                float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,

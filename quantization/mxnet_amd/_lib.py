@@ -50,6 +50,7 @@ EXPORTS = {
     "fq_eval_counters": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "fq_stem_conv3x3s2": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "fq_stem_conv7x7s2": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
+    "fq_stem_conv3x3s2_c16": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp, _int, _uint, _vp]),
     "fq_dwconv3x3": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _uint, _vp, _vp, _vp, _int,
                             _vp, _vp]),
     "fq_dwconv3x3_c16": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _uint, _vp, _vp, _vp, _int,

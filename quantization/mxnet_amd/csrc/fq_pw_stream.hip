@@ -352,8 +352,9 @@ static bool pw_stream_thin_ok(const PwCall& c) {
   const int ct = (int)((c.cout + 31) / 32);
   const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 5 * sizeof(float);
   static const int thin = env_int("FQ_PWS_THIN", 1);                    // A/B: 0 leaves these shapes to the split form
+  // (codes in AND codes out: K = 32 only - MobileNetV2's first 1x1 behind a first convolution that hands its codes over)
   return thin && kt >= 1 && kt <= 6 && lds <= 72 * 1024 && c.stride == 1 && (c.out_thr == nullptr || c.cout % 16 == 0) &&
-         !(c.in_c16 && c.out_thr != nullptr) && !(c.out_thr != nullptr && c.residual != nullptr) &&
+         !(c.in_c16 && c.out_thr != nullptr && kt != 1) && !(c.out_thr != nullptr && c.residual != nullptr) &&
          (c.n * c.hw + 31) / 32 > 4096 && c.n * c.cout * c.hw * 4 < (1ll << 32) && c.n * c.cin * c.hw * 4 < (1ll << 32);
 }
 
@@ -444,7 +445,8 @@ int pw_try_stream(const PwCall& c, bool* taken) {
   }
 #define FQ_PWS_THIN_CASE(KT_)                                                                                          \
   case KT_:                                                                                                            \
-    if (out16) FQ_PWS_THIN(KT_, false, true, false)                                                                    \
+    if (out16 && c.in_c16 && KT_ == 1) FQ_PWS_THIN(1, false, true, true)                                               \
+    else if (out16) FQ_PWS_THIN(KT_, false, true, false)                                                               \
     else if (c.in_c16 && c.residual != nullptr) FQ_PWS_THIN(KT_, true, false, true)                                    \
     else if (c.in_c16) FQ_PWS_THIN(KT_, false, false, true)                                                            \
     else if (c.residual != nullptr) FQ_PWS_THIN(KT_, true, false, false) else FQ_PWS_THIN(KT_, false, false, false)    \

@@ -130,11 +130,20 @@ struct StemGeom {
   FastDiv by_tpi, by_wo;
 };
 
-template <int KS, int COUT, int EPI>
+// OUT16 (round 4; fq_stem_conv3x3s2_c16): y is a C16 code tensor holding the CONSUMER's codes of the values just formed under
+// its stored threshold (offline input quantisation): MobileNetV2's first 1x1 then reads 1 byte per element instead of 4 and
+// this kernel writes 1 instead of 4 (the layer moves 77 + 205 MB otherwise).  The statistic is that of the fp32 values.
+struct StemCodes {
+  const float* thr;
+  float levels;
+  int lo_neg, zoff, CBo;
+};
+
+template <int KS, int COUT, int EPI, bool OUT16 = false>
 __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wt /*[3][KS][KS][COUT]*/, const float* __restrict__ bias,
     float* __restrict__ y, StemGeom g, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
-    float* __restrict__ stat_out) {
+    float* __restrict__ stat_out, StemCodes oc) {
   const int H = g.H, W = g.W, Ho = g.Ho, Wo = g.Wo;
   constexpr int K = 3 * KS * KS, NS = (K + 1) / 2, CT = COUT / 32, PAD = KS / 2;
   constexpr bool WREG = NS * CT <= 16;                                  // weights in registers (3x3 -> 32), else LDS
@@ -281,8 +290,14 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     // ---- epilogue: lane = pixel, register = channel 8 gq + 4 h + r; constants four at a time from LDS, buffer stores --
     float m = 0.0f;
     const unsigned HWo4 = (unsigned)HWo * 4u;
-    const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + (int64_t)cur.smp * COUT * HWo4, (int64_t)COUT * HWo4);
+    const fq_rsrc yr = OUT16 ? make_rsrc(reinterpret_cast<char*>(y) + (int64_t)cur.smp * oc.CBo * HWo * 16, (int64_t)oc.CBo * HWo * 16)
+                             : make_rsrc(reinterpret_cast<char*>(y) + (int64_t)cur.smp * COUT * HWo4, (int64_t)COUT * HWo4);
     const unsigned yo = (unsigned)(4 * h) * HWo4 + cur.jp * 4u;
+    QParams q2;
+    q2.lo = q2.hi = q2.denom = q2.scale = 0.0f;
+    q2.rden = 0.0;
+    if (OUT16) q2 = make_qparams(oc.thr[0], oc.levels, oc.lo_neg != 0, kEps);
+    const int ubias2 = 128 - oc.zoff;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -291,11 +306,19 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
         const f4 bch = *reinterpret_cast<const f4*>(c_bias + c0);
         const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
+        float vq[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = dw_finish<EPI>(acc[ct][4 * gq + r], bias != nullptr, bch[r], has_bn, bsc[r], bsh[r], act);
-          buf_st_f32(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
+          if (!OUT16) buf_st_f32(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
+          vq[r] = v;
           m = fmaxf(m, fabsf(v));
+        }
+        if (OUT16) {     // channels 8 gq + 4 h .. + 3 of the lane's pixel = bytes 8 (gq & 1) + 4 h .. of block 2 ct + gq / 2
+          const int packed = pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
+                                         fq_code_int(vq[3], q2), ubias2);
+          buf_st_f32(yr, cur.jp * 16u + (unsigned)(8 * (gq & 1) + 4 * h), (unsigned)((2 * ct + (gq >> 1)) * HWo * 16),
+                     __int_as_float(packed));
         }
       }
     if (has_stat) {                               // a tile lies within one sample
@@ -324,7 +347,8 @@ extern "C" {
 // shared by both entry points: ksize 3 (3 -> 32) or 7 (3 -> 64)
 static int stem_launch(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
                        int64_t cout, int64_t h, int64_t w, int ksize, const float* bn_scale, const float* bn_shift, int act,
-                       float* stat_out, fqStream_t stream, const char* who) {
+                       float* stat_out, fqStream_t stream, const char* who, const float* out_thr = nullptr, int out_width = 8,
+                       unsigned out_flags = 0) {
   FQ_REQUIRE(x && w_tap_major && y, "%s: null pointer", who);
   FQ_REQUIRE(n > 0 && n < 65536 && h > 0 && w > 0 && h < (1 << 15) && w < (1 << 15) && 3 * h * w * 4 < (1ll << 31),
              "%s: bad shape", who);
@@ -342,7 +366,17 @@ static int stem_launch(const float* x, const float* w_tap_major, const float* bi
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   ProfScope prof(FQ_KERNEL_STEM, 4.0 * ((double)n * cin * h * w + (double)n * cout * hwo), st);
   static const int form = env_int("FQ_STEM_FORM", 0);                   // tuning: 0 auto, 1 VALU form (3x3 only), 2 MFMA form
-  if (ksize == 3 && form == 1) {
+  StemCodes oc;
+  oc.thr = out_thr; oc.levels = 0.0f; oc.lo_neg = 0; oc.zoff = 0; oc.CBo = (int)((cout + 15) / 16);
+  if (out_thr != nullptr) {
+    FQ_REQUIRE(ksize == 3, "%s: the code output is built for the 3x3 form", who);
+    FQ_REQUIRE(out_width >= 2 && out_width <= 8 && !(out_flags & (FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "%s: bad output quantiser", who);
+    FQ_REQUIRE((int64_t)oc.CBo * hwo * 16 < (1ll << 31), "%s: output plane too large", who);
+    oc.levels = act_levels(out_width, out_flags);
+    oc.lo_neg = (out_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+    oc.zoff = (out_flags & FQ_ACT_SIGNED) ? 0 : 128;
+  }
+  if (ksize == 3 && form == 1 && out_thr == nullptr) {
     const int tiles = (int)((hwo + kBlock - 1) / kBlock);
     // enough workgroups to fill the chip, as few statistic atomics per sample as that allows
     int tiles_per_wg = 1;
@@ -373,16 +407,24 @@ static int stem_launch(const float* x, const float* w_tap_major, const float* bi
                       : kEpiRuntime;
 #define FQ_STEM_LAUNCH(KS_, CO_, E_)                                                                                \
   hipLaunchKernelGGL((stem_mfma_kernel<KS_, CO_, E_>), dim3((unsigned)grid), dim3(kBlock), 0, st, x, w_tap_major, bias, \
-                     y, g, bn_scale, bn_shift, act, stat_out)
+                     y, g, bn_scale, bn_shift, act, stat_out, oc)
+#define FQ_STEM_LAUNCH16(E_)                                                                                        \
+  hipLaunchKernelGGL((stem_mfma_kernel<3, 32, E_, true>), dim3((unsigned)grid), dim3(kBlock), 0, st, x, w_tap_major, bias, \
+                     y, g, bn_scale, bn_shift, act, stat_out, oc)
 #define FQ_STEM_EPI(KS_, CO_)                                                                                       \
   do {                                                                                                              \
     if (epi == kEpiBnRelu) FQ_STEM_LAUNCH(KS_, CO_, kEpiBnRelu);                                                    \
     else if (epi == kEpiBnRelu6) FQ_STEM_LAUNCH(KS_, CO_, kEpiBnRelu6);                                             \
     else FQ_STEM_LAUNCH(KS_, CO_, kEpiRuntime);                                                                     \
   } while (0)
-  if (ksize == 3) FQ_STEM_EPI(3, 32);
+  if (out_thr != nullptr) {
+    if (epi == kEpiBnRelu) FQ_STEM_LAUNCH16(kEpiBnRelu);
+    else if (epi == kEpiBnRelu6) FQ_STEM_LAUNCH16(kEpiBnRelu6);
+    else FQ_STEM_LAUNCH16(kEpiRuntime);
+  } else if (ksize == 3) FQ_STEM_EPI(3, 32);
   else FQ_STEM_EPI(7, 64);
 #undef FQ_STEM_EPI
+#undef FQ_STEM_LAUNCH16
 #undef FQ_STEM_LAUNCH
   FQ_LAUNCH_CHECK();
   return FQ_OK;
@@ -393,6 +435,14 @@ int fq_stem_conv3x3s2(const float* x, const float* w_tap_major, const float* bia
                       float* stat_out, fqStream_t stream) {
   return stem_launch(x, w_tap_major, bias, y, n, cin, cout, h, w, 3, bn_scale, bn_shift, act, stat_out, stream,
                      "fq_stem_conv3x3s2");
+}
+
+int fq_stem_conv3x3s2_c16(const float* x, const float* w_tap_major, const float* bias, void* y16, int64_t n, int64_t cin,
+                          int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
+                          float* stat_out, const float* out_thr, int out_width, unsigned out_flags, fqStream_t stream) {
+  FQ_REQUIRE(out_thr != nullptr, "fq_stem_conv3x3s2_c16: out_thr is the consumer's stored threshold");
+  return stem_launch(x, w_tap_major, bias, (float*)y16, n, cin, cout, h, w, 3, bn_scale, bn_shift, act, stat_out, stream,
+                     "fq_stem_conv3x3s2_c16", out_thr, out_width, out_flags);
 }
 
 int fq_stem_conv7x7s2(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,

@@ -511,10 +511,11 @@ def eval_counters(logits, labels, counters):
     return counters
 
 
-def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None):
+def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None, out_codes=None):
     """The un-quantised first convolution - 3x3 / stride 2 / pad 1 / 3 -> 32 channels (MobileNets) or 7x7 / stride 2 / pad 3 /
     3 -> 64 (ResNets) - with fused BatchNorm / activation / per-sample statistic.  w: (Cout, 3, K, K) as the Conv2D parameter
-    holds it; pass `w_tap_major` (= w.permute(1,2,3,0) contiguous) to skip the permutation.  Returns (y, stat (N,) or None)."""
+    holds it; pass `w_tap_major` (= w.permute(1,2,3,0) contiguous) to skip the permutation.  Returns (y, stat (N,) or None).
+    `out_codes=dict(thr=..., width=8, flags=0)` (3x3 form; fq_stem_conv3x3s2_c16): y is a `Codes16` of the consumer's codes."""
     _check(x, "x")
     _check(w, "w")
     if x.dim() != 4 or w.dim() != 4 or w.shape[2] != w.shape[3] or w.shape[2] not in (3, 7) or w.shape[1] != x.shape[1]:
@@ -533,6 +534,15 @@ def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_s
     y = torch.empty((n, cout, (h + 2 * pad - ks) // 2 + 1, (wd + 2 * pad - ks) // 2 + 1), dtype=torch.float32,
                     device=x.device)
     stat, zflag = _stat_target(n, x.device, want_stat)
+    if out_codes is not None:
+        if ks != 3:
+            raise ValueError("the first convolution hands codes over in its 3x3 form only")
+        othr = _check(out_codes["thr"], "out_codes['thr']")
+        yc = Codes16.empty(tuple(y.shape), x.device, othr, out_codes.get("width", 8), out_codes.get("flags", 0))
+        check_call(_lib_().fq_stem_conv3x3s2_c16(_ptr(x), _ptr(wt), _ptr(bias), _ptr(yc.t), n, cin, cout, h, wd, _ptr(bn_scale),
+                                                 _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _ptr(othr), int(yc.width),
+                                                 int(yc.flags), _stream(x)))
+        return yc, stat
     entry = _lib_().fq_stem_conv3x3s2 if ks == 3 else _lib_().fq_stem_conv7x7s2
     check_call(entry(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), n, cin, cout, h, wd, _ptr(bn_scale), _ptr(bn_shift),
                      _ACTS[act] | zflag, _ptr(stat), _stream(x)))

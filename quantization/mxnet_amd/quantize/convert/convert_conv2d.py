@@ -251,7 +251,7 @@ def handover_target(block, fz=None):
     counts only while it can hand over to its own consumer.  Returns the keyword `out_codes` of ops.pwconv_i8 /
     conv3x3_i8 / dwconv3x3_c16, or None."""
     from .. import fuse as _fuse
-    fz = fz if fz is not None else block._fq_pw_fused
+    fz = fz if fz is not None else block._fq_pw_fused          # (the first convolution passes its own record)
     nxt = fz.get("next")
     if nxt is None or not _fuse.HANDOVER or autograd.is_recording() or not _consumer_takes_codes(nxt):
         return None
@@ -379,7 +379,8 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                                                flags=ops.act_flags(signed=a_.in_signed))
             # (a 1x1 convolution that READS codes writes codes too from 256 input channels up - the first 1x1 of a ResNet unit
             # fed by the trunk's code copy; below that the both-sides instantiations are not built)
-            if not extra and (c16_in is None or xshape[1] >= 256):
+            if not extra and (c16_in is None or xshape[1] >= 256 or
+                              (xshape[1] == 32 and xshape[0] * xshape[2] * xshape[3] > 32 * 4096)):
                 # through a depthwise consumer: on every plane by default, `_DW_C16_MIN_PIXELS` above says why and what a batch
                 # alone on the GPU would prefer (fq_dwconv3x3_c16 102 us against 158 at 112x112 stride 2 and 49 against 61 at
                 # 56x56 stride 2, but 23 against 18 at 14x14 where the flat fp32 form is at its best) - profiles/r3_handover.txt

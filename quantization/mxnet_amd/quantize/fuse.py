@@ -147,6 +147,8 @@ HANDOVER = _os.environ.get("FQ_HANDOVER", "1") != "0"      # int8 C16 hand-over 
 # round 4: the closing 1x1 of a ResNet unit stores the trunk twice - fp32 for the shortcut, codes for the next unit's first 1x1
 # (fq_pwconv_i8_c16_dual).  Same logits either way (tests/test_gpu_c16.py)
 SIDE_CODES = _os.environ.get("FQ_HANDOVER_SIDE", "1") != "0"
+# ... and MobileNetV2's first convolution hands its single consumer's codes over (fq_stem_conv3x3s2_c16)
+STEM_CODES = _os.environ.get("FQ_HANDOVER_STEM", "1") != "0"
 
 
 def _identity_forward(self, F, x, *args, **kwargs):
@@ -222,9 +224,19 @@ def _stem_forward(self, F, x, weight, bias=None):
     if st["constants"] is not None:
         scale, shift = st["constants"]()
     t = x._t if x._t.is_contiguous() else x._t.contiguous()
+    out_codes = None
+    if st.get("next") is not None and w.shape[2] == 3 and STEM_CODES:
+        # offline input quantisation: the single consumer's codes instead of the fp32 tensor (fq_stem_conv3x3s2_c16)
+        from .convert.convert_conv2d import handover_target
+        out_codes = handover_target(self, st)
     y, stat = ops.stem_conv_s2(t, w, None if bias is None else bias._t, bn_scale=scale, bn_shift=shift,
-                               act=st["act"], want_stat=True, w_tap_major=st["wt"])
-    out = NDArray(y)
+                               act=st["act"], want_stat=True, w_tap_major=st["wt"],
+                               **({} if out_codes is None else dict(out_codes=out_codes)))
+    if out_codes is not None:
+        out = NDArray(y.t)
+        out._fq_c16 = y
+    else:
+        out = NDArray(y)
     out._fq_stat = stat
     return out
 
@@ -416,7 +428,29 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             if pool is not None:
                 pool._fq_pool_fused = {"orig": pool.hybrid_forward}
                 pool.hybrid_forward = types.MethodType(_pool_stat_forward, pool)
+            b._fq_stem_fused["stem_follower"] = (container, j) if pool is None else None
             fused[0] += 1
+
+    def link_stem(b):
+        """The first convolution's single consumer, when that is a 1x1 convolution taken over on the codes (MobileNetV2: the
+        first unit's expansion) - linked after the pointwise pass, honoured under offline input quantisation only."""
+        st = getattr(b, "_fq_stem_fused", None)
+        if st is None or st.get("stem_follower") is None:
+            return
+        container, j = st["stem_follower"]
+        kids = list(container._children.values())
+        nxt = kids[j] if j < len(kids) else None
+        # (MobileNetV2's units are blocks of their own: the consumer is the first convolution of the unit's body)
+        while nxt is not None and type(nxt) is not nn.Conv2D:
+            inner = getattr(nxt, "out", None) or getattr(nxt, "body", None) or nxt
+            sub = list(inner._children.values()) if isinstance(inner, (nn.Sequential, nn.HybridSequential)) else []
+            if not sub or getattr(nxt, "use_shortcut", False) or sub[0] is nxt:
+                nxt = None
+            else:
+                nxt = sub[0]
+        fz = getattr(nxt, "_fq_pw_fused", None) if nxt is not None else None
+        if fz is not None and fz.get("kind") == "1x1" and nxt._kwargs["stride"] == (1, 1) and b.weight.shape[2] == 3:
+            st["next"] = nxt
 
     def visit_gap(container):
         """GlobalAvgPool2D [-> Flatten]: pool and statistic in one launch (fq_global_avg_pool_stat), the statistic carried
@@ -580,6 +614,8 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
         net.apply(visit_pw)
     net.apply(visit_gap)
     net.apply(visit)
+    if stem and pointwise_int8:
+        net.apply(link_stem)
     if residual:
         net.apply(visit_residual)
         net.apply(visit_side_links)

@@ -165,6 +165,40 @@ def test_closing_pointwise_stores_the_trunk_twice(dev, ops, case):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [(43, 224, 224), (3, 64, 64), (2, 33, 47)], ids=["43x224", "3x64", "2x33x47"])
+@pytest.mark.parametrize("act", ["relu6", "relu"])
+def test_first_convolution_hands_its_consumers_codes_over(dev, ops, shape, act):
+    """fq_stem_conv3x3s2_c16 (round 4): the codes of what fq_stem_conv3x3s2 computes, under the consumer's threshold; same
+    statistic.  And the consumer - a 32 -> 32 1x1 that reads codes AND writes codes (the streaming form's K = 32 both-sides
+    instantiation on the large plane, the split form's fp32-out path otherwise) - computes what it computes from the fp32 tensor."""
+    n, h, w = shape
+    rng = np.random.default_rng(sum(shape) + 29)
+    x = rng.standard_normal((n, 3, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((32, 3, 3, 3)) * 0.3).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 32).astype(np.float32)
+    sh = rng.standard_normal(32).astype(np.float32)
+    thr = np.float32(2.1)
+    thr_t = T(np.float32([thr]), dev)
+    y, stat = ops.stem_conv_s2(T(x, dev), T(wt, dev), None, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act=act)
+    yc, stat_c = ops.stem_conv_s2(T(x, dev), T(wt, dev), None, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act=act,
+                                  out_codes=dict(thr=thr_t, width=8, flags=0))
+    assert isinstance(yc, ops.Codes16) and yc.shape == tuple(y.shape) and torch.equal(stat, stat_c)
+    want = O.to_c16(O.ste_codes(y.cpu().numpy(), O.act_scale(thr, False, 8), thr, np.float32(0)).astype(np.int64), 128)
+    assert np.array_equal(yc.t.cpu().numpy(), want), "codes of the first convolution's output"
+    w2 = (rng.standard_normal((32, 32, 1, 1)) * 0.2).astype(np.float32)
+    codes, scales, rowsum = ops.weight_codes(T(w2, dev), 1, 8)
+    thr2 = np.float32(1.4)
+    kw = dict(in_thr=thr_t, width=8, flags=0, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu6", in_stat=stat)
+    a, sa = ops.pwconv_i8(y, codes, scales, rowsum, form="split", **kw)
+    if n * y.shape[2] * y.shape[3] > 32 * 4096:
+        b, sb = ops.pwconv_i8(yc, codes, scales, rowsum, out_codes=dict(thr=T(np.float32([thr2]), dev), width=8, flags=0), **kw)
+        wantb = O.to_c16(O.ste_codes(a.cpu().numpy(), O.act_scale(thr2, False, 8), thr2, np.float32(0)).astype(np.int64), 128)
+        assert np.array_equal(b.t.cpu().numpy(), wantb) and torch.equal(sa, sb)
+    else:
+        b, sb = ops.pwconv_i8(yc, codes, scales, rowsum, **kw)
+        assert torch.equal(a, b) and torch.equal(sa, sb)
+
+
 DW_CASES = [(2, 96, 112, 112, 2), (2, 144, 56, 56, 1), (3, 24, 9, 11, 1), (2, 192, 28, 28, 2), (3, 384, 14, 14, 1),
             (2, 960, 7, 7, 1), (4, 40, 5, 6, 2), (1, 16, 70, 70, 1)]
 
@@ -287,7 +321,8 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
         fuse.SIDE_CODES = False
         calls.update(c16_out=0, c16_in=0, side=0)
         no_side = net(xs[2]).asnumpy()
-        assert calls["side"] == 0 and calls["c16_in"] == calls["c16_out"]
+        # (MobileNetV2: + the codes its first convolution hands to the first 1x1 - a producer this test does not spy on)
+        assert calls["side"] == 0 and calls["c16_in"] == calls["c16_out"] + (1 if model.startswith("mobilenetv2") else 0)
         assert np.array_equal(no_side, with_codes), "logits with the trunk's code copy differ"
         assert [float(b.current_input_max) for b in net.collect_quantized_blocks()] == \
             [float(b.current_input_max) for b in net.collect_quantized_blocks()]
@@ -317,7 +352,8 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
     # (through the depthwise layer of every unit: 2 hand-overs per unit)
     # (+ 3 for ResNet-50: the shortcut convolution of a stage's first unit reads the trunk's code copy too - it has calibrated to
     # the very threshold of the first 1x1 beside it, both having seen the same tensors)
-    shared = 3 if model == "resnet50_v1" else 0
+    # (+ 1 for MobileNetV2: its first 1x1 reads the codes the first convolution handed over - that producer is not spied on)
+    shared = 3 if model == "resnet50_v1" else (1 if model.startswith("mobilenetv2") else 0)
     assert n_in == n_out + shared and n_out >= {"resnet50_v1": 32, "mobilenetv2_1.0": 32}.get(model, 1), (n_out, n_in)
     assert np.array_equal(with_codes, without), "logits with int8 hand-overs differ from the fp32 hand-over"
     assert cur_with == cur_without
