@@ -290,6 +290,7 @@ def _same_quantiser(block, other, plan, codes):
     return memo[1]
 
 
+_THIN_FORMS = os.environ.get("FQ_PWS_THIN", "1") != "0"      # (the library's A/B switch of the thin streaming instantiations)
 _SIDE_MAX_CIN = int(os.environ.get("FQ_SIDE_MAX_CIN", "512"))      # (A/B: 128 = the 56x56 and 28x28 stages only, 0 = off)
 
 
@@ -380,7 +381,7 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
             # (a 1x1 convolution that READS codes writes codes too from 256 input channels up - the first 1x1 of a ResNet unit
             # fed by the trunk's code copy; below that the both-sides instantiations are not built)
             if not extra and (c16_in is None or xshape[1] >= 256 or
-                              (xshape[1] == 32 and xshape[0] * xshape[2] * xshape[3] > 32 * 4096)):
+                              (xshape[1] == 32 and xshape[0] * xshape[2] * xshape[3] > 32 * 4096 and _THIN_FORMS)):
                 # through a depthwise consumer: on every plane by default, `_DW_C16_MIN_PIXELS` above says why and what a batch
                 # alone on the GPU would prefer (fq_dwconv3x3_c16 102 us against 158 at 112x112 stride 2 and 49 against 61 at
                 # 56x56 stride 2, but 23 against 18 at 14x14 where the flat fp32 form is at its best) - profiles/r3_handover.txt
