@@ -119,6 +119,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef FQ_STEM_CH
 #define FQ_STEM_CH 16
 #endif
+#ifndef FQ_STEM_NOSTORE      // tuning only (tools/stembench.py): the statistic without the stores - what a recomputation would cost
+#define FQ_STEM_NOSTORE 0
+#endif
 
 // Tile bookkeeping is 32-bit and incremental (host: fewer than 2^31 tiles; the wavefront's range, the divisions by the
 // tiles per image and by the output width arrive as per / rem and multiplicative inverses).  With 64-bit tile indices hipcc
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = dw_finish<EPI>(acc[ct][4 * gq + r], bias != nullptr, bch[r], has_bn, bsc[r], bsh[r], act);
-          if (!OUT16) buf_st_f32(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
+          if (!OUT16 && !FQ_STEM_NOSTORE) buf_st_f32(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
           vq[r] = v;
           m = fmaxf(m, fabsf(v));
         }

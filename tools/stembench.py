@@ -2,7 +2,8 @@
 """The first convolutions alone (batch 128, 224x224): 3x3 -> 32 (MobileNets) and 7x7 -> 64 (ResNets), median of 40 launches.
 FQ_LIB_PATH selects a variant library (csrc/build.py --only fq_stem -DFQ_STEM_CH=..); FQ_STEM_WG_PER_CU the grid.  (r4: two to
 four workgroups per CU, 8 or 16 loads in flight, 128 / 168 / 256 registers: 323-375 us for the 7x7 form, none better than the
-default's 324; the 3x3 form 83-87 us.)"""
+default's 324; the 3x3 form 83-87 us.  `-DFQ_STEM_NOSTORE=1`: the statistic without the stores - 53.3 us for the 3x3 form, 297 us
+for the 7x7 form: what a recomputation of these layers would cost)"""
 import os
 import sys
 
