@@ -4,11 +4,15 @@
 // rules; the C16 layout: include/fakequant.h at fq_pwconv_i8_c16)
 #include "fq_common.h"
 
-// tuning build: -DFQ_DW16_V=<bits>  1: unconditional loads from clamped addresses + select (62 exec-masked loads otherwise),
-// 2: stride 2 keeps the row it shares with the next output row, 4: the short quantiser for non-negative output ranges.
-// Default: all three (r4: 526 -> 473 us over MobileNetV2's ten depthwise shapes at batch 128, tools/dw16bench.py)
+// tuning build: -DFQ_DW16_V=<bits>  4: the short quantiser for non-negative output ranges (bits 1 and 2 - unconditional loads
+// from clamped addresses + select instead of 62 exec-masked loads, stride 2 keeping the row it shares with the next output
+// row - are built in since r4: 526 -> 473 us over MobileNetV2's ten depthwise shapes at batch 128, tools/dw16bench.py).
+// -DFQ_DW16_DEPTH=<0|1|2>: output rows between the fetch of an input row and its use.
 #ifndef FQ_DW16_V
 #define FQ_DW16_V 7
+#endif
+#ifndef FQ_DW16_DEPTH
+#define FQ_DW16_DEPTH 2
 #endif
 
 namespace {
@@ -80,24 +84,29 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
   const unsigned* xin = reinterpret_cast<const unsigned*>(x) + (((size_t)smp * g.CB + (lane_ok ? blk : 0u)) * g.H * g.W) * 4u + qd;
   unsigned* yout = reinterpret_cast<unsigned*>(y) + (((size_t)smp * g.CB + (lane_ok ? blk : 0u)) * g.Ho * g.Wo) * 4u + qd;
   const int xc = (int)xo * S;                                           // centre input column
-  // one input row -> 3 columns x 4 dequantised channels
+  // one input row -> 3 columns x 4 dequantised channels, in two steps: `fetch` requests the three dwords (every load
+  // unconditional, from an address clamped into the plane: a load under a lane condition is an exec-masked branch of its own
+  // with a wait behind it), `cook` selects the padding pattern and dequantises.  The rows are fetched FQ_DW16_DEPTH output rows
+  // ahead of their use through three sets of registers in rotation (no copies: a copy needs the loaded value): with the fetch
+  // in the iteration that uses it, a lane's walk down the plane was a chain of Ho load latencies - 14 x 14 and 7 x 7 planes,
+  // 19 MB per layer, took 18-22 us.
   struct Row { float v[3][4]; };
-  auto load_row = [&](int r, Row& row) __attribute__((always_inline)) {
+  struct Raw { unsigned d[3]; };
+  auto fetch = [&](int r, Raw& w) __attribute__((always_inline)) {
+    const int rr = r < 0 ? 0 : (r < g.H ? r : g.H - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int col = xc + k - 1;
+      const int cc = col < 0 ? 0 : (col < g.W ? col : g.W - 1);
+      w.d[k] = xin[((size_t)rr * g.W + cc) * 4u];
+    }
+  };
+  auto cook = [&](int r, const Raw& w, Row& row) __attribute__((always_inline)) {
     const bool rok = lane_ok && r >= 0 && r < g.H;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int col = xc + k - 1;
-      const bool ok = rok && col >= 0 && col < g.W;
-      unsigned d = zero_code;
-      if (FQ_DW16_V & 1) {
-        // every load unconditional, from an address clamped into the plane, the padding selected afterwards: a load under a
-        // lane condition is an exec-masked branch of its own (62 of them in this kernel's ISA) with a wait behind it
-        const int rr = r < 0 ? 0 : (r < g.H ? r : g.H - 1), cc = col < 0 ? 0 : (col < g.W ? col : g.W - 1);
-        const unsigned t = xin[((size_t)rr * g.W + cc) * 4u];
-        d = ok ? t : zero_code;
-      } else if (ok) {
-        d = xin[((size_t)r * g.W + col) * 4u];
-      }
+      const unsigned d = (rok && col >= 0 && col < g.W) ? w.d[k] : zero_code;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const unsigned byte = (d >> (8 * c)) & 255u;
@@ -110,23 +119,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) ra.v[k][c] = rb.v[k][c] = rc.v[k][c] = 0.0f;
+    for (int c = 0; c < 4; ++c) ra.v[k][c] = rb.v[k][c] = rc.v[k][c] = 0.0f;      // (row -1: the code-0 pattern dequantises to 0)
   float m = 0.0f;
-  if (S == 1) {
-    load_row(-1, ra);                                                   // (the code-0 pattern dequantises to 0)
-    load_row(0, rb);
-  }
-  if (S == 2 && (FQ_DW16_V & 2)) load_row(-1, ra);
   const bool nn2 = (FQ_DW16_V & 4) && fq_nonneg(q2);
   const unsigned nn_xor2 = fq_nonneg_xor(ubias2);
-  for (int r = 0; r < g.Ho; ++r) {
-    if (S == 1) {
-      load_row(r + 1, rc);
-    } else {
-      if (!(FQ_DW16_V & 2)) load_row(2 * r - 1, ra);                    // (else: the previous output row's 2r' + 1, kept)
-      load_row(2 * r, rb);
-      load_row(2 * r + 1, rc);
-    }
+  // output row r from the window (ra, rb, rc)
+  auto emit = [&](int r) __attribute__((always_inline)) {
     float v[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -152,11 +150,66 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
                                            fq_code_int(v[3], q2), ubias2);
       yout[((size_t)r * g.Wo + xo) * 4u] = (unsigned)packed;
     }
-    if (S == 1) {
+  };
+  constexpr int DEPTH = FQ_DW16_DEPTH > 2 ? 2 : FQ_DW16_DEPTH;      // output rows between a fetch and its use: 0, 1 or 2 (3, four sets, 136 registers: no better)
+  int r = 0;
+  if (S == 1) {
+    // output row r needs input rows r - 1, r, r + 1: (ra, rb) carried, row r + 1 cooked from the set fetched DEPTH rows ago
+    Raw w0, w1, w2;
+    fetch(0, w0);
+    cook(0, w0, rb);
+    if (DEPTH >= 1) fetch(1, w0);
+    if (DEPTH >= 2) fetch(2, w1);
+    auto step = [&](Raw& mine, Raw& far) __attribute__((always_inline)) {
+      if (DEPTH == 0) fetch(r + 1, mine);
+      else fetch(r + 1 + DEPTH, far);
+      cook(r + 1, mine, rc);
+      emit(r);
       ra = rb;
       rb = rc;
-    } else if (FQ_DW16_V & 2) {
+      ++r;
+    };
+    while (r < g.Ho) {
+      if (DEPTH == 0) { step(w0, w0); continue; }
+      if (DEPTH == 1) {
+        step(w0, w1);
+        if (r >= g.Ho) break;
+        step(w1, w0);
+        continue;
+      }
+      step(w0, w2);
+      if (r >= g.Ho) break;
+      step(w1, w0);
+      if (r >= g.Ho) break;
+      step(w2, w1);
+    }
+  } else {
+    // output row r needs input rows 2r - 1 (the previous output row's 2r' + 1, kept in ra), 2r, 2r + 1
+    Raw a0, b0, a1, b1, a2, b2;
+    if (DEPTH >= 1) { fetch(0, a0); fetch(1, b0); }
+    if (DEPTH >= 2) { fetch(2, a1); fetch(3, b1); }
+    auto step = [&](Raw& ma, Raw& mb, Raw& fa, Raw& fb) __attribute__((always_inline)) {
+      if (DEPTH == 0) { fetch(2 * r, ma); fetch(2 * r + 1, mb); }
+      else { fetch(2 * (r + DEPTH), fa); fetch(2 * (r + DEPTH) + 1, fb); }
+      cook(2 * r, ma, rb);
+      cook(2 * r + 1, mb, rc);
+      emit(r);
       ra = rc;
+      ++r;
+    };
+    while (r < g.Ho) {
+      if (DEPTH == 0) { step(a0, b0, a0, b0); continue; }
+      if (DEPTH == 1) {
+        step(a0, b0, a1, b1);
+        if (r >= g.Ho) break;
+        step(a1, b1, a0, b0);
+        continue;
+      }
+      step(a0, b0, a2, b2);
+      if (r >= g.Ho) break;
+      step(a1, b1, a0, b0);
+      if (r >= g.Ho) break;
+      step(a2, b2, a1, b1);
     }
   }
   if (stat_out != nullptr) {

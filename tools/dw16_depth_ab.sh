@@ -1,0 +1,6 @@
+for r in 1 2; do for lib in "" build_tools/libfq_dw16_d0.so; do
+  FQ_LIB_PATH=$lib python3 bench.py --model mobilenetv2_1.0 --quant-type channel --weight-bits 4 --offline --steps 200 --no-cpu-baseline --no-headline 2>/dev/null | python3 -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=l['roofline']['kernels']
+print('lib=${lib:-default(depth 2)} mobilenetv2_1.0 W4 offline:', l['value'], 'images/s', l['ms_per_step'], 'ms/step; one batch at a time', l['single_stream']['value'], {n:round(v['ms_per_step'],3) for n,v in k.items()})"
+done; done
