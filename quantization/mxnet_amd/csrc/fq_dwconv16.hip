@@ -7,7 +7,7 @@
 // tuning build: -DFQ_DW16_V=<bits>  4: the short quantiser for non-negative output ranges (bits 1 and 2 - unconditional loads
 // from clamped addresses + select instead of 62 exec-masked loads, stride 2 keeping the row it shares with the next output
 // row - are built in since r4: 526 -> 473 us over MobileNetV2's ten depthwise shapes at batch 128, tools/dw16bench.py).
-// -DFQ_DW16_DEPTH=<0|1|2>: output rows between the fetch of an input row and its use.
+// -DFQ_DW16_DEPTH=<0|2>: output rows between the fetch of an input row and its use (1: 452 us, 3: four sets, 136 registers, 440 us).
 #ifndef FQ_DW16_V
 #define FQ_DW16_V 7
 #endif
@@ -38,8 +38,8 @@ struct Dw16Geom {
   int out_lo_neg, out_zoff, in_zoff;
 };
 
-template <int S, bool SIGNED_IN>
-__global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
+template <int S, bool SIGNED_IN, int EPI>
+__global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
     const int8_t* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias, int8_t* __restrict__ y,
     Dw16Geom g, const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max,
     float eps, float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
   const QParams q2 = make_qparams(out_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
   const float sx = q.scale;
   const int ubias2 = 128 - g.out_zoff;
-  const unsigned zero_code = SIGNED_IN ? 0u : 0x80808080u;              // four codes "0" as stored
   const unsigned ch = (lane_ok ? blk : 0u) * 16u + qd * 4u;             // first of this lane's four channels
   float wt[9][4], bch[4], bsc[4], bsh[4];
 #pragma unroll
@@ -106,112 +105,101 @@ __global__ __launch_bounds__(256) void dwconv3x3_c16_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int col = xc + k - 1;
-      const unsigned d = (rok && col >= 0 && col < g.W) ? w.d[k] : zero_code;
+      // the stored byte of an unsigned code is code ^ 0x80: one xor per dword, then the byte-to-float conversions
+      const unsigned d = (rok && col >= 0 && col < g.W) ? (SIGNED_IN ? w.d[k] : w.d[k] ^ 0x80808080u) : 0u;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const unsigned byte = (d >> (8 * c)) & 255u;
-        const float code = SIGNED_IN ? (float)(int)(int8_t)byte : (float)(byte ^ 0x80u);
+        const float code = SIGNED_IN ? (float)(int)(int8_t)byte : (float)byte;
         row.v[k][c] = code * sx;
       }
     }
   };
-  Row ra, rb, rc;
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ra.v[k][c] = rb.v[k][c] = rc.v[k][c] = 0.0f;      // (row -1: the code-0 pattern dequantises to 0)
   float m = 0.0f;
-  const bool nn2 = (FQ_DW16_V & 4) && fq_nonneg(q2);
   const unsigned nn_xor2 = fq_nonneg_xor(ubias2);
-  // output row r from the window (ra, rb, rc)
-  auto emit = [&](int r) __attribute__((always_inline)) {
-    float v[4];
+  // the walk down the plane, instantiated with the 5-instruction quantiser of non-negative output ranges and with the generic
+  // one (a run-time choice between the two inside the loop computes BOTH for every output and selects)
+  auto walk = [&](auto nn_c) __attribute__((always_inline)) {
+    constexpr bool NN = decltype(nn_c)::value;
+    Row ra, rb, rc;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float acc = 0.0f;
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) acc = fmaf(wt[k][c], ra.v[k][c], acc);
+      for (int c = 0; c < 4; ++c) ra.v[k][c] = rb.v[k][c] = rc.v[k][c] = 0.0f;      // (row -1: code 0 dequantises to 0)
+    // output row r from the window (A, B, C) = input rows above / at / below
+    auto emit = [&](int r, const Row& A, const Row& B, const Row& C) __attribute__((always_inline)) {
+      float v[4];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) acc = fmaf(wt[3 + k][c], rb.v[k][c], acc);
+      for (int c = 0; c < 4; ++c) {
+        float acc = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) acc = fmaf(wt[6 + k][c], rc.v[k][c], acc);
-      if (bias != nullptr) acc = acc + bch[c];
-      if (bn_scale != nullptr) {
-        acc = acc * bsc[c];
-        acc = acc + bsh[c];
+        for (int k = 0; k < 3; ++k) acc = fmaf(wt[k][c], A.v[k][c], acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc = fmaf(wt[3 + k][c], B.v[k][c], acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc = fmaf(wt[6 + k][c], C.v[k][c], acc);
+        acc = dw_finish<EPI>(acc, bias != nullptr, bch[c], bn_scale != nullptr, bsc[c], bsh[c], act);
+        v[c] = acc;
+        m = fmaxf(m, fabsf(acc));
       }
-      acc = act_rt(acc, act);
-      v[c] = acc;
-      m = fmaxf(m, fabsf(acc));
-    }
-    if (lane_ok) {
-      const int packed = nn2 ? fq_pack4<true>(v[0], v[1], v[2], v[3], q2, ubias2, nn_xor2)
-                             : pack4_codes(fq_code_int(v[0], q2), fq_code_int(v[1], q2), fq_code_int(v[2], q2),
-                                           fq_code_int(v[3], q2), ubias2);
-      yout[((size_t)r * g.Wo + xo) * 4u] = (unsigned)packed;
+      if (lane_ok) {
+        const int packed = fq_pack4<NN>(v[0], v[1], v[2], v[3], q2, ubias2, nn_xor2);
+        yout[((size_t)r * g.Wo + xo) * 4u] = (unsigned)packed;
+      }
+    };
+    // The walk is unrolled over the period of BOTH rotations - the fetched sets and the window's rows change roles instead of
+    // being copied (24 register moves per output row otherwise, of ~140 instructions).
+    constexpr bool AHEAD = FQ_DW16_DEPTH != 0;        // (0: fetch and use in the same step - the tuning baseline)
+    int r = 0;
+    if (S == 1) {
+      // output row r needs input rows r - 1, r, r + 1: rows (A, B) carried, row r + 1 cooked into C from the set fetched two
+      // output rows ago
+      Raw w0, w1, w2;
+      fetch(0, w0);
+      cook(0, w0, rb);
+      if (AHEAD) {
+        fetch(1, w0);
+        fetch(2, w1);
+      }
+      auto step = [&](Raw& mine, Raw& far, const Row& A, const Row& B, Row& C) __attribute__((always_inline)) {
+        if (AHEAD) fetch(r + 3, far);
+        else fetch(r + 1, mine);
+        cook(r + 1, mine, C);
+        emit(r, A, B, C);
+        ++r;
+      };
+      while (r < g.Ho) {
+        step(w0, w2, ra, rb, rc);
+        if (r >= g.Ho) break;
+        step(w1, w0, rb, rc, ra);
+        if (r >= g.Ho) break;
+        step(w2, w1, rc, ra, rb);
+      }
+    } else {
+      // output row r needs input rows 2r - 1 (the previous output row's 2r' + 1: its C is this row's A), 2r, 2r + 1
+      // (fetched ONE output row = two input rows ahead: two more sets cost the fourth wavefront per SIMD and bought nothing)
+      Raw a0, b0, a1, b1;
+      if (AHEAD) {
+        fetch(0, a0);
+        fetch(1, b0);
+      }
+      auto step = [&](Raw& ma, Raw& mb, Raw& fa, Raw& fb, const Row& A, Row& B, Row& C) __attribute__((always_inline)) {
+        if (AHEAD) { fetch(2 * r + 2, fa); fetch(2 * r + 3, fb); }
+        else { fetch(2 * r, ma); fetch(2 * r + 1, mb); }
+        cook(2 * r, ma, B);
+        cook(2 * r + 1, mb, C);
+        emit(r, A, B, C);
+        ++r;
+      };
+      while (r < g.Ho) {
+        step(a0, b0, a1, b1, ra, rb, rc);
+        if (r >= g.Ho) break;
+        step(a1, b1, a0, b0, rc, rb, ra);
+      }
     }
   };
-  constexpr int DEPTH = FQ_DW16_DEPTH > 2 ? 2 : FQ_DW16_DEPTH;      // output rows between a fetch and its use: 0, 1 or 2 (3, four sets, 136 registers: no better)
-  int r = 0;
-  if (S == 1) {
-    // output row r needs input rows r - 1, r, r + 1: (ra, rb) carried, row r + 1 cooked from the set fetched DEPTH rows ago
-    Raw w0, w1, w2;
-    fetch(0, w0);
-    cook(0, w0, rb);
-    if (DEPTH >= 1) fetch(1, w0);
-    if (DEPTH >= 2) fetch(2, w1);
-    auto step = [&](Raw& mine, Raw& far) __attribute__((always_inline)) {
-      if (DEPTH == 0) fetch(r + 1, mine);
-      else fetch(r + 1 + DEPTH, far);
-      cook(r + 1, mine, rc);
-      emit(r);
-      ra = rb;
-      rb = rc;
-      ++r;
-    };
-    while (r < g.Ho) {
-      if (DEPTH == 0) { step(w0, w0); continue; }
-      if (DEPTH == 1) {
-        step(w0, w1);
-        if (r >= g.Ho) break;
-        step(w1, w0);
-        continue;
-      }
-      step(w0, w2);
-      if (r >= g.Ho) break;
-      step(w1, w0);
-      if (r >= g.Ho) break;
-      step(w2, w1);
-    }
-  } else {
-    // output row r needs input rows 2r - 1 (the previous output row's 2r' + 1, kept in ra), 2r, 2r + 1
-    Raw a0, b0, a1, b1, a2, b2;
-    if (DEPTH >= 1) { fetch(0, a0); fetch(1, b0); }
-    if (DEPTH >= 2) { fetch(2, a1); fetch(3, b1); }
-    auto step = [&](Raw& ma, Raw& mb, Raw& fa, Raw& fb) __attribute__((always_inline)) {
-      if (DEPTH == 0) { fetch(2 * r, ma); fetch(2 * r + 1, mb); }
-      else { fetch(2 * (r + DEPTH), fa); fetch(2 * (r + DEPTH) + 1, fb); }
-      cook(2 * r, ma, rb);
-      cook(2 * r + 1, mb, rc);
-      emit(r);
-      ra = rc;
-      ++r;
-    };
-    while (r < g.Ho) {
-      if (DEPTH == 0) { step(a0, b0, a0, b0); continue; }
-      if (DEPTH == 1) {
-        step(a0, b0, a1, b1);
-        if (r >= g.Ho) break;
-        step(a1, b1, a0, b0);
-        continue;
-      }
-      step(a0, b0, a2, b2);
-      if (r >= g.Ho) break;
-      step(a1, b1, a0, b0);
-      if (r >= g.Ho) break;
-      step(a2, b2, a1, b1);
-    }
-  }
+  if ((FQ_DW16_V & 4) && fq_nonneg(q2)) walk(std::true_type{});
+  else walk(std::false_type{});
   if (stat_out != nullptr) {
     const float wm = wave_max_nonneg(lane_ok ? m : 0.0f);
     if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = wm;
@@ -259,15 +247,25 @@ int fq_dwconv3x3_c16(const void* x, const float* w, const float* bias, void* y, 
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   // (SURVEY.md 8d's definition of the algorithmic bytes - 4 B per input and per output element - as for the fp32 form)
   ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * g.Ho * g.Wo), st);
-#define FQ_DW16(S_, SG_)                                                                                                \
-  hipLaunchKernelGGL((dwconv3x3_c16_kernel<S_, SG_>), dim3((unsigned)grid), dim3(256), 0, st, (const int8_t*)x, w, bias,  \
+#define FQ_DW16(S_, SG_, E_)                                                                                            \
+  hipLaunchKernelGGL((dwconv3x3_c16_kernel<S_, SG_, E_>), dim3((unsigned)grid), dim3(256), 0, st, (const int8_t*)x, w, bias, \
                      (int8_t*)y, g, in_stat, (int)n, in_thr, levels, lo_neg, kEps, out_current_max, bn_scale, bn_shift,  \
                      act, stat_out, out_thr)
   const bool sg = (in_flags & FQ_ACT_SIGNED) != 0;
+  // compile-time epilogues for the fused-inference case (BatchNorm, no bias, ReLU / ReLU6) on unsigned input codes
+  const int epi = (!sg && bn_scale != nullptr && bias == nullptr)
+                      ? (act == FQ_ACT_RELU ? kEpiBnRelu : act == FQ_ACT_RELU6 ? kEpiBnRelu6 : kEpiRuntime)
+                      : kEpiRuntime;
   if (stride == 1) {
-    if (sg) FQ_DW16(1, true); else FQ_DW16(1, false);
+    if (sg) FQ_DW16(1, true, kEpiRuntime);
+    else if (epi == kEpiBnRelu) FQ_DW16(1, false, kEpiBnRelu);
+    else if (epi == kEpiBnRelu6) FQ_DW16(1, false, kEpiBnRelu6);
+    else FQ_DW16(1, false, kEpiRuntime);
   } else {
-    if (sg) FQ_DW16(2, true); else FQ_DW16(2, false);
+    if (sg) FQ_DW16(2, true, kEpiRuntime);
+    else if (epi == kEpiBnRelu) FQ_DW16(2, false, kEpiBnRelu);
+    else if (epi == kEpiBnRelu6) FQ_DW16(2, false, kEpiBnRelu6);
+    else FQ_DW16(2, false, kEpiRuntime);
   }
 #undef FQ_DW16
   FQ_LAUNCH_CHECK();
