@@ -235,6 +235,44 @@ def test_depthwise_between_two_code_tensors(dev, ops, case, signed):
     assert torch.equal(st, want_stat) and torch.equal(cur_a, cur_b)
 
 
+DW_EDGE_CASES = [(2, 16, 1, 1, 1), (2, 20, 1, 5, 2), (1, 32, 2, 3, 1), (1, 32, 2, 2, 2), (2, 16, 3, 70, 2), (1, 48, 4, 4, 1),
+                 (1, 16, 5, 5, 1), (1, 16, 6, 7, 2), (1, 16, 7, 66, 1), (1, 16, 9, 130, 2)]
+
+
+@pytest.mark.parametrize("case", DW_EDGE_CASES, ids=["%dx%d@%dx%d/s%d" % c for c in DW_EDGE_CASES])
+@pytest.mark.parametrize("epi", ["bn-relu", "bn-none-signed-out", "bias-bn-relu6", "plain"])
+def test_depthwise_on_codes_every_epilogue_on_planes_shorter_than_the_prefetch(dev, ops, case, epi):
+    """fq_dwconv3x3_c16 fetches its input rows two output rows ahead through rotating register sets and is instantiated per
+    epilogue and output quantiser: planes of 1-9 rows (shorter than the rotation's period, rows fetched past the end), more
+    than 64 columns (column tiles), every epilogue instantiation and the generic (signed-range) output quantiser - against
+    fq_dwconv3x3 on the fp32 tensor + the oracle's codes."""
+    n, c, h, w, stride = case
+    rng = np.random.default_rng(sum(case) + 29 + len(epi))
+    x = np.maximum((rng.standard_normal((n, c, h, w)) * 2).astype(np.float32), 0)
+    wt = (rng.standard_normal((c, 1, 3, 3)) * 0.4).astype(np.float32)
+    sc = rng.uniform(0.3, 1.5, c).astype(np.float32)
+    sh = rng.standard_normal(c).astype(np.float32)
+    bias = T(rng.standard_normal(c).astype(np.float32), dev) if epi == "bias-bn-relu6" else None
+    act = {"bn-relu": "relu", "bn-none-signed-out": None, "bias-bn-relu6": "relu6", "plain": None}[epi]
+    out_signed = epi == "bn-none-signed-out"
+    thr, thr2 = np.float32(2.3), np.float32(1.7)
+    thr_t = T(np.float32([thr]), dev)
+    kw = dict(stride=stride, in_thr=thr_t, width=8, flags=ops.act_flags(signed=False), act=act)
+    if epi != "plain":
+        kw.update(bn_scale=T(sc, dev), bn_shift=T(sh, dev))
+    want, want_stat = ops.dwconv3x3(T(x, dev), T(wt, dev), bias, **kw)
+    cx = O.ste_codes(x, O.act_scale(thr, False, 8), thr, np.float32(0))
+    xc = ops.Codes16(T(O.to_c16(cx.astype(np.int64), 128), dev), x.shape, thr_t, 8, ops.act_flags(signed=False))
+    yc, st = ops.dwconv3x3_c16(xc, T(wt, dev), bias, out_codes=dict(thr=T(np.float32([thr2]), dev), width=8,
+                                                                   flags=ops.act_flags(signed=out_signed)), **kw)
+    lo = np.float32(-thr2) if out_signed else np.float32(0)
+    wantc = O.to_c16(O.ste_codes(want.cpu().numpy(), O.act_scale(thr2, out_signed, 8), thr2, lo).astype(np.int64),
+                     0 if out_signed else 128)
+    assert yc.shape == tuple(want.shape)
+    assert np.array_equal(yc.t.cpu().numpy(), wantc), "codes of the depthwise output"
+    assert torch.equal(st, want_stat)
+
+
 C3_CASES = [(2, 64, 64, 9, 11), (3, 128, 128, 7, 7), (2, 256, 256, 5, 6), (1, 512, 512, 7, 7), (2, 64, 128, 14, 14),
             (5, 64, 96, 3, 3), (2, 128, 160, 28, 28), (1, 64, 64, 56, 56)]
 
