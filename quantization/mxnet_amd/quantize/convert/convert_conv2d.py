@@ -258,7 +258,7 @@ def handover_target(block, fz=None):
     # a user hook on the producer, on the consumer or on a block bypassed between them (folded BatchNorm, bypassed
     # activation) would be shown a C16 code tensor where it expects the fp32 activation (collect_feature_maps hooks `x[0]` of
     # every quantised block): no hand-over past a hook
-    if any(_hooked(b) for b in (block, nxt, fz.get("bn"), fz.get("act_block"))):
+    if any(_hooked(b) for b in (block, nxt, fz.get("bn"), fz.get("act_block")) + tuple(fz.get("via", ()))):
         return None
     dw = getattr(nxt, "_fq_dw_fused", None)
     if dw is not None and (handover_target(nxt, dw) is None or not fz.get("c16_pays", True)):
@@ -379,9 +379,10 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                     extra["side_codes"] = dict(thr=side_blk.input_max.data()._t, width=a_.in_width,
                                                flags=ops.act_flags(signed=a_.in_signed))
             # (a 1x1 convolution that READS codes writes codes too from 256 input channels up - the first 1x1 of a ResNet unit
-            # fed by the trunk's code copy; below that the both-sides instantiations are not built)
+            # fed by the trunk's code copy - and, on large planes, up to 32: MobileNetV2's 32 -> 16 and 16 -> 96 behind a first
+            # convolution that hands its codes over; in between the both-sides instantiations are not built)
             if not extra and (c16_in is None or xshape[1] >= 256 or
-                              (xshape[1] == 32 and xshape[0] * xshape[2] * xshape[3] > 32 * 4096 and _THIN_FORMS)):
+                              (xshape[1] <= 32 and xshape[0] * xshape[2] * xshape[3] > 32 * 4096 and _THIN_FORMS)):
                 # through a depthwise consumer: on every plane by default, `_DW_C16_MIN_PIXELS` above says why and what a batch
                 # alone on the GPU would prefer (fq_dwconv3x3_c16 102 us against 158 at 112x112 stride 2 and 49 against 61 at
                 # 56x56 stride 2, but 23 against 18 at 14x14 where the flat fp32 form is at its best) - profiles/r3_handover.txt
@@ -389,6 +390,13 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                 s_ = block._kwargs["stride"][0]
                 fz["c16_pays"] = len(xs) == 4 and ((xs[2] - 1) // s_ + 1) * ((xs[3] - 1) // s_ + 1) >= _DW_C16_MIN_PIXELS
                 out_codes = handover_target(block)
+                if out_codes is not None and fz.get("via") is not None:
+                    # across two MobileNetV2 units (fuse.visit_unit_links): only while the consumer, which will READ codes, can
+                    # write codes as well (the rule above, for ITS input) - otherwise its depthwise layer falls back to fp32
+                    co = block._kwargs["num_filter"]
+                    if not (co >= 256 or (co <= 32 and xs[0] * ((xs[2] - 1) // s_ + 1) * ((xs[3] - 1) // s_ + 1) > 32 * 4096
+                                          and _THIN_FORMS)):
+                        out_codes = None
                 if out_codes is not None:
                     extra = dict(out_codes=out_codes)
             out = ops.pwconv_i8(x_arg, codes, scales, rowsum, None if bias is None else bias._t,

@@ -149,6 +149,7 @@ HANDOVER = _os.environ.get("FQ_HANDOVER", "1") != "0"      # int8 C16 hand-over 
 SIDE_CODES = _os.environ.get("FQ_HANDOVER_SIDE", "1") != "0"
 # ... and MobileNetV2's first convolution hands its single consumer's codes over (fq_stem_conv3x3s2_c16)
 STEM_CODES = _os.environ.get("FQ_HANDOVER_STEM", "1") != "0"
+UNIT_LINKS = _os.environ.get("FQ_HANDOVER_UNITS", "1") != "0"      # hand-over from a MobileNetV2 unit without shortcut to the next block (A/B)
 
 
 def _identity_forward(self, F, x, *args, **kwargs):
@@ -600,6 +601,33 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
                 continue
             fa["side_next"] = first
 
+    def visit_unit_links(container):
+        """MobileNetV2: a unit WITHOUT shortcut followed by another unit without shortcut (32 -> 16 then 16 -> 24: the 16-channel
+        tensor at 112 x 112): the projection's only reader is the next unit's first 1x1 - the int8 hand-over link across the two
+        containers (`via`: no hand-over past a hook on either of them)."""
+        if not isinstance(container, (nn.Sequential, nn.HybridSequential)) or not UNIT_LINKS:
+            return
+        kids = list(container._children.values())
+
+        def first_conv(seq):
+            while isinstance(seq, (nn.Sequential, nn.HybridSequential)) and len(seq._children):
+                seq = list(seq._children.values())[0]
+            return seq if type(seq) is nn.Conv2D else None
+        for a_, b_ in zip(kids, kids[1:]):
+            if not (_is_linear_bottleneck(a_) and not a_.use_shortcut):
+                continue
+            tail = _tail_conv(a_.out)
+            # (the 320-channel tensor in front of the last 1x1 has the same property, but its producer - 960 -> 320 at 7 x 7 -
+            # has no codes-in-and-out instantiation)
+            first = first_conv(b_.out) if _is_linear_bottleneck(b_) and not b_.use_shortcut else None
+            fa = getattr(tail, "_fq_pw_fused", None) if tail is not None else None
+            fb = getattr(first, "_fq_pw_fused", None) if first is not None else None
+            if fa is None or fb is None or fa.get("next") is not None or fb.get("kind") != "1x1" or fb.get("sliced") \
+                    or not hasattr(first, "quantize_args") or not hasattr(tail, "quantize_args"):
+                continue
+            fa["next"] = first
+            fa["via"] = (a_, b_)
+
     def visit_dense(b):
         if type(b) is nn.Dense and hasattr(b, "quantize_args") and dense_int8 and not hasattr(b, "_fq_dense_int8"):
             b._fq_dense_int8 = True                # convert_dense: the classifier on the integer codes
@@ -619,6 +647,8 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
     if residual:
         net.apply(visit_residual)
         net.apply(visit_side_links)
+    if pointwise_int8:
+        net.apply(visit_unit_links)
     _install_stat_arena(net, fused[0])
     return fused[0]
 

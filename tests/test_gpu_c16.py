@@ -94,7 +94,10 @@ def test_pointwise_consumer_of_codes_equals_consumer_of_fp32(dev, ops, case, mod
 
 
 BOTH_CASES = [(3, 256, 64, 56, 56, 1), (2, 512, 128, 28, 28, 1), (5, 1024, 256, 14, 14, 1), (7, 2048, 512, 7, 7, 1), (2, 256, 64, 9, 11, 1),
-              (2, 512, 128, 28, 28, 2)]
+              (2, 512, 128, 28, 28, 2),
+              # the thin streaming form's both-sides instantiation (more than 4096 pixel tiles, Cin <= 32): MobileNetV2's
+              # 32 -> 16 and 16 -> 96 at 112 x 112, and a ragged 24 -> 144
+              (11, 32, 16, 112, 112, 1), (11, 16, 96, 112, 112, 1), (43, 24, 144, 56, 56, 1), (11, 32, 32, 112, 112, 1)]
 
 
 @pytest.mark.parametrize("case", BOTH_CASES, ids=["%dx%d->%d@%dx%d/s%d" % c for c in BOTH_CASES])
@@ -307,6 +310,52 @@ def test_dense3x3_with_codes_on_both_sides(dev, ops, case, signed):
         yc, st = ops.conv3x3_i8(src, codes, scales, rowsum, out_codes=oc, **kw)
         assert np.array_equal(yc.t.cpu().numpy(), wantc), what
         assert torch.equal(st, want_stat), what
+
+
+def test_mobilenetv2_units_without_shortcut_hand_codes_to_the_next_block(gpu):
+    """quantize/fuse.py: visit_unit_links - the 16-channel tensor between MobileNetV2's first two units (no shortcut on either
+    side) crosses their containers as codes: at a batch whose 112 x 112 planes make more than 4096 pixel tiles the 16 -> 96
+    convolution READS codes (and writes codes); logits and every batch statistic equal those of the
+    net without the links bit for bit."""
+    from quantization.mxnet_amd import mx, ops
+    from quantization.mxnet_amd.quantize import fuse
+    from test_gpu_net import _build
+    was_deterministic = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        outs, stats, seen = {}, {}, {}
+        for links in (True, False):
+            fuse.UNIT_LINKS = links
+            net = _build("mobilenetv2_1.0", 1000, gpu, quant_type="channel", wt=4)
+            rng = np.random.default_rng(5)
+            xs = [mx.nd.array(rng.standard_normal((11, 3, 224, 224)).astype(np.float32), ctx=gpu) for _ in range(3)]
+            net.quantize_input(enable=True, online=True)
+            for x in xs[:2]:
+                net(x)
+                net.update_ema()
+            net.fix_params()
+            net.quantize_input(enable=True, online=False)
+            net(xs[2])
+            fuse.fuse_inference(net)
+            real = ops.pwconv_i8
+            thin = []
+
+            def spy(x, *a, **k):
+                if isinstance(x, ops.Codes16) and x.shape[1] == 16:
+                    thin.append((x.shape[1], k.get("out_codes") is not None))
+                return real(x, *a, **k)
+            ops.pwconv_i8 = spy
+            try:
+                outs[links] = net(xs[2]).asnumpy()
+            finally:
+                ops.pwconv_i8 = real
+            stats[links] = [float(b.current_input_max) for b in net.collect_quantized_blocks()]
+            seen[links] = thin
+        assert seen[True] == [(16, True)] and seen[False] == [], seen
+        assert np.array_equal(outs[True], outs[False]) and stats[True] == stats[False]
+    finally:
+        fuse.UNIT_LINKS = True
+        torch.backends.cudnn.deterministic = was_deterministic
 
 
 @pytest.mark.parametrize("model,kw", [("resnet50_v1", dict(quant_type="channel")), ("cifar_resnet20_v1", dict()),

@@ -1,0 +1,9 @@
+#!/bin/bash
+# MobileNetV2 W4 offline with the both-sides thin link (32 -> 16 -> 96 at 112 x 112 on codes) and without (FQ_HANDOVER_UNITS=0),
+# alternating, one call.
+for r in 1 2 3; do for m in 1 0; do
+  FQ_HANDOVER_UNITS=$m python3 bench.py --model mobilenetv2_1.0 --quant-type channel --weight-bits 4 --offline --steps 200 --no-cpu-baseline --no-headline 2>/dev/null | python3 -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=l['roofline']['kernels']
+print('FQ_HANDOVER_UNITS=$m mobilenetv2_1.0 W4 offline:', l['value'], 'images/s', l['ms_per_step'], 'ms/step; one batch at a time', l['single_stream']['value'], {n:round(v['ms_per_step'],3) for n,v in k.items()})"
+done; done
