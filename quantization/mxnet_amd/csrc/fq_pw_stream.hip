@@ -352,10 +352,13 @@ static bool pw_stream_thin_ok(const PwCall& c) {
   const int ct = (int)((c.cout + 31) / 32);
   const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 5 * sizeof(float);
   static const int thin = env_int("FQ_PWS_THIN", 1);                    // A/B: 0 leaves these shapes to the split form
+  // (r4: 3000 instead of 4096 - the 28 x 28 planes of a batch of 128 are 3136 tiles: MobileNetV2 W4 offline 144.8 -> 146.9 k
+  // images/s, ResNet-50 offline unchanged; 1500 / 700 add nothing, profiles/r4_thin_tiles_ab.txt)
+  static const int thin_min_tiles = env_int("FQ_PWS_THIN_MIN_TILES", 3000);
   // (codes in AND codes out: K = 32 only - MobileNetV2's first 1x1 behind a first convolution that hands its codes over)
   return thin && kt >= 1 && kt <= 6 && lds <= 72 * 1024 && c.stride == 1 && (c.out_thr == nullptr || c.cout % 16 == 0) &&
          !(c.in_c16 && c.out_thr != nullptr && kt != 1) && !(c.out_thr != nullptr && c.residual != nullptr) &&
-         (c.n * c.hw + 31) / 32 > 4096 && c.n * c.cout * c.hw * 4 < (1ll << 32) && c.n * c.cin * c.hw * 4 < (1ll << 32);
+         (c.n * c.hw + 31) / 32 > thin_min_tiles && c.n * c.cout * c.hw * 4 < (1ll << 32) && c.n * c.cin * c.hw * 4 < (1ll << 32);
 }
 
 // streaming form: the whole weight matrix in LDS, activations straight from NCHW into MFMA registers
