@@ -25,9 +25,13 @@ int pw_try_split(const PwCall& a, bool* taken) {
   const bool c16 = a.in_c16 || a.out_thr != nullptr;                    // (only this form reads / writes C16 code tensors)
   FQ_REQUIRE(a.y16 == nullptr || (a.in_c16 && a.out_thr == nullptr && a.stride == 1), "fq_pwconv_i8_c16_dual: a second output "
              "goes with a C16 input, fp32 y and stride 1");
+  // (r4, tools/pwforms.py --resnet: with a residual operand the streaming form loses its lead on the largest planes -
+  // 64 -> 256 @56x56 + residual, ResNet-50's largest kernel: 207.5 us against 183.7 here)
+  static const int res_split = env_int("FQ_PWS_RES_SPLIT", 1);
   bool want = a.form == 6 || a.stride != 1 || c16;                      // (only this form reads strided inputs)
   if (a.form == 0 && shape_ok && a.stride == 1)
-    want = mode == 2 || (mode == 1 && (tiles <= (int64_t)num_cu() * 16 || !pw_stream_shape_ok(a)));
+    want = mode == 2 || (mode == 1 && (tiles <= (int64_t)num_cu() * 16 || !pw_stream_shape_ok(a) ||
+                                       (res_split && a.residual != nullptr && a.cin <= 64)));
   if (want && shape_ok) {
     // channel tiles per wavefront (cw) and wavefronts per SIMD (lb).  Measured in the model: two tiles per wavefront at
     // four wavefronts per SIMD is the best or within 3 % of it on every shape (the grid then fills the chip in one or two

@@ -11,9 +11,14 @@ from quantization.mxnet_amd import ops  # noqa: E402
 
 LAYERS = [(32, 64, 112), (64, 128, 56), (128, 128, 56), (128, 256, 28), (256, 256, 28), (256, 512, 14), (512, 512, 14),
           (512, 1024, 7), (1024, 1024, 7)]
+if "--resnet" in sys.argv:          # resnet50_v1's 1x1 layers: (Cin, Cout, plane, residual operand)
+    LAYERS = [(64, 64, 56, 0), (64, 256, 56, 1), (256, 64, 56, 0), (256, 128, 56, 0), (128, 512, 28, 1), (512, 128, 28, 0),
+              (512, 256, 28, 0), (256, 1024, 14, 1), (1024, 256, 14, 0), (1024, 512, 14, 0), (512, 2048, 7, 1), (2048, 512, 7, 0)]
 dev = torch.device("cuda", 0)
 n = 128
-for cin, cout, hw in LAYERS:
+for layer in LAYERS:
+    cin, cout, hw = layer[:3]
+    res = torch.randn(n, cout, hw, hw, device=dev) if len(layer) > 3 and layer[3] else None
     torch.manual_seed(7)
     x = torch.relu(torch.randn(n, cin, hw, hw, device=dev))
     w = torch.randn(cout, cin, 1, 1, device=dev) * 0.1
@@ -24,6 +29,8 @@ for cin, cout, hw in LAYERS:
     out = []
     for form in (None, "stream", "sample", "split"):
         kw = dict(in_stat=stat, width=8, flags=0, cur_out=cur, bn_scale=sc, bn_shift=sh, act="relu")
+        if res is not None:
+            kw["residual"] = res
         if form:
             kw["form"] = form
         try:
@@ -40,4 +47,4 @@ for cin, cout, hw in LAYERS:
             out.append("%s %6.1f" % (form or "auto", sorted(a.elapsed_time(b) for a, b in ev)[15] * 1e3))
         except Exception:
             out.append("%s      -" % (form or "auto"))
-    print("%4d->%4d @%3d: " % (cin, cout, hw) + "   ".join(out) + "  us")
+    print("%4d->%4d @%3d%s: " % (cin, cout, hw, " +res" if res is not None else "     ") + "   ".join(out) + "  us")
