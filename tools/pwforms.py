@@ -16,6 +16,11 @@ if "--resnet" in sys.argv:          # resnet50_v1's 1x1 layers: (Cin, Cout, plan
               (512, 256, 28, 0), (256, 1024, 14, 1), (1024, 256, 14, 0), (1024, 512, 14, 0), (512, 2048, 7, 1), (2048, 512, 7, 0)]
 dev = torch.device("cuda", 0)
 n = 128
+if "--mobilenetv2" in sys.argv:     # mobilenetv2_1.0's 1x1 layers (expansion, projection with / without the unit's shortcut)
+    LAYERS = [(32, 32, 112, 0), (32, 16, 112, 0), (16, 96, 112, 0), (96, 24, 56, 0), (24, 144, 56, 0), (144, 24, 56, 1),
+              (144, 32, 28, 0), (32, 192, 28, 0), (192, 32, 28, 1), (192, 64, 14, 0), (64, 384, 14, 0), (384, 64, 14, 1),
+              (384, 96, 14, 0), (96, 576, 14, 0), (576, 96, 14, 1), (576, 160, 7, 0), (160, 960, 7, 0), (960, 160, 7, 1),
+              (960, 320, 7, 0), (320, 1280, 7, 0)]
 for layer in LAYERS:
     cin, cout, hw = layer[:3]
     res = torch.randn(n, cout, hw, hw, device=dev) if len(layer) > 3 and layer[3] else None
