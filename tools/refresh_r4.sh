@@ -49,4 +49,11 @@ BENCH_ARGS="--model resnet50_v1 --quant-type channel --streams 1 --graph 0" MIN_
 BENCH_ARGS="--model resnet50_v1 --quant-type channel --offline --streams 1 --graph 0" MIN_US=8 bash tools/kprof.sh "" > $O/${TAG}_kprof_resnet50_offline.txt 2>&1
 [ -f build_tools/libfakequant_trace.so ] && python3 tools/c3_trace.py > $O/${TAG}_c3_trace.txt 2>/dev/null
 [ -x build_tools/grid_barrier_probe ] && ./build_tools/grid_barrier_probe > $O/${TAG}_grid_barrier_probe.txt 2>&1
+# the round's last A/Bs (each alternates its two settings inside one call) and the form sweeps
+bash tools/thin_link_ab.sh > $O/${TAG}_unit_link_ab.txt 2>&1
+bash tools/thin_tiles_ab.sh > $O/${TAG}_thin_tiles_ab.txt 2>&1
+bash tools/thin_tiles_ab_r50.sh >> $O/${TAG}_thin_tiles_ab.txt 2>&1
+bash tools/res_split_ab.sh > $O/${TAG}_res_split_ab.txt 2>&1
+( python3 tools/pwforms.py; python3 tools/pwforms.py --resnet; python3 tools/pwforms.py --mobilenetv2 ) > $O/${TAG}_pwforms.txt 2>/dev/null
+python3 tools/stembench.py > $O/${TAG}_stembench.txt 2>/dev/null
 ls -la $O | head -80
