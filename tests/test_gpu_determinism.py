@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("tool,env", [("dw_determinism.py", {}), ("dw_determinism.py", {"FQ_DW_FLAT": "31"}),
-                                      ("pw_determinism.py", {})],
-                         ids=["depthwise", "depthwise-28x28s2-flat", "pointwise"])
+                                      ("pw_determinism.py", {}), ("dw16_determinism.py", {})],
+                         ids=["depthwise", "depthwise-28x28s2-flat", "pointwise", "depthwise-on-codes"])
 def test_full_size_repeats_are_bit_identical(tool, env):
     """50 repeats per shape, half of them beside a competing stream (tools/dw_determinism.py).  FQ_DW_FLAT=31 also sends
     28x28 stride 2 through the flat form - the instantiation whose irreproducibility led to the store-data hazard
