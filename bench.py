@@ -321,9 +321,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--min-block-s", type=float, default=0.5,
                     help="a timed block of --steps steps shorter than this is repeated (see --min-region-s)")
-    ap.add_argument("--min-region-s", type=float, default=1.0,
-                    help="total time to cover with repeated blocks when one block is shorter than --min-block-s")
-    ap.add_argument("--max-repeats", type=int, default=100)
+    ap.add_argument("--min-region-s", type=float, default=8.0,
+                    help="total time to cover with repeated blocks when one block is shorter than --min-block-s (8 s: long "
+                         "enough for a once-per-few-seconds utilisation sampler beside the run to see the GPU busy)")
+    ap.add_argument("--max-repeats", type=int, default=4000)
     ap.add_argument("--event-every", type=int, default=None,
                     help="bracket the library's kernels with HIP events in every n-th timed step (default 50 - calibration "
                          "phases, whose blocks are a dozen batches with a special first one: 7 -: 10 steps of the "
@@ -605,6 +606,7 @@ def main():
                 ops.profile_enable(False)
         barrier()
         dt = time.perf_counter() - t0
+        own_blocks.append(dt)
         if distributed:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             all_reduce(t, dist.ReduceOp.MAX)
@@ -614,11 +616,22 @@ def main():
     # A block shorter than MIN_BLOCK_S (the driver's `--steps 20` is 24 ms) is REPEATED — same steps, same warm-up, each
     # block bracketed as above — until MIN_REGION_S has been timed; `value` is then the median block.  Every rank takes
     # the same decision: it is made on the rank-maximum.
+    own_blocks = []
+    fqdist.collective_stats(reset=True)              # (what warm-up and set-up exchanged is not the timed region's)
     blocks = [timed_block(0)]
     if blocks[0] < args.min_block_s:
         while sum(blocks) < args.min_region_s and len(blocks) < args.max_repeats:
             blocks.append(timed_block(len(blocks) * args.steps))
     elapsed = float(np.median(blocks))
+    # what each rank's own clock says about the same blocks (the line's figures are the per-block MAXIMUM over ranks)
+    rank_ms = None
+    if distributed:
+        mine = torch.tensor([float(np.median(own_blocks)) / args.steps * 1e3], dtype=torch.float64, device=dev)
+        lo, hi = mine.clone(), mine.clone()
+        all_reduce(lo, dist.ReduceOp.MIN)
+        all_reduce(hi, dist.ReduceOp.MAX)
+        rank_ms = (float(lo.item()), float(hi.item()))
+    coll = fqdist.collective_stats()
     # the same steps on ONE stream (the figure of rounds 1-3), no kernel events: one block, reported beside `value`
     single_s = None
     if n_streams > 1:
@@ -693,18 +706,28 @@ def main():
                             "ms_per_step": round(ms_k / max(profiled_steps, 1), 4),
                             "ms_per_step_raw_events": round(ms_raw / max(profiled_steps, 1), 4)}
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
-        traffic, traffic_src = None, None
+        # `traffic` would be HBM bytes of THIS run's dominant kernel, which only a rocprofv3 --pmc pass around the process can
+        # give: this line never carries it (null).  What the committed PMC passes measured for the same command is quoted under
+        # its own key, with where it came from.
+        traffic_from_profiles = None
         default_workload = (args.model == "mobilenet1.0" and args.quant_type == "layer" and not args.offline
                             and args.weight_bits == 8 and args.input_bits == 8 and not args.no_fuse)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if dominant and default_workload and os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
-                traffic = rec.get("kernels", {}).get(dominant, {}).get("hbm_bytes_per_launch")
-                traffic_src = "NOT measured in this run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes around " \
-                              "this command, committed as profiles/pmc_traffic.json (%s)" % rec.get("source", "")
+                krec = rec.get("kernels", {}).get(dominant, {})
+                if krec.get("hbm_bytes_per_launch") is not None:
+                    traffic_from_profiles = {
+                        "kernel": dominant, "hbm_bytes_per_launch": krec["hbm_bytes_per_launch"],
+                        "read_bytes_per_launch": krec.get("read_bytes_per_launch"),
+                        "write_bytes_per_launch": krec.get("write_bytes_per_launch"),
+                        "source": rec.get("source", ""), "commit": rec.get("commit"), "box": rec.get("box"),
+                        "file": "profiles/pmc_traffic.json",
+                        "what": "NOT measured in this run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes around this "
+                                "command (tools/pmc_run.py), gfx950 corrections of MI355X_MICROARCH.md applied"}
             except Exception:
-                traffic = None
+                traffic_from_profiles = None
         dk = kernels.get(dominant, {"achieved": 0.0, "frac": 0.0, "frac_raw_events": 0.0, "kernel": None})
         whole = step_bytes / (ms_per_step * 1e-3) / 1e9 if step_bytes else 0.0
         flavour = "%s W%dA%d, %s input quant" % ({"layer": "per-layer", "group": "per-group", "channel": "per-channel"}
@@ -757,8 +780,10 @@ def main():
                                       "(tools/check_events_vs_rocprof.py, profiles/r4_events_vs_rocprof.txt); frac_raw_events keeps the "
                                       "event pairs' cost in (a lower bound; 11-15 % low inside a profiled process, 2-10 % otherwise)",
                          "frac_raw_events": dk["frac_raw_events"],
-                         "traffic": traffic, "traffic_is_stored_constant": traffic is not None,
-                         "traffic_source": traffic_src,
+                         "traffic": None, "traffic_from_profiles": traffic_from_profiles,
+                         "frac_method": "fixed since round 4 (events minus the measured pair cost); last validated against "
+                                        "profiles/r5_bench_kernel_stats.csv by tools/check_events_vs_rocprof.py "
+                                        "(profiles/r5_events_vs_rocprof.txt)",
                          "dominant_by": "largest HIP-event time per step among this library's kernels",
                          "event_sampling": "HIP events bracket every library launch in %d of the %d timed steps%s"
                                            % (profiled_steps, args.steps * len(blocks),
@@ -777,6 +802,17 @@ def main():
                                                 "ms_per_step (library convolutions and launch gaps included in the time)"},
                          "kernels": kernels},
             "repeats": len(blocks),
+            "ranks": {"world": world, "backend": backend if distributed else None,
+                      "rccl_world": (dist.get_world_size() if distributed and backend == "nccl" else None),
+                      "ms_per_step_min_over_ranks": None if rank_ms is None else round(rank_ms[0], 4),
+                      "ms_per_step_max_over_ranks": None if rank_ms is None else round(rank_ms[1], 4),
+                      "collectives_in_timed_region": coll,
+                      "collectives_per_step": {k: round(v["calls"] / float(args.steps * len(blocks)), 4) for k, v in coll.items()},
+                      "bytes_per_collective": {k: round(v["bytes"] / float(max(v["calls"], 1)), 1) for k, v in coll.items()},
+                      "what": "data-path collectives issued through quantization.mxnet_amd.dist between the first and the last "
+                              "timed step (the timing's own rank-maximum reductions and barriers are not in here): eval - none; "
+                              "calib-naive - one all-reduce of L + 1 doubles per step; calib-kl - one range broadcast + one "
+                              "histogram all-reduce per collection"},
             "consistency": {"timed_block_s": round(elapsed, 5), "timed_region_s": round(sum(blocks), 4),
                             "blocks": len(blocks),
                             "what": "each block = exactly --steps steps between barrier + synchronize; ms_per_step / "

@@ -399,6 +399,8 @@ class Simulation(object):
         self.signed = opt.input_signed == 'true'
         self.net = None
         self.last_result = None
+        self.data_source = 'unknown'
+        self.weights_source = 'unknown'
 
     # -- model ---------------------------------------------------------------------------------------------------------
     def build_net(self):
@@ -412,6 +414,9 @@ class Simulation(object):
         if opt.last_gamma:
             zoo_args['last_gamma'] = True
         self.net = get_model(opt.model, **zoo_args)
+        from quantization.mxnet_amd.mx.gluon.model_zoo import find_checkpoint
+        ckpt = pretrained if isinstance(pretrained, str) else (find_checkpoint(opt.model.lower()) if pretrained else None)
+        self.weights_source = ckpt if ckpt else 'seeded He-normal (no checkpoint found)'
         if opt.print_model:
             banner(opt.model, [repr(self.net)], self.chief)
 
@@ -460,9 +465,15 @@ class Simulation(object):
         shard = fqdist.shard_loader_kwargs()
         dataset = vision.ImageNet if opt.dataset == 'imagenet' else vision.CIFAR10
         needs_calibration_data = opt.quantize_input_offline and not opt.load_qparams
-        eval_set = dataset(train=False).transform_first(self._transform())
+        eval_raw = dataset(train=False)
+        eval_set = eval_raw.transform_first(self._transform())
+        self.data_source = eval_raw.source
         self.train_loader = None
         if opt.synthetic_on_device:
+            if eval_raw.source != 'synthetic':
+                raise SystemExit("--synthetic-on-device asks for generated batches but %s holds the dataset: drop the flag (or "
+                                 "point FQ_IMAGENET_ROOT / FQ_CIFAR10_ROOT elsewhere)" % eval_raw.source[5:])
+            self.data_source = 'synthetic (generated on the device)'
             side = 224 if opt.dataset == 'imagenet' else 32
             self.eval_loader = DeviceSyntheticLoader(len(eval_set), opt.batch_size, (3, side, side), self.classes,
                                                      self.ctx, 7, resident=opt.synthetic_resident, **shard)
@@ -544,6 +555,9 @@ class Simulation(object):
             print('{0: <8}: {1:2.2f}%'.format('acc', acc * 100))
             print('{0: <8}: {1:2.2f}%'.format('avg_acc', avg_acc * 100))
             print('{0: <8}: {1:.1f} images/sec on {2} GPU(s)'.format('speed', evaluate.last_images_per_sec, self.world))
+            # where the images and the weights came from: an accuracy on synthetic images / random weights means nothing
+            print('{0: <8}: {1}'.format('data', self.data_source))
+            print('{0: <8}: {1}'.format('weights', self.weights_source))
 
     def final_evaluation(self, online):
         self.net.fix_params()

@@ -30,7 +30,7 @@ struct PwCall {
   bool prezeroed;
   void* ws;
   hipStream_t st;
-  int form;                      // FQ_PW_FORM: 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample, 8 rows
+  int form;                      // FQ_PW_FORM: 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample, 8 rows, 9 pipe
   // C16 code tensors (fq_pwconv_i8_c16): x / y are [n][ceil(C/16)][pixels][16 codes] instead of fp32 NCHW
   bool in_c16 = false;
   const float* out_thr = nullptr;   // non-null: y is a C16 tensor holding the CONSUMER's codes for this threshold
@@ -53,6 +53,7 @@ int pw_try_split(const PwCall& c, bool* taken);     // K2m  fq_pw_split.hip
 int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t grid, size_t lds, const int8_t* wfrag,
                       bool* launched);
 int pw_try_sample(const PwCall& c, bool* taken);    // K2r  fq_pw_sample.hip (14x14 planes)
+int pw_try_pipe(const PwCall& c, bool* taken);      // K2w  fq_pw_pipe.hip (14x14 planes, K = 256 / 512: weights resident in registers)
 int pw_try_rows(const PwCall& c, bool* taken);      // K2t  fq_pw_rows.hip (planes of one pixel: the classifier)
 size_t pw_rows_eval_ws_bytes(int64_t n, int64_t cout);
 int pw_two_kernels(const PwCall& c);                // K2f  fq_pw_generic.hip (takes every shape)

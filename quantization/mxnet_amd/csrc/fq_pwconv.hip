@@ -82,6 +82,12 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   // range_taken != nullptr: range mode (fq_common.h: kRangeMode) - in_thr is a range record, bias holds int32 codes; only
   // the one-launch forms serve it and *range_taken says whether one took the shape
   const bool range = range_taken != nullptr;
+  if (range && x && (!aligned16(x) || !(hw < (1ll << 30) && n * hw < (1ll << 31) - 512))) {
+    // a legal input of the stand-alone block that the one-launch forms do not take (a batch slice of an odd-sized tensor, an
+    // oversized plane): not an error there - the exact direct kernel serves the layer
+    *range_taken = false;
+    return FQ_OK;
+  }
   FQ_REQUIRE(x && wcodes && wscale && wsum && y && (ws || range), "fq_pwconv_i8: null pointer");
   FQ_REQUIRE(n > 0 && cin > 0 && cout > 0 && hw > 0 && hw < (1ll << 30) && n * hw < (1ll << 31) - 512,
              "fq_pwconv_i8: bad shape");
@@ -123,10 +129,11 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
     c.out_zoff = (out_flags & FQ_ACT_SIGNED) ? 0 : 128;
   }
   c.eval_labels = eval_labels; c.eval_counters = eval_counters; c.eval_ws = eval_ws;
-  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample, 8 rows
+  static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample, 8 rows, 9 pipe
   c.form = (in_c16 || c.out_thr) ? 6 : (eval_labels ? 8 : (forced_form ? forced_form : pw_form));
-  FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6 || c.form == 7 || c.form == 8, "fq_pwconv_i8: unknown "
-             "form %d (1 two kernels, 3 stream, 6 split, 7 sample, 8 rows; the panel / chunk / tile forms 2, 4, 5 were retired "
+  FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6 || c.form == 7 || c.form == 8 || c.form == 9,
+             "fq_pwconv_i8: unknown "
+             "form %d (1 two kernels, 3 stream, 6 split, 7 sample, 8 rows, 9 pipe; the panel / chunk / tile forms 2, 4, 5 were retired "
              "in favour of the split form)", c.form);
   FQ_REQUIRE(stride == 1 || c.form == 0 || c.form == 6, "fq_pwconv_i8_strided: only the split form reads strided inputs");
   FQ_REQUIRE(residual == nullptr || c.form != 1, "fq_pwconv_i8_strided: the two-kernel form takes no residual operand");
@@ -144,6 +151,10 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   }
   FQ_REQUIRE(c.form != 8, "fq_pwconv_i8: the rows form takes planes of one pixel");
   if (!(in_c16 || out_thr)) {
+    if (int rc = pw_try_pipe(c, &taken)) return rc;
+    if (taken) return FQ_OK;
+    FQ_REQUIRE(c.form != 9, "fq_pwconv_i8: the pipe form takes stride 1, no residual, fp32 in and out, Cin = 256 or 512, Cout a "
+               "multiple of 512 and planes of a multiple of four pixels (16..1024)");
     if (int rc = pw_try_sample(c, &taken)) return rc;
     if (taken) return FQ_OK;
   } else if (out_thr && !in_c16) {                      // C16 output on the largest planes: the streaming form writes it too

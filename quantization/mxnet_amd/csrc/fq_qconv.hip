@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void qconv_direct_kernel(const float* __res
                                                               const float* __restrict__ bn_scale,
                                                               const float* __restrict__ bn_shift,
                                                               float* __restrict__ stat_out) {
-  if (only_if_flagged && !(__float_as_int(rec[kRecFlags]) & kFlagFixup)) return;
+  if (only_if_flagged && !((__float_as_int(rec[kRecFlags]) | __float_as_int(wrec[kRecFlags])) & kFlagFixup)) return;
   // this kernel keeps no per-sample statistic: a consumer that was promised one takes its range from the tensor instead
   if (stat_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stat_out[0] = -1.0f;
   const float xh = rec[kRecHi], xl = rec[kRecLo], xs = rec[kRecScale];
@@ -421,6 +421,31 @@ inline WLayout wlayout(int64_t cin, int64_t cout, int kh, int kw, int sh, int sw
 
 using namespace fqi;
 
+namespace {
+// Which quantiser a prepared-weights buffer was made with (host-side: the record itself lives on the device).  The fast
+// kernels multiply int8 codes of ONE symmetric grid: a buffer prepared with uint8 / fixed-range weights (codes that need not
+// fit int8: wrec carries kFlagFixup) must take the exact direct kernel whatever `force_direct` says, and a buffer this
+// process did not prepare (copied, or prepared through another handle) keeps the conditional fix-up launch behind the fast
+// kernel, which reads both records on the device.
+std::mutex g_wmode_mu;
+std::vector<std::pair<const void*, int>> g_wmode;
+void wmode_set(const void* wbuf, int mode) {
+  std::lock_guard<std::mutex> lk(g_wmode_mu);
+  for (auto& e : g_wmode)
+    if (e.first == wbuf) {
+      e.second = mode;
+      return;
+    }
+  g_wmode.emplace_back(wbuf, mode);
+}
+int wmode_get(const void* wbuf) {                                       // -1: unknown
+  std::lock_guard<std::mutex> lk(g_wmode_mu);
+  for (const auto& e : g_wmode)
+    if (e.first == wbuf) return e.second;
+  return -1;
+}
+}  // namespace
+
 extern "C" {
 
 size_t fq_qconv_weights_bytes(int64_t cin, int64_t cout, int kh, int kw, int sh, int sw, int ph, int pw, int groups) {
@@ -468,6 +493,7 @@ int fq_qconv_weights_prepare(const float* w, int64_t cin, int64_t cout, int kh, 
                        (float*)(base + L.off_codes));
   }
   FQ_LAUNCH_CHECK();
+  wmode_set(wbuf, weight_mode);
   return FQ_OK;
 }
 
@@ -517,7 +543,10 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
   s.wo = (int)((wdt + 2 * pw - kw) / sw + 1);
   const int64_t numel = n * cin * h * wdt, out_numel = n * cout * (int64_t)s.ho * s.wo;
   FQ_REQUIRE(numel < (1ll << 40) && out_numel < (1ll << 40), "fq_qconv2d_forward: tensor too large");
-  int kind = force_direct ? kKindDirect : L.kind;
+  const int wmode = wmode_get(wbuf);
+  // (asymmetric / fixed-range weight codes are not on the int8 grid the fast kernels multiply: the exact kernel, whatever
+  // the caller asked for)
+  int kind = (force_direct || (wmode != -1 && wmode != FQ_CODES_INT8)) ? kKindDirect : L.kind;
   // ---- 1. the input's range (unless given, or known from the producer's per-sample maxima) ----------------------------
   if (input_mode != FQ_CODES_RANGE && in_stat == nullptr) {
     ProfScope prof(FQ_KERNEL_GLOBAL_MAX, 4.0 * (double)numel, st);
@@ -558,8 +587,13 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
   // ---- 4. the exact direct form: the whole layer, or the conditional fix-up behind a fast kernel ------------------------------
   // (symmetric ranges and [0, max] ranges always fit a byte - L = 0 or codes within +-127 - so no fix-up can be asked for; the
   // per-sample statistic of the output is only offered there, where the fast kernel's result is final)
+  // The one flag such a record can still carry is the non-finite scale of an ALL-ZERO tensor (sc = 0: a dead ReLU), and there
+  // the fast kernels already produce the exact kernel's values - every code is 0 on both sides ((int) of the NaN quotient),
+  // the integer sums are the bias codes, the dequantisation factor is 0 (tests/test_gpu_qconv.py, all-zero inputs).  The
+  // shortcut needs weights KNOWN to be symmetric int8 (a buffer of unknown origin gets the conditional launch, which reads
+  // the weight record's flag too).
   const bool representable = input_mode == FQ_CODES_INT8 || (in_stat != nullptr && (ph > 0 || pw > 0));
-  if (fast && representable) return FQ_OK;
+  if (fast && representable && wmode == FQ_CODES_INT8) return FQ_OK;
   // (as a conditional fix-up - which a record of a [0, max] range with one zero in the tensor never asks for - the launch
   // returns at once: one workgroup per CU keeps that at ~2 us instead of the 4.6 us of 4096 workgroups; the recomputation
   // itself, when it does run, walks its outputs with that smaller grid)

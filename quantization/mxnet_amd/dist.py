@@ -104,8 +104,27 @@ def _not_while_capturing(t):
                            "calibration steps and the final counter all-reduce must run outside hipGraph capture")
 
 
+_COLLECTIVES = {}       # kind -> [calls, payload bytes]: what this module issued (bench.py reports it per step)
+
+
+def _note(kind, t):
+    rec = _COLLECTIVES.setdefault(kind, [0, 0])
+    rec[0] += 1
+    rec[1] += t.numel() * t.element_size()
+
+
+def collective_stats(reset=False):
+    """{kind: {"calls", "bytes"}} of the collectives issued through this module since the last reset - the data-path exchanges
+    of a calibration step / a KL collection / the final counter sum, for checking a multi-GPU line in one pass."""
+    out = {k: {"calls": v[0], "bytes": v[1]} for k, v in _COLLECTIVES.items()}
+    if reset:
+        _COLLECTIVES.clear()
+    return out
+
+
 def all_reduce(t, op=None):
     op = dist.ReduceOp.SUM if op is None else op
+    _note("all_reduce", t)
     if _via_host(t):
         h = t.detach().cpu()
         dist.all_reduce(h, op=op)
@@ -116,6 +135,7 @@ def all_reduce(t, op=None):
 
 
 def broadcast(t, src=0):
+    _note("broadcast", t)
     if _via_host(t):
         h = t.detach().cpu()
         dist.broadcast(h, src=src)
@@ -126,6 +146,7 @@ def broadcast(t, src=0):
 
 
 def all_gather_into(gathered, piece):
+    _note("all_gather", gathered)
     if _via_host(piece):
         h = torch.empty(gathered.shape, dtype=gathered.dtype)
         dist.all_gather_into_tensor(h, piece.detach().cpu())

@@ -165,11 +165,48 @@ class Block(object):
         self._forward_pre_hooks[self._hook_id] = hook
         return HookHandle(self._forward_pre_hooks, self._hook_id)
 
+    def _collect_params_with_prefix(self, prefix=""):
+        """{structural name: Parameter} - attribute paths joined by dots (`features.0.weight`, `output.bias`): the names
+        MXNet's `save_parameters` writes and the gluoncv model zoo's `.params` checkpoints carry."""
+        if prefix:
+            prefix += "."
+        ret = {prefix + key: val for key, val in self._reg_params.items()}
+        for name, child in self._children.items():
+            ret.update(child._collect_params_with_prefix(prefix + name))
+        return ret
+
     def save_parameters(self, filename):
-        self.collect_params().save(filename, strip_prefix=self.prefix)
+        """`*.npz`: an npz archive of the prefix-stripped full names (this package's own checkpoints: --save-qparams); any
+        other name: MXNet's NDArray-list format with structural names, as `mxnet.gluon.Block.save_parameters` writes it."""
+        if str(filename).endswith(".npz"):
+            self.collect_params().save(filename, strip_prefix=self.prefix)
+            return
+        from .. import ndarray_file
+        ndarray_file.save(filename, {k: p.data().asnumpy() for k, p in self._collect_params_with_prefix().items()})
 
     def load_parameters(self, filename, ctx=None, allow_missing=False, ignore_extra=False):
-        self.collect_params().load(filename, ctx, allow_missing, ignore_extra, restore_prefix=self.prefix)
+        """mxnet.gluon.Block.load_parameters: structural names (`features.0.weight`: files written by `save_parameters`, the
+        model zoo's checkpoints) when any name holds a dot, else the legacy full-name form through `collect_params().load`."""
+        from .parameter import read_parameter_file
+        loaded = read_parameter_file(filename)
+        params = self._collect_params_with_prefix()
+        if not loaded and not params:
+            return
+        if not any("." in k for k in loaded):
+            self.collect_params().load(filename, ctx, allow_missing, ignore_extra, restore_prefix=self.prefix)
+            return
+        if not allow_missing:
+            for name in params:
+                assert name in loaded, "Parameter '%s' is missing in file '%s', which contains parameters: %s. Set " \
+                    "allow_missing=True to ignore missing parameters." % (name, filename, ", ".join(sorted(loaded)[:8]) + " ...")
+        for name, arr in loaded.items():
+            if name not in params:
+                if not ignore_extra:
+                    raise ValueError("Parameter '%s' loaded from file '%s' is not present in the Block, which contains "
+                                     "parameters %s. Set ignore_extra=True to ignore." %
+                                     (name, filename, ", ".join(sorted(params)[:8]) + " ..."))
+                continue
+            params[name]._load_init(arr, ctx)
 
     def __call__(self, *args):
         # torch's grad mode follows mx.autograd's recording flag: outside `autograd.record()` no graph is ever built

@@ -1,10 +1,11 @@
 """`gluon.data` surface of the CLI (examples/simulate_quantization.py:24-30,151-175,257-292): `Sampler`, `DataLoader`,
 `vision.transforms`, and ImageNet / CIFAR10 datasets.
 
-No dataset can be downloaded here; when `root` holds no data the vision datasets are SYNTHETIC: deterministic
-uint8 images of the final crop size (seeded per index) with uniformly cycling labels, so the evaluation and
-calibration loops, the `UniformSampler`, and rank-sharding run end to end.  Accuracy on them is meaningless and
-the CLI says so.
+ImageNet (gluoncv's ImageFolder layout) and CIFAR-10 (MXNet's binary batches or the python pickles) are read from disk
+when their root holds them.  No dataset can be downloaded here; when the root holds no data the vision datasets are
+SYNTHETIC: deterministic uint8 images of the final crop size (seeded per index) with uniformly cycling labels, so the
+evaluation and calibration loops, the `UniformSampler`, and rank-sharding run end to end.  Accuracy on them is
+meaningless; every dataset says where its images came from (`source`) and the CLI prints it.
 """
 import os
 
@@ -156,8 +157,16 @@ def _batchify(items):
     return NDArray(torch.from_numpy(arr))
 
 
+def _base_dataset(ds):
+    """The dataset under `transform` / `transform_first` wrappers."""
+    while isinstance(ds, _LazyTransformDataset):
+        ds = ds._data
+    return ds
+
+
 class DataLoader(object):
-    """Synchronous loader (`num_workers` accepted and ignored: synthetic data costs nothing to produce).
+    """Loader in the calling process; `num_workers` threads decode a batch's image files side by side when the dataset is
+    read from disk (synthetic data costs nothing to produce: no threads).
 
     `rank`/`world_size` (new; the reference is single-device) stride the batch LIST across one-process-per-GPU
     ranks: every rank draws the identical sampler sequence (same numpy seed), then keeps batches i with
@@ -178,12 +187,27 @@ class DataLoader(object):
         self._batch_sampler = batch_sampler
         self._batchify_fn = batchify_fn or _batchify
         self._rank, self._world = rank, world_size
+        # worker threads only where an item costs something to make (files on disk); synthetic items are seeded arrays
+        self._workers = int(num_workers) if getattr(_base_dataset(dataset), "source", "synthetic") != "synthetic" else 0
 
     def __iter__(self):
-        for i, batch in enumerate(self._batch_sampler):
-            if i % self._world != self._rank:
-                continue
-            yield self._batchify_fn([self._dataset[int(idx)] for idx in batch])
+        pool = None
+        if self._workers > 0:
+            # decoding an image file releases the interpreter lock (PIL): `num_workers` threads fetch a batch's items side by side
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=self._workers)
+        try:
+            for i, batch in enumerate(self._batch_sampler):
+                if i % self._world != self._rank:
+                    continue
+                if pool is not None:
+                    items = list(pool.map(lambda idx: self._dataset[int(idx)], batch))
+                else:
+                    items = [self._dataset[int(idx)] for idx in batch]
+                yield self._batchify_fn(items)
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
 
     def __len__(self):
         n = len(self._batch_sampler)
@@ -299,28 +323,158 @@ def _synthetic_count(train, classes, default_per_class):
     return default_per_class * classes if train else None
 
 
-class _ImageNet(_SyntheticImages):
-    """gluoncv.data.ImageNet stand-in: 1000 classes, 224x224 (already at crop size)."""
+def _datasets_dir(name, root=None, env=None):
+    """`root`, else $<env>, else MXNet's `~/.mxnet/datasets/<name>` ($MXNET_HOME/datasets/<name> when that is set, as
+    `mxnet.base.data_dir()` has it)."""
+    if root is None:
+        root = os.environ.get(env) if env else None
+    if root is None:
+        root = os.path.join(os.environ.get("MXNET_HOME", os.path.join("~", ".mxnet")), "datasets", name)
+    return os.path.expanduser(root)
 
-    def __init__(self, root="~/.mxnet/datasets/imagenet", train=True, transform=None):
-        n = _synthetic_count(train, 1000, 6) or 2048
-        super(_ImageNet, self).__init__(n, 1000, 224, 7 if train else 77)
-        print("[data] ImageNet not available (no network / no %s): %d synthetic %s images"
-              % (root, n, "train" if train else "val"))
+
+def _decode_image(path):
+    """An image file as an (H, W, 3) uint8 array, RGB - what `mx.image.imread(path, flag=1)` hands the transforms."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.array(im.convert("RGB"), dtype=np.uint8)          # (a writable copy)
 
 
-class _CIFAR10(_SyntheticImages):
-    def __init__(self, root="~/.mxnet/datasets/cifar10", train=True, transform=None):
-        n = _synthetic_count(train, 10, 100) or 2000
-        super(_CIFAR10, self).__init__(n, 10, 32, 11 if train else 111)
-        print("[data] CIFAR10 not available (no network / no %s): %d synthetic %s images"
-              % (root, n, "train" if train else "val"))
+class ImageFolderDataset(Dataset):
+    """`mxnet.gluon.data.vision.ImageFolderDataset`: `root/<category>/<image>`; categories are the sorted sub-directories
+    (`synsets`), `items` the sorted (path, label) list; an item is (H x W x 3 uint8 NDArray, label)."""
+    _exts = (".jpg", ".jpeg", ".png")
+
+    def __init__(self, root, flag=1, transform=None):
+        self._root = os.path.expanduser(root)
+        self._flag = flag
+        self._transform = transform
+        self.synsets, self.items = [], []
+        for folder in sorted(os.listdir(self._root)):
+            path = os.path.join(self._root, folder)
+            if not os.path.isdir(path):
+                continue
+            label = len(self.synsets)
+            self.synsets.append(folder)
+            for filename in sorted(os.listdir(path)):
+                if os.path.splitext(filename)[1].lower() in self._exts:
+                    self.items.append((os.path.join(path, filename), label))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, idx):
+        img = NDArray(torch.from_numpy(_decode_image(self.items[idx][0])))
+        label = self.items[idx][1]
+        if self._transform is not None:
+            return self._transform(img, label)
+        return img, label
+
+
+def _has_class_dirs(path):
+    try:
+        return any(os.path.isdir(os.path.join(path, d)) for d in os.listdir(path))
+    except OSError:
+        return False
+
+
+class _ImageNet(Dataset):
+    """`gluoncv.data.ImageNet(root='~/.mxnet/datasets/imagenet', train=True, transform=None)` (reference
+    examples/simulate_quantization.py:272-279): the ImageFolder layout gluoncv's set-up script leaves - `root/train/<wnid>/*.JPEG`,
+    `root/val/<wnid>/*.JPEG` - read from disk when that split exists (root: the argument, $FQ_IMAGENET_ROOT, or MXNet's
+    default).  Without it: SYNTHETIC images of the crop size (there is no network to fetch the dataset) - `source` says which,
+    and the CLI prints it beside every result."""
+
+    def __init__(self, root=None, train=True, transform=None):
+        base = _datasets_dir("imagenet", root, "FQ_IMAGENET_ROOT")
+        split = os.path.join(base, "train" if train else "val")
+        if _has_class_dirs(split):
+            self._impl = ImageFolderDataset(split, 1, transform)
+            self.source = "disk:" + split
+            print("[data] ImageNet %s: %d images in %d classes from %s"
+                  % ("train" if train else "val", len(self._impl), len(self._impl.synsets), split))
+        else:
+            n = _synthetic_count(train, 1000, 6) or 2048
+            self._impl = _SyntheticImages(n, 1000, 224, 7 if train else 77)
+            self.source = "synthetic"
+            print("[data] ImageNet not available (no network / no %s): %d synthetic %s images"
+                  % (split, n, "train" if train else "val"))
+        self.items, self.synsets = self._impl.items, self._impl.synsets
+
+    def __len__(self):
+        return len(self._impl)
+
+    def __getitem__(self, idx):
+        return self._impl[idx]
+
+
+def _cifar10_files(base, train):
+    """The batch files of one split, as (kind, [paths]): MXNet's binary records (`data_batch_1..5.bin` / `test_batch.bin`, in
+    the root or in `cifar-10-batches-bin/`) or the python pickles of `cifar-10-batches-py/`; None when neither is complete."""
+    names = ["data_batch_%d" % i for i in range(1, 6)] if train else ["test_batch"]
+    for sub, ext, kind in (("", ".bin", "bin"), ("cifar-10-batches-bin", ".bin", "bin"), ("cifar-10-batches-py", "", "py"),
+                           ("", "", "py")):
+        paths = [os.path.join(base, sub, nme + ext) for nme in names]
+        if all(os.path.isfile(q) for q in paths):
+            return kind, paths
+    return None
+
+
+def _read_cifar_batch(kind, path):
+    if kind == "bin":           # mxnet/gluon/data/vision/datasets.py CIFAR10._read_batch: 1 label byte + 3 x 32 x 32 bytes, CHW
+        rec = np.fromfile(path, dtype=np.uint8).reshape(-1, 3072 + 1)
+        return rec[:, 1:].reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1), rec[:, 0].astype(np.int32)
+    import pickle
+    with open(path, "rb") as f:
+        d = pickle.load(f, encoding="bytes")
+    data = np.asarray(d[b"data"], dtype=np.uint8).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1)
+    return data, np.asarray(d[b"labels"], dtype=np.int32)
+
+
+class _CIFAR10(Dataset):
+    """`mxnet.gluon.data.vision.CIFAR10(root='~/.mxnet/datasets/cifar10', train=True, transform=None)`: the batch files read
+    from disk when they are there (root: the argument, $FQ_CIFAR10_ROOT, or MXNet's default) into `_data` (N x 32 x 32 x 3
+    uint8) and `_label` (int32; the reference's UniformSampler reads it, simulate_quantization.py:281); synthetic otherwise."""
+
+    def __init__(self, root=None, train=True, transform=None):
+        base = _datasets_dir("cifar10", root, "FQ_CIFAR10_ROOT")
+        found = _cifar10_files(base, train)
+        self._transform = transform
+        if found is not None:
+            parts = [_read_cifar_batch(found[0], q) for q in found[1]]
+            self._data = NDArray(torch.from_numpy(np.ascontiguousarray(np.concatenate([a for a, _ in parts]))))
+            self._label = np.concatenate([l for _, l in parts])
+            self._impl = None
+            self.source = "disk:" + os.path.dirname(found[1][0])
+            print("[data] CIFAR10 %s: %d images from %s" % ("train" if train else "test", len(self._label), self.source[5:]))
+        else:
+            n = _synthetic_count(train, 10, 100) or 2000
+            self._impl = _SyntheticImages(n, 10, 32, 11 if train else 111)
+            self._label = self._impl._label
+            self.source = "synthetic"
+            print("[data] CIFAR10 not available (no network / no batch files under %s): %d synthetic %s images"
+                  % (base, n, "train" if train else "val"))
+        self.items = _Items(self._label)
+        self.synsets = ["airplane", "automobile", "bird", "cat", "deer", "dog", "frog", "horse", "ship", "truck"]
+
+    def __len__(self):
+        return len(self._label)
+
+    def __getitem__(self, idx):
+        if self._impl is not None:
+            item = self._impl[idx]
+        else:
+            item = (NDArray(self._data._t[idx]), int(self._label[idx]))
+        if self._transform is not None:
+            return self._transform(*item)
+        return item
 
 
 class _Vision(object):
     transforms = _Transforms
     ImageNet = _ImageNet
     CIFAR10 = _CIFAR10
+    ImageFolderDataset = ImageFolderDataset
 
 
 vision = _Vision

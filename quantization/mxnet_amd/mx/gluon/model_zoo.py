@@ -249,6 +249,25 @@ for _n, (_b, _l, _c) in _RESNET_SPEC.items():
     _MODELS["resnet%d_v1" % _n] = (lambda b, l, c: (lambda **kw: ResNetV1(b, l, c, **kw)))(_b, _l, _c)
 
 
+def _models_dir(root=None):
+    """`~/.mxnet/models` ($MXNET_HOME/models when that is set, as MXNet's `base.data_dir()` has it)."""
+    return os.path.expanduser(root or os.path.join(os.environ.get("MXNET_HOME", os.path.join("~", ".mxnet")), "models"))
+
+
+def find_checkpoint(name, root=None):
+    """The parameter file `get_model(name, pretrained=True)` would use: gluoncv's `<name>-<hash>.params` (its
+    `model_store.get_model_file` naming, MXNet NDArray-list format), a plain `<name>.params`, or this package's
+    `<name>.params.npz` - the first that exists under `root` (default `~/.mxnet/models`); None when there is none."""
+    import glob
+    d = _models_dir(root)
+    cands = sorted(glob.glob(os.path.join(d, glob.escape(name) + "-*.params"))) + \
+        [os.path.join(d, name + ".params"), os.path.join(d, name + ".params.npz")]
+    for c in cands:
+        if os.path.isfile(c):
+            return c
+    return None
+
+
 def get_model_list():
     return list(_MODELS.keys())
 
@@ -256,9 +275,10 @@ def get_model_list():
 def get_model(name, pretrained=False, classes=None, ctx=None, root=None, **kwargs):
     """gluoncv.model_zoo.get_model(name, pretrained=True, classes=...) (examples/simulate_quantization.py:188-204).
 
-    `pretrained` may be a path to a parameter file written by `net.save_parameters`; `True` looks for
-    `<root or ~/.mxnet/models>/<name>.params.npz` and otherwise falls back to seeded He-normal weights with a
-    notice (there is no network to fetch gluoncv's checkpoints).
+    `pretrained` may be a path to a parameter file (MXNet's `.params` NDArray-list format with gluoncv's structural names, or
+    this package's npz); `True` looks under `<root or ~/.mxnet/models>` for gluoncv's `<name>-<hash>.params`, `<name>.params`
+    or `<name>.params.npz` (`find_checkpoint`) and otherwise falls back to seeded He-normal weights with a notice (there is no
+    network to fetch gluoncv's checkpoints).
     """
     name = name.lower()
     if name not in _MODELS:
@@ -276,10 +296,12 @@ def get_model(name, pretrained=False, classes=None, ctx=None, root=None, **kwarg
     if isinstance(pretrained, str):
         path = pretrained
     elif pretrained:
-        cand = os.path.join(os.path.expanduser(root or "~/.mxnet/models"), name + ".params.npz")
-        path = cand if os.path.exists(cand) else None
+        path = find_checkpoint(name, root)
         if path is None:
-            print("[model_zoo] no checkpoint for %s (no network): using seeded He-normal weights" % name)
+            print("[model_zoo] no checkpoint for %s under %s (no network): using seeded He-normal weights"
+                  % (name, _models_dir(root)))
+        else:
+            print("[model_zoo] %s: parameters from %s" % (name, path))
     if path is not None:
         net.load_parameters(path, ctx=ctx)
     return net

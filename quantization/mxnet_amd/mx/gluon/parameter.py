@@ -112,6 +112,20 @@ class Parameter(object):
         with torch.no_grad():
             self._data._t.copy_(data._t)
 
+    def _load_init(self, arr, ctx=None):
+        """A value read from a parameter file: initialises a deferred Parameter with it, or overwrites the data in place."""
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        if self._data is None:
+            if self._deferred is None:
+                self._deferred = (_init.Zero(), ctx or cpu())
+            self.shape = tuple(arr.shape)
+            self._finish_init(_init.Constant(arr), self._deferred[1] if ctx is None else ctx)
+        else:
+            assert tuple(arr.shape) == tuple(self._data.shape), \
+                "Failed loading Parameter '%s' from saved params: shape incompatible expected %s vs saved %s" \
+                % (self.name, tuple(self._data.shape), tuple(arr.shape))
+            self.set_data(NDArray(torch.from_numpy(arr)))
+
     def reset_ctx(self, ctx):
         if isinstance(ctx, (list, tuple)):
             ctx = ctx[0]
@@ -148,6 +162,16 @@ class Parameter(object):
 
     def cast(self, dtype):
         self.dtype = dtype
+
+
+def read_parameter_file(filename):
+    """{name: numpy array} of a parameter file: an npz archive (what this package writes for `*.npz` names) or MXNet's
+    NDArray-list format (`.params`: mx/ndarray_file.py), `arg:` / `aux:` prefixes stripped."""
+    from .. import ndarray_file
+    if ndarray_file.is_ndarray_file(filename):
+        return ndarray_file.load_params(filename)
+    with np.load(filename) as z:
+        return {k: z[k] for k in z.files}
 
 
 class ParameterDict(object):
@@ -241,8 +265,9 @@ class ParameterDict(object):
             np.savez(f, **out)
 
     def load(self, filename, ctx=None, allow_missing=False, ignore_extra=False, restore_prefix=""):
-        with np.load(filename) as z:
-            loaded = {restore_prefix + k: z[k] for k in z.files}
+        """Full-name files: the npz this package writes, or an MXNet NDArray-list file (`collect_params().save`, the legacy
+        `save_params`, exported `arg:` / `aux:` checkpoints) - told apart by their first bytes."""
+        loaded = {restore_prefix + k: v for k, v in read_parameter_file(filename).items()}
         if not allow_missing:
             for name in self.keys():
                 assert name in loaded, "Parameter %s is missing in file %s" % (name, filename)
@@ -250,14 +275,7 @@ class ParameterDict(object):
             if name not in self._params:
                 assert ignore_extra, "Parameter %s loaded from file %s is not present in ParameterDict" % (name, filename)
                 continue
-            p = self._params[name]
-            if p._data is None:
-                if p._deferred is None:
-                    p._deferred = (_init.Zero(), ctx or cpu())
-                p.shape = tuple(arr.shape)
-                p._finish_init(_init.Constant(arr), p._deferred[1] if ctx is None else ctx)
-            else:
-                p.set_data(NDArray(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))))
+            self._params[name]._load_init(arr, ctx)
 
     def select(self, pattern):
         """`collect_params(select)` filter: regex matched against the full name (Gluon uses re.match)."""

@@ -42,8 +42,12 @@ class Trainer(object):
         # capturable: the step counter and Adam's bias-corrected rate live on the device and are advanced by device
         # operations inside `step`, so that a whole training step (forward + backward + step) can be captured into a
         # hipGraph and replayed (examples/qat_finetune.py --graph): a replay runs no Python, a host-side `t` would stay frozen
+        # The learning rate is a device scalar too (`set_learning_rate` fills it in place): a replay reads it, so a schedule
+        # keeps working after capture.  One step counter serves every parameter, which is only MXNet's per-parameter `t` when
+        # every parameter takes part in every step - `step` checks that.
         self._capturable = bool(op_capturable)
         self._dev_t = None
+        self._dev_lr = None
 
     @property
     def learning_rate(self):
@@ -51,6 +55,16 @@ class Trainer(object):
 
     def set_learning_rate(self, lr):
         self._lr = float(lr)
+        if self._dev_lr is not None:
+            self._dev_lr.fill_(self._lr)           # in place: captured steps hold this tensor's address
+
+    def _lr_operand(self, like):
+        """The rate `step` multiplies by: the Python float, or (capturable) a device scalar that replays re-read."""
+        if not self._capturable:
+            return self._lr
+        if self._dev_lr is None:
+            self._dev_lr = torch.full((), self._lr, dtype=torch.float64, device=like.device)
+        return self._dev_lr
 
     def step(self, batch_size, ignore_stale_grad=False):
         """One update of every Parameter that received a gradient.  The arithmetic is the per-parameter rule of the module
@@ -70,6 +84,10 @@ class Trainer(object):
             live.append((p, w))
         if not live:
             return
+        if self._capturable and len(live) != sum(1 for p in self._params if p._data is not None):
+            raise RuntimeError("Trainer(capturable=True): every parameter must receive a gradient on every step (one device "
+                               "step counter serves them all); %d of %d did" %
+                               (len(live), sum(1 for p in self._params if p._data is not None)))
         with torch.no_grad():
             ws = [w for _, w in live]
             gs = torch._foreach_mul([w.grad for w in ws], rescale)                   # g' = rescale * g
@@ -77,7 +95,9 @@ class Trainer(object):
                 gs = [g.clamp_(-float(self._clip), float(self._clip)) for g in gs]
             if self._wd:
                 torch._foreach_add_(gs, torch._foreach_mul(ws, self._wd))            # + wd * w
+            lr = self._lr_operand(ws[0])
             if self._opt == "sgd":
+                lr32 = lr.to(torch.float32) if self._capturable else lr                # fp32(lr), as the scalar overload rounds it
                 if self._momentum:
                     moms = []
                     for p, w in live:
@@ -86,10 +106,10 @@ class Trainer(object):
                             mom = self._state[id(p)] = torch.zeros_like(w)
                         moms.append(mom)
                     torch._foreach_mul_(moms, self._momentum)
-                    torch._foreach_sub_(moms, torch._foreach_mul(gs, self._lr))      # mom = momentum * mom - lr * g'
+                    torch._foreach_sub_(moms, torch._foreach_mul(gs, lr32))          # mom = momentum * mom - lr * g'
                     torch._foreach_add_(ws, moms)
                 else:
-                    torch._foreach_sub_(ws, torch._foreach_mul(gs, self._lr))
+                    torch._foreach_sub_(ws, torch._foreach_mul(gs, lr32))
             else:
                 ms, vs, by_t = [], [], {}
                 for i, (p, w) in enumerate(live):
@@ -114,7 +134,7 @@ class Trainer(object):
                     self._dev_t += 1.0
                     b1 = torch.full_like(self._dev_t, self._beta1)
                     b2 = torch.full_like(self._dev_t, self._beta2)
-                    lr_t = (self._lr * torch.sqrt(1.0 - torch.pow(b2, self._dev_t)) /
+                    lr_t = (lr * torch.sqrt(1.0 - torch.pow(b2, self._dev_t)) /
                             (1.0 - torch.pow(b1, self._dev_t))).to(torch.float32)
                     num = torch._foreach_mul(ms, lr_t)
                     torch._foreach_div_(num, den)

@@ -22,6 +22,7 @@ here to MXNet's documented behaviour:
   multiply and add (no FMA), so Winograd transforms are reproducible bit-for-bit.
 """
 import numbers
+import struct
 
 import numpy as np
 import torch
@@ -32,7 +33,7 @@ from .context import Context, cpu
 __all__ = ["NDArray", "array", "zeros", "ones", "zeros_like", "ones_like", "uniform", "normal", "dot",
            "concat", "stack", "split", "max", "min", "abs", "sqrt", "round", "cast", "clip", "relu",
            "Convolution", "FullyConnected", "Activation", "BatchNorm", "Pooling", "Flatten", "pad",
-           "argmax", "sum", "mean", "waitall", "arange", "broadcast_div"]
+           "argmax", "sum", "mean", "waitall", "arange", "broadcast_div", "save", "load"]
 
 _DTYPES = {
     "float32": torch.float32, "float64": torch.float64, "float16": torch.float16,
@@ -330,7 +331,8 @@ def _unwrap_key(key):
     return key
 
 
-_scalars = {}          # (device, dtype, value) -> 0-dim tensor: read-only operands, made once
+_scalars = {}          # (device, dtype, bits of the value) -> 0-dim tensor: read-only operands, made once
+_SCALARS_MAX = 4096
 
 
 def _operand(o, like):
@@ -344,12 +346,17 @@ def _operand(o, like):
         return o
     if isinstance(o, (numbers.Number, np.generic)):
         if like.dtype.is_floating_point:
-            key = (like.device, like.dtype, float(o))
+            # keyed by the BIT PATTERN (0.0 / -0.0 and the NaNs are different operands: x / -0.0, x * -0.0)
+            key = (like.device, like.dtype, struct.pack("<d", float(o)))
             t = _scalars.get(key)
             if t is None:
-                if len(_scalars) > 4096:
-                    _scalars.clear()
-                t = _scalars[key] = torch.full((), float(o), dtype=like.dtype, device=like.device)
+                t = torch.full((), float(o), dtype=like.dtype, device=like.device)
+                # an entry is NEVER dropped: a hipGraph captured earlier may hold its address (update_ema's 0.9 / 0.1, a QAT
+                # step), and memory the allocator recycled would make every replay read another constant without an error.
+                # A run that keeps producing new scalars (a decaying lr, a loss scale) gets uncached tensors once the table is
+                # full - correct, only slower.
+                if len(_scalars) < _SCALARS_MAX:
+                    _scalars[key] = t
             return t
         return o
     if isinstance(o, np.ndarray):
@@ -623,3 +630,20 @@ def Pooling(data, kernel=(1, 1), pool_type="max", global_pool=False, stride=None
 def waitall():
     if torch.cuda.is_available():
         torch.cuda.synchronize()
+
+
+# -- files -------------------------------------------------------------------------------------
+def save(fname, data):
+    """`mx.nd.save`: a list or a {name: NDArray} dict in MXNet's NDArray-list format (mx/ndarray_file.py)."""
+    from . import ndarray_file
+    if isinstance(data, NDArray):
+        data = [data]
+    ndarray_file.save(fname, data)
+
+
+def load(fname):
+    """`mx.nd.load`: the list or {name: NDArray} dict of an NDArray-list file (on the CPU, as MXNet loads them)."""
+    from . import ndarray_file
+    out = ndarray_file.load(fname)
+    wrap = lambda a: None if a is None else NDArray(torch.from_numpy(a))
+    return {k: wrap(v) for k, v in out.items()} if isinstance(out, dict) else [wrap(a) for a in out]

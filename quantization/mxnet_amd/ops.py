@@ -660,7 +660,7 @@ class Codes16(object):
             (self.flags & 3) == (int(flags) & 3)
 
 
-PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6, "sample": 7, "rows": 8}
+PW_FORMS = {None: 0, "auto": 0, "two_kernels": 1, "stream": 3, "split": 6, "sample": 7, "rows": 8, "pipe": 9}
 
 
 SPLIT_KT = (2, 4, 6, 8, 10, 12, 16, 18, 30, 32, 64)     # padded Cin / 32 the split form of fq_pwconv_i8 is built for
@@ -991,8 +991,18 @@ def comm_destroy():
     check_call(_lib_().fq_comm_destroy())
 
 
+_STATE_EPOCH = [0]
+
+
+def state_epoch():
+    """Counts the library's own in-place updates of calibration state (they go through raw pointers, so the tensor library's
+    version counters do not see them): host-side memos about threshold VALUES key on it (quantize/convert/convert_conv2d.py)."""
+    return _STATE_EPOCH[0]
+
+
 def ema_update(state, current, momentum=0.9):
     """`_update_ema` (convert.py:66-79) over a contiguous vector of per-block scalars, in place on `state`."""
+    _STATE_EPOCH[0] += 1
     _check(state, "state")
     _check(current, "current")
     if state.numel() != current.numel():

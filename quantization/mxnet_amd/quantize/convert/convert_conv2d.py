@@ -281,7 +281,8 @@ def _same_quantiser(block, other, plan, codes):
     tb = tb.data()._t
     if tb.data_ptr() != codes.thr.data_ptr():
         return False
-    key = (ta.data_ptr(), ta._version, tb.data_ptr(), tb._version)
+    # (`ops.state_epoch()`: update_ema writes the thresholds through raw pointers, which no version counter sees)
+    key = (ta.data_ptr(), ta._version, tb.data_ptr(), tb._version, ops.state_epoch())
     memo = block.__dict__.get("_fq_same_thr")
     if memo is None or memo[0] != key:
         if ta.is_cuda and torch.cuda.is_current_stream_capturing():

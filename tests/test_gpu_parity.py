@@ -511,6 +511,12 @@ FORM_CASES = [
     # ... whole small planes in two pixel tiles: 7x7 (49 pixels: the last one has a load of its own) and 8x8, K/32 = 16 and 32
     ("sample", (5, 512, 1024, 7, 7)), ("sample", (3, 1024, 1024, 7, 7)), ("sample", (2, 512, 256, 8, 8)),
     ("sample", (9, 1024, 512, 7, 7)), ("sample", (3, 1024, 256, 14, 14)),
+    # pipe (round 5: weights resident in registers, sub-tiles of <= 7 / 8 pixel groups through LDS-DMA): K = 512 and 256; 14x14
+    # in two blocks of 25 + 24 groups (four sub-tiles each), two channel groups, XCD shares left ragged by the sample count,
+    # one block of 25 groups (10x10), three blocks of 32 (16x24), a single sub-tile (4x4), two sub-tiles of 5 + 4 (6x6)
+    ("pipe", (3, 512, 512, 14, 14)), ("pipe", (9, 256, 512, 14, 14)), ("pipe", (17, 256, 1024, 14, 14)),
+    ("pipe", (2, 512, 1024, 10, 10)), ("pipe", (2, 256, 512, 16, 24)), ("pipe", (2, 512, 512, 4, 4)),
+    ("pipe", (5, 512, 512, 6, 6)), ("pipe", (2, 512, 512, 28, 28)),
     # rows (planes of one pixel = the classifier): the model zoo's heads at batch 128, a partial sample tile, a partial unit
     # tile with padded K (100 -> 128), K in two rounds of slabs (2048), fewer slabs than wavefronts (64)
     ("rows", (128, 1024, 1000, 1, 1)), ("rows", (70, 512, 512, 1, 1)), ("rows", (33, 100, 37, 1, 1)),

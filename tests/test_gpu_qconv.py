@@ -288,3 +288,66 @@ def test_bad_arguments_fail_loudly(dev, ops):
     from quantization.mxnet_amd._lib import FakeQuantError
     with pytest.raises(FakeQuantError):
         ops.qconv2d(x.cpu(), w, wbuf, None, (1, 1), (1, 1), 1, ws)
+
+
+# ---- records that carry the fix-up flag behind the fast kernels ----------------------------------------------------
+@pytest.mark.parametrize("geom", ["pw", "c3", "dw"])
+def test_all_zero_input_fast_kernels_equal_the_exact_kernel(dev, ops, geom):
+    """A dead-ReLU tensor gives scale 0 (the record is flagged non-finite).  With an int8 input, or the producer's statistic
+    on a padded layer, the conditional fix-up launch is skipped - the fast kernels' values must then BE the exact kernel's
+    (every code is (int)NaN = 0 on both sides, the dequantisation factor is 0)."""
+    rng = np.random.default_rng(11)
+    n, c = 3, 64
+    if geom == "pw":
+        w, stride, pad, groups = rng.standard_normal((128, c, 1, 1)).astype(np.float32), (1, 1), (0, 0), 1
+    elif geom == "c3":
+        w, stride, pad, groups = rng.standard_normal((64, c, 3, 3)).astype(np.float32), (1, 1), (1, 1), 1
+    else:
+        w, stride, pad, groups = rng.standard_normal((c, 1, 3, 3)).astype(np.float32), (1, 1), (1, 1), c
+    x = np.zeros((n, c, 14, 14), np.float32)
+    bsc = rng.uniform(0.5, 1.5, w.shape[0]).astype(np.float32)
+    bsh = rng.standard_normal(w.shape[0]).astype(np.float32)
+    for kw in (dict(input_dtype="int8"), dict(input_dtype="uint8", in_stat=T(np.zeros(n, np.float32), dev))):
+        if geom == "pw" and "in_stat" in kw:
+            continue                                                   # (no padding: that call keeps its conditional launch)
+        common = dict(act="relu", bn_scale=T(bsc, dev), bn_shift=T(bsh, dev), want_stat=True, **kw)
+        fast, fstat = run(ops, dev, x, w, None, stride, pad, groups, **common)
+        exact = run(ops, dev, x, w, None, stride, pad, groups, force_direct=True, **common)
+        exact = exact[0] if isinstance(exact, tuple) else exact
+        np.testing.assert_array_equal(fast, exact)
+        np.testing.assert_array_equal(fast, np.broadcast_to(np.maximum(bsh, 0).reshape(1, -1, 1, 1), fast.shape))
+        np.testing.assert_array_equal(fstat, np.full(n, np.maximum(bsh, 0).max(), np.float32))
+
+
+def test_asymmetric_weight_codes_take_the_exact_kernel_whatever_the_caller_asks(dev, ops):
+    """uint8 weights are not on one symmetric int8 grid.  The library remembers how a weight buffer was prepared: a C caller
+    that passes force_direct = 0 for such a buffer still gets the exact kernel (the Python block always asked for it)."""
+    rng = np.random.default_rng(12)
+    x = relu_like(rng, (2, 64, 14, 14))
+    w = rng.uniform(0.0, 1.0, (128, 64, 1, 1)).astype(np.float32)
+    wt = T(w, dev)
+    wbuf = ops.qconv_weights(wt, (1, 1), (0, 0), 1, "uint8", None)
+    ws = ops.qconv_workspace(128, dev)
+    got = ops.qconv2d(T(x, dev), wt, wbuf, None, (1, 1), (0, 0), 1, ws, input_dtype="uint8", force_direct=False)
+    want = H.qconv2d_forward(x, w, None, (1, 1), (0, 0), 1, input_dtype="uint8", weight_dtype="uint8")
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_unaligned_1x1_input_takes_the_exact_kernel(dev, ops):
+    """a contiguous tensor that does not start on a 16-byte boundary (a slice of an odd-sized buffer) is a legal
+    input of the block; the one-launch pointwise forms want aligned rows, so the layer must fall back to the exact direct
+    kernel instead of failing."""
+    rng = np.random.default_rng(13)
+    n, c, h, w_ = 2, 64, 7, 7
+    x = relu_like(rng, (n, c, h, w_))
+    w = rng.standard_normal((128, c, 1, 1)).astype(np.float32)
+    big = torch.empty(1 + x.size, device=dev)
+    xt = big[1:].view(n, c, h, w_)
+    xt.copy_(T(x, dev))
+    assert xt.data_ptr() % 16 == 4 and xt.is_contiguous()
+    wt = T(w, dev)
+    wbuf = ops.qconv_weights(wt, (1, 1), (0, 0), 1)
+    ws = ops.qconv_workspace(128, dev)
+    got = ops.qconv2d(xt, wt, wbuf, None, (1, 1), (0, 0), 1, ws, input_dtype="uint8")
+    want = H.qconv2d_forward(x, w, None, (1, 1), (0, 0), 1, input_dtype="uint8")
+    np.testing.assert_array_equal(got.cpu().numpy(), want)

@@ -504,3 +504,21 @@ def test_collection_with_binning_producers_equals_one_pass_per_block():
         # producer took over and drops by the blocks that share a tensor with a sibling)
         assert passes[False] == 3 * len(blocks) and len(blocks) - 3 <= passes[True] / 3 <= len(blocks)
         assert passes[True] < passes[False]
+
+
+def test_scalar_operand_cache_keeps_its_entries_and_tells_signed_zeros_apart():
+    """the device-scalar cache behind `x * c` must never drop an entry (a captured hipGraph may hold its address)
+    and must key on the bit pattern (x / -0.0 is -inf, x / 0.0 is +inf)."""
+    from quantization.mxnet_amd.mx import ndarray as nd_mod
+    x = mx.nd.array(np.float32([1.0, 2.0]))
+    assert np.all(np.isposinf((x / 0.0).asnumpy())) and np.all(np.isneginf((x / -0.0).asnumpy()))
+    assert np.array_equal(np.signbit((x * -0.0).asnumpy()), [True, True])
+    first = nd_mod._operand(0.9, x._t)
+    saved, nd_mod._SCALARS_MAX = nd_mod._SCALARS_MAX, len(nd_mod._scalars)      # the table is "full" from here on
+    try:
+        t = nd_mod._operand(123.456, x._t)
+        assert float(t) == pytest.approx(123.456) and nd_mod._operand(0.9, x._t) is first
+        assert nd_mod._operand(123.456, x._t) is not t                            # uncached, but right
+        assert len(nd_mod._scalars) == nd_mod._SCALARS_MAX
+    finally:
+        nd_mod._SCALARS_MAX = saved

@@ -403,6 +403,11 @@ def test_capturable_adam_takes_the_same_steps():
     rng = np.random.default_rng(2)
     for it in range(5):
         x = mx.nd.array(rng.standard_normal((6, 4)).astype(np.float32))
+        if it == 3:                                    # a schedule: the capturable trainer's rate is a device scalar filled in place
+            lr_tensor = trs[1]._dev_lr
+            for tr in trs:
+                tr.set_learning_rate(2.5e-3)
+            assert trs[1]._dev_lr is lr_tensor and float(lr_tensor) == 2.5e-3
         for d, tr in zip(nets, trs):
             with mx.autograd.record():
                 out = (d(x) * d(x)).sum()
@@ -411,6 +416,40 @@ def test_capturable_adam_takes_the_same_steps():
         np.testing.assert_allclose(nets[1].weight.data().asnumpy(), nets[0].weight.data().asnumpy(), rtol=2e-7, atol=1e-9)
         np.testing.assert_allclose(nets[1].bias.data().asnumpy(), nets[0].bias.data().asnumpy(), rtol=2e-7, atol=1e-9)
     assert float(trs[1]._dev_t) == 5.0
+    # one device step counter serves every parameter: a step that leaves one without a gradient is refused
+    with mx.autograd.record():
+        out = (nets[1].weight.data() * 2.0).sum()
+    out.backward()
+    with pytest.raises(RuntimeError, match="every parameter"):
+        trs[1].step(6, ignore_stale_grad=True)
+
+
+def test_capturable_sgd_reads_its_rate_from_the_device():
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.mx import gluon
+    from quantization.mxnet_amd.mx.gluon import nn
+    nets, trs = [], []
+    for cap in (False, True):
+        np.random.seed(7)
+        d = nn.Dense(3, in_units=4)
+        d.initialize(mx.init.Xavier())
+        nets.append(d)
+        trs.append(gluon.Trainer(d.collect_params(), "sgd", {"learning_rate": 0.3, "momentum": 0.9, "capturable": cap}))
+    nets[1].weight.set_data(nets[0].weight.data())
+    nets[1].bias.set_data(nets[0].bias.data())
+    rng = np.random.default_rng(3)
+    for it in range(4):
+        x = mx.nd.array(rng.standard_normal((6, 4)).astype(np.float32))
+        if it == 2:
+            for tr in trs:
+                tr.set_learning_rate(0.07)
+        for d, tr in zip(nets, trs):
+            with mx.autograd.record():
+                out = (d(x) * d(x)).sum()
+            out.backward()
+            tr.step(6)
+        assert np.array_equal(nets[1].weight.data().asnumpy(), nets[0].weight.data().asnumpy())
+        assert np.array_equal(nets[1].bias.data().asnumpy(), nets[0].bias.data().asnumpy())
 
 
 @pytest.mark.gpu

@@ -32,7 +32,7 @@ for layer in LAYERS:
     cur = torch.empty(1, device=dev)
     codes, scales, rowsum = ops.weight_codes(w, cout, 8)
     out = []
-    for form in (None, "stream", "sample", "split"):
+    for form in (None, "stream", "sample", "split", "pipe"):
         kw = dict(in_stat=stat, width=8, flags=0, cur_out=cur, bn_scale=sc, bn_shift=sh, act="relu")
         if res is not None:
             kw["residual"] = res
