@@ -321,7 +321,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--min-block-s", type=float, default=0.5,
                     help="a timed block of --steps steps shorter than this is repeated (see --min-region-s)")
-    ap.add_argument("--min-region-s", type=float, default=8.0,
+    ap.add_argument("--min-region-s", type=float, default=float(os.environ.get("FQ_BENCH_MIN_REGION_S", "8.0")),
                     help="total time to cover with repeated blocks when one block is shorter than --min-block-s (8 s: long "
                          "enough for a once-per-few-seconds utilisation sampler beside the run to see the GPU busy)")
     ap.add_argument("--max-repeats", type=int, default=4000)
@@ -619,9 +619,8 @@ def main():
     own_blocks = []
     fqdist.collective_stats(reset=True)              # (what warm-up and set-up exchanged is not the timed region's)
     blocks = [timed_block(0)]
-    if blocks[0] < args.min_block_s:
-        while sum(blocks) < args.min_region_s and len(blocks) < args.max_repeats:
-            blocks.append(timed_block(len(blocks) * args.steps))
+    while sum(blocks) < args.min_region_s and len(blocks) < args.max_repeats:
+        blocks.append(timed_block(len(blocks) * args.steps))
     elapsed = float(np.median(blocks))
     # what each rank's own clock says about the same blocks (the line's figures are the per-block MAXIMUM over ranks)
     rank_ms = None
@@ -678,6 +677,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         kernels = {}
         step_bytes = 0.0
+        step_moved = 0.0
         for key, rec in prof.items():
             if not rec["launches"]:
                 continue
@@ -697,9 +697,16 @@ def main():
             gbs_raw = rec["bytes"] / (ms_raw * 1e-3) / 1e9
             gbs_k = rec["bytes"] / (ms_k * 1e-3) / 1e9
             step_bytes += rec["bytes"] / max(profiled_steps, 1)
+            moved = rec.get("bytes_moved", rec["bytes"])
+            step_moved += moved / max(profiled_steps, 1)
+            gbs_moved = moved / (ms_k * 1e-3) / 1e9
             kernels[key] = {"kernel": KERNEL_NAMES.get(key, key), "achieved": round(gbs_k, 1),
                             "frac": round(gbs_k / HBM_PEAK_GBS, 4),
                             "frac_raw_events": round(gbs_raw / HBM_PEAK_GBS, 4), "launches": rec["launches"],
+                            # bytes the launches really moved (1 B per element of a C16 code tensor): THE roofline fraction of a
+                            # code-hand-over run - `frac` there measures what the hand-over saves and may exceed 1
+                            "achieved_actual": round(gbs_moved, 1), "frac_actual": round(gbs_moved / HBM_PEAK_GBS, 4),
+                            "moved_bytes_per_launch": round(moved / rec["launches"], 1),
                             "avg_launch_us": round(ms_k * 1e3 / rec["launches"], 3),
                             "avg_launch_us_raw_events": round(ms_raw * 1e3 / rec["launches"], 3),
                             "algorithmic_bytes_per_launch": round(rec["bytes"] / rec["launches"], 1),
@@ -730,6 +737,7 @@ def main():
                 traffic_from_profiles = None
         dk = kernels.get(dominant, {"achieved": 0.0, "frac": 0.0, "frac_raw_events": 0.0, "kernel": None})
         whole = step_bytes / (ms_per_step * 1e-3) / 1e9 if step_bytes else 0.0
+        whole_moved = step_moved / (ms_per_step * 1e-3) / 1e9 if step_moved else 0.0
         flavour = "%s W%dA%d, %s input quant" % ({"layer": "per-layer", "group": "per-group", "channel": "per-channel"}
                                                   [args.quant_type], args.weight_bits, args.input_bits,
                                                   "offline" if args.offline else "online")
@@ -773,7 +781,10 @@ def main():
                                        "of their block, alone on one stream (inside the timed region)" if n_streams > 1
                                        else "one stream"},
             "roofline": {"bound": "hbm", "kernel": dk["kernel"], "achieved": dk["achieved"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dk["frac"],
+                         "unit": "GB/s", "frac": dk["frac"], "frac_actual": dk.get("frac_actual", dk["frac"]),
+                         "frac_actual_what": "the same with the bytes the launches really moved (1 B per element where a side is a "
+                                             "C16 code tensor: offline hand-over configurations); equal to frac when every tensor "
+                                             "crosses HBM as fp32 (the default workload)",
                          "frac_what": "algorithmic bytes / (HIP-event time of the family's launches - per launch the cost of the "
                                       "event pair, measured in this process on a self-timing kernel: launch_overhead_us_measured); in "
                                       "a process under rocprofv3 this equals the profiler's kernel table of that process to 0.3-1.7 % "
@@ -798,6 +809,8 @@ def main():
                          "null_kernel_us_measured": round(null_kernel_ms * 1e3, 3),
                          "whole_step": {"algorithmic_bytes_per_step": round(step_bytes, 1), "achieved": round(whole, 1),
                                         "frac": round(whole / HBM_PEAK_GBS, 4),
+                                        "moved_bytes_per_step": round(step_moved, 1), "achieved_actual": round(whole_moved, 1),
+                                        "frac_actual": round(whole_moved / HBM_PEAK_GBS, 4),
                                         "what": "sum of the algorithmic bytes of every library launch of one step / "
                                                 "ms_per_step (library convolutions and launch gaps included in the time)"},
                          "kernels": kernels},

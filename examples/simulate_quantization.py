@@ -110,11 +110,12 @@ EXTRA_FLAGS = [
                                    'per-forward device state per stream): the ramp and the tail of one batch\'s kernels fill '
                                    'with the next batch\'s work; results are those of one batch at a time.  Calibration passes '
                                    '(update_ema) always run one batch at a time.  (default: 3)')),
-    (['--eval-graph'], dict(type=int, default=1,
-                            help='1 (default): evaluation of a fused net replays a hipGraph of the step per lane (static input / '
-                                 'label buffers the batches are copied into; the first batch of a lane and a ragged last batch '
-                                 'launch eagerly) - the host no longer has to launch every kernel of every batch; 0: every batch '
-                                 'launched from Python.  Same kernels on the same data either way')),
+    (['--eval-graph'], dict(type=int, default=2,
+                            help='evaluation of a fused net may replay a hipGraph of the step per lane (static input / label '
+                                 'buffers the batches are copied into; the first batch of a lane and a ragged last batch launch '
+                                 'eagerly) so that the host no longer launches every kernel of every batch.  2 (default): only '
+                                 'where launching from Python would hold the GPU back (host time against device time of the '
+                                 'first eager steps); 1: always; 0: never.  Same kernels on the same data either way')),
     (['--strict-global-batch'], dict(action='store_true',
                                      help='(multi-GPU naive calibration) reproduce ONE device that sees the global batch bit '
                                           'for bit: one small all-gather per quantised layer per forward instead of the '
@@ -233,16 +234,27 @@ class _Lane(object):
       * any other batch is copied into the lane's static input buffer - for a host batch that IS its host-to-device copy,
         for a device batch one extra device copy (77 MB for 128 ImageNet images: ~6 % of a MobileNet step)."""
     MAX_GRAPHS = 16
+    capture_s, captures = 0.0, 0        # host time spent capturing + instantiating, all lanes (FQ_EVAL_TIMING=1 prints it)
+    replay_s = 0.0                      # host time inside hipGraphLaunch, all lanes
 
     def __init__(self, dev, stream):
         self.dev, self.stream = dev, stream
         self.graphs, self.full_shape, self.failed = {}, None, False
         self.capture_stream = None
+        self.pool = None
         self.eager_done = 0
 
     def _capture(self, xbuf, ybuf, step):
         """The step captured with the graph's own begin / end calls on the lane's stream - NOT the `torch.cuda.graph`
         context, whose device-wide synchronise + gc.collect + empty_cache cost a 0.4 s evaluation pass a third of its time."""
+        t0 = time.perf_counter()
+        try:
+            return self._capture_impl(xbuf, ybuf, step)
+        finally:
+            _Lane.capture_s += time.perf_counter() - t0
+            _Lane.captures += 1
+
+    def _capture_impl(self, xbuf, ybuf, step):
         g = torch.cuda.CUDAGraph()
         side = self.stream
         if side is None:                             # one lane on the default stream: capture needs a stream of its own
@@ -250,7 +262,11 @@ class _Lane(object):
             side.wait_stream(torch.cuda.current_stream(self.dev))
         try:
             with torch.cuda.stream(side):
-                g.capture_begin(capture_error_mode="thread_local")
+                # one memory pool per lane: its graphs never overlap in time, and consecutive batches of a lane then run over the
+                # SAME intermediate buffers (what bench.py does) instead of one private set of activations per captured graph
+                if self.pool is None:
+                    self.pool = torch.cuda.graph_pool_handle()
+                g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
                 try:
                     step(xbuf, ybuf)
                 finally:
@@ -291,8 +307,47 @@ class _Lane(object):
         if not in_place:
             xbuf.copy_(x, non_blocking=True)
             ybuf.copy_(y, non_blocking=True)         # (in place: the labels of a resident batch never change)
+        t0 = time.perf_counter()
         g.replay()
+        _Lane.replay_s += time.perf_counter() - t0
         return True
+
+
+class _EvalState(object):
+    """What an evaluation pass builds once and later passes over the same net in the same mode take over: the lanes (streams,
+    captured graphs, static buffers), the device counters every graph writes to, the decision whether to replay at all.
+    Kept on the net, valid while `convert.mode_epoch()` stands (quantize_input / enable / fix_params / fusing change which
+    kernels a forward launches: the graphs of an older epoch are dropped; calibration only changes values the kernels read)."""
+
+    def __init__(self, dev, n_lanes, num_class, epoch):
+        self.epoch = epoch
+        self.counters = torch.zeros(2 + 2 * num_class, dtype=torch.float32, device=dev)
+        if dev.type == "cuda" and n_lanes > 1:
+            for _ in range(int(os.environ.get("FQ_EVAL_SKIP_STREAMS", "0"))):      # (measurement: shifts which pool streams the lanes get)
+                torch.cuda.Stream(dev)
+        self.lanes = [_Lane(dev, torch.cuda.Stream(dev) if n_lanes > 1 else None) for _ in range(n_lanes)] \
+            if dev.type == "cuda" else None
+        self.use_graph = None              # undecided / True / False ("auto": decided from the first eager batches)
+        self.passes = 0
+
+
+def _eval_state(net, dev, n_lanes, num_class, update_ema):
+    from quantization.mxnet_amd.quantize.convert.convert import mode_epoch
+    cache = net.__dict__.setdefault("_fq_eval_states", {})
+    key = (str(dev), n_lanes, num_class, bool(update_ema))
+    st = cache.get(key)
+    if st is None or st.epoch != mode_epoch():
+        st = cache[key] = _EvalState(dev, n_lanes, num_class, mode_epoch())
+    return st
+
+
+# `--eval-graph 2` (auto, the default): replay only where launching a step from Python cannot keep up with the GPU.  The host
+# time of a lane's first (eager) step is compared with the device time of the same step (an event pair); with S lanes the host
+# must issue S steps while the device runs one lane's step, so eager launches suffice when host < margin x device.  mobilenet1.0
+# (45 launches per step) stays eager - 109.6 k images/s against 105.9 k with its captures paid (profiles/r4_cli_vs_bench.txt);
+# MobileNetV2 (~100 launches) replays: 121 k against 54 k.
+_AUTO_GRAPH_MARGIN = float(os.environ.get("FQ_EVAL_AUTO_MARGIN", "0.8"))
+_NOSYNC = os.environ.get("FQ_EVAL_NOSYNC", "0") == "1"      # measurement only: no per-batch wait_stream / record_stream
 
 
 def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval", streams=1, graph=False):
@@ -300,24 +355,36 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
     `evaluate`, :122-148).  The counters [n_correct, total, correct[c], label[c]] live on the device (fq_eval_counters; in
     the classifier's own launch when the net is fused: quantize.fuse.EvalHead) and cross the ranks in one all-reduce; with
     `update_ema` every batch is a calibration step.  `streams` > 1 (evaluation only): that many batches in flight.  `graph`
-    (evaluation of a fused net only): each lane replays a hipGraph of its step over static buffers the batches are copied
-    into (the first batch of a lane and batches of another shape - the ragged last one - launch eagerly); same kernels on
-    the same data, so the same counters."""
+    (evaluation of a fused net only; 1 = always, 2 = where the host would otherwise be the bottleneck, see
+    `_AUTO_GRAPH_MARGIN`): each lane replays a hipGraph of its step over static buffers the batches are copied into (the
+    first batch of a lane and batches of another shape - the ragged last one - launch eagerly); same kernels on the same
+    data, so the same counters.  Lanes, graphs and counters are kept on the net and reused by later passes in the same mode
+    (`_EvalState`): calibration epochs and `--eval-per-calib` evaluations capture once."""
     from quantization.mxnet_amd.quantize import fuse as _fuse
     dev = ctx.torch_device
-    counters = torch.zeros(2 + 2 * num_class, dtype=torch.float32, device=dev)
+    on_gpu = dev.type == "cuda"
+    n_lanes = streams if streams > 1 and not update_ema and on_gpu else 1
+    state = _eval_state(net, dev, n_lanes, num_class, update_ema)
+    counters = state.counters
+    counters.zero_()
     seen, started = 0, time.perf_counter()
     steps = fqdist.calibration_steps(_total_batches(dataloader)) if update_ema and fqdist.group_is_live() else None
     done = 0
-    on_gpu = dev.type == "cuda"
-    n_lanes = streams if streams > 1 and not update_ema and on_gpu else 1
-    lanes = [_Lane(dev, torch.cuda.Stream(dev) if n_lanes > 1 else None) for _ in range(n_lanes)] if on_gpu else None
+    lanes = state.lanes
     # (a calibration pass replays too when no process group exists: its step - forward with online scales + update_ema -
     # holds no collective and no host synchronisation; with a group the step's all-reduce must stay outside any capture)
-    graph = bool(graph) and on_gpu and hasattr(net, "_fq_arena_hooks") and not (update_ema and fqdist.group_is_live())
+    graph_ok = on_gpu and hasattr(net, "_fq_arena_hooks") and not (update_ema and fqdist.group_is_live())
+    mode = int(graph) if graph_ok else 0
+    if mode == 1:
+        state.use_graph = True
+    elif mode == 0:
+        state.use_graph = False
     head = _fuse.eval_head(net, counters) if on_gpu else None
     replayed = 0
     resident = bool(getattr(dataloader, "resident_batches", False))
+    timing = {"eager_host_s": [], "eager_dev_ev": [], "first_s": 0.0}
+    captures0, capture_s0, replay_s0 = _Lane.captures, _Lane.capture_s, _Lane.replay_s
+    steady = {"t": None, "seen": 0, "captures": _Lane.captures, "capture_at": 0}   # from where the steady-state figure counts
 
     def step(xt, labels):
         """forward + counters of one batch on the current stream"""
@@ -331,10 +398,26 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
 
     producer = torch.cuda.current_stream(dev) if on_gpu else None      # the stream the loader's device work is issued on
 
+    def decide():
+        """auto mode: host time against device time of the eager steps seen so far (the first one of a pass that freezes the
+        weights is left out when there are others)."""
+        if state.use_graph is not None or not timing["eager_dev_ev"]:
+            return
+        torch.cuda.synchronize(dev)
+        dev_ms = [a.elapsed_time(b) for a, b in timing["eager_dev_ev"]]
+        host_ms = [h * 1e3 for h in timing["eager_host_s"]]
+        if len(dev_ms) > 1:
+            dev_ms, host_ms = dev_ms[1:], host_ms[1:]
+        d, h = min(dev_ms), min(host_ms)
+        # the device finishes a step every ~0.9 d with the lanes overlapping; the one host thread needs h per step
+        state.use_graph = not (h < _AUTO_GRAPH_MARGIN * 0.9 * d)
+        state.decision = "host %.2f ms / device %.2f ms per eager step, %d lane(s) -> %s" % (
+            h, d, n_lanes, "replay from hipGraphs" if state.use_graph else "eager launches keep up")
+
     def run_batch(lane, X, y, index):
         """One batch on its lane (called with the lane's stream current).  Returns True when it went through a graph."""
         side = lane.stream if lane is not None else None
-        if side is not None:
+        if side is not None and not (_NOSYNC and index >= 4 * n_lanes):
             # the lanes are non-blocking streams: what the producer stream has issued so far - the calibrated thresholds, this
             # batch if the loader made it on the device - must be complete before the lane reads it, and the batch's memory
             # must not go back to the producer's pool while the lane still reads it
@@ -342,9 +425,18 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
             for t in (X._t, y._t):
                 if t.is_cuda:
                     t.record_stream(side)
-        if graph and index >= n_lanes and lane.replay(X._t, y._t, step, resident and not update_ema):
+        if state.use_graph and lane.eager_done > 0 and lane.replay(X._t, y._t, step, resident and not update_ema):
             return True
+        measure = on_gpu and state.use_graph is None and len(timing["eager_dev_ev"]) < max(2, n_lanes)
+        if measure:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            t0 = time.perf_counter()
         step(X.as_in_context(ctx)._t, y.as_in_context(ctx)._t.long())
+        if measure:
+            timing["eager_host_s"].append(time.perf_counter() - t0)
+            ev[1].record()
+            timing["eager_dev_ev"].append(ev)
         if lane is not None:
             lane.eager_done += 1
         return False
@@ -362,10 +454,20 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
                 seen += int(y._t.numel())
                 done += 1
                 bar.update(1)
-                if n_lanes > 1 and done == 1:
+                if on_gpu and done == 1 and state.passes == 0:
                     # what the first forward creates once - frozen weights, weight codes, folded BatchNorm constants - is read
                     # by the forwards on the other streams: wait for it
                     torch.cuda.synchronize(dev)
+                    timing["first_s"] = time.perf_counter() - started
+                if on_gpu and mode == 2 and state.use_graph is None and done == max(2, n_lanes):
+                    decide()
+                if _Lane.captures != steady["captures"]:
+                    steady["captures"], steady["capture_at"] = _Lane.captures, done
+                if on_gpu and steady["t"] is None and done >= 2 * n_lanes and done - steady["capture_at"] >= n_lanes \
+                        and (mode != 2 or state.use_graph is not None):
+                    # set-up is behind us (first forwards, the decision, the captures so far): the steady state starts
+                    torch.cuda.synchronize(dev)
+                    steady["t"], steady["seen"] = time.perf_counter(), seen
     finally:
         if head is not None:
             head.release()
@@ -375,16 +477,32 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
     if on_gpu:
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - started
+    state.passes += 1
     fqdist.allreduce_eval_counters(counters)
     c = counters.cpu().numpy()
     evaluate.last_images_per_sec = seen * fqdist.world_size() / max(elapsed, 1e-9)
+    evaluate.last_steady_images_per_sec = None
+    if steady["t"] is not None and seen > steady["seen"]:
+        evaluate.last_steady_images_per_sec = (seen - steady["seen"]) * fqdist.world_size() / max(
+            started + elapsed - steady["t"], 1e-9)
     evaluate.last_replayed = replayed
+    evaluate.last_setup = {"first_batch_s": timing["first_s"], "captures": _Lane.captures - captures0,
+                           "capture_s": _Lane.capture_s - capture_s0, "graph_mode": mode, "use_graph": state.use_graph,
+                           "decision": getattr(state, "decision", None), "pass_of_this_state": state.passes}
+    if os.environ.get("FQ_EVAL_TIMING", "0") == "1" and fqdist.rank() == 0:
+        print("[eval] %s: %d images in %.3f s; set-up: first batch %.0f ms, %d capture(s) %.0f ms; %s; %d of %d batches replayed, "
+              "%.0f us of host time per hipGraphLaunch"
+              % (tqdm_desc, seen, elapsed, timing["first_s"] * 1e3, _Lane.captures - captures0,
+                 (_Lane.capture_s - capture_s0) * 1e3, getattr(state, "decision", None) or "graph mode %d" % mode, replayed, done,
+                 (_Lane.replay_s - replay_s0) * 1e6 / max(replayed, 1)))
     per_class = c[2:2 + num_class] / (c[2 + num_class:] + 1e-10)
     return float(c[0] / max(c[1], 1.0)), float(per_class.mean())
 
 
 evaluate.last_images_per_sec = 0.0
+evaluate.last_steady_images_per_sec = None
 evaluate.last_replayed = 0
+evaluate.last_setup = {}
 
 
 # ---- the program -----------------------------------------------------------------------------------------------------------
@@ -554,7 +672,17 @@ class Simulation(object):
         if self.chief:
             print('{0: <8}: {1:2.2f}%'.format('acc', acc * 100))
             print('{0: <8}: {1:2.2f}%'.format('avg_acc', avg_acc * 100))
-            print('{0: <8}: {1:.1f} images/sec on {2} GPU(s)'.format('speed', evaluate.last_images_per_sec, self.world))
+            # the figure comparable with bench.py's (which warms up before it times): batches per second once the pass is set up -
+            # the first forward of a process loads kernels and freezes the weights (~0.1 s), a replayed evaluation captures its
+            # graphs; the whole-pass figure, set-up included, follows
+            steady, su = evaluate.last_steady_images_per_sec, evaluate.last_setup
+            if steady:
+                print('{0: <8}: {1:.1f} images/sec on {2} GPU(s) once set up (first forward {3:.0f} ms, {4} graph capture(s) {5:.0f} '
+                      'ms; {6})'.format('speed', steady, self.world, su.get("first_batch_s", 0.0) * 1e3, su.get("captures", 0),
+                                        su.get("capture_s", 0.0) * 1e3, su.get("decision") or "--eval-graph %d" % su.get("graph_mode", 0)))
+                print('{0: <8}: {1:.1f} images/sec over the whole pass, set-up included'.format('', evaluate.last_images_per_sec))
+            else:
+                print('{0: <8}: {1:.1f} images/sec on {2} GPU(s)'.format('speed', evaluate.last_images_per_sec, self.world))
             # where the images and the weights came from: an accuracy on synthetic images / random weights means nothing
             print('{0: <8}: {1}'.format('data', self.data_source))
             print('{0: <8}: {1}'.format('weights', self.weights_source))

@@ -75,6 +75,11 @@ int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront)
 int fq_profile_enable(int on);
 int fq_profile_reset(void);
 int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes);
+/* The bytes the recorded launches of `kernel_id` really moved: equal to fq_profile_read's algorithmic bytes (4 B per input and
+ * per output element) except where a side of a launch was a C16 code tensor - 1 B per element there (fq_pwconv_i8_c16,
+ * fq_conv3x3_i8_c16, fq_dwconv3x3_c16, fq_stem_conv3x3s2_c16).  A roofline fraction of a code-hand-over run is
+ * moved / time / peak; algorithmic / time / peak can exceed 1 there (it measures what the hand-over SAVES). */
+int fq_profile_read_moved(int kernel_id, double* total_moved_bytes);
 /* The fixed cost an event pair adds to a bracketed launch, measured on `stream`:
  *   pair_ms        <- median elapsed time of an event pair around ONE one-element fill kernel (`repeats` samples);
  *   null_kernel_ms <- elapsed time of `repeats` back-to-back launches of that kernel inside ONE event pair / repeats, i.e.
@@ -226,6 +231,17 @@ int fq_stem_conv3x3s2_c16(const float* x, const float* w_tap_major, const float*
 int fq_stem_conv7x7s2(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
                       int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
                       float* stat_out, fqStream_t stream);
+/* The head of the ImageNet ResNets in ONE launch (round 5): fq_stem_conv7x7s2 followed by MaxPool2D(3, stride 2, pad 1) -
+ * gluoncv's resnet*_v1 `features[0..3]` (Conv2D, BatchNorm, Activation, MaxPool2D), which examples/simulate_quantization.py
+ * leaves un-quantised (--exclude-first-conv).  y: (n, 64, hp, wp) with hp = (ho - 1) / 2 + 1; y = max over the 3x3 window
+ * (padding never wins) of act(BN(conv)): the values fq_stem_conv7x7s2 + fq_bn_act_maxpool_stat (identity BatchNorm) give,
+ * bit for bit; stat_out[n] (may be NULL) <- max|y[n]| of the POOLED tensor.  The convolution output stays in LDS: 77 + 103 MB
+ * of traffic at batch 128 instead of 77 + 411 + 411 + 103.  fq_stem_conv7x7s2_pool_supported(h, w): 1 when a row of the
+ * convolution output cuts into four tiles of at most 32 columns and three rows of it fit LDS (224 x 224: yes). */
+int fq_stem_conv7x7s2_pool_supported(int64_t h, int64_t w);
+int fq_stem_conv7x7s2_pool(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n, int64_t cin,
+                           int64_t cout, int64_t h, int64_t w, const float* bn_scale, const float* bn_shift, int act,
+                           float* stat_out, fqStream_t stream);
 
 /* Depthwise 3x3 convolution (pad 1, dilation 1, stride 1|2, one filter per channel) with the fake-quant of its INPUT
  * folded into the load and BatchNorm/activation/statistic folded into the store — per depthwise layer x is read once

@@ -72,6 +72,9 @@ int fq_stem_conv3x3s2_c16_host(const float* x, const float* w_tap_major, const f
 int fq_stem_conv7x7s2_host(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n,
                            int64_t cin, int64_t cout, int64_t h, int64_t w, const float* bn_scale,
                            const float* bn_shift, int act, float* stat_out, fqStream_t stream);
+int fq_stem_conv7x7s2_pool_host(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n,
+                                int64_t cin, int64_t cout, int64_t h, int64_t w, const float* bn_scale,
+                                const float* bn_shift, int act, float* stat_out, fqStream_t stream);
 int fq_dwconv3x3_host(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
                       int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width,
                       unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift, int act,

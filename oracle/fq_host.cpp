@@ -439,6 +439,22 @@ int fq_stem_conv7x7s2_host(const float* x, const float* w_tap_major, const float
   return stem_conv_impl(x, w_tap_major, bias, y, n, cin, cout, h, w, 7, bn_scale, bn_shift, act, stat_out);
 }
 
+// fq_stem_conv7x7s2_pool: the 7x7 first convolution (BatchNorm / activation folded) followed by MaxPool2D(3, 2, 1) - the two
+// host entry points above, one after the other (reference: gluoncv resnet*_v1 features[0..3] = Convolution, BatchNorm,
+// Activation, Pooling operators in sequence)
+int fq_stem_conv7x7s2_pool_host(const float* x, const float* w_tap_major, const float* bias, float* y, int64_t n,
+                                int64_t cin, int64_t cout, int64_t h, int64_t w, const float* bn_scale,
+                                const float* bn_shift, int act, float* stat_out, fqStream_t stream) {
+  REQUIRE(x && w_tap_major && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "fq_stem_conv7x7s2_pool_host: bad arguments");
+  const int64_t ho = (h + 6 - 7) / 2 + 1, wo = (w + 6 - 7) / 2 + 1;
+  std::vector<float> conv((size_t)(n * cout * ho * wo)), one((size_t)cout, 1.0f), zero((size_t)cout, 0.0f);
+  if (int rc = stem_conv_impl(x, w_tap_major, bias, conv.data(), n, cin, cout, h, w, 7, bn_scale, bn_shift,
+                              (act & ~FQ_STAT_PREZEROED) | FQ_STAT_PREZEROED, nullptr))
+    return rc;
+  return fq_bn_act_maxpool_stat_host(conv.data(), y, n, cout, ho, wo, one.data(), zero.data(),
+                                     FQ_ACT_NONE | (act & FQ_STAT_PREZEROED), stat_out, stream);
+}
+
 int fq_dwconv3x3_host(const float* x, const float* w, const float* bias, float* y, int64_t n, int64_t c, int64_t h,
                       int64_t wdt, int stride, const float* in_stat, const float* in_thr, int in_width,
                       unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift, int act,

@@ -209,15 +209,17 @@ def global_avg_pool(x, want_stat=False):
     return (y, stat) if want_stat else y
 
 
-def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=False):
+def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=False, pool=False):
     x, w = _f32(x), _f32(w)
     n, cin, h, wd = x.shape
     cout, ks = w.shape[0], w.shape[2]
     pad = ks // 2
     wt = np.ascontiguousarray(w.transpose(1, 2, 3, 0))
-    y = np.empty((n, cout, (h + 2 * pad - ks) // 2 + 1, (wd + 2 * pad - ks) // 2 + 1), F32)
+    ho, wo = (h + 2 * pad - ks) // 2 + 1, (wd + 2 * pad - ks) // 2 + 1
+    y = np.empty((n, cout, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1) if pool else (n, cout, ho, wo), F32)
     stat = np.zeros(n, F32) if want_stat else None
-    _call({3: "fq_stem_conv3x3s2_host", 7: "fq_stem_conv7x7s2_host"}[ks], x, wt, None if bias is None else _f32(bias), y, n,
+    name = "fq_stem_conv7x7s2_pool_host" if pool else {3: "fq_stem_conv3x3s2_host", 7: "fq_stem_conv7x7s2_host"}[ks]
+    _call(name, x, wt, None if bias is None else _f32(bias), y, n,
           cin, cout, h, wd, None if bn_scale is None else _f32(bn_scale), None if bn_shift is None else _f32(bn_shift),
           _i(_ACTS[act]), stat, None)
     return (y, stat) if want_stat else y

@@ -8,4 +8,14 @@ Layout (DESIGN.md):
   nn/        the reference's `nn.Conv2D` (int-code conv)
   dist.py    one-process-per-GPU sharding + the RCCL all-reduces of calibration statistics
 """
+import os as _os
+
+# Several evaluation batches in flight (quantize/fuse.py's per-stream state; bench.py --streams, the CLI's --eval-streams) need
+# their HIP streams on DIFFERENT hardware queues: the runtime maps streams onto GPU_MAX_HW_QUEUES queues (default 4) and two
+# lanes that land on one queue run one after the other - the CLI's three lanes did, next to the streams its captures and the
+# tensor library keep (MobileNetV2 evaluation 125 k -> 152 k images/s with 8 queues, profiles/r5_cli_lanes.txt).  The variable
+# is read when the HIP runtime initialises, i.e. at the first device call: setting it here, at import, is early enough unless
+# the process touched the GPU before importing this package; a value the user exported wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __version__ = "0.1.0"

@@ -28,6 +28,7 @@ EXPORTS = {
     "fq_profile_reset": (_int, []),
     "fq_profile_read": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                                ctypes.POINTER(ctypes.c_double)]),
+    "fq_profile_read_moved": (_int, [_int, ctypes.POINTER(ctypes.c_double)]),
     "fq_profile_calibrate": (_int, [_vp, _int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]),
     "fq_profile_launch_overhead": (_int, [_vp, _int, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]),
@@ -50,6 +51,8 @@ EXPORTS = {
     "fq_eval_counters": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "fq_stem_conv3x3s2": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
     "fq_stem_conv7x7s2": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
+    "fq_stem_conv7x7s2_pool": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
+    "fq_stem_conv7x7s2_pool_supported": (_int, [_i64, _i64]),
     "fq_stem_conv3x3s2_c16": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp, _int, _uint, _vp]),
     "fq_dwconv3x3": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int, _uint, _vp, _vp, _vp, _int,
                             _vp, _vp]),

@@ -65,7 +65,8 @@ int stream_policy(int kernel_id, int64_t numel);    // kPol* bits by kernel and 
 
 struct ProfRec {
   int kid;
-  double bytes;
+  double bytes;        // algorithmic bytes (4 B per input and per output element, also for code tensors)
+  double moved;        // bytes the launch really moves: 1 B per element on a side that is a C16 code tensor
   hipEvent_t a, b;
 };
 extern bool g_prof_on;
@@ -76,10 +77,11 @@ struct ProfScope {
   bool on;
   ProfRec r;
   hipStream_t st;
-  ProfScope(int kid, double bytes, hipStream_t s) : on(g_prof_on), st(s) {
+  ProfScope(int kid, double bytes, hipStream_t s, double moved = -1.0) : on(g_prof_on), st(s) {
     if (!on) return;
     r.kid = kid;
     r.bytes = bytes;
+    r.moved = moved < 0.0 ? bytes : moved;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
       on = false;
       return;

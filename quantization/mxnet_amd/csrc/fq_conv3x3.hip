@@ -156,7 +156,9 @@ int conv3x3_launch(const float* x, const int8_t* wcodes, const float* wscale, co
   const float levels = act_levels(in_width, in_flags);
   const int lo_neg = range ? kRangeMode : ((in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0);
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
-  ProfScope prof(FQ_KERNEL_CONV3X3, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), st);
+  ProfScope prof(FQ_KERNEL_CONV3X3, 4.0 * ((double)n * cin * hw + (double)n * cout * hw), st,
+                 (in_c16 ? (double)n * g.CBi * 16.0 * hw : 4.0 * (double)n * cin * hw) +
+                     (out_thr != nullptr ? (double)n * g.CBo * 16.0 * hw : 4.0 * (double)n * cout * hw));
   bool launched = false;
   if (c16) {
     if (int rc = fqi::conv3x3_c16_launch(x, wfrag, wscale, wsum, bias, y, &g, kt, ptw, wc, grid, lds, st, in_stat, (int)n,

@@ -117,6 +117,17 @@ int fq_profile_reset(void) {
   return FQ_OK;
 }
 
+int fq_profile_read_moved(int kernel_id, double* total_moved_bytes) {
+  FQ_REQUIRE(kernel_id >= 0 && kernel_id < FQ_KERNEL_COUNT, "fq_profile_read_moved: bad kernel id %d", kernel_id);
+  FQ_REQUIRE(total_moved_bytes, "fq_profile_read_moved: null pointer");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double moved = 0.0;
+  for (auto& r : g_prof)
+    if (r.kid == kernel_id) moved += r.moved;
+  *total_moved_bytes = moved;
+  return FQ_OK;
+}
+
 int fq_profile_read(int kernel_id, double* total_ms, int64_t* launches, double* total_bytes) {
   FQ_REQUIRE(kernel_id >= 0 && kernel_id < FQ_KERNEL_COUNT, "fq_profile_read: bad kernel id %d", kernel_id);
   FQ_REQUIRE(total_ms && launches && total_bytes, "fq_profile_read: null pointer");

@@ -246,7 +246,9 @@ int fq_dwconv3x3_c16(const void* x, const float* w, const float* bias, void* y, 
   const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   // (SURVEY.md 8d's definition of the algorithmic bytes - 4 B per input and per output element - as for the fp32 form)
-  ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * g.Ho * g.Wo), st);
+  // (moved: both sides are C16 code tensors - 1 B per element, channels padded to blocks of 16)
+  ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * g.Ho * g.Wo), st,
+                 (double)n * g.CB * 16.0 * ((double)h * wdt + (double)g.Ho * g.Wo));
 #define FQ_DW16(S_, SG_, E_)                                                                                            \
   hipLaunchKernelGGL((dwconv3x3_c16_kernel<S_, SG_, E_>), dim3((unsigned)grid), dim3(256), 0, st, (const int8_t*)x, w, bias, \
                      (int8_t*)y, g, in_stat, (int)n, in_thr, levels, lo_neg, kEps, out_current_max, bn_scale, bn_shift,  \

@@ -141,8 +141,12 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   // (SURVEY.md 8d's definition - 4 B per input and per output element - also when a side is a C16 code tensor: the line of
   // such a run says so and `frac` then measures what the hand-over saves)
   // (the classifier - planes of one pixel - is accounted on its own: 1 MB of latency-bound work is no pointwise layer)
-  ProfScope prof(hw == 1 ? FQ_KERNEL_DENSE : FQ_KERNEL_PWCONV,
-                 4.0 * ((double)n * cin * hw + (residual ? 2.0 : 1.0) * (double)n * cout * hw), c.st);
+  // (second figure: the bytes really moved - 1 B per element of a side that is a C16 code tensor, 16-channel blocks padded)
+  const double in_elems = (double)n * cin * hw, out_elems = (double)n * cout * hw;
+  const double moved = (in_c16 ? (double)n * ((cin + 15) / 16 * 16) * hw : 4.0 * in_elems) +
+                       (c.out_thr != nullptr ? (double)n * ((cout + 15) / 16 * 16) * hw : 4.0 * out_elems) +
+                       (y16 != nullptr ? (double)n * ((cout + 15) / 16 * 16) * hw : 0.0) + (residual ? 4.0 * out_elems : 0.0);
+  ProfScope prof(hw == 1 ? FQ_KERNEL_DENSE : FQ_KERNEL_PWCONV, 4.0 * (in_elems + (residual ? 2.0 : 1.0) * out_elems), c.st, moved);
   bool taken = false;
   out_thr = c.out_thr;                                  // (from here on: "y is a C16 tensor")
   if (hw == 1 && !(in_c16 || out_thr) && !range) {      // (the rows form is not built for range records)

@@ -167,14 +167,18 @@ __global__ __launch_bounds__(kBlock) void qconv_finish_kernel(float* __restrict_
     const float ql = roundf(mn / sc), qh = roundf(mx / sc);
     const bool finite = sc > 0.0f && sc < INFINITY && fabsf(ql) < 1e9f && fabsf(qh) < 1e9f;
     const int L = finite ? (int)ql : 0, H = finite ? (int)qh : 0;
+    // An ALL-ZERO tensor (a dead ReLU) has scale 0: every code is (int)NaN = 0 in the reference's arithmetic and the layer's
+    // output is its bias / BatchNorm shift.  The fast kernels get exactly that from a record that DIVIDES by 1 and
+    // multiplies back by 0 (a zero divisor would hand the depthwise kernel's fp32 codes a NaN: round 4's advice) - no fix-up.
+    const bool all_zero = sc == 0.0f;
     int flags = 0;
-    if (!finite) flags |= kFlagFixup;
+    if (!finite && !all_zero) flags |= kFlagFixup;
     if (!sym && H - L > 255) flags |= kFlagFixup;                       // 257 codes: do not fit a byte
     if (padded && !(mn <= 0.0f && mx >= 0.0f)) flags |= kFlagFixup;     // the padding zero is clipped to a non-zero code
     if (kind == kKindDw && (L < -14000 || H > 14000)) flags |= kFlagFixup;   // 9 * 127 * |code| must stay below 2^24
     rec[kRecHi] = mx;
     rec[kRecLo] = mn;
-    rec[kRecDenom] = sc;
+    rec[kRecDenom] = all_zero ? 1.0f : sc;
     rec[kRecMul] = kind == kKindDw ? 1.0f : sc;
     rec[kRecUbias] = __int_as_float(sym ? 128 : -L);
     rec[kRecFlags] = __int_as_float(flags);
@@ -587,11 +591,10 @@ int fq_qconv2d_forward(const float* x, const float* w, const void* wbuf, const f
   // ---- 4. the exact direct form: the whole layer, or the conditional fix-up behind a fast kernel ------------------------------
   // (symmetric ranges and [0, max] ranges always fit a byte - L = 0 or codes within +-127 - so no fix-up can be asked for; the
   // per-sample statistic of the output is only offered there, where the fast kernel's result is final)
-  // The one flag such a record can still carry is the non-finite scale of an ALL-ZERO tensor (sc = 0: a dead ReLU), and there
-  // the fast kernels already produce the exact kernel's values - every code is 0 on both sides ((int) of the NaN quotient),
-  // the integer sums are the bias codes, the dequantisation factor is 0 (tests/test_gpu_qconv.py, all-zero inputs).  The
-  // shortcut needs weights KNOWN to be symmetric int8 (a buffer of unknown origin gets the conditional launch, which reads
-  // the weight record's flag too).
+  // (an all-zero tensor - scale 0 - is no fix-up case: qconv_finish_kernel writes a record the fast kernels are exact with,
+  // tests/test_gpu_qconv.py, all-zero inputs; a tensor that holds Inf / NaN has no defined result in the reference either.)
+  // The shortcut needs weights KNOWN to be symmetric int8 (a buffer of unknown origin gets the conditional launch, which
+  // reads the weight record's flag too).
   const bool representable = input_mode == FQ_CODES_INT8 || (in_stat != nullptr && (ph > 0 || pw > 0));
   if (fast && representable && wmode == FQ_CODES_INT8) return FQ_OK;
   // (as a conditional fix-up - which a record of a [0, max] range with one zero in the tensor never asks for - the launch

@@ -367,7 +367,8 @@ static int stem_launch(const float* x, const float* w_tap_major, const float* bi
   const int Ho = (int)((h + 2 * pad - ksize) / 2 + 1), Wo = (int)((w + 2 * pad - ksize) / 2 + 1);
   const int64_t hwo = (int64_t)Ho * Wo;
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
-  ProfScope prof(FQ_KERNEL_STEM, 4.0 * ((double)n * cin * h * w + (double)n * cout * hwo), st);
+  ProfScope prof(FQ_KERNEL_STEM, 4.0 * ((double)n * cin * h * w + (double)n * cout * hwo), st,
+                 4.0 * (double)n * cin * h * w + (out_thr != nullptr ? 1.0 : 4.0) * (double)n * cout * hwo);
   static const int form = env_int("FQ_STEM_FORM", 0);                   // tuning: 0 auto, 1 VALU form (3x3 only), 2 MFMA form
   StemCodes oc;
   oc.thr = out_thr; oc.levels = 0.0f; oc.lo_neg = 0; oc.zoff = 0; oc.CBo = (int)((cout + 15) / 16);

@@ -112,12 +112,15 @@ def profile_reset():
 
 
 def profile_read():
-    """{kernel: {"ms": total, "launches": n, "bytes": algorithmic bytes}} since the last reset (synchronises)."""
+    """{kernel: {"ms": total, "launches": n, "bytes": algorithmic bytes, "bytes_moved": bytes really moved (1 B per element of
+    a C16 code tensor)}} since the last reset (synchronises)."""
     out = {}
     for name, kid in KERNEL_IDS.items():
         ms, n, b = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
         check_call(_lib_().fq_profile_read(kid, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)))
-        out[name] = {"ms": ms.value, "launches": n.value, "bytes": b.value}
+        mv = ctypes.c_double(0)
+        check_call(_lib_().fq_profile_read_moved(kid, ctypes.byref(mv)))
+        out[name] = {"ms": ms.value, "launches": n.value, "bytes": b.value, "bytes_moved": mv.value}
     return out
 
 
@@ -511,11 +514,14 @@ def eval_counters(logits, labels, counters):
     return counters
 
 
-def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None, out_codes=None):
+def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None, out_codes=None,
+                 pool=False):
     """The un-quantised first convolution - 3x3 / stride 2 / pad 1 / 3 -> 32 channels (MobileNets) or 7x7 / stride 2 / pad 3 /
     3 -> 64 (ResNets) - with fused BatchNorm / activation / per-sample statistic.  w: (Cout, 3, K, K) as the Conv2D parameter
     holds it; pass `w_tap_major` (= w.permute(1,2,3,0) contiguous) to skip the permutation.  Returns (y, stat (N,) or None).
-    `out_codes=dict(thr=..., width=8, flags=0)` (3x3 form; fq_stem_conv3x3s2_c16): y is a `Codes16` of the consumer's codes."""
+    `out_codes=dict(thr=..., width=8, flags=0)` (3x3 form; fq_stem_conv3x3s2_c16): y is a `Codes16` of the consumer's codes.
+    `pool=True` (7x7 form; fq_stem_conv7x7s2_pool): MaxPool2D(3, 2, 1) of the result in the same launch - y is the pooled tensor,
+    stat its statistic (`stem_pool_supported(h, w)` says whether the shape is built)."""
     _check(x, "x")
     _check(w, "w")
     if x.dim() != 4 or w.dim() != 4 or w.shape[2] != w.shape[3] or w.shape[2] not in (3, 7) or w.shape[1] != x.shape[1]:
@@ -543,6 +549,15 @@ def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_s
                                                  _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _ptr(othr), int(yc.width),
                                                  int(yc.flags), _stream(x)))
         return yc, stat
+    if pool:
+        if ks != 7 or not stem_pool_supported(h, wd):
+            raise ValueError("the pooled form is built for the 7x7 first convolution on planes whose output rows cut into four "
+                             "tiles of at most 32 columns; got K = %d on %d x %d" % (ks, h, wd))
+        ho, wo = y.shape[2], y.shape[3]
+        yp = torch.empty((n, cout, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+        check_call(_lib_().fq_stem_conv7x7s2_pool(_ptr(x), _ptr(wt), _ptr(bias), _ptr(yp), n, cin, cout, h, wd, _ptr(bn_scale),
+                                                  _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _stream(x)))
+        return yp, stat
     entry = _lib_().fq_stem_conv3x3s2 if ks == 3 else _lib_().fq_stem_conv7x7s2
     check_call(entry(_ptr(x), _ptr(wt), _ptr(bias), _ptr(y), n, cin, cout, h, wd, _ptr(bn_scale), _ptr(bn_shift),
                      _ACTS[act] | zflag, _ptr(stat), _stream(x)))
@@ -550,6 +565,10 @@ def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_s
 
 
 stem_conv3x3s2 = stem_conv_s2          # the 3x3 -> 32 case had its own name first
+
+
+def stem_pool_supported(h, w):
+    return bool(_lib_().fq_stem_conv7x7s2_pool_supported(int(h), int(w)))
 
 
 def stem_conv_supported(cin, cout, kernel, stride, pad):

@@ -79,6 +79,20 @@ def _calibration_slots(blocks):
     return slots
 
 
+_MODE_EPOCH = [0]
+
+
+def mode_epoch():
+    """Counts the calls that change WHICH kernels a converted net's forward launches or the buffers they read - quantize_input,
+    enable / disable, fix_params, (un)fusing - as opposed to the values in those buffers (calibration).  Anything that recorded
+    a forward for replay (the CLI's evaluation graphs) is valid for as long as this number stands."""
+    return _MODE_EPOCH[0]
+
+
+def bump_mode_epoch():
+    _MODE_EPOCH[0] += 1
+
+
 class NetControls(object):
     """The control surface `convert_model` installs on a net."""
 
@@ -135,6 +149,7 @@ class NetControls(object):
 
     # :92-102
     def quantize_input(self, enable=True, online=True):
+        bump_mode_epoch()
         for blk in self.blocks():
             if type(blk) is nn.Activation:
                 if enable and not blk.quantize_args.quantize_act:
@@ -147,6 +162,7 @@ class NetControls(object):
 
     # :105-114
     def _switch(self, on):
+        bump_mode_epoch()
         for blk in self.blocks():
             blk.enable_quantize = on
 
@@ -158,6 +174,7 @@ class NetControls(object):
 
     # :117-121 — convolutions only, as in the reference (a Dense never freezes)
     def fix_params(self):
+        bump_mode_epoch()
         for blk in self.blocks():
             if isinstance(blk, nn.Conv2D):
                 blk.fixed_params = 0

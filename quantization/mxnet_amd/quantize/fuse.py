@@ -117,7 +117,10 @@ def _pool_after_bn_forward(self, F, x):
 
 def _pool_stat_forward(self, F, x):
     """MaxPool2D(3, 2, 1) behind a fused producer (the ResNets' first convolution): pooling + the per-sample statistic of the
-    pooled tensor in one pass (fq_bn_act_maxpool_stat with the identity BatchNorm: x * 1 + 0 is x)."""
+    pooled tensor in one pass (fq_bn_act_maxpool_stat with the identity BatchNorm: x * 1 + 0 is x) - unless the convolution's
+    own launch has pooled already (fq_stem_conv7x7s2_pool)."""
+    if self.__dict__.pop("_fq_pool_done", False):
+        return x
     t = x._t if x._t.is_contiguous() else x._t.contiguous()
     if t.dim() != 4 or t.shape[3] % 4 or not t.is_cuda:
         return self._fq_pool_fused["orig"](F, x)
@@ -230,9 +233,14 @@ def _stem_forward(self, F, x, weight, bias=None):
         # offline input quantisation: the single consumer's codes instead of the fp32 tensor (fq_stem_conv3x3s2_c16)
         from .convert.convert_conv2d import handover_target
         out_codes = handover_target(self, st)
+    pool = st.get("pool")
+    pooled = (pool is not None and STEM_POOL and out_codes is None and w.shape[2] == 7 and t.dim() == 4
+              and ops.stem_pool_supported(t.shape[2], t.shape[3]))
     y, stat = ops.stem_conv_s2(t, w, None if bias is None else bias._t, bn_scale=scale, bn_shift=shift,
-                               act=st["act"], want_stat=True, w_tap_major=st["wt"],
+                               act=st["act"], want_stat=True, w_tap_major=st["wt"], pool=pooled,
                                **({} if out_codes is None else dict(out_codes=out_codes)))
+    if pooled:
+        pool._fq_pool_done = True                   # the MaxPool2D block behind hands the tensor through
     if out_codes is not None:
         out = NDArray(y.t)
         out._fq_c16 = y
@@ -364,6 +372,8 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
     pass).  On by default since round 3's rows form (csrc/fq_pw_rows.hip; FQ_DENSE_INT8=0 turns the default off): the forms
     made for convolution planes took 23-28 us for the 1024 -> 1000 layer at batch 128 against 16.5 us for the apply pass +
     rocBLAS, which is why it used to be opt-in."""
+    from .convert.convert import bump_mode_epoch
+    bump_mode_epoch()
     if dense_int8 is None:
         dense_int8 = DENSE_INT8
     fused = [0]
@@ -429,6 +439,9 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             if pool is not None:
                 pool._fq_pool_fused = {"orig": pool.hybrid_forward}
                 pool.hybrid_forward = types.MethodType(_pool_stat_forward, pool)
+                # ... and, where the shape is built, inside the convolution's own launch (fq_stem_conv7x7s2_pool: the
+                # convolution output never leaves the CU; STEM_POOL=0 / FQ_STEM_POOL=0 keeps the two launches)
+                b._fq_stem_fused["pool"] = pool
             b._fq_stem_fused["stem_follower"] = (container, j) if pool is None else None
             fused[0] += 1
 
@@ -689,6 +702,9 @@ def _install_stat_arena(net, producers):
 
 def refresh(net):
     """Recompute the folded BatchNorm constants (after in-place parameter changes)."""
+    from .convert.convert import bump_mode_epoch
+    bump_mode_epoch()
+
     def visit(b):
         if hasattr(b, "_fq_fused"):
             b._fq_fused["key"] = None
@@ -698,6 +714,7 @@ def refresh(net):
 
 
 DENSE_INT8 = _os.environ.get("FQ_DENSE_INT8", "1") != "0"
+STEM_POOL = _os.environ.get("FQ_STEM_POOL", "1") != "0"      # A/B: 0 = first convolution and max-pool as two launches
 
 
 class EvalHead(object):
@@ -731,6 +748,8 @@ def eval_head(net, counters):
 
 
 def unfuse(net):
+    from .convert.convert import bump_mode_epoch
+    bump_mode_epoch()
     if hasattr(net, "_fq_arena_hooks"):
         del net.forward                                     # the class's own forward again (_install_stat_arena)
         del net._fq_arena_hooks

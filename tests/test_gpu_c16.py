@@ -400,6 +400,7 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
     try:
         fuse.HANDOVER = True
         with_codes = net(xs[2]).asnumpy()
+        cur_with_side = [float(b.current_input_max) for b in net.collect_quantized_blocks()]
         n_side = calls.get("side", 0)
         # round 4: the closing 1x1 of a ResNet-50 unit stores the trunk twice when the next unit of its stage opens with a 1x1
         # (2 + 3 + 5 + 2 pairs of consecutive units, and the 3 stage boundaries, whose consumer is a strided 1x1); switched off, the
@@ -411,9 +412,8 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
         # (MobileNetV2: + the codes its first convolution hands to the first 1x1 - a producer this test does not spy on)
         assert calls["side"] == 0 and calls["c16_in"] == calls["c16_out"] + (1 if model.startswith("mobilenetv2") else 0)
         assert np.array_equal(no_side, with_codes), "logits with the trunk's code copy differ"
-        assert [float(b.current_input_max) for b in net.collect_quantized_blocks()] == \
-            [float(b.current_input_max) for b in net.collect_quantized_blocks()]
         cur_no_side = [float(b.current_input_max) for b in net.collect_quantized_blocks()]
+        assert cur_no_side == cur_with_side, "batch statistics with the trunk's code copy differ"
         fuse.SIDE_CODES = True
         calls.update(c16_out=0, c16_in=0, side=0)
         with_codes = net(xs[2]).asnumpy()
@@ -535,3 +535,52 @@ def test_thin_streaming_form_equals_the_split_form(dev, ops, case, mode):
     got, got_stat = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, bias, in_stat=stat_in, cur_out=cur_b, **kw)
     assert torch.equal(got, want)
     assert torch.equal(got_stat, want_stat) and torch.equal(cur_a, cur_b)
+
+
+def test_hand_over_logits_against_the_oracle_chain(gpu):
+    """VERDICT r4 (housekeeping): the code-hand-over net compared with the ORACLE directly, not with the fp32-hand-over product
+    path - the same net (same seed, the GPU net's calibrated thresholds copied over) run on the CPU through the numpy oracle's
+    entry points (oracle.patch), offline input quantisation.  Quantised blocks are exact on both sides; what differs is the
+    un-quantised first convolution (MIOpen vs numpy summation order), hence a tolerance, as in test_gpu_net.py."""
+    from oracle.patch import oracle_ops
+    from quantization.mxnet_amd import mx, ops
+    from quantization.mxnet_amd.quantize import fuse
+    from test_gpu_net import _build
+    model, classes, hw, batch = "cifar_resnet20_v1", 10, 32, 8
+    net = _build(model, classes, gpu)
+    rng = np.random.default_rng(3)
+    xs_np = [rng.standard_normal((batch, 3, hw, hw)).astype(np.float32) for _ in range(3)]
+    xs = [mx.nd.array(a, ctx=gpu) for a in xs_np]
+    net.quantize_input(enable=True, online=True)
+    for x in xs[:2]:
+        net(x)
+        net.update_ema()
+    net.fix_params()
+    net.quantize_input(enable=True, online=False)
+    net(xs[2])
+    fuse.fuse_inference(net)
+    handed = {"n": 0}
+    real = ops.conv3x3_i8
+
+    def spy(x, *a, **k):
+        handed["n"] += isinstance(x, ops.Codes16) or k.get("out_codes") is not None
+        return real(x, *a, **k)
+    ops.conv3x3_i8 = spy
+    try:
+        got = net(xs[2]).asnumpy()
+    finally:
+        ops.conv3x3_i8 = real
+    assert handed["n"] > 0, "no code hand-over took place: the comparison would not cover it"
+    thresholds = [b.input_max.data().asnumpy().copy() for b in net.collect_quantized_blocks()]
+    with oracle_ops():
+        ref_net = _build(model, classes, mx.cpu())
+        ref_net.quantize_input(enable=True, online=True)
+        ref_net(mx.nd.array(xs_np[0]))                                   # (allocates the calibration state)
+        for b, t in zip(ref_net.collect_quantized_blocks(), thresholds):
+            b.input_max.set_data(mx.nd.array(t))
+        ref_net.fix_params()
+        ref_net.quantize_input(enable=True, online=False)
+        want = ref_net(mx.nd.array(xs_np[2])).asnumpy()
+    # (a code that flips in an early layer - the first convolution's last bit decides it - moves a logit by a few hundredths)
+    np.testing.assert_allclose(got, want, rtol=2e-2, atol=1e-1)
+    assert np.abs(got - want).mean() < 3e-2

@@ -58,6 +58,40 @@ def test_bench_launches_its_own_ranks(gpu, streams):
     assert rec["config"]["streams"] == streams and ("single_stream" in rec) == (streams == 2)
     assert abs(rec["value"] - 256 * 3 / (rec["ms_per_step"] * 3e-3)) / rec["value"] < 1e-3
     assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec and "headline_tensor" not in rec
+    # what a first multi-GPU line is checked with in one pass: the transport, each rank's own clock, the data-path collectives
+    # (an evaluation step has none), and no HBM-traffic figure that this run did not measure
+    rk = rec["ranks"]
+    assert rk["world"] == 2 and rk["backend"] == "gloo" and rk["rccl_world"] is None
+    assert 0 < rk["ms_per_step_min_over_ranks"] <= rk["ms_per_step_max_over_ranks"] <= rec["consistency"]["ms_per_step_max"] * 1.001
+    assert rk["collectives_in_timed_region"] == {} and rk["collectives_per_step"] == {}
+    assert rec["roofline"]["traffic"] is None and rec["roofline"]["frac_actual"] == rec["roofline"]["frac"]
+
+
+@pytest.mark.parametrize("phase", ["calib-naive", "calib-kl"])
+def test_bench_calibration_phases_report_their_collectives(gpu, phase):
+    """`bench.py --gpus 2 --phase calib-naive|calib-kl`: the line says how many data-path collectives a step issued and how
+    large they were - ONE all-reduce of L + 1 doubles per naive-EMA step (north_star's collective); one range broadcast and one
+    exact-histogram all-reduce per KL collection."""
+    env = dict(os.environ, FQ_BENCH_SHARE_GPU="1", FQ_BENCH_BACKEND="gloo", FQ_DIST_BACKEND="gloo", FQ_DIST_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--phase", phase,
+           "--model", "cifar_resnet20_v1", "--batch-size", "16", "--no-cpu-baseline", "--max-repeats", "2"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    rk = rec["ranks"]
+    assert rk["world"] == 2 and rec["repeats"] == 2
+    if phase == "calib-naive":
+        assert set(rk["collectives_per_step"]) == {"all_reduce"} and rk["collectives_per_step"]["all_reduce"] == 1.0
+        # L + 1 doubles: the per-layer sums and the sample count of the global batch
+        assert rk["bytes_per_collective"]["all_reduce"] % 8 == 0 and 8 * 10 < rk["bytes_per_collective"]["all_reduce"] < 8 * 64
+    else:
+        blocks = rec["repeats"]
+        assert rk["collectives_in_timed_region"]["broadcast"]["calls"] == blocks          # the first batch's ranges
+        assert rk["collectives_in_timed_region"]["all_reduce"]["calls"] == blocks         # the histograms, once per collection
+        assert rk["bytes_per_collective"]["all_reduce"] % (2048 * 8) == 0                 # [L x 2048] int64
 
 
 def test_bench_refuses_more_ranks_than_devices(gpu):

@@ -932,6 +932,54 @@ def test_stem_conv_s2_vs_oracle(dev, ops, shape, mode, ks, cout):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 200, 232), (1, 3, 195, 201), (5, 3, 31, 250), (130, 3, 64, 224)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("mode", ["bn_relu", "plain", "bias_relu6"])
+def test_stem_conv7x7_with_maxpool_in_one_launch_vs_oracle(dev, ops, shape, mode):
+    """fq_stem_conv7x7s2_pool (round 5): Conv2D(3 -> 64, 7x7, s2) -> BatchNorm -> activation -> MaxPool2D(3, 2, 1) with the
+    convolution output kept in LDS, against `O.stem_conv_s2 -> O.bn_act_maxpool` (identity BatchNorm) and against the
+    two-launch product path it replaces - bit for bit: odd output heights and widths (a last pooled row / column of two
+    taps), bands of pooled rows with and without a halo row (batch 1 ... 130), signed values under the pool (no activation:
+    the padding must not win)."""
+    rng = np.random.default_rng(sum(shape) + len(mode))
+    x = rng.standard_normal(shape).astype(np.float32)
+    wt = (rng.standard_normal((64, 3, 7, 7)) * 0.3).astype(np.float32)
+    kw, okw = {}, {}
+    if mode == "bn_relu":
+        sc = rng.uniform(0.3, 1.5, 64).astype(np.float32)
+        sh = rng.standard_normal(64).astype(np.float32)
+        kw.update(bn_scale=T(sc, dev), bn_shift=T(sh, dev), act="relu")
+        okw.update(bn_scale=sc, bn_shift=sh, act="relu")
+    if mode == "bias_relu6":
+        b = rng.standard_normal(64).astype(np.float32)
+        kw.update(bias=T(b, dev), act="relu6")
+        okw.update(bias=b, act="relu6")
+    assert ops.stem_pool_supported(shape[2], shape[3])
+    y, stat = ops.stem_conv_s2(T(x, dev), T(wt, dev), pool=True, **kw)
+    # the product's two launches: the convolution, then pooling + statistic with the identity BatchNorm
+    y2, _ = ops.stem_conv_s2(T(x, dev), T(wt, dev), **kw)
+    one, zero = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    p2, stat2 = (ops.bn_act_maxpool_stat(y2, one, zero, "none", want_stat=True) if y2.shape[3] % 4 == 0 else (None, None))
+    got = N(y)
+    if p2 is not None:
+        _eq(got, N(p2), "one launch == convolution launch + pooling launch")
+        _eq(N(stat), N(stat2), "statistic of the pooled tensor")
+    from oracle import host as H
+    conv = H.stem_conv_s2(x, wt, **okw)
+    want = O.bn_act_maxpool(conv, np.ones(64, np.float32), np.zeros(64, np.float32), "none")
+    assert got.shape == want.shape
+    _eq(got, want, "fmaf-chain convolution -> BatchNorm -> activation -> 3x3 / 2 max-pool")
+    _eq(N(stat), O.absmax_per_sample(got), "statistic of the produced output")
+
+
+def test_stem_pool_shapes_outside_the_built_range_are_refused(dev, ops):
+    assert not ops.stem_pool_supported(600, 600) and not ops.stem_pool_supported(4, 4)
+    x = torch.zeros(1, 3, 600, 600, device=dev)
+    w = torch.zeros(64, 3, 7, 7, device=dev)
+    with pytest.raises(ValueError, match="pooled form"):
+        ops.stem_conv_s2(x, w, pool=True)
+
+
 def test_stem_conv_rejects_other_shapes(dev, ops):
     from quantization.mxnet_amd._lib import FakeQuantError
     x = torch.zeros(1, 4, 8, 8, device=dev)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # A/B of library variants on the whole benchmark step inside ONE GPU call: each argument is a quoted list of VAR=VALUE
 # settings ("" = defaults); prints images/s and the per-family ms per step of every run.
 #   tools/benchvar.sh "" "FQ_PWS_AUTO=1" "FQ_PWS_AUTO=1 FQ_PWS_CW=4"

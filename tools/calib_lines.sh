@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # End-to-end calibration lines (bench.py --phase) + their rocprofv3 kernel tables; run on the GPU box from the repo root.
 #   tools/calib_lines.sh r3  -> gpurun_out/calib/: r3_calib_naive_line.json, r3_calib_kl_line.json, *_kernel_stats_top30.csv
 set -u

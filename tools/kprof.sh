@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # Per-kernel averages of the benchmark step under rocprofv3 (kernel trace only), one table per variant, inside ONE GPU call:
 #   tools/kprof.sh "" "FQ_PWS_AUTO=1 FQ_PWS_CFG=44"          (each argument: VAR=VALUE settings exported for that run)
 # Dispatches are grouped by (kernel, grid size), so layers that share a kernel show up separately.  Prints calls per step,

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # The kernels of ONE benchmark step in launch order, with the idle gap in front of each (rocprofv3 kernel trace):
 #   tools/kseq.sh ["VAR=VALUE ..."]        BENCH_ARGS adds bench.py flags
 # Prints the median step (by total span) of the timed steps: per kernel start-to-end us, gap to the previous kernel's end.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # SQ-level counters of the benchmark's kernels (separate --pmc passes, kernel-trace only), summarised per kernel name.
 set -u
 R=$(pwd); OUT=$R/gpurun_out/pmc_sq; rm -rf $OUT; mkdir -p $OUT

@@ -1,3 +1,4 @@
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # A/B of library builds / environment settings inside ONE GPU call: bench.py (100 steps) per variant
 run() { env "$@" python bench.py --steps 100 --no-cpu-baseline --no-headline 2>/dev/null | python -c "
 import sys,json

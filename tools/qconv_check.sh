@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # nn.Conv2D(quantized=True): GPU tests + the quantized_mobilenet bench in its three launch modes + the default bench line
 # (run on the GPU box from the repo root; results under gpurun_out/)
 TAG=${1:-r4c}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # Round evidence in one GPU call (run from the repo root on the GPU box): default-workload rocprof trace + PMC traffic +
 # bench line (tools/refresh_profiles.sh), calibration kernels, the other BASELINE configurations (bench line + rocprofv3
 # kernel table each), SQ counters, host baseline.  Everything lands in gpurun_out/refresh*/; copy into profiles/.

@@ -1,3 +1,4 @@
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 set -u
 R=$(pwd); O=$R/gpurun_out/mini; rm -rf $O; mkdir -p $O
 for cfg in "--model resnet50_v1 --quant-type channel" "--model resnet50_v1 --quant-type channel --offline" \

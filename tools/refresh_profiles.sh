@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # Regenerates the rocprofv3 evidence under gpurun_out/refresh (run on the GPU box from the repo root); copy what should be
 # judged into profiles/ afterwards (tools/refresh_profiles.sh r2 -> names prefixed r2_).  PMC passes are separate from each
 # other and carry only --kernel-trace.
@@ -26,7 +27,7 @@ cd $R
 HF=$(find $OUT/pmc_hfetch -name '*counter_collection.csv' | head -1); HW=$(find $OUT/pmc_hwrite -name '*counter_collection.csv' | head -1)
 python3 tools/pmc_summary.py $HF $HW /dev/null "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around tools/pmc_run.py (headline tensor 128x64x112x112), $TAG" > $OUT/${TAG}_pmc_headline.txt 2>&1
 rm -rf $OUT/pmc_hfetch $OUT/pmc_hwrite
-python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
+FQ_BENCH_MIN_REGION_S=8 python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err   # (the line as the driver runs it)
 python3 bench.py --streams 1 --graph 0 --no-cpu-baseline --no-headline > $OUT/${TAG}_bench_line_one_stream.json 2>> $OUT/bench.err
 # (the table the line's per-kernel event figures agree with keeps the plain name)
 cp $(find $OUT/trace1 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats.csv

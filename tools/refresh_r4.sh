@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # Round-4 evidence in one GPU call (run from the repo root on the GPU box): everything tools/refresh_all.sh collects (default
 # workload: rocprofv3 tables with the headline-tensor kernels, PMC traffic incl. the headline tensor, events-vs-rocprof check,
 # other BASELINE configurations, SQ counters, calibration kernels, host baseline), the calibration phases end to end, and the

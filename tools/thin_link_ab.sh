@@ -1,4 +1,5 @@
 #!/bin/bash
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 # MobileNetV2 W4 offline with the both-sides thin link (32 -> 16 -> 96 at 112 x 112 on codes) and without (FQ_HANDOVER_UNITS=0),
 # alternating, one call.
 for r in 1 2 3; do for m in 1 0; do

@@ -1,3 +1,4 @@
+export FQ_BENCH_MIN_REGION_S=${FQ_BENCH_MIN_REGION_S:-1}   # (tools time with 1 s regions; the driver's plain bench.py run uses its 8 s default)
 for r in 1 2; do for m in 4096 3000 1500 700; do
   FQ_PWS_THIN_MIN_TILES=$m python3 bench.py --model mobilenetv2_1.0 --quant-type channel --weight-bits 4 --offline --steps 200 --no-cpu-baseline --no-headline 2>/dev/null | python3 -c "
 import json,sys
