@@ -37,8 +37,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# (the package sets this at import too - quantization/mxnet_amd/__init__.py says why - but this script asks torch for the GPU
+# before it imports the package, and the variable is read when the HIP runtime initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -719,8 +723,12 @@ def main():
         traffic_from_profiles = None
         default_workload = (args.model == "mobilenet1.0" and args.quant_type == "layer" and not args.offline
                             and args.weight_bits == 8 and args.input_bits == 8 and not args.no_fuse)
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if dominant and default_workload and os.path.exists(tpath):
+        # (the default workload's passes: profiles/pmc_traffic.json; another configuration's: profiles/pmc_traffic_<key>.json,
+        # tools/refresh_r5.sh writes them for BASELINE configurations 3 and 4)
+        cfg_key = "%s_%s_w%da%d%s" % (args.model, args.quant_type, args.weight_bits, args.input_bits,
+                                      "_offline" if args.offline else "")
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json" if default_workload else "pmc_traffic_%s.json" % cfg_key)
+        if dominant and args.phase == "eval" and not args.no_fuse and args.wino == "none" and os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
                 krec = rec.get("kernels", {}).get(dominant, {})

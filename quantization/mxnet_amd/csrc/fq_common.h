@@ -253,6 +253,9 @@ __device__ __forceinline__ v4i buf_ld_v4i(fq_rsrc r, unsigned voff, unsigned sof
 __device__ __forceinline__ void buf_st_f32(fq_rsrc r, unsigned voff, unsigned soff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
+__device__ __forceinline__ void buf_st_f32_nt(fq_rsrc r, unsigned voff, unsigned soff, float v) {      // nontemporal hint
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 2);
+}
 
 // Wavefront-wide reductions of the batch-mean prologue without the LDS pipeline: four DPP steps inside the rows of 16 lanes
 // (quad swaps, half-row and row mirrors: after each step every lane of the group holds the group's result), then the four row
@@ -583,6 +586,10 @@ constexpr int kPolNtLoad = 1, kPolNtStore = 2, kPolReverse = 4;
 
 __device__ __forceinline__ f4 buf_ld_v4f(fq_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+// the same with the nontemporal hint (cache-policy bit 1 = `nt` on gfx940+): a tensor that is read once
+__device__ __forceinline__ f4 buf_ld_v4f_nt(fq_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2));
 }
 // 16-byte buffer store.  HAZARD (found in round 3, profiles/r3_dw_flat_race.txt): `buffer_store_dwordx4 v[a:a+3], voff,
 // rsrc, sN offen` reads its data registers for several cycles after it issues, and a VALU instruction that follows it

@@ -2,6 +2,12 @@
 // (see fq_common.h for the list of translation units and the design rules)
 #include "fq_common.h"
 
+#ifndef FQ_DWFLAT_NTL
+// the flat form's activation loads carry the nontemporal hint: its input (a 26-103 MB tensor the producer left in the Infinity
+// Cache) is read once - +0.9 % images/s with three batches in flight, five alternating runs (profiles/r5_nt_sweep3.txt; 0 = off)
+#define FQ_DWFLAT_NTL 1
+#endif
+
 namespace {
 
 // Experiment hook: cap the scalar registers of the depthwise kernels (-DFQ_DW_SGPR=80).  A 256-thread workgroup is admitted
@@ -202,6 +208,7 @@ struct DwColGeom {
   int nsegx;    // segments per plane row
   int SEG;      // lanes per segment (sw + halo lanes)
   int segs;     // segments per wavefront
+  int nts;      // cols4 form: nontemporal stores (an output the Infinity Cache cannot hold beside the other batches' tensors)
 };
 
 template <int S, bool QUANT, bool ONLINE, int EPI>
@@ -808,7 +815,8 @@ __global__ __launch_bounds__(kBlock) void dwconv3x3_flat_kernel(
     const unsigned lim = TAIL_OK ? np * (IN / 4) : (np == (unsigned)P ? (unsigned)NFI : 0u);   // 16-byte groups that exist
 #pragma unroll
     for (int i = 0; i < NLI; ++i)
-      k.raw[i] = buf_ld_v4f(rx, (lane + 64u * i) < lim ? lane * 16u : kOob, base * (IN * 4u) + 1024u * i);
+      k.raw[i] = FQ_DWFLAT_NTL ? buf_ld_v4f_nt(rx, (lane + 64u * i) < lim ? lane * 16u : kOob, base * (IN * 4u) + 1024u * i)
+                               : buf_ld_v4f(rx, (lane + 64u * i) < lim ? lane * 16u : kOob, base * (IN * 4u) + 1024u * i);
     const unsigned ch = (b_lane && j < left) ? fast_mod(base + j, g.by_c) : 0u;
     k.w03 = buf_ld_v4f(rw, ch * 36u, 0);
     k.w47 = buf_ld_v4f(rw, ch * 36u, 16);
@@ -1151,7 +1159,10 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
         }
         const float mm = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
         m = fmaxf(m, keep(mm, is_out));
-        if (is_out) *reinterpret_cast<f4*>(yp + (int64_t)r * g.Wo) = (f4){o[0], o[1], o[2], o[3]};
+        if (is_out) {
+          if (g.nts) __builtin_nontemporal_store((f4){o[0], o[1], o[2], o[3]}, reinterpret_cast<f4*>(yp + (int64_t)r * g.Wo));
+          else *reinterpret_cast<f4*>(yp + (int64_t)r * g.Wo) = (f4){o[0], o[1], o[2], o[3]};
+        }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           a[k] = b[k];
@@ -1200,7 +1211,11 @@ __global__ __launch_bounds__(kBlock) FQ_DW_ATTR void dwconv3x3_cols4_kernel(
           o[k] = finish(acc);
         }
         m = fmaxf(m, keep(fmaxf(fabsf(o[0]), fabsf(o[1])), is_out));
-        if (is_out) *reinterpret_cast<float2*>(yp + (int64_t)r * g.Wo) = make_float2(o[0], o[1]);
+        if (is_out) {
+          typedef float f2v __attribute__((ext_vector_type(2)));
+          if (g.nts) __builtin_nontemporal_store((f2v){o[0], o[1]}, reinterpret_cast<f2v*>(yp + (int64_t)r * g.Wo));
+          else *reinterpret_cast<float2*>(yp + (int64_t)r * g.Wo) = make_float2(o[0], o[1]);
+        }
 #pragma unroll
         for (int k = 0; k < 5; ++k) a[k] = c[k];
       };
@@ -1355,7 +1370,7 @@ static int dwconv3x3_impl(const float* x, const float* w, const float* bias, flo
   const bool can_planes = (h == 14 || h == 7) && wdt <= 64 && (stride == 1 || (two_cols && h == 14)) &&
                           n * c * h * wdt * 4 < (1ll << 31);
   if ((form == 4 || (form == 0 && planes_on)) && can_planes) {
-    DwColGeom cg;
+    DwColGeom cg = {};
     cg.C = (int)c;
     cg.H = (int)h;
     cg.W = (int)wdt;
@@ -1403,7 +1418,7 @@ static int dwconv3x3_impl(const float* x, const float* w, const float* bias, flo
     return FQ_OK;
   }
   if ((form == 3 || form == 0) && can4) {
-    DwColGeom cg;
+    DwColGeom cg = {};
     cg.C = (int)c;
     cg.H = (int)h;
     cg.W = (int)wdt;
@@ -1433,6 +1448,8 @@ static int dwconv3x3_impl(const float* x, const float* w, const float* bias, flo
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
     static const int dw_nt_mb = env_int("FQ_DW_NT_MB", 300);              // nontemporal loads above this many MB of input
     const bool nt = 4.0 * (double)n * c * h * wdt > 1e6 * dw_nt_mb;
+    static const int dw_nts_mb = env_int("FQ_DW_NTS_MB", 1 << 30);        // nontemporal stores from this many MB of output on
+    cg.nts = 4.0 * (double)n * c * cg.Ho * cg.Wo >= 1e6 * dw_nts_mb ? 1 : 0;
 #define FQ_DWC4_E(SS, Q, O, NT_, E)                                                                               \
   hipLaunchKernelGGL((dwconv3x3_cols4_kernel<SS, Q, O, NT_, E>), dim3(grid), dim3(kBlock), 0, st, x, w, bias, y,  \
                      cg, total_segs, in_stat, (int)n, in_thr, levels, lo_neg, eps, out_current_max, bn_scale,     \
@@ -1464,7 +1481,7 @@ static int dwconv3x3_impl(const float* x, const float* w, const float* bias, flo
     return FQ_OK;
   }
   if (form == 2 || ((form == 0 || form == 3) && wdt >= 14)) {   // narrow planes (7x7): LDS staging coalesces better
-    DwColGeom cg;
+    DwColGeom cg = {};
     cg.C = (int)c;
     cg.H = (int)h;
     cg.W = (int)wdt;
@@ -1472,6 +1489,7 @@ static int dwconv3x3_impl(const float* x, const float* w, const float* bias, flo
     cg.Wo = (int)((wdt - 1) / stride + 1);
     const int halo = stride == 1 ? 2 : 1;
     const int max_sw = 64 - halo;
+    cg.nts = 0;
     cg.nsegx = (cg.Wo + max_sw - 1) / max_sw;
     cg.sw = (cg.Wo + cg.nsegx - 1) / cg.nsegx;
     cg.SEG = cg.sw + halo;

@@ -29,6 +29,9 @@ constexpr int kSmpPanelWords = 2 * 128 * 4;             // 2 channel halves x 12
 #ifndef FQ_PWSMP_ABL
 #define FQ_PWSMP_ABL 0
 #endif
+#ifndef FQ_PWSMP_NTL
+#define FQ_PWSMP_NTL 0       // A/B builds: 1 = activation loads with the nontemporal hint (profiles/r5_nt_sweep3.txt)
+#endif
 #ifndef FQ_PWSMP_LB4
 #define FQ_PWSMP_LB4 1
 #endif
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
         if (RAGGED) c.r[j] = 0.0f;
         continue;
       }
-      c.v[j] = buf_ld_v4f(xr, xo[item], (unsigned)(ki * KS * 32 + j) * plane4 + (ipix0[item] - pix0) * 4u);
+      c.v[j] = FQ_PWSMP_NTL ? buf_ld_v4f_nt(xr, xo[item], (unsigned)(ki * KS * 32 + j) * plane4 + (ipix0[item] - pix0) * 4u)
+                            : buf_ld_v4f(xr, xo[item], (unsigned)(ki * KS * 32 + j) * plane4 + (ipix0[item] - pix0) * 4u);
       if (RAGGED) c.r[j] = buf_ld_f32(xr, xo1, (unsigned)(ki * KS * 32 + j) * plane4);
     }
   };

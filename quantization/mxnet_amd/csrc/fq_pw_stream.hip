@@ -39,7 +39,11 @@ struct PwsGeom {
 // PART: Cin need not be a multiple of 16 (the loads of a ragged half-slab are clamped to the last channel: whatever code
 // they get meets a zero weight code) and Cout need not be a multiple of 32 (channels past Cout get all-zero constants and an
 // out-of-range buffer offset: the hardware drops their stores and returns 0 for their residual loads).
-template <int KT, bool RES, bool OUT16 = false, bool IN16 = false, bool PART = false, bool DUAL = false>
+// NT (round 5; plain fp32 instantiations only): bit 0 - nontemporal activation loads (the input is dead after this pass), bit 1 -
+// nontemporal stores.  The large-plane layers move 300-600 MB per launch, more than the 256 MB Infinity Cache holds: what they
+// leave there is what the NEXT launches of the batches in flight find (or do not find).  Chosen per launch by tensor size
+// (pw_try_stream; profiles/r5_pws_nt_ab.txt).
+template <int KT, bool RES, bool OUT16 = false, bool IN16 = false, bool PART = false, bool DUAL = false, int NT = 0>
 __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wc, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwsGeom g,
@@ -108,7 +112,10 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
       return;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float*>(ub + (int64_t)i * plane * 4 + off);
+    for (int i = 0; i < 16; ++i) {
+      const float* src = reinterpret_cast<const float*>(ub + (int64_t)i * plane * 4 + off);
+      v[i] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
+    }
   };
 
   float bufa[16], bufb[16];
@@ -237,8 +244,13 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
             buf_st_f32(yrp, chn + 1 < g.Cout ? yoff : 0x80000000u, so + (unsigned)(plane * 4), v.y);
           } else {
             char* yb = reinterpret_cast<char*>(y) + (int64_t)(ct * 32 + 8 * gq + r) * plane * 4 + yoff;
-            *reinterpret_cast<float*>(yb) = v.x;
-            *reinterpret_cast<float*>(yb + plane * 4) = v.y;
+            if (NT & 2) {
+              __builtin_nontemporal_store(v.x, reinterpret_cast<float*>(yb));
+              __builtin_nontemporal_store(v.y, reinterpret_cast<float*>(yb + plane * 4));
+            } else {
+              *reinterpret_cast<float*>(yb) = v.x;
+              *reinterpret_cast<float*>(yb + plane * 4) = v.y;
+            }
           }
           m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
         }
@@ -409,6 +421,16 @@ int pw_try_stream(const PwCall& c, bool* taken) {
   const int64_t need = (s.tiles + 3) / 4;
   if (grid > need) grid = need;
   if (int rc = pw_zero_stat(c)) return rc;
+  // nontemporal policy of the plain instantiations, by tensor size (MB; tuning: FQ_PWS_NTL_MB / FQ_PWS_NTS_MB, 0 = always,
+  // a huge value = never).  The input of a pointwise layer is dead after this pass: always loaded nontemporally; an output
+  // from 150 MB up (the three large-plane layers of MobileNet: 205-411 MB) is stored nontemporally - beside the tensors of two
+  // other batches in flight the 256 MB Infinity Cache would not keep it until its consumer starts anyway, and what it does
+  // keep (the 50-100 MB tensors of the middle layers) is then still there.  Measured with three batches in flight, 18 runs
+  // alternating in three calls: +1.6 ... +3.0 % images/s (profiles/r5_pws_nt_ab.txt, r5_pws_nt_sweep.txt, r5_nt_sweep2.txt; a
+  // box wanders by +-3 % between runs, and the kernels timed ALONE do not show it: the gain is what the OTHER launches find).
+  static const int ntl_mb = env_int("FQ_PWS_NTL_MB", 0), nts_mb = env_int("FQ_PWS_NTS_MB", 150);
+  const double in_mb = 4e-6 * (double)c.n * c.cin * c.hw, out_mb = 4e-6 * (double)c.n * c.cout * c.hw;
+  const int nt = (in_mb >= ntl_mb ? 1 : 0) | (out_mb >= nts_mb ? 2 : 0);
 #define FQ_PWS_LAUNCH(KT_, RES_, O16_)                                                                                 \
   {                                                                                                                    \
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_, RES_, O16_>), \
@@ -419,10 +441,23 @@ int pw_try_stream(const PwCall& c, bool* taken) {
                        c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out, c.residual,       \
                        c.out_thr);                                                                                     \
   }
+#define FQ_PWS_LAUNCH_NT(KT_, NT_)                                                                                     \
+  {                                                                                                                    \
+    static const bool attr_ok =                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_, false, false, false, false, false, NT_>), \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess;                      \
+    FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the streaming kernel");                   \
+    hipLaunchKernelGGL((pwconv_stream_kernel<KT_, false, false, false, false, false, NT_>), dim3((unsigned)grid),      \
+                       dim3(kBlock), lds, c.st, c.x, c.wcodes, c.wscale, (const int*)c.wsum, c.bias, c.y, s, c.in_stat, \
+                       (int)c.n, c.in_thr, c.levels, c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act,  \
+                       c.stat_out, c.residual, c.out_thr);                                                             \
+  }
 #define FQ_PWS_CASE(KT_)                                                                                               \
   case KT_:                                                                                                            \
     if (out16) FQ_PWS_LAUNCH(KT_, false, true)                                                                         \
-    else if (c.residual != nullptr) FQ_PWS_LAUNCH(KT_, true, false) else FQ_PWS_LAUNCH(KT_, false, false)              \
+    else if (c.residual != nullptr) FQ_PWS_LAUNCH(KT_, true, false)                                                    \
+    else if (nt == 3) FQ_PWS_LAUNCH_NT(KT_, 3) else if (nt == 2) FQ_PWS_LAUNCH_NT(KT_, 2)                              \
+    else if (nt == 1) FQ_PWS_LAUNCH_NT(KT_, 1) else FQ_PWS_LAUNCH(KT_, false, false)                                   \
     break;
 #define FQ_PWS_THIN(KT_, RES_, O16_, I16_)                                                                             \
   {                                                                                                                    \
@@ -471,6 +506,7 @@ int pw_try_stream(const PwCall& c, bool* taken) {
 #undef FQ_PWS_THIN_DUAL
 #undef FQ_PWS_THIN
 #undef FQ_PWS_CASE
+#undef FQ_PWS_LAUNCH_NT
 #undef FQ_PWS_LAUNCH
   FQ_LAUNCH_CHECK();
   *taken = true;

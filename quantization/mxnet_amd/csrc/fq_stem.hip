@@ -119,6 +119,11 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef FQ_STEM_CH
 #define FQ_STEM_CH 16
 #endif
+#ifndef FQ_STEM_NTS
+// nontemporal stores of the first convolution's fp32 output (205 MB at batch 128, read once by the first depthwise layer): +1.5 %
+// images/s with three batches in flight in two alternating A/Bs of 5-6 rounds (profiles/r5_nt_sweep4.txt, r5_nt_sweep5.txt; 0 = off)
+#define FQ_STEM_NTS 1
+#endif
 #ifndef FQ_STEM_NOSTORE      // tuning only (tools/stembench.py): the statistic without the stores - what a recomputation would cost
 #define FQ_STEM_NOSTORE 0
 #endif
@@ -313,7 +318,10 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = dw_finish<EPI>(acc[ct][4 * gq + r], bias != nullptr, bch[r], has_bn, bsc[r], bsh[r], act);
-          if (!OUT16 && !FQ_STEM_NOSTORE) buf_st_f32(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
+          if (!OUT16 && !FQ_STEM_NOSTORE) {
+            if (FQ_STEM_NTS) buf_st_f32_nt(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
+            else buf_st_f32(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
+          }
           vq[r] = v;
           m = fmaxf(m, fabsf(v));
         }

@@ -24,7 +24,7 @@ FAMILIES = {
     "pwconv": ("pwconv_stream_kernel", "pwconv_sample_kernel", "pwconv_split_kernel", "quant_transpose_i8_kernel",
                "pwconv_i8_kernel", "qconv_pw"),
     "dwconv": ("dwconv3x3", "qconv_dw"),
-    "stem": ("stem_mfma_kernel", "stem_conv3x3s2_kernel"),
+    "stem": ("stem_mfma_kernel", "stem_conv3x3s2_kernel", "stem7_pool_kernel"),
     "pool": ("gap_stat",),
     "dense": ("pwconv_rows_kernel",),
     "conv3x3": ("conv3x3_i8_kernel",),

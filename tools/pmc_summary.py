@@ -23,7 +23,7 @@ def family(n):
         return 'histogram'
     if 'dwconv3x3' in n:
         return 'dwconv'
-    if 'stem_conv3x3s2_kernel' in n or 'stem_mfma_kernel' in n:
+    if 'stem_conv3x3s2_kernel' in n or 'stem_mfma_kernel' in n or 'stem7_pool_kernel' in n:
         return 'stem'
     if 'conv3x3_i8_kernel' in n:
         return 'conv3x3'
