@@ -245,6 +245,9 @@ __device__ __forceinline__ fq_rsrc make_rsrc(const void* base, int64_t bytes) {
 __device__ __forceinline__ float buf_ld_f32(fq_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+__device__ __forceinline__ float buf_ld_f32_nt(fq_rsrc r, unsigned voff, unsigned soff) {             // nontemporal hint
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 2));
+}
 __device__ __forceinline__ v4i buf_ld_v4i(fq_rsrc r, unsigned voff, unsigned soff) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   const v4u t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);

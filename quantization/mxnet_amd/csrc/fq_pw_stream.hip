@@ -200,7 +200,8 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const bool okc = !PART || ct * 32 + 8 * (i >> 2) + 4 * h + (i & 3) < g.Cout;
-          res[i] = buf_ld_f32(rr, okc ? yoff : 0x80000000u, (unsigned)((ct * 32 + 8 * (i >> 2) + (i & 3)) * plane * 4));
+          res[i] = (NT & 1) ? buf_ld_f32_nt(rr, okc ? yoff : 0x80000000u, (unsigned)((ct * 32 + 8 * (i >> 2) + (i & 3)) * plane * 4))
+                            : buf_ld_f32(rr, okc ? yoff : 0x80000000u, (unsigned)((ct * 32 + 8 * (i >> 2) + (i & 3)) * plane * 4));
         }
       }
 #pragma unroll
@@ -441,13 +442,14 @@ int pw_try_stream(const PwCall& c, bool* taken) {
                        c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act, c.stat_out, c.residual,       \
                        c.out_thr);                                                                                     \
   }
-#define FQ_PWS_LAUNCH_NT(KT_, NT_)                                                                                     \
+#define FQ_PWS_LAUNCH_NT(KT_, NT_) FQ_PWS_LAUNCH_NT_R(KT_, false, NT_)
+#define FQ_PWS_LAUNCH_NT_R(KT_, RES_, NT_)                                                                             \
   {                                                                                                                    \
     static const bool attr_ok =                                                                                        \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_, false, false, false, false, false, NT_>), \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_stream_kernel<KT_, RES_, false, false, false, false, NT_>), \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess;                      \
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the streaming kernel");                   \
-    hipLaunchKernelGGL((pwconv_stream_kernel<KT_, false, false, false, false, false, NT_>), dim3((unsigned)grid),      \
+    hipLaunchKernelGGL((pwconv_stream_kernel<KT_, RES_, false, false, false, false, NT_>), dim3((unsigned)grid),       \
                        dim3(kBlock), lds, c.st, c.x, c.wcodes, c.wscale, (const int*)c.wsum, c.bias, c.y, s, c.in_stat, \
                        (int)c.n, c.in_thr, c.levels, c.lo_neg, kEps, c.out_current_max, c.bn_scale, c.bn_shift, c.act,  \
                        c.stat_out, c.residual, c.out_thr);                                                             \
@@ -455,6 +457,7 @@ int pw_try_stream(const PwCall& c, bool* taken) {
 #define FQ_PWS_CASE(KT_)                                                                                               \
   case KT_:                                                                                                            \
     if (out16) FQ_PWS_LAUNCH(KT_, false, true)                                                                         \
+    else if (c.residual != nullptr && nt == 3) FQ_PWS_LAUNCH_NT_R(KT_, true, 3)                                        \
     else if (c.residual != nullptr) FQ_PWS_LAUNCH(KT_, true, false)                                                    \
     else if (nt == 3) FQ_PWS_LAUNCH_NT(KT_, 3) else if (nt == 2) FQ_PWS_LAUNCH_NT(KT_, 2)                              \
     else if (nt == 1) FQ_PWS_LAUNCH_NT(KT_, 1) else FQ_PWS_LAUNCH(KT_, false, false)                                   \
@@ -506,6 +509,7 @@ int pw_try_stream(const PwCall& c, bool* taken) {
 #undef FQ_PWS_THIN_DUAL
 #undef FQ_PWS_THIN
 #undef FQ_PWS_CASE
+#undef FQ_PWS_LAUNCH_NT_R
 #undef FQ_PWS_LAUNCH_NT
 #undef FQ_PWS_LAUNCH
   FQ_LAUNCH_CHECK();

@@ -30,8 +30,10 @@ def cli_module():
 def local_batches(kind):
     """The LOCAL batches in global order (rank r of W takes r, r + W, ...).  Calibration: seven of them, the last one
     ragged - so with two ranks the last step has a 2-sample batch on rank 0 and NO batch on rank 1.  Evaluation: three."""
-    rng = np.random.default_rng(11 if kind == "calib" else 5)
-    sizes = [LOCAL_BS] * 6 + [2] if kind == "calib" else [LOCAL_BS] * 3
+    rng = np.random.default_rng({"calib": 11, "eval": 5, "eval_lanes": 6}[kind])
+    # ("eval_lanes": eleven batches, the last one ragged - with two ranks and three lanes each, rank 0 replays graphs on all three
+    # lanes and ends on a ragged eager batch, rank 1 has one batch less)
+    sizes = {"calib": [LOCAL_BS] * 6 + [2], "eval": [LOCAL_BS] * 3, "eval_lanes": [LOCAL_BS] * 10 + [3]}[kind]
     out = []
     for i, b in enumerate(sizes):
         x = (rng.standard_normal((b, 3, SIDE, SIDE)) * (1.0 + 0.2 * i)).astype(np.float32)
@@ -116,6 +118,14 @@ def main():
             fqdist.shutdown()
         return
     try:
+        if flow == "strict_lanes":
+            # evaluation with three batches in flight per rank, replayed from hipGraphs, ragged last batch on rank 0
+            thr, acc, avg, _ = run_flow(cli, "naive_strict", ctx, rank, world, local_batches("calib"),
+                                        local_batches("eval_lanes"), LOCAL_BS,
+                                        extra=("--eval-streams", "3", "--eval-graph", "1"))
+            np.savez(os.path.join(out_dir, "rank%d.npz" % rank), thr=thr, acc=np.float64(acc), avg=np.float64(avg),
+                     world=world, device=torch.cuda.current_device(), replayed=np.int64(cli.evaluate.last_replayed))
+            return
         thr, acc, avg, _ = run_flow(cli, flow, ctx, rank, world, local_batches("calib"), local_batches("eval"), LOCAL_BS)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), thr=thr, acc=np.float64(acc), avg=np.float64(avg),
                  world=world, device=torch.cuda.current_device())

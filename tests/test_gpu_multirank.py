@@ -132,6 +132,21 @@ def test_cli_naive_calibration_strict_two_ranks_equals_one_device(gpu, tmp_path)
     assert float(r["acc"]) == acc and float(r["avg"]) == avg
 
 
+def test_cli_evaluation_three_lanes_ragged_last_batch_two_ranks_equals_one_device(gpu, tmp_path):
+    """two ranks, each with THREE evaluation batches in flight replayed from hipGraphs, an odd number of
+    batches (rank 1 gets one less) and a ragged last batch on rank 0 (launched eagerly): the counters, summed over the ranks
+    in one all-reduce, give the accuracy of one device that evaluates the same images one global batch at a time."""
+    import gpu_cli_worker as W
+    r = _two_ranks(tmp_path, "strict_lanes")
+    assert int(r["replayed"]) >= 2                                     # (rank 0: 6 batches, three of them after a lane's first)
+    cli = W.cli_module()
+    thr, acc, avg, _ = W.run_flow(cli, "naive_strict", gpu, 0, 1, W.global_batches("calib", 2),
+                                  W.global_batches("eval_lanes", 2), 2 * W.LOCAL_BS,
+                                  extra=("--eval-streams", "1", "--eval-graph", "0"))
+    np.testing.assert_array_equal(r["thr"], thr)
+    assert float(r["acc"]) == acc and float(r["avg"]) == avg
+
+
 def test_cli_naive_calibration_one_collective_per_step_two_ranks(gpu, tmp_path):
     """Default mode: every rank's forward runs on its local batch; the step's ONE all-reduce gives the batch mean of the
     global batch.  Expected values: one process runs the same local batches, the per-sample statistics of every layer are

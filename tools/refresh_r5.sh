@@ -42,9 +42,9 @@ for ln in open(sys.argv[1]):
     except Exception:
         continue
     r = d["roofline"]; k = r["kernels"]; t = r.get("traffic_from_profiles")
-    print("%s\n  %.1f img/s %.4f ms/step | whole step frac %.3f frac_actual %.3f | %s" % (
-        d["config"]["workload"][:90], d["value"], d["ms_per_step"], r["whole_step"]["frac"], r["whole_step"]["frac_actual"],
-        "  ".join("%s %.3f ms frac %.2f actual %.2f" % (n, k[n]["ms_per_step"], k[n]["frac"], k[n]["frac_actual"]) for n in sorted(k, key=lambda n: -k[n]["ms_per_step"]))))
+    print("%s\n  %.1f img/s %.4f ms/step | whole step frac %.3f (4 B per element: %.3f) | %s" % (
+        d["config"]["workload"][:90], d["value"], d["ms_per_step"], r["whole_step"]["frac"], r["whole_step"]["frac_algorithmic"],
+        "  ".join("%s %.3f ms frac %.2f (%.2f)" % (n, k[n]["ms_per_step"], k[n]["frac"], k[n]["frac_algorithmic"]) for n in sorted(k, key=lambda n: -k[n]["ms_per_step"]))))
     if t:
         print("  PMC traffic of %s: %.1f MB per launch (moved by the line's count: %.1f MB)" % (t["kernel"], t["hbm_bytes_per_launch"] / 1e6, k[t["kernel"]]["moved_bytes_per_launch"] / 1e6))
 P
