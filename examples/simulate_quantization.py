@@ -331,13 +331,21 @@ class _EvalState(object):
         self.passes = 0
 
 
-def _eval_state(net, dev, n_lanes, num_class, update_ema):
+def _epochs():
     from quantization.mxnet_amd.quantize.convert.convert import mode_epoch
+    from quantization.mxnet_amd.mx.gluon.parameter import write_epoch
+    return (mode_epoch(), write_epoch())
+
+
+def _eval_state(net, dev, n_lanes, num_class, update_ema):
     cache = net.__dict__.setdefault("_fq_eval_states", {})
     key = (str(dev), n_lanes, num_class, bool(update_ema))
     st = cache.get(key)
-    if st is None or st.epoch != mode_epoch():
-        st = cache[key] = _EvalState(dev, n_lanes, num_class, mode_epoch())
+    # (a calibration pass of a fake-BN net writes running statistics with set_data in every step: its graphs hold those
+    # tensors' addresses and the writes are in place, but the epoch moves - such a net simply captures once per pass)
+    epoch = _epochs()
+    if st is None or st.epoch != epoch:
+        st = cache[key] = _EvalState(dev, n_lanes, num_class, epoch)
     return st
 
 
@@ -478,6 +486,10 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - started
     state.passes += 1
+    # what this pass itself wrote - the freezing forward stores the quantised weights with set_data (convert_conv2d.py:101-108) -
+    # happened before its first capture (the first batch is launched eagerly and waited for): the graphs belong to the epoch the
+    # pass ENDS in
+    state.epoch = _epochs()
     fqdist.allreduce_eval_counters(counters)
     c = counters.cpu().numpy()
     evaluate.last_images_per_sec = seen * fqdist.world_size() / max(elapsed, 1e-9)

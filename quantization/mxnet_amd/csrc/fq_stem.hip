@@ -124,6 +124,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // images/s with three batches in flight in two alternating A/Bs of 5-6 rounds (profiles/r5_nt_sweep4.txt, r5_nt_sweep5.txt; 0 = off)
 #define FQ_STEM_NTS 1
 #endif
+#ifndef FQ_STEM_NTL
+#define FQ_STEM_NTL 0        // A/B builds: 1 = the gather of the input image with the nontemporal hint
+#endif
 #ifndef FQ_STEM_NOSTORE      // tuning only (tools/stembench.py): the statistic without the stores - what a recomputation would cost
 #define FQ_STEM_NOSTORE 0
 #endif
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     const bool v1 = k1 < K && ((px.ym >> ky1) & (px.xm >> kx1) & 1u) != 0u;
     const bool v = h ? v1 : v0;
     const unsigned off = (unsigned)px.pixoff + (h ? t1 : t0);
-    return buf_ld_f32(xr, v ? off : 0x80000000u, 0u);
+    return FQ_STEM_NTL ? buf_ld_f32_nt(xr, v ? off : 0x80000000u, 0u) : buf_ld_f32(xr, v ? off : 0x80000000u, 0u);
   };
   auto rsrc_of = [&](const Pix& px) __attribute__((always_inline)) {
     return make_rsrc(reinterpret_cast<const char*>(x) + (int64_t)px.smp * x_img, x_img);

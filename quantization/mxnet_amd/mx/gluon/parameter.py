@@ -98,6 +98,7 @@ class Parameter(object):
         return [self._ctx]
 
     def set_data(self, data):
+        _WRITE_EPOCH[0] += 1
         if not isinstance(data, NDArray):
             data = NDArray(torch.as_tensor(np.asarray(data, dtype=np.float32)))
         if self._data is None:
@@ -115,6 +116,7 @@ class Parameter(object):
     def _load_init(self, arr, ctx=None):
         """A value read from a parameter file: initialises a deferred Parameter with it, or overwrites the data in place."""
         arr = np.ascontiguousarray(arr, dtype=np.float32)
+        _WRITE_EPOCH[0] += 1
         if self._data is None:
             if self._deferred is None:
                 self._deferred = (_init.Zero(), ctx or cpu())
@@ -127,6 +129,7 @@ class Parameter(object):
             self.set_data(NDArray(torch.from_numpy(arr)))
 
     def reset_ctx(self, ctx):
+        _WRITE_EPOCH[0] += 1
         if isinstance(ctx, (list, tuple)):
             ctx = ctx[0]
         if self._data is not None:
@@ -162,6 +165,16 @@ class Parameter(object):
 
     def cast(self, dtype):
         self.dtype = dtype
+
+
+# Counts the writes to Parameters through the Gluon surface (set_data, loading a file, moving to another context).  Host-side
+# caches of values DERIVED from parameters (folded BatchNorm constants, weight codes) are rebuilt in new tensors after such a
+# write; whatever recorded the old tensors' addresses - the CLI's evaluation graphs - compares this number and starts over.
+_WRITE_EPOCH = [0]
+
+
+def write_epoch():
+    return _WRITE_EPOCH[0]
 
 
 def read_parameter_file(filename):

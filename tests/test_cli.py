@@ -205,3 +205,43 @@ def test_scale_table_export_on_gpu(tiny_data, tmp_path):
     import json
     js = json.load(open(path + ".json"))
     assert len(js) == 2 * len(blocks) and {e["kind"] for e in js} == {"weight", "input"}
+
+
+@pytest.mark.gpu
+def test_evaluation_state_is_reused_across_passes_and_dropped_when_the_mode_changes(tiny_data, monkeypatch):
+    """Round 5: `evaluate` keeps its lanes, captured graphs and counters on the net.  A second pass over the same (resident)
+    batches replays the first pass's graphs - no new capture - and counts the same; eager launches count the same; a change
+    of mode (`fix_params`: new weight-code tensors) or a parameter written through the Gluon surface drops the graphs."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from quantization.mxnet_amd import mx
+    cli = _cli()
+    opt = cli.parse_args(["--model", "mobilenet1.0", "--use-gpu", "0", "--batch-size", "4", "--pretrained", "false",
+                          "--synthetic-on-device", "--synthetic-resident", "6"])
+    ctx = mx.gpu(0)
+    sim = cli.Simulation(opt, ctx, 0, 1)
+    np.random.seed(opt.fixed_random_seed)
+    sim.build_net()
+    sim.quantise_net()
+    monkeypatch.setenv("FQ_SYNTH_VAL_IMAGES", "50")      # 12 full batches of 4 + a ragged one of 2
+    sim.make_loaders()
+    sim.net.fix_params()
+    sim.net.quantize_input(enable=True, online=True)
+    first = cli.evaluate(sim.net, 1000, sim.eval_loader, ctx, streams=3, graph=1)
+    su1 = dict(cli.evaluate.last_setup)
+    assert su1["captures"] == 6 and cli.evaluate.last_replayed == 9          # 3 eager firsts, ragged last, 9 replays
+    second = cli.evaluate(sim.net, 1000, sim.eval_loader, ctx, streams=3, graph=1)
+    su2 = dict(cli.evaluate.last_setup)
+    assert su2["captures"] == 0 and cli.evaluate.last_replayed == 12 and su2["pass_of_this_state"] == 2
+    eager = cli.evaluate(sim.net, 1000, sim.eval_loader, ctx, streams=1, graph=0)
+    assert first == second == eager
+    sim.net.fix_params()                                 # the next forward freezes the weights again, into NEW tensors
+    third = cli.evaluate(sim.net, 1000, sim.eval_loader, ctx, streams=3, graph=1)
+    assert cli.evaluate.last_setup["captures"] == 6 and cli.evaluate.last_setup["pass_of_this_state"] == 1 and third == first
+    blk = sim.net.collect_quantized_blocks()[3]
+    blk.weight.set_data(blk.weight.data() * 0.5)          # a parameter written through Gluon: derived caches are rebuilt
+    sim.net.fix_params()
+    fourth = cli.evaluate(sim.net, 1000, sim.eval_loader, ctx, streams=3, graph=1)
+    assert cli.evaluate.last_setup["pass_of_this_state"] == 1
+    fifth = cli.evaluate(sim.net, 1000, sim.eval_loader, ctx, streams=1, graph=0)
+    assert fourth == fifth

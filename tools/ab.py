@@ -3,7 +3,7 @@
 between consecutive runs, so single runs say nothing: every round runs every variant once, in order; reported per variant are
 mean / median / min / max images/s and the mean of the PAIRED ratios against the first variant (same round = same mood).
 
-    python tools/ab.py [--rounds 5] [--args "bench.py args"] "label" "label|ENV=V ENV2=V" ...
+    python tools/ab.py [--rounds 5] [--args "bench.py args"] "label" "label|ENV=V ENV2=V" "label||--streams 2" ...
 """
 import json
 import os
@@ -25,14 +25,15 @@ def main():
         argv = argv[2:]
     variants = []
     for a in argv:
-        label, _, envs = a.partition("|")
-        variants.append((label, dict(kv.split("=", 1) for kv in envs.split()) if envs else {}))
-    vals = {label: [] for label, _ in variants}
+        parts = a.split("|")
+        label, envs, vargs = parts[0], (parts[1] if len(parts) > 1 else ""), (parts[2] if len(parts) > 2 else "")
+        variants.append((label, dict(kv.split("=", 1) for kv in envs.split()) if envs else {}, vargs.split()))
+    vals = {label: [] for label, _, _ in variants}
     base_env = dict(os.environ)
     base_env.setdefault("FQ_BENCH_MIN_REGION_S", "3")
     for r in range(rounds):
-        for label, env in variants:
-            res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra.split(), env=dict(base_env, **env),
+        for label, env, vargs in variants:
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra.split() + vargs, env=dict(base_env, **env),
                                  capture_output=True, text=True, cwd=ROOT)
             try:
                 v = json.loads(res.stdout.strip().splitlines()[-1])["value"]
@@ -42,7 +43,7 @@ def main():
             print("round %d  %-32s %10.1f img/s" % (r + 1, label, v), flush=True)
     first = variants[0][0]
     print("%-32s %10s %10s %10s %10s   paired vs %s" % ("variant", "mean", "median", "min", "max", first))
-    for label, _ in variants:
+    for label, _, _ in variants:
         x = [v for v in vals[label] if v == v]
         ratios = [a / b for a, b in zip(vals[label], vals[first]) if a == a and b == b]
         print("%-32s %10.1f %10.1f %10.1f %10.1f   %+.2f %% (sd %.2f)" % (
