@@ -322,9 +322,6 @@ class _EvalState(object):
     def __init__(self, dev, n_lanes, num_class, epoch):
         self.epoch = epoch
         self.counters = torch.zeros(2 + 2 * num_class, dtype=torch.float32, device=dev)
-        if dev.type == "cuda" and n_lanes > 1:
-            for _ in range(int(os.environ.get("FQ_EVAL_SKIP_STREAMS", "0"))):      # (measurement: shifts which pool streams the lanes get)
-                torch.cuda.Stream(dev)
         self.lanes = [_Lane(dev, torch.cuda.Stream(dev) if n_lanes > 1 else None) for _ in range(n_lanes)] \
             if dev.type == "cuda" else None
         self.use_graph = None              # undecided / True / False ("auto": decided from the first eager batches)
@@ -355,7 +352,6 @@ def _eval_state(net, dev, n_lanes, num_class, update_ema):
 # (45 launches per step) stays eager - 109.6 k images/s against 105.9 k with its captures paid (profiles/r4_cli_vs_bench.txt);
 # MobileNetV2 (~100 launches) replays: 121 k against 54 k.
 _AUTO_GRAPH_MARGIN = float(os.environ.get("FQ_EVAL_AUTO_MARGIN", "0.8"))
-_NOSYNC = os.environ.get("FQ_EVAL_NOSYNC", "0") == "1"      # measurement only: no per-batch wait_stream / record_stream
 
 
 def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval", streams=1, graph=False):
@@ -425,7 +421,7 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
     def run_batch(lane, X, y, index):
         """One batch on its lane (called with the lane's stream current).  Returns True when it went through a graph."""
         side = lane.stream if lane is not None else None
-        if side is not None and not (_NOSYNC and index >= 4 * n_lanes):
+        if side is not None:
             # the lanes are non-blocking streams: what the producer stream has issued so far - the calibrated thresholds, this
             # batch if the loader made it on the device - must be complete before the lane reads it, and the batch's memory
             # must not go back to the producer's pool while the lane still reads it

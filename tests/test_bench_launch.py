@@ -23,7 +23,10 @@ def test_gpus_n_without_launcher_starts_ranks_and_returns_their_status():
         return                                    # the GPU-side test (tests/test_gpu_multirank.py) covers the real run
     res = _run(["--gpus", "2", "--steps", "1", "--no-cpu-baseline"], FQ_BENCH_SHARE_GPU="1", FQ_BENCH_BACKEND="gloo")
     assert res.returncode != 0
-    assert res.stderr.count("bench.py needs an MI355X") >= 2, res.stderr[-2000:]      # both ranks ran and said so
+    # a rank ran and said so (torch.distributed.run ends the other rank as soon as the first one fails: on a loaded machine the
+    # second may not get to print), and the launcher's failure report names the rank it came from
+    assert res.stderr.count("bench.py needs an MI355X") >= 1, res.stderr[-2000:]
+    assert "ChildFailedError" in res.stderr or "local_rank" in res.stderr, res.stderr[-2000:]
 
 
 def test_gpus_n_beyond_the_nodes_devices_is_refused_by_the_parent():
