@@ -349,11 +349,14 @@ def main():
                          "host runs ahead of a GPU-bound stream: 108.0 vs 109.3 k images/s), with several batches in flight the "
                          "eager host becomes the limit (100.7 k on a box with a slow host) and replay lifts it (127.7-128.8 k in "
                          "the same call).  0: every step launched from the host")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("FQ_BENCH_STREAMS", "3")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("FQ_BENCH_STREAMS", "4")),
                     help="evaluation steps in flight: step i runs on HIP stream i %% S (same net; per-forward device state is "
                          "kept per stream), so that the ramp and the tail of one batch's ~30 kernels fill with the other batch's work "
                          "(independent batches; every step's kernels, results and counters are what they are with S = 1).  "
-                         "1: one stream, the figure of rounds 1-3; the line reports that too (`single_stream`)")
+                         "1: one stream, the figure of rounds 1-3; the line reports that too (`single_stream`).  Default 4 (rounds 4-5: 3): "
+                         "alternating runs of 4 against 3 gave +0.6 % on the default workload, +1.3 % / 0.0 % on ResNet-50 online / "
+                         "offline and +2.6 % on MobileNetV2 W4 offline, whose code-tensor kernels are the shortest; 5 and 6 lose "
+                         "8-12 % there (profiles/r5_lanes4_ab.txt)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -105,11 +105,11 @@ EXTRA_FLAGS = [
     (['--export-scale-table'], dict(type=str, default=None,
                                     help='after calibration write an ncnn-style int8 scale table (per-channel weight scales '
                                          'after BN folding, one input scale per layer; quantize/freeze/scale_table.py)')),
-    (['--eval-streams'], dict(type=int, default=3,
+    (['--eval-streams'], dict(type=int, default=4,
                               help='batches in flight during evaluation, one HIP stream each (quantize/fuse.py keeps the '
                                    'per-forward device state per stream): the ramp and the tail of one batch\'s kernels fill '
                                    'with the next batch\'s work; results are those of one batch at a time.  Calibration passes '
-                                   '(update_ema) always run one batch at a time.  (default: 3)')),
+                                   '(update_ema) always run one batch at a time.  (default: 4, as bench.py)')),
     (['--eval-graph'], dict(type=int, default=2,
                             help='evaluation of a fused net may replay a hipGraph of the step per lane (static input / label '
                                  'buffers the batches are copied into; the first batch of a lane and a ragged last batch launch '

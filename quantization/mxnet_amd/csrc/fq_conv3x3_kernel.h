@@ -222,8 +222,14 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   PW_STAMP(2);
   const int cvalid = g.Cout - (ch0 + wc * 32);                          // valid channels of this wavefront's tile
   const int zb = stored_zero4(ubias);                                   // four codes "0" in the stored representation
-  auto run = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+  // the consumer's quantiser of a C16 output (nn2_c: its clip range starts at 0 - the five-instruction form of fq_common.h)
+  QParams q2;
+  q2.lo = q2.hi = q2.denom = q2.scale = 0.0f;
+  q2.rden = 0.0;
+  if (OUT16) q2 = make_qparams(out_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
+  auto run = [&](auto bias_c, auto bn_c, auto act_c, auto nn2_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
+    constexpr bool NN2 = decltype(nn2_c)::value;
     v16i acc[NSL][PTW];
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl)
@@ -277,10 +283,6 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
     y16_bytes = y16_bytes < 0x7FFFFFFFll ? y16_bytes : 0x7FFFFFFFll;
     const fq_rsrc yr = OUT16 ? make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp16 + (int64_t)cb0 * HW * 16, y16_bytes)
                              : make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp + (int64_t)(ch0 + wc * 32) * plane4, y_bytes);
-    QParams q2;
-    q2.lo = q2.hi = q2.denom = q2.scale = 0.0f;
-    q2.rden = 0.0;
-    if (OUT16) q2 = make_qparams(out_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
     const int ubias2 = 128 - g.out_zoff;
     const int cb = wc * 32 + 4 * h;
     const bool partial = cvalid < 32;
@@ -326,8 +328,7 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
           m = fmaxf(m, fabsf(v));
         }
         if (OUT16) {                               // (fq_pw_split_kernel.h: the consumer's codes of the four values, 4 bytes)
-          const int packed = pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
-                                         fq_code_int(vq[3], q2), ubias2);
+          const int packed = fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, fq_nonneg_xor(ubias2));
           const bool blk_ok = !partial || 16 * (gq >> 1) < cvalid;
           const unsigned yo16 = (smp[t] - s_base) * (unsigned)g.CBo * HW * 16u + pp[t] * 16u + 4u * h;
           buf_st_f32(yr, blk_ok ? yo16 : 0x80000000u, (unsigned)((gq >> 1) * (int)HW * 16 + 8 * (gq & 1)), __int_as_float(packed));
@@ -353,10 +354,20 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   using std::integral_constant;
   if (cvalid <= 0) {
     // a channel group wider than the layer: this wavefront only helped to quantise the region
-  } else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
-    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
-  else
-    run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});
+  } else {
+    auto go = [&](auto nn2_c) __attribute__((always_inline)) {
+      if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
+        run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, nn2_c);
+      else
+        run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, nn2_c);
+    };
+    if constexpr (OUT16) {                                              // (only a kernel that writes codes is instantiated twice)
+      if (fq_nonneg(q2)) go(std::true_type{});
+      else go(std::false_type{});
+    } else {
+      go(std::false_type{});
+    }
+  }
   PW_STAMP(4);
   if (has_stat) {
     __syncthreads();

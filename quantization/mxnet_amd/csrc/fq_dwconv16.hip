@@ -7,12 +7,19 @@
 // tuning build: -DFQ_DW16_V=<bits>  4: the short quantiser for non-negative output ranges (bits 1 and 2 - unconditional loads
 // from clamped addresses + select instead of 62 exec-masked loads, stride 2 keeping the row it shares with the next output
 // row - are built in since r4: 526 -> 473 us over MobileNetV2's ten depthwise shapes at batch 128, tools/dw16bench.py).
-// -DFQ_DW16_DEPTH=<0|2>: output rows between the fetch of an input row and its use (1: 452 us, 3: four sets, 136 registers, 440 us).
+// -DFQ_DW16_RING=<3|4|5> / -DFQ_DW16_RING2=<2>: input rows (stride 2: row pairs) in flight per lane.
 #ifndef FQ_DW16_V
 #define FQ_DW16_V 7
 #endif
-#ifndef FQ_DW16_DEPTH
-#define FQ_DW16_DEPTH 2
+// input rows in flight per lane, stride 1 / row PAIRS, stride 2 (even): ordinary buffer loads the compiler waits for.  (Issued and
+// awaited by hand - inline assembly and hand-counted s_waitcnt, because hipcc drains the ring where the paths into the
+// unrolled walk meet - six rows were another +0.4 % images/s, but the compiler does not know that such registers are pending:
+// it spilled and copied them, and full-size repeats beside a competing stream differed - tests/test_gpu_determinism.py.)
+#ifndef FQ_DW16_RING
+#define FQ_DW16_RING 4
+#endif
+#ifndef FQ_DW16_RING2
+#define FQ_DW16_RING2 2
 #endif
 
 namespace {
@@ -26,9 +33,9 @@ using namespace fqi;
 //
 // Mapping: a lane owns one output column and a QUARTER of a 16-channel block (4 channels = one dword of a pixel's 16 bytes);
 // the 64 lanes of a wavefront are 16 columns x 4 quarters, so a row access of a wavefront is 256 contiguous bytes.  A
-// workgroup (4 wavefronts = 64 column slots) walks down the output rows of its (sample, block(s)) with a sliding window of
-// three dequantised input rows (3 columns x 4 channels each); planes narrower than 33 columns put several blocks side by
-// side in the 64 slots.  Out-of-image taps take the byte pattern of code 0 before they are dequantised.
+// workgroup (4 wavefronts = 64 column slots) walks down the output rows of its (sample, block(s)): every input row is
+// dequantised once (3 columns x 4 channels) and added to the sums of the three output rows it belongs to; planes narrower
+// than 33 columns put several blocks side by side in the 64 slots.  Out-of-image taps take the byte pattern of code 0 before they are dequantised.
 struct Dw16Geom {
   int C, CB, H, W, Ho, Wo;
   int T;                     // blocks side by side in a workgroup's 64 column slots (W <= 32), else 1
@@ -38,6 +45,28 @@ struct Dw16Geom {
   int out_lo_neg, out_zoff, in_zoff;
 };
 
+// Two fp32 values in a register pair: gfx950 multiplies / adds / fuses both in ONE instruction (v_pk_mul_f32, v_pk_add_f32,
+// v_pk_fma_f32: each component an IEEE operation of its own, so the results are those of the scalar form bit for bit).  The
+// 36 multiply-adds of a lane's four channels are 18 packed ones, BatchNorm one packed multiply and one packed add per pair
+// (~135 -> ~95 instructions per output row and lane).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// What bounds this kernel (round 5; rocprofv3 counters, ablation builds and probes on 144 channels x 56 x 56, batch 128 -
+// profiles/r5_dw16_study.txt): the VECTOR UNIT, and among several batches in flight the number of instructions is what
+// counts.  At 1 B per element HBM is idle (116 MB in 59 us); a build without the walk's loads and stores takes the same time;
+// planes of 28 instead of 56 rows take 0.84 us less per row.  A row-step of a lane (4 outputs) is ~95 instructions: 12
+// byte-to-float conversions + 6 packed multiplies (dequantise 3 columns), 18 packed multiply-adds, BatchNorm / ReLU6 /
+// statistic (10), the consumer's quantiser (clip, fp64 divide in 3, round: 20), packing (4).  tools/pk_probe.hip prices
+// them: v_fma / v_mul / v_add / v_bitop3 issue every ~2.9 cycles per wavefront and SIMD (four wavefronts resident);
+// conversions, v_med3 / v_max3, every fp64 and every packed fp32 instruction every ~4.6-5.0 - a packed multiply-add is 0.83
+// of two scalar ones, not half.  MobileNetV2 W4 offline, four batches in flight, went 157.5 -> 165.0 k images/s (+4.8 %,
+// together with the five-instruction output quantiser of the pointwise kernels) through: buffer addressing (no 64-bit
+// address arithmetic in the vector unit), accumulators instead of a window of cooked rows (below) - which freed the
+// registers for - a ring of 4 instead of 2 rows in flight per lane, requested before the weights and thresholds (3 rows:
+// -1.7 %).  What did NOT help: cutting a plane into chunks of rows for more, shorter workgroups (-3.4 %: every chunk repeats
+// the 44 weight loads and two halo rows); weights through bounded buffer loads instead of 44 loads under a lane condition
+// (-0.5 %).
 template <int S, bool SIGNED_IN, int EPI>
 __global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
     const int8_t* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias, int8_t* __restrict__ y,
@@ -51,150 +80,211 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
   const unsigned ct = b % (unsigned)g.col_tiles;
   b /= (unsigned)g.col_tiles;
   const unsigned grp = b % (unsigned)g.groups, smp = b / (unsigned)g.groups;
-  unsigned blk, xo;                                                     // this lane's block and output column
+  const int nrows = g.Ho;
+  unsigned bl, blk, xo;                                                 // this lane's block (inside the group, in the layer) and output column
   bool lane_ok;
   if (g.T > 1) {
-    const unsigned bl = slot / (unsigned)g.Wo;
+    bl = slot / (unsigned)g.Wo;
     xo = slot - bl * (unsigned)g.Wo;
     blk = grp * (unsigned)g.T + bl;
     lane_ok = bl < (unsigned)g.T && blk < (unsigned)g.CB;
   } else {
+    bl = 0u;
     blk = grp;
     xo = ct * 64u + slot;
     lane_ok = xo < (unsigned)g.Wo;
+  }
+  // Buffer addressing: the resources start at the workgroup's first block of its sample and span the blocks it owns, a lane's
+  // three column offsets (clamped into the plane) and its output offset stay in registers for the whole walk and a row is a
+  // SCALAR offset - no address arithmetic in the vector unit (flat 64-bit addresses cost ~17 of the ~135 instructions per
+  // output row).  A lane without an output gets an offset past the resource: the hardware drops its stores.
+  const unsigned blk0 = g.T > 1 ? grp * (unsigned)g.T : grp;            // (wave-uniform)
+  const unsigned nblk = (unsigned)g.CB - blk0 < (unsigned)g.T ? (unsigned)g.CB - blk0 : (unsigned)g.T;
+  const unsigned plane_in = (unsigned)(g.H * g.W) * 16u, plane_out = (unsigned)(g.Ho * g.Wo) * 16u;
+  const fq_rsrc xr = make_rsrc(x + ((size_t)smp * g.CB + blk0) * plane_in, (int64_t)nblk * plane_in);
+  const fq_rsrc yr = make_rsrc(y + ((size_t)smp * g.CB + blk0) * plane_out, (int64_t)nblk * plane_out);
+  const int xc = (int)xo * S;                                           // centre input column
+  unsigned xoff[3], cmask[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int col = xc + k - 1;
+    const int cc = col < 0 ? 0 : (col < g.W ? col : g.W - 1);
+    xoff[k] = lane_ok ? bl * plane_in + (unsigned)cc * 16u + qd * 4u : 0u;
+    cmask[k] = (lane_ok && col >= 0 && col < g.W) ? 0xFFFFFFFFu : 0u;  // out-of-image taps: the byte pattern of code 0
+  }
+  const unsigned yoff = lane_ok ? bl * plane_out + xo * 16u + qd * 4u : 0x80000000u;
+  const unsigned row_in = (unsigned)g.W * 16u, row_out = (unsigned)g.Wo * 16u;
+  // one input row -> 3 columns x 4 dequantised channels, in two steps: `fetch` requests the three dwords (every load
+  // unconditional, from a row clamped into the plane: a load under a lane condition is an exec-masked branch of its
+  // own with a wait behind it; a repeated row comes from the L1), `cook` dequantises - a row outside the image is all zeros
+  // (code 0), chosen by a SCALAR branch.
+  struct Row { f2 v[3][2]; };
+  struct Raw { unsigned d[3]; };
+  const int last_in = g.H - 1;
+  auto fetch = [&](int r, Raw& w) __attribute__((always_inline)) {
+    const int rr = r < 0 ? 0 : (r < last_in ? r : last_in);
+    const unsigned so = (unsigned)rr * row_in;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w.d[k] = __float_as_uint(buf_ld_f32(xr, xoff[k], so));
+  };
+  float sx = 0.0f;                                                      // (set once the threshold has arrived)
+  auto cook = [&](int r, const Raw& w, Row& row) __attribute__((always_inline)) {
+    if (r >= 0 && r < g.H) {
+      const f2 sx2 = (f2){sx, sx};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        // the stored byte of an unsigned code is code ^ 0x80: one xor per dword, then the byte-to-float conversions
+        const unsigned d = (SIGNED_IN ? w.d[k] : w.d[k] ^ 0x80808080u) & cmask[k];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f2 code;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const unsigned byte = (d >> (8 * (2 * j + e))) & 255u;
+            code[e] = SIGNED_IN ? (float)(int)(int8_t)byte : (float)byte;
+          }
+          row.v[k][j] = code * sx2;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) row.v[k][0] = row.v[k][1] = (f2){0.0f, 0.0f};
+    }
+  };
+  // ---- the ring: every row it holds is requested NOW, ahead of the weights and the thresholds ---------------------------------
+  // S == 1: entry j <-> input row j - 1 (output row t cooks entry t + 2);  S == 2: row -1 (zeros), then pairs: entry t <-> input
+  // rows 2t, 2t + 1
+  // (the run-time epilogue keeps bias and activation selectors alive: a shorter ring there - an in-flight register must never
+  // be spilled)
+  constexpr int NR = S == 1 ? (EPI == kEpiRuntime ? 3 : FQ_DW16_RING) : FQ_DW16_RING2;
+  Raw ring[NR], ring_b[S == 1 ? 1 : NR], first;
+  if (S == 1) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) fetch(j - 1, ring[j]);
+  } else {
+    fetch(-1, first);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      fetch(2 * j, ring[j]);
+      fetch(2 * j + 1, ring_b[j]);
+    }
+  }
+  // (weights and per-channel constants as 44 loads under a lane condition: bounded buffer loads - no branches, ~250
+  // instructions fewer per wavefront - were measured and are NOT faster among batches in flight, -0.4 ... -0.6 % with the ring
+  // they leave registers for, profiles/r5_dw16_study.txt)
+  const unsigned ch = (lane_ok ? blk : 0u) * 16u + qd * 4u;             // first of this lane's four channels
+  f2 wt[9][2], bsc[2], bsh[2];
+  float bch[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool cok = lane_ok && ch + c < (unsigned)g.C;                 // channels past C: zero weights, code 0 out
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t][c >> 1][c & 1] = cok ? wgt[(ch + c) * 9 + t] : 0.0f;
+    bch[c] = cok && bias != nullptr ? bias[ch + c] : 0.0f;
+    bsc[c >> 1][c & 1] = cok ? (bn_scale != nullptr ? bn_scale[ch + c] : 1.0f) : 0.0f;
+    bsh[c >> 1][c & 1] = cok && bn_shift != nullptr ? bn_shift[ch + c] : 0.0f;
   }
   // the batch statistic only feeds current_input_max here (the reference computes it in every mode, convert_conv2d.py:56)
   const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, blockIdx.x == 0);
   const QParams q = make_qparams(max_, levels, lo_neg_max != 0, eps);
   const QParams q2 = make_qparams(out_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
-  const float sx = q.scale;
+  sx = q.scale;
   const int ubias2 = 128 - g.out_zoff;
-  const unsigned ch = (lane_ok ? blk : 0u) * 16u + qd * 4u;             // first of this lane's four channels
-  float wt[9][4], bch[4], bsc[4], bsh[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const bool cok = lane_ok && ch + c < (unsigned)g.C;                 // channels past C: zero weights, code 0 out
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t][c] = cok ? wgt[(ch + c) * 9 + t] : 0.0f;
-    bch[c] = cok && bias != nullptr ? bias[ch + c] : 0.0f;
-    bsc[c] = cok ? (bn_scale != nullptr ? bn_scale[ch + c] : 1.0f) : 0.0f;
-    bsh[c] = cok && bn_shift != nullptr ? bn_shift[ch + c] : 0.0f;
-  }
-  const unsigned* xin = reinterpret_cast<const unsigned*>(x) + (((size_t)smp * g.CB + (lane_ok ? blk : 0u)) * g.H * g.W) * 4u + qd;
-  unsigned* yout = reinterpret_cast<unsigned*>(y) + (((size_t)smp * g.CB + (lane_ok ? blk : 0u)) * g.Ho * g.Wo) * 4u + qd;
-  const int xc = (int)xo * S;                                           // centre input column
-  // one input row -> 3 columns x 4 dequantised channels, in two steps: `fetch` requests the three dwords (every load
-  // unconditional, from an address clamped into the plane: a load under a lane condition is an exec-masked branch of its own
-  // with a wait behind it), `cook` selects the padding pattern and dequantises.  The rows are fetched FQ_DW16_DEPTH output rows
-  // ahead of their use through three sets of registers in rotation (no copies: a copy needs the loaded value): with the fetch
-  // in the iteration that uses it, a lane's walk down the plane was a chain of Ho load latencies - 14 x 14 and 7 x 7 planes,
-  // 19 MB per layer, took 18-22 us.
-  struct Row { float v[3][4]; };
-  struct Raw { unsigned d[3]; };
-  auto fetch = [&](int r, Raw& w) __attribute__((always_inline)) {
-    const int rr = r < 0 ? 0 : (r < g.H ? r : g.H - 1);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int col = xc + k - 1;
-      const int cc = col < 0 ? 0 : (col < g.W ? col : g.W - 1);
-      w.d[k] = xin[((size_t)rr * g.W + cc) * 4u];
-    }
-  };
-  auto cook = [&](int r, const Raw& w, Row& row) __attribute__((always_inline)) {
-    const bool rok = lane_ok && r >= 0 && r < g.H;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int col = xc + k - 1;
-      // the stored byte of an unsigned code is code ^ 0x80: one xor per dword, then the byte-to-float conversions
-      const unsigned d = (rok && col >= 0 && col < g.W) ? (SIGNED_IN ? w.d[k] : w.d[k] ^ 0x80808080u) : 0u;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const unsigned byte = (d >> (8 * c)) & 255u;
-        const float code = SIGNED_IN ? (float)(int)(int8_t)byte : (float)byte;
-        row.v[k][c] = code * sx;
-      }
-    }
-  };
   float m = 0.0f;
   const unsigned nn_xor2 = fq_nonneg_xor(ubias2);
   // the walk down the plane, instantiated with the 5-instruction quantiser of non-negative output ranges and with the generic
   // one (a run-time choice between the two inside the loop computes BOTH for every output and selects)
   auto walk = [&](auto nn_c) __attribute__((always_inline)) {
     constexpr bool NN = decltype(nn_c)::value;
-    Row ra, rb, rc;
+    // An input row is cooked ONCE and spent at once: it adds the taps of kernel row `kr` to the accumulators of the (up to
+    // three) output rows it belongs to - A-part (kr = 0) starts the row below from zero, B-part continues this row, C-part
+    // completes the row above, which is then finished and stored.  Every accumulator still sees its nine taps in row-major
+    // order from 0 (the order of the fp32 form), and what stays alive between steps is 4 sums per output row in progress
+    // instead of three cooked rows of 12 values (round 5: the registers went to the ring).
+    auto taps = [&](int kr, const Row& R, f2 (&a)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) ra.v[k][c] = rb.v[k][c] = rc.v[k][c] = 0.0f;      // (row -1: code 0 dequantises to 0)
-    // output row r from the window (A, B, C) = input rows above / at / below
-    auto emit = [&](int r, const Row& A, const Row& B, const Row& C) __attribute__((always_inline)) {
+        for (int k = 0; k < 3; ++k) a[j] = fma2(wt[3 * kr + k][j], R.v[k][j], a[j]);
+    };
+    auto emit = [&](int r, const f2 (&a)[2]) __attribute__((always_inline)) {
       float v[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float acc = 0.0f;
+      for (int j = 0; j < 2; ++j) {
+        f2 acc = a[j];
+        if (EPI == kEpiRuntime) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) acc = fmaf(wt[k][c], A.v[k][c], acc);
+          for (int e = 0; e < 2; ++e)
+            v[2 * j + e] = dw_finish<EPI>(acc[e], bias != nullptr, bch[2 * j + e], bn_scale != nullptr, bsc[j][e], bsh[j][e], act);
+        } else {
+          acc = acc * bsc[j];
+          acc = acc + bsh[j];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) acc = fmaf(wt[3 + k][c], B.v[k][c], acc);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) acc = fmaf(wt[6 + k][c], C.v[k][c], acc);
-        acc = dw_finish<EPI>(acc, bias != nullptr, bch[c], bn_scale != nullptr, bsc[c], bsh[c], act);
-        v[c] = acc;
-        m = fmaxf(m, fabsf(acc));
+          for (int e = 0; e < 2; ++e) {
+            const float t = fmaxf(acc[e], 0.0f);
+            v[2 * j + e] = EPI == kEpiBnRelu6 ? fminf(t, 6.0f) : t;
+          }
+        }
       }
-      if (lane_ok) {
-        const int packed = fq_pack4<NN>(v[0], v[1], v[2], v[3], q2, ubias2, nn_xor2);
-        yout[((size_t)r * g.Wo + xo) * 4u] = (unsigned)packed;
-      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) m = fmaxf(m, fabsf(v[c]));
+      const int packed = fq_pack4<NN>(v[0], v[1], v[2], v[3], q2, ubias2, nn_xor2);
+      buf_st_f32(yr, yoff, (unsigned)r * row_out, __int_as_float(packed));
     };
-    // The walk is unrolled over the period of BOTH rotations - the fetched sets and the window's rows change roles instead of
-    // being copied (24 register moves per output row otherwise, of ~140 instructions).
-    constexpr bool AHEAD = FQ_DW16_DEPTH != 0;        // (0: fetch and use in the same step - the tuning baseline)
-    int r = 0;
+    const f2 zero2 = (f2){0.0f, 0.0f};
+    // The walk is unrolled over the period of BOTH rotations - the ring's entries and the accumulators change roles instead
+    // of being copied: every index below is a constant once the inner loop is unrolled.
+    Row row;
     if (S == 1) {
-      // output row r needs input rows r - 1, r, r + 1: rows (A, B) carried, row r + 1 cooked into C from the set fetched two
-      // output rows ago
-      Raw w0, w1, w2;
-      fetch(0, w0);
-      cook(0, w0, rb);
-      if (AHEAD) {
-        fetch(1, w0);
-        fetch(2, w1);
-      }
-      auto step = [&](Raw& mine, Raw& far, const Row& A, const Row& B, Row& C) __attribute__((always_inline)) {
-        if (AHEAD) fetch(r + 3, far);
-        else fetch(r + 1, mine);
-        cook(r + 1, mine, C);
-        emit(r, A, B, C);
-        ++r;
-      };
-      while (r < g.Ho) {
-        step(w0, w2, ra, rb, rc);
-        if (r >= g.Ho) break;
-        step(w1, w0, rb, rc, ra);
-        if (r >= g.Ho) break;
-        step(w2, w1, rc, ra, rb);
+      // ring entry j = input row j - 1: A-part of output row j, B-part of j - 1, C-part of j - 2; the sums of output row t live
+      // in acc[t % 3]
+      constexpr int P = NR % 3 == 0 ? NR : 3 * NR;                      // steps until ring entry and accumulator roles repeat
+      f2 acc[3][2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) acc[i][0] = acc[i][1] = zero2;
+      cook(-1, ring[0], row);
+      fetch(NR - 1, ring[0]);
+      taps(0, row, acc[0]);
+      cook(0, ring[1], row);
+      fetch(NR, ring[1]);
+      taps(1, row, acc[0]);
+      if (1 < nrows) taps(0, row, acc[1]);
+      for (int t0 = 0; t0 < nrows; t0 += P) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const int t = t0 + u;
+          if (t >= nrows) break;
+          cook(t + 1, ring[(u + 2) % NR], row);
+          fetch(t + 1 + NR, ring[(u + 2) % NR]);
+          taps(2, row, acc[u % 3]);
+          emit(t, acc[u % 3]);
+          if (t + 1 < nrows) taps(1, row, acc[(u + 1) % 3]);
+          acc[(u + 2) % 3][0] = acc[(u + 2) % 3][1] = zero2;
+          if (t + 2 < nrows) taps(0, row, acc[(u + 2) % 3]);
+        }
       }
     } else {
-      // output row r needs input rows 2r - 1 (the previous output row's 2r' + 1: its C is this row's A), 2r, 2r + 1
-      // (fetched ONE output row = two input rows ahead: two more sets cost the fourth wavefront per SIMD and bought nothing)
-      Raw a0, b0, a1, b1;
-      if (AHEAD) {
-        fetch(0, a0);
-        fetch(1, b0);
-      }
-      auto step = [&](Raw& ma, Raw& mb, Raw& fa, Raw& fb, const Row& A, Row& B, Row& C) __attribute__((always_inline)) {
-        if (AHEAD) { fetch(2 * r + 2, fa); fetch(2 * r + 3, fb); }
-        else { fetch(2 * r, ma); fetch(2 * r + 1, mb); }
-        cook(2 * r, ma, B);
-        cook(2 * r + 1, mb, C);
-        emit(r, A, B, C);
-        ++r;
-      };
-      while (r < g.Ho) {
-        step(a0, b0, a1, b1, ra, rb, rc);
-        if (r >= g.Ho) break;
-        step(a1, b1, a0, b0, rc, rb, ra);
+      // output row r: input rows 2r - 1 (A; it was the C of the row above), 2r (B), 2r + 1 (C); sums in acc[r % 2]
+      static_assert(S == 1 || NR % 2 == 0, "the ring's period must be a multiple of the accumulators'");
+      f2 acc[2][2];
+      acc[0][0] = acc[0][1] = zero2;
+      cook(-1, first, row);
+      taps(0, row, acc[0]);
+      for (int t0 = 0; t0 < nrows; t0 += NR) {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+          const int r = t0 + u, t = r;
+          if (t >= nrows) break;
+          cook(2 * r, ring[u], row);
+          taps(1, row, acc[u & 1]);
+          cook(2 * r + 1, ring_b[u], row);
+          fetch(2 * (r + NR), ring[u]);
+          fetch(2 * (r + NR) + 1, ring_b[u]);
+          taps(2, row, acc[u & 1]);
+          emit(r, acc[u & 1]);
+          acc[(u + 1) & 1][0] = acc[(u + 1) & 1][1] = zero2;
+          if (t + 1 < nrows) taps(0, row, acc[(u + 1) & 1]);
+        }
       }
     }
   };

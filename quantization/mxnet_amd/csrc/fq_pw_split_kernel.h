@@ -207,8 +207,18 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
   __syncthreads();                                                      // panel, constants and the statistic table
   PW_STAMP(3);
   const int cvalid = g.Cout - (ch0 + ctl0 * 32);                       // valid output channels from this wavefront's first tile on
-  auto run = [&](auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+  QParams q2;
+  q2.lo = q2.hi = q2.denom = q2.scale = 0.0f;
+  q2.rden = 0.0;
+  if (OUT16) q2 = make_qparams(out_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
+  // DUAL (fq_pwconv_i8_c16_dual): y is fp32 AND g.y16 receives the codes of the same values under g.dual_thr - the trunk of a
+  // ResNet stored a second time, 1 B per element, for the next unit's first 1x1 (the shortcut keeps reading the fp32 tensor)
+  if (DUAL) q2 = make_qparams(g.dual_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
+  // (nn2_c: the CONSUMER's clip range of a C16 output starts at 0 - the five-instruction quantiser of fq_common.h writes its
+  // codes; round 5: until then only the second output's)
+  auto run = [&](auto bias_c, auto bn_c, auto act_c, auto nn2_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
+    constexpr bool NN2 = decltype(nn2_c)::value;
     // accumulators start at zero (the first MFMA takes the constant): initialising them with the +128 re-centring terms
     // keeps a second set of 16 * CW registers alive next to the destination of the first MFMAs; the terms are added as
     // integers in the epilogue instead (one VALU per output)
@@ -248,13 +258,6 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     const fq_rsrc yr = OUT16 ? make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp16 + (int64_t)cb0 * HW * 16, y16_bytes)
                              : make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp + (int64_t)(ch0 + ctl0 * 32) * plane4, y_bytes);
     const unsigned yo16 = (smp - s_base) * (unsigned)g.CBo * HW * 16u + p * 16u + 4u * h;
-    QParams q2;
-    q2.lo = q2.hi = q2.denom = q2.scale = 0.0f;
-    q2.rden = 0.0;
-    if (OUT16) q2 = make_qparams(out_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
-    // DUAL (fq_pwconv_i8_c16_dual): y is fp32 AND g.y16 receives the codes of the same values under g.dual_thr - the trunk of a
-    // ResNet stored a second time, 1 B per element, for the next unit's first 1x1 (the shortcut keeps reading the fp32 tensor)
-    if (DUAL) q2 = make_qparams(g.dual_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
     const fq_rsrc yr16 = make_rsrc(DUAL ? g.y16 + s_base * y_samp16 + (int64_t)cb0 * HW * 16 : reinterpret_cast<char*>(y),
                                    DUAL ? y16_bytes : 0);
     const int ubias2 = 128 - g.out_zoff;
@@ -312,8 +315,7 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
           // store per lane instead of these four 4-byte ones - the halves exchanged with lane ^ 32 - was built and measured:
           // slower in every C16-writing kernel, ResNet-50 offline 41.7 -> 40.1 k images/s)
           const int packed = DUAL ? fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, 0x80808080u)
-                                  : pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
-                                                fq_code_int(vq[3], q2), ubias2);
+                                  : fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, fq_nonneg_xor(ubias2));
           const bool blk_ok = !MASKED || 16 * (gq >> 1) < cv;             // a whole block past Cout does not exist
           buf_st_f32(OUT16 ? yr : yr16, blk_ok ? yo16 : 0x80000000u,
                      (unsigned)((c * 2 + (gq >> 1)) * (int)HW * 16 + 8 * (gq & 1)), __int_as_float(packed));
@@ -344,16 +346,24 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     }
   };
   using std::integral_constant;
+  auto go = [&](auto nn2_c) __attribute__((always_inline)) {
+    if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
+      run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, nn2_c);
+    else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
+      run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{}, nn2_c);
+    else if (fbias == nullptr && has_bn && act == FQ_ACT_NONE)
+      run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{}, nn2_c);
+    else
+      run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, nn2_c);
+  };
   if (cvalid <= 0) {
     // nothing to multiply (a channel group wider than the layer): this wavefront only helped to quantise the tile
-  } else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
-    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{});
-  else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
-    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{});
-  else if (fbias == nullptr && has_bn && act == FQ_ACT_NONE)
-    run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{});
-  else
-    run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{});
+  } else if constexpr (OUT16 && !DUAL) {                                // (only a kernel that writes codes is instantiated twice)
+    if (fq_nonneg(q2)) go(std::true_type{});
+    else go(std::false_type{});
+  } else {
+    go(std::false_type{});
+  }
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < cols / HW)

@@ -176,7 +176,10 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
     asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
     bfrag[kt] = f;
   };
-  auto tile_done = [&](const Pix& px, auto bias_c, auto bn_c, auto act_c) __attribute__((always_inline)) {
+  // (nn2_c: the CONSUMER's clip range of a C16 output starts at 0 - the five-instruction quantiser of fq_common.h writes its
+  // codes; round 5: it did so for the second output only, the code output took the nine-instruction one whatever its range)
+  auto tile_done = [&](const Pix& px, auto bias_c, auto bn_c, auto act_c, auto nn2_c) __attribute__((always_inline)) {
+    constexpr bool NN2 = decltype(nn2_c)::value;
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
     const unsigned yoff = (unsigned)((((int64_t)px.smp * g.Cout + 4 * h) * plane + px.p) * 4);
     // PART: every store (and residual load) of a channel tile goes through a resource over the whole tensor with an
@@ -259,8 +262,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
           // (DUAL: the host only asks for unsigned codes of a non-negative range - the five-instruction quantiser, fq_common.h;
           // 167 registers: the third workgroup per CU still fits)
           const int packed = DUAL ? fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, 0x80808080u)
-                                  : pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
-                                                fq_code_int(vq[3], q2), ubias2);
+                                  : fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, fq_nonneg_xor(ubias2));
           if (PART && !DUAL) {                         // a whole block past Cout (Cout % 32 == 16) does not exist
             const int blk = 2 * ct + (gq >> 1);
             const unsigned o16 = (unsigned)((((int64_t)px.smp * g.CBo + (blk < g.CBo ? blk : 0)) * plane + px.p) * 16 +
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   };
   // one tile: its first slab is already in `first`; the prefetch of the following slab / tile alternates buffers
   auto run_tile = [&](int64_t t, float (&first)[16], float (&second)[16], auto bias_c, auto bn_c, auto act_c,
-                      auto nn_c) __attribute__((always_inline)) {
+                      auto nn_c, auto nn2_c) __attribute__((always_inline)) {
     const Pix cur = nxt;
     const int64_t tn = t + 1 < g.tiles ? t + 1 : g.tiles - 1;
     nxt = pix_of(tn);
@@ -307,19 +309,19 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
       quant(kt, mine, nn_c);
       FQ_PIN();
     }
-    tile_done(cur, bias_c, bn_c, act_c);
+    tile_done(cur, bias_c, bn_c, act_c, nn2_c);
     FQ_PIN();
   };
-  auto run_all = [&](auto bias_c, auto bn_c, auto act_c, auto nn_c) __attribute__((always_inline)) {
+  auto run_all = [&](auto bias_c, auto bn_c, auto act_c, auto nn_c, auto nn2_c) __attribute__((always_inline)) {
     if (KT & 1) {                                                       // the buffers swap roles from tile to tile
       int64_t t = t_begin;
       for (; t + 1 < t_end; t += 2) {
-        run_tile(t, bufa, bufb, bias_c, bn_c, act_c, nn_c);
-        run_tile(t + 1, bufb, bufa, bias_c, bn_c, act_c, nn_c);
+        run_tile(t, bufa, bufb, bias_c, bn_c, act_c, nn_c, nn2_c);
+        run_tile(t + 1, bufb, bufa, bias_c, bn_c, act_c, nn_c, nn2_c);
       }
-      if (t < t_end) run_tile(t, bufa, bufb, bias_c, bn_c, act_c, nn_c);
+      if (t < t_end) run_tile(t, bufa, bufb, bias_c, bn_c, act_c, nn_c, nn2_c);
     } else {
-      for (int64_t t = t_begin; t < t_end; ++t) run_tile(t, bufa, bufb, bias_c, bn_c, act_c, nn_c);
+      for (int64_t t = t_begin; t < t_end; ++t) run_tile(t, bufa, bufb, bias_c, bn_c, act_c, nn_c, nn2_c);
     }
   };
   // the compile-time epilogues (BatchNorm, no bias, fixed activation: the fused-inference case) come with the 5-instruction
@@ -328,16 +330,25 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   using std::true_type;
   using std::false_type;
   const bool nn = fq_nonneg(q);
-  if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU)
-    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, true_type{});
-  else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
-    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{}, true_type{});
-  else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_NONE)
-    run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{}, true_type{});
-  else if (nn)
-    run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, true_type{});
-  else
-    run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, false_type{});
+  auto go = [&](auto nn2_c) __attribute__((always_inline)) {
+    if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU)
+      run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, true_type{}, nn2_c);
+    else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
+      run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{}, true_type{}, nn2_c);
+    else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_NONE)
+      run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{}, true_type{}, nn2_c);
+    else if (nn)
+      run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, true_type{}, nn2_c);
+    else
+      run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, false_type{}, nn2_c);
+  };
+  // (only a kernel that writes codes is instantiated twice)
+  if constexpr (OUT16 && !DUAL) {
+    if (fq_nonneg(q2)) go(true_type{});
+    else go(false_type{});
+  } else {
+    go(false_type{});
+  }
 
   if (has_stat) {
     __syncthreads();

@@ -329,8 +329,16 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
           m = fmaxf(m, fabsf(v));
         }
         if (OUT16) {     // channels 8 gq + 4 h .. + 3 of the lane's pixel = bytes 8 (gq & 1) + 4 h .. of block 2 ct + gq / 2
-          const int packed = pack4_codes(fq_code_int(vq[0], q2), fq_code_int(vq[1], q2), fq_code_int(vq[2], q2),
-                                         fq_code_int(vq[3], q2), ubias2);
+          // (a clip range that starts at 0 - unsigned activations - takes the five-instruction quantiser of fq_common.h: a
+          // scalar branch; the empty asm statements keep it one - without them both forms are computed and selected)
+          int packed;
+          if (fq_nonneg(q2)) {
+            asm volatile("");
+            packed = fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, fq_nonneg_xor(ubias2));
+          } else {
+            asm volatile("");
+            packed = fq_pack4<false>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, 0u);
+          }
           buf_st_f32(yr, cur.jp * 16u + (unsigned)(8 * (gq & 1) + 4 * h), (unsigned)((2 * ct + (gq >> 1)) * HWo * 16),
                      __int_as_float(packed));
         }
