@@ -7,18 +7,18 @@
 // tuning build: -DFQ_DW16_V=<bits>  4: the short quantiser for non-negative output ranges (bits 1 and 2 - unconditional loads
 // from clamped addresses + select instead of 62 exec-masked loads, stride 2 keeping the row it shares with the next output
 // row - are built in since r4: 526 -> 473 us over MobileNetV2's ten depthwise shapes at batch 128, tools/dw16bench.py).
-// -DFQ_DW16_RING=<3|4|5> / -DFQ_DW16_RING2=<2>: input rows (stride 2: row pairs) in flight per lane.
+// -DFQ_DW16_RING=<3|4|5> / -DFQ_DW16_RING2=<2|3>: input rows (stride 2: row pairs) in flight per lane.
 #ifndef FQ_DW16_V
 #define FQ_DW16_V 7
 #endif
-// input rows in flight per lane, stride 1 / row PAIRS, stride 2 (even): ordinary buffer loads the compiler waits for.  (Issued and
+// input rows in flight per lane, stride 1 / row PAIRS, stride 2: ordinary buffer loads the compiler waits for.  (Issued and
 // awaited by hand - inline assembly and hand-counted s_waitcnt, because hipcc drains the ring where the paths into the
 // unrolled walk meet - six rows were another +0.4 % images/s, but the compiler does not know that such registers are pending:
 // it spilled and copied them, and full-size repeats beside a competing stream differed - tests/test_gpu_determinism.py.)
 #ifndef FQ_DW16_RING
 #define FQ_DW16_RING 4
 #endif
-#ifndef FQ_DW16_RING2
+#ifndef FQ_DW16_RING2                  // (3 pairs: 124-128 registers, -0.2 % images/s)
 #define FQ_DW16_RING2 2
 #endif
 
@@ -265,21 +265,21 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
       }
     } else {
       // output row r: input rows 2r - 1 (A; it was the C of the row above), 2r (B), 2r + 1 (C); sums in acc[r % 2]
-      static_assert(S == 1 || NR % 2 == 0, "the ring's period must be a multiple of the accumulators'");
+      constexpr int P = NR % 2 == 0 ? NR : 2 * NR;                      // steps until ring entry and accumulator roles repeat
       f2 acc[2][2];
       acc[0][0] = acc[0][1] = zero2;
       cook(-1, first, row);
       taps(0, row, acc[0]);
-      for (int t0 = 0; t0 < nrows; t0 += NR) {
+      for (int t0 = 0; t0 < nrows; t0 += P) {
 #pragma unroll
-        for (int u = 0; u < NR; ++u) {
+        for (int u = 0; u < P; ++u) {
           const int r = t0 + u, t = r;
           if (t >= nrows) break;
-          cook(2 * r, ring[u], row);
+          cook(2 * r, ring[u % NR], row);
           taps(1, row, acc[u & 1]);
-          cook(2 * r + 1, ring_b[u], row);
-          fetch(2 * (r + NR), ring[u]);
-          fetch(2 * (r + NR) + 1, ring_b[u]);
+          cook(2 * r + 1, ring_b[u % NR], row);
+          fetch(2 * (r + NR), ring[u % NR]);
+          fetch(2 * (r + NR) + 1, ring_b[u % NR]);
           taps(2, row, acc[u & 1]);
           emit(r, acc[u & 1]);
           acc[(u + 1) & 1][0] = acc[(u + 1) & 1][1] = zero2;
