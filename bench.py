@@ -349,14 +349,14 @@ def main():
                          "host runs ahead of a GPU-bound stream: 108.0 vs 109.3 k images/s), with several batches in flight the "
                          "eager host becomes the limit (100.7 k on a box with a slow host) and replay lifts it (127.7-128.8 k in "
                          "the same call).  0: every step launched from the host")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("FQ_BENCH_STREAMS", "4")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("FQ_BENCH_STREAMS", "0")),
                     help="evaluation steps in flight: step i runs on HIP stream i %% S (same net; per-forward device state is "
                          "kept per stream), so that the ramp and the tail of one batch's ~30 kernels fill with the other batch's work "
                          "(independent batches; every step's kernels, results and counters are what they are with S = 1).  "
-                         "1: one stream, the figure of rounds 1-3; the line reports that too (`single_stream`).  Default 4 (rounds 4-5: 3): "
-                         "alternating runs of 4 against 3 gave +0.6 % on the default workload, +1.3 % / 0.0 % on ResNet-50 online / "
-                         "offline and +2.6 % on MobileNetV2 W4 offline, whose code-tensor kernels are the shortest; 5 and 6 lose "
-                         "8-12 % there (profiles/r5_lanes4_ab.txt)")
+                         "1: one stream, the figure of rounds 1-3; the line reports that too (`single_stream`).  0 (default): 4 where the "
+                         "layers hand integer codes over (--offline: short, vector-unit-bound kernels; 4 against 3 +2.6 % on "
+                         "MobileNetV2 W4, 5 and 6 lose 8-12 %), else 3 (fp32 tensors between the layers: 4 against 3 was +0.6 / "
+                         "+0.8 % on two boxes and -1.1 % (sd 0.05) on a third; profiles/r5_lanes4_ab.txt)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -424,7 +424,9 @@ def main():
     # Steps in flight (--streams): evaluation only, eager launches only.  ONE net: a forward on a side stream keeps its
     # per-forward device state (statistic arena, batch-statistic slots, workspaces) per stream (quantize/fuse.py,
     # quantize/convert/_blocks.py: scalar_slot), so forwards of independent batches may overlap on the device
-    n_streams = max(1, args.streams) if args.phase == "eval" else 1
+    if args.streams <= 0:
+        args.streams = 4 if args.offline else 3
+    n_streams = args.streams if args.phase == "eval" else 1
     net = prepare_net()
     nets = [net] * n_streams
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]

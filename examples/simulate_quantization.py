@@ -105,11 +105,12 @@ EXTRA_FLAGS = [
     (['--export-scale-table'], dict(type=str, default=None,
                                     help='after calibration write an ncnn-style int8 scale table (per-channel weight scales '
                                          'after BN folding, one input scale per layer; quantize/freeze/scale_table.py)')),
-    (['--eval-streams'], dict(type=int, default=4,
+    (['--eval-streams'], dict(type=int, default=0,
                               help='batches in flight during evaluation, one HIP stream each (quantize/fuse.py keeps the '
                                    'per-forward device state per stream): the ramp and the tail of one batch\'s kernels fill '
                                    'with the next batch\'s work; results are those of one batch at a time.  Calibration passes '
-                                   '(update_ema) always run one batch at a time.  (default: 4, as bench.py)')),
+                                   '(update_ema) always run one batch at a time.  (default 0: as bench.py - 4 with '
+                                   '--quantize-input-offline, where the layers hand integer codes over, else 3)')),
     (['--eval-graph'], dict(type=int, default=2,
                             help='evaluation of a fused net may replay a hipGraph of the step per lane (static input / label '
                                  'buffers the batches are copied into; the first batch of a lane and a ragged last batch launch '
@@ -144,6 +145,8 @@ def parse_args(argv=None):
         parser.error("--model is required")
     if opt.use_gn:
         parser.error("--use-gn: the model zoo of this build has no GroupNorm variants (gluoncv.nn.GroupNorm is absent)")
+    if opt.eval_streams <= 0:
+        opt.eval_streams = 4 if opt.quantize_input_offline else 3
     if int(os.environ.get("RANK", "0")) == 0:
         print()
         banner('Settings', ["{0: <25}: {1}".format(k, v) for k, v in vars(opt).items()])
