@@ -632,7 +632,7 @@ def main():
     # The bracketed steps (eager, alone, two marker packets per launch) cost their block 1.5-2 %: they ride in every THIRD block
     # (0, 3, 6 ...), so that with three or more blocks the median block - `value` - is one without them, while the roofline
     # figures still come from events inside the timed region.  Both kinds of block are reported (`consistency`).
-    EVENT_BLOCK_EVERY = 3
+    EVENT_BLOCK_EVERY = max(1, int(os.environ.get("FQ_BENCH_EVENT_BLOCK_EVERY", "3")))       # (1: every block, as rounds 1-4)
     blocks = [timed_block(0)]
     while sum(blocks) < args.min_region_s and len(blocks) < args.max_repeats:
         blocks.append(timed_block(len(blocks) * args.steps, with_events=len(blocks) % EVENT_BLOCK_EVERY == 0))
