@@ -33,14 +33,13 @@ using namespace fqi;
 //
 // Mapping: a lane owns one output column and a QUARTER of a 16-channel block (4 channels = one dword of a pixel's 16 bytes);
 // the 64 lanes of a wavefront are 16 columns x 4 quarters, so a row access of a wavefront is 256 contiguous bytes.  A
-// workgroup (4 wavefronts = 64 column slots) walks down the output rows of its (sample, block(s)): every input row is
-// dequantised once (3 columns x 4 channels) and added to the sums of the three output rows it belongs to; planes narrower
-// than 33 columns put several blocks side by side in the 64 slots.  Out-of-image taps take the byte pattern of code 0 before they are dequantised.
+// workgroup (4 wavefronts = 64 column slots) walks down the output rows of 64 consecutive columns of its sample (columns
+// of one block, then of the next): every input row is dequantised once (3 columns x 4 channels) and added to the sums of
+// the three output rows it belongs to.  Out-of-image taps take the byte pattern of code 0 before they are dequantised.
 struct Dw16Geom {
   int C, CB, H, W, Ho, Wo;
-  int T;                     // blocks side by side in a workgroup's 64 column slots (W <= 32), else 1
-  int col_tiles;             // ceil(Wo / 64) when T == 1
-  int groups;                // ceil(CB / T)
+  int wgs_per_sample;        // ceil(CB * Wo / 64): a workgroup's 64 column slots are consecutive columns of the sample
+  int span;                  // blocks such a run of 64 columns can touch
   float out_levels;
   int out_lo_neg, out_zoff, in_zoff;
 };
@@ -75,31 +74,25 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
     int act, float* __restrict__ stat_out, const float* __restrict__ out_thr) {
   __shared__ float red[4];
   const unsigned slot = threadIdx.x >> 2, qd = threadIdx.x & 3u;        // column slot 0..63, quarter of the block
-  // workgroup -> (sample, block group, column tile)
-  unsigned b = blockIdx.x;
-  const unsigned ct = b % (unsigned)g.col_tiles;
-  b /= (unsigned)g.col_tiles;
-  const unsigned grp = b % (unsigned)g.groups, smp = b / (unsigned)g.groups;
+  // workgroup -> (sample, 64 consecutive output columns of the sample's CB x Wo columns): a lane's column may belong to the
+  // next block than its neighbour's, so 56- and 28-wide planes fill all 64 slots (one block - or a whole number of them -
+  // per workgroup left an eighth of the lanes idle there, and on 112-wide planes whose second column tile is 48 wide)
+  const unsigned wgs = (unsigned)g.wgs_per_sample;
+  const unsigned grp = blockIdx.x % wgs, smp = blockIdx.x / wgs;
+  const unsigned cols_total = (unsigned)(g.CB * g.Wo);
+  const unsigned gcol = grp * 64u + slot;
+  const bool lane_ok = gcol < cols_total;
+  const unsigned blk = (lane_ok ? gcol : cols_total - 1u) / (unsigned)g.Wo;         // this lane's block ...
+  const unsigned xo = (lane_ok ? gcol : cols_total - 1u) - blk * (unsigned)g.Wo;    // ... and output column
+  const unsigned blk0 = (grp * 64u) / (unsigned)g.Wo;                   // first block of the workgroup (wave-uniform)
+  const unsigned bl = blk - blk0;
   const int nrows = g.Ho;
-  unsigned bl, blk, xo;                                                 // this lane's block (inside the group, in the layer) and output column
-  bool lane_ok;
-  if (g.T > 1) {
-    bl = slot / (unsigned)g.Wo;
-    xo = slot - bl * (unsigned)g.Wo;
-    blk = grp * (unsigned)g.T + bl;
-    lane_ok = bl < (unsigned)g.T && blk < (unsigned)g.CB;
-  } else {
-    bl = 0u;
-    blk = grp;
-    xo = ct * 64u + slot;
-    lane_ok = xo < (unsigned)g.Wo;
-  }
   // Buffer addressing: the resources start at the workgroup's first block of its sample and span the blocks it owns, a lane's
   // three column offsets (clamped into the plane) and its output offset stay in registers for the whole walk and a row is a
   // SCALAR offset - no address arithmetic in the vector unit (flat 64-bit addresses cost ~17 of the ~135 instructions per
   // output row).  A lane without an output gets an offset past the resource: the hardware drops its stores.
-  const unsigned blk0 = g.T > 1 ? grp * (unsigned)g.T : grp;            // (wave-uniform)
-  const unsigned nblk = (unsigned)g.CB - blk0 < (unsigned)g.T ? (unsigned)g.CB - blk0 : (unsigned)g.T;
+  const unsigned span = (unsigned)g.span;                               // blocks 64 consecutive columns can touch
+  const unsigned nblk = (unsigned)g.CB - blk0 < span ? (unsigned)g.CB - blk0 : span;
   const unsigned plane_in = (unsigned)(g.H * g.W) * 16u, plane_out = (unsigned)(g.Ho * g.Wo) * 16u;
   const fq_rsrc xr = make_rsrc(x + ((size_t)smp * g.CB + blk0) * plane_in, (int64_t)nblk * plane_in);
   const fq_rsrc yr = make_rsrc(y + ((size_t)smp * g.CB + blk0) * plane_out, (int64_t)nblk * plane_out);
@@ -323,14 +316,13 @@ int fq_dwconv3x3_c16(const void* x, const float* w, const float* bias, void* y, 
   Dw16Geom g;
   g.C = (int)c; g.CB = (int)((c + 15) / 16); g.H = (int)h; g.W = (int)wdt;
   g.Ho = (int)((h - 1) / stride + 1); g.Wo = (int)((wdt - 1) / stride + 1);
-  g.T = g.Wo <= 32 ? 64 / g.Wo : 1;
-  g.col_tiles = g.T > 1 ? 1 : (g.Wo + 63) / 64;
-  g.groups = (g.CB + g.T - 1) / g.T;
+  g.wgs_per_sample = (g.CB * g.Wo + 63) / 64;
+  g.span = (64 + g.Wo - 2) / g.Wo + 1;
   g.out_levels = act_levels(out_width, out_flags);
   g.out_lo_neg = (out_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
   g.out_zoff = (out_flags & FQ_ACT_SIGNED) ? 0 : 128;
   g.in_zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;
-  const int64_t grid = n * g.groups * g.col_tiles;
+  const int64_t grid = n * (int64_t)g.wgs_per_sample;
   FQ_REQUIRE(grid < (1ll << 31), "fq_dwconv3x3_c16: too many workgroups");
   const float levels = act_levels(in_width, in_flags);
   const int lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
