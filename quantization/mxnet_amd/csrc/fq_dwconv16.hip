@@ -185,6 +185,11 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
   const int ubias2 = 128 - g.out_zoff;
   float m = 0.0f;
   const unsigned nn_xor2 = fq_nonneg_xor(ubias2);
+  QParams qc = q2;                                                      // the clip range with the activation folded in (see emit)
+  if (EPI != kEpiRuntime) {
+    qc.lo = 0.0f;
+    if (EPI == kEpiBnRelu6) qc.hi = fminf(q2.hi, 6.0f);
+  }
   // the walk down the plane, instantiated with the 5-instruction quantiser of non-negative output ranges and with the generic
   // one (a run-time choice between the two inside the loop computes BOTH for every output and selects)
   auto walk = [&](auto nn_c) __attribute__((always_inline)) {
@@ -210,18 +215,18 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
           for (int e = 0; e < 2; ++e)
             v[2 * j + e] = dw_finish<EPI>(acc[e], bias != nullptr, bch[2 * j + e], bn_scale != nullptr, bsc[j][e], bsh[j][e], act);
         } else {
+          // ReLU / ReLU6 and the consumer's clip are ONE median: clip(relu6(a), lo <= 0, hi) == med3(a, 0, min(6, hi)) for
+          // every a (NaN -> 0 on both sides) - `qc` below - and the statistic max_i relu6(a_i) == min(max(0, max_i a_i), 6) is
+          // taken from the raw values and clamped once after the walk: a v_med3 less per output
           acc = acc * bsc[j];
           acc = acc + bsh[j];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float t = fmaxf(acc[e], 0.0f);
-            v[2 * j + e] = EPI == kEpiBnRelu6 ? fminf(t, 6.0f) : t;
-          }
+          v[2 * j] = acc[0];
+          v[2 * j + 1] = acc[1];
         }
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) m = fmaxf(m, fabsf(v[c]));
-      const int packed = fq_pack4<NN>(v[0], v[1], v[2], v[3], q2, ubias2, nn_xor2);
+      for (int c = 0; c < 4; ++c) m = EPI == kEpiRuntime ? fmaxf(m, fabsf(v[c])) : fmaxf(m, v[c]);
+      const int packed = fq_pack4<NN>(v[0], v[1], v[2], v[3], qc, ubias2, nn_xor2);
       buf_st_f32(yr, yoff, (unsigned)r * row_out, __int_as_float(packed));
     };
     const f2 zero2 = (f2){0.0f, 0.0f};
@@ -281,8 +286,9 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
       }
     }
   };
-  if ((FQ_DW16_V & 4) && fq_nonneg(q2)) walk(std::true_type{});
+  if ((FQ_DW16_V & 4) && fq_nonneg(qc)) walk(std::true_type{});      // (behind a ReLU every clipped value is >= 0, whatever the consumer's range)
   else walk(std::false_type{});
+  if (EPI == kEpiBnRelu6) m = fminf(m, 6.0f);
   if (stat_out != nullptr) {
     const float wm = wave_max_nonneg(lane_ok ? m : 0.0f);
     if ((threadIdx.x & 63u) == 0u) red[threadIdx.x >> 6] = wm;
