@@ -230,6 +230,11 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   auto run = [&](auto bias_c, auto bn_c, auto act_c, auto nn2_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
     constexpr bool NN2 = decltype(nn2_c)::value;
+    // (a code output behind the compile-time ReLU: activation and the consumer's clip as ONE median, the statistic from the raw
+    // values - fq_pw_split_kernel.h)
+    constexpr bool FOLD = OUT16 && ACT_M == FQ_ACT_RELU;
+    QParams qc = q2;
+    if (FOLD) qc.lo = 0.0f;
     v16i acc[NSL][PTW];
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl)
@@ -319,16 +324,16 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
             v = v * bsc[r];
             v = v + bsh[r];
           }
-          v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
+          if (!FOLD) v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
           vq[r] = v;
           if (!OUT16) {
             const unsigned off = partial ? (8 * gq + 4 * h + r < cvalid ? yo : 0x80000000u) : yo;
             buf_st_f32(yr, off, (unsigned)(8 * gq + r) * plane4, v);
           }
-          m = fmaxf(m, fabsf(v));
+          m = FOLD ? fmaxf(m, v) : fmaxf(m, fabsf(v));
         }
         if (OUT16) {                               // (fq_pw_split_kernel.h: the consumer's codes of the four values, 4 bytes)
-          const int packed = fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, fq_nonneg_xor(ubias2));
+          const int packed = fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], qc, ubias2, fq_nonneg_xor(ubias2));
           const bool blk_ok = !partial || 16 * (gq >> 1) < cvalid;
           const unsigned yo16 = (smp[t] - s_base) * (unsigned)g.CBo * HW * 16u + pp[t] * 16u + 4u * h;
           buf_st_f32(yr, blk_ok ? yo16 : 0x80000000u, (unsigned)((gq >> 1) * (int)HW * 16 + 8 * (gq & 1)), __int_as_float(packed));
@@ -355,18 +360,19 @@ __global__ __launch_bounds__(NW * 64, LB) void conv3x3_i8_kernel(
   if (cvalid <= 0) {
     // a channel group wider than the layer: this wavefront only helped to quantise the region
   } else {
-    auto go = [&](auto nn2_c) __attribute__((always_inline)) {
-      if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
-        run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, nn2_c);
-      else
-        run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, nn2_c);
+    auto go = [&](auto bias_c, auto bn_c, auto act_c, bool nn2) __attribute__((always_inline)) {
+      if constexpr (OUT16) {                                            // (only a kernel that writes codes is instantiated twice)
+        if (nn2) run(bias_c, bn_c, act_c, std::true_type{});
+        else run(bias_c, bn_c, act_c, std::false_type{});
+      } else {
+        run(bias_c, bn_c, act_c, std::false_type{});
+      }
     };
-    if constexpr (OUT16) {                                              // (only a kernel that writes codes is instantiated twice)
-      if (fq_nonneg(q2)) go(std::true_type{});
-      else go(std::false_type{});
-    } else {
-      go(std::false_type{});
-    }
+    // (the five-instruction output quantiser where the clipped values cannot be negative: behind the ReLU, or a range from 0)
+    if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
+      go(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, q2.denom > 0.0f);
+    else
+      go(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, fq_nonneg(q2));
   }
   PW_STAMP(4);
   if (has_stat) {

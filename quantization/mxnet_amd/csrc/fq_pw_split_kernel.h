@@ -219,6 +219,15 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
   auto run = [&](auto bias_c, auto bn_c, auto act_c, auto nn2_c) __attribute__((always_inline)) {
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
     constexpr bool NN2 = decltype(nn2_c)::value;
+    // A code output behind a compile-time ReLU / ReLU6: activation and the consumer's clip are ONE median - clip(relu6(v), lo
+    // <= 0, hi) == med3(v, 0, min(6, hi)) for every v, NaN -> 0 on both sides - and the statistic max_i relu6(v_i) ==
+    // min(max(0, max_i v_i), 6) is taken from the raw values and clamped once per wavefront (a v_med3 less per output)
+    constexpr bool FOLD = OUT16 && !DUAL && (ACT_M == FQ_ACT_RELU || ACT_M == FQ_ACT_RELU6);
+    QParams qc = q2;
+    if (FOLD) {
+      qc.lo = 0.0f;
+      if (ACT_M == FQ_ACT_RELU6) qc.hi = fminf(q2.hi, 6.0f);
+    }
     // accumulators start at zero (the first MFMA takes the constant): initialising them with the +128 re-centring terms
     // keeps a second set of 16 * CW registers alive next to the destination of the first MFMAs; the terms are added as
     // integers in the epilogue instead (one VALU per output)
@@ -300,13 +309,13 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
             v = v + bsh[r];
           }
           if (has_res) v = v + res[4 * gq + r];
-          v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
+          if (!FOLD) v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
           vq[r] = v;
           if (!OUT16) {
             const unsigned off = MASKED ? (8 * gq + 4 * h + r < cv ? yo : 0x80000000u) : yo;
             buf_st_f32(yr, off, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
           }
-          m = fmaxf(m, fabsf(v));                  // channels past Cout have all-zero constants: v == 0
+          m = FOLD ? fmaxf(m, v) : fmaxf(m, fabsf(v));   // channels past Cout have all-zero constants: v == 0
         }
         if (OUT16 || DUAL) {
           // the four channels 8 gq + 4 h .. + 3 of this lane's pixel are bytes 8 (gq & 1) + 4 h .. of block (c * 2 + gq / 2):
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
           // store per lane instead of these four 4-byte ones - the halves exchanged with lane ^ 32 - was built and measured:
           // slower in every C16-writing kernel, ResNet-50 offline 41.7 -> 40.1 k images/s)
           const int packed = DUAL ? fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, 0x80808080u)
-                                  : fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, fq_nonneg_xor(ubias2));
+                                  : fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], qc, ubias2, fq_nonneg_xor(ubias2));
           const bool blk_ok = !MASKED || 16 * (gq >> 1) < cv;             // a whole block past Cout does not exist
           buf_st_f32(OUT16 ? yr : yr16, blk_ok ? yo16 : 0x80000000u,
                      (unsigned)((c * 2 + (gq >> 1)) * (int)HW * 16 + 8 * (gq & 1)), __int_as_float(packed));
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
       if (cv >= 32) store_tile(c, cv, std::false_type{});
       else if (cv > 0) store_tile(c, cv, std::true_type{});
     }
+    if (FOLD && ACT_M == FQ_ACT_RELU6) m = fminf(m, 6.0f);
     if (has_stat) {
       const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)smp);
       if (__all(smp == s0)) {
@@ -346,24 +356,27 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     }
   };
   using std::integral_constant;
-  auto go = [&](auto nn2_c) __attribute__((always_inline)) {
-    if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
-      run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, nn2_c);
-    else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
-      run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{}, nn2_c);
-    else if (fbias == nullptr && has_bn && act == FQ_ACT_NONE)
-      run(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{}, nn2_c);
-    else
-      run(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, nn2_c);
+  // (only a kernel that writes codes is instantiated twice: with the five-instruction quantiser of fq_common.h where the values it
+  // clips cannot be negative - the consumer's range starts at 0, or a ReLU stands in front of it - and with the general one)
+  auto go = [&](auto bias_c, auto bn_c, auto act_c, bool nn2) __attribute__((always_inline)) {
+    if constexpr (OUT16 && !DUAL) {
+      if (nn2) run(bias_c, bn_c, act_c, std::true_type{});
+      else run(bias_c, bn_c, act_c, std::false_type{});
+    } else {
+      run(bias_c, bn_c, act_c, std::false_type{});
+    }
   };
+  const bool nn2_relu = q2.denom > 0.0f, nn2_any = fq_nonneg(q2);
   if (cvalid <= 0) {
     // nothing to multiply (a channel group wider than the layer): this wavefront only helped to quantise the tile
-  } else if constexpr (OUT16 && !DUAL) {                                // (only a kernel that writes codes is instantiated twice)
-    if (fq_nonneg(q2)) go(std::true_type{});
-    else go(std::false_type{});
-  } else {
-    go(std::false_type{});
-  }
+  } else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU)
+    go(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, nn2_relu);
+  else if (fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
+    go(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{}, nn2_relu);
+  else if (fbias == nullptr && has_bn && act == FQ_ACT_NONE)
+    go(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{}, nn2_any);
+  else
+    go(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, nn2_any);
   if (has_stat) {
     __syncthreads();
     if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < cols / HW)

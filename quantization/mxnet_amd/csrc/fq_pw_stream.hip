@@ -181,6 +181,14 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   auto tile_done = [&](const Pix& px, auto bias_c, auto bn_c, auto act_c, auto nn2_c) __attribute__((always_inline)) {
     constexpr bool NN2 = decltype(nn2_c)::value;
     constexpr int BIAS_M = decltype(bias_c)::value, BN_M = decltype(bn_c)::value, ACT_M = decltype(act_c)::value;
+    // (a code output behind a compile-time ReLU / ReLU6: activation and the consumer's clip as ONE median, the statistic from
+    // the raw values - fq_pw_split_kernel.h)
+    constexpr bool FOLD = OUT16 && !DUAL && (ACT_M == FQ_ACT_RELU || ACT_M == FQ_ACT_RELU6);
+    QParams qc = q2;
+    if (FOLD) {
+      qc.lo = 0.0f;
+      if (ACT_M == FQ_ACT_RELU6) qc.hi = fminf(q2.hi, 6.0f);
+    }
     const unsigned yoff = (unsigned)((((int64_t)px.smp * g.Cout + 4 * h) * plane + px.p) * 4);
     // PART: every store (and residual load) of a channel tile goes through a resource over the whole tensor with an
     // out-of-range offset for channels past Cout
@@ -232,8 +240,10 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
             v = v + (f2){bsh[r], bsh[r + 1]};
           }
           if (RES) v = v + (f2){res[4 * gq + r], res[4 * gq + r + 1]};
-          v.x = ACT_M < 0 ? act_rt(v.x, act) : act_rt(v.x, ACT_M);
-          v.y = ACT_M < 0 ? act_rt(v.y, act) : act_rt(v.y, ACT_M);
+          if (!FOLD) {
+            v.x = ACT_M < 0 ? act_rt(v.x, act) : act_rt(v.x, ACT_M);
+            v.y = ACT_M < 0 ? act_rt(v.y, act) : act_rt(v.y, ACT_M);
+          }
           // no masks: lanes past the end hold a copy of the last pixel (clamped loads) and re-store its values, and the
           // host guarantees Cout % 32 == 0
           if (OUT16 || DUAL) {
@@ -256,13 +266,13 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
               *reinterpret_cast<float*>(yb + plane * 4) = v.y;
             }
           }
-          m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+          m = FOLD ? fmaxf(m, fmaxf(v.x, v.y)) : fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
         }
         if (OUT16 || DUAL) {   // channels 8 gq + 4 h .. + 3 of the lane's pixel = bytes 8 (gq & 1) + 4 h .. of block 2 ct + gq / 2
           // (DUAL: the host only asks for unsigned codes of a non-negative range - the five-instruction quantiser, fq_common.h;
           // 167 registers: the third workgroup per CU still fits)
           const int packed = DUAL ? fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, 0x80808080u)
-                                  : fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, fq_nonneg_xor(ubias2));
+                                  : fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], qc, ubias2, fq_nonneg_xor(ubias2));
           if (PART && !DUAL) {                         // a whole block past Cout (Cout % 32 == 16) does not exist
             const int blk = 2 * ct + (gq >> 1);
             const unsigned o16 = (unsigned)((((int64_t)px.smp * g.CBo + (blk < g.CBo ? blk : 0)) * plane + px.p) * 16 +
@@ -276,6 +286,7 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
         }
       }
     }
+    if (FOLD && ACT_M == FQ_ACT_RELU6) m = fminf(m, 6.0f);
     if (has_stat) {
       const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)px.smp);
       const bool uniform = __all(!px.valid || px.smp == s0);
@@ -330,25 +341,27 @@ __global__ __launch_bounds__(kBlock, 2) void pwconv_stream_kernel(
   using std::true_type;
   using std::false_type;
   const bool nn = fq_nonneg(q);
-  auto go = [&](auto nn2_c) __attribute__((always_inline)) {
-    if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU)
-      run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, true_type{}, nn2_c);
-    else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
-      run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{}, true_type{}, nn2_c);
-    else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_NONE)
-      run_all(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{}, true_type{}, nn2_c);
-    else if (nn)
-      run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, true_type{}, nn2_c);
-    else
-      run_all(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, false_type{}, nn2_c);
+  // (only a kernel that writes codes is instantiated twice: with the five-instruction output quantiser where the values it clips
+  // cannot be negative - the consumer's range starts at 0, or a ReLU stands in front of it - and with the general one)
+  auto go = [&](auto bias_c, auto bn_c, auto act_c, auto nn_c, bool nn2) __attribute__((always_inline)) {
+    if constexpr (OUT16 && !DUAL) {
+      if (nn2) run_all(bias_c, bn_c, act_c, nn_c, true_type{});
+      else run_all(bias_c, bn_c, act_c, nn_c, false_type{});
+    } else {
+      run_all(bias_c, bn_c, act_c, nn_c, false_type{});
+    }
   };
-  // (only a kernel that writes codes is instantiated twice)
-  if constexpr (OUT16 && !DUAL) {
-    if (fq_nonneg(q2)) go(true_type{});
-    else go(false_type{});
-  } else {
-    go(false_type{});
-  }
+  const bool nn2_relu = q2.denom > 0.0f, nn2_any = fq_nonneg(q2);
+  if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU)
+    go(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU>{}, true_type{}, nn2_relu);
+  else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_RELU6)
+    go(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_RELU6>{}, true_type{}, nn2_relu);
+  else if (nn && fbias == nullptr && has_bn && act == FQ_ACT_NONE)
+    go(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, FQ_ACT_NONE>{}, true_type{}, nn2_any);
+  else if (nn)
+    go(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, true_type{}, nn2_any);
+  else
+    go(integral_constant<int, -1>{}, integral_constant<int, -1>{}, integral_constant<int, -1>{}, false_type{}, nn2_any);
 
   if (has_stat) {
     __syncthreads();
