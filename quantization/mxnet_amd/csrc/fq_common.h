@@ -734,7 +734,9 @@ constexpr int kEpiRuntime = 0, kEpiBnRelu = 1, kEpiBnRelu6 = 2;
 // MULTIPLIES the sum instead of being added - the dequantisation factor in_scale * w_scale of nn.Conv2D(quantized=True)'s
 // depthwise layer, applied to the exact integer sum before a folded BatchNorm (its own multiply and add stay separate)
 constexpr int kActBiasMul = 0x10;
-template <int EPI>
+// (ACT = false: a compile-time epilogue WITHOUT its activation - for a code output, where ReLU / ReLU6 and the consumer's clip
+// are one median: clip(relu6(v), lo <= 0, hi) == med3(v, 0, min(6, hi)))
+template <int EPI, bool ACT = true>
 __device__ __forceinline__ float dw_finish(float acc, bool has_bias, float bch, bool has_bn, float bsc, float bsh, int act) {
   if (EPI == kEpiRuntime) {
     if (has_bias) acc = (act & kActBiasMul) ? acc * bch : acc + bch;
@@ -746,6 +748,7 @@ __device__ __forceinline__ float dw_finish(float acc, bool has_bias, float bch, 
   }
   acc = acc * bsc;
   acc = acc + bsh;
+  if (!ACT) return acc;
   acc = fmaxf(acc, 0.0f);
   return EPI == kEpiBnRelu6 ? fminf(acc, 6.0f) : acc;
 }

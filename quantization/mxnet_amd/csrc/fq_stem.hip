@@ -309,6 +309,14 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
     q2.rden = 0.0;
     if (OUT16) q2 = make_qparams(oc.thr[0], oc.levels, oc.lo_neg != 0, kEps);
     const int ubias2 = 128 - oc.zoff;
+    // (a code output behind a compile-time ReLU / ReLU6: activation and the consumer's clip as ONE median, the statistic from
+    // the raw values - fq_pw_split_kernel.h)
+    constexpr bool FOLD = OUT16 && EPI != kEpiRuntime;
+    QParams qc = q2;
+    if (FOLD) {
+      qc.lo = 0.0f;
+      if (EPI == kEpiBnRelu6) qc.hi = fminf(q2.hi, 6.0f);
+    }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -320,29 +328,30 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
         float vq[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = dw_finish<EPI>(acc[ct][4 * gq + r], bias != nullptr, bch[r], has_bn, bsc[r], bsh[r], act);
+          float v = dw_finish<EPI, !FOLD>(acc[ct][4 * gq + r], bias != nullptr, bch[r], has_bn, bsc[r], bsh[r], act);
           if (!OUT16 && !FQ_STEM_NOSTORE) {
             if (FQ_STEM_NTS) buf_st_f32_nt(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
             else buf_st_f32(yr, yo, (unsigned)(ct * 32 + 8 * gq + r) * HWo4, v);
           }
           vq[r] = v;
-          m = fmaxf(m, fabsf(v));
+          m = FOLD ? fmaxf(m, v) : fmaxf(m, fabsf(v));
         }
         if (OUT16) {     // channels 8 gq + 4 h .. + 3 of the lane's pixel = bytes 8 (gq & 1) + 4 h .. of block 2 ct + gq / 2
           // (a clip range that starts at 0 - unsigned activations - takes the five-instruction quantiser of fq_common.h: a
           // scalar branch; the empty asm statements keep it one - without them both forms are computed and selected)
           int packed;
-          if (fq_nonneg(q2)) {
+          if (fq_nonneg(qc)) {
             asm volatile("");
-            packed = fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, fq_nonneg_xor(ubias2));
+            packed = fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], qc, ubias2, fq_nonneg_xor(ubias2));
           } else {
             asm volatile("");
-            packed = fq_pack4<false>(vq[0], vq[1], vq[2], vq[3], q2, ubias2, 0u);
+            packed = fq_pack4<false>(vq[0], vq[1], vq[2], vq[3], qc, ubias2, 0u);
           }
           buf_st_f32(yr, cur.jp * 16u + (unsigned)(8 * (gq & 1) + 4 * h), (unsigned)((2 * ct + (gq >> 1)) * HWo * 16),
                      __int_as_float(packed));
         }
       }
+    if (FOLD && EPI == kEpiBnRelu6) m = fminf(m, 6.0f);
     if (has_stat) {                               // a tile lies within one sample
       const float wm = wave_max_nonneg(m);
       if (lane == 0) {
