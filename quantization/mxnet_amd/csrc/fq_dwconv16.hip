@@ -4,10 +4,8 @@
 // rules; the C16 layout: include/fakequant.h at fq_pwconv_i8_c16)
 #include "fq_common.h"
 
-// tuning build: -DFQ_DW16_V=<bits>  4: the short quantiser for non-negative output ranges (bits 1 and 2 - unconditional loads
-// from clamped addresses + select instead of 62 exec-masked loads, stride 2 keeping the row it shares with the next output
-// row - are built in since r4: 526 -> 473 us over MobileNetV2's ten depthwise shapes at batch 128, tools/dw16bench.py).
-// -DFQ_DW16_RING=<3|4|5> / -DFQ_DW16_RING2=<2|3>: input rows (stride 2: row pairs) in flight per lane.
+// tuning builds: -DFQ_DW16_V=3 (the general output quantiser everywhere; bit 4 = the short one for values that cannot be
+// negative), -DFQ_DW16_RING=<3|4|5> / -DFQ_DW16_RING2=<2|3>: input rows (stride 2: row pairs) in flight per lane.
 #ifndef FQ_DW16_V
 #define FQ_DW16_V 7
 #endif
@@ -113,9 +111,8 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
   // (code 0), chosen by a SCALAR branch.
   struct Row { f2 v[3][2]; };
   struct Raw { unsigned d[3]; };
-  const int last_in = g.H - 1;
   auto fetch = [&](int r, Raw& w) __attribute__((always_inline)) {
-    const int rr = r < 0 ? 0 : (r < last_in ? r : last_in);
+    const int rr = r < 0 ? 0 : (r < g.H ? r : g.H - 1);
     const unsigned so = (unsigned)rr * row_in;
 #pragma unroll
     for (int k = 0; k < 3; ++k) w.d[k] = __float_as_uint(buf_ld_f32(xr, xoff[k], so));
@@ -147,8 +144,7 @@ __global__ __launch_bounds__(256, 4) void dwconv3x3_c16_kernel(
   // ---- the ring: every row it holds is requested NOW, ahead of the weights and the thresholds ---------------------------------
   // S == 1: entry j <-> input row j - 1 (output row t cooks entry t + 2);  S == 2: row -1 (zeros), then pairs: entry t <-> input
   // rows 2t, 2t + 1
-  // (the run-time epilogue keeps bias and activation selectors alive: a shorter ring there - an in-flight register must never
-  // be spilled)
+  // (the run-time epilogue keeps bias and activation selectors alive: a shorter ring there, or it spills)
   constexpr int NR = S == 1 ? (EPI == kEpiRuntime ? 3 : FQ_DW16_RING) : FQ_DW16_RING2;
   Raw ring[NR], ring_b[S == 1 ? 1 : NR], first;
   if (S == 1) {
