@@ -36,8 +36,11 @@ PW_CASES = [(12, 16, 96, 112, 112, 1), (11, 32, 16, 112, 112, 1), (43, 96, 24, 5
 
 
 @pytest.mark.parametrize("case", PW_CASES, ids=["%dx%d->%d@%dx%d/s%d" % c for c in PW_CASES])
-@pytest.mark.parametrize("signed_out", [False, True], ids=["u8-out", "s8-out"])
-def test_pointwise_producer_writes_the_consumers_codes(dev, ops, case, signed_out):
+@pytest.mark.parametrize("mode", ["u8-out", "s8-out", "s8-out-relu", "u8-out-relu6-thr9"])
+def test_pointwise_producer_writes_the_consumers_codes(dev, ops, case, mode):
+    """(the last two modes: a ReLU in front of a SIGNED consumer range, and a ReLU6 whose 6 lies below the consumer's threshold -
+    the epilogue folds the activation into the clip, med3(v, 0, min(6, hi)), and takes the statistic from the raw values)"""
+    signed_out = mode.startswith("s8")
     n, cin, cout, h, w, stride = case
     rng = np.random.default_rng(sum(case) + 3)
     x = np.maximum(rng.standard_normal((n, cin, h, w)) * 2, 0).astype(np.float32)
@@ -46,10 +49,12 @@ def test_pointwise_producer_writes_the_consumers_codes(dev, ops, case, signed_ou
     sh = rng.standard_normal(cout).astype(np.float32)
     codes, scales, rowsum = ops.weight_codes(T(wt, dev), 1, 8)
     thr_in = T(np.float32([2.7]), dev)
-    act = None if signed_out else "relu6"
+    act = {"u8-out": "relu6", "s8-out": None, "s8-out-relu": "relu", "u8-out-relu6-thr9": "relu6"}[mode]
+    if mode == "u8-out-relu6-thr9":
+        sc = sc * np.float32(4)                                          # (values beyond 6, so that the 6 is what clips)
     kw = dict(in_thr=thr_in, width=8, flags=0, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act=act, stride=stride)
     y, stat = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, form="split", **kw)
-    thr_out = np.float32(1.9)
+    thr_out = np.float32(9.0 if mode == "u8-out-relu6-thr9" else 1.9)
     oflags = ops.act_flags(signed=signed_out)
     yc, stat_c = ops.pwconv_i8(T(x, dev), codes, scales, rowsum, out_codes=dict(thr=T(np.float32([thr_out]), dev), width=8,
                                                                                 flags=oflags), **kw)
@@ -243,7 +248,7 @@ DW_EDGE_CASES = [(2, 16, 1, 1, 1), (2, 20, 1, 5, 2), (1, 32, 2, 3, 1), (1, 32, 2
 
 
 @pytest.mark.parametrize("case", DW_EDGE_CASES, ids=["%dx%d@%dx%d/s%d" % c for c in DW_EDGE_CASES])
-@pytest.mark.parametrize("epi", ["bn-relu", "bn-none-signed-out", "bias-bn-relu6", "plain"])
+@pytest.mark.parametrize("epi", ["bn-relu", "bn-none-signed-out", "bias-bn-relu6", "plain", "bn-relu-signed-out", "bn-relu6-thr9"])
 def test_depthwise_on_codes_every_epilogue_on_planes_shorter_than_the_prefetch(dev, ops, case, epi):
     """fq_dwconv3x3_c16 fetches its input rows two output rows ahead through rotating register sets and is instantiated per
     epilogue and output quantiser: planes of 1-9 rows (shorter than the rotation's period, rows fetched past the end), more
@@ -256,9 +261,14 @@ def test_depthwise_on_codes_every_epilogue_on_planes_shorter_than_the_prefetch(d
     sc = rng.uniform(0.3, 1.5, c).astype(np.float32)
     sh = rng.standard_normal(c).astype(np.float32)
     bias = T(rng.standard_normal(c).astype(np.float32), dev) if epi == "bias-bn-relu6" else None
-    act = {"bn-relu": "relu", "bn-none-signed-out": None, "bias-bn-relu6": "relu6", "plain": None}[epi]
-    out_signed = epi == "bn-none-signed-out"
-    thr, thr2 = np.float32(2.3), np.float32(1.7)
+    act = {"bn-relu": "relu", "bn-none-signed-out": None, "bias-bn-relu6": "relu6", "plain": None, "bn-relu-signed-out": "relu",
+           "bn-relu6-thr9": "relu6"}[epi]
+    out_signed = epi in ("bn-none-signed-out", "bn-relu-signed-out")
+    # (the last two: ReLU in front of a signed consumer range, and a ReLU6 whose 6 lies below the consumer's threshold - the
+    # compile-time epilogues fold the activation into the clip and take the statistic from the raw sums)
+    thr, thr2 = np.float32(2.3), np.float32(9.0 if epi == "bn-relu6-thr9" else 1.7)
+    if epi == "bn-relu6-thr9":
+        sc = sc * np.float32(3)
     thr_t = T(np.float32([thr]), dev)
     kw = dict(stride=stride, in_thr=thr_t, width=8, flags=ops.act_flags(signed=False), act=act)
     if epi != "plain":
