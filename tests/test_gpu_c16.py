@@ -174,7 +174,7 @@ def test_closing_pointwise_stores_the_trunk_twice(dev, ops, case):
 
 
 @pytest.mark.parametrize("shape", [(43, 224, 224), (3, 64, 64), (2, 33, 47)], ids=["43x224", "3x64", "2x33x47"])
-@pytest.mark.parametrize("act", ["relu6", "relu"])
+@pytest.mark.parametrize("act", ["relu6", "relu", "relu6-thr9"])
 def test_first_convolution_hands_its_consumers_codes_over(dev, ops, shape, act):
     """fq_stem_conv3x3s2_c16 (round 4): the codes of what fq_stem_conv3x3s2 computes, under the consumer's threshold; same
     statistic.  And the consumer - a 32 -> 32 1x1 that reads codes AND writes codes (the streaming form's K = 32 both-sides
@@ -186,6 +186,8 @@ def test_first_convolution_hands_its_consumers_codes_over(dev, ops, shape, act):
     sc = rng.uniform(0.5, 1.5, 32).astype(np.float32)
     sh = rng.standard_normal(32).astype(np.float32)
     thr = np.float32(2.1)
+    if act == "relu6-thr9":                      # (a ReLU6 whose 6 lies below the consumer's threshold: the 6 is what clips)
+        act, thr, sc = "relu6", np.float32(9.0), sc * np.float32(6)
     thr_t = T(np.float32([thr]), dev)
     y, stat = ops.stem_conv_s2(T(x, dev), T(wt, dev), None, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act=act)
     yc, stat_c = ops.stem_conv_s2(T(x, dev), T(wt, dev), None, bn_scale=T(sc, dev), bn_shift=T(sh, dev), act=act,
