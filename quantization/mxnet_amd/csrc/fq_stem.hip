@@ -127,6 +127,13 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef FQ_STEM_NTL
 #define FQ_STEM_NTL 0        // A/B builds: 1 = the gather of the input image with the nontemporal hint
 #endif
+#ifndef FQ_STEM_INTERLEAVE
+// The four wavefronts of a workgroup take the workgroup's tiles in turn (tile T0 + wave, + 4, ...) instead of a quarter of the
+// range each: they then walk the same output rows at the same time and their input rows meet in the L1 / L2 - a wavefront on
+// its own 14 output rows keeps 78 KB of input alive, the 16-32 wavefronts of a CU together far more than the caches hold
+// (PMC: 106.6 MB fetched for the 77 MB input).  0: the round-4 assignment (A/B builds).
+#define FQ_STEM_INTERLEAVE 1
+#endif
 #ifndef FQ_STEM_NOSTORE      // tuning only (tools/stembench.py): the statistic without the stores - what a recomputation would cost
 #define FQ_STEM_NOSTORE 0
 #endif
@@ -179,7 +186,12 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
   const int HWo = Ho * Wo;
   const bool has_bn = bn_scale != nullptr, has_stat = stat_out != nullptr;
   const unsigned wid = blockIdx.x * 4u + (unsigned)wave, wid0 = blockIdx.x * 4u;
-  const unsigned t_begin = wid * g.per + (wid < g.rem ? wid : g.rem), t_end = t_begin + g.per + (wid < g.rem ? 1u : 0u);
+  // the workgroup's tiles [wg_begin, wg_end) = those of its four wavefronts; a wavefront takes every TSTEP-th of them
+  constexpr unsigned TSTEP = FQ_STEM_INTERLEAVE ? 4u : 1u;
+  const unsigned wg_begin = wid0 * g.per + (wid0 < g.rem ? wid0 : g.rem);
+  const unsigned wid1 = wid0 + 4u, wg_end = wid1 * g.per + (wid1 < g.rem ? wid1 : g.rem);
+  const unsigned t_begin = FQ_STEM_INTERLEAVE ? wg_begin + (unsigned)wave : wid * g.per + (wid < g.rem ? wid : g.rem);
+  const unsigned t_end = FQ_STEM_INTERLEAVE ? wg_end : t_begin + g.per + (wid < g.rem ? 1u : 0u);
   const unsigned s_base = fast_div(wid0 * g.per + (wid0 < g.rem ? wid0 : g.rem), g.by_tpi);
   float areg[WREG ? NS * CT : 1];
   if (WREG) {
@@ -215,9 +227,9 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
   auto pix_next = [&](const Pix& p, bool more) __attribute__((always_inline)) {
     unsigned smp = p.smp, tin = p.tin;
     if (more) {
-      ++tin;
-      if (tin == g.tiles_per_img) {
-        tin = 0;
+      tin += TSTEP;
+      while (tin >= g.tiles_per_img) {
+        tin -= g.tiles_per_img;
         ++smp;
       }
     }
@@ -253,10 +265,9 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < CH; ++i) bbuf[0][i] = issue(xr, cur, i);
   }
-  for (unsigned t = t_begin; t < t_end; ++t) {
-    if (t == t_begin + 1) PW_STAMP(2);
-    if (t == t_begin + (t_end - t_begin) / 2) PW_STAMP(3);
-    const Pix nxt = pix_next(cur, t + 1 < g.total_tiles);
+  for (unsigned t = t_begin; t < t_end; t += TSTEP) {
+    if (t == t_begin + TSTEP) PW_STAMP(2);
+    const Pix nxt = pix_next(cur, t + TSTEP < g.total_tiles);
     const fq_rsrc xr = rsrc_of(cur), xn = rsrc_of(nxt);
     v16f acc[CT];
 #pragma unroll
