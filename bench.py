@@ -478,7 +478,7 @@ def main():
 
         def __iter__(self):
             for i in range(self.first, self.first + self.count):
-                on = self.sample_events and (i % self.sample_events == 0)
+                on = self.sample_events and ((i - self.first) % self.sample_events == 0)
                 ops.profile_enable(bool(on))
                 self.profiled += 1 if on else 0
                 yield batches[i % rotate], None
@@ -593,7 +593,7 @@ def main():
         else:
             sampled = []
             for i in range(first_step, first_step + args.steps):
-                on = bool(every) and (i % every == 0)
+                on = bool(every) and ((i - first_step) % every == 0)
                 if on and n_streams > 1:
                     sampled.append(i)                 # two steps in flight: the sampled steps run at the END of the block, alone
                 elif on:
@@ -630,15 +630,26 @@ def main():
     own_blocks = []
     fqdist.collective_stats(reset=True)              # (what warm-up and set-up exchanged is not the timed region's)
     # The bracketed steps (eager, alone, two marker packets per launch) cost their block 1.5-2 %: they ride in every THIRD block
-    # (0, 3, 6 ...), so that with three or more blocks the median block - `value` - is one without them, while the roofline
-    # figures still come from events inside the timed region.  Both kinds of block are reported (`consistency`).
+    # (1, 4, 7 ... - not in block 0, the first after the warm-up, whose steps run up to 5 % slower on some boxes), so that
+    # with three or more blocks the median block - `value` - is one without them, while the roofline figures still come from
+    # events inside the timed region.  A run of a single block gets a second one that carries them.  Both kinds of block
+    # are reported (`consistency`).
     EVENT_BLOCK_EVERY = max(1, int(os.environ.get("FQ_BENCH_EVENT_BLOCK_EVERY", "3")))       # (1: every block, as rounds 1-4)
-    blocks = [timed_block(0)]
+
+    def carries_events(k):
+        return EVENT_BLOCK_EVERY == 1 or k % EVENT_BLOCK_EVERY == 1
+
+    blocks = [timed_block(0, with_events=carries_events(0))]
     while sum(blocks) < args.min_region_s and len(blocks) < args.max_repeats:
-        blocks.append(timed_block(len(blocks) * args.steps, with_events=len(blocks) % EVENT_BLOCK_EVERY == 0))
+        blocks.append(timed_block(len(blocks) * args.steps, with_events=carries_events(len(blocks))))
+    if event_every and not any(carries_events(k) for k in range(len(blocks))):
+        blocks.append(timed_block(len(blocks) * args.steps, with_events=True))
+        event_idx = {len(blocks) - 1}
+    else:
+        event_idx = {k for k in range(len(blocks)) if carries_events(k)}
     elapsed = float(np.median(blocks))
-    event_blocks = [b for k, b in enumerate(blocks) if k % EVENT_BLOCK_EVERY == 0]
-    plain_blocks = [b for k, b in enumerate(blocks) if k % EVENT_BLOCK_EVERY != 0]
+    event_blocks = [b for k, b in enumerate(blocks) if k in event_idx]
+    plain_blocks = [b for k, b in enumerate(blocks) if k not in event_idx]
     # what each rank's own clock says about the same blocks (the line's figures are the per-block MAXIMUM over ranks)
     rank_ms = None
     if distributed:
@@ -862,11 +873,11 @@ def main():
                             "ms_per_step_min": round(min(blocks) / args.steps * 1e3, 4),
                             "ms_per_step_max": round(max(blocks) / args.steps * 1e3, 4),
                             "ms_per_step_first_block": round(blocks[0] / args.steps * 1e3, 4),
-                            "event_blocks": {"which": "blocks 0, %d, %d ... carry the steps bracketed with HIP events (eager, "
-                                                      "alone on one stream); the other blocks are plain" % (EVENT_BLOCK_EVERY,
-                                                                                                            2 * EVENT_BLOCK_EVERY),
+                            "event_blocks": {"which": "blocks %s carry the steps bracketed with HIP events (eager, alone on "
+                                                      "one stream); the other blocks are plain" % sorted(event_idx),
                                              "n": len(event_blocks), "ms_per_step_median": round(
-                                                 float(np.median(event_blocks)) / args.steps * 1e3, 4)},
+                                                 float(np.median(event_blocks)) / args.steps * 1e3, 4) if event_blocks
+                                             else None},
                             "plain_blocks": {"n": len(plain_blocks), "ms_per_step_median": round(
                                 float(np.median(plain_blocks)) / args.steps * 1e3, 4) if plain_blocks else None}},
             "eval_counters": {"images": float(counters[1].item()), "top1_correct": float(counters[0].item()),
