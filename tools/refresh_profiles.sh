@@ -13,8 +13,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- p
 # the same steps one batch at a time and launched eagerly: with batches in flight a kernel's wall duration includes the time it
 # shares the CUs with another batch's kernels (the durations of a step then add up to more than the step); this table is the
 # one the event-timed per-kernel figures of the line (taken on steps that run alone) are to be compared with
-# (--event-every 10: the bracketed steps ride in every third block only - ten per block keep ~30 of them in this short run)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o bench -- python3 $R/bench.py --steps 100 --warmup 5 --streams 1 --graph 0 --event-every 10 --no-cpu-baseline > $OUT/${TAG}_bench_line_one_stream_under_rocprof.json 2> $OUT/trace1.err
+# (FQ_BENCH_EVENT_BLOCK_EVERY=1, --event-every 10: bracketed steps in EVERY block of this short run, ten per block - what is
+# checked here is the event method, not `value`; the driver's run keeps them in every third block)
+FQ_BENCH_EVENT_BLOCK_EVERY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o bench -- python3 $R/bench.py --steps 100 --warmup 5 --streams 1 --graph 0 --event-every 10 --no-cpu-baseline > $OUT/${TAG}_bench_line_one_stream_under_rocprof.json 2> $OUT/trace1.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-headline --no-kernel-events > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-headline --no-kernel-events > /dev/null 2> $OUT/pmc_write.err
 cd $R
