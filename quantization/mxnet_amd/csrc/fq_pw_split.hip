@@ -38,12 +38,16 @@ int pw_try_split(const PwCall& a, bool* taken) {
     // resident rounds); narrow layers take one tile per wavefront so that all four wavefronts have channels.
     int cw = a.cout > 128 ? 2 : 1;
     int lb = 4;
-    // eight wavefronts per workgroup for wide layers with FEW tiles (7x7 planes: 196): a tile is then quantised by half as
-    // many channel groups (measured in the model: 1024 -> 1024 @7x7 31.2 -> 25.8 us, 512 -> 1024 @7x7 19.8 -> 18.5; the 14x14
-    // layers with their 784 tiles get 5 % slower)
+    // eight wavefronts per workgroup for wide layers: a tile is then quantised by half as many channel groups (measured in
+    // the model: 1024 -> 1024 @7x7 31.2 -> 25.8 us, 512 -> 1024 @7x7 19.8 -> 18.5).  Alone the 14x14 layers with their 784
+    // tiles get 5 % slower that way (round 3: hence "few tiles only"); among three batches in flight what counts is the work
+    // saved: ResNet-50 online +0.75 % with the limit at 1024 tiles, +1.2 % at 4096 = 16 tiles per CU (28x28 planes included),
+    // +1.1 % without limit (round 5, alternating runs: profiles/r5_r50_nw8_ab.txt)
     static const int nw_tune = env_int("FQ_PWS_NW", 0);
     const bool nw8_built = kt == 8 || kt == 16 || kt == 32 || kt == 64;
-    int nw = (nw_tune == 4 || nw_tune == 8) ? nw_tune : ((a.cout >= 512 && tiles <= (int64_t)num_cu()) ? 8 : 4);
+    static const int nw8_tiles = env_int("FQ_PWS_NW8_TILES", 0);        // tuning: most tiles a layer may have to take nw = 8
+    const int64_t nw8_max = nw8_tiles > 0 ? nw8_tiles : 16 * (int64_t)num_cu();
+    int nw = (nw_tune == 4 || nw_tune == 8) ? nw_tune : ((a.cout >= 512 && tiles <= nw8_max) ? 8 : 4);
     if (!nw8_built || c16) nw = 4;
     const int tune = c16 ? 0 : env_int("FQ_PWS_CFG", 0);                 // tuning: 10 * lb + cw, read per call
     if (tune > 0) {
