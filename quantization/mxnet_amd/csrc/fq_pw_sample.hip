@@ -435,7 +435,8 @@ namespace fqi {
 // grid = samples x channel groups x pixel blocks (rounded to whole rounds over the 8 XCDs).
 int pw_try_sample(const PwCall& a, bool* taken) {
   *taken = false;
-  static const int mode = env_int("FQ_PWSMP", 1);                       // tuning: 0 never, 1 blocked planes up to 1024 pixels, 2 every shape it takes
+  // 0 never, 1 blocked planes up to 1024 pixels without a residual operand (rounds 2-4), 2 every shape it takes (round 5)
+  static const int mode = env_int("FQ_PWSMP", 2);
   const int kt = (int)(a.cin_pad / 32);
   const bool small = a.hw <= 64;                                        // one block of two pixel tiles
   const int64_t quads = (a.hw + 3) / 4;
@@ -447,11 +448,17 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   // by shape: the small and middle planes (measured in the model against the split form: 512 -> 512 @14x14 32.0 -> 25.2 us,
   // 256 -> 512 @14x14 24.0 -> 20.7, 256 -> 256 @28x28 48.0 -> 39.7, 128 -> 256 @28x28 38.8 -> 33.7); the streaming form keeps
   // the large planes
-  // (whole small planes are built and tested, but not chosen: 1024 -> 1024 @7x7 27.9 us against the split form's 26.6,
-  // 512 -> 1024 @7x7 19.9 against 20.4 - 32 chunks with a barrier each)
-  // (nor with a residual operand: ResNet-50 128 -> 512 @28x28 103.9 us against the split form's 99.0, 256 -> 1024 @14x14 55.1
-  // against 51.0; without one, 1024 -> 256 @14x14: 30.2 against 34.8)
-  const bool by_shape = a.form == 0 && (mode == 2 || (mode == 1 && a.hw <= 1024 && !small && a.residual == nullptr));
+  // Whole small planes and layers with a residual operand were left to the split form through round 4, on times measured with
+  // each kernel ALONE (1024 -> 1024 @7x7 27.9 us against the split form's 26.6, 512 -> 1024 @7x7 19.9 against 20.4; ResNet-50
+  // 128 -> 512 @28x28 + residual 103.9 against 99.0, 256 -> 1024 @14x14 + residual 55.1 against 51.0).  Among three batches
+  // in flight the sample form wins both - every value is quantised once per 256 or 512 output channels instead of once per
+  // 256: ResNet-50 online +1.8 % (sd 0.1; the residual layers), MobileNet default workload +0.4 ... +0.5 % (the 7x7 layers);
+  // planes of more than 1024 pixels: no difference (profiles/r5_pwsmp_modes_ab.txt)
+  // (tuning: 3 = as 1 + whole small planes, 4 = as 1 + layers with a residual operand, 5 = as 1 + planes of more than 1024 pixels)
+  const bool base = a.hw <= 1024 && !small && a.residual == nullptr;
+  const bool by_shape = a.form == 0 && (mode == 2 || (mode == 1 && base) ||
+                                        (mode == 3 && (base || (small && a.residual == nullptr))) ||
+                                        (mode == 4 && a.hw <= 1024 && !small) || (mode == 5 && !small && a.residual == nullptr));
   if (!shape_ok || !(a.form == 7 || by_shape)) return FQ_OK;
   const int64_t rows_pad = (a.cout + 31) / 32 * 32;
   static const int ctw_tune = env_int("FQ_PWSMP_CTW", 0);               // tuning: 1 = 256 channels per workgroup everywhere

@@ -46,6 +46,9 @@ def main():
     for label, _, _ in variants:
         x = [v for v in vals[label] if v == v]
         ratios = [a / b for a, b in zip(vals[label], vals[first]) if a == a and b == b]
+        if not x or not ratios:
+            print("%-32s (no run of this variant produced a line)" % label)
+            continue
         print("%-32s %10.1f %10.1f %10.1f %10.1f   %+.2f %% (sd %.2f)" % (
             label, statistics.mean(x), statistics.median(x), min(x), max(x), (statistics.mean(ratios) - 1) * 100,
             statistics.pstdev(ratios) * 100 if len(ratios) > 1 else 0.0))
