@@ -1303,10 +1303,11 @@ static int dwconv3x3_impl(const float* x, const float* w, const float* bias, flo
   // to run at full size; round 3 found the cause - NOT a data race: a VALU write of a 16-byte buffer store's data register
   // right behind the store, a hazard hipcc does not guard when soffset is a register (fq_common.h at buf_st_v4f,
   // profiles/r3_dw_flat_race.txt, tools/dw_race_repro.py, tools/isa_lint.py) - every instantiation of this kernel had the
-  // pattern one instruction further away.  With the stores guarded the form is exact at every occupancy; it is built and
-  // tested (FQ_DW_FLAT=31) but not chosen by shape: inside the model it is no faster than the four-columns-per-lane form
-  // (28.3 us against ~25; whole step 1.1967 against 1.1919 ms, profiles/r3_dw_flat_race.txt).)
-  static const int flat_on = env_int("FQ_DW_FLAT", 15) & 31;
+  // pattern one instruction further away.  With the stores guarded the form is exact at every occupancy.  Through round 4 it
+  // was built and tested but not chosen by shape - one batch at a time it was no faster than the four-columns-per-lane form
+  // (28.3 us against ~25; whole step 1.1967 against 1.1919 ms, profiles/r3_dw_flat_race.txt); with three batches in flight and
+  // its nontemporal loads it is: default workload +1.77 % images/s (sd 0.03, profiles/r5_heuristics_ab.txt).)
+  static const int flat_on = env_int("FQ_DW_FLAT", 31) & 31;
   {
     const int kind = (h == 14 && wdt == 14) ? (stride == 1 ? 0 : 1)
                      : (h == 7 && wdt == 7 && stride == 1) ? 2
