@@ -1447,7 +1447,9 @@ static int dwconv3x3_impl(const float* x, const float* w, const float* bias, flo
     const float eps = (in_flags & FQ_ACT_NO_EPS) ? 0.0f : kEps;
     if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
     ProfScope prof(FQ_KERNEL_DWCONV, 4.0 * ((double)n * c * h * wdt + (double)n * c * cg.Ho * cg.Wo), st);
-    static const int dw_nt_mb = env_int("FQ_DW_NT_MB", 300);              // nontemporal loads above this many MB of input
+    // nontemporal loads above this many MB of input (300 through round 4 = the 411 MB tensor only; 200 takes in the three
+    // 205 MB ones: +0.4 ... +0.7 % images/s in two alternating A/Bs, 100 +0.3 %, 500 -0.5 %: profiles/r5_heuristics_ab.txt)
+    static const int dw_nt_mb = env_int("FQ_DW_NT_MB", 200);
     const bool nt = 4.0 * (double)n * c * h * wdt > 1e6 * dw_nt_mb;
     static const int dw_nts_mb = env_int("FQ_DW_NTS_MB", 1 << 30);        // nontemporal stores from this many MB of output on
     cg.nts = 4.0 * (double)n * c * cg.Ho * cg.Wo >= 1e6 * dw_nts_mb ? 1 : 0;
