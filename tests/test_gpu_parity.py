@@ -585,7 +585,8 @@ def _pwconv_case(dev, ops, case, mode, form=None):
 
 PW_RES_CASES = [("split", (2, 256, 1024, 14, 14)), ("split", (3, 512, 2048, 7, 7)), ("stream", (2, 64, 256, 28, 28)),
                 ("split", (2, 144, 24, 14, 14)), ("split", (3, 384, 64, 7, 7)), (None, (2, 128, 512, 9, 11)),
-                ("sample", (3, 256, 1024, 14, 14)), ("sample", (2, 128, 512, 28, 28)), ("sample", (2, 512, 512, 14, 14))]
+                ("sample", (3, 256, 1024, 14, 14)), ("sample", (2, 128, 512, 28, 28)), ("sample", (2, 512, 512, 14, 14)),
+                ("sample", (3, 512, 2048, 7, 7)), (None, (9, 512, 2048, 7, 7)), ("sample", (2, 512, 1024, 8, 8))]
 
 
 @pytest.mark.parametrize("form,case", PW_RES_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in PW_RES_CASES])
