@@ -431,7 +431,7 @@ namespace fqi {
 
 // sample form (K2r): stride 1, Cout a multiple of 256, Cin a multiple of 32, and either
 //   planes of a multiple of 4 pixels that cut into blocks of 96..128 pixels (14x14: two, 28x28: seven), K / 32 in {4, 8, 16}, or
-//   whole planes of 45..64 pixels with 0 or 1 pixel past a multiple of four (7x7, 8x8), K / 32 in {16, 32} (a residual operand: 16).
+//   whole planes of 45..64 pixels with 0 or 1 pixel past a multiple of four (7x7, 8x8), K / 32 in {16, 32, 64} (a residual operand: 16).
 // grid = samples x channel groups x pixel blocks (rounded to whole rounds over the 8 XCDs).
 int pw_try_sample(const PwCall& a, bool* taken) {
   *taken = false;
@@ -441,7 +441,7 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   const bool small = a.hw <= 64;                                        // one block of two pixel tiles
   const int64_t quads = (a.hw + 3) / 4;
   const int nb = small ? 1 : (int)((quads + 31) / 32);                  // fewest blocks of at most 32 pixel groups
-  const bool plane_ok = small ? (a.hw >= 45 && a.hw % 4 <= 1 && (kt == 16 || (kt == 32 && a.residual == nullptr)))
+  const bool plane_ok = small ? (a.hw >= 45 && a.hw % 4 <= 1 && (kt == 16 || ((kt == 32 || kt == 64) && a.residual == nullptr)))
                               : (a.hw % 4 == 0 && quads / nb >= 24 && (kt == 4 || kt == 8 || kt == 16 || kt == 32));
   const bool shape_ok = plane_ok && a.stride == 1 && a.cin == a.cin_pad && a.cout % 256 == 0 &&
                         a.n < (1 << 20) && a.cin * a.hw * 4 < (1ll << 31) && (small || aligned16(a.x));
@@ -509,6 +509,7 @@ int pw_try_sample(const PwCall& a, bool* taken) {
 #endif
   // whole small planes
   FQ_PWSMP_CASE(16, 1, 2, 1) FQ_PWSMP_CASE(16, 2, 2, 1) FQ_PWSMP_CASE(32, 1, 2, 1) FQ_PWSMP_CASE(32, 2, 2, 1)
+  FQ_PWSMP_CASE(64, 1, 2, 1) FQ_PWSMP_CASE(64, 2, 2, 1)                 // (2048 -> 512 @7x7, ResNet-50's last stage)
   // with a residual operand: the last 1x1 convolutions of the ResNet bottlenecks (128 -> 512 @28x28, 256 -> 1024 @14x14)
   FQ_PWSMP_CASE_R(4, 2, 4, true, 1) FQ_PWSMP_CASE_R(8, 2, 4, true, 1) FQ_PWSMP_CASE_R(16, 2, 4, true, 1)
   // ... and 512 -> 2048 @7x7 (a whole small plane)

@@ -510,7 +510,8 @@ FORM_CASES = [
     ("sample", (5, 128, 512, 10, 10)), ("sample", (2, 256, 768, 16, 24)),
     # ... whole small planes in two pixel tiles: 7x7 (49 pixels: the last one has a load of its own) and 8x8, K/32 = 16 and 32
     ("sample", (5, 512, 1024, 7, 7)), ("sample", (3, 1024, 1024, 7, 7)), ("sample", (2, 512, 256, 8, 8)),
-    ("sample", (9, 1024, 512, 7, 7)), ("sample", (3, 1024, 256, 14, 14)),
+    ("sample", (9, 1024, 512, 7, 7)), ("sample", (3, 1024, 256, 14, 14)), ("sample", (3, 2048, 512, 7, 7)),
+    ("sample", (2, 2048, 256, 8, 8)),
     # pipe (round 5: weights resident in registers, sub-tiles of <= 7 / 8 pixel groups through LDS-DMA): K = 512 and 256; 14x14
     # in two blocks of 25 + 24 groups (four sub-tiles each), two channel groups, XCD shares left ragged by the sample count,
     # one block of 25 groups (10x10), three blocks of 32 (16x24), a single sub-tile (4x4), two sub-tiles of 5 + 4 (6x6)
