@@ -333,7 +333,10 @@ def main():
                     help="bracket the library's kernels with HIP events in every n-th timed step (default 50 - calibration "
                          "phases, whose blocks are a dozen batches with a special first one: 7 -: 10 steps of the "
                          "default 500 = 130 launches per family; a bracketed step is launched eagerly and, with --streams > 1, "
-                         "runs alone - at every 25th step that cost `value` 4 %%: 126 k against 132 k images/s without events)")
+                         "runs alone - at every 25th step that cost `value` 4 %%: 126 k against 132 k images/s without events).  "
+                         "Only every third block (1, 4, 7 ...; FQ_BENCH_EVENT_BLOCK_EVERY, 1 = every block) carries bracketed "
+                         "steps, so the median block has none; a run that needs a single block gets a second one for them "
+                         "(one more than --max-repeats 1 allows)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events in the timed region (roofline fields become empty)")
     ap.add_argument("--no-headline", action="store_true",
