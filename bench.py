@@ -357,9 +357,9 @@ def main():
                          "kept per stream), so that the ramp and the tail of one batch's ~30 kernels fill with the other batch's work "
                          "(independent batches; every step's kernels, results and counters are what they are with S = 1).  "
                          "1: one stream, the figure of rounds 1-3; the line reports that too (`single_stream`).  0 (default): 4 where the "
-                         "layers hand integer codes over (--offline: short, vector-unit-bound kernels; 4 against 3 +2.6 % on "
-                         "MobileNetV2 W4, 5 and 6 lose 8-12 %), else 3 (fp32 tensors between the layers: 4 against 3 was +0.6 / "
-                         "+0.8 % on two boxes and -1.1 % (sd 0.05) on a third; profiles/r5_lanes4_ab.txt)")
+                         "layers hand integer codes over (--offline: short, vector-unit-bound kernels; 4 against 3 +2.6 %% on "
+                         "MobileNetV2 W4, 5 and 6 lose 8-12 %%), else 3 (fp32 tensors between the layers: 4 against 3 was +0.6 / "
+                         "+0.8 %% on two boxes and -1.1 %% (sd 0.05) on a third; profiles/r5_lanes4_ab.txt)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

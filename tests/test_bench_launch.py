@@ -42,3 +42,10 @@ def test_mismatched_world_is_an_error():
                          env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True,
                          timeout=300)
     assert res.returncode != 0 and "launcher started 2" in res.stderr
+
+
+def test_help_texts_format():
+    """argparse expands help strings with %: a bare per-cent sign in one of them only shows when --help is asked for."""
+    for script in ("bench.py", os.path.join("examples", "simulate_quantization.py")):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, script), "--help"], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and "usage" in res.stdout, res.stderr[-1500:]
