@@ -131,6 +131,30 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   c.eval_labels = eval_labels; c.eval_counters = eval_counters; c.eval_ws = eval_ws;
   static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample, 8 rows, 9 pipe
   c.form = (in_c16 || c.out_thr) ? 6 : (eval_labels ? 8 : (forced_form ? forced_form : pw_form));
+  // tuning: FQ_PW_FORM_AT="<pixels per plane>:<form>[,...]" names a form for the layers of one plane size (A/Bs of a form choice
+  // inside a model, where a kernel's time alone is not what decides - DESIGN.md 3.6); parsed once
+  {
+    static int at_hw[8], at_form[8], at_n = -1;
+    if (at_n < 0) {
+      int k = 0;
+      if (const char* e = getenv("FQ_PW_FORM_AT")) {
+        while (*e && k < 8) {
+          char* end = nullptr;
+          const long a = strtol(e, &end, 10);
+          if (end == e || *end != ':') break;
+          const long f = strtol(end + 1, &end, 10);
+          at_hw[k] = (int)a;
+          at_form[k++] = (int)f;
+          e = *end == ',' ? end + 1 : end;
+          if (*end != ',') break;
+        }
+      }
+      at_n = k;
+    }
+    if (c.form == 0 && !range)
+      for (int k = 0; k < at_n; ++k)
+        if (at_hw[k] == (int)hw) c.form = at_form[k];
+  }
   FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6 || c.form == 7 || c.form == 8 || c.form == 9,
              "fq_pwconv_i8: unknown "
              "form %d (1 two kernels, 3 stream, 6 split, 7 sample, 8 rows, 9 pipe; the panel / chunk / tile forms 2, 4, 5 were retired "
