@@ -32,7 +32,9 @@ def T(a, dev):
 # the streaming form, round 4, instead of one-tile workgroups of the split form; all of them are compared with the split form)
 PW_CASES = [(12, 16, 96, 112, 112, 1), (11, 32, 16, 112, 112, 1), (43, 96, 24, 56, 56, 1), (43, 24, 144, 56, 56, 1),
             (43, 144, 24, 56, 56, 1), (2, 64, 64, 14, 14, 1), (3, 16, 96, 9, 11, 1), (2, 144, 24, 7, 7, 1), (2, 96, 40, 5, 6, 1), (2, 256, 512, 8, 8, 2),
-            (1, 320, 1280, 7, 7, 1), (4, 960, 160, 3, 3, 1), (1, 32, 192, 28, 28, 1)]
+            (1, 320, 1280, 7, 7, 1), (4, 960, 160, 3, 3, 1), (1, 32, 192, 28, 28, 1),
+            # (MobileNetV2's expansions on 14x14 / 7x7: fp32 in, codes out)
+            (3, 64, 384, 14, 14, 1), (2, 96, 576, 14, 14, 1), (3, 160, 960, 7, 7, 1), (2, 64, 320, 5, 5, 1)]
 
 
 @pytest.mark.parametrize("case", PW_CASES, ids=["%dx%d->%d@%dx%d/s%d" % c for c in PW_CASES])
