@@ -134,26 +134,27 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   // tuning: FQ_PW_FORM_AT="<pixels per plane>:<form>[,...]" names a form for the layers of one plane size (A/Bs of a form choice
   // inside a model, where a kernel's time alone is not what decides - DESIGN.md 3.6); parsed once
   {
-    static int at_hw[8], at_form[8], at_n = -1;
-    if (at_n < 0) {
-      int k = 0;
+    struct FormAt { int hw[8], form[8], n; };
+    static const FormAt at = [] {
+      FormAt t;
+      t.n = 0;
       if (const char* e = getenv("FQ_PW_FORM_AT")) {
-        while (*e && k < 8) {
+        while (*e && t.n < 8) {
           char* end = nullptr;
           const long a = strtol(e, &end, 10);
           if (end == e || *end != ':') break;
           const long f = strtol(end + 1, &end, 10);
-          at_hw[k] = (int)a;
-          at_form[k++] = (int)f;
-          e = *end == ',' ? end + 1 : end;
+          t.hw[t.n] = (int)a;
+          t.form[t.n++] = (int)f;
           if (*end != ',') break;
+          e = end + 1;
         }
       }
-      at_n = k;
-    }
+      return t;
+    }();
     if (c.form == 0 && !range)
-      for (int k = 0; k < at_n; ++k)
-        if (at_hw[k] == (int)hw) c.form = at_form[k];
+      for (int k = 0; k < at.n; ++k)
+        if (at.hw[k] == (int)hw) c.form = at.form[k];
   }
   FQ_REQUIRE(c.form == 0 || c.form == 1 || c.form == 3 || c.form == 6 || c.form == 7 || c.form == 8 || c.form == 9,
              "fq_pwconv_i8: unknown "
