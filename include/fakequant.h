@@ -321,6 +321,42 @@ int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wsca
                          unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
                          int act, float* stat_out, const float* residual, void* ws, fqStream_t stream);
 
+/* ---- a pointwise convolution and the depthwise 3x3 behind it WITHOUT the tensor between them (round 6) ---------------------
+ * Under ONLINE input quantisation (convert_conv2d.py:56-58: the threshold of a block is the batch mean of the per-sample maxima
+ * of the tensor it is handed in this very forward) a producer cannot hand codes to its consumer - the threshold exists only
+ * after the producer's last value.  It CAN be computed twice: for the pair  x -> [1x1 + BN + act] -> y -> [3x3 depthwise + BN +
+ * act] -> z  of the MobileNets (y has up to twice x's channels)
+ *   (A) fq_pwconv_i8_stat: fq_pwconv_i8 without its stores - stat_out[n] <- max|y[n]|, out_current_max <- the 1x1 block's
+ *       `current_input_max`; reads x, writes n floats;
+ *   (B) fq_pwdw_fused: recomputes y from x tile by tile (the same exact int32 sums and the same epilogue: bit for bit the
+ *       values (A) took the maxima of), fake-quantises it with the threshold mid_stat now determines (LinearQuantizeSTE,
+ *       ste_func.py:41, as the depthwise block's activation branch convert_conv2d.py:53-66 would) and runs the depthwise
+ *       chain of fq_dwconv3x3 on it: z, stat_out[n] <- max|z[n]|, mid_current_max <- the depthwise block's
+ *       `current_input_max`.  y never exists in memory: 4x + 4x + 4z bytes instead of 4x + 4y + 4y + 4z.
+ * Values: exactly those of fq_pwconv_i8 followed by fq_dwconv3x3 (tests/test_gpu_pwdw.py: bit-equal z, statistics and
+ * thresholds, and against the host twins).  Offline thresholds work too (in_thr / mid_thr: then (A) is not needed at all).
+ * Shapes: fq_pwdw_fused_supported - cin in (0, 256] with ceil(cin / 32) in {1, 2, 4, 8}, cout % 32 == 0 (at most 8 wavefronts:
+ * ceil(w / 30) * cout / 64 <= 8), w % 4 == 0, w >= 30 or w == 28; stride 2 needs even h and w % 8 == 0.  x: (n, cin, h, w);
+ * z: (n, cout, ho, wo).  wcodes: fq_weight_codes' buffer (both copies), cout_pad its rows_pad.  dw_act may carry
+ * FQ_STAT_PREZEROED.                                                                                                      */
+int fq_pwconv_i8_stat_supported(int64_t n, int64_t cin, int64_t cout, int64_t hw);
+int fq_pwconv_i8_stat(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                      int64_t n, int64_t cin, int64_t cin_pad, int64_t cout_pad, int64_t cout, int64_t hw,
+                      const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                      const float* bn_scale, const float* bn_shift, int act, float* stat_out, fqStream_t stream);
+int fq_pwdw_fused_supported(int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, int stride);
+/* Test hook: out[i] <- the fp32 quotient c[i] / d[0] as the two kernels above compute it (the fp32 correction step of
+ * csrc/fq_common.h: fast_quot, or the fp64-reciprocal form when d[0] does not qualify; took_fast_path[0] says which) - must
+ * equal the IEEE fp32 division bit for bit wherever a code depends on it (tests/test_gpu_pwdw.py).                         */
+int fq_debug_fast_quotient(const float* c, int64_t n, const float* d, float* out, int* took_fast_path, fqStream_t stream);
+int fq_pwdw_fused(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* pw_bias,
+                  int64_t n, int64_t cin, int64_t cin_pad, int64_t cout_pad, int64_t cout, int64_t h, int64_t w,
+                  const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, const float* pw_bn_scale,
+                  const float* pw_bn_shift, int pw_act, const float* mid_stat, const float* mid_thr, int mid_width,
+                  unsigned mid_flags, float* mid_current_max, const float* dw_w, const float* dw_bias, int dw_stride,
+                  const float* dw_bn_scale, const float* dw_bn_shift, int dw_act, float* y, float* stat_out,
+                  fqStream_t stream);
+
 /* ---- int8 hand-over between fused convolutions under OFFLINE input quantisation (round 3) ------------------------------
  * When the consumer quantises its input with a STORED threshold (`--quantize-input-offline`: convert_conv2d.py:58 takes
  * `input_max`, known before the producer runs), the producer's epilogue can apply the consumer's LinearQuantizeSTE

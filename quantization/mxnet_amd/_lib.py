@@ -62,6 +62,16 @@ EXPORTS = {
     "fq_pwconv_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "fq_pwconv_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                             _vp, _int, _vp, _vp, _vp]),
+    "fq_pwconv_i8_stat_supported": (_int, [_i64, _i64, _i64, _i64]),
+    "fq_pwconv_i8_stat": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
+                                 _vp, _int, _vp, _vp]),
+    "fq_pwdw_fused_supported": (_int, [_i64, _i64, _i64, _i64, _i64, _int]),
+    # x, wcodes, wscale, wsum, pw_bias, n, cin, cin_pad, cout_pad, cout, h, w, in_stat, in_thr, in_width, in_flags, pw_bn_scale,
+    # pw_bn_shift, pw_act, mid_stat, mid_thr, mid_width, mid_flags, mid_cur, dw_w, dw_bias, dw_stride, dw_bn_scale, dw_bn_shift,
+    # dw_act, y, stat_out, stream
+    "fq_pwdw_fused": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp,
+                             _vp, _int, _vp, _vp, _int, _uint, _vp, _vp, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp]),
+    "fq_debug_fast_quotient": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "fq_dense_i8_eval_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "fq_dense_i8_eval": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp, _vp,
                                 _vp, _vp, _vp]),

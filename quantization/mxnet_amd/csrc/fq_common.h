@@ -487,6 +487,44 @@ __device__ __forceinline__ int stored_zero4(int ubias) { return (int)(((unsigned
 // as in IEEE (rden = inf).  Checked exhaustively around every .5 tie in tests/test_gpu_parity.py.
 __device__ __forceinline__ float ieee_div_by(float c, double rden) { return (float)((double)c * rden); }
 
+// The same correctly rounded quotient WITHOUT fp64 instructions (round 6; the recompute kernels of fq_pwdw.hip are bound by
+// vector-instruction CYCLES, and v_cvt_f64_f32 / v_mul_f64 / v_cvt_f32_f64 cost about twice an fp32 instruction each:
+// profiles/r6_pwdw_pmc.txt).  Markstein's correction step: with y = RN_f32(1/d),
+//   q = RN(c * y);  r = fma(-q, d, c)  (exact: the residual of a quotient that is within an ulp);  q' = fma(r, y, q)
+// is RN_f32(c / d) whenever nothing under- or overflows and the significand of d is not all ones (P. Markstein, "Computation of
+// elementary functions on the IBM RISC System/6000", IBM J. Res. Dev. 1990; the FMA-based division chapter of Muller et al.,
+// Handbook of Floating-Point Arithmetic).  make_fast_quot() decides once per launch - a wave-uniform branch - whether the divisor
+// qualifies (normal, significand not all ones, reciprocal normal) and otherwise the caller stays with ieee_div_by().
+// What is NEEDED is less than the theorem gives: only the integer the quotient rounds to, for quotients in [0, levels]; a
+// quotient below 0.25 rounds to 0 whatever its last bits (that covers dividends so small that q or r would be denormal).
+// tests/test_gpu_pwdw.py drives fq_debug_fast_quotient over every k + 0.5 tie +- 4 ulp for thousands of divisors.
+struct FastQuot {
+  float d, y;        // divisor, RN_f32(1 / d)
+  bool ok;
+};
+__device__ __forceinline__ FastQuot make_fast_quot(float d) {
+  FastQuot f;
+  f.d = d;
+  // RN_f32(1/d) without double rounding: among the fp32 neighbours of (float)(1.0 / d) take the one whose product with d is
+  // closest to 1 (the products of two fp32 numbers are exact in fp64, and so is their distance from 1)
+  const double dd = (double)d;
+  float y = (float)(1.0 / dd);
+  const float ylo = __uint_as_float(__float_as_uint(y) - 1u), yhi = __uint_as_float(__float_as_uint(y) + 1u);
+  const double e = fabs(1.0 - (double)y * dd), elo = fabs(1.0 - (double)ylo * dd), ehi = fabs(1.0 - (double)yhi * dd);
+  if (elo < e && elo <= ehi) y = ylo;
+  else if (ehi < e) y = yhi;
+  f.y = y;
+  const unsigned db = __float_as_uint(d), yb = __float_as_uint(y);
+  const unsigned de = (db >> 23) & 0xFFu, ye = (yb >> 23) & 0xFFu;
+  f.ok = (db >> 31) == 0u && de >= 1u && de <= 253u && ye >= 1u && ye <= 253u && (db & 0x7FFFFFu) != 0x7FFFFFu;
+  return f;
+}
+__device__ __forceinline__ float fast_quot(float c, const FastQuot& f) {
+  const float q = c * f.y;
+  const float r = fmaf(-q, f.d, c);
+  return fmaf(r, f.y, q);
+}
+
 // The integer stage and the dequantised value (ste_func.py:41): clip -> IEEE divide -> roundf -> multiply.
 // roundf(Q) (half away from zero) == trunc(Q + copysign(pred(0.5), Q)) for every fp32 |Q| < 2^23: the only fp32 whose
 // sum with 0.5 would round across an integer is pred(0.5), and pred(0.5) + pred(0.5) is exact (checked exhaustively for

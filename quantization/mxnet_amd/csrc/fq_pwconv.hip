@@ -220,6 +220,44 @@ int fq_pwconv_i8(const float* x, const int8_t* wcodes, const float* wscale, cons
                          in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, nullptr, ws, stream);
 }
 
+// The statistic-only pass in front of fq_pwdw_fused (round 6): the per-sample maxima fq_pwconv_i8 would leave in stat_out
+// (and its out_current_max) without computing, let alone storing, more of the output than its extreme sums (fq_pwdw.hip, K2z).
+int fq_pwconv_i8_stat_supported(int64_t n, int64_t cin, int64_t cout, int64_t hw) {
+  return pw_stat_shape_ok(n, cin, cout, hw) ? 1 : 0;
+}
+
+int fq_pwconv_i8_stat(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                      int64_t n, int64_t cin, int64_t cin_pad, int64_t cout_pad, int64_t cout, int64_t hw,
+                      const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                      const float* bn_scale, const float* bn_shift, int act, float* stat_out, fqStream_t stream) {
+  FQ_REQUIRE(x && wcodes && wscale && wsum && stat_out, "fq_pwconv_i8_stat: null pointer");
+  FQ_REQUIRE(pw_stat_shape_ok(n, cin, cout, hw), "fq_pwconv_i8_stat: shape not taken (n=%lld cin=%lld cout=%lld hw=%lld): see "
+             "fq_pwconv_i8_stat_supported", (long long)n, (long long)cin, (long long)cout, (long long)hw);
+  FQ_REQUIRE(cin_pad >= cin && cin_pad % 64 == 0 && cin_pad <= 8192 && cout_pad >= cout && cout_pad % 32 == 0,
+             "fq_pwconv_i8_stat: cin_pad / cout_pad must be those of fq_weight_codes");
+  FQ_REQUIRE(in_stat != nullptr || in_thr != nullptr, "fq_pwconv_i8_stat: give in_stat (online), in_thr (offline) or both");
+  FQ_REQUIRE(in_width >= 2 && in_width <= 8, "fq_pwconv_i8_stat: input width %d does not fit int8 codes", in_width);
+  FQ_REQUIRE(!(in_flags & (FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "fq_pwconv_i8_stat: unsupported activation flags");
+  FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_pwconv_i8_stat: bn_scale and bn_shift go together");
+  PwCall c;
+  c.prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_pwconv_i8_stat: unknown activation %d", act);
+  FQ_REQUIRE(aligned16(wcodes) && aligned16(x), "fq_pwconv_i8_stat: x and wcodes must be 16-byte aligned");
+  c.x = x; c.wcodes = wcodes + cout_pad * cin_pad; c.wscale = wscale; c.wsum = wsum; c.bias = bias; c.y = nullptr;
+  c.n = n; c.cin = cin; c.cin_pad = cin_pad; c.cout = cout; c.hw = hw; c.stride = 1; c.h_in = c.w_in = c.w_out = 0;
+  c.in_stat = in_stat; c.in_thr = in_thr;
+  c.levels = act_levels(in_width, in_flags);
+  c.lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0;
+  c.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;
+  c.out_current_max = out_current_max; c.bn_scale = bn_scale; c.bn_shift = bn_shift; c.act = act;
+  c.stat_out = stat_out; c.residual = nullptr; c.ws = nullptr; c.st = (hipStream_t)stream; c.form = 0;
+  // algorithmic bytes: the pointwise layer's (this launch stands for it); moved: its input only
+  const double in_elems = (double)n * cin * hw, out_elems = (double)n * cout * hw;
+  ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * (in_elems + out_elems), c.st, 4.0 * in_elems);
+  return pw_stat_launch(c);
+}
+
 int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                          const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h,
                          int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,

@@ -70,7 +70,11 @@ class NDArray(object):
     # feature maps (quantize/distribution_calibrate.py): who made this tensor, and whether that pass already binned it.
     # _fq_side: optional (consumer block, ops.Codes16) - `_t` is the fp32 trunk of a ResNet and the codes of the SAME values under
     # that consumer's stored threshold ride beside it (fq_pwconv_i8_c16_dual; quantize/convert/convert_conv2d.pointwise_fused).
-    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl", "_fq_side")
+    # _fq_deferred: optional dict - this NDArray stands for the output of a fused 1x1 convolution that was NOT stored: only its
+    # per-sample statistic was computed (`_fq_stat`, fq_pwconv_i8_stat) and the single consumer, the depthwise convolution
+    # linked behind it, recomputes the values inside its own launch (fq_pwdw_fused; quantize/convert/convert_conv2d.py).  `_t`
+    # is then an int8 placeholder of the right shape without storage, so that any other reader fails loudly.
+    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl", "_fq_side", "_fq_deferred")
     __array_priority__ = 1000.0
     __array_ufunc__ = None
 
@@ -82,6 +86,7 @@ class NDArray(object):
         self._fq_nonneg = False
         self._fq_kl = None
         self._fq_side = None
+        self._fq_deferred = None
 
     # -- plumbing ---------------------------------------------------------------------------
     @property

@@ -629,6 +629,79 @@ def dwconv3x3_c16(x, w, bias=None, stride=1, in_stat=None, in_thr=None, width=8,
     return y, stat
 
 
+def pwdw_supported(xshape, cout, stride):
+    """True when the pair (1x1 to `cout` channels, depthwise 3x3 of stride `stride`) on an (N, Cin, H, W) input is a shape both
+    fq_pwconv_i8_stat and fq_pwdw_fused take."""
+    n, cin, h, w = (int(v) for v in xshape)
+    lib = _lib_()
+    return bool(lib.fq_pwconv_i8_stat_supported(n, cin, int(cout), h * w)) and \
+        bool(lib.fq_pwdw_fused_supported(n, cin, int(cout), h, w, int(stride)))
+
+
+def pwconv_i8_stat(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
+                   bn_scale=None, bn_shift=None, act=None):
+    """The statistic-only pass of a fused 1x1 convolution (fq_pwconv_i8_stat): what `pwconv_i8` computes without storing it.
+    Returns the per-sample maxima max|y[n]| (N,)."""
+    _check(x, "x")
+    _check(wcodes, "wcodes", torch.int8)
+    _check(wscale, "wscale")
+    _check(wsum, "wsum", torch.int32)
+    for name, t in (("bias", bias), ("in_stat", in_stat), ("in_thr", in_thr), ("bn_scale", bn_scale),
+                    ("bn_shift", bn_shift), ("cur_out", cur_out)):
+        if t is not None:
+            _check(t, name)
+    n, cin = x.shape[0], x.shape[1]
+    cout = wscale.numel()
+    cin_pad = wcodes.shape[1]
+    if (cin + 63) // 64 * 64 != cin_pad:
+        raise ValueError("x has %d channels but the weight codes were made for a row length that pads to %d" % (cin, cin_pad))
+    if in_stat is not None and cur_out is None:
+        cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+    stat, zflag = _stat_target(n, x.device, True)
+    hw = x.numel() // (n * cin)
+    check_call(_lib_().fq_pwconv_i8_stat(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), n, cin, cin_pad,
+                                         wcodes.shape[0], cout, hw, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(cur_out),
+                                         _ptr(bn_scale), _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _stream(x)))
+    return stat
+
+
+def pwdw_fused(x, wcodes, wscale, wsum, dw_w, pw_bias=None, in_stat=None, in_thr=None, width=8, flags=0, pw_bn_scale=None,
+               pw_bn_shift=None, pw_act=None, mid_stat=None, mid_thr=None, mid_width=8, mid_flags=0, mid_cur_out=None,
+               dw_bias=None, stride=1, dw_bn_scale=None, dw_bn_shift=None, dw_act=None, want_stat=True):
+    """A fused 1x1 convolution and the depthwise 3x3 behind it in one launch (fq_pwdw_fused): the values of `pwconv_i8`
+    followed by `dwconv3x3` with quantise-on-load, without the tensor between them.  `mid_stat`: the per-sample maxima of the
+    1x1 output (`pwconv_i8_stat`), or `mid_thr`: a stored threshold.  Returns (z, stat or None)."""
+    _check(x, "x")
+    _check(wcodes, "wcodes", torch.int8)
+    _check(wscale, "wscale")
+    _check(wsum, "wsum", torch.int32)
+    _check(dw_w, "dw_w")
+    for name, t in (("pw_bias", pw_bias), ("in_stat", in_stat), ("in_thr", in_thr), ("pw_bn_scale", pw_bn_scale),
+                    ("pw_bn_shift", pw_bn_shift), ("mid_stat", mid_stat), ("mid_thr", mid_thr), ("mid_cur_out", mid_cur_out),
+                    ("dw_bias", dw_bias), ("dw_bn_scale", dw_bn_scale), ("dw_bn_shift", dw_bn_shift)):
+        if t is not None:
+            _check(t, name)
+    if x.dim() != 4:
+        raise ValueError("pwdw_fused wants x (N, Cin, H, W); got %s" % (tuple(x.shape),))
+    n, cin, h, w = x.shape
+    cout = wscale.numel()
+    if dw_w.dim() != 4 or tuple(dw_w.shape) != (cout, 1, 3, 3):
+        raise ValueError("pwdw_fused wants dw_w (%d,1,3,3); got %s" % (cout, tuple(dw_w.shape)))
+    cout_pad, cin_pad = wcodes.shape
+    if (cin + 63) // 64 * 64 != cin_pad:
+        raise ValueError("x has %d channels but the weight codes were made for a row length that pads to %d" % (cin, cin_pad))
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+    stat, zflag = _stat_target(n, x.device, want_stat)
+    check_call(_lib_().fq_pwdw_fused(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(pw_bias), n, cin, cin_pad, cout_pad,
+                                     cout, h, w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(pw_bn_scale),
+                                     _ptr(pw_bn_shift), _ACTS[pw_act], _ptr(mid_stat), _ptr(mid_thr), int(mid_width),
+                                     int(mid_flags), _ptr(mid_cur_out), _ptr(dw_w), _ptr(dw_bias), int(stride),
+                                     _ptr(dw_bn_scale), _ptr(dw_bn_shift), _ACTS[dw_act] | zflag, _ptr(y), _ptr(stat),
+                                     _stream(x)))
+    return y, stat
+
+
 def weight_codes(w, rows_per_scale, width=8):
     """Integer codes of the weight fake-quant (convert_conv2d.py:70-95): code = roundf(w / (s + 1e-10)) with one scale
     per `rows_per_scale` leading rows.  Returns (codes int8 [rows_pad, row_pad] zero padded to multiples of 64,

@@ -312,6 +312,81 @@ def side_target(block, c16_in):
     return nxt
 
 
+_PLACEHOLDERS = {}
+
+
+def _placeholder(shape, device):
+    """An int8 tensor of `shape` without storage of its own (one byte, expanded): what a deferred NDArray carries as `_t` - any
+    reader but the linked consumer fails on the dtype."""
+    one = _PLACEHOLDERS.get(device)
+    if one is None:
+        one = _PLACEHOLDERS[device] = torch.zeros(1, dtype=torch.int8, device=device)
+    return one.expand(*shape)
+
+
+def recompute_target(block, fz, x, plan, c16_in):
+    """The depthwise block behind this fused 1x1 convolution when the pair may run as statistic pass + ONE recomputing launch
+    (fq_pwconv_i8_stat + fq_pwdw_fused; quantize/fuse.py links `pair_dw`): both blocks quantise their inputs ONLINE in this very
+    forward (convert_conv2d.py:56-58 - the case in which no codes can be handed over), nothing observes the tensor between them
+    (no hooks, no KL collection, no multi-GPU exchange of the depthwise block's statistic), no residual operand, and the shape
+    is one both kernels take.  Returns the block or None."""
+    from .. import fuse as _fuse
+    nxt = fz.get("pair_dw")
+    if nxt is None or not _fuse.RECOMPUTE or c16_in is not None or autograd.is_recording() or _fuse._collection is not None:
+        return None
+    if "in_stat" not in plan or "in_thr" in plan or getattr(block, "_fq_residual", None) is not None:
+        return None
+    a = nxt.quantize_args
+    if not (nxt.enable_quantize and a.quantize_input and nxt.quantize_input and not nxt.quantize_input_offline
+            and getattr(nxt, "_fq_global_stat", None) is None and not a.fake_bn and nxt._kwargs["num_group"] == block._kwargs["num_filter"]):
+        return None
+    if any(_hooked(b) for b in (block, nxt, fz.get("bn"), fz.get("act_block"))):
+        return None
+    t = x._t
+    if t.dim() != 4 or t.shape[2] * t.shape[3] < _fuse.RECOMPUTE_MIN_PIXELS or t.shape[1] > _fuse.RECOMPUTE_MAX_CIN:
+        return None
+    if not ops.pwdw_supported(tuple(t.shape), block._kwargs["num_filter"], nxt._kwargs["stride"][0]):
+        return None
+    return nxt
+
+
+def _materialise(x):
+    """The tensor a deferred NDArray stands for, computed after all (its consumer turned out not to be the linked depthwise
+    block in a state that takes it): the storing launch with the arguments the statistic pass had."""
+    d = x._fq_deferred
+    y, stat = ops.pwconv_i8(d["x"], *d["codes"], d["bias"], bn_scale=d["bn"][0], bn_shift=d["bn"][1], act=d["act"], **d["plan"])
+    out = NDArray(y)
+    out._fq_stat = stat
+    return out
+
+
+def depthwise_recompute(block, x, weight_q, bias, flags, width):
+    """The second half of a recompute pair: `x` is a deferred NDArray (statistic only); this block's activation branch
+    (convert_conv2d.py:53-66) and its convolution (:108) run inside fq_pwdw_fused on the 1x1 output recomputed there."""
+    d = x._fq_deferred
+    fz = block._fq_dw_fused
+    scale, shift = fz["constants"]() if fz["bn"] is not None else (None, None)
+    src = d["x"]
+    n = src.shape[0]
+    cur, side = scalar_slot(block, src)
+    stat = x._fq_stat
+    rows = getattr(block, "_fq_stat_ws", None)
+    if rows is not None and rows.device == src.device and rows.numel() >= n:
+        rows[:n].copy_(stat)                              # (calibration under dist.py reads the statistic matrix back)
+    p = d["plan"]
+    z, zstat = ops.pwdw_fused(src, *d["codes"], contiguous(weight_q._t), pw_bias=d["bias"], in_stat=p["in_stat"],
+                              width=p["width"], flags=p["flags"], pw_bn_scale=d["bn"][0], pw_bn_shift=d["bn"][1],
+                              pw_act=d["act"], mid_stat=stat, mid_width=width, mid_flags=flags, mid_cur_out=cur,
+                              dw_bias=None if bias is None else bias._t, stride=block._kwargs["stride"][0],
+                              dw_bn_scale=scale, dw_bn_shift=shift, dw_act=fz["act"])
+    if not side:
+        block._fq_last_n = n
+        block.current_input_max = DeviceScalar(cur)
+    out = NDArray(z)
+    out._fq_stat = zstat
+    return out
+
+
 def _handed_over(x):
     """ops.Codes16 riding on an NDArray a producer handed over, else None."""
     return getattr(x, "_fq_c16", None)
@@ -400,6 +475,18 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                         out_codes = None
                 if out_codes is not None:
                     extra = dict(out_codes=out_codes)
+            pair = recompute_target(block, fz, x, plan, c16_in) if not extra else None
+            if pair is not None:
+                # statistic only; the depthwise block behind recomputes the values inside its own launch
+                b_ = None if bias is None else bias._t
+                stat = ops.pwconv_i8_stat(x_arg, codes, scales, rowsum, b_, bn_scale=scale, bn_shift=shift, act=fz["act"], **plan)
+                xs = tuple(x_arg.shape)
+                res_ = NDArray(_placeholder((xs[0], block._kwargs["num_filter"], xs[2], xs[3]), x_arg.device))
+                res_._fq_stat = stat
+                res_._fq_deferred = dict(x=x_arg, codes=(codes, scales, rowsum), bias=b_, bn=(scale, shift), act=fz["act"],
+                                         plan=dict(in_stat=plan["in_stat"], width=plan["width"], flags=plan["flags"],
+                                                   cur_out=plan.get("cur_out")), consumer=pair)
+                return res_
             out = ops.pwconv_i8(x_arg, codes, scales, rowsum, None if bias is None else bias._t,
                                 bn_scale=scale, bn_shift=shift,
                                 act=res["act"] if "residual" in extra else fz["act"],
@@ -501,9 +588,16 @@ def _quantised_conv(self, F, x, weight, bias=None, input_max=None,
         terms = BatchNormTerms(gamma, beta, running_mean, running_var)
         weight, bias = terms.fold_weight(F, weight), terms.fold_bias(F, bias)
 
+    deferred = getattr(x, "_fq_deferred", None)
+    if deferred is not None and not (deferred["consumer"] is self and dw is not None and self.enable_quantize
+                                     and args.quantize_input and self.quantize_input and not self.quantize_input_offline):
+        x, deferred = _materialise(x), None              # (not the consumer the pair was made for: the stored tensor after all)
+
     weight_q = weight
     if self.enable_quantize:
-        if args.quantize_input:                                                # :55-66
+        if args.quantize_input and deferred is not None:                       # :55-66, inside the recomputing launch
+            flags = ops.act_flags(signed=args.in_signed)
+        elif args.quantize_input:                                              # :55-66
             flags = ops.act_flags(signed=args.in_signed)
             if taken_over:
                 plan = fused_input_plan(self, x, input_max, flags, args.in_width)
@@ -518,6 +612,8 @@ def _quantised_conv(self, F, x, weight, bias=None, input_max=None,
         if bias is not None:
             self.bias.set_data(bias)
 
+    if deferred is not None:
+        return depthwise_recompute(self, x, weight_q, bias, flags, args.in_width)
     if dw is not None:
         return depthwise_fused(self, x, weight_q, bias, plan)
     if pw is not None:

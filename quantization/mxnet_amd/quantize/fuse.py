@@ -152,6 +152,13 @@ HANDOVER = _os.environ.get("FQ_HANDOVER", "1") != "0"      # int8 C16 hand-over 
 SIDE_CODES = _os.environ.get("FQ_HANDOVER_SIDE", "1") != "0"
 # ... and MobileNetV2's first convolution hands its single consumer's codes over (fq_stem_conv3x3s2_c16)
 STEM_CODES = _os.environ.get("FQ_HANDOVER_STEM", "1") != "0"
+# Recompute pairs (round 6, csrc/fq_pwdw.hip): under ONLINE input quantisation a fused 1x1 convolution followed by a fused
+# depthwise 3x3 runs as a statistic-only pass + ONE launch that recomputes the 1x1 output inside the depthwise kernel - the
+# tensor between them is never written.  FQ_RECOMPUTE=0 keeps the two storing launches (A/B); FQ_RECOMPUTE_MIN_PIXELS: the
+# smallest input plane (pixels) the pair is taken on.
+RECOMPUTE = _os.environ.get("FQ_RECOMPUTE", "1") != "0"
+RECOMPUTE_MIN_PIXELS = int(_os.environ.get("FQ_RECOMPUTE_MIN_PIXELS", "3136"))
+RECOMPUTE_MAX_CIN = int(_os.environ.get("FQ_RECOMPUTE_MAX_CIN", "64"))      # (input channels of the 1x1: see DESIGN.md for the pairs that pay)
 UNIT_LINKS = _os.environ.get("FQ_HANDOVER_UNITS", "1") != "0"      # hand-over from a MobileNetV2 unit without shortcut to the next block (A/B)
 
 
@@ -539,6 +546,9 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
                 fz["next"] = nxt
             elif getattr(nxt, "_fq_dw_fused", None) is not None and fz.get("kind") == "1x1":
                 fz["next"] = nxt                  # (honoured only while the depthwise block hands over too)
+                # ... and, under online input quantisation, the recompute pair (convert_conv2d.recompute_target)
+                if b._kwargs["stride"] == (1, 1) and b._kwargs["num_group"] == 1:
+                    fz["pair_dw"] = nxt
 
     def visit(container):
         kids = list(container._children.values())

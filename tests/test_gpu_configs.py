@@ -263,13 +263,51 @@ def test_config2_mobilenet_fused_producers_full_batch_against_host_twins(gpu):
         _same(np_(stat), wstat, "pooling statistic")
         seen["gap"] += 1
         return y, stat
+    # the recompute pairs (round 6): the statistic-only pass against the twin of the storing kernel, and the fused launch
+    # against the twins of the two launches it replaces, fed with the launch's own inputs
+    real["pwconv_i8_stat"], real["pwdw_fused"] = ops.pwconv_i8_stat, ops.pwdw_fused
+
+    def pw_host(x, codes, scales, rowsum, bias, in_stat, width, flags, bn_scale, bn_shift, act):
+        cout, cin = scales.numel(), x.shape[1]
+        want = np.empty((x.shape[0], cout, x.shape[2], x.shape[3]), np.float32)
+        wstat = np.zeros(x.shape[0], np.float32)
+        cur = np.empty(1, np.float32)
+        H._call("fq_pwconv_i8_host", np_(x), np.ascontiguousarray(np_(codes)), np_(scales), np_(rowsum), np_(bias), want,
+                x.shape[0], cin, codes.shape[1], cout, x.shape[2] * x.shape[3], np_(in_stat), None, H._i(width), H._u(flags), cur,
+                np_(bn_scale), np_(bn_shift), H._i(H._ACTS[act]), wstat, None, None)
+        return want, wstat, cur
+
+    def pw_stat(x, codes, scales, rowsum, bias=None, **k):
+        stat = real["pwconv_i8_stat"](x, codes, scales, rowsum, bias, **k)
+        _, wstat, cur = pw_host(x, codes, scales, rowsum, bias, k["in_stat"], k["width"], k["flags"], k.get("bn_scale"),
+                                k.get("bn_shift"), k.get("act"))
+        _same(np_(stat), wstat, "statistic-only pointwise pass %s" % (tuple(x.shape),))
+        assert np_(k["cur_out"])[0] == cur[0]
+        seen["pw"] += 1
+        seen["pairs"] = seen.get("pairs", 0) + 1
+        return stat
+
+    def pwdw(x, codes, scales, rowsum, dw_w, **k):
+        z, zstat = real["pwdw_fused"](x, codes, scales, rowsum, dw_w, **k)
+        y, ystat, _ = pw_host(x, codes, scales, rowsum, k.get("pw_bias"), k["in_stat"], k["width"], k["flags"],
+                              k.get("pw_bn_scale"), k.get("pw_bn_shift"), k.get("pw_act"))
+        _same(np_(k["mid_stat"]), ystat, "statistic handed to the recomputing launch")
+        want, wstat = H.dwconv3x3(y, np_(dw_w), np_(k.get("dw_bias")), k["stride"], in_stat=ystat, bn_scale=np_(k["dw_bn_scale"]),
+                                  bn_shift=np_(k["dw_bn_shift"]), act=k["dw_act"], want_stat=True)
+        _same(np_(z), want, "recomputing pointwise + depthwise launch %s" % (tuple(x.shape),))
+        _same(np_(zstat), wstat, "its statistic")
+        seen["dw"] += 1
+        return z, zstat
     ops.dwconv3x3, ops.pwconv_i8, ops.stem_conv_s2, ops.global_avg_pool_stat = dw, pw, stem, gap
+    ops.pwconv_i8_stat, ops.pwdw_fused = pw_stat, pwdw
     try:
         out = net(X)
     finally:
         for k, fn in real.items():
             setattr(ops, k, fn)
+    pairs = seen.pop("pairs", 0)
     assert seen == {"dw": 13, "pw": 14, "stem": 1, "gap": 1}, seen          # 13 pointwise layers + the classifier
+    assert pairs >= (2 if fuse.RECOMPUTE else 0), pairs                     # 32->64 @112 and 64->128 @56 at least
     assert bool(torch.isfinite(out._t).all())
 
 
