@@ -29,6 +29,11 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          "-Wno-unused-function", "-I", INCLUDE, "-I", HERE]
 
 
+# per-unit extras.  fq_pwdw: the SLP vectoriser packs the depthwise chains into v_pk_fma_f32 and pays two v_mov per pair for it
+# (a packed fp32 instruction costs about 1.7 plain ones on gfx950, profiles/r5_pk_probe.txt): 72 instead of 48 instructions
+UNIT_FLAGS = {"fq_pwdw": ["-fno-slp-vectorize"]}
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.sep not in cand or os.path.exists(cand)):
@@ -58,7 +63,7 @@ def source_id(defines=()):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS[:-4] + list(defines)).encode())        # (the include paths are machine-specific)
+    h.update(" ".join(FLAGS[:-4] + list(defines) + [repr(sorted(UNIT_FLAGS.items()))]).encode())        # (the include paths are machine-specific)
     return h.hexdigest()
 
 
@@ -152,7 +157,8 @@ def build_library(force=False, verbose=True, defines=(), out=OUT, amalgamate=Fal
             fresh = fresh and os.path.exists(idfile) and open(idfile).read() == bid
         if mine and (force or not fresh):
             udefs = defines if (not only or unit in only) else []
-            todo.append(([cc] + FLAGS + udefs + extra + ["-c", s, "-o", o], o + ".id" if unit == "fq_core" else None))
+            todo.append(([cc] + FLAGS + UNIT_FLAGS.get(unit, []) + udefs + extra + ["-c", s, "-o", o],
+                         o + ".id" if unit == "fq_core" else None))
     jobs = jobs or min(len(todo) or 1, os.cpu_count() or 4)
 
     def compile_one(job):

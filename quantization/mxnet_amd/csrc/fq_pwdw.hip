@@ -41,12 +41,18 @@ constexpr int kRowSlack = 8;          // floats in front of each row buffer (a s
 
 // slabs in flight per lane: a ring of NB buffers of 16 values, the loads of slab q + NB - 1 issued before slab q is quantised
 // (stride 1 keeps 32 more partial sums per channel tile: two buffers there)
+#ifdef FQ_PWDW_OCC3      // tuning build: three wavefronts per SIMD (at most 168 registers), two buffers
+#define FQ_PWDW_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+template <int KT, int S> struct PwDwRing { static constexpr int NB = 2; };
+#else
+#define FQ_PWDW_OCC
 template <int KT, int S> struct PwDwRing { static constexpr int NB = S == 1 ? 2 : (KT <= 2 ? 3 : 4); };
+#endif
 
 // FAST 0: every epilogue decided at run time, general quantisers; 1: the fused-inference case - no bias, BatchNorm and ReLU
 // (ReLU6 when `relu6`) behind both convolutions, unsigned activations (both clip ranges start at 0)
 template <int KT, int CW, int S, int LZ, int FAST>
-__global__ __launch_bounds__(512) void pwdw_kernel(
+__global__ __launch_bounds__(512) FQ_PWDW_OCC void pwdw_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias1, PwDwGeom g, const float* __restrict__ in_stat, int n,
     const float* __restrict__ in_thr, float levels1, int lo_neg1, float eps, const float* __restrict__ bn1_scale,
@@ -225,8 +231,51 @@ __global__ __launch_bounds__(512) void pwdw_kernel(
 #pragma unroll
       for (int j = 0; j < CW; ++j) {
         const int ct = cgi * CW + j;
+        const float* kc = ldsK + (ct * 32 + i32) * 13;
+        // a finished row of this lane's channel -> LDS row buffer (the statistic is taken when the row leaves it)
+        auto finish_store = [&](const float (&sum)[NO]) __attribute__((always_inline)) {
+          if (!emits) return;
+          float* dst = rbuf + (ct * 32 + i32) * g.pitch + obase;
+          const float b2 = kDwLds ? kc[9] : k_b2[j], bsc2 = kDwLds ? kc[10] : k_bsc2[j], bsh2 = kDwLds ? kc[11] : k_bsh2[j];
+#pragma unroll
+          for (int k = 0; k < NO; ++k) {
+            float o;
+            if (FAST == 0) {
+              o = dw_finish<kEpiRuntime>(sum[k], has_b2, b2, has_bn2, bsc2, bsh2, act2);
+            } else {
+              o = sum[k] * bsc2;
+              o = o + bsh2;
+              o = __builtin_amdgcn_fmed3f(o, 0.0f, top);      // = min(max(o, 0), top), a NaN gives 0 either way
+            }
+            if (S == 1 && k == 0) {
+              if (h == 1) dst[k] = o;
+            } else if (k == NO - 1) {
+              if (h == 0) dst[k] = o;
+            } else {
+              dst[k] = o;
+            }
+          }
+        };
+        if (!row_ok) {
+          // a row of zero padding adds nothing to any sum (every product is +-0 and the sums are never -0): the row it
+          // closes leaves, the open sums move up
+          if (S == 1) {
+            finish_store(sumA[j]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              sumA[j][k] = sumB[j][k];
+              sumB[j][k] = 0.0f;
+            }
+          } else if (t & 1) {
+            finish_store(sumA[j]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sumA[j][c] = 0.0f;
+          }
+          FQ_PIN();
+          continue;
+        }
         float e[18];                                // dequantised pointwise outputs: e[k + 1] = own pixel k, e[0] / e[17] the neighbours'
-        if (row_ok) {
+        {
           // (the re-centring term zoff * rowsum joins AFTER the multiplication: as the accumulator's initial value it is a
           // loop-invariant 16-register splat per channel tile, which the compiler keeps alive across the whole row loop)
           v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -261,40 +310,12 @@ __global__ __launch_bounds__(512) void pwdw_kernel(
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(e[1]), __float_as_uint(e[16]), false, false);
           e[0] = __uint_as_float(sw[0]);             // upper half: the lower half's pixel 15 (lower half: its own pixel 0, unused)
           e[17] = __uint_as_float(sw[1]);            // lower half: the upper half's pixel 0 (upper half: its own pixel 15, unused)
-        } else {
-#pragma unroll
-          for (int k = 0; k < 18; ++k) e[k] = 0.0f;
         }
-        const float* kc = ldsK + (ct * 32 + i32) * 13;
         float w[9];
         if (!kDwLds) {
 #pragma unroll
           for (int t = 0; t < 9; ++t) w[t] = k_w[j][t];
         }
-        // a finished row of this lane's channel -> LDS row buffer (the statistic is taken when the row leaves it)
-        auto finish_store = [&](const float (&sum)[NO]) __attribute__((always_inline)) {
-          if (!emits) return;
-          float* dst = rbuf + (ct * 32 + i32) * g.pitch + obase;
-          const float b2 = kDwLds ? kc[9] : k_b2[j], bsc2 = kDwLds ? kc[10] : k_bsc2[j], bsh2 = kDwLds ? kc[11] : k_bsh2[j];
-#pragma unroll
-          for (int k = 0; k < NO; ++k) {
-            float o;
-            if (FAST == 0) {
-              o = dw_finish<kEpiRuntime>(sum[k], has_b2, b2, has_bn2, bsc2, bsh2, act2);
-            } else {
-              o = sum[k] * bsc2;
-              o = o + bsh2;
-              o = __builtin_amdgcn_fmed3f(o, 0.0f, top);      // = min(max(o, 0), top), a NaN gives 0 either way
-            }
-            if (S == 1 && k == 0) {
-              if (h == 1) dst[k] = o;
-            } else if (k == NO - 1) {
-              if (h == 0) dst[k] = o;
-            } else {
-              dst[k] = o;
-            }
-          }
-        };
         if (S == 1) {
           // A: += tap row 2 -> output row t - 1 complete; B: += tap row 1; C (new): tap row 0 from +0
           w[6] = kc[6]; w[7] = kc[7]; w[8] = kc[8];
@@ -424,7 +445,7 @@ struct PwStatGeom {
 };
 
 template <int KT>
-__global__ __launch_bounds__(kBlock, 2) void pw_stat_kernel(
+__global__ __launch_bounds__(kBlock, 3) void pw_stat_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, PwStatGeom g, const float* __restrict__ in_stat, int n,
     const float* __restrict__ in_thr, float levels, int lo_neg, float eps, float* __restrict__ cur_max_out,
@@ -450,15 +471,29 @@ __global__ __launch_bounds__(kBlock, 2) void pw_stat_kernel(
     r.p = j - r.smp * HW;
     return r;
   };
-  auto issue = [&](const Pix& px, int kt, float (&v)[16]) __attribute__((always_inline)) {
-    const char* ub = reinterpret_cast<const char*>(x) + ((((int64_t)px.smp * g.Cin + kt * 32 + 16 * h) * HW + px.p) * 4);
+  // slab q of the wave's range = (tile t_begin + q / KT, 32-channel slab q % KT), kept in buffer q % NB; the loads of slab
+  // q + NB - 1 leave before slab q is quantised: NB - 1 slabs (4 KB each) in flight per wavefront, three wavefronts per SIMD.  One tile ahead - the first
+  // version - left every wavefront waiting a memory latency per tile (3.9 TB/s on the 205 MB tensor of the first pair).
+  constexpr int NB = 3;
+  const fq_rsrc rs = make_rsrc(x, (int64_t)(cols / HW) * g.Cin * HW * 4);
+  auto issue = [&](int64_t t, int kt, float (&v)[16]) __attribute__((always_inline)) {
+    if (t >= t_end) return;
+    const Pix px = pix_of(t);
+    // (a ragged half-slab: channels past Cin are out of the buffer's range only for the LAST sample - clamp and zero instead)
+    // (a half-slab past Cin: an offset out of the buffer's range - the loads return 0, whose code meets zero weight codes)
     const bool ok = kt * 32 + 16 * h < g.Cin;
+    const unsigned vo = ok ? (unsigned)(((px.smp * (unsigned)g.Cin + 16u * h) * HW + px.p) * 4u) : 0x80000000u;
+    const unsigned so = (unsigned)kt * 32u * HW * 4u;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = ok ? *reinterpret_cast<const float*>(ub + (int64_t)i * HW * 4) : 0.0f;
+    for (int i = 0; i < 16; ++i) v[i] = buf_ld_f32(rs, vo, so + (unsigned)i * HW * 4u);
   };
-  float bufa[16], bufb[16];
-  Pix nxt = pix_of(t_begin < g.tiles ? t_begin : g.tiles - 1);
-  issue(nxt, 0, bufa);
+  float raw[NB][16];
+#pragma unroll
+  for (int b2 = 0; b2 < NB; ++b2)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) raw[b2][i] = 0.0f;
+#pragma unroll
+  for (int qq = 0; qq < NB - 1; ++qq) issue(t_begin + qq / KT, qq % KT, raw[qq]);
   FQ_PIN();
   const float max_ = input_threshold(in_stat, n, in_thr, cur_max_out, blockIdx.x == 0);
   const QParams q = make_qparams(max_, levels, lo_neg != 0, eps);
@@ -563,20 +598,35 @@ __global__ __launch_bounds__(kBlock, 2) void pw_stat_kernel(
     }
   };
   unsigned cur = fast_div((unsigned)((t_begin < g.tiles ? t_begin : g.tiles - 1) * 32), g.hw);
-  auto run_tile = [&](int64_t t, float (&first)[16], float (&second)[16], auto nn_c) __attribute__((always_inline)) {
-    const Pix curp = nxt;
-    const int64_t tn = t + 1 < g.tiles ? t + 1 : g.tiles - 1;
-    nxt = pix_of(tn);
+  auto run_tile = [&](int64_t t, auto ph_c, auto nn_c) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;                 // the tile's first slab sits in buffer (PH * KT) % NB
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      float (&mine)[16] = (kt & 1) ? second : first;
-      float (&other)[16] = (kt & 1) ? first : second;
-      if (kt + 1 < KT) issue(curp, kt + 1, other);
-      else issue(nxt, 0, other);
+      const int qn = kt + NB - 1;
+      issue(t + qn / KT, qn % KT, raw[(PH * KT + kt + NB - 1) % NB]);
       FQ_PIN();
-      quant(kt, mine, nn_c);
+#if defined(FQ_PST_ABLATE) && FQ_PST_ABLATE == 1       // ablation build: the loads alone (values folded so that they stay alive)
+      {
+        float (&mine)[16] = raw[(PH * KT + kt) % NB];
+        float mm = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mm = fmaxf(mm, mine[i]);
+        afrag[kt] = (v4i){__float_as_int(mm), 0, 0, 0};
+      }
+#else
+      quant(kt, raw[(PH * KT + kt) % NB], nn_c);
+#endif
       FQ_PIN();
     }
+#if defined(FQ_PST_ABLATE)                             // ... 2: loads + quantiser, no matrix cores, no reduction
+    {
+      int keep = 0;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) keep |= afrag[kt][0] | afrag[kt][1] | afrag[kt][2] | afrag[kt][3];
+      if (keep == 0x7fffffff) my[lane] = keep;
+      return;
+    }
+#endif
     const unsigned j0 = (unsigned)t * 32u, j1 = j0 + 31u < cols ? j0 + 31u : cols - 1;
     const unsigned s0 = fast_div(j0, g.hw), s1 = fast_div(j1, g.hw);
     if (s0 != cur) {
@@ -595,15 +645,13 @@ __global__ __launch_bounds__(kBlock, 2) void pw_stat_kernel(
     FQ_PIN();
   };
   auto run_all = [&](auto nn_c) __attribute__((always_inline)) {
-    if (KT & 1) {
-      int64_t t = t_begin;
-      for (; t + 1 < t_end; t += 2) {
-        run_tile(t, bufa, bufb, nn_c);
-        run_tile(t + 1, bufb, bufa, nn_c);
-      }
-      if (t < t_end) run_tile(t, bufa, bufb, nn_c);
-    } else {
-      for (int64_t t = t_begin; t < t_end; ++t) run_tile(t, bufa, bufb, nn_c);
+    constexpr int U = (KT % NB == 0) ? 1 : NB;                  // tiles per turn: U * KT is a multiple of NB (NB prime)
+    using std::integral_constant;
+    for (int64_t t = t_begin; t < t_end; t += U) {
+      run_tile(t, integral_constant<int, 0>{}, nn_c);
+      if (U > 1 && t + 1 < t_end) run_tile(t + 1, integral_constant<int, 1 % U>{}, nn_c);
+      if (U > 2 && t + 2 < t_end) run_tile(t + 2, integral_constant<int, 2 % U>{}, nn_c);
+      if (U > 3 && t + 3 < t_end) run_tile(t + 3, integral_constant<int, 3 % U>{}, nn_c);
     }
   };
   if (fq_nonneg(q) && fqx.ok) run_all(std::true_type{});
@@ -643,15 +691,38 @@ PwDwPlan pwdw_plan(int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, i
   p.ctg = ct / p.cw;
   p.threads = 64 * p.strips * p.ctg;
   if (p.threads > 512) return p;
-  static const int rb_env = env_int("FQ_PWDW_RB", 0);
-  p.rb = rb_env > 0 ? rb_env : (ho >= 14 ? 14 : ho);
-  p.bands = (ho + p.rb - 1) / p.rb;
   // row-buffer pitch: the widest column any lane writes (invalid outputs past the plane included) + the columns left of it
   const int reach = stride == 1 ? (int)w + 2 + p.lz : 15 * p.strips + 1;
   p.pitch = (reach > wo ? reach : wo) + p.lz;
   p.pitch |= 1;
   p.lds = (size_t)ct * kt * 1024 + 2 * ((size_t)cout * p.pitch + kRowSlack) * 4 + kRowSlack * 4 + (stride == 1 ? (size_t)cout * 13 * 4 : 0);
   if (p.lds > 150 * 1024) return p;
+  // rows per band: the bands of all samples should fill the chip's workgroup slots (two wavefronts per SIMD by registers, the
+  // row buffers by LDS) in as few rounds as possible, a band re-computing the one or two pointwise rows above / below it.
+  // (MobileNet1.0 at batch 128: 14 rows per band on the 56-row outputs - 512 workgroups - and 7 on the 28-row ones; measured
+  // with 14 / 10 / 7: profiles/r6_pwdw_bands.txt)
+  static const int rb_env = env_int("FQ_PWDW_RB", 0);
+  {
+    const int waves = p.threads / 64;
+    int occ = (int)((160 * 1024) / (p.lds + 512));
+    const int by_regs = 8 / waves > 0 ? 8 / waves : 1;
+    occ = occ < by_regs ? occ : by_regs;
+    occ = occ < 1 ? 1 : occ;
+    const double slots = (double)num_cu() * occ;
+    double best = 1e30;
+    int best_rb = ho;
+    for (int b = 1; b <= ho; ++b) {
+      const int rb = (ho + b - 1) / b, bands = (ho + rb - 1) / rb;
+      const double wgs = (double)n * bands, rounds = ceil(wgs / slots), fill = wgs < slots ? wgs / slots : 1.0;
+      const double cost = rounds * (stride * rb + 2) / fill;
+      if (cost < best - 1e-9) {
+        best = cost;
+        best_rb = rb;
+      }
+    }
+    p.rb = rb_env > 0 ? (rb_env < ho ? rb_env : ho) : best_rb;
+  }
+  p.bands = (ho + p.rb - 1) / p.rb;
   if (n * cin * h * w * 4 >= (1ll << 32) || n * cout * ho * wo >= (1ll << 31)) return p;
   p.ok = true;
   return p;

@@ -158,7 +158,7 @@ STEM_CODES = _os.environ.get("FQ_HANDOVER_STEM", "1") != "0"
 # smallest input plane (pixels) the pair is taken on.
 RECOMPUTE = _os.environ.get("FQ_RECOMPUTE", "1") != "0"
 RECOMPUTE_MIN_PIXELS = int(_os.environ.get("FQ_RECOMPUTE_MIN_PIXELS", "3136"))
-RECOMPUTE_MAX_CIN = int(_os.environ.get("FQ_RECOMPUTE_MAX_CIN", "64"))      # (input channels of the 1x1: see DESIGN.md for the pairs that pay)
+RECOMPUTE_MAX_CIN = int(_os.environ.get("FQ_RECOMPUTE_MAX_CIN", "128"))      # (input channels of the 1x1: see DESIGN.md for the pairs that pay)
 UNIT_LINKS = _os.environ.get("FQ_HANDOVER_UNITS", "1") != "0"      # hand-over from a MobileNetV2 unit without shortcut to the next block (A/B)
 
 
