@@ -302,6 +302,42 @@ def _gloo_sum(dist, t, op):
     t.copy_(h)
 
 
+def box_probe_start():
+    """rocm-smi started in the background right before the timed region, so that it reads the clocks of a BUSY GPU."""
+    import subprocess
+    try:
+        return subprocess.Popen(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--showtemp"],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except Exception:
+        return None
+
+
+def box_info(proc=None):
+    """Which box is this?  Clocks, power cap and temperature as rocm-smi printed them during the first timed block (the pool's
+    boxes differ by up to 10 % on the same tree: the line should say what it ran on), the hardware-queue setting the lanes
+    depend on.  Best effort: only the environment where rocm-smi is absent."""
+    import re
+    out = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+    try:
+        txt = proc.communicate(timeout=30)[0] if proc is not None else ""
+    except Exception:
+        return out
+    for key, pat in (("sclk_mhz", r"GPU\[0\].*sclk clock level.*\((\d+)Mhz\)"), ("mclk_mhz", r"GPU\[0\].*mclk clock level.*\((\d+)Mhz\)"),
+                     ("fclk_mhz", r"GPU\[0\].*fclk clock level.*\((\d+)Mhz\)"),
+                     ("power_cap_w", r"GPU\[0\].*Max Graphics Package Power \(W\): ([\d.]+)"),
+                     ("power_w", r"GPU\[0\].*Current Socket Graphics Package Power \(W\): ([\d.]+)"),
+                     ("temp_junction_c", r"GPU\[0\].*Temperature \(Sensor junction\) \(C\): ([\d.]+)"),
+                     ("temp_memory_c", r"GPU\[0\].*Temperature \(Sensor memory\) \(C\): ([\d.]+)")):
+        m = re.search(pat, txt)
+        if m:
+            out[key] = float(m.group(1))
+    m = re.search(r"GPU\[0\].*Performance Level: (\w+)", txt)
+    if m:
+        out["perf_level"] = m.group(1)
+    out["what"] = "rocm-smi started right before the first timed block (read while the GPU is busy)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,11 +359,10 @@ def main():
                          "(:296-315, quantize/distribution_calibrate.py:50-114)")
     ap.add_argument("--rotate", type=int, default=4, help="distinct resident input batches cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--min-block-s", type=float, default=0.5,
-                    help="a timed block of --steps steps shorter than this is repeated (see --min-region-s)")
     ap.add_argument("--min-region-s", type=float, default=float(os.environ.get("FQ_BENCH_MIN_REGION_S", "8.0")),
-                    help="total time to cover with repeated blocks when one block is shorter than --min-block-s (8 s: long "
-                         "enough for a once-per-few-seconds utilisation sampler beside the run to see the GPU busy)")
+                    help="blocks of --steps steps are repeated until they cover this much time (8 s: long enough for a "
+                         "once-per-few-seconds utilisation sampler beside the run to see the GPU busy); `value` is the median "
+                         "block")
     ap.add_argument("--max-repeats", type=int, default=4000)
     ap.add_argument("--event-every", type=int, default=None,
                     help="bracket the library's kernels with HIP events in every n-th timed step (default 50 - calibration "
@@ -642,6 +677,7 @@ def main():
     def carries_events(k):
         return EVENT_BLOCK_EVERY == 1 or k % EVENT_BLOCK_EVERY == 1
 
+    box_probe = box_probe_start() if rank == 0 else None
     blocks = [timed_block(0, with_events=carries_events(0))]
     while sum(blocks) < args.min_region_s and len(blocks) < args.max_repeats:
         blocks.append(timed_block(len(blocks) * args.steps, with_events=carries_events(len(blocks))))
@@ -770,7 +806,7 @@ def main():
                         "read_bytes_per_launch": krec.get("read_bytes_per_launch"),
                         "write_bytes_per_launch": krec.get("write_bytes_per_launch"),
                         "source": rec.get("source", ""), "commit": rec.get("commit"), "box": rec.get("box"),
-                        "file": "profiles/pmc_traffic.json",
+                        "file": "profiles/" + os.path.basename(tpath),
                         "what": "NOT measured in this run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes around this "
                                 "command (tools/pmc_run.py), gfx950 corrections of MI355X_MICROARCH.md applied"}
             except Exception:
@@ -822,9 +858,11 @@ def main():
                                        else "one stream"},
             "roofline": {"bound": "hbm", "kernel": dk["kernel"], "achieved": dk["achieved"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dk["frac"], "frac_actual": dk.get("frac_actual", dk["frac"]),
-                         "frac_actual_what": "= frac: bytes the launches really moved (1 B per element where a side is a C16 code "
-                                             "tensor: offline hand-over configurations; 4 B per element everywhere on the default "
-                                             "workload, where it equals frac_algorithmic)",
+                         "frac_actual_what": "= frac: bytes the launches really moved - 1 B per element where a side is a C16 code "
+                                             "tensor (offline hand-over configurations); for a recompute pair (online thresholds, "
+                                             "round 6: fq_pwconv_i8_stat + fq_pwdw_fused) the statistic pass moves its input only "
+                                             "and the fused launch the 1x1 input + the depthwise output, while frac_algorithmic keeps "
+                                             "counting the 4 B per input and output element of the two layers they stand for",
                          "frac_algorithmic": dk.get("frac_algorithmic", dk["frac"]),
                          "frac_what": "algorithmic bytes / (HIP-event time of the family's launches - per launch the cost of the "
                                       "event pair, measured in this process on a self-timing kernel: launch_overhead_us_measured); in "
@@ -889,8 +927,14 @@ def main():
         }
         if single_s is not None:
             line["single_stream"] = {"value": round(images / single_s, 2), "ms_per_step": round(single_s / args.steps * 1e3, 4),
+                                     "lanes_gain": round(line["value"] / max(images / single_s, 1e-9), 4),
                                      "what": "the same %d steps launched on ONE stream (--streams 1), one block, no kernel "
-                                             "events" % args.steps}
+                                             "events; lanes_gain = value / this" % args.steps}
+        line["box"] = box_info(box_probe)
+        line["consistency"]["value_what"] = ("median over ALL blocks; since round 5 only every third block carries the "
+                                             "event-bracketed steps (which run alone on one stream and cost their block 1-2 %), so "
+                                             "with three or more blocks `value` is a plain block's; rounds 1-4 charged that cost to "
+                                             "every block (FQ_BENCH_EVENT_BLOCK_EVERY=1 reproduces it)")
         if args.phase != "eval":
             del line["eval_counters"]
         if args.phase == "calib-kl":

@@ -320,7 +320,9 @@ class _EvalState(object):
     """What an evaluation pass builds once and later passes over the same net in the same mode take over: the lanes (streams,
     captured graphs, static buffers), the device counters every graph writes to, the decision whether to replay at all.
     Kept on the net, valid while `convert.mode_epoch()` stands (quantize_input / enable / fix_params / fusing change which
-    kernels a forward launches: the graphs of an older epoch are dropped; calibration only changes values the kernels read)."""
+    kernels a forward launches: the graphs of an older epoch are dropped; calibration only changes values the kernels read -
+    but an evaluation state is also dropped after a calibration step, see `_eval_state`).  `quantize_input` / `enable` / `disable`
+    move the epoch only when they change a flag, so the CLI's repeated calls before every epoch keep the graphs."""
 
     def __init__(self, dev, n_lanes, num_class, epoch):
         self.epoch = epoch
@@ -343,7 +345,10 @@ def _eval_state(net, dev, n_lanes, num_class, update_ema):
     st = cache.get(key)
     # (a calibration pass of a fake-BN net writes running statistics with set_data in every step: its graphs hold those
     # tensors' addresses and the writes are in place, but the epoch moves - such a net simply captures once per pass)
-    epoch = _epochs()
+    # ... and an EVALUATION state also dies with the library's own in-place threshold updates (ops.state_epoch(): update_ema
+    # writes through raw pointers): captured graphs bake in host decisions made from threshold VALUES (convert_conv2d.
+    # _same_quantiser), which a calibration between two evaluate() calls may have changed
+    epoch = _epochs() + (() if update_ema else (ops.state_epoch(),))
     if st is None or st.epoch != epoch:
         st = cache[key] = _EvalState(dev, n_lanes, num_class, epoch)
     return st
@@ -488,7 +493,7 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
     # what this pass itself wrote - the freezing forward stores the quantised weights with set_data (convert_conv2d.py:101-108) -
     # happened before its first capture (the first batch is launched eagerly and waited for): the graphs belong to the epoch the
     # pass ENDS in
-    state.epoch = _epochs()
+    state.epoch = _epochs() + (() if update_ema else (ops.state_epoch(),))
     fqdist.allreduce_eval_counters(counters)
     c = counters.cpu().numpy()
     evaluate.last_images_per_sec = seen * fqdist.world_size() / max(elapsed, 1e-9)

@@ -120,6 +120,13 @@ class Parameter(object):
         if self._data is None:
             if self._deferred is None:
                 self._deferred = (_init.Zero(), ctx or cpu())
+            # the declared shape holds wherever it is known (MXNet's Parameter._load_init: 0 = a dimension still to be
+            # inferred); a file of another width or class count must not load silently
+            declared = tuple(self.shape) if self.shape is not None else None
+            if declared is not None and (len(declared) != arr.ndim or
+                                         any(d not in (0, a) for d, a in zip(declared, arr.shape))):
+                raise AssertionError("Failed loading Parameter '%s' from saved params: shape incompatible expected %s vs "
+                                     "saved %s" % (self.name, declared, tuple(arr.shape)))
             self.shape = tuple(arr.shape)
             self._finish_init(_init.Constant(arr), self._deferred[1] if ctx is None else ctx)
         else:

@@ -149,22 +149,29 @@ class NetControls(object):
 
     # :92-102
     def quantize_input(self, enable=True, online=True):
-        bump_mode_epoch()
-        for blk in self.blocks():
+        changed = False                      # (the mode epoch moves only when a flag does: the CLI calls this before every
+        for blk in self.blocks():            #  calibration epoch and evaluation, and recorded forwards should survive that)
             if type(blk) is nn.Activation:
                 if enable and not blk.quantize_args.quantize_act:
                     raise AssertionError("%s was converted with quantize_act=False" % blk.name)
+                changed |= (getattr(blk, "quantize_act", None), getattr(blk, "quantize_act_offline", None)) != (enable, not online)
                 blk.quantize_act, blk.quantize_act_offline = enable, not online
             elif type(blk) in (nn.Dense, nn.Conv2D):
                 if enable and not blk.quantize_args.quantize_input:
                     raise AssertionError("%s was converted with quantize_input=False" % blk.name)
+                changed |= (getattr(blk, "quantize_input", None), getattr(blk, "quantize_input_offline", None)) != (enable, not online)
                 blk.quantize_input, blk.quantize_input_offline = enable, not online
+        if changed:
+            bump_mode_epoch()
 
     # :105-114
     def _switch(self, on):
-        bump_mode_epoch()
+        changed = False
         for blk in self.blocks():
+            changed |= getattr(blk, "enable_quantize", None) != on
             blk.enable_quantize = on
+        if changed:
+            bump_mode_epoch()
 
     def enable(self):
         self._switch(True)
