@@ -49,6 +49,9 @@ int fq_version(void);
 /* sha1 (40 hex digits) of the sources and flags this library was built from: csrc/build.py compares it with the tree to
  * decide whether a built file is current (content, not modification times). */
 const char* fq_build_id(void);
+/* 1 when the library carries the named optional part, else 0.  "pipe": the pipe form of fq_pwconv_i8 (FQ_PW_FORM(9)), built,
+ * measured, slower than the sample form and therefore left out of the shipped library (csrc/build.py --dev builds it). */
+int fq_build_has(const char* feature);
 /* Name (e.g. "gfx950"), compute units and wavefront size of the current HIP device. */
 int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront);
 

@@ -23,6 +23,7 @@ EXPORTS = {
     "fq_last_error": (ctypes.c_char_p, []),
     "fq_version": (_int, []),
     "fq_build_id": (ctypes.c_char_p, []),
+    "fq_build_has": (_int, [ctypes.c_char_p]),
     "fq_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "fq_profile_enable": (_int, [_int]),
     "fq_profile_reset": (_int, []),

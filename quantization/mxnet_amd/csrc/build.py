@@ -1,6 +1,9 @@
 """Build libfakequant.so in-tree with plain hipcc for gfx950 (no JIT cache: the .so travels with the repo snapshot).
 
-    python -m quantization.mxnet_amd.csrc.build [--force] [--prune] [--amalgamate] [-DNAME[=V] ...] [--only UNIT[,UNIT]] [-o OUT]
+    python -m quantization.mxnet_amd.csrc.build [--force] [--prune] [--dev] [--amalgamate] [-DNAME[=V] ...] [--only UNIT[,UNIT]] [-o OUT]
+
+`--dev` also compiles the forms that were measured and shelved (DEV_UNITS: the pipe form of the small-plane pointwise layers) into
+`libfakequant_dev.so`; the shipped library does not carry them.
 
 Every `fq_*.hip` translation unit is compiled to an object under `csrc/build/` (in parallel, only when it or a header
 changed) and the objects are linked into one shared library.  `--amalgamate` compiles all units as ONE translation unit
@@ -41,8 +44,14 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def sources():
-    return sorted(glob.glob(os.path.join(HERE, "fq_*.hip")))
+# forms that were built, measured and lost: kept as evidence with their parity cases, compiled by `--dev` only
+# (-DFQ_DEV_FORMS tells fq_pwconv.hip to dispatch to them; fq_build_has("pipe") tells the tests)
+DEV_UNITS = {"fq_pw_pipe"}
+
+
+def sources(dev=False):
+    return [s for s in sorted(glob.glob(os.path.join(HERE, "fq_*.hip")))
+            if dev or os.path.basename(s)[:-4] not in DEV_UNITS]
 
 
 def headers():
@@ -59,7 +68,7 @@ def source_id(defines=()):
     built from.  It is compiled into the library (fq_build_id(), -DFQ_BUILD_ID on fq_core.hip), so whether a built file
     matches the tree is a question of content, not of modification times (a stale-but-newer .so is not "up to date")."""
     h = hashlib.sha1()
-    for f in sources() + [x for x in headers() if not x.endswith(".py")]:
+    for f in sources("-DFQ_DEV_FORMS" in defines) + [x for x in headers() if not x.endswith(".py")]:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
@@ -140,12 +149,12 @@ def build_library(force=False, verbose=True, defines=(), out=OUT, amalgamate=Fal
     if amalgamate:
         unit = os.path.join(objdir, "fq_all.hip")
         with open(unit, "w") as f:
-            for s in sources():
+            for s in sources("-DFQ_DEV_FORMS" in defines):
                 f.write('#include "%s"\n' % os.path.basename(s))
         _run([cc] + FLAGS + defines + [idflag, "-shared", unit, "-o", out], verbose)
         return out
     todo, objs = [], []
-    for s in sources():
+    for s in sources("-DFQ_DEV_FORMS" in defines):
         unit = os.path.basename(s)[:-4]
         mine = not only or unit in only or unit == "fq_core"
         o = os.path.join(objdir if mine else os.path.join(OBJ_DIR, "default"), unit + ".o")
@@ -183,6 +192,10 @@ if __name__ == "__main__":
     only = argv[argv.index("--only") + 1].split(",") if "--only" in argv else ()
     if "--prune" in argv:
         prune()
+    if "--dev" in argv:                                  # the shelved forms too (a library of its own unless -o names the default)
+        argv = argv + ["-DFQ_DEV_FORMS"]
+        if "-o" not in argv:
+            out = os.path.join(HERE, "libfakequant_dev.so")
     build_library(force="--force" in argv, defines=[a for a in argv if a.startswith("-D")], out=out,
                   amalgamate="--amalgamate" in argv, only=only)
     print(out)

@@ -60,6 +60,7 @@ namespace fqi {
 
 int fail(int code, const char* fmt, ...);           // records the thread-local error text, returns `code`
 int num_cu();                                       // compute units of the CURRENT device (cached per device)
+int max_lds_bytes();                                // LDS a workgroup may ask for on the CURRENT device (cached per device)
 int env_int(const char* name, int dflt);
 int stream_policy(int kernel_id, int64_t numel);    // kPol* bits by kernel and tensor size
 

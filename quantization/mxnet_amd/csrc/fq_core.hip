@@ -40,6 +40,21 @@ int num_cu() {
   return cache[dev];
 }
 
+// LDS a workgroup of the CURRENT device may ask for (160 KB on gfx950); the fused forms that size their tiles by it ask here
+// instead of assuming the figure.  Without a device (the build check on a CPU box): gfx950's.
+int max_lds_bytes() {
+  constexpr int kMaxDev = 64;
+  static int cache[kMaxDev] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 160 * 1024;
+  if (cache[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 160 * 1024;
+    cache[dev] = v;
+  }
+  return cache[dev];
+}
+
 // Streaming policy, by kernel and tensor size.  Measured on MI355X (profiles/r1_policy_sweep.txt, r1_kbench.txt):
 // tensors that (with their output) fit the 256 MiB Infinity Cache want PLAIN loads/stores — the producer just left x
 // there and the consumer (the convolution) will find y there; larger tensors want nontemporal loads+stores in the apply
@@ -86,6 +101,15 @@ int fq_version(void) { return 101; }
 const char* fq_build_id(void) {
   static const char id[] = "FQ_BUILD_ID=" FQ_BUILD_ID;
   return id + 12;
+}
+
+// 1 when this library was built with the named optional part ("pipe": the shelved pipe form of fq_pwconv_i8, csrc/build.py --dev)
+int fq_build_has(const char* feature) {
+  if (feature == nullptr) return 0;
+#ifdef FQ_DEV_FORMS
+  if (strcmp(feature, "pipe") == 0) return 1;
+#endif
+  return 0;
 }
 
 int fq_device_info(char* arch, int arch_len, int* compute_units, int* wavefront) {

@@ -180,10 +180,15 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   }
   FQ_REQUIRE(c.form != 8, "fq_pwconv_i8: the rows form takes planes of one pixel");
   if (!(in_c16 || out_thr)) {
+#ifdef FQ_DEV_FORMS
     if (int rc = pw_try_pipe(c, &taken)) return rc;
     if (taken) return FQ_OK;
     FQ_REQUIRE(c.form != 9, "fq_pwconv_i8: the pipe form takes stride 1, no residual, fp32 in and out, Cin = 256 or 512, Cout a "
                "multiple of 512 and planes of a multiple of four pixels (16..1024)");
+#else
+    FQ_REQUIRE(c.form != 9, "fq_pwconv_i8: the pipe form (9) was measured and shelved (DESIGN.md 3.3): this library was built "
+               "without it - `python -m quantization.mxnet_amd.csrc.build --dev` builds libfakequant_dev.so with it");
+#endif
     if (int rc = pw_try_sample(c, &taken)) return rc;
     if (taken) return FQ_OK;
   } else if (out_thr && !in_c16) {                      // C16 output on the largest planes: the streaming form writes it too

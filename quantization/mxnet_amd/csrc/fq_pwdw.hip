@@ -696,7 +696,7 @@ PwDwPlan pwdw_plan(int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w, i
   p.pitch = (reach > wo ? reach : wo) + p.lz;
   p.pitch |= 1;
   p.lds = (size_t)ct * kt * 1024 + 2 * ((size_t)cout * p.pitch + kRowSlack) * 4 + kRowSlack * 4 + (stride == 1 ? (size_t)cout * 13 * 4 : 0);
-  if (p.lds > 150 * 1024) return p;
+  if (p.lds + 10 * 1024 > (size_t)max_lds_bytes()) return p;
   // rows per band: the bands of all samples should fill the chip's workgroup slots (two wavefronts per SIMD by registers, the
   // row buffers by LDS) in as few rounds as possible, a band re-computing the one or two pointwise rows above / below it.
   // (MobileNet1.0 at batch 128: 14 rows per band on the 56-row outputs - 512 workgroups - and 7 on the 28-row ones; measured

@@ -240,7 +240,8 @@ extern "C" {
 int fq_stem_conv7x7s2_pool_supported(int64_t h, int64_t w) {
   const int64_t Ho = (h + 6 - 7) / 2 + 1, Wo = (w + 6 - 7) / 2 + 1;
   const size_t lds = (size_t)(kNS * 2 * kCout + 3 * kCout + 16 + 3 * kCout * Wo) * sizeof(float);
-  return (h > 0 && w > 0 && Wo >= 4 && (Wo + 3) / 4 <= 32 && Ho >= 1 && lds <= 160 * 1024 - 1024 && 3 * h * w * 4 < (1ll << 31)) ? 1 : 0;
+  return (h > 0 && w > 0 && Wo >= 4 && (Wo + 3) / 4 <= 32 && Ho >= 1 && lds + 1024 <= (size_t)max_lds_bytes() &&
+          3 * h * w * 4 < (1ll << 31)) ? 1 : 0;
 }
 
 // Conv2D(3 -> 64, 7x7, stride 2, pad 3) [+ bias] [-> BatchNorm] [-> activation] -> MaxPool2D(3, stride 2, pad 1), fp32

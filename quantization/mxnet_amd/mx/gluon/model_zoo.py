@@ -288,10 +288,28 @@ def get_model(name, pretrained=False, classes=None, ctx=None, root=None, **kwarg
     kw = {}
     if classes is not None:
         kw["classes"] = classes
-    for k in ("norm_layer", "use_se", "last_gamma", "batch_norm"):
-        kwargs.pop(k, None)
+    # gluoncv's constructor arguments the reference CLI can pass (examples/simulate_quantization.py:188-204): honoured where the
+    # zoo has the feature, refused as gluoncv would refuse an argument the class does not take - never dropped silently
+    last_gamma = bool(kwargs.pop("last_gamma", False))
+    if kwargs.pop("use_se", False):
+        raise NotImplementedError("use_se=True: the model zoo of this build has no squeeze-and-excitation variants")
+    kwargs.pop("norm_layer", None)
+    kwargs.pop("batch_norm", None)                   # (gluoncv passes it to vgg only, which this zoo does not have)
+    if last_gamma and not (name.startswith("resnet") or name.startswith("cifar_resnet")):
+        raise TypeError("%s: __init__() got an unexpected keyword argument 'last_gamma'" % name)
+    if kwargs:
+        raise TypeError("%s: __init__() got unexpected keyword arguments %s" % (name, sorted(kwargs)))
     net = _MODELS[name](**kw)
     net.initialize(_init.MSRAPrelu(factor_type="in", slope=0.0), ctx=ctx)
+    if last_gamma:
+        # gluoncv resnet `last_gamma`: the last BatchNorm of every residual unit starts at gamma = 0 (the unit is the identity)
+        def zero_last(b):
+            body = getattr(b, "body", None)
+            if isinstance(b, (BasicBlockV1, BottleneckV1, CIFARBasicBlockV1)) and body is not None:
+                last = list(body._children.values())[-1]
+                if type(last) is nn.BatchNorm:
+                    last.gamma.set_data(last.gamma.data() * 0)
+        net.apply(zero_last)
     path = None
     if isinstance(pretrained, str):
         path = pretrained

@@ -74,7 +74,9 @@ class NDArray(object):
     # per-sample statistic was computed (`_fq_stat`, fq_pwconv_i8_stat) and the single consumer, the depthwise convolution
     # linked behind it, recomputes the values inside its own launch (fq_pwdw_fused; quantize/convert/convert_conv2d.py).  `_t`
     # is then an int8 placeholder of the right shape without storage, so that any other reader fails loudly.
-    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl", "_fq_side", "_fq_deferred")
+    # _fq_pooled_by: optional MaxPool2D block - the first convolution's launch pooled already (fq_stem_conv7x7s2_pool) and that
+    # block, when it is handed this very tensor, passes it through (quantize/fuse.py).
+    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl", "_fq_side", "_fq_deferred", "_fq_pooled_by")
     __array_priority__ = 1000.0
     __array_ufunc__ = None
 
@@ -87,6 +89,7 @@ class NDArray(object):
         self._fq_kl = None
         self._fq_side = None
         self._fq_deferred = None
+        self._fq_pooled_by = None
 
     # -- plumbing ---------------------------------------------------------------------------
     @property

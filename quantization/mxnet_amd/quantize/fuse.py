@@ -119,7 +119,8 @@ def _pool_stat_forward(self, F, x):
     """MaxPool2D(3, 2, 1) behind a fused producer (the ResNets' first convolution): pooling + the per-sample statistic of the
     pooled tensor in one pass (fq_bn_act_maxpool_stat with the identity BatchNorm: x * 1 + 0 is x) - unless the convolution's
     own launch has pooled already (fq_stem_conv7x7s2_pool)."""
-    if self.__dict__.pop("_fq_pool_done", False):
+    if getattr(x, "_fq_pooled_by", None) is self:    # (the marker rides on the tensor the convolution returned, not on this
+        x._fq_pooled_by = None                       #  block: a forward that never reaches this pool leaves nothing behind)
         return x
     t = x._t if x._t.is_contiguous() else x._t.contiguous()
     if t.dim() != 4 or t.shape[3] % 4 or not t.is_cuda:
@@ -241,18 +242,22 @@ def _stem_forward(self, F, x, weight, bias=None):
         from .convert.convert_conv2d import handover_target
         out_codes = handover_target(self, st)
     pool = st.get("pool")
-    pooled = (pool is not None and STEM_POOL and out_codes is None and w.shape[2] == 7 and t.dim() == 4
+    # (a forward hook on the convolution or on a block bypassed behind it would be shown the pooled 56x56 tensor where it
+    # expects the 112x112 convolution output: the two-launch form then, as convert_conv2d.handover_target has it)
+    hooked = any(bool(getattr(b, "_forward_hooks", None) or getattr(b, "_forward_pre_hooks", None))
+                 for b in (self, st.get("bn"), st.get("act_block"), pool) if b is not None)
+    pooled = (pool is not None and STEM_POOL and out_codes is None and w.shape[2] == 7 and t.dim() == 4 and not hooked
               and ops.stem_pool_supported(t.shape[2], t.shape[3]))
     y, stat = ops.stem_conv_s2(t, w, None if bias is None else bias._t, bn_scale=scale, bn_shift=shift,
                                act=st["act"], want_stat=True, w_tap_major=st["wt"], pool=pooled,
                                **({} if out_codes is None else dict(out_codes=out_codes)))
-    if pooled:
-        pool._fq_pool_done = True                   # the MaxPool2D block behind hands the tensor through
     if out_codes is not None:
         out = NDArray(y.t)
         out._fq_c16 = y
     else:
         out = NDArray(y)
+    if pooled:
+        out._fq_pooled_by = pool                    # the MaxPool2D block behind hands THIS tensor through
     out._fq_stat = stat
     return out
 

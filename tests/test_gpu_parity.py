@@ -524,6 +524,20 @@ FORM_CASES = [
     ("rows", (1, 2048, 1000, 1, 1)), ("rows", (3, 64, 10, 1, 1)), ("rows", (40, 1280, 1000, 1, 1))]
 
 
+def _pipe_built():
+    try:
+        from quantization.mxnet_amd import _lib
+        return bool(_lib.LIB.fq_build_has(b"pipe"))
+    except Exception:
+        return False
+
+
+# (the pipe form is shelved - DESIGN.md 3.3 - and compiled by `csrc/build.py --dev` only: its cases run against such a library,
+# FQ_LIB_PATH=.../libfakequant_dev.so)
+if not _pipe_built():
+    FORM_CASES = [fc for fc in FORM_CASES if fc[0] != "pipe"]
+
+
 @pytest.mark.parametrize("form,case", FORM_CASES, ids=["%s-%dx%d->%d@%dx%d" % ((f,) + c) for f, c in FORM_CASES])
 @pytest.mark.parametrize("mode", ["online_u8_bn_relu", "offline_s8_channel_w4", "dense_quirk_bias"])
 def test_pwconv_i8_every_form_vs_oracle(dev, ops, form, case, mode):
