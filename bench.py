@@ -728,6 +728,20 @@ def main():
         torch.cuda.synchronize()
         kl_search_ms = (time.perf_counter() - t_kl) * 1e3
         thresholds = [float((bb + 0.5) * (kl_extra["ranges"][b] / 2048)) for bb, b in zip(best, blocks_q)]
+    # calibration phases on several ranks: every rank must end with the SAME thresholds, bit for bit (the collectives exist for
+    # exactly that) - a digest of each rank's vector, the minimum and maximum over the ranks compared on rank 0
+    thresholds_equal = None
+    if distributed and args.phase != "eval":
+        if args.phase == "calib-naive":
+            vec = torch.cat([b.input_max.data()._t.reshape(-1).float() for b in net.collect_quantized_blocks()])
+        else:
+            vec = torch.tensor(thresholds, dtype=torch.float32, device=dev)
+        bits = vec.contiguous().view(torch.int32).to(torch.float64)
+        digest = torch.stack([bits.sum(), (bits * torch.arange(1, bits.numel() + 1, device=dev, dtype=torch.float64)).sum()])
+        lo_d, hi_d = digest.clone(), digest.clone()
+        all_reduce(lo_d, dist.ReduceOp.MIN)
+        all_reduce(hi_d, dist.ReduceOp.MAX)
+        thresholds_equal = bool(torch.equal(lo_d, hi_d))
     prof = ops.profile_read()
     ops.profile_reset()
     # A bracketing event pair adds a fixed cost to every launch it times (two marker packets + dispatch latency): the
@@ -900,6 +914,7 @@ def main():
                       "rccl_world": (dist.get_world_size() if distributed and backend == "nccl" else None),
                       "ms_per_step_min_over_ranks": None if rank_ms is None else round(rank_ms[0], 4),
                       "ms_per_step_max_over_ranks": None if rank_ms is None else round(rank_ms[1], 4),
+                      "thresholds_equal_on_all_ranks": thresholds_equal,
                       "collectives_in_timed_region": coll,
                       "collectives_per_step": {k: round(v["calls"] / float(args.steps * len(blocks)), 4) for k, v in coll.items()},
                       "bytes_per_collective": {k: round(v["bytes"] / float(max(v["calls"], 1)), 1) for k, v in coll.items()},

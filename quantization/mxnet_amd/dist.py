@@ -24,6 +24,15 @@ everything here is additive.  The path shards over independent images; the excha
 Transport: `torch.distributed` — backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.  All messages
 are latency-bound (<= 434 KB), so they go on the compute stream with RCCL's defaults; no bucketing is needed.
 
+Second transport, FQ_DIST_BACKEND=fqcomm: the library's own RCCL communicator behind the C ABI (include/fakequant.h:
+fq_comm_unique_id / fq_comm_init / fq_allreduce_* / fq_comm_destroy) - what a host WITHOUT torch.distributed binds, i.e. the
+reference's MXNet process with the ctypes stub of INTEGRATION.md.  Rank and world size come from the same environment
+(RANK / WORLD_SIZE), rank 0's 128-byte unique id travels through a file (FQ_COMM_ID_FILE, default
+$TMPDIR/fq_comm_id_<MASTER_PORT>).  Every exchange of this module is expressed through its ONE primitive, the in-place
+all-reduce: a broadcast is the sum with zeros on the other ranks, an all-gather the sum of zero-padded slices (exact: x + 0).
+Same collectives per step, same bit-identical replicas; exercised with one rank on the one-GPU boxes of this pool
+(tests/test_gpu_rccl.py), like the torch.distributed "nccl" path.
+
 Test knobs (the pool's GPU boxes have ONE device and RCCL refuses two ranks on it): FQ_DIST_BACKEND=gloo selects gloo
 although a GPU is present — device tensors are then staged through the host around each collective — and
 FQ_DIST_SHARE_GPU=1 puts every rank on device 0, so that the N > 1 flows run through the real kernels on such a box.
@@ -39,23 +48,65 @@ __all__ = ["init", "is_distributed", "group_is_live", "rank", "world_size", "sha
            "kl_sync", "allreduce_eval_counters", "shutdown"]
 
 
+_FQ = {"on": False, "rank": 0, "world": 1}          # the fqcomm transport's state (the library holds the communicator)
+
+
+def _td_live():
+    return dist.is_available() and dist.is_initialized()
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return world_size() > 1
 
 
 def group_is_live():
     """A process group exists (also with ONE rank: `FQ_DIST_FORCE_GROUP=1`, or a caller's own init_process_group) - the
     collectives of calibration and evaluation are then really issued, which is how the RCCL branch is exercised end to end
     on a one-GPU box (tests/test_gpu_rccl.py)."""
-    return dist.is_available() and dist.is_initialized()
+    return _FQ["on"] or _td_live()
 
 
 def rank():
-    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    if _FQ["on"]:
+        return _FQ["rank"]
+    return dist.get_rank() if _td_live() else 0
 
 
 def world_size():
-    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if _FQ["on"]:
+        return _FQ["world"]
+    return dist.get_world_size() if _td_live() else 1
+
+
+def _fqcomm_init(rank_, world, local):
+    import tempfile
+    import time
+    torch.cuda.set_device(local)
+    path = os.environ.get("FQ_COMM_ID_FILE") or os.path.join(
+        tempfile.gettempdir(), "fq_comm_id_%s" % os.environ.get("MASTER_PORT", "29533"))
+    if rank_ == 0:
+        uid = ops.comm_unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(path + ".tmp", path)
+    else:
+        deadline = time.time() + float(os.environ.get("FQ_COMM_ID_TIMEOUT_S", "120"))
+        while not os.path.exists(path):
+            if time.time() > deadline:
+                raise RuntimeError("fqcomm: rank 0's unique id did not appear at %s" % path)
+            time.sleep(0.05)
+        with open(path, "rb") as f:
+            uid = f.read()
+    ops.comm_init(rank_, world, uid)
+    _FQ.update(on=True, rank=rank_, world=world, id_file=path if rank_ == 0 else None)
+    # (the file may only go once every rank has read it: the first collective says so)
+    all_reduce(torch.zeros(1, dtype=torch.float32, device=torch.device("cuda", local)))
+    torch.cuda.synchronize()
+    if rank_ == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
 
 
 def init(backend=None):
@@ -74,6 +125,9 @@ def init(backend=None):
         os.environ.setdefault("WORLD_SIZE", "1")
     if backend is None:
         backend = os.environ.get("FQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "fqcomm":
+        _fqcomm_init(int(os.environ.get("RANK", "0")), max(world, 1), local)
+        return _FQ["rank"], local, _FQ["world"]
     if backend == "nccl":
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -83,7 +137,13 @@ def init(backend=None):
 
 
 def shutdown():
-    if dist.is_available() and dist.is_initialized():
+    if _FQ["on"]:
+        all_reduce(torch.zeros(1, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device())))
+        torch.cuda.synchronize()
+        ops.comm_destroy()
+        _FQ.update(on=False, rank=0, world=1)
+        return
+    if _td_live():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -91,7 +151,7 @@ def shutdown():
 # ---- transport ---------------------------------------------------------------------------------------------------------
 def _via_host(t):
     _not_while_capturing(t)
-    return t.is_cuda and dist.get_backend() == "gloo"
+    return t.is_cuda and not _FQ["on"] and dist.get_backend() == "gloo"
 
 
 def _not_while_capturing(t):
@@ -122,9 +182,25 @@ def collective_stats(reset=False):
     return out
 
 
+def _fq_all_reduce(t, op):
+    _not_while_capturing(t)
+    code = ops.COMM_MAX if op == dist.ReduceOp.MAX else ops.COMM_SUM
+    if op not in (dist.ReduceOp.SUM, dist.ReduceOp.MAX):
+        raise ValueError("the fqcomm transport reduces with SUM or MAX (got %r)" % (op,))
+    if t.dtype in (torch.float32, torch.float64, torch.int64) and t.is_contiguous():
+        ops.comm_allreduce(t, code)
+    else:                                        # (int32 counters and the like: through an exact wider copy)
+        w = t.contiguous().to(torch.int64 if not t.dtype.is_floating_point else torch.float64)
+        ops.comm_allreduce(w, code)
+        t.copy_(w.to(t.dtype))
+    return t
+
+
 def all_reduce(t, op=None):
     op = dist.ReduceOp.SUM if op is None else op
     _note("all_reduce", t)
+    if _FQ["on"]:
+        return _fq_all_reduce(t, op)
     if _via_host(t):
         h = t.detach().cpu()
         dist.all_reduce(h, op=op)
@@ -136,6 +212,10 @@ def all_reduce(t, op=None):
 
 def broadcast(t, src=0):
     _note("broadcast", t)
+    if _FQ["on"]:
+        if _FQ["rank"] != src:
+            t.zero_()
+        return _fq_all_reduce(t, dist.ReduceOp.SUM)
     if _via_host(t):
         h = t.detach().cpu()
         dist.broadcast(h, src=src)
@@ -147,6 +227,11 @@ def broadcast(t, src=0):
 
 def all_gather_into(gathered, piece):
     _note("all_gather", gathered)
+    if _FQ["on"]:
+        n = piece.numel()
+        gathered.zero_()
+        gathered.reshape(-1)[_FQ["rank"] * n:(_FQ["rank"] + 1) * n].copy_(piece.reshape(-1))
+        return _fq_all_reduce(gathered, dist.ReduceOp.SUM)
     if _via_host(piece):
         h = torch.empty(gathered.shape, dtype=gathered.dtype)
         dist.all_gather_into_tensor(h, piece.detach().cpu())
@@ -227,7 +312,7 @@ class _LayerCollective(_CalibrationSync):
         self.last_order = None
         by_id = {id(b): b for b in blocks}
         self.by_id = by_id
-        live = dist.is_available() and dist.is_initialized()
+        live = group_is_live()
         for b in blocks:
             b._fq_global_stat = self._hook_for(b) if live else None
             b._fq_keep_rows = False
@@ -251,7 +336,7 @@ class _LayerCollective(_CalibrationSync):
         if n:
             self.last_order = list(self.order)
             return
-        if not (dist.is_available() and dist.is_initialized()):
+        if not group_is_live():
             return
         slot = {}
         for j, (blk, _pattr, _cattr, _pub) in enumerate(arena.slots):
@@ -287,7 +372,7 @@ class _StepCollective(_CalibrationSync):
     def __call__(self, net, arena):
         n_local = self.take_step_count()
         ops.stat_rows_sum(self.stats, n_local, out=self.record)
-        if dist.is_available() and dist.is_initialized():      # (also with one rank: the collective is still issued)
+        if group_is_live():      # (also with one rank: the collective is still issued)
             all_reduce(self.record)
         ops.mean_from_sums(self.record, out=self.means)
         arena.cur.index_copy_(0, self._slots(arena), self.means)

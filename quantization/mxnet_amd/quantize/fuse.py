@@ -157,6 +157,9 @@ STEM_CODES = _os.environ.get("FQ_HANDOVER_STEM", "1") != "0"
 # depthwise 3x3 runs as a statistic-only pass + ONE launch that recomputes the 1x1 output inside the depthwise kernel - the
 # tensor between them is never written.  FQ_RECOMPUTE=0 keeps the two storing launches (A/B); FQ_RECOMPUTE_MIN_PIXELS: the
 # smallest input plane (pixels) the pair is taken on.
+# FQ_WINO_SLICED=0: the 3x3 layers of a Winograd-domain quantised net stay with the tensor library's fp32 convolution of the
+# back-transformed filter instead of the three-slice integer form (tools/sliced_effect.py measures what the slices change)
+WINO_SLICED = _os.environ.get("FQ_WINO_SLICED", "1") != "0"
 RECOMPUTE = _os.environ.get("FQ_RECOMPUTE", "1") != "0"
 RECOMPUTE_MIN_PIXELS = int(_os.environ.get("FQ_RECOMPUTE_MIN_PIXELS", "3136"))
 RECOMPUTE_MAX_CIN = int(_os.environ.get("FQ_RECOMPUTE_MAX_CIN", "128"))      # (input channels of the 1x1: see DESIGN.md for the pairs that pay)
@@ -205,7 +208,7 @@ def _is_dense3x3(b):
     return (k["kernel"] == (3, 3) and k["pad"] == (1, 1) and k["dilate"] == (1, 1) and k["stride"] == (1, 1)
             and k["num_group"] == 1 and k["layout"] == "NCHW" and b.act is None and not a.fake_bn
             and cin in (64, 128, 256, 512) and k["num_filter"] >= 32
-            and (not _wino_sliced(b) or k["num_filter"] % 32 == 0))
+            and (not _wino_sliced(b) or (k["num_filter"] % 32 == 0 and WINO_SLICED)))
 
 
 def _wino_sliced(b):

@@ -19,8 +19,14 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=dev)
     from quantization.mxnet_amd import mx, dist as fqdist
+    if os.environ.get("FQ_DIST_BACKEND") == "fqcomm":
+        # the library's own communicator (fq_comm_*): what a host without torch.distributed binds; no process group exists
+        os.environ["FQ_DIST_FORCE_GROUP"] = "1"
+        fqdist.init()
+        assert not dist.is_initialized() and fqdist.group_is_live()
+    else:
+        dist.init_process_group("nccl", device_id=dev)
     import dist_worker as W
     ctx = mx.gpu(0)
     res = {}

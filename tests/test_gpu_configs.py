@@ -12,6 +12,8 @@ these sizes; the C++ restatement of the same arithmetic needs seconds for a whol
   config 2  mobilenet1.0 with the fused producers of the benchmark (stem / depthwise / pointwise-int8 / pooling kernels):
             every producer call at batch 128 against its host twin
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -173,6 +175,26 @@ def test_config5_resnet50_winograd_f43_online_full_batch(gpu):
     from quantization.mxnet_amd.mx.gluon import nn
     n3x3 = sum(1 for b in chk.blocks if isinstance(b, nn.Conv2D) and b._kwargs["kernel"] == (3, 3))
     assert n3x3 == 16                                                    # the Winograd-eligible convolutions
+
+
+def test_config5_sliced_filters_change_the_logits_no_more_than_fusing_alone_full_batch(gpu):
+    """The one place where the fused path multiplies something other than the reference's operand: under Winograd-domain weight
+    quantisation the 3x3 layers take three int8 digit slices m p of the back-transformed filter g^ = GI U^ GTI
+    (convert_conv2d.py:81-83; |g^ - m p| <= 2^-20 max|g^_c|, asserted per layer in test_gpu_net.py) instead of g^ itself
+    (F.Convolution, :108).  Its effect on the logits at the BASELINE batch, measured against the two neighbours it can be told
+    from (tools/sliced_effect.py): un-fused (A), fused with the fp32 filter through the tensor library (B), fused + sliced (C).
+    Every pair differs by the last-bit noise that ANY other fp32 summation order has on this random-weight net (a few 8-bit
+    rounding decisions flip downstream) - the sliced pair B-C no more than fusing alone, A-B - and the top-1 class agrees on
+    every image."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import sliced_effect
+    scale, out, n = sliced_effect.measure(128, "resnet50_v1", "F43")
+    assert n == 128 and scale > 0
+    for pair, (mx_, mean_, agree) in out.items():
+        assert mx_ <= 2e-2 * scale, (pair, mx_, scale)            # measured: 0.8-0.9 % of max|logit| for all three pairs
+        assert agree == n, (pair, agree)
+    assert out["B-C"][1] <= 1.5 * out["A-B"][1], out              # the slices add nothing beyond the noise fusing alone has
 
 
 # ---- config 4 -----------------------------------------------------------------------------------------------------------------

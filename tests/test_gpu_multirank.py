@@ -94,6 +94,37 @@ def test_bench_calibration_phases_report_their_collectives(gpu, phase):
         assert rk["bytes_per_collective"]["all_reduce"] % (2048 * 8) == 0                 # [L x 2048] int64
 
 
+@pytest.mark.parametrize("phase", ["eval", "calib-naive", "calib-kl"])
+def test_eight_ranks_sharing_gpu0_through_every_phase(gpu, phase):
+    """The world size the driver will use, on the one GPU this box has: eight processes on device 0 over
+    gloo through the production step of each phase.  Hang-freedom (the timeout), rank 0's line, the collectives per step and -
+    for the calibration phases - the SAME thresholds on all eight ranks, bit for bit (`thresholds_equal_on_all_ranks`)."""
+    env = dict(os.environ, FQ_BENCH_SHARE_GPU="1", FQ_BENCH_BACKEND="gloo", FQ_DIST_BACKEND="gloo", FQ_DIST_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--phase", phase,
+           "--model", "cifar_resnet20_v1", "--batch-size", "8", "--no-cpu-baseline", "--no-headline", "--max-repeats", "2",
+           "--min-region-s", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    rk = rec["ranks"]
+    assert rec["n_gpus"] == 8 and rk["world"] == 8 and rec["config"]["global_batch"] == 64
+    assert 0 < rk["ms_per_step_min_over_ranks"] <= rk["ms_per_step_max_over_ranks"]
+    if phase == "eval":
+        assert rk["collectives_per_step"] == {} and rk["thresholds_equal_on_all_ranks"] is None
+        assert rec["eval_counters"]["images"] > 0 and rec["eval_counters"]["images"] % (8 * 8) == 0
+    elif phase == "calib-naive":
+        assert rk["collectives_per_step"] == {"all_reduce": 1.0}             # north_star's ONE collective per calibration step
+        assert rk["thresholds_equal_on_all_ranks"] is True
+    else:
+        blocks = rec["repeats"]
+        assert rk["collectives_in_timed_region"]["broadcast"]["calls"] == blocks
+        assert rk["collectives_in_timed_region"]["all_reduce"]["calls"] == blocks
+        assert rk["thresholds_equal_on_all_ranks"] is True
+
+
 def test_bench_refuses_more_ranks_than_devices(gpu):
     import torch
     want = torch.cuda.device_count() + 1

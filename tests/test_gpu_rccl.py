@@ -53,6 +53,25 @@ def test_collectives_execute_on_rccl_with_one_rank(gpu, tmp_path):
     np.testing.assert_array_equal(r["counters"], [1.0, 10.0])
 
 
+def test_collectives_execute_on_the_librarys_own_communicator_with_one_rank(gpu, tmp_path):
+    """FQ_DIST_BACKEND=fqcomm: dist.py over fq_comm_* (the C ABI's RCCL communicator, what a host without torch.distributed
+    binds - INTEGRATION.md) instead of torch.distributed: the strict mode's all-gather (a zero-padded sum), the fp64 all-reduce
+    of a calibration step and the counter all-reduce go through it on the device; with one rank both modes equal the plain run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", FQ_DIST_BACKEND="fqcomm",
+               FQ_COMM_ID_FILE=os.path.join(str(tmp_path), "uid"))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_worker.py"), str(tmp_path), "6"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r = np.load(os.path.join(tmp_path, "rank0.npz"))
+    want = _single_device_ema(gpu, 6, 1)
+    np.testing.assert_array_equal(r["strict"], want)
+    np.testing.assert_array_equal(r["step"], want)
+    np.testing.assert_array_equal(r["counters"], [1.0, 10.0])
+    assert not os.path.exists(os.path.join(str(tmp_path), "uid"))        # rank 0 removes the id file after the first collective
+
+
 def test_two_ranks_on_one_gpu_over_rccl(gpu, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker as W
