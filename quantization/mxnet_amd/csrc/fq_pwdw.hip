@@ -441,6 +441,7 @@ struct PwStatGeom {
   int Cin, KTS, Cout, CT, HW;
   int64_t cols, tiles;
   int zoff;
+  int table;                 // 1: per-sample maxima through the workgroup's LDS table (few tiles per wavefront)
   FastDiv hw;
 };
 
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(kBlock, 3) void pw_stat_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char pst_smem[];
   v4i* ldsW = reinterpret_cast<v4i*>(pst_smem);                                           // [CT][KT][64]
   int* c_zs = reinterpret_cast<int*>(pst_smem + (size_t)g.CT * KT * 1024);                 // [CT * 32]
-  int* accs = c_zs + g.CT * 32;                                                            // [4 waves][CT][2][64]
+  float* c_k = reinterpret_cast<float*>(c_zs + g.CT * 32);                                 // [4][CT * 32]: w scale, bias, BN scale / shift
+  int* accs = reinterpret_cast<int*>(c_k + 4 * g.CT * 32);                                 // [4 waves][CT][2][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, i32 = lane & 31;
   const unsigned HW = (unsigned)g.HW, cols = (unsigned)g.cols;
@@ -461,6 +463,15 @@ __global__ __launch_bounds__(kBlock, 3) void pw_stat_kernel(
   const int64_t t_begin = g.tiles * wid / nwaves, t_end = g.tiles * (wid + 1) / nwaves;
   const int pl = 16 * ((i32 >> 2) & 1) + 4 * (i32 >> 3) + (i32 & 3);      // tile pixel of this lane's MFMA row
   int* my = accs + (size_t)wave * g.CT * 128;
+  constexpr int kSlots = 8;
+  __shared__ unsigned k_stat[kSlots];
+  if (threadIdx.x < kSlots) k_stat[threadIdx.x] = 0u;
+  unsigned s_base;                               // first sample of the workgroup's tile range
+  {
+    const int64_t t0 = g.tiles * ((int64_t)blockIdx.x * 4) / nwaves;
+    const unsigned j0 = (unsigned)(t0 < g.tiles ? t0 : g.tiles - 1) * 32u;
+    s_base = fast_div(j0 < cols ? j0 : cols - 1, g.hw);
+  }
 
   struct Pix { unsigned smp, p; };
   auto pix_of = [&](int64_t t) __attribute__((always_inline)) {
@@ -503,7 +514,17 @@ __global__ __launch_bounds__(kBlock, 3) void pw_stat_kernel(
     const int f = idx >> 6, ct = f / KT, kt = f - ct * KT;
     ldsW[idx] = *reinterpret_cast<const v4i*>(wfrag + (((int64_t)ct * g.KTS + kt) << 10) + ((idx & 63) << 4));
   }
-  for (int i = threadIdx.x; i < g.CT * 32; i += kBlock) c_zs[i] = i < g.Cout ? g.zoff * wsum[i] : 0;
+  // (the epilogue's per-channel constants too: read from HBM inside flush() they cost every wavefront a memory latency per
+  // channel tile and sample - a fixed 6-25 us that made the pass as slow at batch 32 as at batch 128)
+  const int nchs = g.CT * 32;
+  for (int i = threadIdx.x; i < nchs; i += kBlock) {
+    const bool okc = i < g.Cout;
+    c_zs[i] = okc ? g.zoff * wsum[i] : 0;
+    c_k[i] = okc ? wscale[i] : 0.0f;
+    c_k[nchs + i] = (okc && bias != nullptr) ? bias[i] : 0.0f;
+    c_k[2 * nchs + i] = (okc && bn_scale != nullptr) ? bn_scale[i] : 1.0f;
+    c_k[3 * nchs + i] = (okc && bn_scale != nullptr) ? bn_shift[i] : 0.0f;
+  }
   auto reset = [&]() __attribute__((always_inline)) {
     for (int ct = 0; ct < g.CT; ++ct) {
       my[ct * 128 + lane] = INT_MIN;
@@ -526,9 +547,9 @@ __global__ __launch_bounds__(kBlock, 3) void pw_stat_kernel(
       if (c < g.Cout && hi >= lo) {
         hi += c_zs[c];
         lo += c_zs[c];
-        const float sxw = q.scale * wscale[c];
-        const float bch = bias != nullptr ? bias[c] : 0.0f;
-        const float bsc = has_bn ? bn_scale[c] : 1.0f, bsh = has_bn ? bn_shift[c] : 0.0f;
+        const float sxw = q.scale * c_k[c];
+        const float bch = c_k[nchs + c];
+        const float bsc = c_k[2 * nchs + c], bsh = c_k[3 * nchs + c];
         auto f = [&](int a) {
           float v = (float)a * sxw;
           if (bias != nullptr) v = v + bch;
@@ -542,7 +563,20 @@ __global__ __launch_bounds__(kBlock, 3) void pw_stat_kernel(
       }
     }
     m = wave_max_nonneg(m);
-    if (lane == 0 && __float_as_uint(m) != 0u) FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + smp, __float_as_uint(m));
+    // into the workgroup's table; ONE global atomic per (workgroup, sample) at the end.  (A first version issued one per
+    // wavefront: 3072 atomics on the n floats of stat_out - a single cache line at batch 32 - serialise in L2 at ~10 ns each,
+    // a fixed 30 us that made the pass as slow at batch 32 as at batch 128: profiles/r6_pwstat_atomics.txt)
+    // Where the maximum goes.  Few tiles per wavefront (small batches): into the workgroup's LDS table, ONE global atomic per
+    // (workgroup, sample) at the end - one atomic per wavefront means thousands of same-cache-line atomics (stat_out is n
+    // floats: one line at batch 32) that serialise in L2 at ~10 ns each, a fixed 30 us.  Many tiles per wavefront: straight to
+    // memory - the atomics of a long kernel are spread over its run time and overlap with the other wavefronts' work, while
+    // the table's flush would put them all at the end (40 against 47 us on the first pair at batch 128).
+    // profiles/r6_pwstat_atomics.txt
+    if (lane == 0 && __float_as_uint(m) != 0u) {
+      const unsigned slot = smp - s_base;
+      if (g.table && slot < (unsigned)kSlots) atomicMax(&k_stat[slot], __float_as_uint(m));
+      else FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + smp, __float_as_uint(m));
+    }
     reset();
   };
   v4i afrag[KT];
@@ -657,6 +691,9 @@ __global__ __launch_bounds__(kBlock, 3) void pw_stat_kernel(
   if (fq_nonneg(q) && fqx.ok) run_all(std::true_type{});
   else run_all(std::false_type{});
   if (t_begin < t_end) flush(cur);
+  __syncthreads();
+  if (threadIdx.x < kSlots && k_stat[threadIdx.x] != 0u && s_base + threadIdx.x < cols / HW)
+    FQ_STAT_FLUSH_MAX(reinterpret_cast<unsigned*>(stat_out) + s_base + threadIdx.x, k_stat[threadIdx.x]);
 }
 
 // test hook (fq_debug_fast_quotient): the quotient the recompute kernels divide with, element by element
@@ -736,13 +773,13 @@ bool pw_stat_shape_ok(int64_t n, int64_t cin, int64_t cout, int64_t hw) {
   if (n <= 0 || cin <= 0 || cout <= 0 || hw < 32 || hw >= (1ll << 30) || n * hw >= (1ll << 31) - 512) return false;
   const int kt = (int)((cin + 31) / 32), ct = (int)((cout + 31) / 32);
   if (!(kt == 1 || kt == 2 || kt == 4 || kt == 8) || cin % 16 != 0) return false;
-  const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 4 + 4 * (size_t)ct * 128 * 4;
+  const size_t lds = (size_t)ct * kt * 1024 + 5 * (size_t)ct * 32 * 4 + 4 * (size_t)ct * 128 * 4;
   return lds <= 120 * 1024 && n * cin * hw * 4 < (1ll << 32);
 }
 
 int pw_stat_launch(const PwCall& c) {
   const int kt = (int)((c.cin + 31) / 32), ct = (int)((c.cout + 31) / 32);
-  const size_t lds = (size_t)ct * kt * 1024 + (size_t)ct * 32 * 4 + 4 * (size_t)ct * 128 * 4;
+  const size_t lds = (size_t)ct * kt * 1024 + 5 * (size_t)ct * 32 * 4 + 4 * (size_t)ct * 128 * 4;
   PwStatGeom g;
   g.Cin = (int)c.cin; g.KTS = (int)(c.cin_pad / 32); g.Cout = (int)c.cout; g.CT = ct; g.HW = (int)c.hw;
   g.cols = c.n * c.hw; g.tiles = (g.cols + 31) / 32; g.zoff = c.zoff;
@@ -755,6 +792,8 @@ int pw_stat_launch(const PwCall& c) {
   int64_t grid = (int64_t)num_cu() * per_cu;
   const int64_t need = (g.tiles + 3) / 4;
   if (grid > need) grid = need;
+  static const int table_env = env_int("FQ_PWSTAT_TABLE", -1);
+  g.table = table_env >= 0 ? table_env : (g.tiles < grid * 4 * 10 ? 1 : 0);
 #define FQ_PST_GO(KT_)                                                                                                     \
   case KT_: {                                                                                                              \
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_stat_kernel<KT_>),                   \
