@@ -284,6 +284,31 @@ __global__ __launch_bounds__(512) FQ_PWDW_OCC void pwdw_kernel(
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt)
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[kt], ldsW[((ct * KT + kt) << 6) + wl], acc, 0, 0, 0);
+#ifdef FQ_PWDW_PK        // measured and left out: 64 packed instead of 128 plain instructions per channel tile and row, 2 % SLOWER
+                         // (pair 1: 98.0 against 95.9 us, the step -0.36 %: profiles/r6_pwdw_packed_ab.txt)
+          if constexpr (FAST != 0 && NN) {
+            // the fused-inference chain two pixels at a time as packed fp32 instructions (two IEEE operations each: the same
+            // values)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+              f2 v = (f2){(float)(acc[k] + k_zs[j]), (float)(acc[k + 1] + k_zs[j])};
+              v = v * (f2){k_sxw[j], k_sxw[j]};
+              v = v * (f2){k_bsc1[j], k_bsc1[j]};
+              v = v + (f2){k_bsh1[j], k_bsh1[j]};
+              f2 c = (f2){fq_clip(v.x, qc), fq_clip(v.y, qc)};
+              f2 q = c * (f2){fq2.y, fq2.y};
+              const f2 nd = (f2){-fq2.d, -fq2.d};
+              const f2 r = __builtin_elementwise_fma(q, nd, c);          // fma(-q, d, c) = fma(q, -d, c)
+              q = __builtin_elementwise_fma(r, (f2){fq2.y, fq2.y}, q);
+              q = q + (f2){0.49999997f, 0.49999997f};
+              q = (f2){truncf(q.x), truncf(q.y)};
+              q = q * (f2){q2.scale, q2.scale};
+              e[k + 1] = q.x;
+              e[k + 2] = q.y;
+            }
+          } else
+#endif
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
             float v = (float)(acc[k] + k_zs[j]) * k_sxw[j];
