@@ -22,8 +22,9 @@ import sys
 
 FAMILIES = {
     "pwconv": ("pwconv_stream_kernel", "pwconv_sample_kernel", "pwconv_split_kernel", "quant_transpose_i8_kernel",
-               "pwconv_i8_kernel", "qconv_pw"),
-    "dwconv": ("dwconv3x3", "qconv_dw"),
+               "pwconv_i8_kernel", "qconv_pw", "pw_stat_kernel"),
+    # (round 6: a recompute pair's fused launch stands for the depthwise layer, its statistic pass for the pointwise layer)
+    "dwconv": ("dwconv3x3", "qconv_dw", "pwdw_kernel"),
     "stem": ("stem_mfma_kernel", "stem_conv3x3s2_kernel", "stem7_pool_kernel"),
     "pool": ("gap_stat",),
     "dense": ("pwconv_rows_kernel",),

@@ -21,8 +21,10 @@ def family(n):
         return 'stat'
     if 'histogram_kernel' in n:
         return 'histogram'
-    if 'dwconv3x3' in n:
+    if 'dwconv3x3' in n or 'pwdw_kernel' in n:       # (round 6: the fused launch of a recompute pair is accounted as its depthwise layer)
         return 'dwconv'
+    if 'pw_stat_kernel' in n:                        # ... and the statistic-only pass as its pointwise layer
+        return 'pwconv'
     if 'stem_conv3x3s2_kernel' in n or 'stem_mfma_kernel' in n or 'stem7_pool_kernel' in n:
         return 'stem'
     if 'conv3x3_i8_kernel' in n:
