@@ -93,6 +93,19 @@ int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float*
                               int64_t h, int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,
                               unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
                               int act, float* stat_out, const float* residual, void* ws, fqStream_t stream);
+/* The recompute pair: the two storing twins back to back (the tensor between the layers exists on the host). */
+int fq_pwconv_i8_stat_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                           int64_t n, int64_t cin, int64_t cin_pad, int64_t cout_pad, int64_t cout, int64_t hw,
+                           const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                           float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                           fqStream_t stream);
+int fq_pwdw_fused_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* pw_bias,
+                       int64_t n, int64_t cin, int64_t cin_pad, int64_t cout_pad, int64_t cout, int64_t h, int64_t w,
+                       const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, const float* pw_bn_scale,
+                       const float* pw_bn_shift, int pw_act, const float* mid_stat, const float* mid_thr, int mid_width,
+                       unsigned mid_flags, float* mid_current_max, const float* dw_w, const float* dw_bias, int dw_stride,
+                       const float* dw_bn_scale, const float* dw_bn_shift, int dw_act, float* y, float* stat_out,
+                       fqStream_t stream);
 /* fq_pwconv_i8_host on planes of one pixel, then fq_eval_counters_host on the logits it wrote (eval_ws, ws: unused). */
 int fq_dense_i8_eval_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                           const float* bias, float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout,

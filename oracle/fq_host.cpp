@@ -602,6 +602,39 @@ int fq_pwconv_i8_host(const float* x, const int8_t* wcodes, const float* wscale,
                         out_current_max, bn_scale, bn_shift, act, stat_out, nullptr);
 }
 
+// The recompute pair (include/fakequant.h at fq_pwconv_i8_stat / fq_pwdw_fused): on the host the tensor between the two
+// layers simply exists - the twins are the two storing twins back to back, which is the definition the device kernels are
+// held to (the reference's chain: Conv2D 1x1 -> BatchNorm -> activation -> the depthwise block's activation branch
+// convert_conv2d.py:53-66 -> F.Convolution :108 -> BatchNorm -> activation).
+int fq_pwconv_i8_stat_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                           int64_t n, int64_t cin, int64_t cin_pad, int64_t, int64_t cout, int64_t hw, const float* in_stat,
+                           const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                           const float* bn_scale, const float* bn_shift, int act, float* stat_out, fqStream_t) {
+  REQUIRE(stat_out && n > 0 && cout > 0 && hw > 0, "fq_pwconv_i8_stat_host: bad arguments");
+  std::vector<float> y((size_t)n * cout * hw);
+  return pwconv_i8_impl(x, wcodes, wscale, wsum, bias, y.data(), n, cin, cin_pad, cout, hw, in_stat, in_thr, in_width, in_flags,
+                        out_current_max, bn_scale, bn_shift, act & ~FQ_STAT_PREZEROED, stat_out, nullptr);
+}
+
+int fq_pwdw_fused_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* pw_bias,
+                       int64_t n, int64_t cin, int64_t cin_pad, int64_t, int64_t cout, int64_t h, int64_t w,
+                       const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, const float* pw_bn_scale,
+                       const float* pw_bn_shift, int pw_act, const float* mid_stat, const float* mid_thr, int mid_width,
+                       unsigned mid_flags, float* mid_current_max, const float* dw_w, const float* dw_bias, int dw_stride,
+                       const float* dw_bn_scale, const float* dw_bn_shift, int dw_act, float* y, float* stat_out, fqStream_t) {
+  REQUIRE(x && y && dw_w && n > 0 && cout > 0 && h > 0 && w > 0, "fq_pwdw_fused_host: bad arguments");
+  REQUIRE(mid_stat || mid_thr, "fq_pwdw_fused_host: give mid_stat or mid_thr");
+  std::vector<float> mid((size_t)n * cout * h * w);
+  float cur1 = 0.0f;
+  if (int rc = pwconv_i8_impl(x, wcodes, wscale, wsum, pw_bias, mid.data(), n, cin, cin_pad, cout, h * w, in_stat, in_thr,
+                              in_width, in_flags, &cur1, pw_bn_scale, pw_bn_shift, pw_act, nullptr, nullptr))
+    return rc;
+  float cur2 = 0.0f;
+  return fq_dwconv3x3_host(mid.data(), dw_w, dw_bias, y, n, cout, h, w, dw_stride, mid_stat, mid_thr, mid_width, mid_flags,
+                           mid_current_max ? mid_current_max : &cur2, dw_bn_scale, dw_bn_shift, dw_act & ~FQ_STAT_PREZEROED,
+                           stat_out, nullptr);
+}
+
 // The classifier on the codes + the evaluation counters of its logits (include/fakequant.h at fq_dense_i8_eval):
 // fq_pwconv_i8 with planes of one pixel, then fq_eval_counters on what it wrote.
 int fq_dense_i8_eval_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
