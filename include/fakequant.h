@@ -182,6 +182,17 @@ int fq_bn_act_stat_hist(const float* x, float* y, int64_t n, int64_t c, int64_t 
 int fq_add_act_stat_hist(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
                          const float* hist_max, int bins, uint64_t* hist, uint32_t* neg_count, fqStream_t stream);
 
+/* BatchNorm + residual add + activation in ONE pass (round 6): y = act(fl(fl(x * scale[c]) + shift[c]) + residual), i.e. the
+ * values of fq_bn_act_stat (FQ_ACT_NONE) followed by fq_add_act_stat, 12 B/elem instead of 8 + 12 - the closing BatchNorm of a
+ * ResNet unit, `(body(x) + shortcut).relu()`, while its convolution does not run on the integer codes (quantisation switched
+ * off: the collection forward of the KL calibration, /root/reference/quantize/distribution_calibrate.py:78-106 via
+ * examples/simulate_quantization.py:298, or an fp32 evaluation).  stat_out is required; the _hist form bins what it stores. */
+int fq_bn_add_act_stat(const float* x, const float* residual, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                       const float* shift, int act, float* stat_out, fqStream_t stream);
+int fq_bn_add_act_stat_hist(const float* x, const float* residual, float* y, int64_t n, int64_t c, int64_t hw,
+                            const float* scale, const float* shift, int act, float* stat_out, const float* hist_max, int bins,
+                            uint64_t* hist, uint32_t* neg_count, fqStream_t stream);
+
 /* Global average pooling (gluon GlobalAvgPool2D -> F.Pooling(global_pool=True, pool_type='avg'), the block in front of
  * the classifier of every model of the zoo) with the per-sample statistic the following quantised Dense needs
  * (convert_dense.py:40-41): x (n, c, hw) -> y (n, c) = fp32(sum over hw accumulated in fp64, in order) / fp32(hw);

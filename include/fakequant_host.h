@@ -55,6 +55,11 @@ int fq_add_act_stat_host(const float* a, const float* b, float* y, int64_t n, in
 int fq_bn_act_stat_hist_host(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                              const float* shift, int act, float* stat_out, const float* hist_max, int bins, uint64_t* hist,
                              uint32_t* neg_count, fqStream_t stream);
+int fq_bn_add_act_stat_host(const float* x, const float* residual, float* y, int64_t n, int64_t c, int64_t hw,
+                            const float* scale, const float* shift, int act, float* stat_out, fqStream_t stream);
+int fq_bn_add_act_stat_hist_host(const float* x, const float* residual, float* y, int64_t n, int64_t c, int64_t hw,
+                                 const float* scale, const float* shift, int act, float* stat_out, const float* hist_max,
+                                 int bins, uint64_t* hist, uint32_t* neg_count, fqStream_t stream);
 int fq_add_act_stat_hist_host(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,
                               const float* hist_max, int bins, uint64_t* hist, uint32_t* neg_count, fqStream_t stream);
 int fq_global_avg_pool_stat_host(const float* x, float* y, int64_t n, int64_t c, int64_t hw, int flags,

@@ -1156,6 +1156,23 @@ int fq_add_act_stat_hist_host(const float* a, const float* b, float* y, int64_t 
   return fq_histogram_accumulate_host(y, n * inner, hist_max, bins, hist, neg_count, stream);
 }
 
+// BatchNorm + residual + activation in one pass: on the host the two passes it is defined to equal
+int fq_bn_add_act_stat_host(const float* x, const float* residual, float* y, int64_t n, int64_t c, int64_t hw,
+                            const float* scale, const float* shift, int act, float* stat_out, fqStream_t stream) {
+  REQUIRE(x && residual && y && stat_out && n > 0 && c > 0 && hw > 0, "fq_bn_add_act_stat_host: bad arguments");
+  std::vector<float> t((size_t)n * c * hw);
+  if (int rc = fq_bn_act_stat_host(x, t.data(), n, c, hw, scale, shift, FQ_ACT_NONE, nullptr, stream)) return rc;
+  return fq_add_act_stat_host(t.data(), residual, y, n, c * hw, act, stat_out, stream);
+}
+
+int fq_bn_add_act_stat_hist_host(const float* x, const float* residual, float* y, int64_t n, int64_t c, int64_t hw,
+                                 const float* scale, const float* shift, int act, float* stat_out, const float* hist_max,
+                                 int bins, uint64_t* hist, uint32_t* neg_count, fqStream_t stream) {
+  REQUIRE(stat_out && hist_max && hist && bins > 0 && bins <= 4096, "fq_bn_add_act_stat_hist_host: bad arguments");
+  if (int rc = fq_bn_add_act_stat_host(x, residual, y, n, c, hw, scale, shift, act, stat_out, stream)) return rc;
+  return fq_histogram_accumulate_host(y, n * c * hw, hist_max, bins, hist, neg_count, stream);
+}
+
 int fq_hist_to_float_host(const uint64_t* hist, float* out, int64_t count, fqStream_t) {
   REQUIRE(hist && out && count > 0, "fq_hist_to_float_host: bad arguments");
   for (int64_t i = 0; i < count; ++i) out[i] = (float)hist[i];

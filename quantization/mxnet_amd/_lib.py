@@ -47,6 +47,8 @@ EXPORTS = {
     "fq_add_act_stat": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
     "fq_bn_act_stat_hist": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp]),
     "fq_add_act_stat_hist": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, _vp]),
+    "fq_bn_add_act_stat": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp]),
+    "fq_bn_add_act_stat_hist": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp]),
     "fq_global_avg_pool_stat": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "fq_gemm_i8_codes": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
     "fq_eval_counters": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),

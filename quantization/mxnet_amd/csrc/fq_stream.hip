@@ -243,11 +243,16 @@ struct LdsHist {
   }
 };
 
-template <int ACT, bool STATS, bool VEC, int U, bool HIST = false>
+// RES (round 6, fq_bn_add_act_stat): a residual operand of x's shape joins after BatchNorm and before the activation -
+// act(fl(fl(x * scale) + shift) + res), the value fq_bn_act_stat (no activation) followed by fq_add_act_stat forms, in one
+// pass: 12 B per element instead of 8 + 12 (the closing BatchNorm of a ResNet unit while quantisation is switched off: the
+// KL calibration's collection forward, an fp32 evaluation)
+template <int ACT, bool STATS, bool VEC, int U, bool HIST = false, bool RES = false>
 __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              int64_t inner, int hw, int chunks_per_sample,
                                                              int64_t total_chunks, const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
+                                                             const float* __restrict__ res,
                                                              float* __restrict__ stat_out,
                                                              const float* __restrict__ hist_max, int bins,
                                                              unsigned long long* __restrict__ hist,
@@ -273,15 +278,27 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
     const int64_t off0 = (c - s * chunks_per_sample) * (int64_t)kCh;     // offset inside the sample
     const int64_t gbase = s * inner + off0;
     const int64_t rem = inner - off0;
+    // (RES: BatchNorm without activation, + the residual, then the activation - each step rounded as the two passes round it)
+    auto one = [&](float v, float sc, float sh, float r) __attribute__((always_inline)) {
+      if (!RES) return bn_act1<ACT>(v, sc, sh);
+      float t = bn_act1<FQ_ACT_NONE>(v, sc, sh) + r;
+      if (ACT == FQ_ACT_RELU) t = fmaxf(t, 0.0f);
+      if (ACT == FQ_ACT_RELU6) t = fminf(fmaxf(t, 0.0f), 6.0f);
+      return t;
+    };
     if (VEC) {
       const f4* p = reinterpret_cast<const f4*>(x + gbase);
+      const f4* pr = reinterpret_cast<const f4*>((RES ? res : x) + gbase);
       f4* o = reinterpret_cast<f4*>(y + gbase);
       const int nvec = (int)((rem < kCh ? rem : kCh) / kVec);
-      f4 v[U];
+      f4 v[U], rv[RES ? U : 1];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = threadIdx.x + u * kBlock;
-        if (i < nvec) v[u] = p[i];
+        if (i < nvec) {
+          v[u] = p[i];
+          if (RES) rv[u] = pr[i];
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -291,14 +308,15 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
           unsigned ch = e0 / (unsigned)hw;
           unsigned r = e0 - ch * (unsigned)hw;
           float sc = scale[ch], sh = shift[ch];
+          const f4 rr = RES ? rv[RES ? u : 0] : (f4){0.f, 0.f, 0.f, 0.f};
           f4 q;
-          q.x = bn_act1<ACT>(v[u].x, sc, sh);
+          q.x = one(v[u].x, sc, sh, rr.x);
           if (++r == (unsigned)hw) { r = 0; ++ch; sc = scale[ch]; sh = shift[ch]; }
-          q.y = bn_act1<ACT>(v[u].y, sc, sh);
+          q.y = one(v[u].y, sc, sh, rr.y);
           if (++r == (unsigned)hw) { r = 0; ++ch; sc = scale[ch]; sh = shift[ch]; }
-          q.z = bn_act1<ACT>(v[u].z, sc, sh);
+          q.z = one(v[u].z, sc, sh, rr.z);
           if (++r == (unsigned)hw) { r = 0; ++ch; sc = scale[ch]; sh = shift[ch]; }
-          q.w = bn_act1<ACT>(v[u].w, sc, sh);
+          q.w = one(v[u].w, sc, sh, rr.w);
           if (STATS) m = fmaxf(m, stat4<true>(q));
           o[i] = q;
           if (HIST) lh.put4(q);
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void bn_act_stat_kernel(const float* __rest
       for (int i = threadIdx.x; i < cnt; i += kBlock) {
         const unsigned e = (unsigned)(off0 + i);
         const unsigned ch = e / (unsigned)hw;
-        const float q = bn_act1<ACT>(x[gbase + i], scale[ch], shift[ch]);
+        const float q = one(x[gbase + i], scale[ch], shift[ch], RES ? res[gbase + i] : 0.0f);
         if (STATS) m = fmaxf(m, fabsf(q));
         y[gbase + i] = q;
         if (HIST) lh.put(q);
@@ -853,7 +871,7 @@ static int hist_grid(int64_t work_items) {
 
 static int bn_act_launch(const float* x, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
                          const float* shift, int act, float* stat_out, const float* hist_max, int bins, uint64_t* hist_,
-                         uint32_t* neg_count_, fqStream_t stream) {
+                         uint32_t* neg_count_, fqStream_t stream, const float* res = nullptr) {
   unsigned long long* hist = (unsigned long long*)hist_;
   unsigned int* neg_count = (unsigned int*)neg_count_;
   FQ_REQUIRE(x && y && scale && shift, "fq_bn_act_stat: null pointer");
@@ -867,14 +885,24 @@ static int bn_act_launch(const float* x, float* y, int64_t n, int64_t c, int64_t
   if (stat_out && !prezeroed) FQ_HIP(hipMemsetAsync(stat_out, 0, n * sizeof(float), st));
   const bool small = use_small_chunks(n, inner);
   const Chunking ck = chunking(n, inner, small ? kSmallChunk : kChunk);
-  const bool vec = (inner % kVec == 0) && aligned16(x) && aligned16(y);
+  const bool vec = (inner % kVec == 0) && aligned16(x) && aligned16(y) && (res == nullptr || aligned16(res));
   const bool with_hist = hist != nullptr;
   const int grid = with_hist ? hist_grid(ck.total) : grid_for(ck.total);
   const size_t lds = with_hist ? (size_t)4 * bins * sizeof(unsigned int) : 0;
-  ProfScope prof(FQ_KERNEL_BN_ACT, 8.0 * (double)n * (double)inner, st);
+  ProfScope prof(FQ_KERNEL_BN_ACT, (res ? 12.0 : 8.0) * (double)n * (double)inner, st);
+  // (the residual form exists with the statistic only: its one caller always wants it)
 #define FQ_BN_H(A, S, V, UU, H)                                                                                  \
-  hipLaunchKernelGGL((bn_act_stat_kernel<A, S, V, UU, H>), dim3(grid), dim3(kBlock), lds, st, x, y, inner, (int)hw, \
-                     ck.chunks_per_sample, ck.total, scale, shift, stat_out, hist_max, bins, hist, neg_count)
+  do {                                                                                                           \
+    if (res != nullptr) {                                                                                        \
+      if (S)                                                                                                     \
+        hipLaunchKernelGGL((bn_act_stat_kernel<A, true, V, UU, H, true>), dim3(grid), dim3(kBlock), lds, st, x, y, inner, \
+                           (int)hw, ck.chunks_per_sample, ck.total, scale, shift, res, stat_out, hist_max, bins, hist,    \
+                           neg_count);                                                                           \
+    } else {                                                                                                     \
+      hipLaunchKernelGGL((bn_act_stat_kernel<A, S, V, UU, H>), dim3(grid), dim3(kBlock), lds, st, x, y, inner, (int)hw, \
+                         ck.chunks_per_sample, ck.total, scale, shift, res, stat_out, hist_max, bins, hist, neg_count);  \
+    }                                                                                                            \
+  } while (0)
 #define FQ_BN(A, S, V, UU)                                                  \
   do {                                                                      \
     if (with_hist) { if (S) FQ_BN_H(A, true, V, UU, true); } else FQ_BN_H(A, S, V, UU, false); \
@@ -914,6 +942,20 @@ int fq_bn_act_stat_hist(const float* x, float* y, int64_t n, int64_t c, int64_t 
   FQ_REQUIRE(stat_out && hist_max && hist, "fq_bn_act_stat_hist: null pointer (the statistic is part of this form)");
   FQ_REQUIRE(bins > 0 && bins <= 4096, "fq_bn_act_stat_hist: bins=%d out of range (1..4096: four private copies in 64 KiB of LDS)", bins);
   return bn_act_launch(x, y, n, c, hw, scale, shift, act, stat_out, hist_max, bins, hist, neg_count, stream);
+}
+
+int fq_bn_add_act_stat(const float* x, const float* residual, float* y, int64_t n, int64_t c, int64_t hw, const float* scale,
+                       const float* shift, int act, float* stat_out, fqStream_t stream) {
+  FQ_REQUIRE(residual && stat_out, "fq_bn_add_act_stat: null pointer (residual, stat_out: the statistic is part of this form)");
+  return bn_act_launch(x, y, n, c, hw, scale, shift, act, stat_out, nullptr, 0, nullptr, nullptr, stream, residual);
+}
+
+int fq_bn_add_act_stat_hist(const float* x, const float* residual, float* y, int64_t n, int64_t c, int64_t hw,
+                            const float* scale, const float* shift, int act, float* stat_out, const float* hist_max, int bins,
+                            uint64_t* hist, uint32_t* neg_count, fqStream_t stream) {
+  FQ_REQUIRE(residual && stat_out && hist_max && hist, "fq_bn_add_act_stat_hist: null pointer");
+  FQ_REQUIRE(bins > 0 && bins <= 4096, "fq_bn_add_act_stat_hist: bins=%d out of range (1..4096)", bins);
+  return bn_act_launch(x, y, n, c, hw, scale, shift, act, stat_out, hist_max, bins, hist, neg_count, stream, residual);
 }
 
 static int add_act_launch(const float* a, const float* b, float* y, int64_t n, int64_t inner, int act, float* stat_out,

@@ -356,10 +356,12 @@ def _hist_args(hist, want_stat):
     return _ptr(hist.fm_max), int(hist.hist.numel()), _ptr(hist.hist), _ptr(hist.neg)
 
 
-def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True, hist=None):
+def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True, hist=None, residual=None):
     """Fused inference BatchNorm (per-channel scale/shift) + activation + per-sample max|y| in one pass.
     x: (N, C, ...) ; returns (y, stat (N,) or None).  `hist` (KL collection, distribution_calibrate.py): a sink whose counts
-    also receive y's histogram in the same pass (fq_bn_act_stat_hist) - what `histogram_accumulate(y, ...)` would add."""
+    also receive y's histogram in the same pass (fq_bn_act_stat_hist) - what `histogram_accumulate(y, ...)` would add.
+    `residual` (x's shape; fq_bn_add_act_stat): added after BatchNorm, before the activation - the values of this call without
+    activation followed by `add_act_stat`, in one pass; the statistic is part of that form."""
     _check(x, "x")
     _check(scale, "scale")
     _check(shift, "shift")
@@ -372,6 +374,19 @@ def bn_act_stat(x, scale, shift, act="relu", out=None, want_stat=True, hist=None
     if act not in _ACTS:
         raise ValueError("unknown activation %r" % (act,))
     y = torch.empty_like(x) if out is None else _check(out, "out")
+    if residual is not None:
+        _check(residual, "residual")
+        if tuple(residual.shape) != tuple(x.shape) or not want_stat:
+            raise ValueError("the residual must have x's shape %s (got %s) and the statistic is part of this form"
+                             % (tuple(x.shape), tuple(residual.shape)))
+        stat, zflag = _stat_target(n, x.device, True)
+        if hist is not None:
+            check_call(_lib_().fq_bn_add_act_stat_hist(_ptr(x), _ptr(residual), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift),
+                                                       _ACTS[act] | zflag, _ptr(stat), *_hist_args(hist, True), _stream(x)))
+        else:
+            check_call(_lib_().fq_bn_add_act_stat(_ptr(x), _ptr(residual), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift),
+                                                  _ACTS[act] | zflag, _ptr(stat), _stream(x)))
+        return y, stat
     stat, zflag = _stat_target(n, x.device, want_stat)
     if hist is not None:
         check_call(_lib_().fq_bn_act_stat_hist(_ptr(x), _ptr(y), n, c, hw, _ptr(scale), _ptr(shift), _ACTS[act] | zflag,

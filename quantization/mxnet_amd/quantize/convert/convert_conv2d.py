@@ -509,14 +509,29 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                 xq = ops.fake_quant_offline(t, plan["in_thr"], plan["width"], plan["flags"], want_stat=False)[0]
             x = NDArray(xq)
         out = block.origin_forward(F, x, weight_q, bias)
+        from .. import fuse as _fuse
+        res = getattr(block, "_fq_residual", None)
+        if (res is not None and scale is not None and fz["act"] == "none" and res.get("owner") is not None and _fuse.BN_ADD
+                and tuple(res["t"].shape) == tuple(out._t.shape) and out._t.is_cuda):
+            # the closing convolution of a residual unit that does NOT run on the codes (quantisation switched off: the KL
+            # collection's forward, an fp32 evaluation): its BatchNorm, the unit's add and activation, the statistic - and the
+            # histogram of the unit's output while feature maps are collected - in ONE pass instead of two (fq_bn_add_act_stat)
+            owner = res["owner"]
+            sink = _fuse._kl_sink(owner)
+            y, stat = ops.bn_act_stat(contiguous(out._t), scale, shift, res["act"], hist=sink, residual=res["t"])
+            res["used"] = True
+            r_ = NDArray(y)
+            r_._fq_stat = stat
+            if _fuse._collection is not None:
+                r_._fq_kl = (owner, sink)
+            return r_
         if fz["bn"] is None and fz["act"] == "none":
             return out
         if scale is None:
             c = out.shape[1]
             scale = torch.ones(c, dtype=torch.float32, device=out._t.device)
             shift = torch.zeros(c, dtype=torch.float32, device=out._t.device)
-        from .. import fuse as _fuse                    # (a KL collection past its first batch: this pass bins what it stores)
-        sink = _fuse._kl_sink(block)
+        sink = _fuse._kl_sink(block)                    # (a KL collection past its first batch: this pass bins what it stores)
         y, stat = ops.bn_act_stat(out._t.contiguous(), scale, shift, fz["act"], hist=sink)
         res = NDArray(y)
         res._fq_stat = stat

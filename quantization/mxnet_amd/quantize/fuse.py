@@ -94,7 +94,10 @@ def _fused_bn_forward(self, F, x, gamma, beta, running_mean, running_var):
     if st.get("pool") is not None and t.dim() == 4 and t.shape[3] % 4 == 0:
         # BatchNorm -> activation -> MaxPool2D(3, 2, 1) (the head of the ImageNet ResNets) in one pass
         y, stat = ops.bn_act_maxpool_stat(t, st["scale"], st["shift"], st["act"], want_stat=True)
-        st["pool"]._fq_pool_done = True
+        out = NDArray(y)
+        out._fq_stat = stat
+        out._fq_pooled_by = st["pool"]               # (the marker rides on the tensor: see _pool_stat_forward)
+        return out
     else:
         sink = _kl_sink(self)
         y, stat = ops.bn_act_stat(t, st["scale"], st["shift"], st["act"], want_stat=True, hist=sink)
@@ -103,14 +106,12 @@ def _fused_bn_forward(self, F, x, gamma, beta, running_mean, running_var):
         if _collection is not None:
             out._fq_kl = (self, sink)
         return out
-    out = NDArray(y)
-    out._fq_stat = stat
-    return out
 
 
 def _pool_after_bn_forward(self, F, x):
     """MaxPool2D whose work the preceding BatchNorm already did (quantize/fuse.py); pools itself when it did not (W % 4)."""
-    if self.__dict__.pop("_fq_pool_done", False):
+    if getattr(x, "_fq_pooled_by", None) is self:
+        x._fq_pooled_by = None
         return x
     return self._fq_pool_fused["orig"](F, x)
 
@@ -160,6 +161,8 @@ STEM_CODES = _os.environ.get("FQ_HANDOVER_STEM", "1") != "0"
 # FQ_WINO_SLICED=0: the 3x3 layers of a Winograd-domain quantised net stay with the tensor library's fp32 convolution of the
 # back-transformed filter instead of the three-slice integer form (tools/sliced_effect.py measures what the slices change)
 WINO_SLICED = _os.environ.get("FQ_WINO_SLICED", "1") != "0"
+# FQ_BN_ADD=0: the closing BatchNorm of a residual unit and the unit's add + activation as two passes again (A/B)
+BN_ADD = _os.environ.get("FQ_BN_ADD", "1") != "0"
 RECOMPUTE = _os.environ.get("FQ_RECOMPUTE", "1") != "0"
 RECOMPUTE_MIN_PIXELS = int(_os.environ.get("FQ_RECOMPUTE_MIN_PIXELS", "3136"))
 RECOMPUTE_MAX_CIN = int(_os.environ.get("FQ_RECOMPUTE_MAX_CIN", "128"))      # (input channels of the 1x1: see DESIGN.md for the pairs that pay)
@@ -299,11 +302,11 @@ def _tail_conv(seq):
     return conv if conv._kwargs["stride"] == (1, 1) else None
 
 
-def _with_residual(conv, shortcut, act, run):
+def _with_residual(conv, shortcut, act, run, owner=None):
     """Runs `run()` with the shortcut handed to `conv` (convert_conv2d.pointwise_fused adds it in the convolution's epilogue
     when that call runs on the integer codes).  Returns (output, True) when it was consumed there."""
     t = shortcut._t if shortcut._t.is_contiguous() else shortcut._t.contiguous()
-    conv._fq_residual = {"t": t, "act": act, "used": False}
+    conv._fq_residual = {"t": t, "act": act, "used": False, "owner": owner}
     try:
         out = run()
         return out, conv._fq_residual["used"]
@@ -324,7 +327,7 @@ def _residual_unit_forward(self, x):
     shortcut = x if self.downsample is None else self.downsample(x)
     tail = _tail_conv(self.body)
     if tail is not None:
-        h, consumed = _with_residual(tail, shortcut, "relu", lambda: self.body(x))
+        h, consumed = _with_residual(tail, shortcut, "relu", lambda: self.body(x), owner=self)
         if consumed:
             return h
     else:

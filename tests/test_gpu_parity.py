@@ -442,6 +442,34 @@ def test_add_act_stat_vs_oracle(dev, ops, shape, act):
     _eq(N(y2), want[:, :, 1:], "unaligned / no statistic")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 56, 56), (3, 5, 9, 12), (1, 3, 8, 8), (2, 7, 7, 5), (130, 2, 6, 8)])
+@pytest.mark.parametrize("act", ["relu", "none", "relu6"])
+def test_bn_add_act_stat_is_the_two_passes_in_one(dev, ops, shape, act):
+    """fq_bn_add_act_stat (round 6): BatchNorm, the residual add, the activation and the statistic in one pass - bit for bit
+    fq_bn_act_stat without activation followed by fq_add_act_stat, and the host twin; aligned and unaligned inputs; with a
+    histogram sink the counts the separate histogram pass adds."""
+    from oracle import host as H
+    rng = np.random.default_rng(sum(shape) + 1)
+    x = (rng.standard_normal(shape) * 3).astype(np.float32)
+    r = (rng.standard_normal(shape) * 2).astype(np.float32)
+    sc = (0.5 + rng.random(shape[1])).astype(np.float32) * np.where(rng.random(shape[1]) < 0.2, -1, 1).astype(np.float32)
+    sh = rng.standard_normal(shape[1]).astype(np.float32)
+    y, stat = ops.bn_act_stat(T(x, dev), T(sc, dev), T(sh, dev), act, residual=T(r, dev))
+    t, _ = ops.bn_act_stat(T(x, dev), T(sc, dev), T(sh, dev), "none", want_stat=False)
+    y2, stat2 = ops.add_act_stat(t, T(r, dev), act)
+    _eq(N(y), N(y2), "one pass vs two")
+    _eq(N(stat), N(stat2), "statistic")
+    want, wstat = H.add_act(H.bn_act(x, sc, sh, "none"), r, act, want_stat=True)
+    _eq(N(y), want, "host twins")
+    _eq(N(stat), wstat, "host statistic")
+    xu, ru = T(x, dev).reshape(-1)[1:].clone(), T(r, dev).reshape(-1)[1:].clone()      # storage not 16-byte aligned
+    if shape[0] > 1:
+        xs, rs = T(x, dev)[1:], T(r, dev)[1:]
+        y3, stat3 = ops.bn_act_stat(xs.contiguous(), T(sc, dev), T(sh, dev), act, residual=rs.contiguous())
+        _eq(N(y3), want[1:], "a batch slice")
+    del xu, ru
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 112, 112), (3, 5, 9, 12), (1, 3, 8, 8), (2, 4, 7, 4), (130, 2, 6, 8)])
 @pytest.mark.parametrize("act", ["relu", "none", "relu6"])
 def test_bn_act_maxpool_stat_vs_oracle(dev, ops, shape, act):
