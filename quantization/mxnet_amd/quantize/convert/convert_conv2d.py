@@ -334,6 +334,10 @@ def recompute_target(block, fz, x, plan, c16_in):
     nxt = fz.get("pair_dw")
     if nxt is None or not _fuse.RECOMPUTE or c16_in is not None or autograd.is_recording() or _fuse._collection is not None:
         return None
+    # only inside the forward of the net fuse_inference rewired (its wrapper holds the statistic arena): a caller that runs this
+    # block on its own - feature extraction, a test - must get a tensor, not a promise only the linked depthwise block can keep
+    if getattr(ops.StatArena._tls, "current", None) is None:
+        return None
     if "in_stat" not in plan or "in_thr" in plan or getattr(block, "_fq_residual", None) is not None:
         return None
     a = nxt.quantize_args

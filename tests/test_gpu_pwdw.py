@@ -255,3 +255,48 @@ def test_a_net_with_recompute_pairs_equals_the_same_net_without(dev, ops, model)
     _eq(outs[True][0], outs[False][0], "logits")
     _eq(outs[True][1], outs[False][1], "current_input_max of every block")
     _eq(outs[True][2], outs[False][2], "thresholds after one naive-EMA step")
+
+
+def test_a_block_called_on_its_own_returns_a_tensor_and_a_stray_deferred_array_is_materialised(dev, ops):
+    """The deferred output of a recompute pair exists only inside the rewired net's forward: the 1x1 block called directly
+    returns the stored tensor; and should a deferred array reach another consumer after all, that consumer computes it."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.quantize import fuse
+    from quantization.mxnet_amd.quantize.convert import convert_conv2d as C
+    from test_gpu_net import _build as build
+    net = build("mobilenet1.0", 1000, mx.gpu(0))
+    net.fix_params()
+    net.quantize_input(enable=True, online=True)
+    X = mx.nd.array(np.random.default_rng(3).standard_normal((4, 3, 224, 224)).astype(np.float32), ctx=mx.gpu(0))
+    net(X)
+    fuse.fuse_inference(net)
+    want = net(X).asnumpy()
+    feats = list(net.features._children.values())
+    pairs = [(i, b) for i, b in enumerate(feats) if getattr(b, "_fq_pw_fused", {}).get("pair_dw") is not None]
+    assert len(pairs) >= 3
+    # the layers in front of the first pair, then the 1x1 block on its own
+    h = X
+    i0, pw = pairs[0]
+    for b in feats[:i0]:
+        h = b(h)
+    y = pw(h)
+    assert y._fq_deferred is None and y._t.dtype == torch.float32 and tuple(y.shape) == (4, 64, 112, 112)
+    # a deferred array handed to a block that is not its consumer
+    seen = []
+    real = C._materialise
+    C._materialise = lambda a: (seen.append(1), real(a))[1]
+    try:
+        stat = ops.absmax_per_sample(h._t)
+        codes = C._pointwise_weight_codes(pw, pw.quantize_args, pw.weight.data(), pw.weight.data())
+        fz = pw._fq_pw_fused
+        scale, shift = fz["constants"]()
+        fake = mx.nd.NDArray(C._placeholder((4, 64, 112, 112), h._t.device))
+        fake._fq_stat = ops.pwconv_i8_stat(h._t, *codes, None, in_stat=stat, bn_scale=scale, bn_shift=shift, act=fz["act"])
+        fake._fq_deferred = dict(x=h._t, codes=codes, bias=None, bn=(scale, shift), act=fz["act"],
+                                 plan=dict(in_stat=stat, width=8, flags=0, cur_out=torch.zeros(1, device=h._t.device)),
+                                 consumer=object())
+        z = fz["pair_dw"](fake)                                   # the record names another `consumer`: must materialise
+        assert seen == [1] and z._t.dtype == torch.float32
+    finally:
+        C._materialise = real
+    _eq(net(X).asnumpy(), want, "the net is unchanged by the detour")
