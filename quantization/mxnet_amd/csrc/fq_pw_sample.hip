@@ -460,11 +460,17 @@ int pw_try_sample(const PwCall& a, bool* taken) {
                                         (mode == 3 && (base || (small && a.residual == nullptr))) ||
                                         (mode == 4 && a.hw <= 1024 && !small) || (mode == 5 && !small && a.residual == nullptr));
   if (!shape_ok || !(a.form == 7 || by_shape)) return FQ_OK;
+  // ... and only where its workgroups (one per sample, block and 256 channels) reach a quarter of the CUs: below that the
+  // split form's finer items win (MobileNet images/s +3.5 % at batch 8, equal at 16: profiles/r6_small_batch_forms_ab.txt)
+  if (a.form != 7 && a.n * (a.cout / 256) * nb < num_cu() / 4) return FQ_OK;
   const int64_t rows_pad = (a.cout + 31) / 32 * 32;
   static const int ctw_tune = env_int("FQ_PWSMP_CTW", 0);               // tuning: 1 = 256 channels per workgroup everywhere
   // two channel tiles per wavefront (512 channels per workgroup, every value quantised once) from K = 512 up; below that
   // two workgroups of 256 channels per CU are faster (256 -> 512 @14x14: 20.1 -> 18.4 us; 512 -> 512: 25.2 against 25.7)
-  const int ctw = (a.cout % 512 == 0 && ctw_tune != 1 && (kt >= 16 || ctw_tune == 2 || a.residual != nullptr)) ? 2 : 1;
+  // ... unless the 512-channel workgroups would be fewer than 3/8 of the CUs (batch 32 and below on the 14x14 and 7x7
+  // layers): MobileNet images/s with 256 channels everywhere +2.1 % at batch 16, +0.9 % at 32, -0.35 % at 48, -0.7 % at 64
+  const bool few = ctw_tune == 0 && a.residual == nullptr && a.n * (a.cout / 512) * nb < num_cu() * 3 / 8;
+  const int ctw = (a.cout % 512 == 0 && ctw_tune != 1 && !few && (kt >= 16 || ctw_tune == 2 || a.residual != nullptr)) ? 2 : 1;
   PwSampleGeom t;
   t.Cin = (int)a.cin;
   t.Cout = (int)a.cout;
