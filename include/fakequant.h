@@ -335,6 +335,21 @@ int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wsca
                          unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
                          int act, float* stat_out, const float* residual, void* ws, fqStream_t stream);
 
+/* The closing 1x1 convolution of the last unit of a ResNet-v1 stage (round 6).  Its output - `(body(x) + shortcut).relu()`, the
+ * trunk - has exactly two readers, the first 1x1 and the shortcut 1x1 of the next stage's first unit, both with stride 2 and no
+ * padding (gluon model_zoo BottleneckV1; the reference wraps each in convert_conv2d.py:53-66,108): three quarters of the tensor
+ * are written and never read, and the quarter that is read is fetched with half of every cache line wasted.  This entry point
+ * computes the values of fq_pwconv_i8_strided(stride = 1, residual) and stores y[:, :, ::2, ::2] only, as a dense
+ * (n, cout, ceil(h/2), ceil(w/2)) tensor; stat_out[n] is max|y[n]| over ALL of y (the readers' online thresholds are those of
+ * the whole tensor, convert_conv2d.py:56-58), `residual` has the whole (n, cout, h, w) shape.  The readers then call
+ * fq_pwconv_i8 (stride 1) on that tensor with this statistic.  Shapes: fq_pwconv_i8_sub2_supported(cin, cout).          */
+int fq_pwconv_i8_sub2_supported(int64_t cin, int64_t cout);
+int fq_pwconv_i8_sub2(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                      float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                      const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                      const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual, void* ws,
+                      fqStream_t stream);
+
 /* ---- a pointwise convolution and the depthwise 3x3 behind it WITHOUT the tensor between them (round 6) ---------------------
  * Under ONLINE input quantisation (convert_conv2d.py:56-58: the threshold of a block is the batch mean of the per-sample maxima
  * of the tensor it is handed in this very forward) a producer cannot hand codes to its consumer - the threshold exists only

@@ -669,6 +669,24 @@ int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float*
                         in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual);
 }
 
+// fq_pwconv_i8_sub2: the whole stride-1 output on the host, of which the even pixels of the even rows are handed back.
+int fq_pwconv_i8_sub2_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                           float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                           const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                           float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                           const float* residual, void*, fqStream_t) {
+  REQUIRE(x && y && h > 0 && w > 0, "fq_pwconv_i8_sub2_host: bad arguments");
+  std::vector<float> full((size_t)(n * cout * h * w));
+  if (int rc = pwconv_i8_impl(x, wcodes, wscale, wsum, bias, full.data(), n, cin, cin_pad, cout, h * w, in_stat, in_thr,
+                              in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual))
+    return rc;
+  const int64_t hs = (h + 1) / 2, ws_ = (w + 1) / 2;
+  for (int64_t pc = 0; pc < n * cout; ++pc)
+    for (int64_t r = 0; r < hs; ++r)
+      for (int64_t c = 0; c < ws_; ++c) y[(pc * hs + r) * ws_ + c] = full[(size_t)((pc * h + 2 * r) * w + 2 * c)];
+  return 0;
+}
+
 // Dense 3x3 convolution (stride 1, pad 1) on the integer codes: exact integer sums over (ky, kx, ci), zero padding = code 0.
 // wcodes rows are ordered (tap, ci) - the weights were permuted to (cout, 3, 3, cin) before fq_weight_codes_host.
 static int conv3x3_i8_impl(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,

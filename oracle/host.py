@@ -259,8 +259,23 @@ def weight_codes(w, rows_per_scale, width=8):
 
 
 def pwconv_i8(x, w, rows_per_scale, wt_width, in_max=None, in_stat=None, signed=False, width=8, lo_neg_max=None,
-              bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=False, stride=1, residual=None):
+              bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=False, stride=1, residual=None, subsample=False):
     x = _f32(x)
+    if subsample:
+        assert stride == 1 and x.ndim == 4
+        n, cin, h, wd = x.shape
+        codes, scales, rowsum = weight_codes(np.asarray(w).reshape(np.asarray(w).shape[0], -1), rows_per_scale, wt_width)
+        cout = np.asarray(w).shape[0]
+        y = np.empty((n, cout, (h + 1) // 2, (wd + 1) // 2), F32)
+        stat = np.zeros(n, F32) if want_stat else None
+        thr = None if in_max is None else np.asarray([in_max], F32).reshape(1)
+        cur = np.empty(1, F32)
+        _call("fq_pwconv_i8_sub2_host", x, codes, scales, rowsum, None if bias is None else _f32(bias), y, n, cin,
+              codes.shape[1], cout, h, wd, None if in_stat is None else _f32(in_stat), thr, _i(width),
+              _u(act_flags(signed, lo_neg_max)), cur, None if bn_scale is None else _f32(bn_scale),
+              None if bn_shift is None else _f32(bn_shift), _i(_ACTS[act]), stat,
+              None if residual is None else _f32(residual), None, None)
+        return (y, stat) if want_stat else y
     if stride != 1 or residual is not None:
         return _pwconv_i8_strided(x, w, rows_per_scale, wt_width, in_max, in_stat, signed, width, lo_neg_max, bias,
                                   bn_scale, bn_shift, act, want_stat, stride, residual)

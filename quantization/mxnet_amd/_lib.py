@@ -80,6 +80,9 @@ EXPORTS = {
                                 _vp, _vp, _vp]),
     "fq_pwconv_i8_strided": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,
                                     _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
+    "fq_pwconv_i8_sub2_supported": (_int, [_i64, _i64]),
+    "fq_pwconv_i8_sub2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int,
+                                 _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "fq_pwconv_i8_c16": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,
                                 _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _uint, _vp, _vp]),
     # x, wcodes, wscale, wsum, bias, y, y16, n, cin, cin_pad, cout, h, w, in_stat, in_thr, in_width, in_flags, cur, bn_scale,

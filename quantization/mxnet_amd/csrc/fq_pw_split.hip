@@ -28,8 +28,9 @@ int pw_try_split(const PwCall& a, bool* taken) {
   // (r4, tools/pwforms.py --resnet: with a residual operand the streaming form loses its lead on the largest planes -
   // 64 -> 256 @56x56 + residual, ResNet-50's largest kernel: 207.5 us against 183.7 here)
   static const int res_split = env_int("FQ_PWS_RES_SPLIT", 1);
-  bool want = a.form == 6 || a.stride != 1 || c16;                      // (only this form reads strided inputs)
-  if (a.form == 0 && shape_ok && a.stride == 1)
+  bool want = a.form == 6 || a.stride != 1 || c16 || a.sub;             // (only this form reads strided inputs)
+  if (a.sub) shape_ok = shape_ok && pw_split_sub_shape_ok(a.cin_pad, a.cout) && !c16 && a.stride == 1;
+  if (a.form == 0 && shape_ok && a.stride == 1 && !a.sub)
     want = mode == 2 || (mode == 1 && (tiles <= (int64_t)num_cu() * 16 || !pw_stream_shape_ok(a) ||
                                        (res_split && a.residual != nullptr && a.cin <= 64)));
   if (want && shape_ok) {
@@ -48,8 +49,8 @@ int pw_try_split(const PwCall& a, bool* taken) {
     static const int nw8_tiles = env_int("FQ_PWS_NW8_TILES", 0);        // tuning: most tiles a layer may have to take nw = 8
     const int64_t nw8_max = nw8_tiles > 0 ? nw8_tiles : 16 * (int64_t)num_cu();
     int nw = (nw_tune == 4 || nw_tune == 8) ? nw_tune : ((a.cout >= 512 && tiles <= nw8_max) ? 8 : 4);
-    if (!nw8_built || c16) nw = 4;
-    const int tune = c16 ? 0 : env_int("FQ_PWS_CFG", 0);                 // tuning: 10 * lb + cw, read per call
+    if (!nw8_built || c16 || a.sub) nw = 4;
+    const int tune = (c16 || a.sub) ? 0 : env_int("FQ_PWS_CFG", 0);      // tuning: 10 * lb + cw, read per call
     if (tune > 0) {
       cw = tune % 10;
       lb = tune / 10;
@@ -65,12 +66,22 @@ int pw_try_split(const PwCall& a, bool* taken) {
     t.CBi = (int)((a.cin + 15) / 16); t.CBo = (int)((a.cout + 15) / 16);
     t.out_levels = a.out_levels; t.out_lo_neg = a.out_lo_neg; t.out_zoff = a.out_zoff;
     t.y16 = (char*)a.y16; t.dual_thr = a.dual_thr;
+    t.SW = a.sub ? (int)a.w_in : 0;
+    t.SWs = a.sub ? (int)((a.w_in + 1) / 2) : 0;
+    t.SHWs = a.sub ? (int)((a.h_in + 1) / 2) * t.SWs : 0;
     const int64_t grid = (t.items + 7) / 8 * 8;                           // padded to whole rounds over the 8 XCDs
     FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8: too many tiles for the split form");
     const size_t ldst = (size_t)kt * 1024 + (size_t)(nw * cw * 32) * 5 * sizeof(float);
     const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;               // second half of fq_weight_codes' buffer
     if (int rc = pw_zero_stat(a)) return rc;
     bool launched = false;
+    if (a.sub) {
+      if (int rc = pw_split_sub_launch(a, &t, kt, grid, ldst, wfrag, &launched)) return rc;
+      FQ_REQUIRE(launched, "fq_pwconv_i8_sub2: no instantiation for K/32=%d", kt);
+      FQ_LAUNCH_CHECK();
+      *taken = true;
+      return FQ_OK;
+    }
     if (c16) {
       FQ_REQUIRE(a.residual == nullptr || a.out_thr == nullptr, "fq_pwconv_i8_c16: a residual operand goes with fp32 output");
       if (int rc = pw_split16_launch(a, &t, kt, cw, grid, ldst, wfrag, &launched)) return rc;
@@ -112,6 +123,7 @@ int pw_try_split(const PwCall& a, bool* taken) {
     *taken = true;
     return FQ_OK;
   }
+  FQ_REQUIRE(!a.sub, "fq_pwconv_i8_sub2: shape not taken (see fq_pwconv_i8_sub2_supported)");
   FQ_REQUIRE(!c16, "fq_pwconv_i8_c16: the shape does not fit the split kernel (padded Cin / 32 = %d is not instantiated)", kt);
   FQ_REQUIRE(a.form != 6 && a.stride == 1, "fq_pwconv_i8: %s but the shape does not fit the split kernel (padded Cin / 32 "
              "= %d is not instantiated)", a.stride == 1 ? "FQ_PW_FORM=6" : "a strided call", kt);

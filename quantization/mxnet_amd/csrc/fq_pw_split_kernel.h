@@ -37,19 +37,24 @@ struct PwSplitGeom {
   // DUAL: the second output (C16 codes of y under dual_thr; out_levels / out_lo_neg / out_zoff / CBo describe it)
   char* y16;
   const float* dual_thr;
+  // SUB (fq_pwconv_i8_sub2, round 6): only the pixels (2 i, 2 j) of every output plane are stored, as a dense
+  // (n, Cout, ceil(H / 2), ceil(W / 2)) tensor; SW: the plane's width, SWs / SHWs: width and pixels of a stored plane
+  int SW, SWs, SHWs;
 };
 
 // LB: wavefronts per SIMD the register allocation aims at (3: <= 168 registers, 4: <= 128) - with one tile per workgroup the
 // whole grid should be resident at once (a second round of a few left-over workgroups costs a whole workgroup latency)
 // NW: wavefronts per workgroup.  4: 128 * CW output channels per workgroup; 8 (wide layers): 256 * CW - half as many channel
 // groups quantise the same tile, i.e. half the redundant loads and quantiser VALU.
-template <int KT, int CW, int D, int LB, int NW, bool IN16 = false, bool OUT16 = false, bool DUAL = false>
+// SUB: the output is stored subsampled (see PwSplitGeom); statistic and residual operand cover the whole planes.
+template <int KT, int CW, int D, int LB, int NW, bool IN16 = false, bool OUT16 = false, bool DUAL = false, bool SUB = false>
 __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSplitGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
     float* __restrict__ stat_out, const float* __restrict__ residual, const float* __restrict__ out_thr) {
+  static_assert(!SUB || !(IN16 || OUT16 || DUAL), "the subsampled output is built for fp32 tensors on both sides");
   constexpr int kSlots = 8;
   constexpr int SLABS = (KT + NW - 1) / NW;                             // slabs a wavefront quantises (kt = wave + NW j < KT)
   constexpr int RB = SLABS < 4 ? SLABS : 4;                             // slabs (16 loads each) in flight per lane
@@ -259,13 +264,19 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     // past Cout of a PARTIAL channel tile are masked (the hardware drops the store; no branch, no exec juggling).
     int64_t y_bytes = (n_samp - s_base) * y_samp - (int64_t)(ch0 + ctl0 * 32) * plane4;
     y_bytes = y_bytes < 0x7FFFFFFFll ? y_bytes : 0x7FFFFFFFll;
+    // SUB: stores go to the dense tensor of the even pixels of the even rows (plane4s bytes per channel); the residual
+    // operand keeps the full planes
+    const unsigned plane4s = SUB ? (unsigned)g.SHWs * 4u : plane4;
+    const int64_t y_samp_s = SUB ? (int64_t)g.Cout * g.SHWs * 4 : y_samp;
+    int64_t ys_bytes = (n_samp - s_base) * y_samp_s - (int64_t)(ch0 + ctl0 * 32) * plane4s;
+    ys_bytes = ys_bytes < 0x7FFFFFFFll ? ys_bytes : 0x7FFFFFFFll;
     // OUT16: y is a C16 code tensor; the resource starts at (first sample, this wavefront's first 16-channel block)
     const int64_t y_samp16 = (int64_t)g.CBo * HW * 16;
     const int cb0 = (ch0 + ctl0 * 32) >> 4;                               // first output block of this wavefront
     int64_t y16_bytes = (n_samp - s_base) * y_samp16 - (int64_t)cb0 * HW * 16;
     y16_bytes = y16_bytes < 0x7FFFFFFFll ? y16_bytes : 0x7FFFFFFFll;
     const fq_rsrc yr = OUT16 ? make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp16 + (int64_t)cb0 * HW * 16, y16_bytes)
-                             : make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp + (int64_t)(ch0 + ctl0 * 32) * plane4, y_bytes);
+                             : make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp_s + (int64_t)(ch0 + ctl0 * 32) * plane4s, ys_bytes);
     const unsigned yo16 = (smp - s_base) * (unsigned)g.CBo * HW * 16u + p * 16u + 4u * h;
     const fq_rsrc yr16 = make_rsrc(DUAL ? g.y16 + s_base * y_samp16 + (int64_t)cb0 * HW * 16 : reinterpret_cast<char*>(y),
                                    DUAL ? y16_bytes : 0);
@@ -275,6 +286,12 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     const fq_rsrc rr = make_rsrc(reinterpret_cast<const char*>(has_res ? residual : y) + s_base * y_samp +
                                  (int64_t)(ch0 + ctl0 * 32) * plane4, has_res ? y_bytes : 0);
     const unsigned yo = ((smp - s_base) * (unsigned)g.Cout + 4u * h) * plane4 + p * 4u;
+    unsigned yos = yo;                           // the lane's store offset (SUB: out of range for a pixel that is not stored)
+    if (SUB) {
+      const unsigned ho = p / (unsigned)g.SW, wo = p - ho * (unsigned)g.SW;
+      yos = ((ho | wo) & 1u) ? 0x80000000u
+                             : ((smp - s_base) * (unsigned)g.Cout + 4u * h) * plane4s + ((ho >> 1) * (unsigned)g.SWs + (wo >> 1)) * 4u;
+    }
     float m = 0.0f;
     auto store_tile = [&](int c, int cv, auto masked_c) __attribute__((always_inline)) {
       constexpr bool MASKED = decltype(masked_c)::value;
@@ -312,8 +329,8 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
           if (!FOLD) v = ACT_M < 0 ? act_rt(v, act) : act_rt(v, ACT_M);
           vq[r] = v;
           if (!OUT16) {
-            const unsigned off = MASKED ? (8 * gq + 4 * h + r < cv ? yo : 0x80000000u) : yo;
-            buf_st_f32(yr, off, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
+            const unsigned off = MASKED ? (8 * gq + 4 * h + r < cv ? yos : 0x80000000u) : yos;
+            buf_st_f32(yr, off, (unsigned)(c * 32 + 8 * gq + r) * plane4s, v);
           }
           m = FOLD ? fmaxf(m, v) : fmaxf(m, fabsf(v));   // channels past Cout have all-zero constants: v == 0
         }

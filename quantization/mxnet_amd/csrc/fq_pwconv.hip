@@ -78,7 +78,7 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
                            const float* residual, void* ws, fqStream_t stream, bool in_c16 = false,
                            const float* out_thr = nullptr, int out_width = 8, unsigned out_flags = 0,
                            const long long* eval_labels = nullptr, float* eval_counters = nullptr,
-                           void* eval_ws = nullptr, bool* range_taken = nullptr, void* y16 = nullptr) {
+                           void* eval_ws = nullptr, bool* range_taken = nullptr, void* y16 = nullptr, bool sub = false) {
   // range_taken != nullptr: range mode (fq_common.h: kRangeMode) - in_thr is a range record, bias holds int32 codes; only
   // the one-launch forms serve it and *range_taken says whether one took the shape
   const bool range = range_taken != nullptr;
@@ -129,6 +129,7 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
     c.out_zoff = (out_flags & FQ_ACT_SIGNED) ? 0 : 128;
   }
   c.eval_labels = eval_labels; c.eval_counters = eval_counters; c.eval_ws = eval_ws;
+  c.sub = sub;
   static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample, 8 rows, 9 pipe
   c.form = (in_c16 || c.out_thr) ? 6 : (eval_labels ? 8 : (forced_form ? forced_form : pw_form));
   // tuning: FQ_PW_FORM_AT="<pixels per plane>:<form>[,...]" names a form for the layers of one plane size (A/Bs of a form choice
@@ -168,12 +169,20 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   // (the classifier - planes of one pixel - is accounted on its own: 1 MB of latency-bound work is no pointwise layer)
   // (second figure: the bytes really moved - 1 B per element of a side that is a C16 code tensor, 16-channel blocks padded)
   const double in_elems = (double)n * cin * hw, out_elems = (double)n * cout * hw;
+  // (a subsampled output: the layer's algorithmic bytes stay those of the whole tensor; moved: the quarter that is stored)
+  const double stored = sub ? (double)n * cout * ((h_in + 1) / 2) * ((w_in + 1) / 2) : out_elems;
   const double moved = (in_c16 ? (double)n * ((cin + 15) / 16 * 16) * hw : 4.0 * in_elems) +
-                       (c.out_thr != nullptr ? (double)n * ((cout + 15) / 16 * 16) * hw : 4.0 * out_elems) +
+                       (c.out_thr != nullptr ? (double)n * ((cout + 15) / 16 * 16) * hw : 4.0 * stored) +
                        (y16 != nullptr ? (double)n * ((cout + 15) / 16 * 16) * hw : 0.0) + (residual ? 4.0 * out_elems : 0.0);
   ProfScope prof(hw == 1 ? FQ_KERNEL_DENSE : FQ_KERNEL_PWCONV, 4.0 * (in_elems + (residual ? 2.0 : 1.0) * out_elems), c.st, moved);
   bool taken = false;
   out_thr = c.out_thr;                                  // (from here on: "y is a C16 tensor")
+  if (sub) {                                            // (the split form alone stores subsampled)
+    FQ_REQUIRE(c.form == 0 || c.form == 6, "fq_pwconv_i8_sub2: only the split form stores a subsampled output");
+    if (int rc = pw_try_split(c, &taken)) return rc;
+    FQ_REQUIRE(taken, "fq_pwconv_i8_sub2: shape not taken (see fq_pwconv_i8_sub2_supported)");
+    return FQ_OK;
+  }
   if (hw == 1 && !(in_c16 || out_thr) && !range) {      // (the rows form is not built for range records)
     if (int rc = pw_try_rows(c, &taken)) return rc;
     if (taken) return FQ_OK;
@@ -274,6 +283,26 @@ int fq_pwconv_i8_strided(const float* x, const int8_t* wcodes, const float* wsca
   return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, ho * wo, stride, h, w, wo, in_stat,
                          in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, ws,
                          stream);
+}
+
+// The closing 1x1 of a ResNet-v1 stage when both readers of its output are stride-2 1x1 convolutions (round 6): the values of
+// fq_pwconv_i8_strided with stride 1, of which only y[:, :, ::2, ::2] is stored - densely, (n, cout, ceil(h/2), ceil(w/2)) -
+// while stat_out (and the residual operand) cover all of y.  The readers then run with stride 1 on a quarter of the bytes.
+int fq_pwconv_i8_sub2_supported(int64_t cin, int64_t cout) {
+  return pw_split_sub_shape_ok((cin + 63) / 64 * 64, cout) ? 1 : 0;
+}
+
+int fq_pwconv_i8_sub2(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                      float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                      const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                      const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual, void* ws,
+                      fqStream_t stream) {
+  FQ_REQUIRE(h > 0 && w > 0, "fq_pwconv_i8_sub2: bad plane %lld x %lld", (long long)h, (long long)w);
+  FQ_REQUIRE(pw_split_sub_shape_ok(cin_pad, cout), "fq_pwconv_i8_sub2: built for 64 / 128 / 256 / 512 (padded) input channels "
+             "and more than 128 output channels (got cin_pad=%lld cout=%lld)", (long long)cin_pad, (long long)cout);
+  return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, h * w, 1, h, w, w, in_stat, in_thr,
+                         in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, ws, stream, false,
+                         nullptr, 8, 0, nullptr, nullptr, nullptr, nullptr, nullptr, true);
 }
 
 int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,

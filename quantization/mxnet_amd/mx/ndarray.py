@@ -76,7 +76,10 @@ class NDArray(object):
     # is then an int8 placeholder of the right shape without storage, so that any other reader fails loudly.
     # _fq_pooled_by: optional MaxPool2D block - the first convolution's launch pooled already (fq_stem_conv7x7s2_pool) and that
     # block, when it is handed this very tensor, passes it through (quantize/fuse.py).
-    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl", "_fq_side", "_fq_deferred", "_fq_pooled_by")
+    # _fq_sub2: optional dict - `_t` holds only [:, :, ::2, ::2] of the tensor this NDArray stands for (`hw`: its plane), because
+    # its only readers (`readers`: two Conv2D blocks, 1x1, stride 2, no padding; `unit`: the residual unit that owns them) never
+    # look at the rest; `_fq_stat` is the statistic of the WHOLE tensor (fq_pwconv_i8_sub2; convert_conv2d.sub_target).
+    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl", "_fq_side", "_fq_deferred", "_fq_pooled_by", "_fq_sub2")
     __array_priority__ = 1000.0
     __array_ufunc__ = None
 
@@ -90,6 +93,7 @@ class NDArray(object):
         self._fq_side = None
         self._fq_deferred = None
         self._fq_pooled_by = None
+        self._fq_sub2 = None
 
     # -- plumbing ---------------------------------------------------------------------------
     @property

@@ -778,9 +778,14 @@ def pwconv_strided_supported(cin):
     return ((int(cin) + 63) // 64 * 64) // 32 in SPLIT_KT
 
 
+def pwconv_sub2_supported(cin, cout):
+    """Shapes `pwconv_i8(..., subsample=True)` takes (fq_pwconv_i8_sub2_supported)."""
+    return bool(_lib_().fq_pwconv_i8_sub2_supported(int(cin), int(cout)))
+
+
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
               bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None, out_codes=None,
-              side_codes=None):
+              side_codes=None, subsample=False):
     """1x1 convolution on the integer codes (int8 MFMA, exact int32 accumulation) with quantise-on-load and fused
     BatchNorm / activation / statistic.  x: (N, Cin, H, W) raw activations; stride 1 or 2 (no padding); `residual` (the
     output's shape) is added after BatchNorm and before the activation.  `form` names one of PW_FORMS ("stream", "sample",
@@ -790,8 +795,17 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     Offline hand-over (fq_pwconv_i8_c16): `x` may be a `Codes16` (made with this call's in_thr / width / flags), and
     `out_codes=dict(thr=<consumer's threshold tensor>, width=8, flags=0)` makes `y` a `Codes16` of the consumer's codes.
     `side_codes=dict(thr=..., width=8, flags=0)` (fq_pwconv_i8_c16_dual; a `Codes16` input with a residual operand, stride 1):
-    y stays fp32 and a third value is returned, the `Codes16` of y under that threshold - the trunk of a ResNet stored twice."""
+    y stays fp32 and a third value is returned, the `Codes16` of y under that threshold - the trunk of a ResNet stored twice.
+
+    `subsample=True` (fq_pwconv_i8_sub2; fp32 x (N, Cin, H, W), stride 1): the returned y is y[:, :, ::2, ::2] of the tensor
+    the call stands for - (N, Cout, ceil(H/2), ceil(W/2)), all its stride-2 readers need - while `stat` and `residual` keep the
+    whole planes."""
     in16 = isinstance(x, Codes16)
+    if subsample:
+        if in16 or out_codes is not None or side_codes is not None or stride != 1 or x.dim() != 4:
+            raise ValueError("subsample=True goes with fp32 (N, Cin, H, W) activations, stride 1 and fp32 output")
+        if not pwconv_sub2_supported(x.shape[1], wscale.numel()):
+            raise ValueError("subsample=True: %d -> %d channels is not a shape fq_pwconv_i8_sub2 takes" % (x.shape[1], wscale.numel()))
     if in16:
         if in_thr is None or not x.matches(in_thr, width, flags):
             raise ValueError("the C16 input was quantised with another threshold / width / signedness than this call names")
@@ -855,6 +869,17 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
                                             _ptr(in_thr), int(width), int(flags), _ptr(cur_out), _ptr(bn_scale),
                                             _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _ptr(residual), _ptr(othr),
                                             int(ow), int(of), _ptr(ws), _stream(wcodes)))
+        return y, stat
+    if subsample:
+        h, w = x.shape[2], x.shape[3]
+        y = torch.empty((n, cout, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=x.device)
+        if residual is not None and tuple(residual.shape) != (n, cout, h, w):
+            raise ValueError("the residual must have the whole output's shape %s, got %s" % ((n, cout, h, w), tuple(residual.shape)))
+        ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, h * w), dtype=torch.uint8, device=x.device)
+        check_call(_lib_().fq_pwconv_i8_sub2(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin, cin_pad,
+                                             cout, h, w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(cur_out),
+                                             _ptr(bn_scale), _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _ptr(residual),
+                                             _ptr(ws), _stream(x)))
         return y, stat
     if stride != 1 or residual is not None:
         if x.dim() != 4:

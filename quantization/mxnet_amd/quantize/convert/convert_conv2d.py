@@ -312,6 +312,42 @@ def side_target(block, c16_in):
     return nxt
 
 
+def sub_target(block, fz, c16_in, xshape):
+    """The link to the two readers of this closing 1x1 convolution's output (quantize/fuse.py: `sub_next`, a stage boundary of
+    the v1 bottleneck ResNets) when it may store only what they read: each is a 1x1 convolution with stride 2 and no padding
+    (convert_conv2d.py:108 with the block's own kwargs), i.e. it looks at y[:, :, ::2, ::2] and at the statistic of y, which this
+    launch still takes over all of y.  Nothing else may observe the tensor: no hooks on the blocks between producer and readers,
+    no KL collection, inside the forward of the rewired net only.  Returns the link or None."""
+    from .. import fuse as _fuse
+    link = fz.get("sub_next")
+    if link is None or not _fuse.SUBSAMPLE or c16_in is not None or autograd.is_recording() or _fuse._collection is not None:
+        return None
+    if getattr(ops.StatArena._tls, "current", None) is None or len(xshape) != 4:
+        return None
+    for r in link["readers"]:
+        k = r._kwargs
+        if k["kernel"] != (1, 1) or k["stride"] != (2, 2) or k["pad"] != (0, 0) or getattr(r, "_fq_pw_fused", None) is None:
+            return None
+    if any(_hooked(b) for b in (block, fz.get("bn"), fz.get("act_block")) + tuple(link["readers"]) + tuple(link["via"])):
+        return None
+    for r in link["readers"]:                     # (a BatchNorm or activation folded into a reader is bypassed, not hooked)
+        rz = r._fq_pw_fused
+        if any(_hooked(b) for b in (rz.get("bn"), rz.get("act_block"))):
+            return None
+    if not ops.pwconv_sub2_supported(xshape[1], block._kwargs["num_filter"]):
+        return None
+    return link
+
+
+def _convolve(block, F, x, weight, bias):
+    """convert_conv2d.py:108 - the block's own convolution; of a subsampled trunk (`_fq_sub2`: this block is one of its
+    stride-2 1x1 readers) the stride-1 convolution of what was stored, which is the same values."""
+    if getattr(x, "_fq_sub2", None) is None:
+        return block.origin_forward(F, x, weight, bias)
+    out = F.Convolution(x, weight, bias, name="fwd", **dict(block._kwargs, stride=(1, 1)))
+    return out if block.act is None else block.act(out)
+
+
 _PLACEHOLDERS = {}
 
 
@@ -421,6 +457,8 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
     held = _pointwise_weight_codes(block, args, weight_raw, weight_q) if on_codes else None
     on_codes = held is not None
     c16_in = _handed_over(x)
+    # (one of the two readers of a subsampled trunk: the stored pixels are the ones this block's stride picks)
+    stride_ = 1 if getattr(x, "_fq_sub2", None) is not None else block._kwargs["stride"][0]
     if c16_in is None and on_codes and "in_thr" in plan:
         # the trunk of a ResNet arrives as fp32 (`x._t`, which the unit's shortcut reads) with this block's codes of the same
         # values beside it (`_fq_side`: the previous unit's closing 1x1 stored both, fq_pwconv_i8_c16_dual): read 1 B per element
@@ -448,7 +486,7 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
             res = getattr(block, "_fq_residual", None)
             extra = {}
             xshape = c16_in.shape if c16_in is not None else tuple(x._t.shape)
-            side_blk = None
+            side_blk = sub_link = None
             if res is not None and block._kwargs["stride"][0] == 1 and tuple(res["t"].shape[2:]) == tuple(xshape[2:]) \
                     and res["t"].shape[1] == block._kwargs["num_filter"]:
                 extra = dict(residual=res["t"])
@@ -458,6 +496,10 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                     a_ = side_blk.quantize_args
                     extra["side_codes"] = dict(thr=side_blk.input_max.data()._t, width=a_.in_width,
                                                flags=ops.act_flags(signed=a_.in_signed))
+                else:
+                    sub_link = sub_target(block, fz, c16_in, xshape)
+                    if sub_link is not None:
+                        extra["subsample"] = True
             # (a 1x1 convolution that READS codes writes codes too from 256 input channels up - the first 1x1 of a ResNet unit
             # fed by the trunk's code copy - and, on large planes, up to 32: MobileNetV2's 32 -> 16 and 16 -> 96 behind a first
             # convolution that hands its codes over; in between the both-sides instantiations are not built)
@@ -467,7 +509,7 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                 # alone on the GPU would prefer (fq_dwconv3x3_c16 102 us against 158 at 112x112 stride 2 and 49 against 61 at
                 # 56x56 stride 2, but 23 against 18 at 14x14 where the flat fp32 form is at its best) - profiles/r3_handover.txt
                 xs = c16_in.shape if c16_in is not None else tuple(x._t.shape)
-                s_ = block._kwargs["stride"][0]
+                s_ = stride_
                 fz["c16_pays"] = len(xs) == 4 and ((xs[2] - 1) // s_ + 1) * ((xs[3] - 1) // s_ + 1) >= _DW_C16_MIN_PIXELS
                 out_codes = handover_target(block)
                 if out_codes is not None and fz.get("via") is not None:
@@ -494,8 +536,13 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
             out = ops.pwconv_i8(x_arg, codes, scales, rowsum, None if bias is None else bias._t,
                                 bn_scale=scale, bn_shift=shift,
                                 act=res["act"] if "residual" in extra else fz["act"],
-                                stride=block._kwargs["stride"][0], **extra, **plan)
+                                stride=stride_, **extra, **plan)
             y, stat = out[0], out[1]
+            if sub_link is not None:
+                trunk = NDArray(y)
+                trunk._fq_stat = stat
+                trunk._fq_sub2 = {"hw": tuple(xshape[2:]), "readers": sub_link["readers"], "unit": sub_link["unit"]}
+                return trunk
             if side_blk is not None:
                 trunk = NDArray(y)
                 trunk._fq_stat = stat
@@ -511,8 +558,10 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                 if "in_stat" in plan:
                     ops.batch_mean(plan["in_stat"], out=plan["cur_out"])
                 xq = ops.fake_quant_offline(t, plan["in_thr"], plan["width"], plan["flags"], want_stat=False)[0]
-            x = NDArray(xq)
-        out = block.origin_forward(F, x, weight_q, bias)
+            xq_ = NDArray(xq)
+            xq_._fq_sub2 = x._fq_sub2
+            x = xq_
+        out = _convolve(block, F, x, weight_q, bias)
         from .. import fuse as _fuse
         res = getattr(block, "_fq_residual", None)
         if (res is not None and scale is not None and fz["act"] == "none" and res.get("owner") is not None and _fuse.BN_ADD
@@ -607,6 +656,10 @@ def _quantised_conv(self, F, x, weight, bias=None, input_max=None,
         terms = BatchNormTerms(gamma, beta, running_mean, running_var)
         weight, bias = terms.fold_weight(F, weight), terms.fold_bias(F, bias)
 
+    sub = getattr(x, "_fq_sub2", None)
+    if sub is not None and not any(self is r for r in sub["readers"]):
+        raise RuntimeError("a subsampled trunk (fq_pwconv_i8_sub2) reached a block that is not one of its two readers")
+
     deferred = getattr(x, "_fq_deferred", None)
     if deferred is not None and not (deferred["consumer"] is self and dw is not None and self.enable_quantize
                                      and args.quantize_input and self.quantize_input and not self.quantize_input_offline):
@@ -621,7 +674,10 @@ def _quantised_conv(self, F, x, weight, bias=None, input_max=None,
             if taken_over:
                 plan = fused_input_plan(self, x, input_max, flags, args.in_width)
             else:
-                x = fake_quant_block_input(self, x, input_max, flags, args.in_width)
+                xq = fake_quant_block_input(self, x, input_max, flags, args.in_width)
+                if sub is not None and xq is not x:
+                    xq._fq_sub2 = sub
+                x = xq
         if not frozen:                                                         # :68-99
             weight_q = _fake_quant_weight(self, args, weight)
 
@@ -637,7 +693,7 @@ def _quantised_conv(self, F, x, weight, bias=None, input_max=None,
         return depthwise_fused(self, x, weight_q, bias, plan)
     if pw is not None:
         return pointwise_fused(self, F, x, weight_raw, weight_q, bias, plan, bool(self.enable_quantize))
-    return self.origin_forward(F, x, weight_q, bias)                           # :108 — MIOpen through torch
+    return _convolve(self, F, x, weight_q, bias)                                # :108 — MIOpen through torch
 
 
 # ---- converter -----------------------------------------------------------------------------------------------------------------

@@ -166,6 +166,9 @@ BN_ADD = _os.environ.get("FQ_BN_ADD", "1") != "0"
 RECOMPUTE = _os.environ.get("FQ_RECOMPUTE", "1") != "0"
 RECOMPUTE_MIN_PIXELS = int(_os.environ.get("FQ_RECOMPUTE_MIN_PIXELS", "3136"))
 RECOMPUTE_MAX_CIN = int(_os.environ.get("FQ_RECOMPUTE_MAX_CIN", "128"))      # (input channels of the 1x1: see DESIGN.md for the pairs that pay)
+# Subsampled trunk (round 6, fq_pwconv_i8_sub2): the closing 1x1 of a ResNet-v1 stage stores only the pixels its two readers -
+# the next stage's first 1x1 and shortcut 1x1, both stride 2 without padding - look at (FQ_SUBSAMPLE=0: the whole tensor; A/B)
+SUBSAMPLE = _os.environ.get("FQ_SUBSAMPLE", "1") != "0"
 UNIT_LINKS = _os.environ.get("FQ_HANDOVER_UNITS", "1") != "0"      # hand-over from a MobileNetV2 unit without shortcut to the next block (A/B)
 
 
@@ -324,6 +327,9 @@ def _residual_unit_forward(self, x):
     if autograd.is_recording():
         raise RuntimeError("this net was rewired by quantize.fuse.fuse_inference (inference only): call "
                            "quantize.fuse.unfuse(net) before recording gradients")
+    sub = getattr(x, "_fq_sub2", None)
+    if sub is not None and sub["unit"] is not self:
+        raise RuntimeError("a subsampled trunk (fq_pwconv_i8_sub2) reached a unit it was not made for")
     shortcut = x if self.downsample is None else self.downsample(x)
     tail = _tail_conv(self.body)
     if tail is not None:
@@ -634,6 +640,18 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             if first._kwargs["kernel"] != (1, 1) or first._kwargs["stride"] not in ((1, 1), (2, 2)):
                 continue
             fa["side_next"] = first
+            # a stage boundary of the v1 bottleneck nets: BOTH readers of the trunk - `first` and the shortcut convolution - are
+            # 1x1 with stride 2 and no padding, so only a quarter of it is ever read (convert_conv2d.sub_target)
+            ds = v.downsample
+            ds_kids = list(ds._children.values()) if isinstance(ds, (nn.Sequential, nn.HybridSequential)) else []
+            sc = ds_kids[0] if ds_kids else None
+
+            def strided_1x1(c):
+                return (type(c) is nn.Conv2D and c._kwargs["kernel"] == (1, 1) and c._kwargs["stride"] == (2, 2)
+                        and c._kwargs["pad"] == (0, 0) and c._kwargs["num_group"] == 1
+                        and getattr(c, "_fq_pw_fused", None) is not None and c._fq_pw_fused.get("kind") == "1x1")
+            if ua and sc is not None and strided_1x1(first) and strided_1x1(sc) and hasattr(sc, "quantize_args"):
+                fa["sub_next"] = {"readers": (first, sc), "unit": v, "via": (u, v, a_, b_, ds)}
 
     def visit_unit_links(container):
         """MobileNetV2: a unit WITHOUT shortcut followed by another unit without shortcut (32 -> 16 then 16 -> 24: the 16-channel

@@ -11,8 +11,9 @@ rows = list(csv.DictReader(open(f)))
 with open(sys.argv[2], 'w') as out:
     for r in rows[:40]:
         n = r['Name']
-        n = re.sub(r'\(.*', '', n.replace('void (anonymous namespace)::', ''))
-        line = "%-60s calls %5s  avg %8.1f us  total %9.1f us  %5s %%" % (n[:60], r['Calls'], float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e3, r['Percentage'][:5])
+        n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+        n = re.sub(r'\((?:[^()]|\([^()]*\))*\)\s*(\[clone.*)?$', '', n)    # the argument list only
+        line = "%-76s calls %5s  avg %8.1f us  total %9.1f us  %5s %%" % (n[:76], r['Calls'], float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e3, r['Percentage'][:5])
         out.write(line + "\n")
 PY
 rm -rf $O/$TAG
