@@ -420,6 +420,15 @@ int fq_pwconv_i8_c16_dual(const void* x, const int8_t* wcodes, const float* wsca
                           const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
                           const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual,
                           const float* out_thr, int out_width, unsigned out_flags, void* ws, fqStream_t stream);
+/* ... of the LAST unit of a ResNet-v1 stage, whose two readers have stride 2 (see fq_pwconv_i8_sub2): both outputs hold the even
+ * pixels of the even rows only - y (n, cout, ceil(h/2), ceil(w/2)) fp32, y16 the C16 tensor of that shape; stat_out and `residual`
+ * cover the whole (n, cout, h, w) tensor.  cin_pad as above, cout > 128.                                                       */
+int fq_pwconv_i8_c16_dual_sub2(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                               float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                               const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                               float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                               const float* residual, const float* out_thr, int out_width, unsigned out_flags, void* ws,
+                               fqStream_t stream);
 
 /* Dense 3x3 convolution (stride 1, padding 1, no groups / dilation) on the integer codes: the same identity as
  * fq_pwconv_i8 with K = 9 * Cin, i.e. what the reference's fp32 F.Convolution of the two fake-quantised tensors computes

@@ -140,6 +140,12 @@ int fq_pwconv_i8_c16_dual_host(const void* x, const int8_t* wcodes, const float*
                                float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
                                const float* residual, const float* out_thr, int out_width, unsigned out_flags, void* ws,
                                fqStream_t stream);
+int fq_pwconv_i8_c16_dual_sub2_host(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                                    const float* bias, float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout,
+                                    int64_t h, int64_t w, const float* in_stat, const float* in_thr, int in_width,
+                                    unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
+                                    int act, float* stat_out, const float* residual, const float* out_thr, int out_width,
+                                    unsigned out_flags, void* ws, fqStream_t stream);
 int fq_conv3x3_i8_c16_host(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                            const float* bias, void* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
                            const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,

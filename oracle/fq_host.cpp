@@ -862,6 +862,27 @@ int fq_pwconv_i8_c16_dual_host(const void* x, const int8_t* wcodes, const float*
   return FQ_OK;
 }
 
+// ... both outputs subsampled: the whole fp32 output on the host, its even pixels of the even rows, and their codes
+int fq_pwconv_i8_c16_dual_sub2_host(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                                    const float* bias, float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout,
+                                    int64_t h, int64_t w, const float* in_stat, const float* in_thr, int in_width,
+                                    unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
+                                    int act, float* stat_out, const float* residual, const float* out_thr, int out_width,
+                                    unsigned out_flags, void* ws, fqStream_t stream) {
+  REQUIRE(y && y16 && out_thr && residual && in_thr, "fq_pwconv_i8_c16_dual_sub2_host: null pointer");
+  std::vector<float> full((size_t)(n * cout * h * w));
+  if (int rc = fq_pwconv_i8_c16_host(x, 1, wcodes, wscale, wsum, bias, full.data(), n, cin, cin_pad, cout, h, w, 1, in_stat,
+                                     in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual,
+                                     nullptr, 8, 0, ws, stream))
+    return rc;
+  const int64_t hs = (h + 1) / 2, ws_ = (w + 1) / 2;
+  for (int64_t pc = 0; pc < n * cout; ++pc)
+    for (int64_t r = 0; r < hs; ++r)
+      for (int64_t c = 0; c < ws_; ++c) y[(pc * hs + r) * ws_ + c] = full[(size_t)((pc * h + 2 * r) * w + 2 * c)];
+  c16_encode(y, n, cout, hs * ws_, out_thr, out_width, out_flags, (int8_t*)y16);
+  return FQ_OK;
+}
+
 int fq_conv3x3_i8_c16_host(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                            const float* bias, void* y, int64_t n, int64_t cin, int64_t cout, int64_t h, int64_t w,
                            const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,

@@ -89,6 +89,8 @@ EXPORTS = {
     # bn_shift, act, stat_out, residual, out_thr, out_width, out_flags, ws, stream
     "fq_pwconv_i8_c16_dual": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int,
                                      _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _uint, _vp, _vp]),
+    "fq_pwconv_i8_c16_dual_sub2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int,
+                                          _uint, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _uint, _vp, _vp]),
     "fq_conv3x3_i8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                              _vp, _int, _vp, _vp]),
     "fq_conv3x3_i8_c16": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp,

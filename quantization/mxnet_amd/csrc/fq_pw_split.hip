@@ -29,7 +29,8 @@ int pw_try_split(const PwCall& a, bool* taken) {
   // 64 -> 256 @56x56 + residual, ResNet-50's largest kernel: 207.5 us against 183.7 here)
   static const int res_split = env_int("FQ_PWS_RES_SPLIT", 1);
   bool want = a.form == 6 || a.stride != 1 || c16 || a.sub;             // (only this form reads strided inputs)
-  if (a.sub) shape_ok = shape_ok && pw_split_sub_shape_ok(a.cin_pad, a.cout) && !c16 && a.stride == 1;
+  // (a subsampled output: fp32 in and out, or - the dual form - codes in, fp32 out and its code copy, both subsampled)
+  if (a.sub) shape_ok = shape_ok && pw_split_sub_shape_ok(a.cin_pad, a.cout) && a.stride == 1 && (!c16 || a.y16 != nullptr);
   if (a.form == 0 && shape_ok && a.stride == 1 && !a.sub)
     want = mode == 2 || (mode == 1 && (tiles <= (int64_t)num_cu() * 16 || !pw_stream_shape_ok(a) ||
                                        (res_split && a.residual != nullptr && a.cin <= 64)));
@@ -75,7 +76,7 @@ int pw_try_split(const PwCall& a, bool* taken) {
     const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;               // second half of fq_weight_codes' buffer
     if (int rc = pw_zero_stat(a)) return rc;
     bool launched = false;
-    if (a.sub) {
+    if (a.sub && !c16) {
       if (int rc = pw_split_sub_launch(a, &t, kt, grid, ldst, wfrag, &launched)) return rc;
       FQ_REQUIRE(launched, "fq_pwconv_i8_sub2: no instantiation for K/32=%d", kt);
       FQ_LAUNCH_CHECK();

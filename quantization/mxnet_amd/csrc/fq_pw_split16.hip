@@ -10,17 +10,18 @@ namespace fqi {
 int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t grid, size_t lds, const int8_t* wfrag,
                       bool* launched) {
   const PwSplitGeom& t = *static_cast<const PwSplitGeom*>(geom);
-  const bool in16 = a.in_c16, out16 = a.out_thr != nullptr, dual = a.y16 != nullptr;
+  const bool in16 = a.in_c16, out16 = a.out_thr != nullptr, dual = a.y16 != nullptr, sub = a.sub;
   FQ_REQUIRE(!(in16 && out16) || kt >= 8, "fq_pwconv_i8_c16: codes in AND codes out is built for 256 input channels and more");
   FQ_REQUIRE(!in16 || a.in_thr != nullptr, "fq_pwconv_i8_c16: a C16 input was quantised with a stored threshold: give in_thr");
 #define FQ_PWS16_CASE(KT_, CW_, D_, IN_, OUT_) FQ_PWS16_CASE_D(KT_, CW_, D_, 4, IN_, OUT_, false)
-#define FQ_PWS16_CASE_D(KT_, CW_, D_, LB_, IN_, OUT_, DUAL_)                                                           \
-  if (kt == KT_ && cw == CW_ && in16 == IN_ && out16 == OUT_ && dual == DUAL_) {                                       \
+#define FQ_PWS16_CASE_D(KT_, CW_, D_, LB_, IN_, OUT_, DUAL_) FQ_PWS16_CASE_S(KT_, CW_, D_, LB_, IN_, OUT_, DUAL_, false)
+#define FQ_PWS16_CASE_S(KT_, CW_, D_, LB_, IN_, OUT_, DUAL_, SUB_)                                                     \
+  if (kt == KT_ && cw == CW_ && in16 == IN_ && out16 == OUT_ && dual == DUAL_ && sub == SUB_) {                        \
     static const bool attr_ok =                                                                                        \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_split_kernel<KT_, CW_, D_, LB_, 4, IN_, OUT_, DUAL_>), \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_split_kernel<KT_, CW_, D_, LB_, 4, IN_, OUT_, DUAL_, SUB_>), \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;                      \
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8_c16: cannot raise the dynamic LDS limit of the split kernel");                   \
-    hipLaunchKernelGGL((pwconv_split_kernel<KT_, CW_, D_, LB_, 4, IN_, OUT_, DUAL_>), dim3((unsigned)grid), dim3(256), lds, a.st, \
+    hipLaunchKernelGGL((pwconv_split_kernel<KT_, CW_, D_, LB_, 4, IN_, OUT_, DUAL_, SUB_>), dim3((unsigned)grid), dim3(256), lds, a.st, \
                        a.x, wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, \
                        a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out, a.residual,       \
                        a.out_thr);                                                                                     \
@@ -45,6 +46,12 @@ int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t
   FQ_PWS16_CASE_D(KT_, 2, (KT_ < FQ_PWS16_DUAL_D ? KT_ : FQ_PWS16_DUAL_D), FQ_PWS16_DUAL_LB, true, false, true)
   FQ_PWS16_DUAL(2) FQ_PWS16_DUAL(4) FQ_PWS16_DUAL(8) FQ_PWS16_DUAL(16)
 #undef FQ_PWS16_DUAL
+  // ... both outputs subsampled (fq_pwconv_i8_c16_dual_sub2: the last unit of a ResNet-v1 stage, two channel tiles per wavefront)
+#define FQ_PWS16_DUAL_SUB(KT_) \
+  FQ_PWS16_CASE_S(KT_, 2, (KT_ < FQ_PWS16_DUAL_D ? KT_ : FQ_PWS16_DUAL_D), FQ_PWS16_DUAL_LB, true, false, true, true)
+  FQ_PWS16_DUAL_SUB(2) FQ_PWS16_DUAL_SUB(4) FQ_PWS16_DUAL_SUB(8) FQ_PWS16_DUAL_SUB(16)
+#undef FQ_PWS16_DUAL_SUB
+#undef FQ_PWS16_CASE_S
 #undef FQ_PWS16_CASE_D
 #undef FQ_PWS16_KT
 #undef FQ_PWS16_CASE

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
     float* __restrict__ stat_out, const float* __restrict__ residual, const float* __restrict__ out_thr) {
-  static_assert(!SUB || !(IN16 || OUT16 || DUAL), "the subsampled output is built for fp32 tensors on both sides");
+  static_assert(!SUB || !OUT16, "the subsampled output is built for fp32 output (DUAL: and its code copy)");
   constexpr int kSlots = 8;
   constexpr int SLABS = (KT + NW - 1) / NW;                             // slabs a wavefront quantises (kt = wave + NW j < KT)
   constexpr int RB = SLABS < 4 ? SLABS : 4;                             // slabs (16 loads each) in flight per lane
@@ -271,14 +271,16 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
     int64_t ys_bytes = (n_samp - s_base) * y_samp_s - (int64_t)(ch0 + ctl0 * 32) * plane4s;
     ys_bytes = ys_bytes < 0x7FFFFFFFll ? ys_bytes : 0x7FFFFFFFll;
     // OUT16: y is a C16 code tensor; the resource starts at (first sample, this wavefront's first 16-channel block)
-    const int64_t y_samp16 = (int64_t)g.CBo * HW * 16;
+    // (SUB + DUAL: the code copy holds the stored pixels only, as y does)
+    const unsigned HWo = SUB ? (unsigned)g.SHWs : HW;                      // pixels of a stored plane
+    const int64_t y_samp16 = (int64_t)g.CBo * HWo * 16;
     const int cb0 = (ch0 + ctl0 * 32) >> 4;                               // first output block of this wavefront
-    int64_t y16_bytes = (n_samp - s_base) * y_samp16 - (int64_t)cb0 * HW * 16;
+    int64_t y16_bytes = (n_samp - s_base) * y_samp16 - (int64_t)cb0 * HWo * 16;
     y16_bytes = y16_bytes < 0x7FFFFFFFll ? y16_bytes : 0x7FFFFFFFll;
-    const fq_rsrc yr = OUT16 ? make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp16 + (int64_t)cb0 * HW * 16, y16_bytes)
+    const fq_rsrc yr = OUT16 ? make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp16 + (int64_t)cb0 * HWo * 16, y16_bytes)
                              : make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp_s + (int64_t)(ch0 + ctl0 * 32) * plane4s, ys_bytes);
-    const unsigned yo16 = (smp - s_base) * (unsigned)g.CBo * HW * 16u + p * 16u + 4u * h;
-    const fq_rsrc yr16 = make_rsrc(DUAL ? g.y16 + s_base * y_samp16 + (int64_t)cb0 * HW * 16 : reinterpret_cast<char*>(y),
+    unsigned yo16 = (smp - s_base) * (unsigned)g.CBo * HWo * 16u + p * 16u + 4u * h;
+    const fq_rsrc yr16 = make_rsrc(DUAL ? g.y16 + s_base * y_samp16 + (int64_t)cb0 * HWo * 16 : reinterpret_cast<char*>(y),
                                    DUAL ? y16_bytes : 0);
     const int ubias2 = 128 - g.out_zoff;
     // the residual operand (the shortcut of a ResNet / MobileNetV2 unit) has y's shape: same offsets, added after BatchNorm
@@ -291,6 +293,8 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
       const unsigned ho = p / (unsigned)g.SW, wo = p - ho * (unsigned)g.SW;
       yos = ((ho | wo) & 1u) ? 0x80000000u
                              : ((smp - s_base) * (unsigned)g.Cout + 4u * h) * plane4s + ((ho >> 1) * (unsigned)g.SWs + (wo >> 1)) * 4u;
+      yo16 = ((ho | wo) & 1u) ? 0x80000000u
+                              : (smp - s_base) * (unsigned)g.CBo * HWo * 16u + ((ho >> 1) * (unsigned)g.SWs + (wo >> 1)) * 16u + 4u * h;
     }
     float m = 0.0f;
     auto store_tile = [&](int c, int cv, auto masked_c) __attribute__((always_inline)) {
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, LB) void pwconv_split_kernel(
                                   : fq_pack4<NN2>(vq[0], vq[1], vq[2], vq[3], qc, ubias2, fq_nonneg_xor(ubias2));
           const bool blk_ok = !MASKED || 16 * (gq >> 1) < cv;             // a whole block past Cout does not exist
           buf_st_f32(OUT16 ? yr : yr16, blk_ok ? yo16 : 0x80000000u,
-                     (unsigned)((c * 2 + (gq >> 1)) * (int)HW * 16 + 8 * (gq & 1)), __int_as_float(packed));
+                     (unsigned)((c * 2 + (gq >> 1)) * (int)HWo * 16 + 8 * (gq & 1)), __int_as_float(packed));
         }
       }
     };

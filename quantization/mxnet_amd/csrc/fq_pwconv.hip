@@ -173,7 +173,8 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   const double stored = sub ? (double)n * cout * ((h_in + 1) / 2) * ((w_in + 1) / 2) : out_elems;
   const double moved = (in_c16 ? (double)n * ((cin + 15) / 16 * 16) * hw : 4.0 * in_elems) +
                        (c.out_thr != nullptr ? (double)n * ((cout + 15) / 16 * 16) * hw : 4.0 * stored) +
-                       (y16 != nullptr ? (double)n * ((cout + 15) / 16 * 16) * hw : 0.0) + (residual ? 4.0 * out_elems : 0.0);
+                       (y16 != nullptr ? (double)n * ((cout + 15) / 16 * 16) * (sub ? stored / ((double)n * cout) : (double)hw) : 0.0) +
+                       (residual ? 4.0 * out_elems : 0.0);
   ProfScope prof(hw == 1 ? FQ_KERNEL_DENSE : FQ_KERNEL_PWCONV, 4.0 * (in_elems + (residual ? 2.0 : 1.0) * out_elems), c.st, moved);
   bool taken = false;
   out_thr = c.out_thr;                                  // (from here on: "y is a C16 tensor")
@@ -324,11 +325,11 @@ int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const fl
                          residual, ws, stream, x_is_c16 != 0, out_thr, out_width, out_flags);
 }
 
-int fq_pwconv_i8_c16_dual(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
-                          float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
-                          const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
-                          const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual,
-                          const float* out_thr, int out_width, unsigned out_flags, void* ws, fqStream_t stream) {
+static int pwconv_dual(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                       float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                       const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                       const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual,
+                       const float* out_thr, int out_width, unsigned out_flags, void* ws, fqStream_t stream, bool sub) {
   FQ_REQUIRE(h > 0 && w > 0, "fq_pwconv_i8_c16_dual: bad plane %lld x %lld", (long long)h, (long long)w);
   FQ_REQUIRE(y16 != nullptr && out_thr != nullptr && residual != nullptr && in_thr != nullptr,
              "fq_pwconv_i8_c16_dual: null pointer (y16, out_thr, residual, in_thr: the closing 1x1 of a residual unit, C16 in)");
@@ -339,9 +340,31 @@ int fq_pwconv_i8_c16_dual(const void* x, const int8_t* wcodes, const float* wsca
   const int64_t cbi = (cin + 15) / 16, cbo = (cout + 15) / 16;
   FQ_REQUIRE((32 / (h * w) + 2) * cbi * h * w * 16 < (1ll << 31) && (32 / (h * w) + 2) * cbo * h * w * 16 < (1ll << 31),
              "fq_pwconv_i8_c16_dual: plane too large");
+  FQ_REQUIRE(!sub || pw_split_sub_shape_ok(cin_pad, cout), "fq_pwconv_i8_c16_dual_sub2: more than 128 output channels");
   return pwconv_dispatch((const float*)x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, h * w, 1, h, w, w, in_stat,
                          in_thr, in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, ws, stream,
-                         true, out_thr, out_width, out_flags, nullptr, nullptr, nullptr, nullptr, y16);
+                         true, out_thr, out_width, out_flags, nullptr, nullptr, nullptr, nullptr, y16, sub);
+}
+
+int fq_pwconv_i8_c16_dual(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                          float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                          const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                          const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual,
+                          const float* out_thr, int out_width, unsigned out_flags, void* ws, fqStream_t stream) {
+  return pwconv_dual(x, wcodes, wscale, wsum, bias, y, y16, n, cin, cin_pad, cout, h, w, in_stat, in_thr, in_width, in_flags,
+                     out_current_max, bn_scale, bn_shift, act, stat_out, residual, out_thr, out_width, out_flags, ws, stream, false);
+}
+
+// fq_pwconv_i8_c16_dual with BOTH outputs subsampled as fq_pwconv_i8_sub2 stores y: y is (n, cout, ceil(h/2), ceil(w/2)) fp32 and
+// y16 the C16 code tensor of that shape; statistic and residual operand over the whole planes.
+int fq_pwconv_i8_c16_dual_sub2(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                               float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
+                               const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                               float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                               const float* residual, const float* out_thr, int out_width, unsigned out_flags, void* ws,
+                               fqStream_t stream) {
+  return pwconv_dual(x, wcodes, wscale, wsum, bias, y, y16, n, cin, cin_pad, cout, h, w, in_stat, in_thr, in_width, in_flags,
+                     out_current_max, bn_scale, bn_shift, act, stat_out, residual, out_thr, out_width, out_flags, ws, stream, true);
 }
 
 }  // extern "C"

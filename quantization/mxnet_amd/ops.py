@@ -802,8 +802,9 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     whole planes."""
     in16 = isinstance(x, Codes16)
     if subsample:
-        if in16 or out_codes is not None or side_codes is not None or stride != 1 or x.dim() != 4:
-            raise ValueError("subsample=True goes with fp32 (N, Cin, H, W) activations, stride 1 and fp32 output")
+        if (in16 and side_codes is None) or out_codes is not None or stride != 1 or len(x.shape) != 4:
+            raise ValueError("subsample=True goes with (N, Cin, H, W) activations, stride 1 and fp32 output (codes in: with "
+                             "side_codes, fq_pwconv_i8_c16_dual_sub2)")
         if not pwconv_sub2_supported(x.shape[1], wscale.numel()):
             raise ValueError("subsample=True: %d -> %d channels is not a shape fq_pwconv_i8_sub2 takes" % (x.shape[1], wscale.numel()))
     if in16:
@@ -835,13 +836,14 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
         if not in16 or residual is None or stride != 1 or out_codes is not None or len(xs) != 4:
             raise ValueError("side_codes goes with a Codes16 input, a residual operand, stride 1 and fp32 output")
         h, w = xs[2], xs[3]
-        y = torch.empty((n, cout, h, w), dtype=torch.float32, device=dev)
-        if tuple(residual.shape) != tuple(y.shape):
-            raise ValueError("the residual must have the output's shape %s, got %s" % (tuple(y.shape), tuple(residual.shape)))
+        hs, ws_ = ((h + 1) // 2, (w + 1) // 2) if subsample else (h, w)
+        y = torch.empty((n, cout, hs, ws_), dtype=torch.float32, device=dev)
+        if tuple(residual.shape) != (n, cout, h, w):
+            raise ValueError("the residual must have the whole output's shape %s, got %s" % ((n, cout, h, w), tuple(residual.shape)))
         sthr = _check(side_codes["thr"], "side_codes['thr']")
-        y16 = Codes16.empty((n, cout, h, w), dev, sthr, side_codes.get("width", 8), side_codes.get("flags", 0))
+        y16 = Codes16.empty((n, cout, hs, ws_), dev, sthr, side_codes.get("width", 8), side_codes.get("flags", 0))
         ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, h * w), dtype=torch.uint8, device=dev)
-        check_call(_lib_().fq_pwconv_i8_c16_dual(_ptr(x.t), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y),
+        check_call((_lib_().fq_pwconv_i8_c16_dual_sub2 if subsample else _lib_().fq_pwconv_i8_c16_dual)(_ptr(x.t), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y),
                                                  _ptr(y16.t), n, cin, cin_pad, cout, h, w, _ptr(in_stat), _ptr(in_thr),
                                                  int(width), int(flags), _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift),
                                                  _ACTS[act] | zflag, _ptr(stat), _ptr(residual), _ptr(sthr), int(y16.width),

@@ -312,7 +312,7 @@ def side_target(block, c16_in):
     return nxt
 
 
-def sub_target(block, fz, c16_in, xshape):
+def sub_target(block, fz, xshape):
     """The link to the two readers of this closing 1x1 convolution's output (quantize/fuse.py: `sub_next`, a stage boundary of
     the v1 bottleneck ResNets) when it may store only what they read: each is a 1x1 convolution with stride 2 and no padding
     (convert_conv2d.py:108 with the block's own kwargs), i.e. it looks at y[:, :, ::2, ::2] and at the statistic of y, which this
@@ -320,7 +320,7 @@ def sub_target(block, fz, c16_in, xshape):
     no KL collection, inside the forward of the rewired net only.  Returns the link or None."""
     from .. import fuse as _fuse
     link = fz.get("sub_next")
-    if link is None or not _fuse.SUBSAMPLE or c16_in is not None or autograd.is_recording() or _fuse._collection is not None:
+    if link is None or not _fuse.SUBSAMPLE or autograd.is_recording() or _fuse._collection is not None:
         return None
     if getattr(ops.StatArena._tls, "current", None) is None or len(xshape) != 4:
         return None
@@ -496,8 +496,9 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                     a_ = side_blk.quantize_args
                     extra["side_codes"] = dict(thr=side_blk.input_max.data()._t, width=a_.in_width,
                                                flags=ops.act_flags(signed=a_.in_signed))
-                else:
-                    sub_link = sub_target(block, fz, c16_in, xshape)
+                # (fp32 in and out, or codes in with both outputs of the dual form)
+                if side_blk is not None or c16_in is None:
+                    sub_link = sub_target(block, fz, xshape)
                     if sub_link is not None:
                         extra["subsample"] = True
             # (a 1x1 convolution that READS codes writes codes too from 256 input channels up - the first 1x1 of a ResNet unit
@@ -538,7 +539,7 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                                 act=res["act"] if "residual" in extra else fz["act"],
                                 stride=stride_, **extra, **plan)
             y, stat = out[0], out[1]
-            if sub_link is not None:
+            if sub_link is not None and side_blk is None:
                 trunk = NDArray(y)
                 trunk._fq_stat = stat
                 trunk._fq_sub2 = {"hw": tuple(xshape[2:]), "readers": sub_link["readers"], "unit": sub_link["unit"]}
@@ -547,6 +548,8 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                 trunk = NDArray(y)
                 trunk._fq_stat = stat
                 trunk._fq_side = (side_blk, out[2])
+                if sub_link is not None:
+                    trunk._fq_sub2 = {"hw": tuple(xshape[2:]), "readers": sub_link["readers"], "unit": sub_link["unit"]}
                 return trunk
     else:
         if plan:          # input is to be quantised but the integer path does not apply: explicit apply pass

@@ -200,3 +200,95 @@ def test_a_hook_between_producer_and_readers_keeps_the_whole_trunk_and_a_stray_r
     fake._fq_sub2 = {"hw": (28, 28), "readers": (first,), "unit": None}
     with pytest.raises(RuntimeError, match="not one of its two readers"):
         other(fake)
+
+
+DUAL_CASES = [(3, 64, 256, 56, 56), (3, 128, 512, 28, 28), (5, 256, 1024, 14, 14), (3, 64, 256, 9, 11), (9, 512, 2048, 7, 7)]
+
+
+@pytest.mark.parametrize("case", DUAL_CASES, ids=["%dx%d->%d@%dx%d" % c for c in DUAL_CASES])
+def test_dual_sub2_stores_both_outputs_subsampled(dev, ops, case):
+    """fq_pwconv_i8_c16_dual_sub2: codes in, residual added; the fp32 output and its code copy hold y[:, :, ::2, ::2] of what
+    fq_pwconv_i8_c16_dual stores - same statistic - and agree with the host twin."""
+    from oracle import fq_oracle as O
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + 31)
+    x = np.maximum(rng.standard_normal((n, cin, h, w)) * 2, 0).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 1, 1)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.3, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    res = (rng.standard_normal((n, cout, h, w)) * 2).astype(np.float32)
+    res[n - 1, 3, h - 1 - (h % 2), 1] = np.float32(88.0)            # a maximum on an odd column
+    codes, scales, rowsum = ops.weight_codes(_t(wt, dev), 1, 8)
+    thr, thr2 = np.float32(2.3), np.float32(3.1)
+    thr_t = _t(np.float32([thr]), dev)
+    stat_in = _t(O.absmax_per_sample(x), dev)
+    cx = O.ste_codes(x, O.act_scale(thr, False, 8), thr, np.float32(0))
+    xc = ops.Codes16(_t(O.to_c16(cx.astype(np.int64), 128), dev), x.shape, thr_t, 8, 0)
+    cur_a, cur_b = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    kw = dict(in_thr=thr_t, width=8, flags=0, bn_scale=_t(sc, dev), bn_shift=_t(sh, dev), act="relu", in_stat=stat_in,
+              residual=_t(res, dev))
+    side_kw = dict(thr=_t(np.float32([thr2]), dev), width=8, flags=0)
+    want, want_stat, want_side = ops.pwconv_i8(xc, codes, scales, rowsum, cur_out=cur_a, side_codes=side_kw, **kw)
+    got, got_stat, side = ops.pwconv_i8(xc, codes, scales, rowsum, cur_out=cur_b, side_codes=side_kw, subsample=True, **kw)
+    hs, ws = (h + 1) // 2, (w + 1) // 2
+    assert tuple(got.shape) == (n, cout, hs, ws) and side.shape == (n, cout, hs, ws)
+    _eq(N(got), N(want)[:, :, ::2, ::2], "fp32 output")
+    _eq(N(got_stat), N(want_stat), "statistic")
+    _eq(N(cur_a), N(cur_b), "current_input_max")
+    full16 = N(want_side.t).reshape(n, cout // 16, h, w, 16)
+    _eq(N(side.t).reshape(n, cout // 16, hs, ws, 16), full16[:, :, ::2, ::2], "code copy")
+    if h > 1:
+        assert N(got_stat)[n - 1] >= 80.0
+
+
+def test_resnet50_offline_with_subsampled_stage_boundaries_equals_the_same_net_without(dev, ops):
+    """Offline thresholds: the last unit of a stage stores trunk and code copy subsampled (fq_pwconv_i8_c16_dual_sub2), the two
+    readers take the codes (or the fp32 quarter) with stride 1: logits and every block's current_input_max bit-equal."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.quantize import fuse
+    from test_gpu_net import _build
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        rng = np.random.default_rng(8)
+        xs = [mx.nd.array(rng.standard_normal((4, 3, 224, 224)).astype(np.float32), ctx=mx.gpu(0)) for _ in range(3)]
+        outs = {}
+        for on in (False, True):
+            net = _build("resnet50_v1", 1000, mx.gpu(0), quant_type="channel")
+            net.quantize_input(enable=True, online=True)
+            for x in xs[:2]:
+                net(x)
+                net.update_ema()
+            net.fix_params()
+            net.quantize_input(enable=True, online=False)
+            net(xs[2])
+            fuse.fuse_inference(net)
+            old = fuse.SUBSAMPLE
+            fuse.SUBSAMPLE = on
+            seen, readers = [], []
+            real = ops.pwconv_i8
+
+            def spy(*a, **k):
+                if k.get("subsample"):
+                    seen.append((tuple(a[0].shape), k.get("side_codes") is not None))
+                elif isinstance(a[0], ops.Codes16) and a[0].shape[1] in (256, 512, 1024) and a[0].shape[2] in (28, 14, 7) \
+                        and a[0].shape[1] * a[0].shape[2] == 7168:
+                    readers.append(tuple(a[0].shape))                # (256 @28x28, 512 @14x14, 1024 @7x7: a stage's input)
+                return real(*a, **k)
+            ops.pwconv_i8 = spy
+            try:
+                out = net(xs[2])
+                cur = np.asarray([float(b.current_input_max) for b in net.collect_quantized_blocks()], np.float32)
+            finally:
+                fuse.SUBSAMPLE = old
+                ops.pwconv_i8 = real
+            outs[on] = (N(out._t), cur, seen, readers)
+        assert len(outs[False][2]) == 0 and len(outs[True][2]) == 3, outs[True][2]
+        # both readers of every boundary take the subsampled code copy with stride 1 (256 @28x28, 512 @14x14, 1024 @7x7 are the
+        # shapes of no other code tensor a 1x1 of this net reads)
+        assert len(outs[True][3]) == 6 and len(outs[False][3]) == 0, outs[True][3]
+        assert all(dual for _, dual in outs[True][2]), outs[True][2]          # (codes in, both outputs: the dual form)
+        _eq(outs[True][0], outs[False][0], "logits")
+        _eq(outs[True][1], outs[False][1], "current_input_max of every block")
+    finally:
+        torch.backends.cudnn.deterministic = was
