@@ -86,6 +86,9 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
 #ifndef FQ_PWSMP_PF
 #define FQ_PWSMP_PF 4
 #endif
+#ifndef FQ_PWSMP_RA
+#define FQ_PWSMP_RA 2                  // groups of residual values in flight (two channel tiles x four pixel tiles: 2 x 16 registers)
+#endif
   // chunks requested ahead (8 registers each); fewer with one channel tile per wavefront, which then fits 128 registers
   // = TWO workgroups per CU, whose load and store phases overlap (256 -> 256 @28x28 43.9 -> 39.3 us; K / 32 >= 16 only fits
   // them with two chunks ahead)
@@ -271,6 +274,29 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
     const bool last_ok = 32u * (PT - 1) + (unsigned)pl < inpix[item];
     const unsigned po0 = (unsigned)(4 * h) * plane4 + (ipix0[item] + (unsigned)pl) * 4u;
     const unsigned po_last = last_ok ? po0 + 32u * (PT - 1) * 4u : 0x80000000u;
+    // the residual operand: the 4 x PT values of RA groups of four channels are in flight ahead of the group that is being
+    // stored.  (Through round 5 each group asked for its values right before using them - and, a buffer store being something the
+    // compiler may not move a buffer load across, behind the previous group's stores: 4 CTW exposed memory latencies per item with
+    // one or two wavefronts per SIMD to hide them.  RA = 2: what fits beside the 128 accumulators without spilling - ResNet-50
+    // online +1.3 % images/s; 3: +1.2 % with 20 bytes of scratch; 4 and 6 spill 156 / 308 bytes: -4.8 / -5.0 %,
+    // profiles/r6_sample_residual_ab.txt.  Whole planes of 49 pixels - two pixel tiles - hold all eight groups.)
+    constexpr int NG = CTW * 4;                                         // groups of four channels per wavefront
+    constexpr int RA = !RES ? 1 : (16 * PT * NG <= 64 ? NG : (PT == 4 ? FQ_PWSMP_RA : NG));
+    float resv[RES ? RA * 4 * PT : 1];
+    auto res_issue = [&](int g_) __attribute__((always_inline)) {
+      const int c = g_ / 4, gq = g_ % 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+          resv[RES ? ((g_ % RA) * 4 + r) * PT + pt : 0] =
+              buf_ld_f32(rr, pt == PT - 1 ? po_last : po0 + 32u * pt * 4u, (unsigned)(c * 32 + 8 * gq + r) * plane4);
+    };
+    if (RES) {
+#pragma unroll
+      for (int g_ = 0; g_ < RA && g_ < NG; ++g_) res_issue(g_);
+      FQ_PIN();
+    }
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
       const int cb = (ctl0 + c) * 32 + 4 * h;
@@ -283,13 +309,9 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
         const f4 bch = *reinterpret_cast<const f4*>(c_bias + c0);
         float res[RES ? 4 * PT : 1];
-        if (RES) {                                 // the 4 x PT values of this group in flight before the first use
+        if (RES) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt)
-              res[RES ? r * PT + pt : 0] = buf_ld_f32(rr, pt == PT - 1 ? po_last : po0 + 32u * pt * 4u,
-                                                     (unsigned)(c * 32 + 8 * gq + r) * plane4);
+          for (int i = 0; i < 4 * PT; ++i) res[i] = resv[((c * 4 + gq) % RA) * 4 * PT + i];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -330,6 +352,11 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
               m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
             }
           }
+        }
+        if (RES && c * 4 + gq + RA < NG) {
+          FQ_PIN();
+          res_issue(c * 4 + gq + RA);
+          FQ_PIN();
         }
       }
     }
