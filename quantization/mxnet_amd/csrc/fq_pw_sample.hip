@@ -36,6 +36,22 @@ constexpr int kSmpPanelWords = 2 * 128 * 4;             // 2 channel halves x 12
 #define FQ_PWSMP_LB4 1
 #endif
 
+#ifndef FQ_PWSMP_RESLDS
+#define FQ_PWSMP_RESLDS 1    // A/B builds: 0 = the residual operand through registers on every shape
+#endif
+// one LDS-DMA wave-instruction (fq_pw_pipe.hip, tools/ldsdma_probe.hip): lane l's 16 bytes at (rsrc base + voff + soff) land at LDS
+// byte address lds_base + 16 l; a lane whose offset is out of the resource's range gets zeros
+__device__ __forceinline__ void smp_dma16(v4i rsrc, unsigned voff, unsigned soff, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void smp_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 struct PwSampleGeom {
   int Cin, Cout, CS;         // CS: channel groups of 256 * CTW
   int CTM;                   // 32-channel tiles present in the weight buffer
@@ -70,6 +86,10 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
   // per SIMD exposes every latency of the set-up and the epilogue - 4.7 + 8.4 us instead of 3.7 + 5.1.)
   constexpr int NW = 8;
   constexpr int NCH = NW * CTW * 32;                                    // output channels of one workgroup (256 or 512)
+  // RL: the residual operand arrives by LDS-DMA (two channel tiles x four pixel tiles only: 128 accumulator registers leave room
+  // for two groups of residual values, i.e. four exposed memory latencies per item - see the epilogue)
+  constexpr bool RL = RES && PT == 4 && CTW == 2 && NI == 1 && FQ_PWSMP_RESLDS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smp_dyn[];   // RL: 8 x 16 KB, [wavefront][32 channels][128 pixels]
   constexpr int KS = 4 / PT;                                            // K-steps of 32 channels per chunk
   constexpr int KI = KT / KS;                                           // chunks per item
   constexpr int TI = NI * KI;                                           // chunk iterations of the workgroup
@@ -145,6 +165,28 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
     const unsigned off = kq * 2u * plane4 + (pix0 + pq * 4u) * 4u;
     xo[i] = (pq < inq[i] && !rag_lane) ? off : 0x80000000u;
     if (i == 0 && pq < inq[i] && rag_lane) xo1 = off;
+  }
+  // RL: channel tile 0 of this wavefront's residual values - 32 channels x 128 pixels, 16 KB - is requested NOW, into LDS, and is
+  // there long before the epilogue; instruction i brings channels 2 i and 2 i + 1 (lane: channel 2 i + (lane >> 5), four pixels from
+  // 4 (lane & 31) on; pixel groups past the block's end are out of range: zeros, never stored)
+  const int64_t res_bytes = (int64_t)g.Cout * plane4 - (int64_t)(ch0 + (int)wave * CTW * 32) * plane4;
+  const fq_rsrc rr = make_rsrc(reinterpret_cast<const char*>(RES ? residual : x) +
+                                   (RES ? ((int64_t)smp * g.Cout + ch0 + (int)wave * CTW * 32) * plane4 : 0), RES ? res_bytes : 0);
+  v4i rrd;                                                              // (the same descriptor as four scalars, for the asm statement)
+  {
+    const unsigned long long rb = (unsigned long long)(size_t)(RES ? residual : x) +
+                                  (unsigned long long)(RES ? ((int64_t)smp * g.Cout + ch0 + (int)wave * CTW * 32) * plane4 : 0);
+    rrd[0] = __builtin_amdgcn_readfirstlane((int)(rb & 0xFFFFFFFFull));
+    rrd[1] = __builtin_amdgcn_readfirstlane((int)(rb >> 32));
+    rrd[2] = __builtin_amdgcn_readfirstlane((int)(res_bytes > 0x7FFFFFFFll ? 0x7FFFFFFF : (RES ? res_bytes : 0)));
+    rrd[3] = 0x00020000;
+  }
+  const unsigned rl_base = __builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)smp_dyn + 16384u * (unsigned)wave));
+  const unsigned rl_voff = (((unsigned)lane & 31u) < inq[0]) ? ((unsigned)lane >> 5) * plane4 + (ipix0[0] + 4u * ((unsigned)lane & 31u)) * 4u
+                                                           : 0x80000000u;
+  if (RL) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) smp_dma16(rrd, rl_voff, (unsigned)(2 * i) * plane4, rl_base + 1024u * i);
   }
   struct Chunk {
     f4 v[2];
@@ -267,8 +309,6 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
     constexpr bool FAST = decltype(fast_c)::value;                      // BatchNorm + ReLU, no bias: fixed at compile time
     const int64_t y_bytes = (int64_t)g.Cout * plane4 - (int64_t)(ch0 + ctl0 * 32) * plane4;
     const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + ((int64_t)smp * g.Cout + ch0 + ctl0 * 32) * plane4, y_bytes);
-    const fq_rsrc rr = make_rsrc(reinterpret_cast<const char*>(RES ? residual : y) + ((int64_t)smp * g.Cout + ch0 + ctl0 * 32) * plane4,
-                                 RES ? y_bytes : 0);
     // channel tiles are whole (host: Cout % NCH == 0); only the LAST pixel tile of an item has pixels past its end (offset out
     // of range: the store is dropped) - the others take no mask at all
     const bool last_ok = 32u * (PT - 1) + (unsigned)pl < inpix[item];
@@ -280,8 +320,13 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
     // one or two wavefronts per SIMD to hide them.  RA = 2: what fits beside the 128 accumulators without spilling - ResNet-50
     // online +1.3 % images/s; 3: +1.2 % with 20 bytes of scratch; 4 and 6 spill 156 / 308 bytes: -4.8 / -5.0 %,
     // profiles/r6_sample_residual_ab.txt.  Whole planes of 49 pixels - two pixel tiles - hold all eight groups.)
+    // RL (two channel tiles x four pixel tiles): no registers at all.  Channel tile 0 has been in LDS since the prologue; as soon as
+    // a group of it (8 channels, 4 KB) has been read, the same group of channel tile 1 is requested into its place - four
+    // requests that are all in flight while tile 0 is stored.  vmcnt counts loads and stores in issue order: before group gq of
+    // tile 1 is read, what may still be outstanding is everything issued after its request - counted below.
     constexpr int NG = CTW * 4;                                         // groups of four channels per wavefront
-    constexpr int RA = !RES ? 1 : (16 * PT * NG <= 64 ? NG : (PT == 4 ? FQ_PWSMP_RA : NG));
+    constexpr int RA = (!RES || RL) ? 1 : (16 * PT * NG <= 64 ? NG : (PT == 4 ? FQ_PWSMP_RA : NG));
+    const float* const rl_rd = reinterpret_cast<const float*>(smp_dyn + 16384u * (unsigned)wave) + (4 * h) * 128 + pl;
     float resv[RES ? RA * 4 * PT : 1];
     auto res_issue = [&](int g_) __attribute__((always_inline)) {
       const int c = g_ / 4, gq = g_ % 4;
@@ -292,11 +337,12 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
           resv[RES ? ((g_ % RA) * 4 + r) * PT + pt : 0] =
               buf_ld_f32(rr, pt == PT - 1 ? po_last : po0 + 32u * pt * 4u, (unsigned)(c * 32 + 8 * gq + r) * plane4);
     };
-    if (RES) {
+    if (RES && !RL) {
 #pragma unroll
       for (int g_ = 0; g_ < RA && g_ < NG; ++g_) res_issue(g_);
       FQ_PIN();
     }
+    if (RL) smp_wait_vm<0>();                                           // (the prologue's requests: long done)
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
       const int cb = (ctl0 + c) * 32 + 4 * h;
@@ -309,7 +355,23 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
         const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
         const f4 bch = *reinterpret_cast<const f4*>(c_bias + c0);
         float res[RES ? 4 * PT : 1];
-        if (RES) {
+        if (RL) {
+          // what is issued after the request of (tile 1, group gq) - it goes out right behind the LDS reads of (tile 0, group gq),
+          // ahead of that group's stores: 16 stores + [4 requests + 16 stores] x (3 - gq) of tile 0, then 16 gq stores of tile 1 =
+          // 76 - 4 gq >= 64 vector memory instructions.  The counter holds 63 at most: `vmcnt(63)` is the weakest wait that
+          // proves the request complete (it waits for at most 13 stores more than necessary)
+          if (c == 1) smp_wait_vm<63>();
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) res[r * PT + pt] = rl_rd[(8 * gq + r) * 128 + 32 * pt];
+          if (c == 0) {                            // this group's values are in registers: tile 1's group into its place
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              smp_dma16(rrd, rl_voff, (unsigned)(32 + 8 * gq + 2 * j) * plane4, rl_base + (unsigned)(8 * gq + 2 * j) * 512u);
+          }
+        } else if (RES) {
 #pragma unroll
           for (int i = 0; i < 4 * PT; ++i) res[i] = resv[((c * 4 + gq) % RA) * 4 * PT + i];
         }
@@ -353,7 +415,7 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
             }
           }
         }
-        if (RES && c * 4 + gq + RA < NG) {
+        if (RES && !RL && c * 4 + gq + RA < NG) {
           FQ_PIN();
           res_issue(c * 4 + gq + RA);
           FQ_PIN();
@@ -471,7 +533,8 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   const bool plane_ok = small ? (a.hw >= 45 && a.hw % 4 <= 1 && (kt == 16 || ((kt == 32 || kt == 64) && a.residual == nullptr)))
                               : (a.hw % 4 == 0 && quads / nb >= 24 && (kt == 4 || kt == 8 || kt == 16 || kt == 32));
   const bool shape_ok = plane_ok && a.stride == 1 && a.cin == a.cin_pad && a.cout % 256 == 0 &&
-                        a.n < (1 << 20) && a.cin * a.hw * 4 < (1ll << 31) && (small || aligned16(a.x));
+                        a.n < (1 << 20) && a.cin * a.hw * 4 < (1ll << 31) && (small || aligned16(a.x)) &&
+                        (small || a.residual == nullptr || aligned16(a.residual));    // (16-byte LDS-DMA of the residual operand)
   // by shape: the small and middle planes (measured in the model against the split form: 512 -> 512 @14x14 32.0 -> 25.2 us,
   // 256 -> 512 @14x14 24.0 -> 20.7, 256 -> 256 @28x28 48.0 -> 39.7, 128 -> 256 @28x28 38.8 -> 33.7); the streaming form keeps
   // the large planes
@@ -525,7 +588,15 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   bool launched = false;
 #define FQ_PWSMP_CASE_R(KT_, CTW_, PT_, RES_, NI_)                                                                     \
   if (kt == KT_ && ctw == CTW_ && pt == PT_ && res == RES_ && ni == NI_) {                                             \
-    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_, PT_, RES_, NI_>), dim3((unsigned)grid), dim3(512), 0, a.st,     \
+    /* (the residual operand staged in LDS: 8 wavefronts x 16 KB beside the 18 KB of panels and constants) */          \
+    constexpr size_t dyn_ = (RES_ && PT_ == 4 && CTW_ == 2 && NI_ == 1 && FQ_PWSMP_RESLDS) ? 8 * 16384 : 0;             \
+    if (dyn_ != 0) {                                                                                                   \
+      static const bool attr_ok =                                                                                      \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_sample_kernel<KT_, CTW_, PT_, RES_, NI_>),         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_) == hipSuccess;                    \
+      FQ_REQUIRE(attr_ok, "fq_pwconv_i8: cannot raise the dynamic LDS limit of the sample kernel");                    \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_, PT_, RES_, NI_>), dim3((unsigned)grid), dim3(512), dyn_, a.st,  \
                        a.x, wfrag, a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr,         \
                        a.levels, a.lo_neg, kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out,          \
                        a.residual);                                                                                    \
