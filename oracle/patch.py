@@ -187,7 +187,8 @@ def eval_counters(logits, labels, counters):
     return counters
 
 
-def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None):
+def stem_conv_s2(x, w, bias=None, bn_scale=None, bn_shift=None, act=None, want_stat=True, w_tap_major=None, pool=False):
+    assert not pool, "the oracle's first convolution does not pool (quantize.fuse.STEM_POOL = False)"
     y = O.stem_conv_s2(_np(x), _np(w), None if bias is None else _np(bias),
                          None if bn_scale is None else _np(bn_scale), None if bn_shift is None else _np(bn_shift),
                          None if act in (None, "none") else act)
@@ -229,8 +230,13 @@ def pwconv_strided_supported(cin):
     return True
 
 
+def pwconv_sub2_supported(cin, cout):
+    return cout > 128
+
+
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
-              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None):
+              bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None, subsample=False):
+    """(subsample: the statistic of the whole output, then its even pixels of its even rows - fq_pwconv_i8_sub2)"""
     signed, lo_neg, _, _ = _flags(flags)
     if stride != 1:
         x = x[:, :, ::stride, ::stride].contiguous()
@@ -264,6 +270,8 @@ def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, wid
     elif act == "relu6":
         y = np.minimum(np.maximum(y, F32(0)), F32(6))
     stat = _t(np.abs(y).reshape(n, -1).max(axis=1).astype(F32)) if want_stat else None
+    if subsample:
+        y = np.ascontiguousarray(y[:, :, ::2, ::2])
     return _t(y.astype(F32)), stat
 
 
@@ -487,7 +495,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "dense_i8_eval", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "dense_i8_eval", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "pwconv_sub2_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize", "qconv_weights", "qconv_workspace", "qconv2d"]
 

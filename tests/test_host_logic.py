@@ -522,3 +522,85 @@ def test_scalar_operand_cache_keeps_its_entries_and_tells_signed_zeros_apart():
         assert len(nd_mod._scalars) == nd_mod._SCALARS_MAX
     finally:
         nd_mod._SCALARS_MAX = saved
+
+
+def test_subsampled_trunk_links_and_host_plumbing_on_the_oracle():
+    """quantize/fuse.py `sub_next` + convert_conv2d.sub_target / _convolve (round 6), with the oracle standing in for the library:
+    the closing 1x1 of the last unit of ResNet-50's stages 1-3 is linked to the two stride-2 1x1 readers of the next stage (none in
+    ResNet-18, whose units open with a 3x3); with the link honoured the producer hands y[:, :, ::2, ::2] and the statistic of all
+    of y, the readers run with stride 1 - same logits, same `current_input_max` everywhere; a reader that cannot run on the
+    integer codes convolves the subsampled tensor with stride 1 (convert_conv2d.py:108 with the block's kwargs otherwise)."""
+    from quantization.mxnet_amd import ops
+    from quantization.mxnet_amd.mx.gluon.model_zoo import get_model
+    from quantization.mxnet_amd.quantize import fuse
+
+    def build(name):
+        reset_naming()
+        np.random.seed(4)
+        net = get_model(name, classes=10)
+        fn = {nn.Conv2D: convert.gen_conv2d_converter(quantize_input=True, quant_type="channel"),
+              nn.Dense: convert.gen_dense_converter(quantize_input=True, quant_type="channel"), nn.Activation: None,
+              nn.BatchNorm: None}
+        convert.convert_model(net, exclude=[net.features[0], net.features[1]], convert_fn=fn)
+        net.initialize(mx.init.Xavier())
+        qparams_init(net)
+        return net
+
+    def links(net):
+        found = []
+        net.apply(lambda b: found.append(b._fq_pw_fused["sub_next"]) if getattr(b, "_fq_pw_fused", None) and
+                  b._fq_pw_fused.get("sub_next") else None)
+        return found
+    x = mx.nd.array(np.random.default_rng(2).standard_normal((2, 3, 40, 40)).astype(np.float32))
+    pool_was, fuse.STEM_POOL = fuse.STEM_POOL, False        # (the oracle's first convolution does not pool)
+    try:
+        _subsampled_trunk_checks(build, links, x, ops, fuse)
+    finally:
+        fuse.STEM_POOL = pool_was
+
+
+def _subsampled_trunk_checks(build, links, x, ops, fuse):
+    with oracle_ops():
+        r18 = build("resnet18_v1")
+        r18(x)
+        fuse.fuse_inference(r18)
+        assert links(r18) == []
+        net = build("resnet50_v1")
+        net.quantize_input(enable=True, online=True)
+        net(x)
+        net.fix_params()
+        fuse.fuse_inference(net)
+        found = links(net)
+        assert len(found) == 3
+        for lk in found:
+            first, sc = lk["readers"]
+            assert first is list(lk["unit"].body._children.values())[0] and sc is list(lk["unit"].downsample._children.values())[0]
+            assert first._kwargs["stride"] == (2, 2) and sc._kwargs["stride"] == (2, 2)
+        outs = {}
+        real = ops.pwconv_i8
+        for mode in ("whole", "sub", "sub, one reader off the codes"):
+            seen = []
+
+            def spy(*a, **k):
+                if k.get("subsample"):
+                    seen.append(tuple(a[0].shape))
+                return real(*a, **k)
+            ops.pwconv_i8 = spy
+            old, fuse.SUBSAMPLE = fuse.SUBSAMPLE, mode != "whole"
+            ops.StatArena._tls.current = object()        # (what the rewired net's forward sets on a GPU: "inside the net")
+            if mode.endswith("codes"):
+                found[1]["readers"][1]._fq_no_int8 = True
+            try:
+                out = net(x).asnumpy()
+                cur = [float(b.current_input_max) for b in net.collect_quantized_blocks()]
+            finally:
+                ops.pwconv_i8 = real
+                fuse.SUBSAMPLE = old
+                ops.StatArena._tls.current = None
+            outs[mode] = (out, cur, seen)
+        assert outs["whole"][2] == [] and len(outs["sub"][2]) == 3 and len(outs["sub, one reader off the codes"][2]) == 3
+        np.testing.assert_array_equal(outs["sub"][0], outs["whole"][0])
+        assert outs["sub"][1] == outs["whole"][1]
+        # (the fp32 library convolution of the fake-quantised tensors adds in another order than the integer path: close, not equal)
+        np.testing.assert_allclose(outs["sub, one reader off the codes"][0], outs["whole"][0], rtol=0, atol=2e-3 * np.abs(outs["whole"][0]).max())
+        assert outs["sub, one reader off the codes"][1][:5] == outs["whole"][1][:5]
