@@ -305,6 +305,10 @@ def _gloo_sum(dist, t, op):
 def box_probe_start():
     """rocm-smi started in the background right before the timed region, so that it reads the clocks of a BUSY GPU."""
     import subprocess
+    # (not under rocprofv3: its preloaded library initialises the GPU in every child process, and rocm-smi - a script behind
+    # `#!/usr/bin/env python3` - would then exec from such a process, which the boxes of this pool refuse)
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None
     try:
         return subprocess.Popen(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--showtemp"],
                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
