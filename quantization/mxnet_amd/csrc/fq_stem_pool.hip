@@ -184,6 +184,20 @@ __global__ __launch_bounds__(512, 2) void stem7_pool_kernel(const float* __restr
     po_out[k] = ch * g.Hp * Wp + px;
   }
   float* const yo = y + ((int64_t)smp * kCout * g.Hp) * Wp;
+  // rows of a multiple of eight convolution columns (224 x 224 images: 112): FOUR pooled outputs per task - the nine columns
+  // 2 px - 1 .. 2 px + 7 of a ring row are one 4-byte and two 16-byte LDS reads instead of twelve 4-byte ones, the outputs one
+  // 16-byte store (round 6: the pooling phase, in which the matrix pipe idles, was 63 LDS reads per thread and pooled row)
+  const bool pool4 = (Wo & 7) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0;
+  const int wq = Wp >> 2, total4 = kCout * wq;                          // tasks (channel, group of four pooled columns)
+  constexpr int kPool4Per = (kCout * 16 + 511) / 512;                   // Wp <= 64: <= 16 groups per channel
+  int p4_off[kPool4Per], p4_out[kPool4Per];                             // ch * Wo + 8 g4 | (left tap present) << 20; < 0: none
+#pragma unroll
+  for (int k = 0; k < kPool4Per; ++k) {
+    const int idx = (int)threadIdx.x + 512 * k;
+    const int ch = idx / (wq > 0 ? wq : 1), g4 = idx - ch * wq;
+    p4_off[k] = (pool4 && idx < total4) ? ((ch * Wo + 8 * g4) | ((g4 > 0 ? 1 : 0) << 20)) : -1;
+    p4_out[k] = ch * g.Hp * Wp + 4 * g4;
+  }
   for (int p = p_begin; p < p_end; ++p) {
     const int oy = 2 * p + rsel;
     const Row cur = row_at(oy), nxt = row_at(oy + 2);
@@ -196,6 +210,32 @@ __global__ __launch_bounds__(512, 2) void stem7_pool_kernel(const float* __restr
     const float* const row0 = ring + ((2 * p + 2) % 3) * ring_row;      // row 2 p - 1 (slot (2 p - 1) mod 3)
     const float* const row1 = ring + ((2 * p) % 3) * ring_row;
     const float* const row2 = ring + (r_hi % 3) * ring_row;
+    if (pool4) {                                                        // (uniform)
+#pragma unroll
+      for (int k = 0; k < kPool4Per; ++k) {
+        if (p4_off[k] < 0) continue;
+        const int base = p4_off[k] & 0xFFFFF, c_lo = (p4_off[k] >> 20) & 1;
+        f4 hm[3];                                                       // per ring row: the four horizontal maxima
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float* src = (r == 0 ? row0 : r == 1 ? row1 : row2) + base;
+          const float lo = src[-c_lo];
+          const f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
+          // (the same association as the scalar form: max(max(left, middle), right))
+          hm[r] = (f4){fmaxf(fmaxf(lo, a.x), a.y), fmaxf(fmaxf(a.y, a.z), a.w), fmaxf(fmaxf(a.w, b.x), b.y),
+                       fmaxf(fmaxf(b.y, b.z), b.w)};
+        }
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float m0 = fmaxf(hm[1][j], hm[2][j]);
+          m0 = top ? fmaxf(m0, hm[0][j]) : m0;
+          o[j] = m0;
+          m = fmaxf(m, fabsf(m0));
+        }
+        *reinterpret_cast<f4*>(yo + p4_out[k] + (int64_t)p * Wp) = o;
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < kPoolPer; ++k) {
       if (po_off[k] < 0) continue;
@@ -215,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void stem7_pool_kernel(const float* __restr
       m0 = top ? fmaxf(m0, mt) : m0;
       yo[po_out[k] + (int64_t)p * Wp] = m0;
       m = fmaxf(m, fabsf(m0));
+    }
     }
     __syncthreads();                                                    // the next step overwrites rows 2 p - 1 and 2 p
   }
