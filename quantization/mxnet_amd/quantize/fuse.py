@@ -650,7 +650,11 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
                 return (type(c) is nn.Conv2D and c._kwargs["kernel"] == (1, 1) and c._kwargs["stride"] == (2, 2)
                         and c._kwargs["pad"] == (0, 0) and c._kwargs["num_group"] == 1
                         and getattr(c, "_fq_pw_fused", None) is not None and c._fq_pw_fused.get("kind") == "1x1")
-            if ua and sc is not None and strided_1x1(first) and strided_1x1(sc) and hasattr(sc, "quantize_args"):
+            # (the containers the tensor passes through on its way - the two stages, their parent, the shortcut's Sequential - must
+            # be the stock ones: a subclass with a forward of its own might look at the tensor between two blocks)
+            stock = all(type(c) in (nn.Sequential, nn.HybridSequential) and "forward" not in c.__dict__
+                        for c in (container, a_, b_, ds))
+            if ua and stock and sc is not None and strided_1x1(first) and strided_1x1(sc) and hasattr(sc, "quantize_args"):
                 fa["sub_next"] = {"readers": (first, sc), "unit": v, "via": (u, v, a_, b_, ds)}
 
     def visit_unit_links(container):
