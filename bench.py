@@ -470,6 +470,11 @@ def main():
         args.streams = 4 if args.offline else 3
     n_streams = args.streams if args.phase == "eval" else 1
     net = prepare_net()
+    from quantization.mxnet_amd.quantize import fuse as _fuse_mod
+    lib_gemm = _fuse_mod.library_gemm_blocks(net)
+    if n_streams > 1 and lib_gemm:
+        # (Dense layers through the tensor library - vgg: one batch at a time, quantize.fuse.library_gemm_blocks says why)
+        n_streams = args.streams = 1
     nets = [net] * n_streams
     streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
     if n_streams > 1:

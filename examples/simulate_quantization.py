@@ -376,6 +376,8 @@ def evaluate(net, num_class, dataloader, ctx, update_ema=False, tqdm_desc="Eval"
     dev = ctx.torch_device
     on_gpu = dev.type == "cuda"
     n_lanes = streams if streams > 1 and not update_ema and on_gpu else 1
+    if n_lanes > 1 and _fuse.library_gemm_blocks(net):
+        n_lanes = 1                                        # (library GEMMs in the net: one batch at a time, see fuse.library_gemm_blocks)
     state = _eval_state(net, dev, n_lanes, num_class, update_ema)
     counters = state.counters
     counters.zero_()

@@ -92,7 +92,13 @@ def conv_input_fake_quant(x, signed=False, width=8, offline_threshold=None):
 def dense_input_fake_quant(x, signed=False, width=8, offline_threshold=None):
     """`_dense_forward` (convert_dense.py:39-49): as conv but STE gets no clip_min => clips to [0, max] even when
     signed (reference quirk, kept)."""
-    cur = batch_mean(absmax_per_sample(x))
+    a = np.asarray(x, dtype=F32)
+    if a.ndim > 2:
+        # `F.max(F.abs(x), axis=1).mean()` (:41) on an un-flattened (N, C, H, W) input - vgg's first Dense - reduces over C only;
+        # the mean then averages N * H * W values
+        cur = batch_mean(np.abs(a).max(axis=1).reshape(-1))
+    else:
+        cur = batch_mean(absmax_per_sample(x))
     max_ = F32(offline_threshold) if offline_threshold is not None else cur
     scale = act_scale(max_, signed, width)
     codes = ste_codes(x, scale, max_, None)

@@ -12,7 +12,7 @@ from .block import HybridBlock
 from . import nn
 from .. import initializer as _init
 
-__all__ = ["get_model", "get_model_list", "MobileNet", "MobileNetV2", "ResNetV1", "CIFARResNetV1"]
+__all__ = ["get_model", "get_model_list", "MobileNet", "MobileNetV2", "ResNetV1", "CIFARResNetV1", "VGG"]
 
 
 class RELU6(HybridBlock):
@@ -220,6 +220,40 @@ class CIFARResNetV1(HybridBlock):
         return self.output(self.features(x))
 
 
+class VGG(HybridBlock):
+    """mxnet.gluon.model_zoo.vision.vgg (the net of the reference's tests/test_collect_qparams.py:14): features = stacks of
+    [Conv2D 3x3 pad 1 (+ bias) (, BatchNorm), ReLU] each closed by MaxPool2D(2, 2), then Dense(4096, relu), Dropout, Dense(4096,
+    relu), Dropout; output = Dense(classes)."""
+
+    def __init__(self, layers, filters, classes=1000, batch_norm=False, **kwargs):
+        super(VGG, self).__init__(**kwargs)
+        assert len(layers) == len(filters)
+        with self.name_scope():
+            # (as gluon's vgg.py: every layer is created in THIS block's name scope - vgg0_conv0 ... vgg0_dense2)
+            self.features = nn.HybridSequential(prefix="")
+            cin = 3
+            for num, ch in zip(layers, filters):
+                for _ in range(num):
+                    self.features.add(nn.Conv2D(ch, kernel_size=3, padding=1, in_channels=cin))
+                    if batch_norm:
+                        self.features.add(nn.BatchNorm(in_channels=ch))
+                    self.features.add(nn.Activation("relu"))
+                    cin = ch
+                self.features.add(nn.MaxPool2D(strides=2))
+            self.features.add(nn.Dense(4096, activation="relu"))
+            self.features.add(nn.Dropout(rate=0.5))
+            self.features.add(nn.Dense(4096, activation="relu", in_units=4096))
+            self.features.add(nn.Dropout(rate=0.5))
+            self.output = nn.Dense(classes, in_units=4096)
+
+    def hybrid_forward(self, F, x):
+        return self.output(self.features(x))
+
+
+_VGG_SPEC = {11: ([1, 1, 2, 2, 2], [64, 128, 256, 512, 512]), 13: ([2, 2, 2, 2, 2], [64, 128, 256, 512, 512]),
+             16: ([2, 2, 3, 3, 3], [64, 128, 256, 512, 512]), 19: ([2, 2, 4, 4, 4], [64, 128, 256, 512, 512])}
+
+
 def _cifar_resnet(num_layers, **kw):
     assert (num_layers - 2) % 6 == 0
     n = (num_layers - 2) // 6
@@ -247,6 +281,11 @@ _MODELS = {
 }
 for _n, (_b, _l, _c) in _RESNET_SPEC.items():
     _MODELS["resnet%d_v1" % _n] = (lambda b, l, c: (lambda **kw: ResNetV1(b, l, c, **kw)))(_b, _l, _c)
+
+
+for _n, (_l, _f) in _VGG_SPEC.items():
+    _MODELS["vgg%d" % _n] = (lambda l, f: (lambda **kw: VGG(l, f, **kw)))(_l, _f)
+    _MODELS["vgg%d_bn" % _n] = (lambda l, f: (lambda **kw: VGG(l, f, batch_norm=True, **kw)))(_l, _f)
 
 
 def _models_dir(root=None):
@@ -294,7 +333,12 @@ def get_model(name, pretrained=False, classes=None, ctx=None, root=None, **kwarg
     if kwargs.pop("use_se", False):
         raise NotImplementedError("use_se=True: the model zoo of this build has no squeeze-and-excitation variants")
     kwargs.pop("norm_layer", None)
-    kwargs.pop("batch_norm", None)                   # (gluoncv passes it to vgg only, which this zoo does not have)
+    batch_norm = bool(kwargs.pop("batch_norm", False))    # (the reference CLI passes it to vgg only: `vgg16` + batch_norm = vgg16_bn)
+    if batch_norm:
+        if not name.startswith("vgg"):
+            raise TypeError("%s: __init__() got an unexpected keyword argument 'batch_norm'" % name)
+        if not name.endswith("_bn"):
+            kw["batch_norm"] = True
     if last_gamma and not (name.startswith("resnet") or name.startswith("cifar_resnet")):
         raise TypeError("%s: __init__() got an unexpected keyword argument 'last_gamma'" % name)
     if kwargs:

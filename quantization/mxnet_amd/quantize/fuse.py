@@ -709,6 +709,21 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
     return fused[0]
 
 
+def library_gemm_blocks(net):
+    """The Dense blocks of `net` whose product runs as a GEMM of the tensor library (rocBLAS / hipBLASLt through torch): those
+    with an activation of their own and those `fuse_inference` did not put on the integer codes.  An evaluation loop keeps
+    SEVERAL batches in flight only for nets without such blocks: vgg11's forward (Dense(25088 -> 4096, relu) through the library)
+    replayed as three hipGraphs on three streams never returned on an MI355X, while one stream and eager launches ran - the
+    library's kernels are not ours to vouch for when they compete with each other for CUs (profiles/r6_vgg_streams.txt)."""
+    found = []
+
+    def visit(b):
+        if type(b) is nn.Dense and (b.act is not None or not getattr(b, "_fq_dense_int8", False)):
+            found.append(b)
+    net.apply(visit)
+    return found
+
+
 def _install_stat_arena(net, producers):
     """One zeroing launch per forward for all producers' per-sample statistic rows (ops.StatArena)."""
     if producers <= 0 or hasattr(net, "_fq_arena_hooks"):

@@ -604,3 +604,60 @@ def _subsampled_trunk_checks(build, links, x, ops, fuse):
         # (the fp32 library convolution of the fake-quantised tensors adds in another order than the integer path: close, not equal)
         np.testing.assert_allclose(outs["sub, one reader off the codes"][0], outs["whole"][0], rtol=0, atol=2e-3 * np.abs(outs["whole"][0]).max())
         assert outs["sub, one reader off the codes"][1][:5] == outs["whole"][1][:5]
+
+
+def test_vgg16_through_convert_model_and_collect_qparams_as_the_reference_test_does():
+    """The reference's tests/test_collect_qparams.py: `vgg16(pretrained=True)` -> `convert_model(net)` -> `qparams_init(net)` ->
+    `collect_qparams(net)` / `print_all_qparams(net)` (it asserts nothing; here: one `input_max` per Conv2D and Dense, gluon's
+    parameter names).  And the zoo's `batch_norm` argument, which the reference CLI passes to vgg only (simulate_quantization.py:197)."""
+    from quantization.mxnet_amd.mx.gluon.model_zoo import get_model, get_model_list
+    from quantization.mxnet_amd.quantize import collect_qparams, print_all_qparams
+    np.random.seed(7)
+    net = get_model("vgg16", pretrained=False)
+    convert.convert_model(net)
+    qparams_init(net)
+    q = collect_qparams(net)
+    assert len(q) == 16 and sorted(q)[0] == "vgg0_conv0_input_max" and "vgg0_dense2_input_max" in q      # 13 convolutions + 3 Dense
+    print_all_qparams(net)
+    assert {"vgg11", "vgg13", "vgg16", "vgg19", "vgg16_bn"} <= set(get_model_list())
+    bn = get_model("vgg16", pretrained=False, batch_norm=True)
+    assert sum(type(b) is nn.BatchNorm for b in bn.features._children.values()) == 13
+    with pytest.raises(TypeError):
+        get_model("mobilenet1.0", pretrained=False, batch_norm=True)
+    x = mx.nd.array(np.random.default_rng(0).standard_normal((2, 3, 32, 32)).astype(np.float32))
+    small = get_model("vgg11", pretrained=False, classes=10)
+    assert small(x).shape == (2, 10)
+    # several batches in flight only for nets without library GEMMs (quantize.fuse.library_gemm_blocks)
+    from quantization.mxnet_amd.quantize import fuse
+    assert len(fuse.library_gemm_blocks(small)) == 3
+    mb = get_model("mobilenet1.0", pretrained=False, classes=10)
+    assert len(fuse.library_gemm_blocks(mb)) == 1            # (not converted, not fused: its classifier is the library's)
+    mb.output._fq_dense_int8 = True
+    assert fuse.library_gemm_blocks(mb) == []
+
+
+def test_dense_on_an_unflattened_input_takes_the_statistic_the_reference_takes():
+    """convert_dense.py:41 - `F.max(F.abs(x), axis=1).mean()` - on an (N, C, H, W) input (vgg's first Dense, fed by a pooling
+    layer) reduces over C only and averages N * H * W maxima: not the per-sample maximum a flattened input gives.  The
+    reference's own expression through the facade, the oracle, and the converted block agree."""
+    from oracle import fq_oracle as O
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((3, 8, 2, 2)).astype(np.float32)
+    xa = mx.nd.array(x)
+    want_cur = mx.nd.max(mx.nd.abs(xa), axis=1).mean().asscalar()                       # the reference's line, verbatim
+    y, cur, _, _ = O.dense_input_fake_quant(x, False, 8)
+    assert np.float32(cur) == np.float32(want_cur) and cur != O.batch_mean(O.absmax_per_sample(x))
+    reset_naming()
+    net = nn.HybridSequential()
+    net.add(nn.Dense(4, in_units=32))
+    net.initialize(mx.init.Xavier())
+    convert.convert_model(net, convert_fn={nn.Dense: convert.gen_dense_converter(quantize_input=True)})
+    qparams_init(net)
+    blk = net[0]
+    seen = {}
+    real = blk.origin_forward
+    blk.origin_forward = lambda F, xq, w, b=None: (seen.setdefault("xq", xq.asnumpy()), real(F, xq, w, b))[1]
+    with oracle_ops():
+        blk(xa)
+    assert np.float32(float(blk.current_input_max)) == np.float32(want_cur)
+    np.testing.assert_array_equal(seen["xq"], y)
