@@ -659,3 +659,35 @@ def test_calibration_on_a_non_default_stream_is_an_ordinary_calibration(gpu, fus
         with pytest.raises(RuntimeError, match="batches_in_flight"):
             net.update_ema()
     assert not ops.in_flight()
+
+
+def test_dense_on_an_unflattened_input_against_the_reference_fixture(gpu, golden):
+    """G12 (tests/golden/g12_dense_unflattened.npz: the reference's `_dense_forward` on (N, C, H, W) inputs): the converted Dense on
+    the GPU quantises with the statistic of convert_dense.py:41 - max over axis 1 only, mean over N * H * W values - online and
+    with a stored threshold."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.mx.gluon import nn
+    from quantization.mxnet_amd.quantize import convert
+    from quantization.mxnet_amd.quantize.initialize import qparams_init
+    g = golden("g12_dense_unflattened")
+    for tag in sorted({k.split("/")[0] for k in g}):
+        x = g[tag + "/x"]
+        net = nn.HybridSequential()
+        net.add(nn.Dense(5, in_units=int(np.prod(x.shape[1:]))))
+        net.initialize(mx.init.Xavier())
+        convert.convert_model(net, convert_fn={nn.Dense: convert.gen_dense_converter(quantize_input=True, input_signed=tag.endswith("_s"))})
+        qparams_init(net)
+        net.collect_params().reset_ctx(gpu)
+        blk = net[0]
+        seen = []
+        real = blk.origin_forward
+        blk.origin_forward = lambda F, xq, w, b=None, _r=real: (seen.append(xq.asnumpy()), _r(F, xq, w, b))[1]
+        X = mx.nd.array(x, ctx=gpu)
+        net(X)
+        assert np.float32(float(blk.current_input_max)) == g[tag + "/online_max"], tag
+        assert np.array_equal(seen[-1], g[tag + "/online_y"]), tag
+        blk.input_max.set_data(mx.nd.array(np.asarray([g[tag + "/offline_thr"]], np.float32), ctx=gpu))
+        net.quantize_input(enable=True, online=False)
+        net(X)
+        assert np.array_equal(seen[-1], g[tag + "/offline_y"]), tag + " offline"
+        assert np.float32(float(blk.current_input_max)) == g[tag + "/offline_curmax"], tag

@@ -164,8 +164,9 @@ def test_activation_vs_numpy_oracle(shape, signed, width):
     _eq(y2, want_y)
     thr = np.float32(1.7)
     _eq(H.fake_quant_offline(x, thr, width, H.act_flags(signed))[0], O.conv_input_fake_quant(x, signed, width, thr)[0])
-    _eq(H.fake_quant_online(x, width, H.act_flags(signed, lo_neg_max=False))[0],
-        O.dense_input_fake_quant(x, signed, width)[0])
+    # (the Dense block's clip range on its FLATTENED input; an un-flattened one has its own statistic, convert_dense.py:41)
+    _eq(H.fake_quant_online(x, width, H.act_flags(signed, lo_neg_max=False))[0].reshape(x.shape[0], -1),
+        O.dense_input_fake_quant(x.reshape(x.shape[0], -1), signed, width)[0])
     a = np.abs(x) + np.float32(0.1)
     ya, cura, _ = H.fake_quant_online(a, width, H.act_flags(no_abs=True, no_eps=True))
     wa, wcur, _, _ = O.act_output_fake_quant(a, width)

@@ -110,6 +110,25 @@ def test_dense_activation_fake_quant(golden):
         _eq(y, g[tag + "/offline_y"], tag + " offline")
 
 
+def test_dense_on_an_unflattened_input_golden(golden):
+    """G12: the reference's `_dense_forward` on (N, C, H, W) inputs (vgg's first Dense): `F.max(F.abs(x), axis=1).mean()` reduces
+    over C only.  The oracle follows the line - and differs from the per-sample statistic a flattened input gives."""
+    g = golden("g12_dense_unflattened")
+    tags = sorted({k.split("/")[0] for k in g})
+    assert len(tags) == 6
+    for tag in tags:
+        signed = tag.endswith("_s")
+        x = g[tag + "/x"]
+        y, cur, _, _ = O.dense_input_fake_quant(x, signed, 8)
+        assert cur == g[tag + "/online_max"], tag
+        _eq(y, g[tag + "/online_y"], tag)
+        if x.shape[2] * x.shape[3] > 1:
+            assert cur != O.dense_input_fake_quant(x.reshape(x.shape[0], -1), signed, 8)[1]
+        y, cur_off, _, _ = O.dense_input_fake_quant(x, signed, 8, offline_threshold=g[tag + "/offline_thr"])
+        _eq(y, g[tag + "/offline_y"], tag + " offline")
+        assert cur_off == g[tag + "/offline_curmax"]
+
+
 # ---- G5/G6: weights ------------------------------------------------------------------------------------------
 def test_weight_fake_quant(golden):
     g = golden("g5_weight")

@@ -696,6 +696,33 @@ def gen_qat(mx, convert, initialize, out):
     np.savez_compressed(os.path.join(out, "g11_qat.npz"), **cases)
 
 
+def gen_dense_unflattened(mx, convert, initialize, out):
+    """G12 (round 6): `_dense_forward` (convert_dense.py:39-49) on an UN-flattened (N, C, H, W) input - vgg's first Dense behind a
+    pooling layer: `F.max(F.abs(x), axis=1).mean()` reduces over C only.  The reference's own forward through the stand-in."""
+    nn = mx.gluon.nn
+    rng = np.random.default_rng(SEED + 12)
+    cases = {}
+    for shape in ((3, 8, 2, 2), (2, 16, 7, 7), (4, 6, 1, 3)):
+        for signed in (False, True):
+            tag = "dense4d_%s_%s" % ("x".join(map(str, shape)), "s" if signed else "u")
+            x = _tie_rich(rng, shape, signed, 4.0)
+            dense = nn.Dense(5, in_units=int(np.prod(shape[1:])))
+            dense.initialize()
+            convert.gen_dense_converter(input_signed=signed, input_width=8)(dense)
+            dense.input_max.initialize(mx.initializer.Constant(0))
+            cap = _capture_conv(mx, convert, initialize, dense, x)
+            cases[tag + "/x"] = x
+            cases[tag + "/online_y"] = cap["xq"]
+            cases[tag + "/online_max"] = cap["current_input_max"]
+            thr = np.float32(cap["current_input_max"] * np.float32(0.5))
+            dense.input_max.set_data(mx.nd.array([thr]))
+            cap = _capture_conv(mx, convert, initialize, dense, x, quantize_input_offline=True)
+            cases[tag + "/offline_thr"] = thr
+            cases[tag + "/offline_y"] = cap["xq"]
+            cases[tag + "/offline_curmax"] = cap["current_input_max"]
+    np.savez_compressed(os.path.join(out, "g12_dense_unflattened.npz"), **cases)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -737,6 +764,9 @@ def main():
     if want("g11"):
         gen_qat(mx, convert, initialize, args.out)
         print("g11 done", flush=True)
+    if want("g12"):
+        gen_dense_unflattened(mx, convert, initialize, args.out)
+        print("g12 done", flush=True)
     with open(os.path.join(args.out, "PROVENANCE.txt"), "w") as f:
         import scipy
         import torch
