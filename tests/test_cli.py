@@ -89,6 +89,24 @@ def test_cli_flows_on_cpu_with_oracle(tiny_data, capsys, extra):
         assert all(b.quantize_input_offline and float(b.input_max.data().asscalar()) > 0 for b in blocks)
 
 
+def test_cli_runs_vgg_with_the_batch_norm_flag_on_cpu_with_oracle(tiny_data, capsys):
+    """`--batch-norm` goes to the zoo for vgg names only (simulate_quantization.py:197); with `--merge-bn` the thirteen BatchNorms are
+    folded into their convolutions (convert_conv2d.py:47-51).  vgg11: 7 quantised convolutions (the first is excluded) + 3 Dense."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.mx.gluon import nn
+    cli = _cli()
+    opt = cli.parse_args(["--model", "vgg11", "--batch-norm", "--dataset", "cifar10", "--batch-size", "8", "--num-sample", "1",
+                          "--quantize-input-offline", "--calib-epoch", "1"])
+    with oracle_ops():
+        acc, avg_acc, net = cli.run(opt, mx.cpu())
+    out = capsys.readouterr().out
+    assert "Result" in out and 0.0 <= acc <= 1.0
+    blocks = net.collect_quantized_blocks()
+    assert sum(isinstance(b, nn.Conv2D) for b in blocks) == 7 and sum(isinstance(b, nn.Dense) for b in blocks) == 3
+    assert sum(type(b) is nn.BatchNorm for b in net.features._children.values()) == 8
+    assert all(float(b.input_max.data().asscalar()) > 0 for b in blocks)
+
+
 def test_cli_kl_flow_and_qparams_roundtrip_on_cpu_with_oracle(tiny_data, capsys, tmp_path):
     from quantization.mxnet_amd import mx
     cli = _cli()
