@@ -392,9 +392,15 @@ static bool pw_stream_thin_ok(const PwCall& c) {
   // (r4: 3000 instead of 4096 - the 28 x 28 planes of a batch of 128 are 3136 tiles: MobileNetV2 W4 offline 144.8 -> 146.9 k
   // images/s, ResNet-50 offline unchanged; 1500 / 700 add nothing, profiles/r4_thin_tiles_ab.txt)
   static const int thin_min_tiles = env_int("FQ_PWS_THIN_MIN_TILES", 3000);
-  // (codes in AND codes out: K = 32 only - MobileNetV2's first 1x1 behind a first convolution that hands its codes over)
-  return thin && kt >= 1 && kt <= 6 && lds <= 72 * 1024 && c.stride == 1 && (c.out_thr == nullptr || c.cout % 16 == 0) &&
-         !(c.in_c16 && c.out_thr != nullptr && kt != 1) && !(c.out_thr != nullptr && c.residual != nullptr) &&
+  // (codes in AND codes out: K = 32 - MobileNetV2's first 1x1 behind a first convolution that hands its codes over - and, round 6,
+  // K = 256 / 512: the first 1x1 of ResNet-50's units on the 56x56 and 28x28 planes, which the split form ran as 12 544 / 3 136
+  // one-tile workgroups at 2.2 / 2.0 TB/s of their 1-byte-per-element traffic: ResNet-50 offline +2.4 % images/s,
+  // profiles/r6_wide_c16_stream_ab.txt)
+  static const int both_wide = env_int("FQ_PWS_THIN_WIDE", 1);           // A/B: 0 leaves them to the split form
+  const bool both = c.in_c16 && c.out_thr != nullptr;
+  const bool wide = both && both_wide && (kt == 8 || kt == 16) && c.cin % 32 == 0 && c.cout % 32 == 0 && c.residual == nullptr;
+  return thin && kt >= 1 && (kt <= 6 || wide) && lds <= 72 * 1024 && c.stride == 1 && (c.out_thr == nullptr || c.cout % 16 == 0) &&
+         !(both && kt != 1 && !wide) && !(c.out_thr != nullptr && c.residual != nullptr) &&
          (c.n * c.hw + 31) / 32 > thin_min_tiles && c.n * c.cout * c.hw * 4 < (1ll << 32) && c.n * c.cin * c.hw * 4 < (1ll << 32);
 }
 
@@ -518,6 +524,10 @@ int pw_try_stream(const PwCall& c, bool* taken) {
     break;
   if (thin && c.y16 != nullptr) {
     if (kt == 2) FQ_PWS_THIN_DUAL(2) else FQ_PWS_THIN_DUAL(4)
+  } else if (thin && kt == 8) {
+    FQ_PWS_THIN(8, false, true, true)
+  } else if (thin && kt == 16) {
+    FQ_PWS_THIN(16, false, true, true)
   } else if (thin) {
     switch (kt) {
       FQ_PWS_THIN_CASE(1) FQ_PWS_THIN_CASE(2) FQ_PWS_THIN_CASE(3) FQ_PWS_THIN_CASE(4) FQ_PWS_THIN_CASE(5) FQ_PWS_THIN_CASE(6)

@@ -598,3 +598,31 @@ def test_hand_over_logits_against_the_oracle_chain(gpu):
     # (a code that flips in an early layer - the first convolution's last bit decides it - moves a logit by a few hundredths)
     np.testing.assert_allclose(got, want, rtol=2e-2, atol=1e-1)
     assert np.abs(got - want).mean() < 3e-2
+
+
+@pytest.mark.parametrize("cin,cout,hw,n", [(256, 64, 56, 32), (512, 128, 28, 128)], ids=["256->64@56x56", "512->128@28x28"])
+@pytest.mark.parametrize("act", ["relu", None])
+def test_wide_codes_in_codes_out_streaming_form_equals_the_split_form(dev, ops, cin, cout, hw, n, act):
+    """Round 6: the first 1x1 of a ResNet-50 unit on the 56x56 / 28x28 planes, codes in and codes out, takes the streaming form from
+    3000 pixel tiles up (K = 256 / 512 instantiations).  Under a stored threshold every sample is independent: the first samples of
+    the full batch (streaming form) must equal the same samples run alone (few tiles: split form) - codes, statistic."""
+    rng = torch.Generator(device="cpu").manual_seed(cin + hw)
+    t16 = torch.randint(-128, 128, (n, cin // 16, hw * hw, 16), generator=rng, dtype=torch.int8).to(dev)
+    thr = torch.full((1,), 2.75, device=dev)
+    othr = torch.full((1,), 1.9, device=dev)
+    w = torch.randn(cout, cin, generator=rng).to(dev) * 0.05
+    codes, scales, rowsum = ops.weight_codes(w, 1, 8)
+    sc = (torch.rand(cout, generator=rng) + 0.5).to(dev)
+    sh = torch.randn(cout, generator=rng).to(dev) * 0.2
+    kw = dict(in_thr=thr, width=8, flags=0, bn_scale=sc, bn_shift=sh, act=act, out_codes=dict(thr=othr, width=8, flags=0))
+    full, full_stat = ops.pwconv_i8(ops.Codes16(t16, (n, cin, hw, hw), thr, 8, 0), codes, scales, rowsum, **kw)
+    k = 3
+    part, part_stat = ops.pwconv_i8(ops.Codes16(t16[:k].contiguous(), (k, cin, hw, hw), thr, 8, 0), codes, scales, rowsum, **kw)
+    assert isinstance(full, ops.Codes16) and full.shape == (n, cout, hw, hw)
+    assert torch.equal(full.t[:k], part.t), "codes of the first samples"
+    assert torch.equal(full_stat[:k], part_stat)
+    # ... and the codes are those of the fp32 output under the consumer's threshold (oracle quantiser on the fp32 twin of the call)
+    yf, _ = ops.pwconv_i8(ops.Codes16(t16[:k].contiguous(), (k, cin, hw, hw), thr, 8, 0), codes, scales, rowsum,
+                          in_thr=thr, width=8, flags=0, bn_scale=sc, bn_shift=sh, act=act)
+    want = O.to_c16(O.ste_codes(yf.cpu().numpy(), O.act_scale(np.float32(1.9), False, 8), np.float32(1.9), np.float32(0)).astype(np.int64), 128)
+    assert np.array_equal(part.t.cpu().numpy(), want)
