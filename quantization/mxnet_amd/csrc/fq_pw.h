@@ -57,7 +57,7 @@ bool pw_stream_shape_ok(const PwCall& c);           //      shapes the streaming
 bool pw_stream_thin_takes(const PwCall& c);         //      ... and the thin instantiations (C16 input, ragged Cin / Cout) on large planes
 int pw_try_split(const PwCall& c, bool* taken);     // K2m  fq_pw_split.hip
 int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t grid, size_t lds, const int8_t* wfrag,
-                      bool* launched);
+                      bool* launched, int nw = 4);
 bool pw_split_sub_shape_ok(int64_t cin_pad, int64_t cout);        // fq_pw_split_sub.hip: the subsampled-output instantiations
 int pw_split_sub_launch(const PwCall& a, const void* geom, int kt, int64_t grid, size_t lds, const int8_t* wfrag, bool* launched);
 int pw_try_sample(const PwCall& c, bool* taken);    // K2r  fq_pw_sample.hip (14x14 planes)

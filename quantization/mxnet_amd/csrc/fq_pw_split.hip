@@ -50,7 +50,12 @@ int pw_try_split(const PwCall& a, bool* taken) {
     static const int nw8_tiles = env_int("FQ_PWS_NW8_TILES", 0);        // tuning: most tiles a layer may have to take nw = 8
     const int64_t nw8_max = nw8_tiles > 0 ? nw8_tiles : 16 * (int64_t)num_cu();
     int nw = (nw_tune == 4 || nw_tune == 8) ? nw_tune : ((a.cout >= 512 && tiles <= nw8_max) ? 8 : 4);
-    if (!nw8_built || c16 || a.sub) nw = 4;
+    // (C16 code tensors: four wavefronts - except the dual form of the 14x14 / 7x7 stages, K = 256 / 512, round 6: eight, i.e. 512
+    // channels per workgroup and half as many workgroups copying the same tile's codes - FQ_PWS16_DUAL_NW8=0 for the A/B)
+    static const int dual_nw8 = env_int("FQ_PWS16_DUAL_NW8", 1);
+    const bool dual8 = c16 && a.y16 != nullptr && !a.sub && dual_nw8 && (kt == 8 || kt == 16) && a.cout >= 512 && tiles <= nw8_max;
+    if (!nw8_built || (c16 && !dual8) || a.sub) nw = 4;
+    if (dual8) nw = 8;
     const int tune = (c16 || a.sub) ? 0 : env_int("FQ_PWS_CFG", 0);      // tuning: 10 * lb + cw, read per call
     if (tune > 0) {
       cw = tune % 10;
@@ -85,7 +90,7 @@ int pw_try_split(const PwCall& a, bool* taken) {
     }
     if (c16) {
       FQ_REQUIRE(a.residual == nullptr || a.out_thr == nullptr, "fq_pwconv_i8_c16: a residual operand goes with fp32 output");
-      if (int rc = pw_split16_launch(a, &t, kt, cw, grid, ldst, wfrag, &launched)) return rc;
+      if (int rc = pw_split16_launch(a, &t, kt, cw, grid, ldst, wfrag, &launched, nw)) return rc;
       FQ_REQUIRE(launched, "fq_pwconv_i8_c16: no instantiation for K/32=%d with %d channel tiles per wavefront", kt, cw);
       FQ_LAUNCH_CHECK();
       *taken = true;
