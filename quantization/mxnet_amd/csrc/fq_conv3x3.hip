@@ -121,7 +121,8 @@ int conv3x3_launch(const float* x, const int8_t* wcodes, const float* wscale, co
   // (measured in the ResNet-50 step: 256 @14x14 32.8 -> 28.6 us; 512 @7x7, where only 196 workgroups would remain, 34.1 -> 35.1)
   const bool nw8_fills = ((cols + 63) / 64) * ((cout + 255) / 256) >= (int64_t)num_cu();
   int nw = (nw_tune == 4 || nw_tune == 8) ? nw_tune : ((cout >= 256 && (kt == 8 || kt == 16) && nw8_fills) ? 8 : 4);
-  if (cout < 256 || !(kt == 8 || kt == 16) || nsl != 1 || c16) nw = 4;   // (the sliced / C16 forms are built for four wavefronts)
+  // (the C16 forms are built for four wavefronts; the sliced form - round 6 - for eight on the 256-channel 14x14 layers)
+  if (cout < 256 || !(kt == 8 || kt == 16) || (nsl != 1 && kt != 8) || c16) nw = 4;
   if (nsl != 1) FQ_REQUIRE(cout % 32 == 0, "fq_conv3x3_i8_sliced: Cout must be a multiple of 32, got %lld", (long long)cout);
   const int wc = nw == 8 ? 8 : (cout >= 128 ? 4 : 2);
   const int wp = nw / wc;
@@ -194,6 +195,7 @@ int conv3x3_launch(const float* x, const int8_t* wcodes, const float* wscale, co
   FQ_C3_KT(2) FQ_C3_KT(4) FQ_C3_KT(8) FQ_C3_KT(16)
   FQ_C3_CASE_NW(8, 1, 8, 6, 4, 8) FQ_C3_CASE_NW(8, 2, 8, 4, 4, 8) FQ_C3_CASE_NW(16, 1, 8, 6, 4, 8) FQ_C3_CASE_NW(16, 2, 8, 4, 4, 8)
   FQ_C3_SLICED(2) FQ_C3_SLICED(4) FQ_C3_SLICED(8) FQ_C3_SLICED(16)
+  FQ_C3_CASE_NS(8, 1, 8, 3, 2, 8, 3) FQ_C3_CASE_NS(8, 2, 8, 2, 2, 8, 3)
 #undef FQ_C3_SLICED
 #undef FQ_C3_KT
 #undef FQ_C3_CASE
