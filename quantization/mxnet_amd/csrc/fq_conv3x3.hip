@@ -121,8 +121,10 @@ int conv3x3_launch(const float* x, const int8_t* wcodes, const float* wscale, co
   // (measured in the ResNet-50 step: 256 @14x14 32.8 -> 28.6 us; 512 @7x7, where only 196 workgroups would remain, 34.1 -> 35.1)
   const bool nw8_fills = ((cols + 63) / 64) * ((cout + 255) / 256) >= (int64_t)num_cu();
   int nw = (nw_tune == 4 || nw_tune == 8) ? nw_tune : ((cout >= 256 && (kt == 8 || kt == 16) && nw8_fills) ? 8 : 4);
-  // (the C16 forms are built for four wavefronts; the sliced form - round 6 - for eight on the 256-channel 14x14 layers)
-  if (cout < 256 || !(kt == 8 || kt == 16) || (nsl != 1 && kt != 8) || c16) nw = 4;
+  // (the C16 forms are built for four wavefronts; round 6: the sliced form and the codes-in-AND-codes-out form for eight on the
+  // 256-channel 14x14 layers)
+  const bool c16_both8 = c16 && in_c16 && out_thr != nullptr && kt == 8 && nsl == 1;
+  if (cout < 256 || !(kt == 8 || kt == 16) || (nsl != 1 && kt != 8) || (c16 && !c16_both8)) nw = 4;
   if (nsl != 1) FQ_REQUIRE(cout % 32 == 0, "fq_conv3x3_i8_sliced: Cout must be a multiple of 32, got %lld", (long long)cout);
   const int wc = nw == 8 ? 8 : (cout >= 128 ? 4 : 2);
   const int wp = nw / wc;

@@ -30,6 +30,20 @@ int conv3x3_c16_launch(const float* x, const int8_t* wfrag, const float* wscale,
 #undef FQ_C316_KT
 #undef FQ_C316_IO
 #undef FQ_C316_CASE
+  // eight wavefronts (256 channels per workgroup): codes in and out on the 256-channel layers (round 6)
+#define FQ_C316_CASE8(KT_, PTW_, D_)                                                                                   \
+  if (kt == KT_ && ptw == PTW_ && wc == 8 && in16 && out16) {                                                          \
+    static const bool attr_ok =                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_i8_kernel<KT_, PTW_, 8, D_, 4, 8, 1, true, true>),  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;                     \
+    FQ_REQUIRE(attr_ok, "fq_conv3x3_i8_c16: cannot raise the dynamic LDS limit");                                      \
+    hipLaunchKernelGGL((conv3x3_i8_kernel<KT_, PTW_, 8, D_, 4, 8, 1, true, true>), dim3((unsigned)grid), dim3(512), lds, st, \
+                       x, wfrag, wscale, (const int*)wsum, bias, y, g, in_stat, n, in_thr, levels, lo_neg, kEps,       \
+                       out_current_max, bn_scale, bn_shift, act, stat_out, out_thr);                                   \
+    *launched = true;                                                                                                  \
+  }
+  FQ_C316_CASE8(8, 1, 6) FQ_C316_CASE8(8, 2, 4)
+#undef FQ_C316_CASE8
   return FQ_OK;
 }
 

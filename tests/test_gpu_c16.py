@@ -626,3 +626,26 @@ def test_wide_codes_in_codes_out_streaming_form_equals_the_split_form(dev, ops, 
                           in_thr=thr, width=8, flags=0, bn_scale=sc, bn_shift=sh, act=act)
     want = O.to_c16(O.ste_codes(yf.cpu().numpy(), O.act_scale(np.float32(1.9), False, 8), np.float32(1.9), np.float32(0)).astype(np.int64), 128)
     assert np.array_equal(part.t.cpu().numpy(), want)
+
+
+def test_dense3x3_on_codes_with_eight_wavefronts_equals_the_four_wavefront_form(dev, ops):
+    """Round 6: 256 -> 256 @14x14, codes in and codes out, takes eight wavefronts per workgroup once the layer fills the chip (batch
+    96: 294 blocks of 64 pixels).  Under a stored threshold samples are independent and a block of 64 flattened pixels never
+    reaches more than one sample back: the first samples of the full batch equal the same samples run alone (four wavefronts)."""
+    n, c, hw = 96, 256, 14
+    rng = torch.Generator(device="cpu").manual_seed(99)
+    t16 = torch.randint(-128, 128, (n, c // 16, hw * hw, 16), generator=rng, dtype=torch.int8).to(dev)
+    thr = torch.full((1,), 3.1, device=dev)
+    othr = torch.full((1,), 2.2, device=dev)
+    w = torch.randn(c, c, 3, 3, generator=rng).to(dev) * 0.02
+    codes, scales, rowsum = ops.weight_codes_3x3(w, 1, 8)
+    sc = (torch.rand(c, generator=rng) + 0.5).to(dev)
+    sh = torch.randn(c, generator=rng).to(dev) * 0.2
+    kw = dict(in_thr=thr, width=8, flags=0, bn_scale=sc, bn_shift=sh, act="relu", out_codes=dict(thr=othr, width=8, flags=0))
+    full, full_stat = ops.conv3x3_i8(ops.Codes16(t16, (n, c, hw, hw), thr, 8, 0), codes, scales, rowsum, **kw)
+    k = 5
+    part, part_stat = ops.conv3x3_i8(ops.Codes16(t16[:k].contiguous(), (k, c, hw, hw), thr, 8, 0), codes, scales, rowsum, **kw)
+    assert torch.equal(full.t[:k], part.t) and torch.equal(full_stat[:k], part_stat)
+    # ... and the last samples against the same samples alone (the tail of the flattened pixel order)
+    tail, tail_stat = ops.conv3x3_i8(ops.Codes16(t16[-k:].contiguous(), (k, c, hw, hw), thr, 8, 0), codes, scales, rowsum, **kw)
+    assert torch.equal(full.t[-k:], tail.t) and torch.equal(full_stat[-k:], tail_stat)
