@@ -350,6 +350,19 @@ int fq_pwconv_i8_sub2(const float* x, const int8_t* wcodes, const float* wscale,
                       const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual, void* ws,
                       fqStream_t stream);
 
+/* A 1x1 convolution and the global average pooling behind it in ONE launch (round 6).  The last 1x1 convolution of the MobileNets
+ * (gluon model_zoo: ... Conv2D(1x1), BatchNorm, Activation, GlobalAvgPool2D, Flatten, Dense; the reference wraps the convolution in
+ * convert_conv2d.py:53-66,108 and leaves the pooling to MXNet's Pooling operator) writes a tensor whose only reader is that pooling.
+ * This entry point computes the values of fq_pwconv_i8_strided(stride = 1, residual) and, without storing them, their plane means
+ * as fq_global_avg_pool_stat computes them - pixels added in the order 0 .. hw - 1 in fp64, divided by fp32(hw): bit for bit.
+ * y: (n, cout); stat_out[n] = max|y[n]| (the statistic the classifier's activation branch needs, convert_dense.py:41).
+ * Shapes: fq_pwconv_i8_gap_supported(n, cin, cout, hw, has_residual) - whole planes of 45 .. 64 pixels.                        */
+int fq_pwconv_i8_gap_supported(int64_t n, int64_t cin, int64_t cout, int64_t hw, int has_residual);
+int fq_pwconv_i8_gap(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                     float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                     const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                     const float* bn_shift, int act, float* stat_out, const float* residual, void* ws, fqStream_t stream);
+
 /* ---- a pointwise convolution and the depthwise 3x3 behind it WITHOUT the tensor between them (round 6) ---------------------
  * Under ONLINE input quantisation (convert_conv2d.py:56-58: the threshold of a block is the batch mean of the per-sample maxima
  * of the tensor it is handed in this very forward) a producer cannot hand codes to its consumer - the threshold exists only

@@ -98,6 +98,10 @@ int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float*
                               int64_t h, int64_t w, int stride, const float* in_stat, const float* in_thr, int in_width,
                               unsigned in_flags, float* out_current_max, const float* bn_scale, const float* bn_shift,
                               int act, float* stat_out, const float* residual, void* ws, fqStream_t stream);
+int fq_pwconv_i8_gap_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                          float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                          const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                          const float* bn_shift, int act, float* stat_out, const float* residual, void* ws, fqStream_t stream);
 int fq_pwconv_i8_sub2_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
                            float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
                            const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,

@@ -669,6 +669,20 @@ int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float*
                         in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual);
 }
 
+// fq_pwconv_i8_gap: the two storing twins back to back (the convolution's output exists on the host).
+int fq_pwconv_i8_gap_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                          float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                          const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                          const float* bn_shift, int act, float* stat_out, const float* residual, void*, fqStream_t st) {
+  REQUIRE(x && y && hw > 0, "fq_pwconv_i8_gap_host: bad arguments");
+  std::vector<float> full((size_t)(n * cout * hw));
+  const int prez = act & FQ_STAT_PREZEROED;
+  if (int rc = pwconv_i8_impl(x, wcodes, wscale, wsum, bias, full.data(), n, cin, cin_pad, cout, hw, in_stat, in_thr, in_width,
+                              in_flags, out_current_max, bn_scale, bn_shift, act & ~FQ_STAT_PREZEROED, nullptr, residual))
+    return rc;
+  return fq_global_avg_pool_stat_host(full.data(), y, n, cout, hw, prez, stat_out, st);
+}
+
 // fq_pwconv_i8_sub2: the whole stride-1 output on the host, of which the even pixels of the even rows are handed back.
 int fq_pwconv_i8_sub2_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
                            float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,

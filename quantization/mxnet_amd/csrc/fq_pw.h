@@ -43,6 +43,9 @@ struct PwCall {
   // fq_pwconv_i8_sub2: stride 1, y is the dense (n, cout, ceil(h_in / 2), ceil(w_in / 2)) tensor of the output's even pixels of
   // its even rows; statistic and residual operand cover the whole h_in x w_in planes (split form only)
   bool sub = false;
+  // fq_pwconv_i8_gap: y is (n, cout) - the mean of every output plane (global average pooling) - and stat_out the per-sample
+  // maximum of |mean|; the convolution's own output is not stored (sample form, whole small planes only)
+  bool gap = false;
   // fq_dense_i8_eval (rows form): the evaluation counters of the logits in the same launch
   const long long* eval_labels = nullptr;
   float* eval_counters = nullptr;
@@ -61,6 +64,7 @@ int pw_split16_launch(const PwCall& a, const void* geom, int kt, int cw, int64_t
 bool pw_split_sub_shape_ok(int64_t cin_pad, int64_t cout);        // fq_pw_split_sub.hip: the subsampled-output instantiations
 int pw_split_sub_launch(const PwCall& a, const void* geom, int kt, int64_t grid, size_t lds, const int8_t* wfrag, bool* launched);
 int pw_try_sample(const PwCall& c, bool* taken);    // K2r  fq_pw_sample.hip (14x14 planes)
+bool pw_sample_gap_shape_ok(int64_t n, int64_t cin, int64_t cout, int64_t hw, bool residual);   //      shapes of fq_pwconv_i8_gap
 int pw_try_pipe(const PwCall& c, bool* taken);      // K2w  fq_pw_pipe.hip (14x14 planes, K = 256 / 512: weights resident in registers)
 int pw_try_rows(const PwCall& c, bool* taken);      // K2t  fq_pw_rows.hip (planes of one pixel: the classifier)
 size_t pw_rows_eval_ws_bytes(int64_t n, int64_t cout);

@@ -74,7 +74,11 @@ struct PwSampleGeom {
 //     Planes of fewer than 64 pixels taken whole (7x7; the plane is not a multiple of four pixels: its last pixel is requested
 //     by a 4-byte load of its own) are one item of PT = 2.
 // RES: a residual operand of y's shape is added after BatchNorm, before the activation (the shortcut of a ResNet unit).
-template <int KT, int CTW, int PT, bool RES, int NI>
+// GAP (round 6, fq_pwconv_i8_gap; whole planes only, PT = 2): the layer's output is not stored - its only reader is the global average
+//     pooling behind it (the last 1x1 of the MobileNets, 26 MB written and read back by a 9 us launch of its own).  The epilogue's
+//     values go to an LDS tile [channel][pixel]; thread t then adds up channel t's pixels in the order and the precision
+//     fq_global_avg_pool_stat adds them (0 .. HW - 1, fp64) and stores the mean: y is (n, Cout), stat_out the per-sample max|mean|.
+template <int KT, int CTW, int PT, bool RES, int NI, bool GAP = false>
 __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 || PT == 2) ? 2 : 1)) void pwconv_sample_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwSampleGeom g,
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
   // RL: the residual operand arrives by LDS-DMA (two channel tiles x four pixel tiles only: 128 accumulator registers leave room
   // for two groups of residual values, i.e. four exposed memory latencies per item - see the epilogue)
   constexpr bool RL = RES && PT == 4 && CTW == 2 && NI == 1 && FQ_PWSMP_RESLDS;
+  static_assert(!GAP || (PT == 2 && NI == 1 && !RL), "the pooling epilogue takes whole planes (one item of two pixel tiles)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smp_dyn[];   // RL: 8 x 16 KB, [wavefront][32 channels][128 pixels]
   constexpr int KS = 4 / PT;                                            // K-steps of 32 channels per chunk
   constexpr int KI = KT / KS;                                           // chunks per item
@@ -405,6 +410,12 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
               m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
               continue;
             }
+            if (GAP) {                               // (PT = 2: pixel tiles 0 and 1; the tile keeps [channel][pixel])
+              float* const tp = reinterpret_cast<float*>(smp_dyn) + ((ctl0 + c) * 32 + 8 * gq + 4 * h + r) * g.HW + pl;
+              tp[0] = v.x;
+              if (last_ok) tp[32] = v.y;
+              continue;
+            }
             buf_st_f32(yr, po0 + 32u * pp * 4u, so, v.x);
             if (pp + 1 == PT - 1) {
               buf_st_f32(yr, po_last, so, v.y);
@@ -499,6 +510,19 @@ __global__ __launch_bounds__(512, (CTW == 1 && FQ_PWSMP_LB4) ? 4 : ((CTW == 1 ||
   PW_STAMP(2);
   finish_item(NI - 1);
   PW_STAMP(3);
+  if (GAP) {
+    __syncthreads();                                                    // the tile is complete
+    if (threadIdx.x < NCH) {
+      const float* const p = reinterpret_cast<const float*>(smp_dyn) + threadIdx.x * g.HW;
+      double acc = 0.0;
+      for (int i = 0; i < g.HW; ++i) acc += (double)p[i];
+      const float v = (float)acc / (float)g.HW;
+      y[(int64_t)smp * g.Cout + ch0 + (int)threadIdx.x] = v;
+      m = fabsf(v);
+    } else {
+      m = 0.0f;
+    }
+  }
   if (has_stat) {                                                       // the whole workgroup is one sample
     // ONE atomic per workgroup: with one per wavefront (4096 atomics on 128 addresses) the kernel got 3.5-6 us slower
     const float wm = wave_max_nonneg(m);
@@ -549,10 +573,11 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   const bool by_shape = a.form == 0 && (mode == 2 || (mode == 1 && base) ||
                                         (mode == 3 && (base || (small && a.residual == nullptr))) ||
                                         (mode == 4 && a.hw <= 1024 && !small) || (mode == 5 && !small && a.residual == nullptr));
-  if (!shape_ok || !(a.form == 7 || by_shape)) return FQ_OK;
+  if (a.gap && !(shape_ok && small)) return FQ_OK;                        // (fq_pwconv_i8_gap: whole small planes only; the caller refuses)
+  if (!shape_ok || !(a.form == 7 || by_shape || a.gap)) return FQ_OK;
   // ... and only where its workgroups (one per sample, block and 256 channels) reach a quarter of the CUs: below that the
   // split form's finer items win (MobileNet images/s +3.5 % at batch 8, equal at 16: profiles/r6_small_batch_forms_ab.txt)
-  if (a.form != 7 && a.n * (a.cout / 256) * nb < num_cu() / 4) return FQ_OK;
+  if (a.form != 7 && !a.gap && a.n * (a.cout / 256) * nb < num_cu() / 4) return FQ_OK;
   const int64_t rows_pad = (a.cout + 31) / 32 * 32;
   static const int ctw_tune = env_int("FQ_PWSMP_CTW", 0);               // tuning: 1 = 256 channels per workgroup everywhere
   // two channel tiles per wavefront (512 channels per workgroup, every value quantised once) from K = 512 up; below that
@@ -587,7 +612,7 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   if (int rc = pw_zero_stat(a)) return rc;
   bool launched = false;
 #define FQ_PWSMP_CASE_R(KT_, CTW_, PT_, RES_, NI_)                                                                     \
-  if (kt == KT_ && ctw == CTW_ && pt == PT_ && res == RES_ && ni == NI_) {                                             \
+  if (!a.gap && kt == KT_ && ctw == CTW_ && pt == PT_ && res == RES_ && ni == NI_) {                                   \
     /* (the residual operand staged in LDS: 8 wavefronts x 16 KB beside the 18 KB of panels and constants) */          \
     constexpr size_t dyn_ = (RES_ && PT_ == 4 && CTW_ == 2 && NI_ == 1 && FQ_PWSMP_RESLDS) ? 8 * 16384 : 0;             \
     if (dyn_ != 0) {                                                                                                   \
@@ -620,6 +645,22 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   FQ_PWSMP_CASE_R(16, 2, 2, true, 1)
 #undef FQ_PWSMP_CASE
 #undef FQ_PWSMP_CASE_R
+  // ... with the global average pooling behind them in the same launch (fq_pwconv_i8_gap): an LDS tile of NCH x HW floats
+#define FQ_PWSMP_GAP(KT_, CTW_, RES_)                                                                                  \
+  if (a.gap && kt == KT_ && ctw == CTW_ && pt == 2 && res == RES_ && ni == 1) {                                        \
+    static const bool attr_ok =                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_sample_kernel<KT_, CTW_, 2, RES_, 1, true>),         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;                     \
+    FQ_REQUIRE(attr_ok, "fq_pwconv_i8_gap: cannot raise the dynamic LDS limit of the sample kernel");                  \
+    hipLaunchKernelGGL((pwconv_sample_kernel<KT_, CTW_, 2, RES_, 1, true>), dim3((unsigned)grid), dim3(512),           \
+                       (size_t)(256 * CTW_) * (size_t)a.hw * sizeof(float), a.st, a.x, wfrag, a.wscale, (const int*)a.wsum, \
+                       a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, a.lo_neg, kEps, a.out_current_max,     \
+                       a.bn_scale, a.bn_shift, a.act, a.stat_out, a.residual);                                         \
+    launched = true;                                                                                                   \
+  }
+  FQ_PWSMP_GAP(16, 1, false) FQ_PWSMP_GAP(16, 2, false) FQ_PWSMP_GAP(32, 1, false) FQ_PWSMP_GAP(32, 2, false)
+  FQ_PWSMP_GAP(64, 1, false) FQ_PWSMP_GAP(64, 2, false) FQ_PWSMP_GAP(16, 2, true)
+#undef FQ_PWSMP_GAP
   if (!launched) {                                                     // (a combination that is not built: another form takes it)
     FQ_REQUIRE(a.form != 7, "fq_pwconv_i8: this K / channel-group / residual combination of the sample form is not built");
     return FQ_OK;
@@ -627,6 +668,13 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   FQ_LAUNCH_CHECK();
   *taken = true;
   return FQ_OK;
+}
+
+// shapes fq_pwconv_i8_gap takes: what pw_try_sample's whole-small-plane instantiations take
+bool pw_sample_gap_shape_ok(int64_t n, int64_t cin, int64_t cout, int64_t hw, bool residual) {
+  const int64_t kt = cin / 32;
+  return n > 0 && n < (1 << 20) && cin % 64 == 0 && hw >= 45 && hw <= 64 && hw % 4 <= 1 && cout % 256 == 0 &&
+         (kt == 16 || ((kt == 32 || kt == 64) && !residual)) && (!residual || cout % 512 == 0) && cin * hw * 4 < (1ll << 31);
 }
 
 }  // namespace fqi

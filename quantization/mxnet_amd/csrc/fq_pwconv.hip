@@ -78,7 +78,8 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
                            const float* residual, void* ws, fqStream_t stream, bool in_c16 = false,
                            const float* out_thr = nullptr, int out_width = 8, unsigned out_flags = 0,
                            const long long* eval_labels = nullptr, float* eval_counters = nullptr,
-                           void* eval_ws = nullptr, bool* range_taken = nullptr, void* y16 = nullptr, bool sub = false) {
+                           void* eval_ws = nullptr, bool* range_taken = nullptr, void* y16 = nullptr, bool sub = false,
+                           bool gap = false) {
   // range_taken != nullptr: range mode (fq_common.h: kRangeMode) - in_thr is a range record, bias holds int32 codes; only
   // the one-launch forms serve it and *range_taken says whether one took the shape
   const bool range = range_taken != nullptr;
@@ -130,6 +131,7 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   }
   c.eval_labels = eval_labels; c.eval_counters = eval_counters; c.eval_ws = eval_ws;
   c.sub = sub;
+  c.gap = gap;
   static const int pw_form = env_int("FQ_PW_FORM", 0);      // 0 auto, 1 two kernels, 3 stream, 6 split, 7 sample, 8 rows, 9 pipe
   c.form = (in_c16 || c.out_thr) ? 6 : (eval_labels ? 8 : (forced_form ? forced_form : pw_form));
   // tuning: FQ_PW_FORM_AT="<pixels per plane>:<form>[,...]" names a form for the layers of one plane size (A/Bs of a form choice
@@ -170,14 +172,22 @@ static int pwconv_dispatch(const float* x, const int8_t* wcodes, const float* ws
   // (second figure: the bytes really moved - 1 B per element of a side that is a C16 code tensor, 16-channel blocks padded)
   const double in_elems = (double)n * cin * hw, out_elems = (double)n * cout * hw;
   // (a subsampled output: the layer's algorithmic bytes stay those of the whole tensor; moved: the quarter that is stored)
-  const double stored = sub ? (double)n * cout * ((h_in + 1) / 2) * ((w_in + 1) / 2) : out_elems;
+  // (the pooling behind it in the same launch: the layer's and the pooling pass's algorithmic bytes; moved: n * cout means)
+  const double stored = gap ? (double)n * cout : (sub ? (double)n * cout * ((h_in + 1) / 2) * ((w_in + 1) / 2) : out_elems);
   const double moved = (in_c16 ? (double)n * ((cin + 15) / 16 * 16) * hw : 4.0 * in_elems) +
                        (c.out_thr != nullptr ? (double)n * ((cout + 15) / 16 * 16) * hw : 4.0 * stored) +
                        (y16 != nullptr ? (double)n * ((cout + 15) / 16 * 16) * (sub ? stored / ((double)n * cout) : (double)hw) : 0.0) +
                        (residual ? 4.0 * out_elems : 0.0);
-  ProfScope prof(hw == 1 ? FQ_KERNEL_DENSE : FQ_KERNEL_PWCONV, 4.0 * (in_elems + (residual ? 2.0 : 1.0) * out_elems), c.st, moved);
+  ProfScope prof(hw == 1 ? FQ_KERNEL_DENSE : FQ_KERNEL_PWCONV,
+                 4.0 * (in_elems + (residual ? 2.0 : 1.0) * out_elems + (gap ? out_elems + (double)n * cout : 0.0)), c.st, moved);
   bool taken = false;
   out_thr = c.out_thr;                                  // (from here on: "y is a C16 tensor")
+  if (gap) {                                            // (the sample form's whole-plane instantiations alone pool)
+    FQ_REQUIRE(c.form == 0 || c.form == 7, "fq_pwconv_i8_gap: only the sample form pools");
+    if (int rc = pw_try_sample(c, &taken)) return rc;
+    FQ_REQUIRE(taken, "fq_pwconv_i8_gap: shape not taken (see fq_pwconv_i8_gap_supported)");
+    return FQ_OK;
+  }
   if (sub) {                                            // (the split form alone stores subsampled)
     FQ_REQUIRE(c.form == 0 || c.form == 6, "fq_pwconv_i8_sub2: only the split form stores a subsampled output");
     if (int rc = pw_try_split(c, &taken)) return rc;
@@ -304,6 +314,26 @@ int fq_pwconv_i8_sub2(const float* x, const int8_t* wcodes, const float* wscale,
   return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, h * w, 1, h, w, w, in_stat, in_thr,
                          in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, ws, stream, false,
                          nullptr, 8, 0, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+}
+
+// A 1x1 convolution and the global average pooling behind it in ONE launch (round 6): the last 1x1 of the MobileNets
+// (features: ... Conv2D 1x1, BatchNorm, ReLU, GlobalAvgPool2D, Flatten), whose output has no other reader.  y: (n, cout) = what
+// fq_global_avg_pool_stat gives for the output of fq_pwconv_i8_strided(stride 1, residual): the same values added up in the same
+// order (pixels 0 .. hw - 1, fp64) - bit for bit; stat_out[n] = max|y[n]|.  Whole planes of 45 .. 64 pixels (7x7, 8x8).
+int fq_pwconv_i8_gap_supported(int64_t n, int64_t cin, int64_t cout, int64_t hw, int has_residual) {
+  return pw_sample_gap_shape_ok(n, cin, cout, hw, has_residual != 0) ? 1 : 0;
+}
+
+int fq_pwconv_i8_gap(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                     float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                     const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                     const float* bn_shift, int act, float* stat_out, const float* residual, void* ws, fqStream_t stream) {
+  FQ_REQUIRE(cin == cin_pad && pw_sample_gap_shape_ok(n, cin, cout, hw, residual != nullptr),
+             "fq_pwconv_i8_gap: shape not taken (n=%lld cin=%lld cout=%lld hw=%lld%s): see fq_pwconv_i8_gap_supported",
+             (long long)n, (long long)cin, (long long)cout, (long long)hw, residual ? ", residual" : "");
+  return pwconv_dispatch(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, hw, 1, 0, 0, 0, in_stat, in_thr, in_width,
+                         in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual, ws, stream, false, nullptr, 8, 0,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, false, true);
 }
 
 int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,

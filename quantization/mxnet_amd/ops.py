@@ -778,6 +778,48 @@ def pwconv_strided_supported(cin):
     return ((int(cin) + 63) // 64 * 64) // 32 in SPLIT_KT
 
 
+def pwconv_gap_supported(xshape, cout, residual=False):
+    """Shapes `pwconv_i8_gap` takes (fq_pwconv_i8_gap_supported): whole planes of 45 .. 64 pixels."""
+    if len(xshape) != 4:
+        return False
+    return bool(_lib_().fq_pwconv_i8_gap_supported(int(xshape[0]), int(xshape[1]), int(cout), int(xshape[2]) * int(xshape[3]),
+                                                    1 if residual else 0))
+
+
+def pwconv_i8_gap(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
+                  bn_scale=None, bn_shift=None, act=None, residual=None):
+    """`pwconv_i8` and the global average pooling behind it in one launch (fq_pwconv_i8_gap): returns (means (N, Cout, 1, 1), stat)
+    - what `global_avg_pool_stat(pwconv_i8(...)[0])` returns, bit for bit, without the tensor between."""
+    _check(x, "x")
+    _check(wcodes, "wcodes", torch.int8)
+    _check(wscale, "wscale")
+    _check(wsum, "wsum", torch.int32)
+    for name, t in (("bias", bias), ("in_stat", in_stat), ("in_thr", in_thr), ("bn_scale", bn_scale), ("bn_shift", bn_shift),
+                    ("cur_out", cur_out), ("residual", residual)):
+        if t is not None:
+            _check(t, name)
+    if x.dim() != 4:
+        raise ValueError("pwconv_i8_gap wants x (N, Cin, H, W); got %s" % (tuple(x.shape),))
+    n, cin, h, w = x.shape
+    cout = wscale.numel()
+    cin_pad = wcodes.shape[1]
+    if cin != cin_pad:
+        raise ValueError("pwconv_i8_gap: Cin = %d must be a multiple of 64" % cin)
+    if residual is not None and tuple(residual.shape) != (n, cout, h, w):
+        raise ValueError("the residual must have the convolution output's shape %s, got %s" % ((n, cout, h, w), tuple(residual.shape)))
+    if not pwconv_gap_supported(tuple(x.shape), cout, residual is not None):
+        raise ValueError("pwconv_i8_gap: shape %s -> %d channels is not taken (fq_pwconv_i8_gap_supported)" % (tuple(x.shape), cout))
+    if in_stat is not None and cur_out is None:
+        cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+    y = torch.empty((n, cout, 1, 1), dtype=torch.float32, device=x.device)
+    stat, zflag = _stat_target(n, x.device, True)
+    ws = torch.empty(_lib_().fq_pwconv_workspace_bytes(n, cin_pad, h * w), dtype=torch.uint8, device=x.device)
+    check_call(_lib_().fq_pwconv_i8_gap(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin, cin_pad, cout,
+                                        h * w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(cur_out), _ptr(bn_scale),
+                                        _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _ptr(residual), _ptr(ws), _stream(x)))
+    return y, stat
+
+
 def pwconv_sub2_supported(cin, cout):
     """Shapes `pwconv_i8(..., subsample=True)` takes (fq_pwconv_i8_sub2_supported)."""
     return bool(_lib_().fq_pwconv_i8_sub2_supported(int(cin), int(cout)))

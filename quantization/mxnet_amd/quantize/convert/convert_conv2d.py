@@ -339,6 +339,23 @@ def sub_target(block, fz, xshape):
     return link
 
 
+def gap_target(block, fz, c16_in, xshape, residual):
+    """The GlobalAvgPool2D block behind this fused 1x1 convolution (quantize/fuse.py links `gap_next`) when the convolution may hand
+    it the plane means instead of the planes (fq_pwconv_i8_gap): nothing else reads the tensor, nothing observes it (no hooks, no
+    KL collection), the call is part of the rewired net's forward and the shape is one the pooling epilogue takes."""
+    from .. import fuse as _fuse
+    link = fz.get("gap_next")
+    if link is None or not _fuse.GAP_FUSE or c16_in is not None or autograd.is_recording() or _fuse._collection is not None:
+        return None
+    if getattr(ops.StatArena._tls, "current", None) is None or block._kwargs["stride"] != (1, 1):
+        return None
+    if any(_hooked(b) for b in (block, fz.get("bn"), fz.get("act_block"), link["gap"]) + tuple(link["via"])):
+        return None
+    if not ops.pwconv_gap_supported(xshape, block._kwargs["num_filter"], residual):
+        return None
+    return link["gap"]
+
+
 def _convolve(block, F, x, weight, bias):
     """convert_conv2d.py:108 - the block's own convolution; of a subsampled trunk (`_fq_sub2`: this block is one of its
     stride-2 1x1 readers) the stride-1 convolution of what was stored, which is the same values."""
@@ -522,6 +539,16 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                         out_codes = None
                 if out_codes is not None:
                     extra = dict(out_codes=out_codes)
+            if not extra or (set(extra) == {"residual"} and side_blk is None):
+                gap = gap_target(block, fz, c16_in, xshape, "residual" in extra)
+                if gap is not None:
+                    y, stat = ops.pwconv_i8_gap(x_arg, codes, scales, rowsum, None if bias is None else bias._t, bn_scale=scale,
+                                                bn_shift=shift, act=res["act"] if "residual" in extra else fz["act"],
+                                                residual=extra.get("residual"), **plan)
+                    pooled = NDArray(y)
+                    pooled._fq_stat = stat
+                    pooled._fq_pooled_by = gap                # (the pooling block behind hands THIS tensor through)
+                    return pooled
             pair = recompute_target(block, fz, x, plan, c16_in) if not extra else None
             if pair is not None:
                 # statistic only; the depthwise block behind recomputes the values inside its own launch

@@ -169,6 +169,9 @@ RECOMPUTE_MAX_CIN = int(_os.environ.get("FQ_RECOMPUTE_MAX_CIN", "128"))      # (
 # Subsampled trunk (round 6, fq_pwconv_i8_sub2): the closing 1x1 of a ResNet-v1 stage stores only the pixels its two readers -
 # the next stage's first 1x1 and shortcut 1x1, both stride 2 without padding - look at (FQ_SUBSAMPLE=0: the whole tensor; A/B)
 SUBSAMPLE = _os.environ.get("FQ_SUBSAMPLE", "1") != "0"
+# Pooled producer (round 6, fq_pwconv_i8_gap): the 1x1 convolution in front of a global average pooling - the last 1x1 of the
+# MobileNets, the closing 1x1 of ResNet-50's last unit - hands the plane means over instead of the planes (FQ_GAP_FUSE=0: two launches)
+GAP_FUSE = _os.environ.get("FQ_GAP_FUSE", "1") != "0"
 UNIT_LINKS = _os.environ.get("FQ_HANDOVER_UNITS", "1") != "0"      # hand-over from a MobileNetV2 unit without shortcut to the next block (A/B)
 
 
@@ -272,6 +275,9 @@ def _stem_forward(self, F, x, weight, bias=None):
 
 
 def _gap_stat_forward(self, F, x):
+    if getattr(x, "_fq_pooled_by", None) is self:       # (the producer's launch pooled already: fq_pwconv_i8_gap)
+        x._fq_pooled_by = None
+        return x
     t = x._t if x._t.is_contiguous() else x._t.contiguous()
     y, stat = ops.global_avg_pool_stat(t, want_stat=True)
     out = NDArray(y)
@@ -511,6 +517,24 @@ def fuse_inference(net, depthwise=True, pointwise_int8=True, stem=True, residual
             b._fq_gap_fused = {"orig": b.hybrid_forward, "flatten": flat,
                                "flatten_orig": None if flat is None else flat.hybrid_forward}
             b.hybrid_forward = types.MethodType(_gap_stat_forward, b)
+            # the producer of the pooled tensor when that is a fused 1x1 convolution with no other reader: the convolution right in
+            # front of the pooling (behind the BatchNorm / activation it folded: the MobileNets), or the closing 1x1 of the last
+            # residual unit of the stage in front of it (ResNet-50) - convert_conv2d.gap_target
+            own = list(container._children.values())
+            if i < len(own) and own[i] is b and type(container) in (nn.Sequential, nn.HybridSequential) \
+                    and "forward" not in container.__dict__:
+                for k, c in enumerate(own[:i]):
+                    fz = getattr(c, "_fq_pw_fused", None)
+                    if fz is not None and fz.get("kind") == "1x1" and type(c) is nn.Conv2D and hasattr(c, "quantize_args") and \
+                            k + 1 + (1 if fz["bn"] is not None else 0) + (1 if fz["act_block"] is not None else 0) == i:
+                        fz["gap_next"] = {"gap": b, "via": ()}
+                prev = own[i - 1] if i > 0 else None
+                if type(prev) in (nn.Sequential, nn.HybridSequential) and "forward" not in prev.__dict__ and len(prev._children):
+                    unit = list(prev._children.values())[-1]
+                    if _is_residual_unit(unit):
+                        tail = _tail_conv(unit.body)
+                        if tail is not None and hasattr(tail, "quantize_args"):
+                            tail._fq_pw_fused["gap_next"] = {"gap": b, "via": (unit, prev)}
             if flat is not None:
                 flat.hybrid_forward = types.MethodType(_flatten_keep_stat_forward, flat)
             fused[0] += 1
