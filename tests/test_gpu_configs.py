@@ -320,8 +320,22 @@ def test_config2_mobilenet_fused_producers_full_batch_against_host_twins(gpu):
         _same(np_(zstat), wstat, "its statistic")
         seen["dw"] += 1
         return z, zstat
+    # the pooled producer (round 6): the last 1x1 and the pooling behind it in one launch, against the twins of both
+    real["pwconv_i8_gap"] = ops.pwconv_i8_gap
+
+    def pw_gap(x, codes, scales, rowsum, bias=None, **k):
+        y, stat = real["pwconv_i8_gap"](x, codes, scales, rowsum, bias, **k)
+        full, _, cur = pw_host(x, codes, scales, rowsum, bias, k["in_stat"], k["width"], k["flags"], k.get("bn_scale"),
+                               k.get("bn_shift"), k.get("act"))
+        want, wstat = H.global_avg_pool(full, want_stat=True)
+        _same(np_(y).reshape(want.shape), want, "pointwise + global average pool in one launch %s" % (tuple(x.shape),))
+        _same(np_(stat), wstat, "its statistic")
+        assert np_(k["cur_out"])[0] == cur[0]
+        seen["pw"] += 1
+        seen["gap"] += 1
+        return y, stat
     ops.dwconv3x3, ops.pwconv_i8, ops.stem_conv_s2, ops.global_avg_pool_stat = dw, pw, stem, gap
-    ops.pwconv_i8_stat, ops.pwdw_fused = pw_stat, pwdw
+    ops.pwconv_i8_stat, ops.pwdw_fused, ops.pwconv_i8_gap = pw_stat, pwdw, pw_gap
     try:
         out = net(X)
     finally:
