@@ -554,7 +554,9 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   const bool small = a.hw <= 64;                                        // one block of two pixel tiles
   const int64_t quads = (a.hw + 3) / 4;
   const int nb = small ? 1 : (int)((quads + 31) / 32);                  // fewest blocks of at most 32 pixel groups
-  const bool plane_ok = small ? (a.hw >= 45 && a.hw % 4 <= 1 && (kt == 16 || ((kt == 32 || kt == 64) && a.residual == nullptr)))
+  // (K = 320 - MobileNetV2's last 1x1 - only with the pooling epilogue, fq_pwconv_i8_gap)
+  const bool plane_ok = small ? (a.hw >= 45 && a.hw % 4 <= 1 && (kt == 16 || ((kt == 32 || kt == 64) && a.residual == nullptr) ||
+                                                                 (kt == 10 && a.gap && a.residual == nullptr)))
                               : (a.hw % 4 == 0 && quads / nb >= 24 && (kt == 4 || kt == 8 || kt == 16 || kt == 32));
   const bool shape_ok = plane_ok && a.stride == 1 && a.cin == a.cin_pad && a.cout % 256 == 0 &&
                         a.n < (1 << 20) && a.cin * a.hw * 4 < (1ll << 31) && (small || aligned16(a.x)) &&
@@ -660,6 +662,7 @@ int pw_try_sample(const PwCall& a, bool* taken) {
   }
   FQ_PWSMP_GAP(16, 1, false) FQ_PWSMP_GAP(16, 2, false) FQ_PWSMP_GAP(32, 1, false) FQ_PWSMP_GAP(32, 2, false)
   FQ_PWSMP_GAP(64, 1, false) FQ_PWSMP_GAP(64, 2, false) FQ_PWSMP_GAP(16, 2, true)
+  FQ_PWSMP_GAP(10, 1, false) FQ_PWSMP_GAP(10, 2, false)                 // (320 -> 1280 @7x7: MobileNetV2)
 #undef FQ_PWSMP_GAP
   if (!launched) {                                                     // (a combination that is not built: another form takes it)
     FQ_REQUIRE(a.form != 7, "fq_pwconv_i8: this K / channel-group / residual combination of the sample form is not built");
@@ -674,7 +677,8 @@ int pw_try_sample(const PwCall& a, bool* taken) {
 bool pw_sample_gap_shape_ok(int64_t n, int64_t cin, int64_t cout, int64_t hw, bool residual) {
   const int64_t kt = cin / 32;
   return n > 0 && n < (1 << 20) && cin % 64 == 0 && hw >= 45 && hw <= 64 && hw % 4 <= 1 && cout % 256 == 0 &&
-         (kt == 16 || ((kt == 32 || kt == 64) && !residual)) && (!residual || cout % 512 == 0) && cin * hw * 4 < (1ll << 31);
+         (kt == 16 || ((kt == 10 || kt == 32 || kt == 64) && !residual)) && (!residual || cout % 512 == 0) &&
+         cin * hw * 4 < (1ll << 31);
 }
 
 }  // namespace fqi

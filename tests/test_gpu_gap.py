@@ -47,6 +47,7 @@ CASES = [
     (3, 2048, 512, 7, 7, False),        # K / 32 = 64
     (4, 512, 2048, 7, 7, True),         # ResNet-50's last closing 1x1, with its residual operand
     (3, 512, 1024, 8, 8, False),        # 64-pixel planes (256 x 256 images)
+    (5, 320, 1280, 7, 7, False),        # MobileNetV2's last 1x1 (K / 32 = 10, five channel groups of 256)
 ]
 MODES = ["online_u8_bn_relu", "online_s8_bn_none", "offline_u8_bias_relu6"]
 
@@ -94,7 +95,8 @@ def test_gap_producer_equals_the_two_launches_and_the_host_twin(dev, ops, case, 
 
 def test_gap_producer_refuses_what_it_is_not_built_for(dev, ops):
     assert ops.pwconv_gap_supported((4, 1024, 7, 7), 1024) and not ops.pwconv_gap_supported((4, 1024, 14, 14), 1024)
-    assert not ops.pwconv_gap_supported((4, 320, 7, 7), 1280) and not ops.pwconv_gap_supported((4, 1024, 7, 7), 1000)
+    assert ops.pwconv_gap_supported((4, 320, 7, 7), 1280) and not ops.pwconv_gap_supported((4, 1024, 7, 7), 1000)
+    assert not ops.pwconv_gap_supported((4, 192, 7, 7), 1280)
     x = torch.zeros(2, 1024, 14, 14, device=dev)
     codes, scales, rowsum = ops.weight_codes(torch.ones(1024, 1024, device=dev), 1, 8)
     with pytest.raises(ValueError):
@@ -147,3 +149,43 @@ def test_a_net_with_the_pooled_producer_equals_the_same_net_without(dev, ops, mo
         hk.detach()
     assert len(shapes) == 1 and shapes[0][2:] == (7, 7)
     _eq(got, outs[True][0], "logits with a hook on the pooling block")
+
+
+def test_mobilenetv2_offline_with_the_pooled_producer_equals_the_same_net_without(dev, ops):
+    """BASELINE configuration 4 (per-channel W4A8, stored thresholds): the last 1x1 (320 -> 1280, ReLU6) hands the plane means to the
+    un-quantised classifier convolution; logits and every block's current_input_max bit-equal with and without."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.quantize import fuse
+    from test_gpu_net import _build as build
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        rng = np.random.default_rng(4)
+        xs = [mx.nd.array(rng.standard_normal((6, 3, 224, 224)).astype(np.float32), ctx=mx.gpu(0)) for _ in range(3)]
+        outs = {}
+        for on in (False, True):
+            net = build("mobilenetv2_1.0", 1000, mx.gpu(0), quant_type="channel", wt=4)
+            net.quantize_input(enable=True, online=True)
+            for x in xs[:2]:
+                net(x)
+                net.update_ema()
+            net.fix_params()
+            net.quantize_input(enable=True, online=False)
+            net(xs[2])
+            fuse.fuse_inference(net)
+            old, fuse.GAP_FUSE = fuse.GAP_FUSE, on
+            seen = []
+            real = ops.pwconv_i8_gap
+            ops.pwconv_i8_gap = lambda *a, **k: (seen.append(tuple(a[0].shape)), real(*a, **k))[1]
+            try:
+                out = net(xs[2])
+                cur = np.asarray([float(b.current_input_max) for b in net.collect_quantized_blocks()], np.float32)
+            finally:
+                fuse.GAP_FUSE = old
+                ops.pwconv_i8_gap = real
+            outs[on] = (N(out._t), cur, seen)
+        assert outs[False][2] == [] and outs[True][2] == [(6, 320, 7, 7)], outs[True][2]
+        _eq(outs[True][0], outs[False][0], "logits")
+        _eq(outs[True][1], outs[False][1], "current_input_max of every block")
+    finally:
+        torch.backends.cudnn.deterministic = was
