@@ -9,7 +9,7 @@ import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 with open(sys.argv[2], 'w') as out:
-    for r in rows[:40]:
+    for r in rows[:80]:
         n = r['Name']
         n = n.replace('(anonymous namespace)::', '').replace('void ', '')
         n = re.sub(r'\((?:[^()]|\([^()]*\))*\)\s*(\[clone.*)?$', '', n)    # the argument list only
