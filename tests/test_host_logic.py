@@ -661,3 +661,21 @@ def test_dense_on_an_unflattened_input_takes_the_statistic_the_reference_takes()
         blk(xa)
     assert np.float32(float(blk.current_input_max)) == np.float32(want_cur)
     np.testing.assert_array_equal(seen["xq"], y)
+
+
+def test_every_environment_variable_the_product_reads_is_listed_in_docs_knobs():
+    """the tuning surface is one table - a variable read anywhere in the package, bench.py or the examples and
+    missing from docs/knobs.md fails here."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [f for f in glob.glob(os.path.join(root, "quantization", "**", "*"), recursive=True)
+             if f.endswith((".py", ".hip", ".h"))] + [os.path.join(root, "bench.py")] + glob.glob(os.path.join(root, "examples", "*.py"))
+    names = set()
+    for f in files:
+        t = open(f, errors="ignore").read()
+        names |= set(re.findall(r'(?:env_int|getenv|environ\.get|environ\[|setdefault)\(\s*["\'](FQ_[A-Z0-9_]+)["\']', t))
+    doc = open(os.path.join(root, "docs", "knobs.md")).read()
+    assert len(names) >= 70
+    assert sorted(n for n in names if n not in doc) == []
