@@ -350,6 +350,24 @@ int fq_pwconv_i8_sub2(const float* x, const int8_t* wcodes, const float* wscale,
                       const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* residual, void* ws,
                       fqStream_t stream);
 
+/* The closing 1x1 convolution of a residual unit and the unit's shortcut convolution in ONE launch (round 6).  gluon's BottleneckV1
+ * with a `downsample` branch - the first unit of every stage of the v1 ResNets - computes
+ *   act(BatchNorm3(conv3(x)) + BatchNormD(convD(x2)))            (conv3: the body's last 1x1; convD: `downsample[0]`, a 1x1 of the
+ * unit's input; each wrapped by convert_conv2d.py:53-66,108): the shortcut tensor is as large as the result, has no other reader and
+ * feeds no quantised block.  This entry point computes the sum without it - both integer convolutions per (pixel tile, channel
+ * group), the same fp32 operations in the same order as fq_pwconv_i8_strided(x2 ..., no activation) followed by
+ * fq_pwconv_i8_strided(x ..., residual = that): bit-equal.  x: (n, cin, hw), x2: (n, cin2, hw) fp32 (a strided shortcut reads the
+ * subsampled trunk of fq_pwconv_i8_sub2); `..2` arguments are the shortcut convolution's (no bias; its BatchNorm is mandatory);
+ * stat_out[n] = max|y[n]|.  Shapes: fq_pwconv_i8_shortcut_supported(cin, cin2, cout).                                            */
+int fq_pwconv_i8_shortcut_supported(int64_t cin, int64_t cin2, int64_t cout);
+int fq_pwconv_i8_shortcut(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                          float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                          const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                          const float* bn_shift, int act, float* stat_out, const float* x2, const int8_t* wcodes2,
+                          const float* wscale2, const int32_t* wsum2, int64_t cin2, int64_t cin2_pad, const float* in_stat2,
+                          const float* in_thr2, int in_width2, unsigned in_flags2, float* out_current_max2,
+                          const float* bn_scale2, const float* bn_shift2, fqStream_t stream);
+
 /* A 1x1 convolution and the global average pooling behind it in ONE launch (round 6).  The last 1x1 convolution of the MobileNets
  * (gluon model_zoo: ... Conv2D(1x1), BatchNorm, Activation, GlobalAvgPool2D, Flatten, Dense; the reference wraps the convolution in
  * convert_conv2d.py:53-66,108 and leaves the pooling to MXNet's Pooling operator) writes a tensor whose only reader is that pooling.

@@ -669,6 +669,23 @@ int fq_pwconv_i8_strided_host(const float* x, const int8_t* wcodes, const float*
                         in_width, in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, residual);
 }
 
+// fq_pwconv_i8_shortcut: the two storing twins back to back (the shortcut tensor exists on the host).
+int fq_pwconv_i8_shortcut_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                               float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                               const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                               const float* bn_scale, const float* bn_shift, int act, float* stat_out, const float* x2,
+                               const int8_t* wcodes2, const float* wscale2, const int32_t* wsum2, int64_t cin2, int64_t cin2_pad,
+                               const float* in_stat2, const float* in_thr2, int in_width2, unsigned in_flags2,
+                               float* out_current_max2, const float* bn_scale2, const float* bn_shift2, fqStream_t) {
+  REQUIRE(x && x2 && y && hw > 0, "fq_pwconv_i8_shortcut_host: bad arguments");
+  std::vector<float> sc((size_t)(n * cout * hw));
+  if (int rc = pwconv_i8_impl(x2, wcodes2, wscale2, wsum2, nullptr, sc.data(), n, cin2, cin2_pad, cout, hw, in_stat2, in_thr2,
+                              in_width2, in_flags2, out_current_max2, bn_scale2, bn_shift2, FQ_ACT_NONE, nullptr, nullptr))
+    return rc;
+  return pwconv_i8_impl(x, wcodes, wscale, wsum, bias, y, n, cin, cin_pad, cout, hw, in_stat, in_thr, in_width, in_flags,
+                        out_current_max, bn_scale, bn_shift, act, stat_out, sc.data());
+}
+
 // fq_pwconv_i8_gap: the two storing twins back to back (the convolution's output exists on the host).
 int fq_pwconv_i8_gap_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
                           float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,

@@ -238,6 +238,20 @@ def pwconv_gap_supported(xshape, cout, residual=False):
     return False                              # (the oracle pools in a pass of its own)
 
 
+def pwconv_shortcut_supported(cin, cin2, cout):
+    return cout % 256 == 0
+
+
+def pwconv_i8_shortcut(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
+                       bn_scale=None, bn_shift=None, act=None, x2=None, wcodes2=None, wscale2=None, wsum2=None, in_stat2=None,
+                       in_thr2=None, width2=8, flags2=0, cur_out2=None, bn_scale2=None, bn_shift2=None):
+    """fq_pwconv_i8_shortcut: the shortcut convolution (+ BatchNorm, no activation), then the closing one with it as residual"""
+    s, _ = pwconv_i8(x2, wcodes2, wscale2, wsum2, None, in_stat=in_stat2, in_thr=in_thr2, width=width2, flags=flags2,
+                     cur_out=cur_out2, bn_scale=bn_scale2, bn_shift=bn_shift2, act=None, want_stat=False)
+    return pwconv_i8(x, wcodes, wscale, wsum, bias, in_stat=in_stat, in_thr=in_thr, width=width, flags=flags, cur_out=cur_out,
+                     bn_scale=bn_scale, bn_shift=bn_shift, act=act, residual=s)
+
+
 def pwconv_i8(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
               bn_scale=None, bn_shift=None, act=None, want_stat=True, form=None, stride=1, residual=None, subsample=False):
     """(subsample: the statistic of the whole output, then its even pixels of its even rows - fq_pwconv_i8_sub2)"""
@@ -499,7 +513,7 @@ def default_device(what="this call"):
 
 
 _REPLACED = ["require_hip", "default_device", "add_act_stat", "stat_rows_sum", "mean_from_sums", "batch_mean_rows", "batch_mean_gathered", "fake_quant_online_prestat",
-             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "dense_i8_eval", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "pwconv_sub2_supported", "pwconv_gap_supported", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
+             "bn_act_stat", "bn_act_maxpool_stat", "eval_counters", "dense_i8_eval", "gemm_i8_codes", "global_avg_pool_stat", "stem_conv3x3s2", "stem_conv_s2", "dwconv3x3", "weight_codes", "pwconv_i8", "pwconv_strided_supported", "pwconv_sub2_supported", "pwconv_gap_supported", "pwconv_shortcut_supported", "pwconv_i8_shortcut", "weight_codes_3x3", "weight_slices_3x3", "conv3x3_i8", "absmax_per_sample", "batch_mean", "fake_quant_online", "fake_quant_offline", "ste_forward",
              "weight_fake_quant", "wino_weight_fake_quant", "ema_update", "global_max", "histogram_accumulate",
              "hist_to_float", "kl_search", "quantize_codes", "dequantize", "qconv_weights", "qconv_workspace", "qconv2d"]
 

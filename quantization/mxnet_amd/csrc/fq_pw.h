@@ -55,6 +55,9 @@ struct PwCall {
 // K2z  fq_pwdw.hip: the statistic-only pass (fq_pwconv_i8_stat): stat_out and out_current_max only, c.y is not touched
 bool pw_stat_shape_ok(int64_t n, int64_t cin, int64_t cout, int64_t hw);
 int pw_stat_launch(const PwCall& c);
+// K2s  fq_pw_short.hip: the closing 1x1 of a residual unit (a) with the unit's shortcut convolution (b) in the same launch
+bool pw_short_shape_ok(int64_t cin, int64_t cin2, int64_t cout);
+int pw_short_launch(const PwCall& a, const PwCall& b);
 int pw_try_stream(const PwCall& c, bool* taken);    // K2h  fq_pw_stream.hip
 bool pw_stream_shape_ok(const PwCall& c);           //      shapes the streaming form takes
 bool pw_stream_thin_takes(const PwCall& c);         //      ... and the thin instantiations (C16 input, ragged Cin / Cout) on large planes

@@ -336,6 +336,53 @@ int fq_pwconv_i8_gap(const float* x, const int8_t* wcodes, const float* wscale, 
                          nullptr, nullptr, nullptr, nullptr, nullptr, false, true);
 }
 
+// The closing 1x1 convolution of a residual unit and the unit's shortcut convolution in ONE launch (round 6; K2s, fq_pw_short.hip):
+//   y = act(BN3(conv3(x)) + BNd(convd(x2)))
+// - the values fq_pwconv_i8_strided(x2 ..., stride 1, no activation) followed by fq_pwconv_i8_strided(x ..., residual = that)
+// give, bit for bit, without the shortcut tensor.  Both inputs fp32 (n, cin / cin2, hw); both convolutions quantise their inputs
+// on load with their own statistic or threshold and leave their own current_input_max.
+int fq_pwconv_i8_shortcut_supported(int64_t cin, int64_t cin2, int64_t cout) {
+  return pw_short_shape_ok(cin, cin2, cout) ? 1 : 0;
+}
+
+int fq_pwconv_i8_shortcut(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                          float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                          const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                          const float* bn_shift, int act, float* stat_out, const float* x2, const int8_t* wcodes2,
+                          const float* wscale2, const int32_t* wsum2, int64_t cin2, int64_t cin2_pad, const float* in_stat2,
+                          const float* in_thr2, int in_width2, unsigned in_flags2, float* out_current_max2,
+                          const float* bn_scale2, const float* bn_shift2, fqStream_t stream) {
+  FQ_REQUIRE(x && wcodes && wscale && wsum && y && x2 && wcodes2 && wscale2 && wsum2 && bn_scale2 && bn_shift2,
+             "fq_pwconv_i8_shortcut: null pointer (the shortcut convolution needs its BatchNorm constants)");
+  FQ_REQUIRE(n > 0 && hw > 0 && hw < (1ll << 30) && n * hw < (1ll << 31) - 512, "fq_pwconv_i8_shortcut: bad shape");
+  FQ_REQUIRE((in_stat || in_thr) && (in_stat2 || in_thr2), "fq_pwconv_i8_shortcut: each convolution needs in_stat (online) or in_thr");
+  FQ_REQUIRE((in_thr || out_current_max) && (in_thr2 || out_current_max2), "fq_pwconv_i8_shortcut: online mode needs out_current_max");
+  FQ_REQUIRE(in_width >= 2 && in_width <= 8 && in_width2 >= 2 && in_width2 <= 8, "fq_pwconv_i8_shortcut: input widths must fit int8 codes");
+  FQ_REQUIRE(!((in_flags | in_flags2) & (FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)), "fq_pwconv_i8_shortcut: unsupported activation flags");
+  FQ_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "fq_pwconv_i8_shortcut: bn_scale and bn_shift go together");
+  PwCall a, b;
+  a.prezeroed = (act & FQ_STAT_PREZEROED) != 0;
+  act &= ~FQ_STAT_PREZEROED;
+  FQ_REQUIRE(act >= FQ_ACT_NONE && act <= FQ_ACT_RELU6, "fq_pwconv_i8_shortcut: unknown activation %d", act);
+  FQ_REQUIRE(aligned16(wcodes) && aligned16(wcodes2), "fq_pwconv_i8_shortcut: the weight codes must be 16-byte aligned");
+  a.x = x; a.wcodes = wcodes; a.wscale = wscale; a.wsum = wsum; a.bias = bias; a.y = y;
+  a.n = n; a.cin = cin; a.cin_pad = cin_pad; a.cout = cout; a.hw = hw; a.stride = 1; a.h_in = a.w_in = a.w_out = 0;
+  a.in_stat = in_stat; a.in_thr = in_thr; a.levels = act_levels(in_width, in_flags);
+  a.lo_neg = (in_flags & FQ_ACT_LO_NEG_MAX) ? 1 : 0; a.zoff = (in_flags & FQ_ACT_SIGNED) ? 0 : 128;
+  a.out_current_max = out_current_max; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.act = act; a.stat_out = stat_out;
+  a.residual = nullptr; a.ws = nullptr; a.st = (hipStream_t)stream; a.form = 0;
+  b = a;
+  b.x = x2; b.wcodes = wcodes2; b.wscale = wscale2; b.wsum = wsum2; b.bias = nullptr; b.y = nullptr;
+  b.cin = cin2; b.cin_pad = cin2_pad; b.in_stat = in_stat2; b.in_thr = in_thr2; b.levels = act_levels(in_width2, in_flags2);
+  b.lo_neg = (in_flags2 & FQ_ACT_LO_NEG_MAX) ? 1 : 0; b.zoff = (in_flags2 & FQ_ACT_SIGNED) ? 0 : 128;
+  b.out_current_max = out_current_max2; b.bn_scale = bn_scale2; b.bn_shift = bn_shift2; b.act = FQ_ACT_NONE; b.stat_out = nullptr;
+  // algorithmic bytes: those of the two layers it stands for (shortcut: in + out; closing: in + residual + out); moved: both
+  // inputs and the output
+  const double in1 = (double)n * cin * hw, in2 = (double)n * cin2 * hw, out = (double)n * cout * hw;
+  ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * (in2 + out + in1 + 2.0 * out), a.st, 4.0 * (in1 + in2 + out));
+  return pw_short_launch(a, b);
+}
+
 int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                      const float* bias, void* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t h, int64_t w,
                      int stride, const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,

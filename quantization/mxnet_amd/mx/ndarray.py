@@ -79,7 +79,11 @@ class NDArray(object):
     # _fq_sub2: optional dict - `_t` holds only [:, :, ::2, ::2] of the tensor this NDArray stands for (`hw`: its plane), because
     # its only readers (`readers`: two Conv2D blocks, 1x1, stride 2, no padding; `unit`: the residual unit that owns them) never
     # look at the rest; `_fq_stat` is the statistic of the WHOLE tensor (fq_pwconv_i8_sub2; convert_conv2d.sub_target).
-    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl", "_fq_side", "_fq_deferred", "_fq_pooled_by", "_fq_sub2")
+    # _fq_short: optional dict - this NDArray stands for the output of a residual unit's shortcut convolution (+ BatchNorm) that was
+    # NOT computed: the unit's closing 1x1 computes it inside its own launch (fq_pwconv_i8_shortcut) from the record's operands, or
+    # whoever else gets hold of it materialises it (convert_conv2d.materialise_shortcut).  `_t` is a placeholder without storage.
+    __slots__ = ("_t", "_fq_stat", "_fq_c16", "_fq_nonneg", "_fq_kl", "_fq_side", "_fq_deferred", "_fq_pooled_by", "_fq_sub2",
+                 "_fq_short")
     __array_priority__ = 1000.0
     __array_ufunc__ = None
 
@@ -94,6 +98,7 @@ class NDArray(object):
         self._fq_deferred = None
         self._fq_pooled_by = None
         self._fq_sub2 = None
+        self._fq_short = None
 
     # -- plumbing ---------------------------------------------------------------------------
     @property

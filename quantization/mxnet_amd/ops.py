@@ -778,6 +778,51 @@ def pwconv_strided_supported(cin):
     return ((int(cin) + 63) // 64 * 64) // 32 in SPLIT_KT
 
 
+def pwconv_shortcut_supported(cin, cin2, cout):
+    """Shapes `pwconv_i8_shortcut` takes (fq_pwconv_i8_shortcut_supported): the stage heads of the v1 bottleneck ResNets."""
+    return bool(_lib_().fq_pwconv_i8_shortcut_supported(int(cin), int(cin2), int(cout)))
+
+
+def pwconv_i8_shortcut(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
+                       bn_scale=None, bn_shift=None, act=None, x2=None, wcodes2=None, wscale2=None, wsum2=None, in_stat2=None,
+                       in_thr2=None, width2=8, flags2=0, cur_out2=None, bn_scale2=None, bn_shift2=None):
+    """The closing 1x1 convolution of a residual unit and the unit's shortcut convolution (`..2` arguments: 1x1 on x2, BatchNorm,
+    no activation, no bias) in one launch (fq_pwconv_i8_shortcut): what `pwconv_i8(x, ..., residual=pwconv_i8(x2, ...)[0])` returns,
+    bit for bit, without the shortcut tensor.  Returns (y, stat)."""
+    for name, t, dt in (("x", x, None), ("wcodes", wcodes, torch.int8), ("wscale", wscale, None), ("wsum", wsum, torch.int32),
+                        ("x2", x2, None), ("wcodes2", wcodes2, torch.int8), ("wscale2", wscale2, None), ("wsum2", wsum2, torch.int32),
+                        ("bn_scale2", bn_scale2, None), ("bn_shift2", bn_shift2, None)):
+        if dt is None:
+            _check(t, name)
+        else:
+            _check(t, name, dt)
+    for name, t in (("bias", bias), ("in_stat", in_stat), ("in_thr", in_thr), ("bn_scale", bn_scale), ("bn_shift", bn_shift),
+                    ("cur_out", cur_out), ("in_stat2", in_stat2), ("in_thr2", in_thr2), ("cur_out2", cur_out2)):
+        if t is not None:
+            _check(t, name)
+    if x.dim() != 4 or x2.dim() != 4 or tuple(x.shape[2:]) != tuple(x2.shape[2:]) or x.shape[0] != x2.shape[0]:
+        raise ValueError("pwconv_i8_shortcut wants x (N, Cin, H, W) and x2 (N, Cin2, H, W); got %s and %s" % (tuple(x.shape), tuple(x2.shape)))
+    n, cin, h, w = x.shape
+    cin2 = x2.shape[1]
+    cout = wscale.numel()
+    if wscale2.numel() != cout:
+        raise ValueError("the two convolutions must have the same number of filters (%d and %d)" % (cout, wscale2.numel()))
+    if wcodes.shape[1] != cin or wcodes2.shape[1] != cin2 or not pwconv_shortcut_supported(cin, cin2, cout):
+        raise ValueError("pwconv_i8_shortcut: %d / %d -> %d channels is not a shape it takes" % (cin, cin2, cout))
+    if in_stat is not None and cur_out is None:
+        cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+    if in_stat2 is not None and cur_out2 is None:
+        cur_out2 = torch.empty(1, dtype=torch.float32, device=x.device)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    stat, zflag = _stat_target(n, x.device, True)
+    check_call(_lib_().fq_pwconv_i8_shortcut(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin, cin, cout,
+                                             h * w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(cur_out), _ptr(bn_scale),
+                                             _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _ptr(x2), _ptr(wcodes2), _ptr(wscale2),
+                                             _ptr(wsum2), cin2, cin2, _ptr(in_stat2), _ptr(in_thr2), int(width2), int(flags2),
+                                             _ptr(cur_out2), _ptr(bn_scale2), _ptr(bn_shift2), _stream(x)))
+    return y, stat
+
+
 def pwconv_gap_supported(xshape, cout, residual=False):
     """Shapes `pwconv_i8_gap` takes (fq_pwconv_i8_gap_supported): whole planes of 45 .. 64 pixels."""
     if len(xshape) != 4:

@@ -356,6 +356,37 @@ def gap_target(block, fz, c16_in, xshape, residual):
     return link["gap"]
 
 
+def defer_shortcut(block, fz, x, x_arg, c16_in, codes3, bias, scale, shift, plan, stride_, extra):
+    """The record a residual unit's shortcut convolution answers with instead of launching (quantize/fuse.py sets `_fq_defer_short`
+    for the one call from `_residual_unit_forward`): its operands, for the closing 1x1 of the unit to compute it inside its own
+    launch (fq_pwconv_i8_shortcut).  None when the call must run as it is."""
+    from .. import fuse as _fuse
+    if not getattr(block, "_fq_defer_short", False):
+        return None
+    block._fq_defer_short = False
+    if extra or c16_in is not None or bias is not None or scale is None or fz["act"] != "none" or stride_ != 1:
+        return None
+    if autograd.is_recording() or _fuse._collection is not None or getattr(ops.StatArena._tls, "current", None) is None:
+        return None
+    if any(_hooked(b) for b in (block, fz.get("bn"))) or not plan:
+        return None
+    xs = tuple(x_arg.shape)
+    out = NDArray(_placeholder((xs[0], block._kwargs["num_filter"], xs[2], xs[3]), x_arg.device))
+    out._fq_short = dict(x=x_arg, codes=codes3, bn=(scale, shift), plan=dict(plan), block=block)
+    return out
+
+
+def materialise_shortcut_record(d):
+    """The tensor a deferred shortcut's record stands for: the launch its convolution would have made."""
+    return ops.pwconv_i8(d["x"], *d["codes"], None, bn_scale=d["bn"][0], bn_shift=d["bn"][1], act=None, want_stat=False,
+                         **d["plan"])[0]
+
+
+def materialise_shortcut(s):
+    """... as the NDArray the unit would have been handed."""
+    return NDArray(materialise_shortcut_record(s._fq_short))
+
+
 def _convolve(block, F, x, weight, bias):
     """convert_conv2d.py:108 - the block's own convolution; of a subsampled trunk (`_fq_sub2`: this block is one of its
     stride-2 1x1 readers) the stride-1 convolution of what was stored, which is the same values."""
@@ -473,6 +504,9 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
         and not getattr(block, "_fq_no_int8", False)
     held = _pointwise_weight_codes(block, args, weight_raw, weight_q) if on_codes else None
     on_codes = held is not None
+    res0 = getattr(block, "_fq_residual", None)
+    if res0 is not None and res0.get("short") is not None and not (on_codes and fz.get("kind") == "1x1"):
+        res0["t"], res0["short"] = materialise_shortcut_record(res0["short"]), None      # (no integer path here: the tensor after all)
     c16_in = _handed_over(x)
     # (one of the two readers of a subsampled trunk: the stored pixels are the ones this block's stride picks)
     stride_ = 1 if getattr(x, "_fq_sub2", None) is not None else block._kwargs["stride"][0]
@@ -504,6 +538,26 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
             extra = {}
             xshape = c16_in.shape if c16_in is not None else tuple(x._t.shape)
             side_blk = sub_link = None
+            if res is not None and res.get("short") is not None:
+                # the unit's shortcut arrives as the record of its convolution: both sums in this launch when the shapes are built
+                # (fp32 inputs on both sides, BatchNorm here as there), else the shortcut is computed now and added as a tensor
+                d = res["short"]
+                if (c16_in is None and block._kwargs["stride"][0] == 1 and scale is not None and not _hooked(block)
+                        and tuple(d["x"].shape[2:]) == tuple(xshape[2:]) and d["x"].shape[0] == xshape[0]
+                        and ops.pwconv_shortcut_supported(xshape[1], d["x"].shape[1], block._kwargs["num_filter"])
+                        and not autograd.is_recording()):
+                    p2 = d["plan"]
+                    y, stat = ops.pwconv_i8_shortcut(x_arg, codes, scales, rowsum, None if bias is None else bias._t, bn_scale=scale,
+                                                     bn_shift=shift, act=res["act"], x2=d["x"], wcodes2=d["codes"][0],
+                                                     wscale2=d["codes"][1], wsum2=d["codes"][2], in_stat2=p2.get("in_stat"),
+                                                     in_thr2=p2.get("in_thr"), width2=p2["width"], flags2=p2["flags"],
+                                                     cur_out2=p2.get("cur_out"), bn_scale2=d["bn"][0], bn_shift2=d["bn"][1], **plan)
+                    res["used"] = True
+                    folded = NDArray(y)
+                    folded._fq_stat = stat
+                    return folded
+                res["t"] = materialise_shortcut_record(d)
+                res["short"] = None
             if res is not None and block._kwargs["stride"][0] == 1 and tuple(res["t"].shape[2:]) == tuple(xshape[2:]) \
                     and res["t"].shape[1] == block._kwargs["num_filter"]:
                 extra = dict(residual=res["t"])
@@ -549,6 +603,9 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                     pooled._fq_stat = stat
                     pooled._fq_pooled_by = gap                # (the pooling block behind hands THIS tensor through)
                     return pooled
+            short = defer_shortcut(block, fz, x, x_arg, c16_in, (codes, scales, rowsum), bias, scale, shift, plan, stride_, extra)
+            if short is not None:
+                return short
             pair = recompute_target(block, fz, x, plan, c16_in) if not extra else None
             if pair is not None:
                 # statistic only; the depthwise block behind recomputes the values inside its own launch

@@ -172,6 +172,9 @@ SUBSAMPLE = _os.environ.get("FQ_SUBSAMPLE", "1") != "0"
 # Pooled producer (round 6, fq_pwconv_i8_gap): the 1x1 convolution in front of a global average pooling - the last 1x1 of the
 # MobileNets, the closing 1x1 of ResNet-50's last unit - hands the plane means over instead of the planes (FQ_GAP_FUSE=0: two launches)
 GAP_FUSE = _os.environ.get("FQ_GAP_FUSE", "1") != "0"
+# Folded shortcut (round 6, fq_pwconv_i8_shortcut): the shortcut convolution of a stage's first unit is computed inside the launch of
+# the unit's closing 1x1 - the shortcut tensor is never written (FQ_SHORTCUT_FUSE=0: two launches)
+SHORTCUT_FUSE = _os.environ.get("FQ_SHORTCUT_FUSE", "1") != "0"
 UNIT_LINKS = _os.environ.get("FQ_HANDOVER_UNITS", "1") != "0"      # hand-over from a MobileNetV2 unit without shortcut to the next block (A/B)
 
 
@@ -313,9 +316,11 @@ def _tail_conv(seq):
 
 def _with_residual(conv, shortcut, act, run, owner=None):
     """Runs `run()` with the shortcut handed to `conv` (convert_conv2d.pointwise_fused adds it in the convolution's epilogue
-    when that call runs on the integer codes).  Returns (output, True) when it was consumed there."""
-    t = shortcut._t if shortcut._t.is_contiguous() else shortcut._t.contiguous()
-    conv._fq_residual = {"t": t, "act": act, "used": False, "owner": owner}
+    when that call runs on the integer codes).  Returns (output, True) when it was consumed there.  A shortcut that was not
+    computed (`_fq_short`: the record of the shortcut convolution's operands) travels as that record."""
+    short = getattr(shortcut, "_fq_short", None)
+    t = None if short is not None else (shortcut._t if shortcut._t.is_contiguous() else shortcut._t.contiguous())
+    conv._fq_residual = {"t": t, "short": short, "act": act, "used": False, "owner": owner}
     try:
         out = run()
         return out, conv._fq_residual["used"]
@@ -336,14 +341,24 @@ def _residual_unit_forward(self, x):
     sub = getattr(x, "_fq_sub2", None)
     if sub is not None and sub["unit"] is not self:
         raise RuntimeError("a subsampled trunk (fq_pwconv_i8_sub2) reached a unit it was not made for")
-    shortcut = x if self.downsample is None else self.downsample(x)
     tail = _tail_conv(self.body)
+    sc = _shortcut_conv(self) if (tail is not None and SHORTCUT_FUSE) else None
+    if sc is not None:
+        sc._fq_defer_short = True                  # one shot: convert_conv2d.pointwise_fused may answer with a record instead
+    try:
+        shortcut = x if self.downsample is None else self.downsample(x)
+    finally:
+        if sc is not None:
+            sc._fq_defer_short = False
     if tail is not None:
         h, consumed = _with_residual(tail, shortcut, "relu", lambda: self.body(x), owner=self)
         if consumed:
             return h
     else:
         h = self.body(x)
+    if getattr(shortcut, "_fq_short", None) is not None:       # (nobody folded it after all)
+        from .convert.convert_conv2d import materialise_shortcut
+        shortcut = materialise_shortcut(shortcut)
     a = h._t if h._t.is_contiguous() else h._t.contiguous()
     b = shortcut._t if shortcut._t.is_contiguous() else shortcut._t.contiguous()
     sink = _kl_sink(self)
@@ -353,6 +368,20 @@ def _residual_unit_forward(self, x):
     if _collection is not None:
         out._fq_kl = (self, sink)
     return out
+
+
+def _shortcut_conv(unit):
+    """`downsample[0]` of a residual unit when it is a fused 1x1 convolution whose BatchNorm it folded and nothing else follows."""
+    ds = getattr(unit, "downsample", None)
+    if type(ds) not in (nn.Sequential, nn.HybridSequential) or "forward" in ds.__dict__:
+        return None
+    kids = list(ds._children.values())
+    if len(kids) != 2 or type(kids[0]) is not nn.Conv2D or type(kids[1]) is not nn.BatchNorm:
+        return None
+    fz = getattr(kids[0], "_fq_pw_fused", None)
+    if fz is None or fz.get("kind") != "1x1" or fz["bn"] is not kids[1] or fz["act"] != "none":
+        return None
+    return kids[0]
 
 
 def _linear_bottleneck_forward(self, x):

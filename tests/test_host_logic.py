@@ -599,6 +599,8 @@ def _subsampled_trunk_checks(build, links, x, ops, fuse):
                 ops.StatArena._tls.current = None
             outs[mode] = (out, cur, seen)
         assert outs["whole"][2] == [] and len(outs["sub"][2]) == 3 and len(outs["sub, one reader off the codes"][2]) == 3
+        # (the same forwards fold four shortcut convolutions into their units' closing 1x1 - the oracle's stand-in composes the two
+        # launches - and the reader that left the integer path has its record materialised)
         np.testing.assert_array_equal(outs["sub"][0], outs["whole"][0])
         assert outs["sub"][1] == outs["whole"][1]
         # (the fp32 library convolution of the fake-quantised tensors adds in another order than the integer path: close, not equal)

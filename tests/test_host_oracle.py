@@ -36,7 +36,7 @@ def test_host_library_exports_every_declared_symbol():
             "fq_kl_workspace_bytes", "fq_dense_i8_eval_workspace_bytes", "fq_build_id", "fq_profile_launch_overhead",
             "fq_qconv_weights_bytes", "fq_qconv_kind", "fq_qconv_workspace_bytes", "fq_qconv_workspace_init",
             "fq_profile_read_moved", "fq_stem_conv7x7s2_pool_supported", "fq_pwconv_i8_stat_supported",
-            "fq_pwdw_fused_supported", "fq_build_has", "fq_debug_fast_quotient", "fq_pwconv_i8_sub2_supported", "fq_pwconv_i8_gap_supported",
+            "fq_pwdw_fused_supported", "fq_build_has", "fq_debug_fast_quotient", "fq_pwconv_i8_sub2_supported", "fq_pwconv_i8_gap_supported", "fq_pwconv_i8_shortcut_supported",
             # transport, not arithmetic: the RCCL collectives of multi-GPU calibration
             "fq_comm_unique_id", "fq_comm_init", "fq_comm_world", "fq_allreduce_f32", "fq_allreduce_f64",
             "fq_allreduce_i64", "fq_comm_destroy"}
