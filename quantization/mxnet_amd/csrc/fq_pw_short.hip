@@ -37,18 +37,20 @@ struct PwShortIn2 {
   int lo_neg;
 };
 
-constexpr int kShNW = 4, kShCW = 2, kShNCH = kShNW * kShCW * 32;       // 256 output channels per workgroup
+constexpr int kShCW = 2;                                               // channel tiles per wavefront
 constexpr int kShD = 4;                                                // A fragments in flight per wavefront
 
-template <int KT, int KT2>
-__global__ __launch_bounds__(kShNW * 64, 3) void pwconv_short_kernel(
+// NW wavefronts per workgroup: 4 (256 output channels) or 8 (512: half as many workgroups quantise the same tile's slabs)
+template <int KT, int KT2, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void pwconv_short_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwShortGeom g,
     const float* __restrict__ in_stat, int n, const float* __restrict__ in_thr, float levels, int lo_neg_max, float eps,
     float* __restrict__ cur_max_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int act,
     float* __restrict__ stat_out, PwShortIn2 s2) {
   constexpr int kSlots = 8;
-  constexpr int NCH = kShNCH;
+  constexpr int kShNW = NW;
+  constexpr int NCH = NW * kShCW * 32;
   constexpr int NS = KT + KT2;                                          // slabs of the two inputs together
   constexpr int SLABS = (NS + kShNW - 1) / kShNW;                       // ... a wavefront quantises (s = wave + 4 j < NS)
   constexpr int RB = SLABS < 4 ? SLABS : 4;                             // slabs (16 loads each) in flight per lane
@@ -260,11 +262,13 @@ __global__ __launch_bounds__(kShNW * 64, 3) void pwconv_short_kernel(
 
 namespace fqi {
 
-// shapes fq_pwconv_i8_shortcut takes: the four stage heads of the v1 bottleneck ResNets (K of the closing convolution / K of the
-// shortcut convolution: 64 / 64, 128 / 256, 256 / 512, 512 / 1024), Cout a multiple of 256
+// shapes fq_pwconv_i8_shortcut takes: the stage heads of the v1 bottleneck ResNets on the 56x56, 28x28 and 14x14 planes (K of the
+// closing convolution / K of the shortcut convolution: 64 / 64, 128 / 256, 256 / 512), Cout a multiple of 512 (of 256 for 64 / 64).
+// (512 / 1024 -> 2048 @7x7 was built and measured: 89 us against 34 + 31 for the two launches - eight channel groups quantise the
+// same 48 slabs of a 32-pixel tile - and is left to them.)
 bool pw_short_shape_ok(int64_t cin, int64_t cin2, int64_t cout) {
-  const bool pair = (cin == 64 && cin2 == 64) || (cin == 128 && cin2 == 256) || (cin == 256 && cin2 == 512) || (cin == 512 && cin2 == 1024);
-  return pair && cout % 256 == 0 && cout > 0;
+  const bool pair = (cin == 64 && cin2 == 64) || (cin == 128 && cin2 == 256) || (cin == 256 && cin2 == 512);
+  return pair && cout > 0 && cout % (cin == 64 ? 256 : 512) == 0;
 }
 
 int pw_short_launch(const PwCall& a, const PwCall& b) {
@@ -275,15 +279,17 @@ int pw_short_launch(const PwCall& a, const PwCall& b) {
   const int64_t tiles = (a.n * a.hw + 31) / 32;
   FQ_REQUIRE((32 / a.hw + 2) * a.cout * a.hw * 4 < (1ll << 31) && (32 / a.hw + 2) * b.cin * a.hw * 4 < (1ll << 31),
              "fq_pwconv_i8_shortcut: a tile must stay within 2 GiB of its first sample");
+  static const int nw_tune = env_int("FQ_PWSH_NW", 0);                   // tuning: 4 / 8 wavefronts per workgroup
+  const int nw = (nw_tune == 4 || nw_tune == 8) ? (a.cout % 512 == 0 ? nw_tune : 4) : (a.cout % 512 == 0 && kt >= 4 ? 8 : 4);
   PwShortGeom t;
   t.Cin = (int)a.cin; t.Cin2 = (int)b.cin; t.Cout = (int)a.cout; t.HW = (int)a.hw;
-  t.CS = (int)(a.cout / kShNCH);
+  t.CS = (int)(a.cout / (nw * kShCW * 32));
   t.CTM = (int)((a.cout + 63) / 64 * 64 / 32); t.CTM2 = t.CTM;
   t.cols = a.n * a.hw; t.tiles = tiles; t.items = tiles * t.CS;
   t.zoff = a.zoff; t.zoff2 = b.zoff;
   const int64_t grid = (t.items + 7) / 8 * 8;
   FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8_shortcut: too many tiles");
-  const size_t lds = (size_t)(kt + kt2) * 1024 + (size_t)kShNCH * 9 * sizeof(float);
+  const size_t lds = (size_t)(kt + kt2) * 1024 + (size_t)(nw * kShCW * 32) * 9 * sizeof(float);
   const int64_t rows_pad = (a.cout + 63) / 64 * 64;
   const int8_t* wfrag = a.wcodes + rows_pad * a.cin_pad;                 // second halves of fq_weight_codes' buffers
   PwShortIn2 s2;
@@ -292,17 +298,17 @@ int pw_short_launch(const PwCall& a, const PwCall& b) {
   s2.cur_max_out = b.out_current_max; s2.levels = b.levels; s2.lo_neg = b.lo_neg;
   if (int rc = pw_zero_stat(a)) return rc;
   bool launched = false;
-#define FQ_PWSH_CASE(KT_, KT2_)                                                                                        \
-  if (kt == KT_ && kt2 == KT2_) {                                                                                      \
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_short_kernel<KT_, KT2_>),    \
+#define FQ_PWSH_CASE(KT_, KT2_, NW_)                                                                                   \
+  if (kt == KT_ && kt2 == KT2_ && nw == NW_) {                                                                         \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_short_kernel<KT_, KT2_, NW_>), \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess; \
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8_shortcut: cannot raise the dynamic LDS limit");                                  \
-    hipLaunchKernelGGL((pwconv_short_kernel<KT_, KT2_>), dim3((unsigned)grid), dim3(kShNW * 64), lds, a.st, a.x, wfrag, \
+    hipLaunchKernelGGL((pwconv_short_kernel<KT_, KT2_, NW_>), dim3((unsigned)grid), dim3(NW_ * 64), lds, a.st, a.x, wfrag, \
                        a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, a.lo_neg, \
                        kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out, s2);                        \
     launched = true;                                                                                                   \
   }
-  FQ_PWSH_CASE(2, 2) FQ_PWSH_CASE(4, 8) FQ_PWSH_CASE(8, 16) FQ_PWSH_CASE(16, 32)
+  FQ_PWSH_CASE(2, 2, 4) FQ_PWSH_CASE(4, 8, 4) FQ_PWSH_CASE(8, 16, 4) FQ_PWSH_CASE(4, 8, 8) FQ_PWSH_CASE(8, 16, 8)
 #undef FQ_PWSH_CASE
   FQ_REQUIRE(launched, "fq_pwconv_i8_shortcut: no instantiation for K/32 = %d and %d", kt, kt2);
   FQ_LAUNCH_CHECK();
