@@ -368,6 +368,18 @@ int fq_pwconv_i8_shortcut(const float* x, const int8_t* wcodes, const float* wsc
                           const float* in_thr2, int in_width2, unsigned in_flags2, float* out_current_max2,
                           const float* bn_scale2, const float* bn_shift2, fqStream_t stream);
 
+/* ... under stored thresholds (the unit's 3x3 handed its codes over): x is a C16 code tensor made with in_thr, the result leaves as
+ * fp32 y AND as y16, its C16 code copy under out_thr / out_width / out_flags for the next unit's first 1x1 - the two outputs of
+ * fq_pwconv_i8_c16_dual - and the shortcut convolution's input x2 is fp32 (x2_is_c16 = 0) or a C16 tensor made with in_thr2.      */
+int fq_pwconv_i8_shortcut_c16(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                              float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
+                              const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                              const float* bn_scale, const float* bn_shift, int act, float* stat_out, const void* x2, int x2_is_c16,
+                              const int8_t* wcodes2, const float* wscale2, const int32_t* wsum2, int64_t cin2, int64_t cin2_pad,
+                              const float* in_stat2, const float* in_thr2, int in_width2, unsigned in_flags2,
+                              float* out_current_max2, const float* bn_scale2, const float* bn_shift2, const float* out_thr,
+                              int out_width, unsigned out_flags, fqStream_t stream);
+
 /* A 1x1 convolution and the global average pooling behind it in ONE launch (round 6).  The last 1x1 convolution of the MobileNets
  * (gluon model_zoo: ... Conv2D(1x1), BatchNorm, Activation, GlobalAvgPool2D, Flatten, Dense; the reference wraps the convolution in
  * convert_conv2d.py:53-66,108 and leaves the pooling to MXNet's Pooling operator) writes a tensor whose only reader is that pooling.

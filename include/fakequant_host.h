@@ -105,6 +105,14 @@ int fq_pwconv_i8_shortcut_host(const float* x, const int8_t* wcodes, const float
                                const int8_t* wcodes2, const float* wscale2, const int32_t* wsum2, int64_t cin2, int64_t cin2_pad,
                                const float* in_stat2, const float* in_thr2, int in_width2, unsigned in_flags2,
                                float* out_current_max2, const float* bn_scale2, const float* bn_shift2, fqStream_t stream);
+int fq_pwconv_i8_shortcut_c16_host(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                                   float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
+                                   const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                                   float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                                   const void* x2, int x2_is_c16, const int8_t* wcodes2, const float* wscale2, const int32_t* wsum2,
+                                   int64_t cin2, int64_t cin2_pad, const float* in_stat2, const float* in_thr2, int in_width2,
+                                   unsigned in_flags2, float* out_current_max2, const float* bn_scale2, const float* bn_shift2,
+                                   const float* out_thr, int out_width, unsigned out_flags, fqStream_t stream);
 int fq_pwconv_i8_gap_host(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
                           float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
                           const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,

@@ -893,6 +893,32 @@ int fq_pwconv_i8_c16_dual_host(const void* x, const int8_t* wcodes, const float*
   return FQ_OK;
 }
 
+// fq_pwconv_i8_shortcut_c16: the shortcut convolution's twin (input fp32 or codes), then the dual form's with it as residual
+int fq_pwconv_i8_shortcut_c16_host(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                                   float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
+                                   const float* in_stat, const float* in_thr, int in_width, unsigned in_flags,
+                                   float* out_current_max, const float* bn_scale, const float* bn_shift, int act, float* stat_out,
+                                   const void* x2, int x2_is_c16, const int8_t* wcodes2, const float* wscale2, const int32_t* wsum2,
+                                   int64_t cin2, int64_t cin2_pad, const float* in_stat2, const float* in_thr2, int in_width2,
+                                   unsigned in_flags2, float* out_current_max2, const float* bn_scale2, const float* bn_shift2,
+                                   const float* out_thr, int out_width, unsigned out_flags, fqStream_t st) {
+  REQUIRE(x && x2 && y && y16 && hw > 0, "fq_pwconv_i8_shortcut_c16_host: bad arguments");
+  std::vector<float> sc((size_t)(n * cout * hw));
+  if (x2_is_c16) {
+    if (int rc = fq_pwconv_i8_c16_host(x2, 1, wcodes2, wscale2, wsum2, nullptr, sc.data(), n, cin2, cin2_pad, cout, hw, 1, 1,
+                                       in_stat2, in_thr2, in_width2, in_flags2, out_current_max2, bn_scale2, bn_shift2,
+                                       FQ_ACT_NONE, nullptr, nullptr, nullptr, 8, 0, nullptr, st))
+      return rc;
+  } else if (int rc = pwconv_i8_impl((const float*)x2, wcodes2, wscale2, wsum2, nullptr, sc.data(), n, cin2, cin2_pad, cout, hw,
+                                     in_stat2, in_thr2, in_width2, in_flags2, out_current_max2, bn_scale2, bn_shift2,
+                                     FQ_ACT_NONE, nullptr, nullptr)) {
+    return rc;
+  }
+  return fq_pwconv_i8_c16_dual_host(x, wcodes, wscale, wsum, bias, y, y16, n, cin, cin_pad, cout, hw, 1, in_stat, in_thr, in_width,
+                                    in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, sc.data(), out_thr, out_width,
+                                    out_flags, nullptr, st);
+}
+
 // ... both outputs subsampled: the whole fp32 output on the host, its even pixels of the even rows, and their codes
 int fq_pwconv_i8_c16_dual_sub2_host(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
                                     const float* bias, float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout,

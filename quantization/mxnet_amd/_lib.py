@@ -83,6 +83,9 @@ EXPORTS = {
     "fq_pwconv_i8_shortcut_supported": (_int, [_i64, _i64, _i64]),
     "fq_pwconv_i8_shortcut": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
                                      _vp, _int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp, _vp, _vp]),
+    "fq_pwconv_i8_shortcut_c16": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp,
+                                         _vp, _vp, _int, _vp, _vp, _int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp,
+                                         _vp, _vp, _int, _uint, _vp]),
     "fq_pwconv_i8_gap_supported": (_int, [_i64, _i64, _i64, _i64, _int]),
     "fq_pwconv_i8_gap": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _int, _uint, _vp, _vp, _vp,
                                 _int, _vp, _vp, _vp, _vp]),

@@ -20,6 +20,14 @@ struct PwShortGeom {
   int CTM, CTM2;             // 32-channel tiles present in the two weight buffers
   int64_t cols, tiles, items;
   int zoff, zoff2;
+  // C16 code tensors (offline thresholds; the layout: include/fakequant.h): A16 - x holds this convolution's codes, CBi blocks of
+  // 16 channels per sample; B16 - the shortcut convolution's input likewise (CBi2); DUAL - g.y16 receives the codes of y under
+  // dual_thr (CBo blocks; out_levels / out_lo_neg / out_zoff describe that quantiser), as fq_pwconv_i8_c16_dual writes them
+  int CBi, CBi2, CBo;
+  float out_levels;
+  int out_lo_neg, out_zoff;
+  char* y16;
+  const float* dual_thr;
 };
 
 // the shortcut convolution's operands (the closing convolution's travel as plain kernel arguments, as in the split form)
@@ -41,7 +49,7 @@ constexpr int kShCW = 2;                                               // channe
 constexpr int kShD = 4;                                                // A fragments in flight per wavefront
 
 // NW wavefronts per workgroup: 4 (256 output channels) or 8 (512: half as many workgroups quantise the same tile's slabs)
-template <int KT, int KT2, int NW>
+template <int KT, int KT2, int NW, bool A16 = false, bool B16 = false, bool DUAL = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void pwconv_short_kernel(
     const float* __restrict__ x, const int8_t* __restrict__ wfrag, const float* __restrict__ wscale,
     const int* __restrict__ wsum, const float* __restrict__ bias, float* __restrict__ y, PwShortGeom g,
@@ -92,18 +100,34 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void pwconv_short_kernel(
   }
   const int64_t n_samp = (int64_t)(cols / HW);
   const int64_t x_samp = (int64_t)g.Cin * HW * 4, x2_samp = (int64_t)g.Cin2 * HW * 4, y_samp = (int64_t)g.Cout * HW * 4;
-  const fq_rsrc xr = make_rsrc(reinterpret_cast<const char*>(x) + s_base * x_samp, (n_samp - s_base) * x_samp);
-  const fq_rsrc xr2 = make_rsrc(reinterpret_cast<const char*>(s2.x) + s_base * x2_samp, (n_samp - s_base) * x2_samp);
-  const unsigned xo = ((smp - s_base) * (unsigned)g.Cin + 16u * h) * plane4 + p * 4u;
-  const unsigned xo2 = ((smp - s_base) * (unsigned)g.Cin2 + 16u * h) * plane4 + p * 4u;
+  const int64_t x_samp16 = (int64_t)g.CBi * HW * 16, x2_samp16 = (int64_t)g.CBi2 * HW * 16;
+  const fq_rsrc xr = A16 ? make_rsrc(reinterpret_cast<const char*>(x) + s_base * x_samp16, (n_samp - s_base) * x_samp16)
+                         : make_rsrc(reinterpret_cast<const char*>(x) + s_base * x_samp, (n_samp - s_base) * x_samp);
+  const fq_rsrc xr2 = B16 ? make_rsrc(reinterpret_cast<const char*>(s2.x) + s_base * x2_samp16, (n_samp - s_base) * x2_samp16)
+                          : make_rsrc(reinterpret_cast<const char*>(s2.x) + s_base * x2_samp, (n_samp - s_base) * x2_samp);
+  // (a C16 input: the lane's 16 codes of a slab's half are ONE 16-byte vector of block 2 kt + h - already the B fragment)
+  const unsigned xo = A16 ? ((smp - s_base) * (unsigned)g.CBi + (unsigned)h) * HW * 16u + p * 16u
+                          : ((smp - s_base) * (unsigned)g.Cin + 16u * h) * plane4 + p * 4u;
+  const unsigned xo2 = B16 ? ((smp - s_base) * (unsigned)g.CBi2 + (unsigned)h) * HW * 16u + p * 16u
+                           : ((smp - s_base) * (unsigned)g.Cin2 + 16u * h) * plane4 + p * 4u;
   // slab s of the two inputs together: s < KT -> slab s of y2, else slab s - KT of x (wave-uniform)
   auto issue = [&](int s, float (&v)[16]) __attribute__((always_inline)) {
     if (s < KT) {
+      if (A16) {
+        const v4i c = buf_ld_v4i(xr, xo, (unsigned)(2 * s) * HW * 16u);
+        v[0] = __int_as_float(c[0]); v[1] = __int_as_float(c[1]); v[2] = __int_as_float(c[2]); v[3] = __int_as_float(c[3]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = buf_ld_f32(xr, xo, (unsigned)(s * 32 + i) * plane4);
+        for (int i = 0; i < 16; ++i) v[i] = buf_ld_f32(xr, xo, (unsigned)(s * 32 + i) * plane4);
+      }
     } else {
+      if (B16) {
+        const v4i c = buf_ld_v4i(xr2, xo2, (unsigned)(2 * (s - KT)) * HW * 16u);
+        v[0] = __int_as_float(c[0]); v[1] = __int_as_float(c[1]); v[2] = __int_as_float(c[2]); v[3] = __int_as_float(c[3]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = buf_ld_f32(xr2, xo2, (unsigned)((s - KT) * 32 + i) * plane4);
+        for (int i = 0; i < 16; ++i) v[i] = buf_ld_f32(xr2, xo2, (unsigned)((s - KT) * 32 + i) * plane4);
+      }
     }
   };
   const ThresholdReq treq = threshold_request(in_stat, n, in_thr, item == 0);        // first in the memory queue
@@ -138,7 +162,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void pwconv_short_kernel(
   auto quant_to_panel = [&](int s, const float (&v)[16]) __attribute__((always_inline)) {
     v4i f;
     const bool first = s < KT;                                          // (wave-uniform, as are nn1 / nn2: four branches)
-    if (first && nn1) {
+    if ((first && A16) || (!first && B16)) {                            // codes: they ARE the fragment
+      f = (v4i){__float_as_int(v[0]), __float_as_int(v[1]), __float_as_int(v[2]), __float_as_int(v[3])};
+    } else if (first && nn1) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) f[d] = fq_pack4<true>(v[4 * d + 0], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3], q, ubias, nn_xor);
     } else if (first) {
@@ -189,6 +215,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void pwconv_short_kernel(
   y_bytes = y_bytes < 0x7FFFFFFFll ? y_bytes : 0x7FFFFFFFll;
   const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + s_base * y_samp + (int64_t)(ch0 + ctl0 * 32) * plane4, y_bytes);
   const unsigned yo = ((smp - s_base) * (unsigned)g.Cout + 4u * h) * plane4 + p * 4u;
+  // DUAL: the codes of y under the next unit's first convolution's threshold, beside y (unsigned codes of a [0, thr] range)
+  QParams q3;
+  q3.lo = q3.hi = q3.denom = q3.scale = 0.0f;
+  q3.rden = 0.0;
+  if (DUAL) q3 = make_qparams(g.dual_thr[0], g.out_levels, g.out_lo_neg != 0, eps);
+  const int ubias3 = 128 - g.out_zoff;
+  const int64_t y_samp16 = (int64_t)g.CBo * HW * 16;
+  const int cb0 = (ch0 + ctl0 * 32) >> 4;                               // first output block of this wavefront
+  int64_t y16_bytes = (n_samp - s_base) * y_samp16 - (int64_t)cb0 * HW * 16;
+  y16_bytes = y16_bytes < 0x7FFFFFFFll ? y16_bytes : 0x7FFFFFFFll;
+  const fq_rsrc yr16 = make_rsrc(DUAL ? g.y16 + s_base * y_samp16 + (int64_t)cb0 * HW * 16 : reinterpret_cast<char*>(y),
+                                 DUAL ? y16_bytes : 0);
+  const unsigned yo16 = (smp - s_base) * (unsigned)g.CBo * HW * 16u + p * 16u + 4u * h;
   float m = 0.0f;
 #pragma unroll
   for (int c = 0; c < kShCW; ++c) {
@@ -218,6 +257,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void pwconv_short_kernel(
       const f4 sxw2 = *reinterpret_cast<const f4*>(c_sxw2 + c0);
       const f4 bsc2 = *reinterpret_cast<const f4*>(c_bsc2 + c0);
       const f4 bsh2 = *reinterpret_cast<const f4*>(c_bsh2 + c0);
+      float vq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         // the shortcut's value, as fq_pwconv_i8_strided computes and stores it: fp32(sum) * (sx * sw), BatchNorm, no activation
@@ -235,6 +275,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void pwconv_short_kernel(
         v = act_rt(v, act);
         buf_st_f32(yr, yo, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
         m = fmaxf(m, fabsf(v));
+        vq[r] = v;
+      }
+      if (DUAL) {
+        // channels 8 gq + 4 h .. + 3 of this lane's pixel are bytes 8 (gq & 1) + 4 h .. of block (c * 2 + gq / 2): one 4-byte store
+        const int packed = fq_pack4<true>(vq[0], vq[1], vq[2], vq[3], q3, ubias3, 0x80808080u);
+        buf_st_f32(yr16, yo16, (unsigned)((c * 2 + (gq >> 1)) * (int)HW * 16 + 8 * (gq & 1)), __int_as_float(packed));
       }
     }
   }
@@ -287,6 +333,14 @@ int pw_short_launch(const PwCall& a, const PwCall& b) {
   t.CTM = (int)((a.cout + 63) / 64 * 64 / 32); t.CTM2 = t.CTM;
   t.cols = a.n * a.hw; t.tiles = tiles; t.items = tiles * t.CS;
   t.zoff = a.zoff; t.zoff2 = b.zoff;
+  t.CBi = (int)((a.cin + 15) / 16); t.CBi2 = (int)((b.cin + 15) / 16); t.CBo = (int)((a.cout + 15) / 16);
+  t.out_levels = a.out_levels; t.out_lo_neg = a.out_lo_neg; t.out_zoff = a.out_zoff;
+  t.y16 = (char*)a.y16; t.dual_thr = a.dual_thr;
+  const bool a16 = a.in_c16, b16 = b.in_c16, dual = a.y16 != nullptr;
+  FQ_REQUIRE((!a16 && !b16 && !dual) || (a16 && dual), "fq_pwconv_i8_shortcut_c16: built for fp32 on every side, or for codes in + "
+             "the code copy out (the shortcut convolution's input fp32 or codes)");
+  FQ_REQUIRE(!a16 || a.in_thr != nullptr, "fq_pwconv_i8_shortcut_c16: a C16 input was quantised with a stored threshold: give in_thr");
+  FQ_REQUIRE(!b16 || b.in_thr != nullptr, "fq_pwconv_i8_shortcut_c16: a C16 shortcut input needs in_thr2");
   const int64_t grid = (t.items + 7) / 8 * 8;
   FQ_REQUIRE(grid < (1ll << 31), "fq_pwconv_i8_shortcut: too many tiles");
   const size_t lds = (size_t)(kt + kt2) * 1024 + (size_t)(nw * kShCW * 32) * 9 * sizeof(float);
@@ -298,17 +352,23 @@ int pw_short_launch(const PwCall& a, const PwCall& b) {
   s2.cur_max_out = b.out_current_max; s2.levels = b.levels; s2.lo_neg = b.lo_neg;
   if (int rc = pw_zero_stat(a)) return rc;
   bool launched = false;
-#define FQ_PWSH_CASE(KT_, KT2_, NW_)                                                                                   \
-  if (kt == KT_ && kt2 == KT2_ && nw == NW_) {                                                                         \
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_short_kernel<KT_, KT2_, NW_>), \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess; \
+#define FQ_PWSH_CASE(KT_, KT2_, NW_) FQ_PWSH_CASE_C(KT_, KT2_, NW_, false, false, false)
+#define FQ_PWSH_CASE_C(KT_, KT2_, NW_, A_, B_, D_)                                                                     \
+  if (kt == KT_ && kt2 == KT2_ && nw == NW_ && a16 == A_ && b16 == B_ && dual == D_) {                                 \
+    static const bool attr_ok =                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pwconv_short_kernel<KT_, KT2_, NW_, A_, B_, D_>),           \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;                      \
     FQ_REQUIRE(attr_ok, "fq_pwconv_i8_shortcut: cannot raise the dynamic LDS limit");                                  \
-    hipLaunchKernelGGL((pwconv_short_kernel<KT_, KT2_, NW_>), dim3((unsigned)grid), dim3(NW_ * 64), lds, a.st, a.x, wfrag, \
+    hipLaunchKernelGGL((pwconv_short_kernel<KT_, KT2_, NW_, A_, B_, D_>), dim3((unsigned)grid), dim3(NW_ * 64), lds, a.st, a.x, wfrag, \
                        a.wscale, (const int*)a.wsum, a.bias, a.y, t, a.in_stat, (int)a.n, a.in_thr, a.levels, a.lo_neg, \
                        kEps, a.out_current_max, a.bn_scale, a.bn_shift, a.act, a.stat_out, s2);                        \
     launched = true;                                                                                                   \
   }
   FQ_PWSH_CASE(2, 2, 4) FQ_PWSH_CASE(4, 8, 4) FQ_PWSH_CASE(8, 16, 4) FQ_PWSH_CASE(4, 8, 8) FQ_PWSH_CASE(8, 16, 8)
+  // stored thresholds: codes in, fp32 + code copy out; the shortcut's input fp32 (stage 1: the pooled first convolution) or codes
+  FQ_PWSH_CASE_C(2, 2, 4, true, false, true) FQ_PWSH_CASE_C(4, 8, 8, true, false, true) FQ_PWSH_CASE_C(8, 16, 8, true, false, true)
+  FQ_PWSH_CASE_C(4, 8, 8, true, true, true) FQ_PWSH_CASE_C(8, 16, 8, true, true, true)
+#undef FQ_PWSH_CASE_C
 #undef FQ_PWSH_CASE
   FQ_REQUIRE(launched, "fq_pwconv_i8_shortcut: no instantiation for K/32 = %d and %d", kt, kt2);
   FQ_LAUNCH_CHECK();

@@ -345,13 +345,16 @@ int fq_pwconv_i8_shortcut_supported(int64_t cin, int64_t cin2, int64_t cout) {
   return pw_short_shape_ok(cin, cin2, cout) ? 1 : 0;
 }
 
-int fq_pwconv_i8_shortcut(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
-                          float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
-                          const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
-                          const float* bn_shift, int act, float* stat_out, const float* x2, const int8_t* wcodes2,
-                          const float* wscale2, const int32_t* wsum2, int64_t cin2, int64_t cin2_pad, const float* in_stat2,
-                          const float* in_thr2, int in_width2, unsigned in_flags2, float* out_current_max2,
-                          const float* bn_scale2, const float* bn_shift2, fqStream_t stream) {
+static int pwconv_shortcut(const void* xv, bool x_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,
+                           const float* bias, float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
+                           const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                           const float* bn_scale, const float* bn_shift, int act, float* stat_out, const void* x2v, bool x2_c16,
+                           const int8_t* wcodes2, const float* wscale2, const int32_t* wsum2, int64_t cin2, int64_t cin2_pad,
+                           const float* in_stat2, const float* in_thr2, int in_width2, unsigned in_flags2,
+                           float* out_current_max2, const float* bn_scale2, const float* bn_shift2, const float* out_thr,
+                           int out_width, unsigned out_flags, fqStream_t stream) {
+  const float* x = (const float*)xv;
+  const float* x2 = (const float*)x2v;
   FQ_REQUIRE(x && wcodes && wscale && wsum && y && x2 && wcodes2 && wscale2 && wsum2 && bn_scale2 && bn_shift2,
              "fq_pwconv_i8_shortcut: null pointer (the shortcut convolution needs its BatchNorm constants)");
   FQ_REQUIRE(n > 0 && hw > 0 && hw < (1ll << 30) && n * hw < (1ll << 31) - 512, "fq_pwconv_i8_shortcut: bad shape");
@@ -376,11 +379,50 @@ int fq_pwconv_i8_shortcut(const float* x, const int8_t* wcodes, const float* wsc
   b.cin = cin2; b.cin_pad = cin2_pad; b.in_stat = in_stat2; b.in_thr = in_thr2; b.levels = act_levels(in_width2, in_flags2);
   b.lo_neg = (in_flags2 & FQ_ACT_LO_NEG_MAX) ? 1 : 0; b.zoff = (in_flags2 & FQ_ACT_SIGNED) ? 0 : 128;
   b.out_current_max = out_current_max2; b.bn_scale = bn_scale2; b.bn_shift = bn_shift2; b.act = FQ_ACT_NONE; b.stat_out = nullptr;
+  a.in_c16 = x_c16;
+  b.in_c16 = x2_c16;
+  if (y16 != nullptr) {                                 // the code copy of y under the next unit's first convolution's threshold
+    FQ_REQUIRE(out_thr != nullptr && out_width >= 2 && out_width <= 8 && !(out_flags & (FQ_ACT_SIGNED | FQ_ACT_LO_NEG_MAX | FQ_ACT_NO_ABS | FQ_ACT_NO_EPS)),
+               "fq_pwconv_i8_shortcut_c16: the code copy holds unsigned codes of a [0, thr] range and needs out_thr");
+    a.y16 = y16; a.dual_thr = out_thr; a.out_levels = act_levels(out_width, out_flags); a.out_lo_neg = 0; a.out_zoff = 128;
+    FQ_REQUIRE((32 / hw + 2) * ((cout + 15) / 16) * hw * 16 < (1ll << 31), "fq_pwconv_i8_shortcut_c16: plane too large");
+  }
   // algorithmic bytes: those of the two layers it stands for (shortcut: in + out; closing: in + residual + out); moved: both
   // inputs and the output
   const double in1 = (double)n * cin * hw, in2 = (double)n * cin2 * hw, out = (double)n * cout * hw;
-  ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * (in2 + out + in1 + 2.0 * out), a.st, 4.0 * (in1 + in2 + out));
+  ProfScope prof(FQ_KERNEL_PWCONV, 4.0 * (in2 + out + in1 + 2.0 * out), a.st,
+                 (x_c16 ? 1.0 : 4.0) * in1 + (x2_c16 ? 1.0 : 4.0) * in2 + (y16 != nullptr ? 5.0 : 4.0) * out);
   return pw_short_launch(a, b);
+}
+
+int fq_pwconv_i8_shortcut(const float* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                          float* y, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw, const float* in_stat,
+                          const float* in_thr, int in_width, unsigned in_flags, float* out_current_max, const float* bn_scale,
+                          const float* bn_shift, int act, float* stat_out, const float* x2, const int8_t* wcodes2,
+                          const float* wscale2, const int32_t* wsum2, int64_t cin2, int64_t cin2_pad, const float* in_stat2,
+                          const float* in_thr2, int in_width2, unsigned in_flags2, float* out_current_max2,
+                          const float* bn_scale2, const float* bn_shift2, fqStream_t stream) {
+  return pwconv_shortcut(x, false, wcodes, wscale, wsum, bias, y, nullptr, n, cin, cin_pad, cout, hw, in_stat, in_thr, in_width,
+                         in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, x2, false, wcodes2, wscale2, wsum2, cin2,
+                         cin2_pad, in_stat2, in_thr2, in_width2, in_flags2, out_current_max2, bn_scale2, bn_shift2, nullptr, 8, 0,
+                         stream);
+}
+
+// ... under stored thresholds: x a C16 code tensor (the unit's 3x3 handed its codes over), y fp32 AND y16 its code copy for the next
+// unit's first 1x1 (fq_pwconv_i8_c16_dual's pair of outputs), the shortcut convolution's input fp32 or a C16 tensor.
+int fq_pwconv_i8_shortcut_c16(const void* x, const int8_t* wcodes, const float* wscale, const int32_t* wsum, const float* bias,
+                              float* y, void* y16, int64_t n, int64_t cin, int64_t cin_pad, int64_t cout, int64_t hw,
+                              const float* in_stat, const float* in_thr, int in_width, unsigned in_flags, float* out_current_max,
+                              const float* bn_scale, const float* bn_shift, int act, float* stat_out, const void* x2, int x2_is_c16,
+                              const int8_t* wcodes2, const float* wscale2, const int32_t* wsum2, int64_t cin2, int64_t cin2_pad,
+                              const float* in_stat2, const float* in_thr2, int in_width2, unsigned in_flags2,
+                              float* out_current_max2, const float* bn_scale2, const float* bn_shift2, const float* out_thr,
+                              int out_width, unsigned out_flags, fqStream_t stream) {
+  FQ_REQUIRE(y16 != nullptr && in_thr != nullptr, "fq_pwconv_i8_shortcut_c16: null pointer (y16, in_thr: codes in, code copy out)");
+  return pwconv_shortcut(x, true, wcodes, wscale, wsum, bias, y, y16, n, cin, cin_pad, cout, hw, in_stat, in_thr, in_width,
+                         in_flags, out_current_max, bn_scale, bn_shift, act, stat_out, x2, x2_is_c16 != 0, wcodes2, wscale2, wsum2,
+                         cin2, cin2_pad, in_stat2, in_thr2, in_width2, in_flags2, out_current_max2, bn_scale2, bn_shift2, out_thr,
+                         out_width, out_flags, stream);
 }
 
 int fq_pwconv_i8_c16(const void* x, int x_is_c16, const int8_t* wcodes, const float* wscale, const int32_t* wsum,

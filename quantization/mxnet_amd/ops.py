@@ -785,13 +785,27 @@ def pwconv_shortcut_supported(cin, cin2, cout):
 
 def pwconv_i8_shortcut(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=None, width=8, flags=0, cur_out=None,
                        bn_scale=None, bn_shift=None, act=None, x2=None, wcodes2=None, wscale2=None, wsum2=None, in_stat2=None,
-                       in_thr2=None, width2=8, flags2=0, cur_out2=None, bn_scale2=None, bn_shift2=None):
+                       in_thr2=None, width2=8, flags2=0, cur_out2=None, bn_scale2=None, bn_shift2=None, side_codes=None):
     """The closing 1x1 convolution of a residual unit and the unit's shortcut convolution (`..2` arguments: 1x1 on x2, BatchNorm,
     no activation, no bias) in one launch (fq_pwconv_i8_shortcut): what `pwconv_i8(x, ..., residual=pwconv_i8(x2, ...)[0])` returns,
-    bit for bit, without the shortcut tensor.  Returns (y, stat)."""
-    for name, t, dt in (("x", x, None), ("wcodes", wcodes, torch.int8), ("wscale", wscale, None), ("wsum", wsum, torch.int32),
-                        ("x2", x2, None), ("wcodes2", wcodes2, torch.int8), ("wscale2", wscale2, None), ("wsum2", wsum2, torch.int32),
-                        ("bn_scale2", bn_scale2, None), ("bn_shift2", bn_shift2, None)):
+    bit for bit, without the shortcut tensor.  Returns (y, stat).
+
+    Stored thresholds (fq_pwconv_i8_shortcut_c16): `x` a `Codes16` made with in_thr, `side_codes=dict(thr=, width=8, flags=0)` - y
+    leaves as fp32 and, third value, as the `Codes16` of y under that threshold (as `pwconv_i8(..., side_codes=)`); `x2` fp32 or a
+    `Codes16` made with in_thr2."""
+    a16, b16 = isinstance(x, Codes16), isinstance(x2, Codes16)
+    if a16 != (side_codes is not None) or (b16 and not a16):
+        raise ValueError("pwconv_i8_shortcut: fp32 on every side, or a Codes16 x with side_codes (x2 then fp32 or Codes16)")
+    if a16 and (in_thr is None or not x.matches(in_thr, width, flags)):
+        raise ValueError("the C16 input was quantised with another threshold / width / signedness than this call names")
+    if b16 and (in_thr2 is None or not x2.matches(in_thr2, width2, flags2)):
+        raise ValueError("the C16 shortcut input was quantised with another threshold / width / signedness than this call names")
+    xt, x2t = (x.t if a16 else x), (x2.t if b16 else x2)
+    xs, x2s = (x.shape if a16 else tuple(x.shape)), (x2.shape if b16 else tuple(x2.shape))
+    for name, t, dt in (("x", xt, torch.int8 if a16 else None), ("wcodes", wcodes, torch.int8), ("wscale", wscale, None),
+                        ("wsum", wsum, torch.int32), ("x2", x2t, torch.int8 if b16 else None), ("wcodes2", wcodes2, torch.int8),
+                        ("wscale2", wscale2, None), ("wsum2", wsum2, torch.int32), ("bn_scale2", bn_scale2, None),
+                        ("bn_shift2", bn_shift2, None)):
         if dt is None:
             _check(t, name)
         else:
@@ -800,27 +814,40 @@ def pwconv_i8_shortcut(x, wcodes, wscale, wsum, bias=None, in_stat=None, in_thr=
                     ("cur_out", cur_out), ("in_stat2", in_stat2), ("in_thr2", in_thr2), ("cur_out2", cur_out2)):
         if t is not None:
             _check(t, name)
-    if x.dim() != 4 or x2.dim() != 4 or tuple(x.shape[2:]) != tuple(x2.shape[2:]) or x.shape[0] != x2.shape[0]:
-        raise ValueError("pwconv_i8_shortcut wants x (N, Cin, H, W) and x2 (N, Cin2, H, W); got %s and %s" % (tuple(x.shape), tuple(x2.shape)))
-    n, cin, h, w = x.shape
-    cin2 = x2.shape[1]
+    if len(xs) != 4 or len(x2s) != 4 or tuple(xs[2:]) != tuple(x2s[2:]) or xs[0] != x2s[0]:
+        raise ValueError("pwconv_i8_shortcut wants x (N, Cin, H, W) and x2 (N, Cin2, H, W); got %s and %s" % (tuple(xs), tuple(x2s)))
+    n, cin, h, w = xs
+    cin2 = x2s[1]
+    dev = xt.device
     cout = wscale.numel()
     if wscale2.numel() != cout:
         raise ValueError("the two convolutions must have the same number of filters (%d and %d)" % (cout, wscale2.numel()))
     if wcodes.shape[1] != cin or wcodes2.shape[1] != cin2 or not pwconv_shortcut_supported(cin, cin2, cout):
         raise ValueError("pwconv_i8_shortcut: %d / %d -> %d channels is not a shape it takes" % (cin, cin2, cout))
     if in_stat is not None and cur_out is None:
-        cur_out = torch.empty(1, dtype=torch.float32, device=x.device)
+        cur_out = torch.empty(1, dtype=torch.float32, device=dev)
     if in_stat2 is not None and cur_out2 is None:
-        cur_out2 = torch.empty(1, dtype=torch.float32, device=x.device)
-    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
-    stat, zflag = _stat_target(n, x.device, True)
-    check_call(_lib_().fq_pwconv_i8_shortcut(_ptr(x), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin, cin, cout,
-                                             h * w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(cur_out), _ptr(bn_scale),
-                                             _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _ptr(x2), _ptr(wcodes2), _ptr(wscale2),
-                                             _ptr(wsum2), cin2, cin2, _ptr(in_stat2), _ptr(in_thr2), int(width2), int(flags2),
-                                             _ptr(cur_out2), _ptr(bn_scale2), _ptr(bn_shift2), _stream(x)))
-    return y, stat
+        cur_out2 = torch.empty(1, dtype=torch.float32, device=dev)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=dev)
+    stat, zflag = _stat_target(n, dev, True)
+    if not a16:
+        check_call(_lib_().fq_pwconv_i8_shortcut(_ptr(xt), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), n, cin, cin,
+                                                 cout, h * w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags), _ptr(cur_out),
+                                                 _ptr(bn_scale), _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat), _ptr(x2t),
+                                                 _ptr(wcodes2), _ptr(wscale2), _ptr(wsum2), cin2, cin2, _ptr(in_stat2), _ptr(in_thr2),
+                                                 int(width2), int(flags2), _ptr(cur_out2), _ptr(bn_scale2), _ptr(bn_shift2),
+                                                 _stream(xt)))
+        return y, stat
+    sthr = _check(side_codes["thr"], "side_codes['thr']")
+    y16 = Codes16.empty((n, cout, h, w), dev, sthr, side_codes.get("width", 8), side_codes.get("flags", 0))
+    check_call(_lib_().fq_pwconv_i8_shortcut_c16(_ptr(xt), _ptr(wcodes), _ptr(wscale), _ptr(wsum), _ptr(bias), _ptr(y), _ptr(y16.t), n,
+                                                 cin, cin, cout, h * w, _ptr(in_stat), _ptr(in_thr), int(width), int(flags),
+                                                 _ptr(cur_out), _ptr(bn_scale), _ptr(bn_shift), _ACTS[act] | zflag, _ptr(stat),
+                                                 _ptr(x2t), 1 if b16 else 0, _ptr(wcodes2), _ptr(wscale2), _ptr(wsum2), cin2, cin2,
+                                                 _ptr(in_stat2), _ptr(in_thr2), int(width2), int(flags2), _ptr(cur_out2),
+                                                 _ptr(bn_scale2), _ptr(bn_shift2), _ptr(sthr), int(y16.width), int(y16.flags),
+                                                 _stream(wcodes)))
+    return y, stat, y16
 
 
 def pwconv_gap_supported(xshape, cout, residual=False):

@@ -364,14 +364,17 @@ def defer_shortcut(block, fz, x, x_arg, c16_in, codes3, bias, scale, shift, plan
     if not getattr(block, "_fq_defer_short", False):
         return None
     block._fq_defer_short = False
-    if extra or c16_in is not None or bias is not None or scale is None or fz["act"] != "none" or stride_ != 1:
+    if extra or bias is not None or scale is None or fz["act"] != "none" or stride_ != 1:
+        return None
+    if c16_in is not None and "in_thr" not in plan:
         return None
     if autograd.is_recording() or _fuse._collection is not None or getattr(ops.StatArena._tls, "current", None) is None:
         return None
     if any(_hooked(b) for b in (block, fz.get("bn"))) or not plan:
         return None
     xs = tuple(x_arg.shape)
-    out = NDArray(_placeholder((xs[0], block._kwargs["num_filter"], xs[2], xs[3]), x_arg.device))
+    dev = x_arg.t.device if isinstance(x_arg, ops.Codes16) else x_arg.device
+    out = NDArray(_placeholder((xs[0], block._kwargs["num_filter"], xs[2], xs[3]), dev))
     out._fq_short = dict(x=x_arg, codes=codes3, bn=(scale, shift), plan=dict(plan), block=block)
     return out
 
@@ -542,19 +545,30 @@ def pointwise_fused(block, F, x, weight_raw, weight_q, bias, plan, weights_quant
                 # the unit's shortcut arrives as the record of its convolution: both sums in this launch when the shapes are built
                 # (fp32 inputs on both sides, BatchNorm here as there), else the shortcut is computed now and added as a tensor
                 d = res["short"]
-                if (c16_in is None and block._kwargs["stride"][0] == 1 and scale is not None and not _hooked(block)
+                # (stored thresholds: this convolution reads the 3x3's codes and leaves the code copy for the next unit's first 1x1 -
+                # the dual form's pair of outputs; the shortcut convolution's input may be codes as well)
+                side_s = side_target(block, c16_in) if c16_in is not None else None
+                d16 = isinstance(d["x"], ops.Codes16)
+                if (block._kwargs["stride"][0] == 1 and scale is not None and not _hooked(block)
+                        and (c16_in is None and not d16 or (side_s is not None and "in_thr" in plan))
                         and tuple(d["x"].shape[2:]) == tuple(xshape[2:]) and d["x"].shape[0] == xshape[0]
                         and ops.pwconv_shortcut_supported(xshape[1], d["x"].shape[1], block._kwargs["num_filter"])
+                        and (c16_in is None or block._kwargs["num_filter"] % 512 == 0 or xshape[1] == 64)
                         and not autograd.is_recording()):
                     p2 = d["plan"]
-                    y, stat = ops.pwconv_i8_shortcut(x_arg, codes, scales, rowsum, None if bias is None else bias._t, bn_scale=scale,
-                                                     bn_shift=shift, act=res["act"], x2=d["x"], wcodes2=d["codes"][0],
-                                                     wscale2=d["codes"][1], wsum2=d["codes"][2], in_stat2=p2.get("in_stat"),
-                                                     in_thr2=p2.get("in_thr"), width2=p2["width"], flags2=p2["flags"],
-                                                     cur_out2=p2.get("cur_out"), bn_scale2=d["bn"][0], bn_shift2=d["bn"][1], **plan)
+                    kw2 = dict(x2=d["x"], wcodes2=d["codes"][0], wscale2=d["codes"][1], wsum2=d["codes"][2], in_stat2=p2.get("in_stat"),
+                               in_thr2=p2.get("in_thr"), width2=p2["width"], flags2=p2["flags"], cur_out2=p2.get("cur_out"),
+                               bn_scale2=d["bn"][0], bn_shift2=d["bn"][1])
+                    if side_s is not None:
+                        a_ = side_s.quantize_args
+                        kw2["side_codes"] = dict(thr=side_s.input_max.data()._t, width=a_.in_width, flags=ops.act_flags(signed=a_.in_signed))
+                    out = ops.pwconv_i8_shortcut(x_arg, codes, scales, rowsum, None if bias is None else bias._t, bn_scale=scale,
+                                                 bn_shift=shift, act=res["act"], **kw2, **plan)
                     res["used"] = True
-                    folded = NDArray(y)
-                    folded._fq_stat = stat
+                    folded = NDArray(out[0])
+                    folded._fq_stat = out[1]
+                    if side_s is not None:
+                        folded._fq_side = (side_s, out[2])
                     return folded
                 res["t"] = materialise_shortcut_record(d)
                 res["short"] = None

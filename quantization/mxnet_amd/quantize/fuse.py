@@ -342,9 +342,7 @@ def _residual_unit_forward(self, x):
     if sub is not None and sub["unit"] is not self:
         raise RuntimeError("a subsampled trunk (fq_pwconv_i8_sub2) reached a unit it was not made for")
     tail = _tail_conv(self.body)
-    # (under stored thresholds the closing convolution is handed codes by the unit's 3x3 and runs the dual form: no folding there,
-    # and the shortcut convolution keeps its place in the launch order)
-    sc = _shortcut_conv(self) if (tail is not None and SHORTCUT_FUSE and not getattr(tail, "quantize_input_offline", False)) else None
+    sc = _shortcut_conv(self) if (tail is not None and SHORTCUT_FUSE) else None
     if sc is not None:
         sc._fq_defer_short = True                  # one shot: convert_conv2d.pointwise_fused may answer with a record instead
     try:

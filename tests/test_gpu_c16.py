@@ -411,6 +411,14 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
             return fn(x, *a, **k)
         return wrapped
     ops.pwconv_i8, ops.conv3x3_i8, ops.dwconv3x3_c16 = count(real_pw), count(real_c3), count(real_dw)
+    # (round 6: the closing 1x1 of a stage's first unit computes the unit's shortcut convolution itself - fq_pwconv_i8_shortcut_c16 -
+    # and reads that convolution's input, codes on stages 2 and 3, as its second operand)
+    real_short = ops.pwconv_i8_shortcut
+
+    def counted_short(x, *a, **k):
+        calls["c16_in"] += isinstance(k.get("x2"), ops.Codes16)
+        return count(real_short)(x, *a, **k)
+    ops.pwconv_i8_shortcut = counted_short
     try:
         fuse.HANDOVER = True
         with_codes = net(xs[2]).asnumpy()
@@ -446,6 +454,7 @@ def test_net_with_hand_overs_equals_net_without(gpu, model, kw):
         assert calls["c16_out"] == 0 and calls["c16_in"] == 0, "online quantisation: the threshold is not known to the producer"
     finally:
         ops.pwconv_i8, ops.conv3x3_i8, ops.dwconv3x3_c16 = real_pw, real_c3, real_dw
+        ops.pwconv_i8_shortcut = real_short
         fuse.HANDOVER = True
         fuse.SIDE_CODES = True
         torch.backends.cudnn.deterministic = was_deterministic

@@ -196,3 +196,92 @@ def test_a_deferred_shortcut_nobody_folds_is_materialised(dev, ops):
     finally:
         fuse.SUBSAMPLE = old
         ops.pwconv_i8_shortcut = real
+
+
+C16_CASES = [(3, 64, 64, 256, 56, 56, False), (3, 128, 256, 512, 28, 28, True), (3, 128, 256, 512, 28, 28, False),
+             (5, 256, 512, 1024, 14, 14, True), (9, 256, 512, 1024, 7, 7, False)]
+
+
+@pytest.mark.parametrize("case", C16_CASES, ids=["%dx%d+%d->%d@%dx%d%s" % (c[:6] + ("-codes" if c[6] else "-fp32",)) for c in C16_CASES])
+def test_folded_shortcut_under_stored_thresholds_equals_the_two_launches(dev, ops, case):
+    """fq_pwconv_i8_shortcut_c16: x as codes, y as fp32 + code copy, the shortcut's input fp32 or codes - against the shortcut's own
+    launch followed by fq_pwconv_i8_c16_dual with it as residual: y, code copy, statistic, both current_input_max."""
+    from oracle import fq_oracle as O
+    n, cin, cin2, cout, h, w, b16 = case
+    rng = np.random.default_rng(cin + cin2 + h + int(b16))
+    x = np.maximum(rng.standard_normal((n, cin, h, w)) * 1.5, 0).astype(np.float32)
+    x2 = np.maximum(rng.standard_normal((n, cin2, h, w)) * 2.0, 0).astype(np.float32)
+    thr, thr2, thr3 = np.float32(2.3), np.float32(3.7), np.float32(4.1)
+    thr_t, thr2_t, thr3_t = (_t(np.float32([v]), dev) for v in (thr, thr2, thr3))
+    cx = O.ste_codes(x, O.act_scale(thr, False, 8), thr, np.float32(0))
+    xc = ops.Codes16(_t(O.to_c16(cx.astype(np.int64), 128), dev), x.shape, thr_t, 8, 0)
+    if b16:
+        cx2 = O.ste_codes(x2, O.act_scale(thr2, False, 8), thr2, np.float32(0))
+        x2a = ops.Codes16(_t(O.to_c16(cx2.astype(np.int64), 128), dev), x2.shape, thr2_t, 8, 0)
+    else:
+        x2a = _t(x2, dev)
+    c1 = ops.weight_codes(_t((rng.standard_normal((cout, cin)) * 0.1).astype(np.float32), dev), 1, 8)
+    c2 = ops.weight_codes(_t((rng.standard_normal((cout, cin2)) * 0.05).astype(np.float32), dev), 1, 8)
+    bn = (_t((0.5 + rng.random(cout)).astype(np.float32), dev), _t((rng.standard_normal(cout) * 0.3).astype(np.float32), dev))
+    bn2 = (_t((0.5 + rng.random(cout)).astype(np.float32), dev), _t((rng.standard_normal(cout) * 0.3).astype(np.float32), dev))
+    st1, st2 = _t(O.absmax_per_sample(x), dev), _t(O.absmax_per_sample(x2), dev)
+    side = dict(thr=thr3_t, width=8, flags=0)
+    cur = [torch.zeros(1, device=dev) for _ in range(4)]
+    s, _ = ops.pwconv_i8(x2a, *c2, None, in_thr=thr2_t, in_stat=st2, width=8, flags=0, cur_out=cur[0], bn_scale=bn2[0], bn_shift=bn2[1],
+                         act=None, want_stat=False)
+    want, want_stat, want16 = ops.pwconv_i8(xc, *c1, None, in_thr=thr_t, in_stat=st1, width=8, flags=0, cur_out=cur[1], bn_scale=bn[0],
+                                            bn_shift=bn[1], act="relu", residual=s, side_codes=side)
+    got, got_stat, got16 = ops.pwconv_i8_shortcut(xc, *c1, None, in_thr=thr_t, in_stat=st1, width=8, flags=0, cur_out=cur[3],
+                                                  bn_scale=bn[0], bn_shift=bn[1], act="relu", x2=x2a, wcodes2=c2[0], wscale2=c2[1],
+                                                  wsum2=c2[2], in_thr2=thr2_t, in_stat2=st2, width2=8, flags2=0, cur_out2=cur[2],
+                                                  bn_scale2=bn2[0], bn_shift2=bn2[1], side_codes=side)
+    _eq(N(got), N(want), "fp32 output")
+    _eq(N(got16.t), N(want16.t), "code copy")
+    _eq(N(got_stat), N(want_stat), "statistic")
+    _eq(N(cur[2]), N(cur[0]), "current_input_max of the shortcut convolution")
+    _eq(N(cur[3]), N(cur[1]), "current_input_max of the closing convolution")
+
+
+def test_resnet50_offline_with_folded_shortcuts_equals_the_same_net_without(dev, ops):
+    """BASELINE configuration 3's evaluation (stored thresholds, codes between the layers): the three stage heads fold their shortcut
+    convolution (fq_pwconv_i8_shortcut_c16: codes in, fp32 + code copy out); logits and every current_input_max bit-equal."""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.quantize import fuse
+    from test_gpu_net import _build
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        rng = np.random.default_rng(18)
+        xs = [mx.nd.array(rng.standard_normal((4, 3, 224, 224)).astype(np.float32), ctx=mx.gpu(0)) for _ in range(3)]
+        outs = {}
+        for on in (False, True):
+            net = _build("resnet50_v1", 1000, mx.gpu(0), quant_type="channel")
+            net.quantize_input(enable=True, online=True)
+            for x in xs[:2]:
+                net(x)
+                net.update_ema()
+            net.fix_params()
+            net.quantize_input(enable=True, online=False)
+            net(xs[2])
+            fuse.fuse_inference(net)
+            old, fuse.SHORTCUT_FUSE = fuse.SHORTCUT_FUSE, on
+            seen = []
+            real = ops.pwconv_i8_shortcut
+
+            def spy(*a, **k):
+                seen.append((isinstance(a[0], ops.Codes16), isinstance(k["x2"], ops.Codes16), k.get("side_codes") is not None))
+                return real(*a, **k)
+            ops.pwconv_i8_shortcut = spy
+            try:
+                out = net(xs[2])
+                cur = np.asarray([float(b.current_input_max) for b in net.collect_quantized_blocks()], np.float32)
+            finally:
+                fuse.SHORTCUT_FUSE = old
+                ops.pwconv_i8_shortcut = real
+            outs[on] = (N(out._t), cur, seen)
+        # stage 1: the pooled first convolution's output is fp32; stages 2 and 3: the subsampled trunk's code copy
+        assert outs[False][2] == [] and outs[True][2] == [(True, False, True), (True, True, True), (True, True, True)], outs[True][2]
+        _eq(outs[True][0], outs[False][0], "logits")
+        _eq(outs[True][1], outs[False][1], "current_input_max of every block")
+    finally:
+        torch.backends.cudnn.deterministic = was

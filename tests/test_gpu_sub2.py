@@ -276,12 +276,22 @@ def test_resnet50_offline_with_subsampled_stage_boundaries_equals_the_same_net_w
                     readers.append(tuple(a[0].shape))                # (256 @28x28, 512 @14x14, 1024 @7x7: a stage's input)
                 return real(*a, **k)
             ops.pwconv_i8 = spy
+            # (the shortcut convolutions of stages 2 and 3 read the subsampled code copy as the second operand of their unit's closing
+            # 1x1: fq_pwconv_i8_shortcut_c16)
+            real_short = ops.pwconv_i8_shortcut
+
+            def spy_short(*a, **k):
+                if isinstance(k.get("x2"), ops.Codes16) and k["x2"].shape[1] * k["x2"].shape[2] == 7168:
+                    readers.append(tuple(k["x2"].shape))
+                return real_short(*a, **k)
+            ops.pwconv_i8_shortcut = spy_short
             try:
                 out = net(xs[2])
                 cur = np.asarray([float(b.current_input_max) for b in net.collect_quantized_blocks()], np.float32)
             finally:
                 fuse.SUBSAMPLE = old
                 ops.pwconv_i8 = real
+                ops.pwconv_i8_shortcut = real_short
             outs[on] = (N(out._t), cur, seen, readers)
         assert len(outs[False][2]) == 0 and len(outs[True][2]) == 3, outs[True][2]
         # both readers of every boundary take the subsampled code copy with stride 1 (256 @28x28, 512 @14x14, 1024 @7x7 are the
