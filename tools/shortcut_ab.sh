@@ -10,7 +10,8 @@ ab() { echo "## $1"; python3 tools/ab.py --rounds $2 --args "$3" "two launches|F
   ab "resnet50_v1 online, batch 32" 2 "--model resnet50_v1 --quant-type channel --batch-size 32 --steps 200"
   ab "resnet50_v1 online, batch 64" 2 "--model resnet50_v1 --quant-type channel --batch-size 64 --steps 150"
   ab "resnet101_v1 online, batch 128 (no rule was tuned on it)" 2 "--model resnet101_v1 --quant-type channel --steps 60"
-  ab "resnet50_v1 offline (codes between the layers: not taken - must be equal)" 2 "--model resnet50_v1 --quant-type channel --offline --steps 100"
+  ab "resnet50_v1 per-channel W8A8 offline (BASELINE configuration 3), batch 128" 3 "--model resnet50_v1 --quant-type channel --offline --steps 100"
+  ab "resnet152_v1 offline, batch 128" 2 "--model resnet152_v1 --quant-type channel --offline --steps 40"
 } > $O/ab.txt 2>&1
 cat $O/ab.txt
 bash tools/kernel_table.sh cfg3on_short --model resnet50_v1 --quant-type channel > /dev/null 2>&1
