@@ -308,12 +308,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void pwconv_short_kernel(
 
 namespace fqi {
 
-// shapes fq_pwconv_i8_shortcut takes: the stage heads of the v1 bottleneck ResNets on the 56x56, 28x28 and 14x14 planes (K of the
-// closing convolution / K of the shortcut convolution: 64 / 64, 128 / 256, 256 / 512), Cout a multiple of 512 (of 256 for 64 / 64).
-// (512 / 1024 -> 2048 @7x7 was built and measured: 89 us against 34 + 31 for the two launches - eight channel groups quantise the
-// same 48 slabs of a 32-pixel tile - and is left to them.)
+// shapes fq_pwconv_i8_shortcut takes: the four stage heads of the v1 bottleneck ResNets (K of the closing convolution / K of the
+// shortcut convolution: 64 / 64, 128 / 256, 256 / 512, 512 / 1024), Cout a multiple of 512 (of 256 for 64 / 64).
+// (512 / 1024 -> 2048 @7x7 with FOUR wavefronts - eight channel groups quantise the same 48 slabs of a 32-pixel tile - was 89 us
+// against 34 + 31 for the two launches; with eight wavefronts it is worth +0.24 % (sd 0.08) of ResNet-50's images/s.)
 bool pw_short_shape_ok(int64_t cin, int64_t cin2, int64_t cout) {
-  const bool pair = (cin == 64 && cin2 == 64) || (cin == 128 && cin2 == 256) || (cin == 256 && cin2 == 512);
+  const bool pair = (cin == 64 && cin2 == 64) || (cin == 128 && cin2 == 256) || (cin == 256 && cin2 == 512) || (cin == 512 && cin2 == 1024);
   return pair && cout > 0 && cout % (cin == 64 ? 256 : 512) == 0;
 }
 
@@ -365,9 +365,11 @@ int pw_short_launch(const PwCall& a, const PwCall& b) {
     launched = true;                                                                                                   \
   }
   FQ_PWSH_CASE(2, 2, 4) FQ_PWSH_CASE(4, 8, 4) FQ_PWSH_CASE(8, 16, 4) FQ_PWSH_CASE(4, 8, 8) FQ_PWSH_CASE(8, 16, 8)
+  FQ_PWSH_CASE(16, 32, 8)
   // stored thresholds: codes in, fp32 + code copy out; the shortcut's input fp32 (stage 1: the pooled first convolution) or codes
   FQ_PWSH_CASE_C(2, 2, 4, true, false, true) FQ_PWSH_CASE_C(4, 8, 8, true, false, true) FQ_PWSH_CASE_C(8, 16, 8, true, false, true)
   FQ_PWSH_CASE_C(4, 8, 8, true, true, true) FQ_PWSH_CASE_C(8, 16, 8, true, true, true)
+  FQ_PWSH_CASE_C(16, 32, 8, true, false, true) FQ_PWSH_CASE_C(16, 32, 8, true, true, true)
 #undef FQ_PWSH_CASE_C
 #undef FQ_PWSH_CASE
   FQ_REQUIRE(launched, "fq_pwconv_i8_shortcut: no instantiation for K/32 = %d and %d", kt, kt2);

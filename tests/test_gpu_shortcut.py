@@ -45,6 +45,7 @@ CASES = [
     (3, 128, 256, 512, 28, 28),      # stage 2 (the shortcut reads the subsampled trunk)
     (5, 256, 512, 1024, 14, 14),     # stage 3
     (9, 256, 512, 1024, 7, 7),       # tiles straddle samples (49 pixels), nine samples
+    (6, 512, 1024, 2048, 7, 7),      # stage 4
     (2, 64, 64, 256, 5, 3),          # tiny planes: several samples per tile
 ]
 MODES = ["online_u8_relu", "online_s8_none", "offline_u8_relu", "mixed_relu6_bias"]
@@ -119,14 +120,14 @@ def test_folded_shortcut_equals_the_two_launches_and_the_host_twin(dev, ops, cas
 
 def test_folded_shortcut_refuses_what_it_is_not_built_for(dev, ops):
     assert ops.pwconv_shortcut_supported(64, 64, 256) and ops.pwconv_shortcut_supported(256, 512, 1024)
-    assert not ops.pwconv_shortcut_supported(512, 1024, 2048)        # (measured slower than the two launches at 7x7: left to them)
+    assert ops.pwconv_shortcut_supported(512, 1024, 2048) and not ops.pwconv_shortcut_supported(512, 1024, 1280)
     assert not ops.pwconv_shortcut_supported(64, 128, 256) and not ops.pwconv_shortcut_supported(64, 64, 128)
 
 
 @pytest.mark.parametrize("wino", ["none", "F43"])
 def test_resnet50_with_folded_shortcuts_equals_the_same_net_without(dev, ops, wino):
-    """Three launches compute their unit's shortcut convolution themselves (stage 1 on the pooled input, stages 2 and 3 on the
-    subsampled trunk; stage 4's 7x7 planes keep the two launches): logits, every block's current_input_max and the thresholds after a naive-EMA step are bit-equal."""
+    """Four launches compute their unit's shortcut convolution themselves (stage 1 on the pooled input, stages 2 to 4 on the
+    subsampled trunk): logits, every block's current_input_max and the thresholds after a naive-EMA step are bit-equal."""
     from quantization.mxnet_amd import mx
     from quantization.mxnet_amd.quantize import fuse
     from test_gpu_net import _build as build
@@ -152,7 +153,7 @@ def test_resnet50_with_folded_shortcuts_equals_the_same_net_without(dev, ops, wi
             fuse.SHORTCUT_FUSE = old
             ops.pwconv_i8_shortcut = real
         outs[on] = (N(out._t), cur, thr, seen)
-    assert outs[False][3] == [] and len(outs[True][3]) == 3, outs[True][3]
+    assert outs[False][3] == [] and len(outs[True][3]) == 4, outs[True][3]
     assert outs[True][3][0] == ((4, 64, 56, 56), (4, 64, 56, 56)) and outs[True][3][1] == ((4, 128, 28, 28), (4, 256, 28, 28))
     _eq(outs[True][0], outs[False][0], "logits")
     _eq(outs[True][1], outs[False][1], "current_input_max of every block")
@@ -189,7 +190,7 @@ def test_a_deferred_shortcut_nobody_folds_is_materialised(dev, ops):
         tail._fq_no_int8 = True
         del seen[:]
         got = net(X).asnumpy()
-        assert len(seen) == 2 and (2, 64, 56, 56) not in seen
+        assert len(seen) == 3 and (2, 64, 56, 56) not in seen
         # (a library convolution of the fake-quantised tensors where the integer path was: another summation order, amplified by
         # the online thresholds behind it - the distance fusing itself has)
         assert np.abs(got - want).max() <= 2e-2 * np.abs(want).max()
@@ -199,7 +200,7 @@ def test_a_deferred_shortcut_nobody_folds_is_materialised(dev, ops):
 
 
 C16_CASES = [(3, 64, 64, 256, 56, 56, False), (3, 128, 256, 512, 28, 28, True), (3, 128, 256, 512, 28, 28, False),
-             (5, 256, 512, 1024, 14, 14, True), (9, 256, 512, 1024, 7, 7, False)]
+             (5, 256, 512, 1024, 14, 14, True), (9, 256, 512, 1024, 7, 7, False), (4, 512, 1024, 2048, 7, 7, True)]
 
 
 @pytest.mark.parametrize("case", C16_CASES, ids=["%dx%d+%d->%d@%dx%d%s" % (c[:6] + ("-codes" if c[6] else "-fp32",)) for c in C16_CASES])
@@ -280,7 +281,7 @@ def test_resnet50_offline_with_folded_shortcuts_equals_the_same_net_without(dev,
                 ops.pwconv_i8_shortcut = real
             outs[on] = (N(out._t), cur, seen)
         # stage 1: the pooled first convolution's output is fp32; stages 2 and 3: the subsampled trunk's code copy
-        assert outs[False][2] == [] and outs[True][2] == [(True, False, True), (True, True, True), (True, True, True)], outs[True][2]
+        assert outs[False][2] == [] and outs[True][2] == [(True, False, True)] + [(True, True, True)] * 3, outs[True][2]
         _eq(outs[True][0], outs[False][0], "logits")
         _eq(outs[True][1], outs[False][1], "current_input_max of every block")
     finally:

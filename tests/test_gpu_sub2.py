@@ -276,7 +276,7 @@ def test_resnet50_offline_with_subsampled_stage_boundaries_equals_the_same_net_w
                     readers.append(tuple(a[0].shape))                # (256 @28x28, 512 @14x14, 1024 @7x7: a stage's input)
                 return real(*a, **k)
             ops.pwconv_i8 = spy
-            # (the shortcut convolutions of stages 2 and 3 read the subsampled code copy as the second operand of their unit's closing
+            # (the shortcut convolutions of stages 2 to 4 read the subsampled code copy as the second operand of their unit's closing
             # 1x1: fq_pwconv_i8_shortcut_c16)
             real_short = ops.pwconv_i8_shortcut
 
