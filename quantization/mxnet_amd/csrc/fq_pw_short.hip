@@ -28,6 +28,7 @@ struct PwShortGeom {
   int out_lo_neg, out_zoff;
   char* y16;
   const float* dual_thr;
+  int nts;                   // nontemporal stores of y (an output the Infinity Cache cannot hold until its readers start)
 };
 
 // the shortcut convolution's operands (the closing convolution's travel as plain kernel arguments, as in the split form)
@@ -273,7 +274,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void pwconv_short_kernel(
         }
         v = v + s;
         v = act_rt(v, act);
-        buf_st_f32(yr, yo, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
+        if (g.nts) buf_st_f32_nt(yr, yo, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
+        else buf_st_f32(yr, yo, (unsigned)(c * 32 + 8 * gq + r) * plane4, v);
         m = fmaxf(m, fabsf(v));
         vq[r] = v;
       }
@@ -336,6 +338,8 @@ int pw_short_launch(const PwCall& a, const PwCall& b) {
   t.CBi = (int)((a.cin + 15) / 16); t.CBi2 = (int)((b.cin + 15) / 16); t.CBo = (int)((a.cout + 15) / 16);
   t.out_levels = a.out_levels; t.out_lo_neg = a.out_lo_neg; t.out_zoff = a.out_zoff;
   t.y16 = (char*)a.y16; t.dual_thr = a.dual_thr;
+  static const int nts_mb = env_int("FQ_PWSH_NTS_MB", 150);              // (the streaming form's policy, FQ_PWS_NTS_MB)
+  t.nts = 4e-6 * (double)a.n * a.cout * a.hw >= nts_mb ? 1 : 0;
   const bool a16 = a.in_c16, b16 = b.in_c16, dual = a.y16 != nullptr;
   FQ_REQUIRE((!a16 && !b16 && !dual) || (a16 && dual), "fq_pwconv_i8_shortcut_c16: built for fp32 on every side, or for codes in + "
              "the code copy out (the shortcut convolution's input fp32 or codes)");
