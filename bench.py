@@ -889,14 +889,19 @@ def main():
                          "frac_algorithmic": dk.get("frac_algorithmic", dk["frac"]),
                          "frac_what": "algorithmic bytes / (HIP-event time of the family's launches - per launch the cost of the "
                                       "event pair, measured in this process on a self-timing kernel: launch_overhead_us_measured); in "
-                                      "a process under rocprofv3 this equals the profiler's kernel table of that process to 0.3-1.7 % "
-                                      "(tools/check_events_vs_rocprof.py, profiles/r4_events_vs_rocprof.txt); frac_raw_events keeps the "
-                                      "event pairs' cost in (a lower bound; 11-15 % low inside a profiled process, 2-10 % otherwise)",
+                                      "an un-profiled process (this line) the family times equal rocprofv3's kernel table of the same box "
+                                      "to 0.1-2.4 % (round 6: dwconv 0.992 / 1.001, pwconv 0.984 / 1.024; tools/check_events_vs_"
+                                      "rocprof.py, profiles/r6_events_vs_rocprof.txt); the line a process prints UNDER rocprofv3 matched "
+                                      "its own table to 0.3-1.7 % in rounds 4-5 and sits 3-7 % above it in round 6's runs (the "
+                                      "profiler's gap between two dispatches, which the calibration's back-to-back launches count as "
+                                      "kernel time, grew: null-kernel launch 8.5 us there against 6.1 us in round 5 and 1.6 us "
+                                      "un-profiled); frac_raw_events keeps the event pairs' cost in (a lower bound; 11-25 % low "
+                                      "inside a profiled process, 2-10 % otherwise)",
                          "frac_raw_events": dk["frac_raw_events"],
                          "traffic": None, "traffic_from_profiles": traffic_from_profiles,
                          "frac_method": "fixed since round 4 (events minus the measured pair cost); last validated against "
-                                        "profiles/r5_bench_kernel_stats.csv by tools/check_events_vs_rocprof.py "
-                                        "(profiles/r5_events_vs_rocprof.txt)",
+                                        "profiles/r6_bench_kernel_stats.csv by tools/check_events_vs_rocprof.py "
+                                        "(profiles/r6_events_vs_rocprof.txt)",
                          "dominant_by": "largest HIP-event time per step among this library's kernels",
                          "event_sampling": "HIP events bracket every library launch in %d of the %d timed steps (every %d-th "
                                            "step of every third block)%s"

@@ -1,6 +1,6 @@
 """Do the per-kernel figures of a bench.py line follow from a rocprofv3 kernel table?
 
-    python tools/check_events_vs_rocprof.py LINE.json KERNEL_STATS.csv [--tol 0.03] [--steps-from gap_stat]
+    python tools/check_events_vs_rocprof.py LINE.json KERNEL_STATS.csv [--tol 0.03] [--steps-from KERNEL]
 
 LINE.json: a line of `bench.py`: `roofline.kernels[family]` carries `ms_per_step` / `avg_launch_us` / `frac` (HIP-event time
 minus the event pairs' cost measured in that process) and the same with `_raw_events`.  KERNEL_STATS.csv: `rocprofv3
@@ -15,6 +15,10 @@ that process' table - exit status 1 when the DOMINANT family (the one `roofline.
 the same lines: 1.11-1.15.)  A line from ANOTHER process of the same box can be given too, but then two processes are being
 compared: on this pool they differ by up to 10 % whatever is measured (same command, same box, minutes apart: 109.8 k vs
 115.8 k images/s), so that comparison is printed with its ratios and only gated when --cross-process-gate is given.
+Round 6: the same-process ratios are 1.03-1.07 (rc 1) - under the profiler two consecutive dispatches are now 8.5 us apart
+(6.1 us in round 5, 1.6 us un-profiled), and the calibration's back-to-back launches count that gap as kernel time, so the
+event pairs' cost is under-estimated THERE; the un-profiled lines of the same box agree with the table to 0.1-2.4 %, and
+tools/refresh_profiles.sh gates the un-profiled one-stream line too (--cross-process-gate).
 """
 import csv
 import json
@@ -43,8 +47,13 @@ def main(argv):
         tol = float(argv[argv.index("--tol") + 1])
     line = json.load(open(argv[0]))
     rows = list(csv.DictReader(open(argv[1])))
-    steps_kernel = argv[argv.index("--steps-from") + 1] if "--steps-from" in argv else "gap_stat"
-    steps = sum(int(r["Calls"]) for r in rows if steps_kernel in r["Name"])
+    # a kernel every step holds exactly once: the pooling pass, or - since the last 1x1 stores the pooled means itself
+    #  and that pass is gone from the default workload - the classifier's launch
+    steps = 0
+    for steps_kernel in ([argv[argv.index("--steps-from") + 1]] if "--steps-from" in argv else ["gap_stat", "pwconv_rows_kernel"]):
+        steps = sum(int(r["Calls"]) for r in rows if steps_kernel in r["Name"])
+        if steps:
+            break
     if not steps:
         print("no '%s' kernel in the table: cannot tell how many steps the profiled process ran" % steps_kernel)
         return 2
