@@ -681,3 +681,16 @@ def test_every_environment_variable_the_product_reads_is_listed_in_docs_knobs():
     doc = open(os.path.join(root, "docs", "knobs.md")).read()
     assert len(names) >= 70
     assert sorted(n for n in names if n not in doc) == []
+
+
+def test_every_entry_point_of_the_header_is_named_in_integration_md():
+    """The drop-in boundary is documented entry by entry: a function declared in include/fakequant.h and missing from
+    INTEGRATION.md (what it replaces in the reference, or what helper it is) fails here."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "fakequant.h")).read()
+    names = set(re.findall(r'\b(fq_[a-z0-9_]+)\s*\(', re.sub(r'/\*.*?\*/', '', header, flags=re.S)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert len(names) >= 80
+    assert sorted(n for n in names if n not in doc) == []
