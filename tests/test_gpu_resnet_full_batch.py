@@ -114,3 +114,76 @@ def test_resnet50_at_batch_128_with_the_rounds_forms_equals_the_same_net_without
     assert outs[False][2] == 0 and outs[True][2] == 8, (outs[False][2], outs[True][2])        # four stage heads, two forwards
     S._eq(outs[True][0], outs[False][0], "logits")
     S._eq(outs[True][1], outs[False][1], "current_input_max of every block")
+
+
+def _on_off(dev, model, kw, offline, names):
+    """logits and every current_input_max of `model` at (128, 3, 224, 224), the fuse.py switches `names` off and on (a net per setting, the same
+    seeded weights), each forward run twice"""
+    from quantization.mxnet_amd import mx
+    from quantization.mxnet_amd.quantize import fuse
+    from test_gpu_net import _build
+    g = torch.Generator(device=dev).manual_seed(5)
+    X = mx.nd.NDArray(torch.randn(128, 3, 224, 224, device=dev, generator=g))
+    small = [mx.nd.NDArray(X._t[4 * i:4 * i + 4].contiguous()) for i in range(3)]
+    outs = {}
+    for on in (False, True):
+        net = _build(model, 1000, mx.gpu(0), **kw)
+        net.quantize_input(enable=True, online=True)
+        if offline:
+            for x in small[:2]:
+                net(x)
+                net.update_ema()
+        net.fix_params()
+        net.quantize_input(enable=True, online=not offline)
+        net(small[2])
+        fuse.fuse_inference(net)
+        old = [getattr(fuse, n) for n in names]
+        for n in names:
+            setattr(fuse, n, on)
+        try:
+            out = net(X)._t.clone()
+            cur = np.asarray([float(b.current_input_max) for b in net.collect_quantized_blocks()], np.float32)
+            again = net(X)._t.clone()
+        finally:
+            for n, v in zip(names, old):
+                setattr(fuse, n, v)
+        assert torch.equal(out, again), "two forwards of one batch differ (%s %s)" % (names, on)
+        assert bool(torch.isfinite(out).all())
+        outs[on] = (out.cpu().numpy(), cur)
+    return outs
+
+
+@pytest.mark.parametrize("model,kw", [("resnet50_v1", dict(quant_type="channel")), ("mobilenetv2_1.0", dict(quant_type="channel", wt=4))],
+                         ids=["resnet50_v1", "mobilenetv2_1.0-w4"])
+def test_offline_nets_at_batch_128_with_hand_overs_equal_the_same_nets_without(dev, ops, model, kw):
+    """BASELINE configurations 3 and 4 as bench.py runs them: int8 codes between the fused layers (the wide code-to-code streaming
+    forms, the dual closing 1x1 and the 3x3 on codes with eight wavefronts, the depthwise layer on codes - forms a full batch selects)
+    against fp32 between the same layers."""
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    calls = []
+    real = ops.pwconv_i8
+    ops.pwconv_i8 = lambda x, *a, **k: (calls.append(isinstance(x, ops.Codes16)), real(x, *a, **k))[1]
+    try:
+        outs = _on_off(dev, model, kw, True, ("HANDOVER",))
+    finally:
+        ops.pwconv_i8 = real
+        torch.backends.cudnn.deterministic = was
+    assert sum(calls) >= 30, sum(calls)                      # (the switched-on forwards did read codes)
+    S._eq(outs[True][0], outs[False][0], "logits")
+    S._eq(outs[True][1], outs[False][1], "current_input_max of every block")
+
+
+def test_mobilenet_at_batch_128_with_recompute_pairs_and_pooled_producer_equals_the_same_net_without(dev, ops):
+    """The default workload as bench.py runs it (three recompute pairs, the last 1x1 storing the pooled means) against the same net
+    with one storing launch per layer and the pooling pass."""
+    seen = []
+    real = ops.pwdw_fused
+    ops.pwdw_fused = lambda *a, **k: (seen.append(1), real(*a, **k))[1]
+    try:
+        outs = _on_off(dev, "mobilenet1.0", dict(quant_type="layer"), False, ("RECOMPUTE", "GAP_FUSE"))
+    finally:
+        ops.pwdw_fused = real
+    assert len(seen) == 6, len(seen)                         # three pairs, two forwards
+    S._eq(outs[True][0], outs[False][0], "logits")
+    S._eq(outs[True][1], outs[False][1], "current_input_max of every block")
