@@ -187,3 +187,78 @@ def test_mobilenet_at_batch_128_with_recompute_pairs_and_pooled_producer_equals_
     assert len(seen) == 6, len(seen)                         # three pairs, two forwards
     S._eq(outs[True][0], outs[False][0], "logits")
     S._eq(outs[True][1], outs[False][1], "current_input_max of every block")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# (n, c, h, w): the 3x3 of every stage (c -> c)
+C3 = [(128, 64, 56, 56), (128, 128, 28, 28), (128, 256, 14, 14), (128, 512, 7, 7)]
+
+
+@pytest.mark.parametrize("case", C3, ids=["%dx%d@%dx%d" % c for c in C3])
+@pytest.mark.parametrize("sliced", [False, True], ids=["one-slice", "three-slices-F43"])
+def test_dense3x3_at_batch_128_against_the_host_twin(dev, ops, case, sliced):
+    """fq_conv3x3_i8 / fq_conv3x3_i8_sliced on ResNet-50's four 3x3 shapes at the benchmark's batch (the eight-wavefront
+    instantiations, 1.5 workgroups per CU on the 14x14 planes) against the C++ twin fed with the same tensors: output, per-sample
+    statistic, current_input_max; and twice in a row."""
+    from oracle import host as H
+    from oracle import fq_oracle as O
+    n, c, h, w = case
+    g = torch.Generator(device=dev).manual_seed(c + h)
+    x = torch.relu(torch.randn(n, c, h, w, device=dev, generator=g) * 2)
+    wt = torch.randn(c, c, 3, 3, device=dev, generator=g) * (torch.rand(c, 1, 1, 1, device=dev, generator=g) * 0.2 + 0.02)
+    sc = torch.rand(c, device=dev, generator=g) + 0.4
+    sh = torch.randn(c, device=dev, generator=g)
+    if sliced:
+        wt = torch.from_numpy(O.wino_weight_fake_quant(_np(wt), "F43", 8)[0]).to(dev)      # the filter configuration 5 multiplies
+        codes = ops.weight_slices_3x3(wt)
+    else:
+        codes = ops.weight_codes_3x3(wt, 1, 8)
+    stat = ops.absmax_per_sample(x)
+    cur = torch.zeros(1, device=dev)
+    kw = dict(in_stat=stat, width=8, flags=0, bn_scale=sc, bn_shift=sh, act="relu")
+    y, ystat = ops.conv3x3_i8(x, *codes, cur_out=cur, **kw)
+    y2, ystat2 = ops.conv3x3_i8(x, *codes, cur_out=torch.zeros(1, device=dev), **kw)
+    assert torch.equal(y, y2) and torch.equal(ystat, ystat2), "repeats differ"
+    twin = H.conv3x3_i8_sliced if sliced else (lambda *a, **k: H.conv3x3_i8(a[0], a[1], 1, 8, **k))
+    want, wstat = twin(_np(x), _np(wt), in_stat=_np(stat), bn_scale=_np(sc), bn_shift=_np(sh), act="relu", want_stat=True)
+    S._eq(_np(y), want, "output")
+    S._eq(_np(ystat), wstat, "statistic")
+    assert float(cur) == float(H.batch_mean(_np(stat)))
+
+
+# (n, cin, cout, h, w, stride, residual): first 1x1 of a unit (wide -> narrow), of a stage's first unit (stride 2, round 5 and before:
+# now stride 1 on the subsampled trunk), closing 1x1 with the trunk as residual
+PW = [(128, 256, 64, 56, 56, 1, False), (128, 512, 128, 28, 28, 1, False), (128, 1024, 256, 14, 14, 1, False),
+      (128, 2048, 512, 7, 7, 1, False), (128, 256, 128, 56, 56, 2, False), (128, 64, 256, 56, 56, 1, True),
+      (128, 128, 512, 28, 28, 1, True), (128, 256, 1024, 14, 14, 1, True), (128, 512, 2048, 7, 7, 1, True)]
+
+
+@pytest.mark.parametrize("case", PW, ids=["%dx%d->%d@%dx%d-s%d%s" % (c[:6] + ("-res" if c[6] else "",)) for c in PW])
+def test_pointwise_at_batch_128_against_the_host_twin(dev, ops, case):
+    """fq_pwconv_i8 / fq_pwconv_i8_strided on ResNet-50's 1x1 shapes at the benchmark's batch - whatever form the shape-based choice
+    takes there (stream / sample with the residual operand prefetched / split) - against the C++ twin; and twice in a row."""
+    from oracle import host as H
+    n, cin, cout, h, w, stride, res = case
+    g = torch.Generator(device=dev).manual_seed(cin + cout + h)
+    x = torch.relu(torch.randn(n, cin, h, w, device=dev, generator=g) * 1.7)
+    wt = torch.randn(cout, cin, 1, 1, device=dev, generator=g) * 0.1
+    sc = (torch.rand(cout, device=dev, generator=g) + 0.4) * torch.where(torch.rand(cout, device=dev, generator=g) < 0.1, -1.0, 1.0)
+    sh = torch.randn(cout, device=dev, generator=g) * 0.3
+    r = torch.randn(n, cout, h, w, device=dev, generator=g) * 2 if res else None
+    codes = ops.weight_codes(wt, 1, 8)
+    stat = ops.absmax_per_sample(x)
+    kw = dict(in_stat=stat, width=8, flags=0, bn_scale=sc, bn_shift=sh, act="relu", residual=r)
+    if stride != 1:
+        kw["stride"] = stride
+    cur = torch.zeros(1, device=dev)
+    y, ystat = ops.pwconv_i8(x, *codes, None, cur_out=cur, **kw)
+    y2, ystat2 = ops.pwconv_i8(x, *codes, None, cur_out=torch.zeros(1, device=dev), **kw)
+    assert torch.equal(y, y2) and torch.equal(ystat, ystat2), "repeats differ"
+    want, wstat = H.pwconv_i8(_np(x), _np(wt), 1, 8, in_stat=_np(stat), bn_scale=_np(sc), bn_shift=_np(sh), act="relu",
+                              want_stat=True, stride=stride, residual=None if r is None else _np(r))
+    S._eq(_np(y), want, "output")
+    S._eq(_np(ystat), wstat, "statistic")
+    assert float(cur) == float(H.batch_mean(_np(stat)))
