@@ -58,7 +58,7 @@ KERNEL_NAMES = {
     "dwconv": "dwconv3x3_{cols4,flat,planes,cols,}_kernel (depthwise 3x3 with fake-quant on load + BN/ReLU/statistic on "
               "store, 4 B/in-elem + 4 B/out-elem)",
     "bn_act": "bn_act_stat_kernel (BatchNorm + ReLU + statistic in one pass, 8 B/elem)",
-    "stem": "stem_mfma_kernel (un-quantised first conv on the fp32 matrix cores + BN + ReLU + statistic, 4 B/in-elem + "
+    "stem": "stem3_rows_kernel / stem7_pool_lds_kernel / stem_mfma_kernel (un-quantised first conv on the fp32 matrix cores + BN + ReLU + statistic, 4 B/in-elem + "
             "4 B/out-elem)",
     "pool": "gap_stat_kernel (global average pool + statistic, 4 B/in-elem + 4 B/out-elem)",
     "pwconv": "pwconv_{stream,sample,split}_kernel (1x1 conv on int8 codes: fake-quant on load, exact int32 MFMA sums, "

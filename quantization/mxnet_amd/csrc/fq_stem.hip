@@ -382,6 +382,164 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
   PW_STAMP(5);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K2r (round 6, last hours): the 3x3 -> 32 first convolution with its INPUT staged in LDS.  K2q gathers its B operand from global
+// memory - 14 four-byte loads per lane and tile with an 8-byte lane stride - and without its stores it still takes 53 us for an
+// 18 us matrix chain (tools/stembench.py, -DFQ_STEM_NOSTORE): the texture path bounds it, as it bounded the 7x7 head until
+// its input rows were staged (fq_stem_pool.hip, profiles/r6_stem_pool_lds_ab.txt).  Here a workgroup of eight wavefronts walks
+// down a band of output rows of ONE image, four rows (Wo / 8 tiles of 32 consecutive pixels: whole 128-byte lines per channel,
+// as before) per step; the nine input rows 8 q - 1 .. 8 q + 7 of step q live in LDS ([slot = (iy + 1) mod 17][ci][4 zeros | W |
+// 4 zeros]: the padding is data), the eight new rows of step q + 1 are requested before the tiles of step q and written into the
+// other eight slots behind them - ONE barrier per step.  Same k order (ci, ky, kx), same fmaf chain: bit-identical to K2q.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kR3Slots = 17, kR3Rows = 4, kR3ST = 3;                    // 16-byte loads per thread for eight rows: 6 W <= 512 kR3ST
+
+struct Stem3Geom {
+  int H, W, Ho, Wo;
+  int nbands, steps_per_band, total_steps;
+  FastDiv by_wo;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, EPI == kEpiRuntime ? 2 : 4) void stem3_rows_kernel(const float* __restrict__ x, const float* __restrict__ wt /*[3][3][3][32]*/,
+                                                            const float* __restrict__ bias, float* __restrict__ y, Stem3Geom g,
+                                                            const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+                                                            int act, float* __restrict__ stat_out) {
+  constexpr int K = 27, NS = 14, COUT = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s3_smem[];
+  float* const c_bias = reinterpret_cast<float*>(s3_smem);
+  float* const c_bsc = c_bias + COUT;
+  float* const c_bsh = c_bsc + COUT;
+  float* const red = c_bsh + COUT;                                      // 8 (+ 24 unused: keeps xin 16-byte aligned)
+  float* const xin = red + 32;                                          // [17][3][XW]
+  const int H = g.H, W = g.W, Ho = g.Ho, Wo = g.Wo;
+  const int XW = W + 8;
+  for (int i = threadIdx.x; i < COUT; i += 512) {
+    c_bias[i] = bias != nullptr ? bias[i] : 0.0f;
+    c_bsc[i] = bn_scale != nullptr ? bn_scale[i] : 1.0f;
+    c_bsh[i] = bn_scale != nullptr ? bn_shift[i] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < kR3Slots * 3 * XW; i += 512) xin[i] = 0.0f;   // (the borders stay zero: rows are written from column 4 on)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int h = lane >> 5, pl = lane & 31;
+  const bool has_bn = bn_scale != nullptr;
+  const int smp = (int)blockIdx.x / g.nbands, band = (int)blockIdx.x - smp * g.nbands;
+  const int q_begin = band * g.steps_per_band;
+  const int q_end = q_begin + g.steps_per_band < g.total_steps ? q_begin + g.steps_per_band : g.total_steps;
+  const float* const xs = x + (int64_t)smp * 3 * H * W;
+  const int HWo = Ho * Wo;
+  // the lane's weights: W[co = pl][k = 2 s + h], the padded k a zero
+  float areg[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) areg[s] = 2 * s + h < K ? wt[(2 * s + h) * COUT + pl] : 0.0f;
+  __syncthreads();
+
+  // ---- staging: eight input rows (x three channels) per call, thread -> (row, channel, 16-byte column) ---------------------
+  const int W4 = W >> 2;
+  int st_r[kR3ST], st_ci[kR3ST], st_c4[kR3ST];
+#pragma unroll
+  for (int k = 0; k < kR3ST; ++k) {
+    const int idx = (int)threadIdx.x + 512 * k;
+    const int line = idx / W4;
+    st_c4[k] = idx - line * W4;
+    st_r[k] = line < 24 ? line / 3 : -1;
+    st_ci[k] = line % 3;
+  }
+  f4 sreg[kR3ST];
+  auto stage_load = [&](int row_lo, int nrows) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < kR3ST; ++k) {
+      const int iy = row_lo + st_r[k];
+      const bool ok = st_r[k] >= 0 && st_r[k] < nrows && iy >= 0 && iy < H;
+      sreg[k] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+      if (ok) sreg[k] = *reinterpret_cast<const f4*>(xs + ((int64_t)st_ci[k] * H + iy) * W + 4 * st_c4[k]);
+    }
+  };
+  auto stage_store = [&](int row_lo, int nrows) __attribute__((always_inline)) {
+    const int s0 = (row_lo + 1) % kR3Slots;                             // (uniform; row_lo >= -1)
+#pragma unroll
+    for (int k = 0; k < kR3ST; ++k) {
+      if (st_r[k] < 0 || st_r[k] >= nrows) continue;
+      int sl = s0 + st_r[k];
+      sl -= sl >= kR3Slots ? kR3Slots : 0;
+      *reinterpret_cast<f4*>(xin + (sl * 3 + st_ci[k]) * XW + 4 + 4 * st_c4[k]) = sreg[k];
+    }
+  };
+  stage_load(8 * q_begin - 1, 8);
+  stage_store(8 * q_begin - 1, 8);
+  stage_load(8 * q_begin + 7, 1);
+  stage_store(8 * q_begin + 7, 1);
+  __syncthreads();
+
+  const unsigned HWo4 = (unsigned)HWo * 4u;
+  const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + (int64_t)smp * COUT * HWo4, (int64_t)COUT * HWo4);
+  float m = 0.0f;
+  for (int q = q_begin; q < q_end; ++q) {
+    const bool more = q + 1 < q_end;
+    if (more) stage_load(8 * q + 8, 8);                                 // the next step's eight new rows: in flight under the tiles
+    const int rows = Ho - kR3Rows * q < kR3Rows ? Ho - kR3Rows * q : kR3Rows;
+    const int p0 = kR3Rows * q * Wo, nt = (rows * Wo + 31) >> 5;
+    const int sbase = (8 * q) % kR3Slots;                               // slot of input row 8 q - 1
+    for (int t = wave; t < nt; t += 8) {
+      int jp = p0 + 32 * t + pl;
+      jp = jp < HWo ? jp : HWo - 1;                                     // lanes past the image's end copy its last pixel
+      const int oy = (int)fast_div((unsigned)jp, g.by_wo), ox = jp - oy * Wo;
+      const int rel = 2 * (oy - kR3Rows * q);                           // input row 2 oy - 1 + ky = (8 q - 1) + rel + ky
+      int rb[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        int sl = sbase + rel + ky;
+        sl -= sl >= kR3Slots ? kR3Slots : 0;
+        rb[ky] = sl * 3 * XW + 2 * ox + 3;                              // + column of tap kx = 0: ix + 4 = 2 ox - 1 + 4
+      }
+      float bv[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;
+        const int ky0 = (k0 / 3) % 3, kx0 = k0 % 3, ci0 = k0 / 9;
+        const int ky1 = k1 < K ? (k1 / 3) % 3 : 0, kx1 = k1 < K ? k1 % 3 : 0, ci1 = k1 < K ? k1 / 9 : 0;
+        const int o0 = rb[ky0] + ci0 * XW + kx0;
+        const int o1 = k1 < K ? rb[ky1] + ci1 * XW + kx1 : 0;           // the padded k: a border zero (its weight is zero too)
+        bv[s] = xin[h ? o1 : o0];
+      }
+      v16f acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], bv[s], acc, 0, 0, 0);
+      const unsigned yo = (unsigned)(4 * h) * HWo4 + (unsigned)jp * 4u;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int c0 = 8 * gq + 4 * h;
+        const f4 bch = *reinterpret_cast<const f4*>(c_bias + c0);
+        const f4 bsc = *reinterpret_cast<const f4*>(c_bsc + c0);
+        const f4 bsh = *reinterpret_cast<const f4*>(c_bsh + c0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = dw_finish<EPI>(acc[4 * gq + r], bias != nullptr, bch[r], has_bn, bsc[r], bsh[r], act);
+          if (FQ_STEM_NTS) buf_st_f32_nt(yr, yo, (unsigned)(8 * gq + r) * HWo4, v);
+          else buf_st_f32(yr, yo, (unsigned)(8 * gq + r) * HWo4, v);
+          m = fmaxf(m, fabsf(v));
+        }
+      }
+    }
+    if (more) stage_store(8 * q + 8, 8);                                // (slots no tile of this step reads)
+    __syncthreads();
+  }
+  if (stat_out != nullptr) {
+    const float wm = wave_max_nonneg(m);
+    if (lane == 0) red[wave] = wm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = red[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) t = fmaxf(t, red[i]);
+      if (__float_as_uint(t) != 0u) atomic_max_f32(stat_out + smp, t);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -429,6 +587,42 @@ static int stem_launch(const float* x, const float* w_tap_major, const float* bi
                        Ho, Wo, tiles_per_wg, bn_scale, bn_shift, act, stat_out);
     FQ_LAUNCH_CHECK();
     return FQ_OK;
+  }
+  // K2r: the 3x3 form with its input rows staged in LDS (fp32 output; rows of a multiple of eight output columns so that a
+  // step of four rows is whole tiles; FQ_STEM_ROWS=0: never)
+  static const int use_rows = env_int("FQ_STEM_ROWS", 1);
+  if (ksize == 3 && out_thr == nullptr && form == 0 && use_rows != 0 && (w & 3) == 0 && (Wo & 7) == 0 && 6 * w <= 512 * kR3ST &&
+      ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(y)) & 15) == 0 && (int64_t)cout * hwo * 4 < (1ll << 31)) {
+    Stem3Geom g3;
+    g3.H = (int)h; g3.W = (int)w; g3.Ho = Ho; g3.Wo = Wo;
+    g3.total_steps = (Ho + kR3Rows - 1) / kR3Rows;
+    static const int rows_wg = env_int("FQ_STEM_ROWS_WG", 2);          // workgroups per CU the grid is cut for
+    int nb = (int)(((rows_wg > 0 ? rows_wg : 2) * (int64_t)num_cu() + n - 1) / n);   // as few bands as that allows
+    nb = nb < 1 ? 1 : (nb > g3.total_steps ? g3.total_steps : nb);
+    g3.steps_per_band = (g3.total_steps + nb - 1) / nb;
+    g3.nbands = (g3.total_steps + g3.steps_per_band - 1) / g3.steps_per_band;
+    g3.by_wo = fast_div_for((unsigned)Wo);
+    const size_t lds3 = (size_t)(3 * 32 + 32 + kR3Slots * 3 * (w + 8)) * sizeof(float);
+    const int epi3 = (bn_scale != nullptr && bias == nullptr)
+                         ? (act == FQ_ACT_RELU ? kEpiBnRelu : act == FQ_ACT_RELU6 ? kEpiBnRelu6 : kEpiRuntime)
+                         : kEpiRuntime;
+    const dim3 grid3((unsigned)(n * g3.nbands));
+#define FQ_STEM3_LAUNCH(E_)                                                                                            \
+  {                                                                                                                    \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem3_rows_kernel<E_>),             \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess; \
+    FQ_REQUIRE(attr_ok, "%s: cannot raise the dynamic LDS limit", who);                                                \
+    hipLaunchKernelGGL((stem3_rows_kernel<E_>), grid3, dim3(512), lds3, st, x, w_tap_major, bias, y, g3, bn_scale,     \
+                       bn_shift, act, stat_out);                                                                       \
+  }
+    if (lds3 <= 64 * 1024) {
+      if (epi3 == kEpiBnRelu) FQ_STEM3_LAUNCH(kEpiBnRelu)
+      else if (epi3 == kEpiBnRelu6) FQ_STEM3_LAUNCH(kEpiBnRelu6)
+      else FQ_STEM3_LAUNCH(kEpiRuntime)
+      FQ_LAUNCH_CHECK();
+      return FQ_OK;
+    }
+#undef FQ_STEM3_LAUNCH
   }
   const int tiles_per_img = (int)((hwo + 31) / 32);
   const int64_t total = (int64_t)tiles_per_img * n;

@@ -29,7 +29,7 @@ FAMILIES = {
                "pwconv_i8_kernel", "qconv_pw", "pw_stat_kernel"),
     # (round 6: a recompute pair's fused launch stands for the depthwise layer, its statistic pass for the pointwise layer)
     "dwconv": ("dwconv3x3", "qconv_dw", "pwdw_kernel"),
-    "stem": ("stem_mfma_kernel", "stem_conv3x3s2_kernel", "stem7_pool_kernel", "stem7_pool_lds_kernel"),
+    "stem": ("stem_mfma_kernel", "stem_conv3x3s2_kernel", "stem7_pool_kernel", "stem7_pool_lds_kernel", "stem3_rows_kernel"),
     "pool": ("gap_stat",),
     "dense": ("pwconv_rows_kernel",),
     "conv3x3": ("conv3x3_i8_kernel",),

@@ -16,7 +16,7 @@ import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 flt, min_us = sys.argv[2], float(sys.argv[3])
 # steps the profiled process ran = launches of a kernel every step holds exactly once (bench.py repeats short blocks)
-steps = float(sum(1 for r in rows if "stem_mfma" in r["Kernel_Name"] or "stem_conv3x3s2" in r["Kernel_Name"] or "stem7_pool" in r["Kernel_Name"]) or 33)
+steps = float(sum(1 for r in rows if "stem_mfma" in r["Kernel_Name"] or "stem_conv3x3s2" in r["Kernel_Name"] or "stem7_pool" in r["Kernel_Name"] or "stem3_rows" in r["Kernel_Name"]) or 33)
 g = collections.OrderedDict()
 for r in rows:
     name = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("(")[0]

@@ -25,7 +25,7 @@ def family(n):
         return 'dwconv'
     if 'pw_stat_kernel' in n:                        # ... and the statistic-only pass as its pointwise layer
         return 'pwconv'
-    if 'stem_conv3x3s2_kernel' in n or 'stem_mfma_kernel' in n or 'stem7_pool_kernel' in n or 'stem7_pool_lds_kernel' in n:
+    if 'stem_conv3x3s2_kernel' in n or 'stem_mfma_kernel' in n or 'stem7_pool_kernel' in n or 'stem7_pool_lds_kernel' in n or 'stem3_rows_kernel' in n:
         return 'stem'
     if 'conv3x3_i8_kernel' in n:
         return 'conv3x3'
