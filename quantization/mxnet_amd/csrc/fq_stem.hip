@@ -389,8 +389,9 @@ __global__ __launch_bounds__(kBlock) void stem_mfma_kernel(
 // its input rows were staged (fq_stem_pool.hip, profiles/r6_stem_pool_lds_ab.txt).  Here a workgroup of eight wavefronts walks
 // down a band of output rows of ONE image, four rows (Wo / 8 tiles of 32 consecutive pixels: whole 128-byte lines per channel,
 // as before) per step; the nine input rows 8 q - 1 .. 8 q + 7 of step q live in LDS ([slot = (iy + 1) mod 17][ci][4 zeros | W |
-// 4 zeros]: the padding is data), the eight new rows of step q + 1 are requested before the tiles of step q and written into the
-// other eight slots behind them - ONE barrier per step.  Same k order (ci, ky, kx), same fmaf chain: bit-identical to K2q.
+// 4 zeros]: the padding is data), the eight new rows of step q + 1 - requested a step earlier, two steps of rows are in flight: with
+// one the step waited for memory, the first convolution of a step 70 us against 60 - are written into the other eight slots behind
+// the tiles of step q - ONE barrier per step.  Same k order (ci, ky, kx), same fmaf chain: bit-identical to K2q.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kR3Slots = 17, kR3Rows = 4, kR3ST = 3;                    // 16-byte loads per thread for eight rows: 6 W <= 512 kR3ST
 
@@ -446,8 +447,8 @@ __global__ __launch_bounds__(512, EPI == kEpiRuntime ? 2 : 4) void stem3_rows_ke
     st_r[k] = line < 24 ? line / 3 : -1;
     st_ci[k] = line % 3;
   }
-  f4 sreg[kR3ST];
-  auto stage_load = [&](int row_lo, int nrows) __attribute__((always_inline)) {
+  f4 sreg[kR3ST], sreg2[kR3ST];                                         // two steps of rows in flight
+  auto stage_load = [&](f4 (&sreg)[kR3ST], int row_lo, int nrows) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < kR3ST; ++k) {
       const int iy = row_lo + st_r[k];
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(512, EPI == kEpiRuntime ? 2 : 4) void stem3_rows_ke
       if (ok) sreg[k] = *reinterpret_cast<const f4*>(xs + ((int64_t)st_ci[k] * H + iy) * W + 4 * st_c4[k]);
     }
   };
-  auto stage_store = [&](int row_lo, int nrows) __attribute__((always_inline)) {
+  auto stage_store = [&](f4 (&sreg)[kR3ST], int row_lo, int nrows) __attribute__((always_inline)) {
     const int s0 = (row_lo + 1) % kR3Slots;                             // (uniform; row_lo >= -1)
 #pragma unroll
     for (int k = 0; k < kR3ST; ++k) {
@@ -466,18 +467,20 @@ __global__ __launch_bounds__(512, EPI == kEpiRuntime ? 2 : 4) void stem3_rows_ke
       *reinterpret_cast<f4*>(xin + (sl * 3 + st_ci[k]) * XW + 4 + 4 * st_c4[k]) = sreg[k];
     }
   };
-  stage_load(8 * q_begin - 1, 8);
-  stage_store(8 * q_begin - 1, 8);
-  stage_load(8 * q_begin + 7, 1);
-  stage_store(8 * q_begin + 7, 1);
+  stage_load(sreg, 8 * q_begin - 1, 8);
+  stage_load(sreg2, 8 * q_begin + 7, 1);
+  stage_store(sreg, 8 * q_begin - 1, 8);
+  stage_store(sreg2, 8 * q_begin + 7, 1);
+  if (q_begin + 1 < q_end) stage_load(sreg2, 8 * q_begin + 8, 8);      // the second step's rows: stored at the end of the first
   __syncthreads();
 
   const unsigned HWo4 = (unsigned)HWo * 4u;
   const fq_rsrc yr = make_rsrc(reinterpret_cast<char*>(y) + (int64_t)smp * COUT * HWo4, (int64_t)COUT * HWo4);
   float m = 0.0f;
-  for (int q = q_begin; q < q_end; ++q) {
-    const bool more = q + 1 < q_end;
-    if (more) stage_load(8 * q + 8, 8);                                 // the next step's eight new rows: in flight under the tiles
+  // step q: the rows of step q + 2 are requested (into `ld`), the tiles of step q computed, the rows of step q + 1 (requested a step
+  // ago, in `st`) written into the eight slots this step does not read - a load has a whole step and more to arrive
+  auto step = [&](int q, f4 (&ld)[kR3ST], f4 (&st)[kR3ST]) __attribute__((always_inline)) {
+    if (q + 2 < q_end) stage_load(ld, 8 * q + 16, 8);
     const int rows = Ho - kR3Rows * q < kR3Rows ? Ho - kR3Rows * q : kR3Rows;
     const int p0 = kR3Rows * q * Wo, nt = (rows * Wo + 31) >> 5;
     const int sbase = (8 * q) % kR3Slots;                               // slot of input row 8 q - 1
@@ -524,8 +527,12 @@ __global__ __launch_bounds__(512, EPI == kEpiRuntime ? 2 : 4) void stem3_rows_ke
         }
       }
     }
-    if (more) stage_store(8 * q + 8, 8);                                // (slots no tile of this step reads)
+    if (q + 1 < q_end) stage_store(st, 8 * q + 8, 8);                   // (slots no tile of this step reads)
     __syncthreads();
+  };
+  for (int q = q_begin; q < q_end; q += 2) {
+    step(q, sreg, sreg2);
+    if (q + 1 < q_end) step(q + 1, sreg2, sreg);                        // (uniform)
   }
   if (stat_out != nullptr) {
     const float wm = wave_max_nonneg(m);
