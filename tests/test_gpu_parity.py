@@ -938,7 +938,10 @@ def test_division_by_double_reciprocal_is_ieee_exact(dev, ops):
         _eq(N(y), want_y, "y")
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 32, 32), (3, 3, 33, 47), (1, 3, 224, 224), (5, 3, 18, 130)])
+# (the last three: the 3x3 form with its input rows staged in LDS on an odd height, one step per band, and bands of five steps with
+# a last step of two rows - two steps of rows in flight)
+@pytest.mark.parametrize("shape", [(2, 3, 32, 32), (3, 3, 33, 47), (1, 3, 224, 224), (5, 3, 18, 130), (3, 3, 45, 64), (70, 3, 50, 96),
+                                   (260, 3, 76, 64)])
 @pytest.mark.parametrize("mode", ["plain", "bn_relu", "bias_relu6"])
 @pytest.mark.parametrize("ks,cout", [(3, 32), (7, 64)], ids=["3x3->32", "7x7->64"])
 def test_stem_conv_s2_vs_oracle(dev, ops, shape, mode, ks, cout):
