@@ -980,7 +980,7 @@ def test_stem_conv_s2_vs_oracle(dev, ops, shape, mode, ks, cout):
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 200, 232), (1, 3, 195, 201), (5, 3, 31, 250), (130, 3, 64, 224),
-                                   (40, 3, 96, 160), (128, 3, 224, 224)],
+                                   (40, 3, 96, 160), (128, 3, 224, 224), (6, 3, 75, 96), (200, 3, 75, 96)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("mode", ["bn_relu", "plain", "bias_relu6"])
 def test_stem_conv7x7_with_maxpool_in_one_launch_vs_oracle(dev, ops, shape, mode):
